@@ -1,0 +1,184 @@
+"""ctypes binding of libcartpolepp_hip.so (the C ABI declared in include/cartpolepp_abi.h).
+
+There is no CPU fallback: if the HIP library is missing or fails to load, importing this module
+raises.  Build it with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C cartpoleplusplus_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcartpolepp_hip.so")
+
+CPP_F32, CPP_F16 = 0, 1
+CPP_ACTOR, CPP_CRITIC = 0, 1
+
+
+class NetSpec(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("pixel", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("C", C.c_int32), ("state_elems", C.c_int32), ("action_dim", C.c_int32),
+                ("n_hidden", C.c_int32), ("hidden", C.c_int32 * 8)]
+
+
+class DdpgHyper(C.Structure):
+    _fields_ = [("actor_learning_rate", C.c_float), ("critic_learning_rate", C.c_float),
+                ("discount", C.c_float), ("gradient_clip", C.c_float),
+                ("target_update_rate", C.c_float)]
+
+
+_P = C.c_void_p
+_I, _L, _F = C.c_int, C.c_int64, C.c_float
+_U64 = C.c_uint64
+_PP = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes).  Every symbol declared in include/cartpolepp_abi.h appears here;
+# tests/test_abi_symbols.py checks the header and this table against the built library.
+SIGNATURES = {
+    "cpp_abi_version": (_I, []),
+    "cpp_last_error": (C.c_char_p, []),
+    "cpp_ctx_create": (_I, [_I, _P, _PP]),
+    "cpp_ctx_destroy": (_I, [_P]),
+    "cpp_sync": (_I, [_P]),
+    "cpp_timer_begin": (_I, [_P]),
+    "cpp_timer_end": (_I, [_P, C.POINTER(_F)]),
+    "cpp_prof_enable": (_I, [_P, _I]),
+    "cpp_prof_reset": (_I, [_P]),
+    "cpp_prof_num_kernels": (_I, []),
+    "cpp_prof_kernel_name": (C.c_char_p, [_I]),
+    "cpp_prof_read": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(_L)]),
+    "cpp_net_create": (_I, [_P, C.POINTER(NetSpec), _I, _PP]),
+    "cpp_net_destroy": (_I, [_P]),
+    "cpp_net_num_params": (_L, [_P]),
+    "cpp_net_num_vars": (_I, [_P]),
+    "cpp_net_var_info": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_L)]),
+    "cpp_net_set_params": (_I, [_P, _P, _L]),
+    "cpp_net_get_params": (_I, [_P, _P, _L]),
+    "cpp_net_get_grads": (_I, [_P, _P, _L]),
+    "cpp_net_soft_update": (_I, [_P, _P, _F]),
+    "cpp_net_forward": (_I, [_P, _P, _I, _I, _P, _P]),
+    "cpp_net_get_pool": (_I, [_P, _I, _I, _P]),
+    "cpp_batch_create": (_I, [_P, _I, _L, _I, _PP]),
+    "cpp_batch_destroy": (_I, [_P]),
+    "cpp_batch_upload": (_I, [_P, _I, _P, _P, _I, _P, _P, _P]),
+    "cpp_batch_download": (_I, [_P, _P, _P, _P, _P, _P]),
+    "cpp_batch_size": (_I, [_P]),
+    "cpp_batch_state_dtype": (_I, [_P]),
+    "cpp_replay_create": (_I, [_P, _I, _I, _L, _I, _PP]),
+    "cpp_replay_destroy": (_I, [_P]),
+    "cpp_replay_write_states": (_I, [_P, _P, _I, _P, _I]),
+    "cpp_replay_write_rows": (_I, [_P, _P, _I, _P, _P, _P, _P, _P]),
+    "cpp_replay_set_size": (_I, [_P, _I]),
+    "cpp_replay_read_states": (_I, [_P, _P, _I, _P]),
+    "cpp_replay_sample": (_I, [_P, _I, _P, _U64, _U64, _I, _P]),
+    "cpp_replay_last_indexes": (_I, [_P, _I, _P]),
+    "cpp_replay_fill_synthetic": (_I, [_P, _I, _U64]),
+    "cpp_ddpg_create": (_I, [_P, _P, _P, _P, _P, C.POINTER(DdpgHyper), _PP]),
+    "cpp_ddpg_destroy": (_I, [_P]),
+    "cpp_ddpg_train_actor": (_I, [_P, _P]),
+    "cpp_ddpg_train_critic": (_I, [_P, _P]),
+    "cpp_ddpg_check_loss": (_I, [_P, _P, _P, _P, _P]),
+    "cpp_ddpg_q_gradients_wrt_actions": (_I, [_P, _P, _P, _P, _P]),
+    "cpp_ddpg_compute_gradients": (_I, [_P, _P]),
+    "cpp_ddpg_grad_buffer": (_I, [_P, _PP, C.POINTER(_L)]),
+    "cpp_ddpg_apply_gradients": (_I, [_P, _F]),
+    "cpp_ddpg_update_targets": (_I, [_P]),
+    "cpp_ddpg_train_step": (_I, [_P, _P, _I, _I, _P, _U64]),
+    "cpp_ddpg_last_stats": (_I, [_P, _P]),
+}
+
+
+def _load():
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(
+            "cartpoleplusplus_amd: %s not found. This package has no CPU fallback; build the HIP "
+            "library first (python -c 'import __graft_entry__ as g; g.build()')." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here == ABI/library mismatch: fail loudly
+        fn.restype, fn.argtypes = res, args
+    if lib.cpp_abi_version() != 1:
+        raise ImportError("cartpoleplusplus_amd: ABI version mismatch")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError((lib.cpp_last_error() or b"").decode("utf-8", "replace"))
+
+
+def ptr(arr):
+    """host pointer of a C-contiguous numpy array (or None)."""
+    if arr is None:
+        return None
+    assert arr.flags["C_CONTIGUOUS"]
+    return arr.ctypes.data_as(C.c_void_p)
+
+
+def as_state_array(x):
+    """States cross the ABI as f16 (what the replay memory stores) or f32 (what the env emits)."""
+    x = np.asarray(x)
+    if x.dtype == np.float16:
+        return np.ascontiguousarray(x), CPP_F16
+    return np.ascontiguousarray(x, dtype=np.float32), CPP_F32
+
+
+class Context(object):
+    """One GPU + one HIP stream: the stand-in for the reference's default tf.Session
+    (ddpg_cartpole.py:416; `tf.get_default_session()` everywhere else)."""
+
+    def __init__(self, device_id=0, stream=None):
+        h = C.c_void_p()
+        check(lib.cpp_ctx_create(int(device_id), C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.handle, self.device_id = h, int(device_id)
+
+    def sync(self):
+        check(lib.cpp_sync(self.handle))
+
+    def timer_begin(self):
+        check(lib.cpp_timer_begin(self.handle))
+
+    def timer_end(self):
+        ms = C.c_float()
+        check(lib.cpp_timer_end(self.handle, C.byref(ms)))
+        return ms.value
+
+    def prof_enable(self, on=True):
+        check(lib.cpp_prof_enable(self.handle, 1 if on else 0))
+
+    def prof_reset(self):
+        check(lib.cpp_prof_reset(self.handle))
+
+    def prof_read(self):
+        """{kernel name: (total_ms, launches)} for kernels launched while profiling was on."""
+        out = {}
+        for k in range(lib.cpp_prof_num_kernels()):
+            ms, n = C.c_double(), C.c_int64()
+            check(lib.cpp_prof_read(self.handle, k, C.byref(ms), C.byref(n)))
+            if n.value:
+                out[lib.cpp_prof_kernel_name(k).decode()] = (ms.value, n.value)
+        return out
+
+    def close(self):
+        if self.handle:
+            lib.cpp_ctx_destroy(self.handle)
+            self.handle = None
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return _default_ctx
+
+
+def set_default_context(ctx):
+    global _default_ctx
+    _default_ctx = ctx

@@ -1,0 +1,149 @@
+// Shared declarations of libcartpolepp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CPP_NOUT_MAX 16       // one MFMA N tile; the reference hard-codes 10 filters (base_network.py:103)
+#define CPP_MAX_CHANNELS 64
+
+// kernel ids for the per-kernel HIP-event profile (cpp_prof_*)
+enum KernelId {
+  K_GATHER_STATS = 0, K_STATS_FINALIZE, K_STATS_GENERIC,
+  K_CONV1_FWD, K_CONV2_FWD, K_CONV3_FWD,
+  K_CONV1_DW, K_CONV2_DW, K_CONV3_DW,
+  K_CONV2_DX, K_CONV3_DX,
+  K_DW_REDUCE, K_GEMM, K_ELEMENTWISE, K_TD, K_SUMSQ, K_CLIP_SGD, K_SOFT_UPDATE,
+  K_REPLAY_FILL, K_NUM_KERNELS
+};
+
+struct cpp_ctx {
+  int device;
+  hipStream_t stream;
+  bool own_stream;
+  hipEvent_t t0, t1;
+  // profiling
+  bool prof;
+  double prof_ms[K_NUM_KERNELS];
+  int64_t prof_n[K_NUM_KERNELS];
+  hipEvent_t pe0, pe1;
+  int num_cus;
+};
+
+// ---------------------------------------------------------------------------------------------
+// conv kernels (conv.hip)
+// ---------------------------------------------------------------------------------------------
+enum ConvInMode { IN_F16_WHITEN = 0, IN_F32_WHITEN = 1, IN_F32_PLAIN = 2, IN_DY = 3 };
+enum ConvEpi { EPI_RELU_POOL = 0, EPI_PLAIN = 1 };
+
+// How to rebuild the gradient w.r.t. a conv's pre-activation output from the pooled-resolution
+// gradient: dY[b,y,x,o] = dpool[b,y/2,x/2,o] if amax == (y&1)*2+(x&1) and pool > 0 else 0.
+struct DyDesc {
+  const float* dpool; const float* pool; const uint8_t* amax;
+  long dpool_bstride, pool_bstride;       // elements between images
+  int Hp, Wp;
+};
+
+struct ConvArgs {
+  const void* in;            // f16/f32 images, or f32 activations (IN_F32_PLAIN)
+  long in_bstride;
+  const float* scale; const float* shift;   // whitening (IN_*_WHITEN)
+  DyDesc dy;                 // IN_DY (forward kernel in "dX" mode) / dW kernel B operand
+  const float* w;            // HWIO weights of the layer
+  const float* bias;
+  float* out; long out_bstride; uint8_t* out_amax;   // EPI_RELU_POOL: pooled + argmax code
+  float* partial;            // dW kernel: per-block partial sums [grid][pstride]
+  int pstride;
+  int B, H, W;               // conv spatial dims (SAME: input == output)
+  int cin_rt;                // runtime copy of CIN (checked against the template)
+  int nout;                  // valid output channels of this kernel (<= 16)
+  int tiles_x, tiles_y, ntiles;
+};
+
+int launch_conv_fwd(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi, ConvArgs a);
+int launch_conv_dw(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, ConvArgs a, float* grad_w,
+                   float* grad_b);
+size_t conv_dw_partial_floats(cpp_ctx* ctx, int cin, int ks, int nout);
+
+// ---------------------------------------------------------------------------------------------
+// gemm + elementwise (gemm.hip)
+// ---------------------------------------------------------------------------------------------
+enum GemmEpi { GE_NONE = 0, GE_RELU = 1, GE_TANH = 2, GE_MUL_RELU_GRAD = 3, GE_MUL_TANH_GRAD = 4 };
+struct GemmArgs {
+  const float* A; long sAm, sAk;
+  const float* B; long sBk, sBn;
+  float* C; long ldc;
+  const float* Y; long ldy;     // activation output for the *_GRAD epilogues
+  int M, N, K, epi;
+};
+int launch_gemm(cpp_ctx* ctx, const GemmArgs& g);
+int launch_copy_cols(cpp_ctx* ctx, float* dst, long ldd, int dcol0, const float* src, long lds_,
+                     int scol0, int ncols, int rows);
+int launch_fill(cpp_ctx* ctx, float* dst, long ld, int col0, int ncols, int rows, float v);
+int launch_state_to_f32(cpp_ctx* ctx, float* dst, long ldd, const void* src, int dtype, long elems,
+                        int rows);
+int launch_actor_head_grad(cpp_ctx* ctx, float* dz, const float* dq_da, const float* act, int n);
+int launch_td(cpp_ctx* ctx, const float* q, const float* tq, const float* r, const float* mask,
+              float discount, int B, float* td, float* dq, float* loss);
+
+// ---------------------------------------------------------------------------------------------
+// replay + whitening statistics (replay.hip)
+// ---------------------------------------------------------------------------------------------
+struct GatherArgs {
+  const void* store[2];         // per state column: [slots, elems] store (or the batch itself when s_idx == nullptr)
+  const int32_t* s_idx[2];      // state_1_idx / state_2_idx columns (nullptr: identity rows)
+  const int32_t* rows;          // caller-provided rows, or nullptr -> philox
+  int32_t* rows_out;            // rows actually used
+  const float* action; const float* reward; const float* mask;
+  void* out_state[2];           // gathered states (nullptr: no copy, statistics only)
+  float* out_action; float* out_reward; float* out_mask;
+  double* part;                 // [2][B][2*C] per-row partial sums
+  uint64_t seed; const uint64_t* counter;
+  long elems; int B; int size; int action_dim; int C;
+};
+int launch_gather_stats(cpp_ctx* ctx, const GatherArgs& a, int dtype);
+int launch_stats_finalize(cpp_ctx* ctx, const double* part, int nparts, int which_count, int C,
+                          double count, float* white);
+int launch_stats_generic(cpp_ctx* ctx, const void* x, int dtype, long npix, int C, float* white);
+int launch_replay_fill(cpp_ctx* ctx, __half* store, long elems, int slots, int32_t* s1, int32_t* s2,
+                       float* action, float* reward, float* mask, int rows, int action_dim,
+                       uint64_t seed);
+int launch_f32_to_f16(cpp_ctx* ctx, __half* dst, const float* src, long n);
+int launch_counter_add(cpp_ctx* ctx, uint64_t* counter, uint64_t inc);
+
+// ---------------------------------------------------------------------------------------------
+// optimiser (optim.hip)
+// ---------------------------------------------------------------------------------------------
+struct Seg2 { float* p[2]; const float* g[2]; long n[2]; float lr[2]; };
+int launch_sumsq(cpp_ctx* ctx, const Seg2& s, float grad_scale, double* part, int nparts);
+int launch_clip_sgd(cpp_ctx* ctx, const Seg2& s, float grad_scale, float clip, const double* part,
+                    int nparts, float* norms_out);
+int launch_soft_update(cpp_ctx* ctx, float* t0, const float* s0, long n0, float* t1, const float* s1,
+                       long n1, float coeff);
+
+// ---------------------------------------------------------------------------------------------
+// launch bookkeeping
+// ---------------------------------------------------------------------------------------------
+void cpp_set_error(const char* fmt, ...);
+void prof_begin(cpp_ctx* ctx);
+void prof_end(cpp_ctx* ctx, int kid);
+
+#define HIP_CHECK(expr)                                                                    \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      cpp_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));  \
+      return 2;                                                                            \
+    }                                                                                      \
+  } while (0)
+
+#define LAUNCH_CHECK()                                                                     \
+  do {                                                                                     \
+    hipError_t _e = hipGetLastError();                                                     \
+    if (_e != hipSuccess) {                                                                \
+      cpp_set_error("%s:%d: kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(_e)); \
+      return 2;                                                                            \
+    }                                                                                      \
+  } while (0)

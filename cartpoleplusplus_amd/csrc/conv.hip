@@ -1,0 +1,53 @@
+// Host-side launchers of the conv kernels (geometry selection + profiling brackets).
+#include "conv_impl.h"
+
+static int pick_xtw(int in_mode, int W) {
+  if (in_mode == IN_F16_WHITEN || in_mode == IN_F32_WHITEN) return 4;   // conv1: always 64-wide tiles
+  return W > 32 ? 4 : (W > 16 ? 2 : 1);
+}
+
+static void set_tiles(ConvArgs& a, int xtw) {
+  a.tiles_x = (a.W + 16 * xtw - 1) / (16 * xtw);
+  a.tiles_y = (a.H + CONV_TH - 1) / CONV_TH;
+  a.ntiles = a.B * a.tiles_x * a.tiles_y;
+}
+
+int launch_conv_fwd(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi, ConvArgs a) {
+  const int xtw = pick_xtw(in_mode, a.W);
+  set_tiles(a, xtw);
+  a.cin_rt = cin;
+  if (a.nout > CPP_NOUT_MAX) { cpp_set_error("conv: nout %d > 16", a.nout); return 1; }
+  prof_begin(ctx);
+  int rc;
+  if (in_mode == IN_F16_WHITEN || in_mode == IN_F32_WHITEN)
+    rc = conv_fwd_dispatch_l1(ctx, cin, ks, xtw, in_mode, epi, a);
+  else
+    rc = conv_fwd_dispatch_l23(ctx, cin, ks, xtw, in_mode, epi, a);
+  prof_end(ctx, kid);
+  return rc;
+}
+
+size_t conv_dw_partial_floats(cpp_ctx* ctx, int cin, int ks, int nout) {
+  return (size_t)(ctx->num_cus * 2) * (size_t)(ks * ks * cin * nout + nout);
+}
+
+int launch_conv_dw(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, ConvArgs a, float* grad_w,
+                   float* grad_b) {
+  const int xtw = pick_xtw(in_mode, a.W);
+  set_tiles(a, xtw);
+  a.cin_rt = cin;
+  const int nw = ks * ks * cin * a.nout;
+  a.pstride = nw + a.nout;
+  int grid = 0, rc;
+  prof_begin(ctx);
+  if (in_mode == IN_F16_WHITEN || in_mode == IN_F32_WHITEN)
+    rc = conv_dw_dispatch_l1(ctx, cin, ks, xtw, in_mode, a, &grid);
+  else
+    rc = conv_dw_dispatch_l23(ctx, cin, ks, xtw, in_mode, a, &grid);
+  prof_end(ctx, kid);
+  if (rc) return rc;
+  prof_begin(ctx);
+  rc = launch_dw_reduce(ctx, a.partial, grid, a.pstride, nw, a.nout, grad_w, grad_b);
+  prof_end(ctx, K_DW_REDUCE);
+  return rc;
+}

@@ -1,0 +1,19 @@
+// conv1 dW/db instantiations (input is the whitened image batch; conv1 needs no dX).
+#include "conv_impl.h"
+
+#define DW1_CASE(CIN_)                                                                             \
+  if (cin == CIN_ && in_mode == IN_F16_WHITEN)                                                     \
+    return conv_dw_launch_t<CIN_, 5, 4, IN_F16_WHITEN>(ctx, a, grid);                              \
+  if (cin == CIN_ && in_mode == IN_F32_WHITEN)                                                     \
+    return conv_dw_launch_t<CIN_, 5, 4, IN_F32_WHITEN>(ctx, a, grid);
+
+int conv_dw_dispatch_l1(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, const ConvArgs& a,
+                        int* grid) {
+  if (ks != 5 || xtw != 4) {
+    cpp_set_error("conv1 dW: unsupported geometry ks=%d xtw=%d", ks, xtw);
+    return 1;
+  }
+  DW1_CASE(6) DW1_CASE(9) DW1_CASE(18) DW1_CASE(30)
+  cpp_set_error("conv1 dW: unsupported channel count %d (built: 6, 9, 18, 30)", cin);
+  return 1;
+}

@@ -1,0 +1,19 @@
+// conv1 forward instantiations: f16/f32 image batch -> whiten -> 5x5 conv -> bias+ReLU+2x2 pool.
+#include "conv_impl.h"
+
+#define L1_CASE(CIN_)                                                                              \
+  if (cin == CIN_ && in_mode == IN_F16_WHITEN)                                                     \
+    return conv_fwd_launch_t<CIN_, 5, 4, IN_F16_WHITEN, EPI_RELU_POOL>(ctx, a);                    \
+  if (cin == CIN_ && in_mode == IN_F32_WHITEN)                                                     \
+    return conv_fwd_launch_t<CIN_, 5, 4, IN_F32_WHITEN, EPI_RELU_POOL>(ctx, a);
+
+int conv_fwd_dispatch_l1(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, int epi,
+                         const ConvArgs& a) {
+  if (ks != 5 || xtw != 4 || epi != EPI_RELU_POOL) {
+    cpp_set_error("conv1 forward: unsupported geometry ks=%d xtw=%d", ks, xtw);
+    return 1;
+  }
+  L1_CASE(6) L1_CASE(9) L1_CASE(18) L1_CASE(30)
+  cpp_set_error("conv1 forward: unsupported channel count %d (built: 6, 9, 18, 30)", cin);
+  return 1;
+}

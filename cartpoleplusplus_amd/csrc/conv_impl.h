@@ -1,0 +1,364 @@
+// Implicit-GEMM convolution kernels on v_mfma_f32_16x16x4_f32 for the cartpole++ conv trunk
+// (base_network.py:103-127: three slim.conv2d with 10 filters, stride 1, SAME, ReLU, each followed by
+// a 2x2/2 VALID max-pool) and its backward.  Exact f32 (the MFMA is a k-ordered fmaf chain).
+//
+// Mapping (forward / dX):   D[pixel, o] += A[pixel, k] * B[k, o]
+//   M tile  = 16 consecutive x positions of one output row          (MFMA rows,  lane & 15)
+//   N tile  = the 10 output channels, padded to 16                  (MFMA cols,  lane & 15)
+//   K       = (ky, (kx, c)); per ky the KS*CIN contiguous floats of an NHWC LDS row, padded to x4
+// The weights live in VGPRs for the whole kernel (one B fragment per k-step, preloaded once per
+// persistent workgroup); the A fragment is a single conflict-free ds_read_b32 from the LDS-staged,
+// already whitened input tile (zero padding is applied in whitened space, base_network.py:97-99).
+// A workgroup is 4 waves; wave w owns output rows 2w, 2w+1 of an 8-row tile, so the 2x2 max-pool,
+// bias and ReLU happen in registers in the epilogue (the MFMA C layout gives every lane 4 consecutive
+// x positions of one channel).
+//
+// Mapping (dW):             D[k', o] += A[k', pixel] * B[pixel, o]     (reduction over pixels, 4/MFMA)
+//   one accumulator tile per (ky, 16 consecutive (kx,c)); B = dY rebuilt on the fly from the pooled
+//   gradient + argmax code; accumulators persist across all tiles of a persistent workgroup and are
+//   reduced deterministically (fixed order) through LDS and a second-stage kernel.
+#pragma once
+#include "common.h"
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+constexpr int CONV_TH = 8;          // output rows per workgroup tile (4 waves x 2 rows)
+constexpr int CONV_THREADS = 256;
+constexpr int CONV_LDS_PAD = 16;    // floats; covers the k-padding over-read of the last tile row
+
+// XCD-aware persistent tile order: workgroup b runs on XCD b % 8 (observed dispatch order, speed
+// only); give every XCD a contiguous run of tiles so neighbouring row tiles of one image (which share
+// 4 halo rows) hit the same 4 MiB L2.
+__device__ __forceinline__ void conv_tile_range(int ntiles, int& start, int& step, int& end) {
+  const int nb = gridDim.x, bid = blockIdx.x;
+  if ((nb & 7) == 0) {
+    const int chunk = (ntiles + 7) >> 3;
+    start = (bid & 7) * chunk + (bid >> 3);
+    step = nb >> 3;
+    end = min(((bid & 7) + 1) * chunk, ntiles);
+  } else {
+    start = bid; step = nb; end = ntiles;
+  }
+}
+
+__device__ __forceinline__ float dy_value(const DyDesc& d, int b, int y, int x, int ch, int nch) {
+  const int py = y >> 1, px = x >> 1;
+  if (py >= d.Hp || px >= d.Wp) return 0.f;
+  const long e = (long)(py * d.Wp + px) * nch + ch;
+  const float pv = d.pool[(long)b * d.pool_bstride + e];
+  const float g = d.dpool[(long)b * d.dpool_bstride + e];
+  const int code = d.amax[(long)b * d.Hp * d.Wp * nch + e];
+  return (pv > 0.f && code == ((y & 1) * 2 + (x & 1))) ? g : 0.f;
+}
+
+template <int CIN, int KS, int XTW, int IN_MODE>
+__device__ __forceinline__ void conv_stage_tile(float* lds, const ConvArgs& a, int b, int y0, int x0,
+                                                int tid) {
+  constexpr int P = KS / 2, TR = CONV_TH + KS - 1, TC = 16 * XTW + KS - 1;
+  constexpr int TILE = TR * TC * CIN;
+  for (int idx = tid; idx < TILE; idx += CONV_THREADS) {
+    const int c = idx % CIN;
+    const int pc = idx / CIN;
+    const int col = pc % TC;
+    const int row = pc / TC;
+    const int gy = y0 - P + row, gx = x0 - P + col;
+    float v = 0.f;
+    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+      if (IN_MODE == IN_F16_WHITEN) {
+        const __half* src = (const __half*)a.in + (long)b * a.in_bstride;
+        v = __half2float(src[((long)gy * a.W + gx) * CIN + c]) * a.scale[c] + a.shift[c];
+      } else if (IN_MODE == IN_F32_WHITEN) {
+        const float* src = (const float*)a.in + (long)b * a.in_bstride;
+        v = src[((long)gy * a.W + gx) * CIN + c] * a.scale[c] + a.shift[c];
+      } else if (IN_MODE == IN_F32_PLAIN) {
+        const float* src = (const float*)a.in + (long)b * a.in_bstride;
+        v = src[((long)gy * a.W + gx) * CIN + c];
+      } else {
+        v = dy_value(a.dy, b, gy, gx, c, CIN);
+      }
+    }
+    lds[idx] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward / dX kernel
+// ---------------------------------------------------------------------------------------------
+template <int CIN, int KS, int XTW, int IN_MODE, int EPI>
+__global__ __launch_bounds__(CONV_THREADS, 2) void conv_fwd_kernel(const ConvArgs a) {
+  constexpr int TR = CONV_TH + KS - 1, TCOLS = 16 * XTW, TC = TCOLS + KS - 1;
+  constexpr int KROW = (KS * CIN + 3) / 4;
+  constexpr int TILE = TR * TC * CIN;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lj = lane >> 4;
+
+  if (tid < CONV_LDS_PAD) lds[TILE + tid] = 0.f;
+
+  // B fragments: wf[ky][kk] = W[ky][k' = 4kk + lj][o = li]  (0 outside the real K x N range)
+  float wf[KS][KROW];
+#pragma unroll
+  for (int ky = 0; ky < KS; ++ky) {
+#pragma unroll
+    for (int kk = 0; kk < KROW; ++kk) {
+      const int kp = 4 * kk + lj;
+      float v = 0.f;
+      if (kp < KS * CIN && li < a.nout) {
+        if (IN_MODE == IN_DY) {
+          // dX = correlation of dY with the flipped, transposed weights:
+          //   W'[ky][kx][o][c] = W[KS-1-ky][KS-1-kx][c][o],  W stored (KS,KS,Cin=nout,Cout=CIN)
+          const int kx = kp / CIN, o = kp % CIN;
+          v = a.w[(((KS - 1 - ky) * KS + (KS - 1 - kx)) * a.nout + li) * CIN + o];
+        } else {
+          v = a.w[(ky * KS * CIN + kp) * a.nout + li];
+        }
+      }
+      wf[ky][kk] = v;
+    }
+  }
+  float bias = 0.f;
+  if (EPI == EPI_RELU_POOL && li < a.nout) bias = a.bias[li];
+
+  const int Hp = a.H >> 1, Wp = a.W >> 1;
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  int t_start, t_step, t_end;
+  conv_tile_range(a.ntiles, t_start, t_step, t_end);
+
+  for (int tile = t_start; tile < t_end; tile += t_step) {
+    const int b = tile / tiles_per_img;
+    const int rem = tile - b * tiles_per_img;
+    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+    const int y0 = ty * CONV_TH, x0 = tx * TCOLS;
+
+    conv_stage_tile<CIN, KS, XTW, IN_MODE>(lds, a, b, y0, x0, tid);
+    __syncthreads();
+
+    const int yrow = y0 + 2 * wave;
+    if (yrow < a.H) {   // wave-uniform
+      f32x4 acc[2][XTW];
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int t = 0; t < XTW; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+      const float* lp = lds + (2 * wave) * TC * CIN + li * CIN + lj;
+      // tile row q = r + ky feeds output row 0 with W[ky=q] and output row 1 with W[ky=q-1]
+#pragma unroll
+      for (int q = 0; q < KS + 1; ++q) {
+#pragma unroll
+        for (int kk = 0; kk < KROW; ++kk) {
+#pragma unroll
+          for (int t = 0; t < XTW; ++t) {
+            const float av = lp[(q * TC + t * 16) * CIN + 4 * kk];
+            if (q < KS) acc[0][t] = MFMA16(av, wf[q < KS ? q : 0][kk], acc[0][t]);
+            if (q >= 1) acc[1][t] = MFMA16(av, wf[q >= 1 ? q - 1 : 0][kk], acc[1][t]);
+          }
+        }
+      }
+
+      if (EPI == EPI_RELU_POOL) {
+        const int py = yrow >> 1;
+        if (py < Hp && li < a.nout) {
+#pragma unroll
+          for (int t = 0; t < XTW; ++t) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int px = ((x0 + t * 16 + 4 * lj) >> 1) + h;
+              const float z00 = acc[0][t][2 * h] + bias, z01 = acc[0][t][2 * h + 1] + bias;
+              const float z10 = acc[1][t][2 * h] + bias, z11 = acc[1][t][2 * h + 1] + bias;
+              float m = z00; int code = 0;
+              if (z01 > m) { m = z01; code = 1; }
+              if (z10 > m) { m = z10; code = 2; }
+              if (z11 > m) { m = z11; code = 3; }
+              if (px < Wp) {
+                const long e = (long)(py * Wp + px) * a.nout + li;
+                a.out[(long)b * a.out_bstride + e] = fmaxf(m, 0.f);
+                a.out_amax[(long)b * Hp * Wp * a.nout + e] = (uint8_t)code;
+              }
+            }
+          }
+        }
+      } else {
+        if (li < a.nout) {
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int y = yrow + r;
+            if (y < a.H) {
+#pragma unroll
+              for (int t = 0; t < XTW; ++t) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  const int x = x0 + t * 16 + 4 * lj + i;
+                  if (x < a.W)
+                    a.out[(long)b * a.out_bstride + ((long)y * a.W + x) * a.nout + li] = acc[r][t][i];
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dW / db kernel
+// ---------------------------------------------------------------------------------------------
+template <int CIN, int KS>
+struct DwGeom {
+  static constexpr int KT = (KS * CIN + 15) / 16;   // 16-row accumulator tiles per ky
+  static constexpr int NT = KS * KT;
+};
+
+template <int CIN, int KS, int XTW, int IN_MODE>
+__global__ __launch_bounds__(CONV_THREADS, 2) void conv_dw_kernel(const ConvArgs a) {
+  constexpr int TR = CONV_TH + KS - 1, TCOLS = 16 * XTW, TC = TCOLS + KS - 1;
+  constexpr int TILE = TR * TC * CIN;
+  constexpr int KT = DwGeom<CIN, KS>::KT, NT = DwGeom<CIN, KS>::NT;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lj = lane >> 4;
+
+  if (tid < CONV_LDS_PAD) lds[TILE + tid] = 0.f;
+
+  f32x4 acc[KS][KT];
+#pragma unroll
+  for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+    for (int t = 0; t < KT; ++t) acc[ky][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  int t_start, t_step, t_end;
+  conv_tile_range(a.ntiles, t_start, t_step, t_end);
+
+  for (int tile = t_start; tile < t_end; tile += t_step) {
+    const int b = tile / tiles_per_img;
+    const int rem = tile - b * tiles_per_img;
+    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+    const int y0 = ty * CONV_TH, x0 = tx * TCOLS;
+
+    conv_stage_tile<CIN, KS, XTW, IN_MODE>(lds, a, b, y0, x0, tid);
+    __syncthreads();
+
+    const int yrow = y0 + 2 * wave;
+    if (yrow < a.H) {
+      for (int x4 = 0; x4 < 4 * XTW; ++x4) {
+        const int x = x0 + 4 * x4 + lj;
+        if (x0 + 4 * x4 >= a.W) break;   // wave-uniform
+        float b0 = 0.f, b1 = 0.f;
+        if (li < a.nout && x < a.W) {
+          b0 = dy_value(a.dy, b, yrow, x, li, a.nout);
+          if (yrow + 1 < a.H) b1 = dy_value(a.dy, b, yrow + 1, x, li, a.nout);
+        }
+        bsum += b0 + b1;
+        const float* lp = lds + ((2 * wave) * TC + 4 * x4 + lj) * CIN + li;
+#pragma unroll
+        for (int q = 0; q < KS + 1; ++q) {
+#pragma unroll
+          for (int t = 0; t < KT; ++t) {
+            const float av = lp[q * TC * CIN + 16 * t];
+            if (q < KS) acc[q < KS ? q : 0][t] = MFMA16(av, b0, acc[q < KS ? q : 0][t]);
+            if (q >= 1) acc[q >= 1 ? q - 1 : 0][t] = MFMA16(av, b1, acc[q >= 1 ? q - 1 : 0][t]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // cross-wave reduction in fixed order (wave 0, 1, 2, 3) through LDS, then one partial per block
+  float* red = lds;   // NT*256 floats (launch sizes the LDS for max(TILE+pad, NT*256 + 64))
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int idx = ((ky * KT + t) * 64 + lane) * 4 + i;
+            if (w == 0) red[idx] = acc[ky][t][i]; else red[idx] += acc[ky][t][i];
+          }
+    }
+    __syncthreads();
+  }
+  // db: sum the 4 pixel lanes of each channel, then the waves
+  bsum += __shfl_xor(bsum, 16);
+  bsum += __shfl_xor(bsum, 32);
+  float* bred = lds + NT * 256;
+  if (lj == 0) bred[wave * 16 + li] = bsum;
+  __syncthreads();
+
+  float* part = a.partial + (long)blockIdx.x * a.pstride;
+  const int nw = KS * KS * CIN * a.nout;
+  for (int e = tid; e < nw; e += CONV_THREADS) {
+    const int o = e % a.nout;
+    const int kfull = e / a.nout;            // ky*KS*CIN + k'
+    const int ky = kfull / (KS * CIN), kp = kfull - ky * (KS * CIN);
+    const int t = kp >> 4, row = kp & 15;
+    const int ln = (row >> 2) * 16 + o;      // D[row][col]: lane = (row/4)*16 + col, reg = row%4
+    part[e] = red[((ky * KT + t) * 64 + ln) * 4 + (row & 3)];
+  }
+  if (tid < a.nout) part[nw + tid] = (bred[tid] + bred[16 + tid]) + (bred[32 + tid] + bred[48 + tid]);
+}
+
+// second stage: grad[e] = sum_blocks partial[blk][e], fixed order (conv_dw_l23.hip)
+int launch_dw_reduce(cpp_ctx* ctx, const float* partial, int nblocks, int pstride, int nw, int nout,
+                     float* grad_w, float* grad_b);
+
+template <int CIN, int KS, int XTW, int IN_MODE, int EPI>
+static inline int conv_fwd_launch_t(cpp_ctx* ctx, const ConvArgs& a) {
+  constexpr int TR = CONV_TH + KS - 1, TC = 16 * XTW + KS - 1;
+  const size_t lds_bytes = (size_t)(TR * TC * CIN + CONV_LDS_PAD) * sizeof(float);
+  auto kern = conv_fwd_kernel<CIN, KS, XTW, IN_MODE, EPI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds_bytes));
+    attr_done = true;
+  }
+  const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
+  int grid = ctx->num_cus * per_cu;
+  if (grid > a.ntiles) grid = a.ntiles;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(CONV_THREADS), lds_bytes, ctx->stream, a);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+template <int CIN, int KS>
+static inline int conv_dw_grid(cpp_ctx* ctx, int xtw_max) {
+  (void)xtw_max;
+  return ctx->num_cus * 2;
+}
+
+template <int CIN, int KS, int XTW, int IN_MODE>
+static inline int conv_dw_launch_t(cpp_ctx* ctx, const ConvArgs& a, int* grid_out) {
+  constexpr int TR = CONV_TH + KS - 1, TC = 16 * XTW + KS - 1;
+  constexpr int NT = DwGeom<CIN, KS>::NT;
+  size_t fl = (size_t)(TR * TC * CIN + CONV_LDS_PAD);
+  if (fl < (size_t)NT * 256 + 64) fl = (size_t)NT * 256 + 64;
+  const size_t lds_bytes = fl * sizeof(float);
+  auto kern = conv_dw_kernel<CIN, KS, XTW, IN_MODE>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds_bytes));
+    attr_done = true;
+  }
+  const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
+  int grid = ctx->num_cus * per_cu;
+  if (grid > a.ntiles) grid = a.ntiles;
+  *grid_out = grid;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(CONV_THREADS), lds_bytes, ctx->stream, a);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+// per-translation-unit dispatchers (each .hip file instantiates a slice of the template space so the
+// big fully-unrolled kernels compile in parallel)
+int conv_fwd_dispatch_l1(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, int epi, const ConvArgs& a);
+int conv_fwd_dispatch_l23(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, int epi, const ConvArgs& a);
+int conv_dw_dispatch_l1(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, const ConvArgs& a, int* grid);
+int conv_dw_dispatch_l23(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, const ConvArgs& a, int* grid);

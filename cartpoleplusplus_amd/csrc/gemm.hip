@@ -1,0 +1,170 @@
+// Small fused GEMM (+activation / activation-gradient epilogue) on v_mfma_f32_16x16x4_f32 for the
+// actor / critic MLP heads (base_network.py:58-71, ddpg_cartpole.py:95-100, :168-171, :180-184) and a
+// few elementwise helpers.  Biases ride along as the last row of each weight matrix: the flat parameter
+// layout stores "<scope>/biases" directly after "<scope>/weights", so [W; b] is one (n_in+1, n_out)
+// matrix and every activation buffer carries a constant 1.0 in its last column -- forward bias add,
+// db = sum(dz) and dW = x^T dz all fall out of the same GEMM.
+#include "common.h"
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// One wave per 16x16 output tile; operands straight from global/L2 (all matrices here are < 1 MB).
+// A(m,k) = A[m*sAm + k*sAk], B(k,n) = B[k*sBk + n*sBn]: the strides express the transposes of the
+// backward passes (dX = dz W^T, dW = x^T dz) without materialising them.
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs g) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lj = lane >> 4;
+  const int tiles_n = (g.N + 15) >> 4, tiles_m = (g.M + 15) >> 4;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= tiles_m * tiles_n) return;
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m = tm * 16 + li, n = tn * 16 + li;
+  const bool mv = m < g.M, nv = n < g.N;
+  const float* ap = g.A + (long)m * g.sAm;
+  const float* bp = g.B + (long)n * g.sBn;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 8;
+  for (int k0 = 0; k0 < g.K; k0 += 4 * U) {
+    float av[U], bv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + 4 * u + lj;
+      const bool kv = k < g.K;
+      av[u] = (mv && kv) ? ap[(long)k * g.sAk] : 0.f;
+      bv[u] = (nv && kv) ? bp[(long)k * g.sBk] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc = MFMA16(av[u], bv[u], acc);
+  }
+  if (!nv) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = tm * 16 + 4 * lj + i;
+    if (row < g.M) {
+      float v = acc[i];
+      if (g.epi == GE_RELU) v = fmaxf(v, 0.f);
+      else if (g.epi == GE_TANH) v = tanhf(v);
+      else if (g.epi == GE_MUL_RELU_GRAD) v = g.Y[(long)row * g.ldy + n] > 0.f ? v : 0.f;
+      else if (g.epi == GE_MUL_TANH_GRAD) { const float y = g.Y[(long)row * g.ldy + n]; v = v * (1.f - y * y); }
+      g.C[(long)row * g.ldc + n] = v;
+    }
+  }
+}
+
+int launch_gemm(cpp_ctx* ctx, const GemmArgs& g) {
+  const int tiles = ((g.M + 15) / 16) * ((g.N + 15) / 16);
+  prof_begin(ctx);
+  hipLaunchKernelGGL(gemm_mfma_kernel, dim3((tiles + 3) / 4), dim3(256), 0, ctx->stream, g);
+  LAUNCH_CHECK();
+  prof_end(ctx, K_GEMM);
+  return 0;
+}
+
+__global__ void copy_cols_kernel(float* dst, long ldd, int dcol0, const float* src, long lds_,
+                                 int scol0, int ncols, int rows) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * ncols) return;
+  const int r = i / ncols, c = i - r * ncols;
+  dst[(long)r * ldd + dcol0 + c] = src[(long)r * lds_ + scol0 + c];
+}
+
+int launch_copy_cols(cpp_ctx* ctx, float* dst, long ldd, int dcol0, const float* src, long lds_,
+                     int scol0, int ncols, int rows) {
+  const int n = rows * ncols;
+  if (n <= 0) return 0;
+  prof_begin(ctx);
+  hipLaunchKernelGGL(copy_cols_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dst, ldd,
+                     dcol0, src, lds_, scol0, ncols, rows);
+  LAUNCH_CHECK();
+  prof_end(ctx, K_ELEMENTWISE);
+  return 0;
+}
+
+__global__ void fill_kernel(float* dst, long ld, int col0, int ncols, int rows, float v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * ncols) return;
+  const int r = i / ncols, c = i - r * ncols;
+  dst[(long)r * ld + col0 + c] = v;
+}
+
+int launch_fill(cpp_ctx* ctx, float* dst, long ld, int col0, int ncols, int rows, float v) {
+  const int n = rows * ncols;
+  if (n <= 0) return 0;
+  prof_begin(ctx);
+  hipLaunchKernelGGL(fill_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dst, ld, col0,
+                     ncols, rows, v);
+  LAUNCH_CHECK();
+  prof_end(ctx, K_ELEMENTWISE);
+  return 0;
+}
+
+// low-dim states: (rows, elems) f16|f32 -> f32 activation buffer with row stride ldd
+__global__ void state_to_f32_kernel(float* dst, long ldd, const void* src, int dtype, long elems,
+                                    int rows) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= elems * rows) return;
+  const long r = i / elems, c = i - r * elems;
+  dst[r * ldd + c] = dtype == 1 ? __half2float(((const __half*)src)[i]) : ((const float*)src)[i];
+}
+
+int launch_state_to_f32(cpp_ctx* ctx, float* dst, long ldd, const void* src, int dtype, long elems,
+                        int rows) {
+  const long n = elems * rows;
+  prof_begin(ctx);
+  hipLaunchKernelGGL(state_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     ctx->stream, dst, ldd, src, dtype, elems, rows);
+  LAUNCH_CHECK();
+  prof_end(ctx, K_ELEMENTWISE);
+  return 0;
+}
+
+// grad_ys of ddpg_cartpole.py:111-113 pushed through the tanh head: dz = -dq_da * (1 - a^2)
+__global__ void actor_head_grad_kernel(float* dz, const float* dq_da, const float* act, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float a = act[i];
+  dz[i] = -dq_da[i] * (1.f - a * a);
+}
+
+int launch_actor_head_grad(cpp_ctx* ctx, float* dz, const float* dq_da, const float* act, int n) {
+  prof_begin(ctx);
+  hipLaunchKernelGGL(actor_head_grad_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dz,
+                     dq_da, act, n);
+  LAUNCH_CHECK();
+  prof_end(ctx, K_ELEMENTWISE);
+  return 0;
+}
+
+// ddpg_cartpole.py:199-209: y = r + (mask*discount)*Q'(s2, mu'(s2)); td = Q - y; loss = mean(td^2);
+// dq = d loss / d Q = 2 td / B.
+__global__ __launch_bounds__(256) void td_kernel(const float* q, const float* tq, const float* r,
+                                                 const float* mask, float discount, int B, float* td,
+                                                 float* dq, float* loss) {
+  __shared__ double red[256];
+  double s = 0.0;
+  const float inv_b = 2.f / (float)B;
+  for (int i = threadIdx.x; i < B; i += 256) {
+    const float y = r[i] + (mask[i] * discount) * tq[i];
+    const float t = q[i] - y;
+    td[i] = t;
+    if (dq) dq[i] = t * inv_b;
+    s += (double)t * (double)t;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = (float)(red[0] / (double)B);
+}
+
+int launch_td(cpp_ctx* ctx, const float* q, const float* tq, const float* r, const float* mask,
+              float discount, int B, float* td, float* dq, float* loss) {
+  prof_begin(ctx);
+  hipLaunchKernelGGL(td_kernel, dim3(1), dim3(256), 0, ctx->stream, q, tq, r, mask, discount, B, td,
+                     dq, loss);
+  LAUNCH_CHECK();
+  prof_end(ctx, K_TD);
+  return 0;
+}

@@ -1,0 +1,287 @@
+// Device-resident replay memory kernels: fused uniform-sample + minibatch-gather + whitening
+// statistics (replay_memory.py:123-138 + base_network.py:95-96), plus helpers.
+//
+// gather_stats_kernel: grid (B, 2) -- one 256-thread workgroup per sampled row and per state column
+// (state_1 / state_2).  Lane 0 of each wave draws the row (Philox4x32-10 keyed by (seed, counter), or
+// the caller's index), follows the double indirection state[state_k_idx[row]] and broadcasts the slot
+// with a wavefront shuffle; all lanes then stream the 144 KiB f16 state with 16-byte loads/stores.
+// Per-channel sum(x), sum(x^2) are accumulated in the same pass: a lane only ever touches vectors
+// v = lane (mod P), P = C / gcd(8, C), so the 8 elements of every vector it loads belong to the same 8
+// channels and the accumulators are plain registers.  Row partials leave the kernel in f64 and are
+// combined in fixed order by stats_finalize_kernel (deterministic).
+#include "common.h"
+
+struct u32x4 { uint32_t x, y, z, w; };
+
+__host__ __device__ inline u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
+    u32x4 n;
+    n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+    n.y = (uint32_t)p1;
+    n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+    n.w = (uint32_t)p0;
+    c = n;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+
+__device__ __forceinline__ int sample_row(uint64_t seed, uint64_t counter, int b, int size) {
+  u32x4 c = {(uint32_t)b, 0u, (uint32_t)counter, (uint32_t)(counter >> 32)};
+  const u32x4 r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  return (int)(((uint64_t)r.x * (uint64_t)size) >> 32);      // uniform in [0, size)
+}
+
+template <typename T> struct Vec8;
+template <> struct Vec8<__half> {
+  uint4 raw;
+  __device__ void load(const __half* p) { raw = *reinterpret_cast<const uint4*>(p); }
+  __device__ void store(__half* p) const { *reinterpret_cast<uint4*>(p) = raw; }
+  __device__ float get(int e) const {
+    const uint32_t w = e < 2 ? raw.x : (e < 4 ? raw.y : (e < 6 ? raw.z : raw.w));
+    const unsigned short h = (e & 1) ? (unsigned short)(w >> 16) : (unsigned short)(w & 0xffffu);
+    return __half2float(__ushort_as_half(h));
+  }
+};
+template <> struct Vec8<float> {
+  float4 a, b;
+  __device__ void load(const float* p) {
+    a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4);
+  }
+  __device__ void store(float* p) const {
+    *reinterpret_cast<float4*>(p) = a; *reinterpret_cast<float4*>(p + 4) = b;
+  }
+  __device__ float get(int e) const {
+    switch (e) { case 0: return a.x; case 1: return a.y; case 2: return a.z; case 3: return a.w;
+                 case 4: return b.x; case 5: return b.y; case 6: return b.z; default: return b.w; }
+  }
+};
+
+__host__ __device__ inline int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_stats_kernel(const GatherArgs a) {
+  __shared__ float sh[256 * 16];
+  __shared__ double dsh[CPP_MAX_CHANNELS * 16];
+  const int b = blockIdx.x, which = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // --- sample + double indirection on lane 0, broadcast by wavefront shuffle
+  int row = 0, slot = 0;
+  if (lane == 0) {
+    if (a.s_idx[0] == nullptr) { row = b; slot = b; }       // statistics over an already gathered batch
+    else {
+      row = a.rows ? a.rows[b] : sample_row(a.seed, a.counter ? *a.counter : 0, b, a.size);
+      slot = a.s_idx[which][row];
+    }
+  }
+  row = __shfl(row, 0);
+  slot = __shfl(slot, 0);
+
+  if (which == 0 && a.s_idx[0] != nullptr) {
+    if (tid == 0 && a.rows_out) a.rows_out[b] = row;
+    if (tid < a.action_dim) a.out_action[(long)b * a.action_dim + tid] = a.action[(long)row * a.action_dim + tid];
+    if (tid == 64) a.out_reward[b] = a.reward[row];
+    if (tid == 65) a.out_mask[b] = a.mask[row];
+  }
+
+  const T* src = (const T*)a.store[which] + (long)slot * a.elems;
+  T* dst = a.out_state[which] ? (T*)a.out_state[which] + (long)b * a.elems : nullptr;
+  const long nvec = a.elems >> 3;
+  const int C = a.C;
+
+  if (C <= 0) {                                   // gather only (low-dim states)
+    for (long v = tid; v < nvec; v += 256) { Vec8<T> x; x.load(src + v * 8); if (dst) x.store(dst + v * 8); }
+    for (long e = nvec * 8 + tid; e < a.elems; e += 256) if (dst) dst[e] = src[e];
+    return;
+  }
+
+  const int P = C / gcd_int(8, C);
+  const int act = (64 / P) * P;                   // lanes in use per wave: multiple of the period
+  float s[8], ss[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+  if (lane < act) {
+    for (long v = wave * act + lane; v < nvec; v += 4 * act) {
+      Vec8<T> x;
+      x.load(src + v * 8);
+      if (dst) x.store(dst + v * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float f = x.get(e); s[e] += f; ss[e] = fmaf(f, f, ss[e]); }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sh[tid * 16 + e] = s[e]; sh[tid * 16 + 8 + e] = ss[e]; }
+  __syncthreads();
+  // stage 2: per (class q, element e): sum the lanes of that class over the 4 waves, in f64
+  if (tid < P * 16) {
+    const int q = tid >> 4, e = tid & 15;
+    double acc = 0.0;
+    for (int w = 0; w < 4; ++w)
+      for (int l = q; l < act; l += P) acc += (double)sh[(w * 64 + l) * 16 + e];
+    dsh[q * 16 + e] = acc;
+  }
+  __syncthreads();
+  // stage 3: per channel: the (q, e) pairs with (8q + e) % C == c
+  if (tid < 2 * C) {
+    const int stat = tid / C, c = tid - stat * C;
+    double acc = 0.0;
+    for (int q = 0; q < P; ++q)
+      for (int e = 0; e < 8; ++e)
+        if ((8 * q + e) % C == c) acc += dsh[q * 16 + stat * 8 + e];
+    a.part[((long)which * a.B + b) * 2 * C + tid] = acc;
+  }
+}
+
+int launch_gather_stats(cpp_ctx* ctx, const GatherArgs& a, int dtype) {
+  if (a.C > CPP_MAX_CHANNELS) { cpp_set_error("gather: %d channels > %d", a.C, CPP_MAX_CHANNELS); return 1; }
+  if (a.C > 0 && (a.elems % 8 != 0 || a.elems % a.C != 0 || a.C / gcd_int(8, a.C) > 16)) {
+    cpp_set_error("gather: vector statistics path needs state_elems %ld %% 8 == 0 and period <= 16 (C=%d)",
+                  a.elems, a.C);
+    return 1;
+  }
+  prof_begin(ctx);
+  if (dtype == 1) hipLaunchKernelGGL(gather_stats_kernel<__half>, dim3(a.B, 2), dim3(256), 0, ctx->stream, a);
+  else hipLaunchKernelGGL(gather_stats_kernel<float>, dim3(a.B, 2), dim3(256), 0, ctx->stream, a);
+  LAUNCH_CHECK();
+  prof_end(ctx, K_GATHER_STATS);
+  return 0;
+}
+
+// white[w][0][c] = rsqrt(var + 1e-6), white[w][1][c] = -mean * rsqrt(var + 1e-6)   (base_network.py:97-99)
+__global__ void stats_finalize_kernel(const double* part, int nparts, int which_count, int C,
+                                      double count, float* white) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= which_count * C) return;
+  const int w = t / C, c = t - w * C;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < nparts; ++b) {
+    const double* p = part + ((long)w * nparts + b) * 2 * C;
+    s += p[c]; ss += p[C + c];
+  }
+  const double mean = s / count;
+  const double var = ss / count - mean * mean;     // one-pass form of tf.nn.moments (r0.9-r0.11)
+  const double inv = 1.0 / sqrt(var + 1e-6);
+  white[(long)w * 2 * C + c] = (float)inv;
+  white[(long)w * 2 * C + C + c] = (float)(-mean * inv);
+}
+
+int launch_stats_finalize(cpp_ctx* ctx, const double* part, int nparts, int which_count, int C,
+                          double count, float* white) {
+  prof_begin(ctx);
+  const int n = which_count * C;
+  hipLaunchKernelGGL(stats_finalize_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, part, nparts,
+                     which_count, C, count, white);
+  LAUNCH_CHECK();
+  prof_end(ctx, K_STATS_FINALIZE);
+  return 0;
+}
+
+// fallback for shapes the vector path cannot take (elems % 8 != 0): one workgroup per channel
+template <typename T>
+__global__ __launch_bounds__(256) void stats_generic_kernel(const T* x, long npix, int C, float* white) {
+  __shared__ double r0[256], r1[256];
+  const int c = blockIdx.x;
+  double s = 0.0, ss = 0.0;
+  for (long p = threadIdx.x; p < npix; p += 256) {
+    const double f = (double)(float)x[p * C + c];
+    s += f; ss += f * f;
+  }
+  r0[threadIdx.x] = s; r1[threadIdx.x] = ss;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { r0[threadIdx.x] += r0[threadIdx.x + o]; r1[threadIdx.x] += r1[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double mean = r0[0] / (double)npix;
+    const double var = r1[0] / (double)npix - mean * mean;
+    const double inv = 1.0 / sqrt(var + 1e-6);
+    white[c] = (float)inv;
+    white[C + c] = (float)(-mean * inv);
+  }
+}
+
+int launch_stats_generic(cpp_ctx* ctx, const void* x, int dtype, long npix, int C, float* white) {
+  prof_begin(ctx);
+  if (dtype == 1) hipLaunchKernelGGL(stats_generic_kernel<__half>, dim3(C), dim3(256), 0, ctx->stream,
+                                     (const __half*)x, npix, C, white);
+  else hipLaunchKernelGGL(stats_generic_kernel<float>, dim3(C), dim3(256), 0, ctx->stream,
+                          (const float*)x, npix, C, white);
+  LAUNCH_CHECK();
+  prof_end(ctx, K_STATS_GENERIC);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic fill (bench / tests): SURVEY 8d inputs generated on the device
+// ---------------------------------------------------------------------------------------------
+__global__ void replay_fill_states_kernel(__half* store, long total, uint64_t seed) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // 16 elements per thread
+  if (i * 16 >= total) return;
+  u32x4 c = {(uint32_t)i, (uint32_t)(i >> 32), 0x5eedu, 1u};
+  const u32x4 r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+  for (int e = 0; e < 16; ++e) {
+    const long idx = i * 16 + e;
+    if (idx < total) {
+      const uint32_t k = (w[e >> 2] >> (8 * (e & 3))) & 0xffu;
+      store[idx] = __float2half((float)k / 255.0f);             // f16(k/255): bullet_cartpole.py:239-243
+    }
+  }
+}
+
+__global__ void replay_fill_rows_kernel(int32_t* s1, int32_t* s2, float* action, float* reward,
+                                        float* mask, int rows, int action_dim, uint64_t seed) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  const int ep = i / 50;                         // fixed 50-step episodes: terminal w.p. 1/50
+  s1[i] = i + ep;
+  s2[i] = i + ep + 1;
+  reward[i] = 1.0f;
+  mask[i] = (i % 50 == 49) ? 0.0f : 1.0f;
+  u32x4 c = {(uint32_t)i, 0u, 0xac7u, 2u};
+  const u32x4 r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+  for (int k = 0; k < action_dim; ++k)
+    action[(long)i * action_dim + k] = (float)(w[k & 3] >> 8) * (2.0f / 16777216.0f) - 1.0f;
+}
+
+int launch_replay_fill(cpp_ctx* ctx, __half* store, long elems, int slots, int32_t* s1, int32_t* s2,
+                       float* action, float* reward, float* mask, int rows, int action_dim,
+                       uint64_t seed) {
+  const long total = elems * (long)slots;
+  const long nthreads = (total + 15) / 16;
+  prof_begin(ctx);
+  hipLaunchKernelGGL(replay_fill_states_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0,
+                     ctx->stream, store, total, seed);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(replay_fill_rows_kernel, dim3((rows + 255) / 256), dim3(256), 0, ctx->stream, s1, s2,
+                     action, reward, mask, rows, action_dim, seed);
+  LAUNCH_CHECK();
+  prof_end(ctx, K_REPLAY_FILL);
+  return 0;
+}
+
+__global__ void f32_to_f16_kernel(__half* dst, const float* src, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = __float2half(src[i]);      // round-to-nearest-even, like numpy's astype(float16)
+}
+
+int launch_f32_to_f16(cpp_ctx* ctx, __half* dst, const float* src, long n) {
+  hipLaunchKernelGGL(f32_to_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                     dst, src, n);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void counter_add_kernel(uint64_t* counter, uint64_t inc) { *counter += inc; }
+
+int launch_counter_add(cpp_ctx* ctx, uint64_t* counter, uint64_t inc) {
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, ctx->stream, counter, inc);
+  LAUNCH_CHECK();
+  return 0;
+}

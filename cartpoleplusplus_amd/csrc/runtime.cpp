@@ -1,0 +1,1045 @@
+// C-ABI implementation (include/cartpolepp_abi.h): handles, device memory, and the launch sequences
+// of the DDPG-from-pixels hot path.  Host-side logic only; all arithmetic is in the HIP kernels.
+#include "../../include/cartpolepp_abi.h"
+#include "common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// ---------------------------------------------------------------------------------------------
+// errors / profiling brackets
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+void cpp_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* cpp_last_error(void) { return g_err; }
+extern "C" int cpp_abi_version(void) { return CPP_ABI_VERSION; }
+
+#define ARG_CHECK(cond, ...)                \
+  do {                                      \
+    if (!(cond)) {                          \
+      cpp_set_error(__VA_ARGS__);           \
+      return CPP_ERR_ARG;                   \
+    }                                       \
+  } while (0)
+#define RC(expr)                  \
+  do {                            \
+    int _rc = (expr);             \
+    if (_rc) return _rc;          \
+  } while (0)
+
+void prof_begin(cpp_ctx* ctx) {
+  if (ctx->prof) (void)hipEventRecord(ctx->pe0, ctx->stream);
+}
+void prof_end(cpp_ctx* ctx, int kid) {
+  if (!ctx->prof) return;
+  (void)hipEventRecord(ctx->pe1, ctx->stream);
+  (void)hipEventSynchronize(ctx->pe1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, ctx->pe0, ctx->pe1);
+  ctx->prof_ms[kid] += ms;
+  ctx->prof_n[kid] += 1;
+}
+
+static const char* kKernelNames[K_NUM_KERNELS] = {
+    "gather_stats", "stats_finalize", "stats_generic", "conv1_fwd", "conv2_fwd", "conv3_fwd",
+    "conv1_dw", "conv2_dw", "conv3_dw", "conv2_dx", "conv3_dx", "dw_reduce", "gemm", "elementwise",
+    "td", "sumsq", "clip_sgd", "soft_update", "replay_fill"};
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+extern "C" int cpp_ctx_create(int device_id, void* hip_stream, cpp_ctx** out) {
+  ARG_CHECK(out, "cpp_ctx_create: out is NULL");
+  int ndev = 0;
+  HIP_CHECK(hipGetDeviceCount(&ndev));
+  ARG_CHECK(device_id >= 0 && device_id < ndev, "cpp_ctx_create: device %d not in [0,%d)", device_id, ndev);
+  HIP_CHECK(hipSetDevice(device_id));
+  cpp_ctx* c = new cpp_ctx();
+  memset(c, 0, sizeof(*c));
+  c->device = device_id;
+  if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
+  else { HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+  HIP_CHECK(hipEventCreate(&c->t0));
+  HIP_CHECK(hipEventCreate(&c->t1));
+  HIP_CHECK(hipEventCreate(&c->pe0));
+  HIP_CHECK(hipEventCreate(&c->pe1));
+  HIP_CHECK(hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, device_id));
+  *out = c;
+  return CPP_OK;
+}
+
+extern "C" int cpp_ctx_destroy(cpp_ctx* c) {
+  if (!c) return CPP_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipEventDestroy(c->t0); (void)hipEventDestroy(c->t1);
+  (void)hipEventDestroy(c->pe0); (void)hipEventDestroy(c->pe1);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return CPP_OK;
+}
+
+extern "C" int cpp_sync(cpp_ctx* c) {
+  ARG_CHECK(c, "cpp_sync: ctx is NULL");
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  return CPP_OK;
+}
+
+extern "C" int cpp_timer_begin(cpp_ctx* c) {
+  ARG_CHECK(c, "ctx is NULL");
+  HIP_CHECK(hipEventRecord(c->t0, c->stream));
+  return CPP_OK;
+}
+extern "C" int cpp_timer_end(cpp_ctx* c, float* ms) {
+  ARG_CHECK(c && ms, "ctx/ms is NULL");
+  HIP_CHECK(hipEventRecord(c->t1, c->stream));
+  HIP_CHECK(hipEventSynchronize(c->t1));
+  HIP_CHECK(hipEventElapsedTime(ms, c->t0, c->t1));
+  return CPP_OK;
+}
+extern "C" int cpp_prof_enable(cpp_ctx* c, int on) { ARG_CHECK(c, "ctx is NULL"); c->prof = on != 0; return CPP_OK; }
+extern "C" int cpp_prof_reset(cpp_ctx* c) {
+  ARG_CHECK(c, "ctx is NULL");
+  memset(c->prof_ms, 0, sizeof(c->prof_ms)); memset(c->prof_n, 0, sizeof(c->prof_n));
+  return CPP_OK;
+}
+extern "C" int cpp_prof_num_kernels(void) { return K_NUM_KERNELS; }
+extern "C" const char* cpp_prof_kernel_name(int k) { return (k >= 0 && k < K_NUM_KERNELS) ? kKernelNames[k] : ""; }
+extern "C" int cpp_prof_read(cpp_ctx* c, int k, double* total_ms, int64_t* launches) {
+  ARG_CHECK(c && k >= 0 && k < K_NUM_KERNELS, "cpp_prof_read: bad kernel id %d", k);
+  if (total_ms) *total_ms = c->prof_ms[k];
+  if (launches) *launches = c->prof_n[k];
+  return CPP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device memory helper
+// ---------------------------------------------------------------------------------------------
+struct Arena {
+  std::vector<void*> ptrs;
+  hipStream_t stream = nullptr;     // zero-fills are ordered on the owning ctx's stream (never the null stream)
+  int alloc(void** p, size_t bytes, bool zero = true) {
+    if (bytes == 0) bytes = 16;
+    HIP_CHECK(hipMalloc(p, bytes));
+    ptrs.push_back(*p);
+    if (zero) HIP_CHECK(hipMemsetAsync(*p, 0, bytes, stream));
+    return 0;
+  }
+  void release() { for (void* p : ptrs) (void)hipFree(p); ptrs.clear(); }
+};
+template <typename T> static int dalloc(Arena& a, T** p, size_t count, bool zero = true) {
+  return a.alloc((void**)p, count * sizeof(T), zero);
+}
+
+// ---------------------------------------------------------------------------------------------
+// networks
+// ---------------------------------------------------------------------------------------------
+static const int kConvKs[3] = {5, 5, 3};          // base_network.py:103,111,119
+static const int kConvOut = 10;
+static const char* kConvNames[3] = {"conv1", "conv2", "conv3"};
+
+struct ConvL { int H, W, Cin, ks, Hp, Wp; long w_off, b_off; };
+struct FcL { int n_in, n_out, act, cat; long w_off; std::string name; };   // bias row at w_off + n_in*n_out
+struct VarInfo { std::string name; int rank; int shape[4]; long offset; };
+
+struct Workspace {
+  float* pool[3] = {nullptr, nullptr, nullptr};
+  uint8_t* amax[3] = {nullptr, nullptr, nullptr};
+  float* dpool[3] = {nullptr, nullptr, nullptr};
+  std::vector<float*> fcin, dz;
+  float* out = nullptr;
+};
+
+struct cpp_net {
+  cpp_ctx* ctx; cpp_net_spec spec; int maxB;
+  std::vector<ConvL> conv; std::vector<FcL> fc; std::vector<VarInfo> vars;
+  long nparams; int flat; int cat_layer; long state_elems;
+  float* params; float* grads; float* own_grads;
+  Workspace ws[2];
+  float* white;            // [2][C] statistics for cpp_net_forward
+  double* stats_part;      // [maxB][2C]
+  float* dw_partial;
+  void* stage_state; float* stage_action; float* stage_out;
+  Arena arena;
+};
+
+static int net_build(cpp_net* n) {
+  const cpp_net_spec& s = n->spec;
+  long off = 0;
+  int h = s.H, w = s.W, cin = s.C;
+  if (s.pixel) {
+    for (int i = 0; i < 3; ++i) {
+      ConvL L; L.H = h; L.W = w; L.Cin = cin; L.ks = kConvKs[i]; L.Hp = h / 2; L.Wp = w / 2;
+      L.w_off = off; off += (long)L.ks * L.ks * cin * kConvOut; L.b_off = off; off += kConvOut;
+      n->conv.push_back(L);
+      VarInfo vw; vw.name = std::string(kConvNames[i]) + "/weights"; vw.rank = 4;
+      vw.shape[0] = L.ks; vw.shape[1] = L.ks; vw.shape[2] = cin; vw.shape[3] = kConvOut; vw.offset = L.w_off;
+      VarInfo vb; vb.name = std::string(kConvNames[i]) + "/biases"; vb.rank = 1;
+      vb.shape[0] = kConvOut; vb.shape[1] = vb.shape[2] = vb.shape[3] = 0; vb.offset = L.b_off;
+      n->vars.push_back(vw); n->vars.push_back(vb);
+      cin = kConvOut; h /= 2; w /= 2;
+    }
+    if (h < 1 || w < 1) { cpp_set_error("image %dx%d too small for three 2x2 pools", s.H, s.W); return CPP_ERR_ARG; }
+    n->flat = h * w * kConvOut;
+    n->state_elems = (long)s.H * s.W * s.C;
+  } else {
+    n->flat = s.state_elems;
+    n->state_elems = s.state_elems;
+  }
+  const int A = s.action_dim;
+  auto add_fc = [&](const std::string& name, int n_in, int n_out, int act, int cat) {
+    FcL L; L.n_in = n_in; L.n_out = n_out; L.act = act; L.cat = cat; L.w_off = off; L.name = name;
+    off += (long)n_in * n_out + n_out;
+    n->fc.push_back(L);
+    VarInfo vw; vw.name = name + "/weights"; vw.rank = 2; vw.shape[0] = n_in; vw.shape[1] = n_out;
+    vw.shape[2] = vw.shape[3] = 0; vw.offset = L.w_off;
+    VarInfo vb; vb.name = name + "/biases"; vb.rank = 1; vb.shape[0] = n_out;
+    vb.shape[1] = vb.shape[2] = vb.shape[3] = 0; vb.offset = L.w_off + (long)n_in * n_out;
+    n->vars.push_back(vw); n->vars.push_back(vb);
+  };
+  n->cat_layer = -1;
+  int n_in = n->flat;
+  if (s.kind == CPP_ACTOR) {
+    for (int i = 0; i < s.n_hidden; ++i) { add_fc("h" + std::to_string(i), n_in, s.hidden[i], GE_RELU, 0); n_in = s.hidden[i]; }
+    add_fc("output_action", n_in, A, GE_TANH, 0);                       // ddpg_cartpole.py:95-100
+  } else if (s.pixel) {                                                 // ddpg_cartpole.py:168-171 (intent)
+    add_fc("hidden1", n_in, 200, GE_RELU, 0);
+    add_fc("hidden2", 200, 50, GE_RELU, 0);
+    add_fc("hidden3", 50 + A, 50, GE_RELU, 1); n->cat_layer = 2;
+    add_fc("q_value", 50, 1, GE_NONE, 0);
+  } else {                                                              // ddpg_cartpole.py:174-177
+    n_in += A;
+    for (int i = 0; i < s.n_hidden; ++i) { add_fc("h" + std::to_string(i), n_in, s.hidden[i], GE_RELU, i == 0); n_in = s.hidden[i]; }
+    n->cat_layer = 0;
+    add_fc("q_value", n_in, 1, GE_NONE, 0);
+  }
+  n->nparams = off;
+  return CPP_OK;
+}
+
+static int ws_alloc(cpp_net* n, Workspace& w, int from_layer, bool trunk) {
+  const int mb = n->maxB;
+  const int nfc = (int)n->fc.size();
+  w.fcin.assign(nfc, nullptr);
+  w.dz.assign(nfc, nullptr);
+  for (int l = from_layer; l < nfc; ++l) {
+    const FcL& L = n->fc[l];
+    RC(dalloc(n->arena, &w.fcin[l], (size_t)mb * (L.n_in + 1)));
+    RC(launch_fill(n->ctx, w.fcin[l], L.n_in + 1, L.n_in, 1, mb, 1.0f));   // the bias "ones" column
+    RC(dalloc(n->arena, &w.dz[l], (size_t)mb * L.n_out));
+  }
+  RC(dalloc(n->arena, &w.out, (size_t)mb * n->fc.back().n_out));
+  if (trunk && n->spec.pixel) {
+    for (int i = 0; i < 3; ++i) {
+      const ConvL& L = n->conv[i];
+      const size_t pe = (size_t)mb * L.Hp * L.Wp * kConvOut;
+      if (i < 2) RC(dalloc(n->arena, &w.pool[i], pe)); else w.pool[i] = w.fcin[0];
+      RC(dalloc(n->arena, &w.amax[i], pe));
+      RC(dalloc(n->arena, &w.dpool[i], pe));
+    }
+  }
+  return CPP_OK;
+}
+
+extern "C" int cpp_net_create(cpp_ctx* ctx, const cpp_net_spec* spec, int max_batch, cpp_net** out) {
+  ARG_CHECK(ctx && spec && out, "cpp_net_create: NULL argument");
+  ARG_CHECK(max_batch >= 1, "cpp_net_create: max_batch %d", max_batch);
+  ARG_CHECK(spec->kind == CPP_ACTOR || spec->kind == CPP_CRITIC, "cpp_net_create: kind %d", spec->kind);
+  ARG_CHECK(spec->action_dim >= 1 && spec->action_dim <= 16, "cpp_net_create: action_dim %d", spec->action_dim);
+  ARG_CHECK(spec->n_hidden >= 0 && spec->n_hidden <= 8, "cpp_net_create: n_hidden %d", spec->n_hidden);
+  if (spec->pixel) ARG_CHECK(spec->H >= 8 && spec->W >= 8 && spec->C >= 1 && spec->C <= CPP_MAX_CHANNELS,
+                             "cpp_net_create: pixel dims %dx%dx%d", spec->H, spec->W, spec->C);
+  else ARG_CHECK(spec->state_elems >= 1, "cpp_net_create: state_elems %d", spec->state_elems);
+  if (spec->kind == CPP_ACTOR || !spec->pixel) ARG_CHECK(spec->n_hidden >= 1, "cpp_net_create: need hidden layers");
+  HIP_CHECK(hipSetDevice(ctx->device));
+  cpp_net* n = new cpp_net();
+  n->ctx = ctx; n->spec = *spec; n->maxB = max_batch; n->arena.stream = ctx->stream;
+  n->grads = nullptr; n->own_grads = nullptr; n->stage_state = nullptr; n->stage_action = nullptr;
+  n->stage_out = nullptr; n->dw_partial = nullptr; n->white = nullptr; n->stats_part = nullptr;
+  int rc = net_build(n);
+  if (rc) { delete n; return rc; }
+  auto fail = [&](int r) { n->arena.release(); delete n; return r; };
+  if ((rc = dalloc(n->arena, &n->params, (size_t)n->nparams))) return fail(rc);
+  if ((rc = ws_alloc(n, n->ws[0], 0, true))) return fail(rc);
+  if (spec->kind == CPP_CRITIC) {
+    n->ws[1] = n->ws[0];
+    if ((rc = ws_alloc(n, n->ws[1], n->cat_layer, false))) return fail(rc);
+    for (int l = 0; l < n->cat_layer; ++l) { n->ws[1].fcin[l] = n->ws[0].fcin[l]; n->ws[1].dz[l] = n->ws[0].dz[l]; }
+    for (int i = 0; i < 3; ++i) { n->ws[1].pool[i] = n->ws[0].pool[i]; n->ws[1].amax[i] = n->ws[0].amax[i]; n->ws[1].dpool[i] = n->ws[0].dpool[i]; }
+  }
+  if (spec->pixel) {
+    size_t pf = 0;
+    for (const ConvL& L : n->conv) { size_t f = conv_dw_partial_floats(ctx, L.Cin, L.ks, kConvOut); if (f > pf) pf = f; }
+    if ((rc = dalloc(n->arena, &n->dw_partial, pf))) return fail(rc);
+    if ((rc = dalloc(n->arena, &n->white, (size_t)2 * spec->C))) return fail(rc);
+    if ((rc = dalloc(n->arena, &n->stats_part, (size_t)2 * max_batch * 2 * spec->C))) return fail(rc);
+  }
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  *out = n;
+  return CPP_OK;
+}
+
+extern "C" int cpp_net_destroy(cpp_net* n) {
+  if (!n) return CPP_OK;
+  (void)hipSetDevice(n->ctx->device);
+  (void)hipStreamSynchronize(n->ctx->stream);
+  n->arena.release();
+  delete n;
+  return CPP_OK;
+}
+
+extern "C" int64_t cpp_net_num_params(const cpp_net* n) { return n ? n->nparams : -1; }
+extern "C" int cpp_net_num_vars(const cpp_net* n) { return n ? (int)n->vars.size() : -1; }
+extern "C" int cpp_net_var_info(const cpp_net* n, int i, char* name, int cap, int* rank, int shape[4], int64_t* offset) {
+  ARG_CHECK(n && i >= 0 && i < (int)n->vars.size(), "cpp_net_var_info: index %d", i);
+  const VarInfo& v = n->vars[i];
+  if (name && cap > 0) { strncpy(name, v.name.c_str(), cap - 1); name[cap - 1] = 0; }
+  if (rank) *rank = v.rank;
+  if (shape) for (int k = 0; k < 4; ++k) shape[k] = v.shape[k];
+  if (offset) *offset = v.offset;
+  return CPP_OK;
+}
+
+extern "C" int cpp_net_set_params(cpp_net* n, const float* host, int64_t cnt) {
+  ARG_CHECK(n && host, "cpp_net_set_params: NULL argument");
+  ARG_CHECK(cnt == n->nparams, "cpp_net_set_params: got %ld values, network has %ld", (long)cnt, n->nparams);
+  HIP_CHECK(hipMemcpyAsync(n->params, host, cnt * sizeof(float), hipMemcpyHostToDevice, n->ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(n->ctx->stream));
+  return CPP_OK;
+}
+extern "C" int cpp_net_get_params(cpp_net* n, float* host, int64_t cnt) {
+  ARG_CHECK(n && host, "cpp_net_get_params: NULL argument");
+  ARG_CHECK(cnt == n->nparams, "cpp_net_get_params: asked %ld values, network has %ld", (long)cnt, n->nparams);
+  HIP_CHECK(hipMemcpyAsync(host, n->params, cnt * sizeof(float), hipMemcpyDeviceToHost, n->ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(n->ctx->stream));
+  return CPP_OK;
+}
+extern "C" int cpp_net_get_grads(cpp_net* n, float* host, int64_t cnt) {
+  ARG_CHECK(n && host, "cpp_net_get_grads: NULL argument");
+  ARG_CHECK(cnt == n->nparams, "cpp_net_get_grads: asked %ld values, network has %ld", (long)cnt, n->nparams);
+  if (!n->grads) { cpp_set_error("cpp_net_get_grads: network has no train op (init_ops_for_training not called)"); return CPP_ERR_STATE; }
+  HIP_CHECK(hipMemcpyAsync(host, n->grads, cnt * sizeof(float), hipMemcpyDeviceToHost, n->ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(n->ctx->stream));
+  return CPP_OK;
+}
+
+extern "C" int cpp_net_soft_update(cpp_net* target, const cpp_net* source, float coeff) {
+  ARG_CHECK(target && source, "cpp_net_soft_update: NULL argument");
+  ARG_CHECK(coeff >= 0.f && coeff <= 1.f, "affine_combo_coeff %g outside [0,1]", coeff);    // base_network.py:22
+  ARG_CHECK(target->nparams == source->nparams, "cpp_net_soft_update: shapes differ (%ld vs %ld)",
+            target->nparams, source->nparams);                                             // base_network.py:30
+  return launch_soft_update(target->ctx, target->params, source->params, target->nparams, nullptr, nullptr, 0, coeff);
+}
+
+// --- launch sequences -------------------------------------------------------------------------
+static int gemm(cpp_ctx* ctx, const float* A, long sAm, long sAk, const float* Bm, long sBk, long sBn,
+                float* C, long ldc, int M, int N, int K, int epi, const float* Y = nullptr, long ldy = 0) {
+  GemmArgs g; g.A = A; g.sAm = sAm; g.sAk = sAk; g.B = Bm; g.sBk = sBk; g.sBn = sBn; g.C = C; g.ldc = ldc;
+  g.Y = Y; g.ldy = ldy; g.M = M; g.N = N; g.K = K; g.epi = epi;
+  return launch_gemm(ctx, g);
+}
+
+static const int kFwdKid[3] = {K_CONV1_FWD, K_CONV2_FWD, K_CONV3_FWD};
+static const int kDwKid[3] = {K_CONV1_DW, K_CONV2_DW, K_CONV3_DW};
+static const int kDxKid[3] = {-1, K_CONV2_DX, K_CONV3_DX};
+
+// conv trunk (pixel) or state conversion (low-dim) into ws.fcin[0]
+static int net_forward_trunk(cpp_net* n, Workspace& w, const void* state, int dtype, const float* white, int B) {
+  cpp_ctx* ctx = n->ctx;
+  if (!n->spec.pixel)
+    return launch_state_to_f32(ctx, w.fcin[0], n->fc[0].n_in + 1, state, dtype, n->state_elems, B);
+  for (int i = 0; i < 3; ++i) {
+    const ConvL& L = n->conv[i];
+    ConvArgs a; memset(&a, 0, sizeof(a));
+    int mode;
+    if (i == 0) { a.in = state; a.in_bstride = n->state_elems; a.scale = white; a.shift = white + n->spec.C;
+                  mode = dtype == CPP_F16 ? IN_F16_WHITEN : IN_F32_WHITEN; }
+    else { a.in = w.pool[i - 1]; a.in_bstride = (long)L.H * L.W * L.Cin; mode = IN_F32_PLAIN; }
+    a.w = n->params + L.w_off; a.bias = n->params + L.b_off;
+    a.out = w.pool[i]; a.out_bstride = (i == 2) ? (long)n->flat + 1 : (long)L.Hp * L.Wp * kConvOut;
+    a.out_amax = w.amax[i];
+    a.B = B; a.H = L.H; a.W = L.W; a.nout = kConvOut;
+    RC(launch_conv_fwd(ctx, kFwdKid[i], L.Cin, L.ks, mode, EPI_RELU_POOL, a));
+  }
+  return CPP_OK;
+}
+
+// fully connected layers [from, end); `action` (device, (B, A)) is spliced in front of the cat layer
+static int net_forward_fc(cpp_net* n, Workspace& w, int from, int B, const float* action) {
+  cpp_ctx* ctx = n->ctx;
+  const int nfc = (int)n->fc.size(), A = n->spec.action_dim;
+  for (int l = from; l < nfc; ++l) {
+    const FcL& L = n->fc[l];
+    if (L.cat) {
+      if (!action) { cpp_set_error("critic forward needs an action batch"); return CPP_ERR_ARG; }
+      RC(launch_copy_cols(ctx, w.fcin[l], L.n_in + 1, L.n_in - A, action, A, 0, A, B));
+    }
+    float* C = (l + 1 < nfc) ? w.fcin[l + 1] : w.out;
+    const long ldc = (l + 1 < nfc) ? n->fc[l + 1].n_in + 1 : L.n_out;
+    RC(gemm(ctx, w.fcin[l], L.n_in + 1, 1, n->params + L.w_off, L.n_out, 1, C, ldc, B, L.n_out, L.n_in + 1, L.act));
+  }
+  return CPP_OK;
+}
+
+// Backward from w.dz[last] (gradient w.r.t. the last layer's pre-activation).  want_params: write
+// [dW; db] of every layer into n->grads, otherwise stop once d_action is known.  d_action: (B, A) out.
+static int net_backward(cpp_net* n, Workspace& w, int B, bool want_params, float* d_action,
+                        const void* state, int dtype, const float* white) {
+  cpp_ctx* ctx = n->ctx;
+  const int nfc = (int)n->fc.size(), A = n->spec.action_dim;
+  if (want_params && !n->grads) { cpp_set_error("network has no gradient buffer"); return CPP_ERR_STATE; }
+  for (int l = nfc - 1; l >= 0; --l) {
+    const FcL& L = n->fc[l];
+    const float* dz = w.dz[l];
+    const float* W = n->params + L.w_off;
+    if (want_params)    // [dW; db] = [x, 1]^T dz
+      RC(gemm(ctx, w.fcin[l], 1, L.n_in + 1, dz, L.n_out, 1, n->grads + L.w_off, L.n_out, L.n_in + 1, L.n_out, B, GE_NONE));
+    if (L.cat) {
+      if (d_action)     // dQ/da: the action columns of dz W^T (ddpg_cartpole.py:222)
+        RC(gemm(ctx, dz, L.n_out, 1, W + (long)(L.n_in - A) * L.n_out, 1, L.n_out, d_action, A, B, A, L.n_out, GE_NONE));
+      if (!want_params) return CPP_OK;
+      if (l > 0)
+        RC(gemm(ctx, dz, L.n_out, 1, W, 1, L.n_out, w.dz[l - 1], L.n_in - A, B, L.n_in - A, L.n_out,
+                GE_MUL_RELU_GRAD, w.fcin[l], L.n_in + 1));
+    } else if (l > 0) {
+      RC(gemm(ctx, dz, L.n_out, 1, W, 1, L.n_out, w.dz[l - 1], L.n_in, B, L.n_in, L.n_out,
+              GE_MUL_RELU_GRAD, w.fcin[l], L.n_in + 1));
+    } else if (n->spec.pixel && want_params) {
+      RC(gemm(ctx, dz, L.n_out, 1, W, 1, L.n_out, w.dpool[2], n->flat, B, n->flat, L.n_out, GE_NONE));
+    }
+  }
+  if (!want_params || !n->spec.pixel) return CPP_OK;
+  for (int i = 2; i >= 0; --i) {
+    const ConvL& L = n->conv[i];
+    ConvArgs a; memset(&a, 0, sizeof(a));
+    a.dy.dpool = w.dpool[i]; a.dy.pool = w.pool[i]; a.dy.amax = w.amax[i];
+    a.dy.dpool_bstride = (i == 2) ? (long)n->flat : (long)L.Hp * L.Wp * kConvOut;
+    a.dy.pool_bstride = (i == 2) ? (long)n->flat + 1 : (long)L.Hp * L.Wp * kConvOut;
+    a.dy.Hp = L.Hp; a.dy.Wp = L.Wp;
+    a.B = B; a.H = L.H; a.W = L.W;
+    // dW / db
+    ConvArgs d = a;
+    int mode;
+    if (i == 0) { d.in = state; d.in_bstride = n->state_elems; d.scale = white; d.shift = white + n->spec.C;
+                  mode = dtype == CPP_F16 ? IN_F16_WHITEN : IN_F32_WHITEN; }
+    else { d.in = w.pool[i - 1]; d.in_bstride = (long)L.H * L.W * L.Cin; mode = IN_F32_PLAIN; }
+    d.nout = kConvOut; d.partial = n->dw_partial;
+    RC(launch_conv_dw(ctx, kDwKid[i], L.Cin, L.ks, mode, d, n->grads + L.w_off, n->grads + L.b_off));
+    // dX -> gradient w.r.t. the previous pooled output (conv1's input is data: no dX)
+    if (i > 0) {
+      ConvArgs x = a;
+      x.w = n->params + L.w_off; x.nout = L.Cin;
+      x.out = w.dpool[i - 1]; x.out_bstride = (long)L.H * L.W * L.Cin;
+      RC(launch_conv_fwd(ctx, kDxKid[i], kConvOut, L.ks, IN_DY, EPI_PLAIN, x));
+    }
+  }
+  return CPP_OK;
+}
+
+// whitening statistics of a device-resident (B, H*W*C) batch -> white[2][C]
+static int batch_stats(cpp_ctx* ctx, const void* s0, const void* s1, int dtype, long elems, int B, int C,
+                       double* part, float* white) {
+  int g = 8, c = C; while (c) { int t = g % c; g = c; c = t; }     // gcd(8, C)
+  const bool vec = (elems % 8 == 0) && (C / g <= 16);
+  const int nw = s1 ? 2 : 1;
+  if (vec) {
+    GatherArgs a; memset(&a, 0, sizeof(a));
+    a.store[0] = s0; a.store[1] = s1 ? s1 : s0; a.part = part; a.elems = elems; a.B = B; a.C = C;
+    RC(launch_gather_stats(ctx, a, dtype));     // grid (B,2): second column recomputes s0 when s1 == NULL (cheap, rare)
+    RC(launch_stats_finalize(ctx, part, B, nw, C, (double)B * (double)(elems / C), white));
+  } else {
+    RC(launch_stats_generic(ctx, s0, dtype, (long)B * (elems / C), C, white));
+    if (s1) RC(launch_stats_generic(ctx, s1, dtype, (long)B * (elems / C), C, white + 2 * C));
+  }
+  return CPP_OK;
+}
+
+extern "C" int cpp_net_forward(cpp_net* n, const void* state, int state_dtype, int B, const float* action, float* out) {
+  ARG_CHECK(n && state && out, "cpp_net_forward: NULL argument");
+  ARG_CHECK(B >= 1 && B <= n->maxB, "cpp_net_forward: batch %d outside [1,%d]", B, n->maxB);
+  ARG_CHECK(state_dtype == CPP_F32 || state_dtype == CPP_F16, "cpp_net_forward: dtype %d", state_dtype);
+  ARG_CHECK(n->spec.kind == CPP_ACTOR || action, "cpp_net_forward: critic needs an action batch");
+  cpp_ctx* ctx = n->ctx;
+  HIP_CHECK(hipSetDevice(ctx->device));
+  const int A = n->spec.action_dim, no = n->fc.back().n_out;
+  if (!n->stage_state) {
+    RC(n->arena.alloc(&n->stage_state, (size_t)n->maxB * n->state_elems * sizeof(float), false));
+    RC(dalloc(n->arena, &n->stage_action, (size_t)n->maxB * A));
+  }
+  const size_t esz = state_dtype == CPP_F16 ? 2 : 4;
+  HIP_CHECK(hipMemcpyAsync(n->stage_state, state, (size_t)B * n->state_elems * esz, hipMemcpyHostToDevice, ctx->stream));
+  if (action) HIP_CHECK(hipMemcpyAsync(n->stage_action, action, (size_t)B * A * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  if (n->spec.pixel)
+    RC(batch_stats(ctx, n->stage_state, nullptr, state_dtype, n->state_elems, B, n->spec.C, n->stats_part, n->white));
+  RC(net_forward_trunk(n, n->ws[0], n->stage_state, state_dtype, n->white, B));
+  RC(net_forward_fc(n, n->ws[0], 0, B, action ? n->stage_action : nullptr));
+  HIP_CHECK(hipMemcpyAsync(out, n->ws[0].out, (size_t)B * no * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return CPP_OK;
+}
+
+extern "C" int cpp_net_get_pool(cpp_net* n, int which, int B, float* out) {
+  ARG_CHECK(n && out, "cpp_net_get_pool: NULL argument");
+  ARG_CHECK(n->spec.pixel && which >= 1 && which <= 3, "cpp_net_get_pool: which=%d (pixel nets, 1..3)", which);
+  ARG_CHECK(B >= 1 && B <= n->maxB, "cpp_net_get_pool: batch %d", B);
+  const ConvL& L = n->conv[which - 1];
+  const size_t row = (size_t)L.Hp * L.Wp * kConvOut * sizeof(float);
+  const size_t spitch = (which == 3) ? ((size_t)n->flat + 1) * sizeof(float) : row;
+  HIP_CHECK(hipMemcpy2DAsync(out, row, n->ws[0].pool[which - 1], spitch, row, B, hipMemcpyDeviceToHost, n->ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(n->ctx->stream));
+  return CPP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// batch
+// ---------------------------------------------------------------------------------------------
+struct cpp_batch {
+  cpp_ctx* ctx; int maxB, B; long elems; int A; int dtype;
+  void* s[2]; float *a, *r, *m;
+  float* white;        // [2 states][2][CPP_MAX_CHANNELS]-compatible: laid out [2][2*C] for the current C
+  double* part;        // [2][maxB][2*CPP_MAX_CHANNELS]
+  int stats_C;         // channels the statistics were computed for (0: none yet)
+  Arena arena;
+};
+
+extern "C" int cpp_batch_create(cpp_ctx* ctx, int max_batch, int64_t state_elems, int action_dim, cpp_batch** out) {
+  ARG_CHECK(ctx && out, "cpp_batch_create: NULL argument");
+  ARG_CHECK(max_batch >= 1 && state_elems >= 1 && action_dim >= 1, "cpp_batch_create: bad sizes");
+  HIP_CHECK(hipSetDevice(ctx->device));
+  cpp_batch* b = new cpp_batch();
+  b->arena.stream = ctx->stream;
+  b->ctx = ctx; b->maxB = max_batch; b->B = 0; b->elems = state_elems; b->A = action_dim; b->dtype = CPP_F16; b->stats_C = 0;
+  int rc = 0;
+  for (int k = 0; k < 2 && !rc; ++k) rc = b->arena.alloc(&b->s[k], (size_t)max_batch * state_elems * sizeof(float), false);
+  if (!rc) rc = dalloc(b->arena, &b->a, (size_t)max_batch * action_dim);
+  if (!rc) rc = dalloc(b->arena, &b->r, (size_t)max_batch);
+  if (!rc) rc = dalloc(b->arena, &b->m, (size_t)max_batch);
+  if (!rc) rc = dalloc(b->arena, &b->white, (size_t)4 * CPP_MAX_CHANNELS);
+  if (!rc) rc = dalloc(b->arena, &b->part, (size_t)2 * max_batch * 2 * CPP_MAX_CHANNELS);
+  if (rc) { b->arena.release(); delete b; return rc; }
+  *out = b;
+  return CPP_OK;
+}
+extern "C" int cpp_batch_destroy(cpp_batch* b) {
+  if (!b) return CPP_OK;
+  (void)hipSetDevice(b->ctx->device);
+  (void)hipStreamSynchronize(b->ctx->stream);
+  b->arena.release(); delete b; return CPP_OK;
+}
+extern "C" int cpp_batch_size(const cpp_batch* b) { return b ? b->B : -1; }
+extern "C" int cpp_batch_state_dtype(const cpp_batch* b) { return b ? b->dtype : -1; }
+
+extern "C" int cpp_batch_upload(cpp_batch* b, int B, const void* s1, const void* s2, int dtype,
+                                const float* action, const float* reward, const float* mask) {
+  ARG_CHECK(b && s1, "cpp_batch_upload: NULL argument");
+  ARG_CHECK(B >= 1 && B <= b->maxB, "cpp_batch_upload: batch %d outside [1,%d]", B, b->maxB);
+  ARG_CHECK(dtype == CPP_F32 || dtype == CPP_F16, "cpp_batch_upload: dtype %d", dtype);
+  hipStream_t st = b->ctx->stream;
+  HIP_CHECK(hipSetDevice(b->ctx->device));
+  const size_t sb = (size_t)B * b->elems * (dtype == CPP_F16 ? 2 : 4);
+  HIP_CHECK(hipMemcpyAsync(b->s[0], s1, sb, hipMemcpyHostToDevice, st));
+  if (s2) HIP_CHECK(hipMemcpyAsync(b->s[1], s2, sb, hipMemcpyHostToDevice, st));
+  if (action) HIP_CHECK(hipMemcpyAsync(b->a, action, (size_t)B * b->A * sizeof(float), hipMemcpyHostToDevice, st));
+  if (reward) HIP_CHECK(hipMemcpyAsync(b->r, reward, (size_t)B * sizeof(float), hipMemcpyHostToDevice, st));
+  if (mask) HIP_CHECK(hipMemcpyAsync(b->m, mask, (size_t)B * sizeof(float), hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  b->B = B; b->dtype = dtype; b->stats_C = 0;
+  return CPP_OK;
+}
+
+extern "C" int cpp_batch_download(cpp_batch* b, void* s1, void* s2, float* action, float* reward, float* mask) {
+  ARG_CHECK(b, "cpp_batch_download: NULL argument");
+  ARG_CHECK(b->B >= 1, "cpp_batch_download: batch is empty");
+  hipStream_t st = b->ctx->stream;
+  const size_t sb = (size_t)b->B * b->elems * (b->dtype == CPP_F16 ? 2 : 4);
+  if (s1) HIP_CHECK(hipMemcpyAsync(s1, b->s[0], sb, hipMemcpyDeviceToHost, st));
+  if (s2) HIP_CHECK(hipMemcpyAsync(s2, b->s[1], sb, hipMemcpyDeviceToHost, st));
+  if (action) HIP_CHECK(hipMemcpyAsync(action, b->a, (size_t)b->B * b->A * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (reward) HIP_CHECK(hipMemcpyAsync(reward, b->r, (size_t)b->B * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (mask) HIP_CHECK(hipMemcpyAsync(mask, b->m, (size_t)b->B * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  return CPP_OK;
+}
+
+static int batch_ensure_stats(cpp_batch* b, int C) {
+  if (C <= 0 || b->stats_C == C) return CPP_OK;
+  RC(batch_stats(b->ctx, b->s[0], b->s[1], b->dtype, b->elems, b->B, C, b->part, b->white));
+  b->stats_C = C;
+  return CPP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// replay
+// ---------------------------------------------------------------------------------------------
+struct cpp_replay {
+  cpp_ctx* ctx; int rows, slots, A, size; long elems;
+  __half* store; int32_t *s1, *s2, *rows_in, *rows_out; float *action, *reward, *mask;
+  uint64_t* counter;       // device-side Philox counter for graph replay
+  float* stage_f32; size_t stage_cap;
+  Arena arena;
+};
+
+extern "C" int cpp_replay_create(cpp_ctx* ctx, int buffer_size, int state_slots, int64_t state_elems,
+                                 int action_dim, cpp_replay** out) {
+  ARG_CHECK(ctx && out, "cpp_replay_create: NULL argument");
+  ARG_CHECK(buffer_size >= 1 && state_elems >= 1 && action_dim >= 1, "cpp_replay_create: bad sizes");
+  ARG_CHECK(state_slots >= buffer_size + 1, "cpp_replay_create: %d state slots for %d rows", state_slots, buffer_size);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  cpp_replay* r = new cpp_replay();
+  r->arena.stream = ctx->stream;
+  r->ctx = ctx; r->rows = buffer_size; r->slots = state_slots; r->A = action_dim; r->size = 0; r->elems = state_elems;
+  r->stage_f32 = nullptr; r->stage_cap = 0;
+  int rc = r->arena.alloc((void**)&r->store, (size_t)state_slots * state_elems * sizeof(__half), false);
+  if (!rc) rc = dalloc(r->arena, &r->s1, (size_t)buffer_size);
+  if (!rc) rc = dalloc(r->arena, &r->s2, (size_t)buffer_size);
+  if (!rc) rc = dalloc(r->arena, &r->rows_in, (size_t)65536);
+  if (!rc) rc = dalloc(r->arena, &r->rows_out, (size_t)65536);
+  if (!rc) rc = dalloc(r->arena, &r->action, (size_t)buffer_size * action_dim);
+  if (!rc) rc = dalloc(r->arena, &r->reward, (size_t)buffer_size);
+  if (!rc) rc = dalloc(r->arena, &r->mask, (size_t)buffer_size);
+  if (!rc) rc = dalloc(r->arena, &r->counter, (size_t)1);
+  if (rc) { r->arena.release(); delete r; return rc; }
+  *out = r;
+  return CPP_OK;
+}
+extern "C" int cpp_replay_destroy(cpp_replay* r) {
+  if (!r) return CPP_OK;
+  (void)hipSetDevice(r->ctx->device);
+  (void)hipStreamSynchronize(r->ctx->stream);
+  if (r->stage_f32) (void)hipFree(r->stage_f32);
+  r->arena.release(); delete r; return CPP_OK;
+}
+
+extern "C" int cpp_replay_write_states(cpp_replay* r, const int32_t* slots, int n, const void* states, int dtype) {
+  ARG_CHECK(r && slots && states, "cpp_replay_write_states: NULL argument");
+  ARG_CHECK(dtype == CPP_F32 || dtype == CPP_F16, "cpp_replay_write_states: dtype %d", dtype);
+  hipStream_t st = r->ctx->stream;
+  HIP_CHECK(hipSetDevice(r->ctx->device));
+  for (int i = 0; i < n; ++i)
+    ARG_CHECK(slots[i] >= 0 && slots[i] < r->slots, "cpp_replay_write_states: slot %d outside [0,%d)", slots[i], r->slots);
+  if (dtype == CPP_F32) {
+    const size_t need = (size_t)n * r->elems * sizeof(float);
+    if (need > r->stage_cap) {
+      if (r->stage_f32) HIP_CHECK(hipFree(r->stage_f32));
+      HIP_CHECK(hipMalloc((void**)&r->stage_f32, need)); r->stage_cap = need;
+    }
+    HIP_CHECK(hipMemcpyAsync(r->stage_f32, states, need, hipMemcpyHostToDevice, st));
+    for (int i = 0; i < n; ++i)
+      RC(launch_f32_to_f16(r->ctx, r->store + (size_t)slots[i] * r->elems, r->stage_f32 + (size_t)i * r->elems, r->elems));
+  } else {
+    for (int i = 0; i < n; ++i)
+      HIP_CHECK(hipMemcpyAsync(r->store + (size_t)slots[i] * r->elems, (const __half*)states + (size_t)i * r->elems,
+                               (size_t)r->elems * sizeof(__half), hipMemcpyHostToDevice, st));
+  }
+  HIP_CHECK(hipStreamSynchronize(st));
+  return CPP_OK;
+}
+
+extern "C" int cpp_replay_write_rows(cpp_replay* r, const int32_t* rows, int n, const int32_t* s1, const int32_t* s2,
+                                     const float* action, const float* reward, const float* mask) {
+  ARG_CHECK(r && rows && s1 && s2 && action && reward && mask, "cpp_replay_write_rows: NULL argument");
+  hipStream_t st = r->ctx->stream;
+  HIP_CHECK(hipSetDevice(r->ctx->device));
+  int i = 0;
+  while (i < n) {          // contiguous runs of rows go out as one copy per column
+    ARG_CHECK(rows[i] >= 0 && rows[i] < r->rows, "cpp_replay_write_rows: row %d outside [0,%d)", rows[i], r->rows);
+    int j = i + 1;
+    while (j < n && rows[j] == rows[j - 1] + 1) ++j;
+    const int cnt = j - i, r0 = rows[i];
+    HIP_CHECK(hipMemcpyAsync(r->s1 + r0, s1 + i, cnt * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(r->s2 + r0, s2 + i, cnt * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(r->action + (size_t)r0 * r->A, action + (size_t)i * r->A, (size_t)cnt * r->A * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(r->reward + r0, reward + i, cnt * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(r->mask + r0, mask + i, cnt * sizeof(float), hipMemcpyHostToDevice, st));
+    i = j;
+  }
+  HIP_CHECK(hipStreamSynchronize(st));
+  return CPP_OK;
+}
+
+extern "C" int cpp_replay_set_size(cpp_replay* r, int size) {
+  ARG_CHECK(r && size >= 0 && size <= r->rows, "cpp_replay_set_size: size %d", size);
+  r->size = size;
+  return CPP_OK;
+}
+
+extern "C" int cpp_replay_read_states(cpp_replay* r, const int32_t* slots, int n, void* out_f16) {
+  ARG_CHECK(r && slots && out_f16, "cpp_replay_read_states: NULL argument");
+  hipStream_t st = r->ctx->stream;
+  for (int i = 0; i < n; ++i) {
+    ARG_CHECK(slots[i] >= 0 && slots[i] < r->slots, "cpp_replay_read_states: slot %d", slots[i]);
+    HIP_CHECK(hipMemcpyAsync((__half*)out_f16 + (size_t)i * r->elems, r->store + (size_t)slots[i] * r->elems,
+                             (size_t)r->elems * sizeof(__half), hipMemcpyDeviceToHost, st));
+  }
+  HIP_CHECK(hipStreamSynchronize(st));
+  return CPP_OK;
+}
+
+// device-only part of sampling (graph-capturable when rows_dev == nullptr or already resident)
+static int replay_sample_device(cpp_replay* r, int B, const int32_t* rows_dev, uint64_t seed, const uint64_t* counter_dev,
+                                int channels, cpp_batch* out) {
+  cpp_ctx* ctx = r->ctx;
+  int C = channels;
+  if (C > 0) {
+    int g = 8, c = C; while (c) { int t = g % c; g = c; c = t; }
+    if (r->elems % 8 != 0 || C / g > 16 || r->elems % C != 0) C = 0;    // statistics via the generic path below
+  }
+  GatherArgs a; memset(&a, 0, sizeof(a));
+  a.store[0] = r->store; a.store[1] = r->store; a.s_idx[0] = r->s1; a.s_idx[1] = r->s2;
+  a.rows = rows_dev; a.rows_out = r->rows_out;
+  a.action = r->action; a.reward = r->reward; a.mask = r->mask;
+  a.out_state[0] = out->s[0]; a.out_state[1] = out->s[1];
+  a.out_action = out->a; a.out_reward = out->r; a.out_mask = out->m;
+  a.part = out->part; a.seed = seed; a.counter = counter_dev;
+  a.elems = r->elems; a.B = B; a.size = r->size; a.action_dim = r->A; a.C = C;
+  RC(launch_gather_stats(ctx, a, CPP_F16));
+  out->B = B; out->dtype = CPP_F16; out->stats_C = 0;
+  if (C > 0) {
+    RC(launch_stats_finalize(ctx, out->part, B, 2, C, (double)B * (double)(r->elems / C), out->white));
+    out->stats_C = C;
+  } else if (channels > 0) {
+    RC(batch_ensure_stats(out, channels));
+  }
+  return CPP_OK;
+}
+
+extern "C" int cpp_replay_sample(cpp_replay* r, int B, const int32_t* idxs, uint64_t seed, uint64_t counter,
+                                 int channels, cpp_batch* out) {
+  ARG_CHECK(r && out, "cpp_replay_sample: NULL argument");
+  ARG_CHECK(B >= 1 && B <= out->maxB && B <= 65536, "cpp_replay_sample: batch %d outside [1,%d]", B, out->maxB);
+  ARG_CHECK(out->elems == r->elems && out->A == r->A, "cpp_replay_sample: batch/replay shapes differ");
+  ARG_CHECK(channels >= 0 && channels <= CPP_MAX_CHANNELS, "cpp_replay_sample: channels %d", channels);
+  if (r->size <= 0) { cpp_set_error("cpp_replay_sample: replay memory is empty"); return CPP_ERR_STATE; }
+  hipStream_t st = r->ctx->stream;
+  HIP_CHECK(hipSetDevice(r->ctx->device));
+  const int32_t* rows_dev = nullptr;
+  if (idxs) {
+    for (int i = 0; i < B; ++i)
+      ARG_CHECK(idxs[i] >= 0 && idxs[i] < r->size, "cpp_replay_sample: index %d outside [0,%d)", idxs[i], r->size);
+    HIP_CHECK(hipMemcpyAsync(r->rows_in, idxs, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    rows_dev = r->rows_in;
+  } else {
+    HIP_CHECK(hipMemcpyAsync(r->counter, &counter, sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  }
+  RC(replay_sample_device(r, B, rows_dev, seed, idxs ? nullptr : r->counter, channels, out));
+  HIP_CHECK(hipStreamSynchronize(st));
+  return CPP_OK;
+}
+
+extern "C" int cpp_replay_last_indexes(cpp_replay* r, int B, int32_t* out) {
+  ARG_CHECK(r && out && B >= 1 && B <= 65536, "cpp_replay_last_indexes: bad argument");
+  HIP_CHECK(hipMemcpyAsync(out, r->rows_out, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, r->ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(r->ctx->stream));
+  return CPP_OK;
+}
+
+extern "C" int cpp_replay_fill_synthetic(cpp_replay* r, int n_rows, uint64_t seed) {
+  ARG_CHECK(r && n_rows >= 1 && n_rows <= r->rows, "cpp_replay_fill_synthetic: rows %d", n_rows);
+  ARG_CHECK(n_rows + n_rows / 50 + 1 <= r->slots, "cpp_replay_fill_synthetic: not enough state slots");
+  HIP_CHECK(hipSetDevice(r->ctx->device));
+  RC(launch_replay_fill(r->ctx, r->store, r->elems, r->slots, r->s1, r->s2, r->action, r->reward, r->mask,
+                        n_rows, r->A, seed));
+  HIP_CHECK(hipStreamSynchronize(r->ctx->stream));
+  r->size = n_rows;
+  return CPP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// DDPG
+// ---------------------------------------------------------------------------------------------
+constexpr int NORM_PARTS = 64;
+
+struct cpp_ddpg {
+  cpp_ctx* ctx; cpp_net *actor, *critic, *tactor, *tcritic; cpp_ddpg_hyper hp;
+  int maxB; long nA, nC;
+  float* gradbuf; float *dq_da, *td, *dq, *loss_norms /* [0] loss [1] actor norm [2] critic norm */, *ones;
+  double* norm_part;
+  // graph replay of the full inner step
+  hipGraph_t graph; hipGraphExec_t gexec; bool graph_ok; int g_B, g_nb; uint64_t g_seed; cpp_replay* g_replay;
+  cpp_batch* step_batch;
+  Arena arena;
+};
+
+extern "C" int cpp_ddpg_create(cpp_ctx* ctx, cpp_net* actor, cpp_net* critic, cpp_net* tactor, cpp_net* tcritic,
+                               const cpp_ddpg_hyper* hp, cpp_ddpg** out) {
+  ARG_CHECK(ctx && actor && critic && tactor && tcritic && hp && out, "cpp_ddpg_create: NULL argument");
+  ARG_CHECK(actor->spec.kind == CPP_ACTOR && tactor->spec.kind == CPP_ACTOR, "cpp_ddpg_create: actor kinds");
+  ARG_CHECK(critic->spec.kind == CPP_CRITIC && tcritic->spec.kind == CPP_CRITIC, "cpp_ddpg_create: critic kinds");
+  ARG_CHECK(actor->nparams == tactor->nparams && critic->nparams == tcritic->nparams, "cpp_ddpg_create: target shapes differ");
+  ARG_CHECK(actor->state_elems == critic->state_elems && actor->spec.action_dim == critic->spec.action_dim,
+            "cpp_ddpg_create: actor/critic input shapes differ");
+  HIP_CHECK(hipSetDevice(ctx->device));
+  cpp_ddpg* d = new cpp_ddpg();
+  d->arena.stream = ctx->stream;
+  d->ctx = ctx; d->actor = actor; d->critic = critic; d->tactor = tactor; d->tcritic = tcritic; d->hp = *hp;
+  d->maxB = actor->maxB < critic->maxB ? actor->maxB : critic->maxB;
+  d->nA = actor->nparams; d->nC = critic->nparams;
+  d->graph = nullptr; d->gexec = nullptr; d->graph_ok = false; d->step_batch = nullptr; d->g_replay = nullptr;
+  const int A = actor->spec.action_dim;
+  int rc = dalloc(d->arena, &d->gradbuf, (size_t)(d->nA + d->nC));
+  if (!rc) rc = dalloc(d->arena, &d->dq_da, (size_t)d->maxB * A);
+  if (!rc) rc = dalloc(d->arena, &d->td, (size_t)d->maxB);
+  if (!rc) rc = dalloc(d->arena, &d->dq, (size_t)d->maxB);
+  if (!rc) rc = dalloc(d->arena, &d->ones, (size_t)d->maxB);
+  if (!rc) rc = dalloc(d->arena, &d->loss_norms, (size_t)4);
+  if (!rc) rc = dalloc(d->arena, &d->norm_part, (size_t)2 * NORM_PARTS);
+  if (!rc) rc = launch_fill(ctx, d->ones, 1, 0, 1, d->maxB, 1.0f);
+  if (rc) { d->arena.release(); delete d; return rc; }
+  actor->grads = d->gradbuf; critic->grads = d->gradbuf + d->nA;
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  *out = d;
+  return CPP_OK;
+}
+
+extern "C" int cpp_ddpg_destroy(cpp_ddpg* d) {
+  if (!d) return CPP_OK;
+  (void)hipSetDevice(d->ctx->device);
+  (void)hipStreamSynchronize(d->ctx->stream);
+  if (d->gexec) (void)hipGraphExecDestroy(d->gexec);
+  if (d->graph) (void)hipGraphDestroy(d->graph);
+  if (d->step_batch) cpp_batch_destroy(d->step_batch);
+  d->actor->grads = nullptr; d->critic->grads = nullptr;
+  d->arena.release(); delete d; return CPP_OK;
+}
+
+static int check_batch(cpp_ddpg* d, cpp_batch* b, const char* who) {
+  ARG_CHECK(d && b, "%s: NULL argument", who);
+  ARG_CHECK(b->B >= 1 && b->B <= d->maxB, "%s: batch size %d outside [1,%d]", who, b->B, d->maxB);
+  ARG_CHECK(b->elems == d->actor->state_elems && b->A == d->actor->spec.action_dim, "%s: batch shape does not match the networks", who);
+  return CPP_OK;
+}
+
+static const float* white_of(cpp_batch* b, int which, int C) { return b->white + (long)which * 2 * C; }
+
+// critic "prefix": conv trunk + the fully connected layers in front of the action splice
+static int critic_prefix(cpp_net* c, const void* state, int dtype, const float* white, int B) {
+  RC(net_forward_trunk(c, c->ws[0], state, dtype, white, B));
+  if (c->cat_layer > 0) {
+    // run layers [0, cat) only
+    for (int l = 0; l < c->cat_layer; ++l) {
+      const FcL& L = c->fc[l];
+      RC(gemm(c->ctx, c->ws[0].fcin[l], L.n_in + 1, 1, c->params + L.w_off, L.n_out, 1, c->ws[0].fcin[l + 1],
+              c->fc[l + 1].n_in + 1, B, L.n_out, L.n_in + 1, L.act));
+    }
+  }
+  return CPP_OK;
+}
+
+// evaluate the critic head from the splice on, in workspace `wi`, with the given device action batch
+static int critic_head(cpp_net* c, int wi, const float* action, int B) {
+  const int cl = c->cat_layer, A = c->spec.action_dim;
+  if (wi == 1) {
+    const FcL& L = c->fc[cl];
+    RC(launch_copy_cols(c->ctx, c->ws[1].fcin[cl], L.n_in + 1, 0, c->ws[0].fcin[cl], L.n_in + 1, 0, L.n_in - A, B));
+  }
+  return net_forward_fc(c, c->ws[wi], cl, B, action);
+}
+
+// ddpg_cartpole.py:111-113 + :220-222.  critic_prefix_done: the critic prefix for batch.state_1 is
+// already in critic->ws[0] (fused step computes it once for both updates).
+static int actor_gradients(cpp_ddpg* d, cpp_batch* b, bool critic_prefix_done) {
+  cpp_net *a = d->actor, *c = d->critic;
+  const int B = b->B, C = a->spec.pixel ? a->spec.C : 0;
+  const float* w1 = white_of(b, 0, C);
+  RC(net_forward_trunk(a, a->ws[0], b->s[0], b->dtype, w1, B));
+  RC(net_forward_fc(a, a->ws[0], 0, B, nullptr));
+  if (!critic_prefix_done) RC(critic_prefix(c, b->s[0], b->dtype, w1, B));
+  RC(critic_head(c, 1, a->ws[0].out, B));
+  // d(sum_b Q)/da: dz of the linear q layer is 1
+  const int last = (int)c->fc.size() - 1;
+  RC(launch_copy_cols(d->ctx, c->ws[1].dz[last], 1, 0, d->ones, 1, 0, 1, B));
+  // walk back to the splice (hidden layers after the splice are ReLU)
+  for (int l = last; l > c->cat_layer; --l) {
+    const FcL& L = c->fc[l];
+    RC(gemm(d->ctx, c->ws[1].dz[l], L.n_out, 1, c->params + L.w_off, 1, L.n_out, c->ws[1].dz[l - 1], L.n_in, B, L.n_in,
+            L.n_out, GE_MUL_RELU_GRAD, c->ws[1].fcin[l], L.n_in + 1));
+  }
+  {
+    const FcL& L = c->fc[c->cat_layer];
+    const int A = c->spec.action_dim;
+    RC(gemm(d->ctx, c->ws[1].dz[c->cat_layer], L.n_out, 1, c->params + L.w_off + (long)(L.n_in - A) * L.n_out, 1, L.n_out,
+            d->dq_da, A, B, A, L.n_out, GE_NONE));
+  }
+  // grad_ys = -dQ/da through the tanh head, then the whole actor backward
+  const int alast = (int)a->fc.size() - 1;
+  RC(launch_actor_head_grad(d->ctx, a->ws[0].dz[alast], d->dq_da, a->ws[0].out, B * a->spec.action_dim));
+  RC(net_backward(a, a->ws[0], B, true, nullptr, b->s[0], b->dtype, w1));
+  return CPP_OK;
+}
+
+// ddpg_cartpole.py:199-214
+static int critic_gradients(cpp_ddpg* d, cpp_batch* b, bool critic_prefix_done, bool backward) {
+  cpp_net *c = d->critic, *ta = d->tactor, *tc = d->tcritic;
+  const int B = b->B, C = c->spec.pixel ? c->spec.C : 0;
+  const float *w1 = white_of(b, 0, C), *w2 = white_of(b, 1, C);
+  RC(net_forward_trunk(ta, ta->ws[0], b->s[1], b->dtype, w2, B));
+  RC(net_forward_fc(ta, ta->ws[0], 0, B, nullptr));
+  RC(critic_prefix(tc, b->s[1], b->dtype, w2, B));
+  RC(critic_head(tc, 0, ta->ws[0].out, B));
+  if (!critic_prefix_done) RC(critic_prefix(c, b->s[0], b->dtype, w1, B));
+  RC(critic_head(c, 0, b->a, B));
+  const int last = (int)c->fc.size() - 1;
+  RC(launch_td(d->ctx, c->ws[0].out, tc->ws[0].out, b->r, b->m, d->hp.discount, B, d->td,
+               backward ? c->ws[0].dz[last] : nullptr, d->loss_norms));
+  if (backward) RC(net_backward(c, c->ws[0], B, true, nullptr, b->s[0], b->dtype, w1));
+  return CPP_OK;
+}
+
+static int apply(cpp_ddpg* d, bool do_actor, bool do_critic, float grad_scale) {
+  Seg2 s;
+  s.p[0] = d->actor->params; s.g[0] = d->gradbuf; s.n[0] = do_actor ? d->nA : 0; s.lr[0] = d->hp.actor_learning_rate;
+  s.p[1] = d->critic->params; s.g[1] = d->gradbuf + d->nA; s.n[1] = do_critic ? d->nC : 0; s.lr[1] = d->hp.critic_learning_rate;
+  RC(launch_sumsq(d->ctx, s, grad_scale, d->norm_part, NORM_PARTS));
+  // norms_out is only written for lists that were applied (n > 0)
+  RC(launch_clip_sgd(d->ctx, s, grad_scale, d->hp.gradient_clip, d->norm_part, NORM_PARTS, d->loss_norms + 1));
+  return CPP_OK;
+}
+
+static int prep_batch(cpp_ddpg* d, cpp_batch* b) {
+  if (d->actor->spec.pixel) RC(batch_ensure_stats(b, d->actor->spec.C));
+  return CPP_OK;
+}
+
+extern "C" int cpp_ddpg_train_actor(cpp_ddpg* d, cpp_batch* b) {
+  RC(check_batch(d, b, "cpp_ddpg_train_actor"));
+  HIP_CHECK(hipSetDevice(d->ctx->device));
+  RC(prep_batch(d, b));
+  RC(actor_gradients(d, b, false));
+  RC(apply(d, true, false, 1.0f));
+  return CPP_OK;
+}
+
+extern "C" int cpp_ddpg_train_critic(cpp_ddpg* d, cpp_batch* b) {
+  RC(check_batch(d, b, "cpp_ddpg_train_critic"));
+  HIP_CHECK(hipSetDevice(d->ctx->device));
+  RC(prep_batch(d, b));
+  RC(critic_gradients(d, b, false, true));
+  RC(apply(d, false, true, 1.0f));
+  return CPP_OK;
+}
+
+extern "C" int cpp_ddpg_check_loss(cpp_ddpg* d, cpp_batch* b, float* loss, float* td, float* q) {
+  RC(check_batch(d, b, "cpp_ddpg_check_loss"));
+  HIP_CHECK(hipSetDevice(d->ctx->device));
+  RC(prep_batch(d, b));
+  RC(critic_gradients(d, b, false, false));
+  hipStream_t st = d->ctx->stream;
+  if (loss) HIP_CHECK(hipMemcpyAsync(loss, d->loss_norms, sizeof(float), hipMemcpyDeviceToHost, st));
+  if (td) HIP_CHECK(hipMemcpyAsync(td, d->td, (size_t)b->B * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (q) HIP_CHECK(hipMemcpyAsync(q, d->critic->ws[0].out, (size_t)b->B * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  return CPP_OK;
+}
+
+extern "C" int cpp_ddpg_q_gradients_wrt_actions(cpp_ddpg* d, cpp_batch* b, float* dq_da, float* actions, float* q) {
+  RC(check_batch(d, b, "cpp_ddpg_q_gradients_wrt_actions"));
+  HIP_CHECK(hipSetDevice(d->ctx->device));
+  RC(prep_batch(d, b));
+  RC(actor_gradients(d, b, false));
+  hipStream_t st = d->ctx->stream;
+  const int A = d->actor->spec.action_dim;
+  if (dq_da) HIP_CHECK(hipMemcpyAsync(dq_da, d->dq_da, (size_t)b->B * A * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (actions) HIP_CHECK(hipMemcpyAsync(actions, d->actor->ws[0].out, (size_t)b->B * A * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (q) HIP_CHECK(hipMemcpyAsync(q, d->critic->ws[1].out, (size_t)b->B * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  return CPP_OK;
+}
+
+static int compute_gradients(cpp_ddpg* d, cpp_batch* b) {
+  const int C = d->critic->spec.pixel ? d->critic->spec.C : 0;
+  RC(critic_prefix(d->critic, b->s[0], b->dtype, white_of(b, 0, C), b->B));    // shared by both updates
+  RC(actor_gradients(d, b, true));
+  RC(critic_gradients(d, b, true, true));
+  return CPP_OK;
+}
+
+extern "C" int cpp_ddpg_compute_gradients(cpp_ddpg* d, cpp_batch* b) {
+  RC(check_batch(d, b, "cpp_ddpg_compute_gradients"));
+  HIP_CHECK(hipSetDevice(d->ctx->device));
+  RC(prep_batch(d, b));
+  return compute_gradients(d, b);
+}
+
+extern "C" int cpp_ddpg_grad_buffer(cpp_ddpg* d, void** p, int64_t* n) {
+  ARG_CHECK(d && p && n, "cpp_ddpg_grad_buffer: NULL argument");
+  *p = d->gradbuf; *n = d->nA + d->nC;
+  return CPP_OK;
+}
+
+extern "C" int cpp_ddpg_apply_gradients(cpp_ddpg* d, float grad_scale) {
+  ARG_CHECK(d, "cpp_ddpg_apply_gradients: NULL argument");
+  HIP_CHECK(hipSetDevice(d->ctx->device));
+  return apply(d, true, true, grad_scale);
+}
+
+extern "C" int cpp_ddpg_update_targets(cpp_ddpg* d) {
+  ARG_CHECK(d, "cpp_ddpg_update_targets: NULL argument");
+  HIP_CHECK(hipSetDevice(d->ctx->device));
+  return launch_soft_update(d->ctx, d->tactor->params, d->actor->params, d->nA, d->tcritic->params, d->critic->params,
+                            d->nC, d->hp.target_update_rate);
+}
+
+static int step_body(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int32_t* rows_dev, uint64_t seed) {
+  const int C = d->actor->spec.pixel ? d->actor->spec.C : 0;
+  for (int i = 0; i < n_batches; ++i) {
+    RC(replay_sample_device(r, B, rows_dev ? rows_dev + (size_t)i * B : nullptr, seed, rows_dev ? nullptr : r->counter, C,
+                            d->step_batch));
+    if (!rows_dev) RC(launch_counter_add(d->ctx, r->counter, 1));
+    RC(compute_gradients(d, d->step_batch));
+    RC(apply(d, true, true, 1.0f));
+  }
+  return cpp_ddpg_update_targets(d);
+}
+
+extern "C" int cpp_ddpg_train_step(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int32_t* idxs, uint64_t seed) {
+  ARG_CHECK(d && r, "cpp_ddpg_train_step: NULL argument");
+  ARG_CHECK(B >= 1 && B <= d->maxB, "cpp_ddpg_train_step: batch %d outside [1,%d]", B, d->maxB);
+  ARG_CHECK(n_batches >= 1 && (size_t)n_batches * B <= 65536, "cpp_ddpg_train_step: n_batches %d", n_batches);
+  ARG_CHECK(r->elems == d->actor->state_elems && r->A == d->actor->spec.action_dim, "cpp_ddpg_train_step: replay shape does not match the networks");
+  if (r->size <= 0) { cpp_set_error("cpp_ddpg_train_step: replay memory is empty"); return CPP_ERR_STATE; }
+  cpp_ctx* ctx = d->ctx;
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (!d->step_batch) RC(cpp_batch_create(ctx, d->maxB, r->elems, r->A, &d->step_batch));
+  if (idxs) {
+    for (int i = 0; i < n_batches * B; ++i)
+      ARG_CHECK(idxs[i] >= 0 && idxs[i] < r->size, "cpp_ddpg_train_step: index %d outside [0,%d)", idxs[i], r->size);
+    HIP_CHECK(hipMemcpyAsync(r->rows_in, idxs, (size_t)n_batches * B * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    return step_body(d, r, B, n_batches, r->rows_in, seed);
+  }
+  if (ctx->prof) return step_body(d, r, B, n_batches, nullptr, seed);
+  if (!d->graph_ok || d->g_B != B || d->g_nb != n_batches || d->g_seed != seed || d->g_replay != r) {
+    if (d->gexec) { (void)hipGraphExecDestroy(d->gexec); d->gexec = nullptr; }
+    if (d->graph) { (void)hipGraphDestroy(d->graph); d->graph = nullptr; }
+    d->graph_ok = false;
+    // one eager pass first: it sets every kernel's LDS attribute (not allowed during capture)
+    RC(step_body(d, r, B, n_batches, nullptr, seed));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    int rc = step_body(d, r, B, n_batches, nullptr, seed);
+    hipError_t e = hipStreamEndCapture(ctx->stream, &d->graph);
+    if (rc) return rc;
+    if (e != hipSuccess) { cpp_set_error("hipStreamEndCapture -> %s", hipGetErrorString(e)); return CPP_ERR_HIP; }
+    HIP_CHECK(hipGraphInstantiate(&d->gexec, d->graph, nullptr, nullptr, 0));
+    d->graph_ok = true; d->g_B = B; d->g_nb = n_batches; d->g_seed = seed; d->g_replay = r;
+    return CPP_OK;   // the eager pass above was this call's step
+  }
+  HIP_CHECK(hipGraphLaunch(d->gexec, ctx->stream));
+  return CPP_OK;
+}
+
+extern "C" int cpp_ddpg_last_stats(cpp_ddpg* d, float out[3]) {
+  ARG_CHECK(d && out, "cpp_ddpg_last_stats: NULL argument");
+  HIP_CHECK(hipMemcpyAsync(out, d->loss_norms, 3 * sizeof(float), hipMemcpyDeviceToHost, d->ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(d->ctx->stream));
+  return CPP_OK;
+}

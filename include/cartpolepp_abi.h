@@ -1,0 +1,185 @@
+/*
+ * cartpolepp_abi.h -- C ABI of libcartpolepp_hip.so (MI355X / gfx950).
+ *
+ * The reference (matpalm/cartpoleplusplus, /root/reference) has no FFI boundary of its own: its
+ * DDPG-from-pixels hot path sits behind plain Python classes that call TensorFlow.  This header is
+ * the boundary inserted directly beneath those classes; every entry point cites the reference
+ * interface it replaces (paths relative to /root/reference).  Plain pointers and sizes only: no
+ * torch types, no Python objects, no C++ exceptions cross.  INTEGRATION.md shows the ctypes stubs a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns CPP_OK (0) or a CPP_ERR_* code; cpp_last_error() gives the message
+ *     (thread-local).  Python wrappers raise RuntimeError(cpp_last_error()).
+ *   - the library owns all device memory behind opaque handles; every *_create has a *_destroy.
+ *   - host pointers are read/written only for the duration of the call.
+ *   - a cpp_ctx is one GPU + one HIP stream; calls on one ctx are serialised by the caller
+ *     (the reference is single-threaded: one implicit tf.Session).
+ *   - all arithmetic is IEEE f32 (f32-input MFMA); replay states are stored as f16 exactly like
+ *     replay_memory.py:32; indices are int32.
+ *   - flat parameter order = TF variable creation order "<scope>/weights", "<scope>/biases":
+ *     conv1, conv2, conv3, then the fully connected layers.
+ */
+#ifndef CARTPOLEPP_ABI_H
+#define CARTPOLEPP_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPP_ABI_VERSION 1
+
+enum { CPP_OK = 0, CPP_ERR_ARG = 1, CPP_ERR_HIP = 2, CPP_ERR_STATE = 3, CPP_ERR_NUMERIC = 4 };
+enum { CPP_F32 = 0, CPP_F16 = 1 };          /* host/device element type of state payloads        */
+enum { CPP_ACTOR = 0, CPP_CRITIC = 1 };     /* ddpg_cartpole.py:78 ActorNetwork / :148 CriticNetwork */
+
+typedef struct cpp_ctx cpp_ctx;
+typedef struct cpp_net cpp_net;
+typedef struct cpp_batch cpp_batch;
+typedef struct cpp_replay cpp_replay;
+typedef struct cpp_ddpg cpp_ddpg;
+
+/* ---- library / context ------------------------------------------------------------------- */
+int cpp_abi_version(void);
+const char* cpp_last_error(void);
+
+/* One GPU + one stream.  `hip_stream` may be NULL (library creates its own non-blocking stream) or
+ * an existing hipStream_t (e.g. torch.cuda.Stream().cuda_stream) so that host-side RCCL collectives
+ * issued through torch.distributed are ordered with the kernels.  Replaces the implicit default
+ * tf.Session of ddpg_cartpole.py:416. */
+int cpp_ctx_create(int device_id, void* hip_stream, cpp_ctx** out);
+int cpp_ctx_destroy(cpp_ctx* ctx);
+int cpp_sync(cpp_ctx* ctx);
+
+/* HIP-event stopwatch on the ctx stream (bench.py; the reference only has util.StopWatch, util.py:22). */
+int cpp_timer_begin(cpp_ctx* ctx);
+int cpp_timer_end(cpp_ctx* ctx, float* elapsed_ms);
+
+/* Per-kernel HIP-event profile of the launches issued on this ctx (disables graph replay while on).
+ * kernel ids: see cpp_prof_kernel_name(). */
+int cpp_prof_enable(cpp_ctx* ctx, int on);
+int cpp_prof_reset(cpp_ctx* ctx);
+int cpp_prof_num_kernels(void);
+const char* cpp_prof_kernel_name(int kernel_id);
+int cpp_prof_read(cpp_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);
+
+/* ---- networks (base_network.py:13-134, ddpg_cartpole.py:78-100, :148-184) ------------------- */
+typedef struct cpp_net_spec {
+  int32_t kind;          /* CPP_ACTOR / CPP_CRITIC                                              */
+  int32_t pixel;         /* opts.use_raw_pixels: conv trunk (base_network.py:73-127) in front    */
+  int32_t H, W, C;       /* pixel: image dims, C = 3*num_cameras*action_repeats (:85-90)         */
+  int32_t state_elems;   /* low-dim: flattened state length (repeats*2*7, bullet_cartpole.py:125) */
+  int32_t action_dim;
+  int32_t n_hidden;      /* actor: opts.actor_hidden_layers; low-dim critic: critic_hidden_layers */
+  int32_t hidden[8];     /* (pixel critic is the fixed 200/50/+action/50 head of :168-171)       */
+} cpp_net_spec;
+
+int cpp_net_create(cpp_ctx* ctx, const cpp_net_spec* spec, int max_batch, cpp_net** out);
+int cpp_net_destroy(cpp_net* net);
+/* Network.trainable_model_vars (base_network.py:51-56): variables in creation order. */
+int64_t cpp_net_num_params(const cpp_net* net);
+int cpp_net_num_vars(const cpp_net* net);
+int cpp_net_var_info(const cpp_net* net, int i, char* name, int name_cap, int* rank,
+                     int shape[4], int64_t* offset);
+/* variable init / checkpoint restore / SIGUSR2 weight dump (ddpg_cartpole.py:421-427, :402-409) */
+int cpp_net_set_params(cpp_net* net, const float* host, int64_t n);
+int cpp_net_get_params(cpp_net* net, float* host, int64_t n);
+int cpp_net_get_grads(cpp_net* net, float* host, int64_t n);   /* pre-clip gradients of last train */
+/* Network._create_variables_copy_op (base_network.py:20-33): target -= coeff * (target - source). */
+int cpp_net_soft_update(cpp_net* target, const cpp_net* source, float coeff);
+/* session.run(output_action | q_value) on a fed state batch (ddpg_cartpole.py:123-125).  `state` is
+ * a host array (B, state_elems) of `state_dtype`; `action` (B, action_dim) host f32, critics only.
+ * Whitening always uses the statistics of THIS batch (base_network.py:95-99), also at B = 1. */
+int cpp_net_forward(cpp_net* net, const void* state, int state_dtype, int B, const float* action,
+                    float* out);
+/* Network.pool1/2/3 (base_network.py:108,116,124) of the last forward: which = 1..3, (B,h,w,10). */
+int cpp_net_get_pool(cpp_net* net, int which, int B, float* out);
+
+/* ---- minibatch resident in HBM (replay_memory.py:9 Batch) ----------------------------------- */
+int cpp_batch_create(cpp_ctx* ctx, int max_batch, int64_t state_elems, int action_dim, cpp_batch** out);
+int cpp_batch_destroy(cpp_batch* batch);
+/* feed_dict of ddpg_cartpole.py:231-237: host Batch -> device. */
+int cpp_batch_upload(cpp_batch* batch, int B, const void* state_1, const void* state_2,
+                     int state_dtype, const float* action, const float* reward,
+                     const float* terminal_mask);
+/* np.copy(...) columns of replay_memory.py:134-138: device -> caller-owned host arrays.  States come
+ * back in the batch's stored dtype (f16 after cpp_replay_sample). */
+int cpp_batch_download(cpp_batch* batch, void* state_1, void* state_2, float* action,
+                       float* reward, float* terminal_mask);
+int cpp_batch_size(const cpp_batch* batch);
+int cpp_batch_state_dtype(const cpp_batch* batch);
+
+/* ---- replay memory payload in HBM (replay_memory.py:11-138) --------------------------------- */
+/* Slot allocation / eviction (replay_memory.py:66,84,90,104) stays on the host so the FIFO order is
+ * exact; the device holds the f16 state store and mirrors of the five event columns. */
+int cpp_replay_create(cpp_ctx* ctx, int buffer_size, int state_slots, int64_t state_elems,
+                      int action_dim, cpp_replay** out);
+int cpp_replay_destroy(cpp_replay* replay);
+/* self.state[idx] = s (replay_memory.py:67,106): n states, f32 is rounded to f16 (RNE) like numpy. */
+int cpp_replay_write_states(cpp_replay* replay, const int32_t* slots, int n, const void* states,
+                            int state_dtype);
+/* rows of the five event columns (replay_memory.py:94-101,105). */
+int cpp_replay_write_rows(cpp_replay* replay, const int32_t* rows, int n, const int32_t* state_1_idx,
+                          const int32_t* state_2_idx, const float* action, const float* reward,
+                          const float* terminal_mask);
+int cpp_replay_set_size(cpp_replay* replay, int size);          /* ReplayMemory.size(), :120 */
+int cpp_replay_read_states(cpp_replay* replay, const int32_t* slots, int n, void* out_f16);
+/* random_indexes + batch (replay_memory.py:123-138) fused: idxs == NULL draws B uniform rows on the
+ * device with Philox4x32-10 keyed (seed, counter); otherwise uses the caller's rows (parity tests,
+ * numpy-RNG-driven callers).  Also produces the per-channel whitening statistics of both state
+ * batches for pixel states of `channels` interleaved channels (channels = 0: none). */
+int cpp_replay_sample(cpp_replay* replay, int B, const int32_t* idxs, uint64_t seed, uint64_t counter,
+                      int channels, cpp_batch* out);
+int cpp_replay_last_indexes(cpp_replay* replay, int B, int32_t* out);   /* rows drawn by last sample */
+/* bench/test helper: fill n_rows transitions on the device (SURVEY 8d synthetic inputs):
+ * states f16(k/255), k~U{0..255}; a~U(-1,1); reward 1; terminal w.p. 1/50; s2 = s1 slot + 1. */
+int cpp_replay_fill_synthetic(cpp_replay* replay, int n_rows, uint64_t seed);
+
+/* ---- DDPG train ops (ddpg_cartpole.py:102-119, :186-248, :329-337) --------------------------- */
+typedef struct cpp_ddpg_hyper {
+  float actor_learning_rate;     /* --actor-learning-rate  (ddpg_cartpole.py:41)  */
+  float critic_learning_rate;    /* --critic-learning-rate (:42)                  */
+  float discount;                /* --discount             (:43)                  */
+  float gradient_clip;           /* --gradient-clip, util.py:11; <= 0 disables    */
+  float target_update_rate;      /* --target-update-rate   (:35)                  */
+} cpp_ddpg_hyper;
+
+int cpp_ddpg_create(cpp_ctx* ctx, cpp_net* actor, cpp_net* critic, cpp_net* target_actor,
+                    cpp_net* target_critic, const cpp_ddpg_hyper* hyper, cpp_ddpg** out);
+int cpp_ddpg_destroy(cpp_ddpg* ddpg);
+/* ActorNetwork.train(state) (ddpg_cartpole.py:140-145): uses batch.state_1 only. */
+int cpp_ddpg_train_actor(cpp_ddpg* ddpg, cpp_batch* batch);
+/* CriticNetwork.train(batch) (:230-237). */
+int cpp_ddpg_train_critic(cpp_ddpg* ddpg, cpp_batch* batch);
+/* CriticNetwork.check_loss(batch) (:239-248): loss scalar, td (B), q (B). */
+int cpp_ddpg_check_loss(cpp_ddpg* ddpg, cpp_batch* batch, float* loss, float* td, float* q);
+/* CriticNetwork.q_gradients_wrt_actions() evaluated at a = actor(state_1) (:220-222): (B, A);
+ * also returns the actions and q-values of that evaluation when the pointers are non-NULL. */
+int cpp_ddpg_q_gradients_wrt_actions(cpp_ddpg* ddpg, cpp_batch* batch, float* dq_da, float* actions,
+                                     float* q);
+/* Fused form of one loop body of :331-334.  Both gradient sets are taken from the same parameter
+ * snapshot (the critic step never reads the live actor, the actor step never writes the critic) and
+ * land in ONE flat f32 buffer [actor grads | critic grads] that a data-parallel host all-reduces
+ * (RCCL) between the two calls. */
+int cpp_ddpg_compute_gradients(cpp_ddpg* ddpg, cpp_batch* batch);
+int cpp_ddpg_grad_buffer(cpp_ddpg* ddpg, void** device_ptr, int64_t* n_floats);
+/* clip_by_global_norm per list (util.py:47-50) + SGD (ddpg_cartpole.py:118-119,213,218).  The
+ * gradients are first multiplied by grad_scale (1/world_size after a sum all-reduce). */
+int cpp_ddpg_apply_gradients(cpp_ddpg* ddpg, float grad_scale);
+/* target_actor.update_weights(); target_critic.update_weights() (:336-337). */
+int cpp_ddpg_update_targets(cpp_ddpg* ddpg);
+/* The whole inner step :331-337 on device-resident replay: n_batches x {sample B, both updates},
+ * then the target updates.  idxs: NULL (device Philox, counter advances by one per minibatch) or
+ * n_batches*B caller-chosen rows.  Captured into a hipGraph after the first call per (B, n_batches)
+ * when idxs == NULL and profiling is off. */
+int cpp_ddpg_train_step(cpp_ddpg* ddpg, cpp_replay* replay, int B, int n_batches,
+                        const int32_t* idxs, uint64_t seed);
+/* scalars of the last minibatch: [0] td loss, [1] actor grad norm, [2] critic grad norm (pre-clip). */
+int cpp_ddpg_last_stats(cpp_ddpg* ddpg, float out[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CARTPOLEPP_ABI_H */

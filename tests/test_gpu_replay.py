@@ -1,0 +1,112 @@
+"""GPU tests of the device-resident replay memory against the reference's own known answers
+(replay_memory_test.py, values typed in as data) and against the oracle replay.  Bit-exact."""
+import numpy as np
+import pytest
+
+from oracle.replay_np import OracleReplayMemory
+from tests.test_oracle_replay import s_for, soak
+
+pytestmark = pytest.mark.gpu
+
+
+def make(**kw):
+    from cartpoleplusplus_amd.replay_memory import ReplayMemory
+    args = dict(buffer_size=3, state_shape=(2, 3), action_dim=2, load_factor=2)
+    args.update(kw)
+    return ReplayMemory(**args)
+
+
+def test_empty_memory():            # replay_memory_test.py:19-30
+    rm = make()
+    assert rm.size() == 0
+    assert list(rm.random_indexes()) == []
+    b = rm.batch(4)
+    assert len(b) == 5
+    for i in range(5):
+        assert len(b[i]) == 0
+    assert rm.insert == 0 and rm.full is False
+    rm.close()
+
+
+def test_adds_to_full():            # replay_memory_test.py:32-56
+    rm = make()
+    rm.add_episode([[11, 12, 13], [14, 15, 16]],
+                   [(17, 18, [[21, 22, 23], [24, 25, 26]]),
+                    (27, 28, [[31, 32, 33], [34, 35, 36]]),
+                    (37, 38, [[41, 42, 43], [44, 45, 46]])])
+    assert rm.size() == 3
+    idxs = rm.random_indexes(n=100)
+    assert len(idxs) == 100 and sorted(set(idxs)) == [0, 1, 2]
+    assert rm.insert == 0 and rm.full is True
+    for slot, first in enumerate([11, 21, 31, 41]):
+        assert rm.state[slot][0][0] == first
+    rm.close()
+
+
+def test_adds_over_full():          # replay_memory_test.py:58-86
+    rm = make()
+    rm.add_episode(s_for(0), [((i * 10) + 7, (i * 10) + 8, s_for(i)) for i in range(1, 5)])
+    rm.add_episode(s_for(5), [((i * 10) + 7, (i * 10) + 8, s_for(i)) for i in range(6, 9)])
+    assert rm.size() == 3
+    assert sorted(set(rm.random_indexes(n=100))) == [0, 1, 2]
+    b = rm.batch(idxs=[0, 1, 2])
+    assert np.array_equal(b.reward, [[88], [68], [78]])
+    assert np.array_equal(b.terminal_mask, [[0], [1], [1]])
+    assert np.array_equal(b.state_1[:, 0, 0], [71, 51, 61]) and np.array_equal(b.state_2[:, 0, 0], [81, 61, 71])
+    rm.close()
+
+
+def test_soak_invariant():          # replay_memory.py:166-200
+    from cartpoleplusplus_amd.replay_memory import ReplayMemory
+    np.random.seed(3)
+    rm = soak(ReplayMemory, 120)
+    assert rm.current_stats()[">add_episode"] == 120
+    rm.close()
+
+
+def test_gather_and_statistics_match_oracle_bitwise():
+    from cartpoleplusplus_amd.replay_memory import ReplayMemory
+    shape = (16, 16, 3, 2, 3)
+    rng = np.random.default_rng(4)
+    rm, orm = ReplayMemory(40, shape, 2), OracleReplayMemory(40, shape, 2)
+    for _ in range(14):
+        n = int(rng.integers(1, 8))
+        mk = lambda: rng.uniform(0, 1, shape).astype(np.float32)       # f32 in: cast to f16 on store (RNE)
+        s0, seq = mk(), [(rng.uniform(-1, 1, (1, 2)), float(rng.integers(0, 9)), mk()) for _ in range(n)]
+        rm.add_episode(s0, seq); orm.add_episode(s0, seq)
+    assert np.array_equal(rm.state_1_idx, orm.state_1_idx) and np.array_equal(rm.state_2_idx, orm.state_2_idx)
+    assert list(rm.state_free_slots) == list(orm.state_free_slots)
+    idxs = rng.integers(0, 40, 33)
+    got, want = rm.batch(idxs=idxs), orm.batch(idxs=idxs)
+    for g, w in zip(got, want):
+        assert g.dtype == w.dtype and np.array_equal(g, w)
+    assert np.array_equal(got.state_1_idx, orm.state_1_idx[idxs])
+    rm.close()
+
+
+def _philox4x32_10(ctr, key):
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    c, k = list(ctr), list(key)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k[0]) & 0xFFFFFFFF, p1 & 0xFFFFFFFF,
+             ((p0 >> 32) ^ c[3] ^ k[1]) & 0xFFFFFFFF, p0 & 0xFFFFFFFF]
+        k = [(k[0] + W0) & 0xFFFFFFFF, (k[1] + W1) & 0xFFFFFFFF]
+    return c
+
+
+def test_device_philox_rows_are_the_published_philox_and_uniform():
+    from cartpoleplusplus_amd.replay_memory import ReplayMemory
+    rm = ReplayMemory(1000, (4, 2), 2)
+    rm.fill_synthetic(777, seed=5)
+    B, seed, counter = 256, 0x1234567890, 42
+    b = rm.sample_on_device(B, seed=seed, counter=counter)
+    want = [(_philox4x32_10([i, 0, counter & 0xFFFFFFFF, counter >> 32],
+                            [seed & 0xFFFFFFFF, seed >> 32])[0] * 777) >> 32 for i in range(B)]
+    assert np.array_equal(b.idxs, want)
+    assert b.idxs.min() >= 0 and b.idxs.max() < 777 and len(set(b.idxs.tolist())) > 150
+    # the gathered rows are the rows of those indexes
+    assert np.array_equal(b.reward, rm.reward[b.idxs]) and np.array_equal(b.terminal_mask, rm.terminal_mask[b.idxs])
+    s1 = rm.state[rm.state_1_idx[b.idxs]]
+    assert np.array_equal(b.state_1, s1)
+    rm.close()
