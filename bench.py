@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""Headline benchmark: DDPG training steps/sec on synthetic 64x64x18 pixel minibatches, batch 256
+(BASELINE.json metric).  One process per GPU; N > 1 is launched by torch.distributed.run.
+
+A "step" is one minibatch update of the hot path: fused sample + gather of B transitions from the
+HBM-resident replay memory, actor update, critic update (4 conv-trunk forwards, 2 backwards), global-norm
+clip + SGD for both nets, with both target soft updates after every 5th minibatch
+(ddpg_cartpole.py:331-337).  Inputs are resident in HBM when the timed region starts.
+
+Prints ONE JSON line (rank 0).  Besides the contract keys it carries
+  roofline     : the dominant kernel (conv1 forward) against the dense f32-MFMA peak, launch durations
+                 measured with HIP events on the stream the kernel runs on (a profiled pass of the same
+                 step sequence, run right after the timed region; the timed region itself is one hipGraph
+                 replay per 5 minibatches and cannot carry per-kernel events)
+  cpu_baseline : the oracle (numpy f32 restatement, BLAS-threaded) timed on this host on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (state_shape (H, W, 3, cameras, repeats), batch)
+    "cfg3": ((64, 64, 3, 2, 3), 256),    # 64x64x18, B=256 -- the configuration the metric is quoted on
+    "cfg2": ((64, 64, 3, 1, 3), 256),    # 64x64x9
+}
+BATCHES_PER_STEP = 5                     # --batches-per-step default (ddpg_cartpole.py:30)
+REPLAY_ROWS = 22000                      # --replay-memory-size default (ddpg_cartpole.py:46)
+PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: dense f32-input MFMA peak
+CONV_DEFS = ((5, 10), (5, 10), (3, 10))
+
+
+def conv_macs(shape):
+    """per-image forward MACs F and backward MACs Bk of the trunk (bwd = conv1 dW +
+    conv2/3 dW + dX), unpadded."""
+    H, W, cin = shape[0], shape[1], int(np.prod(shape[2:]))
+    per_layer = []
+    for k, cout in CONV_DEFS:
+        per_layer.append(H * W * k * k * cin * cout)
+        cin, H, W = cout, H // 2, W // 2
+    F = sum(per_layer)
+    Bk = per_layer[0] + 2 * sum(per_layer[1:])
+    return F, Bk, per_layer
+
+
+def cpu_baseline(shape, B, sample_B=64):
+    """one minibatch update of the oracle (f32) on a bounded sample: sample_B of the B rows."""
+    from oracle import ddpg_np as O          # checker / baseline only
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([d.get("num_threads", 1) for d in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    rng = np.random.default_rng(0)
+    kw = dict(pixel=True, H=shape[0], W=shape[1], C=int(np.prod(shape[2:])))
+    aspec, cspec = O.NetSpec("actor", 2, [100, 100, 50], **kw), O.NetSpec("critic", 2, [], **kw)
+    agent = O.DDPG(aspec, cspec, O.init_params(aspec, rng), O.init_params(cspec, rng), np.float32)
+    batch = O.synthetic_batch(rng, sample_B, shape, 2, True)
+    t0 = time.time()
+    agent.train_minibatch(batch)
+    dt = time.time() - t0
+    steps_per_sec = (sample_B / float(B)) / dt
+    return {"value": steps_per_sec, "unit": "steps/s", "cores": int(threads), "kind": "port",
+            "sample": "1 minibatch update of oracle/ddpg_np.py (numpy f32, OpenBLAS threads=%d) on %d of the "
+                      "%d rows of the workload batch, %.1f s; scaled by %d/%d"
+                      % (threads, sample_B, B, dt, sample_B, B)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=10, help="minibatches of the per-kernel HIP-event pass")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+    shape, B = WORKLOADS[args.workload]
+
+    import torch
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from cartpoleplusplus_amd import _lib, ddpg_cartpole as D
+    from cartpoleplusplus_amd.distributed import GradAllReducer, DataParallelLearner, AgentOps
+
+    stream = torch.cuda.Stream(device=local_rank)
+    ctx = _lib.Context(local_rank, stream=stream.cuda_stream)
+    _lib.set_default_context(ctx)
+
+    class Env(object):
+        class S(object):
+            def __init__(self, s): self.shape = tuple(s)
+        observation_space, action_space = S(shape), S((1, 2))
+
+    D.set_opts(D.default_opts(use_raw_pixels=True, render_height=shape[0], render_width=shape[1],
+                              num_cameras=shape[3], action_repeats=shape[4], batch_size=B,
+                              replay_memory_size=REPLAY_ROWS, sample_seed=1234 + rank))
+    agent = D.DeepDeterministicPolicyGradientAgent(Env())
+    agent.initialise_variables(seed=42)                 # identical replicas on every rank
+    agent.post_var_init_setup()
+    agent.replay_memory.fill_synthetic(REPLAY_ROWS, seed=1234 + rank)   # own replay shard per learner
+
+    groups, tail = divmod(args.steps, BATCHES_PER_STEP)
+    wgroups = max(1, -(-args.warmup // BATCHES_PER_STEP))
+
+    if world == 1:
+        def run(g, t):
+            for _ in range(g):
+                agent.train_step(B, BATCHES_PER_STEP)
+            if t:
+                agent.train_step(B, t)
+    else:
+        learner = DataParallelLearner(AgentOps(agent, B, 1234 + rank),
+                                      GradAllReducer.for_trainer(agent.trainer, stream))
+
+        def run(g, t):
+            for _ in range(g):
+                learner.train_step(BATCHES_PER_STEP)
+            if t:
+                learner.train_step(t)
+
+    def full_sync():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    # warm-up (also captures the hipGraphs for both call shapes)
+    run(wgroups, tail)
+    run(1, tail)
+    full_sync()
+    t0 = time.perf_counter()
+    run(groups, tail)
+    full_sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % local_rank)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    steps = groups * BATCHES_PER_STEP + tail
+    ms_per_step = 1e3 * elapsed / steps
+    value = world * steps / elapsed
+
+    # ---- per-kernel HIP-event pass (rank 0 reports) -> roofline of the dominant kernel
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    pgroups = max(1, args.profile_steps // BATCHES_PER_STEP)
+    for _ in range(pgroups):
+        agent.train_step(B, BATCHES_PER_STEP)
+    ctx.sync()
+    ctx.prof_enable(False)
+    prof = ctx.prof_read()
+    pm = pgroups * BATCHES_PER_STEP
+
+    F, Bk, per_layer = conv_macs(shape)
+    conv_flops_step = 2.0 * B * (4 * F + 2 * Bk)
+    c1_ms, c1_n = prof.get("conv1_fwd", (0.0, 0))
+    flops_per_launch = 2.0 * B * per_layer[0]             # one network's conv1 forward over the minibatch
+    avg_ms = c1_ms / max(c1_n, 1)
+    achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    kernels = {k: {"ms_per_step": round(v[0] / pm, 4), "launches_per_step": round(v[1] / pm, 2)}
+               for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+
+    out = {
+        "metric": "DDPG training steps/sec, 64x64x18 pixel obs, batch=256",
+        "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": wgroups * BATCHES_PER_STEP,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: DDPG pixel obs %dx%dx%d, batch=%d per GPU, replay %d rows/GPU in HBM (f16), "
+                               "target soft-update every %d minibatches" % (
+                                   args.workload, shape[0], shape[1], int(np.prod(shape[2:])), B, REPLAY_ROWS,
+                                   BATCHES_PER_STEP),
+                   "parallelism": "dp%d (one learner per GPU, flat-gradient all-reduce per minibatch)" % world,
+                   "global_steps_per_sec": round(steps / elapsed, 3),
+                   "conv_gflop_per_step": round(conv_flops_step / 1e9, 3),
+                   "conv_roofline_frac_whole_step": round(conv_flops_step * steps / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+        "roofline": {"bound": "mfma", "kernel": "conv1_fwd", "achieved": round(achieved, 3),
+                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                     "traffic": None, "flops_per_launch": flops_per_launch, "avg_launch_ms": round(avg_ms, 5),
+                     "launches": int(c1_n)},
+        "kernels": kernels,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(shape, B)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    agent.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -85,6 +85,7 @@ SIGNATURES = {
     "cpp_ddpg_apply_gradients": (_I, [_P, _F]),
     "cpp_ddpg_update_targets": (_I, [_P]),
     "cpp_ddpg_train_step": (_I, [_P, _P, _I, _I, _P, _U64]),
+    "cpp_ddpg_sample_and_compute": (_I, [_P, _P, _I, _U64]),
     "cpp_ddpg_last_stats": (_I, [_P, _P]),
 }
 

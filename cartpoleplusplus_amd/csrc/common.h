@@ -60,6 +60,7 @@ struct ConvArgs {
   int cin_rt;                // runtime copy of CIN (checked against the template)
   int nout;                  // valid output channels of this kernel (<= 16)
   int tiles_x, tiles_y, ntiles;
+  int vec_ok;                // input rows may be staged with aligned 16-byte loads
 };
 
 int launch_conv_fwd(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi, ConvArgs a);

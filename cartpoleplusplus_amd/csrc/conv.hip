@@ -6,6 +6,13 @@ static int pick_xtw(int in_mode, int W) {
   return W > 32 ? 4 : (W > 16 ? 2 : 1);
 }
 
+// aligned 16-byte row staging needs 16-byte aligned image bases
+static int vec_ok_for(const ConvArgs& a, int in_mode) {
+  if (in_mode == IN_DY) return 0;
+  const long esz = in_mode == IN_F16_WHITEN ? 2 : 4;
+  return (((uintptr_t)a.in) % 16 == 0) && ((a.in_bstride * esz) % 16 == 0);
+}
+
 static void set_tiles(ConvArgs& a, int xtw) {
   a.tiles_x = (a.W + 16 * xtw - 1) / (16 * xtw);
   a.tiles_y = (a.H + CONV_TH - 1) / CONV_TH;
@@ -16,6 +23,7 @@ int launch_conv_fwd(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi
   const int xtw = pick_xtw(in_mode, a.W);
   set_tiles(a, xtw);
   a.cin_rt = cin;
+  a.vec_ok = vec_ok_for(a, in_mode);
   if (a.nout > CPP_NOUT_MAX) { cpp_set_error("conv: nout %d > 16", a.nout); return 1; }
   prof_begin(ctx);
   int rc;
@@ -36,6 +44,7 @@ int launch_conv_dw(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, ConvArgs
   const int xtw = pick_xtw(in_mode, a.W);
   set_tiles(a, xtw);
   a.cin_rt = cin;
+  a.vec_ok = vec_ok_for(a, in_mode);
   const int nw = ks * ks * cin * a.nout;
   a.pstride = nw + a.nout;
   int grid = 0, rc;

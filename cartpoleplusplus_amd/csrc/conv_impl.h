@@ -81,6 +81,104 @@ __device__ __forceinline__ void conv_stage_tile(float* lds, const ConvArgs& a, i
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Vectorised, register-prefetched tile staging (f16 / f32 NHWC images or activations).
+// A tile row [x0-P, x0-P+TC) x CIN is contiguous in memory AND in the LDS image, so a row is staged
+// as aligned 16-byte chunks (8 halfs / 4 floats) with a per-element range test; the chunks of the NEXT
+// tile are loaded into registers before the MFMA phase of the current one and only converted /
+// whitened / written to LDS afterwards (issue-early / write-late), so HBM latency hides under compute.
+// Positions outside the image are zero-filled by a separate pass (zero padding lives in whitened
+// space, base_network.py:97-99).
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct ChunkOps;
+template <> struct ChunkOps<__half> {
+  static constexpr int EPC = 8;
+  static __device__ __forceinline__ float get(const uint4& v, int k) {
+    const uint32_t w = k < 2 ? v.x : (k < 4 ? v.y : (k < 6 ? v.z : v.w));
+    return __half2float(__ushort_as_half((unsigned short)((k & 1) ? (w >> 16) : (w & 0xffffu))));
+  }
+};
+template <> struct ChunkOps<float> {
+  static constexpr int EPC = 4;
+  static __device__ __forceinline__ float get(const uint4& v, int k) {
+    return __uint_as_float(k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)));
+  }
+};
+
+template <int CIN, int KS, int XTW, typename T, bool WHITEN>
+struct RowStager {
+  static constexpr int P = KS / 2, TR = CONV_TH + KS - 1, TC = 16 * XTW + KS - 1;
+  static constexpr int EPC = ChunkOps<T>::EPC;
+  static constexpr int CH = (TC * CIN + EPC - 1) / EPC + 1;    // chunks per tile row incl. alignment slack
+  static constexpr int NCH = TR * CH;
+  static constexpr int NV = (NCH + CONV_THREADS - 1) / CONV_THREADS;
+  uint4 v[NV];
+
+  // geometry of chunk `ch` of the tile at (y0, x0): returns false when the chunk holds nothing
+  static __device__ __forceinline__ bool geom(const ConvArgs& a, int ch, int y0, int x0, int& r,
+                                              int& a0, int& rowstart, int& rowend, int& gxs) {
+    r = ch / CH;
+    const int j = ch - r * CH;
+    const int gy = y0 - P + r;
+    if (ch >= NCH || gy < 0 || gy >= a.H) return false;
+    gxs = max(x0 - P, 0);
+    const int gxe = min(x0 - P + TC, a.W);
+    rowstart = (gy * a.W + gxs) * CIN;
+    rowend = (gy * a.W + gxe) * CIN;
+    a0 = (rowstart & ~(EPC - 1)) + j * EPC;
+    return a0 < rowend;
+  }
+
+  __device__ __forceinline__ void load(const ConvArgs& a, int b, int y0, int x0, int tid) {
+    const T* img = (const T*)a.in + (long)b * a.in_bstride;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int r, a0, rs, re, gxs;
+      v[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (geom(a, tid + CONV_THREADS * i, y0, x0, r, a0, rs, re, gxs))
+        v[i] = *reinterpret_cast<const uint4*>(img + a0);
+    }
+  }
+
+  __device__ __forceinline__ void store(float* lds, const float2* wl, const ConvArgs& a, int y0, int x0,
+                                        int tid) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int r, a0, rs, re, gxs;
+      if (geom(a, tid + CONV_THREADS * i, y0, x0, r, a0, rs, re, gxs)) {
+        const int lbase = r * TC * CIN + (gxs - (x0 - P)) * CIN - rs;    // lds index = lbase + e
+        int c = a0 % CIN;
+#pragma unroll
+        for (int k = 0; k < EPC; ++k) {
+          const int e = a0 + k;
+          if (e >= rs && e < re) {
+            float x = ChunkOps<T>::get(v[i], k);
+            if (WHITEN) { const float2 w = wl[c]; x = x * w.x + w.y; }
+            lds[lbase + e] = x;
+          }
+          c = (c + 1 == CIN) ? 0 : c + 1;
+        }
+      }
+    }
+  }
+
+  // zero every tile position that lies outside the image
+  static __device__ __forceinline__ void zero_halo(float* lds, const ConvArgs& a, int y0, int x0, int tid) {
+    for (int p = tid; p < TR * TC; p += CONV_THREADS) {
+      const int r = p / TC, col = p - r * TC;
+      const int gy = y0 - P + r, gx = x0 - P + col;
+      if (gy < 0 || gy >= a.H || gx < 0 || gx >= a.W) {
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) lds[p * CIN + c] = 0.f;
+      }
+    }
+  }
+};
+
+template <int IN_MODE> struct StageType { typedef float type; };
+template <> struct StageType<IN_F16_WHITEN> { typedef __half type; };
+
 // ---------------------------------------------------------------------------------------------
 // forward / dX kernel
 // ---------------------------------------------------------------------------------------------
@@ -124,14 +222,44 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_fwd_kernel(const ConvArg
   int t_start, t_step, t_end;
   conv_tile_range(a.ntiles, t_start, t_step, t_end);
 
+  typedef typename StageType<IN_MODE>::type ST;
+  constexpr bool WHITEN = (IN_MODE == IN_F16_WHITEN || IN_MODE == IN_F32_WHITEN);
+  constexpr bool VEC = (IN_MODE != IN_DY);
+  // prefetch the next tile's chunks into registers across the MFMA phase when the budget allows
+  constexpr bool PREFETCH = VEC && (RowStager<CIN, KS, XTW, ST, WHITEN>::NV <= 8);
+  RowStager<CIN, KS, XTW, ST, WHITEN> stg;
+  float2* wl = reinterpret_cast<float2*>(lds + TILE + CONV_LDS_PAD);
+  if (WHITEN && tid < CIN) wl[tid] = make_float2(a.scale[tid], a.shift[tid]);
+  const bool vec = VEC && a.vec_ok;
+  if (WHITEN) __syncthreads();
+  if (PREFETCH && vec && t_start < t_end) {
+    const int b = t_start / tiles_per_img;
+    const int rem = t_start - b * tiles_per_img;
+    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+    stg.load(a, b, ty * CONV_TH, tx * TCOLS, tid);
+  }
+
   for (int tile = t_start; tile < t_end; tile += t_step) {
     const int b = tile / tiles_per_img;
     const int rem = tile - b * tiles_per_img;
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
     const int y0 = ty * CONV_TH, x0 = tx * TCOLS;
 
-    conv_stage_tile<CIN, KS, XTW, IN_MODE>(lds, a, b, y0, x0, tid);
+    if (vec) {
+      if (!PREFETCH) stg.load(a, b, y0, x0, tid);
+      stg.store(lds, wl, a, y0, x0, tid);
+      RowStager<CIN, KS, XTW, ST, WHITEN>::zero_halo(lds, a, y0, x0, tid);
+    } else {
+      conv_stage_tile<CIN, KS, XTW, IN_MODE>(lds, a, b, y0, x0, tid);
+    }
     __syncthreads();
+    if (PREFETCH && vec && tile + t_step < t_end) {
+      const int nt = tile + t_step;
+      const int nb = nt / tiles_per_img;
+      const int nrem = nt - nb * tiles_per_img;
+      const int nty = nrem / a.tiles_x, ntx = nrem - nty * a.tiles_x;
+      stg.load(a, nb, nty * CONV_TH, ntx * TCOLS, tid);
+    }
 
     const int yrow = y0 + 2 * wave;
     if (yrow < a.H) {   // wave-uniform
@@ -233,14 +361,44 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_dw_kernel(const ConvArgs
   int t_start, t_step, t_end;
   conv_tile_range(a.ntiles, t_start, t_step, t_end);
 
+  typedef typename StageType<IN_MODE>::type ST;
+  constexpr bool WHITEN = (IN_MODE == IN_F16_WHITEN || IN_MODE == IN_F32_WHITEN);
+  constexpr bool VEC = (IN_MODE != IN_DY);
+  // prefetch the next tile's chunks into registers across the MFMA phase when the budget allows
+  constexpr bool PREFETCH = VEC && (RowStager<CIN, KS, XTW, ST, WHITEN>::NV <= 8);
+  RowStager<CIN, KS, XTW, ST, WHITEN> stg;
+  float2* wl = reinterpret_cast<float2*>(lds + TILE + CONV_LDS_PAD);
+  if (WHITEN && tid < CIN) wl[tid] = make_float2(a.scale[tid], a.shift[tid]);
+  const bool vec = VEC && a.vec_ok;
+  if (WHITEN) __syncthreads();
+  if (PREFETCH && vec && t_start < t_end) {
+    const int b = t_start / tiles_per_img;
+    const int rem = t_start - b * tiles_per_img;
+    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+    stg.load(a, b, ty * CONV_TH, tx * TCOLS, tid);
+  }
+
   for (int tile = t_start; tile < t_end; tile += t_step) {
     const int b = tile / tiles_per_img;
     const int rem = tile - b * tiles_per_img;
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
     const int y0 = ty * CONV_TH, x0 = tx * TCOLS;
 
-    conv_stage_tile<CIN, KS, XTW, IN_MODE>(lds, a, b, y0, x0, tid);
+    if (vec) {
+      if (!PREFETCH) stg.load(a, b, y0, x0, tid);
+      stg.store(lds, wl, a, y0, x0, tid);
+      RowStager<CIN, KS, XTW, ST, WHITEN>::zero_halo(lds, a, y0, x0, tid);
+    } else {
+      conv_stage_tile<CIN, KS, XTW, IN_MODE>(lds, a, b, y0, x0, tid);
+    }
     __syncthreads();
+    if (PREFETCH && vec && tile + t_step < t_end) {
+      const int nt = tile + t_step;
+      const int nb = nt / tiles_per_img;
+      const int nrem = nt - nb * tiles_per_img;
+      const int nty = nrem / a.tiles_x, ntx = nrem - nty * a.tiles_x;
+      stg.load(a, nb, nty * CONV_TH, ntx * TCOLS, tid);
+    }
 
     const int yrow = y0 + 2 * wave;
     if (yrow < a.H) {
@@ -311,7 +469,7 @@ int launch_dw_reduce(cpp_ctx* ctx, const float* partial, int nblocks, int pstrid
 template <int CIN, int KS, int XTW, int IN_MODE, int EPI>
 static inline int conv_fwd_launch_t(cpp_ctx* ctx, const ConvArgs& a) {
   constexpr int TR = CONV_TH + KS - 1, TC = 16 * XTW + KS - 1;
-  const size_t lds_bytes = (size_t)(TR * TC * CIN + CONV_LDS_PAD) * sizeof(float);
+  const size_t lds_bytes = (size_t)(TR * TC * CIN + CONV_LDS_PAD + 2 * CIN) * sizeof(float);
   auto kern = conv_fwd_kernel<CIN, KS, XTW, IN_MODE, EPI>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -337,7 +495,7 @@ template <int CIN, int KS, int XTW, int IN_MODE>
 static inline int conv_dw_launch_t(cpp_ctx* ctx, const ConvArgs& a, int* grid_out) {
   constexpr int TR = CONV_TH + KS - 1, TC = 16 * XTW + KS - 1;
   constexpr int NT = DwGeom<CIN, KS>::NT;
-  size_t fl = (size_t)(TR * TC * CIN + CONV_LDS_PAD);
+  size_t fl = (size_t)(TR * TC * CIN + CONV_LDS_PAD + 2 * CIN);
   if (fl < (size_t)NT * 256 + 64) fl = (size_t)NT * 256 + 64;
   const size_t lds_bytes = fl * sizeof(float);
   auto kern = conv_dw_kernel<CIN, KS, XTW, IN_MODE>;

@@ -8,23 +8,24 @@
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-// One wave per 16x16 output tile; operands straight from global/L2 (all matrices here are < 1 MB).
+// One 4-wave workgroup per 16x16 output tile, K split across the waves in interleaved chunks of 64 (the
+// matrices are tiny and L2 resident, so the kernel is a latency chain: 32 loads in flight per lane and a
+// 4x shorter chain matter more than tiling).  Partial tiles are combined through LDS in fixed order.
 // A(m,k) = A[m*sAm + k*sAk], B(k,n) = B[k*sBk + n*sBn]: the strides express the transposes of the
 // backward passes (dX = dz W^T, dW = x^T dz) without materialising them.
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs g) {
+  __shared__ float red[3][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lj = lane >> 4;
-  const int tiles_n = (g.N + 15) >> 4, tiles_m = (g.M + 15) >> 4;
-  const int tile = blockIdx.x * 4 + wave;
-  if (tile >= tiles_m * tiles_n) return;
-  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int tiles_n = (g.N + 15) >> 4;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
   const int m = tm * 16 + li, n = tn * 16 + li;
   const bool mv = m < g.M, nv = n < g.N;
   const float* ap = g.A + (long)m * g.sAm;
   const float* bp = g.B + (long)n * g.sBn;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  constexpr int U = 8;
-  for (int k0 = 0; k0 < g.K; k0 += 4 * U) {
+  constexpr int U = 16;
+  for (int k0 = wave * 4 * U; k0 < g.K; k0 += 4 * 4 * U) {
     float av[U], bv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -36,12 +37,17 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs g) {
 #pragma unroll
     for (int u = 0; u < U; ++u) acc = MFMA16(av[u], bv[u], acc);
   }
-  if (!nv) return;
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave - 1][lane * 4 + i] = acc[i];
+  }
+  __syncthreads();
+  if (wave != 0 || !nv) return;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = tm * 16 + 4 * lj + i;
     if (row < g.M) {
-      float v = acc[i];
+      float v = ((acc[i] + red[0][lane * 4 + i]) + red[1][lane * 4 + i]) + red[2][lane * 4 + i];
       if (g.epi == GE_RELU) v = fmaxf(v, 0.f);
       else if (g.epi == GE_TANH) v = tanhf(v);
       else if (g.epi == GE_MUL_RELU_GRAD) v = g.Y[(long)row * g.ldy + n] > 0.f ? v : 0.f;
@@ -54,7 +60,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs g) {
 int launch_gemm(cpp_ctx* ctx, const GemmArgs& g) {
   const int tiles = ((g.M + 15) / 16) * ((g.N + 15) / 16);
   prof_begin(ctx);
-  hipLaunchKernelGGL(gemm_mfma_kernel, dim3((tiles + 3) / 4), dim3(256), 0, ctx->stream, g);
+  hipLaunchKernelGGL(gemm_mfma_kernel, dim3(tiles), dim3(256), 0, ctx->stream, g);
   LAUNCH_CHECK();
   prof_end(ctx, K_GEMM);
   return 0;

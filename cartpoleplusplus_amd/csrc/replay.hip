@@ -152,28 +152,30 @@ int launch_gather_stats(cpp_ctx* ctx, const GatherArgs& a, int dtype) {
 }
 
 // white[w][0][c] = rsqrt(var + 1e-6), white[w][1][c] = -mean * rsqrt(var + 1e-6)   (base_network.py:97-99)
-__global__ void stats_finalize_kernel(const double* part, int nparts, int which_count, int C,
-                                      double count, float* white) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= which_count * C) return;
-  const int w = t / C, c = t - w * C;
+// one 64-lane wave per (state column, channel): lanes stride over the per-row partials, fixed-order
+// butterfly combine (deterministic)
+__global__ __launch_bounds__(64) void stats_finalize_kernel(const double* part, int nparts, int which_count,
+                                                            int C, double count, float* white) {
+  const int w = blockIdx.x / C, c = blockIdx.x - w * C;
   double s = 0.0, ss = 0.0;
-  for (int b = 0; b < nparts; ++b) {
+  for (int b = threadIdx.x; b < nparts; b += 64) {
     const double* p = part + ((long)w * nparts + b) * 2 * C;
     s += p[c]; ss += p[C + c];
   }
-  const double mean = s / count;
-  const double var = ss / count - mean * mean;     // one-pass form of tf.nn.moments (r0.9-r0.11)
-  const double inv = 1.0 / sqrt(var + 1e-6);
-  white[(long)w * 2 * C + c] = (float)inv;
-  white[(long)w * 2 * C + C + c] = (float)(-mean * inv);
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+  if (threadIdx.x == 0) {
+    const double mean = s / count;
+    const double var = ss / count - mean * mean;     // one-pass form of tf.nn.moments (r0.9-r0.11)
+    const double inv = 1.0 / sqrt(var + 1e-6);
+    white[(long)w * 2 * C + c] = (float)inv;
+    white[(long)w * 2 * C + C + c] = (float)(-mean * inv);
+  }
 }
 
 int launch_stats_finalize(cpp_ctx* ctx, const double* part, int nparts, int which_count, int C,
                           double count, float* white) {
   prof_begin(ctx);
-  const int n = which_count * C;
-  hipLaunchKernelGGL(stats_finalize_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, part, nparts,
+  hipLaunchKernelGGL(stats_finalize_kernel, dim3(which_count * C), dim3(64), 0, ctx->stream, part, nparts,
                      which_count, C, count, white);
   LAUNCH_CHECK();
   prof_end(ctx, K_STATS_FINALIZE);

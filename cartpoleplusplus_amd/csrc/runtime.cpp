@@ -732,7 +732,7 @@ extern "C" int cpp_replay_sample(cpp_replay* r, int B, const int32_t* idxs, uint
     HIP_CHECK(hipMemcpyAsync(r->counter, &counter, sizeof(uint64_t), hipMemcpyHostToDevice, st));
   }
   RC(replay_sample_device(r, B, rows_dev, seed, idxs ? nullptr : r->counter, channels, out));
-  HIP_CHECK(hipStreamSynchronize(st));
+  if (idxs) HIP_CHECK(hipStreamSynchronize(st));     // the caller's index array may go away after return
   return CPP_OK;
 }
 
@@ -767,6 +767,8 @@ struct cpp_ddpg {
   // graph replay of the full inner step
   hipGraph_t graph; hipGraphExec_t gexec; bool graph_ok; int g_B, g_nb; uint64_t g_seed; cpp_replay* g_replay;
   cpp_batch* step_batch;
+  // graph replay of the data-parallel half step (sample + both gradient sets)
+  hipGraph_t hgraph; hipGraphExec_t hexec; bool hgraph_ok; int h_B; uint64_t h_seed; cpp_replay* h_replay;
   Arena arena;
 };
 
@@ -785,6 +787,7 @@ extern "C" int cpp_ddpg_create(cpp_ctx* ctx, cpp_net* actor, cpp_net* critic, cp
   d->maxB = actor->maxB < critic->maxB ? actor->maxB : critic->maxB;
   d->nA = actor->nparams; d->nC = critic->nparams;
   d->graph = nullptr; d->gexec = nullptr; d->graph_ok = false; d->step_batch = nullptr; d->g_replay = nullptr;
+  d->hgraph = nullptr; d->hexec = nullptr; d->hgraph_ok = false; d->h_replay = nullptr;
   const int A = actor->spec.action_dim;
   int rc = dalloc(d->arena, &d->gradbuf, (size_t)(d->nA + d->nC));
   if (!rc) rc = dalloc(d->arena, &d->dq_da, (size_t)d->maxB * A);
@@ -807,6 +810,8 @@ extern "C" int cpp_ddpg_destroy(cpp_ddpg* d) {
   (void)hipStreamSynchronize(d->ctx->stream);
   if (d->gexec) (void)hipGraphExecDestroy(d->gexec);
   if (d->graph) (void)hipGraphDestroy(d->graph);
+  if (d->hexec) (void)hipGraphExecDestroy(d->hexec);
+  if (d->hgraph) (void)hipGraphDestroy(d->hgraph);
   if (d->step_batch) cpp_batch_destroy(d->step_batch);
   d->actor->grads = nullptr; d->critic->grads = nullptr;
   d->arena.release(); delete d; return CPP_OK;
@@ -1034,6 +1039,41 @@ extern "C" int cpp_ddpg_train_step(cpp_ddpg* d, cpp_replay* r, int B, int n_batc
     return CPP_OK;   // the eager pass above was this call's step
   }
   HIP_CHECK(hipGraphLaunch(d->gexec, ctx->stream));
+  return CPP_OK;
+}
+
+static int half_step_body(cpp_ddpg* d, cpp_replay* r, int B, uint64_t seed) {
+  const int C = d->actor->spec.pixel ? d->actor->spec.C : 0;
+  RC(replay_sample_device(r, B, nullptr, seed, r->counter, C, d->step_batch));
+  RC(launch_counter_add(d->ctx, r->counter, 1));
+  return compute_gradients(d, d->step_batch);
+}
+
+extern "C" int cpp_ddpg_sample_and_compute(cpp_ddpg* d, cpp_replay* r, int B, uint64_t seed) {
+  ARG_CHECK(d && r, "cpp_ddpg_sample_and_compute: NULL argument");
+  ARG_CHECK(B >= 1 && B <= d->maxB, "cpp_ddpg_sample_and_compute: batch %d outside [1,%d]", B, d->maxB);
+  ARG_CHECK(r->elems == d->actor->state_elems && r->A == d->actor->spec.action_dim, "cpp_ddpg_sample_and_compute: replay shape does not match the networks");
+  if (r->size <= 0) { cpp_set_error("cpp_ddpg_sample_and_compute: replay memory is empty"); return CPP_ERR_STATE; }
+  cpp_ctx* ctx = d->ctx;
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (!d->step_batch) RC(cpp_batch_create(ctx, d->maxB, r->elems, r->A, &d->step_batch));
+  if (ctx->prof) return half_step_body(d, r, B, seed);
+  if (!d->hgraph_ok || d->h_B != B || d->h_seed != seed || d->h_replay != r) {
+    if (d->hexec) { (void)hipGraphExecDestroy(d->hexec); d->hexec = nullptr; }
+    if (d->hgraph) { (void)hipGraphDestroy(d->hgraph); d->hgraph = nullptr; }
+    d->hgraph_ok = false;
+    RC(half_step_body(d, r, B, seed));            // eager pass: sets kernel attributes, is this call's work
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    int rc = half_step_body(d, r, B, seed);
+    hipError_t e = hipStreamEndCapture(ctx->stream, &d->hgraph);
+    if (rc) return rc;
+    if (e != hipSuccess) { cpp_set_error("hipStreamEndCapture -> %s", hipGetErrorString(e)); return CPP_ERR_HIP; }
+    HIP_CHECK(hipGraphInstantiate(&d->hexec, d->hgraph, nullptr, nullptr, 0));
+    d->hgraph_ok = true; d->h_B = B; d->h_seed = seed; d->h_replay = r;
+    return CPP_OK;
+  }
+  HIP_CHECK(hipGraphLaunch(d->hexec, ctx->stream));
   return CPP_OK;
 }
 

@@ -176,6 +176,11 @@ int cpp_ddpg_update_targets(cpp_ddpg* ddpg);
  * when idxs == NULL and profiling is off. */
 int cpp_ddpg_train_step(cpp_ddpg* ddpg, cpp_replay* replay, int B, int n_batches,
                         const int32_t* idxs, uint64_t seed);
+/* Data-parallel learners: the first half of one minibatch of the inner step -- sample B rows on the
+ * device (Philox; the counter advances by one) and leave both gradient sets in the flat gradient
+ * buffer.  The host then all-reduces that buffer (RCCL) and calls cpp_ddpg_apply_gradients(1/N).
+ * hipGraph-captured after the first call per (B, seed, replay). */
+int cpp_ddpg_sample_and_compute(cpp_ddpg* ddpg, cpp_replay* replay, int B, uint64_t seed);
 /* scalars of the last minibatch: [0] td loss, [1] actor grad norm, [2] critic grad norm (pre-clip). */
 int cpp_ddpg_last_stats(cpp_ddpg* ddpg, float out[3]);
 
