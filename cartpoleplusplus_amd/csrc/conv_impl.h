@@ -26,6 +26,12 @@ constexpr int CONV_TH = 8;          // output rows per workgroup tile (4 waves x
 constexpr int CONV_THREADS = 256;
 constexpr int CONV_LDS_PAD = 16;    // floats; covers the k-padding over-read of the last tile row
 
+// waves per SIMD the register allocator must leave room for: 2 workgroups per CU while the tile fits
+// twice into the 160 KiB LDS, otherwise 1 (and up to 512 VGPRs)
+constexpr int conv_wps(int cin, int ks, int xtw) {
+  return ((CONV_TH + ks - 1) * (16 * xtw + ks - 1) * cin * 4 > 76 * 1024) ? 1 : 2;
+}
+
 // XCD-aware persistent tile order: workgroup b runs on XCD b % 8 (observed dispatch order, speed
 // only); give every XCD a contiguous run of tiles so neighbouring row tiles of one image (which share
 // 4 halo rows) hit the same 4 MiB L2.
@@ -94,6 +100,10 @@ __device__ __forceinline__ void conv_stage_tile(float* lds, const ConvArgs& a, i
 template <typename T> struct ChunkOps;
 template <> struct ChunkOps<__half> {
   static constexpr int EPC = 8;
+  static __device__ __forceinline__ float get_dyn(const uint4& v, int k) {      // k lane-dependent
+    const uint32_t w = k < 4 ? (k < 2 ? v.x : v.y) : (k < 6 ? v.z : v.w);
+    return __half2float(__ushort_as_half((unsigned short)((w >> ((k & 1) * 16)) & 0xffffu)));
+  }
   static __device__ __forceinline__ float get(const uint4& v, int k) {
     const uint32_t w = k < 2 ? v.x : (k < 4 ? v.y : (k < 6 ? v.z : v.w));
     return __half2float(__ushort_as_half((unsigned short)((k & 1) ? (w >> 16) : (w & 0xffffu))));
@@ -101,6 +111,9 @@ template <> struct ChunkOps<__half> {
 };
 template <> struct ChunkOps<float> {
   static constexpr int EPC = 4;
+  static __device__ __forceinline__ float get_dyn(const uint4& v, int k) {
+    return __uint_as_float(k < 2 ? (k == 0 ? v.x : v.y) : (k == 2 ? v.z : v.w));
+  }
   static __device__ __forceinline__ float get(const uint4& v, int k) {
     return __uint_as_float(k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)));
   }
@@ -141,6 +154,9 @@ struct RowStager {
     }
   }
 
+  // Lanes hold consecutive chunks (LDS addresses EPC dwords apart): a chunk that lies wholly inside its
+  // row and lands 16-byte aligned in LDS goes out as ds_write_b128 (the common case: all but the two
+  // chunks at the row ends); anything else falls back to per-element ds_write_b32.
   __device__ __forceinline__ void store(float* lds, const float2* wl, const ConvArgs& a, int y0, int x0,
                                         int tid) const {
 #pragma unroll
@@ -149,15 +165,22 @@ struct RowStager {
       if (geom(a, tid + CONV_THREADS * i, y0, x0, r, a0, rs, re, gxs)) {
         const int lbase = r * TC * CIN + (gxs - (x0 - P)) * CIN - rs;    // lds index = lbase + e
         int c = a0 % CIN;
+        float x[EPC];
 #pragma unroll
         for (int k = 0; k < EPC; ++k) {
-          const int e = a0 + k;
-          if (e >= rs && e < re) {
-            float x = ChunkOps<T>::get(v[i], k);
-            if (WHITEN) { const float2 w = wl[c]; x = x * w.x + w.y; }
-            lds[lbase + e] = x;
-          }
+          x[k] = ChunkOps<T>::get(v[i], k);
+          if (WHITEN) { const float2 w = wl[c]; x[k] = x[k] * w.x + w.y; }
           c = (c + 1 == CIN) ? 0 : c + 1;
+        }
+        float* dst = lds + lbase + a0;
+        if (a0 >= rs && a0 + EPC <= re && (((lbase + a0) & 3) == 0)) {
+#pragma unroll
+          for (int k = 0; k < EPC; k += 4)
+            *reinterpret_cast<float4*>(dst + k) = make_float4(x[k], x[k + 1], x[k + 2], x[k + 3]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < EPC; ++k)
+            if (a0 + k >= rs && a0 + k < re) dst[k] = x[k];
         }
       }
     }
@@ -183,7 +206,7 @@ template <> struct StageType<IN_F16_WHITEN> { typedef __half type; };
 // forward / dX kernel
 // ---------------------------------------------------------------------------------------------
 template <int CIN, int KS, int XTW, int IN_MODE, int EPI>
-__global__ __launch_bounds__(CONV_THREADS, 2) void conv_fwd_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd_kernel(const ConvArgs a) {
   constexpr int TR = CONV_TH + KS - 1, TCOLS = 16 * XTW, TC = TCOLS + KS - 1;
   constexpr int KROW = (KS * CIN + 3) / 4;
   constexpr int TILE = TR * TC * CIN;
@@ -339,16 +362,66 @@ struct DwGeom {
   static constexpr int NT = KS * KT;
 };
 
+// dY of a tile is kept in LDS at POOLED resolution: gm = (pool > 0 ? dpool : 0) and the argmax code,
+// (CONV_TH/2) x (TCOLS/2) cells x DW_GP dwords; the two output rows of a wave share one pooled row, so
+// one gm + one code read give the B operands of both rows.
+constexpr int DW_GP = 20;     // dwords per pooled cell: 16 channels + pad so lane groups 8 px apart miss each other's banks
+
+template <int XTW>
+struct DyStager {
+  static constexpr int PR = CONV_TH / 2, PC = 8 * XTW;
+  static constexpr int NE_MAX = PR * PC * CPP_NOUT_MAX;
+  static constexpr int NV = (PR * PC * 10 + CONV_THREADS - 1) / CONV_THREADS;   // nout <= 10 fast path
+  float g[NV], pv[NV];
+  int code[NV];
+
+  __device__ __forceinline__ void load(const ConvArgs& a, int b, int y0, int x0, int tid) {
+    const DyDesc& d = a.dy;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + CONV_THREADS * i;
+      const int o = idx % a.nout, pp = idx / a.nout;
+      const int pc = pp % PC, pr = pp / PC;
+      const int py = (y0 >> 1) + pr, px = (x0 >> 1) + pc;
+      g[i] = 0.f; pv[i] = 0.f; code[i] = 255;
+      if (pr < PR && py < d.Hp && px < d.Wp) {
+        const long e = (long)(py * d.Wp + px) * a.nout + o;
+        g[i] = d.dpool[(long)b * d.dpool_bstride + e];
+        pv[i] = d.pool[(long)b * d.pool_bstride + e];
+        code[i] = d.amax[(long)b * d.Hp * d.Wp * a.nout + e];
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float* gm, unsigned char* gc, const ConvArgs& a, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + CONV_THREADS * i;
+      const int o = idx % a.nout, pp = idx / a.nout;
+      if (pp < PR * PC) {
+        gm[pp * DW_GP + o] = pv[i] > 0.f ? g[i] : 0.f;
+        gc[pp * DW_GP + o] = (unsigned char)code[i];
+      }
+    }
+  }
+};
+
 template <int CIN, int KS, int XTW, int IN_MODE>
-__global__ __launch_bounds__(CONV_THREADS, 2) void conv_dw_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_dw_kernel(const ConvArgs a) {
   constexpr int TR = CONV_TH + KS - 1, TCOLS = 16 * XTW, TC = TCOLS + KS - 1;
   constexpr int TILE = TR * TC * CIN;
   constexpr int KT = DwGeom<CIN, KS>::KT, NT = DwGeom<CIN, KS>::NT;
+  constexpr int SP = TCOLS >= 32 ? 8 : 4;          // pixel spacing inside one MFMA step (bank spread)
+  constexpr int GMF = (CONV_TH / 2) * (TCOLS / 2) * DW_GP;   // floats of the gm image
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lj = lane >> 4;
 
   if (tid < CONV_LDS_PAD) lds[TILE + tid] = 0.f;
+  float2* wl = reinterpret_cast<float2*>(lds + TILE + CONV_LDS_PAD);
+  float* gm = lds + TILE + CONV_LDS_PAD + 2 * CIN;
+  unsigned char* gc = reinterpret_cast<unsigned char*>(gm + GMF);
+  // zero the channel padding of gm / gc once (lanes li >= nout read it)
+  for (int i = tid; i < GMF; i += CONV_THREADS) { gm[i] = 0.f; gc[i] = 255; }
 
   f32x4 acc[KS][KT];
 #pragma unroll
@@ -363,19 +436,18 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_dw_kernel(const ConvArgs
 
   typedef typename StageType<IN_MODE>::type ST;
   constexpr bool WHITEN = (IN_MODE == IN_F16_WHITEN || IN_MODE == IN_F32_WHITEN);
-  constexpr bool VEC = (IN_MODE != IN_DY);
-  // prefetch the next tile's chunks into registers across the MFMA phase when the budget allows
-  constexpr bool PREFETCH = VEC && (RowStager<CIN, KS, XTW, ST, WHITEN>::NV <= 8);
+  constexpr bool PREFETCH = (RowStager<CIN, KS, XTW, ST, WHITEN>::NV <= 8);
   RowStager<CIN, KS, XTW, ST, WHITEN> stg;
-  float2* wl = reinterpret_cast<float2*>(lds + TILE + CONV_LDS_PAD);
+  DyStager<XTW> dst;
   if (WHITEN && tid < CIN) wl[tid] = make_float2(a.scale[tid], a.shift[tid]);
-  const bool vec = VEC && a.vec_ok;
-  if (WHITEN) __syncthreads();
-  if (PREFETCH && vec && t_start < t_end) {
+  const bool vec = a.vec_ok;
+  const bool dyfast = a.nout <= 10;
+  __syncthreads();
+  if (t_start < t_end) {
     const int b = t_start / tiles_per_img;
     const int rem = t_start - b * tiles_per_img;
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
-    stg.load(a, b, ty * CONV_TH, tx * TCOLS, tid);
+    if (PREFETCH && vec) stg.load(a, b, ty * CONV_TH, tx * TCOLS, tid);
   }
 
   for (int tile = t_start; tile < t_end; tile += t_step) {
@@ -384,6 +456,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_dw_kernel(const ConvArgs
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
     const int y0 = ty * CONV_TH, x0 = tx * TCOLS;
 
+    if (dyfast) dst.load(a, b, y0, x0, tid);      // issued first: their latency hides under the tile stores
     if (vec) {
       if (!PREFETCH) stg.load(a, b, y0, x0, tid);
       stg.store(lds, wl, a, y0, x0, tid);
@@ -391,27 +464,46 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_dw_kernel(const ConvArgs
     } else {
       conv_stage_tile<CIN, KS, XTW, IN_MODE>(lds, a, b, y0, x0, tid);
     }
+    if (dyfast) {
+      dst.store(gm, gc, a, tid);
+    } else {       // generic (nout > 10): straight from global
+      for (int idx = tid; idx < (CONV_TH / 2) * (TCOLS / 2) * a.nout; idx += CONV_THREADS) {
+        const int o = idx % a.nout, pp = idx / a.nout;
+        const int pc = pp % (TCOLS / 2), pr = pp / (TCOLS / 2);
+        const int py = (y0 >> 1) + pr, px = (x0 >> 1) + pc;
+        float gv = 0.f; int cd = 255;
+        if (py < a.dy.Hp && px < a.dy.Wp) {
+          const long e = (long)(py * a.dy.Wp + px) * a.nout + o;
+          const float pvv = a.dy.pool[(long)b * a.dy.pool_bstride + e];
+          gv = pvv > 0.f ? a.dy.dpool[(long)b * a.dy.dpool_bstride + e] : 0.f;
+          cd = a.dy.amax[(long)b * a.dy.Hp * a.dy.Wp * a.nout + e];
+        }
+        gm[pp * DW_GP + o] = gv; gc[pp * DW_GP + o] = (unsigned char)cd;
+      }
+    }
     __syncthreads();
-    if (PREFETCH && vec && tile + t_step < t_end) {
+    if (tile + t_step < t_end) {
       const int nt = tile + t_step;
       const int nb = nt / tiles_per_img;
       const int nrem = nt - nb * tiles_per_img;
       const int nty = nrem / a.tiles_x, ntx = nrem - nty * a.tiles_x;
-      stg.load(a, nb, nty * CONV_TH, ntx * TCOLS, tid);
+      if (PREFETCH && vec) stg.load(a, nb, nty * CONV_TH, ntx * TCOLS, tid);
     }
 
     const int yrow = y0 + 2 * wave;
     if (yrow < a.H) {
-      for (int x4 = 0; x4 < 4 * XTW; ++x4) {
-        const int x = x0 + 4 * x4 + lj;
-        if (x0 + 4 * x4 >= a.W) break;   // wave-uniform
-        float b0 = 0.f, b1 = 0.f;
-        if (li < a.nout && x < a.W) {
-          b0 = dy_value(a.dy, b, yrow, x, li, a.nout);
-          if (yrow + 1 < a.H) b1 = dy_value(a.dy, b, yrow + 1, x, li, a.nout);
-        }
+#pragma unroll 1
+      for (int st = 0; st < TCOLS / 4; ++st) {
+        const int xbase = (st / SP) * 4 * SP + (st % SP);        // smallest of the step's 4 pixels
+        if (x0 + xbase >= a.W) continue;                          // wave-uniform
+        const int xloc = xbase + SP * lj;
+        const int cell = (wave * (TCOLS / 2) + (xloc >> 1)) * DW_GP + li;
+        const float gv = gm[cell];
+        const int cd = gc[cell];
+        const float b0 = (cd == (xloc & 1)) ? gv : 0.f;           // row 2w   : code = 0*2 + (x&1)
+        const float b1 = (cd == 2 + (xloc & 1)) ? gv : 0.f;       // row 2w+1 : code = 1*2 + (x&1)
         bsum += b0 + b1;
-        const float* lp = lds + ((2 * wave) * TC + 4 * x4 + lj) * CIN + li;
+        const float* lp = lds + ((2 * wave) * TC + xloc) * CIN + li;
 #pragma unroll
         for (int q = 0; q < KS + 1; ++q) {
 #pragma unroll
@@ -427,7 +519,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_dw_kernel(const ConvArgs
   }
 
   // cross-wave reduction in fixed order (wave 0, 1, 2, 3) through LDS, then one partial per block
-  float* red = lds;   // NT*256 floats (launch sizes the LDS for max(TILE+pad, NT*256 + 64))
+  float* red = lds;   // NT*256 floats (launch sizes the LDS for max(tile image, NT*256 + 64))
   for (int w = 0; w < 4; ++w) {
     if (wave == w) {
 #pragma unroll
@@ -495,7 +587,8 @@ template <int CIN, int KS, int XTW, int IN_MODE>
 static inline int conv_dw_launch_t(cpp_ctx* ctx, const ConvArgs& a, int* grid_out) {
   constexpr int TR = CONV_TH + KS - 1, TC = 16 * XTW + KS - 1;
   constexpr int NT = DwGeom<CIN, KS>::NT;
-  size_t fl = (size_t)(TR * TC * CIN + CONV_LDS_PAD + 2 * CIN);
+  constexpr int GMF = (CONV_TH / 2) * (8 * XTW) * DW_GP;
+  size_t fl = (size_t)(TR * TC * CIN + CONV_LDS_PAD + 2 * CIN) + GMF + GMF / 4 + 4;
   if (fl < (size_t)NT * 256 + 64) fl = (size_t)NT * 256 + 64;
   const size_t lds_bytes = fl * sizeof(float);
   auto kern = conv_dw_kernel<CIN, KS, XTW, IN_MODE>;
