@@ -49,8 +49,8 @@ def conv_macs(shape):
     return F, Bk, per_layer
 
 
-def cpu_baseline(shape, B, sample_B=64):
-    """one minibatch update of the oracle (f32) on a bounded sample: sample_B of the B rows."""
+def cpu_baseline(shape, B, budget_s=12.0, max_reps=6):
+    """full-batch minibatch updates of the oracle (f32) on this host until ~budget_s of CPU work is done."""
     from oracle import ddpg_np as O          # checker / baseline only
     try:
         from threadpoolctl import threadpool_info
@@ -61,15 +61,15 @@ def cpu_baseline(shape, B, sample_B=64):
     kw = dict(pixel=True, H=shape[0], W=shape[1], C=int(np.prod(shape[2:])))
     aspec, cspec = O.NetSpec("actor", 2, [100, 100, 50], **kw), O.NetSpec("critic", 2, [], **kw)
     agent = O.DDPG(aspec, cspec, O.init_params(aspec, rng), O.init_params(cspec, rng), np.float32)
-    batch = O.synthetic_batch(rng, sample_B, shape, 2, True)
-    t0 = time.time()
-    agent.train_minibatch(batch)
+    batch = O.synthetic_batch(rng, B, shape, 2, True)
+    reps, t0 = 0, time.time()
+    while reps < max_reps and (reps == 0 or time.time() - t0 < budget_s):
+        agent.train_minibatch(batch)
+        reps += 1
     dt = time.time() - t0
-    steps_per_sec = (sample_B / float(B)) / dt
-    return {"value": steps_per_sec, "unit": "steps/s", "cores": int(threads), "kind": "port",
-            "sample": "1 minibatch update of oracle/ddpg_np.py (numpy f32, OpenBLAS threads=%d) on %d of the "
-                      "%d rows of the workload batch, %.1f s; scaled by %d/%d"
-                      % (threads, sample_B, B, dt, sample_B, B)}
+    return {"value": reps / dt, "unit": "steps/s", "cores": int(threads), "kind": "port",
+            "sample": "%d full minibatch update(s) (B=%d, same shapes as the GPU workload) of oracle/ddpg_np.py, "
+                      "numpy f32 with OpenBLAS on %d threads, %.1f s wall" % (reps, B, threads, dt)}
 
 
 def main():

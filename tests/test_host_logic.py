@@ -1,0 +1,45 @@
+"""CPU tests of host-side logic that needs no GPU: flags, exploration noise, helper functions."""
+import numpy as np
+
+from cartpoleplusplus_amd import util
+
+
+def test_flag_defaults_match_the_reference():
+    from cartpoleplusplus_amd import ddpg_cartpole as D
+    o = D.default_opts()
+    # ddpg_cartpole.py:18-57, util.py:10-20
+    assert (o.batch_size, o.batches_per_step, o.target_update_rate) == (128, 5, 0.0001)
+    assert (o.actor_learning_rate, o.critic_learning_rate, o.discount) == (0.001, 0.01, 0.99)
+    assert (o.replay_memory_size, o.replay_memory_burn_in) == (22000, 1000)
+    assert (o.action_noise_theta, o.action_noise_sigma) == (0.01, 0.05)
+    assert o.gradient_clip == 5 and o.actor_hidden_layers == "100,100,50"
+    assert util.gradient_clip_value(o) == 5.0
+
+
+def test_ou_noise_reproduces_the_clip_quirk():
+    np.random.seed(0)
+    n = util.OrnsteinUhlenbeckNoise(2, theta=0.5, sigma=10.0)
+    xs = np.array([n.sample() for _ in range(300)])
+    assert xs.max() <= 1.5 and xs.min() < -1.5      # util.py:155: only the upper bound is enforced
+    from oracle.ddpg_np import OUNoise
+    np.random.seed(7); a = util.OrnsteinUhlenbeckNoise(3, 0.01, 0.2)
+    b = OUNoise(3, 0.01, 0.2, rng=np.random.RandomState(7))
+    for _ in range(20):
+        assert np.array_equal(a.sample(), b.sample())
+
+
+def test_collapsed_successive_ranges():
+    assert util.collapsed_successive_ranges([2, 3, 4, 5, 13, 14, 15]) == "2-5, 13-15"
+    assert util.collapsed_successive_ranges([7]) == "7-7"
+
+
+def test_synthetic_env_shapes():
+    from cartpoleplusplus_amd import ddpg_cartpole as D
+    from cartpoleplusplus_amd.synthetic_env import SyntheticCartpole
+    o = D.default_opts(use_raw_pixels=True, render_height=64, render_width=64, num_cameras=2, action_repeats=3)
+    env = SyntheticCartpole(o)
+    s = env.reset()
+    assert s.shape == (64, 64, 3, 2, 3) and s.dtype == np.float32
+    assert np.array_equal(s, s.astype(np.float16).astype(np.float32))   # f16(k/255) values
+    s2, r, done, _ = env.step(np.zeros((1, 2)))
+    assert s2.shape == s.shape and r == 1.0
