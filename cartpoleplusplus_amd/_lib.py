@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcartpolepp_hip.so")
+LIB_PATH = os.environ.get("CARTPOLEPP_LIB") or os.path.join(_HERE, "lib", "libcartpolepp_hip.so")   # env: ablation builds only
 
 CPP_F32, CPP_F16 = 0, 1
 CPP_ACTOR, CPP_CRITIC = 0, 1

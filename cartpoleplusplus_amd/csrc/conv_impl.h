@@ -268,6 +268,10 @@ __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
     const int y0 = ty * CONV_TH, x0 = tx * TCOLS;
 
+#ifdef CONV_ABLATE_NOSTAGE
+    if (tile == t_start)
+#endif
+    {
     if (vec) {
       if (!PREFETCH) stg.load(a, b, y0, x0, tid);
       stg.store(lds, wl, a, y0, x0, tid);
@@ -275,7 +279,9 @@ __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd
     } else {
       conv_stage_tile<CIN, KS, XTW, IN_MODE>(lds, a, b, y0, x0, tid);
     }
+    }
     __syncthreads();
+#ifndef CONV_ABLATE_NOSTAGE
     if (PREFETCH && vec && tile + t_step < t_end) {
       const int nt = tile + t_step;
       const int nb = nt / tiles_per_img;
@@ -283,6 +289,7 @@ __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd
       const int nty = nrem / a.tiles_x, ntx = nrem - nty * a.tiles_x;
       stg.load(a, nb, nty * CONV_TH, ntx * TCOLS, tid);
     }
+#endif
 
     const int yrow = y0 + 2 * wave;
     if (yrow < a.H) {   // wave-uniform
@@ -295,7 +302,11 @@ __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd
       const float* lp = lds + (2 * wave) * TC * CIN + li * CIN + lj;
       // tile row q = r + ky feeds output row 0 with W[ky=q] and output row 1 with W[ky=q-1]
 #pragma unroll
+#ifdef CONV_ABLATE_NOMFMA
+      for (int q = 0; q < 1; ++q) {
+#else
       for (int q = 0; q < KS + 1; ++q) {
+#endif
 #pragma unroll
         for (int kk = 0; kk < KROW; ++kk) {
 #pragma unroll

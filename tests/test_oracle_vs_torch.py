@@ -137,3 +137,114 @@ def test_ou_noise_quirk():
     n = O.OUNoise(2, theta=0.5, sigma=10.0, rng=np.random.RandomState(0))
     xs = np.array([n.sample() for _ in range(200)])
     assert xs.max() <= 1.5 and xs.min() < -1.5           # util.py:155 enforces the upper bound only
+
+
+# ---------------------------------------------------------------------------------------------
+# NAF (naf_cartpole.py) restatement vs torch autograd
+# ---------------------------------------------------------------------------------------------
+from oracle import naf_np as N
+
+
+def _torch_head_forward(spec, p, state):
+    """HeadSpec network in torch (trunk as torch_forward, then hidden stack + 'fc')."""
+    return torch_forward(spec, p, state)
+
+
+NAF_CASES = [
+    dict(shape=(8, 8, 3, 1, 2), B=4, pixel=True, share=True),
+    dict(shape=(12, 10, 3, 1, 3), B=3, pixel=True, share=False),
+    dict(shape=(2, 2, 7), B=6, pixel=False, share=True),
+    dict(shape=(2, 2, 7), B=6, pixel=False, share=False),
+]
+
+
+def naf_specs(shape, pixel, share, A=2, hidden=(100, 50)):
+    kw = dict(pixel=True, H=shape[0], W=shape[1], C=int(np.prod(shape[2:]))) if pixel else \
+        dict(pixel=False, state_elems=int(np.prod(shape)))
+    vspec = N.HeadSpec(1, "linear", list(hidden), **kw)
+    if share:
+        mspec = N.HeadSpec(A, "tanh", [], False, state_elems=hidden[-1], head_only=True)
+        lspec = N.HeadSpec(N.num_l_values(A), "linear", [], False, state_elems=hidden[-1], head_only=True)
+    else:
+        mspec = N.HeadSpec(A, "tanh", list(hidden), **kw)
+        lspec = N.HeadSpec(N.num_l_values(A), "linear", list(hidden), **kw)
+    return vspec, mspec, lspec
+
+
+@pytest.mark.parametrize("case", NAF_CASES)
+def test_naf_gradients_match_autograd(case):
+    rng = np.random.default_rng(17)
+    shape, B, pixel, share = case["shape"], case["B"], case["pixel"], case["share"]
+    vspec, mspec, lspec = naf_specs(shape, pixel, share)
+    vf = N.init_head_params(vspec, rng) + rng.normal(0, 0.05, vspec.num_params()).astype(np.float32)
+    mf = N.init_head_params(mspec, rng, small_head=True) + rng.normal(0, 0.05, mspec.num_params()).astype(np.float32)
+    lf = N.init_head_params(lspec, rng) + rng.normal(0, 0.05, lspec.num_params()).astype(np.float32)
+    tvf = vf + rng.normal(0, 0.01, vf.shape).astype(np.float32)
+    batch = O.synthetic_batch(rng, B, shape, 2, pixel)
+    s1, a, r, mask, s2 = batch
+    naf = N.NAF(vspec, mspec, lspec, vf, mf, lf, share, 2, np.float64)
+    naf.target_value = O.Net(vspec, tvf, np.float64)
+    out = naf.forward_backward(batch)
+
+    pv, pm, pl, ptv = tparams(vspec, vf), tparams(mspec, mf), tparams(lspec, lf), tparams(vspec, tvf)
+    ts1, ts2 = torch.tensor(s1.astype(np.float64)), torch.tensor(s2.astype(np.float64))
+
+    def rep_and_value(p, x):
+        Bn = x.shape[0]
+        if vspec.pixel:
+            full = torch_forward(vspec, p, x)      # value
+            # representation = input of the last layer: recompute without the head
+            sub = N.HeadSpec(1, "linear", vspec.hidden, True, vspec.H, vspec.W, vspec.C)
+            sub.fc = vspec.fc[:-1]
+            rep = torch_forward(sub, p, x)
+        else:
+            full = torch_forward(vspec, p, x)
+            sub = N.HeadSpec(1, "linear", vspec.hidden, False, state_elems=vspec.state_elems)
+            sub.fc = vspec.fc[:-1]
+            rep = torch_forward(sub, p, x)
+        return rep, full
+
+    rep, V = rep_and_value(pv, ts1)
+    if share:
+        mu = torch.tanh(rep @ pm["fc/weights"] + pm["fc/biases"])
+        lv = rep @ pl["fc/weights"] + pl["fc/biases"]
+    else:
+        mu, lv = torch_forward(mspec, pm, ts1), torch_forward(lspec, pl, ts1)
+    L = torch.zeros(B, 2, 2)
+    L[:, 0, 0] = torch.exp(lv[:, 0]); L[:, 1, 0] = lv[:, 1]; L[:, 1, 1] = torch.exp(lv[:, 2])
+    P = L @ L.transpose(1, 2)
+    d = (torch.tensor(a.astype(np.float64)) - mu).unsqueeze(-1)
+    adv = (-0.5 * d.transpose(1, 2) @ (P @ d)).reshape(-1, 1)
+    with torch.no_grad():
+        tv = torch_forward(vspec, ptv, ts2)
+        y = torch.tensor(r.astype(np.float64)) + torch.tensor(mask.astype(np.float64)) * 0.99 * tv
+    q = V + adv
+    loss = ((q - y) ** 2).mean()
+    params = list(pv.values()) + list(pm.values()) + list(pl.values())
+    grads = torch.autograd.grad(loss, params)
+    np.testing.assert_allclose(out["loss"], loss.item(), rtol=1e-10)
+    np.testing.assert_allclose(out["advantage"], adv.detach().numpy(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(out["grads"], np.concatenate([g.numpy().ravel() for g in grads]), rtol=1e-8, atol=1e-11)
+
+
+def test_naf_optimisers_match_torch():
+    rng = np.random.default_rng(5)
+    shape = (2, 2, 7)
+    vspec, mspec, lspec = naf_specs(shape, False, True)
+    vf, mf, lf = N.init_head_params(vspec, rng), N.init_head_params(mspec, rng, True), N.init_head_params(lspec, rng)
+    for name, args, topt in [
+        ("GradientDescent", {"learning_rate": 0.01}, lambda p: torch.optim.SGD(p, lr=0.01)),
+        ("Momentum", {"learning_rate": 0.01, "momentum": 0.9}, lambda p: torch.optim.SGD(p, lr=0.01, momentum=0.9)),
+        ("Adam", {"learning_rate": 0.001}, lambda p: torch.optim.Adam(p, lr=0.001, eps=1e-8)),
+    ]:
+        naf = N.NAF(vspec, mspec, lspec, vf, mf, lf, True, 2, np.float64, gradient_clip=1e9,
+                    optimiser=N.make_optimiser(name, args))
+        x = torch.tensor(naf.flat().copy(), requires_grad=True)
+        opt = topt([x])
+        for step in range(4):
+            g = rng.normal(size=x.shape[0])
+            naf.apply(g.copy())
+            opt.zero_grad(); x.grad = torch.tensor(g); opt.step()
+            # TF Adam folds the bias correction into lr_t and adds eps to sqrt(v) (not sqrt(v_hat)):
+            tol = 2e-5 if name == "Adam" else 1e-12
+            np.testing.assert_allclose(naf.flat(), x.detach().numpy(), rtol=0, atol=tol)
