@@ -13,19 +13,27 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CARTPOLEPP_LIB") or os.path.join(_HERE, "lib", "libcartpolepp_hip.so")   # env: ablation builds only
 
 CPP_F32, CPP_F16 = 0, 1
-CPP_ACTOR, CPP_CRITIC = 0, 1
+CPP_ACTOR, CPP_CRITIC, CPP_HEAD = 0, 1, 2
+CPP_OPT_SGD, CPP_OPT_MOMENTUM, CPP_OPT_ADAM = 0, 1, 2
 
 
 class NetSpec(C.Structure):
     _fields_ = [("kind", C.c_int32), ("pixel", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("C", C.c_int32), ("state_elems", C.c_int32), ("action_dim", C.c_int32),
-                ("n_hidden", C.c_int32), ("hidden", C.c_int32 * 8)]
+                ("n_hidden", C.c_int32), ("hidden", C.c_int32 * 8), ("head_out", C.c_int32),
+                ("head_act", C.c_int32)]
 
 
 class DdpgHyper(C.Structure):
     _fields_ = [("actor_learning_rate", C.c_float), ("critic_learning_rate", C.c_float),
                 ("discount", C.c_float), ("gradient_clip", C.c_float),
                 ("target_update_rate", C.c_float)]
+
+
+class NafHyper(C.Structure):
+    _fields_ = [("discount", C.c_float), ("gradient_clip", C.c_float), ("target_update_rate", C.c_float),
+                ("optimiser", C.c_int32), ("learning_rate", C.c_float), ("momentum", C.c_float),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("epsilon", C.c_float)]
 
 
 _P = C.c_void_p
@@ -87,6 +95,17 @@ SIGNATURES = {
     "cpp_ddpg_train_step": (_I, [_P, _P, _I, _I, _P, _U64]),
     "cpp_ddpg_sample_and_compute": (_I, [_P, _P, _I, _U64]),
     "cpp_ddpg_last_stats": (_I, [_P, _P]),
+    "cpp_naf_create": (_I, [_P, _P, _P, _P, _P, _I, C.POINTER(NafHyper), _PP]),
+    "cpp_naf_destroy": (_I, [_P]),
+    "cpp_naf_action": (_I, [_P, _P, _I, _I, _P]),
+    "cpp_naf_train": (_I, [_P, _P, C.POINTER(_F)]),
+    "cpp_naf_debug_values": (_I, [_P, _P, _P, _P, _P, _P, _P]),
+    "cpp_naf_compute_gradients": (_I, [_P, _P]),
+    "cpp_naf_grad_buffer": (_I, [_P, _PP, C.POINTER(_L)]),
+    "cpp_naf_apply_gradients": (_I, [_P, _F]),
+    "cpp_naf_update_targets": (_I, [_P]),
+    "cpp_naf_train_step": (_I, [_P, _P, _I, _I, _P, _U64]),
+    "cpp_naf_last_stats": (_I, [_P, _P]),
 }
 
 

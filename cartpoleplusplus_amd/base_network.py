@@ -119,10 +119,11 @@ class Network(object):
         return self.hidden_layers_starting_at(input_state, opts.hidden_layers, opts)
 
     # ------------------------------------------------------------------ native instantiation
-    def _build_native(self, kind, action_dim, max_batch, ctx=None):
+    def _build_native(self, kind, action_dim, max_batch, ctx=None, head_out=0, head_act=0):
         self.ctx = ctx or _lib.default_context()
         spec = _lib.NetSpec()
         spec.kind, spec.action_dim = kind, int(action_dim)
+        spec.head_out, spec.head_act = int(head_out), int(head_act)
         if self._conv_input is not None:
             spec.pixel, (spec.H, spec.W, spec.C) = 1, self._conv_input
         else:
@@ -158,7 +159,9 @@ class Network(object):
             n = int(np.prod(v.shape))
             if v.name.endswith("biases:0"):
                 continue
-            if "/output_action/" in v.name:
+            # the tanh action heads use U(-1e-3, 1e-3): 'actor/output_action/weights' (ddpg_cartpole.py:94) and
+            # 'naf/output_action/fc/weights' (naf_cartpole.py:155) -- not the state networks beneath them
+            if "/output_action/" in v.name and v.name.split("/output_action/")[1].split("/")[0] in ("weights:0", "fc"):
                 vals = rng.uniform(-0.001, 0.001, n)
             else:
                 if len(v.shape) == 4:

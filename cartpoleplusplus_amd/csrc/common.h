@@ -16,7 +16,7 @@ enum KernelId {
   K_CONV1_DW, K_CONV2_DW, K_CONV3_DW,
   K_CONV2_DX, K_CONV3_DX,
   K_DW_REDUCE, K_GEMM, K_ELEMENTWISE, K_TD, K_SUMSQ, K_CLIP_SGD, K_SOFT_UPDATE,
-  K_REPLAY_FILL, K_NUM_KERNELS
+  K_REPLAY_FILL, K_NAF_HEAD, K_NUM_KERNELS
 };
 
 struct cpp_ctx {
@@ -78,6 +78,7 @@ struct GemmArgs {
   float* C; long ldc;
   const float* Y; long ldy;     // activation output for the *_GRAD epilogues
   int M, N, K, epi;
+  int accumulate;               // C = C + A*B before the epilogue (sums several heads' d(representation))
 };
 int launch_gemm(cpp_ctx* ctx, const GemmArgs& g);
 int launch_copy_cols(cpp_ctx* ctx, float* dst, long ldd, int dcol0, const float* src, long lds_,
@@ -117,12 +118,32 @@ int launch_counter_add(cpp_ctx* ctx, uint64_t* counter, uint64_t inc);
 // ---------------------------------------------------------------------------------------------
 // optimiser (optim.hip)
 // ---------------------------------------------------------------------------------------------
-struct Seg2 { float* p[2]; const float* g[2]; long n[2]; float lr[2]; };
-int launch_sumsq(cpp_ctx* ctx, const Seg2& s, float grad_scale, double* part, int nparts);
-int launch_clip_sgd(cpp_ctx* ctx, const Seg2& s, float grad_scale, float clip, const double* part,
-                    int nparts, float* norms_out);
+enum OptKind { OPT_SGD = 0, OPT_MOMENTUM = 1, OPT_ADAM = 2 };
+#define OPT_MAX_SEGS 4
+// Up to 4 flat (param, grad) segments.  Segments with the same `group` share one global gradient norm
+// (tf.clip_by_global_norm over one gradient list): DDPG clips the actor and critic lists separately
+// (ddpg_cartpole.py:116,216), NAF clips one list spanning all its networks (naf_cartpole.py:237).
+struct OptSegs {
+  float* p[OPT_MAX_SEGS]; const float* g[OPT_MAX_SEGS]; float* m[OPT_MAX_SEGS]; float* v[OPT_MAX_SEGS];
+  long n[OPT_MAX_SEGS]; float lr[OPT_MAX_SEGS]; int group[OPT_MAX_SEGS];
+  int nseg; int kind; float momentum, beta1, beta2, epsilon;
+  const uint64_t* step;        // Adam: number of applies so far INCLUDING this one (device counter)
+};
+int launch_sumsq(cpp_ctx* ctx, const OptSegs& s, float grad_scale, double* part, int nparts);
+int launch_opt_apply(cpp_ctx* ctx, const OptSegs& s, float grad_scale, float clip, const double* part,
+                     int nparts, float* norms_out);
 int launch_soft_update(cpp_ctx* ctx, float* t0, const float* s0, long n0, float* t1, const float* s1,
                        long n1, float coeff);
+
+struct NafHeadArgs {
+  const float* value; const float* mu; const float* lv; const float* action; const float* reward;
+  const float* mask; const float* target_value;
+  float discount; int B, A;
+  float* adv; float* q; float* td; float* loss;     // loss[0]
+  float* d_value; float* d_mu_z; float* d_l;        // nullptr: forward only
+  int* nonfinite;                                   // set to 1 when l_values / L / loss are not finite
+};
+int launch_naf_head(cpp_ctx* ctx, const NafHeadArgs& a);
 
 // ---------------------------------------------------------------------------------------------
 // launch bookkeeping

@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs g) {
     const int row = tm * 16 + 4 * lj + i;
     if (row < g.M) {
       float v = ((acc[i] + red[0][lane * 4 + i]) + red[1][lane * 4 + i]) + red[2][lane * 4 + i];
+      if (g.accumulate) v += g.C[(long)row * g.ldc + n];
       if (g.epi == GE_RELU) v = fmaxf(v, 0.f);
       else if (g.epi == GE_TANH) v = tanhf(v);
       else if (g.epi == GE_MUL_RELU_GRAD) v = g.Y[(long)row * g.ldy + n] > 0.f ? v : 0.f;
@@ -172,5 +173,85 @@ int launch_td(cpp_ctx* ctx, const float* q, const float* tq, const float* r, con
                      dq, loss);
   LAUNCH_CHECK();
   prof_end(ctx, K_TD);
+  return 0;
+}
+
+
+// NAF head (naf_cartpole.py:186-230) forward + backward, one row per thread iteration:
+//   L = [lower | exp(diag) | 0] from l_values; d = u - mu; z = L^T d; A = -1/2 |z|^2; Q = V + A;
+//   y = r + (mask*discount)*V'(s2); td = Q - y; loss = mean(td^2)
+// backward of the loss: dQ = 2 td / B; dz = -z dQ; dL[i][j] = d_i dz_j; dd = L dz;
+//   dl(off-diag) = dL, dl(diag) = dL * exp(l); d_mu = -dd, pushed through tanh: * (1 - mu^2).
+#define NAF_MAX_A 8
+__global__ __launch_bounds__(256) void naf_head_kernel(const NafHeadArgs a) {
+  __shared__ double red[256];
+  __shared__ int bad;
+  if (threadIdx.x == 0) bad = 0;
+  __syncthreads();
+  const int A = a.A, NL = A * (A + 1) / 2;
+  const float inv_b = 2.f / (float)a.B;
+  double s = 0.0;
+  int mybad = 0;
+  for (int b = threadIdx.x; b < a.B; b += 256) {
+    float L[NAF_MAX_A][NAF_MAX_A], d[NAF_MAX_A], z[NAF_MAX_A];
+    const float* lv = a.lv + (long)b * NL;
+    for (int i = 0; i < A; ++i) {
+      const int off = i * (i + 1) / 2;
+      for (int j = 0; j < A; ++j) L[i][j] = 0.f;
+      for (int j = 0; j < i; ++j) { L[i][j] = lv[off + j]; if (!isfinite(L[i][j])) mybad = 1; }
+      L[i][i] = expf(lv[off + i]);
+      if (!isfinite(lv[off + i]) || !isfinite(L[i][i])) mybad = 1;
+      d[i] = a.action[(long)b * A + i] - a.mu[(long)b * A + i];
+    }
+    float zz = 0.f;
+    for (int j = 0; j < A; ++j) {
+      float t = 0.f;
+      for (int i = j; i < A; ++i) t += L[i][j] * d[i];
+      z[j] = t; zz += t * t;
+    }
+    const float adv = -0.5f * zz;
+    const float q = a.value[b] + adv;
+    const float y = a.reward[b] + (a.mask[b] * a.discount) * a.target_value[b];
+    const float td = q - y;
+    if (a.adv) a.adv[b] = adv;
+    if (a.q) a.q[b] = q;
+    if (a.td) a.td[b] = td;
+    s += (double)td * (double)td;
+    if (a.d_value) {
+      const float dq = td * inv_b;
+      a.d_value[b] = dq;
+      float dz[NAF_MAX_A];
+      for (int j = 0; j < A; ++j) dz[j] = -z[j] * dq;
+      for (int i = 0; i < A; ++i) {
+        const int off = i * (i + 1) / 2;
+        float dd = 0.f;
+        for (int j = 0; j <= i; ++j) dd += L[i][j] * dz[j];
+        for (int j = 0; j < i; ++j) a.d_l[(long)b * NL + off + j] = d[i] * dz[j];
+        a.d_l[(long)b * NL + off + i] = d[i] * dz[i] * L[i][i];
+        const float m = a.mu[(long)b * A + i];
+        a.d_mu_z[(long)b * A + i] = -dd * (1.f - m * m);
+      }
+    }
+  }
+  if (mybad) atomicOr(&bad, 1);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float loss = (float)(red[0] / (double)a.B);
+    a.loss[0] = loss;
+    if (a.nonfinite && (bad || !isfinite(loss))) a.nonfinite[0] = 1;
+  }
+}
+
+int launch_naf_head(cpp_ctx* ctx, const NafHeadArgs& a) {
+  if (a.A > NAF_MAX_A) { cpp_set_error("naf head: action_dim %d > %d", a.A, NAF_MAX_A); return 1; }
+  prof_begin(ctx);
+  hipLaunchKernelGGL(naf_head_kernel, dim3(1), dim3(256), 0, ctx->stream, a);
+  LAUNCH_CHECK();
+  prof_end(ctx, K_NAF_HEAD);
   return 0;
 }

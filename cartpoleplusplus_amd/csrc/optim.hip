@@ -1,13 +1,14 @@
 // Optimiser kernels over the flat parameter buffers: global-norm clip (util.py:45-50,
-// tf.clip_by_global_norm) fused with the SGD apply (ddpg_cartpole.py:118-119, :213, :218), and the
-// target-network soft update (base_network.py:20-33).  Both gradient lists (actor, critic) are
-// handled by one launch each (blockIdx.y = list).  Reductions are two-stage and fixed-order.
+// tf.clip_by_global_norm) fused with the optimiser apply -- plain SGD for DDPG (ddpg_cartpole.py:118-119,
+// :213, :218); GradientDescent / Momentum / Adam for NAF (util.py:73-76, naf_cartpole.py:233-239) -- and the
+// target-network soft update (base_network.py:20-33).  All gradient lists are handled by one launch each
+// (blockIdx.y = segment).  Reductions are two-stage and fixed-order.
 #include "common.h"
 
 constexpr int OPT_THREADS = 256;
 
 // part[seg][blk] = sum over the block's slice of (grad_scale * g)^2, in f64
-__global__ __launch_bounds__(OPT_THREADS) void sumsq_kernel(const Seg2 s, float grad_scale,
+__global__ __launch_bounds__(OPT_THREADS) void sumsq_kernel(const OptSegs s, float grad_scale,
                                                             double* part, int nparts) {
   __shared__ double red[OPT_THREADS];
   const int seg = blockIdx.y;
@@ -27,43 +28,75 @@ __global__ __launch_bounds__(OPT_THREADS) void sumsq_kernel(const Seg2 s, float 
   if (threadIdx.x == 0) part[seg * nparts + blockIdx.x] = red[0];
 }
 
-int launch_sumsq(cpp_ctx* ctx, const Seg2& s, float grad_scale, double* part, int nparts) {
+int launch_sumsq(cpp_ctx* ctx, const OptSegs& s, float grad_scale, double* part, int nparts) {
   prof_begin(ctx);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(nparts, 2), dim3(OPT_THREADS), 0, ctx->stream, s, grad_scale,
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nparts, s.nseg), dim3(OPT_THREADS), 0, ctx->stream, s, grad_scale,
                      part, nparts);
   LAUNCH_CHECK();
   prof_end(ctx, K_SUMSQ);
   return 0;
 }
 
-// g <- g * clip * min(1/norm, 1/clip);  p <- p - lr * g      (clip <= 0: no clipping)
-__global__ __launch_bounds__(OPT_THREADS) void clip_sgd_kernel(const Seg2 s, float grad_scale,
-                                                               float clip, const double* part,
-                                                               int nparts, float* norms_out) {
-  __shared__ float sh_scale;
+// g <- g * clip * min(1/norm, 1/clip) with norm over the segment's group (clip <= 0: no clipping), then
+//   SGD      : p -= lr * g
+//   Momentum : m = momentum * m + g;  p -= lr * m
+//   Adam     : lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t);  m, v moments;  p -= lr_t * m / (sqrt(v) + eps)
+__global__ __launch_bounds__(OPT_THREADS) void opt_apply_kernel(const OptSegs s, float grad_scale,
+                                                                float clip, const double* part,
+                                                                int nparts, float* norms_out) {
+  __shared__ float sh_scale, sh_lr;
   const int seg = blockIdx.y;
   if (threadIdx.x == 0) {
     double tot = 0.0;
-    for (int i = 0; i < nparts; ++i) tot += part[seg * nparts + i];
+    for (int k = 0; k < s.nseg; ++k)
+      if (s.group[k] == s.group[seg])
+        for (int i = 0; i < nparts; ++i) tot += part[k * nparts + i];
     const float norm = (float)sqrt(tot);
     float sc = 1.f;
     if (clip > 0.f) sc = clip * fminf(1.f / norm, 1.f / clip);
     sh_scale = sc * grad_scale;
-    if (blockIdx.x == 0 && norms_out) norms_out[seg] = norm;
+    float lr = s.lr[seg];
+    if (s.kind == OPT_ADAM) {
+      const double t = (double)(*s.step);
+      lr = (float)((double)lr * sqrt(1.0 - pow((double)s.beta2, t)) / (1.0 - pow((double)s.beta1, t)));
+    }
+    sh_lr = lr;
+    if (blockIdx.x == 0 && norms_out && s.n[seg] > 0) norms_out[s.group[seg]] = norm;
   }
   __syncthreads();
-  const float sc = sh_scale, lr = s.lr[seg];
+  const float sc = sh_scale, lr = sh_lr;
   float* p = s.p[seg];
   const float* g = s.g[seg];
   const long n = s.n[seg];
-  for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * OPT_THREADS)
-    p[i] = p[i] - lr * (g[i] * sc);
+  const long stride = (long)gridDim.x * OPT_THREADS;
+  if (s.kind == OPT_SGD) {
+    for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += stride)
+      p[i] = p[i] - lr * (g[i] * sc);
+  } else if (s.kind == OPT_MOMENTUM) {
+    float* m = s.m[seg];
+    for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += stride) {
+      const float acc = s.momentum * m[i] + g[i] * sc;
+      m[i] = acc;
+      p[i] = p[i] - lr * acc;
+    }
+  } else {
+    float* m = s.m[seg];
+    float* v = s.v[seg];
+    const float b1 = s.beta1, b2 = s.beta2;
+    for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += stride) {
+      const float gi = g[i] * sc;
+      const float mi = b1 * m[i] + (1.f - b1) * gi;
+      const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+      m[i] = mi; v[i] = vi;
+      p[i] = p[i] - lr * mi / (sqrtf(vi) + s.epsilon);
+    }
+  }
 }
 
-int launch_clip_sgd(cpp_ctx* ctx, const Seg2& s, float grad_scale, float clip, const double* part,
-                    int nparts, float* norms_out) {
+int launch_opt_apply(cpp_ctx* ctx, const OptSegs& s, float grad_scale, float clip, const double* part,
+                     int nparts, float* norms_out) {
   prof_begin(ctx);
-  hipLaunchKernelGGL(clip_sgd_kernel, dim3(128, 2), dim3(OPT_THREADS), 0, ctx->stream, s, grad_scale,
+  hipLaunchKernelGGL(opt_apply_kernel, dim3(128, s.nseg), dim3(OPT_THREADS), 0, ctx->stream, s, grad_scale,
                      clip, part, nparts, norms_out);
   LAUNCH_CHECK();
   prof_end(ctx, K_CLIP_SGD);

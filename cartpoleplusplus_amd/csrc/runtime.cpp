@@ -53,7 +53,7 @@ void prof_end(cpp_ctx* ctx, int kid) {
 static const char* kKernelNames[K_NUM_KERNELS] = {
     "gather_stats", "stats_finalize", "stats_generic", "conv1_fwd", "conv2_fwd", "conv3_fwd",
     "conv1_dw", "conv2_dw", "conv3_dw", "conv2_dx", "conv3_dx", "dw_reduce", "gemm", "elementwise",
-    "td", "sumsq", "clip_sgd", "soft_update", "replay_fill"};
+    "td", "sumsq", "clip_sgd", "soft_update", "replay_fill", "naf_head"};
 
 // ---------------------------------------------------------------------------------------------
 // context
@@ -212,6 +212,9 @@ static int net_build(cpp_net* n) {
   if (s.kind == CPP_ACTOR) {
     for (int i = 0; i < s.n_hidden; ++i) { add_fc("h" + std::to_string(i), n_in, s.hidden[i], GE_RELU, 0); n_in = s.hidden[i]; }
     add_fc("output_action", n_in, A, GE_TANH, 0);                       // ddpg_cartpole.py:95-100
+  } else if (s.kind == CPP_HEAD) {                                      // naf_cartpole.py:104-109,156-161,180-184
+    for (int i = 0; i < s.n_hidden; ++i) { add_fc("h" + std::to_string(i), n_in, s.hidden[i], GE_RELU, 0); n_in = s.hidden[i]; }
+    add_fc("fc", n_in, s.head_out, s.head_act == 2 ? GE_TANH : GE_NONE, 0);
   } else if (s.pixel) {                                                 // ddpg_cartpole.py:168-171 (intent)
     add_fc("hidden1", n_in, 200, GE_RELU, 0);
     add_fc("hidden2", 200, 50, GE_RELU, 0);
@@ -254,13 +257,15 @@ static int ws_alloc(cpp_net* n, Workspace& w, int from_layer, bool trunk) {
 extern "C" int cpp_net_create(cpp_ctx* ctx, const cpp_net_spec* spec, int max_batch, cpp_net** out) {
   ARG_CHECK(ctx && spec && out, "cpp_net_create: NULL argument");
   ARG_CHECK(max_batch >= 1, "cpp_net_create: max_batch %d", max_batch);
-  ARG_CHECK(spec->kind == CPP_ACTOR || spec->kind == CPP_CRITIC, "cpp_net_create: kind %d", spec->kind);
+  ARG_CHECK(spec->kind == CPP_ACTOR || spec->kind == CPP_CRITIC || spec->kind == CPP_HEAD, "cpp_net_create: kind %d", spec->kind);
+  if (spec->kind == CPP_HEAD) ARG_CHECK(spec->head_out >= 1 && spec->head_out <= 64 && (spec->head_act == 0 || spec->head_act == 2),
+                                        "cpp_net_create: head_out %d head_act %d", spec->head_out, spec->head_act);
   ARG_CHECK(spec->action_dim >= 1 && spec->action_dim <= 16, "cpp_net_create: action_dim %d", spec->action_dim);
   ARG_CHECK(spec->n_hidden >= 0 && spec->n_hidden <= 8, "cpp_net_create: n_hidden %d", spec->n_hidden);
   if (spec->pixel) ARG_CHECK(spec->H >= 8 && spec->W >= 8 && spec->C >= 1 && spec->C <= CPP_MAX_CHANNELS,
                              "cpp_net_create: pixel dims %dx%dx%d", spec->H, spec->W, spec->C);
   else ARG_CHECK(spec->state_elems >= 1, "cpp_net_create: state_elems %d", spec->state_elems);
-  if (spec->kind == CPP_ACTOR || !spec->pixel) ARG_CHECK(spec->n_hidden >= 1, "cpp_net_create: need hidden layers");
+  if (spec->kind == CPP_ACTOR || (spec->kind == CPP_CRITIC && !spec->pixel)) ARG_CHECK(spec->n_hidden >= 1, "cpp_net_create: need hidden layers");
   HIP_CHECK(hipSetDevice(ctx->device));
   cpp_net* n = new cpp_net();
   n->ctx = ctx; n->spec = *spec; n->maxB = max_batch; n->arena.stream = ctx->stream;
@@ -343,8 +348,9 @@ extern "C" int cpp_net_soft_update(cpp_net* target, const cpp_net* source, float
 
 // --- launch sequences -------------------------------------------------------------------------
 static int gemm(cpp_ctx* ctx, const float* A, long sAm, long sAk, const float* Bm, long sBk, long sBn,
-                float* C, long ldc, int M, int N, int K, int epi, const float* Y = nullptr, long ldy = 0) {
-  GemmArgs g; g.A = A; g.sAm = sAm; g.sAk = sAk; g.B = Bm; g.sBk = sBk; g.sBn = sBn; g.C = C; g.ldc = ldc;
+                float* C, long ldc, int M, int N, int K, int epi, const float* Y = nullptr, long ldy = 0,
+                int accumulate = 0) {
+  GemmArgs g; g.accumulate = accumulate; g.A = A; g.sAm = sAm; g.sAk = sAk; g.B = Bm; g.sBk = sBk; g.sBn = sBn; g.C = C; g.ldc = ldc;
   g.Y = Y; g.ldy = ldy; g.M = M; g.N = N; g.K = K; g.epi = epi;
   return launch_gemm(ctx, g);
 }
@@ -394,11 +400,12 @@ static int net_forward_fc(cpp_net* n, Workspace& w, int from, int B, const float
 // Backward from w.dz[last] (gradient w.r.t. the last layer's pre-activation).  want_params: write
 // [dW; db] of every layer into n->grads, otherwise stop once d_action is known.  d_action: (B, A) out.
 static int net_backward(cpp_net* n, Workspace& w, int B, bool want_params, float* d_action,
-                        const void* state, int dtype, const float* white) {
+                        const void* state, int dtype, const float* white, int start_layer = -2) {
   cpp_ctx* ctx = n->ctx;
   const int nfc = (int)n->fc.size(), A = n->spec.action_dim;
   if (want_params && !n->grads) { cpp_set_error("network has no gradient buffer"); return CPP_ERR_STATE; }
-  for (int l = nfc - 1; l >= 0; --l) {
+  if (start_layer == -2) start_layer = nfc - 1;       // -1: only the conv trunk (w.dpool[2] already holds d flat)
+  for (int l = start_layer; l >= 0; --l) {
     const FcL& L = n->fc[l];
     const float* dz = w.dz[l];
     const float* W = n->params + L.w_off;
@@ -468,7 +475,7 @@ extern "C" int cpp_net_forward(cpp_net* n, const void* state, int state_dtype, i
   ARG_CHECK(n && state && out, "cpp_net_forward: NULL argument");
   ARG_CHECK(B >= 1 && B <= n->maxB, "cpp_net_forward: batch %d outside [1,%d]", B, n->maxB);
   ARG_CHECK(state_dtype == CPP_F32 || state_dtype == CPP_F16, "cpp_net_forward: dtype %d", state_dtype);
-  ARG_CHECK(n->spec.kind == CPP_ACTOR || action, "cpp_net_forward: critic needs an action batch");
+  ARG_CHECK(n->spec.kind != CPP_CRITIC || action, "cpp_net_forward: critic needs an action batch");
   cpp_ctx* ctx = n->ctx;
   HIP_CHECK(hipSetDevice(ctx->device));
   const int A = n->spec.action_dim, no = n->fc.back().n_out;
@@ -795,7 +802,7 @@ extern "C" int cpp_ddpg_create(cpp_ctx* ctx, cpp_net* actor, cpp_net* critic, cp
   if (!rc) rc = dalloc(d->arena, &d->dq, (size_t)d->maxB);
   if (!rc) rc = dalloc(d->arena, &d->ones, (size_t)d->maxB);
   if (!rc) rc = dalloc(d->arena, &d->loss_norms, (size_t)4);
-  if (!rc) rc = dalloc(d->arena, &d->norm_part, (size_t)2 * NORM_PARTS);
+  if (!rc) rc = dalloc(d->arena, &d->norm_part, (size_t)OPT_MAX_SEGS * NORM_PARTS);
   if (!rc) rc = launch_fill(ctx, d->ones, 1, 0, 1, d->maxB, 1.0f);
   if (rc) { d->arena.release(); delete d; return rc; }
   actor->grads = d->gradbuf; critic->grads = d->gradbuf + d->nA;
@@ -901,12 +908,13 @@ static int critic_gradients(cpp_ddpg* d, cpp_batch* b, bool critic_prefix_done, 
 }
 
 static int apply(cpp_ddpg* d, bool do_actor, bool do_critic, float grad_scale) {
-  Seg2 s;
-  s.p[0] = d->actor->params; s.g[0] = d->gradbuf; s.n[0] = do_actor ? d->nA : 0; s.lr[0] = d->hp.actor_learning_rate;
-  s.p[1] = d->critic->params; s.g[1] = d->gradbuf + d->nA; s.n[1] = do_critic ? d->nC : 0; s.lr[1] = d->hp.critic_learning_rate;
+  OptSegs s; memset(&s, 0, sizeof(s));
+  s.nseg = 2; s.kind = OPT_SGD;
+  s.p[0] = d->actor->params; s.g[0] = d->gradbuf; s.n[0] = do_actor ? d->nA : 0; s.lr[0] = d->hp.actor_learning_rate; s.group[0] = 0;
+  s.p[1] = d->critic->params; s.g[1] = d->gradbuf + d->nA; s.n[1] = do_critic ? d->nC : 0; s.lr[1] = d->hp.critic_learning_rate; s.group[1] = 1;
   RC(launch_sumsq(d->ctx, s, grad_scale, d->norm_part, NORM_PARTS));
-  // norms_out is only written for lists that were applied (n > 0)
-  RC(launch_clip_sgd(d->ctx, s, grad_scale, d->hp.gradient_clip, d->norm_part, NORM_PARTS, d->loss_norms + 1));
+  // norms_out[group] is only written for lists that were applied (n > 0)
+  RC(launch_opt_apply(d->ctx, s, grad_scale, d->hp.gradient_clip, d->norm_part, NORM_PARTS, d->loss_norms + 1));
   return CPP_OK;
 }
 
@@ -1081,5 +1089,296 @@ extern "C" int cpp_ddpg_last_stats(cpp_ddpg* d, float out[3]) {
   ARG_CHECK(d && out, "cpp_ddpg_last_stats: NULL argument");
   HIP_CHECK(hipMemcpyAsync(out, d->loss_norms, 3 * sizeof(float), hipMemcpyDeviceToHost, d->ctx->stream));
   HIP_CHECK(hipStreamSynchronize(d->ctx->stream));
+  return CPP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NAF (naf_cartpole.py)
+// ---------------------------------------------------------------------------------------------
+struct cpp_naf {
+  cpp_ctx* ctx; cpp_net *value, *tvalue, *mu, *lv; int share; cpp_naf_hyper hp;
+  int maxB, A, NL; long nV, nM, nL;
+  float* gradbuf; float *m, *v;           // optimiser state over the same flat layout (Momentum / Adam)
+  float *adv, *q, *td, *stats;            // stats: [0] loss [1] norm
+  int* nonfinite; uint64_t* opt_step; double* norm_part;
+  hipGraph_t graph; hipGraphExec_t gexec; bool graph_ok; int g_B, g_nb; uint64_t g_seed; cpp_replay* g_replay;
+  cpp_batch* step_batch;
+  Arena arena;
+};
+
+extern "C" int cpp_naf_create(cpp_ctx* ctx, cpp_net* value, cpp_net* tvalue, cpp_net* mu, cpp_net* lv, int share,
+                              const cpp_naf_hyper* hp, cpp_naf** out) {
+  ARG_CHECK(ctx && value && tvalue && mu && lv && hp && out, "cpp_naf_create: NULL argument");
+  for (cpp_net* n : {value, tvalue, mu, lv}) ARG_CHECK(n->spec.kind == CPP_HEAD, "cpp_naf_create: networks must be CPP_HEAD");
+  ARG_CHECK(value->spec.head_out == 1 && tvalue->spec.head_out == 1 && value->nparams == tvalue->nparams,
+            "cpp_naf_create: value / target_value shapes");
+  const int A = mu->spec.head_out;
+  ARG_CHECK(A >= 1 && A <= 8 && lv->spec.head_out == A * (A + 1) / 2, "cpp_naf_create: mu has %d outputs, l_values %d (want A and A(A+1)/2)",
+            A, lv->spec.head_out);
+  ARG_CHECK(mu->spec.head_act == 2 && lv->spec.head_act == 0 && value->spec.head_act == 0, "cpp_naf_create: head activations");
+  ARG_CHECK(hp->optimiser >= CPP_OPT_SGD && hp->optimiser <= CPP_OPT_ADAM, "cpp_naf_create: optimiser %d", hp->optimiser);
+  const int rep = value->fc.back().n_in;
+  if (share) {
+    for (cpp_net* n : {mu, lv})
+      ARG_CHECK(!n->spec.pixel && n->fc.size() == 1 && n->fc[0].n_in == rep,
+                "cpp_naf_create: shared heads must be head-only nets over the %d-wide representation", rep);
+  } else {
+    for (cpp_net* n : {mu, lv}) ARG_CHECK(n->state_elems == value->state_elems, "cpp_naf_create: state shapes differ");
+  }
+  HIP_CHECK(hipSetDevice(ctx->device));
+  cpp_naf* f = new cpp_naf();
+  f->arena.stream = ctx->stream;
+  f->ctx = ctx; f->value = value; f->tvalue = tvalue; f->mu = mu; f->lv = lv; f->share = share; f->hp = *hp;
+  f->maxB = value->maxB; f->A = A; f->NL = A * (A + 1) / 2;
+  for (cpp_net* n : {tvalue, mu, lv}) if (n->maxB < f->maxB) f->maxB = n->maxB;
+  f->nV = value->nparams; f->nM = mu->nparams; f->nL = lv->nparams;
+  f->graph = nullptr; f->gexec = nullptr; f->graph_ok = false; f->step_batch = nullptr; f->g_replay = nullptr;
+  const size_t nall = (size_t)(f->nV + f->nM + f->nL);
+  int rc = dalloc(f->arena, &f->gradbuf, nall);
+  if (!rc) rc = dalloc(f->arena, &f->m, nall);
+  if (!rc) rc = dalloc(f->arena, &f->v, nall);
+  if (!rc) rc = dalloc(f->arena, &f->adv, (size_t)f->maxB);
+  if (!rc) rc = dalloc(f->arena, &f->q, (size_t)f->maxB);
+  if (!rc) rc = dalloc(f->arena, &f->td, (size_t)f->maxB);
+  if (!rc) rc = dalloc(f->arena, &f->stats, (size_t)4);
+  if (!rc) rc = dalloc(f->arena, &f->nonfinite, (size_t)1);
+  if (!rc) rc = dalloc(f->arena, &f->opt_step, (size_t)1);
+  if (!rc) rc = dalloc(f->arena, &f->norm_part, (size_t)OPT_MAX_SEGS * NORM_PARTS);
+  if (rc) { f->arena.release(); delete f; return rc; }
+  value->grads = f->gradbuf; mu->grads = f->gradbuf + f->nV; lv->grads = f->gradbuf + f->nV + f->nM;
+  if (share) {      // the heads read value's input_state_representation in place (naf_cartpole.py:151-152,176-177)
+    mu->ws[0].fcin[0] = value->ws[0].fcin.back();
+    lv->ws[0].fcin[0] = value->ws[0].fcin.back();
+  }
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  *out = f;
+  return CPP_OK;
+}
+
+extern "C" int cpp_naf_destroy(cpp_naf* f) {
+  if (!f) return CPP_OK;
+  (void)hipSetDevice(f->ctx->device);
+  (void)hipStreamSynchronize(f->ctx->stream);
+  if (f->gexec) (void)hipGraphExecDestroy(f->gexec);
+  if (f->graph) (void)hipGraphDestroy(f->graph);
+  if (f->step_batch) cpp_batch_destroy(f->step_batch);
+  f->value->grads = nullptr; f->mu->grads = nullptr; f->lv->grads = nullptr;
+  f->arena.release(); delete f; return CPP_OK;
+}
+
+static int naf_check_batch(cpp_naf* f, cpp_batch* b, const char* who) {
+  ARG_CHECK(f && b, "%s: NULL argument", who);
+  ARG_CHECK(b->B >= 1 && b->B <= f->maxB, "%s: batch size %d outside [1,%d]", who, b->B, f->maxB);
+  ARG_CHECK(b->elems == f->value->state_elems && b->A == f->A, "%s: batch shape does not match the networks", who);
+  if (f->value->spec.pixel) RC(batch_ensure_stats(b, f->value->spec.C));
+  return CPP_OK;
+}
+
+// value / mu / l_values on state_1 (device pointer), optionally V'(state_2)
+static int naf_forward(cpp_naf* f, const void* s1, const void* s2, int dtype, const float* w1, const float* w2, int B) {
+  cpp_net *v = f->value, *tv = f->tvalue;
+  RC(net_forward_trunk(v, v->ws[0], s1, dtype, w1, B));
+  RC(net_forward_fc(v, v->ws[0], 0, B, nullptr));
+  for (cpp_net* n : {f->mu, f->lv}) {
+    if (!f->share) RC(net_forward_trunk(n, n->ws[0], s1, dtype, w1, B));
+    RC(net_forward_fc(n, n->ws[0], 0, B, nullptr));
+  }
+  if (s2) {
+    RC(net_forward_trunk(tv, tv->ws[0], s2, dtype, w2, B));
+    RC(net_forward_fc(tv, tv->ws[0], 0, B, nullptr));
+  }
+  return CPP_OK;
+}
+
+static int naf_head(cpp_naf* f, cpp_batch* b, bool backward) {
+  NafHeadArgs a; memset(&a, 0, sizeof(a));
+  a.value = f->value->ws[0].out; a.mu = f->mu->ws[0].out; a.lv = f->lv->ws[0].out;
+  a.action = b->a; a.reward = b->r; a.mask = b->m; a.target_value = f->tvalue->ws[0].out;
+  a.discount = f->hp.discount; a.B = b->B; a.A = f->A;
+  a.adv = f->adv; a.q = f->q; a.td = f->td; a.loss = f->stats; a.nonfinite = f->nonfinite;
+  if (backward) {
+    a.d_value = f->value->ws[0].dz.back(); a.d_mu_z = f->mu->ws[0].dz.back(); a.d_l = f->lv->ws[0].dz.back();
+  }
+  return launch_naf_head(f->ctx, a);
+}
+
+static int naf_compute_gradients(cpp_naf* f, cpp_batch* b) {
+  cpp_ctx* ctx = f->ctx;
+  cpp_net *v = f->value, *mu = f->mu, *lv = f->lv;
+  const int B = b->B, C = v->spec.pixel ? v->spec.C : 0;
+  const float *w1 = white_of(b, 0, C), *w2 = white_of(b, 1, C);
+  RC(naf_forward(f, b->s[0], b->s[1], b->dtype, w1, w2, B));
+  RC(naf_head(f, b, true));
+  if (!f->share) {
+    RC(net_backward(v, v->ws[0], B, true, nullptr, b->s[0], b->dtype, w1));
+    RC(net_backward(mu, mu->ws[0], B, true, nullptr, b->s[0], b->dtype, w1));
+    RC(net_backward(lv, lv->ws[0], B, true, nullptr, b->s[0], b->dtype, w1));
+    return CPP_OK;
+  }
+  // shared representation: head gradients, then d(rep) = sum of the three heads' contributions
+  const int Lh = (int)v->fc.size() - 1;          // index of value's 'fc' head
+  const FcL& hv = v->fc[Lh];
+  const int rep = hv.n_in;
+  struct Head { cpp_net* n; const FcL* L; const float* dz; };
+  Head heads[3] = {{v, &hv, v->ws[0].dz[Lh]}, {mu, &mu->fc[0], mu->ws[0].dz[0]}, {lv, &lv->fc[0], lv->ws[0].dz[0]}};
+  float* drep; long ldd; int final_epi = GE_NONE; const float* Y = nullptr; long ldy = 0;
+  if (Lh > 0) { drep = v->ws[0].dz[Lh - 1]; ldd = rep; final_epi = GE_MUL_RELU_GRAD; Y = v->ws[0].fcin[Lh]; ldy = rep + 1; }
+  else if (v->spec.pixel) { drep = v->ws[0].dpool[2]; ldd = rep; }
+  else { drep = nullptr; ldd = 0; }
+  for (int k = 0; k < 3; ++k) {
+    const Head& h = heads[k];
+    const float* x = v->ws[0].fcin[Lh];          // [rep, 1] rows, shared by the three heads
+    RC(gemm(ctx, x, 1, rep + 1, h.dz, h.L->n_out, 1, h.n->grads + h.L->w_off, h.L->n_out, rep + 1, h.L->n_out, B, GE_NONE));
+    if (drep)
+      RC(gemm(ctx, h.dz, h.L->n_out, 1, h.n->params + h.L->w_off, 1, h.L->n_out, drep, ldd, B, rep, h.L->n_out,
+              k == 2 ? final_epi : GE_NONE, k == 2 ? Y : nullptr, ldy, k > 0));
+  }
+  return net_backward(v, v->ws[0], B, true, nullptr, b->s[0], b->dtype, w1, Lh - 1);
+}
+
+static int naf_apply(cpp_naf* f, float grad_scale) {
+  OptSegs s; memset(&s, 0, sizeof(s));
+  s.nseg = 3; s.kind = f->hp.optimiser; s.momentum = f->hp.momentum; s.beta1 = f->hp.beta1; s.beta2 = f->hp.beta2;
+  s.epsilon = f->hp.epsilon; s.step = f->opt_step;
+  cpp_net* nets[3] = {f->value, f->mu, f->lv};
+  long off = 0;
+  for (int k = 0; k < 3; ++k) {
+    s.p[k] = nets[k]->params; s.g[k] = f->gradbuf + off; s.m[k] = f->m + off; s.v[k] = f->v + off;
+    s.n[k] = nets[k]->nparams; s.lr[k] = f->hp.learning_rate; s.group[k] = 0;      // ONE list, one global norm
+    off += nets[k]->nparams;
+  }
+  RC(launch_counter_add(f->ctx, f->opt_step, 1));
+  RC(launch_sumsq(f->ctx, s, grad_scale, f->norm_part, NORM_PARTS));
+  return launch_opt_apply(f->ctx, s, grad_scale, f->hp.gradient_clip, f->norm_part, NORM_PARTS, f->stats + 1);
+}
+
+extern "C" int cpp_naf_action(cpp_naf* f, const void* state, int dtype, int B, float* out) {
+  ARG_CHECK(f && state && out, "cpp_naf_action: NULL argument");
+  ARG_CHECK(B >= 1 && B <= f->maxB, "cpp_naf_action: batch %d outside [1,%d]", B, f->maxB);
+  ARG_CHECK(dtype == CPP_F32 || dtype == CPP_F16, "cpp_naf_action: dtype %d", dtype);
+  cpp_ctx* ctx = f->ctx;
+  cpp_net* n = f->share ? f->value : f->mu;       // the network whose trunk sees the state
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (!n->stage_state) {
+    RC(n->arena.alloc(&n->stage_state, (size_t)n->maxB * n->state_elems * sizeof(float), false));
+    RC(dalloc(n->arena, &n->stage_action, (size_t)n->maxB * f->A));
+  }
+  HIP_CHECK(hipMemcpyAsync(n->stage_state, state, (size_t)B * n->state_elems * (dtype == CPP_F16 ? 2 : 4), hipMemcpyHostToDevice, ctx->stream));
+  if (n->spec.pixel) RC(batch_stats(ctx, n->stage_state, nullptr, dtype, n->state_elems, B, n->spec.C, n->stats_part, n->white));
+  RC(net_forward_trunk(n, n->ws[0], n->stage_state, dtype, n->white, B));
+  RC(net_forward_fc(n, n->ws[0], 0, B, nullptr));
+  if (f->share) RC(net_forward_fc(f->mu, f->mu->ws[0], 0, B, nullptr));
+  HIP_CHECK(hipMemcpyAsync(out, f->mu->ws[0].out, (size_t)B * f->A * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return CPP_OK;
+}
+
+extern "C" int cpp_naf_compute_gradients(cpp_naf* f, cpp_batch* b) {
+  RC(naf_check_batch(f, b, "cpp_naf_compute_gradients"));
+  HIP_CHECK(hipSetDevice(f->ctx->device));
+  return naf_compute_gradients(f, b);
+}
+extern "C" int cpp_naf_grad_buffer(cpp_naf* f, void** p, int64_t* n) {
+  ARG_CHECK(f && p && n, "cpp_naf_grad_buffer: NULL argument");
+  *p = f->gradbuf; *n = f->nV + f->nM + f->nL;
+  return CPP_OK;
+}
+extern "C" int cpp_naf_apply_gradients(cpp_naf* f, float grad_scale) {
+  ARG_CHECK(f, "cpp_naf_apply_gradients: NULL argument");
+  HIP_CHECK(hipSetDevice(f->ctx->device));
+  return naf_apply(f, grad_scale);
+}
+extern "C" int cpp_naf_update_targets(cpp_naf* f) {
+  ARG_CHECK(f, "cpp_naf_update_targets: NULL argument");
+  HIP_CHECK(hipSetDevice(f->ctx->device));
+  return launch_soft_update(f->ctx, f->tvalue->params, f->value->params, f->nV, nullptr, nullptr, 0, f->hp.target_update_rate);
+}
+
+extern "C" int cpp_naf_train(cpp_naf* f, cpp_batch* b, float* loss) {
+  RC(naf_check_batch(f, b, "cpp_naf_train"));
+  cpp_ctx* ctx = f->ctx;
+  HIP_CHECK(hipSetDevice(ctx->device));
+  HIP_CHECK(hipMemsetAsync(f->nonfinite, 0, sizeof(int), ctx->stream));
+  RC(naf_compute_gradients(f, b));
+  int bad = 0; float l = 0.f;
+  HIP_CHECK(hipMemcpyAsync(&bad, f->nonfinite, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipMemcpyAsync(&l, f->stats, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (loss) *loss = l;
+  if (bad) { cpp_set_error("check_numerics: l_values / L / loss is not finite (naf_cartpole.py:242-245)"); return CPP_ERR_NUMERIC; }
+  return naf_apply(f, 1.0f);
+}
+
+extern "C" int cpp_naf_debug_values(cpp_naf* f, cpp_batch* b, float* l_values, float* loss, float* value, float* advantage,
+                                    float* target_value) {
+  RC(naf_check_batch(f, b, "cpp_naf_debug_values"));
+  cpp_ctx* ctx = f->ctx;
+  HIP_CHECK(hipSetDevice(ctx->device));
+  const int B = b->B, C = f->value->spec.pixel ? f->value->spec.C : 0;
+  RC(naf_forward(f, b->s[0], b->s[1], b->dtype, white_of(b, 0, C), white_of(b, 1, C), B));
+  RC(naf_head(f, b, false));
+  hipStream_t st = ctx->stream;
+  if (l_values) HIP_CHECK(hipMemcpyAsync(l_values, f->lv->ws[0].out, (size_t)B * f->NL * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (loss) HIP_CHECK(hipMemcpyAsync(loss, f->stats, sizeof(float), hipMemcpyDeviceToHost, st));
+  if (value) HIP_CHECK(hipMemcpyAsync(value, f->value->ws[0].out, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (advantage) HIP_CHECK(hipMemcpyAsync(advantage, f->adv, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (target_value) HIP_CHECK(hipMemcpyAsync(target_value, f->tvalue->ws[0].out, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  return CPP_OK;
+}
+
+static int naf_step_body(cpp_naf* f, cpp_replay* r, int B, int n_batches, const int32_t* rows_dev, uint64_t seed) {
+  const int C = f->value->spec.pixel ? f->value->spec.C : 0;
+  for (int i = 0; i < n_batches; ++i) {
+    RC(replay_sample_device(r, B, rows_dev ? rows_dev + (size_t)i * B : nullptr, seed, rows_dev ? nullptr : r->counter, C, f->step_batch));
+    if (!rows_dev) RC(launch_counter_add(f->ctx, r->counter, 1));
+    RC(naf_compute_gradients(f, f->step_batch));
+    RC(naf_apply(f, 1.0f));
+  }
+  return cpp_naf_update_targets(f);
+}
+
+extern "C" int cpp_naf_train_step(cpp_naf* f, cpp_replay* r, int B, int n_batches, const int32_t* idxs, uint64_t seed) {
+  ARG_CHECK(f && r, "cpp_naf_train_step: NULL argument");
+  ARG_CHECK(B >= 1 && B <= f->maxB, "cpp_naf_train_step: batch %d outside [1,%d]", B, f->maxB);
+  ARG_CHECK(n_batches >= 1 && (size_t)n_batches * B <= 65536, "cpp_naf_train_step: n_batches %d", n_batches);
+  ARG_CHECK(r->elems == f->value->state_elems && r->A == f->A, "cpp_naf_train_step: replay shape does not match the networks");
+  if (r->size <= 0) { cpp_set_error("cpp_naf_train_step: replay memory is empty"); return CPP_ERR_STATE; }
+  cpp_ctx* ctx = f->ctx;
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (!f->step_batch) RC(cpp_batch_create(ctx, f->maxB, r->elems, r->A, &f->step_batch));
+  if (idxs) {
+    for (int i = 0; i < n_batches * B; ++i)
+      ARG_CHECK(idxs[i] >= 0 && idxs[i] < r->size, "cpp_naf_train_step: index %d outside [0,%d)", idxs[i], r->size);
+    HIP_CHECK(hipMemcpyAsync(r->rows_in, idxs, (size_t)n_batches * B * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    return naf_step_body(f, r, B, n_batches, r->rows_in, seed);
+  }
+  if (ctx->prof) return naf_step_body(f, r, B, n_batches, nullptr, seed);
+  if (!f->graph_ok || f->g_B != B || f->g_nb != n_batches || f->g_seed != seed || f->g_replay != r) {
+    if (f->gexec) { (void)hipGraphExecDestroy(f->gexec); f->gexec = nullptr; }
+    if (f->graph) { (void)hipGraphDestroy(f->graph); f->graph = nullptr; }
+    f->graph_ok = false;
+    RC(naf_step_body(f, r, B, n_batches, nullptr, seed));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    int rc = naf_step_body(f, r, B, n_batches, nullptr, seed);
+    hipError_t e = hipStreamEndCapture(ctx->stream, &f->graph);
+    if (rc) return rc;
+    if (e != hipSuccess) { cpp_set_error("hipStreamEndCapture -> %s", hipGetErrorString(e)); return CPP_ERR_HIP; }
+    HIP_CHECK(hipGraphInstantiate(&f->gexec, f->graph, nullptr, nullptr, 0));
+    f->graph_ok = true; f->g_B = B; f->g_nb = n_batches; f->g_seed = seed; f->g_replay = r;
+    return CPP_OK;
+  }
+  HIP_CHECK(hipGraphLaunch(f->gexec, ctx->stream));
+  return CPP_OK;
+}
+
+extern "C" int cpp_naf_last_stats(cpp_naf* f, float out[3]) {
+  ARG_CHECK(f && out, "cpp_naf_last_stats: NULL argument");
+  int bad = 0;
+  HIP_CHECK(hipMemcpyAsync(out, f->stats, 2 * sizeof(float), hipMemcpyDeviceToHost, f->ctx->stream));
+  HIP_CHECK(hipMemcpyAsync(&bad, f->nonfinite, sizeof(int), hipMemcpyDeviceToHost, f->ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
+  out[2] = (float)bad;
   return CPP_OK;
 }

@@ -1,0 +1,350 @@
+#!/usr/bin/env python
+"""NAF agent for cartpole++ with the interface of the reference's naf_cartpole.py, on the same HIP
+kernels as the DDPG path (conv trunk, MFMA MLP heads, fused clip + optimiser) plus a small fused NAF head
+kernel (L matrix, advantage, TD loss and their gradients).
+
+Reference surface kept (paths relative to /root/reference/naf_cartpole.py): flags :18-67, ValueNetwork
+:93-114 (`value`, `input_state_representation`, `value_given`), NafNetwork :117-284 (`action_given`,
+`train(batch) -> loss`, `debug_values`, attrs `input_state`, `input_action`, `output_action`, `q_value`,
+`advantage`, `loss`, `train_op`, `exploration_noise`), NormalizedAdvantageFunctionAgent :287-456.
+tf.check_numerics (:242-245) becomes a device flag: `train` raises FloatingPointError when l_values, L or
+the loss is not finite.
+"""
+import argparse
+import collections
+import ctypes as C
+import datetime
+import json
+import sys
+import time
+
+import numpy as np
+
+from . import _lib, base_network, replay_memory, util
+from ._lib import lib, check, ptr
+
+VERBOSE_DEBUG = False
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    a = parser.add_argument
+    a('--num-eval', type=int, default=0, help="if >0 just run this many episodes with no training")
+    a('--max-num-actions', type=int, default=0, help="train for (at least) this number of actions")
+    a('--max-run-time', type=int, default=0, help="train for (at least) this number of seconds")
+    a('--ckpt-dir', type=str, default=None, help="if set save ckpts to this dir")
+    a('--ckpt-freq', type=int, default=3600, help="freq (sec) to save ckpts")
+    a('--batch-size', type=int, default=128, help="training batch size")
+    a('--batches-per-step', type=int, default=5, help="number of batches to train per step")
+    a('--dont-do-rollouts', action="store_true", help="train from the replay memory only")
+    a('--target-update-rate', type=float, default=0.0001, help="affine combo for updating target networks")
+    a('--share-input-state-representation', action='store_true',
+      help="one network for processing input state shared between value, l_value and output_action networks")
+    a('--hidden-layers', type=str, default="100,50", help="hidden layer sizes")
+    a('--use-batch-norm', action='store_true', help="whether to use batch norm on conv layers")
+    a('--discount', type=float, default=0.99, help="discount for RHS of bellman equation update")
+    a('--event-log-in', type=str, default=None, help="prepopulate replay memory from this event log")
+    a('--replay-memory-size', type=int, default=22000, help="max size of replay memory")
+    a('--replay-memory-burn-in', type=int, default=1000, help="dont train until replay memory reaches this size")
+    a('--eval-action-noise', action='store_true', help="whether to use noise during eval")
+    a('--action-noise-theta', type=float, default=0.01, help="OrnsteinUhlenbeckNoise theta")
+    a('--action-noise-sigma', type=float, default=0.05, help="OrnsteinUhlenbeckNoise sigma")
+    util.add_opts(parser)
+    a('--action-repeats', type=int, default=2, help="number of action repeats")
+    a('--num-cameras', type=int, default=1, help="how many camera points to render; 1 or 2")
+    a('--max-episode-len', type=int, default=200, help="maximum episode len for cartpole")
+    a('--use-raw-pixels', action='store_true', help="use raw pixels as state instead of poses")
+    a('--render-width', type=int, default=50, help="if --use-raw-pixels render with this width")
+    a('--render-height', type=int, default=50, help="if --use-raw-pixels render with this height")
+    a('--host-rng-sampling', action='store_true', help="draw minibatch rows with numpy's RNG like the reference")
+    a('--sample-seed', type=int, default=0, help="seed of the device-side minibatch sampler")
+    a('--synthetic-env', action='store_true', help="random-frame stand-in env")
+    return parser
+
+
+def default_opts(**overrides):
+    o = build_parser().parse_args([])
+    for k, v in overrides.items():
+        assert hasattr(o, k), k
+        setattr(o, k, v)
+    return o
+
+
+opts = default_opts()
+
+
+def set_opts(o):
+    global opts
+    opts = o
+
+
+class _Op(object):
+    def __init__(self, name):
+        self.name = name
+
+
+def _forward_host(net, states, n_out):
+    s, dt = _lib.as_state_array(states)
+    B = s.shape[0]
+    out = np.empty((B, n_out), np.float32)
+    check(lib.cpp_net_forward(net.handle, ptr(s), dt, B, None, ptr(out)))
+    return out
+
+
+class ValueNetwork(base_network.Network):
+    """ Value network component of a NAF network. Created as seperate net because it has a target network."""
+
+    def __init__(self, namespace, input_state, hidden_layer_config):
+        super(ValueNetwork, self).__init__(namespace)
+        self.input_state = input_state
+        opts.hidden_layers = hidden_layer_config
+        # exposed since it is the network "shared" by the l_value & output_action heads when running
+        # --share-input-state-representation
+        self.input_state_representation = self.input_state_network(input_state, opts)
+        self._build_native(_lib.CPP_HEAD, 1, max(int(opts.batch_size), 1), head_out=1, head_act=0)
+        self.value = _Op(namespace + "/fc")
+
+    def value_given(self, state):
+        return _forward_host(self, state, 1)
+
+
+class _HeadNetwork(base_network.Network):
+    """'naf/output_action' or 'naf/l_values': its own state network + 'fc' head, or (shared mode) just the
+    'fc' head on top of the value network's representation (naf_cartpole.py:149-161, :174-184)."""
+
+    def __init__(self, namespace, input_state, value_net, head_out, head_act):
+        super(_HeadNetwork, self).__init__(namespace)
+        if opts.share_input_state_representation:
+            self._state_elems = int(value_net.input_state_representation.get_shape()[1])
+            self._hidden, self._conv_input = [], None
+        else:
+            self.input_state_network(input_state, opts)
+        self._build_native(_lib.CPP_HEAD, head_out, max(int(opts.batch_size), 1), head_out=head_out, head_act=head_act)
+
+
+class NafNetwork(base_network.Network):
+    def __init__(self, namespace, input_state, input_state_2, value_net, target_value_net, action_dim):
+        super(NafNetwork, self).__init__(namespace)
+        self.exploration_noise = util.OrnsteinUhlenbeckNoise(action_dim, opts.action_noise_theta,
+                                                             opts.action_noise_sigma)
+        self.value_net, self.target_value_net = value_net, target_value_net
+        self.input_state, self.input_state_2 = input_state, input_state_2
+        self.action_dim = int(action_dim)
+        self.input_action = base_network.Placeholder([None, action_dim], name="input_action")
+        self.reward = base_network.Placeholder([None, 1], name="reward")
+        self.terminal_mask = base_network.Placeholder([None, 1], name="terminal_mask")
+        self.ctx = value_net.ctx
+        num_l_values = (action_dim * (action_dim + 1)) // 2
+        self.mu_net = _HeadNetwork(namespace + "/output_action", input_state, value_net, action_dim, 2)
+        self.l_net = _HeadNetwork(namespace + "/l_values", input_state, value_net, num_l_values, 0)
+        self.output_action = _Op(namespace + "/output_action/fc")
+        self._l_values = _Op(namespace + "/l_values/fc")
+        self.advantage, self.q_value = _Op(namespace + "/advantage"), _Op(namespace + "/q_value")
+        self.loss, self.train_op = _Op(namespace + "/loss"), _Op(namespace + "/optimiser/train_op")
+        kind, lr, mom, b1, b2, eps = util.construct_optimiser(opts)              # :233
+        hp = _lib.NafHyper(float(opts.discount), util.gradient_clip_value(opts), float(opts.target_update_rate),
+                           kind, lr, mom, b1, b2, eps)
+        h = C.c_void_p()
+        check(lib.cpp_naf_create(self.ctx.handle, value_net.handle, target_value_net.handle, self.mu_net.handle,
+                                 self.l_net.handle, 1 if opts.share_input_state_representation else 0,
+                                 C.byref(hp), C.byref(h)))
+        self.handle = h
+        self._state_elems = int(np.prod([int(d) for d in input_state.get_shape()[1:]]))
+        self._upload = {}
+
+    def trainable_model_vars(self):
+        return self.mu_net.trainable_model_vars() + self.l_net.trainable_model_vars()
+
+    def initialise_variables(self, rng=None):
+        self.mu_net.initialise_variables(rng)
+        self.l_net.initialise_variables(rng)
+
+    def _device_batch(self, batch):
+        if isinstance(batch, replay_memory.Batch) and batch.device is not None:
+            return batch.device
+        B = np.asarray(batch.state_1).shape[0]
+        if B not in self._upload:
+            self._upload[B] = replay_memory.DeviceBatch(B, self._state_elems, self.action_dim, self.ctx)
+        return self._upload[B].upload(batch.state_1, batch.action, batch.reward, batch.terminal_mask, batch.state_2)
+
+    def forward(self, states):
+        s, dt = _lib.as_state_array(states)
+        out = np.empty((s.shape[0], self.action_dim), np.float32)
+        check(lib.cpp_naf_action(self.handle, ptr(s), dt, s.shape[0], ptr(out)))
+        return out
+
+    def action_given(self, state, add_noise):
+        actions = self.forward(np.asarray(state)[None])
+        if add_noise:
+            actions[0] += self.exploration_noise.sample()
+            actions = np.minimum(1, actions)     # np.clip(1, -1, actions): upper bound only (:259)
+        return actions
+
+    def train(self, batch):
+        dev = self._device_batch(batch)
+        loss = C.c_float()
+        rc = lib.cpp_naf_train(self.handle, dev.handle, C.byref(loss))
+        if rc == 4:          # CPP_ERR_NUMERIC: the reference raises InvalidArgumentError from tf.check_numerics
+            raise FloatingPointError(lib.cpp_last_error().decode())
+        check(rc)
+        return loss.value
+
+    def debug_values(self, batch):
+        dev = self._device_batch(batch)
+        B = dev.size
+        nl = (self.action_dim * (self.action_dim + 1)) // 2
+        l_values, loss = np.empty((B, nl), np.float32), np.zeros(1, np.float32)
+        v, a, vp = np.empty(B, np.float32), np.empty(B, np.float32), np.empty(B, np.float32)
+        check(lib.cpp_naf_debug_values(self.handle, dev.handle, ptr(l_values), ptr(loss), ptr(v), ptr(a), ptr(vp)))
+        return [np.squeeze(l_values), loss[0], v, a, vp]
+
+    def get_grads(self):
+        p, n = C.c_void_p(), C.c_int64()
+        check(lib.cpp_naf_grad_buffer(self.handle, C.byref(p), C.byref(n)))
+        return np.concatenate([self.value_net.get_grads(), self.mu_net.get_grads(), self.l_net.get_grads()])
+
+    def last_stats(self):
+        out = np.zeros(3, np.float32)
+        check(lib.cpp_naf_last_stats(self.handle, ptr(out)))
+        return out
+
+    def close(self):
+        for b in self._upload.values():
+            b.close()
+        if self.handle:
+            lib.cpp_naf_destroy(self.handle)
+            self.handle = None
+        self.mu_net.close()
+        self.l_net.close()
+
+
+class NormalizedAdvantageFunctionAgent(object):
+    def __init__(self, env):
+        self.env = env
+        state_shape = self.env.observation_space.shape
+        action_dim = self.env.action_space.shape[1]
+        self.replay_memory = replay_memory.ReplayMemory(opts.replay_memory_size, state_shape, action_dim)
+        batched_state_shape = [None] + list(state_shape)
+        s1 = base_network.Placeholder(batched_state_shape)
+        s2 = base_network.Placeholder(batched_state_shape)
+        self.value_net = ValueNetwork("value", s1, opts.hidden_layers)
+        self.target_value_net = ValueNetwork("target_value", s2, opts.hidden_layers)
+        self.naf = NafNetwork("naf", s1, s2, self.value_net, self.target_value_net, action_dim)
+
+    def initialise_variables(self, seed=None):
+        rng = np.random.RandomState(seed) if seed is not None else np.random
+        self.value_net.initialise_variables(rng)
+        self.target_value_net.initialise_variables(rng)
+        self.naf.initialise_variables(rng)
+
+    def post_var_init_setup(self):
+        if opts.event_log_in:
+            self.replay_memory.reset_from_event_log(opts.event_log_in)
+        self.target_value_net.set_as_target_network_for(self.value_net, opts.target_update_rate)
+
+    def train_step(self, batch_size, batches_per_step, idxs=None):
+        """the inner step naf_cartpole.py:367-373 as one device-side sequence (hipGraph after the first call)."""
+        rows = None
+        if idxs is not None:
+            rows = np.ascontiguousarray(np.asarray(idxs).reshape(-1), dtype=np.int32)
+        self.replay_memory.stats[">batch"] += batches_per_step
+        check(lib.cpp_naf_train_step(self.naf.handle, self.replay_memory.handle, int(batch_size),
+                                     int(batches_per_step), ptr(rows), int(opts.sample_seed)))
+
+    def run_training(self, max_num_actions, max_run_time, batch_size, batches_per_step, saver_util):
+        start_time = time.time()
+        num_actions_taken, n = 0, 0
+        while True:
+            rewards, losses = [], []
+            if not opts.dont_do_rollouts:
+                state_1 = self.env.reset()
+                initial_state = np.copy(state_1)
+                action_reward_state_sequence = []
+                episode_start = time.time()
+                done = False
+                while not done:
+                    action = self.naf.action_given(state_1, add_noise=True)
+                    state_2, reward, done, _ = self.env.step(action)
+                    rewards.append(reward)
+                    action_reward_state_sequence.append((action, reward, np.copy(state_2)))
+                    state_1 = state_2
+                print("episode_took", time.time() - episode_start, len(rewards))
+                replay_add_start = time.time()
+                self.replay_memory.add_episode(initial_state, action_reward_state_sequence)
+                print("replay_took", time.time() - replay_add_start)
+            if self.replay_memory.size() > opts.replay_memory_burn_in:
+                if opts.host_rng_sampling:
+                    for _ in range(batches_per_step):
+                        batch_start = time.time()
+                        batch = self.replay_memory.batch(batch_size)
+                        losses.append(self.naf.train(batch))
+                        print("batch_took", time.time() - batch_start)
+                    self.target_value_net.update_weights()
+                else:
+                    batch_start = time.time()
+                    self.train_step(batch_size, batches_per_step)
+                    st = self.naf.last_stats()
+                    if st[2] != 0:
+                        raise FloatingPointError("check_numerics: non-finite l_values / L / loss")
+                    losses.append(float(st[0]))
+                    print("batch_took", (time.time() - batch_start) / batches_per_step)
+            stats = collections.OrderedDict()
+            stats["time"] = time.time()
+            stats["n"] = n
+            stats["mean_losses"] = float(np.mean(losses)) if losses else float("nan")
+            stats["total_reward"] = float(np.sum(rewards))
+            stats["episode_len"] = len(rewards)
+            stats["replay_memory_stats"] = self.replay_memory.current_stats()
+            print("STATS %s\t%s" % (datetime.datetime.now().strftime('%Y-%m-%d %H:%M:%S'), json.dumps(stats)))
+            sys.stdout.flush()
+            n += 1
+            if VERBOSE_DEBUG or n % 10 == 0:
+                self.run_eval(1)
+            num_actions_taken += len(rewards)
+            if max_num_actions > 0 and num_actions_taken > max_num_actions:
+                break
+            if max_run_time > 0 and time.time() > start_time + max_run_time:
+                break
+            if opts.dont_do_rollouts and max_num_actions <= 0 and max_run_time <= 0:
+                break
+
+    def run_eval(self, num_episodes, add_noise=False):
+        for i in range(num_episodes):
+            state = self.env.reset()
+            total_reward, steps, done = 0, 0, False
+            while not done:
+                action = self.naf.action_given(state, add_noise)
+                state, reward, done, _ = self.env.step(action)
+                print("EVALSTEP e%d s%d action=%s (l2=%s) => reward %s" % (i, steps, action, np.linalg.norm(action), reward))
+                total_reward += reward
+                steps += 1
+            print("EVAL", i, steps, total_reward)
+        sys.stdout.flush()
+
+    def close(self):
+        self.naf.close()
+        self.value_net.close()
+        self.target_value_net.close()
+        self.replay_memory.close()
+
+
+def main(argv=None):
+    set_opts(build_parser().parse_args(argv))
+    sys.stderr.write("%s\n" % opts)
+    from .ddpg_cartpole import make_env
+    env = make_env(opts)
+    agent = NormalizedAdvantageFunctionAgent(env=env)
+    if opts.ckpt_dir is not None:
+        raise NotImplementedError("checkpointing (util.SaverUtil) is SURVEY 8(f) row N4")
+    agent.initialise_variables()
+    agent.post_var_init_setup()
+    if opts.num_eval > 0:
+        agent.run_eval(opts.num_eval, opts.eval_action_noise)
+    else:
+        agent.run_training(opts.max_num_actions, opts.max_run_time, opts.batch_size, opts.batches_per_step, None)
+    env.reset()
+    agent.close()
+
+
+if __name__ == "__main__":
+    main()

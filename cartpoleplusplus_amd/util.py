@@ -38,6 +38,23 @@ def gradient_clip_value(opts):
     return 0.0 if clip is None else float(clip)
 
 
+def construct_optimiser(opts):
+    """util.py:73-76: `tf.train.<opts.optimiser>Optimizer(**json.loads(opts.optimiser_args))`.  Returns the
+    (kind, learning_rate, momentum, beta1, beta2, epsilon) tuple the fused clip+apply kernel takes; the three
+    optimisers the reference's experiments use are built (GradientDescent, Momentum, Adam; TF defaults)."""
+    import json
+    args = json.loads(opts.optimiser_args)
+    lr = float(args.get("learning_rate", 0.001))
+    if opts.optimiser == "GradientDescent":
+        return (0, lr, 0.0, 0.0, 0.0, 0.0)
+    if opts.optimiser == "Momentum":
+        return (1, lr, float(args["momentum"]), 0.0, 0.0, 0.0)
+    if opts.optimiser == "Adam":
+        return (2, lr, 0.0, float(args.get("beta1", 0.9)), float(args.get("beta2", 0.999)),
+                float(args.get("epsilon", 1e-8)))
+    raise ValueError("optimiser %r not built (GradientDescent, Momentum, Adam)" % opts.optimiser)
+
+
 def collapsed_successive_ranges(values):
     """[2,3,4,5,13,14,15] -> '2-5, 13-15'"""
     spans, lo, prev = [], None, None

@@ -33,13 +33,16 @@ extern "C" {
 
 enum { CPP_OK = 0, CPP_ERR_ARG = 1, CPP_ERR_HIP = 2, CPP_ERR_STATE = 3, CPP_ERR_NUMERIC = 4 };
 enum { CPP_F32 = 0, CPP_F16 = 1 };          /* host/device element type of state payloads        */
-enum { CPP_ACTOR = 0, CPP_CRITIC = 1 };     /* ddpg_cartpole.py:78 ActorNetwork / :148 CriticNetwork */
+enum { CPP_ACTOR = 0, CPP_CRITIC = 1,       /* ddpg_cartpole.py:78 ActorNetwork / :148 CriticNetwork */
+       CPP_HEAD = 2 };                      /* naf_cartpole.py: state network + one 'fc' head (value / mu / l_values) */
+enum { CPP_OPT_SGD = 0, CPP_OPT_MOMENTUM = 1, CPP_OPT_ADAM = 2 };   /* util.py:73-76 tf.train.<name>Optimizer */
 
 typedef struct cpp_ctx cpp_ctx;
 typedef struct cpp_net cpp_net;
 typedef struct cpp_batch cpp_batch;
 typedef struct cpp_replay cpp_replay;
 typedef struct cpp_ddpg cpp_ddpg;
+typedef struct cpp_naf cpp_naf;
 
 /* ---- library / context ------------------------------------------------------------------- */
 int cpp_abi_version(void);
@@ -74,6 +77,8 @@ typedef struct cpp_net_spec {
   int32_t action_dim;
   int32_t n_hidden;      /* actor: opts.actor_hidden_layers; low-dim critic: critic_hidden_layers */
   int32_t hidden[8];     /* (pixel critic is the fixed 200/50/+action/50 head of :168-171)       */
+  int32_t head_out;      /* CPP_HEAD: outputs of the 'fc' head (1, action_dim, action_dim*(action_dim+1)/2) */
+  int32_t head_act;      /* CPP_HEAD: 0 linear, 2 tanh (naf_cartpole.py:109,161,184)              */
 } cpp_net_spec;
 
 int cpp_net_create(cpp_ctx* ctx, const cpp_net_spec* spec, int max_batch, cpp_net** out);
@@ -183,6 +188,47 @@ int cpp_ddpg_train_step(cpp_ddpg* ddpg, cpp_replay* replay, int B, int n_batches
 int cpp_ddpg_sample_and_compute(cpp_ddpg* ddpg, cpp_replay* replay, int B, uint64_t seed);
 /* scalars of the last minibatch: [0] td loss, [1] actor grad norm, [2] critic grad norm (pre-clip). */
 int cpp_ddpg_last_stats(cpp_ddpg* ddpg, float out[3]);
+
+/* ---- NAF train ops (naf_cartpole.py:93-284, :365-373) ----------------------------------------- */
+typedef struct cpp_naf_hyper {
+  float discount;                /* --discount (naf_cartpole.py:46)                               */
+  float gradient_clip;           /* --gradient-clip (util.py:11); <= 0 disables                    */
+  float target_update_rate;      /* --target-update-rate (:36)                                     */
+  int32_t optimiser;             /* --optimiser: CPP_OPT_* (util.py:15, :73-76)                    */
+  float learning_rate;           /* --optimiser-args                                               */
+  float momentum;                /*   Momentum                                                     */
+  float beta1, beta2, epsilon;   /*   Adam (TF defaults .9 / .999 / 1e-8)                          */
+} cpp_naf_hyper;
+
+/* NafNetwork.__init__ (:117-245).  value / target_value: CPP_HEAD nets with head_out 1 (ValueNetwork,
+ * :93-114).  mu: tanh head with action_dim outputs, l_values: linear head with A(A+1)/2 outputs.  With
+ * share != 0 (--share-input-state-representation, :151-152,176-177) mu and l_values must be head-only
+ * nets (pixel = 0, n_hidden = 0, state_elems = width of value's last hidden layer) and read value's
+ * input_state_representation; otherwise they are full nets with their own trunks on state_1. */
+int cpp_naf_create(cpp_ctx* ctx, cpp_net* value, cpp_net* target_value, cpp_net* mu, cpp_net* l_values,
+                   int share, const cpp_naf_hyper* hyper, cpp_naf** out);
+int cpp_naf_destroy(cpp_naf* naf);
+/* NafNetwork.action_given without the noise (:247-253): output_action for a host state batch. */
+int cpp_naf_action(cpp_naf* naf, const void* state, int state_dtype, int B, float* out);
+/* NafNetwork.train(batch) (:264-272): check_numerics + train_op + loss.  Returns CPP_ERR_NUMERIC when
+ * l_values, L or the loss is not finite (tf.check_numerics, :242-245); parameters are then untouched. */
+int cpp_naf_train(cpp_naf* naf, cpp_batch* batch, float* loss);
+/* NafNetwork.debug_values(batch) (:274-284): l_values (B, A(A+1)/2), loss, value (B), advantage (B),
+ * target value (B). */
+int cpp_naf_debug_values(cpp_naf* naf, cpp_batch* batch, float* l_values, float* loss, float* value,
+                         float* advantage, float* target_value);
+/* Gradient halves for data-parallel learners, as for DDPG: flat buffer [value | mu | l_values]. */
+int cpp_naf_compute_gradients(cpp_naf* naf, cpp_batch* batch);
+int cpp_naf_grad_buffer(cpp_naf* naf, void** device_ptr, int64_t* n_floats);
+int cpp_naf_apply_gradients(cpp_naf* naf, float grad_scale);
+/* target_value_net.update_weights() (:373). */
+int cpp_naf_update_targets(cpp_naf* naf);
+/* The whole inner step :367-373 on device-resident replay; hipGraph-captured like cpp_ddpg_train_step.
+ * A non-finite minibatch sets a sticky flag that cpp_naf_last_stats reports (out[2] != 0). */
+int cpp_naf_train_step(cpp_naf* naf, cpp_replay* replay, int B, int n_batches, const int32_t* idxs,
+                       uint64_t seed);
+/* [0] loss of the last minibatch, [1] pre-clip global gradient norm, [2] non-finite flag (sticky). */
+int cpp_naf_last_stats(cpp_naf* naf, float out[3]);
 
 #ifdef __cplusplus
 }
