@@ -79,8 +79,12 @@ struct GemmArgs {
   const float* Y; long ldy;     // activation output for the *_GRAD epilogues
   int M, N, K, epi;
   int accumulate;               // C = C + A*B before the epilogue (sums several heads' d(representation))
+  float* C2; long ldc2;         // optional second copy of the output (e.g. actions straight into the critic's input)
 };
+#define GEMM_BATCH_MAX 8
+struct GemmBatch { GemmArgs g[GEMM_BATCH_MAX]; int tile_start[GEMM_BATCH_MAX + 1]; int n; };
 int launch_gemm(cpp_ctx* ctx, const GemmArgs& g);
+int launch_gemm_batch(cpp_ctx* ctx, const GemmArgs* list, int n);   // independent GEMMs in one launch
 int launch_copy_cols(cpp_ctx* ctx, float* dst, long ldd, int dcol0, const float* src, long lds_,
                      int scol0, int ncols, int rows);
 int launch_fill(cpp_ctx* ctx, float* dst, long ld, int col0, int ncols, int rows, float v);

@@ -13,12 +13,11 @@
 // 4x shorter chain matter more than tiling).  Partial tiles are combined through LDS in fixed order.
 // A(m,k) = A[m*sAm + k*sAk], B(k,n) = B[k*sBk + n*sBn]: the strides express the transposes of the
 // backward passes (dX = dz W^T, dW = x^T dz) without materialising them.
-__global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs g) {
-  __shared__ float red[3][256];
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, float (*red)[256]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lj = lane >> 4;
   const int tiles_n = (g.N + 15) >> 4;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int m = tm * 16 + li, n = tn * 16 + li;
   const bool mv = m < g.M, nv = n < g.N;
   const float* ap = g.A + (long)m * g.sAm;
@@ -54,8 +53,22 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs g) {
       else if (g.epi == GE_MUL_RELU_GRAD) v = g.Y[(long)row * g.ldy + n] > 0.f ? v : 0.f;
       else if (g.epi == GE_MUL_TANH_GRAD) { const float y = g.Y[(long)row * g.ldy + n]; v = v * (1.f - y * y); }
       g.C[(long)row * g.ldc + n] = v;
+      if (g.C2) g.C2[(long)row * g.ldc2 + n] = v;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs g) {
+  __shared__ float red[3][256];
+  gemm_tile(g, blockIdx.x, red);
+}
+
+// several independent GEMMs in one launch: workgroup -> (problem, tile) through a prefix table
+__global__ __launch_bounds__(256) void gemm_batch_kernel(const GemmBatch gb) {
+  __shared__ float red[3][256];
+  int p = 0;
+  while (p + 1 < gb.n && (int)blockIdx.x >= gb.tile_start[p + 1]) ++p;
+  gemm_tile(gb.g[p], blockIdx.x - gb.tile_start[p], red);
 }
 
 int launch_gemm(cpp_ctx* ctx, const GemmArgs& g) {
@@ -64,6 +77,24 @@ int launch_gemm(cpp_ctx* ctx, const GemmArgs& g) {
   hipLaunchKernelGGL(gemm_mfma_kernel, dim3(tiles), dim3(256), 0, ctx->stream, g);
   LAUNCH_CHECK();
   prof_end(ctx, K_GEMM);
+  return 0;
+}
+
+int launch_gemm_batch(cpp_ctx* ctx, const GemmArgs* list, int n) {
+  for (int i0 = 0; i0 < n; i0 += GEMM_BATCH_MAX) {
+    const int cnt = n - i0 < GEMM_BATCH_MAX ? n - i0 : GEMM_BATCH_MAX;
+    if (cnt == 1) { int rc = launch_gemm(ctx, list[i0]); if (rc) return rc; continue; }
+    GemmBatch gb;
+    gb.n = cnt; gb.tile_start[0] = 0;
+    for (int i = 0; i < cnt; ++i) {
+      gb.g[i] = list[i0 + i];
+      gb.tile_start[i + 1] = gb.tile_start[i] + ((gb.g[i].M + 15) / 16) * ((gb.g[i].N + 15) / 16);
+    }
+    prof_begin(ctx);
+    hipLaunchKernelGGL(gemm_batch_kernel, dim3(gb.tile_start[cnt]), dim3(256), 0, ctx->stream, gb);
+    LAUNCH_CHECK();
+    prof_end(ctx, K_GEMM);
+  }
   return 0;
 }
 

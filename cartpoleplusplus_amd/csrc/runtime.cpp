@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -350,7 +351,7 @@ extern "C" int cpp_net_soft_update(cpp_net* target, const cpp_net* source, float
 static int gemm(cpp_ctx* ctx, const float* A, long sAm, long sAk, const float* Bm, long sBk, long sBn,
                 float* C, long ldc, int M, int N, int K, int epi, const float* Y = nullptr, long ldy = 0,
                 int accumulate = 0) {
-  GemmArgs g; g.accumulate = accumulate; g.A = A; g.sAm = sAm; g.sAk = sAk; g.B = Bm; g.sBk = sBk; g.sBn = sBn; g.C = C; g.ldc = ldc;
+  GemmArgs g; g.accumulate = accumulate; g.C2 = nullptr; g.ldc2 = 0; g.A = A; g.sAm = sAm; g.sAk = sAk; g.B = Bm; g.sBk = sBk; g.sBn = sBn; g.C = C; g.ldc = ldc;
   g.Y = Y; g.ldy = ldy; g.M = M; g.N = N; g.K = K; g.epi = epi;
   return launch_gemm(ctx, g);
 }
@@ -397,6 +398,36 @@ static int net_forward_fc(cpp_net* n, Workspace& w, int from, int B, const float
   return CPP_OK;
 }
 
+// conv trunk backward from w.dpool[2] (= d flat): dW/db of the three convs, dX for conv3/conv2
+static int net_backward_conv(cpp_net* n, Workspace& w, int B, const void* state, int dtype, const float* white) {
+  cpp_ctx* ctx = n->ctx;
+  for (int i = 2; i >= 0; --i) {
+    const ConvL& L = n->conv[i];
+    ConvArgs a; memset(&a, 0, sizeof(a));
+    a.dy.dpool = w.dpool[i]; a.dy.pool = w.pool[i]; a.dy.amax = w.amax[i];
+    a.dy.dpool_bstride = (i == 2) ? (long)n->flat : (long)L.Hp * L.Wp * kConvOut;
+    a.dy.pool_bstride = (i == 2) ? (long)n->flat + 1 : (long)L.Hp * L.Wp * kConvOut;
+    a.dy.Hp = L.Hp; a.dy.Wp = L.Wp;
+    a.B = B; a.H = L.H; a.W = L.W;
+    // dW / db
+    ConvArgs d = a;
+    int mode;
+    if (i == 0) { d.in = state; d.in_bstride = n->state_elems; d.scale = white; d.shift = white + n->spec.C;
+                  mode = dtype == CPP_F16 ? IN_F16_WHITEN : IN_F32_WHITEN; }
+    else { d.in = w.pool[i - 1]; d.in_bstride = (long)L.H * L.W * L.Cin; mode = IN_F32_PLAIN; }
+    d.nout = kConvOut; d.partial = n->dw_partial;
+    RC(launch_conv_dw(ctx, kDwKid[i], L.Cin, L.ks, mode, d, n->grads + L.w_off, n->grads + L.b_off));
+    // dX -> gradient w.r.t. the previous pooled output (conv1's input is data: no dX)
+    if (i > 0) {
+      ConvArgs x = a;
+      x.w = n->params + L.w_off; x.nout = L.Cin;
+      x.out = w.dpool[i - 1]; x.out_bstride = (long)L.H * L.W * L.Cin;
+      RC(launch_conv_fwd(ctx, kDxKid[i], kConvOut, L.ks, IN_DY, EPI_PLAIN, x));
+    }
+  }
+  return CPP_OK;
+}
+
 // Backward from w.dz[last] (gradient w.r.t. the last layer's pre-activation).  want_params: write
 // [dW; db] of every layer into n->grads, otherwise stop once d_action is known.  d_action: (B, A) out.
 static int net_backward(cpp_net* n, Workspace& w, int B, bool want_params, float* d_action,
@@ -426,31 +457,77 @@ static int net_backward(cpp_net* n, Workspace& w, int B, bool want_params, float
     }
   }
   if (!want_params || !n->spec.pixel) return CPP_OK;
-  for (int i = 2; i >= 0; --i) {
-    const ConvL& L = n->conv[i];
-    ConvArgs a; memset(&a, 0, sizeof(a));
-    a.dy.dpool = w.dpool[i]; a.dy.pool = w.pool[i]; a.dy.amax = w.amax[i];
-    a.dy.dpool_bstride = (i == 2) ? (long)n->flat : (long)L.Hp * L.Wp * kConvOut;
-    a.dy.pool_bstride = (i == 2) ? (long)n->flat + 1 : (long)L.Hp * L.Wp * kConvOut;
-    a.dy.Hp = L.Hp; a.dy.Wp = L.Wp;
-    a.B = B; a.H = L.H; a.W = L.W;
-    // dW / db
-    ConvArgs d = a;
-    int mode;
-    if (i == 0) { d.in = state; d.in_bstride = n->state_elems; d.scale = white; d.shift = white + n->spec.C;
-                  mode = dtype == CPP_F16 ? IN_F16_WHITEN : IN_F32_WHITEN; }
-    else { d.in = w.pool[i - 1]; d.in_bstride = (long)L.H * L.W * L.Cin; mode = IN_F32_PLAIN; }
-    d.nout = kConvOut; d.partial = n->dw_partial;
-    RC(launch_conv_dw(ctx, kDwKid[i], L.Cin, L.ks, mode, d, n->grads + L.w_off, n->grads + L.b_off));
-    // dX -> gradient w.r.t. the previous pooled output (conv1's input is data: no dX)
-    if (i > 0) {
-      ConvArgs x = a;
-      x.w = n->params + L.w_off; x.nout = L.Cin;
-      x.out = w.dpool[i - 1]; x.out_bstride = (long)L.H * L.W * L.Cin;
-      RC(launch_conv_fwd(ctx, kDxKid[i], kConvOut, L.ks, IN_DY, EPI_PLAIN, x));
-    }
+  return net_backward_conv(n, w, B, state, dtype, white);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Level-synchronous launch scheduler for the fused step.  The MLP heads are ~36 tiny, latency-bound
+// GEMMs per minibatch; most of them are mutually independent (four networks' forwards, dW vs dX of one
+// layer, the actor's and the critic's backward chains).  Ops declare their dependencies; each round
+// launches every ready op, with all ready GEMMs sharing ONE launch (gemm_batch_kernel).  Everything stays
+// on the ctx stream, so the order is also what a hipGraph capture records.
+// ---------------------------------------------------------------------------------------------
+struct OpGraph {
+  struct Op { bool is_gemm; GemmArgs g; std::function<int()> fn; std::vector<int> deps; bool done; };
+  std::vector<Op> ops;
+  int gemm(const GemmArgs& g, std::initializer_list<int> deps) {
+    Op o; o.is_gemm = true; o.g = g; o.done = false;
+    for (int d : deps) if (d >= 0) o.deps.push_back(d);
+    ops.push_back(o); return (int)ops.size() - 1;
   }
-  return CPP_OK;
+  int fn(std::function<int()> f, std::initializer_list<int> deps) {
+    Op o; o.is_gemm = false; o.fn = f; o.done = false; memset(&o.g, 0, sizeof(o.g));
+    for (int d : deps) if (d >= 0) o.deps.push_back(d);
+    ops.push_back(o); return (int)ops.size() - 1;
+  }
+  int run(cpp_ctx* ctx) {
+    size_t remaining = ops.size();
+    std::vector<int> ready; std::vector<GemmArgs> batch;
+    while (remaining) {
+      ready.clear(); batch.clear();
+      for (size_t i = 0; i < ops.size(); ++i) {
+        if (ops[i].done) continue;
+        bool ok = true;
+        for (int d : ops[i].deps) if (!ops[d].done) { ok = false; break; }
+        if (ok) ready.push_back((int)i);
+      }
+      if (ready.empty()) { cpp_set_error("OpGraph: dependency cycle"); return CPP_ERR_STATE; }
+      for (int i : ready) if (!ops[i].is_gemm) RC(ops[i].fn());
+      for (int i : ready) if (ops[i].is_gemm) batch.push_back(ops[i].g);
+      if (!batch.empty()) RC(launch_gemm_batch(ctx, batch.data(), (int)batch.size()));
+      for (int i : ready) ops[i].done = true;
+      remaining -= ready.size();
+    }
+    return CPP_OK;
+  }
+};
+
+static GemmArgs mk_gemm(const float* A, long sAm, long sAk, const float* Bm, long sBk, long sBn, float* C, long ldc,
+                        int M, int N, int K, int epi, const float* Y = nullptr, long ldy = 0) {
+  GemmArgs g; memset(&g, 0, sizeof(g));
+  g.A = A; g.sAm = sAm; g.sAk = sAk; g.B = Bm; g.sBk = sBk; g.sBn = sBn; g.C = C; g.ldc = ldc;
+  g.Y = Y; g.ldy = ldy; g.M = M; g.N = N; g.K = K; g.epi = epi;
+  return g;
+}
+// y = act([x, 1] [W; b]) of layer l into the next layer's input buffer (or w.out for the last layer)
+static GemmArgs fc_fwd_args(cpp_net* n, Workspace& w, int l, int B) {
+  const FcL& L = n->fc[l];
+  const int nfc = (int)n->fc.size();
+  float* C = (l + 1 < nfc) ? w.fcin[l + 1] : w.out;
+  const long ldc = (l + 1 < nfc) ? n->fc[l + 1].n_in + 1 : L.n_out;
+  return mk_gemm(w.fcin[l], L.n_in + 1, 1, n->params + L.w_off, L.n_out, 1, C, ldc, B, L.n_out, L.n_in + 1, L.act);
+}
+// [dW; db] = [x, 1]^T dz
+static GemmArgs fc_dw_args(cpp_net* n, Workspace& w, int l, int B, const float* dz) {
+  const FcL& L = n->fc[l];
+  return mk_gemm(w.fcin[l], 1, L.n_in + 1, dz, L.n_out, 1, n->grads + L.w_off, L.n_out, L.n_in + 1, L.n_out, B, GE_NONE);
+}
+// columns [col0, col0+ncols) of dz W^T, optionally times relu'(Y)
+static GemmArgs fc_dx_args(cpp_net* n, int l, int B, const float* dz, long dz_ld, int col0, int ncols, float* C, long ldc,
+                           int epi, const float* Y, long ldy) {
+  const FcL& L = n->fc[l];
+  return mk_gemm(dz, dz_ld, 1, n->params + L.w_off + (long)col0 * L.n_out, 1, L.n_out, C, ldc, B, ncols, L.n_out, epi, Y, ldy);
 }
 
 // whitening statistics of a device-resident (B, H*W*C) batch -> white[2][C]
@@ -968,12 +1045,93 @@ extern "C" int cpp_ddpg_q_gradients_wrt_actions(cpp_ddpg* d, cpp_batch* b, float
   return CPP_OK;
 }
 
+// Both gradient sets of one minibatch (ddpg_cartpole.py:331-334) as one dependency graph: 4 conv trunk
+// forwards, the MLP GEMMs batched level by level, 2 conv trunk backwards.  The critic trunk + the layers in
+// front of the action splice run once for both uses of critic(s1, .).
 static int compute_gradients(cpp_ddpg* d, cpp_batch* b) {
-  const int C = d->critic->spec.pixel ? d->critic->spec.C : 0;
-  RC(critic_prefix(d->critic, b->s[0], b->dtype, white_of(b, 0, C), b->B));    // shared by both updates
-  RC(actor_gradients(d, b, true));
-  RC(critic_gradients(d, b, true, true));
-  return CPP_OK;
+  cpp_ctx* ctx = d->ctx;
+  cpp_net *a = d->actor, *c = d->critic, *ta = d->tactor, *tc = d->tcritic;
+  const int B = b->B, A = a->spec.action_dim, C = a->spec.pixel ? a->spec.C : 0;
+  const float *w1 = white_of(b, 0, C), *w2 = white_of(b, 1, C);
+  const void *s1 = b->s[0], *s2 = b->s[1];
+  const int dt = b->dtype;
+  const int na = (int)a->fc.size(), nc = (int)c->fc.size(), cat = c->cat_layer;
+  const FcL& Lcat = c->fc[cat];
+  const long ldcat = Lcat.n_in + 1;
+  OpGraph G;
+
+  // ---- forward
+  const int tA = G.fn([=] { return net_forward_trunk(a, a->ws[0], s1, dt, w1, B); }, {});
+  const int tC = G.fn([=] { return net_forward_trunk(c, c->ws[0], s1, dt, w1, B); }, {});
+  const int tTA = G.fn([=] { return net_forward_trunk(ta, ta->ws[0], s2, dt, w2, B); }, {});
+  const int tTC = G.fn([=] { return net_forward_trunk(tc, tc->ws[0], s2, dt, w2, B); }, {});
+  const int cb = G.fn([=] { return launch_copy_cols(ctx, c->ws[0].fcin[cat], ldcat, Lcat.n_in - A, b->a, A, 0, A, B); }, {});
+  int aF = tA, taF = tTA;
+  for (int l = 0; l < na; ++l) {
+    GemmArgs g = fc_fwd_args(a, a->ws[0], l, B), t = fc_fwd_args(ta, ta->ws[0], l, B);
+    if (l == na - 1) {      // actions land directly in the critics' splice columns as well
+      g.C2 = c->ws[1].fcin[cat] + (Lcat.n_in - A); g.ldc2 = ldcat;
+      t.C2 = tc->ws[0].fcin[cat] + (Lcat.n_in - A); t.ldc2 = ldcat;
+    }
+    aF = G.gemm(g, {aF}); taF = G.gemm(t, {taF});
+  }
+  int cP = tC, tcP = tTC;
+  for (int l = 0; l < cat; ++l) {
+    GemmArgs g = fc_fwd_args(c, c->ws[0], l, B);
+    if (l == cat - 1) { g.C2 = c->ws[1].fcin[cat]; g.ldc2 = ldcat; }   // same prefix for the second evaluation
+    cP = G.gemm(g, {cP});
+    tcP = G.gemm(fc_fwd_args(tc, tc->ws[0], l, B), {tcP});
+  }
+  if (cat == 0)     // low-dim critic: the "prefix" is the converted state itself
+    cP = G.fn([=] { return launch_copy_cols(ctx, c->ws[1].fcin[0], ldcat, 0, c->ws[0].fcin[0], ldcat, 0, Lcat.n_in - A, B); }, {tC});
+  int c1 = -1, c0 = -1, tcH = -1;
+  for (int l = cat; l < nc; ++l) {
+    c1 = G.gemm(fc_fwd_args(c, c->ws[1], l, B), {l == cat ? cP : c1, l == cat ? aF : -1});
+    c0 = G.gemm(fc_fwd_args(c, c->ws[0], l, B), {l == cat ? cP : c0, l == cat ? cb : -1, l == cat ? tC : -1});
+    tcH = G.gemm(fc_fwd_args(tc, tc->ws[0], l, B), {l == cat ? tcP : tcH, l == cat ? taF : -1});
+  }
+
+  // ---- dQ/da at a = actor(s1): back through q_value .. splice on the second evaluation (dz of q is 1)
+  int g = c1;
+  for (int l = nc - 1; l > cat; --l) {
+    const FcL& L = c->fc[l];
+    const float* dz = (l == nc - 1) ? d->ones : c->ws[1].dz[l];
+    g = G.gemm(fc_dx_args(c, l, B, dz, L.n_out, 0, L.n_in, c->ws[1].dz[l - 1], L.n_in, GE_MUL_RELU_GRAD,
+                          c->ws[1].fcin[l], L.n_in + 1), {g});
+  }
+  {
+    const float* dz = (cat == nc - 1) ? d->ones : c->ws[1].dz[cat];
+    g = G.gemm(fc_dx_args(c, cat, B, dz, Lcat.n_out, Lcat.n_in - A, A, d->dq_da, A, GE_NONE, nullptr, 0), {g});
+  }
+  int adz = G.fn([=] { return launch_actor_head_grad(ctx, a->ws[0].dz[na - 1], d->dq_da, a->ws[0].out, B * A); }, {g});
+
+  // ---- actor backward
+  for (int l = na - 1; l >= 0; --l) {
+    const FcL& L = a->fc[l];
+    G.gemm(fc_dw_args(a, a->ws[0], l, B, a->ws[0].dz[l]), {adz});
+    if (l > 0)
+      adz = G.gemm(fc_dx_args(a, l, B, a->ws[0].dz[l], L.n_out, 0, L.n_in, a->ws[0].dz[l - 1], L.n_in, GE_MUL_RELU_GRAD,
+                              a->ws[0].fcin[l], L.n_in + 1), {adz});
+    else if (a->spec.pixel)
+      adz = G.gemm(fc_dx_args(a, 0, B, a->ws[0].dz[0], L.n_out, 0, a->flat, a->ws[0].dpool[2], a->flat, GE_NONE, nullptr, 0), {adz});
+  }
+  if (a->spec.pixel) G.fn([=] { return net_backward_conv(a, a->ws[0], B, s1, dt, w1); }, {adz});
+
+  // ---- TD target + critic backward on the first evaluation (fed actions)
+  int cdz = G.fn([=] { return launch_td(ctx, c->ws[0].out, tc->ws[0].out, b->r, b->m, d->hp.discount, B, d->td,
+                                        c->ws[0].dz[nc - 1], d->loss_norms); }, {c0, tcH});
+  for (int l = nc - 1; l >= 0; --l) {
+    const FcL& L = c->fc[l];
+    G.gemm(fc_dw_args(c, c->ws[0], l, B, c->ws[0].dz[l]), {cdz});
+    const int ncols = L.cat ? L.n_in - A : L.n_in;
+    if (l > 0)
+      cdz = G.gemm(fc_dx_args(c, l, B, c->ws[0].dz[l], L.n_out, 0, ncols, c->ws[0].dz[l - 1], ncols, GE_MUL_RELU_GRAD,
+                              c->ws[0].fcin[l], L.n_in + 1), {cdz});
+    else if (c->spec.pixel)
+      cdz = G.gemm(fc_dx_args(c, 0, B, c->ws[0].dz[0], L.n_out, 0, c->flat, c->ws[0].dpool[2], c->flat, GE_NONE, nullptr, 0), {cdz});
+  }
+  if (c->spec.pixel) G.fn([=] { return net_backward_conv(c, c->ws[0], B, s1, dt, w1); }, {cdz});
+  return G.run(ctx);
 }
 
 extern "C" int cpp_ddpg_compute_gradients(cpp_ddpg* d, cpp_batch* b) {
