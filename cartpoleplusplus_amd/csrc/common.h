@@ -19,6 +19,10 @@ enum KernelId {
   K_REPLAY_FILL, K_NAF_HEAD, K_NUM_KERNELS
 };
 
+// deferred second-stage reductions of the conv dW partials (flushed in one launch)
+struct DwReduceDesc { const float* partial; int nblocks, pstride, nw, nout; float* grad_w; float* grad_b; };
+#define DW_REDUCE_MAX 8
+
 struct cpp_ctx {
   int device;
   hipStream_t stream;
@@ -30,6 +34,8 @@ struct cpp_ctx {
   int64_t prof_n[K_NUM_KERNELS];
   hipEvent_t pe0, pe1;
   int num_cus;
+  DwReduceDesc pending[DW_REDUCE_MAX];
+  int npending;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -67,6 +73,7 @@ int launch_conv_fwd(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi
 int launch_conv_dw(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, ConvArgs a, float* grad_w,
                    float* grad_b);
 size_t conv_dw_partial_floats(cpp_ctx* ctx, int cin, int ks, int nout);
+int flush_dw_reduce(cpp_ctx* ctx);     // one launch for every dW reduction queued by launch_conv_dw
 
 // ---------------------------------------------------------------------------------------------
 // gemm + elementwise (gemm.hip)

@@ -55,8 +55,24 @@ int launch_conv_dw(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, ConvArgs
     rc = conv_dw_dispatch_l23(ctx, cin, ks, xtw, in_mode, a, &grid);
   prof_end(ctx, kid);
   if (rc) return rc;
+  if (ctx->npending == DW_REDUCE_MAX) { rc = flush_dw_reduce(ctx); if (rc) return rc; }
+  DwReduceDesc& d = ctx->pending[ctx->npending++];
+  d.partial = a.partial; d.nblocks = grid; d.pstride = a.pstride; d.nw = nw; d.nout = a.nout;
+  d.grad_w = grad_w; d.grad_b = grad_b;
+  return 0;
+}
+
+int flush_dw_reduce(cpp_ctx* ctx) {
+  if (ctx->npending == 0) return 0;
+  DwReduceBatch rb;
+  rb.n = ctx->npending; rb.block_start[0] = 0;
+  for (int i = 0; i < rb.n; ++i) {
+    rb.d[i] = ctx->pending[i];
+    rb.block_start[i + 1] = rb.block_start[i] + (rb.d[i].nw + rb.d[i].nout + 63) / 64;
+  }
+  ctx->npending = 0;
   prof_begin(ctx);
-  rc = launch_dw_reduce(ctx, a.partial, grid, a.pstride, nw, a.nout, grad_w, grad_b);
+  int rc = launch_dw_reduce_batch(ctx, rb);
   prof_end(ctx, K_DW_REDUCE);
   return rc;
 }

@@ -1,42 +1,40 @@
 // conv2 / conv3 dW/db instantiations + the second-stage partial reduction.
 #include "conv_impl.h"
 
-// 64 outputs x 4 slices of the partial list per workgroup; slices are combined in fixed order
-__global__ __launch_bounds__(256) void conv_dw_reduce_kernel(const float* __restrict__ partial, int nblocks,
-                                                             int pstride, int nw, int nout,
-                                                             float* __restrict__ grad_w,
-                                                             float* __restrict__ grad_b) {
+// 64 outputs x 4 slices of the partial list per workgroup; slices are combined in fixed order.  One launch
+// serves every queued (layer, network) reduction: workgroup -> (descriptor, output block) via a prefix table.
+__global__ __launch_bounds__(256) void conv_dw_reduce_kernel(const DwReduceBatch rb) {
   __shared__ float red[4][64];
+  int p = 0;
+  while (p + 1 < rb.n && (int)blockIdx.x >= rb.block_start[p + 1]) ++p;
+  const DwReduceDesc d = rb.d[p];
   const int el = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + el;
-  const int n = nw + nout;
-  const int per = (nblocks + 3) >> 2;
-  const int b0 = slice * per, b1 = min(b0 + per, nblocks);
+  const int e = (blockIdx.x - rb.block_start[p]) * 64 + el;
+  const int n = d.nw + d.nout;
+  const int per = (d.nblocks + 3) >> 2;
+  const int b0 = slice * per, b1 = min(b0 + per, d.nblocks);
   float s = 0.f;
   if (e < n) {
     int b = b0;
     for (; b + 8 <= b1; b += 8) {
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = partial[(long)(b + u) * pstride + e];
+      for (int u = 0; u < 8; ++u) v[u] = d.partial[(long)(b + u) * d.pstride + e];
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += v[u];
     }
-    for (; b < b1; ++b) s += partial[(long)b * pstride + e];
+    for (; b < b1; ++b) s += d.partial[(long)b * d.pstride + e];
   }
   red[slice][el] = s;
   __syncthreads();
   if (slice == 0 && e < n) {
     const float t = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
-    if (e < nw) grad_w[e] = t; else grad_b[e - nw] = t;
+    if (e < d.nw) d.grad_w[e] = t; else d.grad_b[e - d.nw] = t;
   }
 }
 
-int launch_dw_reduce(cpp_ctx* ctx, const float* partial, int nblocks, int pstride, int nw, int nout,
-                     float* grad_w, float* grad_b) {
-  const int n = nw + nout;
-  hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, ctx->stream, partial,
-                     nblocks, pstride, nw, nout, grad_w, grad_b);
+int launch_dw_reduce_batch(cpp_ctx* ctx, const DwReduceBatch& rb) {
+  hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3(rb.block_start[rb.n]), dim3(256), 0, ctx->stream, rb);
   LAUNCH_CHECK();
   return 0;
 }

@@ -566,8 +566,8 @@ __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_dw_
 }
 
 // second stage: grad[e] = sum_blocks partial[blk][e], fixed order (conv_dw_l23.hip)
-int launch_dw_reduce(cpp_ctx* ctx, const float* partial, int nblocks, int pstride, int nw, int nout,
-                     float* grad_w, float* grad_b);
+struct DwReduceBatch { DwReduceDesc d[DW_REDUCE_MAX]; int block_start[DW_REDUCE_MAX + 1]; int n; };
+int launch_dw_reduce_batch(cpp_ctx* ctx, const DwReduceBatch& rb);
 
 template <int CIN, int KS, int XTW, int IN_MODE, int EPI>
 static inline int conv_fwd_launch_t(cpp_ctx* ctx, const ConvArgs& a) {

@@ -169,7 +169,7 @@ struct cpp_net {
   Workspace ws[2];
   float* white;            // [2][C] statistics for cpp_net_forward
   double* stats_part;      // [maxB][2C]
-  float* dw_partial;
+  float* dw_partial[3];     // one per conv layer: their reductions are deferred and batched
   void* stage_state; float* stage_action; float* stage_out;
   Arena arena;
 };
@@ -271,7 +271,7 @@ extern "C" int cpp_net_create(cpp_ctx* ctx, const cpp_net_spec* spec, int max_ba
   cpp_net* n = new cpp_net();
   n->ctx = ctx; n->spec = *spec; n->maxB = max_batch; n->arena.stream = ctx->stream;
   n->grads = nullptr; n->own_grads = nullptr; n->stage_state = nullptr; n->stage_action = nullptr;
-  n->stage_out = nullptr; n->dw_partial = nullptr; n->white = nullptr; n->stats_part = nullptr;
+  n->stage_out = nullptr; n->dw_partial[0] = n->dw_partial[1] = n->dw_partial[2] = nullptr; n->white = nullptr; n->stats_part = nullptr;
   int rc = net_build(n);
   if (rc) { delete n; return rc; }
   auto fail = [&](int r) { n->arena.release(); delete n; return r; };
@@ -284,9 +284,8 @@ extern "C" int cpp_net_create(cpp_ctx* ctx, const cpp_net_spec* spec, int max_ba
     for (int i = 0; i < 3; ++i) { n->ws[1].pool[i] = n->ws[0].pool[i]; n->ws[1].amax[i] = n->ws[0].amax[i]; n->ws[1].dpool[i] = n->ws[0].dpool[i]; }
   }
   if (spec->pixel) {
-    size_t pf = 0;
-    for (const ConvL& L : n->conv) { size_t f = conv_dw_partial_floats(ctx, L.Cin, L.ks, kConvOut); if (f > pf) pf = f; }
-    if ((rc = dalloc(n->arena, &n->dw_partial, pf))) return fail(rc);
+    for (int i = 0; i < 3; ++i)
+      if ((rc = dalloc(n->arena, &n->dw_partial[i], conv_dw_partial_floats(ctx, n->conv[i].Cin, n->conv[i].ks, kConvOut)))) return fail(rc);
     if ((rc = dalloc(n->arena, &n->white, (size_t)2 * spec->C))) return fail(rc);
     if ((rc = dalloc(n->arena, &n->stats_part, (size_t)2 * max_batch * 2 * spec->C))) return fail(rc);
   }
@@ -415,7 +414,7 @@ static int net_backward_conv(cpp_net* n, Workspace& w, int B, const void* state,
     if (i == 0) { d.in = state; d.in_bstride = n->state_elems; d.scale = white; d.shift = white + n->spec.C;
                   mode = dtype == CPP_F16 ? IN_F16_WHITEN : IN_F32_WHITEN; }
     else { d.in = w.pool[i - 1]; d.in_bstride = (long)L.H * L.W * L.Cin; mode = IN_F32_PLAIN; }
-    d.nout = kConvOut; d.partial = n->dw_partial;
+    d.nout = kConvOut; d.partial = n->dw_partial[i];
     RC(launch_conv_dw(ctx, kDwKid[i], L.Cin, L.ks, mode, d, n->grads + L.w_off, n->grads + L.b_off));
     // dX -> gradient w.r.t. the previous pooled output (conv1's input is data: no dX)
     if (i > 0) {
@@ -457,7 +456,8 @@ static int net_backward(cpp_net* n, Workspace& w, int B, bool want_params, float
     }
   }
   if (!want_params || !n->spec.pixel) return CPP_OK;
-  return net_backward_conv(n, w, B, state, dtype, white);
+  RC(net_backward_conv(n, w, B, state, dtype, white));
+  return flush_dw_reduce(ctx);
 }
 
 
@@ -1131,7 +1131,8 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b) {
       cdz = G.gemm(fc_dx_args(c, 0, B, c->ws[0].dz[0], L.n_out, 0, c->flat, c->ws[0].dpool[2], c->flat, GE_NONE, nullptr, 0), {cdz});
   }
   if (c->spec.pixel) G.fn([=] { return net_backward_conv(c, c->ws[0], B, s1, dt, w1); }, {cdz});
-  return G.run(ctx);
+  RC(G.run(ctx));
+  return flush_dw_reduce(ctx);      // all six dW reductions (3 layers x 2 networks) in one launch
 }
 
 extern "C" int cpp_ddpg_compute_gradients(cpp_ddpg* d, cpp_batch* b) {
