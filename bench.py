@@ -80,7 +80,13 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=10, help="minibatches of the per-kernel HIP-event pass")
+    ap.add_argument("--force-dp", action="store_true", help="use the data-parallel learner path (RCCL all-reduce) even at world size 1")
     args = ap.parse_args()
+
+    # keep real stdout for the ONE JSON line: RCCL / libraries print banners to fd 1
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -94,9 +100,11 @@ def main():
     import torch
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
-    if world > 1:
+    use_dp = world > 1 or args.force_dp
+    if use_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from cartpoleplusplus_amd import _lib, ddpg_cartpole as D
     from cartpoleplusplus_amd.distributed import GradAllReducer, DataParallelLearner, AgentOps
@@ -121,15 +129,16 @@ def main():
     groups, tail = divmod(args.steps, BATCHES_PER_STEP)
     wgroups = max(1, -(-args.warmup // BATCHES_PER_STEP))
 
-    if world == 1:
+    if not use_dp:
         def run(g, t):
             for _ in range(g):
                 agent.train_step(B, BATCHES_PER_STEP)
             if t:
                 agent.train_step(B, t)
     else:
-        learner = DataParallelLearner(AgentOps(agent, B, 1234 + rank),
-                                      GradAllReducer.for_trainer(agent.trainer, stream))
+        reducer = GradAllReducer.for_trainer(agent.trainer, stream)
+        reducer.always = args.force_dp
+        learner = DataParallelLearner(AgentOps(agent, B, 1234 + rank), reducer)
 
         def run(g, t):
             for _ in range(g):
@@ -140,7 +149,7 @@ def main():
     def full_sync():
         ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dp:
             dist.barrier()
 
     # warm-up (also captures the hipGraphs for both call shapes)
@@ -202,10 +211,13 @@ def main():
         out["cpu_baseline"] = cpu_baseline(shape, B)
     elif rank == 0:
         out["cpu_baseline"] = None
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     agent.close()
-    if world > 1:
+    if use_dp:
         dist.destroy_process_group()
 
 
