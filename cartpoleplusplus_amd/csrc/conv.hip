@@ -1,5 +1,6 @@
 // Host-side launchers of the conv kernels (geometry selection + profiling brackets).
 #include "conv_impl.h"
+#include <cstdlib>
 
 static int pick_xtw(int in_mode, int W) {
   if (in_mode == IN_F16_WHITEN || in_mode == IN_F32_WHITEN) return 4;   // conv1: always 64-wide tiles
@@ -27,7 +28,15 @@ int launch_conv_fwd(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi
   if (a.nout > CPP_NOUT_MAX) { cpp_set_error("conv: nout %d > 16", a.nout); return 1; }
   prof_begin(ctx);
   int rc;
-  if (in_mode == IN_F16_WHITEN || in_mode == IN_F32_WHITEN)
+  // (kx,o)-column kernel (experimental, opt-in with CPP_CONV_KXO=1): 20 % fewer MFMAs but measured slower on
+  // MI355X under hipcc's register allocation (conv1: 0.66-0.78 ms/step vs 0.54) -- see DESIGN.md section 6
+  static const bool want_kxo = getenv("CPP_CONV_KXO") != nullptr;
+  const bool kxo = want_kxo && epi == EPI_RELU_POOL && a.tiles_x == 1 && a.nout <= 10 && in_mode != IN_DY && cin != 30;
+  if (kxo && (in_mode == IN_F16_WHITEN || in_mode == IN_F32_WHITEN))
+    rc = conv_fwd_kxo_dispatch_l1(ctx, cin, ks, xtw, in_mode, a);
+  else if (kxo)
+    rc = conv_fwd_kxo_dispatch_l23(ctx, cin, ks, xtw, in_mode, a);
+  else if (in_mode == IN_F16_WHITEN || in_mode == IN_F32_WHITEN)
     rc = conv_fwd_dispatch_l1(ctx, cin, ks, xtw, in_mode, epi, a);
   else
     rc = conv_fwd_dispatch_l23(ctx, cin, ks, xtw, in_mode, epi, a);
