@@ -1,0 +1,122 @@
+"""GPU tests at BASELINE.json's full sizes (B = 256, 64x64x18; replay in HBM), through size-independent
+properties, plus the geometry paths the small cases do not reach (128-wide images: partial-width tiles,
+30 input channels)."""
+import numpy as np
+import pytest
+
+from oracle import ddpg_np as O
+from tests.helpers import make_pair, assert_flat_close
+
+pytestmark = pytest.mark.gpu
+
+SHAPE, B = (64, 64, 3, 2, 3), 256
+
+
+def test_full_size_gather_is_exact_and_statistics_match_f64():
+    from cartpoleplusplus_amd.replay_memory import ReplayMemory
+    rm = ReplayMemory(3000, SHAPE, 2)
+    rm.fill_synthetic(2500, seed=11)
+    b = rm.sample_on_device(B, seed=99, counter=7)
+    assert b.idxs.min() >= 0 and b.idxs.max() < 2500
+    # property: every gathered row is bit-for-bit the stored row of its index (double indirection)
+    rows = np.random.default_rng(0).choice(B, 24, replace=False)
+    s1 = rm.state[rm.state_1_idx[b.idxs[rows]]]
+    s2 = rm.state[rm.state_2_idx[b.idxs[rows]]]
+    assert np.array_equal(b.state_1[rows], s1) and np.array_equal(b.state_2[rows], s2)
+    assert np.array_equal(b.terminal_mask[:, 0], rm.terminal_mask[b.idxs, 0])
+    # property: pixel values are the 256 f16(k/255) levels
+    lv = (np.arange(256).astype(np.float16) / np.float16(255))
+    assert np.isin(b.state_1[:8].ravel(), lv).all()
+    rm.close()
+
+
+def test_full_size_whitening_statistics_and_forward_against_f64_oracle_slice():
+    """whitening uses the statistics of the whole 256-row batch; check them (and a forward through all three
+    convs) by recomputing in f64 on the host for the same batch."""
+    agent, ref, _ = make_pair(SHAPE, B, True, replay_size=600)
+    try:
+        agent.replay_memory.fill_synthetic(500, seed=5)
+        b = agent.replay_memory.sample_on_device(B, seed=3, counter=0)
+        s1 = b.state_1
+        x = s1.reshape(B, 64, 64, 18)
+        scale, shift = O.whiten_stats(x, np.float64)
+        # conv1 of the first 4 images with the FULL batch statistics
+        sub = ref.actor.forward(s1[:4], white=(scale, shift))
+        got = agent.actor.forward(s1)            # device: batch statistics of all 256 rows
+        assert np.abs(got[:4] - sub["out"]).max() < 1e-5
+        pool1 = agent.actor.pool1.eval(B)
+        assert np.abs(pool1[:4] - sub["conv1"][1]).max() < 1e-5
+    finally:
+        agent.close()
+
+
+def test_full_size_fused_step_equals_unfused_ops_and_is_deterministic():
+    """the hipGraph / batched-GEMM / deferred-reduction path and the op-by-op path are different launch
+    sequences over the same kernels: they must agree to rounding; two fused runs must agree bit for bit."""
+    results = []
+    for mode in ("fused", "fused", "unfused"):
+        agent, ref, (aspec, cspec) = make_pair(SHAPE, B, True, replay_size=600)
+        try:
+            agent.replay_memory.fill_synthetic(500, seed=5)
+            idxs = np.random.default_rng(1).integers(0, 500, 2 * B)
+            if mode == "fused":
+                agent.train_step(B, 2, idxs=idxs)
+            else:
+                for i in range(2):
+                    batch = agent.replay_memory.batch(idxs=idxs[i * B:(i + 1) * B])
+                    agent.actor.train(batch)
+                    agent.critic.train(batch)
+                agent.target_actor.update_weights(); agent.target_critic.update_weights()
+            results.append((agent.actor.get_params(), agent.critic.get_params(),
+                            agent.target_actor.get_params(), agent.target_critic.get_params()))
+        finally:
+            agent.close()
+    for k in range(4):
+        assert np.array_equal(results[0][k], results[1][k])
+    assert_flat_close(aspec, results[0][0], results[2][0], rel=1e-5, what="actor fused vs unfused")
+    assert_flat_close(cspec, results[0][1], results[2][1], rel=1e-5, what="critic fused vs unfused")
+    assert np.isfinite(results[0][0]).all() and np.isfinite(results[0][1]).all()
+
+
+def test_full_size_critic_gradient_against_f32_oracle():
+    """one full-size minibatch: critic TD gradients vs the oracle (float32 twin, BLAS) on the same batch."""
+    agent, ref64, (aspec, cspec) = make_pair(SHAPE, B, True, replay_size=600)
+    try:
+        agent.replay_memory.fill_synthetic(500, seed=8)
+        batch = agent.replay_memory.batch(idxs=np.random.default_rng(4).integers(0, 500, B))
+        t = (batch.state_1, batch.action, batch.reward, batch.terminal_mask, batch.state_2)
+        ref = O.DDPG(aspec, cspec, agent.actor.get_params(), agent.critic.get_params(), np.float32)
+        ref.set_targets(agent.target_actor.get_params(), agent.target_critic.get_params())
+        cg = ref.critic_gradients(t)
+        loss, td, q = agent.critic.check_loss(batch)
+        assert np.abs(q - cg["q"]).max() < 2e-5 and np.abs(td - cg["td"]).max() < 2e-5
+        agent.critic.train(batch)
+        assert_flat_close(cspec, agent.critic.get_grads(), cg["grads"], rel=2e-4, what="critic grads (f32 oracle)")
+    finally:
+        agent.close()
+
+
+@pytest.mark.parametrize("shape,Bs", [((128, 128, 3, 2, 5), 2), ((64, 64, 3, 1, 3), 3)],
+                         ids=["128x128x30-cfg5-shape", "64x64x9-cfg2-shape"])
+def test_wide_image_geometry_parity(shape, Bs):
+    """cfg5 image shape: two 64-column tiles per row (partial-width tiles with real halo columns), 30 input
+    channels (one workgroup per CU), conv2 on 64x64, conv3 on 32x32."""
+    agent, ref, (aspec, cspec) = make_pair(shape, Bs, True)
+    rng = np.random.default_rng(6)
+    t = O.synthetic_batch(rng, Bs, shape, 2, True)
+    try:
+        class HB(object):
+            pass
+        hb = HB(); hb.state_1, hb.action, hb.reward, hb.terminal_mask, hb.state_2 = t
+        ag, cg = ref.actor_gradients(t[0]), ref.critic_gradients(t)
+        assert np.abs(agent.actor.forward(t[0]) - ag["actions"]).max() < 1e-5
+        loss, td, q = agent.critic.check_loss(hb)
+        assert np.abs(q - cg["q"]).max() < 1e-5
+        pa = agent.actor.get_params()
+        agent.actor.train(hb)
+        assert_flat_close(aspec, agent.actor.get_grads(), ag["grads"], what="actor grads")
+        agent.actor.set_params(pa)
+        agent.critic.train(hb)
+        assert_flat_close(cspec, agent.critic.get_grads(), cg["grads"], what="critic grads")
+    finally:
+        agent.close()
