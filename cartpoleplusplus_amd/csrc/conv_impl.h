@@ -570,7 +570,23 @@ struct DwGeom {
 // dY of a tile is kept in LDS at POOLED resolution: gm = (pool > 0 ? dpool : 0) and the argmax code,
 // (CONV_TH/2) x (TCOLS/2) cells x DW_GP dwords; the two output rows of a wave share one pooled row, so
 // one gm + one code read give the B operands of both rows.
+#ifndef DW_PREFETCH
+#define DW_PREFETCH 1
+#endif
+#ifndef DW_STEP_UNROLL
+#define DW_STEP_UNROLL 1
+#endif
 constexpr int DW_GP = 20;     // dwords per pooled cell: 16 channels + pad so lane groups 8 px apart miss each other's banks
+
+// sched_group_barrier wants literal constants: unroll the per-tile-row pattern through templates
+template <int Q, int KS, int KT>
+struct DwSched {
+  static __device__ __forceinline__ void emit() {
+    if constexpr (Q + 2 < KS + 1) __builtin_amdgcn_sched_group_barrier(0x100, (KT + 1) / 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, (Q == 0 || Q == KS) ? KT : 2 * KT, 0);
+    if constexpr (Q < KS) DwSched<Q + 1, KS, KT>::emit();
+  }
+};
 
 template <int XTW>
 struct DyStager {
@@ -611,7 +627,8 @@ struct DyStager {
 };
 
 template <int CIN, int KS, int XTW, int IN_MODE>
-__global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_dw_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW))
+__attribute__((amdgpu_waves_per_eu(conv_wps(CIN, KS, XTW), conv_wps(CIN, KS, XTW)))) void conv_dw_kernel(const ConvArgs a) {
   constexpr int TR = CONV_TH + KS - 1, TCOLS = 16 * XTW, TC = TCOLS + KS - 1;
   constexpr int TILE = TR * TC * CIN;
   constexpr int KT = DwGeom<CIN, KS>::KT, NT = DwGeom<CIN, KS>::NT;
@@ -641,7 +658,7 @@ __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_dw_
 
   typedef typename StageType<IN_MODE>::type ST;
   constexpr bool WHITEN = (IN_MODE == IN_F16_WHITEN || IN_MODE == IN_F32_WHITEN);
-  constexpr bool PREFETCH = (RowStager<CIN, KS, XTW, ST, WHITEN>::NV <= 8);
+  constexpr bool PREFETCH = (RowStager<CIN, KS, XTW, ST, WHITEN>::NV <= 8) && (DW_PREFETCH != 0);
   RowStager<CIN, KS, XTW, ST, WHITEN> stg;
   DyStager<XTW> dst;
   if (WHITEN && tid < CIN) wl[tid] = make_float2(a.scale[tid], a.shift[tid]);
@@ -697,7 +714,7 @@ __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_dw_
 
     const int yrow = y0 + 2 * wave;
     if (yrow < a.H) {
-#pragma unroll 1
+#pragma unroll DW_STEP_UNROLL
       for (int st = 0; st < TCOLS / 4; ++st) {
         const int xbase = (st / SP) * 4 * SP + (st % SP);        // smallest of the step's 4 pixels
         if (x0 + xbase >= a.W) continue;                          // wave-uniform
@@ -709,15 +726,27 @@ __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_dw_
         const float b1 = (cd == 2 + (xloc & 1)) ? gv : 0.f;       // row 2w+1 : code = 1*2 + (x&1)
         bsum += b0 + b1;
         const float* lp = lds + ((2 * wave) * TC + xloc) * CIN + li;
+        // issue the A reads of two tile rows ahead of the MFMAs that consume them (the scheduler otherwise
+        // recycles one register pair and exposes the LDS latency after every 4 MFMAs)
+        float av[KS + 1][KT];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) { av[0][t] = lp[16 * t]; av[1][t] = lp[TC * CIN + 16 * t]; }
 #pragma unroll
         for (int q = 0; q < KS + 1; ++q) {
+          if (q + 2 < KS + 1) {
+#pragma unroll
+            for (int t = 0; t < KT; ++t) av[q + 2][t] = lp[(q + 2) * TC * CIN + 16 * t];
+          }
 #pragma unroll
           for (int t = 0; t < KT; ++t) {
-            const float av = lp[q * TC * CIN + 16 * t];
-            if (q < KS) acc[q < KS ? q : 0][t] = MFMA16(av, b0, acc[q < KS ? q : 0][t]);
-            if (q >= 1) acc[q >= 1 ? q - 1 : 0][t] = MFMA16(av, b1, acc[q >= 1 ? q - 1 : 0][t]);
+            if (q < KS) acc[q < KS ? q : 0][t] = MFMA16(av[q][t], b0, acc[q < KS ? q : 0][t]);
+            if (q >= 1) acc[q >= 1 ? q - 1 : 0][t] = MFMA16(av[q][t], b1, acc[q >= 1 ? q - 1 : 0][t]);
           }
         }
+        // pin the software pipeline in the emitted code: [reads of rows 0,1 + the dY cell] then per tile row
+        // [reads of row q+2][MFMAs of row q]
+        __builtin_amdgcn_sched_group_barrier(0x100, KT + 2, 0);
+        DwSched<0, KS, KT>::emit();
       }
     }
     __syncthreads();
