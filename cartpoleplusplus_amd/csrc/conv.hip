@@ -14,15 +14,16 @@ static int vec_ok_for(const ConvArgs& a, int in_mode) {
   return (((uintptr_t)a.in) % 16 == 0) && ((a.in_bstride * esz) % 16 == 0);
 }
 
-static void set_tiles(ConvArgs& a, int xtw) {
+static void set_tiles(ConvArgs& a, int cin, int xtw) {
+  const int th = conv_th(cin, xtw);
   a.tiles_x = (a.W + 16 * xtw - 1) / (16 * xtw);
-  a.tiles_y = (a.H + CONV_TH - 1) / CONV_TH;
+  a.tiles_y = (a.H + th - 1) / th;
   a.ntiles = a.B * a.tiles_x * a.tiles_y;
 }
 
 int launch_conv_fwd(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi, ConvArgs a) {
   const int xtw = pick_xtw(in_mode, a.W);
-  set_tiles(a, xtw);
+  set_tiles(a, cin, xtw);
   a.cin_rt = cin;
   a.vec_ok = vec_ok_for(a, in_mode);
   if (a.nout > CPP_NOUT_MAX) { cpp_set_error("conv: nout %d > 16", a.nout); return 1; }
@@ -51,7 +52,7 @@ size_t conv_dw_partial_floats(cpp_ctx* ctx, int cin, int ks, int nout) {
 int launch_conv_dw(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, ConvArgs a, float* grad_w,
                    float* grad_b) {
   const int xtw = pick_xtw(in_mode, a.W);
-  set_tiles(a, xtw);
+  set_tiles(a, cin, xtw);
   a.cin_rt = cin;
   a.vec_ok = vec_ok_for(a, in_mode);
   const int nw = ks * ks * cin * a.nout;

@@ -22,14 +22,17 @@
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-constexpr int CONV_TH = 8;          // output rows per workgroup tile (4 waves x 2 rows)
+constexpr int CONV_TH = 8;          // output rows per workgroup tile (4 waves x 2 rows) for the wide layers
+// conv2 / conv3 (10 input channels, <= 32 columns) use 16-row tiles: each wave then owns two row pairs, which
+// halves the per-tile staging / barrier overhead of these small layers (their tiles hold only ~260 MFMAs per wave)
+constexpr int conv_th(int cin, int xtw) { return (cin == 10 && xtw <= 2) ? 16 : 8; }
 constexpr int CONV_THREADS = 256;
 constexpr int CONV_LDS_PAD = 16;    // floats; covers the k-padding over-read of the last tile row
 
 // waves per SIMD the register allocator must leave room for: 2 workgroups per CU while the tile fits
 // twice into the 160 KiB LDS, otherwise 1 (and up to 512 VGPRs)
 constexpr int conv_wps(int cin, int ks, int xtw) {
-  return ((CONV_TH + ks - 1) * (16 * xtw + ks - 1) * cin * 4 > 76 * 1024) ? 1 : 2;
+  return ((conv_th(cin, xtw) + ks - 1) * (16 * xtw + ks - 1) * cin * 4 > 76 * 1024) ? 1 : 2;
 }
 
 // XCD-aware persistent tile order: workgroup b runs on XCD b % 8 (observed dispatch order, speed
@@ -60,7 +63,7 @@ __device__ __forceinline__ float dy_value(const DyDesc& d, int b, int y, int x, 
 template <int CIN, int KS, int XTW, int IN_MODE>
 __device__ __forceinline__ void conv_stage_tile(float* lds, const ConvArgs& a, int b, int y0, int x0,
                                                 int tid) {
-  constexpr int P = KS / 2, TR = CONV_TH + KS - 1, TC = 16 * XTW + KS - 1;
+  constexpr int P = KS / 2, TR = conv_th(CIN, XTW) + KS - 1, TC = 16 * XTW + KS - 1;
   constexpr int TILE = TR * TC * CIN;
   for (int idx = tid; idx < TILE; idx += CONV_THREADS) {
     const int c = idx % CIN;
@@ -121,7 +124,7 @@ template <> struct ChunkOps<float> {
 
 template <int CIN, int KS, int XTW, typename T, bool WHITEN>
 struct RowStager {
-  static constexpr int P = KS / 2, TR = CONV_TH + KS - 1, TC = 16 * XTW + KS - 1;
+  static constexpr int P = KS / 2, TR = conv_th(CIN, XTW) + KS - 1, TC = 16 * XTW + KS - 1;
   static constexpr int EPC = ChunkOps<T>::EPC;
   static constexpr int CH = (TC * CIN + EPC - 1) / EPC + 1;    // chunks per tile row incl. alignment slack
   static constexpr int NCH = TR * CH;
@@ -207,7 +210,7 @@ template <> struct StageType<IN_F16_WHITEN> { typedef __half type; };
 // ---------------------------------------------------------------------------------------------
 template <int CIN, int KS, int XTW, int IN_MODE, int EPI>
 __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd_kernel(const ConvArgs a) {
-  constexpr int TR = CONV_TH + KS - 1, TCOLS = 16 * XTW, TC = TCOLS + KS - 1;
+  constexpr int TR = conv_th(CIN, XTW) + KS - 1, TCOLS = 16 * XTW, TC = TCOLS + KS - 1;
   constexpr int KROW = (KS * CIN + 3) / 4;
   constexpr int TILE = TR * TC * CIN;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -259,14 +262,14 @@ __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd
     const int b = t_start / tiles_per_img;
     const int rem = t_start - b * tiles_per_img;
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
-    stg.load(a, b, ty * CONV_TH, tx * TCOLS, tid);
+    stg.load(a, b, ty * conv_th(CIN, XTW), tx * TCOLS, tid);
   }
 
   for (int tile = t_start; tile < t_end; tile += t_step) {
     const int b = tile / tiles_per_img;
     const int rem = tile - b * tiles_per_img;
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
-    const int y0 = ty * CONV_TH, x0 = tx * TCOLS;
+    const int y0 = ty * conv_th(CIN, XTW), x0 = tx * TCOLS;
 
 #ifdef CONV_ABLATE_NOSTAGE
     if (tile == t_start)
@@ -287,11 +290,14 @@ __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd
       const int nb = nt / tiles_per_img;
       const int nrem = nt - nb * tiles_per_img;
       const int nty = nrem / a.tiles_x, ntx = nrem - nty * a.tiles_x;
-      stg.load(a, nb, nty * CONV_TH, ntx * TCOLS, tid);
+      stg.load(a, nb, nty * conv_th(CIN, XTW), ntx * TCOLS, tid);
     }
 #endif
 
-    const int yrow = y0 + 2 * wave;
+#pragma unroll 1
+    for (int rp = 0; rp < conv_th(CIN, XTW) / 8; ++rp) {     // row pairs of this wave (2 for the 16-row tiles)
+    const int wrow = wave + 4 * rp;
+    const int yrow = y0 + 2 * wrow;
     if (yrow < a.H) {   // wave-uniform
       f32x4 acc[2][XTW];
 #pragma unroll
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd
 #pragma unroll
         for (int t = 0; t < XTW; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-      const float* lp = lds + (2 * wave) * TC * CIN + li * CIN + lj;
+      const float* lp = lds + (2 * wrow) * TC * CIN + li * CIN + lj;
       // tile row q = r + ky feeds output row 0 with W[ky=q] and output row 1 with W[ky=q-1]
 #pragma unroll
 #ifdef CONV_ABLATE_NOMFMA
@@ -360,6 +366,7 @@ __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd
         }
       }
     }
+    }   // row pairs
     __syncthreads();
   }
 }
@@ -381,7 +388,7 @@ constexpr int KXO_PBW = 52;      // floats per buffer row: 50 columns + pad (16-
 
 template <int CIN, int KS, int XTW, int IN_MODE>
 __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd_kxo_kernel(const ConvArgs a) {
-  constexpr int P = KS / 2, TR = CONV_TH + KS - 1, TCOLS = 16 * XTW, TC = TCOLS + KS - 1;
+  constexpr int P = KS / 2, TR = conv_th(CIN, XTW) + KS - 1, TCOLS = 16 * XTW, TC = TCOLS + KS - 1;
   constexpr int KK = (KS * CIN + 3) / 4;                  // k-steps over k = ky*CIN + c
   constexpr int NTC = (KS * 10 + 15) / 16;                // column tiles over col = kx*nout + o
   constexpr int TILE = TR * TC * CIN;
@@ -423,11 +430,11 @@ __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd
   if (WHITEN && tid < CIN) wl[tid] = make_float2(a.scale[tid], a.shift[tid]);
   const bool vec = a.vec_ok;
   if (WHITEN) __syncthreads();
-  if (PREFETCH && vec && t_start < t_end) stg.load(a, t_start / a.tiles_y, (t_start % a.tiles_y) * CONV_TH, 0, tid);
+  if (PREFETCH && vec && t_start < t_end) stg.load(a, t_start / a.tiles_y, (t_start % a.tiles_y) * conv_th(CIN, XTW), 0, tid);
 
   for (int tile = t_start; tile < t_end; tile += t_step) {
     const int b = tile / a.tiles_y;
-    const int y0 = (tile - b * a.tiles_y) * CONV_TH;        // tiles_x == 1: x0 = 0
+    const int y0 = (tile - b * a.tiles_y) * conv_th(CIN, XTW);        // tiles_x == 1: x0 = 0
 
     if (vec) {
       if (!PREFETCH) stg.load(a, b, y0, 0, tid);
@@ -439,10 +446,13 @@ __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd
     __syncthreads();
     if (PREFETCH && vec && tile + t_step < t_end) {
       const int nt = tile + t_step;
-      stg.load(a, nt / a.tiles_y, (nt % a.tiles_y) * CONV_TH, 0, tid);
+      stg.load(a, nt / a.tiles_y, (nt % a.tiles_y) * conv_th(CIN, XTW), 0, tid);
     }
 
-    const int yrow = y0 + 2 * wave;
+#pragma unroll 1
+    for (int rp = 0; rp < conv_th(CIN, XTW) / 8; ++rp) {
+    const int wrow = wave + 4 * rp;
+    const int yrow = y0 + 2 * wrow;
     if (yrow < a.H) {   // wave-uniform
       // the two output rows of the wave run one after the other (rolled loop: one set of accumulators)
       float out0[XTW][4];
@@ -454,7 +464,7 @@ __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd
 #pragma unroll
           for (int nt = 0; nt < NTC; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // A[x' = 16t + li][k = 4kk + lj] = tile[(2w + r + ky), P + x', c]
-        const float* lp = lds + ((2 * wave + r) * TC + P + li) * CIN + lj;
+        const float* lp = lds + ((2 * wrow + r) * TC + P + li) * CIN + lj;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
           const int kb = 4 * kk;
@@ -536,13 +546,14 @@ __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd
         }
       }
     }
+    }   // row pairs
     __syncthreads();
   }
 }
 
 template <int CIN, int KS, int XTW, int IN_MODE>
 static inline int conv_fwd_kxo_launch_t(cpp_ctx* ctx, const ConvArgs& a) {
-  constexpr int P = KS / 2, TR = CONV_TH + KS - 1, TC = 16 * XTW + KS - 1;
+  constexpr int P = KS / 2, TR = conv_th(CIN, XTW) + KS - 1, TC = 16 * XTW + KS - 1;
   const size_t lds_bytes = (size_t)(TR * TC * CIN + CONV_LDS_PAD + 2 * CIN + 4 * (16 + 2 * P) * KXO_PBW) * sizeof(float);
   auto kern = conv_fwd_kxo_kernel<CIN, KS, XTW, IN_MODE>;
   static bool attr_done = false;
@@ -588,9 +599,9 @@ struct DwSched {
   }
 };
 
-template <int XTW>
+template <int XTW, int TH>
 struct DyStager {
-  static constexpr int PR = CONV_TH / 2, PC = 8 * XTW;
+  static constexpr int PR = TH / 2, PC = 8 * XTW;
   static constexpr int NE_MAX = PR * PC * CPP_NOUT_MAX;
   static constexpr int NV = (PR * PC * 10 + CONV_THREADS - 1) / CONV_THREADS;   // nout <= 10 fast path
   float g[NV], pv[NV];
@@ -629,11 +640,11 @@ struct DyStager {
 template <int CIN, int KS, int XTW, int IN_MODE>
 __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW))
 __attribute__((amdgpu_waves_per_eu(conv_wps(CIN, KS, XTW), conv_wps(CIN, KS, XTW)))) void conv_dw_kernel(const ConvArgs a) {
-  constexpr int TR = CONV_TH + KS - 1, TCOLS = 16 * XTW, TC = TCOLS + KS - 1;
+  constexpr int TR = conv_th(CIN, XTW) + KS - 1, TCOLS = 16 * XTW, TC = TCOLS + KS - 1;
   constexpr int TILE = TR * TC * CIN;
   constexpr int KT = DwGeom<CIN, KS>::KT, NT = DwGeom<CIN, KS>::NT;
   constexpr int SP = TCOLS >= 32 ? 8 : 4;          // pixel spacing inside one MFMA step (bank spread)
-  constexpr int GMF = (CONV_TH / 2) * (TCOLS / 2) * DW_GP;   // floats of the gm image
+  constexpr int GMF = (conv_th(CIN, XTW) / 2) * (TCOLS / 2) * DW_GP;   // floats of the gm image
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lj = lane >> 4;
@@ -660,7 +671,7 @@ __attribute__((amdgpu_waves_per_eu(conv_wps(CIN, KS, XTW), conv_wps(CIN, KS, XTW
   constexpr bool WHITEN = (IN_MODE == IN_F16_WHITEN || IN_MODE == IN_F32_WHITEN);
   constexpr bool PREFETCH = (RowStager<CIN, KS, XTW, ST, WHITEN>::NV <= 8) && (DW_PREFETCH != 0);
   RowStager<CIN, KS, XTW, ST, WHITEN> stg;
-  DyStager<XTW> dst;
+  DyStager<XTW, conv_th(CIN, XTW)> dst;
   if (WHITEN && tid < CIN) wl[tid] = make_float2(a.scale[tid], a.shift[tid]);
   const bool vec = a.vec_ok;
   const bool dyfast = a.nout <= 10;
@@ -669,14 +680,14 @@ __attribute__((amdgpu_waves_per_eu(conv_wps(CIN, KS, XTW), conv_wps(CIN, KS, XTW
     const int b = t_start / tiles_per_img;
     const int rem = t_start - b * tiles_per_img;
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
-    if (PREFETCH && vec) stg.load(a, b, ty * CONV_TH, tx * TCOLS, tid);
+    if (PREFETCH && vec) stg.load(a, b, ty * conv_th(CIN, XTW), tx * TCOLS, tid);
   }
 
   for (int tile = t_start; tile < t_end; tile += t_step) {
     const int b = tile / tiles_per_img;
     const int rem = tile - b * tiles_per_img;
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
-    const int y0 = ty * CONV_TH, x0 = tx * TCOLS;
+    const int y0 = ty * conv_th(CIN, XTW), x0 = tx * TCOLS;
 
     if (dyfast) dst.load(a, b, y0, x0, tid);      // issued first: their latency hides under the tile stores
     if (vec) {
@@ -689,7 +700,7 @@ __attribute__((amdgpu_waves_per_eu(conv_wps(CIN, KS, XTW), conv_wps(CIN, KS, XTW
     if (dyfast) {
       dst.store(gm, gc, a, tid);
     } else {       // generic (nout > 10): straight from global
-      for (int idx = tid; idx < (CONV_TH / 2) * (TCOLS / 2) * a.nout; idx += CONV_THREADS) {
+      for (int idx = tid; idx < (conv_th(CIN, XTW) / 2) * (TCOLS / 2) * a.nout; idx += CONV_THREADS) {
         const int o = idx % a.nout, pp = idx / a.nout;
         const int pc = pp % (TCOLS / 2), pr = pp / (TCOLS / 2);
         const int py = (y0 >> 1) + pr, px = (x0 >> 1) + pc;
@@ -709,23 +720,26 @@ __attribute__((amdgpu_waves_per_eu(conv_wps(CIN, KS, XTW), conv_wps(CIN, KS, XTW
       const int nb = nt / tiles_per_img;
       const int nrem = nt - nb * tiles_per_img;
       const int nty = nrem / a.tiles_x, ntx = nrem - nty * a.tiles_x;
-      if (PREFETCH && vec) stg.load(a, nb, nty * CONV_TH, ntx * TCOLS, tid);
+      if (PREFETCH && vec) stg.load(a, nb, nty * conv_th(CIN, XTW), ntx * TCOLS, tid);
     }
 
-    const int yrow = y0 + 2 * wave;
+#pragma unroll 1
+    for (int rp = 0; rp < conv_th(CIN, XTW) / 8; ++rp) {     // row pairs of this wave
+    const int wrow = wave + 4 * rp;
+    const int yrow = y0 + 2 * wrow;
     if (yrow < a.H) {
 #pragma unroll DW_STEP_UNROLL
       for (int st = 0; st < TCOLS / 4; ++st) {
         const int xbase = (st / SP) * 4 * SP + (st % SP);        // smallest of the step's 4 pixels
         if (x0 + xbase >= a.W) continue;                          // wave-uniform
         const int xloc = xbase + SP * lj;
-        const int cell = (wave * (TCOLS / 2) + (xloc >> 1)) * DW_GP + li;
+        const int cell = (wrow * (TCOLS / 2) + (xloc >> 1)) * DW_GP + li;
         const float gv = gm[cell];
         const int cd = gc[cell];
         const float b0 = (cd == (xloc & 1)) ? gv : 0.f;           // row 2w   : code = 0*2 + (x&1)
         const float b1 = (cd == 2 + (xloc & 1)) ? gv : 0.f;       // row 2w+1 : code = 1*2 + (x&1)
         bsum += b0 + b1;
-        const float* lp = lds + ((2 * wave) * TC + xloc) * CIN + li;
+        const float* lp = lds + ((2 * wrow) * TC + xloc) * CIN + li;
         // issue the A reads of two tile rows ahead of the MFMAs that consume them (the scheduler otherwise
         // recycles one register pair and exposes the LDS latency after every 4 MFMAs)
         float av[KS + 1][KT];
@@ -749,6 +763,7 @@ __attribute__((amdgpu_waves_per_eu(conv_wps(CIN, KS, XTW), conv_wps(CIN, KS, XTW
         DwSched<0, KS, KT>::emit();
       }
     }
+    }   // row pairs
     __syncthreads();
   }
 
@@ -794,7 +809,7 @@ int launch_dw_reduce_batch(cpp_ctx* ctx, const DwReduceBatch& rb);
 
 template <int CIN, int KS, int XTW, int IN_MODE, int EPI>
 static inline int conv_fwd_launch_t(cpp_ctx* ctx, const ConvArgs& a) {
-  constexpr int TR = CONV_TH + KS - 1, TC = 16 * XTW + KS - 1;
+  constexpr int TR = conv_th(CIN, XTW) + KS - 1, TC = 16 * XTW + KS - 1;
   const size_t lds_bytes = (size_t)(TR * TC * CIN + CONV_LDS_PAD + 2 * CIN) * sizeof(float);
   auto kern = conv_fwd_kernel<CIN, KS, XTW, IN_MODE, EPI>;
   static bool attr_done = false;
@@ -819,9 +834,9 @@ static inline int conv_dw_grid(cpp_ctx* ctx, int xtw_max) {
 
 template <int CIN, int KS, int XTW, int IN_MODE>
 static inline int conv_dw_launch_t(cpp_ctx* ctx, const ConvArgs& a, int* grid_out) {
-  constexpr int TR = CONV_TH + KS - 1, TC = 16 * XTW + KS - 1;
+  constexpr int TR = conv_th(CIN, XTW) + KS - 1, TC = 16 * XTW + KS - 1;
   constexpr int NT = DwGeom<CIN, KS>::NT;
-  constexpr int GMF = (CONV_TH / 2) * (8 * XTW) * DW_GP;
+  constexpr int GMF = (conv_th(CIN, XTW) / 2) * (8 * XTW) * DW_GP;
   size_t fl = (size_t)(TR * TC * CIN + CONV_LDS_PAD + 2 * CIN) + GMF + GMF / 4 + 4;
   if (fl < (size_t)NT * 256 + 64) fl = (size_t)NT * 256 + 64;
   const size_t lds_bytes = fl * sizeof(float);
