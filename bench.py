@@ -188,6 +188,19 @@ def main():
     kernels = {k: {"ms_per_step": round(v[0] / pm, 4), "launches_per_step": round(v[1] / pm, 2)}
                for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; they come from
+    # separate rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
+    # committed under profiles/
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
+            pmc = json.load(f)
+        if args.workload == "cfg3":
+            traffic = pmc["kernels"]["conv1_fwd"]["hbm_bytes_per_launch"]
+            traffic_src = "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, bytes per launch)"
+    except Exception:
+        pass
+
     out = {
         "metric": "DDPG training steps/sec, 64x64x18 pixel obs, batch=256",
         "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": wgroups * BATCHES_PER_STEP,
@@ -203,7 +216,7 @@ def main():
                    "conv_roofline_frac_whole_step": round(conv_flops_step * steps / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
         "roofline": {"bound": "mfma", "kernel": "conv1_fwd", "achieved": round(achieved, 3),
                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                     "traffic": None, "flops_per_launch": flops_per_launch, "avg_launch_ms": round(avg_ms, 5),
+                     "traffic": traffic, "traffic_source": traffic_src, "flops_per_launch": flops_per_launch, "avg_launch_ms": round(avg_ms, 5),
                      "launches": int(c1_n)},
         "kernels": kernels,
     }
