@@ -78,7 +78,8 @@ int flush_dw_reduce(cpp_ctx* ctx);     // one launch for every dW reduction queu
 // ---------------------------------------------------------------------------------------------
 // gemm + elementwise (gemm.hip)
 // ---------------------------------------------------------------------------------------------
-enum GemmEpi { GE_NONE = 0, GE_RELU = 1, GE_TANH = 2, GE_MUL_RELU_GRAD = 3, GE_MUL_TANH_GRAD = 4 };
+enum GemmEpi { GE_NONE = 0, GE_RELU = 1, GE_TANH = 2, GE_MUL_RELU_GRAD = 3, GE_MUL_TANH_GRAD = 4,
+               GE_ACTOR_HEAD = 5 };   // C = v (dQ/da), C2 = -v * (1 - Y^2): grad_ys of ddpg_cartpole.py:111-113 through tanh
 struct GemmArgs {
   const float* A; long sAm, sAk;
   const float* B; long sBk, sBn;
@@ -139,6 +140,7 @@ struct OptSegs {
   long n[OPT_MAX_SEGS]; float lr[OPT_MAX_SEGS]; int group[OPT_MAX_SEGS];
   int nseg; int kind; float momentum, beta1, beta2, epsilon;
   const uint64_t* step;        // Adam: number of applies so far INCLUDING this one (device counter)
+  uint64_t* bump;              // optional: device counter incremented once by this launch (the replay sampler's Philox counter)
 };
 int launch_sumsq(cpp_ctx* ctx, const OptSegs& s, float grad_scale, double* part, int nparts);
 int launch_opt_apply(cpp_ctx* ctx, const OptSegs& s, float grad_scale, float clip, const double* part,

@@ -53,7 +53,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, float (*r
       else if (g.epi == GE_MUL_RELU_GRAD) v = g.Y[(long)row * g.ldy + n] > 0.f ? v : 0.f;
       else if (g.epi == GE_MUL_TANH_GRAD) { const float y = g.Y[(long)row * g.ldy + n]; v = v * (1.f - y * y); }
       g.C[(long)row * g.ldc + n] = v;
-      if (g.C2) g.C2[(long)row * g.ldc2 + n] = v;
+      if (g.epi == GE_ACTOR_HEAD) { const float y = g.Y[(long)row * g.ldy + n]; g.C2[(long)row * g.ldc2 + n] = -v * (1.f - y * y); }
+      else if (g.C2) g.C2[(long)row * g.ldc2 + n] = v;
     }
   }
 }

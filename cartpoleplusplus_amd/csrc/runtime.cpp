@@ -984,8 +984,9 @@ static int critic_gradients(cpp_ddpg* d, cpp_batch* b, bool critic_prefix_done, 
   return CPP_OK;
 }
 
-static int apply(cpp_ddpg* d, bool do_actor, bool do_critic, float grad_scale) {
+static int apply(cpp_ddpg* d, bool do_actor, bool do_critic, float grad_scale, uint64_t* bump = nullptr) {
   OptSegs s; memset(&s, 0, sizeof(s));
+  s.bump = bump;
   s.nseg = 2; s.kind = OPT_SGD;
   s.p[0] = d->actor->params; s.g[0] = d->gradbuf; s.n[0] = do_actor ? d->nA : 0; s.lr[0] = d->hp.actor_learning_rate; s.group[0] = 0;
   s.p[1] = d->critic->params; s.g[1] = d->gradbuf + d->nA; s.n[1] = do_critic ? d->nC : 0; s.lr[1] = d->hp.critic_learning_rate; s.group[1] = 1;
@@ -1099,11 +1100,13 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b) {
     g = G.gemm(fc_dx_args(c, l, B, dz, L.n_out, 0, L.n_in, c->ws[1].dz[l - 1], L.n_in, GE_MUL_RELU_GRAD,
                           c->ws[1].fcin[l], L.n_in + 1), {g});
   }
-  {
+  int adz;
+  {   // dQ/da (kept for cpp_ddpg_q_gradients_wrt_actions) and, in the same epilogue, the actor's head gradient
     const float* dz = (cat == nc - 1) ? d->ones : c->ws[1].dz[cat];
-    g = G.gemm(fc_dx_args(c, cat, B, dz, Lcat.n_out, Lcat.n_in - A, A, d->dq_da, A, GE_NONE, nullptr, 0), {g});
+    GemmArgs ga = fc_dx_args(c, cat, B, dz, Lcat.n_out, Lcat.n_in - A, A, d->dq_da, A, GE_ACTOR_HEAD, a->ws[0].out, A);
+    ga.C2 = a->ws[0].dz[na - 1]; ga.ldc2 = A;
+    adz = G.gemm(ga, {g, aF});
   }
-  int adz = G.fn([=] { return launch_actor_head_grad(ctx, a->ws[0].dz[na - 1], d->dq_da, a->ws[0].out, B * A); }, {g});
 
   // ---- actor backward
   for (int l = na - 1; l >= 0; --l) {
@@ -1166,9 +1169,8 @@ static int step_body(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int
   for (int i = 0; i < n_batches; ++i) {
     RC(replay_sample_device(r, B, rows_dev ? rows_dev + (size_t)i * B : nullptr, seed, rows_dev ? nullptr : r->counter, C,
                             d->step_batch));
-    if (!rows_dev) RC(launch_counter_add(d->ctx, r->counter, 1));
     RC(compute_gradients(d, d->step_batch));
-    RC(apply(d, true, true, 1.0f));
+    RC(apply(d, true, true, 1.0f, rows_dev ? nullptr : r->counter));   // also advances the sampler's counter
   }
   return cpp_ddpg_update_targets(d);
 }
