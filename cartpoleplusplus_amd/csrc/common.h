@@ -69,7 +69,15 @@ struct ConvArgs {
   int vec_ok;                // input rows may be staged with aligned 16-byte loads
 };
 
+// Same-geometry convolutions of several networks in ONE launch (blockIdx.y selects the descriptor): the
+// narrow conv2/conv3 layers and their backward kernels do not fill the chip on their own.
+#define CONV_BATCH_MAX 4
+struct ConvArgsN { ConvArgs a[CONV_BATCH_MAX]; int n; };
+
 int launch_conv_fwd(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi, ConvArgs a);
+int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi, const ConvArgs* list, int n);
+int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, const ConvArgs* list, int n,
+                         float* const* grad_w, float* const* grad_b);
 int launch_conv_dw(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, ConvArgs a, float* grad_w,
                    float* grad_b);
 size_t conv_dw_partial_floats(cpp_ctx* ctx, int cin, int ks, int nout);

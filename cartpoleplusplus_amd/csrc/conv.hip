@@ -21,12 +21,22 @@ static void set_tiles(ConvArgs& a, int cin, int xtw) {
   a.ntiles = a.B * a.tiles_x * a.tiles_y;
 }
 
-int launch_conv_fwd(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi, ConvArgs a) {
-  const int xtw = pick_xtw(in_mode, a.W);
-  set_tiles(a, cin, xtw);
-  a.cin_rt = cin;
-  a.vec_ok = vec_ok_for(a, in_mode);
-  if (a.nout > CPP_NOUT_MAX) { cpp_set_error("conv: nout %d > 16", a.nout); return 1; }
+int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi, const ConvArgs* list, int n) {
+  if (n < 1 || n > CONV_BATCH_MAX) { cpp_set_error("conv: batch of %d networks", n); return 1; }
+  const int xtw = pick_xtw(in_mode, list[0].W);
+  ConvArgsN batch; batch.n = n;
+  for (int i = 0; i < n; ++i) {
+    ConvArgs& a = batch.a[i];
+    a = list[i];
+    if (a.H != list[0].H || a.W != list[0].W || a.B != list[0].B || a.nout != list[0].nout) {
+      cpp_set_error("conv: batched networks differ in geometry"); return 1;
+    }
+    set_tiles(a, cin, xtw);
+    a.cin_rt = cin;
+    a.vec_ok = vec_ok_for(a, in_mode);
+    if (a.nout > CPP_NOUT_MAX) { cpp_set_error("conv: nout %d > 16", a.nout); return 1; }
+  }
+  const ConvArgs& a = batch.a[0];
   prof_begin(ctx);
   int rc;
   // (kx,o)-column kernel (experimental, opt-in with CPP_CONV_KXO=1): 20 % fewer MFMAs but measured slower on
@@ -34,42 +44,63 @@ int launch_conv_fwd(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi
   static const bool want_kxo = getenv("CPP_CONV_KXO") != nullptr;
   const bool kxo = want_kxo && epi == EPI_RELU_POOL && a.tiles_x == 1 && a.nout <= 10 && in_mode != IN_DY && cin != 30;
   if (kxo && (in_mode == IN_F16_WHITEN || in_mode == IN_F32_WHITEN))
-    rc = conv_fwd_kxo_dispatch_l1(ctx, cin, ks, xtw, in_mode, a);
+    rc = conv_fwd_kxo_dispatch_l1(ctx, cin, ks, xtw, in_mode, batch);
   else if (kxo)
-    rc = conv_fwd_kxo_dispatch_l23(ctx, cin, ks, xtw, in_mode, a);
+    rc = conv_fwd_kxo_dispatch_l23(ctx, cin, ks, xtw, in_mode, batch);
   else if (in_mode == IN_F16_WHITEN || in_mode == IN_F32_WHITEN)
-    rc = conv_fwd_dispatch_l1(ctx, cin, ks, xtw, in_mode, epi, a);
+    rc = conv_fwd_dispatch_l1(ctx, cin, ks, xtw, in_mode, epi, batch);
   else
-    rc = conv_fwd_dispatch_l23(ctx, cin, ks, xtw, in_mode, epi, a);
+    rc = conv_fwd_dispatch_l23(ctx, cin, ks, xtw, in_mode, epi, batch);
   prof_end(ctx, kid);
   return rc;
+}
+
+int launch_conv_fwd(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi, ConvArgs a) {
+  return launch_conv_fwd_multi(ctx, kid, cin, ks, in_mode, epi, &a, 1);
 }
 
 size_t conv_dw_partial_floats(cpp_ctx* ctx, int cin, int ks, int nout) {
   return (size_t)(ctx->num_cus * 2) * (size_t)(ks * ks * cin * nout + nout);
 }
 
-int launch_conv_dw(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, ConvArgs a, float* grad_w,
-                   float* grad_b) {
-  const int xtw = pick_xtw(in_mode, a.W);
-  set_tiles(a, cin, xtw);
-  a.cin_rt = cin;
-  a.vec_ok = vec_ok_for(a, in_mode);
-  const int nw = ks * ks * cin * a.nout;
-  a.pstride = nw + a.nout;
+int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, const ConvArgs* list, int n,
+                         float* const* grad_w, float* const* grad_b) {
+  if (n < 1 || n > CONV_BATCH_MAX) { cpp_set_error("conv dW: batch of %d networks", n); return 1; }
+  const int xtw = pick_xtw(in_mode, list[0].W);
+  const int nout = list[0].nout;
+  const int nw = ks * ks * cin * nout;
+  ConvArgsN batch; batch.n = n;
+  for (int i = 0; i < n; ++i) {
+    ConvArgs& a = batch.a[i];
+    a = list[i];
+    if (a.H != list[0].H || a.W != list[0].W || a.B != list[0].B || a.nout != nout) {
+      cpp_set_error("conv dW: batched networks differ in geometry"); return 1;
+    }
+    set_tiles(a, cin, xtw);
+    a.cin_rt = cin;
+    a.vec_ok = vec_ok_for(a, in_mode);
+    a.pstride = nw + nout;
+  }
   int grid = 0, rc;
   prof_begin(ctx);
   if (in_mode == IN_F16_WHITEN || in_mode == IN_F32_WHITEN)
-    rc = conv_dw_dispatch_l1(ctx, cin, ks, xtw, in_mode, a, &grid);
+    rc = conv_dw_dispatch_l1(ctx, cin, ks, xtw, in_mode, batch, &grid);
   else
-    rc = conv_dw_dispatch_l23(ctx, cin, ks, xtw, in_mode, a, &grid);
+    rc = conv_dw_dispatch_l23(ctx, cin, ks, xtw, in_mode, batch, &grid);
   prof_end(ctx, kid);
   if (rc) return rc;
-  if (ctx->npending == DW_REDUCE_MAX) { rc = flush_dw_reduce(ctx); if (rc) return rc; }
-  DwReduceDesc& d = ctx->pending[ctx->npending++];
-  d.partial = a.partial; d.nblocks = grid; d.pstride = a.pstride; d.nw = nw; d.nout = a.nout;
-  d.grad_w = grad_w; d.grad_b = grad_b;
+  for (int i = 0; i < n; ++i) {
+    if (ctx->npending == DW_REDUCE_MAX) { rc = flush_dw_reduce(ctx); if (rc) return rc; }
+    DwReduceDesc& d = ctx->pending[ctx->npending++];
+    d.partial = batch.a[i].partial; d.nblocks = grid; d.pstride = nw + nout; d.nw = nw; d.nout = nout;
+    d.grad_w = grad_w[i]; d.grad_b = grad_b[i];
+  }
   return 0;
+}
+
+int launch_conv_dw(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, ConvArgs a, float* grad_w,
+                   float* grad_b) {
+  return launch_conv_dw_multi(ctx, kid, cin, ks, in_mode, &a, 1, &grad_w, &grad_b);
 }
 
 int flush_dw_reduce(cpp_ctx* ctx) {

@@ -7,7 +7,7 @@
   if (cin == CIN_ && in_mode == IN_F32_WHITEN)                                                     \
     return conv_dw_launch_t<CIN_, 5, 4, IN_F32_WHITEN>(ctx, a, grid);
 
-int conv_dw_dispatch_l1(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, const ConvArgs& a,
+int conv_dw_dispatch_l1(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, const ConvArgsN& a,
                         int* grid) {
   if (ks != 5 || xtw != 4) {
     cpp_set_error("conv1 dW: unsupported geometry ks=%d xtw=%d", ks, xtw);

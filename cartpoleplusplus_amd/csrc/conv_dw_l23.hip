@@ -43,7 +43,7 @@ int launch_dw_reduce_batch(cpp_ctx* ctx, const DwReduceBatch& rb) {
   if (ks == KS_ && xtw == XTW_ && in_mode == IN_F32_PLAIN)                                         \
     return conv_dw_launch_t<10, KS_, XTW_, IN_F32_PLAIN>(ctx, a, grid);
 
-int conv_dw_dispatch_l23(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, const ConvArgs& a,
+int conv_dw_dispatch_l23(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, const ConvArgsN& a,
                          int* grid) {
   if (cin != 10) {
     cpp_set_error("conv2/3 dW: expected 10 input channels, got %d", cin);

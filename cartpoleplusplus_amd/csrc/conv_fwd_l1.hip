@@ -8,7 +8,7 @@
     return conv_fwd_launch_t<CIN_, 5, 4, IN_F32_WHITEN, EPI_RELU_POOL>(ctx, a);
 
 int conv_fwd_dispatch_l1(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, int epi,
-                         const ConvArgs& a) {
+                         const ConvArgsN& a) {
   if (ks != 5 || xtw != 4 || epi != EPI_RELU_POOL) {
     cpp_set_error("conv1 forward: unsupported geometry ks=%d xtw=%d", ks, xtw);
     return 1;

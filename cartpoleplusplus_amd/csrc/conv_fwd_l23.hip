@@ -9,7 +9,7 @@
     return conv_fwd_launch_t<10, KS_, XTW_, IN_DY, EPI_PLAIN>(ctx, a);
 
 int conv_fwd_dispatch_l23(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, int epi,
-                          const ConvArgs& a) {
+                          const ConvArgsN& a) {
   if (cin != 10) {
     cpp_set_error("conv2/3: expected 10 input channels, got %d", cin);
     return 1;

@@ -35,6 +35,15 @@ constexpr int conv_wps(int cin, int ks, int xtw) {
   return ((conv_th(cin, xtw) + ks - 1) * (16 * xtw + ks - 1) * cin * 4 > 76 * 1024) ? 1 : 2;
 }
 
+// persistent workgroups per descriptor: the chip's resident capacity split over the batched networks, kept a
+// multiple of 8 so every XCD gets a contiguous run of tiles
+static inline int conv_grid_x(int capacity, int n, int ntiles) {
+  int g = capacity / (n > 0 ? n : 1);
+  if (g >= 8) g &= ~7;
+  if (g < 1) g = 1;
+  return g > ntiles ? ntiles : g;
+}
+
 // XCD-aware persistent tile order: workgroup b runs on XCD b % 8 (observed dispatch order, speed
 // only); give every XCD a contiguous run of tiles so neighbouring row tiles of one image (which share
 // 4 halo rows) hit the same 4 MiB L2.
@@ -209,7 +218,8 @@ template <> struct StageType<IN_F16_WHITEN> { typedef __half type; };
 // forward / dX kernel
 // ---------------------------------------------------------------------------------------------
 template <int CIN, int KS, int XTW, int IN_MODE, int EPI>
-__global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd_kernel(const ConvArgsN batch) {
+  const ConvArgs& a = batch.a[blockIdx.y];
   constexpr int TR = conv_th(CIN, XTW) + KS - 1, TCOLS = 16 * XTW, TC = TCOLS + KS - 1;
   constexpr int KROW = (KS * CIN + 3) / 4;
   constexpr int TILE = TR * TC * CIN;
@@ -387,7 +397,8 @@ __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd
 constexpr int KXO_PBW = 52;      // floats per buffer row: 50 columns + pad (16-lane groups 4 rows apart miss each other's banks)
 
 template <int CIN, int KS, int XTW, int IN_MODE>
-__global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd_kxo_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd_kxo_kernel(const ConvArgsN batch) {
+  const ConvArgs& a = batch.a[blockIdx.y];
   constexpr int P = KS / 2, TR = conv_th(CIN, XTW) + KS - 1, TCOLS = 16 * XTW, TC = TCOLS + KS - 1;
   constexpr int KK = (KS * CIN + 3) / 4;                  // k-steps over k = ky*CIN + c
   constexpr int NTC = (KS * 10 + 15) / 16;                // column tiles over col = kx*nout + o
@@ -552,7 +563,8 @@ __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd
 }
 
 template <int CIN, int KS, int XTW, int IN_MODE>
-static inline int conv_fwd_kxo_launch_t(cpp_ctx* ctx, const ConvArgs& a) {
+static inline int conv_fwd_kxo_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
+  const ConvArgs& a = batch.a[0];
   constexpr int P = KS / 2, TR = conv_th(CIN, XTW) + KS - 1, TC = 16 * XTW + KS - 1;
   const size_t lds_bytes = (size_t)(TR * TC * CIN + CONV_LDS_PAD + 2 * CIN + 4 * (16 + 2 * P) * KXO_PBW) * sizeof(float);
   auto kern = conv_fwd_kxo_kernel<CIN, KS, XTW, IN_MODE>;
@@ -562,9 +574,8 @@ static inline int conv_fwd_kxo_launch_t(cpp_ctx* ctx, const ConvArgs& a) {
     attr_done = true;
   }
   const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
-  int grid = ctx->num_cus * per_cu;
-  if (grid > a.ntiles) grid = a.ntiles;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(CONV_THREADS), lds_bytes, ctx->stream, a);
+  const int grid = conv_grid_x(ctx->num_cus * per_cu, batch.n, a.ntiles);
+  hipLaunchKernelGGL(kern, dim3(grid, batch.n), dim3(CONV_THREADS), lds_bytes, ctx->stream, batch);
   LAUNCH_CHECK();
   return 0;
 }
@@ -639,7 +650,8 @@ struct DyStager {
 
 template <int CIN, int KS, int XTW, int IN_MODE>
 __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW))
-__attribute__((amdgpu_waves_per_eu(conv_wps(CIN, KS, XTW), conv_wps(CIN, KS, XTW)))) void conv_dw_kernel(const ConvArgs a) {
+__attribute__((amdgpu_waves_per_eu(conv_wps(CIN, KS, XTW), conv_wps(CIN, KS, XTW)))) void conv_dw_kernel(const ConvArgsN batch) {
+  const ConvArgs& a = batch.a[blockIdx.y];
   constexpr int TR = conv_th(CIN, XTW) + KS - 1, TCOLS = 16 * XTW, TC = TCOLS + KS - 1;
   constexpr int TILE = TR * TC * CIN;
   constexpr int KT = DwGeom<CIN, KS>::KT, NT = DwGeom<CIN, KS>::NT;
@@ -808,7 +820,8 @@ struct DwReduceBatch { DwReduceDesc d[DW_REDUCE_MAX]; int block_start[DW_REDUCE_
 int launch_dw_reduce_batch(cpp_ctx* ctx, const DwReduceBatch& rb);
 
 template <int CIN, int KS, int XTW, int IN_MODE, int EPI>
-static inline int conv_fwd_launch_t(cpp_ctx* ctx, const ConvArgs& a) {
+static inline int conv_fwd_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
+  const ConvArgs& a = batch.a[0];
   constexpr int TR = conv_th(CIN, XTW) + KS - 1, TC = 16 * XTW + KS - 1;
   const size_t lds_bytes = (size_t)(TR * TC * CIN + CONV_LDS_PAD + 2 * CIN) * sizeof(float);
   auto kern = conv_fwd_kernel<CIN, KS, XTW, IN_MODE, EPI>;
@@ -819,9 +832,8 @@ static inline int conv_fwd_launch_t(cpp_ctx* ctx, const ConvArgs& a) {
     attr_done = true;
   }
   const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
-  int grid = ctx->num_cus * per_cu;
-  if (grid > a.ntiles) grid = a.ntiles;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(CONV_THREADS), lds_bytes, ctx->stream, a);
+  const int grid = conv_grid_x(ctx->num_cus * per_cu, batch.n, a.ntiles);
+  hipLaunchKernelGGL(kern, dim3(grid, batch.n), dim3(CONV_THREADS), lds_bytes, ctx->stream, batch);
   LAUNCH_CHECK();
   return 0;
 }
@@ -833,7 +845,8 @@ static inline int conv_dw_grid(cpp_ctx* ctx, int xtw_max) {
 }
 
 template <int CIN, int KS, int XTW, int IN_MODE>
-static inline int conv_dw_launch_t(cpp_ctx* ctx, const ConvArgs& a, int* grid_out) {
+static inline int conv_dw_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int* grid_out) {
+  const ConvArgs& a = batch.a[0];
   constexpr int TR = conv_th(CIN, XTW) + KS - 1, TC = 16 * XTW + KS - 1;
   constexpr int NT = DwGeom<CIN, KS>::NT;
   constexpr int GMF = (conv_th(CIN, XTW) / 2) * (8 * XTW) * DW_GP;
@@ -848,19 +861,18 @@ static inline int conv_dw_launch_t(cpp_ctx* ctx, const ConvArgs& a, int* grid_ou
     attr_done = true;
   }
   const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
-  int grid = ctx->num_cus * per_cu;
-  if (grid > a.ntiles) grid = a.ntiles;
+  const int grid = conv_grid_x(ctx->num_cus * per_cu, batch.n, a.ntiles);
   *grid_out = grid;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(CONV_THREADS), lds_bytes, ctx->stream, a);
+  hipLaunchKernelGGL(kern, dim3(grid, batch.n), dim3(CONV_THREADS), lds_bytes, ctx->stream, batch);
   LAUNCH_CHECK();
   return 0;
 }
 
 // per-translation-unit dispatchers (each .hip file instantiates a slice of the template space so the
 // big fully-unrolled kernels compile in parallel)
-int conv_fwd_dispatch_l1(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, int epi, const ConvArgs& a);
-int conv_fwd_kxo_dispatch_l1(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, const ConvArgs& a);
-int conv_fwd_kxo_dispatch_l23(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, const ConvArgs& a);
-int conv_fwd_dispatch_l23(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, int epi, const ConvArgs& a);
-int conv_dw_dispatch_l1(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, const ConvArgs& a, int* grid);
-int conv_dw_dispatch_l23(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, const ConvArgs& a, int* grid);
+int conv_fwd_dispatch_l1(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, int epi, const ConvArgsN& a);
+int conv_fwd_kxo_dispatch_l1(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, const ConvArgsN& a);
+int conv_fwd_kxo_dispatch_l23(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, const ConvArgsN& a);
+int conv_fwd_dispatch_l23(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, int epi, const ConvArgsN& a);
+int conv_dw_dispatch_l1(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, const ConvArgsN& a, int* grid);
+int conv_dw_dispatch_l23(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, const ConvArgsN& a, int* grid);

@@ -359,23 +359,55 @@ static const int kFwdKid[3] = {K_CONV1_FWD, K_CONV2_FWD, K_CONV3_FWD};
 static const int kDwKid[3] = {K_CONV1_DW, K_CONV2_DW, K_CONV3_DW};
 static const int kDxKid[3] = {-1, K_CONV2_DX, K_CONV3_DX};
 
+// launch descriptors of conv layer i of a network (forward, dW, dX)
+static ConvArgs conv_fwd_args(cpp_net* n, Workspace& w, int i, const void* state, int dtype, const float* white, int B, int* mode) {
+  const ConvL& L = n->conv[i];
+  ConvArgs a; memset(&a, 0, sizeof(a));
+  if (i == 0) { a.in = state; a.in_bstride = n->state_elems; a.scale = white; a.shift = white + n->spec.C;
+                *mode = dtype == CPP_F16 ? IN_F16_WHITEN : IN_F32_WHITEN; }
+  else { a.in = w.pool[i - 1]; a.in_bstride = (long)L.H * L.W * L.Cin; *mode = IN_F32_PLAIN; }
+  a.w = n->params + L.w_off; a.bias = n->params + L.b_off;
+  a.out = w.pool[i]; a.out_bstride = (i == 2) ? (long)n->flat + 1 : (long)L.Hp * L.Wp * kConvOut;
+  a.out_amax = w.amax[i];
+  a.B = B; a.H = L.H; a.W = L.W; a.nout = kConvOut;
+  return a;
+}
+static void conv_dy_desc(cpp_net* n, Workspace& w, int i, ConvArgs& a, int B) {
+  const ConvL& L = n->conv[i];
+  a.dy.dpool = w.dpool[i]; a.dy.pool = w.pool[i]; a.dy.amax = w.amax[i];
+  a.dy.dpool_bstride = (i == 2) ? (long)n->flat : (long)L.Hp * L.Wp * kConvOut;
+  a.dy.pool_bstride = (i == 2) ? (long)n->flat + 1 : (long)L.Hp * L.Wp * kConvOut;
+  a.dy.Hp = L.Hp; a.dy.Wp = L.Wp;
+  a.B = B; a.H = L.H; a.W = L.W;
+}
+static ConvArgs conv_dw_args(cpp_net* n, Workspace& w, int i, const void* state, int dtype, const float* white, int B, int* mode) {
+  const ConvL& L = n->conv[i];
+  ConvArgs d; memset(&d, 0, sizeof(d));
+  conv_dy_desc(n, w, i, d, B);
+  if (i == 0) { d.in = state; d.in_bstride = n->state_elems; d.scale = white; d.shift = white + n->spec.C;
+                *mode = dtype == CPP_F16 ? IN_F16_WHITEN : IN_F32_WHITEN; }
+  else { d.in = w.pool[i - 1]; d.in_bstride = (long)L.H * L.W * L.Cin; *mode = IN_F32_PLAIN; }
+  d.nout = kConvOut; d.partial = n->dw_partial[i];
+  return d;
+}
+static ConvArgs conv_dx_args(cpp_net* n, Workspace& w, int i, int B) {
+  const ConvL& L = n->conv[i];
+  ConvArgs x; memset(&x, 0, sizeof(x));
+  conv_dy_desc(n, w, i, x, B);
+  x.w = n->params + L.w_off; x.nout = L.Cin;
+  x.out = w.dpool[i - 1]; x.out_bstride = (long)L.H * L.W * L.Cin;
+  return x;
+}
+
 // conv trunk (pixel) or state conversion (low-dim) into ws.fcin[0]
 static int net_forward_trunk(cpp_net* n, Workspace& w, const void* state, int dtype, const float* white, int B) {
   cpp_ctx* ctx = n->ctx;
   if (!n->spec.pixel)
     return launch_state_to_f32(ctx, w.fcin[0], n->fc[0].n_in + 1, state, dtype, n->state_elems, B);
   for (int i = 0; i < 3; ++i) {
-    const ConvL& L = n->conv[i];
-    ConvArgs a; memset(&a, 0, sizeof(a));
     int mode;
-    if (i == 0) { a.in = state; a.in_bstride = n->state_elems; a.scale = white; a.shift = white + n->spec.C;
-                  mode = dtype == CPP_F16 ? IN_F16_WHITEN : IN_F32_WHITEN; }
-    else { a.in = w.pool[i - 1]; a.in_bstride = (long)L.H * L.W * L.Cin; mode = IN_F32_PLAIN; }
-    a.w = n->params + L.w_off; a.bias = n->params + L.b_off;
-    a.out = w.pool[i]; a.out_bstride = (i == 2) ? (long)n->flat + 1 : (long)L.Hp * L.Wp * kConvOut;
-    a.out_amax = w.amax[i];
-    a.B = B; a.H = L.H; a.W = L.W; a.nout = kConvOut;
-    RC(launch_conv_fwd(ctx, kFwdKid[i], L.Cin, L.ks, mode, EPI_RELU_POOL, a));
+    ConvArgs a = conv_fwd_args(n, w, i, state, dtype, white, B, &mode);
+    RC(launch_conv_fwd(ctx, kFwdKid[i], n->conv[i].Cin, n->conv[i].ks, mode, EPI_RELU_POOL, a));
   }
   return CPP_OK;
 }
@@ -402,27 +434,28 @@ static int net_backward_conv(cpp_net* n, Workspace& w, int B, const void* state,
   cpp_ctx* ctx = n->ctx;
   for (int i = 2; i >= 0; --i) {
     const ConvL& L = n->conv[i];
-    ConvArgs a; memset(&a, 0, sizeof(a));
-    a.dy.dpool = w.dpool[i]; a.dy.pool = w.pool[i]; a.dy.amax = w.amax[i];
-    a.dy.dpool_bstride = (i == 2) ? (long)n->flat : (long)L.Hp * L.Wp * kConvOut;
-    a.dy.pool_bstride = (i == 2) ? (long)n->flat + 1 : (long)L.Hp * L.Wp * kConvOut;
-    a.dy.Hp = L.Hp; a.dy.Wp = L.Wp;
-    a.B = B; a.H = L.H; a.W = L.W;
-    // dW / db
-    ConvArgs d = a;
     int mode;
-    if (i == 0) { d.in = state; d.in_bstride = n->state_elems; d.scale = white; d.shift = white + n->spec.C;
-                  mode = dtype == CPP_F16 ? IN_F16_WHITEN : IN_F32_WHITEN; }
-    else { d.in = w.pool[i - 1]; d.in_bstride = (long)L.H * L.W * L.Cin; mode = IN_F32_PLAIN; }
-    d.nout = kConvOut; d.partial = n->dw_partial[i];
+    ConvArgs d = conv_dw_args(n, w, i, state, dtype, white, B, &mode);
     RC(launch_conv_dw(ctx, kDwKid[i], L.Cin, L.ks, mode, d, n->grads + L.w_off, n->grads + L.b_off));
-    // dX -> gradient w.r.t. the previous pooled output (conv1's input is data: no dX)
-    if (i > 0) {
-      ConvArgs x = a;
-      x.w = n->params + L.w_off; x.nout = L.Cin;
-      x.out = w.dpool[i - 1]; x.out_bstride = (long)L.H * L.W * L.Cin;
-      RC(launch_conv_fwd(ctx, kDxKid[i], kConvOut, L.ks, IN_DY, EPI_PLAIN, x));
+    if (i > 0)      // dX -> gradient w.r.t. the previous pooled output (conv1's input is data: no dX)
+      RC(launch_conv_fwd(ctx, kDxKid[i], kConvOut, L.ks, IN_DY, EPI_PLAIN, conv_dx_args(n, w, i, B)));
+  }
+  return CPP_OK;
+}
+
+// the same for several networks with identical geometry, every layer's kernels batched into one launch
+static int nets_backward_conv(cpp_ctx* ctx, cpp_net* const* nets, int nn, int B, const void* state, int dtype, const float* white) {
+  for (int i = 2; i >= 0; --i) {
+    const ConvL& L = nets[0]->conv[i];
+    ConvArgs dl[CONV_BATCH_MAX], xl[CONV_BATCH_MAX]; float *gw[CONV_BATCH_MAX], *gb[CONV_BATCH_MAX];
+    int mode = 0;
+    for (int k = 0; k < nn; ++k) {
+      dl[k] = conv_dw_args(nets[k], nets[k]->ws[0], i, state, dtype, white, B, &mode);
+      gw[k] = nets[k]->grads + L.w_off; gb[k] = nets[k]->grads + L.b_off;
+      if (i > 0) xl[k] = conv_dx_args(nets[k], nets[k]->ws[0], i, B);
     }
+    RC(launch_conv_dw_multi(ctx, kDwKid[i], L.Cin, L.ks, mode, dl, nn, gw, gb));
+    if (i > 0) RC(launch_conv_fwd_multi(ctx, kDxKid[i], kConvOut, L.ks, IN_DY, EPI_PLAIN, xl, nn));
   }
   return CPP_OK;
 }
@@ -1061,11 +1094,32 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b) {
   const long ldcat = Lcat.n_in + 1;
   OpGraph G;
 
-  // ---- forward
-  const int tA = G.fn([=] { return net_forward_trunk(a, a->ws[0], s1, dt, w1, B); }, {});
-  const int tC = G.fn([=] { return net_forward_trunk(c, c->ws[0], s1, dt, w1, B); }, {});
-  const int tTA = G.fn([=] { return net_forward_trunk(ta, ta->ws[0], s2, dt, w2, B); }, {});
-  const int tTC = G.fn([=] { return net_forward_trunk(tc, tc->ws[0], s2, dt, w2, B); }, {});
+  // ---- forward: the four conv trunks.  conv1 saturates the chip per network; the narrow conv2 / conv3 layers
+  // of all four networks share one launch each.
+  int tA, tC, tTA, tTC;
+  if (a->spec.pixel) {
+    cpp_net* nets[4] = {a, c, ta, tc};
+    const void* sts[4] = {s1, s1, s2, s2};
+    const float* whs[4] = {w1, w1, w2, w2};
+    const int t1 = G.fn([=] {
+      for (int k = 0; k < 4; ++k) {
+        int mode;
+        ConvArgs ca = conv_fwd_args(nets[k], nets[k]->ws[0], 0, sts[k], dt, whs[k], B, &mode);
+        RC(launch_conv_fwd(ctx, kFwdKid[0], nets[k]->conv[0].Cin, nets[k]->conv[0].ks, mode, EPI_RELU_POOL, ca));
+      }
+      for (int i = 1; i < 3; ++i) {
+        ConvArgs cl[4]; int mode = 0;
+        for (int k = 0; k < 4; ++k) cl[k] = conv_fwd_args(nets[k], nets[k]->ws[0], i, sts[k], dt, whs[k], B, &mode);
+        RC(launch_conv_fwd_multi(ctx, kFwdKid[i], a->conv[i].Cin, a->conv[i].ks, mode, EPI_RELU_POOL, cl, 4));
+      }
+      return (int)CPP_OK; }, {});
+    tA = tC = tTA = tTC = t1;
+  } else {
+    tA = G.fn([=] { return net_forward_trunk(a, a->ws[0], s1, dt, w1, B); }, {});
+    tC = G.fn([=] { return net_forward_trunk(c, c->ws[0], s1, dt, w1, B); }, {});
+    tTA = G.fn([=] { return net_forward_trunk(ta, ta->ws[0], s2, dt, w2, B); }, {});
+    tTC = G.fn([=] { return net_forward_trunk(tc, tc->ws[0], s2, dt, w2, B); }, {});
+  }
   const int cb = G.fn([=] { return launch_copy_cols(ctx, c->ws[0].fcin[cat], ldcat, Lcat.n_in - A, b->a, A, 0, A, B); }, {});
   int aF = tA, taF = tTA;
   for (int l = 0; l < na; ++l) {
@@ -1118,7 +1172,6 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b) {
     else if (a->spec.pixel)
       adz = G.gemm(fc_dx_args(a, 0, B, a->ws[0].dz[0], L.n_out, 0, a->flat, a->ws[0].dpool[2], a->flat, GE_NONE, nullptr, 0), {adz});
   }
-  if (a->spec.pixel) G.fn([=] { return net_backward_conv(a, a->ws[0], B, s1, dt, w1); }, {adz});
 
   // ---- TD target + critic backward on the first evaluation (fed actions)
   int cdz = G.fn([=] { return launch_td(ctx, c->ws[0].out, tc->ws[0].out, b->r, b->m, d->hp.discount, B, d->td,
@@ -1133,7 +1186,10 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b) {
     else if (c->spec.pixel)
       cdz = G.gemm(fc_dx_args(c, 0, B, c->ws[0].dz[0], L.n_out, 0, c->flat, c->ws[0].dpool[2], c->flat, GE_NONE, nullptr, 0), {cdz});
   }
-  if (c->spec.pixel) G.fn([=] { return net_backward_conv(c, c->ws[0], B, s1, dt, w1); }, {cdz});
+  if (c->spec.pixel) {     // both conv backward passes, layer by layer, two networks per launch
+    cpp_net* bn[2] = {a, c};
+    G.fn([=] { return nets_backward_conv(ctx, bn, 2, B, s1, dt, w1); }, {adz, cdz});
+  }
   RC(G.run(ctx));
   return flush_dw_reduce(ctx);      // all six dW reductions (3 layers x 2 networks) in one launch
 }
