@@ -74,6 +74,34 @@ __device__ __forceinline__ void conv_stage_tile(float* lds, const ConvArgs& a, i
                                                 int tid) {
   constexpr int P = KS / 2, TR = conv_th(CIN, XTW) + KS - 1, TC = 16 * XTW + KS - 1;
   constexpr int TILE = TR * TC * CIN;
+  if (IN_MODE == IN_DY) {
+    // dY tile rebuilt from POOLED cells: one (dpool, pool, amax) triple serves the 4 full-resolution positions
+    // of its 2x2 window (4x fewer loads than per element).  The cells tile the plane, so every tile position is
+    // written exactly once (zeros outside the image / where the arg-max is elsewhere).
+    const DyDesc& d = a.dy;
+    const int ty0 = y0 - P, tx0 = x0 - P;
+    const int pr0 = ty0 >> 1, pc0 = tx0 >> 1;                       // floor, also for negatives
+    constexpr int NPR = TR / 2 + 1, NPC = TC / 2 + 1;
+    for (int idx = tid; idx < NPR * NPC * CIN; idx += CONV_THREADS) {
+      const int c = idx % CIN;
+      const int cell = idx / CIN;
+      const int py = pr0 + cell / NPC, px = pc0 + cell % NPC;
+      float gmv = 0.f; int code = -1;
+      if (py >= 0 && py < d.Hp && px >= 0 && px < d.Wp) {
+        const long e = (long)(py * d.Wp + px) * CIN + c;
+        const float pv = d.pool[(long)b * d.pool_bstride + e];
+        gmv = pv > 0.f ? d.dpool[(long)b * d.dpool_bstride + e] : 0.f;
+        code = d.amax[(long)b * d.Hp * d.Wp * CIN + e];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = 2 * py + (k >> 1) - ty0, col = 2 * px + (k & 1) - tx0;
+        if (row >= 0 && row < TR && col >= 0 && col < TC)
+          lds[(row * TC + col) * CIN + c] = (code == k) ? gmv : 0.f;
+      }
+    }
+    return;
+  }
   for (int idx = tid; idx < TILE; idx += CONV_THREADS) {
     const int c = idx % CIN;
     const int pc = idx / CIN;
@@ -88,11 +116,9 @@ __device__ __forceinline__ void conv_stage_tile(float* lds, const ConvArgs& a, i
       } else if (IN_MODE == IN_F32_WHITEN) {
         const float* src = (const float*)a.in + (long)b * a.in_bstride;
         v = src[((long)gy * a.W + gx) * CIN + c] * a.scale[c] + a.shift[c];
-      } else if (IN_MODE == IN_F32_PLAIN) {
+      } else {
         const float* src = (const float*)a.in + (long)b * a.in_bstride;
         v = src[((long)gy * a.W + gx) * CIN + c];
-      } else {
-        v = dy_value(a.dy, b, gy, gx, c, CIN);
       }
     }
     lds[idx] = v;
