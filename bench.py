@@ -182,7 +182,10 @@ def main():
     F, Bk, per_layer = conv_macs(shape)
     conv_flops_step = 2.0 * B * (4 * F + 2 * Bk)
     c1_ms, c1_n = prof.get("conv1_fwd", (0.0, 0))
-    flops_per_launch = 2.0 * B * per_layer[0]             # one network's conv1 forward over the minibatch
+    # a step runs conv1 forward for 4 networks (actor, critic, both targets); the fused step batches them
+    # into c1_n / pm launches (blockIdx.y = network), each over the whole minibatch
+    nets_per_launch = 4.0 * pm / max(c1_n, 1)
+    flops_per_launch = 2.0 * B * per_layer[0] * nets_per_launch
     avg_ms = c1_ms / max(c1_n, 1)
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
     kernels = {k: {"ms_per_step": round(v[0] / pm, 4), "launches_per_step": round(v[1] / pm, 2)}
@@ -217,7 +220,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "conv1_fwd", "achieved": round(achieved, 3),
                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                      "traffic": traffic, "traffic_source": traffic_src, "flops_per_launch": flops_per_launch, "avg_launch_ms": round(avg_ms, 5),
-                     "launches": int(c1_n)},
+                     "launches": int(c1_n), "networks_per_launch": nets_per_launch},
         "kernels": kernels,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
