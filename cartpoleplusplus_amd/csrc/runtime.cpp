@@ -1422,38 +1422,102 @@ static int naf_head(cpp_naf* f, cpp_batch* b, bool backward) {
   return launch_naf_head(f->ctx, a);
 }
 
+// backward of the fully connected stack of a network without an action splice, from layer `start` down:
+// per layer {[dW;db], dX} as two independent GEMMs.  Returns the op that completes d(flat) (pixel) / dz[0].
+static int add_fc_backward(OpGraph& G, cpp_net* n, Workspace& w, int B, int start, int dep) {
+  for (int l = start; l >= 0; --l) {
+    const FcL& L = n->fc[l];
+    G.gemm(fc_dw_args(n, w, l, B, w.dz[l]), {dep});
+    if (l > 0)
+      dep = G.gemm(fc_dx_args(n, l, B, w.dz[l], L.n_out, 0, L.n_in, w.dz[l - 1], L.n_in, GE_MUL_RELU_GRAD, w.fcin[l], L.n_in + 1), {dep});
+    else if (n->spec.pixel)
+      dep = G.gemm(fc_dx_args(n, 0, B, w.dz[0], L.n_out, 0, n->flat, w.dpool[2], n->flat, GE_NONE, nullptr, 0), {dep});
+  }
+  return dep;
+}
+
+// One NAF minibatch (naf_cartpole.py:264-272 without the apply) as a dependency graph, batched like the DDPG
+// step: conv layers of the networks that run them share launches, independent GEMMs share launches.
 static int naf_compute_gradients(cpp_naf* f, cpp_batch* b) {
   cpp_ctx* ctx = f->ctx;
-  cpp_net *v = f->value, *mu = f->mu, *lv = f->lv;
-  const int B = b->B, C = v->spec.pixel ? v->spec.C : 0;
+  cpp_net *v = f->value, *tv = f->tvalue, *mu = f->mu, *lv = f->lv;
+  const int B = b->B, C = v->spec.pixel ? v->spec.C : 0, dt = b->dtype;
   const float *w1 = white_of(b, 0, C), *w2 = white_of(b, 1, C);
-  RC(naf_forward(f, b->s[0], b->s[1], b->dtype, w1, w2, B));
-  RC(naf_head(f, b, true));
-  if (!f->share) {
-    RC(net_backward(v, v->ws[0], B, true, nullptr, b->s[0], b->dtype, w1));
-    RC(net_backward(mu, mu->ws[0], B, true, nullptr, b->s[0], b->dtype, w1));
-    RC(net_backward(lv, lv->ws[0], B, true, nullptr, b->s[0], b->dtype, w1));
-    return CPP_OK;
+  const void *s1 = b->s[0], *s2 = b->s[1];
+  const bool share = f->share != 0;
+  OpGraph G;
+
+  // ---- forward trunks
+  cpp_net* tn[4]; const void* ts[4]; const float* tw[4]; int nt = 0;
+  tn[nt] = v; ts[nt] = s1; tw[nt] = w1; ++nt;
+  if (!share) { tn[nt] = mu; ts[nt] = s1; tw[nt] = w1; ++nt; tn[nt] = lv; ts[nt] = s1; tw[nt] = w1; ++nt; }
+  tn[nt] = tv; ts[nt] = s2; tw[nt] = w2; ++nt;
+  int t1;
+  if (v->spec.pixel) {
+    std::vector<cpp_net*> nets(tn, tn + nt); std::vector<const void*> sts(ts, ts + nt); std::vector<const float*> whs(tw, tw + nt);
+    t1 = G.fn([=] {
+      for (int i = 0; i < 3; ++i) {
+        ConvArgs cl[CONV_BATCH_MAX]; int mode = 0;
+        for (int k = 0; k < nt; ++k) cl[k] = conv_fwd_args(nets[k], nets[k]->ws[0], i, sts[k], dt, whs[k], B, &mode);
+        RC(launch_conv_fwd_multi(ctx, kFwdKid[i], v->conv[i].Cin, v->conv[i].ks, mode, EPI_RELU_POOL, cl, nt));
+      }
+      return (int)CPP_OK; }, {});
+  } else {
+    std::vector<cpp_net*> nets(tn, tn + nt); std::vector<const void*> sts(ts, ts + nt);
+    t1 = G.fn([=] {
+      for (int k = 0; k < nt; ++k) RC(net_forward_trunk(nets[k], nets[k]->ws[0], sts[k], dt, nullptr, B));
+      return (int)CPP_OK; }, {});
   }
-  // shared representation: head gradients, then d(rep) = sum of the three heads' contributions
-  const int Lh = (int)v->fc.size() - 1;          // index of value's 'fc' head
-  const FcL& hv = v->fc[Lh];
-  const int rep = hv.n_in;
-  struct Head { cpp_net* n; const FcL* L; const float* dz; };
-  Head heads[3] = {{v, &hv, v->ws[0].dz[Lh]}, {mu, &mu->fc[0], mu->ws[0].dz[0]}, {lv, &lv->fc[0], lv->ws[0].dz[0]}};
-  float* drep; long ldd; int final_epi = GE_NONE; const float* Y = nullptr; long ldy = 0;
-  if (Lh > 0) { drep = v->ws[0].dz[Lh - 1]; ldd = rep; final_epi = GE_MUL_RELU_GRAD; Y = v->ws[0].fcin[Lh]; ldy = rep + 1; }
-  else if (v->spec.pixel) { drep = v->ws[0].dpool[2]; ldd = rep; }
-  else { drep = nullptr; ldd = 0; }
-  for (int k = 0; k < 3; ++k) {
-    const Head& h = heads[k];
-    const float* x = v->ws[0].fcin[Lh];          // [rep, 1] rows, shared by the three heads
-    RC(gemm(ctx, x, 1, rep + 1, h.dz, h.L->n_out, 1, h.n->grads + h.L->w_off, h.L->n_out, rep + 1, h.L->n_out, B, GE_NONE));
-    if (drep)
-      RC(gemm(ctx, h.dz, h.L->n_out, 1, h.n->params + h.L->w_off, 1, h.L->n_out, drep, ldd, B, rep, h.L->n_out,
-              k == 2 ? final_epi : GE_NONE, k == 2 ? Y : nullptr, ldy, k > 0));
+  // ---- forward MLPs
+  auto chain = [&](cpp_net* n, int from, int dep) {
+    for (int l = from; l < (int)n->fc.size(); ++l) dep = G.gemm(fc_fwd_args(n, n->ws[0], l, B), {dep});
+    return dep;
+  };
+  const int Lh = (int)v->fc.size() - 1;                 // value's 'fc' head
+  int vrep = t1;
+  for (int l = 0; l < Lh; ++l) vrep = G.gemm(fc_fwd_args(v, v->ws[0], l, B), {vrep});
+  const int vout = G.gemm(fc_fwd_args(v, v->ws[0], Lh, B), {vrep});
+  const int tvout = chain(tv, 0, t1);
+  const int muout = share ? chain(mu, 0, vrep) : chain(mu, 0, t1);
+  const int lvout = share ? chain(lv, 0, vrep) : chain(lv, 0, t1);
+  // ---- NAF head: L, advantage, TD loss and the gradients of the three head outputs
+  const int head = G.fn([=] { return naf_head(f, b, true); }, {vout, tvout, muout, lvout});
+
+  // ---- backward
+  if (!share) {
+    const int dv = add_fc_backward(G, v, v->ws[0], B, (int)v->fc.size() - 1, head);
+    const int dm = add_fc_backward(G, mu, mu->ws[0], B, (int)mu->fc.size() - 1, head);
+    const int dl = add_fc_backward(G, lv, lv->ws[0], B, (int)lv->fc.size() - 1, head);
+    if (v->spec.pixel) {
+      cpp_net* bn[3] = {v, mu, lv};
+      G.fn([=] { return nets_backward_conv(ctx, bn, 3, B, s1, dt, w1); }, {dv, dm, dl});
+    }
+  } else {
+    // shared representation: head gradients, then d(rep) = sum of the three heads' contributions
+    const FcL& hv = v->fc[Lh];
+    const int rep = hv.n_in;
+    struct Head { cpp_net* n; const FcL* L; const float* dz; };
+    Head heads[3] = {{v, &hv, v->ws[0].dz[Lh]}, {mu, &mu->fc[0], mu->ws[0].dz[0]}, {lv, &lv->fc[0], lv->ws[0].dz[0]}};
+    float* drep = nullptr; long ldd = rep; int final_epi = GE_NONE; const float* Y = nullptr; long ldy = 0;
+    if (Lh > 0) { drep = v->ws[0].dz[Lh - 1]; final_epi = GE_MUL_RELU_GRAD; Y = v->ws[0].fcin[Lh]; ldy = rep + 1; }
+    else if (v->spec.pixel) { drep = v->ws[0].dpool[2]; }
+    int dep = head;
+    for (int k = 0; k < 3; ++k) {
+      const Head& h = heads[k];
+      const float* x = v->ws[0].fcin[Lh];        // [rep, 1] rows, shared by the three heads
+      G.gemm(mk_gemm(x, 1, rep + 1, h.dz, h.L->n_out, 1, h.n->grads + h.L->w_off, h.L->n_out, rep + 1, h.L->n_out, B, GE_NONE), {head});
+      if (drep) {
+        GemmArgs g = mk_gemm(h.dz, h.L->n_out, 1, h.n->params + h.L->w_off, 1, h.L->n_out, drep, ldd, B, rep, h.L->n_out,
+                             k == 2 ? final_epi : GE_NONE, k == 2 ? Y : nullptr, ldy);
+        g.accumulate = k > 0;
+        dep = G.gemm(g, {dep});                  // accumulation order value -> mu -> l_values is fixed
+      }
+    }
+    const int dv = add_fc_backward(G, v, v->ws[0], B, Lh - 1, dep);
+    if (v->spec.pixel) G.fn([=] { return net_backward_conv(v, v->ws[0], B, s1, dt, w1); }, {dv});
   }
-  return net_backward(v, v->ws[0], B, true, nullptr, b->s[0], b->dtype, w1, Lh - 1);
+  RC(G.run(ctx));
+  return flush_dw_reduce(ctx);
 }
 
 static int naf_apply(cpp_naf* f, float grad_scale) {
