@@ -331,6 +331,9 @@ class DeepDeterministicPolicyGradientAgent(object):
         for net in (self.actor, self.critic, self.target_actor, self.target_critic):
             net.initialise_variables(rng)
 
+    def networks(self):
+        return [self.actor, self.critic, self.target_actor, self.target_critic]
+
     def post_var_init_setup(self):
         if opts.event_log_in:
             self.replay_memory.reset_from_event_log(opts.event_log_in)
@@ -462,9 +465,12 @@ def main(argv=None):
     sys.stderr.write("%s\n" % opts)
     env = make_env(opts)
     agent = DeepDeterministicPolicyGradientAgent(env=env)
+    # either load the latest ckpt or init variables (ddpg_cartpole.py:419-424)
+    saver_util = None
     if opts.ckpt_dir is not None:
-        raise NotImplementedError("checkpointing (util.SaverUtil) is SURVEY 8(f) row N4")
-    agent.initialise_variables()
+        saver_util = util.SaverUtil(agent, opts.ckpt_dir, opts.ckpt_freq)
+    else:
+        agent.initialise_variables()
     for net in (agent.actor, agent.critic, agent.target_actor, agent.target_critic):
         for v in net.trainable_model_vars():
             sys.stderr.write("%s %s\n" % (v.name, util.shape_and_product_of(v.shape)))
@@ -473,7 +479,9 @@ def main(argv=None):
         agent.run_eval(opts.num_eval, opts.eval_action_noise)
     else:
         agent.run_training(opts.max_num_actions, opts.max_run_time, opts.batch_size,
-                           opts.batches_per_step, None)
+                           opts.batches_per_step, saver_util)
+        if saver_util is not None:
+            saver_util.force_save()
     env.reset()
     agent.close()
 

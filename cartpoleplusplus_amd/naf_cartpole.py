@@ -237,6 +237,9 @@ class NormalizedAdvantageFunctionAgent(object):
         self.target_value_net.initialise_variables(rng)
         self.naf.initialise_variables(rng)
 
+    def networks(self):
+        return [self.value_net, self.target_value_net, self.naf.mu_net, self.naf.l_net]
+
     def post_var_init_setup(self):
         if opts.event_log_in:
             self.replay_memory.reset_from_event_log(opts.event_log_in)
@@ -298,6 +301,8 @@ class NormalizedAdvantageFunctionAgent(object):
             print("STATS %s\t%s" % (datetime.datetime.now().strftime('%Y-%m-%d %H:%M:%S'), json.dumps(stats)))
             sys.stdout.flush()
             n += 1
+            if saver_util is not None:
+                saver_util.save_if_required()
             if VERBOSE_DEBUG or n % 10 == 0:
                 self.run_eval(1)
             num_actions_taken += len(rewards)
@@ -334,14 +339,18 @@ def main(argv=None):
     from .ddpg_cartpole import make_env
     env = make_env(opts)
     agent = NormalizedAdvantageFunctionAgent(env=env)
+    saver_util = None
     if opts.ckpt_dir is not None:
-        raise NotImplementedError("checkpointing (util.SaverUtil) is SURVEY 8(f) row N4")
-    agent.initialise_variables()
+        saver_util = util.SaverUtil(agent, opts.ckpt_dir, opts.ckpt_freq)
+    else:
+        agent.initialise_variables()
     agent.post_var_init_setup()
     if opts.num_eval > 0:
         agent.run_eval(opts.num_eval, opts.eval_action_noise)
     else:
-        agent.run_training(opts.max_num_actions, opts.max_run_time, opts.batch_size, opts.batches_per_step, None)
+        agent.run_training(opts.max_num_actions, opts.max_run_time, opts.batch_size, opts.batches_per_step, saver_util)
+        if saver_util is not None:
+            saver_util.force_save()
     env.reset()
     agent.close()
 

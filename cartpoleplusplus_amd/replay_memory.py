@@ -288,7 +288,31 @@ class ReplayMemory(object):
         return out
 
     def reset_from_event_log(self, log_file):
-        raise NotImplementedError("event-log priming (replay_memory.py:40-61) is SURVEY 8(f) row N3")
+        """prime the memory from an event log (replay_memory.py:40-61): the first event of an episode carries only
+        the initial state, every later one (action, reward, state_2); stop once the memory is full."""
+        import sys
+        import time
+        from . import event_log
+        elr = event_log.EventLogReader(log_file)
+        num_episodes = num_events = 0
+        start = time.time()
+        for episode in elr.entries():
+            initial_state, seq = None, []
+            for event_id, event in enumerate(episode.event):
+                if event_id == 0:
+                    assert len(event.action) == 0
+                    assert not event.HasField("reward")
+                    initial_state = event_log.read_state_from_event(event)
+                else:
+                    seq.append((np.asarray(event.action, np.float32), event.reward,
+                                event_log.read_state_from_event(event)))
+                num_events += 1
+            num_episodes += 1
+            self.add_episode(initial_state, seq)
+            if self.full:
+                break
+        sys.stderr.write("reset_from_event_log \"%s\" num_episodes=%d num_events=%d took %s sec\n"
+                         % (log_file, num_episodes, num_events, time.time() - start))
 
     def close(self):
         for b in self._batches.values():

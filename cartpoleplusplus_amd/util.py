@@ -5,6 +5,9 @@ Reference: /root/reference/util.py -- add_opts :10-20, StopWatch :22-26, clip_an
 collapsed_successive_ranges :60-71, OrnsteinUhlenbeckNoise :134-156.  Checkpoint / png helpers are out
 of scope.
 """
+import datetime
+import os
+import sys
 import time
 
 import numpy as np
@@ -73,6 +76,64 @@ def collapsed_successive_ranges(values):
 def shape_and_product_of(shape):
     dims = [d for d in shape if d is not None]
     return "%s #%s" % (tuple(shape), int(np.prod(dims)) if dims else 1)
+
+
+class SaverUtil(object):
+    """checkpoint save / restore with the behaviour of the reference's util.SaverUtil (util.py:88-131): on start,
+    restore the latest checkpoint named in `<dir>/checkpoint` or initialise the variables and save at once;
+    `save_if_required()` saves every `save_freq` seconds; `force_save()` at exit.  The replay memory is not
+    checkpointed (util.py:91).  The reference hands a tf.Session to tf.train.Saver; here the first argument is
+    the agent (anything with `.networks()` -> [Network] and `.initialise_variables()`), and a checkpoint is one
+    `.npz` with the flat f32 buffer of every namespace (variable names and shapes stored alongside and checked
+    on restore).  The `checkpoint` index file keeps TF's `model_checkpoint_path: "<name>"` line."""
+
+    def __init__(self, agent, ckpt_dir="/tmp", save_freq=60):
+        self.agent, self.ckpt_dir = agent, ckpt_dir
+        if not os.path.exists(self.ckpt_dir):
+            os.makedirs(self.ckpt_dir)
+        assert save_freq > 0
+        self.save_freq = save_freq
+        self.load_latest_ckpt_or_init_if_none()
+
+    def _index(self):
+        return "%s/checkpoint" % self.ckpt_dir
+
+    def load_latest_ckpt_or_init_if_none(self):
+        if os.path.isfile(self._index()):
+            line = [l for l in open(self._index()) if l.startswith("model_checkpoint_path")][0]
+            name = line.split(":", 1)[1].strip().strip('"')
+            most_recent_ckpt = "%s/%s" % (self.ckpt_dir, name)
+            sys.stderr.write("loading ckpt %s\n" % most_recent_ckpt)
+            data = np.load(most_recent_ckpt + ".npz", allow_pickle=False)
+            for net in self.agent.networks():
+                layout = "|".join("%s%s" % (v.name, tuple(v.shape)) for v in net.trainable_model_vars())
+                assert str(data[net.namespace + "::layout"]) == layout, "checkpoint does not match %s" % net.namespace
+                net.set_params(data[net.namespace])
+            self.next_scheduled_save_time = time.time() + self.save_freq
+        else:
+            sys.stderr.write("no latest ckpt in %s, just initing vars...\n" % self.ckpt_dir)
+            self.agent.initialise_variables()
+            self.force_save()
+
+    def force_save(self):
+        dts = datetime.datetime.now().strftime('%Y%m%d_%H%M%S_%f')
+        name = "ckpt.%s" % dts
+        sys.stderr.write("saving ckpt %s/%s\n" % (self.ckpt_dir, name))
+        start_time = time.time()
+        blob = {}
+        for net in self.agent.networks():
+            blob[net.namespace] = net.get_params()
+            blob[net.namespace + "::layout"] = np.array(
+                "|".join("%s%s" % (v.name, tuple(v.shape)) for v in net.trainable_model_vars()))
+        np.savez("%s/%s.npz" % (self.ckpt_dir, name), **blob)
+        with open(self._index(), "w") as f:
+            f.write('model_checkpoint_path: "%s"\n' % name)
+        print("save_took", time.time() - start_time)
+        self.next_scheduled_save_time = time.time() + self.save_freq
+
+    def save_if_required(self):
+        if time.time() >= self.next_scheduled_save_time:
+            self.force_save()
 
 
 class OrnsteinUhlenbeckNoise(object):

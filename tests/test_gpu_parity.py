@@ -198,3 +198,47 @@ def test_graph_replay_is_deterministic_and_equals_eager():
         assert np.array_equal(params[0][k], params[1][k])
         assert np.array_equal(params[0][k], params[2][k])
     assert np.isfinite(params[0][0]).all() and np.isfinite(params[0][1]).all()
+
+
+def test_end_to_end_cli_with_checkpoints_and_event_log(tmp_path, capsys):
+    """the agent's own main(): rollouts on the stand-in env, replay in HBM, fused train steps, STATS lines, a
+    checkpoint that restores bit for bit, then offline training from the event log it wrote (--event-log-in
+    --dont-do-rollouts, as exps/run_81-84 do)."""
+    import json
+    from cartpoleplusplus_amd import ddpg_cartpole as D, event_log as E
+    from cartpoleplusplus_amd.synthetic_env import SyntheticCartpole
+    ck = str(tmp_path / "ckpts")
+    common = ["--synthetic-env", "--use-raw-pixels", "--render-width", "16", "--render-height", "16", "--batch-size", "8",
+              "--replay-memory-size", "120", "--replay-memory-burn-in", "20", "--max-episode-len", "12", "--ckpt-dir", ck]
+    D.main(common + ["--max-num-actions", "60"])
+    out = capsys.readouterr().out
+    stats = [json.loads(l.split("\t", 1)[1]) for l in out.splitlines() if l.startswith("STATS")]
+    assert len(stats) >= 4 and stats[-1]["replay_memory_stats"][">add"] >= 60
+    assert any(np.isfinite(s["mean_losses"]) for s in stats)          # training ran once the burn-in was passed
+    # restore: a fresh agent built from the checkpoint has the saved parameters
+    D.set_opts(D.build_parser().parse_args(common))
+    agent = D.DeepDeterministicPolicyGradientAgent(SyntheticCartpole(D.opts))
+    from cartpoleplusplus_amd import util
+    saver = util.SaverUtil(agent, ck, 3600)
+    latest = [l for l in open(ck + "/checkpoint")][0].split('"')[1]
+    blob = np.load("%s/%s.npz" % (ck, latest))
+    for net in agent.networks():
+        assert np.array_equal(net.get_params(), blob[net.namespace])
+    # an event log written by EventLog primes the replay memory for rollout-free training
+    path = str(tmp_path / "events")
+    log = E.EventLog(path, use_raw_pixels=True)
+    env = SyntheticCartpole(D.opts, seed=3)
+    for _ in range(4):
+        log.reset()
+        log.add_just_state(env.reset())
+        done = False
+        while not done:
+            a = np.random.uniform(-1, 1, (1, 2)).astype(np.float32)
+            s2, r, done, _ = env.step(a)
+            log.add(s2, a, r)
+    log.close()
+    agent.close()
+    D.main(common[:-2] + ["--event-log-in", path, "--dont-do-rollouts"])
+    out = capsys.readouterr().out
+    last = json.loads([l for l in out.splitlines() if l.startswith("STATS")][-1].split("\t", 1)[1])
+    assert last["episode_len"] == 0 and last["replay_memory_stats"][">add_episode"] == 4 and np.isfinite(last["mean_losses"])

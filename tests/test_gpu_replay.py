@@ -110,3 +110,33 @@ def test_device_philox_rows_are_the_published_philox_and_uniform():
     s1 = rm.state[rm.state_1_idx[b.idxs]]
     assert np.array_equal(b.state_1, s1)
     rm.close()
+
+
+def test_reset_from_event_log_primes_the_device_memory(tmp_path):
+    """--event-log-in (replay_memory.py:40-61): episodes written by EventLog land in HBM exactly like add_episode."""
+    from cartpoleplusplus_amd import event_log as E
+    from cartpoleplusplus_amd.replay_memory import ReplayMemory
+    rng = np.random.default_rng(9)
+    shape = (16, 16, 3, 1, 2)
+    path = str(tmp_path / "events")
+    log = E.EventLog(path, use_raw_pixels=True)
+    orm = OracleReplayMemory(12, shape, 2)
+    for ep in range(4):
+        log.reset()
+        n = int(rng.integers(2, 5))
+        fr = [(rng.integers(0, 256, shape).astype(np.float16) / np.float16(255)).astype(np.float32) for _ in range(n + 1)]
+        acts = [rng.uniform(-1, 1, (1, 2)).astype(np.float32) for _ in range(n)]
+        log.add_just_state(fr[0])
+        for k in range(n):
+            log.add(fr[k + 1], acts[k], 1.0)
+        if not orm.full:
+            orm.add_episode(fr[0], [(acts[k], 1.0, fr[k + 1]) for k in range(n)])
+    log.close()
+    rm = ReplayMemory(12, shape, 2)
+    rm.reset_from_event_log(path)
+    assert rm.size() == orm.size() and rm.full == orm.full
+    idxs = np.arange(rm.size())
+    got, want = rm.batch(idxs=idxs), orm.batch(idxs=idxs)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    rm.close()
