@@ -1,0 +1,98 @@
+#!/usr/bin/env python
+"""gpurun_out/{prof,pmc}_<round> rocpd databases (written by profiles/run_profiles.sh on the GPU box) ->
+profiles/<round>_kernel_stats.md and profiles/<round>_pmc.json.
+
+  python profiles/make_profiles.py r01
+
+HBM bytes follow MI355X_MICROARCH.md's HBM section: FETCH_SIZE and WRITE_SIZE in separate passes, both in KB,
+FETCH_SIZE doubled for the gfx950 under-count of 16-byte coalesced reads (an upper bound for narrower reads);
+values are means per dispatch of one kernel symbol.
+"""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# kernel symbol prefix -> short name used by bench.py
+SHORT = [("void conv_fwd_kernel<18, 5, 4, 0, 0>", "conv1_fwd"), ("void conv_dw_kernel<18, 5, 4, 0>", "conv1_dw"),
+         ("void conv_fwd_kernel<10, 5, 2, 2, 0>", "conv2_fwd"), ("void conv_fwd_kernel<10, 5, 2, 3, 1>", "conv2_dx"),
+         ("void conv_dw_kernel<10, 5, 2, 2>", "conv2_dw"), ("void conv_fwd_kernel<10, 3, 1, 2, 0>", "conv3_fwd"),
+         ("void conv_fwd_kernel<10, 3, 1, 3, 1>", "conv3_dx"), ("void conv_dw_kernel<10, 3, 1, 2>", "conv3_dw"),
+         ("void gather_stats_kernel<__half>", "gather_stats"), ("gemm_batch_kernel", "gemm_batch")]
+
+
+def short(name):
+    for p, s in SHORT:
+        if name.startswith(p):
+            return s
+    return None
+
+
+def db_of(d):
+    f = glob.glob(os.path.join(ROOT, "gpurun_out", d, "**", "*.db"), recursive=True)
+    assert f, "no rocpd database under gpurun_out/%s" % d
+    return sqlite3.connect(f[0])
+
+
+def counters(con):
+    out = {}
+    for name, ctr, n, mean in con.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
+                                          "group by kernel_name, counter_name"):
+        s = short(name)
+        if s:
+            out.setdefault(s, {})[ctr] = (n, mean)
+    return out
+
+
+def main(rnd):
+    con = db_of("prof_%s" % rnd)
+    rows = con.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
+    bench_line = open(os.path.join(ROOT, "gpurun_out", "bench_%s.json" % rnd)).read().strip()
+    with open(os.path.join(ROOT, "profiles", "%s_kernel_stats.md" % rnd), "w") as f:
+        f.write("# Round %s profile: bench.py (cfg3, 64x64x18, B=256), MI355X\n\n" % rnd[1:])
+        f.write("Command (profiles/run_profiles.sh): `rocprofv3 --kernel-trace --stats -d gpurun_out/prof_%s -o k -- python bench.py "
+                "--steps 50 --warmup 10 --no-cpu-baseline --profile-steps 5`\n\n" % rnd)
+        f.write("70 minibatch steps in total (warm-up, hipGraph-replayed timed steps, and the eager HIP-event pass); durations in\n"
+                "microseconds, from the rocpd database's `top_kernels` view (profiles/make_profiles.py).  One `conv_fwd_kernel<18,5,4,0,0>`\n"
+                "launch computes conv1 of all four networks of a minibatch (blockIdx.y = network); likewise conv2/conv3 forward;\n"
+                "the dW / dX launches carry the actor and the critic together.\n\n")
+        f.write("| kernel | calls | total us | avg us | % |\n|---|---|---|---|---|\n")
+        for name, calls, tot, avg, pct in rows:
+            f.write("| `%s` | %d | %.1f | %.3f | %.2f |\n" % (name, calls, tot, avg, pct))
+        f.write("\n## bench.py JSON line of the same build (un-profiled default run, same box)\n\n```\n%s\n```\n" % bench_line)
+    sq, fe, wr = counters(db_of("pmc_%s_sq" % rnd)), counters(db_of("pmc_%s_fetch" % rnd)), counters(db_of("pmc_%s_write" % rnd))
+    kernels = {}
+    for k in sq:
+        e = {"dispatches_sampled": sq[k]["SQ_WAVE_CYCLES"][0]}
+        g = lambda c: sq[k].get(c, (0, 0.0))[1]
+        e["mfma_busy_cycles_per_launch"] = g("SQ_VALU_MFMA_BUSY_CYCLES")
+        e["sq_busy_cycles_per_launch"] = g("SQ_BUSY_CYCLES")
+        e["wave_cycles_per_launch"] = g("SQ_WAVE_CYCLES")
+        tot = g("SQ_ACTIVE_INST_ANY") + g("SQ_WAIT_ANY") + g("SQ_WAIT_INST_ANY")
+        if tot > 0:
+            e["wave_time_split"] = {"active_inst": round(g("SQ_ACTIVE_INST_ANY") / tot, 4), "wait_any": round(g("SQ_WAIT_ANY") / tot, 4),
+                                    "wait_inst": round(g("SQ_WAIT_INST_ANY") / tot, 4)}
+        if g("SQ_LDS_IDX_ACTIVE") > 0:
+            e["lds_bank_conflict_frac"] = round(g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE"), 4)
+        if k in fe and k in wr:
+            e["FETCH_SIZE_KB_raw"] = fe[k]["FETCH_SIZE"][1]
+            e["WRITE_SIZE_KB"] = wr[k]["WRITE_SIZE"][1]
+            e["hbm_read_bytes_corrected"] = 2.0 * 1024.0 * e["FETCH_SIZE_KB_raw"]
+            e["hbm_write_bytes"] = 1024.0 * e["WRITE_SIZE_KB"]
+            e["hbm_bytes_per_launch"] = e["hbm_read_bytes_corrected"] + e["hbm_write_bytes"]
+        kernels[k] = e
+    blob = {"source": "profiles/run_profiles.sh: rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --steps 10 --warmup 5 "
+                      "--no-cpu-baseline --profile-steps 5 (three separate passes: SQ_*, FETCH_SIZE, WRITE_SIZE)",
+            "note": "means per dispatch; FETCH_SIZE (KB) doubled per the gfx950 correction for 16-byte coalesced reads; conv*_fwd "
+                    "launches carry four networks, conv*_dw / conv*_dx launches two",
+            "kernels": kernels}
+    with open(os.path.join(ROOT, "profiles", "%s_pmc.json" % rnd), "w") as f:
+        json.dump(blob, f, indent=1)
+    print(json.dumps({k: {"hbm": v.get("hbm_bytes_per_launch"), "split": v.get("wave_time_split")} for k, v in kernels.items()}, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
