@@ -1,5 +1,5 @@
 // Host-side launchers of the conv kernels (geometry selection + profiling brackets).
-#include "conv_impl.h"
+#include "conv_kyo.h"
 #include <cstdlib>
 
 static int pick_xtw(int in_mode, int W) {
@@ -43,6 +43,24 @@ int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, i
   // MI355X under hipcc's register allocation (conv1: 0.66-0.78 ms/step vs 0.54) -- see DESIGN.md section 6
   static const bool want_kxo = getenv("CPP_CONV_KXO") != nullptr;
   const bool kxo = want_kxo && epi == EPI_RELU_POOL && a.tiles_x == 1 && a.nout <= 10 && in_mode != IN_DY && cin != 30;
+  // (ky,o)-column kernel: the default for the pooled forward layers whose rows can be staged as aligned 16-byte
+  // chunks (CPP_CONV_KYO=0 selects the (ky,(kx,c)) x o kernel for A/B measurements)
+  static const bool no_kyo = getenv("CPP_CONV_KYO") != nullptr && atoi(getenv("CPP_CONV_KYO")) == 0;
+  bool kyo = !no_kyo && !kxo && epi == EPI_RELU_POOL && in_mode != IN_DY && a.nout <= 10 && a.H >= 2;
+  if (kyo) {
+    const int epc = in_mode == IN_F16_WHITEN ? 8 : 4;
+    for (int i = 0; i < n; ++i) kyo = kyo && batch.a[i].vec_ok && (a.W * cin) % epc == 0;
+  }
+  // the narrow layers (conv2 / conv3: 32 / 16 rows of 52 / 16 MFMAs per wave) are latency bound either way and
+  // measured slightly slower with one barrier per row: opt-in with CPP_CONV_KYO23=1
+  static const bool kyo23 = getenv("CPP_CONV_KYO23") != nullptr && atoi(getenv("CPP_CONV_KYO23")) != 0;
+  if (in_mode == IN_F32_PLAIN && !kyo23) kyo = false;
+  if (kyo) {
+    bool handled = false;
+    rc = (in_mode == IN_F32_PLAIN) ? conv_fwd_kyo_dispatch_l23(ctx, cin, ks, in_mode, batch, &handled)
+                                   : conv_fwd_kyo_dispatch_l1(ctx, cin, ks, in_mode, batch, &handled);
+    if (handled) { prof_end(ctx, kid); return rc; }
+  }
   if (kxo && (in_mode == IN_F16_WHITEN || in_mode == IN_F32_WHITEN))
     rc = conv_fwd_kxo_dispatch_l1(ctx, cin, ks, xtw, in_mode, batch);
   else if (kxo)
