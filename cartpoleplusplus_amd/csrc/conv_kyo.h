@@ -23,6 +23,22 @@
 #pragma once
 #include "conv_impl.h"
 
+// LDS accesses through explicit 32-bit addresses: a pointer into the dynamic LDS block is (relocated base + offset),
+// and hipcc re-adds base and large constant offsets in VGPRs at every use.  f32 MFMAs do not overlap with VALU work
+// on this chip, so the row loop keeps finished addresses in registers (made opaque once, outside the loop) and lets
+// the ds_read / ds_write immediate offset field do the rest.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)p; }
+__device__ __forceinline__ uint32_t keep_in_vgpr(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
+template <typename T>
+__device__ __forceinline__ T lds_load(uint32_t addr, int byte_off = 0) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) T*>((uintptr_t)(addr + (uint32_t)byte_off));
+}
+template <typename T>
+__device__ __forceinline__ void lds_store(uint32_t addr, int byte_off, const T& v) {
+  *reinterpret_cast<__attribute__((address_space(3))) T*>((uintptr_t)(addr + (uint32_t)byte_off)) = v;
+}
+
 constexpr int KYO_NO = 10;                         // filters per layer (base_network.py:103,111,119)
 
 template <int CIN, int KS, int XT, int IPW>
@@ -31,9 +47,13 @@ struct KyoGeom {
   static constexpr int NT = (KS * KYO_NO + 15) / 16;        // N tiles over columns (p, o)
   static constexpr int STRIPS = 4 / IPW, SW = 16 * XT, WPAD = STRIPS * SW;
   static constexpr int KROW = KS * CIN;                     // k = (kx, c) of one input row
-  static constexpr int NG = KROW / 16, REM = KROW % 16, RS = (REM + 3) / 4;
-  static constexpr int NGT = NG + (RS > 0 ? 1 : 0);         // groups of up to 4 k-steps
-  static constexpr int KSTEPS = 4 * NG + RS;
+  // K order inside a row: lane group lj (= MFMA k index) owns the contiguous run [Q4*lj, Q4*lj + Q4) of the first
+  // 4*Q4 values (Q4 even: its operand pairs are 8-byte aligned), step st < Q4 takes k = Q4*lj + st; the remaining
+  // R < 8 values go to XS extra steps with k = 4*Q4 + 4*(st - Q4) + lj.  A lane's operands of consecutive steps are
+  // contiguous in LDS (one ds_read2_b64 feeds 4 MFMAs) and every step's address is one register + an immediate.
+  static constexpr int Q4 = (KROW / 4) & ~1, R = KROW - 4 * Q4, XS = (R + 3) / 4;
+  static constexpr int KSTEPS = Q4 + XS;                    // = ceil(KROW / 4)
+  static constexpr int NGT = (KSTEPS + 3) / 4;              // groups of up to 4 k-steps (one B fragment read each)
   static constexpr int FP = (4 - (P * CIN) % 4) % 4;        // front pad: image column 0 lands 16-byte aligned
   static constexpr int ROWF = ((FP + (WPAD + KS - 1) * CIN + 8) + 3) & ~3;   // floats per staged row (+ k over-read)
   static constexpr int WLF = KS * NGT * 4 * KYO_NO * 4;     // weight floats in LDS: [ky][group][lj][o][step]
@@ -41,14 +61,11 @@ struct KyoGeom {
                                                             // already visible (its first operands prefetch across the
                                                             // barrier), q+2 is being written
   static constexpr int EF = 2 * 8 * XT * KYO_NO * 2;        // per wave: (value, code) of the two rows of a pool pair
-  static constexpr int LDS_FLOATS = WLF + RING * IPW * ROWF + 4 * EF;
-  // steps of group g and the k index (within the row) of lane group lj at step s
-  static __host__ __device__ constexpr int steps(int g) { return g < NG ? 4 : RS; }
-  static __host__ __device__ constexpr int kidx(int g, int s, int lj) {
-    return (g < NG || RS == 4) ? 16 * g + 4 * lj + s
-         : (RS == 3) ? (s < 2 ? 16 * g + 2 * lj + s : 16 * g + 8 + lj)
-         : (RS == 2) ? 16 * g + 2 * lj + s
-         : 16 * g + lj;
+  static constexpr int WHF = 2 * ((CIN + 8 + 3) & ~3);      // whitening scale[] and shift[], each extended by 8 (wrap-around)
+  static constexpr int LDS_FLOATS = WLF + RING * IPW * ROWF + 4 * EF + WHF;
+  static __host__ __device__ constexpr int steps(int g) { return KSTEPS - 4 * g < 4 ? KSTEPS - 4 * g : 4; }
+  static __host__ __device__ constexpr int kmap(int st, int lj) {
+    return st < Q4 ? Q4 * lj + st : 4 * Q4 + 4 * (st - Q4) + lj;
   }
 };
 
@@ -59,7 +76,7 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
   constexpr bool WHITEN = (IN_MODE == IN_F16_WHITEN || IN_MODE == IN_F32_WHITEN);
   constexpr int P = G::P, NT = G::NT, NGT = G::NGT, ROWF = G::ROWF, NO = KYO_NO;
   constexpr int EPC = ChunkOps<ST>::EPC;
-  constexpr bool A64 = (CIN % 2 == 0) && (G::FP % 2 == 0);      // A operand pairs are 8-byte aligned in LDS
+  constexpr bool A64 = (CIN % 2 == 0) && (G::FP % 2 == 0);      // A operand pairs are 8-byte aligned in LDS (Q4 is even)
   constexpr int RING = G::RING, RSET = IPW * ROWF;              // row buffers in flight, floats per buffer
 #ifdef KYO_CLOCK_PROBE
   const unsigned long long pe = __builtin_amdgcn_s_memrealtime();
@@ -69,11 +86,12 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
   float* wl = lds;                                   // [KS][NGT][4][NO][4]
   float* rows = lds + G::WLF;                        // [RING][IPW][ROWF]
   float2* ebuf = reinterpret_cast<float2*>(rows + RING * RSET);   // [4 waves][2 parities][8*XT][NO] (value, code)
+  float* whs = rows + RING * RSET + 4 * G::EF;       // whitening scale[c mod CIN], c < CIN + 8; then shift[] likewise
+  float* wht = whs + G::WHF / 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lj = lane >> 4;
   const int img = wave / G::STRIPS, strip = wave % G::STRIPS;
   const int b0 = blockIdx.x * IPW;
-  const int bimg = b0 + img;
   const int H = a.H, W = a.W, Hp = H >> 1, Wp = W >> 1, nout = a.nout;
 
   // ---- one-time setup: zero the row buffers (padding columns stay zero), weights into the permuted LDS layout
@@ -86,7 +104,7 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
       const int i = tid + n * CONV_THREADS;
       const int s = i & 3, o = (i >> 2) % NO, r = (i >> 2) / NO;
       const int l = r & 3, g = (r >> 2) % NGT, ky = (r >> 2) / NGT;
-      const int k = G::kidx(g, s, l);
+      const int k = G::kmap(4 * g + s, l);
       const bool ok = i < G::WLF && s < G::steps(g) && o < nout && k < G::KROW;
       const float v = a.w[ok ? (ky * G::KROW + k) * nout + o : 0];
       wv[n] = ok ? v : 0.f;
@@ -97,123 +115,158 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
   }
 
   // ---- row staging: chunk ch -> (image, 16-byte chunk of the row); a thread's chunks are the same for every row,
-  // so the source pointer, the LDS destination and the per-element whitening constants are fixed up front
+  // so the byte offset from the (uniform) row base, the LDS destination and the whitening constants' address are
+  // fixed up front
   const int cpr = (W * CIN) / EPC;                   // chunks per image row (W*CIN % EPC == 0 checked by the host)
   constexpr int NVMAX = (IPW * G::WPAD * CIN / EPC + CONV_THREADS - 1) / CONV_THREADS;
   uint4 sv[NVMAX];
-  const ST* ssrc[NVMAX];
-  int sdst[NVMAX];
-  float2 swh[WHITEN ? NVMAX : 1][EPC];
+  unsigned sbyte[NVMAX];                             // byte offset of the chunk from the row base of image b0
+  bool sact[NVMAX];
+  uint32_t sdst[NVMAX];                              // LDS address of the chunk in ring slot 0
+  uint32_t swh[NVMAX];                               // LDS address of the whitening scale of the chunk's first channel
+  if (WHITEN) {
+    for (int c = tid; c < CIN + 8; c += CONV_THREADS) { whs[c] = a.scale[c % CIN]; wht[c] = a.shift[c % CIN]; }
+  }
 #pragma unroll
   for (int i = 0; i < NVMAX; ++i) {
     const int ch = tid + CONV_THREADS * i;
     const int im = ch / cpr, j = ch - im * cpr;
-    const bool act = im < IPW && b0 + im < a.B;
-    ssrc[i] = act ? (const ST*)a.in + (long)(b0 + im) * a.in_bstride + j * EPC : nullptr;
-    sdst[i] = im * ROWF + G::FP + P * CIN + j * EPC;
-    if (WHITEN) {
-      int c = (j * EPC) % CIN;
-#pragma unroll
-      for (int k = 0; k < EPC; ++k) {
-        swh[i][k] = make_float2(a.scale[c], a.shift[c]);
-        c = (c + 1 == CIN) ? 0 : c + 1;
-      }
-    }
+    sact[i] = im < IPW && b0 + im < a.B;
+    sbyte[i] = (unsigned)((long)im * a.in_bstride + j * EPC) * (unsigned)sizeof(ST);
+    sdst[i] = keep_in_vgpr(lds_addr(rows + im * ROWF + G::FP + P * CIN + j * EPC));
+    swh[i] = keep_in_vgpr(lds_addr(whs + (j * EPC) % CIN));
   }
+  // buffer addressing: uniform descriptor (images b0 .. b0+IPW-1) + per-lane byte offset (constant) + scalar row
+  // offset -- no vector address arithmetic per row
+  const int nimg = a.B - b0 < IPW ? a.B - b0 : IPW;
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<ST*>((const ST*)a.in + (long)b0 * a.in_bstride), 0, (int)(nimg * a.in_bstride * (long)sizeof(ST)), 0x00020000);
+  const int rowbytes = W * CIN * (int)sizeof(ST);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   auto stage_load = [&](int y) {
 #pragma unroll
-    for (int i = 0; i < NVMAX; ++i)
-      if (ssrc[i]) sv[i] = *reinterpret_cast<const uint4*>(ssrc[i] + (long)y * W * CIN);
+    for (int i = 0; i < NVMAX; ++i) {
+      if (sact[i]) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)sbyte[i], y * rowbytes, 0);
+        sv[i] = make_uint4(v.x, v.y, v.z, v.w);
+      }
+    }
   };
-  auto stage_store = [&](float* dstrows) {
+  auto stage_store = [&](int slot) {                 // slot: uniform ring slot
 #pragma unroll
     for (int i = 0; i < NVMAX; ++i) {
-      if (ssrc[i]) {
+      if (sact[i]) {
         float x[EPC];
 #pragma unroll
-        for (int k = 0; k < EPC; ++k) {
-          x[k] = ChunkOps<ST>::get(sv[i], k);
-          if (WHITEN) x[k] = x[k] * swh[i][k].x + swh[i][k].y;
-        }
-        float* dst = dstrows + sdst[i];
+        for (int k = 0; k < EPC; ++k) x[k] = ChunkOps<ST>::get(sv[i], k);
+        if (WHITEN) {
 #pragma unroll
-        for (int k = 0; k < EPC; k += 4)
-          *reinterpret_cast<float4*>(dst + k) = make_float4(x[k], x[k + 1], x[k + 2], x[k + 3]);
+          for (int k = 0; k < EPC; k += 2) {         // pairs are 8-byte aligned when CIN is even
+            f32x2 sc, sh;
+            if (CIN % 2 == 0) {
+              sc = lds_load<f32x2>(swh[i], 4 * k);
+              sh = lds_load<f32x2>(swh[i], 4 * (G::WHF / 2 + k));
+            } else {
+              sc = (f32x2){lds_load<float>(swh[i], 4 * k), lds_load<float>(swh[i], 4 * k + 4)};
+              sh = (f32x2){lds_load<float>(swh[i], 4 * (G::WHF / 2 + k)), lds_load<float>(swh[i], 4 * (G::WHF / 2 + k) + 4)};
+            }
+            x[k] = x[k] * sc.x + sh.x;
+            x[k + 1] = x[k + 1] * sc.y + sh.y;
+          }
+        }
+        const uint32_t dst = sdst[i] + (uint32_t)(slot * RSET * 4);
+#pragma unroll
+        for (int k = 0; k < EPC; k += 4) lds_store(dst, 4 * k, (f32x4){x[k], x[k + 1], x[k + 2], x[k + 3]});
       }
     }
   };
 
-  // ---- per-lane column bookkeeping: column j = 16 t + li = p * NO + o of N tile t.  Consecutive tiles are 16
-  // columns apart (> NO), so for a given block p a lane holds at most ONE tile with a column of that block.
-  int pt[NT], wofs[NT], eofs[NT];
+  // ---- per-lane column bookkeeping: column j = 16 t + li = p * NO + o of N tile t.  The row loop is unrolled by KS,
+  // so ky of a block in unrolled step sq is (sq + P - p) mod KS for every pass of the loop: one LDS address per
+  // (step, tile) held in registers replaces all per-row address arithmetic for the rotating weights.
+  uint32_t wadr[KS][NT];
+  uint32_t eadr[NT];                                 // pool-pair buffer slot of (pooled x = 2 lj, o), parity 0
   float biast[NT];
+  const int swave = __builtin_amdgcn_readfirstlane(wave);       // scalar copies: uniform address arithmetic below
+  const int simg = swave / G::STRIPS, sstrip = swave % G::STRIPS;
+  const int sbimg = b0 + simg;
+  float2* ev = ebuf + swave * (2 * 8 * XT * NO);     // [2 parities][8*XT][NO]
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int j = 16 * t + li;
-    const bool valid = j < KS * NO && (j % NO) < nout;
-    const int o = valid ? j % NO : 0;
-    pt[t] = valid ? j / NO : -1;
-    biast[t] = a.bias[o];
-    eofs[t] = (lj * 2) * NO + o;                               // slot of (pooled x = 2 lj, o) in the pool-pair buffer
-    const int p = valid ? pt[t] : 0;
-    const int ky0 = (P - p + KS) % KS;                         // ky at q = 0
-    wofs[t] = ((ky0 * NGT * 4 + lj) * NO + o) * 4;              // float offset of (ky, group 0, lj, o, step 0)
+    const bool valid = j < KS * NO;
+    const int o = j % NO;
+    biast[t] = (valid && o < nout) ? a.bias[o] : 0.f;
+    eadr[t] = keep_in_vgpr(lds_addr(ev + (lj * 2) * NO + o));
+    const int p = valid ? j / NO : 0;
+#pragma unroll
+    for (int sq = 0; sq < KS; ++sq) {
+      const int ky = (sq + P - p + KS) % KS;
+      wadr[sq][t] = keep_in_vgpr(lds_addr(wl + ((ky * NGT * 4 + lj) * NO + (valid ? o : 0)) * 4));   // (ky, group 0, lj, o, step 0)
+    }
   }
-  constexpr int KYSTRIDE = NGT * 4 * NO * 4, GSTRIDE = 4 * NO * 4;
+  constexpr int GBYTES = 4 * NO * 4 * 4;             // bytes between the groups of one ky plane
 
   // ---- pooled-row writer: entry idx = xl * nout + o of this wave's 8*XT pooled columns, two entries per lane at most
   constexpr int NC = (8 * XT * NO + 63) / 64;
-  int ce[NC], coe[NC];
+  uint32_t cadr[NC];
+  bool cact[NC];
+  unsigned coe[NC];
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     const int idx = lane + 64 * i;
     const int xl = idx / nout, o = idx - xl * nout;
-    const int px = ((strip * G::SW) >> 1) + xl;
-    const bool ok = idx < 8 * XT * nout && px < Wp && bimg < a.B;
-    ce[i] = ok ? xl * NO + o : -1;
-    coe[i] = px * nout + o;
+    const int px = ((sstrip * G::SW) >> 1) + xl;
+    cact[i] = idx < 8 * XT * nout && px < Wp && sbimg < a.B;
+    cadr[i] = keep_in_vgpr(lds_addr(ev + (cact[i] ? xl * NO + o : 0)));
+    coe[i] = (unsigned)(px * nout + o);
   }
+  const int simg_ok = sbimg < a.B ? sbimg : 0;
+  const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      a.out + (long)simg_ok * a.out_bstride, 0, Hp * Wp * nout * 4, 0x00020000);             // uniform (per wave)
+  const __amdgpu_buffer_rsrc_t amax_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      a.out_amax + (long)simg_ok * Hp * Wp * nout, 0, Hp * Wp * nout, 0x00020000);
 
+  // accumulators start at (and are reset to) the bias of their column: conv + bias without an add in the epilogue
   f32x4 acc[XT][NT];
 #pragma unroll
   for (int m = 0; m < XT; ++m)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t) acc[m][t] = (f32x4){biast[t], biast[t], biast[t], biast[t]};
 
-  __syncthreads();                                   // zeroed row buffers visible before the first rows are written
+  __syncthreads();                                   // zeroed row buffers + whitening table visible
   for (int r = 0; r < RING - 1; ++r) {
-    if (r < H) { stage_load(r); stage_store(rows + r * RSET); }
+    if (r < H) { stage_load(r); stage_store(r); }
   }
   if (RING - 1 < H) stage_load(RING - 1);
   __syncthreads();
 
-  float2* ev = ebuf + wave * (2 * 8 * XT * NO);      // [2 parities][8*XT][NO]
-  const int xcol0 = strip * G::SW;                   // first image column of this wave's strip
-  int pdone = (KS - P) % KS;                         // block of row y = q - P
-  int rcur = 0;                                      // ring slot of row q
+  int rcur = 0;                                      // ring slot of row q (uniform)
 
   // operands of one group of k-steps; two sets so that the loads of group g+1 are in flight under the MFMAs of g
   float av[2][XT][4];
   f32x4 bv[2][NT];
-  auto load_ops = [&](int g, int set, const float* ab) {
+  auto load_ops = [&](int g, int set, uint32_t ab, uint32_t ax, const uint32_t* wa) {
 #pragma unroll
     for (int m = 0; m < XT; ++m) {
-      const float* ap = ab + m * 16 * CIN;
-#ifdef KYO_ABL_NOLDSA
-      av[set][m][0] = av[set][m][1] = av[set][m][2] = av[set][m][3] = biast[0];
-      if (false) {} else
-#endif
-      if (A64 && (g < G::NG || G::RS == 4)) {
-        const float2 u0 = *reinterpret_cast<const float2*>(ap + 16 * g + 4 * lj);
-        const float2 u1 = *reinterpret_cast<const float2*>(ap + 16 * g + 4 * lj + 2);
-        av[set][m][0] = u0.x; av[set][m][1] = u0.y; av[set][m][2] = u1.x; av[set][m][3] = u1.y;
-      } else if (A64 && G::RS >= 2) {
-        const float2 u0 = *reinterpret_cast<const float2*>(ap + 16 * g + 2 * lj);
-        av[set][m][0] = u0.x; av[set][m][1] = u0.y;
-        av[set][m][2] = (G::RS == 3) ? ap[16 * g + 8 + lj] : 0.f; av[set][m][3] = 0.f;
-      } else {
+      const int mo = 4 * (m * 16 * CIN);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) av[set][m][s] = s < G::steps(g) ? ap[G::kidx(g, s, lj)] : 0.f;
+      for (int s = 0; s < 4; ++s) {
+        const int st = 4 * g + s;
+#ifdef KYO_ABL_NOLDSA
+        av[set][m][s] = biast[0];
+#else
+        if (s >= G::steps(g)) {
+          av[set][m][s] = 0.f;
+        } else if (st >= G::Q4) {
+          av[set][m][s] = lds_load<float>(ax, mo + 4 * (4 * (st - G::Q4)));
+        } else if (A64 && (s & 1) == 0 && st + 1 < G::Q4) {
+          const f32x2 u = lds_load<f32x2>(ab, mo + 4 * st);
+          av[set][m][s] = u.x; av[set][m][s + 1] = u.y;
+        } else if (!(A64 && (s & 1) == 1 && st < G::Q4)) {
+          av[set][m][s] = lds_load<float>(ab, mo + 4 * st);
+        }
+#endif
       }
     }
 #pragma unroll
@@ -221,136 +274,126 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
 #ifdef KYO_ABL_NOLDSB
       bv[set][t] = (f32x4){biast[t], biast[t], biast[t], biast[t]};
 #else
-      bv[set][t] = *reinterpret_cast<const f32x4*>(wl + wofs[t] + g * GSTRIDE);
+      bv[set][t] = lds_load<f32x4>(wa[t], g * GBYTES);
 #endif
     }
   };
-  const int aofs = img * ROWF + G::FP + (xcol0 + li) * CIN;    // operand k = (kx, c) of output column x starts at x * CIN
-  load_ops(0, 0, rows + aofs);
+  // operand k = (kx, c) of output column x starts at x * CIN of the staged row; the lane-group part of k is folded
+  // into the two address registers (main run, extra steps)
+  const float* const arow0 = rows + img * ROWF + G::FP + (strip * G::SW + li) * CIN;
+  const uint32_t arow = keep_in_vgpr(lds_addr(arow0 + G::Q4 * lj));
+  const uint32_t axtr = keep_in_vgpr(lds_addr(arow0 + 4 * G::Q4 + lj));
+  load_ops(0, 0, arow, axtr, wadr[0]);
 
 #ifdef KYO_CLOCK_PROBE
   const unsigned long long pc0 = __builtin_readcyclecounter(), pr0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  for (int q = 0; q < H + P; ++q) {
-    const int rnext = rcur + 1 == RING ? 0 : rcur + 1;
+  // The row loop is unrolled by KS so that the block that completes in a step -- and with it the (tile, lane range)
+  // that is taken out and reset -- is a compile-time constant: no per-lane block compares or select chains.
+  for (int q0 = 0; q0 < H + P; q0 += KS) {
+#pragma unroll
+    for (int sq = 0; sq < KS; ++sq) {
+      const int q = q0 + sq;
+      if (q >= H + P) break;                         // uniform
+      constexpr int PD_BASE = (KS - P) % KS;
+      const int pdone = (PD_BASE + sq) % KS;         // block of row y = q - P: constant after unrolling
+      const int rnext = rcur + 1 == RING ? 0 : rcur + 1;
 #ifndef KYO_ABL_NOSTAGE
-    {                                                // row q + RING - 1 -> the slot row q - 1 has just left
-      const int rw = rcur == 0 ? RING - 1 : rcur - 1;
-      if (q + RING - 1 < H) stage_store(rows + rw * RSET);
-      if (q + RING < H) stage_load(q + RING);
-    }
+      {                                              // row q + RING - 1 -> the slot row q - 1 has just left
+        const int rw = rcur == 0 ? RING - 1 : rcur - 1;
+        if (q + RING - 1 < H) stage_store(rw);
+        if (q + RING < H) stage_load(q + RING);
+      }
 #endif
 
-    if (q < H) {
-      const float* ab = rows + rcur * RSET + aofs;
-#ifdef KYO_PRIO
-      __builtin_amdgcn_s_setprio(KYO_PRIO);
-#endif
+      if (q < H) {
+        const uint32_t ab = arow + (uint32_t)(rcur * RSET * 4), ax = axtr + (uint32_t)(rcur * RSET * 4);
 #pragma unroll
-      for (int g = 0; g < NGT; ++g) {
-        if (g + 1 < NGT) load_ops(g + 1, (g + 1) & 1, ab);
+        for (int g = 0; g < NGT; ++g) {
+          if (g + 1 < NGT) load_ops(g + 1, (g + 1) & 1, ab, ax, wadr[sq]);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          if (s < G::steps(g)) {
+          for (int s = 0; s < 4; ++s) {
+            if (s < G::steps(g)) {
 #pragma unroll
-            for (int m = 0; m < XT; ++m)
+              for (int m = 0; m < XT; ++m)
 #pragma unroll
-              for (int t = 0; t < NT; ++t) acc[m][t] = MFMA16(av[g & 1][m][s], bv[g & 1][t][s], acc[m][t]);
+                for (int t = 0; t < NT; ++t) acc[m][t] = MFMA16(av[g & 1][m][s], bv[g & 1][t][s], acc[m][t]);
+            }
           }
         }
       }
-#ifdef KYO_PRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
-    }
-    // rotate the weights: ky of every block advances by one
+      // group 0 of the next row (made visible by the previous barrier) loads under the epilogue
+      if (q + 1 < H) {
+        load_ops(0, NGT & 1, arow + (uint32_t)(rnext * RSET * 4), axtr + (uint32_t)(rnext * RSET * 4), wadr[(sq + 1) % KS]);
+        if (NGT & 1) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      wofs[t] += KYSTRIDE;
-      if (wofs[t] >= KS * KYSTRIDE) wofs[t] -= KS * KYSTRIDE;
-    }
-    // group 0 of the next row (made visible by the previous barrier) loads under the epilogue
-    if (q + 1 < H) {
-      load_ops(0, NGT & 1, rows + rnext * RSET + aofs);
-      if (NGT & 1) {
+          for (int m = 0; m < XT; ++m)
 #pragma unroll
-        for (int m = 0; m < XT; ++m)
+            for (int s = 0; s < 4; ++s) av[0][m][s] = av[1][m][s];
 #pragma unroll
-          for (int s = 0; s < 4; ++s) av[0][m][s] = av[1][m][s];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) bv[0][t] = bv[1][t];
+          for (int t = 0; t < NT; ++t) bv[0][t] = bv[1][t];
+        }
       }
-    }
 
-    // ---- output row y = q - P is complete (rows y < 0 do not exist: their block only needs clearing): take the
-    // block out of the accumulators with selects (no divergence), x half of the max-pool in registers
+      // ---- output row y = q - P is complete (rows y < 0 do not exist: their block is only reset): the lanes of block
+      // pdone in the one or two tiles it spans do the x half of the max-pool and park (value, code) in the pool-pair
+      // buffer; the block restarts from the bias
 #ifdef KYO_ABL_NOEPI
-    const int y = (q == H + P - 1) ? q - P : -1;
+      const int y = (q == H + P - 1) ? q - P : -1;
 #else
-    const int y = q - P;
+      const int y = q - P;
 #endif
-    const int par = y & 1;
-    {
-      f32x4 z[XT];
-      float bsel = 0.f; int esel = 0; bool mine = false;
-#pragma unroll
-      for (int m = 0; m < XT; ++m) z[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int par = y & 1;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const bool hit = pt[t] == pdone;
-        mine = mine || hit;
-        bsel = hit ? biast[t] : bsel;
-        esel = hit ? eofs[t] : esel;
+        const int clo = pdone * NO - 16 * t, chi = pdone * NO + NO - 1 - 16 * t;    // block columns relative to tile t
+        if (chi >= 0 && clo <= 15) {                 // compile-time: the block has columns in this tile
+          const bool inr = li >= clo && li <= chi;
+          if (inr) {
 #pragma unroll
-        for (int m = 0; m < XT; ++m) {
+            for (int m = 0; m < XT; ++m) {
+              if (y >= 0) {
+                const uint32_t ea = eadr[t] + (uint32_t)(par * (8 * XT * NO) * 8);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            z[m][r] = hit ? acc[m][t][r] : z[m][r];
-            acc[m][t][r] = hit ? 0.f : acc[m][t][r];
+                for (int h = 0; h < 2; ++h) {
+                  const float z0 = acc[m][t][2 * h], z1 = acc[m][t][2 * h + 1];
+                  lds_store(ea, ((m * 8 + h) * NO) * 8, (f32x2){z1 > z0 ? z1 : z0, __int_as_float(z1 > z0 ? 1 : 0)});
+                }
+              }
+              acc[m][t] = (f32x4){biast[t], biast[t], biast[t], biast[t]};
+            }
           }
         }
       }
-      if (mine && y >= 0) {
+      if (y >= 0 && par == 1 && (y >> 1) < Hp) {       // wave-uniform: both rows of a pool pair are in the buffer
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int orow = (y >> 1) * Wp * nout;         // uniform
 #pragma unroll
-        for (int m = 0; m < XT; ++m) {
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const float z0 = z[m][2 * h] + bsel, z1 = z[m][2 * h + 1] + bsel;
-            ev[par * (8 * XT * NO) + (m * 8 + h) * NO + esel] =
-                make_float2(z1 > z0 ? z1 : z0, __int_as_float(z1 > z0 ? 1 : 0));
-          }
-        }
-      }
-    }
-    pdone = pdone + 1 == KS ? 0 : pdone + 1;
-    if (y >= 0 && par == 1 && (y >> 1) < Hp) {         // wave-uniform: both rows of a pool pair are in the buffer
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const long orow = (long)(y >> 1) * Wp * nout;
-#pragma unroll
-      for (int i = 0; i < NC; ++i) {
-        if (ce[i] >= 0) {
-          const float2 top = ev[ce[i]], bot = ev[8 * XT * NO + ce[i]];
-          const bool lower = bot.x > top.x;
-          const float mx = lower ? bot.x : top.x;
-          const int code = lower ? 2 + __float_as_int(bot.y) : __float_as_int(top.y);
+        for (int i = 0; i < NC; ++i) {
+          if (cact[i]) {
+            const f32x2 top = lds_load<f32x2>(cadr[i], 0), bot = lds_load<f32x2>(cadr[i], (8 * XT * NO) * 8);
+            const bool lower = bot.x > top.x;
+            const float mx = lower ? bot.x : top.x;
+            const int code = lower ? 2 + __float_as_int(bot.y) : __float_as_int(top.y);
 #ifdef KYO_ABL_NOSTORE
-          if (mx == 123.456f)
+            if (mx == 123.456f)
 #endif
-          a.out[(long)bimg * a.out_bstride + orow + coe[i]] = fmaxf(mx, 0.f);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mx > 0.f ? mx : 0.f), out_rsrc, (int)(coe[i] * 4), orow * 4, 0);
 #if defined(KYO_ABL_NOSTORE) || defined(KYO_ABL_NOCODE)
-          if (mx == 123.456f)
+            if (mx == 123.456f)
 #endif
-          a.out_amax[(long)bimg * Hp * Wp * nout + orow + coe[i]] = (uint8_t)code;
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)code, amax_rsrc, (int)coe[i], orow, 0);
+          }
         }
+        __builtin_amdgcn_wave_barrier();
       }
-      __builtin_amdgcn_wave_barrier();
-    }
-    rcur = rnext;
+      rcur = rnext;
 #ifndef KYO_ABL_NOBAR
-    __syncthreads();
+      __syncthreads();
 #endif
+    }
   }
 #ifdef KYO_CLOCK_PROBE
   if (tid == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1) {

@@ -608,8 +608,17 @@ extern "C" int cpp_net_forward(cpp_net* n, const void* state, int state_dtype, i
 
 extern "C" int cpp_net_get_pool(cpp_net* n, int which, int B, float* out) {
   ARG_CHECK(n && out, "cpp_net_get_pool: NULL argument");
-  ARG_CHECK(n->spec.pixel && which >= 1 && which <= 3, "cpp_net_get_pool: which=%d (pixel nets, 1..3)", which);
   ARG_CHECK(B >= 1 && B <= n->maxB, "cpp_net_get_pool: batch %d", B);
+  if (n->spec.pixel && which >= 11 && which <= 13) {   // debug: arg-max codes (0..3) of the 2x2 windows, as floats
+    const ConvL& L = n->conv[which - 11];
+    const size_t cnt = (size_t)B * L.Hp * L.Wp * kConvOut;
+    std::vector<uint8_t> tmp(cnt);
+    HIP_CHECK(hipMemcpyAsync(tmp.data(), n->ws[0].amax[which - 11], cnt, hipMemcpyDeviceToHost, n->ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(n->ctx->stream));
+    for (size_t i = 0; i < cnt; ++i) out[i] = (float)tmp[i];
+    return CPP_OK;
+  }
+  ARG_CHECK(n->spec.pixel && which >= 1 && which <= 3, "cpp_net_get_pool: which=%d (pixel nets, 1..3)", which);
   const ConvL& L = n->conv[which - 1];
   const size_t row = (size_t)L.Hp * L.Wp * kConvOut * sizeof(float);
   const size_t spitch = (which == 3) ? ((size_t)n->flat + 1) * sizeof(float) : row;

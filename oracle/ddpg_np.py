@@ -214,6 +214,17 @@ def relu_pool_fwd(z):
     return np.maximum(zmax, 0), amax.astype(np.uint8)
 
 
+def pool_window_margin(z):
+    """largest minus second-largest value of every 2x2 window: how close the arg-max decision of relu_pool_fwd is
+    to a tie (the routing of the max-pool gradient is discontinuous there; tests use this to tell a rounding-level
+    tie-break difference from an error)."""
+    B, H, W, C = z.shape
+    hp, wp = H // 2, W // 2
+    win = z[:, :2 * hp, :2 * wp, :].reshape(B, hp, 2, wp, 2, C).transpose(0, 1, 3, 5, 2, 4).reshape(B, hp, wp, C, 4)
+    part = np.partition(win, 2, axis=-1)
+    return part[..., 3] - part[..., 2]
+
+
 def relu_pool_bwd(dp, pooled, amax, H, W):
     """route dp to the window arg-max where the pooled (post-relu) value is > 0."""
     B, hp, wp, C = dp.shape
@@ -249,6 +260,7 @@ class Net(object):
     def __init__(self, spec, flat_params, dt):
         self.spec, self.dt = spec, dt
         self.p = unflatten(spec, flat_params, dt)
+        self.amax_override = None     # tests only: {conv name: arg-max codes} to route the pool gradient with
 
     def flat(self):
         return flatten(self.spec, self.p, self.dt)
@@ -269,6 +281,9 @@ class Net(object):
             for (name, _k, _co), (h, w) in zip(CONV_DEFS, sp.conv_hw):
                 z = conv_fwd(x, self.p[name + "/weights"], self.p[name + "/biases"])
                 pooled, amax = relu_pool_fwd(z)
+                c[name + ":margin"] = pool_window_margin(z)
+                if self.amax_override is not None and name in self.amax_override:
+                    amax = np.asarray(self.amax_override[name]).astype(np.uint8).reshape(amax.shape)
                 c[name] = (x, pooled, amax, h, w)
                 x = pooled
             c["pool_shape"] = x.shape

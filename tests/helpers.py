@@ -70,3 +70,50 @@ def assert_flat_close(spec, got, want, rel=2e-5, what=""):
     bad = [r for r in rows if r[2] > rel and r[1] > rel * scale]
     msg = "\n".join("%-28s max_abs=%.3e rel_l2=%.3e" % r for r in rows)
     assert not bad, "%s mismatch (rel tol %g):\n%s" % (what, rel, msg)
+
+
+def device_pool_codes(net, B):
+    """arg-max codes (0..3) of the 2x2 pooling windows of the device network's last forward, per conv layer."""
+    from cartpoleplusplus_amd._lib import lib, check, ptr
+    out = {}
+    for i, (name, _k, _co) in enumerate(O.CONV_DEFS):
+        shp = getattr(net, "pool%d" % (i + 1)).get_shape()
+        codes = np.empty((B,) + tuple(shp[1:]), np.float32)
+        check(lib.cpp_net_get_pool(net.handle, 11 + i, B, ptr(codes)))
+        out[name] = codes.astype(np.uint8)
+    return out
+
+
+def assert_grads_close_modulo_pool_ties(spec, device_net, B, oracle_net, oracle_cache_fn, oracle_grads_fn, got,
+                                        what="", rel=2e-5, margin_tol=1e-5):
+    """Gradient parity with the max-pool's discontinuity taken into account.  The pool routes a window's gradient
+    to its arg-max; where the two largest pre-activations of a window agree to rounding level, a different (but
+    equally valid) f32 summation order picks the other element and moves that gradient to a neighbouring pixel.
+    Such a flip is accepted only if the oracle itself sees a near tie there (margin <= margin_tol relative); the
+    oracle's gradient is then recomputed with the device's choice at exactly those windows and must match."""
+    want = oracle_grads_fn()
+    try:
+        assert_flat_close(spec, got, want, rel=rel, what=what)
+        return 0
+    except AssertionError as e:
+        first = e
+    cache = oracle_cache_fn()
+    codes = device_pool_codes(device_net, B)
+    flips = 0
+    for name, _k, _co in O.CONV_DEFS:
+        _x, pooled, amax, _h, _w = cache[name]
+        margin = cache[name + ":margin"]
+        diff = (codes[name] != amax) & (pooled > 0)
+        bad = diff & (margin > margin_tol * np.maximum(1.0, np.abs(pooled)))
+        assert not bad.any(), "%s: %s arg-max differs at %d window(s) that are not near ties\n%s" % (
+            what, name, int(bad.sum()), first)
+        flips += int(diff.sum())
+    assert flips > 0, first
+    oracle_net.amax_override = codes
+    try:
+        want = oracle_grads_fn()
+    finally:
+        oracle_net.amax_override = None
+    assert_flat_close(spec, got, want, rel=rel,
+                      what="%s (oracle re-run with the device's choice at %d near-tie pooling windows)" % (what, flips))
+    return flips

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import ddpg_np as O
-from tests.helpers import make_pair, assert_flat_close
+from tests.helpers import make_pair, assert_flat_close, assert_grads_close_modulo_pool_ties
 
 pytestmark = pytest.mark.gpu
 
@@ -114,9 +114,14 @@ def test_wide_image_geometry_parity(shape, Bs):
         assert np.abs(q - cg["q"]).max() < 1e-5
         pa = agent.actor.get_params()
         agent.actor.train(hb)
-        assert_flat_close(aspec, agent.actor.get_grads(), ag["grads"], what="actor grads")
+        # B is tiny here, so a single rounding-level tie-break in a 2x2 pooling window shows in the conv1 gradient
+        assert_grads_close_modulo_pool_ties(
+            aspec, agent.actor, Bs, ref.actor, lambda: ref.actor.forward(t[0]),
+            lambda: ref.actor_gradients(t[0])["grads"], agent.actor.get_grads(), what="actor grads")
         agent.actor.set_params(pa)
         agent.critic.train(hb)
-        assert_flat_close(cspec, agent.critic.get_grads(), cg["grads"], what="critic grads")
+        assert_grads_close_modulo_pool_ties(
+            cspec, agent.critic, Bs, ref.critic, lambda: ref.critic.forward(t[0], action=np.asarray(t[1])),
+            lambda: ref.critic_gradients(t)["grads"], agent.critic.get_grads(), what="critic grads")
     finally:
         agent.close()
