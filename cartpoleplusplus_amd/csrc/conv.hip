@@ -1,5 +1,5 @@
 // Host-side launchers of the conv kernels (geometry selection + profiling brackets).
-#include "conv_kyo.h"
+#include "conv_dw_kyo.h"
 #include <cstdlib>
 
 static int pick_xtw(int in_mode, int W) {
@@ -51,10 +51,9 @@ int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, i
     const int epc = in_mode == IN_F16_WHITEN ? 8 : 4;
     for (int i = 0; i < n; ++i) kyo = kyo && batch.a[i].vec_ok && (a.W * cin) % epc == 0;
   }
-  // the narrow layers (conv2 / conv3: 32 / 16 rows of 52 / 16 MFMAs per wave) are latency bound either way and
-  // measured slightly slower with one barrier per row: opt-in with CPP_CONV_KYO23=1
-  static const bool kyo23 = getenv("CPP_CONV_KYO23") != nullptr && atoi(getenv("CPP_CONV_KYO23")) != 0;
-  if (in_mode == IN_F32_PLAIN && !kyo23) kyo = false;
+  // CPP_CONV_KYO23=0 keeps the narrow layers (conv2 / conv3) on the old kernel
+  static const bool no_kyo23 = getenv("CPP_CONV_KYO23") != nullptr && atoi(getenv("CPP_CONV_KYO23")) == 0;
+  if (in_mode == IN_F32_PLAIN && no_kyo23) kyo = false;
   if (kyo) {
     bool handled = false;
     rc = (in_mode == IN_F32_PLAIN) ? conv_fwd_kyo_dispatch_l23(ctx, cin, ks, in_mode, batch, &handled)
@@ -78,7 +77,7 @@ int launch_conv_fwd(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi
 }
 
 size_t conv_dw_partial_floats(cpp_ctx* ctx, int cin, int ks, int nout) {
-  return (size_t)(ctx->num_cus * 2) * (size_t)(ks * ks * cin * nout + nout);
+  return (size_t)(ctx->num_cus * 4) * (size_t)(ks * ks * cin * nout + nout);   // one partial per resident workgroup
 }
 
 int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, const ConvArgs* list, int n,
@@ -101,7 +100,17 @@ int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, co
   }
   int grid = 0, rc;
   prof_begin(ctx);
-  if (in_mode == IN_F16_WHITEN || in_mode == IN_F32_WHITEN)
+  // (ky,o)-column kernel for the 5x5 layers whose rows stage as aligned 16-byte chunks (CPP_CONV_KYO=0: old kernel)
+  static const bool no_kyo = getenv("CPP_CONV_KYO") != nullptr && atoi(getenv("CPP_CONV_KYO")) == 0;
+  bool kyo = !no_kyo && ks == 5 && nout <= 10 && (batch.a[0].H % 2) == 0 && batch.a[0].H >= 4;
+  if (kyo) {
+    const int epc = in_mode == IN_F16_WHITEN ? 8 : 4;
+    for (int i = 0; i < n; ++i) kyo = kyo && batch.a[i].vec_ok && (batch.a[i].W * cin) % epc == 0;
+  }
+  bool handled = false;
+  if (kyo) rc = conv_dw_kyo_dispatch(ctx, cin, ks, in_mode, batch, &grid, &handled);
+  if (handled) {
+  } else if (in_mode == IN_F16_WHITEN || in_mode == IN_F32_WHITEN)
     rc = conv_dw_dispatch_l1(ctx, cin, ks, xtw, in_mode, batch, &grid);
   else
     rc = conv_dw_dispatch_l23(ctx, cin, ks, xtw, in_mode, batch, &grid);
