@@ -32,7 +32,9 @@ struct DwKyoGeom {
   static constexpr int NS = NS_, WPAD = 4 * NS;               // k-steps per row (multiple of 4), padded row width
   static constexpr int FP = (4 - (P * CIN) % 4) % 4;
   static constexpr int ROWF = ((FP + (WPAD + KS - 1) * CIN + 16 * MT) + 3) & ~3;   // staged input row (+ m over-read)
-  static constexpr int DROW = NO * 4 * NS + 8;               // one dY row [o][k][s] (+ skew between ring slots)
+  static constexpr int KST = NS + 4, OST = 4 * KST + 4;      // dY row [o][k][s] with skewed strides: the staging writes of one
+                                                             // wave (cells (px, o), o fastest) and the B reads spread over the banks
+  static constexpr int DROW = NO * OST + 8;                  // (+ skew between ring slots)
   static constexpr int RING_IN = 3, RING_DY = 6, UNROLL = 6;
   static constexpr int WHF = 2 * ((CIN + 8 + 3) & ~3);
   static constexpr int NCELL = (2 * NS * NO + CONV_THREADS - 1) / CONV_THREADS;    // pooled cells of a row per thread
@@ -61,7 +63,8 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_dw_kyo_kernel(const Conv
   const int li = lane & 15, lj = lane >> 4;
   const int H = a.H, W = a.W, Hp = H >> 1, Wp = W >> 1, nout = a.nout;
 
-  for (int i = tid; i < G::RING_IN * ROWF + G::RING_DY * DROW; i += CONV_THREADS) lds[i] = 0.f;
+  for (int i = tid; i < (G::RING_IN * ROWF + G::RING_DY * DROW) / 4; i += CONV_THREADS)
+    reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (WHITEN) {
     for (int c = tid; c < CIN + 8; c += CONV_THREADS) { whs[c] = a.scale[c % CIN]; wht[c] = a.shift[c % CIN]; }
   }
@@ -132,25 +135,34 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_dw_kyo_kernel(const Conv
     const int idx = tid + CONV_THREADS * c;
     const int px = idx / nout, o = idx - px * nout;
     cact[c] = idx < Wp * nout;
-    cdst[c] = keep_in_vgpr(lds_addr(dyring + o * (4 * NS) + ((2 * px) & 3) * NS + (px >> 1)));
+    cdst[c] = keep_in_vgpr(lds_addr(dyring + o * G::OST + ((2 * px) & 3) * G::KST + (px >> 1)));
     cg[c] = 0.f; ccode[c] = 0; dbsum[c] = 0.f;
   }
-  // load the cells of pooled row py (zero outside the image); count each cell once for the bias gradient
-  auto dy_load = [&](const __amdgpu_buffer_rsrc_t& rp, const __amdgpu_buffer_rsrc_t& rd,
-                     const __amdgpu_buffer_rsrc_t& rc, int py, bool count) {
+  // request the cells of pooled row py (zero outside the image) into raw register set `set`; dy_conv turns them into
+  // (masked gradient, code) one step later, so the global latency hides under a step's MFMAs.  Each cell is counted
+  // once for the bias gradient.
+  float rpv[2][NCELL], rdv[2][NCELL];
+  int rcd[2][NCELL];
+  auto dy_issue = [&](const __amdgpu_buffer_rsrc_t& rp, const __amdgpu_buffer_rsrc_t& rd,
+                      const __amdgpu_buffer_rsrc_t& rc, int py, int set) {
     const bool rowok = py >= 0 && py < Hp;           // uniform
 #pragma unroll
     for (int c = 0; c < NCELL; ++c) {
-      float g = 0.f; int code = 0;
+      rpv[set][c] = 0.f; rdv[set][c] = 0.f; rcd[set][c] = 0;
       if (rowok && cact[c]) {
         const int vo = (tid + CONV_THREADS * c) * 4, so = py * Wp * nout * 4;
-        const float pv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rp, vo, so, 0));
-        const float dv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, vo, so, 0));
-        code = __builtin_amdgcn_raw_buffer_load_b8(rc, vo >> 2, so >> 2, 0);
-        g = pv > 0.f ? dv : 0.f;
+        rpv[set][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rp, vo, so, 0));
+        rdv[set][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, vo, so, 0));
+        rcd[set][c] = __builtin_amdgcn_raw_buffer_load_b8(rc, vo >> 2, so >> 2, 0);
       }
-      cg[c] = g; ccode[c] = code;
-      if (count) dbsum[c] += g;
+    }
+  };
+  auto dy_conv = [&](int set, bool count) {
+#pragma unroll
+    for (int c = 0; c < NCELL; ++c) {
+      cg[c] = rpv[set][c] > 0.f ? rdv[set][c] : 0.f;
+      ccode[c] = rcd[set][c];
+      if (count) dbsum[c] += cg[c];
     }
   };
   // write image row (parity ry of its pooled row) into ring slot `slot`
@@ -160,7 +172,7 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_dw_kyo_kernel(const Conv
       if (cact[c]) {
         const float v0 = ccode[c] == 2 * ry ? cg[c] : 0.f, v1 = ccode[c] == 2 * ry + 1 ? cg[c] : 0.f;
         lds_store(cdst[c], slot * DROW * 4, v0);
-        lds_store(cdst[c], slot * DROW * 4 + NS * 4, v1);
+        lds_store(cdst[c], slot * DROW * 4 + G::KST * 4, v1);
       }
     }
   };
@@ -175,7 +187,7 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_dw_kyo_kernel(const Conv
 #pragma unroll
   for (int sq = 0; sq < G::UNROLL; ++sq) {
     const int slot = (sq - nky + P + G::RING_DY) % G::RING_DY;            // ring slot of dY position t - ky + P, t = sq (mod 6)
-    badr[sq] = keep_in_vgpr(lds_addr(dyring + slot * DROW + no * (4 * NS) + lj * NS));
+    badr[sq] = keep_in_vgpr(lds_addr(dyring + slot * DROW + no * G::OST + lj * G::KST));
   }
   f32x4 acc[MT];
 #pragma unroll
@@ -199,15 +211,21 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_dw_kyo_kernel(const Conv
     // position d of the band's stream <-> image row q_lo - P + d.  Before the first step (t = P): dY positions
     // 0 .. 2P and input positions P, P+1 are in LDS, input position P+2 and the cells of dY position 2P+1 in registers.
     const int y0 = q_lo - P;                          // image row of position 0 (even: P == 2)
-    for (int d = 0; d <= 2 * P; ++d) {
-      const int y = y0 + d;
-      if ((d & 1) == 0) dy_load(rp, rd, rc, y >> 1, y >= q_lo && y < q_lo + rows);
-      dy_store(d % G::RING_DY, d & 1);
-    }
-    for (int d = P; d < P + 2; ++d) {
-      if (d - P < rows) { in_load(in_rs, y0 + d); in_store(d % G::RING_IN); }
-    }
+    auto in_band = [&](int y) { return y >= q_lo && y < q_lo + rows; };
+    if (0 < rows) in_load(in_rs, q_lo);
+    dy_issue(rp, rd, rc, y0 >> 1, 0);
+    dy_issue(rp, rd, rc, (y0 >> 1) + 1, 1);
+    if (0 < rows) in_store(P % G::RING_IN);
+    if (1 < rows) in_load(in_rs, q_lo + 1);
+    dy_conv(0, in_band(y0));
+    dy_store(0, 0); dy_store(1, 1);
+    dy_issue(rp, rd, rc, (y0 >> 1) + 2, 0);
+    dy_conv(1, in_band(y0 + 2));
+    dy_store(2, 0); dy_store(3, 1);
+    if (1 < rows) in_store((P + 1) % G::RING_IN);
     if (2 < rows) in_load(in_rs, q_lo + 2);
+    dy_conv(0, in_band(y0 + 4));
+    dy_store(4, 0);                                   // position 5 (same cells) is stored by the first step
     __syncthreads();
 
     for (int t0 = 0; t0 < rows + P; t0 += G::UNROLL) {
@@ -219,35 +237,52 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_dw_kyo_kernel(const Conv
         // stage ahead: dY position t + P + 1 (its slot held position t - P - 1), input position t + 2
         {
           const int d = t + P + 1, y = y0 + d;
-          if ((d & 1) == 0) dy_load(rp, rd, rc, y >> 1, y >= q_lo && y < q_lo + rows);
+#ifndef DWKYO_ABL_NODY
+          if ((d & 1) == 0) dy_conv(0, in_band(y));                       // requested one step ago
           dy_store((sq + P + 1) % G::RING_DY, (sq + P + 1) & 1);
+          if ((d & 1) == 1) dy_issue(rp, rd, rc, (y + 1) >> 1, 0);        // next pooled row, used from the next step on
+#endif
+#ifndef DWKYO_ABL_NOIN
           if (t + 2 - P < rows) in_store((sq + 2) % G::RING_IN);
           if (t + 3 - P < rows) in_load(in_rs, y0 + t + 3);
+#endif
         }
         // multiply input position t with dY positions t - P .. t + P
         const int islot = sq % G::RING_IN;
+        // operands of k-step st + LOOK are requested before the MFMAs of step st are issued (hipcc otherwise recycles
+        // one register pair per load and waits for each load right before its use)
+        constexpr int LOOK = 2;
+        float av[LOOK + 1][MT];
+        f32x4 bq[2];
+        auto load_a = [&](int st, int set) {
+          const int off = islot * ROWF * 4 + (4 * st) * CIN * 4;
+          if (A64) {
 #pragma unroll
-        for (int g4 = 0; g4 < NS / 4; ++g4) {
-          const f32x4 bq = lds_load<f32x4>(badr[sq], g4 * 16);
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int off = islot * ROWF * 4 + (4 * (4 * g4 + s)) * CIN * 4;
-            float av[MT];
-            if (A64) {
-#pragma unroll
-              for (int mt = 0; mt < MT; mt += 2) {
-                const f32x2 u = lds_load<f32x2>(aadr, off + 4 * mt);
-                av[mt] = u.x; av[mt + 1] = u.y;
-              }
-            } else {
-#pragma unroll
-              for (int mt = 0; mt < MT; ++mt) av[mt] = lds_load<float>(aadr, off + 4 * mt);
+            for (int mt = 0; mt < MT; mt += 2) {
+              const f32x2 u = lds_load<f32x2>(aadr, off + 4 * mt);
+              av[set][mt] = u.x; av[set][mt + 1] = u.y;
             }
+          } else {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = MFMA16(av[mt], bq[s], acc[mt]);
+            for (int mt = 0; mt < MT; ++mt) av[set][mt] = lds_load<float>(aadr, off + 4 * mt);
           }
+        };
+        bq[0] = lds_load<f32x4>(badr[sq], 0);
+#pragma unroll
+        for (int st = 0; st < LOOK; ++st) load_a(st, st);
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+          if (st + LOOK < NS) load_a(st + LOOK, (st + LOOK) % (LOOK + 1));
+          if ((st & 3) == 0 && st + 4 < NS) bq[((st >> 2) + 1) & 1] = lds_load<f32x4>(badr[sq], (st + 4) * 4);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt] = MFMA16(av[st % (LOOK + 1)][mt], bq[(st >> 2) & 1][st & 3], acc[mt]);
+          __builtin_amdgcn_sched_barrier(0);
         }
+#ifndef DWKYO_ABL_NOBAR
         __syncthreads();
+#endif
       }
     }
   }
