@@ -11,6 +11,8 @@ int conv_fwd_kyo_dispatch_l1(cpp_ctx* ctx, int cin, int ks, int in_mode, const C
   *handled = false;
   const int W = a.a[0].W;
   if (ks != 5 || W > 128) return 0;
+  // (two column tiles per wave at W <= 64, i.e. <18, 2, 2>, halves the B-operand LDS traffic but leaves 2 waves per
+  // SIMD: measured 0.391 vs 0.381 ms per step for conv1)
   const int xt = W > 64 ? 2 : 1;
   const int ipw = W > 32 ? 1 : (W > 16 ? 2 : 4);
   KYO1_CASE(18, 1, 1) KYO1_CASE(18, 1, 2) KYO1_CASE(9, 1, 1) KYO1_CASE(6, 1, 1) KYO1_CASE(6, 1, 2) KYO1_CASE(6, 1, 4)
