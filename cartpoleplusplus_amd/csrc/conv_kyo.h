@@ -74,6 +74,9 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
   typedef KyoGeom<CIN, KS, XT, IPW> G;
   typedef typename StageType<IN_MODE>::type ST;
   constexpr bool WHITEN = (IN_MODE == IN_F16_WHITEN || IN_MODE == IN_F32_WHITEN);
+  // IN_DY: the dX pass of the layer -- input rows are dY rows rebuilt from the pooled gradient + arg-max code, the
+  // weights are flipped and transposed, the epilogue writes plain full-resolution rows (no bias / ReLU / pool)
+  constexpr bool DX = (IN_MODE == IN_DY);
   constexpr int P = G::P, NT = G::NT, NGT = G::NGT, ROWF = G::ROWF, NO = KYO_NO;
   constexpr int EPC = ChunkOps<ST>::EPC;
   constexpr bool A64 = (CIN % 2 == 0) && (G::FP % 2 == 0);      // A operand pairs are 8-byte aligned in LDS (Q4 is even)
@@ -106,7 +109,9 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
       const int l = r & 3, g = (r >> 2) % NGT, ky = (r >> 2) / NGT;
       const int k = G::kmap(4 * g + s, l);
       const bool ok = i < G::WLF && s < G::steps(g) && o < nout && k < G::KROW;
-      const float v = a.w[ok ? (ky * G::KROW + k) * nout + o : 0];
+      // dX = correlation of dY with W'[ky][kx][c'][o'] = W[KS-1-ky][KS-1-kx][o'][c'], W stored (KS,KS,Cin = nout,Cout = CIN)
+      const int widx = DX ? (((KS - 1 - ky) * KS + (KS - 1 - k / CIN)) * nout + o) * CIN + k % CIN : (ky * G::KROW + k) * nout + o;
+      const float v = a.w[ok ? widx : 0];
       wv[n] = ok ? v : 0.f;
     }
 #pragma unroll
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
   // ---- row staging: chunk ch -> (image, 16-byte chunk of the row); a thread's chunks are the same for every row,
   // so the byte offset from the (uniform) row base, the LDS destination and the whitening constants' address are
   // fixed up front
-  const int cpr = (W * CIN) / EPC;                   // chunks per image row (W*CIN % EPC == 0 checked by the host)
+  const int cpr = DX ? 1 : (W * CIN) / EPC;          // chunks per image row (W*CIN % EPC == 0 checked by the host)
   constexpr int NVMAX = (IPW * G::WPAD * CIN / EPC + CONV_THREADS - 1) / CONV_THREADS;
   uint4 sv[NVMAX];
   unsigned sbyte[NVMAX];                             // byte offset of the chunk from the row base of image b0
@@ -140,10 +145,72 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
   // offset -- no vector address arithmetic per row
   const int nimg = a.B - b0 < IPW ? a.B - b0 : IPW;
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<ST*>((const ST*)a.in + (long)b0 * a.in_bstride), 0, (int)(nimg * a.in_bstride * (long)sizeof(ST)), 0x00020000);
+      DX ? (void*)const_cast<float*>(a.dy.dpool) : (void*)const_cast<ST*>((const ST*)a.in + (long)b0 * a.in_bstride), 0,
+      DX ? 0 : (int)(nimg * a.in_bstride * (long)sizeof(ST)), 0x00020000);
   const int rowbytes = W * CIN * (int)sizeof(ST);
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  // ---- IN_DY staging: a thread owns pooled cells (image, px, o) -- the same cells for every pooled row; one
+  // (masked gradient, code) pair serves the two dY rows of its pooled row (requested one row ahead)
+  constexpr int NCELL = DX ? (IPW * (G::WPAD / 2) * NO + CONV_THREADS - 1) / CONV_THREADS : 1;
+  bool qact[NCELL]; uint32_t qdst[NCELL]; int qvo[NCELL], qvd[NCELL], qco[NCELL];
+  float qg[NCELL], qpv[NCELL], qdv[NCELL]; int qcode[NCELL], qrc[NCELL];
+  const int dyWp = W >> 1, dyHp = H >> 1;
+  const __amdgpu_buffer_rsrc_t rs_pool = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.dy.pool + (DX ? (long)b0 * a.dy.pool_bstride : 0)), 0, DX ? (int)(nimg * a.dy.pool_bstride * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dpool = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.dy.dpool + (DX ? (long)b0 * a.dy.dpool_bstride : 0)), 0, DX ? (int)(nimg * a.dy.dpool_bstride * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_amax = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(a.dy.amax + (DX ? (long)b0 * dyHp * dyWp * CIN : 0)), 0, DX ? nimg * dyHp * dyWp * CIN : 0, 0x00020000);
+  if (DX) {
+#pragma unroll
+    for (int c = 0; c < NCELL; ++c) {
+      const int idx = tid + CONV_THREADS * c;
+      const int per = dyWp * CIN;                     // cells of one pooled row of one image (dY has CIN channels)
+      const int im = idx / per, e = idx - im * per;
+      const int px = e / CIN, o = e - px * CIN;
+      qact[c] = im < IPW && b0 + im < a.B;
+      qdst[c] = keep_in_vgpr(lds_addr(rows + im * ROWF + G::FP + (2 * px + P) * CIN + o));
+      qvo[c] = (int)((long)im * a.dy.pool_bstride + e) * 4;
+      qvd[c] = (int)((long)im * a.dy.dpool_bstride + e) * 4;
+      qco[c] = im * dyHp * dyWp * CIN + e;
+      qg[c] = 0.f; qcode[c] = 0; qpv[c] = 0.f; qdv[c] = 0.f; qrc[c] = 0;
+    }
+  }
+  auto dy_issue = [&](int py) {
+    const bool rowok = py >= 0 && py < dyHp;         // uniform
+#pragma unroll
+    for (int c = 0; c < NCELL; ++c) {
+      qpv[c] = 0.f; qdv[c] = 0.f; qrc[c] = 0;
+      if (rowok && qact[c]) {
+        const int so = py * dyWp * CIN;
+        qpv[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_pool, qvo[c], so * 4, 0));
+        qdv[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_dpool, qvd[c], so * 4, 0));
+        qrc[c] = __builtin_amdgcn_raw_buffer_load_b8(rs_amax, qco[c], so, 0);
+      }
+    }
+  };
+  auto dy_conv = [&]() {
+#pragma unroll
+    for (int c = 0; c < NCELL; ++c) { qg[c] = qpv[c] > 0.f ? qdv[c] : 0.f; qcode[c] = qrc[c]; }
+  };
+  auto dy_store = [&](int slot, int ry) {
+#pragma unroll
+    for (int c = 0; c < NCELL; ++c) {
+      if (qact[c]) {
+        const float v0 = qcode[c] == 2 * ry ? qg[c] : 0.f, v1 = qcode[c] == 2 * ry + 1 ? qg[c] : 0.f;
+        lds_store(qdst[c], slot * RSET * 4, v0);
+        lds_store(qdst[c], slot * RSET * 4 + CIN * 4, v1);
+      }
+    }
+  };
+  // dY row y into ring slot `slot`: even rows convert the cells requested one row earlier, odd rows request the next
+  auto dx_stage_row = [&](int y, int slot) {
+    if ((y & 1) == 0) dy_conv();
+    dy_store(slot, y & 1);
+    if ((y & 1) == 1) dy_issue((y + 1) >> 1);
+  };
   auto stage_load = [&](int y) {
+    if (DX) return;
 #pragma unroll
     for (int i = 0; i < NVMAX; ++i) {
       if (sact[i]) {
@@ -152,7 +219,8 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
       }
     }
   };
-  auto stage_store = [&](int slot) {                 // slot: uniform ring slot
+  auto stage_store = [&](int slot, int y) {          // slot: uniform ring slot; y: the row being written
+    if (DX) { dx_stage_row(y, slot); return; }
 #pragma unroll
     for (int i = 0; i < NVMAX; ++i) {
       if (sact[i]) {
@@ -196,8 +264,9 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
     const int j = 16 * t + li;
     const bool valid = j < KS * NO;
     const int o = j % NO;
-    biast[t] = (valid && o < nout) ? a.bias[o] : 0.f;
-    eadr[t] = keep_in_vgpr(lds_addr(ev + (lj * 2) * NO + o));
+    biast[t] = (!DX && valid && o < nout) ? a.bias[o] : 0.f;
+    eadr[t] = DX ? (uint32_t)(((sstrip * G::SW + 4 * lj) * nout + o) * 4)      // byte offset of (x = strip + 4 lj, o) in an output row
+                 : keep_in_vgpr(lds_addr(ev + (lj * 2) * NO + o));
     const int p = valid ? j / NO : 0;
 #pragma unroll
     for (int sq = 0; sq < KS; ++sq) {
@@ -223,7 +292,7 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
   }
   const int simg_ok = sbimg < a.B ? sbimg : 0;
   const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      a.out + (long)simg_ok * a.out_bstride, 0, Hp * Wp * nout * 4, 0x00020000);             // uniform (per wave)
+      a.out + (long)simg_ok * a.out_bstride, 0, (DX ? H * W : Hp * Wp) * nout * 4, 0x00020000);   // uniform (per wave)
   const __amdgpu_buffer_rsrc_t amax_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       a.out_amax + (long)simg_ok * Hp * Wp * nout, 0, Hp * Wp * nout, 0x00020000);
 
@@ -235,8 +304,9 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
     for (int t = 0; t < NT; ++t) acc[m][t] = (f32x4){biast[t], biast[t], biast[t], biast[t]};
 
   __syncthreads();                                   // zeroed row buffers + whitening table visible
+  if (DX) dy_issue(0);
   for (int r = 0; r < RING - 1; ++r) {
-    if (r < H) { stage_load(r); stage_store(r); }
+    if (r < H) { stage_load(r); stage_store(r, r); }
   }
   if (RING - 1 < H) stage_load(RING - 1);
   __syncthreads();
@@ -301,7 +371,7 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
 #ifndef KYO_ABL_NOSTAGE
       {                                              // row q + RING - 1 -> the slot row q - 1 has just left
         const int rw = rcur == 0 ? RING - 1 : rcur - 1;
-        if (q + RING - 1 < H) stage_store(rw);
+        if (q + RING - 1 < H) stage_store(rw, q + RING - 1);
         if (q + RING < H) stage_load(q + RING);
       }
 #endif
@@ -352,7 +422,14 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
           if (inr) {
 #pragma unroll
             for (int m = 0; m < XT; ++m) {
-              if (y >= 0) {
+              if (DX) {
+                if (y >= 0 && sbimg < a.B) {
+#pragma unroll
+                  for (int r = 0; r < 4; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][t][r]), out_rsrc,
+                                                          (int)eadr[t] + ((m * 16 + r) * NO) * 4, y * W * nout * 4, 0);
+                }
+              } else if (y >= 0) {
                 const uint32_t ea = eadr[t] + (uint32_t)(par * (8 * XT * NO) * 8);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -365,7 +442,7 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
           }
         }
       }
-      if (y >= 0 && par == 1 && (y >> 1) < Hp) {       // wave-uniform: both rows of a pool pair are in the buffer
+      if (!DX && y >= 0 && par == 1 && (y >> 1) < Hp) {   // wave-uniform: both rows of a pool pair are in the buffer
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
