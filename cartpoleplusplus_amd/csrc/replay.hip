@@ -105,7 +105,23 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(const GatherArgs a) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
   if (lane < act) {
-    for (long v = wave * act + lane; v < nvec; v += 4 * act) {
+    // GU row vectors per thread in flight (one 16-byte load each is far too little to cover the HBM latency with two
+    // workgroups per CU); the accumulation order per lane is unchanged
+    constexpr int GU = 6;
+    long v = wave * act + lane;
+    const long stride = 4 * act;
+    for (; v + (GU - 1) * stride < nvec; v += GU * stride) {
+      Vec8<T> x[GU];
+#pragma unroll
+      for (int u = 0; u < GU; ++u) x[u].load(src + (v + u * stride) * 8);
+#pragma unroll
+      for (int u = 0; u < GU; ++u) {
+        if (dst) x[u].store(dst + (v + u * stride) * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = x[u].get(e); s[e] += f; ss[e] = fmaf(f, f, ss[e]); }
+      }
+    }
+    for (; v < nvec; v += stride) {
       Vec8<T> x;
       x.load(src + v * 8);
       if (dst) x.store(dst + v * 8);
