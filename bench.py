@@ -228,6 +228,11 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     sys.stdout.flush()
+    try:                                   # RCCL's banner sits in the C stdio buffer: flush it to the redirected fd first
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     os.dup2(real_stdout, 1)
     if rank == 0:
         print(json.dumps(out))
