@@ -39,14 +39,10 @@ int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, i
   const ConvArgs& a = batch.a[0];
   prof_begin(ctx);
   int rc;
-  // (kx,o)-column kernel (experimental, opt-in with CPP_CONV_KXO=1): 20 % fewer MFMAs but measured slower on
-  // MI355X under hipcc's register allocation (conv1: 0.66-0.78 ms/step vs 0.54) -- see DESIGN.md section 6
-  static const bool want_kxo = getenv("CPP_CONV_KXO") != nullptr;
-  const bool kxo = want_kxo && epi == EPI_RELU_POOL && a.tiles_x == 1 && a.nout <= 10 && in_mode != IN_DY && cin != 30;
   // (ky,o)-column kernel: the default for the pooled forward layers whose rows can be staged as aligned 16-byte
   // chunks (CPP_CONV_KYO=0 selects the (ky,(kx,c)) x o kernel for A/B measurements)
   static const bool no_kyo = getenv("CPP_CONV_KYO") != nullptr && atoi(getenv("CPP_CONV_KYO")) == 0;
-  bool kyo = !no_kyo && !kxo && a.nout <= 10 && a.H >= 2 &&
+  bool kyo = !no_kyo && a.nout <= 10 && a.H >= 2 &&
              ((epi == EPI_RELU_POOL && in_mode != IN_DY) || (epi == EPI_PLAIN && in_mode == IN_DY));
   if (kyo && in_mode != IN_DY) {
     const int epc = in_mode == IN_F16_WHITEN ? 8 : 4;
@@ -61,11 +57,7 @@ int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, i
                                    : conv_fwd_kyo_dispatch_l1(ctx, cin, ks, in_mode, batch, &handled);
     if (handled) { prof_end(ctx, kid); return rc; }
   }
-  if (kxo && (in_mode == IN_F16_WHITEN || in_mode == IN_F32_WHITEN))
-    rc = conv_fwd_kxo_dispatch_l1(ctx, cin, ks, xtw, in_mode, batch);
-  else if (kxo)
-    rc = conv_fwd_kxo_dispatch_l23(ctx, cin, ks, xtw, in_mode, batch);
-  else if (in_mode == IN_F16_WHITEN || in_mode == IN_F32_WHITEN)
+  if (in_mode == IN_F16_WHITEN || in_mode == IN_F32_WHITEN)
     rc = conv_fwd_dispatch_l1(ctx, cin, ks, xtw, in_mode, epi, batch);
   else
     rc = conv_fwd_dispatch_l23(ctx, cin, ks, xtw, in_mode, epi, batch);

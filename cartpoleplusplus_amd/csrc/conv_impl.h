@@ -408,205 +408,6 @@ __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward kernel, (kx, o)-column formulation (full-width tiles: W <= 16*XTW).
-//   P[x', (kx,o)] = sum_{ky,c} in[y+ky-P, x', c] * W[ky,kx,c,o]          (MFMA: M = x', N = (kx,o), K = (ky,c))
-//   out[y, x, o]  = sum_kx P[x+kx-P, (kx,o)]                              (shift-add along x)
-// With the 10 filters alone in N only 10 of 16 MFMA columns do useful work; putting the horizontal taps
-// next to them uses 50 of 64 (conv1: 368 instead of 460 MFMAs per output row).  x' runs over the image
-// columns only (P = 0 outside: zero padding), so no horizontal halo is computed.  The shift-add goes
-// through a small wave-private LDS buffer (one M tile + its two neighbours' edge columns at a time);
-// bias, ReLU and the 2x2 max-pool then happen in registers as in conv_fwd_kernel.
-// ---------------------------------------------------------------------------------------------
-#ifndef KXO_PREFETCH
-#define KXO_PREFETCH 1
-#endif
-constexpr int KXO_PBW = 52;      // floats per buffer row: 50 columns + pad (16-lane groups 4 rows apart miss each other's banks)
-
-template <int CIN, int KS, int XTW, int IN_MODE>
-__global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd_kxo_kernel(const ConvArgsN batch) {
-  const ConvArgs& a = batch.a[blockIdx.y];
-  constexpr int P = KS / 2, TR = conv_th(CIN, XTW) + KS - 1, TCOLS = 16 * XTW, TC = TCOLS + KS - 1;
-  constexpr int KK = (KS * CIN + 3) / 4;                  // k-steps over k = ky*CIN + c
-  constexpr int NTC = (KS * 10 + 15) / 16;                // column tiles over col = kx*nout + o
-  constexpr int TILE = TR * TC * CIN;
-  constexpr int PBROWS = 16 + 2 * P;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, lj = lane >> 4;
-
-  if (tid < CONV_LDS_PAD) lds[TILE + tid] = 0.f;
-  float2* wl = reinterpret_cast<float2*>(lds + TILE + CONV_LDS_PAD);
-  float* pbuf = lds + TILE + CONV_LDS_PAD + 2 * CIN + wave * (PBROWS * KXO_PBW);
-  constexpr int ncol = KS * 10;      // columns col = kx*10 + o (o < nout <= 10)
-
-  // B fragments: wf[nt][kk] = W[ky][kx][c][o] with k = 4kk + lj = ky*CIN + c, col = 16nt + li = kx*10 + o
-  float wf[NTC][KK];
-#pragma unroll
-  for (int nt = 0; nt < NTC; ++nt) {
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-      const int k = 4 * kk + lj, col = 16 * nt + li;
-      float v = 0.f;
-      if (k < KS * CIN && col < ncol && col % 10 < a.nout) {
-        const int ky = k / CIN, c = k % CIN, kx = col / 10, o = col % 10;
-        v = a.w[((ky * KS + kx) * CIN + c) * a.nout + o];
-      }
-      wf[nt][kk] = v;
-    }
-  }
-  const float bias = li < a.nout ? a.bias[li] : 0.f;
-
-  const int Hp = a.H >> 1, Wp = a.W >> 1;
-  int t_start, t_step, t_end;
-  conv_tile_range(a.ntiles, t_start, t_step, t_end);
-
-  typedef typename StageType<IN_MODE>::type ST;
-  constexpr bool WHITEN = (IN_MODE == IN_F16_WHITEN || IN_MODE == IN_F32_WHITEN);
-  constexpr bool PREFETCH = (RowStager<CIN, KS, XTW, ST, WHITEN>::NV <= 8) && (KXO_PREFETCH != 0);
-  RowStager<CIN, KS, XTW, ST, WHITEN> stg;
-  if (WHITEN && tid < CIN) wl[tid] = make_float2(a.scale[tid], a.shift[tid]);
-  const bool vec = a.vec_ok;
-  if (WHITEN) __syncthreads();
-  if (PREFETCH && vec && t_start < t_end) stg.load(a, t_start / a.tiles_y, (t_start % a.tiles_y) * conv_th(CIN, XTW), 0, tid);
-
-  for (int tile = t_start; tile < t_end; tile += t_step) {
-    const int b = tile / a.tiles_y;
-    const int y0 = (tile - b * a.tiles_y) * conv_th(CIN, XTW);        // tiles_x == 1: x0 = 0
-
-    if (vec) {
-      if (!PREFETCH) stg.load(a, b, y0, 0, tid);
-      stg.store(lds, wl, a, y0, 0, tid);
-      RowStager<CIN, KS, XTW, ST, WHITEN>::zero_halo(lds, a, y0, 0, tid);
-    } else {
-      conv_stage_tile<CIN, KS, XTW, IN_MODE>(lds, a, b, y0, 0, tid);
-    }
-    __syncthreads();
-    if (PREFETCH && vec && tile + t_step < t_end) {
-      const int nt = tile + t_step;
-      stg.load(a, nt / a.tiles_y, (nt % a.tiles_y) * conv_th(CIN, XTW), 0, tid);
-    }
-
-#pragma unroll 1
-    for (int rp = 0; rp < conv_th(CIN, XTW) / 8; ++rp) {
-    const int wrow = wave + 4 * rp;
-    const int yrow = y0 + 2 * wrow;
-    if (yrow < a.H) {   // wave-uniform
-      // the two output rows of the wave run one after the other (rolled loop: one set of accumulators)
-      float out0[XTW][4];
-#pragma unroll 1
-      for (int r = 0; r < 2; ++r) {
-        f32x4 acc[XTW][NTC];
-#pragma unroll
-        for (int t = 0; t < XTW; ++t)
-#pragma unroll
-          for (int nt = 0; nt < NTC; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // A[x' = 16t + li][k = 4kk + lj] = tile[(2w + r + ky), P + x', c]
-        const float* lp = lds + ((2 * wrow + r) * TC + P + li) * CIN + lj;
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-          const int kb = 4 * kk;
-          const int ky0 = kb / CIN, c0 = kb % CIN;                 // compile time
-          int off = ky0 * TC * CIN + c0;
-          if (c0 + 3 >= CIN) {                                     // this k-step straddles two ky rows
-            const int th = CIN - c0;                               // lanes lj >= th belong to ky0 + 1
-            const bool nxt = lj >= th && kb + lj < KS * CIN;
-            off = nxt ? off + TC * CIN - CIN : off;
-          }
-#pragma unroll
-          for (int t = 0; t < XTW; ++t) {
-            const float av = lp[off + t * 16 * CIN];
-#pragma unroll
-            for (int nt = 0; nt < NTC; ++nt) acc[t][nt] = MFMA16(av, wf[nt][kk], acc[t][nt]);
-          }
-        }
-        // shift-add along x through the wave-private buffer, one M tile at a time.  One base pointer per
-        // access class; everything else folds into the ds instruction's immediate offset.
-        float cur[XTW][4];
-        float* pw = pbuf + 4 * lj * KXO_PBW + li;     // own rows: (4lj + i + P, 16nt + li)
-        float* pe = pbuf + li;                        // edge rows copied from the neighbouring M tiles
-#pragma unroll
-        for (int t = 0; t < XTW; ++t) {
-#pragma unroll
-          for (int nt = 0; nt < NTC; ++nt) {
-            if (16 * nt + li < ncol) {
-#pragma unroll
-              for (int i = 0; i < 4; ++i) pw[(i + P) * KXO_PBW + 16 * nt] = acc[t][nt][i];
-              if (lj == 3) {          // left neighbour's last P columns
-#pragma unroll
-                for (int i = 4 - P; i < 4; ++i)
-                  pe[(i - (4 - P)) * KXO_PBW + 16 * nt] = t > 0 ? acc[t > 0 ? t - 1 : 0][nt][i] : 0.f;
-              }
-              if (lj == 0) {          // right neighbour's first P columns
-#pragma unroll
-                for (int i = 0; i < P; ++i)
-                  pe[(16 + P + i) * KXO_PBW + 16 * nt] = t < XTW - 1 ? acc[t < XTW - 1 ? t + 1 : t][nt][i] : 0.f;
-              }
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float sacc = 0.f;
-            if (li < 10) {
-#pragma unroll
-              for (int kx = 0; kx < KS; ++kx) sacc += pw[(i + kx) * KXO_PBW + kx * 10];
-            }
-            cur[t][i] = sacc;
-          }
-        }
-        if (r == 0) {
-#pragma unroll
-          for (int t = 0; t < XTW; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) out0[t][i] = cur[t][i];
-        } else {
-          const int py = yrow >> 1;
-          if (py < Hp && li < a.nout) {
-#pragma unroll
-            for (int t = 0; t < XTW; ++t) {
-#pragma unroll
-              for (int h = 0; h < 2; ++h) {
-                const int px = ((t * 16 + 4 * lj) >> 1) + h;
-                const float z00 = out0[t][2 * h] + bias, z01 = out0[t][2 * h + 1] + bias;
-                const float z10 = cur[t][2 * h] + bias, z11 = cur[t][2 * h + 1] + bias;
-                float m = z00; int code = 0;
-                if (z01 > m) { m = z01; code = 1; }
-                if (z10 > m) { m = z10; code = 2; }
-                if (z11 > m) { m = z11; code = 3; }
-                if (px < Wp) {
-                  const long e = (long)(py * Wp + px) * a.nout + li;
-                  a.out[(long)b * a.out_bstride + e] = fmaxf(m, 0.f);
-                  a.out_amax[(long)b * Hp * Wp * a.nout + e] = (uint8_t)code;
-                }
-              }
-            }
-          }
-        }
-      }
-    }
-    }   // row pairs
-    __syncthreads();
-  }
-}
-
-template <int CIN, int KS, int XTW, int IN_MODE>
-static inline int conv_fwd_kxo_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
-  const ConvArgs& a = batch.a[0];
-  constexpr int P = KS / 2, TR = conv_th(CIN, XTW) + KS - 1, TC = 16 * XTW + KS - 1;
-  const size_t lds_bytes = (size_t)(TR * TC * CIN + CONV_LDS_PAD + 2 * CIN + 4 * (16 + 2 * P) * KXO_PBW) * sizeof(float);
-  auto kern = conv_fwd_kxo_kernel<CIN, KS, XTW, IN_MODE>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_done = true;
-  }
-  const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
-  const int grid = conv_grid_x(ctx->num_cus * per_cu, batch.n, a.ntiles);
-  hipLaunchKernelGGL(kern, dim3(grid, batch.n), dim3(CONV_THREADS), lds_bytes, ctx->stream, batch);
-  LAUNCH_CHECK();
-  return 0;
-}
-
-// ---------------------------------------------------------------------------------------------
 // dW / db kernel
 // ---------------------------------------------------------------------------------------------
 template <int CIN, int KS>
@@ -897,8 +698,6 @@ static inline int conv_dw_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int* gr
 // per-translation-unit dispatchers (each .hip file instantiates a slice of the template space so the
 // big fully-unrolled kernels compile in parallel)
 int conv_fwd_dispatch_l1(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, int epi, const ConvArgsN& a);
-int conv_fwd_kxo_dispatch_l1(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, const ConvArgsN& a);
-int conv_fwd_kxo_dispatch_l23(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, const ConvArgsN& a);
 int conv_fwd_dispatch_l23(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, int epi, const ConvArgsN& a);
 int conv_dw_dispatch_l1(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, const ConvArgsN& a, int* grid);
 int conv_dw_dispatch_l23(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, const ConvArgsN& a, int* grid);

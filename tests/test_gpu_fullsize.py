@@ -125,3 +125,16 @@ def test_wide_image_geometry_parity(shape, Bs):
             lambda: ref.critic_gradients(t)["grads"], agent.critic.get_grads(), what="critic grads")
     finally:
         agent.close()
+
+
+def test_earlier_conv_kernels_stay_parity_green_when_selected():
+    """CPP_CONV_KYO=0 routes every conv layer through the (ky,(kx,c)) x o kernels (normally only the fallback for
+    shapes whose rows cannot be staged as 16-byte chunks): the cfg3 / cfg2-shape parity cases must pass on them too."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CPP_CONV_KYO="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "64x64 and (forward or gradients or fused)"], cwd=root, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    tail = r.stdout.decode()[-1500:]
+    assert r.returncode == 0 and " passed" in tail, tail
