@@ -29,7 +29,9 @@ WORKLOADS = {
     # name: (state_shape (H, W, 3, cameras, repeats), batch)
     "cfg3": ((64, 64, 3, 2, 3), 256),    # 64x64x18, B=256 -- the configuration the metric is quoted on
     "cfg2": ((64, 64, 3, 1, 3), 256),    # 64x64x9
+    "cfg5": ((128, 128, 3, 2, 5), 512),  # 128x128x30, B=512 (BASELINE configs[4]; replay rows reduced, see REPLAY_ROWS_BY)
 }
+REPLAY_ROWS_BY = {"cfg5": 6000}          # 9000 state slots x 983 KB = 8.8 GB (the 1e6-row memory of configs[4] is 1.47 TB / 8 GPUs)
 BATCHES_PER_STEP = 5                     # --batches-per-step default (ddpg_cartpole.py:30)
 REPLAY_ROWS = 22000                      # --replay-memory-size default (ddpg_cartpole.py:46)
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: dense f32-input MFMA peak
@@ -96,6 +98,7 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                      % (args.gpus, args.gpus))
     shape, B = WORKLOADS[args.workload]
+    replay_rows = REPLAY_ROWS_BY.get(args.workload, REPLAY_ROWS)
 
     import torch
     torch.cuda.set_device(local_rank)
@@ -120,11 +123,11 @@ def main():
 
     D.set_opts(D.default_opts(use_raw_pixels=True, render_height=shape[0], render_width=shape[1],
                               num_cameras=shape[3], action_repeats=shape[4], batch_size=B,
-                              replay_memory_size=REPLAY_ROWS, sample_seed=1234 + rank))
+                              replay_memory_size=replay_rows, sample_seed=1234 + rank))
     agent = D.DeepDeterministicPolicyGradientAgent(Env())
     agent.initialise_variables(seed=42)                 # identical replicas on every rank
     agent.post_var_init_setup()
-    agent.replay_memory.fill_synthetic(REPLAY_ROWS, seed=1234 + rank)   # own replay shard per learner
+    agent.replay_memory.fill_synthetic(replay_rows, seed=1234 + rank)   # own replay shard per learner
 
     groups, tail = divmod(args.steps, BATCHES_PER_STEP)
     wgroups = max(1, -(-args.warmup // BATCHES_PER_STEP))
@@ -205,13 +208,13 @@ def main():
         pass
 
     out = {
-        "metric": "DDPG training steps/sec, 64x64x18 pixel obs, batch=256",
+        "metric": "DDPG training steps/sec, %dx%dx%d pixel obs, batch=%d" % (shape[0], shape[1], int(np.prod(shape[2:])), B),
         "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": wgroups * BATCHES_PER_STEP,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: DDPG pixel obs %dx%dx%d, batch=%d per GPU, replay %d rows/GPU in HBM (f16), "
                                "target soft-update every %d minibatches" % (
-                                   args.workload, shape[0], shape[1], int(np.prod(shape[2:])), B, REPLAY_ROWS,
+                                   args.workload, shape[0], shape[1], int(np.prod(shape[2:])), B, replay_rows,
                                    BATCHES_PER_STEP),
                    "parallelism": "dp%d (one learner per GPU, flat-gradient all-reduce per minibatch)" % world,
                    "global_steps_per_sec": round(steps / elapsed, 3),
