@@ -1258,7 +1258,8 @@ extern "C" int cpp_ddpg_train_step(cpp_ddpg* d, cpp_replay* r, int B, int n_batc
     HIP_CHECK(hipMemcpyAsync(r->rows_in, idxs, (size_t)n_batches * B * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     return step_body(d, r, B, n_batches, r->rows_in, seed);
   }
-  if (ctx->prof) return step_body(d, r, B, n_batches, nullptr, seed);
+  static const bool no_graph = getenv("CPP_NO_GRAPH") != nullptr;   // plain in-order stream launches (A/B measurements)
+  if (ctx->prof || no_graph) return step_body(d, r, B, n_batches, nullptr, seed);
   if (!d->graph_ok || d->g_B != B || d->g_nb != n_batches || d->g_seed != seed || d->g_replay != r) {
     if (d->gexec) { (void)hipGraphExecDestroy(d->gexec); d->gexec = nullptr; }
     if (d->graph) { (void)hipGraphDestroy(d->graph); d->graph = nullptr; }
