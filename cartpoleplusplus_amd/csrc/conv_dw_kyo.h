@@ -290,7 +290,11 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_dw_kyo_kernel(const Conv
   // ---- one partial per workgroup: D tile mt holds rows m = MT*i + mt (i = 4 lj + r), column n
   float* part = a.partial + (long)blockIdx.x * a.pstride;
   const int nw = KS * G::KROW * nout;
+#ifdef DWKYO_ABL_NOWRITE
+  if (nvalid && no < nout && acc[0][0] == 123.456f) {
+#else
   if (nvalid && no < nout) {
+#endif
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll

@@ -1,4 +1,7 @@
-// Implicit-GEMM convolution kernels on v_mfma_f32_16x16x4_f32 for the cartpole++ conv trunk
+// Implicit-GEMM convolution kernels, (ky,(kx,c)) x o formulation -- the kernels of the first implementation, now the
+// path for dW of the 3x3 layer and the fallback for shapes the (ky,o)-column kernels (conv_kyo.h, conv_dw_kyo.h) do
+// not take (rows that cannot be staged as aligned 16-byte chunks, dX rows narrower than the strip grid).
+// v_mfma_f32_16x16x4_f32 for the cartpole++ conv trunk
 // (base_network.py:103-127: three slim.conv2d with 10 filters, stride 1, SAME, ReLU, each followed by
 // a 2x2/2 VALID max-pool) and its backward.  Exact f32 (the MFMA is a k-ordered fmaf chain).
 //
