@@ -66,6 +66,7 @@ SIGNATURES = {
     "cpp_net_get_grads": (_I, [_P, _P, _L]),
     "cpp_net_soft_update": (_I, [_P, _P, _F]),
     "cpp_net_forward": (_I, [_P, _P, _I, _I, _P, _P]),
+    "cpp_net_forward_each": (_I, [_P, _P, _I, _I, _P, _P]),
     "cpp_net_get_pool": (_I, [_P, _I, _I, _P]),
     "cpp_batch_create": (_I, [_P, _I, _L, _I, _PP]),
     "cpp_batch_destroy": (_I, [_P]),

@@ -56,6 +56,7 @@ struct ConvArgs {
   const void* in;            // f16/f32 images, or f32 activations (IN_F32_PLAIN)
   long in_bstride;
   const float* scale; const float* shift;   // whitening (IN_*_WHITEN)
+  long white_bstride;        // floats between the (scale, shift) tables of consecutive images; 0: one table for the batch
   DyDesc dy;                 // IN_DY (forward kernel in "dX" mode) / dW kernel B operand
   const float* w;            // HWIO weights of the layer
   const float* bias;

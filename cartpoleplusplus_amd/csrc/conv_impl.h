@@ -115,10 +115,10 @@ __device__ __forceinline__ void conv_stage_tile(float* lds, const ConvArgs& a, i
     if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
       if (IN_MODE == IN_F16_WHITEN) {
         const __half* src = (const __half*)a.in + (long)b * a.in_bstride;
-        v = __half2float(src[((long)gy * a.W + gx) * CIN + c]) * a.scale[c] + a.shift[c];
+        v = __half2float(src[((long)gy * a.W + gx) * CIN + c]) * a.scale[(long)b * a.white_bstride + c] + a.shift[(long)b * a.white_bstride + c];
       } else if (IN_MODE == IN_F32_WHITEN) {
         const float* src = (const float*)a.in + (long)b * a.in_bstride;
-        v = src[((long)gy * a.W + gx) * CIN + c] * a.scale[c] + a.shift[c];
+        v = src[((long)gy * a.W + gx) * CIN + c] * a.scale[(long)b * a.white_bstride + c] + a.shift[(long)b * a.white_bstride + c];
       } else {
         const float* src = (const float*)a.in + (long)b * a.in_bstride;
         v = src[((long)gy * a.W + gx) * CIN + c];
@@ -314,6 +314,11 @@ __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd
     if (tile == t_start)
 #endif
     {
+    if (WHITEN && a.white_bstride != 0) {             // per-image statistics: this tile's image has its own table
+      __syncthreads();
+      if (tid < CIN) wl[tid] = make_float2(a.scale[(long)b * a.white_bstride + tid], a.shift[(long)b * a.white_bstride + tid]);
+      __syncthreads();
+    }
     if (vec) {
       if (!PREFETCH) stg.load(a, b, y0, x0, tid);
       stg.store(lds, wl, a, y0, x0, tid);
@@ -532,6 +537,11 @@ __attribute__((amdgpu_waves_per_eu(conv_wps(CIN, KS, XTW), conv_wps(CIN, KS, XTW
     const int y0 = ty * conv_th(CIN, XTW), x0 = tx * TCOLS;
 
     if (dyfast) dst.load(a, b, y0, x0, tid);      // issued first: their latency hides under the tile stores
+    if (WHITEN && a.white_bstride != 0) {             // per-image statistics: this tile's image has its own table
+      __syncthreads();
+      if (tid < CIN) wl[tid] = make_float2(a.scale[(long)b * a.white_bstride + tid], a.shift[(long)b * a.white_bstride + tid]);
+      __syncthreads();
+    }
     if (vec) {
       if (!PREFETCH) stg.load(a, b, y0, x0, tid);
       stg.store(lds, wl, a, y0, x0, tid);

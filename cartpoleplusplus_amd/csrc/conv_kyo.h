@@ -62,7 +62,7 @@ struct KyoGeom {
                                                             // barrier), q+2 is being written
   static constexpr int EF = 2 * 8 * XT * KYO_NO * 2;        // per wave: (value, code) of the two rows of a pool pair
   static constexpr int WHF = 2 * ((CIN + 8 + 3) & ~3);      // whitening scale[] and shift[], each extended by 8 (wrap-around)
-  static constexpr int LDS_FLOATS = WLF + RING * IPW * ROWF + 4 * EF + WHF;
+  static constexpr int LDS_FLOATS = WLF + RING * IPW * ROWF + 4 * EF + IPW * WHF;     // one whitening table per image
   static __host__ __device__ constexpr int steps(int g) { return KSTEPS - 4 * g < 4 ? KSTEPS - 4 * g : 4; }
   static __host__ __device__ constexpr int kmap(int st, int lj) {
     return st < Q4 ? Q4 * lj + st : 4 * Q4 + 4 * (st - Q4) + lj;
@@ -89,8 +89,7 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
   float* wl = lds;                                   // [KS][NGT][4][NO][4]
   float* rows = lds + G::WLF;                        // [RING][IPW][ROWF]
   float2* ebuf = reinterpret_cast<float2*>(rows + RING * RSET);   // [4 waves][2 parities][8*XT][NO] (value, code)
-  float* whs = rows + RING * RSET + 4 * G::EF;       // whitening scale[c mod CIN], c < CIN + 8; then shift[] likewise
-  float* wht = whs + G::WHF / 2;
+  float* whs = rows + RING * RSET + 4 * G::EF;       // per image: whitening scale[c mod CIN], c < CIN + 8; then shift[] likewise
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lj = lane >> 4;
   const int img = wave / G::STRIPS, strip = wave % G::STRIPS;
@@ -129,8 +128,12 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
   bool sact[NVMAX];
   uint32_t sdst[NVMAX];                              // LDS address of the chunk in ring slot 0
   uint32_t swh[NVMAX];                               // LDS address of the whitening scale of the chunk's first channel
-  if (WHITEN) {
-    for (int c = tid; c < CIN + 8; c += CONV_THREADS) { whs[c] = a.scale[c % CIN]; wht[c] = a.shift[c % CIN]; }
+  if (WHITEN) {                                      // (white_bstride != 0: every image is whitened with its own statistics)
+    for (int e = tid; e < IPW * (CIN + 8); e += CONV_THREADS) {
+      const int im = e / (CIN + 8), c = e - im * (CIN + 8);
+      const long wo = (b0 + im < a.B ? (long)(b0 + im) : 0) * a.white_bstride + c % CIN;
+      whs[im * G::WHF + c] = a.scale[wo]; whs[im * G::WHF + G::WHF / 2 + c] = a.shift[wo];
+    }
   }
 #pragma unroll
   for (int i = 0; i < NVMAX; ++i) {
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
     sact[i] = im < IPW && b0 + im < a.B;
     sbyte[i] = (unsigned)((long)im * a.in_bstride + j * EPC) * (unsigned)sizeof(ST);
     sdst[i] = keep_in_vgpr(lds_addr(rows + im * ROWF + G::FP + P * CIN + j * EPC));
-    swh[i] = keep_in_vgpr(lds_addr(whs + (j * EPC) % CIN));
+    swh[i] = keep_in_vgpr(lds_addr(whs + (im < IPW ? im : 0) * G::WHF + (j * EPC) % CIN));
   }
   // buffer addressing: uniform descriptor (images b0 .. b0+IPW-1) + per-lane byte offset (constant) + scalar row
   // offset -- no vector address arithmetic per row

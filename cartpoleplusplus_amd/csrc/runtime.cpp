@@ -169,6 +169,7 @@ struct cpp_net {
   float* params; float* grads; float* own_grads;
   Workspace ws[2];
   float* white;            // [2][C] statistics for cpp_net_forward
+  float* white_rows;       // [maxB][2][C]: per-image statistics for cpp_net_forward_each
   double* stats_part;      // [maxB][2C]
   float* dw_partial[3];     // one per conv layer: their reductions are deferred and batched
   void* stage_state; float* stage_action; float* stage_out;
@@ -272,7 +273,7 @@ extern "C" int cpp_net_create(cpp_ctx* ctx, const cpp_net_spec* spec, int max_ba
   cpp_net* n = new cpp_net();
   n->ctx = ctx; n->spec = *spec; n->maxB = max_batch; n->arena.stream = ctx->stream;
   n->grads = nullptr; n->own_grads = nullptr; n->stage_state = nullptr; n->stage_action = nullptr;
-  n->stage_out = nullptr; n->dw_partial[0] = n->dw_partial[1] = n->dw_partial[2] = nullptr; n->white = nullptr; n->stats_part = nullptr;
+  n->stage_out = nullptr; n->dw_partial[0] = n->dw_partial[1] = n->dw_partial[2] = nullptr; n->white = nullptr; n->white_rows = nullptr; n->stats_part = nullptr;
   int rc = net_build(n);
   if (rc) { delete n; return rc; }
   auto fail = [&](int r) { n->arena.release(); delete n; return r; };
@@ -288,6 +289,7 @@ extern "C" int cpp_net_create(cpp_ctx* ctx, const cpp_net_spec* spec, int max_ba
     for (int i = 0; i < 3; ++i)
       if ((rc = dalloc(n->arena, &n->dw_partial[i], conv_dw_partial_floats(ctx, n->conv[i].Cin, n->conv[i].ks, kConvOut)))) return fail(rc);
     if ((rc = dalloc(n->arena, &n->white, (size_t)2 * spec->C))) return fail(rc);
+    if ((rc = dalloc(n->arena, &n->white_rows, (size_t)max_batch * 2 * spec->C))) return fail(rc);
     if ((rc = dalloc(n->arena, &n->stats_part, (size_t)2 * max_batch * 2 * spec->C))) return fail(rc);
   }
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -361,10 +363,11 @@ static const int kDwKid[3] = {K_CONV1_DW, K_CONV2_DW, K_CONV3_DW};
 static const int kDxKid[3] = {-1, K_CONV2_DX, K_CONV3_DX};
 
 // launch descriptors of conv layer i of a network (forward, dW, dX)
-static ConvArgs conv_fwd_args(cpp_net* n, Workspace& w, int i, const void* state, int dtype, const float* white, int B, int* mode) {
+static ConvArgs conv_fwd_args(cpp_net* n, Workspace& w, int i, const void* state, int dtype, const float* white, int B, int* mode,
+                              long white_bstride = 0) {
   const ConvL& L = n->conv[i];
   ConvArgs a; memset(&a, 0, sizeof(a));
-  if (i == 0) { a.in = state; a.in_bstride = n->state_elems; a.scale = white; a.shift = white + n->spec.C;
+  if (i == 0) { a.in = state; a.in_bstride = n->state_elems; a.scale = white; a.shift = white + n->spec.C; a.white_bstride = white_bstride;
                 *mode = dtype == CPP_F16 ? IN_F16_WHITEN : IN_F32_WHITEN; }
   else { a.in = w.pool[i - 1]; a.in_bstride = (long)L.H * L.W * L.Cin; *mode = IN_F32_PLAIN; }
   a.w = n->params + L.w_off; a.bias = n->params + L.b_off;
@@ -401,13 +404,14 @@ static ConvArgs conv_dx_args(cpp_net* n, Workspace& w, int i, int B) {
 }
 
 // conv trunk (pixel) or state conversion (low-dim) into ws.fcin[0]
-static int net_forward_trunk(cpp_net* n, Workspace& w, const void* state, int dtype, const float* white, int B) {
+static int net_forward_trunk(cpp_net* n, Workspace& w, const void* state, int dtype, const float* white, int B,
+                             long white_bstride = 0) {
   cpp_ctx* ctx = n->ctx;
   if (!n->spec.pixel)
     return launch_state_to_f32(ctx, w.fcin[0], n->fc[0].n_in + 1, state, dtype, n->state_elems, B);
   for (int i = 0; i < 3; ++i) {
     int mode;
-    ConvArgs a = conv_fwd_args(n, w, i, state, dtype, white, B, &mode);
+    ConvArgs a = conv_fwd_args(n, w, i, state, dtype, white, B, &mode, white_bstride);
     RC(launch_conv_fwd(ctx, kFwdKid[i], n->conv[i].Cin, n->conv[i].ks, mode, EPI_RELU_POOL, a));
   }
   return CPP_OK;
@@ -600,6 +604,47 @@ extern "C" int cpp_net_forward(cpp_net* n, const void* state, int state_dtype, i
   if (n->spec.pixel)
     RC(batch_stats(ctx, n->stage_state, nullptr, state_dtype, n->state_elems, B, n->spec.C, n->stats_part, n->white));
   RC(net_forward_trunk(n, n->ws[0], n->stage_state, state_dtype, n->white, B));
+  RC(net_forward_fc(n, n->ws[0], 0, B, action ? n->stage_action : nullptr));
+  HIP_CHECK(hipMemcpyAsync(out, n->ws[0].out, (size_t)B * no * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return CPP_OK;
+}
+
+// B independent action_given calls in one pass (rollout-side inference for many env workers): every
+// image is whitened with ITS OWN statistics, exactly as B separate batches of one would be (base_network.py:95-99
+// at B = 1); everything after the whitening is row-local anyway.
+extern "C" int cpp_net_forward_each(cpp_net* n, const void* state, int state_dtype, int B, const float* action, float* out) {
+  ARG_CHECK(n && state && out, "cpp_net_forward_each: NULL argument");
+  ARG_CHECK(B >= 1 && B <= n->maxB, "cpp_net_forward_each: batch %d outside [1,%d]", B, n->maxB);
+  ARG_CHECK(state_dtype == CPP_F32 || state_dtype == CPP_F16, "cpp_net_forward_each: dtype %d", state_dtype);
+  ARG_CHECK(n->spec.kind != CPP_CRITIC || action, "cpp_net_forward_each: critic needs an action batch");
+  cpp_ctx* ctx = n->ctx;
+  HIP_CHECK(hipSetDevice(ctx->device));
+  const int A = n->spec.action_dim, no = n->fc.back().n_out, C = n->spec.C;
+  if (!n->stage_state) {
+    RC(n->arena.alloc(&n->stage_state, (size_t)n->maxB * n->state_elems * sizeof(float), false));
+    RC(dalloc(n->arena, &n->stage_action, (size_t)n->maxB * A));
+  }
+  const size_t esz = state_dtype == CPP_F16 ? 2 : 4;
+  HIP_CHECK(hipMemcpyAsync(n->stage_state, state, (size_t)B * n->state_elems * esz, hipMemcpyHostToDevice, ctx->stream));
+  if (action) HIP_CHECK(hipMemcpyAsync(n->stage_action, action, (size_t)B * A * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  long wbs = 0;
+  if (n->spec.pixel) {
+    int g = 8, c = C; while (c) { int t = g % c; g = c; c = t; }
+    const long npix = n->state_elems / C;
+    if (n->state_elems % 8 == 0 && C / g <= 16) {       // per-row partial sums, finalised row by row
+      GatherArgs ga; memset(&ga, 0, sizeof(ga));
+      ga.store[0] = n->stage_state; ga.store[1] = n->stage_state; ga.part = n->stats_part; ga.elems = n->state_elems; ga.B = B; ga.C = C;
+      RC(launch_gather_stats(ctx, ga, state_dtype));
+      RC(launch_stats_finalize(ctx, n->stats_part, 1, B, C, (double)npix, n->white_rows));
+    } else {
+      for (int b = 0; b < B; ++b)
+        RC(launch_stats_generic(ctx, (const char*)n->stage_state + (size_t)b * n->state_elems * esz, state_dtype, npix, C,
+                                n->white_rows + (long)b * 2 * C));
+    }
+    wbs = 2 * C;
+  }
+  RC(net_forward_trunk(n, n->ws[0], n->stage_state, state_dtype, n->white_rows, B, wbs));
   RC(net_forward_fc(n, n->ws[0], 0, B, action ? n->stage_action : nullptr));
   HIP_CHECK(hipMemcpyAsync(out, n->ws[0].out, (size_t)B * no * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIP_CHECK(hipStreamSynchronize(ctx->stream));

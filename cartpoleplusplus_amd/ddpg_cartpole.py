@@ -138,6 +138,23 @@ class ActorNetwork(base_network.Network):
         check(lib.cpp_net_forward(self.handle, ptr(s), dt, B, None, ptr(out)))
         return out
 
+    def actions_given(self, states, add_noise=False):
+        """`action_given` for many env workers at once: states (B, ...) -> actions (B, action_dim),
+        row i identical to action_given(states[i]) -- every image is whitened with its own statistics.  With
+        add_noise each row gets its own Ornstein-Uhlenbeck process (one per worker, created on first use)."""
+        s, dt = _lib.as_state_array(states)
+        B = s.shape[0]
+        actions = np.empty((B, self.action_dim), np.float32)
+        check(lib.cpp_net_forward_each(self.handle, ptr(s), dt, B, None, ptr(actions)))
+        if add_noise:
+            procs = self.__dict__.setdefault("_worker_noise", [])
+            while len(procs) < B:
+                procs.append(util.OrnsteinUhlenbeckNoise(self.action_dim, opts.action_noise_theta, opts.action_noise_sigma))
+            for i in range(B):
+                actions[i] += procs[i].sample()
+            actions = np.minimum(1, actions)     # the reference's clip quirk, per row (:134)
+        return actions
+
     def action_given(self, state, add_noise=False):
         # feed explicitly provided state (batch of one; whitening uses this image's own statistics)
         actions = self.forward(np.asarray(state)[None])

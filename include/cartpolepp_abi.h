@@ -99,6 +99,11 @@ int cpp_net_soft_update(cpp_net* target, const cpp_net* source, float coeff);
  * Whitening always uses the statistics of THIS batch (base_network.py:95-99), also at B = 1. */
 int cpp_net_forward(cpp_net* net, const void* state, int state_dtype, int B, const float* action,
                     float* out);
+/* B independent `action_given` calls (ddpg_cartpole.py:121-126 once per row) in one pass: every image is whitened with
+ * its OWN statistics (base_network.py:95-99 at batch size 1), so row i of `out` equals cpp_net_forward on row i alone.
+ * Rollout-side inference for many env workers. */
+int cpp_net_forward_each(cpp_net* net, const void* state, int state_dtype, int B, const float* action,
+                         float* out);
 /* Network.pool1/2/3 (base_network.py:108,116,124) of the last forward: which = 1..3, (B,h,w,10).
  * Debug: which = 11..13 returns the arg-max codes (0..3, as floats) of the same layers' 2x2 windows. */
 int cpp_net_get_pool(cpp_net* net, int which, int B, float* out);

@@ -242,3 +242,23 @@ def test_end_to_end_cli_with_checkpoints_and_event_log(tmp_path, capsys):
     out = capsys.readouterr().out
     last = json.loads([l for l in out.splitlines() if l.startswith("STATS")][-1].split("\t", 1)[1])
     assert last["episode_len"] == 0 and last["replay_memory_stats"][">add_episode"] == 4 and np.isfinite(last["mean_losses"])
+
+
+@pytest.mark.parametrize("shape,B", [PIXEL_CASES[0], PIXEL_CASES[2], PIXEL_CASES[3], LOWDIM_CASE])
+def test_actions_given_equals_one_action_given_per_row(shape, B):
+    """cpp_net_forward_each: a batch of independent states, each whitened with its own statistics, gives bit for bit
+    the actions of B separate batch-of-one forwards (ddpg_cartpole.py:121-126), and matches the oracle per row."""
+    pixel = len(shape) == 5
+    agent, ref, _ = make_pair(shape, B, pixel)
+    rng = np.random.default_rng(11)
+    t = O.synthetic_batch(rng, B, shape, 2, pixel)
+    try:
+        got = agent.actor.actions_given(t[0])
+        one = np.concatenate([agent.actor.action_given(t[0][i]) for i in range(B)], axis=0)
+        assert got.shape == (B, 2) and np.array_equal(got, one)
+        want = np.concatenate([ref.actor.forward(t[0][i:i + 1])["out"] for i in range(B)], axis=0)
+        assert np.abs(got - want).max() < 1e-5
+        if pixel:       # and it is NOT the batch-statistics forward
+            assert np.abs(got - agent.actor.forward(t[0])).max() > 0
+    finally:
+        agent.close()
