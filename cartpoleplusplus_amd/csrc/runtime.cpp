@@ -531,6 +531,15 @@ struct OpGraph {
         if (ok) ready.push_back((int)i);
       }
       if (ready.empty()) { cpp_set_error("OpGraph: dependency cycle"); return CPP_ERR_STATE; }
+      static const bool dbg = getenv("CPP_OPGRAPH_DEBUG") != nullptr;
+      if (dbg) {
+        fprintf(stderr, "[opgraph] level:");
+        for (int i : ready) {
+          if (ops[i].is_gemm) fprintf(stderr, " gemm#%d(M%d N%d K%d e%d)", i, ops[i].g.M, ops[i].g.N, ops[i].g.K, ops[i].g.epi);
+          else fprintf(stderr, " fn#%d", i);
+        }
+        fprintf(stderr, "\n");
+      }
       for (int i : ready) if (!ops[i].is_gemm) RC(ops[i].fn());
       for (int i : ready) if (ops[i].is_gemm) batch.push_back(ops[i].g);
       if (!batch.empty()) RC(launch_gemm_batch(ctx, batch.data(), (int)batch.size()));
