@@ -49,9 +49,12 @@ class NetSpec(object):
     """kind: 'actor' | 'critic'.  pixel nets take (H, W, C) with C = 3*cameras*repeats
     (base_network.py:85-90); low-dim nets take `state_elems` flattened inputs."""
 
-    def __init__(self, kind, action_dim, hidden, pixel, H=0, W=0, C=0, state_elems=0):
+    def __init__(self, kind, action_dim, hidden, pixel, H=0, W=0, C=0, state_elems=0, batch_norm=False):
         assert kind in ("actor", "critic")
         self.kind, self.action_dim, self.pixel = kind, int(action_dim), bool(pixel)
+        # --use-batch-norm (base_network.py:74-79): slim.batch_norm between every conv and its ReLU.  The conv then has
+        # no bias; the slot "<conv>/biases" of the flat layout holds BatchNorm/beta instead (same size, same place).
+        self.batch_norm = bool(batch_norm) and self.pixel
         self.hidden = [int(h) for h in hidden]
         self.H, self.W, self.C = int(H), int(W), int(C)
         if self.pixel:
@@ -155,6 +158,22 @@ def whiten_stats(x, dt):
     var = (flat * flat).mean(axis=0) - mean * mean
     inv = 1.0 / np.sqrt(var + WHITEN_EPS)
     return inv.astype(dt), (-mean * inv).astype(dt)     # y = x*scale + shift  (base_network.py:97-99)
+
+
+BN_EPS = 1e-3          # slim.batch_norm default epsilon (decay 0.999, center=True, scale=False)
+
+
+def bn_stats(z, dt, training):
+    """slim.batch_norm statistics over (batch, y, x): batch moments (one-pass form, float64 sums as in whiten_stats)
+    when training; otherwise the moving averages -- which the reference never updates (its train ops do not depend on
+    UPDATE_OPS), so they are the initial mean 0 / variance 1.  Returns (mean, 1/sqrt(var + eps))."""
+    C = z.shape[3]
+    if not training:
+        return np.zeros(C, dt), (np.ones(C) / np.sqrt(1.0 + BN_EPS)).astype(dt)
+    z64 = np.asarray(z, dtype=np.float64).reshape(-1, C)
+    mean = z64.mean(axis=0)
+    var = (z64 * z64).mean(axis=0) - mean * mean
+    return mean.astype(dt), (1.0 / np.sqrt(var + BN_EPS)).astype(dt)
 
 
 def whiten(x, dt):
@@ -265,10 +284,10 @@ class Net(object):
     def flat(self):
         return flatten(self.spec, self.p, self.dt)
 
-    def forward(self, state, action=None, white=None):
+    def forward(self, state, action=None, white=None, training=True):
         """state: (B, ...) any float dtype (f16 from replay upcasts exactly).  `white`:
-        optional precomputed (scale, shift).  Returns a cache dict; cache['out'] is
-        (B, A) actions (actor) or (B, 1) q-values (critic)."""
+        optional precomputed (scale, shift).  `training` is base_network.IS_TRAINING (only batch norm looks at it).
+        Returns a cache dict; cache['out'] is (B, A) actions (actor) or (B, 1) q-values (critic)."""
         sp, dt = self.spec, self.dt
         B = state.shape[0]
         c = {"B": B}
@@ -279,7 +298,14 @@ class Net(object):
             x = (x.astype(dt) * white[0] + white[1]).astype(dt)
             c["white"] = white
             for (name, _k, _co), (h, w) in zip(CONV_DEFS, sp.conv_hw):
-                z = conv_fwd(x, self.p[name + "/weights"], self.p[name + "/biases"])
+                if sp.batch_norm:      # conv (no bias) -> (z - mean) * inv + beta -> relu -> pool
+                    z = conv_fwd(x, self.p[name + "/weights"], np.zeros(self.p[name + "/biases"].shape, dt))
+                    mean, inv = bn_stats(z, dt, training)
+                    zhat = ((z - mean) * inv).astype(dt)
+                    c[name + ":bn"] = (zhat, inv, bool(training))
+                    z = (zhat + self.p[name + "/biases"]).astype(dt)
+                else:
+                    z = conv_fwd(x, self.p[name + "/weights"], self.p[name + "/biases"])
                 pooled, amax = relu_pool_fwd(z)
                 c[name + ":margin"] = pool_window_margin(z)
                 if self.amax_override is not None and name in self.amax_override:
@@ -325,7 +351,19 @@ class Net(object):
                 name = CONV_DEFS[idx][0]
                 x, pooled, amax, h, w = c[name]
                 dz = relu_pool_bwd(dp, pooled, amax, h, w)
-                dW, db, dp = conv_bwd(x, self.p[name + "/weights"], dz, need_dx=idx > 0)
+                if sp.batch_norm:
+                    zhat, inv, training = c[name + ":bn"]
+                    dbeta = dz.sum(axis=(0, 1, 2))
+                    if training:       # through the batch moments
+                        m1 = dz.mean(axis=(0, 1, 2), dtype=np.float64).astype(dt)
+                        m2 = (dz * zhat).mean(axis=(0, 1, 2), dtype=np.float64).astype(dt)
+                        dz = (inv * (dz - m1 - zhat * m2)).astype(dt)
+                    else:
+                        dz = (inv * dz).astype(dt)
+                    dW, _db, dp = conv_bwd(x, self.p[name + "/weights"], dz, need_dx=idx > 0)
+                    db = dbeta
+                else:
+                    dW, db, dp = conv_bwd(x, self.p[name + "/weights"], dz, need_dx=idx > 0)
                 g[name + "/weights"], g[name + "/biases"] = dW, db
         ordered = collections.OrderedDict((n, g[n]) for n, _s in sp.layout())
         return ordered, d_action
@@ -376,7 +414,7 @@ class DDPG(object):
 
     # ddpg_cartpole.py:121-125 (noise is added outside, :133-134)
     def action_given(self, state):
-        return self.actor.forward(np.asarray(state)[None])["out"]
+        return self.actor.forward(np.asarray(state)[None], training=False)["out"]       # IS_TRAINING: False (:125)
 
     def _white(self, net, s):
         if not net.spec.pixel:
@@ -395,15 +433,16 @@ class DDPG(object):
         return {"actions": ca["out"], "q": cc["out"], "dq_da": dq_da,
                 "grads": flatten(self.actor.spec, grads, self.dt), "cache_actor": ca}
 
-    def critic_gradients(self, batch):
-        """ddpg_cartpole.py:199-214.  batch = (s1, a, r, mask, s2)."""
+    def critic_gradients(self, batch, training=True):
+        """ddpg_cartpole.py:199-214.  batch = (s1, a, r, mask, s2).  IS_TRAINING is one placeholder for the whole
+        graph: in critic.train (:237) the target networks run in training mode as well."""
         s1, a, r, mask, s2 = batch
         dt = self.dt
         w2 = self._white(self.target_actor, s2)
-        ta = self.target_actor.forward(s2, white=w2)
-        tq = self.target_critic.forward(s2, action=ta["out"], white=w2)
+        ta = self.target_actor.forward(s2, white=w2, training=training)
+        tq = self.target_critic.forward(s2, action=ta["out"], white=w2, training=training)
         y = np.asarray(r, dt) + np.asarray(mask, dt) * dt(self.hp.discount) * tq["out"]
-        cb = self.critic.forward(s1, action=np.asarray(a, dt))
+        cb = self.critic.forward(s1, action=np.asarray(a, dt), training=training)
         td = cb["out"] - y
         B = td.shape[0]
         loss = (td * td).mean(dtype=dt)
@@ -412,8 +451,8 @@ class DDPG(object):
                 "target_actions": ta["out"],
                 "grads": flatten(self.critic.spec, grads, self.dt)}
 
-    def check_loss(self, batch):      # ddpg_cartpole.py:239-248
-        out = self.critic_gradients(batch)
+    def check_loss(self, batch):      # ddpg_cartpole.py:239-248 (IS_TRAINING: False)
+        out = self.critic_gradients(batch, training=False)
         return out["loss"], out["td"], out["q"]
 
     def train_minibatch(self, batch):

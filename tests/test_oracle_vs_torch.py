@@ -10,7 +10,7 @@ from oracle import ddpg_np as O
 torch.set_default_dtype(torch.float64)
 
 
-def torch_forward(spec, p, state, action=None):
+def torch_forward(spec, p, state, action=None, training=True):
     B = state.shape[0]
     if spec.pixel:
         x = state.reshape(B, spec.H, spec.W, spec.C)
@@ -20,7 +20,13 @@ def torch_forward(spec, p, state, action=None):
         x = (x * inv - mean * inv).permute(0, 3, 1, 2)
         for name, k, _co in O.CONV_DEFS:
             w = p[name + "/weights"].permute(3, 2, 0, 1)
-            x = F.relu(F.conv2d(x, w, p[name + "/biases"], padding=k // 2))
+            if spec.batch_norm:     # slim.batch_norm: decay .999, center, no scale, eps 1e-3; moving stats stay (0, 1)
+                z = F.conv2d(x, w, None, padding=k // 2)
+                co = z.shape[1]
+                x = F.relu(F.batch_norm(z, torch.zeros(co), torch.ones(co), weight=None, bias=p[name + "/biases"],
+                                        training=training, momentum=0.0, eps=1e-3))
+            else:
+                x = F.relu(F.conv2d(x, w, p[name + "/biases"], padding=k // 2))
             x = F.max_pool2d(x, 2)
         h = x.permute(0, 2, 3, 1).reshape(B, -1)
     else:
@@ -45,6 +51,8 @@ CASES = [
     dict(B=4, shape=(8, 8, 3, 1, 2), pixel=True),      # 8x8x6
     dict(B=3, shape=(12, 10, 3, 1, 3), pixel=True),    # 12x10x9, odd pooling 10->5->2->1
     dict(B=5, shape=(2, 2, 7), pixel=False),           # cfg1 low-dim pose state
+    dict(B=4, shape=(8, 8, 3, 1, 2), pixel=True, batch_norm=True),     # --use-batch-norm
+    dict(B=3, shape=(16, 12, 3, 1, 3), pixel=True, batch_norm=True),
 ]
 
 
@@ -53,7 +61,7 @@ def test_ddpg_gradients_match_autograd(case):
     rng = np.random.default_rng(7)
     B, shape, pixel = case["B"], case["shape"], case["pixel"]
     if pixel:
-        kw = dict(pixel=True, H=shape[0], W=shape[1], C=int(np.prod(shape[2:])))
+        kw = dict(pixel=True, H=shape[0], W=shape[1], C=int(np.prod(shape[2:])), batch_norm=case.get("batch_norm", False))
     else:
         kw = dict(pixel=False, state_elems=int(np.prod(shape)))
     aspec = O.NetSpec("actor", 2, [100, 100, 50], **kw)
@@ -97,6 +105,17 @@ def test_ddpg_gradients_match_autograd(case):
     np.testing.assert_allclose(cg["loss"], loss.item(), rtol=1e-10)
     np.testing.assert_allclose(cg["td"], (qb - y).detach().numpy(), rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(cg["grads"], tflat(cspec, pc, gc), rtol=1e-8, atol=1e-11)
+
+    # --- inference mode (IS_TRAINING False: action_given / check_loss): moving statistics, never updated
+    with torch.no_grad():
+        a_inf = torch_forward(aspec, pa, ts1[:1], training=False)
+        tq_inf = torch_forward(cspec, ptc, ts2, torch_forward(aspec, pta, ts2, training=False), training=False)
+        y_inf = torch.tensor(r.astype(np.float64)) + torch.tensor(mask.astype(np.float64)) * 0.99 * tq_inf
+        q_inf = torch_forward(cspec, pc, ts1, torch.tensor(a.astype(np.float64)), training=False)
+    np.testing.assert_allclose(agent.action_given(s1[0]), a_inf.numpy(), rtol=1e-10, atol=1e-12)
+    loss_i, td_i, q_i = agent.check_loss(batch)
+    np.testing.assert_allclose(q_i, q_inf.numpy(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(td_i, (q_inf - y_inf).numpy(), rtol=1e-9, atol=1e-12)
 
     # --- clip / sgd / target against torch utilities
     gvec = torch.tensor(cg["grads"]).clone().requires_grad_(False)
