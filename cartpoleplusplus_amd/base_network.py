@@ -95,8 +95,8 @@ class Network(object):
         return Layer([None, self._hidden[-1]], self, "hidden")
 
     def simple_conv_net_on(self, input_layer, opts):
-        if getattr(opts, "use_batch_norm", False):
-            raise NotImplementedError("--use-batch-norm is SURVEY 8(f) row N4 (not built yet)")
+        # --use-batch-norm (base_network.py:74-79): slim.batch_norm after every conv (which then has no bias)
+        self._use_batch_norm = bool(getattr(opts, "use_batch_norm", False))
         # state is (batch, height, width, rgb, camera_idx, repeat); rgb/camera/repeat roll up into
         # channels (base_network.py:85-90)
         shape = input_layer.get_shape()
@@ -124,6 +124,7 @@ class Network(object):
         spec = _lib.NetSpec()
         spec.kind, spec.action_dim = kind, int(action_dim)
         spec.head_out, spec.head_act = int(head_out), int(head_act)
+        spec.use_batch_norm = int(bool(getattr(self, "_use_batch_norm", False)))
         if self._conv_input is not None:
             spec.pixel, (spec.H, spec.W, spec.C) = 1, self._conv_input
         else:
@@ -157,7 +158,7 @@ class Network(object):
         flat = np.zeros(self.num_params, np.float32)
         for v in self.trainable_model_vars():
             n = int(np.prod(v.shape))
-            if v.name.endswith("biases:0"):
+            if v.name.endswith("biases:0") or v.name.endswith("BatchNorm/beta:0"):      # zeros_initializer both
                 continue
             # the tanh action heads use U(-1e-3, 1e-3): 'actor/output_action/weights' (ddpg_cartpole.py:94) and
             # 'naf/output_action/fc/weights' (naf_cartpole.py:155) -- not the state networks beneath them

@@ -41,7 +41,7 @@ struct cpp_ctx {
 // ---------------------------------------------------------------------------------------------
 // conv kernels (conv.hip)
 // ---------------------------------------------------------------------------------------------
-enum ConvInMode { IN_F16_WHITEN = 0, IN_F32_WHITEN = 1, IN_F32_PLAIN = 2, IN_DY = 3 };
+enum ConvInMode { IN_F16_WHITEN = 0, IN_F32_WHITEN = 1, IN_F32_PLAIN = 2, IN_DY = 3, IN_F32_FLIP = 4 };
 enum ConvEpi { EPI_RELU_POOL = 0, EPI_PLAIN = 1 };
 
 // How to rebuild the gradient w.r.t. a conv's pre-activation output from the pooled-resolution
@@ -57,6 +57,9 @@ struct ConvArgs {
   long in_bstride;
   const float* scale; const float* shift;   // whitening (IN_*_WHITEN)
   long white_bstride;        // floats between the (scale, shift) tables of consecutive images; 0: one table for the batch
+  float wscale;              // weights are multiplied by this when loaded (batch norm, inference mode); 0 means 1
+  int flip;                  // plain f32 input rows, but flipped / transposed weights (dX from a dense dY)
+  const float* dy_dense; long dy_dense_bstride;   // dW kernels: dense dY rows (batch norm) instead of the pooled DyDesc
   DyDesc dy;                 // IN_DY (forward kernel in "dX" mode) / dW kernel B operand
   const float* w;            // HWIO weights of the layer
   const float* bias;
@@ -127,9 +130,16 @@ struct GatherArgs {
   long elems; int B; int size; int action_dim; int C;
 };
 int launch_gather_stats(cpp_ctx* ctx, const GatherArgs& a, int dtype);
+// batch norm (bn.hip)
+int launch_bn_relu_pool(cpp_ctx* ctx, const float* z, long z_bstride, const float* stat, const float* beta, float* pool,
+                        long pool_bstride, uint8_t* amax, int B, int H, int W, int C);
+size_t bn_bwd_part_doubles(int C);
+int launch_bn_backward(cpp_ctx* ctx, float* z, long z_bstride, const float* stat, const float* beta, const float* dpool,
+                       long dpool_bstride, const float* pool, long pool_bstride, const uint8_t* amax, int B, int H, int W,
+                       int C, double* part, float* means, float* dbeta);
 int launch_stats_finalize(cpp_ctx* ctx, const double* part, int nparts, int which_count, int C,
-                          double count, float* white);
-int launch_stats_generic(cpp_ctx* ctx, const void* x, int dtype, long npix, int C, float* white);
+                          double count, float* white, double eps = 1e-6);
+int launch_stats_generic(cpp_ctx* ctx, const void* x, int dtype, long npix, int C, float* white, double eps = 1e-6);
 int launch_replay_fill(cpp_ctx* ctx, __half* store, long elems, int slots, int32_t* s1, int32_t* s2,
                        float* action, float* reward, float* mask, int rows, int action_dim,
                        uint64_t seed);

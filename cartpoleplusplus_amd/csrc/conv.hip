@@ -42,25 +42,29 @@ int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, i
   // (ky,o)-column kernel: the default for the pooled forward layers whose rows can be staged as aligned 16-byte
   // chunks (CPP_CONV_KYO=0 selects the (ky,(kx,c)) x o kernel for A/B measurements)
   static const bool no_kyo = getenv("CPP_CONV_KYO") != nullptr && atoi(getenv("CPP_CONV_KYO")) == 0;
-  bool kyo = !no_kyo && a.nout <= 10 && a.H >= 2 &&
-             ((epi == EPI_RELU_POOL && in_mode != IN_DY) || (epi == EPI_PLAIN && in_mode == IN_DY));
+  const bool dx_mode = in_mode == IN_DY || in_mode == IN_F32_FLIP;      // dX passes: plain rows out
+  bool kyo = !no_kyo && a.nout <= 10 && a.H >= 2 && ((epi == EPI_RELU_POOL && !dx_mode) || (epi == EPI_PLAIN && dx_mode));
   if (kyo && in_mode != IN_DY) {
     const int epc = in_mode == IN_F16_WHITEN ? 8 : 4;
     for (int i = 0; i < n; ++i) kyo = kyo && batch.a[i].vec_ok && (a.W * cin) % epc == 0;
   }
   // CPP_CONV_KYO23=0 keeps the narrow layers (conv2 / conv3) on the old kernel
   static const bool no_kyo23 = getenv("CPP_CONV_KYO23") != nullptr && atoi(getenv("CPP_CONV_KYO23")) == 0;
-  if ((in_mode == IN_F32_PLAIN || in_mode == IN_DY) && no_kyo23) kyo = false;
+  if ((in_mode == IN_F32_PLAIN || dx_mode) && no_kyo23) kyo = false;
   if (kyo) {
     bool handled = false;
-    rc = (in_mode == IN_F32_PLAIN || in_mode == IN_DY) ? conv_fwd_kyo_dispatch_l23(ctx, cin, ks, in_mode, batch, &handled)
+    rc = (in_mode == IN_F32_PLAIN || dx_mode) ? conv_fwd_kyo_dispatch_l23(ctx, cin, ks, in_mode, batch, &handled)
                                    : conv_fwd_kyo_dispatch_l1(ctx, cin, ks, in_mode, batch, &handled);
     if (handled) { prof_end(ctx, kid); return rc; }
   }
-  if (in_mode == IN_F16_WHITEN || in_mode == IN_F32_WHITEN)
+  if (in_mode == IN_F16_WHITEN || in_mode == IN_F32_WHITEN) {
     rc = conv_fwd_dispatch_l1(ctx, cin, ks, xtw, in_mode, epi, batch);
-  else
+  } else if (in_mode == IN_F32_FLIP) {               // earlier kernel: plain rows in, weights flipped at load time
+    for (int i = 0; i < n; ++i) batch.a[i].flip = 1;
+    rc = conv_fwd_dispatch_l23(ctx, cin, ks, xtw, IN_F32_PLAIN, epi, batch);
+  } else {
     rc = conv_fwd_dispatch_l23(ctx, cin, ks, xtw, in_mode, epi, batch);
+  }
   prof_end(ctx, kid);
   return rc;
 }

@@ -2,14 +2,18 @@
 #include "conv_impl.h"
 
 #define L1_CASE(CIN_)                                                                              \
-  if (cin == CIN_ && in_mode == IN_F16_WHITEN)                                                     \
+  if (cin == CIN_ && in_mode == IN_F16_WHITEN && epi == EPI_RELU_POOL)                             \
     return conv_fwd_launch_t<CIN_, 5, 4, IN_F16_WHITEN, EPI_RELU_POOL>(ctx, a);                    \
-  if (cin == CIN_ && in_mode == IN_F32_WHITEN)                                                     \
-    return conv_fwd_launch_t<CIN_, 5, 4, IN_F32_WHITEN, EPI_RELU_POOL>(ctx, a);
+  if (cin == CIN_ && in_mode == IN_F32_WHITEN && epi == EPI_RELU_POOL)                             \
+    return conv_fwd_launch_t<CIN_, 5, 4, IN_F32_WHITEN, EPI_RELU_POOL>(ctx, a);                    \
+  if (cin == CIN_ && in_mode == IN_F16_WHITEN && epi == EPI_PLAIN)       /* batch norm: plain conv output */ \
+    return conv_fwd_launch_t<CIN_, 5, 4, IN_F16_WHITEN, EPI_PLAIN>(ctx, a);                        \
+  if (cin == CIN_ && in_mode == IN_F32_WHITEN && epi == EPI_PLAIN)                                 \
+    return conv_fwd_launch_t<CIN_, 5, 4, IN_F32_WHITEN, EPI_PLAIN>(ctx, a);
 
 int conv_fwd_dispatch_l1(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, int epi,
                          const ConvArgsN& a) {
-  if (ks != 5 || xtw != 4 || epi != EPI_RELU_POOL) {
+  if (ks != 5 || xtw != 4) {
     cpp_set_error("conv1 forward: unsupported geometry ks=%d xtw=%d", ks, xtw);
     return 1;
   }

@@ -6,7 +6,9 @@
   if (ks == KS_ && xtw == XTW_ && in_mode == IN_F32_PLAIN && epi == EPI_RELU_POOL)                 \
     return conv_fwd_launch_t<10, KS_, XTW_, IN_F32_PLAIN, EPI_RELU_POOL>(ctx, a);                  \
   if (ks == KS_ && xtw == XTW_ && in_mode == IN_DY && epi == EPI_PLAIN)                            \
-    return conv_fwd_launch_t<10, KS_, XTW_, IN_DY, EPI_PLAIN>(ctx, a);
+    return conv_fwd_launch_t<10, KS_, XTW_, IN_DY, EPI_PLAIN>(ctx, a);                             \
+  if (ks == KS_ && xtw == XTW_ && in_mode == IN_F32_PLAIN && epi == EPI_PLAIN)   /* batch norm: plain output; dX from dense dY (a.flip) */ \
+    return conv_fwd_launch_t<10, KS_, XTW_, IN_F32_PLAIN, EPI_PLAIN>(ctx, a);
 
 int conv_fwd_dispatch_l23(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, int epi,
                           const ConvArgsN& a) {

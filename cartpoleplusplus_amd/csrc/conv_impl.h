@@ -267,7 +267,7 @@ __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd
       const int kp = 4 * kk + lj;
       float v = 0.f;
       if (kp < KS * CIN && li < a.nout) {
-        if (IN_MODE == IN_DY) {
+        if (IN_MODE == IN_DY || a.flip) {
           // dX = correlation of dY with the flipped, transposed weights:
           //   W'[ky][kx][o][c] = W[KS-1-ky][KS-1-kx][c][o],  W stored (KS,KS,Cin=nout,Cout=CIN)
           const int kx = kp / CIN, o = kp % CIN;
@@ -275,6 +275,7 @@ __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd
         } else {
           v = a.w[(ky * KS * CIN + kp) * a.nout + li];
         }
+        if (a.wscale != 0.f) v *= a.wscale;
       }
       wf[ky][kk] = v;
     }

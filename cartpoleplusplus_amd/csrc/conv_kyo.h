@@ -77,6 +77,8 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
   // IN_DY: the dX pass of the layer -- input rows are dY rows rebuilt from the pooled gradient + arg-max code, the
   // weights are flipped and transposed, the epilogue writes plain full-resolution rows (no bias / ReLU / pool)
   constexpr bool DX = (IN_MODE == IN_DY);
+  // IN_F32_FLIP: the same dX pass fed with DENSE dY rows (batch norm): plain f32 row staging, flipped weights, plain rows out
+  constexpr bool FLIP = DX || (IN_MODE == IN_F32_FLIP);
   constexpr int P = G::P, NT = G::NT, NGT = G::NGT, ROWF = G::ROWF, NO = KYO_NO;
   constexpr int EPC = ChunkOps<ST>::EPC;
   constexpr bool A64 = (CIN % 2 == 0) && (G::FP % 2 == 0);      // A operand pairs are 8-byte aligned in LDS (Q4 is even)
@@ -109,9 +111,9 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
       const int k = G::kmap(4 * g + s, l);
       const bool ok = i < G::WLF && s < G::steps(g) && o < nout && k < G::KROW;
       // dX = correlation of dY with W'[ky][kx][c'][o'] = W[KS-1-ky][KS-1-kx][o'][c'], W stored (KS,KS,Cin = nout,Cout = CIN)
-      const int widx = DX ? (((KS - 1 - ky) * KS + (KS - 1 - k / CIN)) * nout + o) * CIN + k % CIN : (ky * G::KROW + k) * nout + o;
+      const int widx = FLIP ? (((KS - 1 - ky) * KS + (KS - 1 - k / CIN)) * nout + o) * CIN + k % CIN : (ky * G::KROW + k) * nout + o;
       const float v = a.w[ok ? widx : 0];
-      wv[n] = ok ? v : 0.f;
+      wv[n] = ok ? (a.wscale != 0.f ? v * a.wscale : v) : 0.f;
     }
 #pragma unroll
     for (int n = 0; n < NW; ++n)
@@ -267,8 +269,8 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
     const int j = 16 * t + li;
     const bool valid = j < KS * NO;
     const int o = j % NO;
-    biast[t] = (!DX && valid && o < nout) ? a.bias[o] : 0.f;
-    eadr[t] = DX ? (uint32_t)(((sstrip * G::SW + 4 * lj) * nout + o) * 4)      // byte offset of (x = strip + 4 lj, o) in an output row
+    biast[t] = (!FLIP && valid && o < nout) ? a.bias[o] : 0.f;
+    eadr[t] = FLIP ? (uint32_t)(((sstrip * G::SW + 4 * lj) * nout + o) * 4)      // byte offset of (x = strip + 4 lj, o) in an output row
                  : keep_in_vgpr(lds_addr(ev + (lj * 2) * NO + o));
     const int p = valid ? j / NO : 0;
 #pragma unroll
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
   }
   const int simg_ok = sbimg < a.B ? sbimg : 0;
   const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      a.out + (long)simg_ok * a.out_bstride, 0, (DX ? H * W : Hp * Wp) * nout * 4, 0x00020000);   // uniform (per wave)
+      a.out + (long)simg_ok * a.out_bstride, 0, (FLIP ? H * W : Hp * Wp) * nout * 4, 0x00020000);   // uniform (per wave)
   const __amdgpu_buffer_rsrc_t amax_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       a.out_amax + (long)simg_ok * Hp * Wp * nout, 0, Hp * Wp * nout, 0x00020000);
 
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
           if (inr) {
 #pragma unroll
             for (int m = 0; m < XT; ++m) {
-              if (DX) {
+              if (FLIP) {
                 if (y >= 0 && sbimg < a.B) {
 #pragma unroll
                   for (int r = 0; r < 4; ++r)
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
           }
         }
       }
-      if (!DX && y >= 0 && par == 1 && (y >> 1) < Hp) {   // wave-uniform: both rows of a pool pair are in the buffer
+      if (!FLIP && y >= 0 && par == 1 && (y >> 1) < Hp) {   // wave-uniform: both rows of a pool pair are in the buffer
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

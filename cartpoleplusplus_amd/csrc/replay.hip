@@ -171,7 +171,7 @@ int launch_gather_stats(cpp_ctx* ctx, const GatherArgs& a, int dtype) {
 // one 64-lane wave per (state column, channel): lanes stride over the per-row partials, fixed-order
 // butterfly combine (deterministic)
 __global__ __launch_bounds__(64) void stats_finalize_kernel(const double* part, int nparts, int which_count,
-                                                            int C, double count, float* white) {
+                                                            int C, double count, float* white, double eps) {
   const int w = blockIdx.x / C, c = blockIdx.x - w * C;
   double s = 0.0, ss = 0.0;
   for (int b = threadIdx.x; b < nparts; b += 64) {
@@ -182,17 +182,17 @@ __global__ __launch_bounds__(64) void stats_finalize_kernel(const double* part, 
   if (threadIdx.x == 0) {
     const double mean = s / count;
     const double var = ss / count - mean * mean;     // one-pass form of tf.nn.moments (r0.9-r0.11)
-    const double inv = 1.0 / sqrt(var + 1e-6);
+    const double inv = 1.0 / sqrt(var + eps);
     white[(long)w * 2 * C + c] = (float)inv;
     white[(long)w * 2 * C + C + c] = (float)(-mean * inv);
   }
 }
 
 int launch_stats_finalize(cpp_ctx* ctx, const double* part, int nparts, int which_count, int C,
-                          double count, float* white) {
+                          double count, float* white, double eps) {
   prof_begin(ctx);
   hipLaunchKernelGGL(stats_finalize_kernel, dim3(which_count * C), dim3(64), 0, ctx->stream, part, nparts,
-                     which_count, C, count, white);
+                     which_count, C, count, white, eps);
   LAUNCH_CHECK();
   prof_end(ctx, K_STATS_FINALIZE);
   return 0;
@@ -200,7 +200,7 @@ int launch_stats_finalize(cpp_ctx* ctx, const double* part, int nparts, int whic
 
 // fallback for shapes the vector path cannot take (elems % 8 != 0): one workgroup per channel
 template <typename T>
-__global__ __launch_bounds__(256) void stats_generic_kernel(const T* x, long npix, int C, float* white) {
+__global__ __launch_bounds__(256) void stats_generic_kernel(const T* x, long npix, int C, float* white, double eps) {
   __shared__ double r0[256], r1[256];
   const int c = blockIdx.x;
   double s = 0.0, ss = 0.0;
@@ -217,18 +217,18 @@ __global__ __launch_bounds__(256) void stats_generic_kernel(const T* x, long npi
   if (threadIdx.x == 0) {
     const double mean = r0[0] / (double)npix;
     const double var = r1[0] / (double)npix - mean * mean;
-    const double inv = 1.0 / sqrt(var + 1e-6);
+    const double inv = 1.0 / sqrt(var + eps);
     white[c] = (float)inv;
     white[C + c] = (float)(-mean * inv);
   }
 }
 
-int launch_stats_generic(cpp_ctx* ctx, const void* x, int dtype, long npix, int C, float* white) {
+int launch_stats_generic(cpp_ctx* ctx, const void* x, int dtype, long npix, int C, float* white, double eps) {
   prof_begin(ctx);
   if (dtype == 1) hipLaunchKernelGGL(stats_generic_kernel<__half>, dim3(C), dim3(256), 0, ctx->stream,
-                                     (const __half*)x, npix, C, white);
+                                     (const __half*)x, npix, C, white, eps);
   else hipLaunchKernelGGL(stats_generic_kernel<float>, dim3(C), dim3(256), 0, ctx->stream,
-                          (const float*)x, npix, C, white);
+                          (const float*)x, npix, C, white, eps);
   LAUNCH_CHECK();
   prof_end(ctx, K_STATS_GENERIC);
   return 0;

@@ -158,6 +158,9 @@ struct Workspace {
   float* pool[3] = {nullptr, nullptr, nullptr};
   uint8_t* amax[3] = {nullptr, nullptr, nullptr};
   float* dpool[3] = {nullptr, nullptr, nullptr};
+  // batch norm (training mode): plain conv output (overwritten by its gradient in the backward pass), (inv, -mean*inv)
+  float* z[3] = {nullptr, nullptr, nullptr};
+  float* bn_stat[3] = {nullptr, nullptr, nullptr};
   std::vector<float*> fcin, dz;
   float* out = nullptr;
 };
@@ -172,6 +175,8 @@ struct cpp_net {
   float* white_rows;       // [maxB][2][C]: per-image statistics for cpp_net_forward_each
   double* stats_part;      // [maxB][2C]
   float* dw_partial[3];     // one per conv layer: their reductions are deferred and batched
+  bool is_training;         // base_network.IS_TRAINING for the next forward (only batch norm looks at it)
+  double* bn_part; float* bn_means; float* bn_scratch;   // batch norm: reduction partials, (mean dy, mean dy*zhat), dW bias-slot dump
   void* stage_state; float* stage_action; float* stage_out;
   Arena arena;
 };
@@ -187,7 +192,7 @@ static int net_build(cpp_net* n) {
       n->conv.push_back(L);
       VarInfo vw; vw.name = std::string(kConvNames[i]) + "/weights"; vw.rank = 4;
       vw.shape[0] = L.ks; vw.shape[1] = L.ks; vw.shape[2] = cin; vw.shape[3] = kConvOut; vw.offset = L.w_off;
-      VarInfo vb; vb.name = std::string(kConvNames[i]) + "/biases"; vb.rank = 1;
+      VarInfo vb; vb.name = std::string(kConvNames[i]) + (s.use_batch_norm ? "/BatchNorm/beta" : "/biases"); vb.rank = 1;
       vb.shape[0] = kConvOut; vb.shape[1] = vb.shape[2] = vb.shape[3] = 0; vb.offset = L.b_off;
       n->vars.push_back(vw); n->vars.push_back(vb);
       cin = kConvOut; h /= 2; w /= 2;
@@ -252,6 +257,10 @@ static int ws_alloc(cpp_net* n, Workspace& w, int from_layer, bool trunk) {
       if (i < 2) RC(dalloc(n->arena, &w.pool[i], pe)); else w.pool[i] = w.fcin[0];
       RC(dalloc(n->arena, &w.amax[i], pe));
       RC(dalloc(n->arena, &w.dpool[i], pe));
+      if (n->spec.use_batch_norm) {
+        RC(dalloc(n->arena, &w.z[i], (size_t)mb * L.H * L.W * kConvOut));
+        RC(dalloc(n->arena, &w.bn_stat[i], (size_t)2 * kConvOut));
+      }
     }
   }
   return CPP_OK;
@@ -274,6 +283,7 @@ extern "C" int cpp_net_create(cpp_ctx* ctx, const cpp_net_spec* spec, int max_ba
   n->ctx = ctx; n->spec = *spec; n->maxB = max_batch; n->arena.stream = ctx->stream;
   n->grads = nullptr; n->own_grads = nullptr; n->stage_state = nullptr; n->stage_action = nullptr;
   n->stage_out = nullptr; n->dw_partial[0] = n->dw_partial[1] = n->dw_partial[2] = nullptr; n->white = nullptr; n->white_rows = nullptr; n->stats_part = nullptr;
+  n->is_training = true; n->bn_part = nullptr; n->bn_means = nullptr; n->bn_scratch = nullptr;
   int rc = net_build(n);
   if (rc) { delete n; return rc; }
   auto fail = [&](int r) { n->arena.release(); delete n; return r; };
@@ -283,7 +293,8 @@ extern "C" int cpp_net_create(cpp_ctx* ctx, const cpp_net_spec* spec, int max_ba
     n->ws[1] = n->ws[0];
     if ((rc = ws_alloc(n, n->ws[1], n->cat_layer, false))) return fail(rc);
     for (int l = 0; l < n->cat_layer; ++l) { n->ws[1].fcin[l] = n->ws[0].fcin[l]; n->ws[1].dz[l] = n->ws[0].dz[l]; }
-    for (int i = 0; i < 3; ++i) { n->ws[1].pool[i] = n->ws[0].pool[i]; n->ws[1].amax[i] = n->ws[0].amax[i]; n->ws[1].dpool[i] = n->ws[0].dpool[i]; }
+    for (int i = 0; i < 3; ++i) { n->ws[1].pool[i] = n->ws[0].pool[i]; n->ws[1].amax[i] = n->ws[0].amax[i]; n->ws[1].dpool[i] = n->ws[0].dpool[i];
+                                  n->ws[1].z[i] = n->ws[0].z[i]; n->ws[1].bn_stat[i] = n->ws[0].bn_stat[i]; }
   }
   if (spec->pixel) {
     for (int i = 0; i < 3; ++i)
@@ -291,6 +302,13 @@ extern "C" int cpp_net_create(cpp_ctx* ctx, const cpp_net_spec* spec, int max_ba
     if ((rc = dalloc(n->arena, &n->white, (size_t)2 * spec->C))) return fail(rc);
     if ((rc = dalloc(n->arena, &n->white_rows, (size_t)max_batch * 2 * spec->C))) return fail(rc);
     if ((rc = dalloc(n->arena, &n->stats_part, (size_t)2 * max_batch * 2 * spec->C))) return fail(rc);
+    if (spec->use_batch_norm) {
+      size_t pd = (size_t)2 * max_batch * 2 * kConvOut;
+      if (pd < bn_bwd_part_doubles(kConvOut)) pd = bn_bwd_part_doubles(kConvOut);
+      if ((rc = n->arena.alloc((void**)&n->bn_part, pd * sizeof(double), false))) return fail(rc);
+      if ((rc = dalloc(n->arena, &n->bn_means, (size_t)2 * kConvOut))) return fail(rc);
+      if ((rc = dalloc(n->arena, &n->bn_scratch, (size_t)kConvOut))) return fail(rc);
+    }
   }
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
   *out = n;
@@ -403,6 +421,22 @@ static ConvArgs conv_dx_args(cpp_net* n, Workspace& w, int i, int B) {
   return x;
 }
 
+// slim.batch_norm's epsilon; the moving variance stays at its initial 1 (never updated by the reference's train ops)
+static const double kBnEps = 1e-3;
+
+// per-channel (inv, -mean*inv) of a plain conv output z (B, H, W, 10)
+static int bn_forward_stats(cpp_net* n, const float* z, int B, int H, int W, float* stat) {
+  cpp_ctx* ctx = n->ctx;
+  const long elems = (long)H * W * kConvOut;
+  if (elems % 8 == 0) {
+    GatherArgs ga; memset(&ga, 0, sizeof(ga));
+    ga.store[0] = z; ga.store[1] = z; ga.part = n->bn_part; ga.elems = elems; ga.B = B; ga.C = kConvOut;
+    RC(launch_gather_stats(ctx, ga, CPP_F32));
+    return launch_stats_finalize(ctx, n->bn_part, B, 1, kConvOut, (double)B * H * W, stat, kBnEps);
+  }
+  return launch_stats_generic(ctx, z, CPP_F32, (long)B * H * W, kConvOut, stat, kBnEps);
+}
+
 // conv trunk (pixel) or state conversion (low-dim) into ws.fcin[0]
 static int net_forward_trunk(cpp_net* n, Workspace& w, const void* state, int dtype, const float* white, int B,
                              long white_bstride = 0) {
@@ -412,7 +446,21 @@ static int net_forward_trunk(cpp_net* n, Workspace& w, const void* state, int dt
   for (int i = 0; i < 3; ++i) {
     int mode;
     ConvArgs a = conv_fwd_args(n, w, i, state, dtype, white, B, &mode, white_bstride);
-    RC(launch_conv_fwd(ctx, kFwdKid[i], n->conv[i].Cin, n->conv[i].ks, mode, EPI_RELU_POOL, a));
+    if (!n->spec.use_batch_norm) {
+      RC(launch_conv_fwd(ctx, kFwdKid[i], n->conv[i].Cin, n->conv[i].ks, mode, EPI_RELU_POOL, a));
+    } else if (!n->is_training) {
+      // inference: (z - 0) / sqrt(1 + eps) + beta  ==  the fused kernel with scaled weights and beta as the bias
+      a.wscale = (float)(1.0 / sqrt(1.0 + kBnEps));
+      RC(launch_conv_fwd(ctx, kFwdKid[i], n->conv[i].Cin, n->conv[i].ks, mode, EPI_RELU_POOL, a));
+    } else {
+      const ConvL& L = n->conv[i];
+      ConvArgs p = a;                                   // plain conv output (no bias) -> statistics -> BN + ReLU + pool
+      p.out = w.z[i]; p.out_bstride = (long)L.H * L.W * kConvOut; p.out_amax = nullptr; p.bias = nullptr;
+      RC(launch_conv_fwd(ctx, kFwdKid[i], L.Cin, L.ks, mode, EPI_PLAIN, p));
+      RC(bn_forward_stats(n, w.z[i], B, L.H, L.W, w.bn_stat[i]));
+      RC(launch_bn_relu_pool(ctx, w.z[i], p.out_bstride, w.bn_stat[i], n->params + L.b_off, a.out, a.out_bstride, a.out_amax,
+                             B, L.H, L.W, kConvOut));
+    }
   }
   return CPP_OK;
 }
@@ -612,7 +660,10 @@ extern "C" int cpp_net_forward(cpp_net* n, const void* state, int state_dtype, i
   if (action) HIP_CHECK(hipMemcpyAsync(n->stage_action, action, (size_t)B * A * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   if (n->spec.pixel)
     RC(batch_stats(ctx, n->stage_state, nullptr, state_dtype, n->state_elems, B, n->spec.C, n->stats_part, n->white));
-  RC(net_forward_trunk(n, n->ws[0], n->stage_state, state_dtype, n->white, B));
+  n->is_training = false;                              // IS_TRAINING: False (ddpg_cartpole.py:125)
+  int frc = net_forward_trunk(n, n->ws[0], n->stage_state, state_dtype, n->white, B);
+  n->is_training = true;
+  if (frc) return frc;
   RC(net_forward_fc(n, n->ws[0], 0, B, action ? n->stage_action : nullptr));
   HIP_CHECK(hipMemcpyAsync(out, n->ws[0].out, (size_t)B * no * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -653,7 +704,10 @@ extern "C" int cpp_net_forward_each(cpp_net* n, const void* state, int state_dty
     }
     wbs = 2 * C;
   }
-  RC(net_forward_trunk(n, n->ws[0], n->stage_state, state_dtype, n->white_rows, B, wbs));
+  n->is_training = false;
+  int frc = net_forward_trunk(n, n->ws[0], n->stage_state, state_dtype, n->white_rows, B, wbs);
+  n->is_training = true;
+  if (frc) return frc;
   RC(net_forward_fc(n, n->ws[0], 0, B, action ? n->stage_action : nullptr));
   HIP_CHECK(hipMemcpyAsync(out, n->ws[0].out, (size_t)B * no * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1064,7 +1118,17 @@ static int actor_gradients(cpp_ddpg* d, cpp_batch* b, bool critic_prefix_done) {
 }
 
 // ddpg_cartpole.py:199-214
+static int critic_gradients_impl(cpp_ddpg* d, cpp_batch* b, bool critic_prefix_done, bool backward);
+// backward == false is check_loss (ddpg_cartpole.py:239-248), which feeds IS_TRAINING False; the train op (:237) feeds
+// True for the whole graph, target networks included
 static int critic_gradients(cpp_ddpg* d, cpp_batch* b, bool critic_prefix_done, bool backward) {
+  cpp_net* nets[3] = {d->critic, d->tactor, d->tcritic};
+  for (cpp_net* n : nets) n->is_training = backward;
+  const int rc = critic_gradients_impl(d, b, critic_prefix_done, backward);
+  for (cpp_net* n : nets) n->is_training = true;
+  return rc;
+}
+static int critic_gradients_impl(cpp_ddpg* d, cpp_batch* b, bool critic_prefix_done, bool backward) {
   cpp_net *c = d->critic, *ta = d->tactor, *tc = d->tcritic;
   const int B = b->B, C = c->spec.pixel ? c->spec.C : 0;
   const float *w1 = white_of(b, 0, C), *w2 = white_of(b, 1, C);

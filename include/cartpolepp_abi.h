@@ -79,6 +79,10 @@ typedef struct cpp_net_spec {
   int32_t hidden[8];     /* (pixel critic is the fixed 200/50/+action/50 head of :168-171)       */
   int32_t head_out;      /* CPP_HEAD: outputs of the 'fc' head (1, action_dim, action_dim*(action_dim+1)/2) */
   int32_t head_act;      /* CPP_HEAD: 0 linear, 2 tanh (naf_cartpole.py:109,161,184)              */
+  int32_t use_batch_norm; /* opts.use_batch_norm (base_network.py:74-79): slim.batch_norm after every conv; the conv then has no
+                           * bias and the '<conv>/biases' slot of the flat layout is '<conv>/BatchNorm/beta'.  Training-mode
+                           * entry points (the train ops) use batch statistics, inference-mode ones (cpp_net_forward*,
+                           * check_loss, NAF action / debug) the never-updated moving averages (mean 0, variance 1).  */
 } cpp_net_spec;
 
 int cpp_net_create(cpp_ctx* ctx, const cpp_net_spec* spec, int max_batch, cpp_net** out);

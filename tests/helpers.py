@@ -42,7 +42,7 @@ def make_pair(shape, B, pixel, seed=0, replay_size=64, perturb=True, dt=np.float
             p = net.get_params()
             net.set_params(p + rng.normal(0, 0.01, p.shape).astype(np.float32))
     if pixel:
-        kw = dict(pixel=True, H=shape[0], W=shape[1], C=int(np.prod(shape[2:])))
+        kw = dict(pixel=True, H=shape[0], W=shape[1], C=int(np.prod(shape[2:])), batch_norm=bool(optkw.get("use_batch_norm", False)))
     else:
         kw = dict(pixel=False, state_elems=int(np.prod(shape)))
     aspec = O.NetSpec("actor", 2, [100, 100, 50], **kw)
