@@ -7,6 +7,16 @@ static int pick_xtw(int in_mode, int W) {
   return W > 32 ? 4 : (W > 16 ? 2 : 1);
 }
 
+// largest staging chunk (16 / 8 / 4 bytes) that the image base, the image stride and the row length are multiples of;
+// 0 if not even one element fits a 4-byte chunk boundary pattern
+static int chunk_bytes_for(const ConvArgs& a, int in_mode, int cin) {
+  if (in_mode == IN_DY) return 16;
+  const long esz = in_mode == IN_F16_WHITEN ? 2 : 4;
+  for (int chb = 16; chb >= 4; chb >>= 1)
+    if (((uintptr_t)a.in) % chb == 0 && (a.in_bstride * esz) % chb == 0 && ((long)a.W * cin * esz) % chb == 0) return chb;
+  return 0;
+}
+
 // aligned 16-byte row staging needs 16-byte aligned image bases
 static int vec_ok_for(const ConvArgs& a, int in_mode) {
   if (in_mode == IN_DY) return 0;
@@ -44,17 +54,18 @@ int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, i
   static const bool no_kyo = getenv("CPP_CONV_KYO") != nullptr && atoi(getenv("CPP_CONV_KYO")) == 0;
   const bool dx_mode = in_mode == IN_DY || in_mode == IN_F32_FLIP;      // dX passes: plain rows out
   bool kyo = !no_kyo && a.nout <= 10 && a.H >= 2 && ((epi == EPI_RELU_POOL && !dx_mode) || (epi == EPI_PLAIN && dx_mode));
-  if (kyo && in_mode != IN_DY) {
-    const int epc = in_mode == IN_F16_WHITEN ? 8 : 4;
-    for (int i = 0; i < n; ++i) kyo = kyo && batch.a[i].vec_ok && (a.W * cin) % epc == 0;
+  int chb = 16;
+  for (int i = 0; i < n && kyo; ++i) {
+    const int c = chunk_bytes_for(batch.a[i], in_mode, cin);
+    if (c == 0) kyo = false; else if (c < chb) chb = c;
   }
   // CPP_CONV_KYO23=0 keeps the narrow layers (conv2 / conv3) on the old kernel
   static const bool no_kyo23 = getenv("CPP_CONV_KYO23") != nullptr && atoi(getenv("CPP_CONV_KYO23")) == 0;
   if ((in_mode == IN_F32_PLAIN || dx_mode) && no_kyo23) kyo = false;
   if (kyo) {
     bool handled = false;
-    rc = (in_mode == IN_F32_PLAIN || dx_mode) ? conv_fwd_kyo_dispatch_l23(ctx, cin, ks, in_mode, batch, &handled)
-                                   : conv_fwd_kyo_dispatch_l1(ctx, cin, ks, in_mode, batch, &handled);
+    rc = (in_mode == IN_F32_PLAIN || dx_mode) ? conv_fwd_kyo_dispatch_l23(ctx, cin, ks, in_mode, chb, batch, &handled)
+                                              : conv_fwd_kyo_dispatch_l1(ctx, cin, ks, in_mode, chb, batch, &handled);
     if (handled) { prof_end(ctx, kid); return rc; }
   }
   if (in_mode == IN_F16_WHITEN || in_mode == IN_F32_WHITEN) {
@@ -97,15 +108,23 @@ int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, co
   }
   int grid = 0, rc;
   prof_begin(ctx);
-  // (ky,o)-column kernel for the 5x5 layers whose rows stage as aligned 16-byte chunks (CPP_CONV_KYO=0: old kernel)
+  // (ky,o)-column kernel for the 5x5 layers (CPP_CONV_KYO=0: old kernel); dense dY rows (batch norm) only exist there
   static const bool no_kyo = getenv("CPP_CONV_KYO") != nullptr && atoi(getenv("CPP_CONV_KYO")) == 0;
-  bool kyo = !no_kyo && ks == 5 && nout <= 10 && (batch.a[0].H % 2) == 0 && batch.a[0].H >= 4;
-  if (kyo) {
-    const int epc = in_mode == IN_F16_WHITEN ? 8 : 4;
-    for (int i = 0; i < n; ++i) kyo = kyo && batch.a[i].vec_ok && (batch.a[i].W * cin) % epc == 0;
+  const bool dense = batch.a[0].dy_dense != nullptr;
+  bool kyo = dense || (!no_kyo && ks == 5 && nout <= 10 && (batch.a[0].H % 2) == 0 && batch.a[0].H >= 4);
+  int chb = 16;
+  for (int i = 0; i < n && kyo; ++i) {
+    const int c = chunk_bytes_for(batch.a[i], in_mode, cin);
+    if (c == 0) kyo = false; else if (c < chb) chb = c;
   }
   bool handled = false;
-  if (kyo) rc = conv_dw_kyo_dispatch(ctx, cin, ks, in_mode, batch, &grid, &handled);
+  if (kyo) rc = conv_dw_kyo_dispatch(ctx, cin, ks, in_mode, chb, dense, batch, &grid, &handled);
+  if (dense && !handled) {
+    cpp_set_error("conv dW from dense dY rows (batch norm): no kernel for %dx%d, %d channels, %dx%d taps, %d-byte rows chunks",
+                  batch.a[0].H, batch.a[0].W, cin, ks, ks, chb);
+    prof_end(ctx, kid);
+    return 1;
+  }
   if (handled) {
   } else if (in_mode == IN_F16_WHITEN || in_mode == IN_F32_WHITEN)
     rc = conv_dw_dispatch_l1(ctx, cin, ks, xtw, in_mode, batch, &grid);

@@ -41,15 +41,18 @@ struct DwKyoGeom {
   static constexpr int LDS_FLOATS = RING_IN * ROWF + RING_DY * DROW + WHF + CONV_THREADS * NCELL;
 };
 
-template <int CIN, int KS, int NS_, int IN_MODE>
+// CHB: bytes per input staging chunk (16 / 8 / 4, as in conv_fwd_kyo_kernel).  DENSE: dY comes as dense f32 rows
+// (a.dy_dense: batch norm's dz) instead of being rebuilt from the pooled gradient; that mode also takes odd heights and
+// the 3x3 layer (two column tiles: waves 2 and 3 then only help with the staging).
+template <int CIN, int KS, int NS_, int IN_MODE, int CHB = 16, bool DENSE = false>
 __global__ __launch_bounds__(CONV_THREADS, 4) void conv_dw_kyo_kernel(const ConvArgsN batch, int units_per_img,
                                                                     int band) {
   typedef DwKyoGeom<CIN, KS, NS_> G;
   typedef typename StageType<IN_MODE>::type ST;
-  static_assert(G::NT == 4, "one column tile per wave");
+  static_assert(G::NT <= 4 && (DENSE || G::NT == 4), "one column tile per wave");
   constexpr bool WHITEN = (IN_MODE == IN_F16_WHITEN || IN_MODE == IN_F32_WHITEN);
   constexpr int P = G::P, NO = G::NO, MT = G::MT, NS = G::NS, ROWF = G::ROWF, DROW = G::DROW;
-  constexpr int EPC = ChunkOps<ST>::EPC;
+  constexpr int EPC = CHB / (int)sizeof(ST);
   constexpr bool A64 = (CIN % 2 == 0) && (MT % 2 == 0) && (G::FP % 2 == 0);
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   const ConvArgs& a = batch.a[blockIdx.y];
@@ -89,8 +92,16 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_dw_kyo_kernel(const Conv
 #pragma unroll
     for (int i = 0; i < NVMAX; ++i) {
       if (sact[i]) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)sbyte[i], q * rowbytes, 0);
-        sv[i] = make_uint4(v.x, v.y, v.z, v.w);
+        if (CHB == 16) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)sbyte[i], q * rowbytes, 0);
+          sv[i] = make_uint4(v.x, v.y, v.z, v.w);
+        } else if (CHB == 8) {
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)sbyte[i], q * rowbytes, 0);
+          sv[i] = make_uint4(v.x, v.y, 0u, 0u);
+        } else {
+          sv[i] = make_uint4(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)sbyte[i], q * rowbytes, 0), 0u, 0u, 0u);
+        }
       }
     }
   };
@@ -104,21 +115,31 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_dw_kyo_kernel(const Conv
         if (WHITEN) {
 #pragma unroll
           for (int k = 0; k < EPC; k += 2) {
-            f32x2 sc, sh;
-            if (CIN % 2 == 0) {
-              sc = lds_load<f32x2>(swh[i], 4 * k);
-              sh = lds_load<f32x2>(swh[i], 4 * (G::WHF / 2 + k));
+            if (k + 1 < EPC) {
+              f32x2 sc, sh;
+              if (CIN % 2 == 0) {
+                sc = lds_load<f32x2>(swh[i], 4 * k);
+                sh = lds_load<f32x2>(swh[i], 4 * (G::WHF / 2 + k));
+              } else {
+                sc = (f32x2){lds_load<float>(swh[i], 4 * k), lds_load<float>(swh[i], 4 * k + 4)};
+                sh = (f32x2){lds_load<float>(swh[i], 4 * (G::WHF / 2 + k)), lds_load<float>(swh[i], 4 * (G::WHF / 2 + k) + 4)};
+              }
+              x[k] = x[k] * sc.x + sh.x;
+              x[k + 1] = x[k + 1] * sc.y + sh.y;
             } else {
-              sc = (f32x2){lds_load<float>(swh[i], 4 * k), lds_load<float>(swh[i], 4 * k + 4)};
-              sh = (f32x2){lds_load<float>(swh[i], 4 * (G::WHF / 2 + k)), lds_load<float>(swh[i], 4 * (G::WHF / 2 + k) + 4)};
+              x[k] = x[k] * lds_load<float>(swh[i], 4 * k) + lds_load<float>(swh[i], 4 * (G::WHF / 2 + k));
             }
-            x[k] = x[k] * sc.x + sh.x;
-            x[k + 1] = x[k + 1] * sc.y + sh.y;
           }
         }
+        if (EPC >= 4) {
 #pragma unroll
-        for (int k = 0; k < EPC; k += 4)
-          lds_store(sdst[i], slot * ROWF * 4 + 4 * k, (f32x4){x[k], x[k + 1], x[k + 2], x[k + 3]});
+          for (int k = 0; k + 3 < EPC; k += 4)
+            lds_store(sdst[i], slot * ROWF * 4 + 4 * k, (f32x4){x[k], x[k + 1], x[k + 2], x[k + 3]});
+        } else if (EPC == 2) {
+          lds_store(sdst[i], slot * ROWF * 4, (f32x2){x[0], x[1]});
+        } else {
+          lds_store(sdst[i], slot * ROWF * 4, x[0]);
+        }
       }
     }
   };
@@ -177,6 +198,39 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_dw_kyo_kernel(const Conv
     }
   };
 
+  // ---- dense dY rows (DENSE): 8-byte chunks = channels (o0, o0 + 1) of one pixel; same LDS layout [o][k][s]
+  constexpr int NDCH = DENSE ? (G::WPAD * NO / 2 + CONV_THREADS - 1) / CONV_THREADS : 1;
+  bool dact[NDCH]; uint32_t ddst[NDCH]; f32x2 dreg[NDCH];
+#pragma unroll
+  for (int c = 0; c < NDCH; ++c) {
+    const int j = tid + CONV_THREADS * c;              // chunk: flattened (x, o) elements 2j, 2j + 1
+    const int x = (2 * j) / nout, o = (2 * j) - x * nout;
+    dact[c] = DENSE && 2 * j < W * nout && (nout % 2) == 0;
+    ddst[c] = keep_in_vgpr(lds_addr(dyring + o * G::OST + (x & 3) * G::KST + (x >> 2)));
+    dreg[c] = (f32x2){0.f, 0.f};
+  }
+  auto dense_load = [&](const __amdgpu_buffer_rsrc_t& rs, int y) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const bool rowok = y >= 0 && y < H;               // uniform
+#pragma unroll
+    for (int c = 0; c < NDCH; ++c) {
+      dreg[c] = (f32x2){0.f, 0.f};
+      if (rowok && dact[c]) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (tid + CONV_THREADS * c) * 8, y * W * nout * 4, 0);
+        dreg[c] = (f32x2){__uint_as_float(v.x), __uint_as_float(v.y)};
+      }
+    }
+  };
+  auto dense_store = [&](int slot) {
+#pragma unroll
+    for (int c = 0; c < NDCH; ++c) {
+      if (dact[c]) {
+        lds_store(ddst[c], slot * DROW * 4, dreg[c].x);
+        lds_store(ddst[c], slot * DROW * 4 + G::OST * 4, dreg[c].y);
+      }
+    }
+  };
+
   // ---- MFMA operands: A = input, lane (i = li, k = lj) reads m = MT*i .. MT*i + MT-1 of pixel x = 4 s + k;
   //                     B = dY,    lane (k = lj, j = li) reads column n = 16 wave + j = (ky, o) of the same pixels
   const uint32_t aadr = keep_in_vgpr(lds_addr(inring + G::FP + lj * CIN + MT * li));
@@ -212,20 +266,30 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_dw_kyo_kernel(const Conv
     // 0 .. 2P and input positions P, P+1 are in LDS, input position P+2 and the cells of dY position 2P+1 in registers.
     const int y0 = q_lo - P;                          // image row of position 0 (even: P == 2)
     auto in_band = [&](int y) { return y >= q_lo && y < q_lo + rows; };
-    if (0 < rows) in_load(in_rs, q_lo);
-    dy_issue(rp, rd, rc, y0 >> 1, 0);
-    dy_issue(rp, rd, rc, (y0 >> 1) + 1, 1);
-    if (0 < rows) in_store(P % G::RING_IN);
-    if (1 < rows) in_load(in_rs, q_lo + 1);
-    dy_conv(0, in_band(y0));
-    dy_store(0, 0); dy_store(1, 1);
-    dy_issue(rp, rd, rc, (y0 >> 1) + 2, 0);
-    dy_conv(1, in_band(y0 + 2));
-    dy_store(2, 0); dy_store(3, 1);
-    if (1 < rows) in_store((P + 1) % G::RING_IN);
-    if (2 < rows) in_load(in_rs, q_lo + 2);
-    dy_conv(0, in_band(y0 + 4));
-    dy_store(4, 0);                                   // position 5 (same cells) is stored by the first step
+    const __amdgpu_buffer_rsrc_t rdense = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(DENSE ? a.dy_dense + (long)b * a.dy_dense_bstride : a.dy.dpool), 0, DENSE ? H * W * nout * 4 : 0, 0x00020000);
+    if (DENSE) {
+      for (int d = 0; d <= 2 * P; ++d) { dense_load(rdense, y0 + d); dense_store(d % G::RING_DY); }
+      dense_load(rdense, y0 + 2 * P + 1);
+      for (int d = P; d < P + 2; ++d)
+        if (d - P < rows) { in_load(in_rs, y0 + d); in_store(d % G::RING_IN); }
+      if (2 < rows) in_load(in_rs, q_lo + 2);
+    } else {
+      if (0 < rows) in_load(in_rs, q_lo);
+      dy_issue(rp, rd, rc, y0 >> 1, 0);
+      dy_issue(rp, rd, rc, (y0 >> 1) + 1, 1);
+      if (0 < rows) in_store(P % G::RING_IN);
+      if (1 < rows) in_load(in_rs, q_lo + 1);
+      dy_conv(0, in_band(y0));
+      dy_store(0, 0); dy_store(1, 1);
+      dy_issue(rp, rd, rc, (y0 >> 1) + 2, 0);
+      dy_conv(1, in_band(y0 + 2));
+      dy_store(2, 0); dy_store(3, 1);
+      if (1 < rows) in_store((P + 1) % G::RING_IN);
+      if (2 < rows) in_load(in_rs, q_lo + 2);
+      dy_conv(0, in_band(y0 + 4));
+      dy_store(4, 0);                                 // position 5 (same cells) is stored by the first step
+    }
     __syncthreads();
 
     for (int t0 = 0; t0 < rows + P; t0 += G::UNROLL) {
@@ -238,9 +302,14 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_dw_kyo_kernel(const Conv
         {
           const int d = t + P + 1, y = y0 + d;
 #ifndef DWKYO_ABL_NODY
-          if ((d & 1) == 0) dy_conv(0, in_band(y));                       // requested one step ago
-          dy_store((sq + P + 1) % G::RING_DY, (sq + P + 1) & 1);
-          if ((d & 1) == 1) dy_issue(rp, rd, rc, (y + 1) >> 1, 0);        // next pooled row, used from the next step on
+          if (DENSE) {
+            dense_store((sq + P + 1) % G::RING_DY);                       // requested one step ago
+            dense_load(rdense, y + 1);
+          } else {
+            if ((d & 1) == 0) dy_conv(0, in_band(y));                     // requested one step ago
+            dy_store((sq + P + 1) % G::RING_DY, (sq + P + 1) & 1);
+            if ((d & 1) == 1) dy_issue(rp, rd, rc, (y + 1) >> 1, 0);      // next pooled row, used from the next step on
+          }
 #endif
 #ifndef DWKYO_ABL_NOIN
           if (t + 2 - P < rows) in_store((sq + 2) % G::RING_IN);
@@ -325,12 +394,12 @@ static inline int dw_kyo_band(int capacity, int B, int H) {
   return band;
 }
 
-template <int CIN, int KS, int NS_, int IN_MODE>
+template <int CIN, int KS, int NS_, int IN_MODE, int CHB = 16, bool DENSE = false>
 static inline int conv_dw_kyo_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int* grid_out) {
   typedef DwKyoGeom<CIN, KS, NS_> G;
   const ConvArgs& a = batch.a[0];
   const size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
-  auto kern = conv_dw_kyo_kernel<CIN, KS, NS_, IN_MODE>;
+  auto kern = conv_dw_kyo_kernel<CIN, KS, NS_, IN_MODE, CHB, DENSE>;
   static bool attr_done = false;
   if (!attr_done) {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -347,4 +416,5 @@ static inline int conv_dw_kyo_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int
   return 0;
 }
 
-int conv_dw_kyo_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArgsN& a, int* grid, bool* handled);
+int conv_dw_kyo_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, int chb, bool dense, const ConvArgsN& a, int* grid, bool* handled);
+int conv_dw_kyo_dispatch_dense(cpp_ctx* ctx, int cin, int ks, int in_mode, int chb, const ConvArgsN& a, int* grid, bool* handled);

@@ -69,7 +69,9 @@ struct KyoGeom {
   }
 };
 
-template <int CIN, int KS, int XT, int IPW, int IN_MODE>
+// CHB: bytes per staging chunk -- 16 when the image rows are 16-byte multiples (64 x 64 x 18 f16), 8 or 4 otherwise (the
+// reference's default 50 x 50 render: 1800-byte rows)
+template <int CIN, int KS, int XT, int IPW, int IN_MODE, int CHB = 16>
 __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_kernel(const ConvArgsN batch) {
   typedef KyoGeom<CIN, KS, XT, IPW> G;
   typedef typename StageType<IN_MODE>::type ST;
@@ -80,7 +82,8 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
   // IN_F32_FLIP: the same dX pass fed with DENSE dY rows (batch norm): plain f32 row staging, flipped weights, plain rows out
   constexpr bool FLIP = DX || (IN_MODE == IN_F32_FLIP);
   constexpr int P = G::P, NT = G::NT, NGT = G::NGT, ROWF = G::ROWF, NO = KYO_NO;
-  constexpr int EPC = ChunkOps<ST>::EPC;
+  constexpr int EPC = CHB / (int)sizeof(ST);          // elements per staging chunk
+  static_assert(EPC >= 1, "chunk smaller than an element");
   constexpr bool A64 = (CIN % 2 == 0) && (G::FP % 2 == 0);      // A operand pairs are 8-byte aligned in LDS (Q4 is even)
   constexpr int RING = G::RING, RSET = IPW * ROWF;              // row buffers in flight, floats per buffer
 #ifdef KYO_CLOCK_PROBE
@@ -219,8 +222,16 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
 #pragma unroll
     for (int i = 0; i < NVMAX; ++i) {
       if (sact[i]) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)sbyte[i], y * rowbytes, 0);
-        sv[i] = make_uint4(v.x, v.y, v.z, v.w);
+        if (CHB == 16) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)sbyte[i], y * rowbytes, 0);
+          sv[i] = make_uint4(v.x, v.y, v.z, v.w);
+        } else if (CHB == 8) {
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, (int)sbyte[i], y * rowbytes, 0);
+          sv[i] = make_uint4(v.x, v.y, 0u, 0u);
+        } else {
+          sv[i] = make_uint4(__builtin_amdgcn_raw_buffer_load_b32(in_rsrc, (int)sbyte[i], y * rowbytes, 0), 0u, 0u, 0u);
+        }
       }
     }
   };
@@ -235,21 +246,31 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
         if (WHITEN) {
 #pragma unroll
           for (int k = 0; k < EPC; k += 2) {         // pairs are 8-byte aligned when CIN is even
-            f32x2 sc, sh;
-            if (CIN % 2 == 0) {
-              sc = lds_load<f32x2>(swh[i], 4 * k);
-              sh = lds_load<f32x2>(swh[i], 4 * (G::WHF / 2 + k));
+            if (k + 1 < EPC) {
+              f32x2 sc, sh;
+              if (CIN % 2 == 0) {
+                sc = lds_load<f32x2>(swh[i], 4 * k);
+                sh = lds_load<f32x2>(swh[i], 4 * (G::WHF / 2 + k));
+              } else {
+                sc = (f32x2){lds_load<float>(swh[i], 4 * k), lds_load<float>(swh[i], 4 * k + 4)};
+                sh = (f32x2){lds_load<float>(swh[i], 4 * (G::WHF / 2 + k)), lds_load<float>(swh[i], 4 * (G::WHF / 2 + k) + 4)};
+              }
+              x[k] = x[k] * sc.x + sh.x;
+              x[k + 1] = x[k + 1] * sc.y + sh.y;
             } else {
-              sc = (f32x2){lds_load<float>(swh[i], 4 * k), lds_load<float>(swh[i], 4 * k + 4)};
-              sh = (f32x2){lds_load<float>(swh[i], 4 * (G::WHF / 2 + k)), lds_load<float>(swh[i], 4 * (G::WHF / 2 + k) + 4)};
+              x[k] = x[k] * lds_load<float>(swh[i], 4 * k) + lds_load<float>(swh[i], 4 * (G::WHF / 2 + k));
             }
-            x[k] = x[k] * sc.x + sh.x;
-            x[k + 1] = x[k + 1] * sc.y + sh.y;
           }
         }
         const uint32_t dst = sdst[i] + (uint32_t)(slot * RSET * 4);
+        if (EPC >= 4) {
 #pragma unroll
-        for (int k = 0; k < EPC; k += 4) lds_store(dst, 4 * k, (f32x4){x[k], x[k + 1], x[k + 2], x[k + 3]});
+          for (int k = 0; k + 3 < EPC; k += 4) lds_store(dst, 4 * k, (f32x4){x[k], x[k + 1], x[k + 2], x[k + 3]});
+        } else if (EPC == 2) {
+          lds_store(dst, 0, (f32x2){x[0], x[1]});
+        } else {
+          lds_store(dst, 0, x[0]);
+        }
       }
     }
   };
@@ -493,12 +514,12 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
 #endif
 }
 
-template <int CIN, int KS, int XT, int IPW, int IN_MODE>
+template <int CIN, int KS, int XT, int IPW, int IN_MODE, int CHB = 16>
 static inline int conv_fwd_kyo_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
   typedef KyoGeom<CIN, KS, XT, IPW> G;
   const ConvArgs& a = batch.a[0];
   const size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
-  auto kern = conv_fwd_kyo_kernel<CIN, KS, XT, IPW, IN_MODE>;
+  auto kern = conv_fwd_kyo_kernel<CIN, KS, XT, IPW, IN_MODE, CHB>;
   static bool attr_done = false;
   if (!attr_done) {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -510,5 +531,5 @@ static inline int conv_fwd_kyo_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
   return 0;
 }
 
-int conv_fwd_kyo_dispatch_l1(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArgsN& a, bool* handled);
-int conv_fwd_kyo_dispatch_l23(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArgsN& a, bool* handled);
+int conv_fwd_kyo_dispatch_l1(cpp_ctx* ctx, int cin, int ks, int in_mode, int chb, const ConvArgsN& a, bool* handled);
+int conv_fwd_kyo_dispatch_l23(cpp_ctx* ctx, int cin, int ks, int in_mode, int chb, const ConvArgsN& a, bool* handled);

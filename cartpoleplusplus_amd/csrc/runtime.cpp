@@ -483,8 +483,35 @@ static int net_forward_fc(cpp_net* n, Workspace& w, int from, int B, const float
 }
 
 // conv trunk backward from w.dpool[2] (= d flat): dW/db of the three convs, dX for conv3/conv2
+// batch norm (training mode): the gradient w.r.t. the plain conv output is dense -- reductions over the pooled tensors,
+// dz written over z, then dW and dX from dense rows.  dbeta goes straight into the '<conv>/BatchNorm/beta' slot.
+static int net_backward_conv_bn(cpp_net* n, Workspace& w, int B, const void* state, int dtype, const float* white) {
+  cpp_ctx* ctx = n->ctx;
+  for (int i = 2; i >= 0; --i) {
+    const ConvL& L = n->conv[i];
+    const long zbs = (long)L.H * L.W * kConvOut;
+    ConvArgs dd; memset(&dd, 0, sizeof(dd));
+    conv_dy_desc(n, w, i, dd, B);
+    RC(launch_bn_backward(ctx, w.z[i], zbs, w.bn_stat[i], n->params + L.b_off, dd.dy.dpool, dd.dy.dpool_bstride, dd.dy.pool,
+                          dd.dy.pool_bstride, dd.dy.amax, B, L.H, L.W, kConvOut, n->bn_part, n->bn_means, n->grads + L.b_off));
+    int mode;
+    ConvArgs d = conv_dw_args(n, w, i, state, dtype, white, B, &mode);
+    d.dy_dense = w.z[i]; d.dy_dense_bstride = zbs;
+    RC(launch_conv_dw(ctx, kDwKid[i], L.Cin, L.ks, mode, d, n->grads + L.w_off, n->bn_scratch));
+    if (i > 0) {
+      ConvArgs x; memset(&x, 0, sizeof(x));
+      x.in = w.z[i]; x.in_bstride = zbs; x.w = n->params + L.w_off; x.nout = L.Cin;
+      x.out = w.dpool[i - 1]; x.out_bstride = (long)L.H * L.W * L.Cin;
+      x.B = B; x.H = L.H; x.W = L.W;
+      RC(launch_conv_fwd(ctx, kDxKid[i], kConvOut, L.ks, IN_F32_FLIP, EPI_PLAIN, x));
+    }
+  }
+  return CPP_OK;
+}
+
 static int net_backward_conv(cpp_net* n, Workspace& w, int B, const void* state, int dtype, const float* white) {
   cpp_ctx* ctx = n->ctx;
+  if (n->spec.use_batch_norm) return net_backward_conv_bn(n, w, B, state, dtype, white);
   for (int i = 2; i >= 0; --i) {
     const ConvL& L = n->conv[i];
     int mode;
@@ -498,6 +525,10 @@ static int net_backward_conv(cpp_net* n, Workspace& w, int B, const void* state,
 
 // the same for several networks with identical geometry, every layer's kernels batched into one launch
 static int nets_backward_conv(cpp_ctx* ctx, cpp_net* const* nets, int nn, int B, const void* state, int dtype, const float* white) {
+  if (nets[0]->spec.use_batch_norm) {                 // per network (the batched launches are for the fused path)
+    for (int k = 0; k < nn; ++k) RC(net_backward_conv_bn(nets[k], nets[k]->ws[0], B, state, dtype, white));
+    return CPP_OK;
+  }
   for (int i = 2; i >= 0; --i) {
     const ConvL& L = nets[0]->conv[i];
     ConvArgs dl[CONV_BATCH_MAX], xl[CONV_BATCH_MAX]; float *gw[CONV_BATCH_MAX], *gb[CONV_BATCH_MAX];
@@ -1225,7 +1256,7 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b) {
   // ---- forward: the four conv trunks.  conv1 saturates the chip per network; the narrow conv2 / conv3 layers
   // of all four networks share one launch each.
   int tA, tC, tTA, tTC;
-  if (a->spec.pixel) {
+  if (a->spec.pixel && !a->spec.use_batch_norm) {
     cpp_net* nets[4] = {a, c, ta, tc};
     const void* sts[4] = {s1, s1, s2, s2};
     const float* whs[4] = {w1, w1, w2, w2};

@@ -46,3 +46,54 @@ def test_inference_mode_uses_the_initial_moving_statistics(shape, B):
         assert np.abs(q - wq).max() < 1e-5 and np.abs(td - wtd).max() < 1e-5 and abs(loss - wl) < 1e-5 * max(1.0, abs(wl))
     finally:
         agent.close()
+
+
+@pytest.mark.parametrize("shape,B", CASES)
+def test_training_mode_gradients(shape, B):
+    """the train ops feed IS_TRAINING True for the whole graph: batch statistics in every network (targets included),
+    gradients through the batch moments, dbeta in the '<conv>/BatchNorm/beta' slot."""
+    agent, ref, (aspec, cspec) = make_pair(shape, B, True, use_batch_norm=True)
+    rng = np.random.default_rng(5)
+    t = O.synthetic_batch(rng, B, shape, 2, True)
+    hb = host_batch(t)
+    try:
+        pa = agent.actor.get_params()
+        agent.actor.train(hb.state_1)
+        assert_grads_close_modulo_pool_ties(
+            aspec, agent.actor, B, ref.actor, lambda: ref.actor.forward(t[0]),
+            lambda: ref.actor_gradients(t[0])["grads"], agent.actor.get_grads(), what="actor grads (batch norm)", rel=5e-5)
+        agent.actor.set_params(pa)
+        agent.critic.train(hb)
+        assert_grads_close_modulo_pool_ties(
+            cspec, agent.critic, B, ref.critic, lambda: ref.critic.forward(t[0], action=np.asarray(t[1])),
+            lambda: ref.critic_gradients(t)["grads"], agent.critic.get_grads(), what="critic grads (batch norm)", rel=5e-5)
+    finally:
+        agent.close()
+
+
+@pytest.mark.parametrize("shape,B", [CASES[0], CASES[2]])
+def test_fused_train_step_with_batch_norm(shape, B):
+    """cpp_ddpg_train_step on batch-norm networks == the oracle's minibatch loop (parameters after two minibatches and a
+    target update)."""
+    agent, ref, (aspec, cspec) = make_pair(shape, B, True, use_batch_norm=True, replay_size=32)
+    rng = np.random.default_rng(9)
+    try:
+        n = 12
+        frames = [(rng.integers(0, 256, shape).astype(np.float16) / np.float16(255)) for _ in range(n + 1)]
+        seq = [(rng.uniform(-1, 1, (1, 2)).astype(np.float32), float(rng.uniform(0, 1)), frames[i + 1]) for i in range(n)]
+        agent.replay_memory.add_episode(frames[0], seq)
+        idxs = rng.integers(0, n, 2 * B)
+        batches = []
+        for k in range(2):
+            ii = idxs[k * B:(k + 1) * B]
+            batches.append((np.stack([frames[i] for i in ii]), np.stack([seq[i][0][0] for i in ii]),
+                            np.array([[seq[i][1]] for i in ii], np.float32),
+                            np.array([[0.0 if i == n - 1 else 1.0] for i in ii], np.float32),
+                            np.stack([frames[i + 1] for i in ii])))
+        ref.train_step(batches)
+        agent.train_step(B, 2, idxs=idxs)
+        assert_flat_close(aspec, agent.actor.get_params(), ref.actor.flat(), rel=2e-5, what="actor params")
+        assert_flat_close(cspec, agent.critic.get_params(), ref.critic.flat(), rel=2e-5, what="critic params")
+        assert_flat_close(aspec, agent.target_actor.get_params(), ref.target_actor.flat(), rel=2e-5, what="target actor")
+    finally:
+        agent.close()
