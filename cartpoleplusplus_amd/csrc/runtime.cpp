@@ -1612,7 +1612,7 @@ static int naf_compute_gradients(cpp_naf* f, cpp_batch* b) {
   if (!share) { tn[nt] = mu; ts[nt] = s1; tw[nt] = w1; ++nt; tn[nt] = lv; ts[nt] = s1; tw[nt] = w1; ++nt; }
   tn[nt] = tv; ts[nt] = s2; tw[nt] = w2; ++nt;
   int t1;
-  if (v->spec.pixel) {
+  if (v->spec.pixel && !v->spec.use_batch_norm) {
     std::vector<cpp_net*> nets(tn, tn + nt); std::vector<const void*> sts(ts, ts + nt); std::vector<const float*> whs(tw, tw + nt);
     t1 = G.fn([=] {
       for (int i = 0; i < 3; ++i) {
@@ -1622,9 +1622,9 @@ static int naf_compute_gradients(cpp_naf* f, cpp_batch* b) {
       }
       return (int)CPP_OK; }, {});
   } else {
-    std::vector<cpp_net*> nets(tn, tn + nt); std::vector<const void*> sts(ts, ts + nt);
-    t1 = G.fn([=] {
-      for (int k = 0; k < nt; ++k) RC(net_forward_trunk(nets[k], nets[k]->ws[0], sts[k], dt, nullptr, B));
+    std::vector<cpp_net*> nets(tn, tn + nt); std::vector<const void*> sts(ts, ts + nt); std::vector<const float*> whs(tw, tw + nt);
+    t1 = G.fn([=] {        // low-dim states, or batch-norm trunks (network by network: statistics between conv and ReLU)
+      for (int k = 0; k < nt; ++k) RC(net_forward_trunk(nets[k], nets[k]->ws[0], sts[k], dt, whs[k], B));
       return (int)CPP_OK; }, {});
   }
   // ---- forward MLPs
@@ -1708,7 +1708,10 @@ extern "C" int cpp_naf_action(cpp_naf* f, const void* state, int dtype, int B, f
   }
   HIP_CHECK(hipMemcpyAsync(n->stage_state, state, (size_t)B * n->state_elems * (dtype == CPP_F16 ? 2 : 4), hipMemcpyHostToDevice, ctx->stream));
   if (n->spec.pixel) RC(batch_stats(ctx, n->stage_state, nullptr, dtype, n->state_elems, B, n->spec.C, n->stats_part, n->white));
-  RC(net_forward_trunk(n, n->ws[0], n->stage_state, dtype, n->white, B));
+  n->is_training = false;                              // IS_TRAINING: False (naf_cartpole.py:253)
+  const int frc = net_forward_trunk(n, n->ws[0], n->stage_state, dtype, n->white, B);
+  n->is_training = true;
+  if (frc) return frc;
   RC(net_forward_fc(n, n->ws[0], 0, B, nullptr));
   if (f->share) RC(net_forward_fc(f->mu, f->mu->ws[0], 0, B, nullptr));
   HIP_CHECK(hipMemcpyAsync(out, f->mu->ws[0].out, (size_t)B * f->A * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -1758,7 +1761,10 @@ extern "C" int cpp_naf_debug_values(cpp_naf* f, cpp_batch* b, float* l_values, f
   cpp_ctx* ctx = f->ctx;
   HIP_CHECK(hipSetDevice(ctx->device));
   const int B = b->B, C = f->value->spec.pixel ? f->value->spec.C : 0;
-  RC(naf_forward(f, b->s[0], b->s[1], b->dtype, white_of(b, 0, C), white_of(b, 1, C), B));
+  for (cpp_net* n : {f->value, f->tvalue, f->mu, f->lv}) n->is_training = false;      // IS_TRAINING: False (naf_cartpole.py:282)
+  const int frc = naf_forward(f, b->s[0], b->s[1], b->dtype, white_of(b, 0, C), white_of(b, 1, C), B);
+  for (cpp_net* n : {f->value, f->tvalue, f->mu, f->lv}) n->is_training = true;
+  if (frc) return frc;
   RC(naf_head(f, b, false));
   hipStream_t st = ctx->stream;
   if (l_values) HIP_CHECK(hipMemcpyAsync(l_values, f->lv->ws[0].out, (size_t)B * f->NL * sizeof(float), hipMemcpyDeviceToHost, st));

@@ -326,6 +326,30 @@ class Net(object):
         c["out"] = h
         return c
 
+    def backward_trunk(self, c, dp):
+        """conv trunk backward from the gradient w.r.t. pool3 (B, h, w, 10): {name: grad} of the conv variables."""
+        sp, dt = self.spec, self.dt
+        g = collections.OrderedDict()
+        for idx in range(len(CONV_DEFS) - 1, -1, -1):
+            name = CONV_DEFS[idx][0]
+            x, pooled, amax, h, w = c[name]
+            dz = relu_pool_bwd(dp, pooled, amax, h, w)
+            if sp.batch_norm:
+                zhat, inv, training = c[name + ":bn"]
+                dbeta = dz.sum(axis=(0, 1, 2))
+                if training:       # through the batch moments
+                    m1 = dz.mean(axis=(0, 1, 2), dtype=np.float64).astype(dt)
+                    m2 = (dz * zhat).mean(axis=(0, 1, 2), dtype=np.float64).astype(dt)
+                    dz = (inv * (dz - m1 - zhat * m2)).astype(dt)
+                else:
+                    dz = (inv * dz).astype(dt)
+                dW, _db, dp = conv_bwd(x, self.p[name + "/weights"], dz, need_dx=idx > 0)
+                db = dbeta
+            else:
+                dW, db, dp = conv_bwd(x, self.p[name + "/weights"], dz, need_dx=idx > 0)
+            g[name + "/weights"], g[name + "/biases"] = dW, db
+        return g
+
     def backward(self, c, dout, params=True):
         """Returns (grads OrderedDict in layout order or None, d_action or None)."""
         sp, dt = self.spec, self.dt
@@ -346,25 +370,7 @@ class Net(object):
         if not params:
             return None, d_action
         if sp.pixel:
-            dp = dh.reshape(c["pool_shape"])
-            for idx in range(len(CONV_DEFS) - 1, -1, -1):
-                name = CONV_DEFS[idx][0]
-                x, pooled, amax, h, w = c[name]
-                dz = relu_pool_bwd(dp, pooled, amax, h, w)
-                if sp.batch_norm:
-                    zhat, inv, training = c[name + ":bn"]
-                    dbeta = dz.sum(axis=(0, 1, 2))
-                    if training:       # through the batch moments
-                        m1 = dz.mean(axis=(0, 1, 2), dtype=np.float64).astype(dt)
-                        m2 = (dz * zhat).mean(axis=(0, 1, 2), dtype=np.float64).astype(dt)
-                        dz = (inv * (dz - m1 - zhat * m2)).astype(dt)
-                    else:
-                        dz = (inv * dz).astype(dt)
-                    dW, _db, dp = conv_bwd(x, self.p[name + "/weights"], dz, need_dx=idx > 0)
-                    db = dbeta
-                else:
-                    dW, db, dp = conv_bwd(x, self.p[name + "/weights"], dz, need_dx=idx > 0)
-                g[name + "/weights"], g[name + "/biases"] = dW, db
+            g.update(self.backward_trunk(c, dh.reshape(c["pool_shape"])))
         ordered = collections.OrderedDict((n, g[n]) for n, _s in sp.layout())
         return ordered, d_action
 

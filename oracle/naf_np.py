@@ -30,10 +30,11 @@ class HeadSpec(O.NetSpec):
     """trunk + hidden stack like the actor, then one 'fc' head (naf_cartpole.py:105-109,156-161,180-184).
     head_only: no trunk / hidden layers -- the input is another network's state representation."""
 
-    def __init__(self, head_out, head_act, hidden, pixel, H=0, W=0, C=0, state_elems=0, head_only=False):
+    def __init__(self, head_out, head_act, hidden, pixel, H=0, W=0, C=0, state_elems=0, head_only=False,
+                 batch_norm=False):
         self.head_out, self.head_act, self.head_only = int(head_out), head_act, head_only
         O.NetSpec.__init__(self, "actor", head_out, [] if head_only else hidden, pixel and not head_only,
-                           H, W, C, state_elems)
+                           H, W, C, state_elems, batch_norm=batch_norm)
 
     def _fc_layers(self):
         out, n_in = [], self.flat
@@ -116,31 +117,33 @@ class NAF(object):
             return None
         return O.whiten_stats(np.asarray(s).reshape(-1, sp.H, sp.W, sp.C), self.dt)
 
-    def _forward(self, s1):
+    def _forward(self, s1, training=True):
         w1 = self._white(self.value, s1)
-        cv = self.value.forward(s1, white=w1)
+        cv = self.value.forward(s1, white=w1, training=training)
         if self.share:
             rep = cv["fc"][-1][0]          # input of value's 'fc' head = input_state_representation
             cm, cl = self.mu.forward(rep), self.l.forward(rep)
         else:
-            cm, cl = self.mu.forward(s1, white=w1), self.l.forward(s1, white=w1)
+            cm, cl = self.mu.forward(s1, white=w1, training=training), self.l.forward(s1, white=w1, training=training)
         return cv, cm, cl
 
     def action_given(self, state):
-        return self._forward(np.asarray(state)[None])[1]["out"]
+        return self._forward(np.asarray(state)[None], training=False)[1]["out"]      # IS_TRAINING: False (:253)
 
     def forward_backward(self, batch, backward=True):
         s1, a, r, mask, s2 = batch
         dt, A = self.dt, self.A
         B = np.asarray(a).shape[0]
-        cv, cm, cl = self._forward(s1)
+        # naf_cartpole.py:271 feeds IS_TRAINING True to the train op (whole graph, target network included); the debug
+        # fetch of :282 feeds False
+        cv, cm, cl = self._forward(s1, training=backward)
         V, mu, lv = cv["out"], cm["out"], cl["out"]
         L = build_L(lv, A, dt)
         d = np.asarray(a, dt) - mu                                   # (B, A)
         z = np.einsum("bij,bi->bj", L, d)                            # L^T d
         adv = (-0.5 * (z * z).sum(axis=1, keepdims=True)).astype(dt)  # -1/2 d^T L L^T d
         q = V + adv
-        tv = self.target_value.forward(s2)["out"]
+        tv = self.target_value.forward(s2, training=backward)["out"]
         y = np.asarray(r, dt) + np.asarray(mask, dt) * dt(self.discount) * tv
         td = q - y
         loss = (td * td).mean(dtype=dt)
@@ -206,13 +209,7 @@ class NAF(object):
             g[name + "/weights"] = h.T @ dz
             dh = dz @ net.p[name + "/weights"].T
         if sp.pixel:
-            dp = dh.reshape(c["pool_shape"])
-            for idx in range(len(O.CONV_DEFS) - 1, -1, -1):
-                name = O.CONV_DEFS[idx][0]
-                x, pooled, amax, hh, ww = c[name]
-                dzc = O.relu_pool_bwd(dp, pooled, amax, hh, ww)
-                dW, db, dp = O.conv_bwd(x, net.p[name + "/weights"], dzc, need_dx=idx > 0)
-                g[name + "/weights"], g[name + "/biases"] = dW, db
+            g.update(net.backward_trunk(c, dh.reshape(c["pool_shape"])))
         return g, None
 
     def apply(self, grads):

@@ -97,3 +97,31 @@ def test_fused_train_step_with_batch_norm(shape, B):
         assert_flat_close(aspec, agent.target_actor.get_params(), ref.target_actor.flat(), rel=2e-5, what="target actor")
     finally:
         agent.close()
+
+
+@pytest.mark.parametrize("shape,B,share", [((8, 8, 3, 1, 2), 4, True), ((12, 10, 3, 1, 3), 3, False), ((64, 64, 3, 2, 3), 2, True)],
+                         ids=["8x8x6-share", "12x10x9-own-trunks", "64x64x18-share-cfg4"])
+def test_naf_with_batch_norm(shape, B, share):
+    """NAF (naf_cartpole.py:93-284) on batch-norm trunks: the debug fetch (:282) and action_given (:253) run in
+    inference mode, the train op (:271) in training mode."""
+    from tests.test_gpu_naf import make_naf, HB as NHB, CatSpec, params_of, ATOL
+    agent, ref, specs = make_naf(shape, B, share, use_batch_norm=True)
+    rng = np.random.default_rng(4)
+    t = O.synthetic_batch(rng, B, shape, 2, True)
+    try:
+        dbg = ref.forward_backward(t, backward=False)
+        l_values, loss, v, a, vp = agent.naf.debug_values(NHB(t))
+        assert np.abs(l_values - dbg["l_values"]).max() < ATOL and np.abs(v - dbg["value"][:, 0]).max() < ATOL
+        assert np.abs(vp - dbg["target_value"][:, 0]).max() < ATOL
+        assert abs(loss - dbg["loss"]) < ATOL * max(1.0, abs(dbg["loss"]))
+        one = agent.naf.action_given(t[0][0].astype(np.float32), add_noise=False)
+        assert np.abs(one - ref.action_given(t[0][0])).max() < ATOL
+        out = ref.forward_backward(t)
+        got_loss = agent.naf.train(NHB(t))
+        assert abs(got_loss - out["loss"]) < ATOL * max(1.0, abs(out["loss"]))
+        cat = CatSpec(specs)
+        assert_flat_close(cat, agent.naf.get_grads(), out["grads"], rel=5e-5, what="naf grads (batch norm)")
+        ref.apply(out["grads"])
+        assert_flat_close(cat, params_of(agent), ref.flat(), rel=1e-5, what="naf params (batch norm)")
+    finally:
+        agent.close()
