@@ -30,6 +30,7 @@ WORKLOADS = {
     "cfg3": ((64, 64, 3, 2, 3), 256),    # 64x64x18, B=256 -- the configuration the metric is quoted on
     "cfg2": ((64, 64, 3, 1, 3), 256),    # 64x64x9
     "cfg5": ((128, 128, 3, 2, 5), 512),  # 128x128x30, B=512 (BASELINE configs[4]; replay rows reduced, see REPLAY_ROWS_BY)
+    "r50": ((50, 50, 3, 2, 3), 256),     # the reference's default 50x50 render (exps/run_98.sh: 2 cameras, 3 repeats)
 }
 REPLAY_ROWS_BY = {"cfg5": 6000}          # 9000 state slots x 983 KB = 8.8 GB (the 1e6-row memory of configs[4] is 1.47 TB / 8 GPUs)
 BATCHES_PER_STEP = 5                     # --batches-per-step default (ddpg_cartpole.py:30)
@@ -82,6 +83,7 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=10, help="minibatches of the per-kernel HIP-event pass")
+    ap.add_argument("--use-batch-norm", action="store_true", help="informational: the networks of exps/run_8x / run_9x (--use-batch-norm)")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel learner path (RCCL all-reduce) even at world size 1")
     args = ap.parse_args()
 
@@ -123,7 +125,8 @@ def main():
 
     D.set_opts(D.default_opts(use_raw_pixels=True, render_height=shape[0], render_width=shape[1],
                               num_cameras=shape[3], action_repeats=shape[4], batch_size=B,
-                              replay_memory_size=replay_rows, sample_seed=1234 + rank))
+                              replay_memory_size=replay_rows, sample_seed=1234 + rank,
+                              use_batch_norm=bool(args.use_batch_norm)))
     agent = D.DeepDeterministicPolicyGradientAgent(Env())
     agent.initialise_variables(seed=42)                 # identical replicas on every rank
     agent.post_var_init_setup()
@@ -213,9 +216,9 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: DDPG pixel obs %dx%dx%d, batch=%d per GPU, replay %d rows/GPU in HBM (f16), "
-                               "target soft-update every %d minibatches" % (
+                               "target soft-update every %d minibatches%s" % (
                                    args.workload, shape[0], shape[1], int(np.prod(shape[2:])), B, replay_rows,
-                                   BATCHES_PER_STEP),
+                                   BATCHES_PER_STEP, ", --use-batch-norm" if args.use_batch_norm else ""),
                    "parallelism": "dp%d (one learner per GPU, flat-gradient all-reduce per minibatch)" % world,
                    "global_steps_per_sec": round(steps / elapsed, 3),
                    "conv_gflop_per_step": round(conv_flops_step / 1e9, 3),

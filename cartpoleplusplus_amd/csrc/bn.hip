@@ -14,10 +14,13 @@
 //             kernels.
 #include "common.h"
 
+// CT: compile-time channel count (10 for every layer of this trunk: cheap index arithmetic), 0: use the argument
+template <int CT>
 __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restrict__ z, long z_bstride,
                                                            const float* __restrict__ stat, const float* __restrict__ beta,
                                                            float* __restrict__ pool, long pool_bstride,
-                                                           uint8_t* __restrict__ amax, int B, int H, int W, int C) {
+                                                           uint8_t* __restrict__ amax, int B, int H, int W, int Carg) {
+  const int C = CT ? CT : Carg;
   const int Hp = H >> 1, Wp = W >> 1;
   const long ncell = (long)B * Hp * Wp * C;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < ncell; idx += (long)gridDim.x * 256) {
@@ -47,8 +50,10 @@ int launch_bn_relu_pool(cpp_ctx* ctx, const float* z, long z_bstride, const floa
   if (grid > 4096) grid = 4096;
   if (grid < 1) grid = 1;
   prof_begin(ctx);
-  hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(grid), dim3(256), 0, ctx->stream, z, z_bstride, stat, beta, pool,
-                     pool_bstride, amax, B, H, W, C);
+  if (C == 10) hipLaunchKernelGGL(bn_relu_pool_kernel<10>, dim3(grid), dim3(256), 0, ctx->stream, z, z_bstride, stat, beta, pool,
+                                  pool_bstride, amax, B, H, W, C);
+  else hipLaunchKernelGGL(bn_relu_pool_kernel<0>, dim3(grid), dim3(256), 0, ctx->stream, z, z_bstride, stat, beta, pool,
+                          pool_bstride, amax, B, H, W, C);
   LAUNCH_CHECK();
   prof_end(ctx, K_ELEMENTWISE);
   return 0;
@@ -100,10 +105,12 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nblk
 }
 
 // z (plain conv output) -> dz in place
+template <int CT>
 __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(float* __restrict__ z, long z_bstride, const float* __restrict__ stat,
                                                         const float* __restrict__ means, const float* __restrict__ dpool,
                                                         long dpool_bstride, const float* __restrict__ pool, long pool_bstride,
-                                                        const uint8_t* __restrict__ amax, int B, int H, int W, int C) {
+                                                        const uint8_t* __restrict__ amax, int B, int H, int W, int Carg) {
+  const int C = CT ? CT : Carg;
   const int Hp = H >> 1, Wp = W >> 1;
   const long n = (long)B * H * W * C;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
@@ -141,8 +148,10 @@ int launch_bn_backward(cpp_ctx* ctx, float* z, long z_bstride, const float* stat
   const long n = (long)B * H * W * C;
   int grid = (int)((n + 255) / 256);
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(bn_bwd_dz_kernel, dim3(grid), dim3(256), 0, ctx->stream, z, z_bstride, stat, means, dpool,
-                     dpool_bstride, pool, pool_bstride, amax, B, H, W, C);
+  if (C == 10) hipLaunchKernelGGL(bn_bwd_dz_kernel<10>, dim3(grid), dim3(256), 0, ctx->stream, z, z_bstride, stat, means, dpool,
+                                  dpool_bstride, pool, pool_bstride, amax, B, H, W, C);
+  else hipLaunchKernelGGL(bn_bwd_dz_kernel<0>, dim3(grid), dim3(256), 0, ctx->stream, z, z_bstride, stat, means, dpool,
+                          dpool_bstride, pool, pool_bstride, amax, B, H, W, C);
   LAUNCH_CHECK();
   prof_end(ctx, K_ELEMENTWISE);
   return 0;

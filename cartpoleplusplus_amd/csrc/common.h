@@ -140,6 +140,8 @@ int launch_bn_backward(cpp_ctx* ctx, float* z, long z_bstride, const float* stat
 int launch_stats_finalize(cpp_ctx* ctx, const double* part, int nparts, int which_count, int C,
                           double count, float* white, double eps = 1e-6);
 int launch_stats_generic(cpp_ctx* ctx, const void* x, int dtype, long npix, int C, float* white, double eps = 1e-6);
+size_t stats_wide_part_doubles(int C);
+int launch_stats_wide(cpp_ctx* ctx, const void* x, int dtype, long npix, int C, double* part, float* white, double eps);
 int launch_replay_fill(cpp_ctx* ctx, __half* store, long elems, int slots, int32_t* s1, int32_t* s2,
                        float* action, float* reward, float* mask, int rows, int action_dim,
                        uint64_t seed);

@@ -305,6 +305,7 @@ extern "C" int cpp_net_create(cpp_ctx* ctx, const cpp_net_spec* spec, int max_ba
     if (spec->use_batch_norm) {
       size_t pd = (size_t)2 * max_batch * 2 * kConvOut;
       if (pd < bn_bwd_part_doubles(kConvOut)) pd = bn_bwd_part_doubles(kConvOut);
+      if (pd < stats_wide_part_doubles(kConvOut)) pd = stats_wide_part_doubles(kConvOut);
       if ((rc = n->arena.alloc((void**)&n->bn_part, pd * sizeof(double), false))) return fail(rc);
       if ((rc = dalloc(n->arena, &n->bn_means, (size_t)2 * kConvOut))) return fail(rc);
       if ((rc = dalloc(n->arena, &n->bn_scratch, (size_t)kConvOut))) return fail(rc);
@@ -434,7 +435,7 @@ static int bn_forward_stats(cpp_net* n, const float* z, int B, int H, int W, flo
     RC(launch_gather_stats(ctx, ga, CPP_F32));
     return launch_stats_finalize(ctx, n->bn_part, B, 1, kConvOut, (double)B * H * W, stat, kBnEps);
   }
-  return launch_stats_generic(ctx, z, CPP_F32, (long)B * H * W, kConvOut, stat, kBnEps);
+  return launch_stats_wide(ctx, z, CPP_F32, (long)B * H * W, kConvOut, n->bn_part, stat, kBnEps);
 }
 
 // conv trunk (pixel) or state conversion (low-dim) into ws.fcin[0]

@@ -12,6 +12,7 @@ CASES = [
     pytest.param((8, 8, 3, 1, 2), 4, id="8x8x6-B4"),
     pytest.param((12, 10, 3, 1, 3), 3, id="12x10x9-B3-oddpool"),
     pytest.param((64, 64, 3, 2, 3), 2, id="64x64x18-B2-cfg3-shape"),
+    pytest.param((50, 50, 3, 2, 3), 2, id="50x50x18-B2-exps-run_98-shape"),     # 1800-byte f16 rows: 8-byte staging chunks
 ]
 
 
@@ -125,3 +126,16 @@ def test_naf_with_batch_norm(shape, B, share):
         assert_flat_close(cat, params_of(agent), ref.flat(), rel=1e-5, what="naf params (batch norm)")
     finally:
         agent.close()
+
+
+def test_cli_with_batch_norm(capsys):
+    """ddpg_cartpole.main --use-batch-norm end to end on the stand-in env (rollouts in inference mode, fused training
+    steps in training mode)."""
+    import json
+    from cartpoleplusplus_amd import ddpg_cartpole as D
+    D.main(["--synthetic-env", "--use-raw-pixels", "--use-batch-norm", "--render-width", "16", "--render-height", "16",
+            "--batch-size", "8", "--replay-memory-size", "120", "--replay-memory-burn-in", "20", "--max-episode-len", "12",
+            "--max-num-actions", "60"])
+    out = capsys.readouterr().out
+    stats = [json.loads(l.split("\t", 1)[1]) for l in out.splitlines() if l.startswith("STATS")]
+    assert len(stats) >= 4 and any(np.isfinite(s["mean_losses"]) for s in stats)

@@ -174,11 +174,13 @@ NAF_CASES = [
     dict(shape=(12, 10, 3, 1, 3), B=3, pixel=True, share=False),
     dict(shape=(2, 2, 7), B=6, pixel=False, share=True),
     dict(shape=(2, 2, 7), B=6, pixel=False, share=False),
+    dict(shape=(8, 8, 3, 1, 2), B=4, pixel=True, share=True, batch_norm=True),
+    dict(shape=(12, 10, 3, 1, 3), B=3, pixel=True, share=False, batch_norm=True),
 ]
 
 
-def naf_specs(shape, pixel, share, A=2, hidden=(100, 50)):
-    kw = dict(pixel=True, H=shape[0], W=shape[1], C=int(np.prod(shape[2:]))) if pixel else \
+def naf_specs(shape, pixel, share, A=2, hidden=(100, 50), batch_norm=False):
+    kw = dict(pixel=True, H=shape[0], W=shape[1], C=int(np.prod(shape[2:])), batch_norm=batch_norm) if pixel else \
         dict(pixel=False, state_elems=int(np.prod(shape)))
     vspec = N.HeadSpec(1, "linear", list(hidden), **kw)
     if share:
@@ -194,7 +196,7 @@ def naf_specs(shape, pixel, share, A=2, hidden=(100, 50)):
 def test_naf_gradients_match_autograd(case):
     rng = np.random.default_rng(17)
     shape, B, pixel, share = case["shape"], case["B"], case["pixel"], case["share"]
-    vspec, mspec, lspec = naf_specs(shape, pixel, share)
+    vspec, mspec, lspec = naf_specs(shape, pixel, share, batch_norm=case.get("batch_norm", False))
     vf = N.init_head_params(vspec, rng) + rng.normal(0, 0.05, vspec.num_params()).astype(np.float32)
     mf = N.init_head_params(mspec, rng, small_head=True) + rng.normal(0, 0.05, mspec.num_params()).astype(np.float32)
     lf = N.init_head_params(lspec, rng) + rng.normal(0, 0.05, lspec.num_params()).astype(np.float32)
@@ -213,7 +215,7 @@ def test_naf_gradients_match_autograd(case):
         if vspec.pixel:
             full = torch_forward(vspec, p, x)      # value
             # representation = input of the last layer: recompute without the head
-            sub = N.HeadSpec(1, "linear", vspec.hidden, True, vspec.H, vspec.W, vspec.C)
+            sub = N.HeadSpec(1, "linear", vspec.hidden, True, vspec.H, vspec.W, vspec.C, batch_norm=vspec.batch_norm)
             sub.fc = vspec.fc[:-1]
             rep = torch_forward(sub, p, x)
         else:
