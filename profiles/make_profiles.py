@@ -23,8 +23,9 @@ SHORT = [("void conv_fwd_kernel<18, 5, 4, 0, 0>", "conv1_fwd"), ("void conv_dw_k
          ("void conv_fwd_kernel<10, 3, 1, 3, 1>", "conv3_dx"), ("void conv_dw_kernel<10, 3, 1, 2>", "conv3_dw"),
          ("void gather_stats_kernel<__half>", "gather_stats"), ("gemm_batch_kernel", "gemm_batch"),
          # (ky,o)-column forward kernels: <CIN, KS, XT, IPW, IN_MODE>
-         ("void conv_fwd_kyo_kernel<18, 5, 1, 1, 0>", "conv1_fwd"), ("void conv_fwd_kyo_kernel<10, 5, 1, 2, 2>", "conv2_fwd"),
-         ("void conv_fwd_kyo_kernel<10, 3, 1, 4, 2>", "conv3_fwd"), ("void conv_dw_kyo_kernel<18, 5", "conv1_dw")]
+         ("void conv_fwd_kyo_kernel<18, 5, 1, 1, 0,", "conv1_fwd"), ("void conv_fwd_kyo_kernel<10, 5, 1, 2, 2,", "conv2_fwd"),
+         ("void conv_fwd_kyo_kernel<10, 3, 1, 4, 2,", "conv3_fwd"), ("void conv_dw_kyo_kernel<18, 5", "conv1_dw"),
+         ("void conv_fwd_kyo_kernel<10, 5, 1, 2, 3,", "conv2_dx"), ("void conv_dw_kyo_kernel<10, 5", "conv2_dw")]
 
 
 def short(name):
