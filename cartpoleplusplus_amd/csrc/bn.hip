@@ -22,13 +22,13 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restri
                                                            uint8_t* __restrict__ amax, int B, int H, int W, int Carg) {
   const int C = CT ? CT : Carg;
   const int Hp = H >> 1, Wp = W >> 1;
-  const long ncell = (long)B * Hp * Wp * C;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < ncell; idx += (long)gridDim.x * 256) {
-    const int o = (int)(idx % C);
-    long r = idx / C;
-    const int px = (int)(r % Wp); r /= Wp;
-    const int py = (int)(r % Hp);
-    const int b = (int)(r / Hp);
+  const unsigned ncell = (unsigned)B * Hp * Wp * C;      // 32-bit index arithmetic (64-bit divisions dominated this kernel)
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < ncell; idx += gridDim.x * 256u) {
+    const int o = (int)(idx % (unsigned)C);
+    unsigned r = idx / (unsigned)C;
+    const int px = (int)(r % (unsigned)Wp); r /= (unsigned)Wp;
+    const int py = (int)(r % (unsigned)Hp);
+    const int b = (int)(r / (unsigned)Hp);
     const float inv = stat[o], sh = stat[C + o], be = beta[o];
     const float* zp = z + (long)b * z_bstride + ((long)(2 * py) * W + 2 * px) * C + o;
     const float v0 = (zp[0] * inv + sh) + be, v1 = (zp[C] * inv + sh) + be;
@@ -71,9 +71,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   if (t < active) {
     const float be = beta[t % C];
     const long ncell = (long)B * cells_per_img;
-    for (long idx = (long)blockIdx.x * active + t; idx < ncell; idx += (long)gridDim.x * active) {
-      const int b = (int)(idx / cells_per_img);
-      const long e = idx - (long)b * cells_per_img;
+    for (unsigned idx = blockIdx.x * (unsigned)active + t; idx < (unsigned)ncell; idx += gridDim.x * (unsigned)active) {
+      const int b = (int)(idx / (unsigned)cells_per_img);
+      const long e = (long)idx - (long)b * cells_per_img;
       const float pv = pool[(long)b * pool_bstride + e];
       if (pv > 0.f) {
         const float g = dpool[(long)b * dpool_bstride + e];
@@ -92,16 +92,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   }
 }
 
-// means[2][C] = (sum dy, sum dy*zhat) / N in fixed block order; dbeta = sum dy
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nblk, int C, double n, float* __restrict__ means,
-                                       float* __restrict__ dbeta) {
-  const int c = threadIdx.x;
-  if (c >= C) return;
+// means[2][C] = (sum dy, sum dy*zhat) / N; dbeta = sum dy.  One 64-lane wave per channel: lanes stride over the block
+// partials, fixed-order butterfly combine (deterministic; a single thread walking 256 partials took 60 us)
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __restrict__ part, int nblk, int C, double n,
+                                                             float* __restrict__ means, float* __restrict__ dbeta) {
+  const int c = blockIdx.x;
   double a1 = 0.0, a2 = 0.0;
-  for (int k = 0; k < nblk; ++k) { a1 += part[((long)k * 2 + 0) * C + c]; a2 += part[((long)k * 2 + 1) * C + c]; }
-  means[c] = (float)(a1 / n);
-  means[C + c] = (float)(a2 / n);
-  dbeta[c] = (float)a1;
+  for (int k = threadIdx.x; k < nblk; k += 64) { a1 += part[((long)k * 2 + 0) * C + c]; a2 += part[((long)k * 2 + 1) * C + c]; }
+  for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
+  if (threadIdx.x == 0) {
+    means[c] = (float)(a1 / n);
+    means[C + c] = (float)(a2 / n);
+    dbeta[c] = (float)a1;
+  }
 }
 
 // z (plain conv output) -> dz in place
@@ -112,13 +115,13 @@ __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(float* __restrict__ z, l
                                                         const uint8_t* __restrict__ amax, int B, int H, int W, int Carg) {
   const int C = CT ? CT : Carg;
   const int Hp = H >> 1, Wp = W >> 1;
-  const long n = (long)B * H * W * C;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
-    const int o = (int)(idx % C);
-    long r = idx / C;
-    const int x = (int)(r % W); r /= W;
-    const int y = (int)(r % H);
-    const int b = (int)(r / H);
+  const unsigned n = (unsigned)B * H * W * C;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < n; idx += gridDim.x * 256u) {
+    const int o = (int)(idx % (unsigned)C);
+    unsigned r = idx / (unsigned)C;
+    const int x = (int)(r % (unsigned)W); r /= (unsigned)W;
+    const int y = (int)(r % (unsigned)H);
+    const int b = (int)(r / (unsigned)H);
     float* zp = z + (long)b * z_bstride + ((long)y * W + x) * C + o;
     const float inv = stat[o];
     const float zhat = *zp * inv + stat[C + o];
@@ -143,7 +146,7 @@ int launch_bn_backward(cpp_ctx* ctx, float* z, long z_bstride, const float* stat
   prof_begin(ctx);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(BN_BWD_BLOCKS), dim3(256), 0, ctx->stream, dpool, dpool_bstride, pool,
                      pool_bstride, beta, B, cells, C, part);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, part, BN_BWD_BLOCKS, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, ctx->stream, part, BN_BWD_BLOCKS, C,
                      (double)B * H * W, means, dbeta);
   const long n = (long)B * H * W * C;
   int grid = (int)((n + 255) / 256);
