@@ -53,7 +53,8 @@ int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, i
   // chunks (CPP_CONV_KYO=0 selects the (ky,(kx,c)) x o kernel for A/B measurements)
   static const bool no_kyo = getenv("CPP_CONV_KYO") != nullptr && atoi(getenv("CPP_CONV_KYO")) == 0;
   const bool dx_mode = in_mode == IN_DY || in_mode == IN_F32_FLIP;      // dX passes: plain rows out
-  bool kyo = !no_kyo && a.nout <= 10 && a.H >= 2 && ((epi == EPI_RELU_POOL && !dx_mode) || (epi == EPI_PLAIN && dx_mode));
+  const bool plain_fwd = epi == EPI_PLAIN && !dx_mode;                   // batch norm: plain conv output
+  bool kyo = !no_kyo && a.nout <= 10 && a.H >= 2;
   int chb = 16;
   for (int i = 0; i < n && kyo; ++i) {
     const int c = chunk_bytes_for(batch.a[i], in_mode, cin);
@@ -64,7 +65,8 @@ int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, i
   if ((in_mode == IN_F32_PLAIN || dx_mode) && no_kyo23) kyo = false;
   if (kyo) {
     bool handled = false;
-    rc = (in_mode == IN_F32_PLAIN || dx_mode) ? conv_fwd_kyo_dispatch_l23(ctx, cin, ks, in_mode, chb, batch, &handled)
+    rc = plain_fwd ? conv_fwd_kyo_dispatch_plain(ctx, cin, ks, in_mode, chb, batch, &handled)
+       : (in_mode == IN_F32_PLAIN || dx_mode) ? conv_fwd_kyo_dispatch_l23(ctx, cin, ks, in_mode, chb, batch, &handled)
                                               : conv_fwd_kyo_dispatch_l1(ctx, cin, ks, in_mode, chb, batch, &handled);
     if (handled) { prof_end(ctx, kid); return rc; }
   }

@@ -71,7 +71,8 @@ struct KyoGeom {
 
 // CHB: bytes per staging chunk -- 16 when the image rows are 16-byte multiples (64 x 64 x 18 f16), 8 or 4 otherwise (the
 // reference's default 50 x 50 render: 1800-byte rows)
-template <int CIN, int KS, int XT, int IPW, int IN_MODE, int CHB = 16>
+// PLAIN: write the plain conv output rows (no bias / ReLU / pool): batch norm needs the statistics of z first
+template <int CIN, int KS, int XT, int IPW, int IN_MODE, int CHB = 16, bool PLAIN = false>
 __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_kernel(const ConvArgsN batch) {
   typedef KyoGeom<CIN, KS, XT, IPW> G;
   typedef typename StageType<IN_MODE>::type ST;
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
   constexpr bool DX = (IN_MODE == IN_DY);
   // IN_F32_FLIP: the same dX pass fed with DENSE dY rows (batch norm): plain f32 row staging, flipped weights, plain rows out
   constexpr bool FLIP = DX || (IN_MODE == IN_F32_FLIP);
+  constexpr bool PLAIN_OUT = FLIP || PLAIN;
   constexpr int P = G::P, NT = G::NT, NGT = G::NGT, ROWF = G::ROWF, NO = KYO_NO;
   constexpr int EPC = CHB / (int)sizeof(ST);          // elements per staging chunk
   static_assert(EPC >= 1, "chunk smaller than an element");
@@ -290,8 +292,8 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
     const int j = 16 * t + li;
     const bool valid = j < KS * NO;
     const int o = j % NO;
-    biast[t] = (!FLIP && valid && o < nout) ? a.bias[o] : 0.f;
-    eadr[t] = FLIP ? (uint32_t)(((sstrip * G::SW + 4 * lj) * nout + o) * 4)      // byte offset of (x = strip + 4 lj, o) in an output row
+    biast[t] = (!PLAIN_OUT && valid && o < nout) ? a.bias[o] : 0.f;
+    eadr[t] = PLAIN_OUT ? (uint32_t)(((sstrip * G::SW + 4 * lj) * nout + o) * 4)      // byte offset of (x = strip + 4 lj, o) in an output row
                  : keep_in_vgpr(lds_addr(ev + (lj * 2) * NO + o));
     const int p = valid ? j / NO : 0;
 #pragma unroll
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
   }
   const int simg_ok = sbimg < a.B ? sbimg : 0;
   const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      a.out + (long)simg_ok * a.out_bstride, 0, (FLIP ? H * W : Hp * Wp) * nout * 4, 0x00020000);   // uniform (per wave)
+      a.out + (long)simg_ok * a.out_bstride, 0, (PLAIN_OUT ? H * W : Hp * Wp) * nout * 4, 0x00020000);   // uniform (per wave)
   const __amdgpu_buffer_rsrc_t amax_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       a.out_amax + (long)simg_ok * Hp * Wp * nout, 0, Hp * Wp * nout, 0x00020000);
 
@@ -455,12 +457,13 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
           if (inr) {
 #pragma unroll
             for (int m = 0; m < XT; ++m) {
-              if (FLIP) {
+              if (PLAIN_OUT) {
                 if (y >= 0 && sbimg < a.B) {
 #pragma unroll
                   for (int r = 0; r < 4; ++r)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][t][r]), out_rsrc,
-                                                          (int)eadr[t] + ((m * 16 + r) * NO) * 4, y * W * nout * 4, 0);
+                    if (FLIP || sstrip * G::SW + m * 16 + 4 * lj + r < W)      // dX rows tile the strips exactly (dispatch)
+                      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][t][r]), out_rsrc,
+                                                            (int)eadr[t] + ((m * 16 + r) * NO) * 4, y * W * nout * 4, 0);
                 }
               } else if (y >= 0) {
                 const uint32_t ea = eadr[t] + (uint32_t)(par * (8 * XT * NO) * 8);
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
           }
         }
       }
-      if (!FLIP && y >= 0 && par == 1 && (y >> 1) < Hp) {   // wave-uniform: both rows of a pool pair are in the buffer
+      if (!PLAIN_OUT && y >= 0 && par == 1 && (y >> 1) < Hp) {   // wave-uniform: both rows of a pool pair are in the buffer
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -514,12 +517,12 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
 #endif
 }
 
-template <int CIN, int KS, int XT, int IPW, int IN_MODE, int CHB = 16>
+template <int CIN, int KS, int XT, int IPW, int IN_MODE, int CHB = 16, bool PLAIN = false>
 static inline int conv_fwd_kyo_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
   typedef KyoGeom<CIN, KS, XT, IPW> G;
   const ConvArgs& a = batch.a[0];
   const size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
-  auto kern = conv_fwd_kyo_kernel<CIN, KS, XT, IPW, IN_MODE, CHB>;
+  auto kern = conv_fwd_kyo_kernel<CIN, KS, XT, IPW, IN_MODE, CHB, PLAIN>;
   static bool attr_done = false;
   if (!attr_done) {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -533,3 +536,4 @@ static inline int conv_fwd_kyo_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
 
 int conv_fwd_kyo_dispatch_l1(cpp_ctx* ctx, int cin, int ks, int in_mode, int chb, const ConvArgsN& a, bool* handled);
 int conv_fwd_kyo_dispatch_l23(cpp_ctx* ctx, int cin, int ks, int in_mode, int chb, const ConvArgsN& a, bool* handled);
+int conv_fwd_kyo_dispatch_plain(cpp_ctx* ctx, int cin, int ks, int in_mode, int chb, const ConvArgsN& a, bool* handled);

@@ -466,6 +466,29 @@ static int net_forward_trunk(cpp_net* n, Workspace& w, const void* state, int dt
   return CPP_OK;
 }
 
+// the same for several batch-norm networks in training mode, layer by layer: ONE plain-conv launch for all of them
+// (the (ky,o) kernel needs the four networks of a minibatch to fill the chip), then statistics + BN/ReLU/pool per network
+static int nets_forward_trunk_bn(cpp_ctx* ctx, cpp_net* const* nets, int nn, const void* const* states, const float* const* whites,
+                                 int dtype, int B) {
+  for (int i = 0; i < 3; ++i) {
+    const ConvL& L = nets[0]->conv[i];
+    ConvArgs full[CONV_BATCH_MAX], plain[CONV_BATCH_MAX]; int mode = 0;
+    for (int k = 0; k < nn; ++k) {
+      full[k] = conv_fwd_args(nets[k], nets[k]->ws[0], i, states[k], dtype, whites[k], B, &mode);
+      plain[k] = full[k];
+      plain[k].out = nets[k]->ws[0].z[i]; plain[k].out_bstride = (long)L.H * L.W * kConvOut; plain[k].out_amax = nullptr; plain[k].bias = nullptr;
+    }
+    RC(launch_conv_fwd_multi(ctx, kFwdKid[i], L.Cin, L.ks, mode, EPI_PLAIN, plain, nn));
+    for (int k = 0; k < nn; ++k) {
+      cpp_net* n = nets[k];
+      RC(bn_forward_stats(n, n->ws[0].z[i], B, L.H, L.W, n->ws[0].bn_stat[i]));
+      RC(launch_bn_relu_pool(ctx, n->ws[0].z[i], plain[k].out_bstride, n->ws[0].bn_stat[i], n->params + L.b_off, full[k].out,
+                             full[k].out_bstride, full[k].out_amax, B, L.H, L.W, kConvOut));
+    }
+  }
+  return CPP_OK;
+}
+
 // fully connected layers [from, end); `action` (device, (B, A)) is spliced in front of the cat layer
 static int net_forward_fc(cpp_net* n, Workspace& w, int from, int B, const float* action) {
   cpp_ctx* ctx = n->ctx;
@@ -1276,6 +1299,12 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b) {
       }
       return (int)CPP_OK; }, {});
     tA = tC = tTA = tTC = t1;
+  } else if (a->spec.pixel) {       // batch norm (training mode for the whole graph, ddpg_cartpole.py:145,237)
+    cpp_net* nets[4] = {a, c, ta, tc};
+    const void* sts[4] = {s1, s1, s2, s2};
+    const float* whs[4] = {w1, w1, w2, w2};
+    const int t1 = G.fn([=] { return nets_forward_trunk_bn(ctx, nets, 4, sts, whs, dt, B); }, {});
+    tA = tC = tTA = tTC = t1;
   } else {
     tA = G.fn([=] { return net_forward_trunk(a, a->ws[0], s1, dt, w1, B); }, {});
     tC = G.fn([=] { return net_forward_trunk(c, c->ws[0], s1, dt, w1, B); }, {});
@@ -1624,7 +1653,8 @@ static int naf_compute_gradients(cpp_naf* f, cpp_batch* b) {
       return (int)CPP_OK; }, {});
   } else {
     std::vector<cpp_net*> nets(tn, tn + nt); std::vector<const void*> sts(ts, ts + nt); std::vector<const float*> whs(tw, tw + nt);
-    t1 = G.fn([=] {        // low-dim states, or batch-norm trunks (network by network: statistics between conv and ReLU)
+    t1 = G.fn([=] {        // low-dim states, or batch-norm trunks (training mode: naf_cartpole.py:271)
+      if (nets[0]->spec.pixel) return nets_forward_trunk_bn(ctx, nets.data(), nt, sts.data(), whs.data(), dt, B);
       for (int k = 0; k < nt; ++k) RC(net_forward_trunk(nets[k], nets[k]->ws[0], sts[k], dt, whs[k], B));
       return (int)CPP_OK; }, {});
   }
