@@ -5,32 +5,73 @@
 // conv kernel with weights scaled by 1/sqrt(1 + eps) and beta as the bias.
 //
 // Training mode cannot stay fused (the statistics of the conv output are needed before the ReLU): the conv writes its
-// plain output z, gather_stats / stats_finalize give (inv, -mean*inv), and the kernels here do the rest:
-//   forward : pooled = pool(relu(z*inv + shift + beta)), arg-max code                     (bn_relu_pool_kernel)
+// plain output z and the kernels here do the rest, for up to four same-shaped networks per launch (blockIdx.y):
+//   forward : (inv, -mean*inv) per channel from block partials (f64, fixed-order combine)      (bn_stats / bn_stats_finalize)
+//             pooled = pool(relu(z*inv + shift + beta)), arg-max code                          (bn_relu_pool)
 //   backward: dy = pooled gradient routed to the arg-max; dbeta = sum dy; with zhat = z*inv + shift
-//             dz = inv * (dy - mean(dy) - zhat * mean(dy * zhat))                          (bn_bwd_reduce / bn_bwd_dz)
+//             dz = inv * (dy - mean(dy) - zhat * mean(dy * zhat))                               (bn_bwd_reduce / _finalize / _dz)
 //             zhat at an arg-max position is (pooled - beta) wherever dy != 0, so both means come from the pooled
 //             tensors alone; dz is dense and overwrites z in place, and feeds the dense-dY modes of the conv dW / dX
 //             kernels.
 #include "common.h"
 
-// CT: compile-time channel count (10 for every layer of this trunk: cheap index arithmetic), 0: use the argument
+#define BN_BLOCKS 256
+
+// ---- forward statistics: a thread keeps one channel (strides are multiples of C)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const BnBatch bb) {
+  __shared__ double r0[256], r1[256];
+  const BnNet& nb = bb.n[blockIdx.y];
+  const int C = bb.C, active = (256 / C) * C, t = threadIdx.x;
+  double s = 0.0, ss = 0.0;
+  if (t < active) {
+    const unsigned n = (unsigned)bb.B * bb.H * bb.W * C;         // z is dense: image stride == H*W*C
+    for (unsigned e = blockIdx.x * (unsigned)active + t; e < n; e += gridDim.x * (unsigned)active) {
+      const double f = (double)nb.z[e];
+      s += f; ss += f * f;
+    }
+  }
+  r0[t] = s; r1[t] = ss;
+  __syncthreads();
+  if (t < C) {
+    double a = 0.0, b = 0.0;
+    for (int k = t; k < active; k += C) { a += r0[k]; b += r1[k]; }
+    nb.part[((long)blockIdx.x * 2 + 0) * C + t] = a;
+    nb.part[((long)blockIdx.x * 2 + 1) * C + t] = b;
+  }
+}
+
+// one 64-lane wave per (channel, network): fixed-order butterfly over the block partials
+__global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const BnBatch bb, int nblk, double eps) {
+  const BnNet& nb = bb.n[blockIdx.y];
+  const int C = bb.C, c = blockIdx.x;
+  double s = 0.0, ss = 0.0;
+  for (int k = threadIdx.x; k < nblk; k += 64) { s += nb.part[((long)k * 2 + 0) * C + c]; ss += nb.part[((long)k * 2 + 1) * C + c]; }
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+  if (threadIdx.x == 0) {
+    const double count = (double)bb.B * bb.H * bb.W;
+    const double mean = s / count;
+    const double var = ss / count - mean * mean;     // one-pass form, as tf.nn.moments of that era
+    const double inv = 1.0 / sqrt(var + eps);
+    nb.stat[c] = (float)inv;
+    nb.stat[C + c] = (float)(-mean * inv);
+  }
+}
+
+// ---- y = z*inv + shift + beta ; relu ; 2x2 max-pool + arg-max code (first maximum wins, as everywhere else)
 template <int CT>
-__global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restrict__ z, long z_bstride,
-                                                           const float* __restrict__ stat, const float* __restrict__ beta,
-                                                           float* __restrict__ pool, long pool_bstride,
-                                                           uint8_t* __restrict__ amax, int B, int H, int W, int Carg) {
-  const int C = CT ? CT : Carg;
-  const int Hp = H >> 1, Wp = W >> 1;
-  const unsigned ncell = (unsigned)B * Hp * Wp * C;      // 32-bit index arithmetic (64-bit divisions dominated this kernel)
+__global__ __launch_bounds__(256) void bn_relu_pool_kernel(const BnBatch bb) {
+  const BnNet& nb = bb.n[blockIdx.y];
+  const int C = CT ? CT : bb.C, H = bb.H, W = bb.W, Hp = H >> 1, Wp = W >> 1;
+  const unsigned ncell = (unsigned)bb.B * Hp * Wp * C;
+  const long zbs = (long)H * W * C;
   for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < ncell; idx += gridDim.x * 256u) {
     const int o = (int)(idx % (unsigned)C);
     unsigned r = idx / (unsigned)C;
     const int px = (int)(r % (unsigned)Wp); r /= (unsigned)Wp;
     const int py = (int)(r % (unsigned)Hp);
     const int b = (int)(r / (unsigned)Hp);
-    const float inv = stat[o], sh = stat[C + o], be = beta[o];
-    const float* zp = z + (long)b * z_bstride + ((long)(2 * py) * W + 2 * px) * C + o;
+    const float inv = nb.stat[o], sh = nb.stat[C + o], be = nb.beta[o];
+    const float* zp = nb.z + (long)b * zbs + ((long)(2 * py) * W + 2 * px) * C + o;
     const float v0 = (zp[0] * inv + sh) + be, v1 = (zp[C] * inv + sh) + be;
     const float v2 = (zp[(long)W * C] * inv + sh) + be, v3 = (zp[(long)W * C + C] * inv + sh) + be;
     float m = v0; int code = 0;
@@ -38,45 +79,27 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restri
     if (v2 > m) { m = v2; code = 2; }
     if (v3 > m) { m = v3; code = 3; }
     const long e = ((long)py * Wp + px) * C + o;
-    pool[(long)b * pool_bstride + e] = m > 0.f ? m : 0.f;
-    amax[(long)b * Hp * Wp * C + e] = (uint8_t)code;
+    nb.pool[(long)b * nb.pool_bstride + e] = m > 0.f ? m : 0.f;
+    nb.amax[(long)b * Hp * Wp * C + e] = (uint8_t)code;
   }
 }
 
-int launch_bn_relu_pool(cpp_ctx* ctx, const float* z, long z_bstride, const float* stat, const float* beta, float* pool,
-                        long pool_bstride, uint8_t* amax, int B, int H, int W, int C) {
-  const long ncell = (long)B * (H / 2) * (W / 2) * C;
-  int grid = (int)((ncell + 255) / 256);
-  if (grid > 4096) grid = 4096;
-  if (grid < 1) grid = 1;
-  prof_begin(ctx);
-  if (C == 10) hipLaunchKernelGGL(bn_relu_pool_kernel<10>, dim3(grid), dim3(256), 0, ctx->stream, z, z_bstride, stat, beta, pool,
-                                  pool_bstride, amax, B, H, W, C);
-  else hipLaunchKernelGGL(bn_relu_pool_kernel<0>, dim3(grid), dim3(256), 0, ctx->stream, z, z_bstride, stat, beta, pool,
-                          pool_bstride, amax, B, H, W, C);
-  LAUNCH_CHECK();
-  prof_end(ctx, K_ELEMENTWISE);
-  return 0;
-}
-
-// part[blk][2][C] (f64): sum of dy and of dy * zhat over the block's slice of pooled cells; a thread keeps one channel
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dpool, long dpool_bstride,
-                                                            const float* __restrict__ pool, long pool_bstride,
-                                                            const float* __restrict__ beta, int B, int cells_per_img, int C,
-                                                            double* __restrict__ part) {
+// ---- backward reductions over the pooled tensors: part[blk][2][C] = (sum dy, sum dy * zhat) of the block's cells
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBatch bb) {
   __shared__ double r1[256], r2[256];
-  const int active = (256 / C) * C;
-  const int t = threadIdx.x;
+  const BnNet& nb = bb.n[blockIdx.y];
+  const int C = bb.C, active = (256 / C) * C, t = threadIdx.x;
+  const int cells_per_img = (bb.H >> 1) * (bb.W >> 1) * C;
   double s1 = 0.0, s2 = 0.0;
   if (t < active) {
-    const float be = beta[t % C];
-    const long ncell = (long)B * cells_per_img;
-    for (unsigned idx = blockIdx.x * (unsigned)active + t; idx < (unsigned)ncell; idx += gridDim.x * (unsigned)active) {
+    const float be = nb.beta[t % C];
+    const unsigned ncell = (unsigned)bb.B * cells_per_img;
+    for (unsigned idx = blockIdx.x * (unsigned)active + t; idx < ncell; idx += gridDim.x * (unsigned)active) {
       const int b = (int)(idx / (unsigned)cells_per_img);
       const long e = (long)idx - (long)b * cells_per_img;
-      const float pv = pool[(long)b * pool_bstride + e];
+      const float pv = nb.pool[(long)b * nb.pool_bstride + e];
       if (pv > 0.f) {
-        const float g = dpool[(long)b * dpool_bstride + e];
+        const float g = nb.dpool[(long)b * nb.dpool_bstride + e];
         s1 += (double)g;
         s2 += (double)g * (double)(pv - be);
       }
@@ -87,74 +110,83 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   if (t < C) {
     double a1 = 0.0, a2 = 0.0;
     for (int k = t; k < active; k += C) { a1 += r1[k]; a2 += r2[k]; }
-    part[((long)blockIdx.x * 2 + 0) * C + t] = a1;
-    part[((long)blockIdx.x * 2 + 1) * C + t] = a2;
+    nb.part[((long)blockIdx.x * 2 + 0) * C + t] = a1;
+    nb.part[((long)blockIdx.x * 2 + 1) * C + t] = a2;
   }
 }
 
-// means[2][C] = (sum dy, sum dy*zhat) / N; dbeta = sum dy.  One 64-lane wave per channel: lanes stride over the block
-// partials, fixed-order butterfly combine (deterministic; a single thread walking 256 partials took 60 us)
-__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __restrict__ part, int nblk, int C, double n,
-                                                             float* __restrict__ means, float* __restrict__ dbeta) {
-  const int c = blockIdx.x;
+// means[2][C] = (sum dy, sum dy*zhat) / N; dbeta = sum dy
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const BnBatch bb, int nblk) {
+  const BnNet& nb = bb.n[blockIdx.y];
+  const int C = bb.C, c = blockIdx.x;
   double a1 = 0.0, a2 = 0.0;
-  for (int k = threadIdx.x; k < nblk; k += 64) { a1 += part[((long)k * 2 + 0) * C + c]; a2 += part[((long)k * 2 + 1) * C + c]; }
+  for (int k = threadIdx.x; k < nblk; k += 64) { a1 += nb.part[((long)k * 2 + 0) * C + c]; a2 += nb.part[((long)k * 2 + 1) * C + c]; }
   for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
   if (threadIdx.x == 0) {
-    means[c] = (float)(a1 / n);
-    means[C + c] = (float)(a2 / n);
-    dbeta[c] = (float)a1;
+    const double n = (double)bb.B * bb.H * bb.W;
+    nb.means[c] = (float)(a1 / n);
+    nb.means[C + c] = (float)(a2 / n);
+    nb.dbeta[c] = (float)a1;
   }
 }
 
 // z (plain conv output) -> dz in place
 template <int CT>
-__global__ __launch_bounds__(256) void bn_bwd_dz_kernel(float* __restrict__ z, long z_bstride, const float* __restrict__ stat,
-                                                        const float* __restrict__ means, const float* __restrict__ dpool,
-                                                        long dpool_bstride, const float* __restrict__ pool, long pool_bstride,
-                                                        const uint8_t* __restrict__ amax, int B, int H, int W, int Carg) {
-  const int C = CT ? CT : Carg;
-  const int Hp = H >> 1, Wp = W >> 1;
-  const unsigned n = (unsigned)B * H * W * C;
+__global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const BnBatch bb) {
+  const BnNet& nb = bb.n[blockIdx.y];
+  const int C = CT ? CT : bb.C, H = bb.H, W = bb.W, Hp = H >> 1, Wp = W >> 1;
+  const unsigned n = (unsigned)bb.B * H * W * C;
+  const long zbs = (long)H * W * C;
   for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < n; idx += gridDim.x * 256u) {
     const int o = (int)(idx % (unsigned)C);
     unsigned r = idx / (unsigned)C;
     const int x = (int)(r % (unsigned)W); r /= (unsigned)W;
     const int y = (int)(r % (unsigned)H);
     const int b = (int)(r / (unsigned)H);
-    float* zp = z + (long)b * z_bstride + ((long)y * W + x) * C + o;
-    const float inv = stat[o];
-    const float zhat = *zp * inv + stat[C + o];
+    float* zp = nb.z + (long)b * zbs + ((long)y * W + x) * C + o;
+    const float inv = nb.stat[o];
+    const float zhat = *zp * inv + nb.stat[C + o];
     float dy = 0.f;
     const int py = y >> 1, px = x >> 1;
     if (py < Hp && px < Wp) {
       const long e = ((long)py * Wp + px) * C + o;
-      if (pool[(long)b * pool_bstride + e] > 0.f && amax[(long)b * Hp * Wp * C + e] == (uint8_t)((y & 1) * 2 + (x & 1)))
-        dy = dpool[(long)b * dpool_bstride + e];
+      if (nb.pool[(long)b * nb.pool_bstride + e] > 0.f && nb.amax[(long)b * Hp * Wp * C + e] == (uint8_t)((y & 1) * 2 + (x & 1)))
+        dy = nb.dpool[(long)b * nb.dpool_bstride + e];
     }
-    *zp = inv * ((dy - means[o]) - zhat * means[C + o]);
+    *zp = inv * ((dy - nb.means[o]) - zhat * nb.means[C + o]);
   }
 }
 
-#define BN_BWD_BLOCKS 256
-size_t bn_bwd_part_doubles(int C) { return (size_t)BN_BWD_BLOCKS * 2 * C; }
+size_t bn_part_doubles(int C) { return (size_t)BN_BLOCKS * 2 * C; }
 
-int launch_bn_backward(cpp_ctx* ctx, float* z, long z_bstride, const float* stat, const float* beta, const float* dpool,
-                       long dpool_bstride, const float* pool, long pool_bstride, const uint8_t* amax, int B, int H, int W,
-                       int C, double* part, float* means, float* dbeta) {
-  const int cells = (H / 2) * (W / 2) * C;
+static int ew_grid(long n, int cap) {
+  long g = (n + 255) / 256;
+  if (g > cap) g = cap;
+  return g < 1 ? 1 : (int)g;
+}
+
+// statistics of z + BN/ReLU/pool for bb.count networks
+int launch_bn_forward(cpp_ctx* ctx, const BnBatch& bb, double eps) {
   prof_begin(ctx);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(BN_BWD_BLOCKS), dim3(256), 0, ctx->stream, dpool, dpool_bstride, pool,
-                     pool_bstride, beta, B, cells, C, part);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, ctx->stream, part, BN_BWD_BLOCKS, C,
-                     (double)B * H * W, means, dbeta);
-  const long n = (long)B * H * W * C;
-  int grid = (int)((n + 255) / 256);
-  if (grid > 8192) grid = 8192;
-  if (C == 10) hipLaunchKernelGGL(bn_bwd_dz_kernel<10>, dim3(grid), dim3(256), 0, ctx->stream, z, z_bstride, stat, means, dpool,
-                                  dpool_bstride, pool, pool_bstride, amax, B, H, W, C);
-  else hipLaunchKernelGGL(bn_bwd_dz_kernel<0>, dim3(grid), dim3(256), 0, ctx->stream, z, z_bstride, stat, means, dpool,
-                          dpool_bstride, pool, pool_bstride, amax, B, H, W, C);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(BN_BLOCKS, bb.count), dim3(256), 0, ctx->stream, bb);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(bb.C, bb.count), dim3(64), 0, ctx->stream, bb, BN_BLOCKS, eps);
+  const long ncell = (long)bb.B * (bb.H / 2) * (bb.W / 2) * bb.C;
+  const int grid = ew_grid(ncell, 4096);
+  if (bb.C == 10) hipLaunchKernelGGL(bn_relu_pool_kernel<10>, dim3(grid, bb.count), dim3(256), 0, ctx->stream, bb);
+  else hipLaunchKernelGGL(bn_relu_pool_kernel<0>, dim3(grid, bb.count), dim3(256), 0, ctx->stream, bb);
+  LAUNCH_CHECK();
+  prof_end(ctx, K_ELEMENTWISE);
+  return 0;
+}
+
+// reductions + dz (over z) for bb.count networks
+int launch_bn_backward(cpp_ctx* ctx, const BnBatch& bb) {
+  prof_begin(ctx);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(BN_BLOCKS, bb.count), dim3(256), 0, ctx->stream, bb);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(bb.C, bb.count), dim3(64), 0, ctx->stream, bb, BN_BLOCKS);
+  const int grid = ew_grid((long)bb.B * bb.H * bb.W * bb.C, 8192);
+  if (bb.C == 10) hipLaunchKernelGGL(bn_bwd_dz_kernel<10>, dim3(grid, bb.count), dim3(256), 0, ctx->stream, bb);
+  else hipLaunchKernelGGL(bn_bwd_dz_kernel<0>, dim3(grid, bb.count), dim3(256), 0, ctx->stream, bb);
   LAUNCH_CHECK();
   prof_end(ctx, K_ELEMENTWISE);
   return 0;

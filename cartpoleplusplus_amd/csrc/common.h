@@ -130,18 +130,24 @@ struct GatherArgs {
   long elems; int B; int size; int action_dim; int C;
 };
 int launch_gather_stats(cpp_ctx* ctx, const GatherArgs& a, int dtype);
-// batch norm (bn.hip)
-int launch_bn_relu_pool(cpp_ctx* ctx, const float* z, long z_bstride, const float* stat, const float* beta, float* pool,
-                        long pool_bstride, uint8_t* amax, int B, int H, int W, int C);
-size_t bn_bwd_part_doubles(int C);
-int launch_bn_backward(cpp_ctx* ctx, float* z, long z_bstride, const float* stat, const float* beta, const float* dpool,
-                       long dpool_bstride, const float* pool, long pool_bstride, const uint8_t* amax, int B, int H, int W,
-                       int C, double* part, float* means, float* dbeta);
+// batch norm (bn.hip): up to four same-shaped networks per launch
+struct BnNet {
+  float* z;                    // (B, H, W, C) plain conv output; overwritten by dz in the backward pass
+  float* stat;                 // [2][C]: inv, -mean * inv
+  const float* beta;
+  float* pool; long pool_bstride; uint8_t* amax;
+  const float* dpool; long dpool_bstride;
+  double* part;                // [BN_BLOCKS][2][C] reduction partials
+  float* means;                // [2][C]: mean dy, mean dy*zhat
+  float* dbeta;
+};
+struct BnBatch { BnNet n[CONV_BATCH_MAX]; int count; int B, H, W, C; };
+size_t bn_part_doubles(int C);
+int launch_bn_forward(cpp_ctx* ctx, const BnBatch& bb, double eps);
+int launch_bn_backward(cpp_ctx* ctx, const BnBatch& bb);
 int launch_stats_finalize(cpp_ctx* ctx, const double* part, int nparts, int which_count, int C,
                           double count, float* white, double eps = 1e-6);
 int launch_stats_generic(cpp_ctx* ctx, const void* x, int dtype, long npix, int C, float* white, double eps = 1e-6);
-size_t stats_wide_part_doubles(int C);
-int launch_stats_wide(cpp_ctx* ctx, const void* x, int dtype, long npix, int C, double* part, float* white, double eps);
 int launch_replay_fill(cpp_ctx* ctx, __half* store, long elems, int slots, int32_t* s1, int32_t* s2,
                        float* action, float* reward, float* mask, int rows, int action_dim,
                        uint64_t seed);

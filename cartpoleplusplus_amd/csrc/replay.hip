@@ -234,44 +234,6 @@ int launch_stats_generic(cpp_ctx* ctx, const void* x, int dtype, long npix, int 
   return 0;
 }
 
-// many-block variant of the same statistics for large tensors (batch norm over a conv output whose rows are not
-// multiples of 8 elements): block partials in f64, combined in fixed order by stats_finalize_kernel
-#define STATS_WIDE_BLOCKS 256
-template <typename T>
-__global__ __launch_bounds__(256) void stats_wide_kernel(const T* __restrict__ x, long npix, int C, double* __restrict__ part) {
-  __shared__ double r0[256], r1[256];
-  const int active = (256 / C) * C;                   // a thread keeps one channel: strides are multiples of C
-  const int t = threadIdx.x;
-  double s = 0.0, ss = 0.0;
-  if (t < active) {
-    const long n = npix * C;
-    for (long e = (long)blockIdx.x * active + t; e < n; e += (long)gridDim.x * active) {
-      const double f = (double)(float)x[e];
-      s += f; ss += f * f;
-    }
-  }
-  r0[t] = s; r1[t] = ss;
-  __syncthreads();
-  if (t < C) {
-    double a = 0.0, b = 0.0;
-    for (int k = t; k < active; k += C) { a += r0[k]; b += r1[k]; }
-    part[(long)blockIdx.x * 2 * C + t] = a;
-    part[(long)blockIdx.x * 2 * C + C + t] = b;
-  }
-}
-
-size_t stats_wide_part_doubles(int C) { return (size_t)STATS_WIDE_BLOCKS * 2 * C; }
-
-int launch_stats_wide(cpp_ctx* ctx, const void* x, int dtype, long npix, int C, double* part, float* white, double eps) {
-  prof_begin(ctx);
-  if (dtype == 1) hipLaunchKernelGGL(stats_wide_kernel<__half>, dim3(STATS_WIDE_BLOCKS), dim3(256), 0, ctx->stream, (const __half*)x, npix, C, part);
-  else hipLaunchKernelGGL(stats_wide_kernel<float>, dim3(STATS_WIDE_BLOCKS), dim3(256), 0, ctx->stream, (const float*)x, npix, C, part);
-  hipLaunchKernelGGL(stats_finalize_kernel, dim3(C), dim3(64), 0, ctx->stream, part, STATS_WIDE_BLOCKS, 1, C, (double)npix, white, eps);
-  LAUNCH_CHECK();
-  prof_end(ctx, K_STATS_GENERIC);
-  return 0;
-}
-
 // ---------------------------------------------------------------------------------------------
 // synthetic fill (bench / tests): SURVEY 8d inputs generated on the device
 // ---------------------------------------------------------------------------------------------

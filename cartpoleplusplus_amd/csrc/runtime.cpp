@@ -304,8 +304,7 @@ extern "C" int cpp_net_create(cpp_ctx* ctx, const cpp_net_spec* spec, int max_ba
     if ((rc = dalloc(n->arena, &n->stats_part, (size_t)2 * max_batch * 2 * spec->C))) return fail(rc);
     if (spec->use_batch_norm) {
       size_t pd = (size_t)2 * max_batch * 2 * kConvOut;
-      if (pd < bn_bwd_part_doubles(kConvOut)) pd = bn_bwd_part_doubles(kConvOut);
-      if (pd < stats_wide_part_doubles(kConvOut)) pd = stats_wide_part_doubles(kConvOut);
+      if (pd < bn_part_doubles(kConvOut)) pd = bn_part_doubles(kConvOut);
       if ((rc = n->arena.alloc((void**)&n->bn_part, pd * sizeof(double), false))) return fail(rc);
       if ((rc = dalloc(n->arena, &n->bn_means, (size_t)2 * kConvOut))) return fail(rc);
       if ((rc = dalloc(n->arena, &n->bn_scratch, (size_t)kConvOut))) return fail(rc);
@@ -425,17 +424,22 @@ static ConvArgs conv_dx_args(cpp_net* n, Workspace& w, int i, int B) {
 // slim.batch_norm's epsilon; the moving variance stays at its initial 1 (never updated by the reference's train ops)
 static const double kBnEps = 1e-3;
 
-// per-channel (inv, -mean*inv) of a plain conv output z (B, H, W, 10)
-static int bn_forward_stats(cpp_net* n, const float* z, int B, int H, int W, float* stat) {
-  cpp_ctx* ctx = n->ctx;
-  const long elems = (long)H * W * kConvOut;
-  if (elems % 8 == 0) {
-    GatherArgs ga; memset(&ga, 0, sizeof(ga));
-    ga.store[0] = z; ga.store[1] = z; ga.part = n->bn_part; ga.elems = elems; ga.B = B; ga.C = kConvOut;
-    RC(launch_gather_stats(ctx, ga, CPP_F32));
-    return launch_stats_finalize(ctx, n->bn_part, B, 1, kConvOut, (double)B * H * W, stat, kBnEps);
-  }
-  return launch_stats_wide(ctx, z, CPP_F32, (long)B * H * W, kConvOut, n->bn_part, stat, kBnEps);
+// descriptor of layer i of a batch-norm network for the bn.hip launches
+static BnNet bn_net_desc(cpp_net* n, Workspace& w, int i) {
+  const ConvL& L = n->conv[i];
+  BnNet d; memset(&d, 0, sizeof(d));
+  d.z = w.z[i]; d.stat = w.bn_stat[i]; d.beta = n->params + L.b_off;
+  d.pool = w.pool[i]; d.pool_bstride = (i == 2) ? (long)n->flat + 1 : (long)L.Hp * L.Wp * kConvOut; d.amax = w.amax[i];
+  d.dpool = w.dpool[i]; d.dpool_bstride = (i == 2) ? (long)n->flat : (long)L.Hp * L.Wp * kConvOut;
+  d.part = n->bn_part; d.means = n->bn_means; d.dbeta = n->grads ? n->grads + L.b_off : nullptr;
+  return d;
+}
+static BnBatch bn_batch(cpp_net* const* nets, int nn, int i, int B) {
+  BnBatch bb; memset(&bb, 0, sizeof(bb));
+  const ConvL& L = nets[0]->conv[i];
+  bb.count = nn; bb.B = B; bb.H = L.H; bb.W = L.W; bb.C = kConvOut;
+  for (int k = 0; k < nn; ++k) bb.n[k] = bn_net_desc(nets[k], nets[k]->ws[0], i);
+  return bb;
 }
 
 // conv trunk (pixel) or state conversion (low-dim) into ws.fcin[0]
@@ -458,9 +462,9 @@ static int net_forward_trunk(cpp_net* n, Workspace& w, const void* state, int dt
       ConvArgs p = a;                                   // plain conv output (no bias) -> statistics -> BN + ReLU + pool
       p.out = w.z[i]; p.out_bstride = (long)L.H * L.W * kConvOut; p.out_amax = nullptr; p.bias = nullptr;
       RC(launch_conv_fwd(ctx, kFwdKid[i], L.Cin, L.ks, mode, EPI_PLAIN, p));
-      RC(bn_forward_stats(n, w.z[i], B, L.H, L.W, w.bn_stat[i]));
-      RC(launch_bn_relu_pool(ctx, w.z[i], p.out_bstride, w.bn_stat[i], n->params + L.b_off, a.out, a.out_bstride, a.out_amax,
-                             B, L.H, L.W, kConvOut));
+      BnBatch bb; memset(&bb, 0, sizeof(bb));
+      bb.count = 1; bb.B = B; bb.H = L.H; bb.W = L.W; bb.C = kConvOut; bb.n[0] = bn_net_desc(n, w, i);
+      RC(launch_bn_forward(ctx, bb, kBnEps));
     }
   }
   return CPP_OK;
@@ -479,12 +483,7 @@ static int nets_forward_trunk_bn(cpp_ctx* ctx, cpp_net* const* nets, int nn, con
       plain[k].out = nets[k]->ws[0].z[i]; plain[k].out_bstride = (long)L.H * L.W * kConvOut; plain[k].out_amax = nullptr; plain[k].bias = nullptr;
     }
     RC(launch_conv_fwd_multi(ctx, kFwdKid[i], L.Cin, L.ks, mode, EPI_PLAIN, plain, nn));
-    for (int k = 0; k < nn; ++k) {
-      cpp_net* n = nets[k];
-      RC(bn_forward_stats(n, n->ws[0].z[i], B, L.H, L.W, n->ws[0].bn_stat[i]));
-      RC(launch_bn_relu_pool(ctx, n->ws[0].z[i], plain[k].out_bstride, n->ws[0].bn_stat[i], n->params + L.b_off, full[k].out,
-                             full[k].out_bstride, full[k].out_amax, B, L.H, L.W, kConvOut));
-    }
+    RC(launch_bn_forward(ctx, bn_batch(nets, nn, i, B), kBnEps));
   }
   return CPP_OK;
 }
@@ -514,10 +513,9 @@ static int net_backward_conv_bn(cpp_net* n, Workspace& w, int B, const void* sta
   for (int i = 2; i >= 0; --i) {
     const ConvL& L = n->conv[i];
     const long zbs = (long)L.H * L.W * kConvOut;
-    ConvArgs dd; memset(&dd, 0, sizeof(dd));
-    conv_dy_desc(n, w, i, dd, B);
-    RC(launch_bn_backward(ctx, w.z[i], zbs, w.bn_stat[i], n->params + L.b_off, dd.dy.dpool, dd.dy.dpool_bstride, dd.dy.pool,
-                          dd.dy.pool_bstride, dd.dy.amax, B, L.H, L.W, kConvOut, n->bn_part, n->bn_means, n->grads + L.b_off));
+    BnBatch bb; memset(&bb, 0, sizeof(bb));
+    bb.count = 1; bb.B = B; bb.H = L.H; bb.W = L.W; bb.C = kConvOut; bb.n[0] = bn_net_desc(n, w, i);
+    RC(launch_bn_backward(ctx, bb));
     int mode;
     ConvArgs d = conv_dw_args(n, w, i, state, dtype, white, B, &mode);
     d.dy_dense = w.z[i]; d.dy_dense_bstride = zbs;
@@ -549,8 +547,28 @@ static int net_backward_conv(cpp_net* n, Workspace& w, int B, const void* state,
 
 // the same for several networks with identical geometry, every layer's kernels batched into one launch
 static int nets_backward_conv(cpp_ctx* ctx, cpp_net* const* nets, int nn, int B, const void* state, int dtype, const float* white) {
-  if (nets[0]->spec.use_batch_norm) {                 // per network (the batched launches are for the fused path)
-    for (int k = 0; k < nn; ++k) RC(net_backward_conv_bn(nets[k], nets[k]->ws[0], B, state, dtype, white));
+  if (nets[0]->spec.use_batch_norm) {                 // dense dz per layer, then dW / dX of all networks in one launch each
+    for (int i = 2; i >= 0; --i) {
+      const ConvL& L = nets[0]->conv[i];
+      const long zbs = (long)L.H * L.W * kConvOut;
+      RC(launch_bn_backward(ctx, bn_batch(nets, nn, i, B)));
+      ConvArgs dl[CONV_BATCH_MAX], xl[CONV_BATCH_MAX]; float *gw[CONV_BATCH_MAX], *gb[CONV_BATCH_MAX];
+      int mode = 0;
+      for (int k = 0; k < nn; ++k) {
+        cpp_net* n = nets[k];
+        dl[k] = conv_dw_args(n, n->ws[0], i, state, dtype, white, B, &mode);
+        dl[k].dy_dense = n->ws[0].z[i]; dl[k].dy_dense_bstride = zbs;
+        gw[k] = n->grads + L.w_off; gb[k] = n->bn_scratch;
+        if (i > 0) {
+          ConvArgs& x = xl[k]; memset(&x, 0, sizeof(x));
+          x.in = n->ws[0].z[i]; x.in_bstride = zbs; x.w = n->params + L.w_off; x.nout = L.Cin;
+          x.out = n->ws[0].dpool[i - 1]; x.out_bstride = (long)L.H * L.W * L.Cin;
+          x.B = B; x.H = L.H; x.W = L.W;
+        }
+      }
+      RC(launch_conv_dw_multi(ctx, kDwKid[i], L.Cin, L.ks, mode, dl, nn, gw, gb));
+      if (i > 0) RC(launch_conv_fwd_multi(ctx, kDxKid[i], kConvOut, L.ks, IN_F32_FLIP, EPI_PLAIN, xl, nn));
+    }
     return CPP_OK;
   }
   for (int i = 2; i >= 0; --i) {
