@@ -21,7 +21,8 @@ class NetSpec(C.Structure):
     _fields_ = [("kind", C.c_int32), ("pixel", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("C", C.c_int32), ("state_elems", C.c_int32), ("action_dim", C.c_int32),
                 ("n_hidden", C.c_int32), ("hidden", C.c_int32 * 8), ("head_out", C.c_int32),
-                ("head_act", C.c_int32), ("use_batch_norm", C.c_int32)]
+                ("head_act", C.c_int32), ("use_batch_norm", C.c_int32), ("use_dropout", C.c_int32),
+                ("dropout_seed", C.c_uint32)]
 
 
 class DdpgHyper(C.Structure):

@@ -13,6 +13,7 @@ layer means calling the C ABI.
 """
 import ctypes as C
 import sys
+import zlib
 
 import numpy as np
 
@@ -89,8 +90,9 @@ class Network(object):
         if not isinstance(layer_sizes, list):
             layer_sizes = [int(s) for s in str(layer_sizes).split(",")]
         assert len(layer_sizes) > 0
-        if opts is not None and getattr(opts, "use_dropout", False):
-            raise NotImplementedError("--use-dropout is SURVEY 8(f) row N4 (not built yet)")
+        # --use-dropout (base_network.py:69-70): slim.dropout after every ReLU of this stack -- only when the caller
+        # passes opts (the low-dim critic does not, ddpg_cartpole.py:176-177)
+        self._use_dropout = bool(opts is not None and getattr(opts, "use_dropout", False))
         self._hidden = [int(s) for s in layer_sizes]
         return Layer([None, self._hidden[-1]], self, "hidden")
 
@@ -125,6 +127,8 @@ class Network(object):
         spec.kind, spec.action_dim = kind, int(action_dim)
         spec.head_out, spec.head_act = int(head_out), int(head_act)
         spec.use_batch_norm = int(bool(getattr(self, "_use_batch_norm", False)))
+        spec.use_dropout = int(bool(getattr(self, "_use_dropout", False)))
+        spec.dropout_seed = zlib.crc32(self.namespace.encode()) & 0xffffffff     # one mask stream per network
         if self._conv_input is not None:
             spec.pixel, (spec.H, spec.W, spec.C) = 1, self._conv_input
         else:

@@ -87,11 +87,33 @@ int launch_conv_dw(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, ConvArgs
 size_t conv_dw_partial_floats(cpp_ctx* ctx, int cin, int ks, int nout);
 int flush_dw_reduce(cpp_ctx* ctx);     // one launch for every dW reduction queued by launch_conv_dw
 
+// Philox4x32-10 (Salmon et al., SC'11): the replay sampler's and the dropout masks' counter-based generator
+struct u32x4 { uint32_t x, y, z, w; };
+__host__ __device__ inline u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
+    u32x4 n;
+    n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+    n.y = (uint32_t)p1;
+    n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+    n.w = (uint32_t)p0;
+    c = n;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+
 // ---------------------------------------------------------------------------------------------
 // gemm + elementwise (gemm.hip)
 // ---------------------------------------------------------------------------------------------
 enum GemmEpi { GE_NONE = 0, GE_RELU = 1, GE_TANH = 2, GE_MUL_RELU_GRAD = 3, GE_MUL_TANH_GRAD = 4,
-               GE_ACTOR_HEAD = 5 };   // C = v (dQ/da), C2 = -v * (1 - Y^2): grad_ys of ddpg_cartpole.py:111-113 through tanh
+               GE_ACTOR_HEAD = 5,     // C = v (dQ/da), C2 = -v * (1 - Y^2): grad_ys of ddpg_cartpole.py:111-113 through tanh
+               // --use-dropout (base_network.py:69-70: slim.dropout, keep 0.5, after the ReLU of a hidden layer):
+               GE_RELU_DROPOUT = 6,   // relu, then keep ? 2 v : 0 with the keep bit from Philox(seed; element, layer, *counter);
+                                      // without a counter (inference: IS_TRAINING False) plain relu
+               GE_MUL_RELU_GRAD_X2 = 7 };   // backward through such a layer: Y > 0 <=> kept and active -> 2 v
 struct GemmArgs {
   const float* A; long sAm, sAk;
   const float* B; long sBk, sBn;
@@ -100,6 +122,7 @@ struct GemmArgs {
   int M, N, K, epi;
   int accumulate;               // C = C + A*B before the epilogue (sums several heads' d(representation))
   float* C2; long ldc2;         // optional second copy of the output (e.g. actions straight into the critic's input)
+  const uint64_t* drop_counter; uint32_t drop_seed, drop_layer;   // GE_RELU_DROPOUT
 };
 #define GEMM_BATCH_MAX 8
 struct GemmBatch { GemmArgs g[GEMM_BATCH_MAX]; int tile_start[GEMM_BATCH_MAX + 1]; int n; };

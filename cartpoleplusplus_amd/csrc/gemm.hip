@@ -51,6 +51,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, float (*r
       if (g.epi == GE_RELU) v = fmaxf(v, 0.f);
       else if (g.epi == GE_TANH) v = tanhf(v);
       else if (g.epi == GE_MUL_RELU_GRAD) v = g.Y[(long)row * g.ldy + n] > 0.f ? v : 0.f;
+      else if (g.epi == GE_MUL_RELU_GRAD_X2) v = g.Y[(long)row * g.ldy + n] > 0.f ? 2.f * v : 0.f;
+      else if (g.epi == GE_RELU_DROPOUT) {
+        v = fmaxf(v, 0.f);
+        if (g.drop_counter) {
+          const uint64_t ctr = *g.drop_counter;
+          const u32x4 c = {(uint32_t)(row * g.N + n), g.drop_layer, (uint32_t)ctr, (uint32_t)(ctr >> 32)};
+          v = (philox4x32_10(c, g.drop_seed, 0u).x & 1u) ? 2.f * v : 0.f;
+        }
+      }
       else if (g.epi == GE_MUL_TANH_GRAD) { const float y = g.Y[(long)row * g.ldy + n]; v = v * (1.f - y * y); }
       g.C[(long)row * g.ldc + n] = v;
       if (g.epi == GE_ACTOR_HEAD) { const float y = g.Y[(long)row * g.ldy + n]; g.C2[(long)row * g.ldc2 + n] = -v * (1.f - y * y); }

@@ -11,24 +11,6 @@
 // combined in fixed order by stats_finalize_kernel (deterministic).
 #include "common.h"
 
-struct u32x4 { uint32_t x, y, z, w; };
-
-__host__ __device__ inline u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) {
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
-    u32x4 n;
-    n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
-    n.y = (uint32_t)p1;
-    n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
-    n.w = (uint32_t)p0;
-    c = n;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  return c;
-}
-
 __device__ __forceinline__ int sample_row(uint64_t seed, uint64_t counter, int b, int size) {
   u32x4 c = {(uint32_t)b, 0u, (uint32_t)counter, (uint32_t)(counter >> 32)};
   const u32x4 r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));

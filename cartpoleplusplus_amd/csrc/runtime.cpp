@@ -175,7 +175,8 @@ struct cpp_net {
   float* white_rows;       // [maxB][2][C]: per-image statistics for cpp_net_forward_each
   double* stats_part;      // [maxB][2C]
   float* dw_partial[3];     // one per conv layer: their reductions are deferred and batched
-  bool is_training;         // base_network.IS_TRAINING for the next forward (only batch norm looks at it)
+  bool is_training;         // base_network.IS_TRAINING for the next forward (batch norm and dropout look at it)
+  uint64_t* drop_counter;   // dropout: number of training-mode forwards so far (device; part of the Philox counter)
   double* bn_part; float* bn_means; float* bn_scratch;   // batch norm: reduction partials, (mean dy, mean dy*zhat), dW bias-slot dump
   void* stage_state; float* stage_action; float* stage_out;
   Arena arena;
@@ -217,11 +218,12 @@ static int net_build(cpp_net* n) {
   };
   n->cat_layer = -1;
   int n_in = n->flat;
+  const int hid_act = s.use_dropout ? GE_RELU_DROPOUT : GE_RELU;       // hidden_layers_starting_at with opts (base_network.py:69-70)
   if (s.kind == CPP_ACTOR) {
-    for (int i = 0; i < s.n_hidden; ++i) { add_fc("h" + std::to_string(i), n_in, s.hidden[i], GE_RELU, 0); n_in = s.hidden[i]; }
+    for (int i = 0; i < s.n_hidden; ++i) { add_fc("h" + std::to_string(i), n_in, s.hidden[i], hid_act, 0); n_in = s.hidden[i]; }
     add_fc("output_action", n_in, A, GE_TANH, 0);                       // ddpg_cartpole.py:95-100
   } else if (s.kind == CPP_HEAD) {                                      // naf_cartpole.py:104-109,156-161,180-184
-    for (int i = 0; i < s.n_hidden; ++i) { add_fc("h" + std::to_string(i), n_in, s.hidden[i], GE_RELU, 0); n_in = s.hidden[i]; }
+    for (int i = 0; i < s.n_hidden; ++i) { add_fc("h" + std::to_string(i), n_in, s.hidden[i], hid_act, 0); n_in = s.hidden[i]; }
     add_fc("fc", n_in, s.head_out, s.head_act == 2 ? GE_TANH : GE_NONE, 0);
   } else if (s.pixel) {                                                 // ddpg_cartpole.py:168-171 (intent)
     add_fc("hidden1", n_in, 200, GE_RELU, 0);
@@ -283,11 +285,12 @@ extern "C" int cpp_net_create(cpp_ctx* ctx, const cpp_net_spec* spec, int max_ba
   n->ctx = ctx; n->spec = *spec; n->maxB = max_batch; n->arena.stream = ctx->stream;
   n->grads = nullptr; n->own_grads = nullptr; n->stage_state = nullptr; n->stage_action = nullptr;
   n->stage_out = nullptr; n->dw_partial[0] = n->dw_partial[1] = n->dw_partial[2] = nullptr; n->white = nullptr; n->white_rows = nullptr; n->stats_part = nullptr;
-  n->is_training = true; n->bn_part = nullptr; n->bn_means = nullptr; n->bn_scratch = nullptr;
+  n->is_training = true; n->drop_counter = nullptr; n->bn_part = nullptr; n->bn_means = nullptr; n->bn_scratch = nullptr;
   int rc = net_build(n);
   if (rc) { delete n; return rc; }
   auto fail = [&](int r) { n->arena.release(); delete n; return r; };
   if ((rc = dalloc(n->arena, &n->params, (size_t)n->nparams))) return fail(rc);
+  if (spec->use_dropout && (rc = n->arena.alloc((void**)&n->drop_counter, sizeof(uint64_t), true))) return fail(rc);
   if ((rc = ws_alloc(n, n->ws[0], 0, true))) return fail(rc);
   if (spec->kind == CPP_CRITIC) {
     n->ws[1] = n->ws[0];
@@ -371,7 +374,7 @@ extern "C" int cpp_net_soft_update(cpp_net* target, const cpp_net* source, float
 static int gemm(cpp_ctx* ctx, const float* A, long sAm, long sAk, const float* Bm, long sBk, long sBn,
                 float* C, long ldc, int M, int N, int K, int epi, const float* Y = nullptr, long ldy = 0,
                 int accumulate = 0) {
-  GemmArgs g; g.accumulate = accumulate; g.C2 = nullptr; g.ldc2 = 0; g.A = A; g.sAm = sAm; g.sAk = sAk; g.B = Bm; g.sBk = sBk; g.sBn = sBn; g.C = C; g.ldc = ldc;
+  GemmArgs g; memset(&g, 0, sizeof(g)); g.accumulate = accumulate; g.A = A; g.sAm = sAm; g.sAk = sAk; g.B = Bm; g.sBk = sBk; g.sBn = sBn; g.C = C; g.ldc = ldc;
   g.Y = Y; g.ldy = ldy; g.M = M; g.N = N; g.K = K; g.epi = epi;
   return launch_gemm(ctx, g);
 }
@@ -489,6 +492,14 @@ static int nets_forward_trunk_bn(cpp_ctx* ctx, cpp_net* const* nets, int nn, con
 }
 
 // fully connected layers [from, end); `action` (device, (B, A)) is spliced in front of the cat layer
+static GemmArgs mk_gemm(const float* A, long sAm, long sAk, const float* Bm, long sBk, long sBn, float* C, long ldc,
+                        int M, int N, int K, int epi, const float* Y, long ldy);
+static GemmArgs mk_gemm(const float* A, long sAm, long sAk, const float* Bm, long sBk, long sBn, float* C, long ldc,
+                        int M, int N, int K, int epi) { return mk_gemm(A, sAm, sAk, Bm, sBk, sBn, C, ldc, M, N, K, epi, nullptr, 0); }
+static void set_dropout(GemmArgs& g, cpp_net* n, int l);
+static int relu_grad_epi(const cpp_net* n, int producer_layer);
+static int bump_dropout(cpp_net* n);
+
 static int net_forward_fc(cpp_net* n, Workspace& w, int from, int B, const float* action) {
   cpp_ctx* ctx = n->ctx;
   const int nfc = (int)n->fc.size(), A = n->spec.action_dim;
@@ -500,9 +511,11 @@ static int net_forward_fc(cpp_net* n, Workspace& w, int from, int B, const float
     }
     float* C = (l + 1 < nfc) ? w.fcin[l + 1] : w.out;
     const long ldc = (l + 1 < nfc) ? n->fc[l + 1].n_in + 1 : L.n_out;
-    RC(gemm(ctx, w.fcin[l], L.n_in + 1, 1, n->params + L.w_off, L.n_out, 1, C, ldc, B, L.n_out, L.n_in + 1, L.act));
+    GemmArgs g = mk_gemm(w.fcin[l], L.n_in + 1, 1, n->params + L.w_off, L.n_out, 1, C, ldc, B, L.n_out, L.n_in + 1, L.act, nullptr, 0);
+    set_dropout(g, n, l);
+    RC(launch_gemm(ctx, g));
   }
-  return CPP_OK;
+  return from == 0 ? bump_dropout(n) : CPP_OK;
 }
 
 // conv trunk backward from w.dpool[2] (= d flat): dW/db of the three convs, dX for conv3/conv2
@@ -606,10 +619,10 @@ static int net_backward(cpp_net* n, Workspace& w, int B, bool want_params, float
       if (!want_params) return CPP_OK;
       if (l > 0)
         RC(gemm(ctx, dz, L.n_out, 1, W, 1, L.n_out, w.dz[l - 1], L.n_in - A, B, L.n_in - A, L.n_out,
-                GE_MUL_RELU_GRAD, w.fcin[l], L.n_in + 1));
+                relu_grad_epi(n, l - 1), w.fcin[l], L.n_in + 1));
     } else if (l > 0) {
       RC(gemm(ctx, dz, L.n_out, 1, W, 1, L.n_out, w.dz[l - 1], L.n_in, B, L.n_in, L.n_out,
-              GE_MUL_RELU_GRAD, w.fcin[l], L.n_in + 1));
+              relu_grad_epi(n, l - 1), w.fcin[l], L.n_in + 1));
     } else if (n->spec.pixel && want_params) {
       RC(gemm(ctx, dz, L.n_out, 1, W, 1, L.n_out, w.dpool[2], n->flat, B, n->flat, L.n_out, GE_NONE));
     }
@@ -672,11 +685,25 @@ struct OpGraph {
 };
 
 static GemmArgs mk_gemm(const float* A, long sAm, long sAk, const float* Bm, long sBk, long sBn, float* C, long ldc,
-                        int M, int N, int K, int epi, const float* Y = nullptr, long ldy = 0) {
+                        int M, int N, int K, int epi, const float* Y, long ldy) {
   GemmArgs g; memset(&g, 0, sizeof(g));
   g.A = A; g.sAm = sAm; g.sAk = sAk; g.B = Bm; g.sBk = sBk; g.sBn = sBn; g.C = C; g.ldc = ldc;
   g.Y = Y; g.ldy = ldy; g.M = M; g.N = N; g.K = K; g.epi = epi;
   return g;
+}
+// --use-dropout: a training-mode forward draws its keep bits from (seed, layer, the network's forward count); inference
+// mode is the plain ReLU.  The backward pass of such a layer doubles what it lets through (Y > 0 <=> kept and active).
+static void set_dropout(GemmArgs& g, cpp_net* n, int l) {
+  if (g.epi != GE_RELU_DROPOUT) return;
+  if (n->is_training && n->drop_counter) { g.drop_counter = n->drop_counter; g.drop_seed = n->spec.dropout_seed; g.drop_layer = (uint32_t)l; }
+  else g.epi = GE_RELU;
+}
+static int relu_grad_epi(const cpp_net* n, int producer_layer) {
+  return (producer_layer >= 0 && n->fc[producer_layer].act == GE_RELU_DROPOUT) ? GE_MUL_RELU_GRAD_X2 : GE_MUL_RELU_GRAD;
+}
+static int bump_dropout(cpp_net* n) {      // after every training-mode forward of the network's FC stack
+  if (!n->drop_counter || !n->is_training) return CPP_OK;
+  return launch_counter_add(n->ctx, n->drop_counter, 1);
 }
 // y = act([x, 1] [W; b]) of layer l into the next layer's input buffer (or w.out for the last layer)
 static GemmArgs fc_fwd_args(cpp_net* n, Workspace& w, int l, int B) {
@@ -684,7 +711,9 @@ static GemmArgs fc_fwd_args(cpp_net* n, Workspace& w, int l, int B) {
   const int nfc = (int)n->fc.size();
   float* C = (l + 1 < nfc) ? w.fcin[l + 1] : w.out;
   const long ldc = (l + 1 < nfc) ? n->fc[l + 1].n_in + 1 : L.n_out;
-  return mk_gemm(w.fcin[l], L.n_in + 1, 1, n->params + L.w_off, L.n_out, 1, C, ldc, B, L.n_out, L.n_in + 1, L.act);
+  GemmArgs g = mk_gemm(w.fcin[l], L.n_in + 1, 1, n->params + L.w_off, L.n_out, 1, C, ldc, B, L.n_out, L.n_in + 1, L.act);
+  set_dropout(g, n, l);
+  return g;
 }
 // [dW; db] = [x, 1]^T dz
 static GemmArgs fc_dw_args(cpp_net* n, Workspace& w, int l, int B, const float* dz) {
@@ -735,9 +764,9 @@ extern "C" int cpp_net_forward(cpp_net* n, const void* state, int state_dtype, i
     RC(batch_stats(ctx, n->stage_state, nullptr, state_dtype, n->state_elems, B, n->spec.C, n->stats_part, n->white));
   n->is_training = false;                              // IS_TRAINING: False (ddpg_cartpole.py:125)
   int frc = net_forward_trunk(n, n->ws[0], n->stage_state, state_dtype, n->white, B);
+  if (!frc) frc = net_forward_fc(n, n->ws[0], 0, B, action ? n->stage_action : nullptr);
   n->is_training = true;
   if (frc) return frc;
-  RC(net_forward_fc(n, n->ws[0], 0, B, action ? n->stage_action : nullptr));
   HIP_CHECK(hipMemcpyAsync(out, n->ws[0].out, (size_t)B * no * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
   return CPP_OK;
@@ -779,9 +808,9 @@ extern "C" int cpp_net_forward_each(cpp_net* n, const void* state, int state_dty
   }
   n->is_training = false;
   int frc = net_forward_trunk(n, n->ws[0], n->stage_state, state_dtype, n->white_rows, B, wbs);
+  if (!frc) frc = net_forward_fc(n, n->ws[0], 0, B, action ? n->stage_action : nullptr);
   n->is_training = true;
   if (frc) return frc;
-  RC(net_forward_fc(n, n->ws[0], 0, B, action ? n->stage_action : nullptr));
   HIP_CHECK(hipMemcpyAsync(out, n->ws[0].out, (size_t)B * no * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
   return CPP_OK;
@@ -1339,6 +1368,10 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b) {
     }
     aF = G.gemm(g, {aF}); taF = G.gemm(t, {taF});
   }
+  if (a->drop_counter) {     // --use-dropout: this forward is counted once its layers have read the counter
+    G.fn([=] { return bump_dropout(a); }, {aF});
+    G.fn([=] { return bump_dropout(ta); }, {taF});
+  }
   int cP = tC, tcP = tTC;
   for (int l = 0; l < cat; ++l) {
     GemmArgs g = fc_fwd_args(c, c->ws[0], l, B);
@@ -1376,7 +1409,7 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b) {
     const FcL& L = a->fc[l];
     G.gemm(fc_dw_args(a, a->ws[0], l, B, a->ws[0].dz[l]), {adz});
     if (l > 0)
-      adz = G.gemm(fc_dx_args(a, l, B, a->ws[0].dz[l], L.n_out, 0, L.n_in, a->ws[0].dz[l - 1], L.n_in, GE_MUL_RELU_GRAD,
+      adz = G.gemm(fc_dx_args(a, l, B, a->ws[0].dz[l], L.n_out, 0, L.n_in, a->ws[0].dz[l - 1], L.n_in, relu_grad_epi(a, l - 1),
                               a->ws[0].fcin[l], L.n_in + 1), {adz});
     else if (a->spec.pixel)
       adz = G.gemm(fc_dx_args(a, 0, B, a->ws[0].dz[0], L.n_out, 0, a->flat, a->ws[0].dpool[2], a->flat, GE_NONE, nullptr, 0), {adz});
@@ -1636,7 +1669,7 @@ static int add_fc_backward(OpGraph& G, cpp_net* n, Workspace& w, int B, int star
     const FcL& L = n->fc[l];
     G.gemm(fc_dw_args(n, w, l, B, w.dz[l]), {dep});
     if (l > 0)
-      dep = G.gemm(fc_dx_args(n, l, B, w.dz[l], L.n_out, 0, L.n_in, w.dz[l - 1], L.n_in, GE_MUL_RELU_GRAD, w.fcin[l], L.n_in + 1), {dep});
+      dep = G.gemm(fc_dx_args(n, l, B, w.dz[l], L.n_out, 0, L.n_in, w.dz[l - 1], L.n_in, relu_grad_epi(n, l - 1), w.fcin[l], L.n_in + 1), {dep});
     else if (n->spec.pixel)
       dep = G.gemm(fc_dx_args(n, 0, B, w.dz[0], L.n_out, 0, n->flat, w.dpool[2], n->flat, GE_NONE, nullptr, 0), {dep});
   }
@@ -1688,6 +1721,11 @@ static int naf_compute_gradients(cpp_naf* f, cpp_batch* b) {
   const int tvout = chain(tv, 0, t1);
   const int muout = share ? chain(mu, 0, vrep) : chain(mu, 0, t1);
   const int lvout = share ? chain(lv, 0, vrep) : chain(lv, 0, t1);
+  if (v->drop_counter) {     // --use-dropout: count this training-mode forward of every network with a hidden stack
+    G.fn([=] { return bump_dropout(v); }, {vout});
+    G.fn([=] { return bump_dropout(tv); }, {tvout});
+    if (!share) { G.fn([=] { return bump_dropout(mu); }, {muout}); G.fn([=] { return bump_dropout(lv); }, {lvout}); }
+  }
   // ---- NAF head: L, advantage, TD loss and the gradients of the three head outputs
   const int head = G.fn([=] { return naf_head(f, b, true); }, {vout, tvout, muout, lvout});
 
@@ -1707,7 +1745,7 @@ static int naf_compute_gradients(cpp_naf* f, cpp_batch* b) {
     struct Head { cpp_net* n; const FcL* L; const float* dz; };
     Head heads[3] = {{v, &hv, v->ws[0].dz[Lh]}, {mu, &mu->fc[0], mu->ws[0].dz[0]}, {lv, &lv->fc[0], lv->ws[0].dz[0]}};
     float* drep = nullptr; long ldd = rep; int final_epi = GE_NONE; const float* Y = nullptr; long ldy = 0;
-    if (Lh > 0) { drep = v->ws[0].dz[Lh - 1]; final_epi = GE_MUL_RELU_GRAD; Y = v->ws[0].fcin[Lh]; ldy = rep + 1; }
+    if (Lh > 0) { drep = v->ws[0].dz[Lh - 1]; final_epi = relu_grad_epi(v, Lh - 1); Y = v->ws[0].fcin[Lh]; ldy = rep + 1; }
     else if (v->spec.pixel) { drep = v->ws[0].dpool[2]; }
     int dep = head;
     for (int k = 0; k < 3; ++k) {
@@ -1757,12 +1795,12 @@ extern "C" int cpp_naf_action(cpp_naf* f, const void* state, int dtype, int B, f
   }
   HIP_CHECK(hipMemcpyAsync(n->stage_state, state, (size_t)B * n->state_elems * (dtype == CPP_F16 ? 2 : 4), hipMemcpyHostToDevice, ctx->stream));
   if (n->spec.pixel) RC(batch_stats(ctx, n->stage_state, nullptr, dtype, n->state_elems, B, n->spec.C, n->stats_part, n->white));
-  n->is_training = false;                              // IS_TRAINING: False (naf_cartpole.py:253)
-  const int frc = net_forward_trunk(n, n->ws[0], n->stage_state, dtype, n->white, B);
-  n->is_training = true;
+  n->is_training = false; f->mu->is_training = false;  // IS_TRAINING: False (naf_cartpole.py:253)
+  int frc = net_forward_trunk(n, n->ws[0], n->stage_state, dtype, n->white, B);
+  if (!frc) frc = net_forward_fc(n, n->ws[0], 0, B, nullptr);
+  if (!frc && f->share) frc = net_forward_fc(f->mu, f->mu->ws[0], 0, B, nullptr);
+  n->is_training = true; f->mu->is_training = true;
   if (frc) return frc;
-  RC(net_forward_fc(n, n->ws[0], 0, B, nullptr));
-  if (f->share) RC(net_forward_fc(f->mu, f->mu->ws[0], 0, B, nullptr));
   HIP_CHECK(hipMemcpyAsync(out, f->mu->ws[0].out, (size_t)B * f->A * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
   return CPP_OK;

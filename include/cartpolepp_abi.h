@@ -83,6 +83,11 @@ typedef struct cpp_net_spec {
                            * bias and the '<conv>/biases' slot of the flat layout is '<conv>/BatchNorm/beta'.  Training-mode
                            * entry points (the train ops) use batch statistics, inference-mode ones (cpp_net_forward*,
                            * check_loss, NAF action / debug) the never-updated moving averages (mean 0, variance 1).  */
+  int32_t use_dropout;   /* opts.use_dropout (base_network.py:69-70): slim.dropout (keep 0.5) after the ReLU of every layer made by
+                          * hidden_layers_starting_at *with opts* -- the actor's and the NAF networks' hidden stacks; the critics
+                          * have none (ddpg_cartpole.py:168-177).  Training-mode entry points draw the keep bits from
+                          * Philox4x32-10(key = dropout_seed; counter = (row * units + unit, layer, forward count)). */
+  uint32_t dropout_seed;
 } cpp_net_spec;
 
 int cpp_net_create(cpp_ctx* ctx, const cpp_net_spec* spec, int max_batch, cpp_net** out);

@@ -49,8 +49,11 @@ class NetSpec(object):
     """kind: 'actor' | 'critic'.  pixel nets take (H, W, C) with C = 3*cameras*repeats
     (base_network.py:85-90); low-dim nets take `state_elems` flattened inputs."""
 
-    def __init__(self, kind, action_dim, hidden, pixel, H=0, W=0, C=0, state_elems=0, batch_norm=False):
+    def __init__(self, kind, action_dim, hidden, pixel, H=0, W=0, C=0, state_elems=0, batch_norm=False, dropout=False):
         assert kind in ("actor", "critic")
+        # --use-dropout (base_network.py:69-70): slim.dropout (keep 0.5) after the ReLU of every layer built by
+        # hidden_layers_starting_at *with opts*: the 'h<i>' stacks of actor-like networks; the critics have none
+        self.dropout = bool(dropout) and kind == "actor"
         self.kind, self.action_dim, self.pixel = kind, int(action_dim), bool(pixel)
         # --use-batch-norm (base_network.py:74-79): slim.batch_norm between every conv and its ReLU.  The conv then has
         # no bias; the slot "<conv>/biases" of the flat layout holds BatchNorm/beta instead (same size, same place).
@@ -280,6 +283,7 @@ class Net(object):
         self.spec, self.dt = spec, dt
         self.p = unflatten(spec, flat_params, dt)
         self.amax_override = None     # tests only: {conv name: arg-max codes} to route the pool gradient with
+        self.drop_masks = None        # dropout keep masks {layer name: (B, units) of 0/1} for the next training forward
 
     def flat(self):
         return flatten(self.spec, self.p, self.dt)
@@ -321,6 +325,10 @@ class Net(object):
             if cat:
                 h = np.concatenate([h, np.asarray(action, dtype=dt).reshape(B, -1)], axis=1)
             y = _act(h @ self.p[name + "/weights"] + self.p[name + "/biases"], act)
+            if sp.dropout and training and name.startswith("h") and name[1:].isdigit():
+                # slim.dropout: x * keep / keep_prob.  The random bits are the caller's (no RNG is shared with TF)
+                y = (y * np.asarray(self.drop_masks[name], dt) * dt(2.0)).astype(dt)
+                c.setdefault("dropped", set()).add(name)
             c["fc"].append((h, y))
             h = y
         c["out"] = h
@@ -358,6 +366,8 @@ class Net(object):
         dh = np.asarray(dout, dtype=dt)
         for (name, n_in, _n_out, act, cat), (h, y) in reversed(list(zip(sp.fc, c["fc"]))):
             dz = _act_bwd(dh, y, act)
+            if name in c.get("dropped", ()):      # y > 0 <=> kept and active; the kept units carry the factor 1/keep_prob
+                dz = (dz * dt(2.0)).astype(dt)
             if params:
                 g[name + "/biases"] = dz.sum(axis=0)
                 g[name + "/weights"] = h.T @ dz

@@ -31,10 +31,10 @@ class HeadSpec(O.NetSpec):
     head_only: no trunk / hidden layers -- the input is another network's state representation."""
 
     def __init__(self, head_out, head_act, hidden, pixel, H=0, W=0, C=0, state_elems=0, head_only=False,
-                 batch_norm=False):
+                 batch_norm=False, dropout=False):
         self.head_out, self.head_act, self.head_only = int(head_out), head_act, head_only
         O.NetSpec.__init__(self, "actor", head_out, [] if head_only else hidden, pixel and not head_only,
-                           H, W, C, state_elems, batch_norm=batch_norm)
+                           H, W, C, state_elems, batch_norm=batch_norm, dropout=dropout)
 
     def _fc_layers(self):
         out, n_in = [], self.flat
@@ -205,6 +205,8 @@ class NAF(object):
         dh = np.asarray(drep, dt)
         for (name, _n_in, _n_out, act, _cat), (h, yv) in reversed(list(zip(sp.fc, c["fc"]))):
             dz = O._act_bwd(dh, yv, act)
+            if name in c.get("dropped", ()):
+                dz = (dz * dt(2.0)).astype(dt)
             g[name + "/biases"] = dz.sum(axis=0)
             g[name + "/weights"] = h.T @ dz
             dh = dz @ net.p[name + "/weights"].T

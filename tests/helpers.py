@@ -45,7 +45,7 @@ def make_pair(shape, B, pixel, seed=0, replay_size=64, perturb=True, dt=np.float
         kw = dict(pixel=True, H=shape[0], W=shape[1], C=int(np.prod(shape[2:])), batch_norm=bool(optkw.get("use_batch_norm", False)))
     else:
         kw = dict(pixel=False, state_elems=int(np.prod(shape)))
-    aspec = O.NetSpec("actor", 2, [100, 100, 50], **kw)
+    aspec = O.NetSpec("actor", 2, [100, 100, 50], dropout=bool(optkw.get("use_dropout", False)), **kw)
     cspec = O.NetSpec("critic", 2, [100, 100, 50], **kw)
     ref = O.DDPG(aspec, cspec, agent.actor.get_params(), agent.critic.get_params(), dt)
     ref.set_targets(agent.target_actor.get_params(), agent.target_critic.get_params())
@@ -117,3 +117,30 @@ def assert_grads_close_modulo_pool_ties(spec, device_net, B, oracle_net, oracle_
     assert_flat_close(spec, got, want, rel=rel,
                       what="%s (oracle re-run with the device's choice at %d near-tie pooling windows)" % (what, flips))
     return flips
+
+
+def philox4x32_10(ctr, key):
+    """Philox4x32-10 (Salmon et al.), the generator of the replay sampler and of the dropout masks."""
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    c, k = list(ctr), list(key)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k[0]) & 0xFFFFFFFF, p1 & 0xFFFFFFFF,
+             ((p0 >> 32) ^ c[3] ^ k[1]) & 0xFFFFFFFF, p0 & 0xFFFFFFFF]
+        k = [(k[0] + W0) & 0xFFFFFFFF, (k[1] + W1) & 0xFFFFFFFF]
+    return c
+
+
+def dropout_masks(namespace, hidden, B, step):
+    """the keep masks the device draws for the `step`-th training-mode forward of network `namespace`
+    (include/cartpolepp_abi.h, cpp_net_spec.use_dropout): {'h<i>': (B, units) of 0/1}."""
+    import zlib
+    seed = zlib.crc32(namespace.encode()) & 0xffffffff
+    out = {}
+    for layer, units in enumerate(hidden):
+        m = np.empty((B, units), np.float64)
+        for b in range(B):
+            for j in range(units):
+                m[b, j] = philox4x32_10([b * units + j, layer, step & 0xFFFFFFFF, step >> 32], [seed, 0])[0] & 1
+        out["h%d" % layer] = m
+    return out

@@ -20,12 +20,12 @@ class HB(object):
 
 
 def make_naf(shape, B, share, optimiser="GradientDescent", optimiser_args=None, seed=0, replay_size=64, clip=5.0,
-             use_batch_norm=False):
+             use_batch_norm=False, use_dropout=False):
     from cartpoleplusplus_amd import naf_cartpole as F
     pixel = len(shape) == 5
     kw = dict(batch_size=B, replay_memory_size=replay_size, share_input_state_representation=share,
               optimiser=optimiser, optimiser_args=json.dumps(optimiser_args or {"learning_rate": 0.01}),
-              gradient_clip=clip, use_batch_norm=use_batch_norm)
+              gradient_clip=clip, use_batch_norm=use_batch_norm, use_dropout=use_dropout)
     if pixel:
         kw.update(use_raw_pixels=True, render_height=shape[0], render_width=shape[1], num_cameras=shape[3],
                   action_repeats=shape[4])
@@ -43,6 +43,7 @@ def make_naf(shape, B, share, optimiser="GradientDescent", optimiser_args=None, 
     agent.target_value_net.set_params(p + rng.normal(0, 0.01, p.shape).astype(np.float32))
     skw = dict(pixel=True, H=shape[0], W=shape[1], C=int(np.prod(shape[2:])), batch_norm=use_batch_norm) if pixel else \
         dict(pixel=False, state_elems=int(np.prod(shape)))
+    skw["dropout"] = use_dropout
     vspec = N.HeadSpec(1, "linear", [100, 50], **skw)
     if share:
         mspec = N.HeadSpec(2, "tanh", [], False, state_elems=50, head_only=True)
