@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=10, help="minibatches of the per-kernel HIP-event pass")
     ap.add_argument("--use-batch-norm", action="store_true", help="informational: the networks of exps/run_8x / run_9x (--use-batch-norm)")
+    ap.add_argument("--replay-store", default="f16", choices=["f16", "u8"],
+                    help="informational: u8 = the 8-bit replay store (same batches, half the gather reads)")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel learner path (RCCL all-reduce) even at world size 1")
     args = ap.parse_args()
 
@@ -126,7 +128,7 @@ def main():
     D.set_opts(D.default_opts(use_raw_pixels=True, render_height=shape[0], render_width=shape[1],
                               num_cameras=shape[3], action_repeats=shape[4], batch_size=B,
                               replay_memory_size=replay_rows, sample_seed=1234 + rank,
-                              use_batch_norm=bool(args.use_batch_norm)))
+                              use_batch_norm=bool(args.use_batch_norm), replay_store=args.replay_store))
     agent = D.DeepDeterministicPolicyGradientAgent(Env())
     agent.initialise_variables(seed=42)                 # identical replicas on every rank
     agent.post_var_init_setup()
@@ -215,9 +217,9 @@ def main():
         "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": wgroups * BATCHES_PER_STEP,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: DDPG pixel obs %dx%dx%d, batch=%d per GPU, replay %d rows/GPU in HBM (f16), "
+        "config": {"workload": "%s: DDPG pixel obs %dx%dx%d, batch=%d per GPU, replay %d rows/GPU in HBM (%s), "
                                "target soft-update every %d minibatches%s" % (
-                                   args.workload, shape[0], shape[1], int(np.prod(shape[2:])), B, replay_rows,
+                                   args.workload, shape[0], shape[1], int(np.prod(shape[2:])), B, replay_rows, args.replay_store,
                                    BATCHES_PER_STEP, ", --use-batch-norm" if args.use_batch_norm else ""),
                    "parallelism": "dp%d (one learner per GPU, flat-gradient all-reduce per minibatch)" % world,
                    "global_steps_per_sec": round(steps / elapsed, 3),

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CARTPOLEPP_LIB") or os.path.join(_HERE, "lib", "libcartpolepp_hip.so")   # env: ablation builds only
 
-CPP_F32, CPP_F16 = 0, 1
+CPP_F32, CPP_F16, CPP_U8 = 0, 1, 2
 CPP_ACTOR, CPP_CRITIC, CPP_HEAD = 0, 1, 2
 CPP_OPT_SGD, CPP_OPT_MOMENTUM, CPP_OPT_ADAM = 0, 1, 2
 
@@ -76,6 +76,7 @@ SIGNATURES = {
     "cpp_batch_size": (_I, [_P]),
     "cpp_batch_state_dtype": (_I, [_P]),
     "cpp_replay_create": (_I, [_P, _I, _I, _L, _I, _PP]),
+    "cpp_replay_create_ex": (_I, [_P, _I, _I, _L, _I, _I, _PP]),
     "cpp_replay_destroy": (_I, [_P]),
     "cpp_replay_write_states": (_I, [_P, _P, _I, _P, _I]),
     "cpp_replay_write_rows": (_I, [_P, _P, _I, _P, _P, _P, _P, _P]),

@@ -150,9 +150,13 @@ struct GatherArgs {
   float* out_action; float* out_reward; float* out_mask;
   double* part;                 // [2][B][2*C] per-row partial sums
   uint64_t seed; const uint64_t* counter;
+  const __half* lut;            // u8 store: f16(k / 255) for the 256 pixel codes
   long elems; int B; int size; int action_dim; int C;
 };
-int launch_gather_stats(cpp_ctx* ctx, const GatherArgs& a, int dtype);
+int launch_gather_stats(cpp_ctx* ctx, const GatherArgs& a, int dtype);   // dtype of the store: CPP_F32 / CPP_F16 / CPP_U8 (gathers to f16)
+int launch_u8_to_f16(cpp_ctx* ctx, __half* dst, const uint8_t* src, long n, const __half* lut);
+int launch_to_u8(cpp_ctx* ctx, uint8_t* dst, const void* src, int src_dtype, long n, const __half* lut, int* bad);
+int launch_replay_fill_u8(cpp_ctx* ctx, uint8_t* store, long total, uint64_t seed);
 // batch norm (bn.hip): up to four same-shaped networks per launch
 struct BnNet {
   float* z;                    // (B, H, W, C) plain conv output; overwritten by dz in the backward pass

@@ -19,6 +19,7 @@ __device__ __forceinline__ int sample_row(uint64_t seed, uint64_t counter, int b
 
 template <typename T> struct Vec8;
 template <> struct Vec8<__half> {
+  typedef __half Out;
   uint4 raw;
   __device__ void load(const __half* p) { raw = *reinterpret_cast<const uint4*>(p); }
   __device__ void store(__half* p) const { *reinterpret_cast<uint4*>(p) = raw; }
@@ -28,7 +29,23 @@ template <> struct Vec8<__half> {
     return __half2float(__ushort_as_half(h));
   }
 };
+// 8-bit pixel codes (CPP_U8 store): 8 codes per vector, looked up in the f16(k/255) table (LDS copy); gathered as f16
+template <> struct Vec8<uint8_t> {
+  typedef __half Out;
+  uint2 raw; const float* lut;
+  __device__ void load(const uint8_t* p) { raw = *reinterpret_cast<const uint2*>(p); }
+  __device__ float get(int e) const { return lut[((e < 4 ? raw.x : raw.y) >> (8 * (e & 3))) & 0xffu]; }
+  __device__ void store(__half* p) const {
+    uint4 o;
+    uint32_t* w = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+    for (int e = 0; e < 8; e += 2)
+      w[e >> 1] = (uint32_t)__half_as_ushort(__float2half(get(e))) | ((uint32_t)__half_as_ushort(__float2half(get(e + 1))) << 16);
+    *reinterpret_cast<uint4*>(p) = o;
+  }
+};
 template <> struct Vec8<float> {
+  typedef float Out;
   float4 a, b;
   __device__ void load(const float* p) {
     a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4);
@@ -42,14 +59,23 @@ template <> struct Vec8<float> {
   }
 };
 
+template <typename V> __device__ __forceinline__ void vec_init(V&, const float*) {}
+__device__ __forceinline__ void vec_init(Vec8<uint8_t>& v, const float* lut) { v.lut = lut; }
+template <typename T, typename O> __device__ __forceinline__ O elem_convert(T x, const float*) { return (O)x; }
+template <> __device__ __forceinline__ __half elem_convert<uint8_t, __half>(uint8_t k, const float* lut) { return __float2half(lut[k]); }
+
 __host__ __device__ inline int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
 
 template <typename T>
 __global__ __launch_bounds__(256) void gather_stats_kernel(const GatherArgs a) {
   __shared__ float sh[256 * 16];
   __shared__ double dsh[CPP_MAX_CHANNELS * 16];
+  __shared__ float lut[256];                      // CPP_U8 store: f16(k/255) as float
   const int b = blockIdx.x, which = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr bool U8 = sizeof(T) == 1;
+  if (U8) { lut[tid] = __half2float(a.lut[tid]); __syncthreads(); }
+  typedef typename Vec8<T>::Out OutT;
 
   // --- sample + double indirection on lane 0, broadcast by wavefront shuffle
   int row = 0, slot = 0;
@@ -71,13 +97,13 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(const GatherArgs a) {
   }
 
   const T* src = (const T*)a.store[which] + (long)slot * a.elems;
-  T* dst = a.out_state[which] ? (T*)a.out_state[which] + (long)b * a.elems : nullptr;
+  OutT* dst = a.out_state[which] ? (OutT*)a.out_state[which] + (long)b * a.elems : nullptr;
   const long nvec = a.elems >> 3;
   const int C = a.C;
 
   if (C <= 0) {                                   // gather only (low-dim states)
-    for (long v = tid; v < nvec; v += 256) { Vec8<T> x; x.load(src + v * 8); if (dst) x.store(dst + v * 8); }
-    for (long e = nvec * 8 + tid; e < a.elems; e += 256) if (dst) dst[e] = src[e];
+    for (long v = tid; v < nvec; v += 256) { Vec8<T> x; vec_init(x, lut); x.load(src + v * 8); if (dst) x.store(dst + v * 8); }
+    for (long e = nvec * 8 + tid; e < a.elems; e += 256) if (dst) dst[e] = elem_convert<T, OutT>(src[e], lut);
     return;
   }
 
@@ -95,7 +121,7 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(const GatherArgs a) {
     for (; v + (GU - 1) * stride < nvec; v += GU * stride) {
       Vec8<T> x[GU];
 #pragma unroll
-      for (int u = 0; u < GU; ++u) x[u].load(src + (v + u * stride) * 8);
+      for (int u = 0; u < GU; ++u) { vec_init(x[u], lut); x[u].load(src + (v + u * stride) * 8); }
 #pragma unroll
       for (int u = 0; u < GU; ++u) {
         if (dst) x[u].store(dst + (v + u * stride) * 8);
@@ -105,6 +131,7 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(const GatherArgs a) {
     }
     for (; v < nvec; v += stride) {
       Vec8<T> x;
+      vec_init(x, lut);
       x.load(src + v * 8);
       if (dst) x.store(dst + v * 8);
 #pragma unroll
@@ -142,7 +169,8 @@ int launch_gather_stats(cpp_ctx* ctx, const GatherArgs& a, int dtype) {
     return 1;
   }
   prof_begin(ctx);
-  if (dtype == 1) hipLaunchKernelGGL(gather_stats_kernel<__half>, dim3(a.B, 2), dim3(256), 0, ctx->stream, a);
+  if (dtype == 2) hipLaunchKernelGGL(gather_stats_kernel<uint8_t>, dim3(a.B, 2), dim3(256), 0, ctx->stream, a);
+  else if (dtype == 1) hipLaunchKernelGGL(gather_stats_kernel<__half>, dim3(a.B, 2), dim3(256), 0, ctx->stream, a);
   else hipLaunchKernelGGL(gather_stats_kernel<float>, dim3(a.B, 2), dim3(256), 0, ctx->stream, a);
   LAUNCH_CHECK();
   prof_end(ctx, K_GATHER_STATS);
@@ -256,9 +284,11 @@ int launch_replay_fill(cpp_ctx* ctx, __half* store, long elems, int slots, int32
   const long total = elems * (long)slots;
   const long nthreads = (total + 15) / 16;
   prof_begin(ctx);
-  hipLaunchKernelGGL(replay_fill_states_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0,
-                     ctx->stream, store, total, seed);
-  LAUNCH_CHECK();
+  if (store) {                                       // (nullptr: the caller fills a CPP_U8 store itself)
+    hipLaunchKernelGGL(replay_fill_states_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0,
+                       ctx->stream, store, total, seed);
+    LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(replay_fill_rows_kernel, dim3((rows + 255) / 256), dim3(256), 0, ctx->stream, s1, s2,
                      action, reward, mask, rows, action_dim, seed);
   LAUNCH_CHECK();
@@ -274,6 +304,58 @@ __global__ void f32_to_f16_kernel(__half* dst, const float* src, long n) {
 int launch_f32_to_f16(cpp_ctx* ctx, __half* dst, const float* src, long n) {
   hipLaunchKernelGGL(f32_to_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                      dst, src, n);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+// CPP_U8 store: states must be 8-bit pixel images, f16(x) == f16(k/255) for some code k (bullet_cartpole.py:239-243); the
+// store keeps k.  Anything else raises the `bad` flag (the caller reports an error instead of storing a lossy copy).
+template <typename T>
+__global__ void to_u8_kernel(uint8_t* dst, const T* src, long n, const __half* lut, int* bad) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const __half h = __float2half((float)src[i]);          // what the f16 store would hold (RNE, like numpy)
+  int k = (int)rintf(__half2float(h) * 255.0f);
+  k = k < 0 ? 0 : (k > 255 ? 255 : k);
+  if (__half_as_ushort(lut[k]) != __half_as_ushort(h)) atomicOr(bad, 1);
+  dst[i] = (uint8_t)k;
+}
+
+int launch_to_u8(cpp_ctx* ctx, uint8_t* dst, const void* src, int src_dtype, long n, const __half* lut, int* bad) {
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  if (src_dtype == 1) hipLaunchKernelGGL(to_u8_kernel<__half>, dim3(grid), dim3(256), 0, ctx->stream, dst, (const __half*)src, n, lut, bad);
+  else hipLaunchKernelGGL(to_u8_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, dst, (const float*)src, n, lut, bad);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+// raw camera bytes into an f16 store: dst = f16(k/255) through the table (the reference's render conversion)
+__global__ void u8_to_f16_kernel(__half* dst, const uint8_t* src, long n, const __half* lut) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = lut[src[i]];
+}
+
+int launch_u8_to_f16(cpp_ctx* ctx, __half* dst, const uint8_t* src, long n, const __half* lut) {
+  hipLaunchKernelGGL(u8_to_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dst, src, n, lut);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void replay_fill_u8_kernel(uint8_t* store, long total, uint64_t seed) {      // same codes as replay_fill_states_kernel
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i * 16 >= total) return;
+  u32x4 c = {(uint32_t)i, (uint32_t)(i >> 32), 0x5eedu, 1u};
+  const u32x4 r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+  for (int e = 0; e < 16; ++e) {
+    const long idx = i * 16 + e;
+    if (idx < total) store[idx] = (uint8_t)((w[e >> 2] >> (8 * (e & 3))) & 0xffu);
+  }
+}
+
+int launch_replay_fill_u8(cpp_ctx* ctx, uint8_t* store, long total, uint64_t seed) {
+  const long nthreads = (total + 15) / 16;
+  hipLaunchKernelGGL(replay_fill_u8_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, ctx->stream, store, total, seed);
   LAUNCH_CHECK();
   return 0;
 }

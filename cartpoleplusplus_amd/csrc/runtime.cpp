@@ -920,23 +920,46 @@ static int batch_ensure_stats(cpp_batch* b, int C) {
 // ---------------------------------------------------------------------------------------------
 struct cpp_replay {
   cpp_ctx* ctx; int rows, slots, A, size; long elems;
-  __half* store; int32_t *s1, *s2, *rows_in, *rows_out; float *action, *reward, *mask;
+  int store_dtype;         // CPP_F16 (replay_memory.py:32) or CPP_U8 (pixel codes k, read back as f16(k/255): half the HBM)
+  void* store; int32_t *s1, *s2, *rows_in, *rows_out; float *action, *reward, *mask;
   uint64_t* counter;       // device-side Philox counter for graph replay
-  float* stage_f32; size_t stage_cap;
+  __half* lut; int* bad; uint16_t lut_host[256];      // CPP_U8: f16(k/255) table, "not a pixel image" flag
+  void* stage; size_t stage_cap;                      // device staging of incoming states (conversion source)
+  void* pinned; size_t pinned_cap; hipEvent_t pinned_free; bool pinned_busy;   // host staging: writes return before the copy ends
   Arena arena;
 };
+static size_t replay_esz(const cpp_replay* r) { return r->store_dtype == CPP_U8 ? 1 : sizeof(__half); }
 
-extern "C" int cpp_replay_create(cpp_ctx* ctx, int buffer_size, int state_slots, int64_t state_elems,
-                                 int action_dim, cpp_replay** out) {
+// f16(k / 255.0) rounded to nearest-even from the exact quotient -- numpy's float16(k / 255.0), which is what the
+// reference's renders hold (bullet_cartpole.py:239-243)
+static uint16_t f16_of_code(int k) {
+  const double d = (double)k / 255.0;
+  const uint16_t h0 = __half_as_ushort(__float2half((float)d));
+  uint16_t best = h0; double berr = 1e9;
+  for (int delta = -1; delta <= 1; ++delta) {
+    const int hb = (int)h0 + delta;
+    if (hb < 0 || hb > 0x7bff) continue;
+    const double err = fabs((double)__half2float(__ushort_as_half((uint16_t)hb)) - d);
+    if (err < berr || (err == berr && (hb & 1) == 0)) { berr = err; best = (uint16_t)hb; }
+  }
+  return best;
+}
+
+static int replay_create(cpp_ctx* ctx, int buffer_size, int state_slots, int64_t state_elems, int action_dim, int store_dtype,
+                         cpp_replay** out) {
   ARG_CHECK(ctx && out, "cpp_replay_create: NULL argument");
   ARG_CHECK(buffer_size >= 1 && state_elems >= 1 && action_dim >= 1, "cpp_replay_create: bad sizes");
   ARG_CHECK(state_slots >= buffer_size + 1, "cpp_replay_create: %d state slots for %d rows", state_slots, buffer_size);
+  ARG_CHECK(store_dtype == CPP_F16 || store_dtype == CPP_U8, "cpp_replay_create: store dtype %d", store_dtype);
+  ARG_CHECK(store_dtype != CPP_U8 || state_elems % 8 == 0, "cpp_replay_create: the 8-bit store needs state_elems %% 8 == 0");
   HIP_CHECK(hipSetDevice(ctx->device));
   cpp_replay* r = new cpp_replay();
   r->arena.stream = ctx->stream;
   r->ctx = ctx; r->rows = buffer_size; r->slots = state_slots; r->A = action_dim; r->size = 0; r->elems = state_elems;
-  r->stage_f32 = nullptr; r->stage_cap = 0;
-  int rc = r->arena.alloc((void**)&r->store, (size_t)state_slots * state_elems * sizeof(__half), false);
+  r->store_dtype = store_dtype;
+  r->stage = nullptr; r->stage_cap = 0; r->pinned = nullptr; r->pinned_cap = 0; r->pinned_busy = false; r->lut = nullptr; r->bad = nullptr;
+  HIP_CHECK(hipEventCreateWithFlags(&r->pinned_free, hipEventDisableTiming));
+  int rc = r->arena.alloc(&r->store, (size_t)state_slots * state_elems * replay_esz(r), false);
   if (!rc) rc = dalloc(r->arena, &r->s1, (size_t)buffer_size);
   if (!rc) rc = dalloc(r->arena, &r->s2, (size_t)buffer_size);
   if (!rc) rc = dalloc(r->arena, &r->rows_in, (size_t)65536);
@@ -945,40 +968,91 @@ extern "C" int cpp_replay_create(cpp_ctx* ctx, int buffer_size, int state_slots,
   if (!rc) rc = dalloc(r->arena, &r->reward, (size_t)buffer_size);
   if (!rc) rc = dalloc(r->arena, &r->mask, (size_t)buffer_size);
   if (!rc) rc = dalloc(r->arena, &r->counter, (size_t)1);
+  if (!rc) {
+    rc = r->arena.alloc((void**)&r->lut, 256 * sizeof(__half), false);
+    if (!rc) rc = r->arena.alloc((void**)&r->bad, sizeof(int), true);
+    if (!rc) {
+      for (int k = 0; k < 256; ++k) r->lut_host[k] = f16_of_code(k);
+      if (hipMemcpy(r->lut, r->lut_host, sizeof(r->lut_host), hipMemcpyHostToDevice) != hipSuccess) rc = CPP_ERR_HIP;
+    }
+  }
   if (rc) { r->arena.release(); delete r; return rc; }
   *out = r;
   return CPP_OK;
+}
+extern "C" int cpp_replay_create(cpp_ctx* ctx, int buffer_size, int state_slots, int64_t state_elems,
+                                 int action_dim, cpp_replay** out) {
+  return replay_create(ctx, buffer_size, state_slots, state_elems, action_dim, CPP_F16, out);
+}
+extern "C" int cpp_replay_create_ex(cpp_ctx* ctx, int buffer_size, int state_slots, int64_t state_elems,
+                                    int action_dim, int store_dtype, cpp_replay** out) {
+  return replay_create(ctx, buffer_size, state_slots, state_elems, action_dim, store_dtype, out);
 }
 extern "C" int cpp_replay_destroy(cpp_replay* r) {
   if (!r) return CPP_OK;
   (void)hipSetDevice(r->ctx->device);
   (void)hipStreamSynchronize(r->ctx->stream);
-  if (r->stage_f32) (void)hipFree(r->stage_f32);
+  if (r->stage) (void)hipFree(r->stage);
+  if (r->pinned) (void)hipHostFree(r->pinned);
+  (void)hipEventDestroy(r->pinned_free);
   r->arena.release(); delete r; return CPP_OK;
 }
 
+// self.state[idx] = s (replay_memory.py:67,106).  The host rows go through a pinned staging buffer, so the call returns
+// as soon as they are copied there: the H2D transfer and the conversions run on the context's stream, in order with
+// everything launched later (rendered frames straight into replay slots, no stall of the rollout loop).
 extern "C" int cpp_replay_write_states(cpp_replay* r, const int32_t* slots, int n, const void* states, int dtype) {
   ARG_CHECK(r && slots && states, "cpp_replay_write_states: NULL argument");
-  ARG_CHECK(dtype == CPP_F32 || dtype == CPP_F16, "cpp_replay_write_states: dtype %d", dtype);
+  ARG_CHECK(dtype == CPP_F32 || dtype == CPP_F16 || dtype == CPP_U8, "cpp_replay_write_states: dtype %d", dtype);
   hipStream_t st = r->ctx->stream;
   HIP_CHECK(hipSetDevice(r->ctx->device));
   for (int i = 0; i < n; ++i)
     ARG_CHECK(slots[i] >= 0 && slots[i] < r->slots, "cpp_replay_write_states: slot %d outside [0,%d)", slots[i], r->slots);
-  if (dtype == CPP_F32) {
-    const size_t need = (size_t)n * r->elems * sizeof(float);
-    if (need > r->stage_cap) {
-      if (r->stage_f32) HIP_CHECK(hipFree(r->stage_f32));
-      HIP_CHECK(hipMalloc((void**)&r->stage_f32, need)); r->stage_cap = need;
-    }
-    HIP_CHECK(hipMemcpyAsync(r->stage_f32, states, need, hipMemcpyHostToDevice, st));
-    for (int i = 0; i < n; ++i)
-      RC(launch_f32_to_f16(r->ctx, r->store + (size_t)slots[i] * r->elems, r->stage_f32 + (size_t)i * r->elems, r->elems));
-  } else {
-    for (int i = 0; i < n; ++i)
-      HIP_CHECK(hipMemcpyAsync(r->store + (size_t)slots[i] * r->elems, (const __half*)states + (size_t)i * r->elems,
-                               (size_t)r->elems * sizeof(__half), hipMemcpyHostToDevice, st));
+  const size_t esz = dtype == CPP_U8 ? 1 : dtype == CPP_F16 ? sizeof(__half) : sizeof(float);
+  const size_t need = (size_t)n * r->elems * esz;
+  if (r->pinned_busy) { HIP_CHECK(hipEventSynchronize(r->pinned_free)); r->pinned_busy = false; }   // previous transfer done
+  if (need > r->pinned_cap) {
+    if (r->pinned) HIP_CHECK(hipHostFree(r->pinned));
+    HIP_CHECK(hipHostMalloc(&r->pinned, need, hipHostMallocDefault)); r->pinned_cap = need;
   }
-  HIP_CHECK(hipStreamSynchronize(st));
+  memcpy(r->pinned, states, need);
+  const bool direct = dtype == r->store_dtype;       // no conversion (f16 -> f16, camera bytes -> 8-bit store): copy into the slots
+  bool checked = false;
+  if (direct) {
+    for (int i = 0; i < n; ++i)
+      HIP_CHECK(hipMemcpyAsync((char*)r->store + (size_t)slots[i] * r->elems * esz, (const char*)r->pinned + (size_t)i * r->elems * esz,
+                               (size_t)r->elems * esz, hipMemcpyHostToDevice, st));
+  } else {
+    if (need > r->stage_cap) {
+      HIP_CHECK(hipStreamSynchronize(st));
+      if (r->stage) HIP_CHECK(hipFree(r->stage));
+      HIP_CHECK(hipMalloc(&r->stage, need)); r->stage_cap = need;
+    }
+    HIP_CHECK(hipMemcpyAsync(r->stage, r->pinned, need, hipMemcpyHostToDevice, st));
+    for (int i = 0; i < n; ++i) {
+      const char* src = (const char*)r->stage + (size_t)i * r->elems * esz;
+      if (r->store_dtype == CPP_U8) {
+        RC(launch_to_u8(r->ctx, (uint8_t*)r->store + (size_t)slots[i] * r->elems, src, dtype, r->elems, r->lut, r->bad));
+        checked = true;
+      } else if (dtype == CPP_U8)
+        RC(launch_u8_to_f16(r->ctx, (__half*)r->store + (size_t)slots[i] * r->elems, (const uint8_t*)src, r->elems, r->lut));
+      else
+        RC(launch_f32_to_f16(r->ctx, (__half*)r->store + (size_t)slots[i] * r->elems, (const float*)src, r->elems));
+    }
+  }
+  HIP_CHECK(hipEventRecord(r->pinned_free, st));
+  r->pinned_busy = true;
+  if (checked) {      // the exactness check is part of the contract: report it with this call
+    int bad = 0;
+    HIP_CHECK(hipMemcpyAsync(&bad, r->bad, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (bad) {
+      HIP_CHECK(hipMemsetAsync(r->bad, 0, sizeof(int), st));
+      cpp_set_error("cpp_replay_write_states: the 8-bit store holds pixel images only (every value must be f16(k/255)); "
+                    "create the memory with the f16 store for other states");
+      return CPP_ERR_ARG;
+    }
+  }
   return CPP_OK;
 }
 
@@ -1013,12 +1087,21 @@ extern "C" int cpp_replay_set_size(cpp_replay* r, int size) {
 extern "C" int cpp_replay_read_states(cpp_replay* r, const int32_t* slots, int n, void* out_f16) {
   ARG_CHECK(r && slots && out_f16, "cpp_replay_read_states: NULL argument");
   hipStream_t st = r->ctx->stream;
+  std::vector<uint8_t> codes(r->store_dtype == CPP_U8 ? (size_t)n * r->elems : 0);
   for (int i = 0; i < n; ++i) {
     ARG_CHECK(slots[i] >= 0 && slots[i] < r->slots, "cpp_replay_read_states: slot %d", slots[i]);
-    HIP_CHECK(hipMemcpyAsync((__half*)out_f16 + (size_t)i * r->elems, r->store + (size_t)slots[i] * r->elems,
-                             (size_t)r->elems * sizeof(__half), hipMemcpyDeviceToHost, st));
+    if (r->store_dtype == CPP_U8)
+      HIP_CHECK(hipMemcpyAsync(codes.data() + (size_t)i * r->elems, (const uint8_t*)r->store + (size_t)slots[i] * r->elems,
+                               (size_t)r->elems, hipMemcpyDeviceToHost, st));
+    else
+      HIP_CHECK(hipMemcpyAsync((__half*)out_f16 + (size_t)i * r->elems, (const __half*)r->store + (size_t)slots[i] * r->elems,
+                               (size_t)r->elems * sizeof(__half), hipMemcpyDeviceToHost, st));
   }
   HIP_CHECK(hipStreamSynchronize(st));
+  if (r->store_dtype == CPP_U8) {
+    uint16_t* o = (uint16_t*)out_f16;
+    for (size_t i = 0; i < codes.size(); ++i) o[i] = r->lut_host[codes[i]];
+  }
   return CPP_OK;
 }
 
@@ -1032,14 +1115,14 @@ static int replay_sample_device(cpp_replay* r, int B, const int32_t* rows_dev, u
     if (r->elems % 8 != 0 || C / g > 16 || r->elems % C != 0) C = 0;    // statistics via the generic path below
   }
   GatherArgs a; memset(&a, 0, sizeof(a));
-  a.store[0] = r->store; a.store[1] = r->store; a.s_idx[0] = r->s1; a.s_idx[1] = r->s2;
+  a.store[0] = r->store; a.store[1] = r->store; a.s_idx[0] = r->s1; a.s_idx[1] = r->s2; a.lut = r->lut;
   a.rows = rows_dev; a.rows_out = r->rows_out;
   a.action = r->action; a.reward = r->reward; a.mask = r->mask;
   a.out_state[0] = out->s[0]; a.out_state[1] = out->s[1];
   a.out_action = out->a; a.out_reward = out->r; a.out_mask = out->m;
   a.part = out->part; a.seed = seed; a.counter = counter_dev;
   a.elems = r->elems; a.B = B; a.size = r->size; a.action_dim = r->A; a.C = C;
-  RC(launch_gather_stats(ctx, a, CPP_F16));
+  RC(launch_gather_stats(ctx, a, r->store_dtype));      // a CPP_U8 store gathers to f16 as well
   out->B = B; out->dtype = CPP_F16; out->stats_C = 0;
   if (C > 0) {
     RC(launch_stats_finalize(ctx, out->part, B, 2, C, (double)B * (double)(r->elems / C), out->white));
@@ -1084,8 +1167,9 @@ extern "C" int cpp_replay_fill_synthetic(cpp_replay* r, int n_rows, uint64_t see
   ARG_CHECK(r && n_rows >= 1 && n_rows <= r->rows, "cpp_replay_fill_synthetic: rows %d", n_rows);
   ARG_CHECK(n_rows + n_rows / 50 + 1 <= r->slots, "cpp_replay_fill_synthetic: not enough state slots");
   HIP_CHECK(hipSetDevice(r->ctx->device));
-  RC(launch_replay_fill(r->ctx, r->store, r->elems, r->slots, r->s1, r->s2, r->action, r->reward, r->mask,
-                        n_rows, r->A, seed));
+  RC(launch_replay_fill(r->ctx, r->store_dtype == CPP_U8 ? nullptr : (__half*)r->store, r->elems, r->slots, r->s1, r->s2,
+                        r->action, r->reward, r->mask, n_rows, r->A, seed));
+  if (r->store_dtype == CPP_U8) RC(launch_replay_fill_u8(r->ctx, (uint8_t*)r->store, r->elems * (long)r->slots, seed));
   HIP_CHECK(hipStreamSynchronize(r->ctx->stream));
   r->size = n_rows;
   return CPP_OK;

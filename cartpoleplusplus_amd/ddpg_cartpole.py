@@ -73,6 +73,9 @@ def build_parser():
     a('--host-rng-sampling', action='store_true',
       help="draw minibatch rows with numpy's RNG on the host like the reference (default: Philox on the GPU)")
     a('--sample-seed', type=int, default=0, help="seed of the device-side minibatch sampler")
+    a('--replay-store', type=str, default="f16", choices=["f16", "u8"],
+      help="element type of the replay memory's state store: f16 as the reference, or u8 pixel codes "
+           "(identical batches for rendered frames, half the memory)")
     a('--synthetic-env', action='store_true', help="random-frame stand-in env (pybullet stays optional)")
     return parser
 
@@ -327,7 +330,8 @@ class DeepDeterministicPolicyGradientAgent(object):
         state_shape = self.env.observation_space.shape
         action_dim = self.env.action_space.shape[1]
         # replay memory: f16 state store resident in HBM (ddpg_cartpole.py:257-261)
-        self.replay_memory = replay_memory.ReplayMemory(opts.replay_memory_size, state_shape, action_dim)
+        self.replay_memory = replay_memory.ReplayMemory(opts.replay_memory_size, state_shape, action_dim,
+                                                       store_dtype=opts.replay_store)
         # s1 and s2 placeholders
         batched_state_shape = [None] + list(state_shape)
         s1 = base_network.Placeholder(batched_state_shape)

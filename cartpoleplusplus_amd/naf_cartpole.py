@@ -58,6 +58,9 @@ def build_parser():
     a('--render-height', type=int, default=50, help="if --use-raw-pixels render with this height")
     a('--host-rng-sampling', action='store_true', help="draw minibatch rows with numpy's RNG like the reference")
     a('--sample-seed', type=int, default=0, help="seed of the device-side minibatch sampler")
+    a('--replay-store', type=str, default="f16", choices=["f16", "u8"],
+      help="element type of the replay memory's state store: f16 as the reference, or u8 pixel codes "
+           "(identical batches for rendered frames, half the memory)")
     a('--synthetic-env', action='store_true', help="random-frame stand-in env")
     return parser
 
@@ -223,7 +226,8 @@ class NormalizedAdvantageFunctionAgent(object):
         self.env = env
         state_shape = self.env.observation_space.shape
         action_dim = self.env.action_space.shape[1]
-        self.replay_memory = replay_memory.ReplayMemory(opts.replay_memory_size, state_shape, action_dim)
+        self.replay_memory = replay_memory.ReplayMemory(opts.replay_memory_size, state_shape, action_dim,
+                                                       store_dtype=opts.replay_store)
         batched_state_shape = [None] + list(state_shape)
         s1 = base_network.Placeholder(batched_state_shape)
         s2 = base_network.Placeholder(batched_state_shape)

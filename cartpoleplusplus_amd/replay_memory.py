@@ -138,7 +138,10 @@ class _StateStoreView(object):
 
 
 class ReplayMemory(object):
-    def __init__(self, buffer_size, state_shape, action_dim, load_factor=1.5, ctx=None):
+    def __init__(self, buffer_size, state_shape, action_dim, load_factor=1.5, ctx=None, store_dtype="f16"):
+        """store_dtype "f16" is the reference's store (replay_memory.py:32).  "u8" keeps 8-bit pixel codes k that read
+        back as f16(k/255) -- bit-identical batches for the reference's renders (bullet_cartpole.py:239-243) in half
+        the HBM and half the gather traffic; it refuses states that are not such images."""
         assert load_factor >= 1.5, "load_factor has to be at least 1.5"      # replay_memory.py:13
         self.ctx = ctx or _lib.default_context()
         self.buffer_size = int(buffer_size)
@@ -157,8 +160,10 @@ class ReplayMemory(object):
         self.state_free_slots = collections.deque(range(self.state_buffer_size))
         self.stats = collections.Counter()
         h = C.c_void_p()
-        check(lib.cpp_replay_create(self.ctx.handle, n, self.state_buffer_size, self.state_elems,
-                                    self.action_dim, C.byref(h)))
+        assert store_dtype in ("f16", "u8"), store_dtype
+        self.store_dtype = store_dtype
+        check(lib.cpp_replay_create_ex(self.ctx.handle, n, self.state_buffer_size, self.state_elems, self.action_dim,
+                                       _lib.CPP_U8 if store_dtype == "u8" else _lib.CPP_F16, C.byref(h)))
         self.handle = h
         self.state = _StateStoreView(self)
         self._batches = {}
@@ -202,7 +207,11 @@ class ReplayMemory(object):
             if self.insert >= self.buffer_size:
                 self.insert, self.full = 0, True
         # --- payload to HBM: n+1 states (cast to f16 = numpy's RNE, :32) and n event rows
-        first, dt = _lib.as_state_array(initial_state)
+        first = np.asarray(initial_state)
+        if first.dtype == np.uint8:            # raw camera bytes: the device applies the /255 table
+            first, dt = np.ascontiguousarray(first), _lib.CPP_U8
+        else:
+            first, dt = _lib.as_state_array(first)
         states = np.empty((n + 1, self.state_elems), first.dtype)
         states[0] = first.reshape(-1)
         for k in range(n):

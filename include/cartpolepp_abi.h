@@ -32,7 +32,8 @@ extern "C" {
 #define CPP_ABI_VERSION 1
 
 enum { CPP_OK = 0, CPP_ERR_ARG = 1, CPP_ERR_HIP = 2, CPP_ERR_STATE = 3, CPP_ERR_NUMERIC = 4 };
-enum { CPP_F32 = 0, CPP_F16 = 1 };          /* host/device element type of state payloads        */
+enum { CPP_F32 = 0, CPP_F16 = 1,           /* host/device element type of state payloads        */
+       CPP_U8 = 2 };                        /* replay store only: 8-bit pixel codes k, read back as f16(k/255) */
 enum { CPP_ACTOR = 0, CPP_CRITIC = 1,       /* ddpg_cartpole.py:78 ActorNetwork / :148 CriticNetwork */
        CPP_HEAD = 2 };                      /* naf_cartpole.py: state network + one 'fc' head (value / mu / l_values) */
 enum { CPP_OPT_SGD = 0, CPP_OPT_MOMENTUM = 1, CPP_OPT_ADAM = 2 };   /* util.py:73-76 tf.train.<name>Optimizer */
@@ -136,6 +137,11 @@ int cpp_batch_state_dtype(const cpp_batch* batch);
  * exact; the device holds the f16 state store and mirrors of the five event columns. */
 int cpp_replay_create(cpp_ctx* ctx, int buffer_size, int state_slots, int64_t state_elems,
                       int action_dim, cpp_replay** out);
+/* The same with a chosen store type: CPP_F16, or CPP_U8 -- 8-bit pixel codes k that read back as f16(k/255), i.e. exactly what
+ * the f16 store holds for the reference's renders (bullet_cartpole.py:239-243) in half the HBM.  A CPP_U8 memory refuses states
+ * that are not such images (cpp_replay_write_states returns an error). */
+int cpp_replay_create_ex(cpp_ctx* ctx, int buffer_size, int state_slots, int64_t state_elems,
+                         int action_dim, int store_dtype, cpp_replay** out);
 int cpp_replay_destroy(cpp_replay* replay);
 /* self.state[idx] = s (replay_memory.py:67,106): n states, f32 is rounded to f16 (RNE) like numpy. */
 int cpp_replay_write_states(cpp_replay* replay, const int32_t* slots, int n, const void* states,

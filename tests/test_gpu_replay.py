@@ -140,3 +140,79 @@ def test_reset_from_event_log_primes_the_device_memory(tmp_path):
     for g, w in zip(got, want):
         assert np.array_equal(g, w)
     rm.close()
+
+
+# ---- 8-bit store (the reference's own TODO, bullet_cartpole.py:237-239: "could just store this as uint8") -------------
+def _render(rng, shape):
+    """A frame exactly as the reference renders it: uint8 codes -> float16, /= 255 (bullet_cartpole.py:239-243)."""
+    f = rng.integers(0, 256, shape).astype(np.float16)
+    f /= 255
+    return f
+
+
+def test_u8_store_is_bit_identical_to_the_f16_store_for_rendered_frames():
+    from cartpoleplusplus_amd.replay_memory import ReplayMemory
+    shape = (16, 16, 3, 2, 3)
+    rng = np.random.default_rng(21)
+    a, b = ReplayMemory(40, shape, 2), ReplayMemory(40, shape, 2, store_dtype="u8")
+    orm = OracleReplayMemory(40, shape, 2)
+    for ep in range(14):
+        n = int(rng.integers(1, 8))
+        cast = (lambda x: x) if ep % 2 else (lambda x: x.astype(np.float32))        # f16 and f32 payloads both
+        s0 = cast(_render(rng, shape))
+        seq = [(rng.uniform(-1, 1, (1, 2)), float(rng.integers(0, 9)), cast(_render(rng, shape))) for _ in range(n)]
+        for m in (a, b, orm):
+            m.add_episode(s0, seq)
+    idxs = rng.integers(0, 40, 33)
+    ga, gb, want = a.batch(idxs=idxs), b.batch(idxs=idxs), orm.batch(idxs=idxs)
+    for x, y, w in zip(ga, gb, want):
+        assert x.dtype == y.dtype == w.dtype and np.array_equal(x, y) and np.array_equal(y, w)
+    slots = np.arange(a.state_buffer_size)
+    used = sorted(set(slots) - set(a.state_free_slots))
+    assert np.array_equal(a.state[used], b.state[used])
+    # device-side sampling + the fused whitening statistics: same rows, same bits
+    sa, sb = a.sample_on_device(32, seed=9, counter=3), b.sample_on_device(32, seed=9, counter=3)
+    assert np.array_equal(sa.idxs, sb.idxs)
+    assert np.array_equal(sa.state_1, sb.state_1) and np.array_equal(sa.state_2, sb.state_2)
+    a.close(); b.close()
+
+
+def test_raw_camera_bytes_take_the_reference_conversion_on_the_device():
+    """uint8 frames handed over as they leave the renderer: both stores must hold what `f16(codes); /= 255` gives."""
+    from cartpoleplusplus_amd.replay_memory import ReplayMemory
+    shape = (8, 8, 3, 1, 2)
+    rng = np.random.default_rng(5)
+    codes = [rng.integers(0, 256, shape).astype(np.uint8) for _ in range(4)]
+    codes[0].reshape(-1)[:256] = np.arange(256)              # every table entry
+    want = []
+    for c in codes:
+        f = c.astype(np.float16); f /= 255
+        want.append(f)
+    for store in ("f16", "u8"):
+        rm = ReplayMemory(6, shape, 2, store_dtype=store)
+        rm.add_episode(codes[0], [(np.zeros((1, 2)), 1.0, codes[k]) for k in range(1, 4)])
+        assert np.array_equal(rm.state[[0, 1, 2, 3]], np.stack(want)), store
+        rm.close()
+
+
+def test_u8_store_refuses_states_that_are_not_pixel_images():
+    from cartpoleplusplus_amd import _lib
+    from cartpoleplusplus_amd.replay_memory import ReplayMemory
+    rm = ReplayMemory(6, (8, 8, 3, 1, 2), 2, store_dtype="u8")
+    rng = np.random.default_rng(6)
+    bad = rng.uniform(0, 1, (8, 8, 3, 1, 2)).astype(np.float32)
+    with pytest.raises(RuntimeError, match="pixel images only"):
+        rm.add_episode(bad, [(np.zeros((1, 2)), 1.0, bad)])
+    rm.close()
+    with pytest.raises(RuntimeError, match="state_elems % 8"):
+        ReplayMemory(6, (7,), 2, store_dtype="u8")
+
+
+def test_u8_synthetic_fill_matches_the_f16_fill():
+    from cartpoleplusplus_amd.replay_memory import ReplayMemory
+    shape = (16, 16, 3, 2, 2)
+    a, b = ReplayMemory(64, shape, 2), ReplayMemory(64, shape, 2, store_dtype="u8")
+    a.fill_synthetic(64, seed=11); b.fill_synthetic(64, seed=11)
+    sa, sb = a.sample_on_device(48, seed=2, counter=1), b.sample_on_device(48, seed=2, counter=1)
+    assert np.array_equal(sa.idxs, sb.idxs) and np.array_equal(sa.state_1, sb.state_1) and np.array_equal(sa.state_2, sb.state_2)
+    a.close(); b.close()
