@@ -36,6 +36,7 @@ REPLAY_ROWS_BY = {"cfg5": 6000}          # 9000 state slots x 983 KB = 8.8 GB (t
 BATCHES_PER_STEP = 5                     # --batches-per-step default (ddpg_cartpole.py:30)
 REPLAY_ROWS = 22000                      # --replay-memory-size default (ddpg_cartpole.py:46)
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_F16_MFMA_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak
 CONV_DEFS = ((5, 10), (5, 10), (3, 10))
 
 
@@ -189,13 +190,27 @@ def main():
 
     F, Bk, per_layer = conv_macs(shape)
     conv_flops_step = 2.0 * B * (4 * F + 2 * Bk)
-    c1_ms, c1_n = prof.get("conv1_fwd", (0.0, 0))
-    # a step runs conv1 forward for 4 networks (actor, critic, both targets); the fused step batches them
-    # into c1_n / pm launches (blockIdx.y = network), each over the whole minibatch
-    nets_per_launch = 4.0 * pm / max(c1_n, 1)
-    flops_per_launch = 2.0 * B * per_layer[0] * nets_per_launch
-    avg_ms = c1_ms / max(c1_n, 1)
-    achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    # a step runs conv1 forward for 4 networks (actor, critic, both targets) and conv1 dW for 2 (actor, critic); the
+    # fused step batches them into one launch each (blockIdx.y = network), each over the whole minibatch.
+    # conv1_fwd_f16x3: the same algorithmic FLOPs on the f16 pipes, three exact f16 products per f32 product
+    # (csrc/conv_k16.h) -> its peak is the dense f16 peak / 3.
+    def roof(name, nets, peak, basis):
+        ms, n = prof.get(name, (0.0, 0))
+        if n == 0:
+            return None
+        per_launch = 2.0 * B * per_layer[0] * nets * pm / n
+        avg = ms / n
+        ach = per_launch / (avg * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": name, "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "peak_basis": basis, "flops_per_launch": per_launch,
+                "avg_launch_ms": round(avg, 5), "launches": int(n), "networks_per_launch": nets * pm / n,
+                "ms_per_step": ms / pm}
+    roofs = [r for r in (
+        roof("conv1_fwd", 4.0, PEAK_F32_MFMA_TFLOPS, "dense f32-input MFMA peak"),
+        roof("conv1_fwd_f16x3", 4.0, PEAK_F16_MFMA_TFLOPS / 3.0,
+             "dense f16 MFMA peak / 3: every f32 product is three exact f16 x f16 products accumulated in f32"),
+        roof("conv1_dw", 2.0, PEAK_F32_MFMA_TFLOPS, "dense f32-input MFMA peak")) if r]
+    roofs.sort(key=lambda r: -r["ms_per_step"])
     kernels = {k: {"ms_per_step": round(v[0] / pm, 4), "launches_per_step": round(v[1] / pm, 2)}
                for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
 
@@ -207,7 +222,7 @@ def main():
         with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
             pmc = json.load(f)
         if args.workload == "cfg3":
-            traffic = pmc["kernels"]["conv1_fwd"]["hbm_bytes_per_launch"]
+            traffic = pmc["kernels"][roofs[0]["kernel"]]["hbm_bytes_per_launch"]
             traffic_src = "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, bytes per launch)"
     except Exception:
         pass
@@ -225,10 +240,8 @@ def main():
                    "global_steps_per_sec": round(steps / elapsed, 3),
                    "conv_gflop_per_step": round(conv_flops_step / 1e9, 3),
                    "conv_roofline_frac_whole_step": round(conv_flops_step * steps / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
-        "roofline": {"bound": "mfma", "kernel": "conv1_fwd", "achieved": round(achieved, 3),
-                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                     "traffic": traffic, "traffic_source": traffic_src, "flops_per_launch": flops_per_launch, "avg_launch_ms": round(avg_ms, 5),
-                     "launches": int(c1_n), "networks_per_launch": nets_per_launch},
+        "roofline": dict(roofs[0], traffic=traffic, traffic_source=traffic_src) if roofs else None,
+        "roofline_next": roofs[1:],
         "kernels": kernels,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

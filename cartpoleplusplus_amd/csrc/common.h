@@ -16,7 +16,9 @@ enum KernelId {
   K_CONV1_DW, K_CONV2_DW, K_CONV3_DW,
   K_CONV2_DX, K_CONV3_DX,
   K_DW_REDUCE, K_GEMM, K_ELEMENTWISE, K_TD, K_SUMSQ, K_CLIP_SGD, K_SOFT_UPDATE,
-  K_REPLAY_FILL, K_NAF_HEAD, K_NUM_KERNELS
+  K_REPLAY_FILL, K_NAF_HEAD,
+  K_CONV1_FWD_F16X3,      // conv1 forward on the f16 pipes with three-piece weights (conv_k16.h)
+  K_NUM_KERNELS
 };
 
 // deferred second-stage reductions of the conv dW partials (flushed in one launch)

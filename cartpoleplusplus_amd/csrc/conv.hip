@@ -1,5 +1,6 @@
 // Host-side launchers of the conv kernels (geometry selection + profiling brackets).
 #include "conv_dw_kyo.h"
+#include "conv_k16.h"
 #include <cstdlib>
 
 static int pick_xtw(int in_mode, int W) {
@@ -63,6 +64,14 @@ int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, i
   // CPP_CONV_KYO23=0 keeps the narrow layers (conv2 / conv3) on the old kernel
   static const bool no_kyo23 = getenv("CPP_CONV_KYO23") != nullptr && atoi(getenv("CPP_CONV_KYO23")) == 0;
   if ((in_mode == IN_F32_PLAIN || dx_mode) && no_kyo23) kyo = false;
+  // conv1 of f16 images: f16 matrix pipes with f32-exact operands (conv_k16.h); CPP_CONV_K16=0 keeps the f32 MFMA kernel.
+  // (B = 1 stays on the f32 kernel: action_given is bit-identical to a row of cpp_net_forward_each)
+  static const bool no_k16 = getenv("CPP_CONV_K16") != nullptr && atoi(getenv("CPP_CONV_K16")) == 0;
+  if (!no_kyo && !no_k16 && in_mode == IN_F16_WHITEN && !dx_mode && cin % 2 == 0 && a.B >= 2 && a.nout <= 10 && a.H >= 2) {
+    bool handled = false;
+    rc = conv_fwd_k16_dispatch(ctx, cin, ks, in_mode, plain_fwd, batch, &handled);
+    if (handled) { prof_end(ctx, kid == K_CONV1_FWD ? K_CONV1_FWD_F16X3 : kid); return rc; }
+  }
   if (kyo) {
     bool handled = false;
     rc = plain_fwd ? conv_fwd_kyo_dispatch_plain(ctx, cin, ks, in_mode, chb, batch, &handled)

@@ -1,0 +1,22 @@
+// conv1 forward on the f16 matrix pipes with f32-exact operands (conv_k16.h): instantiations + geometry selection.
+#include "conv_k16.h"
+
+#define K16_CASE(CIN_, XT_, IPW_, PLAIN_)                                                                    \
+  if (cin == CIN_ && xt == XT_ && ipw == IPW_ && plain == PLAIN_) { *handled = true;                         \
+    return conv_fwd_k16_launch_t<CIN_, 5, XT_, IPW_, PLAIN_>(ctx, a); }
+
+int conv_fwd_k16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool plain, const ConvArgsN& a, bool* handled) {
+  *handled = false;
+  const int W = a.a[0].W;
+  if (ks != 5 || in_mode != IN_F16_WHITEN || W > 128 || (W & 1)) return 0;
+  for (int i = 0; i < a.n; ++i) {
+    if (a.a[i].white_bstride != 0) return 0;          // per-image statistics would need per-image weights (f32 kernel)
+    if (((uintptr_t)a.a[i].in & 3) || (a.a[i].in_bstride & 1)) return 0;      // 4-byte aligned operand loads
+  }
+  const int xt = W > 16 ? 2 : 1;
+  const int ipw = W > 64 ? 1 : (W > 32 ? 2 : 4);
+  K16_CASE(18, 2, 2, false) K16_CASE(18, 2, 2, true) K16_CASE(18, 1, 4, false) K16_CASE(18, 2, 4, false) K16_CASE(18, 2, 1, false)
+  K16_CASE(6, 1, 4, false) K16_CASE(6, 2, 4, false) K16_CASE(6, 2, 2, false)
+  K16_CASE(12, 2, 2, false) K16_CASE(30, 2, 1, false)
+  return 0;
+}

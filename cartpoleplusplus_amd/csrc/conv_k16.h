@@ -1,0 +1,381 @@
+// conv1 forward on the f16 matrix pipes with f32-exact operands ("k16"): v_mfma_f32_16x16x32_f16.
+//
+// The images of this path are 8-bit renders held as f16 (replay_memory.py:32, bullet_cartpole.py:239-243), so the A
+// operand of conv1 is EXACT in f16 as long as it is the raw pixel.  The whitening of base_network.py:95-99 is affine
+// per channel, x_w = x * s_c + t_c inside the image and 0 in the SAME padding, so it moves into the B operand:
+//
+//   z[y,x,o] = b_o + sum_{ky,kx,c} (W[ky,kx,c,o] s_c) x[y+ky-P, x+kx-P, c]  +  sum_{ky,kx} (sum_c W[ky,kx,c,o] t_c) 1[y+ky-P, x+kx-P]
+//
+// where 1[.] is a "ones" channel that is 1 inside the image and 0 in the padding -- the shift term with exactly the
+// zero-padding semantics of the whitened tensor, as CIN+.. extra k values (KS per input row: 90 + 5 = 95 <= 96 for the
+// 5x5x18 layer, no extra MFMA).  The f32 weights V = W s (and the ones weights) are split into three f16 pieces
+// V 2^S = h + m + l (h = f16(V 2^S), m = f16(rest), l = f16(rest); S puts the largest |V| just under 2^15), every
+// f16 x f16 product is exact in the f32 accumulator, and the three MFMAs of a k chunk add  x * (h + m + l): the
+// result is the f32-accumulated sum of exact products of the SAME operands the f32 kernel uses -- no operand is
+// rounded to fewer than its 24 bits (pieces below the f16 normal range keep an absolute 2^-24-S floor, < 1e-9 of the
+// largest weight).  Three 16-cycle MFMAs replace eight 32-cycle ones per 32 k values.
+//
+// Everything else is the (ky,o)-column formulation of conv_kyo.h: one input row per step, KS in-flight output rows
+// in the accumulators, rotating weights read from LDS at per-lane addresses, bias folded into the accumulator reset
+// (scaled by 2^S; the epilogue multiplies the pooled value by 2^-S), pool pairs through a wave-private LDS buffer.
+//
+// The A operand does not go through LDS: a lane's 8 consecutive k values are 16 contiguous bytes of the image row
+// (k = (kx, c) runs along the row), but only 4-byte aligned (36 bytes per pixel), and a misaligned ds_read_b128 is
+// slow (measured: the 6 A reads of a row cost more than its 36 B reads).  buffer_load_dwordx4 takes 4-byte aligned
+// addresses at full rate, so every lane loads its operands of the NEXT row straight from global memory (L1/L2 hits:
+// the windows of neighbouring lanes overlap) right after the MFMAs that consumed the current ones.  No row staging,
+// no barrier in the row loop: the waves of a workgroup only share the weight image.  Elements outside the image
+// (left / right SAME padding, the over-read past k = KROW) are cleared with per-lane AND masks, which only the
+// waves' border tiles apply; reads may touch up to 128 bytes before and 256 after an image (the arena pads).
+#pragma once
+#include "conv_kyo.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned k16_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int CIN, int KS, int XT, int IPW>
+struct K16Geom {
+  static constexpr int NO = KYO_NO;
+  static constexpr int P = KS / 2;
+  static constexpr int NT = (KS * NO + 15) / 16;
+  static constexpr int STRIPS = 4 / IPW, SW = 16 * XT, WPAD = STRIPS * SW;
+  static constexpr int KROW = KS * CIN;                    // real k = (kx, c) of one input row
+  static constexpr int KAUG = KROW + KS;                   // + the ones channel (kx)
+  static constexpr int NCH = (KAUG + 31) / 32;             // MFMA k chunks per row
+  static constexpr int NPC = 3;                            // f16 pieces of a weight
+  // weight image in LDS: slab (chunk, piece) holds the 16-byte operand (ky, lane group g, o) at ky*PS + g*GS + o*16;
+  // the padded strides keep the rotating per-lane reads of a ds_read_b128 at 1.2 accesses per bank quad (2.45 compact)
+  static constexpr bool PADDED = NCH * NPC * 5632 <= 64 * 1024;
+  static constexpr int PS = PADDED ? 1120 : 4 * NO * 16, GS = PADDED ? 256 : NO * 16, SLAB = PADDED ? 5632 : KS * 4 * NO * 16;
+  static constexpr int WLB = NCH * NPC * SLAB;             // bytes
+  static constexpr int EF = 2 * 8 * XT * NO * 2;           // floats per wave: (value, code) of the two rows of a pool pair
+  static constexpr int LDS_BYTES = WLB + 4 * EF * 4 + 64;
+  static constexpr int BIAS_BYTES = 128;                   // the buffer descriptor starts this far before the image
+  // element e of lane group g in chunk ch is k = 32 ch + 8 g + e
+  static __host__ __device__ constexpr bool vgpr_may_be_synthetic(int ch, int v) {       // any lane group: not both real
+    return 32 * ch + 8 * 3 + 2 * v + 1 >= KROW;
+  }
+};
+
+template <int CIN, int KS, int XT, int IPW, bool PLAIN = false>
+__global__ __launch_bounds__(CONV_THREADS, 2) void conv_fwd_k16_kernel(const ConvArgsN batch) {
+  typedef K16Geom<CIN, KS, XT, IPW> G;
+  constexpr int P = G::P, NT = G::NT, NCH = G::NCH, NPC = G::NPC, NO = KYO_NO;
+  static_assert(CIN % 2 == 0, "A operands must be 4-byte aligned");
+  const ConvArgs& a = batch.a[blockIdx.y];
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  unsigned char* wl = lds_raw;                                    // weight image
+  float2* ebuf = reinterpret_cast<float2*>(lds_raw + G::WLB);     // [4 waves][2 parities][8*XT][NO]
+  float* red = reinterpret_cast<float*>(lds_raw + G::WLB + 4 * G::EF * 4);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lj = lane >> 4;
+  const int strip = wave % G::STRIPS;
+  const int b0 = blockIdx.x * IPW;
+  const int H = a.H, W = a.W, Hp = H >> 1, Wp = W >> 1, nout = a.nout;
+
+  // ---- one-time setup: the split weight image
+  float sc, inv;                                      // 2^S, 2^-S
+  {
+    constexpr int NV = KS * NCH * 32 * NO;            // (ky, k, o), o fastest
+    constexpr int NW = (NV + CONV_THREADS - 1) / CONV_THREADS;
+    float wv[NW];
+    float vmax = 0.f;
+#pragma unroll
+    for (int n = 0; n < NW; ++n) {
+      const int i = tid + n * CONV_THREADS;
+      const int o = i % NO, r = i / NO;
+      const int k = r % (NCH * 32), ky = r / (NCH * 32);
+      float v = 0.f;
+      if (i < NV && o < nout) {
+        if (k < G::KROW) {
+          v = a.w[(ky * G::KROW + k) * nout + o] * a.scale[k % CIN];
+        } else if (k < G::KAUG) {                     // ones channel: sum_c W t_c
+          const int kx = k - G::KROW;
+          float s = 0.f;
+          for (int c = 0; c < CIN; ++c) s += a.w[(ky * G::KROW + kx * CIN + c) * nout + o] * a.shift[c];
+          v = s;
+        }
+        if (a.wscale != 0.f) v *= a.wscale;
+      }
+      wv[n] = v;
+      vmax = fmaxf(vmax, fabsf(v));
+    }
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if (lane == 0) red[wave] = vmax;
+    __syncthreads();
+    vmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    int S = 0;
+    if (vmax > 0.f && vmax < 3.0e38f) S = 14 - ilogbf(vmax);       // vmax 2^S in [2^14, 2^15)
+    S = S > 100 ? 100 : (S < -100 ? -100 : S);
+    sc = ldexpf(1.f, S); inv = ldexpf(1.f, -S);
+#pragma unroll
+    for (int n = 0; n < NW; ++n) {
+      const int i = tid + n * CONV_THREADS;
+      if (i < NV) {
+        const int o = i % NO, r = i / NO;
+        const int k = r % (NCH * 32), ky = r / (NCH * 32);
+        const int ch = k >> 5, g = (k >> 3) & 3, e = k & 7;
+        const float v = wv[n] * sc;
+        const _Float16 h = (_Float16)v;
+        const float r1 = v - (float)h;
+        const _Float16 m = (_Float16)r1;
+        const float r2 = r1 - (float)m;
+        const _Float16 l = (_Float16)r2;
+        unsigned char* dst = wl + ky * G::PS + g * G::GS + o * 16 + e * 2;
+        *reinterpret_cast<_Float16*>(dst + (ch * NPC + 0) * G::SLAB) = h;
+        *reinterpret_cast<_Float16*>(dst + (ch * NPC + 1) * G::SLAB) = m;
+        *reinterpret_cast<_Float16*>(dst + (ch * NPC + 2) * G::SLAB) = l;
+      }
+    }
+  }
+  __syncthreads();                                   // weight image visible; no barrier after this one
+
+  const int swave = __builtin_amdgcn_readfirstlane(wave);
+  const int simg = swave / G::STRIPS, sstrip = swave % G::STRIPS;
+  const int sbimg = b0 + simg;
+  if (sbimg >= a.B) return;                          // wave-uniform
+
+  // ---- per-lane column bookkeeping (as conv_kyo.h): column j = 16 t + li = p * NO + o; row loop unrolled by KS
+  uint32_t wadr[KS][NT];
+  uint32_t eadr[NT];
+  float biast[NT];
+  float2* ev = ebuf + swave * (2 * 8 * XT * NO);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int j = 16 * t + li;
+    const bool valid = j < KS * NO;
+    const int o = j % NO;
+    biast[t] = (!PLAIN && valid && o < nout) ? a.bias[o] * sc : 0.f;
+    eadr[t] = PLAIN ? (uint32_t)(((sstrip * G::SW + 4 * lj) * nout + o) * 4)
+                    : keep_in_vgpr(lds_addr(ev + (lj * 2) * NO + o));
+    const int p = valid ? j / NO : 0;
+#pragma unroll
+    for (int sq = 0; sq < KS; ++sq) {
+      const int ky = (sq + P - p + KS) % KS;
+      wadr[sq][t] = keep_in_vgpr(lds_addr(wl + ky * G::PS + lj * G::GS + (valid ? o : 0) * 16));
+    }
+  }
+
+  // ---- operand masks.  amask / acst: the synthetic k values of this lane's group (ones channel, zero fill) -- every
+  // tile.  bmask: additionally the SAME padding (pixel x + kx - P outside [0, W)) -- only tiles that touch a border.
+  unsigned amask[NCH][4], acst[NCH][XT][4], bmask[NCH][XT][4];
+  bool border[XT];
+#pragma unroll
+  for (int m = 0; m < XT; ++m) {
+    const int x0 = sstrip * G::SW + m * 16;            // wave-uniform
+    border[m] = x0 < P || x0 + 15 + (KS - 1 - P) >= W;
+  }
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      unsigned mk = 0u;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if (32 * ch + 8 * lj + 2 * v + h < G::KROW) mk |= 0xFFFFu << (16 * h);
+      amask[ch][v] = mk;
+#pragma unroll
+      for (int m = 0; m < XT; ++m) {
+        unsigned cs = 0u, bm = 0u;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int k = 32 * ch + 8 * lj + 2 * v + h;
+          const int kx = k < G::KROW ? k / CIN : k - G::KROW;
+          const int xi = strip * G::SW + m * 16 + li + kx - P;
+          const bool inside = xi >= 0 && xi < W;
+          if (k < G::KROW && inside) bm |= 0xFFFFu << (16 * h);
+          if (k >= G::KROW && k < G::KAUG && inside) cs |= 0x3C00u << (16 * h);      // f16 1.0
+        }
+        acst[ch][m][v] = cs;
+        bmask[ch][m][v] = bm;
+      }
+    }
+
+  // ---- pooled-row writer (as conv_kyo.h)
+  constexpr int NC = (8 * XT * NO + 63) / 64;
+  uint32_t cadr[NC];
+  bool cact[NC];
+  unsigned coe[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int idx = lane + 64 * i;
+    const int xl = idx / nout, o = idx - xl * nout;
+    const int px = ((sstrip * G::SW) >> 1) + xl;
+    cact[i] = idx < 8 * XT * nout && px < Wp;
+    cadr[i] = keep_in_vgpr(lds_addr(ev + (cact[i] ? xl * NO + o : 0)));
+    coe[i] = (unsigned)(px * nout + o);
+  }
+  const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      a.out + (long)sbimg * a.out_bstride, 0, (PLAIN ? H * W : Hp * Wp) * nout * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t amax_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      a.out_amax + (long)sbimg * Hp * Wp * nout, 0, Hp * Wp * nout, 0x00020000);
+
+  // ---- A operands: 16 bytes per lane and (tile, chunk) straight from the image row
+  const int rowbytes = W * CIN * 2;
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)a.in + ((long)sbimg * a.in_bstride) * 2 - G::BIAS_BYTES), 0, H * rowbytes + G::BIAS_BYTES + 256, 0x00020000);
+  const int avoff = G::BIAS_BYTES + ((strip * G::SW + li - P) * CIN + 8 * lj) * 2;      // >= 128 - 2 P CIN... (checked by the host)
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  k16_u32x4 av[NCH][XT];
+  auto load_a = [&](int ch, int y) {
+#pragma unroll
+    for (int m = 0; m < XT; ++m) {
+#ifdef K16_ABL_NOLDSA
+      av[ch][m] = (k16_u32x4){amask[NCH - 1][1], acst[NCH - 1][0][1], amask[NCH - 1][2], (unsigned)y};
+#else
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, avoff + (m * 16 * CIN + 32 * ch) * 2, y * rowbytes, 0);
+      av[ch][m] = (k16_u32x4){v.x, v.y, v.z, v.w};
+#endif
+    }
+  };
+
+  f32x4 acc[XT][NT];
+#pragma unroll
+  for (int m = 0; m < XT; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[m][t] = (f32x4){biast[t], biast[t], biast[t], biast[t]};
+
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) load_a(ch, 0);
+
+  // B operands of one k chunk; two sets: the loads of chunk ch+1 are in flight under the MFMAs of ch
+  f16x8 bv[2][NT][NPC];
+  auto load_b = [&](int ch, int set, const uint32_t* wa) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int pc = 0; pc < NPC; ++pc) {
+#ifdef K16_ABL_NOLDSB
+        bv[set][t][pc] = __builtin_bit_cast(f16x8, (k16_u32x4){amask[NCH - 1][1], acst[NCH - 1][0][1], amask[NCH - 1][2], wa[t]});
+#else
+        bv[set][t][pc] = lds_load<f16x8>(wa[t], (ch * NPC + pc) * G::SLAB);
+#endif
+      }
+  };
+  load_b(0, 0, wadr[0]);
+
+  for (int q0 = 0; q0 < H + P; q0 += KS) {
+#pragma unroll
+    for (int sq = 0; sq < KS; ++sq) {
+      const int q = q0 + sq;
+      if (q >= H + P) break;                         // uniform
+      constexpr int PD_BASE = (KS - P) % KS;
+      const int pdone = (PD_BASE + sq) % KS;
+      if (q < H) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+          if (ch + 1 < NCH) load_b(ch + 1, (ch + 1) & 1, wadr[sq]);
+          k16_u32x4 af[XT];
+#pragma unroll
+          for (int m = 0; m < XT; ++m) {
+            k16_u32x4 u = av[ch][m];
+            if (border[m]) {                         // wave-uniform
+#pragma unroll
+              for (int v = 0; v < 4; ++v) u[v] = (u[v] & bmask[ch][m][v]) | acst[ch][m][v];
+            } else {
+#pragma unroll
+              for (int v = 0; v < 4; ++v)
+                if (G::vgpr_may_be_synthetic(ch, v)) u[v] = (u[v] & amask[ch][v]) | acst[ch][m][v];
+            }
+            af[m] = u;
+          }
+#ifdef K16_ABL_1PC
+          for (int pc = 0; pc >= 0; --pc)
+#else
+#pragma unroll
+          for (int pc = NPC - 1; pc >= 0; --pc)      // small pieces first; XT*NT independent accumulators between the pieces
+#endif
+#pragma unroll
+            for (int m = 0; m < XT; ++m)
+#pragma unroll
+              for (int t = 0; t < NT; ++t)
+                acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[m]), bv[ch & 1][t][pc], acc[m][t], 0, 0, 0);
+          if (q + 1 < H) load_a(ch, q + 1);          // this chunk's operands of the next row, a whole row period ahead
+        }
+      }
+      if (q + 1 < H) {                               // chunk 0 of the next row loads under the epilogue
+        load_b(0, NCH & 1, wadr[(sq + 1) % KS]);
+        if (NCH & 1) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int pc = 0; pc < NPC; ++pc) bv[0][t][pc] = bv[1][t][pc];
+        }
+      }
+
+#ifdef K16_ABL_NOEPI
+      const int y = (q == H + P - 1) ? q - P : -1;
+#else
+      const int y = q - P;
+#endif
+      const int par = y & 1;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int clo = pdone * NO - 16 * t, chi = pdone * NO + NO - 1 - 16 * t;
+        if (chi >= 0 && clo <= 15) {
+          const bool inr = li >= clo && li <= chi;
+          if (inr) {
+#pragma unroll
+            for (int m = 0; m < XT; ++m) {
+              if (PLAIN) {
+                if (y >= 0) {
+#pragma unroll
+                  for (int r = 0; r < 4; ++r)
+                    if (sstrip * G::SW + m * 16 + 4 * lj + r < W)
+                      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][t][r] * inv), out_rsrc,
+                                                            (int)eadr[t] + ((m * 16 + r) * NO) * 4, y * W * nout * 4, 0);
+                }
+              } else if (y >= 0) {
+                const uint32_t ea = eadr[t] + (uint32_t)(par * (8 * XT * NO) * 8);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                  const float z0 = acc[m][t][2 * h], z1 = acc[m][t][2 * h + 1];
+                  lds_store(ea, ((m * 8 + h) * NO) * 8, (f32x2){z1 > z0 ? z1 : z0, __int_as_float(z1 > z0 ? 1 : 0)});
+                }
+              }
+              acc[m][t] = (f32x4){biast[t], biast[t], biast[t], biast[t]};
+            }
+          }
+        }
+      }
+      if (!PLAIN && y >= 0 && par == 1 && (y >> 1) < Hp) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int orow = (y >> 1) * Wp * nout;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+          if (cact[i]) {
+            const f32x2 top = lds_load<f32x2>(cadr[i], 0), bot = lds_load<f32x2>(cadr[i], (8 * XT * NO) * 8);
+            const bool lower = bot.x > top.x;
+            const float mx = lower ? bot.x : top.x;
+            const int code = lower ? 2 + __float_as_int(bot.y) : __float_as_int(top.y);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mx > 0.f ? mx * inv : 0.f), out_rsrc, (int)(coe[i] * 4), orow * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)code, amax_rsrc, (int)coe[i], orow, 0);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+}
+
+template <int CIN, int KS, int XT, int IPW, bool PLAIN = false>
+static inline int conv_fwd_k16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
+  typedef K16Geom<CIN, KS, XT, IPW> G;
+  const ConvArgs& a = batch.a[0];
+  const size_t lds_bytes = (size_t)G::LDS_BYTES;
+  auto kern = conv_fwd_k16_kernel<CIN, KS, XT, IPW, PLAIN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_done = true;
+  }
+  const int grid = (a.B + IPW - 1) / IPW;
+  hipLaunchKernelGGL(kern, dim3(grid, batch.n), dim3(CONV_THREADS), lds_bytes, ctx->stream, batch);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+// conv1 of f16 image batches with one whitening table for the batch (white_bstride == 0), even CIN and W, 5x5
+int conv_fwd_k16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool plain, const ConvArgsN& a, bool* handled);

@@ -55,7 +55,7 @@ void prof_end(cpp_ctx* ctx, int kid) {
 static const char* kKernelNames[K_NUM_KERNELS] = {
     "gather_stats", "stats_finalize", "stats_generic", "conv1_fwd", "conv2_fwd", "conv3_fwd",
     "conv1_dw", "conv2_dw", "conv3_dw", "conv2_dx", "conv3_dx", "dw_reduce", "gemm", "elementwise",
-    "td", "sumsq", "clip_sgd", "soft_update", "replay_fill", "naf_head"};
+    "td", "sumsq", "clip_sgd", "soft_update", "replay_fill", "naf_head", "conv1_fwd_f16x3"};
 
 // ---------------------------------------------------------------------------------------------
 // context
@@ -130,11 +130,16 @@ extern "C" int cpp_prof_read(cpp_ctx* c, int k, double* total_ms, int64_t* launc
 struct Arena {
   std::vector<void*> ptrs;
   hipStream_t stream = nullptr;     // zero-fills are ordered on the owning ctx's stream (never the null stream)
+  // every allocation sits between two 256-byte guard bands: the conv1 operand loads (conv_k16.h) read up to 128 bytes
+  // before and 256 after an image batch (masked out, but the addresses must be mapped)
+  static constexpr size_t GUARD = 256;
   int alloc(void** p, size_t bytes, bool zero = true) {
     if (bytes == 0) bytes = 16;
-    HIP_CHECK(hipMalloc(p, bytes));
-    ptrs.push_back(*p);
-    if (zero) HIP_CHECK(hipMemsetAsync(*p, 0, bytes, stream));
+    void* raw = nullptr;
+    HIP_CHECK(hipMalloc(&raw, bytes + 2 * GUARD));
+    ptrs.push_back(raw);
+    *p = (char*)raw + GUARD;
+    if (zero) HIP_CHECK(hipMemsetAsync(raw, 0, bytes + 2 * GUARD, stream));
     return 0;
   }
   void release() { for (void* p : ptrs) (void)hipFree(p); ptrs.clear(); }

@@ -138,3 +138,52 @@ def test_earlier_conv_kernels_stay_parity_green_when_selected():
                        stderr=subprocess.STDOUT, timeout=600)
     tail = r.stdout.decode()[-1500:]
     assert r.returncode == 0 and " passed" in tail, tail
+
+
+_CONV1_ERR_SNIPPET = r"""
+import numpy as np
+from oracle import ddpg_np as O
+from tests.helpers import make_pair
+SHAPE, B = (64, 64, 3, 2, 3), 256
+agent, ref, _ = make_pair(SHAPE, B, True, replay_size=600)
+agent.replay_memory.fill_synthetic(500, seed=5)
+b = agent.replay_memory.sample_on_device(B, seed=3, counter=0)
+s1 = b.state_1
+scale, shift = O.whiten_stats(s1.reshape(B, 64, 64, 18), np.float64)
+sub = ref.actor.forward(s1[:6], white=(scale, shift))          # float64 ground truth
+agent.actor.forward(s1)
+pool1 = agent.actor.pool1.eval(B)[:6]
+want = sub["conv1"][1]
+print("CONV1ERR %.3e %.3e" % (np.abs(pool1 - want).max(), np.abs(want).max()))
+agent.close()
+"""
+
+
+def test_f16x3_conv1_is_as_close_to_the_f64_oracle_as_the_f32_mfma_kernel():
+    """conv_k16.h claims f32-grade results (exact f16 x f16 products of the same operands, f32 accumulation): its pooled
+    conv1 output must sit as close to the float64 oracle as the f32-MFMA kernel's (CPP_CONV_K16=0), far inside 1e-5."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    errs = {}
+    for k16 in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", _CONV1_ERR_SNIPPET], cwd=root, env=dict(os.environ, CPP_CONV_K16=k16),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        m = re.search(r"CONV1ERR (\S+) (\S+)", r.stdout.decode())
+        assert r.returncode == 0 and m, r.stdout.decode()[-1500:]
+        errs[k16] = (float(m.group(1)), float(m.group(2)))
+    (e16, mag), (e32, _) = errs["1"], errs["0"]
+    assert mag > 0.5                                   # outputs of order one and more
+    assert e16 < 1e-5 and e32 < 1e-5, errs             # (measured: 3.7e-6 vs 7.0e-6 at |z| up to 7.1)
+    assert e16 <= 1.25 * e32 + 1e-7, errs
+
+
+def test_f32_mfma_conv1_stays_parity_green_when_selected():
+    """CPP_CONV_K16=0 keeps conv1 forward on the f32-input MFMA kernel (the path of f32 states, odd channel counts and
+    per-image whitening): the full-size parity cases must pass on it too."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "64x64 and (forward or gradients or fused)"], cwd=root, env=dict(os.environ, CPP_CONV_K16="0"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    tail = r.stdout.decode()[-1500:]
+    assert r.returncode == 0 and " passed" in tail, tail
