@@ -209,7 +209,9 @@ def main():
         roof("conv1_fwd", 4.0, PEAK_F32_MFMA_TFLOPS, "dense f32-input MFMA peak"),
         roof("conv1_fwd_f16x3", 4.0, PEAK_F16_MFMA_TFLOPS / 3.0,
              "dense f16 MFMA peak / 3: every f32 product is three exact f16 x f16 products accumulated in f32"),
-        roof("conv1_dw", 2.0, PEAK_F32_MFMA_TFLOPS, "dense f32-input MFMA peak")) if r]
+        roof("conv1_dw", 2.0, PEAK_F32_MFMA_TFLOPS, "dense f32-input MFMA peak"),
+        roof("conv1_dw_f16x3", 2.0, PEAK_F16_MFMA_TFLOPS / 3.0,
+             "dense f16 MFMA peak / 3: every f32 product is three exact f16 x f16 products accumulated in f32")) if r]
     roofs.sort(key=lambda r: -r["ms_per_step"])
     kernels = {k: {"ms_per_step": round(v[0] / pm, 4), "launches_per_step": round(v[1] / pm, 2)}
                for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}

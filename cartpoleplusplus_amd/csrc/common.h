@@ -18,6 +18,7 @@ enum KernelId {
   K_DW_REDUCE, K_GEMM, K_ELEMENTWISE, K_TD, K_SUMSQ, K_CLIP_SGD, K_SOFT_UPDATE,
   K_REPLAY_FILL, K_NAF_HEAD,
   K_CONV1_FWD_F16X3,      // conv1 forward on the f16 pipes with three-piece weights (conv_k16.h)
+  K_CONV1_DW_F16X3,       // conv1 dW on the f16 pipes with three-piece dY (conv_dw16.h)
   K_NUM_KERNELS
 };
 

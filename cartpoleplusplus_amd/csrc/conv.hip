@@ -1,6 +1,7 @@
 // Host-side launchers of the conv kernels (geometry selection + profiling brackets).
 #include "conv_dw_kyo.h"
 #include "conv_k16.h"
+#include "conv_dw16.h"
 #include <cstdlib>
 
 static int pick_xtw(int in_mode, int W) {
@@ -129,7 +130,13 @@ int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, co
     if (c == 0) kyo = false; else if (c < chb) chb = c;
   }
   bool handled = false;
-  if (kyo) rc = conv_dw_kyo_dispatch(ctx, cin, ks, in_mode, chb, dense, batch, &grid, &handled);
+  // conv1 of f16 images: f16 matrix pipes with f32-exact operands (conv_dw16.h); CPP_CONV_K16=0 keeps the f32 MFMA kernel
+  static const bool no_k16 = getenv("CPP_CONV_K16") != nullptr && atoi(getenv("CPP_CONV_K16")) == 0;
+  if (!no_kyo && !no_k16 && !dense && in_mode == IN_F16_WHITEN && cin % 2 == 0) {
+    rc = conv_dw16_dispatch(ctx, cin, ks, in_mode, batch, &grid, &handled);
+    if (handled) kid = kid == K_CONV1_DW ? K_CONV1_DW_F16X3 : kid;
+  }
+  if (!handled && kyo) rc = conv_dw_kyo_dispatch(ctx, cin, ks, in_mode, chb, dense, batch, &grid, &handled);
   if (dense && !handled) {
     cpp_set_error("conv dW from dense dY rows (batch norm): no kernel for %dx%d, %d channels, %dx%d taps, %d-byte rows chunks",
                   batch.a[0].H, batch.a[0].W, cin, ks, ks, chb);

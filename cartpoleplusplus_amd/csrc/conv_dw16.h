@@ -1,0 +1,347 @@
+// conv1 weight / bias gradient on the f16 matrix pipes with f32-exact operands ("dw16"): v_mfma_f32_16x16x32_f16.
+//
+//   dW[ky][kx][c][o] = sum_{b,q,x} xw[b, q, x + kx - P, c] * dY[b, q - ky + P, x, o],   xw = x * s_c + t_c inside the image, 0 in the padding
+//                    = s_c * G[ky][kx][c][o] + t_c * T[ky][kx][o]
+//   G = the same correlation with the RAW f16 pixel x (exact in f16: replay_memory.py:32), T = the same with the "ones" channel
+//   (1 inside the image) -- both come out of ONE MFMA stream whose A rows are (kx, c'), c' = 0..CIN-1 the pixel channels, CIN the
+//   ones channel.  dY (f32) is split into three f16 pieces dY 2^S = h + m + l (S from the largest |pooled gradient| the
+//   workgroup will see), every f16 x f16 product is exact, the accumulators are f32: the f32-MFMA kernel's arithmetic
+//   (conv_dw_kyo.h) with exact products, three 16-cycle MFMAs per 32 pixels instead of eight 32-cycle ones.
+//
+// Formulation as conv_dw_kyo.h: per input row q,  D[m = (kx,c'), n = (ky,o)] += A[m, pixel] * B[pixel, n]; wave w owns column
+// tile w of (ky,o) and all MT row tiles; units = (image, band of rows); one partial per workgroup (whitening applied to it:
+// s_c G + t_c T) for conv_dw_reduce_kernel.
+//
+// The contraction runs over PIXELS, but an image row is channel-contiguous.  The row is copied raw into LDS with a pixel
+// pitch of CP = CIN + 2 halves (8-byte aligned pixels; channel CIN holds the constant 1, CIN + 1 is zero), so that
+// A[m = CP kx + c][x] = row[CP x + m] is flat in m, and ds_read_b64_tr_b16 delivers the transposed fragment: lane quad j of a
+// 16-lane group supplies the address of rows 4q..4q+3 of one pixel, lane i receives row i of four pixels.  The pixels of a
+// 32-pixel chunk are dealt to (lane group g, read r, quad j) as x = 16 (g & 1) + 4 j + 2 (g >> 1) + r: the 8 quads of a
+// 32-lane half then hit 8 disjoint bank octets (pitch 10 dwords), and the two reads of a lane are the two pixels of one
+// pooled cell.  dY rows sit in LDS as [piece][o][chunk][g][8 halves] in that same pixel order (16-byte B operands).
+#pragma once
+#include "conv_k16.h"
+
+typedef short dw16_v4s __attribute__((__vector_size__(4 * sizeof(short))));
+typedef unsigned dw16_u32x2 __attribute__((ext_vector_type(2)));
+
+template <int CIN, int KS, int NCHK>
+struct Dw16Geom {
+  static constexpr int P = KS / 2, NO = KYO_NO, NPC = 3;
+  static constexpr int CP = (CIN + 1 + 3) & ~3;               // channel pitch of a pixel in LDS (halves)
+  static constexpr int MROWS = KS * CP, MT = (MROWS + 15) / 16;
+  static constexpr int KROW = KS * CIN;
+  static constexpr int WPAD = 32 * NCHK;
+  static constexpr int ROWH = ((CP * (WPAD + KS - 1) + 16 * MT - MROWS) + 7) & ~7;     // halves per staged input row (+ m over-read)
+  static constexpr int ROWB = ROWH * 2;
+  static constexpr int DOST = 64 * NCHK + 32;                 // bytes per (piece, o): NCHK chunks of 64 + skew
+  static constexpr int DPC = NO * DOST;
+  static constexpr int DSLOT = ((NPC * DPC - 192 + 255) / 256) * 256 + 192;            // = 192 (mod 256): B reads 1.17 accesses per bank quad
+  static constexpr int RING_IN = 3, RING_DY = 6, UNROLL = 6;
+  static constexpr int NCELL = (16 * NCHK * NO + CONV_THREADS - 1) / CONV_THREADS;     // pooled cells of a row per thread
+  static constexpr int NVIN = (WPAD * CIN / 2 + CONV_THREADS - 1) / CONV_THREADS;      // dwords of an input row per thread
+  static constexpr int IN_BYTES = RING_IN * ROWB, DY_BYTES = RING_DY * DSLOT;
+  static constexpr int LDS_BYTES = ((IN_BYTES + 15) & ~15) + DY_BYTES + 64;       // (the epilogue scratch reuses the dY ring)
+  static_assert(DY_BYTES >= CONV_THREADS * NCELL * 4 + 4 * KS * 16 * 4, "epilogue scratch fits the dY ring");
+};
+
+template <int CIN, int KS, int NCHK>
+__global__ __launch_bounds__(CONV_THREADS, 3) void conv_dw16_kernel(const ConvArgsN batch, int units_per_img, int band) {
+  typedef Dw16Geom<CIN, KS, NCHK> G;
+  constexpr int P = G::P, NO = G::NO, MT = G::MT, CP = G::CP, NPC = G::NPC, ROWB = G::ROWB, DSLOT = G::DSLOT;
+  static_assert(CIN % 2 == 0 && (KS * NO + 15) / 16 == 4, "even channel count, one column tile per wave");
+  const ConvArgs& a = batch.a[blockIdx.y];
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  unsigned char* inring = lds_raw;                                         // [3][ROWB]
+  unsigned char* dyring = lds_raw + ((G::IN_BYTES + 15) & ~15);            // [6][DSLOT]
+  float* red = reinterpret_cast<float*>(dyring + G::DY_BYTES);
+  float* texch = reinterpret_cast<float*>(dyring);                         // epilogue (after the last row barrier): [4 waves][KS][16]
+  float* dbs = texch + 4 * KS * 16;                                        // bias-gradient scratch [NCELL][256]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lj = lane >> 4;
+  const int H = a.H, W = a.W, Hp = H >> 1, Wp = W >> 1, nout = a.nout;
+  const int units = a.B * units_per_img;
+
+  // ---- zero both rings; the ones channel of the in-image pixels of every input slot (staging never touches it)
+  for (int i = tid; i < (int)(((G::IN_BYTES + 15) & ~15) + G::DY_BYTES) / 16; i += CONV_THREADS)
+    reinterpret_cast<float4*>(lds_raw)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  for (int i = tid; i < G::RING_IN * W; i += CONV_THREADS) {
+    const int s = i / W, x = i - s * W;
+    *reinterpret_cast<unsigned*>(inring + s * ROWB + 2 * (CP * (x + P) + CIN)) = 0x00003C00u;      // (1.0, 0)
+  }
+
+  // ---- 2^S: the largest |pooled gradient| among the pooled rows this workgroup's units touch lands in [2^14, 2^15)
+  float sc, inv;
+  {
+    float vmax = 0.f;
+    for (int unit = blockIdx.x; unit < units; unit += gridDim.x) {
+      const int b = unit / units_per_img;
+      const int q_lo = (unit - b * units_per_img) * band;
+      const int rows = min(band, H - q_lo);
+      const int py0 = max(0, (q_lo - P) >> 1), py1 = min(Hp - 1, (q_lo + rows - 1 + P) >> 1);
+      const float* dp = a.dy.dpool + (long)b * a.dy.dpool_bstride;
+      for (int e = py0 * Wp * nout + tid; e < (py1 + 1) * Wp * nout; e += CONV_THREADS) vmax = fmaxf(vmax, fabsf(dp[e]));
+    }
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if (lane == 0) red[wave] = vmax;
+    __syncthreads();
+    vmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    int S = 0;
+    if (vmax > 0.f && vmax < 3.0e38f) S = 14 - ilogbf(vmax);
+    S = S > 100 ? 100 : (S < -100 ? -100 : S);
+    sc = ldexpf(1.f, S); inv = ldexpf(1.f, -S);
+  }
+
+  // ---- input row staging: raw dwords (two channels) of the f16 row -> pixel pitch CP
+  unsigned sv[G::NVIN];
+  bool sact[G::NVIN];
+  uint32_t sdst[G::NVIN];
+#pragma unroll
+  for (int i = 0; i < G::NVIN; ++i) {
+    const int d = tid + CONV_THREADS * i;
+    const int x = d / (CIN / 2), w = d - x * (CIN / 2);
+    sact[i] = d < W * (CIN / 2);
+    sdst[i] = keep_in_vgpr(lds_addr(inring + 2 * (CP * (x + P) + 2 * w)));
+  }
+  const int rowbytes = W * CIN * 2;
+  auto in_load = [&](const __amdgpu_buffer_rsrc_t& rs, int q) {
+#pragma unroll
+    for (int i = 0; i < G::NVIN; ++i)
+      if (sact[i]) sv[i] = __builtin_amdgcn_raw_buffer_load_b32(rs, (tid + CONV_THREADS * i) * 4, q * rowbytes, 0);
+  };
+  auto in_store = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < G::NVIN; ++i)
+      if (sact[i]) lds_store(sdst[i], slot * ROWB, sv[i]);
+  };
+
+  // ---- dY staging: a thread owns pooled cells idx = px * nout + o of a pooled row (the same cells for every row); the
+  // masked gradient is scaled, split into three f16 pieces and written to both image rows of the pooled row.
+  // pixel x = 32 ch + w sits in lane group g = 2 ((w >> 1) & 1) + (w >> 4), element e = 4 (w & 1) + ((w >> 2) & 3)
+  constexpr int NCELL = G::NCELL;
+  bool cact[NCELL];
+  uint32_t cdst[NCELL];
+  float cg[NCELL], dbsum[NCELL];
+  unsigned short cpc[NCELL][NPC];
+  int ccode[NCELL];
+#pragma unroll
+  for (int c = 0; c < NCELL; ++c) {
+    const int idx = tid + CONV_THREADS * c;
+    const int px = idx / nout, o = idx - px * nout;
+    cact[c] = idx < Wp * nout;
+    const int x = 2 * px, ch = x >> 5, w = x & 31;
+    const int g = 2 * ((w >> 1) & 1) + (w >> 4), e = (w >> 2) & 3;
+    cdst[c] = keep_in_vgpr(lds_addr(dyring + o * G::DOST + ch * 64 + g * 16 + e * 2));
+    cg[c] = 0.f; ccode[c] = 0; dbsum[c] = 0.f;
+#pragma unroll
+    for (int pc = 0; pc < NPC; ++pc) cpc[c][pc] = 0;
+  }
+  float rpv[2][NCELL], rdv[2][NCELL];
+  int rcd[2][NCELL];
+  auto dy_issue = [&](const __amdgpu_buffer_rsrc_t& rp, const __amdgpu_buffer_rsrc_t& rd,
+                      const __amdgpu_buffer_rsrc_t& rc, int py, int set) {
+    const bool rowok = py >= 0 && py < Hp;           // uniform
+#pragma unroll
+    for (int c = 0; c < NCELL; ++c) {
+      rpv[set][c] = 0.f; rdv[set][c] = 0.f; rcd[set][c] = 0;
+      if (rowok && cact[c]) {
+        const int vo = (tid + CONV_THREADS * c) * 4, so = py * Wp * nout * 4;
+        rpv[set][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rp, vo, so, 0));
+        rdv[set][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, vo, so, 0));
+        rcd[set][c] = __builtin_amdgcn_raw_buffer_load_b8(rc, vo >> 2, so >> 2, 0);
+      }
+    }
+  };
+  auto dy_conv = [&](int set, bool count) {
+#pragma unroll
+    for (int c = 0; c < NCELL; ++c) {
+      cg[c] = rpv[set][c] > 0.f ? rdv[set][c] : 0.f;
+      ccode[c] = rcd[set][c];
+      if (count) dbsum[c] += cg[c];
+      const float v = cg[c] * sc;
+      const _Float16 h = (_Float16)v;
+      const float r1 = v - (float)h;
+      const _Float16 m = (_Float16)r1;
+      const _Float16 l = (_Float16)(r1 - (float)m);
+      cpc[c][0] = __builtin_bit_cast(unsigned short, h);
+      cpc[c][1] = __builtin_bit_cast(unsigned short, m);
+      cpc[c][2] = __builtin_bit_cast(unsigned short, l);
+    }
+  };
+  auto dy_store = [&](int slot, int ry) {            // image row with parity ry of the pooled row -> ring slot
+#pragma unroll
+    for (int c = 0; c < NCELL; ++c) {
+      if (cact[c]) {
+        const bool s0 = ccode[c] == 2 * ry, s1 = ccode[c] == 2 * ry + 1;
+#pragma unroll
+        for (int pc = 0; pc < NPC; ++pc) {
+          lds_store(cdst[c], slot * DSLOT + pc * G::DPC, (unsigned short)(s0 ? cpc[c][pc] : 0));
+          lds_store(cdst[c], slot * DSLOT + pc * G::DPC + 8, (unsigned short)(s1 ? cpc[c][pc] : 0));
+        }
+      }
+    }
+  };
+
+  // ---- MFMA operands
+  const int tj = (lane >> 2) & 3, tq = lane & 3;
+  const uint32_t aadr = keep_in_vgpr(lds_addr(inring + 2 * (CP * (16 * (lj & 1) + 4 * tj + 2 * (lj >> 1)) + 4 * tq)));
+  const int n = 16 * wave + li;
+  const bool nvalid = n < KS * NO;
+  const int nky = nvalid ? n / NO : 0, no = nvalid ? n % NO : 0;
+  uint32_t badr[G::UNROLL];
+#pragma unroll
+  for (int sq = 0; sq < G::UNROLL; ++sq) {
+    const int slot = (sq - nky + P + G::RING_DY) % G::RING_DY;            // ring slot of dY position t - ky + P, t = sq (mod 6)
+    badr[sq] = keep_in_vgpr(lds_addr(dyring + slot * DSLOT + no * G::DOST + lj * 16));
+  }
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  __syncthreads();
+
+  for (int unit = blockIdx.x; unit < units; unit += gridDim.x) {
+    const int b = unit / units_per_img;
+    const int q_lo = (unit - b * units_per_img) * band;
+    const int rows = min(band, H - q_lo);            // band and q_lo are even
+    const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__half*>((const __half*)a.in + (long)b * a.in_bstride), 0, H * rowbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.dy.pool + (long)b * a.dy.pool_bstride), 0, Hp * Wp * nout * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.dy.dpool + (long)b * a.dy.dpool_bstride), 0, Hp * Wp * nout * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(a.dy.amax + (long)b * Hp * Wp * nout), 0, Hp * Wp * nout, 0x00020000);
+    // position d of the band's stream <-> image row q_lo - P + d (conv_dw_kyo.h)
+    const int y0 = q_lo - P;
+    auto in_band = [&](int y) { return y >= q_lo && y < q_lo + rows; };
+    if (0 < rows) in_load(in_rs, q_lo);
+    dy_issue(rp, rd, rc, y0 >> 1, 0);
+    dy_issue(rp, rd, rc, (y0 >> 1) + 1, 1);
+    if (0 < rows) in_store(P % G::RING_IN);
+    if (1 < rows) in_load(in_rs, q_lo + 1);
+    dy_conv(0, in_band(y0));
+    dy_store(0, 0); dy_store(1, 1);
+    dy_issue(rp, rd, rc, (y0 >> 1) + 2, 0);
+    dy_conv(1, in_band(y0 + 2));
+    dy_store(2, 0); dy_store(3, 1);
+    if (1 < rows) in_store((P + 1) % G::RING_IN);
+    if (2 < rows) in_load(in_rs, q_lo + 2);
+    dy_conv(0, in_band(y0 + 4));
+    dy_store(4, 0);                                   // position 5 (same cells) is stored by the first step
+    __syncthreads();
+
+    for (int t0 = 0; t0 < rows + P; t0 += G::UNROLL) {
+#pragma unroll
+      for (int sq = 0; sq < G::UNROLL; ++sq) {
+        const int t = t0 + sq;
+        if (t < P) continue;                          // uniform
+        if (t >= rows + P) break;
+        {  // stage ahead: dY position t + P + 1 (its slot held position t - P - 1), input position t + 2
+          const int d = t + P + 1, y = y0 + d;
+#ifndef DW16_ABL_NODY
+          if ((d & 1) == 0) dy_conv(0, in_band(y));                     // requested one step ago
+          dy_store((sq + P + 1) % G::RING_DY, (sq + P + 1) & 1);
+          if ((d & 1) == 1) dy_issue(rp, rd, rc, (y + 1) >> 1, 0);      // next pooled row, used from the next step on
+#endif
+#ifndef DW16_ABL_NOIN
+          if (t + 2 - P < rows) in_store((sq + 2) % G::RING_IN);
+          if (t + 3 - P < rows) in_load(in_rs, y0 + t + 3);
+#endif
+        }
+        // multiply input position t with dY positions t - P .. t + P
+        const int islot = sq % G::RING_IN;
+#pragma unroll
+        for (int ch = 0; ch < NCHK; ++ch) {
+          f16x8 bq[NPC];
+#pragma unroll
+          for (int pc = 0; pc < NPC; ++pc) bq[pc] = lds_load<f16x8>(badr[sq], pc * G::DPC + ch * 64);
+          k16_u32x4 av[MT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const int off = islot * ROWB + ch * (2 * CP * 32) + mt * 32;
+            const dw16_v4s r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                reinterpret_cast<__attribute__((address_space(3))) dw16_v4s*>((uintptr_t)(aadr + (uint32_t)off)));
+            const dw16_v4s r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                reinterpret_cast<__attribute__((address_space(3))) dw16_v4s*>((uintptr_t)(aadr + (uint32_t)(off + 2 * CP))));
+            const dw16_u32x2 u0 = __builtin_bit_cast(dw16_u32x2, r0), u1 = __builtin_bit_cast(dw16_u32x2, r1);
+            av[mt] = (k16_u32x4){u0.x, u0.y, u1.x, u1.y};
+          }
+#pragma unroll
+          for (int pc = NPC - 1; pc >= 0; --pc)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mt]), bq[pc], acc[mt], 0, 0, 0);
+        }
+#ifndef DW16_ABL_NOBAR
+        __syncthreads();
+#endif
+      }
+    }
+  }
+
+  // ---- one partial per workgroup.  D tile mt holds rows m = 16 mt + 4 lj + r = CP kx + c', column n = (ky, o);
+  // row c' = CIN of every kx is T: it goes through a wave-private LDS table, then dW = 2^-S (s_c G + t_c T)
+  float* part = a.partial + (long)blockIdx.x * a.pstride;
+  const int nw = KS * G::KROW * nout;
+  float* tx = texch + wave * (KS * 16);
+#pragma unroll
+  for (int kx = 0; kx < KS; ++kx) {
+    const int m = CP * kx + CIN;                      // compile-time
+    if (lj == ((m & 15) >> 2)) tx[kx * 16 + li] = acc[m >> 4][m & 3];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (nvalid && no < nout) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 16 * mt + 4 * lj + r;
+        const int kx = m / CP, c = m - kx * CP;
+        if (kx < KS && c < CIN) {
+          const float t = tx[kx * 16 + li];
+          part[(nky * G::KROW + kx * CIN + c) * nout + no] = inv * (a.scale[c] * acc[mt][r] + a.shift[c] * t);
+        }
+      }
+    }
+  }
+  // bias gradient: per-thread cell sums -> LDS -> one thread per channel adds them in fixed order
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < NCELL; ++c) dbs[c * CONV_THREADS + tid] = cact[c] ? dbsum[c] : 0.f;
+  __syncthreads();
+  if (tid < nout) {
+    float s = 0.f;
+    for (int idx = tid; idx < Wp * nout; idx += nout) s += dbs[(idx / CONV_THREADS) * CONV_THREADS + (idx % CONV_THREADS)];
+    part[nw + tid] = s;
+  }
+}
+
+template <int CIN, int KS, int NCHK>
+static inline int conv_dw16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int* grid_out) {
+  typedef Dw16Geom<CIN, KS, NCHK> G;
+  const ConvArgs& a = batch.a[0];
+  const size_t lds_bytes = (size_t)G::LDS_BYTES;
+  auto kern = conv_dw16_kernel<CIN, KS, NCHK>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_done = true;
+  }
+  const int capacity = ctx->num_cus * 4 / batch.n;   // == conv_dw_kyo_grid: the partial buffers are sized for it
+  int band = (a.H + 1) & ~1;
+  while (a.B * ((a.H + band - 1) / band) < capacity && band > 8 && (band / 2) % 2 == 0) band /= 2;
+  const int upi = (a.H + band - 1) / band;
+  const int units = a.B * upi;
+  const int grid = units < capacity ? units : capacity;
+  hipLaunchKernelGGL(kern, dim3(grid, batch.n), dim3(CONV_THREADS), lds_bytes, ctx->stream, batch, upi, band);
+  LAUNCH_CHECK();
+  *grid_out = grid;
+  return 0;
+}
+
+// conv1 dW of f16 image batches with one whitening table (white_bstride == 0), pooled dY (no batch norm), 5x5, even CIN and W
+int conv_dw16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArgsN& a, int* grid, bool* handled);
