@@ -45,8 +45,11 @@ struct Dw16Geom {
   static_assert(DY_BYTES >= CONV_THREADS * NCELL * 4 + 4 * KS * 16 * 4, "epilogue scratch fits the dY ring");
 };
 
+#ifndef DW16_WGS
+#define DW16_WGS 3
+#endif
 template <int CIN, int KS, int NCHK>
-__global__ __launch_bounds__(CONV_THREADS, 3) void conv_dw16_kernel(const ConvArgsN batch, int units_per_img, int band) {
+__global__ __launch_bounds__(CONV_THREADS, DW16_WGS) void conv_dw16_kernel(const ConvArgsN batch, int units_per_img, int band) {
   typedef Dw16Geom<CIN, KS, NCHK> G;
   constexpr int P = G::P, NO = G::NO, MT = G::MT, CP = G::CP, NPC = G::NPC, ROWB = G::ROWB, DSLOT = G::DSLOT;
   static_assert(CIN % 2 == 0 && (KS * NO + 15) / 16 == 4, "even channel count, one column tile per wave");

@@ -25,7 +25,9 @@ SHORT = [("void conv_fwd_kernel<18, 5, 4, 0, 0>", "conv1_fwd"), ("void conv_dw_k
          # (ky,o)-column forward kernels: <CIN, KS, XT, IPW, IN_MODE>
          ("void conv_fwd_kyo_kernel<18, 5, 1, 1, 0,", "conv1_fwd"), ("void conv_fwd_kyo_kernel<10, 5, 1, 2, 2,", "conv2_fwd"),
          ("void conv_fwd_kyo_kernel<10, 3, 1, 4, 2,", "conv3_fwd"), ("void conv_dw_kyo_kernel<18, 5", "conv1_dw"),
-         ("void conv_fwd_kyo_kernel<10, 5, 1, 2, 3,", "conv2_dx"), ("void conv_dw_kyo_kernel<10, 5", "conv2_dw")]
+         ("void conv_fwd_kyo_kernel<10, 5, 1, 2, 3,", "conv2_dx"), ("void conv_dw_kyo_kernel<10, 5", "conv2_dw"),
+         # f16 pipes with f32-exact operands
+         ("void conv_fwd_k16_kernel<18, 5", "conv1_fwd_f16x3"), ("void conv_dw16_kernel<18, 5", "conv1_dw_f16x3")]
 
 
 def short(name):
@@ -60,7 +62,7 @@ def main(rnd):
         f.write("Command (profiles/run_profiles.sh): `rocprofv3 --kernel-trace --stats -d gpurun_out/prof_%s -o k -- python bench.py "
                 "--steps 50 --warmup 10 --no-cpu-baseline --profile-steps 5`\n\n" % rnd)
         f.write("70 minibatch steps in total (warm-up, hipGraph-replayed timed steps, and the eager HIP-event pass); durations in\n"
-                "microseconds, from the rocpd database's `top_kernels` view (profiles/make_profiles.py).  One `conv_fwd_kernel<18,5,4,0,0>`\n"
+                "microseconds, from the rocpd database's `top_kernels` view (profiles/make_profiles.py).  One `conv_fwd_k16_kernel<18,5,2,2>`\n"
                 "launch computes conv1 of all four networks of a minibatch (blockIdx.y = network); likewise conv2/conv3 forward;\n"
                 "the dW / dX launches carry the actor and the critic together.\n\n")
         f.write("| kernel | calls | total us | avg us | % |\n|---|---|---|---|---|\n")

@@ -187,3 +187,40 @@ def test_f32_mfma_conv1_stays_parity_green_when_selected():
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     tail = r.stdout.decode()[-1500:]
     assert r.returncode == 0 and " passed" in tail, tail
+
+
+_CONV1_DW_ERR_SNIPPET = r"""
+import numpy as np
+from oracle import ddpg_np as O
+from tests.helpers import make_pair, device_pool_codes, per_var_report
+SHAPE, B = (64, 64, 3, 2, 3), 16
+agent, ref, (aspec, cspec) = make_pair(SHAPE, B, True)
+class HB(object): pass
+hb = HB()
+t = O.synthetic_batch(np.random.default_rng(17), B, SHAPE, 2, True)       # f16 pixel states
+hb.state_1, hb.action, hb.reward, hb.terminal_mask, hb.state_2 = t
+agent.critic.train(hb)
+got = agent.critic.get_grads()
+ref.critic.amax_override = device_pool_codes(agent.critic, B)             # same pooling routes: rounding is all that is left
+want = ref.critic_gradients(t)["grads"]                                    # float64
+for name, amax, rel in per_var_report(cspec, got, want):
+    if name.endswith("conv1/weights") or name.endswith("conv1/biases"):
+        print("DWERR %s %.3e" % (name.split("/")[-1], rel))
+agent.close()
+"""
+
+
+def test_f16x3_conv1_dw_is_as_close_to_the_f64_oracle_as_the_f32_mfma_kernel():
+    """conv_dw16.h: conv1's weight gradient from exact f16 x f16 products must match the float64 oracle (with the
+    device's pooling routes) at least as well as the f32-MFMA kernel does."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    errs = {}
+    for k16 in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", _CONV1_DW_ERR_SNIPPET], cwd=root, env=dict(os.environ, CPP_CONV_K16=k16),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        m = dict(re.findall(r"DWERR (\S+) (\S+)", r.stdout.decode()))
+        assert r.returncode == 0 and "weights" in m, r.stdout.decode()[-1500:]
+        errs[k16] = float(m["weights"])
+    assert errs["1"] < 5e-6 and errs["0"] < 5e-6, errs
+    assert errs["1"] <= 1.25 * errs["0"] + 1e-8, errs
