@@ -22,6 +22,11 @@ PIXEL_CASES = [
     pytest.param((50, 50, 3, 1, 2), 3, id="50x50x6-B3-default-render"),
     pytest.param((64, 64, 3, 2, 3), 2, id="64x64x18-B2-cfg3-shape"),
     pytest.param((64, 64, 3, 1, 3), 5, id="64x64x9-B5-cfg2-shape"),
+    # further geometries of the f16-pipe conv1 kernels (conv_k16.h / conv_dw16.h): strips, images per workgroup, chunks
+    pytest.param((50, 50, 3, 2, 3), 3, id="50x50x18-B3-run_98-render"),
+    pytest.param((16, 16, 3, 2, 3), 5, id="16x16x18-B5"),
+    pytest.param((32, 32, 3, 2, 3), 3, id="32x32x18-B3"),
+    pytest.param((24, 40, 3, 2, 2), 3, id="24x40x12-B3"),
 ]
 LOWDIM_CASE = pytest.param((2, 2, 7), 5, id="lowdim-28-B5-cfg1")
 
