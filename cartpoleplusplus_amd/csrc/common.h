@@ -205,6 +205,26 @@ int launch_opt_apply(cpp_ctx* ctx, const OptSegs& s, float grad_scale, float cli
 int launch_soft_update(cpp_ctx* ctx, float* t0, const float* s0, long n0, float* t1, const float* s1,
                        long n1, float coeff);
 
+// fused DDPG heads (heads.hip): actor heads, the critic's concat layer + q on three inputs, TD, dQ/da, one backward layer
+struct DdpgHeadsArgs {
+  int B, A; float discount;
+  const float *h2a, *h2ta; int ld_h2a, n2a;        // inputs of the actors' last layer (B x (n2a + 1))
+  const float *Wo, *Wo_t;                          // [(n2a + 1)][A]
+  const float *h2c, *h2tc; int ld_h2c, n2c;        // inputs of the critics' concat layer, first n2c columns (B x (n2c + A + 1))
+  const float *W3, *W3_t; int n3;                  // [(n2c + A + 1)][n3]
+  const float *wq, *wq_t;                          // [(n3 + 1)][1]
+  const float *act, *r, *mask;                     // the batch's actions, rewards, terminal masks
+  float *a_out, *dq_da, *adz, *dz_h2a; int relu_x2;
+  float* cat_splice;                               // the concat layer's action columns (row stride ld_h2c)
+  float* h3_out; int ld_h3;                        // input buffer of the q layer
+  float *q_out, *tq_out, *td, *dzq, *dz3, *dz2c;
+  double* loss_part;                               // [DDPG_HEADS_MAX_WGS] per-workgroup sums of td^2
+};
+#define DDPG_HEADS_MAX_WGS 256
+size_t ddpg_heads_lds_bytes(const DdpgHeadsArgs& h);
+bool ddpg_heads_supported(const DdpgHeadsArgs& h);
+int launch_ddpg_heads(cpp_ctx* ctx, const DdpgHeadsArgs& h);
+
 struct NafHeadArgs {
   const float* value; const float* mu; const float* lv; const float* action; const float* reward;
   const float* mask; const float* target_value;

@@ -1190,6 +1190,9 @@ struct cpp_ddpg {
   int maxB; long nA, nC;
   float* gradbuf; float *dq_da, *td, *dq, *loss_norms /* [0] loss [1] actor norm [2] critic norm */, *ones;
   double* norm_part;
+  double* heads_part;                              // fused heads kernel: per-workgroup partial sums of td^2
+  int heads_grid, heads_B;                         // ... of the last graph built by compute_gradients (0: GEMM levels + td_kernel)
+  int loss_parts, loss_B;                          // how cpp_ddpg_last_stats finds the loss of the last call: partials to add, or loss_norms[0]
   // graph replay of the full inner step
   hipGraph_t graph; hipGraphExec_t gexec; bool graph_ok; int g_B, g_nb; uint64_t g_seed; cpp_replay* g_replay;
   cpp_batch* step_batch;
@@ -1214,6 +1217,7 @@ extern "C" int cpp_ddpg_create(cpp_ctx* ctx, cpp_net* actor, cpp_net* critic, cp
   d->nA = actor->nparams; d->nC = critic->nparams;
   d->graph = nullptr; d->gexec = nullptr; d->graph_ok = false; d->step_batch = nullptr; d->g_replay = nullptr;
   d->hgraph = nullptr; d->hexec = nullptr; d->hgraph_ok = false; d->h_replay = nullptr;
+  d->heads_grid = d->heads_B = d->loss_parts = d->loss_B = 0;
   const int A = actor->spec.action_dim;
   int rc = dalloc(d->arena, &d->gradbuf, (size_t)(d->nA + d->nC));
   if (!rc) rc = dalloc(d->arena, &d->dq_da, (size_t)d->maxB * A);
@@ -1222,6 +1226,7 @@ extern "C" int cpp_ddpg_create(cpp_ctx* ctx, cpp_net* actor, cpp_net* critic, cp
   if (!rc) rc = dalloc(d->arena, &d->ones, (size_t)d->maxB);
   if (!rc) rc = dalloc(d->arena, &d->loss_norms, (size_t)4);
   if (!rc) rc = dalloc(d->arena, &d->norm_part, (size_t)OPT_MAX_SEGS * NORM_PARTS);
+  if (!rc) rc = dalloc(d->arena, &d->heads_part, (size_t)DDPG_HEADS_MAX_WGS);
   if (!rc) rc = launch_fill(ctx, d->ones, 1, 0, 1, d->maxB, 1.0f);
   if (rc) { d->arena.release(); delete d; return rc; }
   actor->grads = d->gradbuf; critic->grads = d->gradbuf + d->nA;
@@ -1332,6 +1337,7 @@ static int critic_gradients_impl(cpp_ddpg* d, cpp_batch* b, bool critic_prefix_d
   const int last = (int)c->fc.size() - 1;
   RC(launch_td(d->ctx, c->ws[0].out, tc->ws[0].out, b->r, b->m, d->hp.discount, B, d->td,
                backward ? c->ws[0].dz[last] : nullptr, d->loss_norms));
+  d->loss_parts = 0;
   if (backward) RC(net_backward(c, c->ws[0], B, true, nullptr, b->s[0], b->dtype, w1));
   return CPP_OK;
 }
@@ -1447,6 +1453,77 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b) {
     tTA = G.fn([=] { return net_forward_trunk(ta, ta->ws[0], s2, dt, w2, B); }, {});
     tTC = G.fn([=] { return net_forward_trunk(tc, tc->ws[0], s2, dt, w2, B); }, {});
   }
+  // ---- fused heads (heads.hip): when the critic is "[prefix, action] -> relu layer -> linear q" and the actor ends in a tanh
+  // layer (the reference's networks, ddpg_cartpole.py:95-100, :166-171), everything from the actors' / critics' last hidden
+  // activations to the first backward layer is one row-local kernel instead of five dependent GEMM levels + TD + copies.
+  // CPP_FUSED_HEADS=0 keeps the GEMM levels.
+  static const bool no_heads = getenv("CPP_FUSED_HEADS") != nullptr && atoi(getenv("CPP_FUSED_HEADS")) == 0;
+  DdpgHeadsArgs hd; memset(&hd, 0, sizeof(hd));
+  bool fused = !no_heads && na >= 2 && cat >= 1 && nc - cat == 2 && a->fc[na - 1].act == GE_TANH && Lcat.act == GE_RELU &&
+               c->fc[nc - 1].n_out == 1 && c->fc[nc - 1].act == GE_NONE && a->fc[na - 1].n_out == A;
+  if (fused) {
+    const FcL& Lo = a->fc[na - 1];
+    hd.B = B; hd.A = A; hd.discount = d->hp.discount;
+    hd.h2a = a->ws[0].fcin[na - 1]; hd.h2ta = ta->ws[0].fcin[na - 1]; hd.ld_h2a = Lo.n_in + 1; hd.n2a = Lo.n_in;
+    hd.Wo = a->params + Lo.w_off; hd.Wo_t = ta->params + Lo.w_off;
+    hd.h2c = c->ws[0].fcin[cat]; hd.h2tc = tc->ws[0].fcin[cat]; hd.ld_h2c = (int)ldcat; hd.n2c = Lcat.n_in - A;
+    hd.W3 = c->params + Lcat.w_off; hd.W3_t = tc->params + Lcat.w_off; hd.n3 = Lcat.n_out;
+    hd.wq = c->params + c->fc[nc - 1].w_off; hd.wq_t = tc->params + c->fc[nc - 1].w_off;
+    hd.act = b->a; hd.r = b->r; hd.mask = b->m;
+    hd.a_out = a->ws[0].out; hd.dq_da = d->dq_da; hd.adz = a->ws[0].dz[na - 1]; hd.dz_h2a = a->ws[0].dz[na - 2];
+    hd.relu_x2 = relu_grad_epi(a, na - 2) == GE_MUL_RELU_GRAD_X2;
+    hd.cat_splice = c->ws[0].fcin[cat] + (Lcat.n_in - A);
+    hd.h3_out = c->ws[0].fcin[nc - 1]; hd.ld_h3 = Lcat.n_out + 1;
+    hd.q_out = c->ws[0].out; hd.tq_out = tc->ws[0].out; hd.td = d->td; hd.dzq = c->ws[0].dz[nc - 1];
+    hd.dz3 = c->ws[0].dz[cat]; hd.dz2c = c->ws[0].dz[cat - 1];
+    hd.loss_part = d->heads_part;
+    fused = ddpg_heads_supported(hd);
+  }
+  d->heads_grid = fused ? (B + 7) / 8 : 0; d->heads_B = B;
+  d->loss_parts = d->heads_grid; d->loss_B = B;
+  int adz, cdz;
+  if (fused) {
+    int aF = tA, taF = tTA;
+    for (int l = 0; l < na - 1; ++l) {
+      aF = G.gemm(fc_fwd_args(a, a->ws[0], l, B), {aF});
+      taF = G.gemm(fc_fwd_args(ta, ta->ws[0], l, B), {taF});
+    }
+    if (a->drop_counter) {     // --use-dropout: this forward is counted once its layers have read the counter
+      G.fn([=] { return bump_dropout(a); }, {aF});
+      G.fn([=] { return bump_dropout(ta); }, {taF});
+    }
+    int cP = tC, tcP = tTC;
+    for (int l = 0; l < cat; ++l) {
+      cP = G.gemm(fc_fwd_args(c, c->ws[0], l, B), {cP});
+      tcP = G.gemm(fc_fwd_args(tc, tc->ws[0], l, B), {tcP});
+    }
+    const int hk = G.fn([=] { return launch_ddpg_heads(ctx, hd); }, {aF, taF, cP, tcP});
+    // ---- actor backward below its head (the head's dX is part of the fused kernel)
+    G.gemm(fc_dw_args(a, a->ws[0], na - 1, B, a->ws[0].dz[na - 1]), {hk});
+    adz = hk;
+    for (int l = na - 2; l >= 0; --l) {
+      const FcL& L = a->fc[l];
+      G.gemm(fc_dw_args(a, a->ws[0], l, B, a->ws[0].dz[l]), {adz});
+      if (l > 0)
+        adz = G.gemm(fc_dx_args(a, l, B, a->ws[0].dz[l], L.n_out, 0, L.n_in, a->ws[0].dz[l - 1], L.n_in, relu_grad_epi(a, l - 1),
+                                a->ws[0].fcin[l], L.n_in + 1), {adz});
+      else if (a->spec.pixel)
+        adz = G.gemm(fc_dx_args(a, 0, B, a->ws[0].dz[0], L.n_out, 0, a->flat, a->ws[0].dpool[2], a->flat, GE_NONE, nullptr, 0), {adz});
+    }
+    // ---- critic backward below its concat layer
+    G.gemm(fc_dw_args(c, c->ws[0], nc - 1, B, c->ws[0].dz[nc - 1]), {hk});
+    G.gemm(fc_dw_args(c, c->ws[0], cat, B, c->ws[0].dz[cat]), {hk});
+    cdz = hk;
+    for (int l = cat - 1; l >= 0; --l) {
+      const FcL& L = c->fc[l];
+      G.gemm(fc_dw_args(c, c->ws[0], l, B, c->ws[0].dz[l]), {cdz});
+      if (l > 0)
+        cdz = G.gemm(fc_dx_args(c, l, B, c->ws[0].dz[l], L.n_out, 0, L.n_in, c->ws[0].dz[l - 1], L.n_in, GE_MUL_RELU_GRAD,
+                                c->ws[0].fcin[l], L.n_in + 1), {cdz});
+      else if (c->spec.pixel)
+        cdz = G.gemm(fc_dx_args(c, 0, B, c->ws[0].dz[0], L.n_out, 0, c->flat, c->ws[0].dpool[2], c->flat, GE_NONE, nullptr, 0), {cdz});
+    }
+  } else {
   const int cb = G.fn([=] { return launch_copy_cols(ctx, c->ws[0].fcin[cat], ldcat, Lcat.n_in - A, b->a, A, 0, A, B); }, {});
   int aF = tA, taF = tTA;
   for (int l = 0; l < na; ++l) {
@@ -1485,7 +1562,6 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b) {
     g = G.gemm(fc_dx_args(c, l, B, dz, L.n_out, 0, L.n_in, c->ws[1].dz[l - 1], L.n_in, GE_MUL_RELU_GRAD,
                           c->ws[1].fcin[l], L.n_in + 1), {g});
   }
-  int adz;
   {   // dQ/da (kept for cpp_ddpg_q_gradients_wrt_actions) and, in the same epilogue, the actor's head gradient
     const float* dz = (cat == nc - 1) ? d->ones : c->ws[1].dz[cat];
     GemmArgs ga = fc_dx_args(c, cat, B, dz, Lcat.n_out, Lcat.n_in - A, A, d->dq_da, A, GE_ACTOR_HEAD, a->ws[0].out, A);
@@ -1505,7 +1581,7 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b) {
   }
 
   // ---- TD target + critic backward on the first evaluation (fed actions)
-  int cdz = G.fn([=] { return launch_td(ctx, c->ws[0].out, tc->ws[0].out, b->r, b->m, d->hp.discount, B, d->td,
+  cdz = G.fn([=] { return launch_td(ctx, c->ws[0].out, tc->ws[0].out, b->r, b->m, d->hp.discount, B, d->td,
                                         c->ws[0].dz[nc - 1], d->loss_norms); }, {c0, tcH});
   for (int l = nc - 1; l >= 0; --l) {
     const FcL& L = c->fc[l];
@@ -1516,6 +1592,7 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b) {
                               c->ws[0].fcin[l], L.n_in + 1), {cdz});
     else if (c->spec.pixel)
       cdz = G.gemm(fc_dx_args(c, 0, B, c->ws[0].dz[0], L.n_out, 0, c->flat, c->ws[0].dpool[2], c->flat, GE_NONE, nullptr, 0), {cdz});
+  }
   }
   if (c->spec.pixel) {     // both conv backward passes, layer by layer, two networks per launch
     cpp_net* bn[2] = {a, c};
@@ -1596,6 +1673,7 @@ extern "C" int cpp_ddpg_train_step(cpp_ddpg* d, cpp_replay* r, int B, int n_batc
     return CPP_OK;   // the eager pass above was this call's step
   }
   HIP_CHECK(hipGraphLaunch(d->gexec, ctx->stream));
+  d->loss_parts = d->heads_grid; d->loss_B = d->heads_B;
   return CPP_OK;
 }
 
@@ -1631,13 +1709,22 @@ extern "C" int cpp_ddpg_sample_and_compute(cpp_ddpg* d, cpp_replay* r, int B, ui
     return CPP_OK;
   }
   HIP_CHECK(hipGraphLaunch(d->hexec, ctx->stream));
+  d->loss_parts = d->heads_grid; d->loss_B = d->heads_B;
   return CPP_OK;
 }
 
 extern "C" int cpp_ddpg_last_stats(cpp_ddpg* d, float out[3]) {
   ARG_CHECK(d && out, "cpp_ddpg_last_stats: NULL argument");
   HIP_CHECK(hipMemcpyAsync(out, d->loss_norms, 3 * sizeof(float), hipMemcpyDeviceToHost, d->ctx->stream));
+  double parts[DDPG_HEADS_MAX_WGS];
+  if (d->loss_parts > 0)
+    HIP_CHECK(hipMemcpyAsync(parts, d->heads_part, (size_t)d->loss_parts * sizeof(double), hipMemcpyDeviceToHost, d->ctx->stream));
   HIP_CHECK(hipStreamSynchronize(d->ctx->stream));
+  if (d->loss_parts > 0) {                          // fused heads kernel: mean(td^2) from its per-workgroup partials, fixed order
+    double s = 0.0;
+    for (int i = 0; i < d->loss_parts; ++i) s += parts[i];
+    out[0] = (float)(s / (double)d->loss_B);
+  }
   return CPP_OK;
 }
 

@@ -51,31 +51,35 @@ def test_full_size_whitening_statistics_and_forward_against_f64_oracle_slice():
 
 
 def test_full_size_fused_step_equals_unfused_ops_and_is_deterministic():
-    """the hipGraph / batched-GEMM / deferred-reduction path and the op-by-op path are different launch
-    sequences over the same kernels: they must agree to rounding; two fused runs must agree bit for bit."""
-    results = []
-    for mode in ("fused", "fused", "unfused"):
+    """the hipGraph / batched-GEMM / fused-heads / deferred-reduction path and the op-by-op path are different launch
+    sequences (and, for the MLP heads, different summation orders): they must agree to rounding; two fused runs must
+    agree bit for bit.  After ONE minibatch the bar is 1e-5; the second minibatch starts from parameters that differ in
+    the last bits, which moves a few max-pool routes of the 2.6 M pooling windows -- a looser bar there."""
+    results = {}
+    for mode, nb in (("fused", 2), ("fused_again", 2), ("unfused", 2), ("fused", 1), ("unfused", 1)):
         agent, ref, (aspec, cspec) = make_pair(SHAPE, B, True, replay_size=600)
         try:
             agent.replay_memory.fill_synthetic(500, seed=5)
             idxs = np.random.default_rng(1).integers(0, 500, 2 * B)
-            if mode == "fused":
-                agent.train_step(B, 2, idxs=idxs)
+            if mode.startswith("fused"):
+                agent.train_step(B, nb, idxs=idxs[:nb * B])
             else:
-                for i in range(2):
+                for i in range(nb):
                     batch = agent.replay_memory.batch(idxs=idxs[i * B:(i + 1) * B])
                     agent.actor.train(batch)
                     agent.critic.train(batch)
                 agent.target_actor.update_weights(); agent.target_critic.update_weights()
-            results.append((agent.actor.get_params(), agent.critic.get_params(),
-                            agent.target_actor.get_params(), agent.target_critic.get_params()))
+            results[(mode, nb)] = (agent.actor.get_params(), agent.critic.get_params(),
+                                   agent.target_actor.get_params(), agent.target_critic.get_params())
         finally:
             agent.close()
     for k in range(4):
-        assert np.array_equal(results[0][k], results[1][k])
-    assert_flat_close(aspec, results[0][0], results[2][0], rel=1e-5, what="actor fused vs unfused")
-    assert_flat_close(cspec, results[0][1], results[2][1], rel=1e-5, what="critic fused vs unfused")
-    assert np.isfinite(results[0][0]).all() and np.isfinite(results[0][1]).all()
+        assert np.array_equal(results[("fused", 2)][k], results[("fused_again", 2)][k])
+    assert_flat_close(aspec, results[("fused", 1)][0], results[("unfused", 1)][0], rel=1e-5, what="actor fused vs unfused, 1 minibatch")
+    assert_flat_close(cspec, results[("fused", 1)][1], results[("unfused", 1)][1], rel=1e-5, what="critic fused vs unfused, 1 minibatch")
+    assert_flat_close(aspec, results[("fused", 2)][0], results[("unfused", 2)][0], rel=2e-4, what="actor fused vs unfused")
+    assert_flat_close(cspec, results[("fused", 2)][1], results[("unfused", 2)][1], rel=2e-4, what="critic fused vs unfused")
+    assert np.isfinite(results[("fused", 2)][0]).all() and np.isfinite(results[("fused", 2)][1]).all()
 
 
 def test_full_size_critic_gradient_against_f32_oracle():
