@@ -28,7 +28,10 @@ typedef unsigned dw16_u32x2 __attribute__((ext_vector_type(2)));
 template <int CIN, int KS, int NCHK>
 struct Dw16Geom {
   static constexpr int P = KS / 2, NO = KYO_NO, NPC = 3;
-  static constexpr int CP = (CIN + 1 + 3) & ~3;               // channel pitch of a pixel in LDS (halves)
+  // channel pitch of a pixel in LDS (halves): CIN + the ones channel, rounded to 8 bytes; a pitch of 0 (mod 8) dwords would
+  // put the 8 pixel quads of a transpose read on the same banks, so those get 4 more halves (30 channels -> 36)
+  static constexpr int CP0 = (CIN + 1 + 3) & ~3;
+  static constexpr int CP = ((CP0 / 2) % 8 == 0) ? CP0 + 4 : CP0;
   static constexpr int MROWS = KS * CP, MT = (MROWS + 15) / 16;
   static constexpr int KROW = KS * CIN;
   static constexpr int WPAD = 32 * NCHK;
@@ -49,7 +52,7 @@ struct Dw16Geom {
 #define DW16_WGS 3
 #endif
 template <int CIN, int KS, int NCHK>
-__global__ __launch_bounds__(CONV_THREADS, DW16_WGS) void conv_dw16_kernel(const ConvArgsN batch, int units_per_img, int band) {
+__global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 : DW16_WGS)) void conv_dw16_kernel(const ConvArgsN batch, int units_per_img, int band) {
   typedef Dw16Geom<CIN, KS, NCHK> G;
   constexpr int P = G::P, NO = G::NO, MT = G::MT, CP = G::CP, NPC = G::NPC, ROWB = G::ROWB, DSLOT = G::DSLOT;
   static_assert(CIN % 2 == 0 && (KS * NO + 15) / 16 == 4, "even channel count, one column tile per wave");
