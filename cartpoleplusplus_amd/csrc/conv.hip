@@ -68,7 +68,7 @@ int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, i
   // conv1 of f16 images: f16 matrix pipes with f32-exact operands (conv_k16.h); CPP_CONV_K16=0 keeps the f32 MFMA kernel.
   // (B = 1 stays on the f32 kernel: action_given is bit-identical to a row of cpp_net_forward_each)
   static const bool no_k16 = getenv("CPP_CONV_K16") != nullptr && atoi(getenv("CPP_CONV_K16")) == 0;
-  if (!no_kyo && !no_k16 && in_mode == IN_F16_WHITEN && !dx_mode && cin % 2 == 0 && a.B >= 2 && a.nout <= 10 && a.H >= 2) {
+  if (!no_kyo && !no_k16 && in_mode == IN_F16_WHITEN && !dx_mode && a.B >= 2 && a.nout <= 10 && a.H >= 2) {
     bool handled = false;
     rc = conv_fwd_k16_dispatch(ctx, cin, ks, in_mode, plain_fwd, batch, &handled);
     if (handled) { prof_end(ctx, kid == K_CONV1_FWD ? K_CONV1_FWD_F16X3 : kid); return rc; }
@@ -132,7 +132,7 @@ int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, co
   bool handled = false;
   // conv1 of f16 images: f16 matrix pipes with f32-exact operands (conv_dw16.h); CPP_CONV_K16=0 keeps the f32 MFMA kernel
   static const bool no_k16 = getenv("CPP_CONV_K16") != nullptr && atoi(getenv("CPP_CONV_K16")) == 0;
-  if (!no_kyo && !no_k16 && !dense && in_mode == IN_F16_WHITEN && cin % 2 == 0) {
+  if (!no_kyo && !no_k16 && !dense && in_mode == IN_F16_WHITEN) {
     rc = conv_dw16_dispatch(ctx, cin, ks, in_mode, batch, &grid, &handled);
     if (handled) kid = kid == K_CONV1_DW ? K_CONV1_DW_F16X3 : kid;
   }

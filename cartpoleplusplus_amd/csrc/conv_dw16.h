@@ -42,7 +42,7 @@ struct Dw16Geom {
   static constexpr int DSLOT = ((NPC * DPC - 192 + 255) / 256) * 256 + 192;            // = 192 (mod 256): B reads 1.17 accesses per bank quad
   static constexpr int RING_IN = 3, RING_DY = 6, UNROLL = 6;
   static constexpr int NCELL = (16 * NCHK * NO + CONV_THREADS - 1) / CONV_THREADS;     // pooled cells of a row per thread
-  static constexpr int NVIN = (WPAD * CIN / 2 + CONV_THREADS - 1) / CONV_THREADS;      // dwords of an input row per thread
+  static constexpr int NVIN = (CIN % 2 ? WPAD * CIN : WPAD * CIN / 2) / CONV_THREADS + 1;   // dwords (odd CIN: halves) of an input row per thread
   static constexpr int IN_BYTES = RING_IN * ROWB, DY_BYTES = RING_DY * DSLOT;
   static constexpr int LDS_BYTES = ((IN_BYTES + 15) & ~15) + DY_BYTES + 64;       // (the epilogue scratch reuses the dY ring)
   static_assert(DY_BYTES >= CONV_THREADS * NCELL * 4 + 4 * KS * 16 * 4, "epilogue scratch fits the dY ring");
@@ -55,7 +55,8 @@ template <int CIN, int KS, int NCHK>
 __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 : DW16_WGS)) void conv_dw16_kernel(const ConvArgsN batch, int units_per_img, int band) {
   typedef Dw16Geom<CIN, KS, NCHK> G;
   constexpr int P = G::P, NO = G::NO, MT = G::MT, CP = G::CP, NPC = G::NPC, ROWB = G::ROWB, DSLOT = G::DSLOT;
-  static_assert(CIN % 2 == 0 && (KS * NO + 15) / 16 == 4, "even channel count, one column tile per wave");
+  static_assert((KS * NO + 15) / 16 == 4, "one column tile per wave");
+  constexpr bool ODD = (CIN & 1) != 0;               // pixels are only 2-byte aligned in memory: rows are staged half by half
   const ConvArgs& a = batch.a[blockIdx.y];
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   unsigned char* inring = lds_raw;                                         // [3][ROWB]
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 
   __syncthreads();
   for (int i = tid; i < G::RING_IN * W; i += CONV_THREADS) {
     const int s = i / W, x = i - s * W;
-    *reinterpret_cast<unsigned*>(inring + s * ROWB + 2 * (CP * (x + P) + CIN)) = 0x00003C00u;      // (1.0, 0)
+    *reinterpret_cast<unsigned short*>(inring + s * ROWB + 2 * (CP * (x + P) + CIN)) = (unsigned short)0x3C00u;      // 1.0
   }
 
   // ---- 2^S: the largest |pooled gradient| among the pooled rows this workgroup's units touch lands in [2^14, 2^15)
@@ -99,27 +100,34 @@ __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 
     sc = ldexpf(1.f, S); inv = ldexpf(1.f, -S);
   }
 
-  // ---- input row staging: raw dwords (two channels) of the f16 row -> pixel pitch CP
+  // ---- input row staging: raw dwords (two channels; odd CIN: single halves) of the f16 row -> pixel pitch CP
   unsigned sv[G::NVIN];
   bool sact[G::NVIN];
   uint32_t sdst[G::NVIN];
+  constexpr int EPX = ODD ? CIN : CIN / 2;            // staging elements per pixel
 #pragma unroll
   for (int i = 0; i < G::NVIN; ++i) {
     const int d = tid + CONV_THREADS * i;
-    const int x = d / (CIN / 2), w = d - x * (CIN / 2);
-    sact[i] = d < W * (CIN / 2);
-    sdst[i] = keep_in_vgpr(lds_addr(inring + 2 * (CP * (x + P) + 2 * w)));
+    const int x = d / EPX, w = d - x * EPX;
+    sact[i] = d < W * EPX;
+    sdst[i] = keep_in_vgpr(lds_addr(inring + 2 * (CP * (x + P) + (ODD ? w : 2 * w))));
   }
   const int rowbytes = W * CIN * 2;
   auto in_load = [&](const __amdgpu_buffer_rsrc_t& rs, int q) {
 #pragma unroll
     for (int i = 0; i < G::NVIN; ++i)
-      if (sact[i]) sv[i] = __builtin_amdgcn_raw_buffer_load_b32(rs, (tid + CONV_THREADS * i) * 4, q * rowbytes, 0);
+      if (sact[i]) {
+        if (ODD) sv[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, (tid + CONV_THREADS * i) * 2, q * rowbytes, 0);
+        else sv[i] = __builtin_amdgcn_raw_buffer_load_b32(rs, (tid + CONV_THREADS * i) * 4, q * rowbytes, 0);
+      }
   };
   auto in_store = [&](int slot) {
 #pragma unroll
     for (int i = 0; i < G::NVIN; ++i)
-      if (sact[i]) lds_store(sdst[i], slot * ROWB, sv[i]);
+      if (sact[i]) {
+        if (ODD) lds_store(sdst[i], slot * ROWB, (unsigned short)sv[i]);
+        else lds_store(sdst[i], slot * ROWB, sv[i]);
+      }
   };
 
   // ---- dY staging: a thread owns pooled cells idx = px * nout + o of a pooled row (the same cells for every row); the

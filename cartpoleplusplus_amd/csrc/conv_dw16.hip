@@ -13,6 +13,6 @@ int conv_dw16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArg
     if (((uintptr_t)a.a[i].in & 3) || (a.a[i].in_bstride & 1)) return 0;        // dword row staging
   }
   const int nchk = W > 64 ? 4 : (W > 32 ? 2 : 1);
-  DW16_CASE(18, 2) DW16_CASE(18, 1) DW16_CASE(6, 2) DW16_CASE(6, 1) DW16_CASE(12, 2) DW16_CASE(30, 4) DW16_CASE(18, 4)
+  DW16_CASE(18, 2) DW16_CASE(18, 1) DW16_CASE(6, 2) DW16_CASE(6, 1) DW16_CASE(12, 2) DW16_CASE(30, 4) DW16_CASE(18, 4) DW16_CASE(9, 2) DW16_CASE(9, 1) DW16_CASE(3, 2) DW16_CASE(3, 1)
   return 0;
 }

@@ -18,5 +18,6 @@ int conv_fwd_k16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool plain
   K16_CASE(18, 2, 2, false) K16_CASE(18, 2, 2, true) K16_CASE(18, 1, 4, false) K16_CASE(18, 2, 4, false) K16_CASE(18, 2, 1, false)
   K16_CASE(6, 1, 4, false) K16_CASE(6, 2, 4, false) K16_CASE(6, 2, 2, false)
   K16_CASE(12, 2, 2, false) K16_CASE(30, 2, 1, false)
+  K16_CASE(9, 2, 2, false) K16_CASE(9, 1, 4, false) K16_CASE(9, 2, 4, false) K16_CASE(9, 2, 1, false) K16_CASE(3, 2, 2, false) K16_CASE(3, 1, 4, false)
   return 0;
 }

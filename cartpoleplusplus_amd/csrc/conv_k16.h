@@ -61,7 +61,7 @@ template <int CIN, int KS, int XT, int IPW, bool PLAIN = false>
 __global__ __launch_bounds__(CONV_THREADS, 2) void conv_fwd_k16_kernel(const ConvArgsN batch) {
   typedef K16Geom<CIN, KS, XT, IPW> G;
   constexpr int P = G::P, NT = G::NT, NCH = G::NCH, NPC = G::NPC, NO = KYO_NO;
-  static_assert(CIN % 2 == 0, "A operands must be 4-byte aligned");
+  constexpr bool ODD = (CIN & 1) != 0;            // 2-byte aligned operand windows: 20 bytes from the aligned address below + a funnel shift
   const ConvArgs& a = batch.a[blockIdx.y];
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   unsigned char* wl = lds_raw;                                    // weight image
@@ -214,9 +214,12 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_fwd_k16_kernel(const Con
   const int rowbytes = W * CIN * 2;
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((const char*)a.in + ((long)sbimg * a.in_bstride) * 2 - G::BIAS_BYTES), 0, H * rowbytes + G::BIAS_BYTES + 256, 0x00020000);
-  const int avoff = G::BIAS_BYTES + ((strip * G::SW + li - P) * CIN + 8 * lj) * 2;      // >= 128 - 2 P CIN... (checked by the host)
+  const int avoff0 = G::BIAS_BYTES + ((strip * G::SW + li - P) * CIN + 8 * lj) * 2;     // >= 128 - 2 P CIN
+  const int avoff = ODD ? (avoff0 & ~3) : avoff0;
+  const unsigned ashift = ODD ? (unsigned)(avoff0 & 2) : 0u;    // per-lane constant: 16 * m * CIN pixels further keeps the parity
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   k16_u32x4 av[NCH][XT];
+  unsigned ax[NCH][XT];                               // ODD: the fifth dword of the window
   auto load_a = [&](int ch, int y) {
 #pragma unroll
     for (int m = 0; m < XT; ++m) {
@@ -225,6 +228,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_fwd_k16_kernel(const Con
 #else
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, avoff + (m * 16 * CIN + 32 * ch) * 2, y * rowbytes, 0);
       av[ch][m] = (k16_u32x4){v.x, v.y, v.z, v.w};
+      if (ODD) ax[ch][m] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, avoff + (m * 16 * CIN + 32 * ch) * 2 + 16, y * rowbytes, 0);
 #endif
     }
   };
@@ -254,6 +258,9 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_fwd_k16_kernel(const Con
   };
   load_b(0, 0, wadr[0]);
 
+#ifdef K16_CLOCK_PROBE
+  const unsigned long long pc0 = __builtin_readcyclecounter(), pr0 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int q0 = 0; q0 < H + P; q0 += KS) {
 #pragma unroll
     for (int sq = 0; sq < KS; ++sq) {
@@ -265,10 +272,20 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_fwd_k16_kernel(const Con
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
           if (ch + 1 < NCH) load_b(ch + 1, (ch + 1) & 1, wadr[sq]);
+#ifdef K16_PRIO
+          __builtin_amdgcn_s_setprio(K16_PRIO);
+#endif
           k16_u32x4 af[XT];
 #pragma unroll
           for (int m = 0; m < XT; ++m) {
             k16_u32x4 u = av[ch][m];
+            if (ODD) {
+#ifndef K16_ABL_NOLDSA
+              const unsigned x4 = ax[ch][m];
+              u = (k16_u32x4){__builtin_amdgcn_alignbyte(u[1], u[0], ashift), __builtin_amdgcn_alignbyte(u[2], u[1], ashift),
+                              __builtin_amdgcn_alignbyte(u[3], u[2], ashift), __builtin_amdgcn_alignbyte(x4, u[3], ashift)};
+#endif
+            }
             if (border[m]) {                         // wave-uniform
 #pragma unroll
               for (int v = 0; v < 4; ++v) u[v] = (u[v] & bmask[ch][m][v]) | acst[ch][m][v];
@@ -290,6 +307,9 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_fwd_k16_kernel(const Con
 #pragma unroll
               for (int t = 0; t < NT; ++t)
                 acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[m]), bv[ch & 1][t][pc], acc[m][t], 0, 0, 0);
+#ifdef K16_PRIO
+          __builtin_amdgcn_s_setprio(0);
+#endif
           if (q + 1 < H) load_a(ch, q + 1);          // this chunk's operands of the next row, a whole row period ahead
         }
       }
@@ -358,6 +378,13 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_fwd_k16_kernel(const Con
       }
     }
   }
+#ifdef K16_CLOCK_PROBE
+  if (lane == 0 && (blockIdx.x % 97) == 5 && blockIdx.y == 1 && wave == 0) {
+    const unsigned long long pc1 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
+    printf("K16CLK block %d: %llu core cycles, %llu ref ticks (100 MHz) in the row loop -> %.3f GHz\n", (int)blockIdx.x, pc1 - pc0, pr1 - pr0,
+           (double)(pc1 - pc0) / (10.0 * (double)(pr1 - pr0)));
+  }
+#endif
 }
 
 template <int CIN, int KS, int XT, int IPW, bool PLAIN = false>
