@@ -74,6 +74,7 @@ struct ConvArgs {
   int nout;                  // valid output channels of this kernel (<= 16)
   int tiles_x, tiles_y, ntiles;
   int vec_ok;                // input rows may be staged with aligned 16-byte loads
+  int nbands, band_rows;     // conv_fwd_kyo_kernel: bands of output rows per image (0 / 1: whole images)
 };
 
 // Same-geometry convolutions of several networks in ONE launch (blockIdx.y selects the descriptor): the

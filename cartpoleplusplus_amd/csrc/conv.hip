@@ -74,6 +74,13 @@ int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, i
     if (handled) { prof_end(ctx, kid == K_CONV1_FWD ? K_CONV1_FWD_F16X3 : kid); return rc; }
   }
   if (kyo) {
+    // few workgroups (the dX passes carry two networks: one wave per SIMD): split the images into two bands of rows
+    // (CPP_CONV_BANDS=0: whole images)
+    static const bool no_bands = getenv("CPP_CONV_BANDS") != nullptr && atoi(getenv("CPP_CONV_BANDS")) == 0;
+    const int ipw = a.W > 32 ? 1 : (a.W > 16 ? 2 : 4);
+    const int wgs = n * ((a.B + ipw - 1) / ipw);
+    if (!no_bands && wgs <= ctx->num_cus && a.H >= 16 && (a.H % 4) == 0 && (in_mode == IN_F32_PLAIN || in_mode == IN_DY))
+      for (int i = 0; i < n; ++i) { batch.a[i].nbands = 2; batch.a[i].band_rows = a.H / 2; }
     bool handled = false;
     rc = plain_fwd ? conv_fwd_kyo_dispatch_plain(ctx, cin, ks, in_mode, chb, batch, &handled)
        : (in_mode == IN_F32_PLAIN || dx_mode) ? conv_fwd_kyo_dispatch_l23(ctx, cin, ks, in_mode, chb, batch, &handled)

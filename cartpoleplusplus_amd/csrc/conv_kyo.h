@@ -100,8 +100,14 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lj = lane >> 4;
   const int img = wave / G::STRIPS, strip = wave % G::STRIPS;
-  const int b0 = blockIdx.x * IPW;
   const int H = a.H, W = a.W, Hp = H >> 1, Wp = W >> 1, nout = a.nout;
+  // launches that would leave most SIMDs with one wave (dX of two networks) split every image into bands of output rows
+  // [ylo, yhi); a band also reads the P (even: 2) input rows above and below it
+  const int nbands = a.nbands > 1 ? a.nbands : 1;
+  const int band = (int)blockIdx.x % nbands;
+  const int b0 = ((int)blockIdx.x / nbands) * IPW;
+  const int ylo = nbands > 1 ? band * a.band_rows : 0, yhi = nbands > 1 ? min(H, ylo + a.band_rows) : H;
+  const int qs = max(0, (ylo - P) & ~1), qe = min(H, yhi + P);      // input rows of the band
 
   // ---- one-time setup: zero the row buffers (padding columns stay zero), weights into the permuted LDS layout
   for (int i = tid; i < RING * RSET; i += CONV_THREADS) rows[i] = 0.f;
@@ -332,11 +338,11 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
     for (int t = 0; t < NT; ++t) acc[m][t] = (f32x4){biast[t], biast[t], biast[t], biast[t]};
 
   __syncthreads();                                   // zeroed row buffers + whitening table visible
-  if (DX) dy_issue(0);
+  if (DX) dy_issue(qs >> 1);
   for (int r = 0; r < RING - 1; ++r) {
-    if (r < H) { stage_load(r); stage_store(r, r); }
+    if (qs + r < qe) { stage_load(qs + r); stage_store(r, qs + r); }
   }
-  if (RING - 1 < H) stage_load(RING - 1);
+  if (qs + RING - 1 < qe) stage_load(qs + RING - 1);
   __syncthreads();
 
   int rcur = 0;                                      // ring slot of row q (uniform)
@@ -381,14 +387,12 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
   const float* const arow0 = rows + img * ROWF + G::FP + (strip * G::SW + li) * CIN;
   const uint32_t arow = keep_in_vgpr(lds_addr(arow0 + G::Q4 * lj));
   const uint32_t axtr = keep_in_vgpr(lds_addr(arow0 + 4 * G::Q4 + lj));
-  load_ops(0, 0, arow, axtr, wadr[0]);
-
 #ifdef KYO_CLOCK_PROBE
   const unsigned long long pc0 = __builtin_readcyclecounter(), pr0 = __builtin_amdgcn_s_memrealtime();
 #endif
   // The row loop is unrolled by KS so that the block that completes in a step -- and with it the (tile, lane range)
   // that is taken out and reset -- is a compile-time constant: no per-lane block compares or select chains.
-  for (int q0 = 0; q0 < H + P; q0 += KS) {
+  for (int q0 = (qs / KS) * KS; q0 < yhi + P; q0 += KS) {
     {  // issue arbitration is by priority, then age: without this the oldest of the co-resident workgroups (one per
        // network) runs ahead and the youngest finishes alone; rotating the priority every KS rows keeps them level
        // (0.3786 -> 0.3745 ms for conv1)
@@ -399,20 +403,22 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
 #pragma unroll
     for (int sq = 0; sq < KS; ++sq) {
       const int q = q0 + sq;
-      if (q >= H + P) break;                         // uniform
+      if (q < qs) continue;                          // uniform: rows above the band
+      if (q >= yhi + P) break;                       // uniform
       constexpr int PD_BASE = (KS - P) % KS;
       const int pdone = (PD_BASE + sq) % KS;         // block of row y = q - P: constant after unrolling
       const int rnext = rcur + 1 == RING ? 0 : rcur + 1;
 #ifndef KYO_ABL_NOSTAGE
       {                                              // row q + RING - 1 -> the slot row q - 1 has just left
         const int rw = rcur == 0 ? RING - 1 : rcur - 1;
-        if (q + RING - 1 < H) stage_store(rw, q + RING - 1);
-        if (q + RING < H) stage_load(q + RING);
+        if (q + RING - 1 < qe) stage_store(rw, q + RING - 1);
+        if (q + RING < qe) stage_load(q + RING);
       }
 #endif
 
-      if (q < H) {
+      if (q < qe) {
         const uint32_t ab = arow + (uint32_t)(rcur * RSET * 4), ax = axtr + (uint32_t)(rcur * RSET * 4);
+        if (q == qs) load_ops(0, 0, ab, ax, wadr[sq]);   // (every later row: prefetched under the previous epilogue)
 #pragma unroll
         for (int g = 0; g < NGT; ++g) {
           if (g + 1 < NGT) load_ops(g + 1, (g + 1) & 1, ab, ax, wadr[sq]);
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
         }
       }
       // group 0 of the next row (made visible by the previous barrier) loads under the epilogue
-      if (q + 1 < H) {
+      if (q + 1 < qe) {
         load_ops(0, NGT & 1, arow + (uint32_t)(rnext * RSET * 4), axtr + (uint32_t)(rnext * RSET * 4), wadr[(sq + 1) % KS]);
         if (NGT & 1) {
 #pragma unroll
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
       // pdone in the one or two tiles it spans do the x half of the max-pool and park (value, code) in the pool-pair
       // buffer; the block restarts from the bias
 #ifdef KYO_ABL_NOEPI
-      const int y = (q == H + P - 1) ? q - P : -1;
+      const int y = (q == yhi + P - 1) ? q - P : -1;
 #else
       const int y = q - P;
 #endif
@@ -458,14 +464,14 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
 #pragma unroll
             for (int m = 0; m < XT; ++m) {
               if (PLAIN_OUT) {
-                if (y >= 0 && sbimg < a.B) {
+                if (y >= ylo && sbimg < a.B) {
 #pragma unroll
                   for (int r = 0; r < 4; ++r)
                     if (FLIP || sstrip * G::SW + m * 16 + 4 * lj + r < W)      // dX rows tile the strips exactly (dispatch)
                       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][t][r]), out_rsrc,
                                                             (int)eadr[t] + ((m * 16 + r) * NO) * 4, y * W * nout * 4, 0);
                 }
-              } else if (y >= 0) {
+              } else if (y >= ylo) {
                 const uint32_t ea = eadr[t] + (uint32_t)(par * (8 * XT * NO) * 8);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -478,7 +484,7 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
           }
         }
       }
-      if (!PLAIN_OUT && y >= 0 && par == 1 && (y >> 1) < Hp) {   // wave-uniform: both rows of a pool pair are in the buffer
+      if (!PLAIN_OUT && y >= ylo && par == 1 && (y >> 1) < Hp) {   // wave-uniform: both rows of a pool pair are in the buffer
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -528,7 +534,7 @@ static inline int conv_fwd_kyo_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_done = true;
   }
-  const int grid = (a.B + IPW - 1) / IPW;
+  const int grid = ((a.B + IPW - 1) / IPW) * (a.nbands > 1 ? a.nbands : 1);
   hipLaunchKernelGGL(kern, dim3(grid, batch.n), dim3(CONV_THREADS), lds_bytes, ctx->stream, batch);
   LAUNCH_CHECK();
   return 0;
