@@ -139,8 +139,8 @@ int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, co
   bool handled = false;
   // conv1 of f16 images: f16 matrix pipes with f32-exact operands (conv_dw16.h); CPP_CONV_K16=0 keeps the f32 MFMA kernel
   static const bool no_k16 = getenv("CPP_CONV_K16") != nullptr && atoi(getenv("CPP_CONV_K16")) == 0;
-  if (!no_kyo && !no_k16 && !dense && in_mode == IN_F16_WHITEN) {
-    rc = conv_dw16_dispatch(ctx, cin, ks, in_mode, batch, &grid, &handled);
+  if (!no_kyo && !no_k16 && in_mode == IN_F16_WHITEN) {
+    rc = conv_dw16_dispatch(ctx, cin, ks, in_mode, dense, batch, &grid, &handled);
     if (handled) kid = kid == K_CONV1_DW ? K_CONV1_DW_F16X3 : kid;
   }
   if (!handled && kyo) rc = conv_dw_kyo_dispatch(ctx, cin, ks, in_mode, chb, dense, batch, &grid, &handled);

@@ -51,7 +51,8 @@ struct Dw16Geom {
 #ifndef DW16_WGS
 #define DW16_WGS 3
 #endif
-template <int CIN, int KS, int NCHK>
+// DENSE: dY comes as dense f32 rows (a.dy_dense: batch norm's dz) instead of being rebuilt from the pooled gradient
+template <int CIN, int KS, int NCHK, bool DENSE = false>
 __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 : DW16_WGS)) void conv_dw16_kernel(const ConvArgsN batch, int units_per_img, int band) {
   typedef Dw16Geom<CIN, KS, NCHK> G;
   constexpr int P = G::P, NO = G::NO, MT = G::MT, CP = G::CP, NPC = G::NPC, ROWB = G::ROWB, DSLOT = G::DSLOT;
@@ -86,9 +87,15 @@ __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 
       const int b = unit / units_per_img;
       const int q_lo = (unit - b * units_per_img) * band;
       const int rows = min(band, H - q_lo);
-      const int py0 = max(0, (q_lo - P) >> 1), py1 = min(Hp - 1, (q_lo + rows - 1 + P) >> 1);
-      const float* dp = a.dy.dpool + (long)b * a.dy.dpool_bstride;
-      for (int e = py0 * Wp * nout + tid; e < (py1 + 1) * Wp * nout; e += CONV_THREADS) vmax = fmaxf(vmax, fabsf(dp[e]));
+      if (DENSE) {
+        const int r0 = max(0, q_lo - P), r1 = min(H - 1, q_lo + rows - 1 + P);
+        const float* dp = a.dy_dense + (long)b * a.dy_dense_bstride;
+        for (int e = r0 * W * nout + tid; e < (r1 + 1) * W * nout; e += CONV_THREADS) vmax = fmaxf(vmax, fabsf(dp[e]));
+      } else {
+        const int py0 = max(0, (q_lo - P) >> 1), py1 = min(Hp - 1, (q_lo + rows - 1 + P) >> 1);
+        const float* dp = a.dy.dpool + (long)b * a.dy.dpool_bstride;
+        for (int e = py0 * Wp * nout + tid; e < (py1 + 1) * Wp * nout; e += CONV_THREADS) vmax = fmaxf(vmax, fabsf(dp[e]));
+      }
     }
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
     if (lane == 0) red[wave] = vmax;
@@ -197,6 +204,43 @@ __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 
     }
   };
 
+  // ---- dense dY rows (DENSE): a thread owns elements idx = x * nout + o of a row; scaled, split, same LDS layout
+  constexpr int NDC = DENSE ? (G::WPAD * NO + CONV_THREADS - 1) / CONV_THREADS : 1;
+  bool dact[NDC]; uint32_t ddst[NDC]; float dreg[NDC];
+#pragma unroll
+  for (int c = 0; c < NDC; ++c) {
+    const int idx = tid + CONV_THREADS * c;
+    const int x = idx / nout, o = idx - x * nout;
+    dact[c] = DENSE && idx < W * nout;
+    const int ch = x >> 5, w = x & 31;
+    const int g = 2 * ((w >> 1) & 1) + (w >> 4), e = 4 * (w & 1) + ((w >> 2) & 3);
+    ddst[c] = keep_in_vgpr(lds_addr(dyring + (o < NO ? o : 0) * G::DOST + ch * 64 + g * 16 + e * 2));
+    dreg[c] = 0.f;
+  }
+  auto dense_load = [&](const __amdgpu_buffer_rsrc_t& rs, int y) {
+    const bool rowok = y >= 0 && y < H;               // uniform
+#pragma unroll
+    for (int c = 0; c < NDC; ++c) {
+      dreg[c] = 0.f;
+      if (rowok && dact[c]) dreg[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (tid + CONV_THREADS * c) * 4, y * W * nout * 4, 0));
+    }
+  };
+  auto dense_store = [&](int slot) {
+#pragma unroll
+    for (int c = 0; c < NDC; ++c) {
+      if (dact[c]) {
+        const float v = dreg[c] * sc;
+        const _Float16 h = (_Float16)v;
+        const float r1 = v - (float)h;
+        const _Float16 m = (_Float16)r1;
+        const _Float16 l = (_Float16)(r1 - (float)m);
+        lds_store(ddst[c], slot * DSLOT, __builtin_bit_cast(unsigned short, h));
+        lds_store(ddst[c], slot * DSLOT + G::DPC, __builtin_bit_cast(unsigned short, m));
+        lds_store(ddst[c], slot * DSLOT + 2 * G::DPC, __builtin_bit_cast(unsigned short, l));
+      }
+    }
+  };
+
   // ---- MFMA operands
   const int tj = (lane >> 2) & 3, tq = lane & 3;
   const uint32_t aadr = keep_in_vgpr(lds_addr(inring + 2 * (CP * (16 * (lj & 1) + 4 * tj + 2 * (lj >> 1)) + 4 * tq)));
@@ -230,6 +274,15 @@ __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 
     // position d of the band's stream <-> image row q_lo - P + d (conv_dw_kyo.h)
     const int y0 = q_lo - P;
     auto in_band = [&](int y) { return y >= q_lo && y < q_lo + rows; };
+    const __amdgpu_buffer_rsrc_t rdense = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(DENSE ? a.dy_dense + (long)b * a.dy_dense_bstride : a.dy.dpool), 0, DENSE ? H * W * nout * 4 : 0, 0x00020000);
+    if (DENSE) {
+      for (int d = 0; d <= 2 * P; ++d) { dense_load(rdense, y0 + d); dense_store(d % G::RING_DY); }
+      dense_load(rdense, y0 + 2 * P + 1);
+      for (int d = P; d < P + 2; ++d)
+        if (d - P < rows) { in_load(in_rs, y0 + d); in_store(d % G::RING_IN); }
+      if (2 < rows) in_load(in_rs, q_lo + 2);
+    } else {
     if (0 < rows) in_load(in_rs, q_lo);
     dy_issue(rp, rd, rc, y0 >> 1, 0);
     dy_issue(rp, rd, rc, (y0 >> 1) + 1, 1);
@@ -244,6 +297,7 @@ __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 
     if (2 < rows) in_load(in_rs, q_lo + 2);
     dy_conv(0, in_band(y0 + 4));
     dy_store(4, 0);                                   // position 5 (same cells) is stored by the first step
+    }
     __syncthreads();
 
     for (int t0 = 0; t0 < rows + P; t0 += G::UNROLL) {
@@ -255,9 +309,14 @@ __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 
         {  // stage ahead: dY position t + P + 1 (its slot held position t - P - 1), input position t + 2
           const int d = t + P + 1, y = y0 + d;
 #ifndef DW16_ABL_NODY
-          if ((d & 1) == 0) dy_conv(0, in_band(y));                     // requested one step ago
-          dy_store((sq + P + 1) % G::RING_DY, (sq + P + 1) & 1);
-          if ((d & 1) == 1) dy_issue(rp, rd, rc, (y + 1) >> 1, 0);      // next pooled row, used from the next step on
+          if (DENSE) {
+            dense_store((sq + P + 1) % G::RING_DY);                       // requested one step ago
+            dense_load(rdense, y + 1);
+          } else {
+            if ((d & 1) == 0) dy_conv(0, in_band(y));                     // requested one step ago
+            dy_store((sq + P + 1) % G::RING_DY, (sq + P + 1) & 1);
+            if ((d & 1) == 1) dy_issue(rp, rd, rc, (y + 1) >> 1, 0);      // next pooled row, used from the next step on
+          }
 #endif
 #ifndef DW16_ABL_NOIN
           if (t + 2 - P < rows) in_store((sq + 2) % G::RING_IN);
@@ -334,12 +393,12 @@ __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 
   }
 }
 
-template <int CIN, int KS, int NCHK>
+template <int CIN, int KS, int NCHK, bool DENSE = false>
 static inline int conv_dw16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int* grid_out) {
   typedef Dw16Geom<CIN, KS, NCHK> G;
   const ConvArgs& a = batch.a[0];
   const size_t lds_bytes = (size_t)G::LDS_BYTES;
-  auto kern = conv_dw16_kernel<CIN, KS, NCHK>;
+  auto kern = conv_dw16_kernel<CIN, KS, NCHK, DENSE>;
   static bool attr_done = false;
   if (!attr_done) {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -358,4 +417,4 @@ static inline int conv_dw16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int* 
 }
 
 // conv1 dW of f16 image batches with one whitening table (white_bstride == 0), pooled dY (no batch norm), 5x5, even CIN and W
-int conv_dw16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArgsN& a, int* grid, bool* handled);
+int conv_dw16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool dense, const ConvArgsN& a, int* grid, bool* handled);

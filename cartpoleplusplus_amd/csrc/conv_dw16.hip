@@ -2,17 +2,20 @@
 #include "conv_dw16.h"
 
 #define DW16_CASE(CIN_, NCHK_)                                                                               \
-  if (cin == CIN_ && nchk == NCHK_) { *handled = true; return conv_dw16_launch_t<CIN_, 5, NCHK_>(ctx, a, grid); }
+  if (cin == CIN_ && nchk == NCHK_ && !dense) { *handled = true; return conv_dw16_launch_t<CIN_, 5, NCHK_>(ctx, a, grid); }
+#define DW16_CASE_DENSE(CIN_, NCHK_)                                                                         \
+  if (cin == CIN_ && nchk == NCHK_ && dense) { *handled = true; return conv_dw16_launch_t<CIN_, 5, NCHK_, true>(ctx, a, grid); }
 
-int conv_dw16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArgsN& a, int* grid, bool* handled) {
+int conv_dw16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool dense, const ConvArgsN& a, int* grid, bool* handled) {
   *handled = false;
   const int W = a.a[0].W, H = a.a[0].H;
   if (ks != 5 || in_mode != IN_F16_WHITEN || W > 128 || (W & 1) || (H & 1) || H < 4 || a.a[0].nout > KYO_NO) return 0;
   for (int i = 0; i < a.n; ++i) {
-    if (a.a[i].white_bstride != 0 || a.a[i].dy_dense != nullptr) return 0;
+    if (a.a[i].white_bstride != 0 || (a.a[i].dy_dense != nullptr) != dense) return 0;
     if (((uintptr_t)a.a[i].in & 3) || (a.a[i].in_bstride & 1)) return 0;        // dword row staging
   }
   const int nchk = W > 64 ? 4 : (W > 32 ? 2 : 1);
+  DW16_CASE_DENSE(18, 2) DW16_CASE_DENSE(6, 2) DW16_CASE_DENSE(12, 2)
   DW16_CASE(18, 2) DW16_CASE(18, 1) DW16_CASE(6, 2) DW16_CASE(6, 1) DW16_CASE(12, 2) DW16_CASE(30, 4) DW16_CASE(18, 4) DW16_CASE(9, 2) DW16_CASE(9, 1) DW16_CASE(3, 2) DW16_CASE(3, 1)
   return 0;
 }

@@ -45,8 +45,13 @@ struct K16Geom {
   static constexpr int NPC = 3;                            // f16 pieces of a weight
   // weight image in LDS: slab (chunk, piece) holds the 16-byte operand (ky, lane group g, o) at ky*PS + g*GS + o*16;
   // the padded strides keep the rotating per-lane reads of a ds_read_b128 at 1.2 accesses per bank quad (2.45 compact)
+#ifdef K16_MID_LAYOUT
+  static constexpr bool PADDED = true;
+  static constexpr int PS = 784, GS = 160, SLAB = 3840;      // 1.6 accesses per bank quad, 34.5 KB for conv1
+#else
   static constexpr bool PADDED = NCH * NPC * 5632 <= 64 * 1024;
   static constexpr int PS = PADDED ? 1120 : 4 * NO * 16, GS = PADDED ? 256 : NO * 16, SLAB = PADDED ? 5632 : KS * 4 * NO * 16;
+#endif
   static constexpr int WLB = NCH * NPC * SLAB;             // bytes
   static constexpr int EF = 2 * 8 * XT * NO * 2;           // floats per wave: (value, code) of the two rows of a pool pair
   static constexpr int LDS_BYTES = WLB + 4 * EF * 4 + 64;
@@ -57,8 +62,11 @@ struct K16Geom {
   }
 };
 
+#ifndef K16_WGS
+#define K16_WGS 2
+#endif
 template <int CIN, int KS, int XT, int IPW, bool PLAIN = false>
-__global__ __launch_bounds__(CONV_THREADS, 2) void conv_fwd_k16_kernel(const ConvArgsN batch) {
+__global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(const ConvArgsN batch) {
   typedef K16Geom<CIN, KS, XT, IPW> G;
   constexpr int P = G::P, NT = G::NT, NCH = G::NCH, NPC = G::NPC, NO = KYO_NO;
   constexpr bool ODD = (CIN & 1) != 0;            // 2-byte aligned operand windows: 20 bytes from the aligned address below + a funnel shift
