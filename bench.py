@@ -234,6 +234,9 @@ def main():
         "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": wgroups * BATCHES_PER_STEP,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "dtype_note": "f32 accumulation everywhere; where the kernel list shows *_f16x3, conv1 multiplies exact f16 operands (the replay "
+                      "store's pixels x three-piece f16 splits of the f32 weights / gradients) on the f16 MFMA pipes: every product exact, "
+                      "results within f32 rounding of the f32-MFMA kernels (DESIGN.md 4, 6; CPP_CONV_K16=0 selects those)",
         "config": {"workload": "%s: DDPG pixel obs %dx%dx%d, batch=%d per GPU, replay %d rows/GPU in HBM (%s), "
                                "target soft-update every %d minibatches%s" % (
                                    args.workload, shape[0], shape[1], int(np.prod(shape[2:])), B, replay_rows, args.replay_store,
@@ -241,7 +244,8 @@ def main():
                    "parallelism": "dp%d (one learner per GPU, flat-gradient all-reduce per minibatch)" % world,
                    "global_steps_per_sec": round(steps / elapsed, 3),
                    "conv_gflop_per_step": round(conv_flops_step / 1e9, 3),
-                   "conv_roofline_frac_whole_step": round(conv_flops_step * steps / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+                   "conv_roofline_frac_whole_step": round(conv_flops_step * steps / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                   "conv_roofline_frac_basis": "algorithmic conv FLOPs of the whole step / 157.3 TFLOP/s (f32-input MFMA peak)"},
         "roofline": dict(roofs[0], traffic=traffic, traffic_source=traffic_src) if roofs else None,
         "roofline_next": roofs[1:],
         "kernels": kernels,
