@@ -13,6 +13,9 @@
 // 4x shorter chain matter more than tiling).  Partial tiles are combined through LDS in fixed order.
 // A(m,k) = A[m*sAm + k*sAk], B(k,n) = B[k*sBk + n*sBn]: the strides express the transposes of the
 // backward passes (dX = dz W^T, dW = x^T dz) without materialising them.
+#ifndef GEMM_U
+#define GEMM_U 8      // k values per wave and round = 4 U: sweeps of 4..32 move the MLP levels by < 3 % (fixed costs dominate); 8 keeps all four waves busy at K = 101
+#endif
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, float (*red)[256]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lj = lane >> 4;
@@ -23,7 +26,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, float (*r
   const float* ap = g.A + (long)m * g.sAm;
   const float* bp = g.B + (long)n * g.sBn;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  constexpr int U = 16;
+  constexpr int U = GEMM_U;
   for (int k0 = wave * 4 * U; k0 < g.K; k0 += 4 * 4 * U) {
     float av[U], bv[U];
 #pragma unroll
