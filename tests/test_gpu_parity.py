@@ -205,6 +205,26 @@ def test_graph_replay_is_deterministic_and_equals_eager():
     assert np.isfinite(params[0][0]).all() and np.isfinite(params[0][1]).all()
 
 
+def test_training_from_the_8_bit_replay_store_is_bit_identical():
+    """--replay-store u8: the gathered minibatches are the same f16 bits, so whole training steps (device sampling,
+    f16-pipe conv1 kernels, fused heads, updates) must leave exactly the same parameters as the f16 store."""
+    shape, B = (16, 16, 3, 2, 3), 8
+    params = []
+    for store in ("f16", "u8"):
+        agent, _ref, _ = make_pair(shape, B, True, replay_size=200, replay_store=store)
+        try:
+            assert agent.replay_memory.store_dtype == store
+            agent.replay_memory.fill_synthetic(150, seed=31)
+            for _ in range(3):
+                agent.train_step(B, 2)
+            params.append((agent.actor.get_params(), agent.critic.get_params(), agent.target_actor.get_params()))
+        finally:
+            agent.close()
+    for k in range(3):
+        assert np.array_equal(params[0][k], params[1][k])
+    assert np.isfinite(params[0][0]).all()
+
+
 def test_end_to_end_cli_with_checkpoints_and_event_log(tmp_path, capsys):
     """the agent's own main(): rollouts on the stand-in env, replay in HBM, fused train steps, STATS lines, a
     checkpoint that restores bit for bit, then offline training from the event log it wrote (--event-log-in
