@@ -75,6 +75,7 @@ struct ConvArgs {
   int tiles_x, tiles_y, ntiles;
   int vec_ok;                // input rows may be staged with aligned 16-byte loads
   int nbands, band_rows;     // conv_fwd_kyo_kernel: bands of output rows per image (0 / 1: whole images)
+  const int32_t* img_slot;   // conv1 on the f16 pipes only: image b is row img_slot[b] of `in` (the replay store itself: no gathered copy)
 };
 
 // Same-geometry convolutions of several networks in ONE launch (blockIdx.y selects the descriptor): the
@@ -82,6 +83,8 @@ struct ConvArgs {
 #define CONV_BATCH_MAX 4
 struct ConvArgsN { ConvArgs a[CONV_BATCH_MAX]; int n; };
 
+// true if conv1 forward (plain: batch norm) and dW (dense dY: batch norm) of this geometry run on conv_k16.h / conv_dw16.h
+bool conv1_f16_pipes_ok(int cin, int H, int W, int B, bool batch_norm);
 int launch_conv_fwd(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi, ConvArgs a);
 int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi, const ConvArgs* list, int n);
 int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, const ConvArgs* list, int n,
@@ -151,6 +154,7 @@ struct GatherArgs {
   int32_t* rows_out;            // rows actually used
   const float* action; const float* reward; const float* mask;
   void* out_state[2];           // gathered states (nullptr: no copy, statistics only)
+  int32_t* out_slot[2];         // store row of every sampled state (nullptr: not wanted): conv1 can read the store itself
   float* out_action; float* out_reward; float* out_mask;
   double* part;                 // [2][B][2*C] per-row partial sums
   uint64_t seed; const uint64_t* counter;

@@ -3,6 +3,7 @@
 #include "conv_k16.h"
 #include "conv_dw16.h"
 #include <cstdlib>
+#include <cstring>
 
 static int pick_xtw(int in_mode, int W) {
   if (in_mode == IN_F16_WHITEN || in_mode == IN_F32_WHITEN) return 4;   // conv1: always 64-wide tiles
@@ -31,6 +32,20 @@ static void set_tiles(ConvArgs& a, int cin, int xtw) {
   a.tiles_x = (a.W + 16 * xtw - 1) / (16 * xtw);
   a.tiles_y = (a.H + th - 1) / th;
   a.ntiles = a.B * a.tiles_x * a.tiles_y;
+}
+
+bool conv1_f16_pipes_ok(int cin, int H, int W, int B, bool batch_norm) {
+  static const bool off = (getenv("CPP_CONV_K16") != nullptr && atoi(getenv("CPP_CONV_K16")) == 0) ||
+                          (getenv("CPP_CONV_KYO") != nullptr && atoi(getenv("CPP_CONV_KYO")) == 0);
+  if (off || B < 2 || H < 4) return false;
+  ConvArgsN q; memset(&q, 0, sizeof(q));
+  q.n = 1; q.a[0].H = H; q.a[0].W = W; q.a[0].B = B; q.a[0].nout = KYO_NO; q.a[0].in_bstride = (long)H * W * cin;
+  float dummy = 0.f;
+  if (batch_norm) q.a[0].dy_dense = &dummy;
+  bool f = false, d = false; int grid = 0;
+  (void)conv_fwd_k16_dispatch(nullptr, cin, 5, IN_F16_WHITEN, batch_norm, q, &f);          // (dry run: no context, no launch)
+  (void)conv_dw16_dispatch(nullptr, cin, 5, IN_F16_WHITEN, batch_norm, q, &grid, &d);
+  return f && d;
 }
 
 int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi, const ConvArgs* list, int n) {
@@ -73,6 +88,8 @@ int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, i
     rc = conv_fwd_k16_dispatch(ctx, cin, ks, in_mode, plain_fwd, batch, &handled);
     if (handled) { prof_end(ctx, kid == K_CONV1_FWD ? K_CONV1_FWD_F16X3 : kid); return rc; }
   }
+  for (int i = 0; i < n; ++i)
+    if (batch.a[i].img_slot) { cpp_set_error("conv forward: images addressed through replay slots need the f16-pipe conv1 kernel"); prof_end(ctx, kid); return 1; }
   if (kyo) {
     // few workgroups (the dX passes carry two networks: one wave per SIMD): split the images into two bands of rows
     // (CPP_CONV_BANDS=0: whole images)
@@ -143,6 +160,9 @@ int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, co
     rc = conv_dw16_dispatch(ctx, cin, ks, in_mode, dense, batch, &grid, &handled);
     if (handled) kid = kid == K_CONV1_DW ? K_CONV1_DW_F16X3 : kid;
   }
+  if (!handled)
+    for (int i = 0; i < n; ++i)
+      if (batch.a[i].img_slot) { cpp_set_error("conv dW: images addressed through replay slots need the f16-pipe conv1 kernel"); prof_end(ctx, kid); return 1; }
   if (!handled && kyo) rc = conv_dw_kyo_dispatch(ctx, cin, ks, in_mode, chb, dense, batch, &grid, &handled);
   if (dense && !handled) {
     cpp_set_error("conv dW from dense dY rows (batch norm): no kernel for %dx%d, %d channels, %dx%d taps, %d-byte rows chunks",

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 
     const int q_lo = (unit - b * units_per_img) * band;
     const int rows = min(band, H - q_lo);            // band and q_lo are even
     const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<__half*>((const __half*)a.in + (long)b * a.in_bstride), 0, H * rowbytes, 0x00020000);
+        const_cast<__half*>((const __half*)a.in + (long)(a.img_slot ? a.img_slot[b] : b) * a.in_bstride), 0, H * rowbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.dy.pool + (long)b * a.dy.pool_bstride), 0, Hp * Wp * nout * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(

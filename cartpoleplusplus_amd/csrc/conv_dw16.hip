@@ -2,9 +2,9 @@
 #include "conv_dw16.h"
 
 #define DW16_CASE(CIN_, NCHK_)                                                                               \
-  if (cin == CIN_ && nchk == NCHK_ && !dense) { *handled = true; return conv_dw16_launch_t<CIN_, 5, NCHK_>(ctx, a, grid); }
+  if (cin == CIN_ && nchk == NCHK_ && !dense) { *handled = true; if (!ctx) return 0; return conv_dw16_launch_t<CIN_, 5, NCHK_>(ctx, a, grid); }
 #define DW16_CASE_DENSE(CIN_, NCHK_)                                                                         \
-  if (cin == CIN_ && nchk == NCHK_ && dense) { *handled = true; return conv_dw16_launch_t<CIN_, 5, NCHK_, true>(ctx, a, grid); }
+  if (cin == CIN_ && nchk == NCHK_ && dense) { *handled = true; if (!ctx) return 0; return conv_dw16_launch_t<CIN_, 5, NCHK_, true>(ctx, a, grid); }
 
 int conv_dw16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool dense, const ConvArgsN& a, int* grid, bool* handled) {
   *handled = false;

@@ -2,7 +2,7 @@
 #include "conv_k16.h"
 
 #define K16_CASE(CIN_, XT_, IPW_, PLAIN_)                                                                    \
-  if (cin == CIN_ && xt == XT_ && ipw == IPW_ && plain == PLAIN_) { *handled = true;                         \
+  if (cin == CIN_ && xt == XT_ && ipw == IPW_ && plain == PLAIN_) { *handled = true; if (!ctx) return 0;      \
     return conv_fwd_k16_launch_t<CIN_, 5, XT_, IPW_, PLAIN_>(ctx, a); }
 
 int conv_fwd_k16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool plain, const ConvArgsN& a, bool* handled) {

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   // ---- A operands: 16 bytes per lane and (tile, chunk) straight from the image row
   const int rowbytes = W * CIN * 2;
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)((const char*)a.in + ((long)sbimg * a.in_bstride) * 2 - G::BIAS_BYTES), 0, H * rowbytes + G::BIAS_BYTES + 256, 0x00020000);
+      (void*)((const char*)a.in + ((long)(a.img_slot ? a.img_slot[sbimg] : sbimg) * a.in_bstride) * 2 - G::BIAS_BYTES), 0, H * rowbytes + G::BIAS_BYTES + 256, 0x00020000);
   const int avoff0 = G::BIAS_BYTES + ((strip * G::SW + li - P) * CIN + 8 * lj) * 2;     // >= 128 - 2 P CIN
   const int avoff = ODD ? (avoff0 & ~3) : avoff0;
   const unsigned ashift = ODD ? (unsigned)(avoff0 & 2) : 0u;    // per-lane constant: 16 * m * CIN pixels further keeps the parity

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(const GatherArgs a) {
   row = __shfl(row, 0);
   slot = __shfl(slot, 0);
 
+  if (tid == 0 && a.out_slot[which]) a.out_slot[which][b] = slot;
   if (which == 0 && a.s_idx[0] != nullptr) {
     if (tid == 0 && a.rows_out) a.rows_out[b] = row;
     if (tid < a.action_dim) a.out_action[(long)b * a.action_dim + tid] = a.action[(long)row * a.action_dim + tid];

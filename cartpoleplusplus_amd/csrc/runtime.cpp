@@ -176,6 +176,7 @@ struct cpp_net {
   long nparams; int flat; int cat_layer; long state_elems;
   float* params; float* grads; float* own_grads;
   Workspace ws[2];
+  const int32_t* img_slot;  // conv1 reads image b from row img_slot[b] of the state pointer (the replay store); nullptr: b
   float* white;            // [2][C] statistics for cpp_net_forward
   float* white_rows;       // [maxB][2][C]: per-image statistics for cpp_net_forward_each
   double* stats_part;      // [maxB][2C]
@@ -290,6 +291,7 @@ extern "C" int cpp_net_create(cpp_ctx* ctx, const cpp_net_spec* spec, int max_ba
   n->ctx = ctx; n->spec = *spec; n->maxB = max_batch; n->arena.stream = ctx->stream;
   n->grads = nullptr; n->own_grads = nullptr; n->stage_state = nullptr; n->stage_action = nullptr;
   n->stage_out = nullptr; n->dw_partial[0] = n->dw_partial[1] = n->dw_partial[2] = nullptr; n->white = nullptr; n->white_rows = nullptr; n->stats_part = nullptr;
+  n->img_slot = nullptr;
   n->is_training = true; n->drop_counter = nullptr; n->bn_part = nullptr; n->bn_means = nullptr; n->bn_scratch = nullptr;
   int rc = net_build(n);
   if (rc) { delete n; return rc; }
@@ -394,6 +396,7 @@ static ConvArgs conv_fwd_args(cpp_net* n, Workspace& w, int i, const void* state
   const ConvL& L = n->conv[i];
   ConvArgs a; memset(&a, 0, sizeof(a));
   if (i == 0) { a.in = state; a.in_bstride = n->state_elems; a.scale = white; a.shift = white + n->spec.C; a.white_bstride = white_bstride;
+                a.img_slot = n->img_slot;
                 *mode = dtype == CPP_F16 ? IN_F16_WHITEN : IN_F32_WHITEN; }
   else { a.in = w.pool[i - 1]; a.in_bstride = (long)L.H * L.W * L.Cin; *mode = IN_F32_PLAIN; }
   a.w = n->params + L.w_off; a.bias = n->params + L.b_off;
@@ -414,7 +417,7 @@ static ConvArgs conv_dw_args(cpp_net* n, Workspace& w, int i, const void* state,
   const ConvL& L = n->conv[i];
   ConvArgs d; memset(&d, 0, sizeof(d));
   conv_dy_desc(n, w, i, d, B);
-  if (i == 0) { d.in = state; d.in_bstride = n->state_elems; d.scale = white; d.shift = white + n->spec.C;
+  if (i == 0) { d.in = state; d.in_bstride = n->state_elems; d.scale = white; d.shift = white + n->spec.C; d.img_slot = n->img_slot;
                 *mode = dtype == CPP_F16 ? IN_F16_WHITEN : IN_F32_WHITEN; }
   else { d.in = w.pool[i - 1]; d.in_bstride = (long)L.H * L.W * L.Cin; *mode = IN_F32_PLAIN; }
   d.nout = kConvOut; d.partial = n->dw_partial[i];
@@ -851,6 +854,9 @@ struct cpp_batch {
   float* white;        // [2 states][2][CPP_MAX_CHANNELS]-compatible: laid out [2][2*C] for the current C
   double* part;        // [2][maxB][2*CPP_MAX_CHANNELS]
   int stats_C;         // channels the statistics were computed for (0: none yet)
+  // device-sampled minibatch that was NOT gathered: state k of row b is row slot[k][b] of direct_store (the replay store);
+  // only the f16-pipe conv1 kernels can consume it (direct_store == nullptr: s[] holds the gathered copy)
+  int32_t* slot[2]; const void* direct_store;
   Arena arena;
 };
 
@@ -868,6 +874,8 @@ extern "C" int cpp_batch_create(cpp_ctx* ctx, int max_batch, int64_t state_elems
   if (!rc) rc = dalloc(b->arena, &b->m, (size_t)max_batch);
   if (!rc) rc = dalloc(b->arena, &b->white, (size_t)4 * CPP_MAX_CHANNELS);
   if (!rc) rc = dalloc(b->arena, &b->part, (size_t)2 * max_batch * 2 * CPP_MAX_CHANNELS);
+  b->direct_store = nullptr;
+  for (int k = 0; k < 2 && !rc; ++k) rc = dalloc(b->arena, &b->slot[k], (size_t)max_batch);
   if (rc) { b->arena.release(); delete b; return rc; }
   *out = b;
   return CPP_OK;
@@ -883,6 +891,7 @@ extern "C" int cpp_batch_state_dtype(const cpp_batch* b) { return b ? b->dtype :
 
 extern "C" int cpp_batch_upload(cpp_batch* b, int B, const void* s1, const void* s2, int dtype,
                                 const float* action, const float* reward, const float* mask) {
+  if (b) b->direct_store = nullptr;
   ARG_CHECK(b && s1, "cpp_batch_upload: NULL argument");
   ARG_CHECK(B >= 1 && B <= b->maxB, "cpp_batch_upload: batch %d outside [1,%d]", B, b->maxB);
   ARG_CHECK(dtype == CPP_F32 || dtype == CPP_F16, "cpp_batch_upload: dtype %d", dtype);
@@ -1112,7 +1121,7 @@ extern "C" int cpp_replay_read_states(cpp_replay* r, const int32_t* slots, int n
 
 // device-only part of sampling (graph-capturable when rows_dev == nullptr or already resident)
 static int replay_sample_device(cpp_replay* r, int B, const int32_t* rows_dev, uint64_t seed, const uint64_t* counter_dev,
-                                int channels, cpp_batch* out) {
+                                int channels, cpp_batch* out, bool direct = false) {
   cpp_ctx* ctx = r->ctx;
   int C = channels;
   if (C > 0) {
@@ -1123,7 +1132,10 @@ static int replay_sample_device(cpp_replay* r, int B, const int32_t* rows_dev, u
   a.store[0] = r->store; a.store[1] = r->store; a.s_idx[0] = r->s1; a.s_idx[1] = r->s2; a.lut = r->lut;
   a.rows = rows_dev; a.rows_out = r->rows_out;
   a.action = r->action; a.reward = r->reward; a.mask = r->mask;
-  a.out_state[0] = out->s[0]; a.out_state[1] = out->s[1];
+  // direct: no gathered copy -- statistics + the store rows of the sampled states; conv1 reads the store (caller checked)
+  a.out_state[0] = direct ? nullptr : out->s[0]; a.out_state[1] = direct ? nullptr : out->s[1];
+  a.out_slot[0] = direct ? out->slot[0] : nullptr; a.out_slot[1] = direct ? out->slot[1] : nullptr;
+  out->direct_store = direct ? r->store : nullptr;
   a.out_action = out->a; a.out_reward = out->r; a.out_mask = out->m;
   a.part = out->part; a.seed = seed; a.counter = counter_dev;
   a.elems = r->elems; a.B = B; a.size = r->size; a.action_dim = r->A; a.C = C;
@@ -1412,7 +1424,14 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b) {
   cpp_net *a = d->actor, *c = d->critic, *ta = d->tactor, *tc = d->tcritic;
   const int B = b->B, A = a->spec.action_dim, C = a->spec.pixel ? a->spec.C : 0;
   const float *w1 = white_of(b, 0, C), *w2 = white_of(b, 1, C);
-  const void *s1 = b->s[0], *s2 = b->s[1];
+  const void *s1 = b->direct_store ? b->direct_store : b->s[0], *s2 = b->direct_store ? b->direct_store : b->s[1];
+  struct SlotScope {      // conv1 of the four networks addresses its images through the sampled slots while this graph runs
+    cpp_net* n[4];
+    SlotScope(cpp_net* a_, cpp_net* c_, cpp_net* ta_, cpp_net* tc_, cpp_batch* b_) : n{a_, c_, ta_, tc_} {
+      if (b_->direct_store) { a_->img_slot = c_->img_slot = b_->slot[0]; ta_->img_slot = tc_->img_slot = b_->slot[1]; }
+    }
+    ~SlotScope() { for (cpp_net* x : n) x->img_slot = nullptr; }
+  } slot_scope(a, c, ta, tc, b);
   const int dt = b->dtype;
   const int na = (int)a->fc.size(), nc = (int)c->fc.size(), cat = c->cat_layer;
   const FcL& Lcat = c->fc[cat];
@@ -1628,11 +1647,24 @@ extern "C" int cpp_ddpg_update_targets(cpp_ddpg* d) {
                             d->nC, d->hp.target_update_rate);
 }
 
+// The fused step does not need a gathered copy of the minibatch when conv1 runs on the f16-pipe kernels: they take the
+// replay store plus the sampled slots (the gather kernel then only reads -- statistics -- and writes 2 B ints).
+// CPP_DIRECT_REPLAY=0 keeps the copy.
+static bool ddpg_direct_replay(cpp_ddpg* d, cpp_replay* r, int B) {
+  static const bool off = getenv("CPP_DIRECT_REPLAY") != nullptr && atoi(getenv("CPP_DIRECT_REPLAY")) == 0;
+  cpp_net* a = d->actor;
+  if (off || !a->spec.pixel || r->store_dtype != CPP_F16) return false;
+  const int C = a->spec.C;
+  int g = 8, c = C; while (c) { int t = g % c; g = c; c = t; }
+  if (r->elems % 8 != 0 || C / g > 16 || r->elems % C != 0) return false;       // statistics come from the gather kernel
+  return conv1_f16_pipes_ok(C, a->conv[0].H, a->conv[0].W, B, a->spec.use_batch_norm != 0);
+}
+
 static int step_body(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int32_t* rows_dev, uint64_t seed) {
   const int C = d->actor->spec.pixel ? d->actor->spec.C : 0;
   for (int i = 0; i < n_batches; ++i) {
     RC(replay_sample_device(r, B, rows_dev ? rows_dev + (size_t)i * B : nullptr, seed, rows_dev ? nullptr : r->counter, C,
-                            d->step_batch));
+                            d->step_batch, ddpg_direct_replay(d, r, B)));
     RC(compute_gradients(d, d->step_batch));
     RC(apply(d, true, true, 1.0f, rows_dev ? nullptr : r->counter));   // also advances the sampler's counter
   }
@@ -1679,7 +1711,7 @@ extern "C" int cpp_ddpg_train_step(cpp_ddpg* d, cpp_replay* r, int B, int n_batc
 
 static int half_step_body(cpp_ddpg* d, cpp_replay* r, int B, uint64_t seed) {
   const int C = d->actor->spec.pixel ? d->actor->spec.C : 0;
-  RC(replay_sample_device(r, B, nullptr, seed, r->counter, C, d->step_batch));
+  RC(replay_sample_device(r, B, nullptr, seed, r->counter, C, d->step_batch, ddpg_direct_replay(d, r, B)));
   RC(launch_counter_add(d->ctx, r->counter, 1));
   return compute_gradients(d, d->step_batch);
 }
