@@ -1650,9 +1650,8 @@ extern "C" int cpp_ddpg_update_targets(cpp_ddpg* d) {
 // The fused step does not need a gathered copy of the minibatch when conv1 runs on the f16-pipe kernels: they take the
 // replay store plus the sampled slots (the gather kernel then only reads -- statistics -- and writes 2 B ints).
 // CPP_DIRECT_REPLAY=0 keeps the copy.
-static bool ddpg_direct_replay(cpp_ddpg* d, cpp_replay* r, int B) {
+static bool direct_replay_ok(cpp_net* a, cpp_replay* r, int B) {
   static const bool off = getenv("CPP_DIRECT_REPLAY") != nullptr && atoi(getenv("CPP_DIRECT_REPLAY")) == 0;
-  cpp_net* a = d->actor;
   if (off || !a->spec.pixel || r->store_dtype != CPP_F16) return false;
   const int C = a->spec.C;
   int g = 8, c = C; while (c) { int t = g % c; g = c; c = t; }
@@ -1664,7 +1663,7 @@ static int step_body(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int
   const int C = d->actor->spec.pixel ? d->actor->spec.C : 0;
   for (int i = 0; i < n_batches; ++i) {
     RC(replay_sample_device(r, B, rows_dev ? rows_dev + (size_t)i * B : nullptr, seed, rows_dev ? nullptr : r->counter, C,
-                            d->step_batch, ddpg_direct_replay(d, r, B)));
+                            d->step_batch, direct_replay_ok(d->actor, r, B)));
     RC(compute_gradients(d, d->step_batch));
     RC(apply(d, true, true, 1.0f, rows_dev ? nullptr : r->counter));   // also advances the sampler's counter
   }
@@ -1711,7 +1710,7 @@ extern "C" int cpp_ddpg_train_step(cpp_ddpg* d, cpp_replay* r, int B, int n_batc
 
 static int half_step_body(cpp_ddpg* d, cpp_replay* r, int B, uint64_t seed) {
   const int C = d->actor->spec.pixel ? d->actor->spec.C : 0;
-  RC(replay_sample_device(r, B, nullptr, seed, r->counter, C, d->step_batch, ddpg_direct_replay(d, r, B)));
+  RC(replay_sample_device(r, B, nullptr, seed, r->counter, C, d->step_batch, direct_replay_ok(d->actor, r, B)));
   RC(launch_counter_add(d->ctx, r->counter, 1));
   return compute_gradients(d, d->step_batch);
 }
@@ -1891,7 +1890,14 @@ static int naf_compute_gradients(cpp_naf* f, cpp_batch* b) {
   cpp_net *v = f->value, *tv = f->tvalue, *mu = f->mu, *lv = f->lv;
   const int B = b->B, C = v->spec.pixel ? v->spec.C : 0, dt = b->dtype;
   const float *w1 = white_of(b, 0, C), *w2 = white_of(b, 1, C);
-  const void *s1 = b->s[0], *s2 = b->s[1];
+  const void *s1 = b->direct_store ? b->direct_store : b->s[0], *s2 = b->direct_store ? b->direct_store : b->s[1];
+  struct SlotScope {      // conv1 addresses its images through the sampled slots while this graph runs
+    cpp_net* n[4];
+    SlotScope(cpp_net* v_, cpp_net* mu_, cpp_net* lv_, cpp_net* tv_, cpp_batch* b_) : n{v_, mu_, lv_, tv_} {
+      if (b_->direct_store) { v_->img_slot = mu_->img_slot = lv_->img_slot = b_->slot[0]; tv_->img_slot = b_->slot[1]; }
+    }
+    ~SlotScope() { for (cpp_net* x : n) x->img_slot = nullptr; }
+  } slot_scope(v, mu, lv, tv, b);
   const bool share = f->share != 0;
   OpGraph G;
 
@@ -2074,7 +2080,8 @@ extern "C" int cpp_naf_debug_values(cpp_naf* f, cpp_batch* b, float* l_values, f
 static int naf_step_body(cpp_naf* f, cpp_replay* r, int B, int n_batches, const int32_t* rows_dev, uint64_t seed) {
   const int C = f->value->spec.pixel ? f->value->spec.C : 0;
   for (int i = 0; i < n_batches; ++i) {
-    RC(replay_sample_device(r, B, rows_dev ? rows_dev + (size_t)i * B : nullptr, seed, rows_dev ? nullptr : r->counter, C, f->step_batch));
+    RC(replay_sample_device(r, B, rows_dev ? rows_dev + (size_t)i * B : nullptr, seed, rows_dev ? nullptr : r->counter, C, f->step_batch,
+                            direct_replay_ok(f->value, r, B)));
     if (!rows_dev) RC(launch_counter_add(f->ctx, r->counter, 1));
     RC(naf_compute_gradients(f, f->step_batch));
     RC(naf_apply(f, 1.0f));
