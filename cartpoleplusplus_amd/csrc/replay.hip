@@ -145,19 +145,22 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(const GatherArgs a) {
   // stage 2: per (class q, element e): sum the lanes of that class over the 4 waves, in f64
   if (tid < P * 16) {
     const int q = tid >> 4, e = tid & 15;
-    double acc = 0.0;
-    for (int w = 0; w < 4; ++w)
-      for (int l = q; l < act; l += P) acc += (double)sh[(w * 64 + l) * 16 + e];
-    dsh[q * 16 + e] = acc;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;    // one chain per wave: four LDS reads in flight instead of one
+    for (int l = q; l < act; l += P) {
+      a0 += (double)sh[(0 * 64 + l) * 16 + e]; a1 += (double)sh[(1 * 64 + l) * 16 + e];
+      a2 += (double)sh[(2 * 64 + l) * 16 + e]; a3 += (double)sh[(3 * 64 + l) * 16 + e];
+    }
+    dsh[q * 16 + e] = (a0 + a1) + (a2 + a3);
   }
   __syncthreads();
   // stage 3: per channel: the (q, e) pairs with (8q + e) % C == c
   if (tid < 2 * C) {
     const int stat = tid / C, c = tid - stat * C;
     double acc = 0.0;
-    for (int q = 0; q < P; ++q)
-      for (int e = 0; e < 8; ++e)
-        if ((8 * q + e) % C == c) acc += dsh[q * 16 + stat * 8 + e];
+    for (int q = 0; q < P; ++q) {                  // elements e of class q with (8 q + e) % C == c, ascending
+      int e = (c - 8 * q) % C; if (e < 0) e += C;
+      for (; e < 8; e += C) acc += dsh[q * 16 + stat * 8 + e];
+    }
     a.part[((long)which * a.B + b) * 2 * C + tid] = acc;
   }
 }
