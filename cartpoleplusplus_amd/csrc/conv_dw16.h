@@ -90,11 +90,30 @@ __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 
       if (DENSE) {
         const int r0 = max(0, q_lo - P), r1 = min(H - 1, q_lo + rows - 1 + P);
         const float* dp = a.dy_dense + (long)b * a.dy_dense_bstride;
-        for (int e = r0 * W * nout + tid; e < (r1 + 1) * W * nout; e += CONV_THREADS) vmax = fmaxf(vmax, fabsf(dp[e]));
+        const int e1 = (r1 + 1) * W * nout;
+        int e = r0 * W * nout + tid;
+        for (; e + 7 * CONV_THREADS < e1; e += 8 * CONV_THREADS) {      // 8 loads in flight (a 1-load loop pays the latency per trip)
+          float t[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t[u] = dp[e + u * CONV_THREADS];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) vmax = fmaxf(vmax, fabsf(t[u]));
+        }
+        for (; e < e1; e += CONV_THREADS) vmax = fmaxf(vmax, fabsf(dp[e]));
       } else {
         const int py0 = max(0, (q_lo - P) >> 1), py1 = min(Hp - 1, (q_lo + rows - 1 + P) >> 1);
         const float* dp = a.dy.dpool + (long)b * a.dy.dpool_bstride;
-        for (int e = py0 * Wp * nout + tid; e < (py1 + 1) * Wp * nout; e += CONV_THREADS) vmax = fmaxf(vmax, fabsf(dp[e]));
+        const int e1 = (py1 + 1) * Wp * nout;
+        int e = py0 * Wp * nout + tid;
+        for (; e + 7 * CONV_THREADS < e1; e += 8 * CONV_THREADS) {      // 8 loads in flight (a 1-load loop pays the latency per trip)
+          float t[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t[u] = dp[e + u * CONV_THREADS];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) vmax = fmaxf(vmax, fabsf(t[u]));
+        }
+#pragma unroll 4
+        for (; e < e1; e += CONV_THREADS) vmax = fmaxf(vmax, fabsf(dp[e]));
       }
     }
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));

@@ -15,7 +15,16 @@ __global__ __launch_bounds__(OPT_THREADS) void sumsq_kernel(const OptSegs s, flo
   const float* g = s.g[seg];
   const long n = s.n[seg];
   double acc = 0.0;
-  for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += (long)nparts * OPT_THREADS) {
+  const long stride = (long)nparts * OPT_THREADS;
+  long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x;
+  for (; i + 7 * stride < n; i += 8 * stride) {      // 8 loads in flight; same order of additions as the plain loop
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = g[i + u * stride] * grad_scale;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += (double)v[u] * (double)v[u];
+  }
+  for (; i < n; i += stride) {
     const float v = g[i] * grad_scale;
     acc += (double)v * (double)v;
   }
@@ -46,11 +55,16 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_apply_kernel(const OptSegs s,
                                                                 int nparts, float* norms_out) {
   __shared__ float sh_scale, sh_lr;
   const int seg = blockIdx.y;
-  if (threadIdx.x == 0) {
-    double tot = 0.0;
+  // squared norm of the segment's group: the first wave adds the partials (one load per lane and segment in flight, then a
+  // fixed-order butterfly) -- a one-thread loop over them was most of this kernel's time
+  double tot = 0.0;
+  if (threadIdx.x < 64) {
     for (int k = 0; k < s.nseg; ++k)
       if (s.group[k] == s.group[seg])
-        for (int i = 0; i < nparts; ++i) tot += part[k * nparts + i];
+        for (int i = threadIdx.x; i < nparts; i += 64) tot += part[k * nparts + i];
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+  }
+  if (threadIdx.x == 0) {
     const float norm = (float)sqrt(tot);
     float sc = 1.f;
     if (clip > 0.f) sc = clip * fminf(1.f / norm, 1.f / clip);
@@ -71,7 +85,15 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_apply_kernel(const OptSegs s,
   const long n = s.n[seg];
   const long stride = (long)gridDim.x * OPT_THREADS;
   if (s.kind == OPT_SGD) {
-    for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += stride)
+    long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+      float pv[4], gv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { pv[u] = p[i + u * stride]; gv[u] = g[i + u * stride]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) p[i + u * stride] = pv[u] - lr * (gv[u] * sc);
+    }
+    for (; i < n; i += stride)
       p[i] = p[i] - lr * (g[i] * sc);
   } else if (s.kind == OPT_MOMENTUM) {
     float* m = s.m[seg];

@@ -188,6 +188,7 @@ __global__ __launch_bounds__(64) void stats_finalize_kernel(const double* part, 
                                                             int C, double count, float* white, double eps) {
   const int w = blockIdx.x / C, c = blockIdx.x - w * C;
   double s = 0.0, ss = 0.0;
+#pragma unroll 4
   for (int b = threadIdx.x; b < nparts; b += 64) {
     const double* p = part + ((long)w * nparts + b) * 2 * C;
     s += p[c]; ss += p[C + c];
