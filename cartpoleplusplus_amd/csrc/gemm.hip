@@ -27,14 +27,33 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, float (*r
   const float* bp = g.B + (long)n * g.sBn;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   constexpr int U = GEMM_U;
+  // k order inside a round of 4 U values: lane group lj takes k0 + U lj + u (u = MFMA step), so an operand that is contiguous
+  // in k (activations / dz in the forward and dX passes: sAk == 1; W^T in dX: sBk == 1) is read with 16-byte loads --
+  // a quarter of the load instructions and of the cache lines the texture path walks (the rounds are bound by that walk:
+  // in-kernel probe, 1.6-2.4 us per round with 4-byte loads).  Any k order works as long as A and B agree.
+  static_assert(U % 4 == 0, "whole float4s per lane");
+  typedef float gemm_f4 __attribute__((ext_vector_type(4), aligned(4)));
+  const bool va = g.sAk == 1, vb = g.sBk == 1;       // uniform
   for (int k0 = wave * 4 * U; k0 < g.K; k0 += 4 * 4 * U) {
     float av[U], bv[U];
+    const int kb = k0 + U * lj;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int k = k0 + 4 * u + lj;
-      const bool kv = k < g.K;
-      av[u] = (mv && kv) ? ap[(long)k * g.sAk] : 0.f;
-      bv[u] = (nv && kv) ? bp[(long)k * g.sBk] : 0.f;
+    for (int q = 0; q < U / 4; ++q) {
+      const int k = kb + 4 * q;
+      if (va && mv && k + 3 < g.K) {
+        const gemm_f4 v = *reinterpret_cast<const gemm_f4*>(ap + k);
+        av[4 * q] = v[0]; av[4 * q + 1] = v[1]; av[4 * q + 2] = v[2]; av[4 * q + 3] = v[3];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[4 * q + e] = (mv && k + e < g.K) ? ap[(long)(k + e) * g.sAk] : 0.f;
+      }
+      if (vb && nv && k + 3 < g.K) {
+        const gemm_f4 v = *reinterpret_cast<const gemm_f4*>(bp + k);
+        bv[4 * q] = v[0]; bv[4 * q + 1] = v[1]; bv[4 * q + 2] = v[2]; bv[4 * q + 3] = v[3];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[4 * q + e] = (nv && k + e < g.K) ? bp[(long)(k + e) * g.sBk] : 0.f;
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) acc = MFMA16(av[u], bv[u], acc);
