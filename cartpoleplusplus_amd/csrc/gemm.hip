@@ -14,7 +14,7 @@
 // A(m,k) = A[m*sAm + k*sAk], B(k,n) = B[k*sBk + n*sBn]: the strides express the transposes of the
 // backward passes (dX = dz W^T, dW = x^T dz) without materialising them.
 #ifndef GEMM_U
-#define GEMM_U 8      // k values per wave and round = 4 U: sweeps of 4..32 move the MLP levels by < 3 % (fixed costs dominate); 8 keeps all four waves busy at K = 101
+#define GEMM_U 4      // k values per wave and round = 4 U (sweep 4 / 8 / 12 / 16 with 16-byte loads: 0.057 / 0.058 / 0.064 / 0.064 ms for the six MLP levels)
 #endif
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, float (*red)[256]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
