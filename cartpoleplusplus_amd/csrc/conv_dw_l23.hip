@@ -3,15 +3,19 @@
 
 // 64 outputs x 4 slices of the partial list per workgroup; slices are combined in fixed order.  One launch
 // serves every queued (layer, network) reduction: workgroup -> (descriptor, output block) via a prefix table.
-__global__ __launch_bounds__(256) void conv_dw_reduce_kernel(const DwReduceBatch rb) {
-  __shared__ float red[4][64];
+#ifndef DWR_SLICES
+#define DWR_SLICES 16
+#endif
+__global__ __launch_bounds__(64 * DWR_SLICES) void conv_dw_reduce_kernel(const DwReduceBatch rb) {
+  constexpr int NS = DWR_SLICES;                     // slices of the partial list per output (each a chain of dependent load rounds)
+  __shared__ float red[NS][64];
   int p = 0;
   while (p + 1 < rb.n && (int)blockIdx.x >= rb.block_start[p + 1]) ++p;
   const DwReduceDesc d = rb.d[p];
   const int el = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const int e = (blockIdx.x - rb.block_start[p]) * 64 + el;
   const int n = d.nw + d.nout;
-  const int per = (d.nblocks + 3) >> 2;
+  const int per = (d.nblocks + NS - 1) / NS;
   const int b0 = slice * per, b1 = min(b0 + per, d.nblocks);
   float s = 0.f;
   if (e < n) {
@@ -28,13 +32,15 @@ __global__ __launch_bounds__(256) void conv_dw_reduce_kernel(const DwReduceBatch
   red[slice][el] = s;
   __syncthreads();
   if (slice == 0 && e < n) {
-    const float t = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) t += red[k][el];     // fixed order
     if (e < d.nw) d.grad_w[e] = t; else d.grad_b[e - d.nw] = t;
   }
 }
 
 int launch_dw_reduce_batch(cpp_ctx* ctx, const DwReduceBatch& rb) {
-  hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3(rb.block_start[rb.n]), dim3(256), 0, ctx->stream, rb);
+  hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3(rb.block_start[rb.n]), dim3(64 * DWR_SLICES), 0, ctx->stream, rb);
   LAUNCH_CHECK();
   return 0;
 }
