@@ -1498,7 +1498,7 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b) {
     hd.loss_part = d->heads_part;
     fused = ddpg_heads_supported(hd);
   }
-  d->heads_grid = fused ? (B + 7) / 8 : 0; d->heads_B = B;
+  d->heads_grid = fused ? (B + 3) / 4 : 0; d->heads_B = B;
   d->loss_parts = d->heads_grid; d->loss_B = B;
   int adz, cdz;
   if (fused) {
