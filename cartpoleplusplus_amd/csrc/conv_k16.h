@@ -70,6 +70,9 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   typedef K16Geom<CIN, KS, XT, IPW> G;
   constexpr int P = G::P, NT = G::NT, NCH = G::NCH, NPC = G::NPC, NO = KYO_NO;
   constexpr bool ODD = (CIN & 1) != 0;            // 2-byte aligned operand windows: 20 bytes from the aligned address below + a funnel shift
+#ifdef K16_CLOCK_PROBE
+  const unsigned long long pe0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const ConvArgs& a = batch.a[blockIdx.y];
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   unsigned char* wl = lds_raw;                                    // weight image
@@ -88,29 +91,50 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     constexpr int NW = (NV + CONV_THREADS - 1) / CONV_THREADS;
     float wv[NW];
     float vmax = 0.f;
+    // branch-free: every load of the build is in flight before the first use (divergent branches around the ones-channel
+    // sums serialised their round trips: 8.5 us of the kernel; in-kernel probe)
+    float* onesw = reinterpret_cast<float*>(ebuf);    // [KS][KS][NO] scratch (the pool-pair buffers are not in use yet)
 #pragma unroll
     for (int n = 0; n < NW; ++n) {
       const int i = tid + n * CONV_THREADS;
       const int o = i % NO, r = i / NO;
       const int k = r % (NCH * 32), ky = r / (NCH * 32);
-      float v = 0.f;
-      if (i < NV && o < nout) {
-        if (k < G::KROW) {
-          v = a.w[(ky * G::KROW + k) * nout + o] * a.scale[k % CIN];
-        } else if (k < G::KAUG) {                     // ones channel: sum_c W t_c
-          const int kx = k - G::KROW;
-          float s = 0.f;
-          for (int c = 0; c < CIN; ++c) s += a.w[(ky * G::KROW + kx * CIN + c) * nout + o] * a.shift[c];
-          v = s;
-        }
-        if (a.wscale != 0.f) v *= a.wscale;
-      }
+      const bool real = i < NV && o < nout && k < G::KROW;
+      const float w = a.w[real ? (ky * G::KROW + k) * nout + o : 0], sck = a.scale[real ? k % CIN : 0];
+      wv[n] = real ? w * sck : 0.f;
+    }
+    {
+      const int o = tid % NO, kk = tid / NO;           // kk = ky * KS + kx
+      const bool act = tid < KS * KS * NO && o < nout;
+      float wq[CIN], sh[CIN];
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) { wq[c] = a.w[act ? (kk * CIN + c) * nout + o : 0]; sh[c] = a.shift[c]; }
+      float sacc = 0.f;
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) sacc += wq[c] * sh[c];
+      if (tid < KS * KS * NO) onesw[tid] = act ? sacc : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NW; ++n) {
+      const int i = tid + n * CONV_THREADS;
+      const int o = i % NO, r = i / NO;
+      const int k = r % (NCH * 32), ky = r / (NCH * 32);
+      float v = wv[n];
+      if (i < NV && k >= G::KROW && k < G::KAUG) v = onesw[(ky * KS + (k - G::KROW)) * NO + o];      // ones channel: sum_c W t_c
+      if (a.wscale != 0.f) v *= a.wscale;
       wv[n] = v;
       vmax = fmaxf(vmax, fabsf(v));
     }
+#ifdef K16_CLOCK_PROBE
+    const unsigned long long pq0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
     if (lane == 0) red[wave] = vmax;
     __syncthreads();
+#ifdef K16_CLOCK_PROBE
+    if (tid == 0 && (blockIdx.x % 97) == 5 && blockIdx.y == 1) printf("K16PRE loads+max %llu, to sync %llu\n", pq0 - pe0, __builtin_amdgcn_s_memrealtime() - pe0);
+#endif
     vmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     int S = 0;
     if (vmax > 0.f && vmax < 3.0e38f) S = 14 - ilogbf(vmax);       // vmax 2^S in [2^14, 2^15)
@@ -137,6 +161,9 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     }
   }
   __syncthreads();                                   // weight image visible; no barrier after this one
+#ifdef K16_CLOCK_PROBE
+  const unsigned long long pe1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   const int swave = __builtin_amdgcn_readfirstlane(wave);
   const int simg = swave / G::STRIPS, sstrip = swave % G::STRIPS;
@@ -389,8 +416,8 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #ifdef K16_CLOCK_PROBE
   if (lane == 0 && (blockIdx.x % 97) == 5 && blockIdx.y == 1 && wave == 0) {
     const unsigned long long pc1 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
-    printf("K16CLK block %d: %llu core cycles, %llu ref ticks (100 MHz) in the row loop -> %.3f GHz\n", (int)blockIdx.x, pc1 - pc0, pr1 - pr0,
-           (double)(pc1 - pc0) / (10.0 * (double)(pr1 - pr0)));
+    printf("K16CLK block %d: %llu core cycles, %llu ref ticks (100 MHz) in the row loop -> %.3f GHz; weight image %llu ticks, setup to loop %llu ticks\n", (int)blockIdx.x, pc1 - pc0, pr1 - pr0,
+           (double)(pc1 - pc0) / (10.0 * (double)(pr1 - pr0)), pe1 - pe0, pr0 - pe1);
   }
 #endif
 }
