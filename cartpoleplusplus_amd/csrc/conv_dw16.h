@@ -177,8 +177,8 @@ __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 
 #pragma unroll
     for (int pc = 0; pc < NPC; ++pc) cpc[c][pc] = 0;
   }
-  float rpv[2][NCELL], rdv[2][NCELL];
-  int rcd[2][NCELL];
+  float rpv[3][NCELL], rdv[3][NCELL];             // (set 2: only the unit prologue, so that its three requests are in flight together)
+  int rcd[3][NCELL];
   auto dy_issue = [&](const __amdgpu_buffer_rsrc_t& rp, const __amdgpu_buffer_rsrc_t& rd,
                       const __amdgpu_buffer_rsrc_t& rc, int py, int set) {
     const bool rowok = py >= 0 && py < Hp;           // uniform
@@ -305,16 +305,16 @@ __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 
     if (0 < rows) in_load(in_rs, q_lo);
     dy_issue(rp, rd, rc, y0 >> 1, 0);
     dy_issue(rp, rd, rc, (y0 >> 1) + 1, 1);
+    dy_issue(rp, rd, rc, (y0 >> 1) + 2, 2);
     if (0 < rows) in_store(P % G::RING_IN);
     if (1 < rows) in_load(in_rs, q_lo + 1);
     dy_conv(0, in_band(y0));
     dy_store(0, 0); dy_store(1, 1);
-    dy_issue(rp, rd, rc, (y0 >> 1) + 2, 0);
     dy_conv(1, in_band(y0 + 2));
     dy_store(2, 0); dy_store(3, 1);
     if (1 < rows) in_store((P + 1) % G::RING_IN);
     if (2 < rows) in_load(in_rs, q_lo + 2);
-    dy_conv(0, in_band(y0 + 4));
+    dy_conv(2, in_band(y0 + 4));
     dy_store(4, 0);                                   // position 5 (same cells) is stored by the first step
     }
     __syncthreads();
