@@ -45,7 +45,7 @@ struct Dw16Geom {
   static constexpr int NVIN = (CIN % 2 ? WPAD * CIN : WPAD * CIN / 2) / CONV_THREADS + 1;   // dwords (odd CIN: halves) of an input row per thread
   static constexpr int IN_BYTES = RING_IN * ROWB, DY_BYTES = RING_DY * DSLOT;
   static constexpr int LDS_BYTES = ((IN_BYTES + 15) & ~15) + DY_BYTES + 64;       // (the epilogue scratch reuses the dY ring)
-  static_assert(DY_BYTES >= CONV_THREADS * NCELL * 4 + 4 * KS * 16 * 4, "epilogue scratch fits the dY ring");
+  static_assert(DY_BYTES >= CONV_THREADS * NCELL * 4 + 4 * KS * 16 * 4 + 2 * CIN * 4, "epilogue scratch fits the dY ring");
 };
 
 #ifndef DW16_WGS
@@ -58,6 +58,10 @@ __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 
   constexpr int P = G::P, NO = G::NO, MT = G::MT, CP = G::CP, NPC = G::NPC, ROWB = G::ROWB, DSLOT = G::DSLOT;
   static_assert((KS * NO + 15) / 16 == 4, "one column tile per wave");
   constexpr bool ODD = (CIN & 1) != 0;               // pixels are only 2-byte aligned in memory: rows are staged half by half
+#ifdef DW16_CLOCK
+  const unsigned long long ce0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long cpro = 0, cloop = 0;
+#endif
   const ConvArgs& a = batch.a[blockIdx.y];
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   unsigned char* inring = lds_raw;                                         // [3][ROWB]
@@ -277,8 +281,14 @@ __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 
   for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   __syncthreads();
+#ifdef DW16_CLOCK
+  const unsigned long long ce1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   for (int unit = blockIdx.x; unit < units; unit += gridDim.x) {
+#ifdef DW16_CLOCK
+    const unsigned long long cu0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int b = unit / units_per_img;
     const int q_lo = (unit - b * units_per_img) * band;
     const int rows = min(band, H - q_lo);            // band and q_lo are even
@@ -318,6 +328,9 @@ __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 
     dy_store(4, 0);                                   // position 5 (same cells) is stored by the first step
     }
     __syncthreads();
+#ifdef DW16_CLOCK
+    const unsigned long long cu1 = __builtin_amdgcn_s_memrealtime(); cpro += cu1 - cu0;
+#endif
 
     for (int t0 = 0; t0 < rows + P; t0 += G::UNROLL) {
 #pragma unroll
@@ -373,11 +386,19 @@ __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 
     }
   }
 
+#ifdef DW16_CLOCK
+  const unsigned long long ce2 = __builtin_amdgcn_s_memrealtime();
+#endif
   // ---- one partial per workgroup.  D tile mt holds rows m = 16 mt + 4 lj + r = CP kx + c', column n = (ky, o);
   // row c' = CIN of every kx is T: it goes through a wave-private LDS table, then dW = 2^-S (s_c G + t_c T)
   float* part = a.partial + (long)blockIdx.x * a.pstride;
   const int nw = KS * G::KROW * nout;
   float* tx = texch + wave * (KS * 16);
+  // whitening scale / shift through LDS: read per (tile, row) below (global loads there were a chain of L2 round trips:
+  // 8.4 us per workgroup, in-kernel probe)
+  float* wsc = dbs + CONV_THREADS * NCELL;           // [CIN] scale, [CIN] shift (behind the bias-gradient scratch)
+  if (tid < CIN) { wsc[tid] = a.scale[tid]; wsc[CIN + tid] = a.shift[tid]; }
+  __syncthreads();
 #pragma unroll
   for (int kx = 0; kx < KS; ++kx) {
     const int m = CP * kx + CIN;                      // compile-time
@@ -395,7 +416,7 @@ __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 
         const int kx = m / CP, c = m - kx * CP;
         if (kx < KS && c < CIN) {
           const float t = tx[kx * 16 + li];
-          part[(nky * G::KROW + kx * CIN + c) * nout + no] = inv * (a.scale[c] * acc[mt][r] + a.shift[c] * t);
+          part[(nky * G::KROW + kx * CIN + c) * nout + no] = inv * (wsc[c] * acc[mt][r] + wsc[CIN + c] * t);
         }
       }
     }
@@ -410,6 +431,9 @@ __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 
     for (int idx = tid; idx < Wp * nout; idx += nout) s += dbs[(idx / CONV_THREADS) * CONV_THREADS + (idx % CONV_THREADS)];
     part[nw + tid] = s;
   }
+#ifdef DW16_CLOCK
+  if (tid == 0 && (blockIdx.x % 211) == 7 && blockIdx.y == 0) printf("DW16CLK block %d: setup %llu, units (prologue %llu) %llu, epilogue %llu ticks\n", (int)blockIdx.x, ce1 - ce0, cpro, ce2 - ce1, __builtin_amdgcn_s_memrealtime() - ce2);
+#endif
 }
 
 template <int CIN, int KS, int NCHK, bool DENSE = false>
@@ -423,7 +447,10 @@ static inline int conv_dw16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int* 
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_done = true;
   }
-  const int capacity = ctx->num_cus * 4 / batch.n;   // == conv_dw_kyo_grid: the partial buffers are sized for it
+#ifndef DW16_CAP
+#define DW16_CAP 4
+#endif
+  const int capacity = ctx->num_cus * DW16_CAP / batch.n;   // <= conv_dw_kyo_grid: the partial buffers are sized for that
   int band = (a.H + 1) & ~1;
   while (a.B * ((a.H + band - 1) / band) < capacity && band > 8 && (band / 2) % 2 == 0) band /= 2;
   const int upi = (a.H + band - 1) / band;
