@@ -2,6 +2,7 @@
 #include "conv_dw_kyo.h"
 #include "conv_k16.h"
 #include "conv_dw16.h"
+#include "conv_dwb16.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -160,6 +161,10 @@ int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, co
     rc = conv_dw16_dispatch(ctx, cin, ks, in_mode, dense, batch, &grid, &handled);
     if (handled) kid = kid == K_CONV1_DW ? K_CONV1_DW_F16X3 : kid;
   }
+  // conv2 (f32 activations in): bf16 pipes, three exact pieces per operand (conv_dwb16.h); CPP_CONV_B16=0 keeps the f32 MFMA kernel
+  static const bool no_b16 = getenv("CPP_CONV_B16") != nullptr && atoi(getenv("CPP_CONV_B16")) == 0;
+  if (!handled && !no_kyo && !no_b16 && !dense && in_mode == IN_F32_PLAIN)
+    rc = conv_dwb16_dispatch(ctx, cin, ks, in_mode, batch, &grid, &handled);
   if (!handled)
     for (int i = 0; i < n; ++i)
       if (batch.a[i].img_slot) { cpp_set_error("conv dW: images addressed through replay slots need the f16-pipe conv1 kernel"); prof_end(ctx, kid); return 1; }
