@@ -75,6 +75,8 @@ struct ConvArgs {
   int tiles_x, tiles_y, ntiles;
   int vec_ok;                // input rows may be staged with aligned 16-byte loads
   int nbands, band_rows;     // conv_fwd_kyo_kernel: bands of output rows per image (0 / 1: whole images)
+  const unsigned short* in_b16; long plane_stride;   // conv_fwd_k16_kernel in B16 mode: the input as three bf16 planes (stride in bytes; in_bstride: halves per image)
+  unsigned short* out_b16; long out_b16_plane;   // conv_fwd_k16_kernel: also write the pooled output as three bf16 planes (plane stride in halves)
   const int32_t* img_slot;   // conv1 on the f16 pipes only: image b is row img_slot[b] of `in` (the replay store itself: no gathered copy)
 };
 
@@ -85,6 +87,8 @@ struct ConvArgsN { ConvArgs a[CONV_BATCH_MAX]; int n; };
 
 // true if conv1 forward (plain: batch norm) and dW (dense dY: batch norm) of this geometry run on conv_k16.h / conv_dw16.h
 bool conv1_f16_pipes_ok(int cin, int H, int W, int B, bool batch_norm);
+// true if conv1 forward runs on conv_k16.h (and can leave bf16 planes of its output) and conv2 forward has a B16 instance
+bool conv12_b16_ok(int cin, int H, int W, int B);
 int launch_conv_fwd(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi, ConvArgs a);
 int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi, const ConvArgs* list, int n);
 int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, const ConvArgs* list, int n,

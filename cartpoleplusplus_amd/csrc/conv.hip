@@ -49,6 +49,20 @@ bool conv1_f16_pipes_ok(int cin, int H, int W, int B, bool batch_norm) {
   return f && d;
 }
 
+bool conv12_b16_ok(int cin, int H, int W, int B) {
+  static const bool off = (getenv("CPP_CONV_K16") != nullptr && atoi(getenv("CPP_CONV_K16")) == 0) ||
+                          (getenv("CPP_CONV_KYO") != nullptr && atoi(getenv("CPP_CONV_KYO")) == 0) ||
+                          (getenv("CPP_CONV_B16") != nullptr && atoi(getenv("CPP_CONV_B16")) == 0);
+  if (off || B < 2 || H < 4 || (H & 1) || (W & 1)) return false;
+  ConvArgsN q; memset(&q, 0, sizeof(q));
+  q.n = 1; q.a[0].H = H; q.a[0].W = W; q.a[0].B = B; q.a[0].nout = KYO_NO; q.a[0].in_bstride = (long)H * W * cin;
+  bool f1 = false, f2 = false;
+  (void)conv_fwd_k16_dispatch(nullptr, cin, 5, IN_F16_WHITEN, false, q, &f1);            // (dry runs)
+  q.a[0].H = H / 2; q.a[0].W = W / 2; q.a[0].in_bstride = (long)(H / 2) * (W / 2) * KYO_NO;
+  (void)conv_fwd_kb16_dispatch(nullptr, KYO_NO, 5, IN_F32_PLAIN, q, &f2);
+  return f1 && f2;
+}
+
 int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi, const ConvArgs* list, int n) {
   if (n < 1 || n > CONV_BATCH_MAX) { cpp_set_error("conv: batch of %d networks", n); return 1; }
   const int xtw = pick_xtw(in_mode, list[0].W);
@@ -91,6 +105,11 @@ int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, i
   }
   for (int i = 0; i < n; ++i)
     if (batch.a[i].img_slot) { cpp_set_error("conv forward: images addressed through replay slots need the f16-pipe conv1 kernel"); prof_end(ctx, kid); return 1; }
+  if (!no_kyo && in_mode == IN_F32_PLAIN && !dx_mode && !plain_fwd && a.in_b16 != nullptr) {      // conv2 from conv1's bf16 planes
+    bool handled = false;
+    rc = conv_fwd_kb16_dispatch(ctx, cin, ks, in_mode, batch, &handled);
+    if (handled) { prof_end(ctx, kid); return rc; }
+  }
   if (kyo) {
     // few workgroups (the dX passes carry two networks: one wave per SIMD): split the images into two bands of rows
     // (CPP_CONV_BANDS=0: whole images)

@@ -8,7 +8,7 @@
 int conv_fwd_k16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool plain, const ConvArgsN& a, bool* handled) {
   *handled = false;
   const int W = a.a[0].W;
-  if (ks != 5 || in_mode != IN_F16_WHITEN || W > 128 || (W & 1)) return 0;
+  if (ks != 5 || in_mode != IN_F16_WHITEN || W > 128 || (W & 1) || (a.a[0].nout & 1)) return 0;
   for (int i = 0; i < a.n; ++i) {
     if (a.a[i].white_bstride != 0) return 0;          // per-image statistics would need per-image weights (f32 kernel)
     if (((uintptr_t)a.a[i].in & 3) || (a.a[i].in_bstride & 1)) return 0;      // 4-byte aligned operand loads
@@ -19,5 +19,21 @@ int conv_fwd_k16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool plain
   K16_CASE(6, 1, 4, false) K16_CASE(6, 2, 4, false) K16_CASE(6, 2, 2, false)
   K16_CASE(12, 2, 2, false) K16_CASE(30, 2, 1, false)
   K16_CASE(9, 2, 2, false) K16_CASE(9, 1, 4, false) K16_CASE(9, 2, 4, false) K16_CASE(9, 2, 1, false) K16_CASE(3, 2, 2, false) K16_CASE(3, 1, 4, false)
+  return 0;
+}
+
+#define KB16_CASE(XT_, IPW_)                                                                                 \
+  if (xt == XT_ && ipw == IPW_) { *handled = true; if (!ctx) return 0;                                       \
+    return conv_fwd_k16_launch_t<10, 5, XT_, IPW_, false, true>(ctx, a); }
+
+int conv_fwd_kb16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArgsN& a, bool* handled) {
+  *handled = false;
+  const int W = a.a[0].W;
+  if (cin != 10 || ks != 5 || in_mode != IN_F32_PLAIN || W > 64 || (W & 1) || a.a[0].nout != KYO_NO) return 0;      // (nout even)
+  for (int i = 0; i < a.n; ++i)
+    if (ctx && (a.a[i].in_b16 == nullptr || a.a[i].plane_stride == 0 || (a.a[i].in_bstride & 1))) return 0;
+  const int xt = W > 32 ? 2 : 1;
+  const int ipw = W > 32 ? 2 : (W > 16 ? 2 : 4);
+  KB16_CASE(1, 2) KB16_CASE(1, 4) KB16_CASE(2, 2)
   return 0;
 }

@@ -31,16 +31,34 @@
 #include "conv_kyo.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 k16_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned k16_u32x4 __attribute__((ext_vector_type(4)));
 
-template <int CIN, int KS, int XT, int IPW>
+// ---- B16 mode (conv2: f32 activations in).  An f32 is exactly the sum of three bf16 numbers (8 + 8 + 8 significand bits, f32's
+// exponent range: no scaling); the previous layer's epilogue writes its pooled output as three bf16 planes next to the
+// f32 tensor, this kernel loads the planes like conv1 loads pixels, the weights are split the same way and all 3 x 3 exact
+// products are issued (nine 16-cycle MFMAs instead of eight 32-cycle ones per 32 k values; no ones channel, no whitening).
+__device__ __forceinline__ unsigned k16_bf16_bits(float x) {        // round-to-nearest-even bf16 of a finite f32
+  const unsigned u = __float_as_uint(x);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void k16_split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {   // x = h + m + l exactly
+  const unsigned hb = k16_bf16_bits(x);
+  const float r1 = x - __uint_as_float(hb << 16);
+  const unsigned mb = k16_bf16_bits(r1);
+  const float r2 = r1 - __uint_as_float(mb << 16);
+  h = (unsigned short)hb; m = (unsigned short)mb; l = (unsigned short)(__float_as_uint(r2) >> 16);     // r2 has <= 8 significant bits
+}
+
+template <int CIN, int KS, int XT, int IPW, bool B16 = false>
 struct K16Geom {
   static constexpr int NO = KYO_NO;
   static constexpr int P = KS / 2;
   static constexpr int NT = (KS * NO + 15) / 16;
   static constexpr int STRIPS = 4 / IPW, SW = 16 * XT, WPAD = STRIPS * SW;
   static constexpr int KROW = KS * CIN;                    // real k = (kx, c) of one input row
-  static constexpr int KAUG = KROW + KS;                   // + the ones channel (kx)
+  static constexpr int KAUG = B16 ? KROW : KROW + KS;      // + the ones channel (kx)
+  static constexpr int NPA = B16 ? 3 : 1;                  // planes of the A operand
   static constexpr int NCH = (KAUG + 31) / 32;             // MFMA k chunks per row
   static constexpr int NPC = 3;                            // f16 pieces of a weight
   // weight image in LDS: slab (chunk, piece) holds the 16-byte operand (ky, lane group g, o) at ky*PS + g*GS + o*16;
@@ -65,10 +83,10 @@ struct K16Geom {
 #ifndef K16_WGS
 #define K16_WGS 2
 #endif
-template <int CIN, int KS, int XT, int IPW, bool PLAIN = false>
+template <int CIN, int KS, int XT, int IPW, bool PLAIN = false, bool B16 = false>
 __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(const ConvArgsN batch) {
-  typedef K16Geom<CIN, KS, XT, IPW> G;
-  constexpr int P = G::P, NT = G::NT, NCH = G::NCH, NPC = G::NPC, NO = KYO_NO;
+  typedef K16Geom<CIN, KS, XT, IPW, B16> G;
+  constexpr int P = G::P, NT = G::NT, NCH = G::NCH, NPC = G::NPC, NPA = G::NPA, NO = KYO_NO;
   constexpr bool ODD = (CIN & 1) != 0;            // 2-byte aligned operand windows: 20 bytes from the aligned address below + a funnel shift
 #ifdef K16_CLOCK_PROBE
   const unsigned long long pe0 = __builtin_amdgcn_s_memrealtime();
@@ -100,10 +118,10 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
       const int o = i % NO, r = i / NO;
       const int k = r % (NCH * 32), ky = r / (NCH * 32);
       const bool real = i < NV && o < nout && k < G::KROW;
-      const float w = a.w[real ? (ky * G::KROW + k) * nout + o : 0], sck = a.scale[real ? k % CIN : 0];
+      const float w = a.w[real ? (ky * G::KROW + k) * nout + o : 0], sck = B16 ? 1.f : a.scale[real ? k % CIN : 0];
       wv[n] = real ? w * sck : 0.f;
     }
-    {
+    if (!B16) {
       const int o = tid % NO, kk = tid / NO;           // kk = ky * KS + kx
       const bool act = tid < KS * KS * NO && o < nout;
       float wq[CIN], sh[CIN];
@@ -137,7 +155,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #endif
     vmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     int S = 0;
-    if (vmax > 0.f && vmax < 3.0e38f) S = 14 - ilogbf(vmax);       // vmax 2^S in [2^14, 2^15)
+    if (!B16 && vmax > 0.f && vmax < 3.0e38f) S = 14 - ilogbf(vmax);       // vmax 2^S in [2^14, 2^15); bf16 pieces need no scale
     S = S > 100 ? 100 : (S < -100 ? -100 : S);
     sc = ldexpf(1.f, S); inv = ldexpf(1.f, -S);
 #pragma unroll
@@ -148,15 +166,20 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
         const int k = r % (NCH * 32), ky = r / (NCH * 32);
         const int ch = k >> 5, g = (k >> 3) & 3, e = k & 7;
         const float v = wv[n] * sc;
-        const _Float16 h = (_Float16)v;
-        const float r1 = v - (float)h;
-        const _Float16 m = (_Float16)r1;
-        const float r2 = r1 - (float)m;
-        const _Float16 l = (_Float16)r2;
+        unsigned short h, m, l;
+        if (B16) k16_split3(v, h, m, l);
+        else {
+          const _Float16 hh = (_Float16)v;
+          const float r1 = v - (float)hh;
+          const _Float16 mm = (_Float16)r1;
+          const float r2 = r1 - (float)mm;
+          const _Float16 ll = (_Float16)r2;
+          h = __builtin_bit_cast(unsigned short, hh); m = __builtin_bit_cast(unsigned short, mm); l = __builtin_bit_cast(unsigned short, ll);
+        }
         unsigned char* dst = wl + ky * G::PS + g * G::GS + o * 16 + e * 2;
-        *reinterpret_cast<_Float16*>(dst + (ch * NPC + 0) * G::SLAB) = h;
-        *reinterpret_cast<_Float16*>(dst + (ch * NPC + 1) * G::SLAB) = m;
-        *reinterpret_cast<_Float16*>(dst + (ch * NPC + 2) * G::SLAB) = l;
+        *reinterpret_cast<unsigned short*>(dst + (ch * NPC + 0) * G::SLAB) = h;
+        *reinterpret_cast<unsigned short*>(dst + (ch * NPC + 1) * G::SLAB) = m;
+        *reinterpret_cast<unsigned short*>(dst + (ch * NPC + 2) * G::SLAB) = l;
       }
     }
   }
@@ -226,20 +249,25 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
       }
     }
 
-  // ---- pooled-row writer (as conv_kyo.h)
-  constexpr int NC = (8 * XT * NO + 63) / 64;
+  // ---- pooled-row writer: a lane owns PAIRS (o, o+1) of the wave's 8*XT pooled columns (nout is even: dispatch) -- one
+  // 8-byte value store, one 2-byte code store and three 4-byte bf16-plane stores per pair
+  constexpr int NC = (8 * XT * (NO / 2) + 63) / 64;
   uint32_t cadr[NC];
   bool cact[NC];
   unsigned coe[NC];
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     const int idx = lane + 64 * i;
-    const int xl = idx / nout, o = idx - xl * nout;
+    const int hn = nout >> 1;
+    const int xl = idx / hn, o = 2 * (idx - xl * hn);
     const int px = ((sstrip * G::SW) >> 1) + xl;
-    cact[i] = idx < 8 * XT * nout && px < Wp;
+    cact[i] = idx < 8 * XT * hn && px < Wp;
     cadr[i] = keep_in_vgpr(lds_addr(ev + (cact[i] ? xl * NO + o : 0)));
     coe[i] = (unsigned)(px * nout + o);
   }
+  const __amdgpu_buffer_rsrc_t b16_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      a.out_b16 ? a.out_b16 + (long)sbimg * (Hp * Wp * nout) : (unsigned short*)a.out, 0, a.out_b16 ? 0x7FFFFFF0 : 0, 0x00020000);
+  const int b16_plane_bytes = (int)(a.out_b16_plane * 2);
   const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       a.out + (long)sbimg * a.out_bstride, 0, (PLAIN ? H * W : Hp * Wp) * nout * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t amax_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -248,21 +276,25 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   // ---- A operands: 16 bytes per lane and (tile, chunk) straight from the image row
   const int rowbytes = W * CIN * 2;
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)((const char*)a.in + ((long)(a.img_slot ? a.img_slot[sbimg] : sbimg) * a.in_bstride) * 2 - G::BIAS_BYTES), 0, H * rowbytes + G::BIAS_BYTES + 256, 0x00020000);
+      (void*)((const char*)(B16 ? (const void*)a.in_b16 : a.in) + ((long)(a.img_slot ? a.img_slot[sbimg] : sbimg) * a.in_bstride) * 2 - G::BIAS_BYTES), 0, B16 ? 0x7FFFFFF0 : H * rowbytes + G::BIAS_BYTES + 256, 0x00020000);
   const int avoff0 = G::BIAS_BYTES + ((strip * G::SW + li - P) * CIN + 8 * lj) * 2;     // >= 128 - 2 P CIN
   const int avoff = ODD ? (avoff0 & ~3) : avoff0;
   const unsigned ashift = ODD ? (unsigned)(avoff0 & 2) : 0u;    // per-lane constant: 16 * m * CIN pixels further keeps the parity
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  k16_u32x4 av[NCH][XT];
+  k16_u32x4 av[NPA][NCH][XT];
   unsigned ax[NCH][XT];                               // ODD: the fifth dword of the window
+  const int plane_bytes = B16 ? (int)a.plane_stride : 0;      // bytes between the bf16 planes of the input
   auto load_a = [&](int ch, int y) {
 #pragma unroll
     for (int m = 0; m < XT; ++m) {
 #ifdef K16_ABL_NOLDSA
-      av[ch][m] = (k16_u32x4){amask[NCH - 1][1], acst[NCH - 1][0][1], amask[NCH - 1][2], (unsigned)y};
+      av[0][ch][m] = (k16_u32x4){amask[NCH - 1][1], acst[NCH - 1][0][1], amask[NCH - 1][2], (unsigned)y};
 #else
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, avoff + (m * 16 * CIN + 32 * ch) * 2, y * rowbytes, 0);
-      av[ch][m] = (k16_u32x4){v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int pa = 0; pa < NPA; ++pa) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, avoff + (m * 16 * CIN + 32 * ch) * 2, pa * plane_bytes + y * rowbytes, 0);
+        av[pa][ch][m] = (k16_u32x4){v.x, v.y, v.z, v.w};
+      }
       if (ODD) ax[ch][m] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, avoff + (m * 16 * CIN + 32 * ch) * 2 + 16, y * rowbytes, 0);
 #endif
     }
@@ -310,10 +342,12 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #ifdef K16_PRIO
           __builtin_amdgcn_s_setprio(K16_PRIO);
 #endif
-          k16_u32x4 af[XT];
+          k16_u32x4 af[NPA][XT];
+#pragma unroll
+          for (int pa = 0; pa < NPA; ++pa)
 #pragma unroll
           for (int m = 0; m < XT; ++m) {
-            k16_u32x4 u = av[ch][m];
+            k16_u32x4 u = av[pa][ch][m];
             if (ODD) {
 #ifndef K16_ABL_NOLDSA
               const unsigned x4 = ax[ch][m];
@@ -329,8 +363,10 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
               for (int v = 0; v < 4; ++v)
                 if (G::vgpr_may_be_synthetic(ch, v)) u[v] = (u[v] & amask[ch][v]) | acst[ch][m][v];
             }
-            af[m] = u;
+            af[pa][m] = u;
           }
+#pragma unroll
+          for (int pa = NPA - 1; pa >= 0; --pa)
 #ifdef K16_ABL_1PC
           for (int pc = 0; pc >= 0; --pc)
 #else
@@ -340,8 +376,11 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #pragma unroll
             for (int m = 0; m < XT; ++m)
 #pragma unroll
-              for (int t = 0; t < NT; ++t)
-                acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[m]), bv[ch & 1][t][pc], acc[m][t], 0, 0, 0);
+              for (int t = 0; t < NT; ++t) {
+                if (B16) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(k16_bf16x8, af[pa][m]),
+                                                                            __builtin_bit_cast(k16_bf16x8, bv[ch & 1][t][pc]), acc[m][t], 0, 0, 0);
+                else acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[pa][m]), bv[ch & 1][t][pc], acc[m][t], 0, 0, 0);
+              }
 #ifdef K16_PRIO
           __builtin_amdgcn_s_setprio(0);
 #endif
@@ -401,12 +440,25 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
           if (cact[i]) {
-            const f32x2 top = lds_load<f32x2>(cadr[i], 0), bot = lds_load<f32x2>(cadr[i], (8 * XT * NO) * 8);
-            const bool lower = bot.x > top.x;
-            const float mx = lower ? bot.x : top.x;
-            const int code = lower ? 2 + __float_as_int(bot.y) : __float_as_int(top.y);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mx > 0.f ? mx * inv : 0.f), out_rsrc, (int)(coe[i] * 4), orow * 4, 0);
-            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)code, amax_rsrc, (int)coe[i], orow, 0);
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const f32x4 top = lds_load<f32x4>(cadr[i], 0), bot = lds_load<f32x4>(cadr[i], (8 * XT * NO) * 8);   // (value, code) x 2
+            float pv[2]; int code[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const bool lower = bot[2 * e] > top[2 * e];
+              const float mx = lower ? bot[2 * e] : top[2 * e];
+              code[e] = lower ? 2 + __float_as_int(bot[2 * e + 1]) : __float_as_int(top[2 * e + 1]);
+              pv[e] = mx > 0.f ? mx * inv : 0.f;
+            }
+            __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(pv[0]), __float_as_uint(pv[1])}, out_rsrc, (int)(coe[i] * 4), orow * 4, 0);
+            if (a.out_b16) {                         // the next layer's A operand: three bf16 planes of the same tensor
+              unsigned short h0, m0, l0, h1, m1, l1;
+              k16_split3(pv[0], h0, m0, l0); k16_split3(pv[1], h1, m1, l1);
+              __builtin_amdgcn_raw_buffer_store_b32((unsigned)h0 | ((unsigned)h1 << 16), b16_rsrc, (int)(coe[i] * 2), orow * 2, 0);
+              __builtin_amdgcn_raw_buffer_store_b32((unsigned)m0 | ((unsigned)m1 << 16), b16_rsrc, (int)(coe[i] * 2), b16_plane_bytes + orow * 2, 0);
+              __builtin_amdgcn_raw_buffer_store_b32((unsigned)l0 | ((unsigned)l1 << 16), b16_rsrc, (int)(coe[i] * 2), 2 * b16_plane_bytes + orow * 2, 0);
+            }
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(code[0] | (code[1] << 8)), amax_rsrc, (int)coe[i], orow, 0);
           }
         }
         __builtin_amdgcn_wave_barrier();
@@ -422,12 +474,12 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #endif
 }
 
-template <int CIN, int KS, int XT, int IPW, bool PLAIN = false>
+template <int CIN, int KS, int XT, int IPW, bool PLAIN = false, bool B16 = false>
 static inline int conv_fwd_k16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
-  typedef K16Geom<CIN, KS, XT, IPW> G;
+  typedef K16Geom<CIN, KS, XT, IPW, B16> G;
   const ConvArgs& a = batch.a[0];
   const size_t lds_bytes = (size_t)G::LDS_BYTES;
-  auto kern = conv_fwd_k16_kernel<CIN, KS, XT, IPW, PLAIN>;
+  auto kern = conv_fwd_k16_kernel<CIN, KS, XT, IPW, PLAIN, B16>;
   static bool attr_done = false;
   if (!attr_done) {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -441,3 +493,5 @@ static inline int conv_fwd_k16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
 
 // conv1 of f16 image batches with one whitening table for the batch (white_bstride == 0), even CIN and W, 5x5
 int conv_fwd_k16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool plain, const ConvArgsN& a, bool* handled);
+// conv2 forward from the bf16 planes conv1 left (a.in_b16): 10 channels, 5x5, even W <= 64
+int conv_fwd_kb16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArgsN& a, bool* handled);

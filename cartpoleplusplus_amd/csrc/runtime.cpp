@@ -161,6 +161,7 @@ struct VarInfo { std::string name; int rank; int shape[4]; long offset; };
 
 struct Workspace {
   float* pool[3] = {nullptr, nullptr, nullptr};
+  unsigned short* pool_b16 = nullptr;      // pool[0] once more as three bf16 planes (conv2 forward on the bf16 pipes)
   uint8_t* amax[3] = {nullptr, nullptr, nullptr};
   float* dpool[3] = {nullptr, nullptr, nullptr};
   // batch norm (training mode): plain conv output (overwritten by its gradient in the backward pass), (inv, -mean*inv)
@@ -176,6 +177,7 @@ struct cpp_net {
   long nparams; int flat; int cat_layer; long state_elems;
   float* params; float* grads; float* own_grads;
   Workspace ws[2];
+  bool use_b16;             // this forward: conv1 (f16 pipes) leaves bf16 planes of pool1, conv2 forward reads them
   const int32_t* img_slot;  // conv1 reads image b from row img_slot[b] of the state pointer (the replay store); nullptr: b
   float* white;            // [2][C] statistics for cpp_net_forward
   float* white_rows;       // [maxB][2][C]: per-image statistics for cpp_net_forward_each
@@ -263,6 +265,7 @@ static int ws_alloc(cpp_net* n, Workspace& w, int from_layer, bool trunk) {
       const ConvL& L = n->conv[i];
       const size_t pe = (size_t)mb * L.Hp * L.Wp * kConvOut;
       if (i < 2) RC(dalloc(n->arena, &w.pool[i], pe)); else w.pool[i] = w.fcin[0];
+      if (i == 0 && !n->spec.use_batch_norm) RC(dalloc(n->arena, &w.pool_b16, 3 * pe));
       RC(dalloc(n->arena, &w.amax[i], pe));
       RC(dalloc(n->arena, &w.dpool[i], pe));
       if (n->spec.use_batch_norm) {
@@ -291,7 +294,7 @@ extern "C" int cpp_net_create(cpp_ctx* ctx, const cpp_net_spec* spec, int max_ba
   n->ctx = ctx; n->spec = *spec; n->maxB = max_batch; n->arena.stream = ctx->stream;
   n->grads = nullptr; n->own_grads = nullptr; n->stage_state = nullptr; n->stage_action = nullptr;
   n->stage_out = nullptr; n->dw_partial[0] = n->dw_partial[1] = n->dw_partial[2] = nullptr; n->white = nullptr; n->white_rows = nullptr; n->stats_part = nullptr;
-  n->img_slot = nullptr;
+  n->img_slot = nullptr; n->use_b16 = false;
   n->is_training = true; n->drop_counter = nullptr; n->bn_part = nullptr; n->bn_means = nullptr; n->bn_scratch = nullptr;
   int rc = net_build(n);
   if (rc) { delete n; return rc; }
@@ -403,6 +406,11 @@ static ConvArgs conv_fwd_args(cpp_net* n, Workspace& w, int i, const void* state
   a.out = w.pool[i]; a.out_bstride = (i == 2) ? (long)n->flat + 1 : (long)L.Hp * L.Wp * kConvOut;
   a.out_amax = w.amax[i];
   a.B = B; a.H = L.H; a.W = L.W; a.nout = kConvOut;
+  if (n->use_b16 && w.pool_b16) {
+    const long plane = (long)n->maxB * n->conv[0].Hp * n->conv[0].Wp * kConvOut;      // halves per plane
+    if (i == 0) { a.out_b16 = w.pool_b16; a.out_b16_plane = plane; }
+    if (i == 1) { a.in_b16 = w.pool_b16; a.plane_stride = plane * 2; }
+  }
   return a;
 }
 static void conv_dy_desc(cpp_net* n, Workspace& w, int i, ConvArgs& a, int B) {
@@ -454,9 +462,16 @@ static BnBatch bn_batch(cpp_net* const* nets, int nn, int i, int B) {
 }
 
 // conv trunk (pixel) or state conversion (low-dim) into ws.fcin[0]
+// conv1 on the f16 pipes can leave bf16 planes of pool1 for a conv2 forward on the bf16 pipes (same launch sequence only)
+static bool trunk_b16(const cpp_net* n, int dtype, int B, long white_bstride) {
+  return n->spec.pixel && !n->spec.use_batch_norm && dtype == CPP_F16 && white_bstride == 0 &&
+         conv12_b16_ok(n->conv[0].Cin, n->conv[0].H, n->conv[0].W, B);
+}
+
 static int net_forward_trunk(cpp_net* n, Workspace& w, const void* state, int dtype, const float* white, int B,
                              long white_bstride = 0) {
   cpp_ctx* ctx = n->ctx;
+  n->use_b16 = trunk_b16(n, dtype, B, white_bstride);
   if (!n->spec.pixel)
     return launch_state_to_f32(ctx, w.fcin[0], n->fc[0].n_in + 1, state, dtype, n->state_elems, B);
   for (int i = 0; i < 3; ++i) {
@@ -1446,6 +1461,7 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b) {
     const void* sts[4] = {s1, s1, s2, s2};
     const float* whs[4] = {w1, w1, w2, w2};
     const int t1 = G.fn([=] {
+      for (int k = 0; k < 4; ++k) nets[k]->use_b16 = trunk_b16(nets[k], dt, B, 0);
       {
         ConvArgs cl[4]; int mode = 0;
         for (int k = 0; k < 4; ++k) cl[k] = conv_fwd_args(nets[k], nets[k]->ws[0], 0, sts[k], dt, whs[k], B, &mode);
@@ -1910,6 +1926,7 @@ static int naf_compute_gradients(cpp_naf* f, cpp_batch* b) {
   if (v->spec.pixel && !v->spec.use_batch_norm) {
     std::vector<cpp_net*> nets(tn, tn + nt); std::vector<const void*> sts(ts, ts + nt); std::vector<const float*> whs(tw, tw + nt);
     t1 = G.fn([=] {
+      for (int k = 0; k < nt; ++k) nets[k]->use_b16 = trunk_b16(nets[k], dt, B, 0);
       for (int i = 0; i < 3; ++i) {
         ConvArgs cl[CONV_BATCH_MAX]; int mode = 0;
         for (int k = 0; k < nt; ++k) cl[k] = conv_fwd_args(nets[k], nets[k]->ws[0], i, sts[k], dt, whs[k], B, &mode);
