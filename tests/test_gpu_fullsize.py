@@ -228,3 +228,46 @@ def test_f16x3_conv1_dw_is_as_close_to_the_f64_oracle_as_the_f32_mfma_kernel():
         errs[k16] = float(m["weights"])
     assert errs["1"] < 5e-6 and errs["0"] < 5e-6, errs
     assert errs["1"] <= 1.25 * errs["0"] + 1e-8, errs
+
+
+_CONV2_ERR_SNIPPET = r"""
+import numpy as np
+from oracle import ddpg_np as O
+from tests.helpers import make_pair, device_pool_codes, per_var_report
+SHAPE, B = (64, 64, 3, 2, 3), 16
+agent, ref, (aspec, cspec) = make_pair(SHAPE, B, True)
+class HB(object): pass
+hb = HB()
+t = O.synthetic_batch(np.random.default_rng(23), B, SHAPE, 2, True)       # f16 pixel states
+hb.state_1, hb.action, hb.reward, hb.terminal_mask, hb.state_2 = t
+agent.critic.train(hb)
+got = agent.critic.get_grads()
+pool2 = agent.critic.pool2.eval(B)
+ref.critic.amax_override = device_pool_codes(agent.critic, B)             # same pooling routes: rounding is all that is left
+cg = ref.critic_gradients(t)                                               # float64
+fw = ref.critic.forward(t[0], action=t[1])
+print("C2FWD %.3e %.3e" % (np.abs(pool2 - fw["conv2"][1]).max(), np.abs(fw["conv2"][1]).max()))
+for name, amax, rel in per_var_report(cspec, got, cg["grads"]):
+    if name.endswith("conv2/weights"):
+        print("C2DW %.3e" % rel)
+agent.close()
+"""
+
+
+def test_bf16_nine_product_conv2_is_as_close_to_the_f64_oracle_as_the_f32_mfma_kernels():
+    """conv2 forward / dW from three exact bf16 pieces per operand (conv_k16.h B16 mode, conv_dwb16.h) against
+    CPP_CONV_B16=0 (f32-input MFMA): pooled conv2 output and conv2 weight gradient vs the float64 oracle."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for b16 in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", _CONV2_ERR_SNIPPET], cwd=root, env=dict(os.environ, CPP_CONV_B16=b16),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        out = r.stdout.decode()
+        f, d = re.search(r"C2FWD (\S+) (\S+)", out), re.search(r"C2DW (\S+)", out)
+        assert r.returncode == 0 and f and d, out[-1500:]
+        res[b16] = (float(f.group(1)), float(f.group(2)), float(d.group(1)))
+    (f16e, mag, d16e), (f32e, _, d32e) = res["1"], res["0"]
+    assert f16e < 1e-5 * max(1.0, mag) and f32e < 1e-5 * max(1.0, mag), res
+    assert f16e <= 1.5 * f32e + 1e-7 * max(1.0, mag), res
+    assert d16e < 5e-6 and d32e < 5e-6 and d16e <= 1.5 * d32e + 1e-8, res
