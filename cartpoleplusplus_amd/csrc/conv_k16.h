@@ -452,11 +452,19 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
             }
             __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(pv[0]), __float_as_uint(pv[1])}, out_rsrc, (int)(coe[i] * 4), orow * 4, 0);
             if (a.out_b16) {                         // the next layer's A operand: three bf16 planes of the same tensor
-              unsigned short h0, m0, l0, h1, m1, l1;
-              k16_split3(pv[0], h0, m0, l0); k16_split3(pv[1], h1, m1, l1);
-              __builtin_amdgcn_raw_buffer_store_b32((unsigned)h0 | ((unsigned)h1 << 16), b16_rsrc, (int)(coe[i] * 2), orow * 2, 0);
-              __builtin_amdgcn_raw_buffer_store_b32((unsigned)m0 | ((unsigned)m1 << 16), b16_rsrc, (int)(coe[i] * 2), b16_plane_bytes + orow * 2, 0);
-              __builtin_amdgcn_raw_buffer_store_b32((unsigned)l0 | ((unsigned)l1 << 16), b16_rsrc, (int)(coe[i] * 2), 2 * b16_plane_bytes + orow * 2, 0);
+              // truncating split (cheaper than round-to-nearest in this MFMA-issue-bound loop, equally exact: the pieces are
+              // the value's three consecutive byte-groups of significand, x = h + m + l)
+              unsigned hb[2], mb[2], lb[2];
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                hb[e] = __float_as_uint(pv[e]) & 0xFFFF0000u;
+                const float r1 = pv[e] - __uint_as_float(hb[e]);
+                mb[e] = __float_as_uint(r1) & 0xFFFF0000u;
+                lb[e] = __float_as_uint(r1 - __uint_as_float(mb[e]));
+              }
+              __builtin_amdgcn_raw_buffer_store_b32((hb[0] >> 16) | hb[1], b16_rsrc, (int)(coe[i] * 2), orow * 2, 0);
+              __builtin_amdgcn_raw_buffer_store_b32((mb[0] >> 16) | mb[1], b16_rsrc, (int)(coe[i] * 2), b16_plane_bytes + orow * 2, 0);
+              __builtin_amdgcn_raw_buffer_store_b32((lb[0] >> 16) | (lb[1] & 0xFFFF0000u), b16_rsrc, (int)(coe[i] * 2), 2 * b16_plane_bytes + orow * 2, 0);
             }
             __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(code[0] | (code[1] << 8)), amax_rsrc, (int)coe[i], orow, 0);
           }
