@@ -19,6 +19,7 @@ enum KernelId {
   K_REPLAY_FILL, K_NAF_HEAD,
   K_CONV1_FWD_F16X3,      // conv1 forward on the f16 pipes with three-piece weights (conv_k16.h)
   K_CONV1_DW_F16X3,       // conv1 dW on the f16 pipes with three-piece dY (conv_dw16.h)
+  K_HEADS,                // fused DDPG heads (heads.hip)
   K_NUM_KERNELS
 };
 

@@ -223,6 +223,6 @@ int launch_ddpg_heads(cpp_ctx* ctx, const DdpgHeadsArgs& h) {
   prof_begin(ctx);
   hipLaunchKernelGGL(ddpg_heads_kernel, dim3((h.B + HEADS_ROWS - 1) / HEADS_ROWS), dim3(HEADS_THREADS), lds, ctx->stream, h);
   LAUNCH_CHECK();
-  prof_end(ctx, K_TD);
+  prof_end(ctx, K_HEADS);
   return 0;
 }
