@@ -229,6 +229,11 @@ struct DdpgHeadsArgs {
   float* h3_out; int ld_h3;                        // input buffer of the q layer
   float *q_out, *tq_out, *td, *dzq, *dz3, *dz2c;
   double* loss_part;                               // [DDPG_HEADS_MAX_WGS] per-workgroup sums of td^2
+  // optional: the actors' last hidden layer as well (n1a > 0): h2a = relu([h1a, 1] [W2; b2]) is computed here (and left in
+  // h2a_out for the head's dW), and dz of the layer below comes out in dz_h1a.  h2a / h2ta are then unused.
+  const float *h1a, *h1ta; int ld_h1a, n1a;        // B x (n1a + 1)
+  const float *W2, *W2_t;                          // [(n1a + 1)][n2a]
+  float *h2a_out, *dz_h1a;                         // B x ld_h2a (first n2a columns), B x n1a
 };
 #define DDPG_HEADS_MAX_WGS 256
 size_t ddpg_heads_lds_bytes(const DdpgHeadsArgs& h);

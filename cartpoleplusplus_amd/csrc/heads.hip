@@ -15,6 +15,8 @@
 
 constexpr int HEADS_THREADS = 256, HEADS_TEAM = 64, HEADS_ROWS = HEADS_THREADS / HEADS_TEAM, HEADS_AMAX = 8;
 constexpr int HEADS_NW4 = 5;                           // 16-byte chunks of [W3; b3] per thread: (n2c + A + 1) * n3 + slack <= 20 * 256
+constexpr int HEADS_NW4P = 5;                          // the same for [W2; b2] of the optional actor layer
+constexpr int HEADS_N1MAX = 2 * HEADS_TEAM;            // its inputs: two per lane
 constexpr int HEADS_N3P = HEADS_TEAM;                  // lane t of a team owns unit t of the concat layer (n3 <= 64)
 constexpr int HEADS_WSLACK = 64;                       // floats after [W3; b3] in LDS: units >= n3 read on into the next row
 typedef float heads_f4 __attribute__((ext_vector_type(4)));
@@ -42,10 +44,13 @@ __device__ __forceinline__ float team_sum(float v) {
   return v;
 }
 
+// AT: compile-time bound of the action loops; EXACT: A == AT (the loops then carry no branches that keep the compiler from
+// batching their LDS reads and interleaving the team sums)
+template <int AT, bool EXACT>
 __global__ __launch_bounds__(HEADS_THREADS) void ddpg_heads_kernel(const DdpgHeadsArgs h) {
   extern __shared__ __attribute__((aligned(16))) float hl[];
   constexpr int N3P = HEADS_N3P;
-  const int A = h.A, n2a = h.n2a, n2c = h.n2c, n3 = h.n3;
+  const int A = EXACT ? AT : h.A, n2a = h.n2a, n2c = h.n2c, n3 = h.n3;
   const int n2cp = (n2c + 3) & ~3;                     // x rows padded with zeros to float4s
   const int k3 = n2c + A + 1;                          // rows of [W3; b3]
   const int WS = n3;                                   // LDS row stride of [W3; b3] = the one in memory
@@ -53,8 +58,12 @@ __global__ __launch_bounds__(HEADS_THREADS) void ddpg_heads_kernel(const DdpgHea
   float* W3 = hl;                  float* W3t = W3 + wfl;
   float* wq = W3t + wfl;           float* wqt = wq + (N3P + 4);       // [0, N3P): weights (zero padded); N3P: the bias
   float* Wo = wqt + (N3P + 4);     float* Wot = Wo + (n2a + 1) * A;
-  float* rowbase = hl + ((2 * wfl + 2 * (N3P + 4) + 2 * (n2a + 1) * A + 3) & ~3);
-  const int rowf = N3P + 2 * n2cp + ((2 * n2a + 3) & ~3);  // per row: dz3 scratch, xc, xtc (16-byte aligned), xa, xta
+  const int n1a = h.n1a, n1ap = (n1a + 3) & ~3;
+  const int w2fl = n1a ? (((n1a + 1) * n2a + HEADS_WSLACK + 3) & ~3) : 0;
+  float* W2 = hl + ((2 * wfl + 2 * (N3P + 4) + 2 * (n2a + 1) * A + 3) & ~3); float* W2t = W2 + w2fl;
+  float* rowbase = W2t + w2fl;
+  const int rowf0 = N3P + 2 * n2cp + ((2 * n2a + 3) & ~3);  // per row: dz3 scratch, xc, xtc (16-byte aligned), xa, xta
+  const int rowf = rowf0 + (n1a ? HEADS_TEAM + 2 * n1ap : 0);   // ... dz2 scratch, x1a, x1ta
   const int tid = threadIdx.x, t = tid & (HEADS_TEAM - 1), team = tid / HEADS_TEAM;
 #ifdef HEADS_CLOCK
   unsigned long long ck[8]; int nck = 0;
@@ -63,7 +72,8 @@ __global__ __launch_bounds__(HEADS_THREADS) void ddpg_heads_kernel(const DdpgHea
 #define HCK()
 #endif
   HCK();
-  float* sc3 = rowbase + team * rowf; float* xc = sc3 + N3P; float* xtc = xc + n2cp; float* xa = xtc + n2cp; float* xta = xa + n2a;
+  float* sc3 = rowbase + team * rowf; float* xc = sc3 + N3P; float* xtc = xc + n2cp;
+  float* sc2 = sc3 + rowf0; float* x1 = sc2 + HEADS_TEAM; float* x1t = x1 + n1ap;
   const int row = blockIdx.x * HEADS_ROWS + team;
   const bool rv = row < h.B;
   // every global load of the kernel is issued here, before the first use (a round trip to another XCD's L2 is ~2 us:
@@ -80,13 +90,33 @@ __global__ __launch_bounds__(HEADS_THREADS) void ddpg_heads_kernel(const DdpgHea
       wtv[n] = __builtin_amdgcn_raw_buffer_load_b128(rwt, i * 16, 0, 0);
     }
   }
-  const float xav = (rv && t < n2a) ? h.h2a[(long)row * h.ld_h2a + t] : 0.f;          // n2a, n2c <= 64: one element per lane
-  const float xtav = (rv && t < n2a) ? h.h2ta[(long)row * h.ld_h2a + t] : 0.f;
+  heads_u4 w2v[HEADS_NW4P], w2tv[HEADS_NW4P];
+  float x1v[2] = {0.f, 0.f}, x1tv[2] = {0.f, 0.f};
+  float xav = 0.f, xtav = 0.f;                         // n2a, n2c <= 64: one element per lane
+  if (n1a) {
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(h.W2), 0, (n1a + 1) * n2a * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(h.W2_t), 0, (n1a + 1) * n2a * 4, 0x00020000);
+#pragma unroll
+    for (int n = 0; n < HEADS_NW4P; ++n) {
+      const int i = tid + n * HEADS_THREADS;
+      w2v[n] = __builtin_amdgcn_raw_buffer_load_b128(rw, i * 16, 0, 0);
+      w2tv[n] = __builtin_amdgcn_raw_buffer_load_b128(rwt, i * 16, 0, 0);
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int j = t + n * HEADS_TEAM;
+      x1v[n] = (rv && j < n1a) ? h.h1a[(long)row * h.ld_h1a + j] : 0.f;
+      x1tv[n] = (rv && j < n1a) ? h.h1ta[(long)row * h.ld_h1a + j] : 0.f;
+    }
+  } else {
+    xav = (rv && t < n2a) ? h.h2a[(long)row * h.ld_h2a + t] : 0.f;
+    xtav = (rv && t < n2a) ? h.h2ta[(long)row * h.ld_h2a + t] : 0.f;
+  }
   const float xcv = (rv && t < n2c) ? h.h2c[(long)row * h.ld_h2c + t] : 0.f;
   const float xtcv = (rv && t < n2c) ? h.h2tc[(long)row * h.ld_h2c + t] : 0.f;
-  float abv[HEADS_AMAX];
+  float abv[AT];
 #pragma unroll
-  for (int i = 0; i < HEADS_AMAX; ++i) abv[i] = (rv && i < A) ? h.act[(long)row * A + i] : 0.f;
+  for (int i = 0; i < AT; ++i) abv[i] = (rv && i < A) ? h.act[(long)row * A + i] : 0.f;
   const float rrow = rv ? h.r[row] : 0.f, mrow = rv ? h.mask[row] : 0.f;
   static_assert(N3P + 1 <= HEADS_THREADS, "one q-layer weight per thread");
   const float wq_a = tid < n3 ? h.wq[tid] : (tid == N3P ? h.wq[n3] : 0.f), wqt_a = tid < n3 ? h.wq_t[tid] : (tid == N3P ? h.wq_t[n3] : 0.f);
@@ -108,12 +138,38 @@ __global__ __launch_bounds__(HEADS_THREADS) void ddpg_heads_kernel(const DdpgHea
     const int i = tid + n * HEADS_THREADS;
     if (i * 4 < wfl) { reinterpret_cast<heads_u4*>(W3)[i] = wv[n]; reinterpret_cast<heads_u4*>(W3t)[i] = wtv[n]; }
   }
+  if (n1a) {
+#pragma unroll
+    for (int n = 0; n < HEADS_NW4P; ++n) {
+      const int i = tid + n * HEADS_THREADS;
+      if (i * 4 < w2fl) { reinterpret_cast<heads_u4*>(W2)[i] = w2v[n]; reinterpret_cast<heads_u4*>(W2t)[i] = w2tv[n]; }
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int j = t + n * HEADS_TEAM;
+      if (j < n1ap) { x1[j] = x1v[n]; x1t[j] = x1tv[n]; }    // (zeros beyond n1a)
+    }
+  }
   __syncthreads();
   HCK();
-  float a[HEADS_AMAX], at[HEADS_AMAX], ab[HEADS_AMAX], dqda[HEADS_AMAX], adz[HEADS_AMAX];
+  if (n1a) {   // ---- the actors' last hidden layer: lane t owns unit t (units >= n2a read on into finite weights and are zeroed)
+    // (x is zero from n1a to n1ap and the rows it meets there -- the bias row, then the zero slack -- are finite: no bounds in the loop)
+    float p2 = W2[n1a * n2a + t], p2t = W2t[n1a * n2a + t], q2 = 0.f, q2t = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < n1ap; k += 4) {
+      const heads_f4 xv = *reinterpret_cast<const heads_f4*>(x1 + k), xtv = *reinterpret_cast<const heads_f4*>(x1t + k);
+      p2 = fmaf(xv[0], W2[(k + 0) * n2a + t], p2); p2t = fmaf(xtv[0], W2t[(k + 0) * n2a + t], p2t);
+      q2 = fmaf(xv[1], W2[(k + 1) * n2a + t], q2); q2t = fmaf(xtv[1], W2t[(k + 1) * n2a + t], q2t);
+      p2 = fmaf(xv[2], W2[(k + 2) * n2a + t], p2); p2t = fmaf(xtv[2], W2t[(k + 2) * n2a + t], p2t);
+      q2 = fmaf(xv[3], W2[(k + 3) * n2a + t], q2); q2t = fmaf(xtv[3], W2t[(k + 3) * n2a + t], q2t);
+    }
+    xav = t < n2a ? fmaxf(p2 + q2, 0.f) : 0.f; xtav = t < n2a ? fmaxf(p2t + q2t, 0.f) : 0.f;
+    if (rv && t < n2a) h.h2a_out[(long)row * h.ld_h2a + t] = xav;
+  }
+  float a[AT], at[AT], ab[AT], dqda[AT], adz[AT];
   // ---- the two actor heads: lane t holds x[t]
 #pragma unroll
-  for (int i = 0; i < HEADS_AMAX; ++i) {
+  for (int i = 0; i < AT; ++i) {
     a[i] = at[i] = ab[i] = dqda[i] = adz[i] = 0.f;
     if (i < A) {
       const float s = t < n2a ? xav * Wo[t * A + i] : 0.f, st = t < n2a ? xtav * Wot[t * A + i] : 0.f;
@@ -124,17 +180,19 @@ __global__ __launch_bounds__(HEADS_THREADS) void ddpg_heads_kernel(const DdpgHea
   }
   HCK();
   // ---- concat layer of the critic: three evaluations sharing the state part; lane t owns unit t; q, q'; dQ/da
-  float p = W3[(n2c + A) * WS + t], pt = W3t[(n2c + A) * WS + t];
-#pragma unroll 2
-  for (int k = 0; k < n2cp; k += 4) {
+  float p = W3[(n2c + A) * WS + t], pt = W3t[(n2c + A) * WS + t], q = 0.f, qt_ = 0.f;
+#pragma unroll 4
+  for (int k = 0; k < n2cp; k += 4) {     // (x is zero from n2c to n2cp; the rows it meets there are finite)
     const heads_f4 xv = *reinterpret_cast<const heads_f4*>(xc + k), xtv = *reinterpret_cast<const heads_f4*>(xtc + k);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-      if (k + kk < n2c) { p = fmaf(xv[kk], W3[(k + kk) * WS + t], p); pt = fmaf(xtv[kk], W3t[(k + kk) * WS + t], pt); }
+    p = fmaf(xv[0], W3[(k + 0) * WS + t], p); pt = fmaf(xtv[0], W3t[(k + 0) * WS + t], pt);
+    q = fmaf(xv[1], W3[(k + 1) * WS + t], q); qt_ = fmaf(xtv[1], W3t[(k + 1) * WS + t], qt_);
+    p = fmaf(xv[2], W3[(k + 2) * WS + t], p); pt = fmaf(xtv[2], W3t[(k + 2) * WS + t], pt);
+    q = fmaf(xv[3], W3[(k + 3) * WS + t], q); qt_ = fmaf(xtv[3], W3t[(k + 3) * WS + t], qt_);
   }
+  p += q; pt += qt_;
   float pm = p, pb = p;
 #pragma unroll
-  for (int i = 0; i < HEADS_AMAX; ++i)
+  for (int i = 0; i < AT; ++i)
     if (i < A) {
       const float w = W3[(n2c + i) * WS + t], wt = W3t[(n2c + i) * WS + t];
       pm = fmaf(a[i], w, pm); pb = fmaf(ab[i], w, pb); pt = fmaf(at[i], wt, pt);
@@ -146,14 +204,14 @@ __global__ __launch_bounds__(HEADS_THREADS) void ddpg_heads_kernel(const DdpgHea
   HCK();
   const float qb = team_sum(h3b * wqv) + wq[N3P], qt = team_sum(fmaxf(pt, 0.f) * wqtv) + wqt[N3P];
 #pragma unroll
-  for (int i = 0; i < HEADS_AMAX; ++i)
+  for (int i = 0; i < AT; ++i)
     if (i < A) { dqda[i] = team_sum(dzm * W3[(n2c + i) * WS + t]); adz[i] = -dqda[i] * (1.f - a[i] * a[i]); }
   const float td = rv ? qb - (rrow + (mrow * h.discount) * qt) : 0.f;
   const float dzq = td * (2.f / (float)h.B);
   if (rv && t == 0) { h.td[row] = td; h.dzq[row] = dzq; h.q_out[row] = qb; h.tq_out[row] = qt; }
   if (rv && t < A) {
 #pragma unroll
-    for (int i = 0; i < HEADS_AMAX; ++i)
+    for (int i = 0; i < AT; ++i)
       if (i == t) {
         h.a_out[(long)row * A + i] = a[i]; h.dq_da[(long)row * A + i] = dqda[i]; h.adz[(long)row * A + i] = adz[i];
         h.cat_splice[(long)row * h.ld_h2c + i] = ab[i];
@@ -161,13 +219,16 @@ __global__ __launch_bounds__(HEADS_THREADS) void ddpg_heads_kernel(const DdpgHea
   }
   HCK();
   // ---- one layer back: the actor's last hidden layer, the critic's concat layer and the layer feeding it
-  if (rv && t < n2a) {
+  float dz2 = 0.f;
+  if (t < n2a) {
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < HEADS_AMAX; ++i)
+    for (int i = 0; i < AT; ++i)
       if (i < A) s = fmaf(adz[i], Wo[t * A + i], s);
-    h.dz_h2a[(long)row * n2a + t] = xav > 0.f ? (h.relu_x2 ? 2.f * s : s) : 0.f;
+    dz2 = xav > 0.f ? (h.relu_x2 ? 2.f * s : s) : 0.f;
+    if (rv) h.dz_h2a[(long)row * n2a + t] = dz2;
   }
+  if (n1a) sc2[t] = dz2;
   const float d3 = h3b > 0.f ? dzq * wqv : 0.f;
   if (rv && t < n3) h.dz3[(long)row * n3 + t] = d3;
   sc3[t] = d3;                                          // (a team is one wave: the reads below see it after the fence)
@@ -177,12 +238,27 @@ __global__ __launch_bounds__(HEADS_THREADS) void ddpg_heads_kernel(const DdpgHea
   HCK();
   if (rv && t < n2c) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // units >= n3: dz3 is zero there, the weights finite
-#pragma unroll 4
+#pragma unroll
     for (int j = 0; j < N3P; j += 4) {
       const heads_f4 dv = *reinterpret_cast<const heads_f4*>(sc3 + j), wv4 = ld4(W3 + t * WS + j);
       s0 = fmaf(dv[0], wv4[0], s0); s1 = fmaf(dv[1], wv4[1], s1); s2 = fmaf(dv[2], wv4[2], s2); s3 = fmaf(dv[3], wv4[3], s3);
     }
     h.dz2c[(long)row * n2c + t] = xcv > 0.f ? (s0 + s1) + (s2 + s3) : 0.f;
+  }
+  if (n1a && rv) {   // ---- and the actor layer below its last hidden layer
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int j = t + n * HEADS_TEAM;
+      if (j < n1a) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;    // units >= n2a: dz2 is zero there, the weights finite
+#pragma unroll
+        for (int c = 0; c < HEADS_TEAM; c += 4) {
+          const heads_f4 dv = *reinterpret_cast<const heads_f4*>(sc2 + c), wv4 = ld4(W2 + j * n2a + c);
+          s0 = fmaf(dv[0], wv4[0], s0); s1 = fmaf(dv[1], wv4[1], s1); s2 = fmaf(dv[2], wv4[2], s2); s3 = fmaf(dv[3], wv4[3], s3);
+        }
+        h.dz_h1a[(long)row * n1a + j] = x1v[n] > 0.f ? (s0 + s1) + (s2 + s3) : 0.f;
+      }
+    }
   }
   HCK();
   // ---- loss = mean(td^2): one partial per workgroup; the reader adds the partials in order (cpp_ddpg_last_stats)
@@ -203,25 +279,32 @@ __global__ __launch_bounds__(HEADS_THREADS) void ddpg_heads_kernel(const DdpgHea
 size_t ddpg_heads_lds_bytes(const DdpgHeadsArgs& h) {
   const size_t k3 = h.n2c + h.A + 1, n3p = HEADS_N3P, n2cp = (h.n2c + 3) & ~3;
   const size_t wfl = (k3 * h.n3 + HEADS_WSLACK + 3) & ~(size_t)3;
-  const size_t w = (2 * wfl + 2 * (n3p + 4) + 2 * (size_t)(h.n2a + 1) * h.A + 3) & ~(size_t)3;
-  const size_t f = w + (size_t)HEADS_ROWS * (n3p + 2 * n2cp + ((2 * h.n2a + 3) & ~3));
+  const size_t w2fl = h.n1a ? (((size_t)(h.n1a + 1) * h.n2a + HEADS_WSLACK + 3) & ~(size_t)3) : 0, n1ap = (h.n1a + 3) & ~3;
+  const size_t w = ((2 * wfl + 2 * (n3p + 4) + 2 * (size_t)(h.n2a + 1) * h.A + 3) & ~(size_t)3) + 2 * w2fl;
+  const size_t f = w + (size_t)HEADS_ROWS * (n3p + 2 * n2cp + ((2 * h.n2a + 3) & ~3) + (h.n1a ? HEADS_TEAM + 2 * n1ap : 0));
   return f * sizeof(float);
 }
 
 bool ddpg_heads_supported(const DdpgHeadsArgs& h) {
+  if (h.n1a && !(h.n1a <= HEADS_N1MAX && (h.n2a & 1) == 0 &&
+                 (h.n1a + 1) * h.n2a + HEADS_WSLACK + 4 <= 4 * HEADS_NW4P * HEADS_THREADS)) return false;
   return h.A <= HEADS_AMAX && h.n3 <= HEADS_N3P && h.n2a <= HEADS_TEAM && h.n2c <= HEADS_TEAM &&
          (h.n2a + 1) * h.A <= 2 * HEADS_THREADS && (h.n2c + h.A + 1) * h.n3 + HEADS_WSLACK + 4 <= 4 * HEADS_NW4 * HEADS_THREADS && (h.n3 & 1) == 0 && ddpg_heads_lds_bytes(h) <= 120 * 1024 && (h.B + HEADS_ROWS - 1) / HEADS_ROWS <= DDPG_HEADS_MAX_WGS;
 }
 
 int launch_ddpg_heads(cpp_ctx* ctx, const DdpgHeadsArgs& h) {
   const size_t lds = ddpg_heads_lds_bytes(h);
-  static size_t attr = 0;
-  if (lds > attr) {
-    HIP_CHECK(hipFuncSetAttribute((const void*)ddpg_heads_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = lds;
+  typedef void (*kern_t)(const DdpgHeadsArgs);
+  static const kern_t kerns[6] = {ddpg_heads_kernel<1, true>, ddpg_heads_kernel<2, true>, ddpg_heads_kernel<4, true>,
+                                  ddpg_heads_kernel<8, true>, ddpg_heads_kernel<4, false>, ddpg_heads_kernel<8, false>};
+  const int ki = h.A == 1 ? 0 : h.A == 2 ? 1 : h.A == 4 ? 2 : h.A == 8 ? 3 : h.A == 3 ? 4 : 5;
+  static size_t attr[6] = {0, 0, 0, 0, 0, 0};
+  if (lds > attr[ki]) {
+    HIP_CHECK(hipFuncSetAttribute((const void*)kerns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr[ki] = lds;
   }
   prof_begin(ctx);
-  hipLaunchKernelGGL(ddpg_heads_kernel, dim3((h.B + HEADS_ROWS - 1) / HEADS_ROWS), dim3(HEADS_THREADS), lds, ctx->stream, h);
+  hipLaunchKernelGGL(kerns[ki], dim3((h.B + HEADS_ROWS - 1) / HEADS_ROWS), dim3(HEADS_THREADS), lds, ctx->stream, h);
   LAUNCH_CHECK();
   prof_end(ctx, K_HEADS);
   return 0;

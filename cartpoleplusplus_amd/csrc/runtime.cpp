@@ -1513,13 +1513,25 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b) {
     hd.dz3 = c->ws[0].dz[cat]; hd.dz2c = c->ws[0].dz[cat - 1];
     hd.loss_part = d->heads_part;
     fused = ddpg_heads_supported(hd);
+    // the actors are one layer deeper than the critics' prefix (100-100-50 against 200-50): their last hidden layer joins the
+    // heads kernel so that both stacks reach it, and leave it, in the same number of GEMM levels.  CPP_HEADS_PRE=0: GEMMs.
+    static const bool no_pre = getenv("CPP_HEADS_PRE") != nullptr && atoi(getenv("CPP_HEADS_PRE")) == 0;
+    if (fused && !no_pre && na >= 3 && !a->drop_counter && a->fc[na - 2].act == GE_RELU && a->fc[na - 3].act == GE_RELU) {
+      DdpgHeadsArgs hp = hd;
+      const FcL& L2 = a->fc[na - 2];
+      hp.h1a = a->ws[0].fcin[na - 2]; hp.h1ta = ta->ws[0].fcin[na - 2]; hp.ld_h1a = L2.n_in + 1; hp.n1a = L2.n_in;
+      hp.W2 = a->params + L2.w_off; hp.W2_t = ta->params + L2.w_off;
+      hp.h2a_out = a->ws[0].fcin[na - 1]; hp.dz_h1a = a->ws[0].dz[na - 3];
+      if (ddpg_heads_supported(hp)) hd = hp;
+    }
   }
+  const int pre = (fused && hd.n1a > 0) ? 1 : 0;
   d->heads_grid = fused ? (B + 3) / 4 : 0; d->heads_B = B;
   d->loss_parts = d->heads_grid; d->loss_B = B;
   int adz, cdz;
   if (fused) {
     int aF = tA, taF = tTA;
-    for (int l = 0; l < na - 1; ++l) {
+    for (int l = 0; l < na - 1 - pre; ++l) {
       aF = G.gemm(fc_fwd_args(a, a->ws[0], l, B), {aF});
       taF = G.gemm(fc_fwd_args(ta, ta->ws[0], l, B), {taF});
     }
@@ -1539,6 +1551,7 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b) {
     for (int l = na - 2; l >= 0; --l) {
       const FcL& L = a->fc[l];
       G.gemm(fc_dw_args(a, a->ws[0], l, B, a->ws[0].dz[l]), {adz});
+      if (pre && l == na - 2) continue;       // dz[l - 1] came out of the heads kernel
       if (l > 0)
         adz = G.gemm(fc_dx_args(a, l, B, a->ws[0].dz[l], L.n_out, 0, L.n_in, a->ws[0].dz[l - 1], L.n_in, relu_grad_epi(a, l - 1),
                                 a->ws[0].fcin[l], L.n_in + 1), {adz});

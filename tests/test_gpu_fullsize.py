@@ -193,6 +193,19 @@ def test_f32_mfma_conv1_stays_parity_green_when_selected():
     assert r.returncode == 0 and " passed" in tail, tail
 
 
+@pytest.mark.parametrize("switch", ["CPP_FUSED_HEADS", "CPP_HEADS_PRE"])
+def test_gemm_level_heads_stay_parity_green_when_selected(switch):
+    """CPP_FUSED_HEADS=0 runs the MLP heads as GEMM levels + TD kernel, CPP_HEADS_PRE=0 keeps the actors' last hidden layer
+    out of the heads kernel (the paths of networks the kernel does not cover: dropout, wide layers): same parity cases."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "fused or gradients or train_ops"], cwd=root, env=dict(os.environ, **{switch: "0"}),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    tail = r.stdout.decode()[-1500:]
+    assert r.returncode == 0 and " passed" in tail, tail
+
+
 _CONV1_DW_ERR_SNIPPET = r"""
 import numpy as np
 from oracle import ddpg_np as O
