@@ -92,6 +92,9 @@ bool conv1_f16_pipes_ok(int cin, int H, int W, int B, bool batch_norm);
 bool conv12_b16_ok(int cin, int H, int W, int B);
 int launch_conv_fwd(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi, ConvArgs a);
 int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi, const ConvArgs* list, int n);
+// conv3 forward of 16x16 inputs with the whole image in LDS (conv3_img.hip)
+bool conv3_img_ok(int cin, int ks, int H, int W, int nout);
+int launch_conv3_img(cpp_ctx* ctx, const struct ConvArgsN& batch);
 int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, const ConvArgs* list, int n,
                          float* const* grad_w, float* const* grad_b);
 int launch_conv_dw(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, ConvArgs a, float* grad_w,

@@ -105,6 +105,12 @@ int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, i
   }
   for (int i = 0; i < n; ++i)
     if (batch.a[i].img_slot) { cpp_set_error("conv forward: images addressed through replay slots need the f16-pipe conv1 kernel"); prof_end(ctx, kid); return 1; }
+  if (!no_kyo && in_mode == IN_F32_PLAIN && !dx_mode && !plain_fwd && epi == EPI_RELU_POOL && a.wscale == 0.f &&
+      conv3_img_ok(cin, ks, a.H, a.W, a.nout)) {      // conv3 of 16x16 inputs: whole images in LDS
+    rc = launch_conv3_img(ctx, batch);
+    prof_end(ctx, kid);
+    return rc;
+  }
   if (!no_kyo && in_mode == IN_F32_PLAIN && !dx_mode && !plain_fwd && a.in_b16 != nullptr) {      // conv2 from conv1's bf16 planes
     bool handled = false;
     rc = conv_fwd_kb16_dispatch(ctx, cin, ks, in_mode, batch, &handled);
