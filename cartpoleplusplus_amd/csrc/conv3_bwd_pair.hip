@@ -1,0 +1,37 @@
+// conv3's dW and dX in ONE launch.  Both read the same pooled gradient, neither needs the other, and each is a latency-bound
+// launch of ~12 us whose grid leaves most of the chip idle most of the time; a graph fork onto a second stream costs more
+// than it hides on this runtime, two kernels in one grid do not: workgroups [0, dX grid) run the row kernel in
+// dX mode, the rest the dW kernel -- the unchanged kernel bodies, told their place in a grid of their own.
+#include <cstring>
+#include "conv_impl.h"
+#include "conv_kyo.h"
+
+__global__ __launch_bounds__(CONV_THREADS, 2) void conv3_bwd_pair_kernel(const ConvArgsN dx, int dx_gx, const ConvArgsN dw, int dw_gx) {
+  const int ndx = dx_gx * dx.n;
+  if ((int)blockIdx.x < ndx) {
+    conv_fwd_kyo_body<10, 3, 1, 4, IN_DY, 16, false>(dx, (int)blockIdx.x % dx_gx, (int)blockIdx.x / dx_gx);
+  } else {
+    const int i = (int)blockIdx.x - ndx;
+    conv_dw_body<10, 3, 1, IN_F32_PLAIN>(dw, i % dw_gx, i / dw_gx, dw_gx);
+  }
+}
+
+int launch_conv3_bwd_pair(cpp_ctx* ctx, const ConvPairSlot& slot) {
+  const int ndx = slot.have_dx ? slot.dx_gx * slot.dx.n : 0, ndw = slot.have_dw ? slot.dw_gx * slot.dw.n : 0;
+  if (ndx + ndw == 0) return 0;
+  const size_t lds = (slot.have_dx ? slot.dx_lds : 0) > (slot.have_dw ? slot.dw_lds : 0) ? slot.dx_lds : slot.dw_lds;
+  static size_t attr = 0;
+  if (lds > attr) {
+    HIP_CHECK(hipFuncSetAttribute((const void*)conv3_bwd_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = lds;
+  }
+  ConvArgsN dx = slot.dx, dw = slot.dw;
+  if (!slot.have_dx) { memset(&dx, 0, sizeof(dx)); dx.n = 0; }
+  if (!slot.have_dw) { memset(&dw, 0, sizeof(dw)); dw.n = 0; }
+  prof_begin(ctx);
+  hipLaunchKernelGGL(conv3_bwd_pair_kernel, dim3(ndx + ndw), dim3(CONV_THREADS), lds, ctx->stream, dx, slot.have_dx ? slot.dx_gx : 1,
+                     dw, slot.have_dw ? slot.dw_gx : 1);
+  LAUNCH_CHECK();
+  prof_end(ctx, K_CONV3_BWD);
+  return 0;
+}

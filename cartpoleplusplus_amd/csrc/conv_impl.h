@@ -50,8 +50,7 @@ static inline int conv_grid_x(int capacity, int n, int ntiles) {
 // XCD-aware persistent tile order: workgroup b runs on XCD b % 8 (observed dispatch order, speed
 // only); give every XCD a contiguous run of tiles so neighbouring row tiles of one image (which share
 // 4 halo rows) hit the same 4 MiB L2.
-__device__ __forceinline__ void conv_tile_range(int ntiles, int& start, int& step, int& end) {
-  const int nb = gridDim.x, bid = blockIdx.x;
+__device__ __forceinline__ void conv_tile_range(int ntiles, int& start, int& step, int& end, int nb, int bid) {
   if ((nb & 7) == 0) {
     const int chunk = (ntiles + 7) >> 3;
     start = (bid & 7) * chunk + (bid >> 3);
@@ -286,7 +285,7 @@ __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd
   const int Hp = a.H >> 1, Wp = a.W >> 1;
   const int tiles_per_img = a.tiles_x * a.tiles_y;
   int t_start, t_step, t_end;
-  conv_tile_range(a.ntiles, t_start, t_step, t_end);
+  conv_tile_range(a.ntiles, t_start, t_step, t_end, gridDim.x, blockIdx.x);
 
   typedef typename StageType<IN_MODE>::type ST;
   constexpr bool WHITEN = (IN_MODE == IN_F16_WHITEN || IN_MODE == IN_F32_WHITEN);
@@ -484,10 +483,11 @@ struct DyStager {
   }
 };
 
+// (bx, by, gx): the workgroup's place in a (gx, networks) grid -- blockIdx / gridDim for a launch of its own, a slice of the
+// grid when the kernel shares a launch with another one (conv3_bwd_pair.hip)
 template <int CIN, int KS, int XTW, int IN_MODE>
-__global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW))
-__attribute__((amdgpu_waves_per_eu(conv_wps(CIN, KS, XTW), conv_wps(CIN, KS, XTW)))) void conv_dw_kernel(const ConvArgsN batch) {
-  const ConvArgs& a = batch.a[blockIdx.y];
+__device__ __forceinline__ void conv_dw_body(const ConvArgsN& batch, const int bx, const int by, const int gx) {
+  const ConvArgs& a = batch.a[by];
   constexpr int TR = conv_th(CIN, XTW) + KS - 1, TCOLS = 16 * XTW, TC = TCOLS + KS - 1;
   constexpr int TILE = TR * TC * CIN;
   constexpr int KT = DwGeom<CIN, KS>::KT, NT = DwGeom<CIN, KS>::NT;
@@ -513,7 +513,7 @@ __attribute__((amdgpu_waves_per_eu(conv_wps(CIN, KS, XTW), conv_wps(CIN, KS, XTW
 
   const int tiles_per_img = a.tiles_x * a.tiles_y;
   int t_start, t_step, t_end;
-  conv_tile_range(a.ntiles, t_start, t_step, t_end);
+  conv_tile_range(a.ntiles, t_start, t_step, t_end, gx, bx);
 
   typedef typename StageType<IN_MODE>::type ST;
   constexpr bool WHITEN = (IN_MODE == IN_F16_WHITEN || IN_MODE == IN_F32_WHITEN);
@@ -643,7 +643,7 @@ __attribute__((amdgpu_waves_per_eu(conv_wps(CIN, KS, XTW), conv_wps(CIN, KS, XTW
   if (lj == 0) bred[wave * 16 + li] = bsum;
   __syncthreads();
 
-  float* part = a.partial + (long)blockIdx.x * a.pstride;
+  float* part = a.partial + (long)bx * a.pstride;
   const int nw = KS * KS * CIN * a.nout;
   for (int e = tid; e < nw; e += CONV_THREADS) {
     const int o = e % a.nout;
@@ -686,6 +686,12 @@ static inline int conv_dw_grid(cpp_ctx* ctx, int xtw_max) {
 }
 
 template <int CIN, int KS, int XTW, int IN_MODE>
+__global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW))
+__attribute__((amdgpu_waves_per_eu(conv_wps(CIN, KS, XTW), conv_wps(CIN, KS, XTW)))) void conv_dw_kernel(const ConvArgsN batch) {
+  conv_dw_body<CIN, KS, XTW, IN_MODE>(batch, blockIdx.x, blockIdx.y, gridDim.x);
+}
+
+template <int CIN, int KS, int XTW, int IN_MODE>
 static inline int conv_dw_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int* grid_out) {
   const ConvArgs& a = batch.a[0];
   constexpr int TR = conv_th(CIN, XTW) + KS - 1, TC = 16 * XTW + KS - 1;
@@ -704,6 +710,10 @@ static inline int conv_dw_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int* gr
   const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
   const int grid = conv_grid_x(ctx->num_cus * per_cu, batch.n, a.ntiles);
   *grid_out = grid;
+  if (ctx->pair && CIN == 10 && KS == 3 && XTW == 1 && IN_MODE == IN_F32_PLAIN) {      // leaves with conv3's dX (conv3_bwd_pair.hip)
+    ctx->pair->dw = batch; ctx->pair->dw_gx = grid; ctx->pair->dw_lds = lds_bytes; ctx->pair->have_dw = true;
+    return 0;
+  }
   hipLaunchKernelGGL(kern, dim3(grid, batch.n), dim3(CONV_THREADS), lds_bytes, ctx->stream, batch);
   LAUNCH_CHECK();
   return 0;

@@ -73,7 +73,7 @@ struct KyoGeom {
 // reference's default 50 x 50 render: 1800-byte rows)
 // PLAIN: write the plain conv output rows (no bias / ReLU / pool): batch norm needs the statistics of z first
 template <int CIN, int KS, int XT, int IPW, int IN_MODE, int CHB = 16, bool PLAIN = false>
-__global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_kernel(const ConvArgsN batch) {
+__device__ __forceinline__ void conv_fwd_kyo_body(const ConvArgsN& batch, const int bx, const int by) {
   typedef KyoGeom<CIN, KS, XT, IPW> G;
   typedef typename StageType<IN_MODE>::type ST;
   constexpr bool WHITEN = (IN_MODE == IN_F16_WHITEN || IN_MODE == IN_F32_WHITEN);
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
 #ifdef KYO_CLOCK_PROBE
   const unsigned long long pe = __builtin_amdgcn_s_memrealtime();
 #endif
-  const ConvArgs& a = batch.a[blockIdx.y];
+  const ConvArgs& a = batch.a[by];
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* wl = lds;                                   // [KS][NGT][4][NO][4]
   float* rows = lds + G::WLF;                        // [RING][IPW][ROWF]
@@ -104,8 +104,8 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
   // launches that would leave most SIMDs with one wave (dX of two networks) split every image into bands of output rows
   // [ylo, yhi); a band also reads the P (even: 2) input rows above and below it
   const int nbands = a.nbands > 1 ? a.nbands : 1;
-  const int band = (int)blockIdx.x % nbands;
-  const int b0 = ((int)blockIdx.x / nbands) * IPW;
+  const int band = bx % nbands;
+  const int b0 = (bx / nbands) * IPW;
   const int ylo = nbands > 1 ? band * a.band_rows : 0, yhi = nbands > 1 ? min(H, ylo + a.band_rows) : H;
   const int qs = max(0, (ylo - P) & ~1), qe = min(H, yhi + P);      // input rows of the band
 
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
     {  // issue arbitration is by priority, then age: without this the oldest of the co-resident workgroups (one per
        // network) runs ahead and the youngest finishes alone; rotating the priority every KS rows keeps them level
        // (0.3786 -> 0.3745 ms for conv1)
-      const int pr = ((int)blockIdx.y + q0 / KS) & 3;
+      const int pr = (by + q0 / KS) & 3;
       if (pr == 0) __builtin_amdgcn_s_setprio(0); else if (pr == 1) __builtin_amdgcn_s_setprio(1);
       else if (pr == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
     }
@@ -523,6 +523,11 @@ __global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_
 #endif
 }
 
+template <int CIN, int KS, int XT, int IPW, int IN_MODE, int CHB, bool PLAIN>
+__global__ __launch_bounds__(CONV_THREADS, (XT == 1 ? 4 : 2)) void conv_fwd_kyo_kernel(const ConvArgsN batch) {
+  conv_fwd_kyo_body<CIN, KS, XT, IPW, IN_MODE, CHB, PLAIN>(batch, blockIdx.x, blockIdx.y);
+}
+
 template <int CIN, int KS, int XT, int IPW, int IN_MODE, int CHB = 16, bool PLAIN = false>
 static inline int conv_fwd_kyo_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
   typedef KyoGeom<CIN, KS, XT, IPW> G;
@@ -535,6 +540,10 @@ static inline int conv_fwd_kyo_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
     attr_done = true;
   }
   const int grid = ((a.B + IPW - 1) / IPW) * (a.nbands > 1 ? a.nbands : 1);
+  if (ctx->pair && CIN == 10 && KS == 3 && XT == 1 && IPW == 4 && IN_MODE == IN_DY && CHB == 16 && !PLAIN) {      // leaves with conv3's dW (conv3_bwd_pair.hip)
+    ctx->pair->dx = batch; ctx->pair->dx_gx = grid; ctx->pair->dx_lds = lds_bytes; ctx->pair->have_dx = true;
+    return 0;
+  }
   hipLaunchKernelGGL(kern, dim3(grid, batch.n), dim3(CONV_THREADS), lds_bytes, ctx->stream, batch);
   LAUNCH_CHECK();
   return 0;
