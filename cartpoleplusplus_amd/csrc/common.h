@@ -21,6 +21,7 @@ enum KernelId {
   K_CONV1_DW_F16X3,       // conv1 dW on the f16 pipes with three-piece dY (conv_dw16.h)
   K_HEADS,                // fused DDPG heads (heads.hip)
   K_CONV3_BWD,            // conv3's dW and dX in one launch (conv3_bwd_pair.hip)
+  K_CONV2_BWD,            // conv2's dW and dX in one launch (conv2_bwd_pair.hip)
   K_NUM_KERNELS
 };
 
@@ -96,8 +97,9 @@ int launch_conv_fwd(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi
 int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi, const ConvArgs* list, int n);
 // conv3 forward of 16x16 inputs with the whole image in LDS (conv3_img.hip)
 // conv3's dW and dX are independent, latency-bound launches of ~12 us each: parked by their launchers and sent as ONE grid
-struct ConvPairSlot { bool have_dw, have_dx; ConvArgsN dw, dx; int dw_gx, dx_gx; size_t dw_lds, dx_lds; };
+struct ConvPairSlot { int layer; bool have_dw, have_dx; ConvArgsN dw, dx; int dw_gx, dx_gx; size_t dw_lds, dx_lds; int upi, band; };
 int launch_conv3_bwd_pair(cpp_ctx* ctx, const ConvPairSlot& slot);
+int launch_conv2_bwd_pair(cpp_ctx* ctx, const ConvPairSlot& slot);
 bool conv3_img_ok(int cin, int ks, int H, int W, int nout);
 int launch_conv3_img(cpp_ctx* ctx, const struct ConvArgsN& batch);
 int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, const ConvArgs* list, int n,

@@ -52,13 +52,14 @@ struct Dwb16Geom {
   static_assert(DY_BYTES >= CONV_THREADS * NCELL * 4, "epilogue scratch fits the dY ring");
 };
 
+// (bx, by, gx): the workgroup's place in a (gx, networks) grid (its own launch, or a slice of a shared one: conv2_bwd_pair.hip)
 template <int CIN, int KS, int NCHK>
-__global__ __launch_bounds__(CONV_THREADS, 3) void conv_dwb16_kernel(const ConvArgsN batch, int units_per_img, int band) {
+__device__ __forceinline__ void conv_dwb16_body(const ConvArgsN& batch, int units_per_img, int band, const int bx, const int by, const int gx) {
   typedef Dwb16Geom<CIN, KS, NCHK> G;
   constexpr int P = G::P, NO = G::NO, MT = G::MT, CP = G::CP, NPC = G::NPC, NPA = G::NPA, ROWB = G::ROWB, DSLOT = G::DSLOT;
   constexpr int SLOTB = NPA * ROWB;                  // bytes per input ring slot (three planes)
   static_assert((KS * NO + 15) / 16 == 4, "one column tile per wave");
-  const ConvArgs& a = batch.a[blockIdx.y];
+  const ConvArgs& a = batch.a[by];
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   unsigned char* inring = lds_raw;                                         // [3 slots][3 planes][ROWB]
   unsigned char* dyring = lds_raw + ((G::IN_BYTES + 15) & ~15);            // [6][DSLOT]
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(CONV_THREADS, 3) void conv_dwb16_kernel(const ConvA
 
   __syncthreads();
 
-  for (int unit = blockIdx.x; unit < units; unit += gridDim.x) {
+  for (int unit = bx; unit < units; unit += gx) {
     const int b = unit / units_per_img;
     const int q_lo = (unit - b * units_per_img) * band;
     const int rows = min(band, H - q_lo);            // band and q_lo are even
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(CONV_THREADS, 3) void conv_dwb16_kernel(const ConvA
   }
 
   // ---- one partial per workgroup: D tile mt holds rows m = 16 mt + 4 lj + r = CP kx + c, column n = (ky, o)
-  float* part = a.partial + (long)blockIdx.x * a.pstride;
+  float* part = a.partial + (long)bx * a.pstride;
   const int nw = KS * G::KROW * nout;
   if (nvalid && no < nout) {
 #pragma unroll
@@ -278,6 +279,11 @@ __global__ __launch_bounds__(CONV_THREADS, 3) void conv_dwb16_kernel(const ConvA
 }
 
 template <int CIN, int KS, int NCHK>
+__global__ __launch_bounds__(CONV_THREADS, 3) void conv_dwb16_kernel(const ConvArgsN batch, int units_per_img, int band) {
+  conv_dwb16_body<CIN, KS, NCHK>(batch, units_per_img, band, blockIdx.x, blockIdx.y, gridDim.x);
+}
+
+template <int CIN, int KS, int NCHK>
 static inline int conv_dwb16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int* grid_out) {
   typedef Dwb16Geom<CIN, KS, NCHK> G;
   const ConvArgs& a = batch.a[0];
@@ -294,6 +300,12 @@ static inline int conv_dwb16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int*
   const int upi = (a.H + band - 1) / band;
   const int units = a.B * upi;
   const int grid = units < capacity ? units : capacity;
+  if (ctx->pair && ctx->pair->layer == 1 && CIN == 10 && KS == 5 && NCHK == 1) {      // leaves with conv2's dX (conv2_bwd_pair.hip)
+    ctx->pair->dw = batch; ctx->pair->dw_gx = grid; ctx->pair->dw_lds = lds_bytes; ctx->pair->have_dw = true;
+    ctx->pair->upi = upi; ctx->pair->band = band;
+    *grid_out = grid;
+    return 0;
+  }
   hipLaunchKernelGGL(kern, dim3(grid, batch.n), dim3(CONV_THREADS), lds_bytes, ctx->stream, batch, upi, band);
   LAUNCH_CHECK();
   *grid_out = grid;

@@ -710,7 +710,7 @@ static inline int conv_dw_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int* gr
   const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
   const int grid = conv_grid_x(ctx->num_cus * per_cu, batch.n, a.ntiles);
   *grid_out = grid;
-  if (ctx->pair && CIN == 10 && KS == 3 && XTW == 1 && IN_MODE == IN_F32_PLAIN) {      // leaves with conv3's dX (conv3_bwd_pair.hip)
+  if (ctx->pair && ctx->pair->layer == 2 && CIN == 10 && KS == 3 && XTW == 1 && IN_MODE == IN_F32_PLAIN) {      // leaves with conv3's dX (conv3_bwd_pair.hip)
     ctx->pair->dw = batch; ctx->pair->dw_gx = grid; ctx->pair->dw_lds = lds_bytes; ctx->pair->have_dw = true;
     return 0;
   }

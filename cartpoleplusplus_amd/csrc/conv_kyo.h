@@ -540,7 +540,8 @@ static inline int conv_fwd_kyo_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
     attr_done = true;
   }
   const int grid = ((a.B + IPW - 1) / IPW) * (a.nbands > 1 ? a.nbands : 1);
-  if (ctx->pair && CIN == 10 && KS == 3 && XT == 1 && IPW == 4 && IN_MODE == IN_DY && CHB == 16 && !PLAIN) {      // leaves with conv3's dW (conv3_bwd_pair.hip)
+  if (ctx->pair && CIN == 10 && IN_MODE == IN_DY && CHB == 16 && !PLAIN && XT == 1 &&
+      ((ctx->pair->layer == 2 && KS == 3 && IPW == 4) || (ctx->pair->layer == 1 && KS == 5 && IPW == 2))) {      // leaves with the layer's dW (conv*_bwd_pair.hip)
     ctx->pair->dx = batch; ctx->pair->dx_gx = grid; ctx->pair->dx_lds = lds_bytes; ctx->pair->have_dx = true;
     return 0;
   }

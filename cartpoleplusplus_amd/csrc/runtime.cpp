@@ -44,7 +44,8 @@ void prof_begin(cpp_ctx* ctx) {
 }
 void prof_end(cpp_ctx* ctx, int kid) {
   if (!ctx->prof) return;
-  if (ctx->pair && (kid == K_CONV3_DW || kid == K_CONV3_DX)) return;      // parked, not launched (conv3_bwd_pair.hip)
+  if (ctx->pair && ((ctx->pair->layer == 2 && (kid == K_CONV3_DW || kid == K_CONV3_DX)) ||
+                    (ctx->pair->layer == 1 && (kid == K_CONV2_DW || kid == K_CONV2_DX)))) return;      // parked, not launched (conv*_bwd_pair.hip)
   (void)hipEventRecord(ctx->pe1, ctx->stream);
   (void)hipEventSynchronize(ctx->pe1);
   float ms = 0.f;
@@ -56,7 +57,7 @@ void prof_end(cpp_ctx* ctx, int kid) {
 static const char* kKernelNames[K_NUM_KERNELS] = {
     "gather_stats", "stats_finalize", "stats_generic", "conv1_fwd", "conv2_fwd", "conv3_fwd",
     "conv1_dw", "conv2_dw", "conv3_dw", "conv2_dx", "conv3_dx", "dw_reduce", "gemm", "elementwise",
-    "td", "sumsq", "clip_sgd", "soft_update", "replay_fill", "naf_head", "conv1_fwd_f16x3", "conv1_dw_f16x3", "heads", "conv3_bwd"};
+    "td", "sumsq", "clip_sgd", "soft_update", "replay_fill", "naf_head", "conv1_fwd_f16x3", "conv1_dw_f16x3", "heads", "conv3_bwd", "conv2_bwd"};
 
 // ---------------------------------------------------------------------------------------------
 // context
@@ -617,15 +618,17 @@ static int nets_backward_conv(cpp_ctx* ctx, cpp_net* const* nets, int nn, int B,
       gw[k] = nets[k]->grads + L.w_off; gb[k] = nets[k]->grads + L.b_off;
       if (i > 0) xl[k] = conv_dx_args(nets[k], nets[k]->ws[0], i, B);
     }
-    // conv3's dW and dX leave in one launch (conv3_bwd_pair.hip; CPP_CONV3_PAIR=0: two launches)
-    static const bool no_pair = getenv("CPP_CONV3_PAIR") != nullptr && atoi(getenv("CPP_CONV3_PAIR")) == 0;
-    ConvPairSlot slot; slot.have_dw = slot.have_dx = false;
-    if (i == 2 && !no_pair) ctx->pair = &slot;
+    // a layer's dW and dX leave in one launch (conv3_bwd_pair.hip, conv2_bwd_pair.hip; CPP_CONV3_PAIR=0 / CPP_CONV2_PAIR=0: two)
+    static const bool no_pair3 = getenv("CPP_CONV3_PAIR") != nullptr && atoi(getenv("CPP_CONV3_PAIR")) == 0;
+    static const bool no_pair2 = getenv("CPP_CONV2_PAIR") != nullptr && atoi(getenv("CPP_CONV2_PAIR")) == 0;
+    const bool no_pair = i == 2 ? no_pair3 : (i == 1 ? no_pair2 : true);
+    ConvPairSlot slot; slot.have_dw = slot.have_dx = false; slot.layer = i;
+    if (!no_pair) ctx->pair = &slot;
     int rc = launch_conv_dw_multi(ctx, kDwKid[i], L.Cin, L.ks, mode, dl, nn, gw, gb);
     if (!rc && i > 0) rc = launch_conv_fwd_multi(ctx, kDxKid[i], kConvOut, L.ks, IN_DY, EPI_PLAIN, xl, nn);
     ctx->pair = nullptr;
     RC(rc);
-    if (i == 2 && !no_pair) RC(launch_conv3_bwd_pair(ctx, slot));
+    if (!no_pair) RC(i == 2 ? launch_conv3_bwd_pair(ctx, slot) : launch_conv2_bwd_pair(ctx, slot));
   }
   return CPP_OK;
 }
