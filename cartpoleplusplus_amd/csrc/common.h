@@ -22,6 +22,7 @@ enum KernelId {
   K_HEADS,                // fused DDPG heads (heads.hip)
   K_CONV3_BWD,            // conv3's dW and dX in one launch (conv3_bwd_pair.hip)
   K_CONV2_BWD,            // conv2's dW and dX in one launch (conv2_bwd_pair.hip)
+  K_REDUCE_GATHER,        // the dW reductions of a minibatch + sample / statistics of the next one in one launch (replay.hip)
   K_NUM_KERNELS
 };
 
@@ -43,6 +44,8 @@ struct cpp_ctx {
   DwReduceDesc pending[DW_REDUCE_MAX];
   int npending;
   struct ConvPairSlot* pair;      // non-null: conv3's dW / dX launchers park their launch here instead of launching
+  const struct GatherArgs* ride;  // non-null: the next minibatch's sample + statistics kernel rides in the dW reduction's launch
+  bool ride_done; int ride_dtype;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -173,10 +176,13 @@ struct GatherArgs {
   float* out_action; float* out_reward; float* out_mask;
   double* part;                 // [2][B][2*C] per-row partial sums
   uint64_t seed; const uint64_t* counter;
+  int counter_add;              // the draw is keyed by *counter + counter_add (a gather that runs before the step that bumps the counter)
   const __half* lut;            // u8 store: f16(k / 255) for the 256 pixel codes
   long elems; int B; int size; int action_dim; int C;
 };
-int launch_gather_stats(cpp_ctx* ctx, const GatherArgs& a, int dtype);   // dtype of the store: CPP_F32 / CPP_F16 / CPP_U8 (gathers to f16)
+int launch_gather_stats(cpp_ctx* ctx, const GatherArgs& a, int dtype);
+struct DwReduceBatch;
+int launch_reduce_gather(cpp_ctx* ctx, const DwReduceBatch& rb, const GatherArgs& a, int dtype);      // f16 / u8 store; replay.hip   // dtype of the store: CPP_F32 / CPP_F16 / CPP_U8 (gathers to f16)
 int launch_u8_to_f16(cpp_ctx* ctx, __half* dst, const uint8_t* src, long n, const __half* lut);
 int launch_to_u8(cpp_ctx* ctx, uint8_t* dst, const void* src, int src_dtype, long n, const __half* lut, int* bad);
 int launch_replay_fill_u8(cpp_ctx* ctx, uint8_t* store, long total, uint64_t seed);

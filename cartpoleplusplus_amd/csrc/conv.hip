@@ -230,6 +230,10 @@ int flush_dw_reduce(cpp_ctx* ctx) {
     rb.block_start[i + 1] = rb.block_start[i] + (rb.d[i].nw + rb.d[i].nout + 63) / 64;
   }
   ctx->npending = 0;
+  if (ctx->ride && !ctx->ride_done) {                 // the next minibatch's sample + statistics pass shares the launch
+    ctx->ride_done = true;
+    return launch_reduce_gather(ctx, rb, *ctx->ride, ctx->ride_dtype);
+  }
   prof_begin(ctx);
   int rc = launch_dw_reduce_batch(ctx, rb);
   prof_end(ctx, K_DW_REDUCE);

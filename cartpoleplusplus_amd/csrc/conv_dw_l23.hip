@@ -7,36 +7,8 @@
 #define DWR_SLICES 16
 #endif
 __global__ __launch_bounds__(64 * DWR_SLICES) void conv_dw_reduce_kernel(const DwReduceBatch rb) {
-  constexpr int NS = DWR_SLICES;                     // slices of the partial list per output (each a chain of dependent load rounds)
-  __shared__ float red[NS][64];
-  int p = 0;
-  while (p + 1 < rb.n && (int)blockIdx.x >= rb.block_start[p + 1]) ++p;
-  const DwReduceDesc d = rb.d[p];
-  const int el = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  const int e = (blockIdx.x - rb.block_start[p]) * 64 + el;
-  const int n = d.nw + d.nout;
-  const int per = (d.nblocks + NS - 1) / NS;
-  const int b0 = slice * per, b1 = min(b0 + per, d.nblocks);
-  float s = 0.f;
-  if (e < n) {
-    int b = b0;
-    for (; b + 8 <= b1; b += 8) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = d.partial[(long)(b + u) * d.pstride + e];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
-    }
-    for (; b < b1; ++b) s += d.partial[(long)b * d.pstride + e];
-  }
-  red[slice][el] = s;
-  __syncthreads();
-  if (slice == 0 && e < n) {
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < NS; ++k) t += red[k][el];     // fixed order
-    if (e < d.nw) d.grad_w[e] = t; else d.grad_b[e - d.nw] = t;
-  }
+  __shared__ float red[DWR_SLICES][64];
+  conv_dw_reduce_body<DWR_SLICES>(rb, (int)blockIdx.x, red);
 }
 
 int launch_dw_reduce_batch(cpp_ctx* ctx, const DwReduceBatch& rb) {

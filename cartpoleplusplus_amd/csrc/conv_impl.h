@@ -658,6 +658,46 @@ __device__ __forceinline__ void conv_dw_body(const ConvArgsN& batch, const int b
 
 // second stage: grad[e] = sum_blocks partial[blk][e], fixed order (conv_dw_l23.hip)
 struct DwReduceBatch { DwReduceDesc d[DW_REDUCE_MAX]; int block_start[DW_REDUCE_MAX + 1]; int n; };
+
+// second stage of the conv dW kernels: 64 outputs x NS slices of the partial list per workgroup (64 NS threads); slices are
+// combined in fixed order.  One launch serves every queued (layer, network) reduction: workgroup -> (descriptor, output
+// block) via a prefix table.  `red`: [NS][64] floats of LDS.
+template <int NS, int TS = NS>      // NS slices of the partial list, walked by TS thread slices (64 TS threads): same sums for any TS
+__device__ __forceinline__ void conv_dw_reduce_body(const DwReduceBatch& rb, const int bx, float (*red)[64]) {
+  static_assert(NS % TS == 0, "whole slices per thread slice");
+  int p = 0;
+  while (p + 1 < rb.n && bx >= rb.block_start[p + 1]) ++p;
+  const DwReduceDesc d = rb.d[p];
+  const int el = threadIdx.x & 63, tslice = threadIdx.x >> 6;
+  const int e = (bx - rb.block_start[p]) * 64 + el;
+  const int n = d.nw + d.nout;
+  const int per = (d.nblocks + NS - 1) / NS;
+#pragma unroll
+  for (int q = 0; q < NS / TS; ++q) {
+    const int slice = tslice * (NS / TS) + q;
+    const int b0 = slice * per, b1 = min(b0 + per, d.nblocks);
+    float s = 0.f;
+    if (e < n) {
+      int b = b0;
+      for (; b + 8 <= b1; b += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = d.partial[(long)(b + u) * d.pstride + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; b < b1; ++b) s += d.partial[(long)b * d.pstride + e];
+    }
+    red[slice][el] = s;
+  }
+  __syncthreads();
+  if (tslice == 0 && e < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) t += red[k][el];     // fixed order
+    if (e < d.nw) d.grad_w[e] = t; else d.grad_b[e - d.nw] = t;
+  }
+}
 int launch_dw_reduce_batch(cpp_ctx* ctx, const DwReduceBatch& rb);
 
 template <int CIN, int KS, int XTW, int IN_MODE, int EPI>

@@ -9,7 +9,7 @@
 // v = lane (mod P), P = C / gcd(8, C), so the 8 elements of every vector it loads belong to the same 8
 // channels and the accumulators are plain registers.  Row partials leave the kernel in f64 and are
 // combined in fixed order by stats_finalize_kernel (deterministic).
-#include "common.h"
+#include "conv_impl.h"
 
 __device__ __forceinline__ int sample_row(uint64_t seed, uint64_t counter, int b, int size) {
   u32x4 c = {(uint32_t)b, 0u, (uint32_t)counter, (uint32_t)(counter >> 32)};
@@ -66,12 +66,12 @@ template <> __device__ __forceinline__ __half elem_convert<uint8_t, __half>(uint
 
 __host__ __device__ inline int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
 
+// (b, which): the workgroup's place in the (B, 2) grid -- blockIdx for a launch of its own
 template <typename T>
-__global__ __launch_bounds__(256) void gather_stats_kernel(const GatherArgs a) {
+__device__ __forceinline__ void gather_stats_body(const GatherArgs& a, const int b, const int which) {
   __shared__ float sh[256 * 16];
   __shared__ double dsh[CPP_MAX_CHANNELS * 16];
   __shared__ float lut[256];                      // CPP_U8 store: f16(k/255) as float
-  const int b = blockIdx.x, which = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr bool U8 = sizeof(T) == 1;
   if (U8) { lut[tid] = __half2float(a.lut[tid]); __syncthreads(); }
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(const GatherArgs a) {
   if (lane == 0) {
     if (a.s_idx[0] == nullptr) { row = b; slot = b; }       // statistics over an already gathered batch
     else {
-      row = a.rows ? a.rows[b] : sample_row(a.seed, a.counter ? *a.counter : 0, b, a.size);
+      row = a.rows ? a.rows[b] : sample_row(a.seed, (a.counter ? *a.counter : 0) + (uint64_t)a.counter_add, b, a.size);
       slot = a.s_idx[which][row];
     }
   }
@@ -163,6 +163,37 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(const GatherArgs a) {
     }
     a.part[((long)which * a.B + b) * 2 * C + tid] = acc;
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_stats_kernel(const GatherArgs a) {
+  gather_stats_body<T>(a, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// The dW reductions that end a minibatch's backward pass and the sample + statistics pass that starts the next minibatch in ONE
+// launch: the gather depends on nothing the step computes (its draw is keyed by the sampler's counter + 1), the reduction
+// is a latency chain on a handful of workgroups -- back to back they cost 8.8 + 19.8 us, together the longer of the two.
+// Workgroups [0, reduction blocks) reduce (4 slices of 64 lanes: its own fixed order, the same for every store type), the rest gather.
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_gather_kernel(const DwReduceBatch rb, const GatherArgs a) {
+  const int nred = rb.block_start[rb.n];
+  if ((int)blockIdx.x < nred) {
+    __shared__ float red[4][64];
+    conv_dw_reduce_body<4>(rb, (int)blockIdx.x, red);
+  } else {
+    const int i = (int)blockIdx.x - nred;
+    gather_stats_body<T>(a, i % a.B, i / a.B);
+  }
+}
+
+int launch_reduce_gather(cpp_ctx* ctx, const DwReduceBatch& rb, const GatherArgs& a, int dtype) {
+  prof_begin(ctx);
+  const dim3 grid(rb.block_start[rb.n] + 2 * a.B);
+  if (dtype == 2) hipLaunchKernelGGL(reduce_gather_kernel<uint8_t>, grid, dim3(256), 0, ctx->stream, rb, a);
+  else hipLaunchKernelGGL(reduce_gather_kernel<__half>, grid, dim3(256), 0, ctx->stream, rb, a);
+  LAUNCH_CHECK();
+  prof_end(ctx, K_REDUCE_GATHER);
+  return 0;
 }
 
 int launch_gather_stats(cpp_ctx* ctx, const GatherArgs& a, int dtype) {

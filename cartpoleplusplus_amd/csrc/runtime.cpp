@@ -57,7 +57,7 @@ void prof_end(cpp_ctx* ctx, int kid) {
 static const char* kKernelNames[K_NUM_KERNELS] = {
     "gather_stats", "stats_finalize", "stats_generic", "conv1_fwd", "conv2_fwd", "conv3_fwd",
     "conv1_dw", "conv2_dw", "conv3_dw", "conv2_dx", "conv3_dx", "dw_reduce", "gemm", "elementwise",
-    "td", "sumsq", "clip_sgd", "soft_update", "replay_fill", "naf_head", "conv1_fwd_f16x3", "conv1_dw_f16x3", "heads", "conv3_bwd", "conv2_bwd"};
+    "td", "sumsq", "clip_sgd", "soft_update", "replay_fill", "naf_head", "conv1_fwd_f16x3", "conv1_dw_f16x3", "heads", "conv3_bwd", "conv2_bwd", "reduce_gather"};
 
 // ---------------------------------------------------------------------------------------------
 // context
@@ -1146,9 +1146,9 @@ extern "C" int cpp_replay_read_states(cpp_replay* r, const int32_t* slots, int n
 }
 
 // device-only part of sampling (graph-capturable when rows_dev == nullptr or already resident)
-static int replay_sample_device(cpp_replay* r, int B, const int32_t* rows_dev, uint64_t seed, const uint64_t* counter_dev,
-                                int channels, cpp_batch* out, bool direct = false) {
-  cpp_ctx* ctx = r->ctx;
+// descriptor of the fused sample + gather + statistics pass into `out` (C_out: channels of the vector statistics path, 0: none)
+static GatherArgs replay_gather_args(cpp_replay* r, int B, const int32_t* rows_dev, uint64_t seed, const uint64_t* counter_dev,
+                                     int channels, cpp_batch* out, bool direct, int* C_out) {
   int C = channels;
   if (C > 0) {
     int g = 8, c = C; while (c) { int t = g % c; g = c; c = t; }
@@ -1165,15 +1165,26 @@ static int replay_sample_device(cpp_replay* r, int B, const int32_t* rows_dev, u
   a.out_action = out->a; a.out_reward = out->r; a.out_mask = out->m;
   a.part = out->part; a.seed = seed; a.counter = counter_dev;
   a.elems = r->elems; a.B = B; a.size = r->size; a.action_dim = r->A; a.C = C;
-  RC(launch_gather_stats(ctx, a, r->store_dtype));      // a CPP_U8 store gathers to f16 as well
+  *C_out = C;
+  return a;
+}
+// what follows the gather kernel: the batch's bookkeeping and the whitening tables
+static int replay_sample_finish(cpp_replay* r, int B, int C, int channels, cpp_batch* out) {
   out->B = B; out->dtype = CPP_F16; out->stats_C = 0;
   if (C > 0) {
-    RC(launch_stats_finalize(ctx, out->part, B, 2, C, (double)B * (double)(r->elems / C), out->white));
+    RC(launch_stats_finalize(r->ctx, out->part, B, 2, C, (double)B * (double)(r->elems / C), out->white));
     out->stats_C = C;
   } else if (channels > 0) {
     RC(batch_ensure_stats(out, channels));
   }
   return CPP_OK;
+}
+static int replay_sample_device(cpp_replay* r, int B, const int32_t* rows_dev, uint64_t seed, const uint64_t* counter_dev,
+                                int channels, cpp_batch* out, bool direct = false) {
+  int C = 0;
+  const GatherArgs a = replay_gather_args(r, B, rows_dev, seed, counter_dev, channels, out, direct, &C);
+  RC(launch_gather_stats(r->ctx, a, r->store_dtype));      // a CPP_U8 store gathers to f16 as well
+  return replay_sample_finish(r, B, C, channels, out);
 }
 
 extern "C" int cpp_replay_sample(cpp_replay* r, int B, const int32_t* idxs, uint64_t seed, uint64_t counter,
@@ -1701,11 +1712,33 @@ static bool direct_replay_ok(cpp_net* a, cpp_replay* r, int B) {
 
 static int step_body(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int32_t* rows_dev, uint64_t seed) {
   const int C = d->actor->spec.pixel ? d->actor->spec.C : 0;
+  cpp_ctx* ctx = d->ctx;
+  const bool direct = direct_replay_ok(d->actor, r, B);
+  // The sample + statistics pass of minibatch i + 1 depends on nothing minibatch i computes: it rides in the launch of i's
+  // dW reductions (reduce_gather_kernel, replay.hip), keyed by the sampler's counter + 1 -- the counter itself moves in i's
+  // optimiser kernel as before, so the rows drawn are the same.  Conv trunks on f16 / u8 stores; CPP_RIDE_GATHER=0: in sequence.
+  static const bool no_ride = getenv("CPP_RIDE_GATHER") != nullptr && atoi(getenv("CPP_RIDE_GATHER")) == 0;
+  const bool ride_ok = !no_ride && C > 0 && (r->store_dtype == CPP_F16 || r->store_dtype == CPP_U8);
+  RC(replay_sample_device(r, B, rows_dev, seed, rows_dev ? nullptr : r->counter, C, d->step_batch, direct));
   for (int i = 0; i < n_batches; ++i) {
-    RC(replay_sample_device(r, B, rows_dev ? rows_dev + (size_t)i * B : nullptr, seed, rows_dev ? nullptr : r->counter, C,
-                            d->step_batch, direct_replay_ok(d->actor, r, B)));
-    RC(compute_gradients(d, d->step_batch));
+    GatherArgs ga; int Cg = 0;
+    const bool more = i + 1 < n_batches;
+    if (more && ride_ok) {
+      ga = replay_gather_args(r, B, rows_dev ? rows_dev + (size_t)(i + 1) * B : nullptr, seed, rows_dev ? nullptr : r->counter, C,
+                              d->step_batch, direct, &Cg);
+      ga.counter_add = 1;
+      ctx->ride = &ga; ctx->ride_done = false; ctx->ride_dtype = r->store_dtype;
+    }
+    const int rc = compute_gradients(d, d->step_batch);
+    const bool rode = ctx->ride != nullptr && ctx->ride_done;
+    ctx->ride = nullptr;
+    RC(rc);
     RC(apply(d, true, true, 1.0f, rows_dev ? nullptr : r->counter));   // also advances the sampler's counter
+    if (more) {
+      if (rode) RC(replay_sample_finish(r, B, Cg, C, d->step_batch));
+      else RC(replay_sample_device(r, B, rows_dev ? rows_dev + (size_t)(i + 1) * B : nullptr, seed, rows_dev ? nullptr : r->counter, C,
+                                   d->step_batch, direct));
+    }
   }
   return cpp_ddpg_update_targets(d);
 }
