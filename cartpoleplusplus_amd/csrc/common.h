@@ -23,6 +23,7 @@ enum KernelId {
   K_CONV3_BWD,            // conv3's dW and dX in one launch (conv3_bwd_pair.hip)
   K_CONV2_BWD,            // conv2's dW and dX in one launch (conv2_bwd_pair.hip)
   K_REDUCE_GATHER,        // the dW reductions of a minibatch + sample / statistics of the next one in one launch (replay.hip)
+  K_CONV1_DW_GATHER,      // conv1 dW (f16 pipes) + sample / statistics of the next minibatch in one launch (conv1_dw_gather.hip)
   K_NUM_KERNELS
 };
 
@@ -46,6 +47,7 @@ struct cpp_ctx {
   struct ConvPairSlot* pair;      // non-null: conv3's dW / dX launchers park their launch here instead of launching
   const struct GatherArgs* ride;  // non-null: the next minibatch's sample + statistics kernel rides in the dW reduction's launch
   bool ride_done; int ride_dtype;
+  bool ride_at_dw;                // the rider may already leave with conv1's dW (its slots are double-buffered: direct replay)
 };
 
 // ---------------------------------------------------------------------------------------------

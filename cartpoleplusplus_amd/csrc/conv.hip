@@ -183,8 +183,10 @@ int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, co
   // conv1 of f16 images: f16 matrix pipes with f32-exact operands (conv_dw16.h); CPP_CONV_K16=0 keeps the f32 MFMA kernel
   static const bool no_k16 = getenv("CPP_CONV_K16") != nullptr && atoi(getenv("CPP_CONV_K16")) == 0;
   if (!no_kyo && !no_k16 && in_mode == IN_F16_WHITEN) {
+    const bool ride_open = ctx->ride != nullptr && !ctx->ride_done;
     rc = conv_dw16_dispatch(ctx, cin, ks, in_mode, dense, batch, &grid, &handled);
     if (handled) kid = kid == K_CONV1_DW ? K_CONV1_DW_F16X3 : kid;
+    if (handled && ride_open && ctx->ride_done) kid = K_CONV1_DW_GATHER;      // the next minibatch's sample pass left with it
   }
   // conv2 (f32 activations in): bf16 pipes, three exact pieces per operand (conv_dwb16.h); CPP_CONV_B16=0 keeps the f32 MFMA kernel
   static const bool no_b16 = getenv("CPP_CONV_B16") != nullptr && atoi(getenv("CPP_CONV_B16")) == 0;

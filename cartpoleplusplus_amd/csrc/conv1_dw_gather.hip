@@ -1,0 +1,36 @@
+// conv1 dW (f16 pipes, conv_dw16.h) of minibatch i and the sample + statistics pass of minibatch i + 1 in ONE launch.  The dW kernel
+// is bound by the matrix pipes and leaves HBM idle; its 1024 workgroups run as a full round of 768 and a second round that leaves
+// two of three slots per CU empty.  The gather's workgroups come last in the grid and fill those slots: 75 MB of HBM reads
+// under MFMA work instead of 20 us behind it.  The rider writes the other set of slot arrays (cpp_batch::slot_alt): conv1's
+// dW still reads the current minibatch's.  Its LDS is carved out of the dW kernel's dynamic allocation (a static array would
+// cost the dW kernel its third workgroup per CU).
+#include "conv_dw16.h"
+#include "gather_body.h"
+
+typedef Dw16Geom<18, 5, 2> DwgG;
+static_assert(DwgG::LDS_BYTES >= GATHER_LDS_BYTES, "the gather's LDS fits the dW kernel's allocation");
+
+__global__ __launch_bounds__(CONV_THREADS, DW16_WGS) void conv1_dw_gather_kernel(const ConvArgsN batch, int units_per_img, int band, int gx, const GatherArgs g) {
+  const int ndw = gx * batch.n;
+  if ((int)blockIdx.x < ndw) {
+    conv_dw16_body<18, 5, 2, false>(batch, units_per_img, band, (int)blockIdx.x % gx, (int)blockIdx.x / gx, gx);
+  } else {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    double* dsh = reinterpret_cast<double*>(lds_raw);
+    float* sh = reinterpret_cast<float*>(lds_raw + CPP_MAX_CHANNELS * 16 * 8);
+    float* lut = sh + 256 * 16;
+    const int i = (int)blockIdx.x - ndw;
+    gather_stats_body<__half>(g, i % g.B, i / g.B, sh, dsh, lut);
+  }
+}
+
+int launch_conv1_dw_gather(cpp_ctx* ctx, const ConvArgsN& batch, int upi, int band, int grid, size_t lds_bytes, const GatherArgs& g) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_CHECK(hipFuncSetAttribute((const void*)conv1_dw_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(conv1_dw_gather_kernel, dim3(grid * batch.n + 2 * g.B), dim3(CONV_THREADS), lds_bytes, ctx->stream, batch, upi, band, grid, g);
+  LAUNCH_CHECK();
+  return 0;
+}

@@ -52,8 +52,9 @@ struct Dw16Geom {
 #define DW16_WGS 3
 #endif
 // DENSE: dY comes as dense f32 rows (a.dy_dense: batch norm's dz) instead of being rebuilt from the pooled gradient
+// (bx, by, gx): the workgroup's place in a (gx, networks) grid (its own launch, or a slice of a shared one: conv1_dw_gather.hip)
 template <int CIN, int KS, int NCHK, bool DENSE = false>
-__global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 : DW16_WGS)) void conv_dw16_kernel(const ConvArgsN batch, int units_per_img, int band) {
+__device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units_per_img, int band, const int bx, const int by, const int gx) {
   typedef Dw16Geom<CIN, KS, NCHK> G;
   constexpr int P = G::P, NO = G::NO, MT = G::MT, CP = G::CP, NPC = G::NPC, ROWB = G::ROWB, DSLOT = G::DSLOT;
   static_assert((KS * NO + 15) / 16 == 4, "one column tile per wave");
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 
   const unsigned long long ce0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long cpro = 0, cloop = 0;
 #endif
-  const ConvArgs& a = batch.a[blockIdx.y];
+  const ConvArgs& a = batch.a[by];
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   unsigned char* inring = lds_raw;                                         // [3][ROWB]
   unsigned char* dyring = lds_raw + ((G::IN_BYTES + 15) & ~15);            // [6][DSLOT]
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 
   float sc, inv;
   {
     float vmax = 0.f;
-    for (int unit = blockIdx.x; unit < units; unit += gridDim.x) {
+    for (int unit = bx; unit < units; unit += gx) {
       const int b = unit / units_per_img;
       const int q_lo = (unit - b * units_per_img) * band;
       const int rows = min(band, H - q_lo);
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 
   const unsigned long long ce1 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-  for (int unit = blockIdx.x; unit < units; unit += gridDim.x) {
+  for (int unit = bx; unit < units; unit += gx) {
 #ifdef DW16_CLOCK
     const unsigned long long cu0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 
 #endif
   // ---- one partial per workgroup.  D tile mt holds rows m = 16 mt + 4 lj + r = CP kx + c', column n = (ky, o);
   // row c' = CIN of every kx is T: it goes through a wave-private LDS table, then dW = 2^-S (s_c G + t_c T)
-  float* part = a.partial + (long)blockIdx.x * a.pstride;
+  float* part = a.partial + (long)bx * a.pstride;
   const int nw = KS * G::KROW * nout;
   float* tx = texch + wave * (KS * 16);
   // whitening scale / shift through LDS: read per (tile, row) below (global loads there were a chain of L2 round trips:
@@ -432,9 +433,16 @@ __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 
     part[nw + tid] = s;
   }
 #ifdef DW16_CLOCK
-  if (tid == 0 && (blockIdx.x % 211) == 7 && blockIdx.y == 0) printf("DW16CLK block %d: setup %llu, units (prologue %llu) %llu, epilogue %llu ticks\n", (int)blockIdx.x, ce1 - ce0, cpro, ce2 - ce1, __builtin_amdgcn_s_memrealtime() - ce2);
+  if (tid == 0 && (bx % 211) == 7 && by == 0) printf("DW16CLK block %d: setup %llu, units (prologue %llu) %llu, epilogue %llu ticks\n", bx, ce1 - ce0, cpro, ce2 - ce1, __builtin_amdgcn_s_memrealtime() - ce2);
 #endif
 }
+
+template <int CIN, int KS, int NCHK, bool DENSE = false>
+__global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 : DW16_WGS)) void conv_dw16_kernel(const ConvArgsN batch, int units_per_img, int band) {
+  conv_dw16_body<CIN, KS, NCHK, DENSE>(batch, units_per_img, band, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+}
+// conv1 dW of the headline shape with the next minibatch's sample + statistics pass behind it in the same grid (conv1_dw_gather.hip)
+int launch_conv1_dw_gather(cpp_ctx* ctx, const ConvArgsN& batch, int upi, int band, int grid, size_t lds_bytes, const GatherArgs& g);
 
 template <int CIN, int KS, int NCHK, bool DENSE = false>
 static inline int conv_dw16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int* grid_out) {
@@ -456,6 +464,11 @@ static inline int conv_dw16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int* 
   const int upi = (a.H + band - 1) / band;
   const int units = a.B * upi;
   const int grid = units < capacity ? units : capacity;
+  if (ctx->ride && !ctx->ride_done && ctx->ride_at_dw && ctx->ride_dtype == 1 && CIN == 18 && KS == 5 && NCHK == 2 && !DENSE) {
+    ctx->ride_done = true;
+    *grid_out = grid;
+    return launch_conv1_dw_gather(ctx, batch, upi, band, grid, lds_bytes, *ctx->ride);
+  }
   hipLaunchKernelGGL(kern, dim3(grid, batch.n), dim3(CONV_THREADS), lds_bytes, ctx->stream, batch, upi, band);
   LAUNCH_CHECK();
   *grid_out = grid;

@@ -57,7 +57,7 @@ void prof_end(cpp_ctx* ctx, int kid) {
 static const char* kKernelNames[K_NUM_KERNELS] = {
     "gather_stats", "stats_finalize", "stats_generic", "conv1_fwd", "conv2_fwd", "conv3_fwd",
     "conv1_dw", "conv2_dw", "conv3_dw", "conv2_dx", "conv3_dx", "dw_reduce", "gemm", "elementwise",
-    "td", "sumsq", "clip_sgd", "soft_update", "replay_fill", "naf_head", "conv1_fwd_f16x3", "conv1_dw_f16x3", "heads", "conv3_bwd", "conv2_bwd", "reduce_gather"};
+    "td", "sumsq", "clip_sgd", "soft_update", "replay_fill", "naf_head", "conv1_fwd_f16x3", "conv1_dw_f16x3", "heads", "conv3_bwd", "conv2_bwd", "reduce_gather", "conv1_dw_gather"};
 
 // ---------------------------------------------------------------------------------------------
 // context
@@ -883,6 +883,7 @@ struct cpp_batch {
   // device-sampled minibatch that was NOT gathered: state k of row b is row slot[k][b] of direct_store (the replay store);
   // only the f16-pipe conv1 kernels can consume it (direct_store == nullptr: s[] holds the gathered copy)
   int32_t* slot[2]; const void* direct_store;
+  int32_t* slot_alt[2];   // the set the NEXT minibatch's sample pass writes while conv1's dW still reads slot[] (step_body)
   Arena arena;
 };
 
@@ -902,6 +903,7 @@ extern "C" int cpp_batch_create(cpp_ctx* ctx, int max_batch, int64_t state_elems
   if (!rc) rc = dalloc(b->arena, &b->part, (size_t)2 * max_batch * 2 * CPP_MAX_CHANNELS);
   b->direct_store = nullptr;
   for (int k = 0; k < 2 && !rc; ++k) rc = dalloc(b->arena, &b->slot[k], (size_t)max_batch);
+  for (int k = 0; k < 2 && !rc; ++k) rc = dalloc(b->arena, &b->slot_alt[k], (size_t)max_batch);
   if (rc) { b->arena.release(); delete b; return rc; }
   *out = b;
   return CPP_OK;
@@ -1727,11 +1729,17 @@ static int step_body(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int
       ga = replay_gather_args(r, B, rows_dev ? rows_dev + (size_t)(i + 1) * B : nullptr, seed, rows_dev ? nullptr : r->counter, C,
                               d->step_batch, direct, &Cg);
       ga.counter_add = 1;
+      // with the slots double-buffered the pass can leave as early as conv1's dW (MFMA-bound, HBM idle, and its second
+      // round of workgroups leaves the CUs half empty: conv1_dw_gather.hip); otherwise it waits for the dW reductions
+      static const bool no_dwride = getenv("CPP_RIDE_DW") != nullptr && atoi(getenv("CPP_RIDE_DW")) == 0;
+      ctx->ride_at_dw = direct && !no_dwride;
+      if (direct) { ga.out_slot[0] = d->step_batch->slot_alt[0]; ga.out_slot[1] = d->step_batch->slot_alt[1]; }
       ctx->ride = &ga; ctx->ride_done = false; ctx->ride_dtype = r->store_dtype;
     }
     const int rc = compute_gradients(d, d->step_batch);
     const bool rode = ctx->ride != nullptr && ctx->ride_done;
     ctx->ride = nullptr;
+    if (rode && direct) { std::swap(d->step_batch->slot[0], d->step_batch->slot_alt[0]); std::swap(d->step_batch->slot[1], d->step_batch->slot_alt[1]); }
     RC(rc);
     RC(apply(d, true, true, 1.0f, rows_dev ? nullptr : r->counter));   // also advances the sampler's counter
     if (more) {
