@@ -1245,10 +1245,10 @@ struct cpp_ddpg {
   int heads_grid, heads_B;                         // ... of the last graph built by compute_gradients (0: GEMM levels + td_kernel)
   int loss_parts, loss_B;                          // how cpp_ddpg_last_stats finds the loss of the last call: partials to add, or loss_norms[0]
   // graph replay of the full inner step
-  hipGraph_t graph; hipGraphExec_t gexec; bool graph_ok; int g_B, g_nb; uint64_t g_seed; cpp_replay* g_replay;
+  hipGraph_t graph; hipGraphExec_t gexec; bool graph_ok; int g_B, g_nb, g_size; uint64_t g_seed; cpp_replay* g_replay;   // g_size: rows in the replay when captured (the sampler's range is a kernel argument)
   cpp_batch* step_batch;
   // graph replay of the data-parallel half step (sample + both gradient sets)
-  hipGraph_t hgraph; hipGraphExec_t hexec; bool hgraph_ok; int h_B; uint64_t h_seed; cpp_replay* h_replay;
+  hipGraph_t hgraph; hipGraphExec_t hexec; bool hgraph_ok; int h_B, h_size; uint64_t h_seed; cpp_replay* h_replay;
   Arena arena;
 };
 
@@ -1768,7 +1768,7 @@ extern "C" int cpp_ddpg_train_step(cpp_ddpg* d, cpp_replay* r, int B, int n_batc
   }
   static const bool no_graph = getenv("CPP_NO_GRAPH") != nullptr;   // plain in-order stream launches (A/B measurements)
   if (ctx->prof || no_graph) return step_body(d, r, B, n_batches, nullptr, seed);
-  if (!d->graph_ok || d->g_B != B || d->g_nb != n_batches || d->g_seed != seed || d->g_replay != r) {
+  if (!d->graph_ok || d->g_B != B || d->g_nb != n_batches || d->g_seed != seed || d->g_replay != r || d->g_size != r->size) {
     if (d->gexec) { (void)hipGraphExecDestroy(d->gexec); d->gexec = nullptr; }
     if (d->graph) { (void)hipGraphDestroy(d->graph); d->graph = nullptr; }
     d->graph_ok = false;
@@ -1781,7 +1781,7 @@ extern "C" int cpp_ddpg_train_step(cpp_ddpg* d, cpp_replay* r, int B, int n_batc
     if (rc) return rc;
     if (e != hipSuccess) { cpp_set_error("hipStreamEndCapture -> %s", hipGetErrorString(e)); return CPP_ERR_HIP; }
     HIP_CHECK(hipGraphInstantiate(&d->gexec, d->graph, nullptr, nullptr, 0));
-    d->graph_ok = true; d->g_B = B; d->g_nb = n_batches; d->g_seed = seed; d->g_replay = r;
+    d->graph_ok = true; d->g_B = B; d->g_nb = n_batches; d->g_seed = seed; d->g_replay = r; d->g_size = r->size;
     return CPP_OK;   // the eager pass above was this call's step
   }
   HIP_CHECK(hipGraphLaunch(d->gexec, ctx->stream));
@@ -1805,7 +1805,7 @@ extern "C" int cpp_ddpg_sample_and_compute(cpp_ddpg* d, cpp_replay* r, int B, ui
   HIP_CHECK(hipSetDevice(ctx->device));
   if (!d->step_batch) RC(cpp_batch_create(ctx, d->maxB, r->elems, r->A, &d->step_batch));
   if (ctx->prof) return half_step_body(d, r, B, seed);
-  if (!d->hgraph_ok || d->h_B != B || d->h_seed != seed || d->h_replay != r) {
+  if (!d->hgraph_ok || d->h_B != B || d->h_seed != seed || d->h_replay != r || d->h_size != r->size) {
     if (d->hexec) { (void)hipGraphExecDestroy(d->hexec); d->hexec = nullptr; }
     if (d->hgraph) { (void)hipGraphDestroy(d->hgraph); d->hgraph = nullptr; }
     d->hgraph_ok = false;
@@ -1817,7 +1817,7 @@ extern "C" int cpp_ddpg_sample_and_compute(cpp_ddpg* d, cpp_replay* r, int B, ui
     if (rc) return rc;
     if (e != hipSuccess) { cpp_set_error("hipStreamEndCapture -> %s", hipGetErrorString(e)); return CPP_ERR_HIP; }
     HIP_CHECK(hipGraphInstantiate(&d->hexec, d->hgraph, nullptr, nullptr, 0));
-    d->hgraph_ok = true; d->h_B = B; d->h_seed = seed; d->h_replay = r;
+    d->hgraph_ok = true; d->h_B = B; d->h_seed = seed; d->h_replay = r; d->h_size = r->size;
     return CPP_OK;
   }
   HIP_CHECK(hipGraphLaunch(d->hexec, ctx->stream));
@@ -1849,7 +1849,7 @@ struct cpp_naf {
   float* gradbuf; float *m, *v;           // optimiser state over the same flat layout (Momentum / Adam)
   float *adv, *q, *td, *stats;            // stats: [0] loss [1] norm
   int* nonfinite; uint64_t* opt_step; double* norm_part;
-  hipGraph_t graph; hipGraphExec_t gexec; bool graph_ok; int g_B, g_nb; uint64_t g_seed; cpp_replay* g_replay;
+  hipGraph_t graph; hipGraphExec_t gexec; bool graph_ok; int g_B, g_nb, g_size; uint64_t g_seed; cpp_replay* g_replay;   // g_size: rows in the replay when captured (the sampler's range is a kernel argument)
   cpp_batch* step_batch;
   Arena arena;
 };
@@ -2187,7 +2187,7 @@ extern "C" int cpp_naf_train_step(cpp_naf* f, cpp_replay* r, int B, int n_batche
     return naf_step_body(f, r, B, n_batches, r->rows_in, seed);
   }
   if (ctx->prof) return naf_step_body(f, r, B, n_batches, nullptr, seed);
-  if (!f->graph_ok || f->g_B != B || f->g_nb != n_batches || f->g_seed != seed || f->g_replay != r) {
+  if (!f->graph_ok || f->g_B != B || f->g_nb != n_batches || f->g_seed != seed || f->g_replay != r || f->g_size != r->size) {
     if (f->gexec) { (void)hipGraphExecDestroy(f->gexec); f->gexec = nullptr; }
     if (f->graph) { (void)hipGraphDestroy(f->graph); f->graph = nullptr; }
     f->graph_ok = false;
@@ -2199,7 +2199,7 @@ extern "C" int cpp_naf_train_step(cpp_naf* f, cpp_replay* r, int B, int n_batche
     if (rc) return rc;
     if (e != hipSuccess) { cpp_set_error("hipStreamEndCapture -> %s", hipGetErrorString(e)); return CPP_ERR_HIP; }
     HIP_CHECK(hipGraphInstantiate(&f->gexec, f->graph, nullptr, nullptr, 0));
-    f->graph_ok = true; f->g_B = B; f->g_nb = n_batches; f->g_seed = seed; f->g_replay = r;
+    f->graph_ok = true; f->g_B = B; f->g_nb = n_batches; f->g_seed = seed; f->g_replay = r; f->g_size = r->size;
     return CPP_OK;
   }
   HIP_CHECK(hipGraphLaunch(f->gexec, ctx->stream));

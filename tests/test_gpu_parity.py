@@ -205,6 +205,34 @@ def test_graph_replay_is_deterministic_and_equals_eager():
     assert np.isfinite(params[0][0]).all() and np.isfinite(params[0][1]).all()
 
 
+def test_replayed_graph_samples_the_grown_replay_memory():
+    """the sampler's range (rows currently in the memory) is an argument of the captured sample kernel: when episodes have
+    been added since the capture, the next train step must draw from the whole memory, not replay the old range."""
+    import ctypes
+    from cartpoleplusplus_amd import _lib
+    shape, B = (16, 16, 3, 1, 2), 64
+    agent, _ref, _ = make_pair(shape, B, True, replay_size=700)
+    try:
+        rm = agent.replay_memory
+        rm.fill_synthetic(100, seed=3)
+        for _ in range(3):                                 # eager + capture + replay
+            agent.train_step(B, 2)
+        idxs = np.empty(B, np.int32)
+        _lib.check(_lib.lib.cpp_replay_last_indexes(rm.handle, B, idxs.ctypes.data_as(ctypes.c_void_p)))
+        assert idxs.min() >= 0 and idxs.max() < 100
+        rm.fill_synthetic(600, seed=3)
+        seen = []
+        for _ in range(3):
+            agent.train_step(B, 2)
+            _lib.check(_lib.lib.cpp_replay_last_indexes(rm.handle, B, idxs.ctypes.data_as(ctypes.c_void_p)))
+            seen.append(idxs.copy())
+        seen = np.concatenate(seen)
+        assert seen.min() >= 0 and seen.max() < 600
+        assert (seen >= 100).sum() > len(seen) // 2, seen    # ~5/6 of uniform draws over 600 rows
+    finally:
+        agent.close()
+
+
 def test_training_from_the_8_bit_replay_store_is_bit_identical():
     """--replay-store u8: the gathered minibatches are the same f16 bits, so whole training steps (device sampling,
     f16-pipe conv1 kernels, fused heads, updates) must leave exactly the same parameters as the f16 store."""
