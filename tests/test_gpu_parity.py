@@ -205,6 +205,33 @@ def test_graph_replay_is_deterministic_and_equals_eager():
     assert np.isfinite(params[0][0]).all() and np.isfinite(params[0][1]).all()
 
 
+def test_data_parallel_half_steps_equal_the_fused_step():
+    """the data-parallel learner's split step (cpp_ddpg_sample_and_compute -> [all-reduce] -> cpp_ddpg_apply_gradients, then
+    the target updates) at world size 1 must walk the same minibatches to the same parameters as the fused train step."""
+    from cartpoleplusplus_amd.distributed import DataParallelLearner, GradAllReducer, AgentOps
+    import torch
+    shape, B = (16, 16, 3, 1, 2), 16
+    params = []
+    for mode in ("fused", "dp"):
+        agent, _ref, _ = make_pair(shape, B, True, replay_size=300)
+        try:
+            agent.replay_memory.fill_synthetic(200, seed=11)
+            if mode == "fused":
+                for _ in range(5):
+                    agent.train_step(B, 3)
+            else:
+                from cartpoleplusplus_amd import ddpg_cartpole as D
+                learner = DataParallelLearner(AgentOps(agent, B, int(D.opts.sample_seed)), GradAllReducer(torch.zeros(1)))
+                for _ in range(5):
+                    learner.train_step(3)
+            agent.actor.ctx.sync()
+            params.append((agent.actor.get_params(), agent.critic.get_params(), agent.target_actor.get_params()))
+        finally:
+            agent.close()
+    for k in range(3):     # (the fused step's dW reductions may sum in 4 slices instead of 16: last-bit differences only)
+        assert np.abs(params[0][k] - params[1][k]).max() < 1e-6, float(np.abs(params[0][k] - params[1][k]).max())
+
+
 def test_replayed_graph_samples_the_grown_replay_memory():
     """the sampler's range (rows currently in the memory) is an argument of the captured sample kernel: when episodes have
     been added since the capture, the next train step must draw from the whole memory, not replay the old range."""
