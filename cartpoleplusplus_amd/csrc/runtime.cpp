@@ -1248,7 +1248,12 @@ struct cpp_ddpg {
   hipGraph_t graph; hipGraphExec_t gexec; bool graph_ok; int g_B, g_nb, g_size; uint64_t g_seed; cpp_replay* g_replay;   // g_size: rows in the replay when captured (the sampler's range is a kernel argument)
   cpp_batch* step_batch;
   // graph replay of the data-parallel half step (sample + both gradient sets)
-  hipGraph_t hgraph; hipGraphExec_t hexec; bool hgraph_ok; int h_B, h_size; uint64_t h_seed; cpp_replay* h_replay;
+  // three variants: 0 samples its own minibatch; 1 / 2 find it presampled (by the previous call's rider, conv1_dw_gather.hip)
+  // in the second / first set of slot arrays.  One key for all three.
+  hipGraph_t hgraph[3]; hipGraphExec_t hexec[3]; bool hgraph_ok[3]; int h_B, h_size; uint64_t h_seed; cpp_replay* h_replay;
+  int h_next[3];           // variant the call after variant v must use (0: the rider did not leave)
+  int pre_variant;         // variant of the next cpp_ddpg_sample_and_compute call if its key still matches (0: sample)
+  int32_t* slot_set[2][2]; // the two sets of slot arrays of step_batch
   Arena arena;
 };
 
@@ -1267,7 +1272,9 @@ extern "C" int cpp_ddpg_create(cpp_ctx* ctx, cpp_net* actor, cpp_net* critic, cp
   d->maxB = actor->maxB < critic->maxB ? actor->maxB : critic->maxB;
   d->nA = actor->nparams; d->nC = critic->nparams;
   d->graph = nullptr; d->gexec = nullptr; d->graph_ok = false; d->step_batch = nullptr; d->g_replay = nullptr;
-  d->hgraph = nullptr; d->hexec = nullptr; d->hgraph_ok = false; d->h_replay = nullptr;
+  for (int v = 0; v < 3; ++v) { d->hgraph[v] = nullptr; d->hexec[v] = nullptr; d->hgraph_ok[v] = false; d->h_next[v] = 0; }
+  d->h_replay = nullptr; d->pre_variant = 0; d->h_B = 0; d->h_size = 0; d->h_seed = 0;
+  memset(d->slot_set, 0, sizeof(d->slot_set));
   d->heads_grid = d->heads_B = d->loss_parts = d->loss_B = 0;
   const int A = actor->spec.action_dim;
   int rc = dalloc(d->arena, &d->gradbuf, (size_t)(d->nA + d->nC));
@@ -1292,8 +1299,10 @@ extern "C" int cpp_ddpg_destroy(cpp_ddpg* d) {
   (void)hipStreamSynchronize(d->ctx->stream);
   if (d->gexec) (void)hipGraphExecDestroy(d->gexec);
   if (d->graph) (void)hipGraphDestroy(d->graph);
-  if (d->hexec) (void)hipGraphExecDestroy(d->hexec);
-  if (d->hgraph) (void)hipGraphDestroy(d->hgraph);
+  for (int v = 0; v < 3; ++v) {
+    if (d->hexec[v]) (void)hipGraphExecDestroy(d->hexec[v]);
+    if (d->hgraph[v]) (void)hipGraphDestroy(d->hgraph[v]);
+  }
   if (d->step_batch) cpp_batch_destroy(d->step_batch);
   d->actor->grads = nullptr; d->critic->grads = nullptr;
   d->arena.release(); delete d; return CPP_OK;
@@ -1713,6 +1722,7 @@ static bool direct_replay_ok(cpp_net* a, cpp_replay* r, int B) {
 }
 
 static int step_body(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int32_t* rows_dev, uint64_t seed) {
+  d->pre_variant = 0;        // (the half steps' presampled minibatch lives in the same step_batch)
   const int C = d->actor->spec.pixel ? d->actor->spec.C : 0;
   cpp_ctx* ctx = d->ctx;
   const bool direct = direct_replay_ok(d->actor, r, B);
@@ -1789,11 +1799,33 @@ extern "C" int cpp_ddpg_train_step(cpp_ddpg* d, cpp_replay* r, int B, int n_batc
   return CPP_OK;
 }
 
-static int half_step_body(cpp_ddpg* d, cpp_replay* r, int B, uint64_t seed) {
+// variant 0: sample + gather + statistics of this call's minibatch; 1 / 2: it was presampled by the previous call's rider into
+// slot set 1 / 0 (only its whitening tables are still to do).  Every variant tries to send the NEXT minibatch's sample pass
+// along with conv1's dW (the sampler's counter has been advanced by then, so the rider draws with the counter as it stands);
+// *next: the variant the following call must use.  CPP_RIDE_DP=0: always variant 0, no rider.
+static int half_step_body(cpp_ddpg* d, cpp_replay* r, int B, uint64_t seed, int variant, int* next) {
   const int C = d->actor->spec.pixel ? d->actor->spec.C : 0;
-  RC(replay_sample_device(r, B, nullptr, seed, r->counter, C, d->step_batch, direct_replay_ok(d->actor, r, B)));
-  RC(launch_counter_add(d->ctx, r->counter, 1));
-  return compute_gradients(d, d->step_batch);
+  cpp_ctx* ctx = d->ctx;
+  cpp_batch* b = d->step_batch;
+  const bool direct = direct_replay_ok(d->actor, r, B);
+  static const bool no_ride = getenv("CPP_RIDE_DP") != nullptr && atoi(getenv("CPP_RIDE_DP")) == 0;
+  const int cur = variant == 1 ? 1 : 0;
+  for (int k = 0; k < 2; ++k) { b->slot[k] = d->slot_set[cur][k]; b->slot_alt[k] = d->slot_set[1 - cur][k]; }
+  int Cg = 0;
+  GatherArgs ga = replay_gather_args(r, B, nullptr, seed, r->counter, C, b, direct, &Cg);
+  if (variant == 0) RC(launch_gather_stats(ctx, ga, r->store_dtype));
+  RC(replay_sample_finish(r, B, Cg, C, b));
+  RC(launch_counter_add(ctx, r->counter, 1));
+  const bool ride_ok = !no_ride && direct && Cg > 0 && r->store_dtype == CPP_F16;
+  if (ride_ok) {
+    ga.out_slot[0] = b->slot_alt[0]; ga.out_slot[1] = b->slot_alt[1];
+    ctx->ride = &ga; ctx->ride_done = false; ctx->ride_dtype = r->store_dtype; ctx->ride_at_dw = true;
+  }
+  const int rc = compute_gradients(d, b);
+  const bool rode = ctx->ride != nullptr && ctx->ride_done;
+  ctx->ride = nullptr;
+  *next = rode ? (cur == 0 ? 1 : 2) : 0;
+  return rc;
 }
 
 extern "C" int cpp_ddpg_sample_and_compute(cpp_ddpg* d, cpp_replay* r, int B, uint64_t seed) {
@@ -1803,24 +1835,55 @@ extern "C" int cpp_ddpg_sample_and_compute(cpp_ddpg* d, cpp_replay* r, int B, ui
   if (r->size <= 0) { cpp_set_error("cpp_ddpg_sample_and_compute: replay memory is empty"); return CPP_ERR_STATE; }
   cpp_ctx* ctx = d->ctx;
   HIP_CHECK(hipSetDevice(ctx->device));
-  if (!d->step_batch) RC(cpp_batch_create(ctx, d->maxB, r->elems, r->A, &d->step_batch));
-  if (ctx->prof) return half_step_body(d, r, B, seed);
-  if (!d->hgraph_ok || d->h_B != B || d->h_seed != seed || d->h_replay != r || d->h_size != r->size) {
-    if (d->hexec) { (void)hipGraphExecDestroy(d->hexec); d->hexec = nullptr; }
-    if (d->hgraph) { (void)hipGraphDestroy(d->hgraph); d->hgraph = nullptr; }
-    d->hgraph_ok = false;
-    RC(half_step_body(d, r, B, seed));            // eager pass: sets kernel attributes, is this call's work
+  if (!d->step_batch) {
+    RC(cpp_batch_create(ctx, d->maxB, r->elems, r->A, &d->step_batch));
+    for (int k = 0; k < 2; ++k) { d->slot_set[0][k] = d->step_batch->slot[k]; d->slot_set[1][k] = d->step_batch->slot_alt[k]; }
+  }
+  if (d->slot_set[0][0] == nullptr)
+    for (int k = 0; k < 2; ++k) { d->slot_set[0][k] = d->step_batch->slot[k]; d->slot_set[1][k] = d->step_batch->slot_alt[k]; }
+  const bool key_ok = d->h_B == B && d->h_seed == seed && d->h_replay == r && d->h_size == r->size;
+  if (!key_ok) {                                     // another batch size / seed / memory, or rows were added: start over
+    for (int v = 0; v < 3; ++v) {
+      if (d->hexec[v]) { (void)hipGraphExecDestroy(d->hexec[v]); d->hexec[v] = nullptr; }
+      if (d->hgraph[v]) { (void)hipGraphDestroy(d->hgraph[v]); d->hgraph[v] = nullptr; }
+      d->hgraph_ok[v] = false;
+    }
+    d->pre_variant = 0;
+    d->h_B = B; d->h_seed = seed; d->h_replay = r; d->h_size = r->size;
+  }
+  const int v = d->pre_variant;
+  d->pre_variant = 0;                                // (stays 0 if anything below fails)
+  int next = 0;
+  if (ctx->prof) { RC(half_step_body(d, r, B, seed, v, &next)); d->pre_variant = next; return CPP_OK; }
+  if (!d->hgraph_ok[v]) {
+    // this call's work is done by the captured graph's first launch: an eager pass first would consume the presampled batch
+    // and leave another one behind.  Kernel attributes: set by the first eager variant-0 pass below.
+    if (v == 0) {
+      RC(half_step_body(d, r, B, seed, 0, &next));            // eager pass: sets kernel attributes, is this call's work
+      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+      int nx = 0;
+      int rc = half_step_body(d, r, B, seed, 0, &nx);
+      hipError_t e = hipStreamEndCapture(ctx->stream, &d->hgraph[0]);
+      if (rc) return rc;
+      if (e != hipSuccess) { cpp_set_error("hipStreamEndCapture -> %s", hipGetErrorString(e)); return CPP_ERR_HIP; }
+      HIP_CHECK(hipGraphInstantiate(&d->hexec[0], d->hgraph[0], nullptr, nullptr, 0));
+      d->hgraph_ok[0] = true; d->h_next[0] = nx;
+      d->pre_variant = next;
+      return CPP_OK;
+    }
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    int rc = half_step_body(d, r, B, seed);
-    hipError_t e = hipStreamEndCapture(ctx->stream, &d->hgraph);
+    int nx = 0;
+    int rc = half_step_body(d, r, B, seed, v, &nx);
+    hipError_t e = hipStreamEndCapture(ctx->stream, &d->hgraph[v]);
     if (rc) return rc;
     if (e != hipSuccess) { cpp_set_error("hipStreamEndCapture -> %s", hipGetErrorString(e)); return CPP_ERR_HIP; }
-    HIP_CHECK(hipGraphInstantiate(&d->hexec, d->hgraph, nullptr, nullptr, 0));
-    d->hgraph_ok = true; d->h_B = B; d->h_seed = seed; d->h_replay = r; d->h_size = r->size;
-    return CPP_OK;
+    HIP_CHECK(hipGraphInstantiate(&d->hexec[v], d->hgraph[v], nullptr, nullptr, 0));
+    d->hgraph_ok[v] = true; d->h_next[v] = nx;
   }
-  HIP_CHECK(hipGraphLaunch(d->hexec, ctx->stream));
+  HIP_CHECK(hipGraphLaunch(d->hexec[v], ctx->stream));
+  d->pre_variant = d->h_next[v];
   d->loss_parts = d->heads_grid; d->loss_B = d->heads_B;
   return CPP_OK;
 }
