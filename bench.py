@@ -8,15 +8,23 @@ clip + SGD for both nets, with both target soft updates after every 5th minibatc
 (ddpg_cartpole.py:331-337).  Inputs are resident in HBM when the timed region starts.
 
 Prints ONE JSON line (rank 0).  Besides the contract keys it carries
-  roofline     : the dominant kernel (conv1 forward) against the dense f32-MFMA peak, launch durations
-                 measured with HIP events on the stream the kernel runs on (a profiled pass of the same
-                 step sequence, run right after the timed region; the timed region itself is one hipGraph
-                 replay per 5 minibatches and cannot carry per-kernel events)
-  cpu_baseline : the oracle (numpy f32 restatement, BLAS-threaded) timed on this host on a bounded sample
+  roofline       : the dominant kernel (conv1 forward) against the matrix-pipe peak of the instruction it issues, launch
+                   durations measured with HIP events on the stream the kernel runs on (a profiled pass of the same step
+                   sequence, run right after the timed region; the timed region itself is one hipGraph replay per 5
+                   minibatches and cannot carry per-kernel events); `traffic` from the committed rocprofv3 PMC passes
+  layers         : every conv launch of the step: algorithmic GFLOP, microseconds, the pipe it runs on, fraction of that
+                   pipe's bound; `conv_bound_frac_whole_step` = sum of the per-layer bound times / step time
+  cpu_baseline   : the same minibatch update on this host's cores: torch-CPU restatement (oracle/ddpg_torch.py, the
+                   stand-in for the reference's TF-CPU kernels) -- and `cpu_baseline_numpy`, the numpy oracle
+  control        : the same step with conv1 / conv2 forced onto the f32-input MFMA kernels (ablation build of the library,
+                   CPP_CONV_K16=0 CPP_CONV_B16=0): the f32 twin of the f16x3 / bf16x9 numbers
+  extra          : short runs of the other BASELINE configs (cfg2, cfg4 = NAF, cfg5), steps/s each
+(N = 1, rank 0 only for the last three; --quick skips them.)
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,18 +34,25 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (state_shape (H, W, 3, cameras, repeats), batch)
-    "cfg3": ((64, 64, 3, 2, 3), 256),    # 64x64x18, B=256 -- the configuration the metric is quoted on
-    "cfg2": ((64, 64, 3, 1, 3), 256),    # 64x64x9
-    "cfg5": ((128, 128, 3, 2, 5), 512),  # 128x128x30, B=512 (BASELINE configs[4]; replay rows reduced, see REPLAY_ROWS_BY)
-    "r50": ((50, 50, 3, 2, 3), 256),     # the reference's default 50x50 render (exps/run_98.sh: 2 cameras, 3 repeats)
+    # name: (state_shape (H, W, 3, cameras, repeats), batch, agent)
+    "cfg3": ((64, 64, 3, 2, 3), 256, "ddpg"),    # 64x64x18, B=256 -- the configuration the metric is quoted on
+    "cfg2": ((64, 64, 3, 1, 3), 256, "ddpg"),    # 64x64x9
+    "cfg4": ((64, 64, 3, 2, 3), 256, "naf"),     # NAF, 64x64x18, shared conv trunk (BASELINE configs[3])
+    "cfg5": ((128, 128, 3, 2, 5), 512, "ddpg"),  # 128x128x30, B=512 (BASELINE configs[4]; replay rows: see REPLAY_ROWS_BY)
+    "r50": ((50, 50, 3, 2, 3), 256, "ddpg"),     # the reference's default 50x50 render (exps/run_98.sh: 2 cameras, 3 repeats)
 }
-REPLAY_ROWS_BY = {"cfg5": 6000}          # 9000 state slots x 983 KB = 8.8 GB (the 1e6-row memory of configs[4] is 1.47 TB / 8 GPUs)
+REPLAY_ROWS_BY = {"cfg5": 6000}          # 9000 state slots x 983 KB = 8.8 GB (--replay-rows overrides; 125 000 rows = one GPU's shard of configs[4])
 BATCHES_PER_STEP = 5                     # --batches-per-step default (ddpg_cartpole.py:30)
 REPLAY_ROWS = 22000                      # --replay-memory-size default (ddpg_cartpole.py:46)
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_F16_MFMA_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak
 CONV_DEFS = ((5, 10), (5, 10), (3, 10))
+# matrix pipe of a profiled kernel name -> (peak TFLOP/s for ALGORITHMIC flops, description)
+PIPES = {
+    "f16x3": (PEAK_F16_MFMA_TFLOPS / 3.0, "f16 MFMA, 3 exact f16 x f16 products per f32 product (2500 / 3)"),
+    "bf16x9": (PEAK_F16_MFMA_TFLOPS / 9.0, "bf16 MFMA, 9 exact bf16 x bf16 products per f32 product (2500 / 9)"),
+    "f32": (PEAK_F32_MFMA_TFLOPS, "f32-input MFMA"),
+}
 
 
 def conv_macs(shape):
@@ -53,27 +68,73 @@ def conv_macs(shape):
     return F, Bk, per_layer
 
 
-def cpu_baseline(shape, B, budget_s=12.0, max_reps=6):
-    """full-batch minibatch updates of the oracle (f32) on this host until ~budget_s of CPU work is done."""
-    from oracle import ddpg_np as O          # checker / baseline only
+def _host_threads():
     try:
         from threadpoolctl import threadpool_info
-        threads = max([d.get("num_threads", 1) for d in threadpool_info()] + [1])
+        return max([d.get("num_threads", 1) for d in threadpool_info()] + [1])
     except Exception:
-        threads = os.cpu_count() or 1
-    rng = np.random.default_rng(0)
+        return os.cpu_count() or 1
+
+
+def _oracle_agent(shape, rng):
+    from oracle import ddpg_np as O          # checker / baseline only
     kw = dict(pixel=True, H=shape[0], W=shape[1], C=int(np.prod(shape[2:])))
     aspec, cspec = O.NetSpec("actor", 2, [100, 100, 50], **kw), O.NetSpec("critic", 2, [], **kw)
-    agent = O.DDPG(aspec, cspec, O.init_params(aspec, rng), O.init_params(cspec, rng), np.float32)
+    return O, aspec, cspec, O.init_params(aspec, rng), O.init_params(cspec, rng)
+
+
+def cpu_baseline_numpy(shape, B, budget_s=10.0, max_reps=4):
+    """full-batch minibatch updates of the numpy oracle (f32) on this host until ~budget_s of CPU work is done."""
+    rng = np.random.default_rng(0)
+    O, aspec, cspec, af, cf = _oracle_agent(shape, rng)
+    agent = O.DDPG(aspec, cspec, af, cf, np.float32)
     batch = O.synthetic_batch(rng, B, shape, 2, True)
+    threads = _host_threads()
     reps, t0 = 0, time.time()
     while reps < max_reps and (reps == 0 or time.time() - t0 < budget_s):
         agent.train_minibatch(batch)
         reps += 1
     dt = time.time() - t0
-    return {"value": reps / dt, "unit": "steps/s", "cores": int(threads), "kind": "port",
+    return {"value": round(reps / dt, 4), "unit": "steps/s", "cores": int(threads), "kind": "port", "impl": "oracle/ddpg_np.py",
             "sample": "%d full minibatch update(s) (B=%d, same shapes as the GPU workload) of oracle/ddpg_np.py, "
                       "numpy f32 with OpenBLAS on %d threads, %.1f s wall" % (reps, B, threads, dt)}
+
+
+def cpu_baseline_torch(shape, B, budget_s=12.0, max_reps=40):
+    """the same update on torch's CPU kernels (oneDNN conv, autograd), all host cores: SURVEY 8(d)'s proxy for the
+    reference's TF-CPU path (TensorFlow 0.x cannot be installed)."""
+    import torch
+    from oracle.ddpg_torch import TorchDDPG   # baseline only
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    rng = np.random.default_rng(0)
+    O, aspec, cspec, af, cf = _oracle_agent(shape, rng)
+    agent = TorchDDPG(aspec, cspec, af, cf)
+    batch = O.synthetic_batch(rng, B, shape, 2, True)
+    agent.train_minibatch(batch)              # warm-up (thread pool, oneDNN primitive cache)
+    reps, t0 = 0, time.time()
+    while reps < max_reps and (reps == 0 or time.time() - t0 < budget_s):
+        agent.train_minibatch(batch)
+        reps += 1
+    dt = time.time() - t0
+    return {"value": round(reps / dt, 4), "unit": "steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "impl": "oracle/ddpg_torch.py (torch %s CPU: oneDNN convolutions + autograd) -- proxy for the reference's TF-CPU kernels" % torch.__version__,
+            "sample": "%d full minibatch update(s) after 1 warm-up (B=%d, same shapes as the GPU workload), float32, "
+                      "torch.set_num_threads(%d), %.1f s wall" % (reps, B, cores, dt)}
+
+
+def sub_bench(extra_args, env=None, timeout=420):
+    """one more bench.py process (another workload, or the ablation library); returns its parsed JSON line or an error."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--quick"] + list(extra_args)
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, **(env or {})), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=timeout)
+        lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": "rc %d: %s" % (r.returncode, r.stderr.decode()[-300:])}
+        return json.loads(lines[-1])
+    except Exception as e:      # noqa: BLE001 -- a failed side run must not take the headline line with it
+        return {"error": repr(e)}
 
 
 def main():
@@ -82,12 +143,15 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--replay-rows", type=int, default=0, help="rows of the replay shard (default: 22000; cfg5: 6000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick", action="store_true", help="headline + roofline only: no cpu baseline, control or extra runs")
     ap.add_argument("--profile-steps", type=int, default=10, help="minibatches of the per-kernel HIP-event pass")
     ap.add_argument("--use-batch-norm", action="store_true", help="informational: the networks of exps/run_8x / run_9x (--use-batch-norm)")
     ap.add_argument("--replay-store", default="f16", choices=["f16", "u8"],
                     help="informational: u8 = the 8-bit replay store (same batches, half the gather reads)")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel learner path (RCCL all-reduce) even at world size 1")
+    ap.add_argument("--sync-every", type=int, default=1, help="data-parallel: k local minibatches between parameter averagings (1: gradient all-reduce per minibatch)")
     args = ap.parse_args()
 
     # keep real stdout for the ONE JSON line: RCCL / libraries print banners to fd 1
@@ -102,8 +166,8 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                      % (args.gpus, args.gpus))
-    shape, B = WORKLOADS[args.workload]
-    replay_rows = REPLAY_ROWS_BY.get(args.workload, REPLAY_ROWS)
+    shape, B, kind = WORKLOADS[args.workload]
+    replay_rows = args.replay_rows or REPLAY_ROWS_BY.get(args.workload, REPLAY_ROWS)
 
     import torch
     torch.cuda.set_device(local_rank)
@@ -114,8 +178,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from cartpoleplusplus_amd import _lib, ddpg_cartpole as D
-    from cartpoleplusplus_amd.distributed import GradAllReducer, DataParallelLearner, AgentOps
+    from cartpoleplusplus_amd import _lib
 
     stream = torch.cuda.Stream(device=local_rank)
     ctx = _lib.Context(local_rank, stream=stream.cuda_stream)
@@ -126,11 +189,18 @@ def main():
             def __init__(self, s): self.shape = tuple(s)
         observation_space, action_space = S(shape), S((1, 2))
 
-    D.set_opts(D.default_opts(use_raw_pixels=True, render_height=shape[0], render_width=shape[1],
-                              num_cameras=shape[3], action_repeats=shape[4], batch_size=B,
-                              replay_memory_size=replay_rows, sample_seed=1234 + rank,
-                              use_batch_norm=bool(args.use_batch_norm), replay_store=args.replay_store))
-    agent = D.DeepDeterministicPolicyGradientAgent(Env())
+    common = dict(use_raw_pixels=True, render_height=shape[0], render_width=shape[1], num_cameras=shape[3],
+                  action_repeats=shape[4], batch_size=B, replay_memory_size=replay_rows,
+                  use_batch_norm=bool(args.use_batch_norm), replay_store=args.replay_store)
+    if kind == "ddpg":
+        from cartpoleplusplus_amd import ddpg_cartpole as D
+        D.set_opts(D.default_opts(sample_seed=1234 + rank, **common))
+        agent = D.DeepDeterministicPolicyGradientAgent(Env())
+    else:       # NAF on the shared trunk, Momentum as in exps/run_93.sh
+        from cartpoleplusplus_amd import naf_cartpole as D
+        D.set_opts(D.default_opts(share_input_state_representation=True, optimiser="Momentum",
+                                  optimiser_args=json.dumps({"learning_rate": 0.01, "momentum": 0.9}), **common))
+        agent = D.NormalizedAdvantageFunctionAgent(Env())
     agent.initialise_variables(seed=42)                 # identical replicas on every rank
     agent.post_var_init_setup()
     agent.replay_memory.fill_synthetic(replay_rows, seed=1234 + rank)   # own replay shard per learner
@@ -138,22 +208,24 @@ def main():
     groups, tail = divmod(args.steps, BATCHES_PER_STEP)
     wgroups = max(1, -(-args.warmup // BATCHES_PER_STEP))
 
+    learner = None
     if not use_dp:
         def run(g, t):
             for _ in range(g):
                 agent.train_step(B, BATCHES_PER_STEP)
             if t:
                 agent.train_step(B, t)
+        parallelism = "single learner: fused inner step (one hipGraph replay per %d minibatches), no collective" % BATCHES_PER_STEP
     else:
-        reducer = GradAllReducer.for_trainer(agent.trainer, stream)
-        reducer.always = args.force_dp
-        learner = DataParallelLearner(AgentOps(agent, B, 1234 + rank), reducer)
+        from cartpoleplusplus_amd.distributed import make_learner
+        learner = make_learner(agent, B, seed=1234 + rank, sync_every=args.sync_every, always=args.force_dp)
 
         def run(g, t):
             for _ in range(g):
                 learner.train_step(BATCHES_PER_STEP)
             if t:
                 learner.train_step(t)
+        parallelism = learner.describe()
 
     def full_sync():
         ctx.sync()
@@ -177,7 +249,7 @@ def main():
     ms_per_step = 1e3 * elapsed / steps
     value = world * steps / elapsed
 
-    # ---- per-kernel HIP-event pass (rank 0 reports) -> roofline of the dominant kernel
+    # ---- per-kernel HIP-event pass (rank 0 reports) -> roofline of the dominant kernel, per-layer table
     ctx.prof_reset()
     ctx.prof_enable(True)
     pgroups = max(1, args.profile_steps // BATCHES_PER_STEP)
@@ -189,71 +261,123 @@ def main():
     pm = pgroups * BATCHES_PER_STEP
 
     F, Bk, per_layer = conv_macs(shape)
-    conv_flops_step = 2.0 * B * (4 * F + 2 * Bk)
-    # a step runs conv1 forward for 4 networks (actor, critic, both targets) and conv1 dW for 2 (actor, critic); the
-    # fused step batches them into one launch each (blockIdx.y = network), each over the whole minibatch.
-    # conv1_fwd_f16x3: the same algorithmic FLOPs on the f16 pipes, three exact f16 products per f32 product
-    # (csrc/conv_k16.h) -> its peak is the dense f16 peak / 3.
-    def roof(name, nets, peak, basis):
-        ms, n = prof.get(name, (0.0, 0))
+    nfwd, nbwd = (4, 2) if kind == "ddpg" else (2, 1)      # trunks per minibatch (NAF shared trunk: value on s1, target on s2)
+    conv_flops_step = 2.0 * B * (nfwd * F + nbwd * Bk)
+    gf = lambda macs, nets: 2.0 * B * macs * nets          # algorithmic FLOPs of one launch over the whole minibatch
+
+    # One row per conv launch of the fused step.  A row may be served by several profiled kernel names (the same kernel with
+    # and without the next minibatch's sample pass riding along: conv1_dw_f16x3 / conv1_dw_gather): their times and launches
+    # are merged, and the FLOPs per launch are a constant of the launch (2 * B * MACs * networks), never derived from counts.
+    # parts: [(algorithmic flops per launch, pipe)] -- a paired launch (dW + dX) is bounded by the sum of its parts' times.
+    def row(label, names, parts):
+        ms = sum(prof.get(n, (0.0, 0))[0] for n in names)
+        n = sum(prof.get(n, (0.0, 0))[1] for n in names)
         if n == 0:
             return None
-        per_launch = 2.0 * B * per_layer[0] * nets * pm / n
-        avg = ms / n
-        ach = per_launch / (avg * 1e-3) / 1e12
-        return {"bound": "mfma", "kernel": name, "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "peak_basis": basis, "flops_per_launch": per_launch,
-                "avg_launch_ms": round(avg, 5), "launches": int(n), "networks_per_launch": nets * pm / n,
-                "ms_per_step": ms / pm}
-    roofs = [r for r in (
-        roof("conv1_fwd", 4.0, PEAK_F32_MFMA_TFLOPS, "dense f32-input MFMA peak"),
-        roof("conv1_fwd_f16x3", 4.0, PEAK_F16_MFMA_TFLOPS / 3.0,
-             "dense f16 MFMA peak / 3: every f32 product is three exact f16 x f16 products accumulated in f32"),
-        roof("conv1_dw", 2.0, PEAK_F32_MFMA_TFLOPS, "dense f32-input MFMA peak"),
-        roof("conv1_dw_f16x3", 2.0, PEAK_F16_MFMA_TFLOPS / 3.0,
-             "dense f16 MFMA peak / 3: every f32 product is three exact f16 x f16 products accumulated in f32")) if r]
-    roofs.sort(key=lambda r: -r["ms_per_step"])
+        avg_us = 1e3 * ms / n
+        flops = sum(p[0] for p in parts)
+        bound_us = sum(1e6 * p[0] / (PIPES[p[1]][0] * 1e12) for p in parts)
+        return {"layer": label, "kernels": [k for k in names if k in prof], "launches_per_step": round(n / pm, 2),
+                "gflop_per_launch": round(flops / 1e9, 3), "avg_launch_us": round(avg_us, 2), "us_per_step": round(1e3 * ms / pm, 2),
+                "pipe": "+".join(p[1] for p in parts), "achieved_tflops": round(flops / (avg_us * 1e-6) / 1e12, 2),
+                "bound_us": round(bound_us, 2), "frac": round(bound_us / avg_us, 4)}
+    L1, L2, L3 = per_layer
+    nb = nbwd
+    rows = [r for r in (
+        row("conv1 forward", ["conv1_fwd_f16x3"], [(gf(L1, nfwd), "f16x3")]),
+        row("conv1 forward (f32 MFMA)", ["conv1_fwd"], [(gf(L1, nfwd), "f32")]),
+        row("conv1 dW", ["conv1_dw_f16x3", "conv1_dw_gather"], [(gf(L1, nb), "f16x3")]),
+        row("conv1 dW (f32 MFMA)", ["conv1_dw"], [(gf(L1, nb), "f32")]),
+        row("conv2 forward", ["conv2_fwd"], [(gf(L2, nfwd), "bf16x9" if "conv1_fwd_f16x3" in prof else "f32")]),
+        row("conv2 dW + dX", ["conv2_bwd"], [(gf(L2, nb), "bf16x9"), (gf(L2, nb), "f32")]),
+        row("conv2 dW", ["conv2_dw"], [(gf(L2, nb), "f32")]),
+        row("conv2 dX", ["conv2_dx"], [(gf(L2, nb), "f32")]),
+        row("conv3 forward", ["conv3_fwd"], [(gf(L3, nfwd), "f32")]),
+        row("conv3 dW + dX", ["conv3_bwd"], [(gf(L3, nb), "f32"), (gf(L3, nb), "f32")]),
+        row("conv3 dW", ["conv3_dw"], [(gf(L3, nb), "f32")]),
+        row("conv3 dX", ["conv3_dx"], [(gf(L3, nb), "f32")])) if r]
+    for r in rows:
+        assert r["frac"] <= 1.0, "roofline accounting error: %r" % (r,)
+    conv_us = sum(r["us_per_step"] for r in rows)
+    bound_us_step = sum(r["bound_us"] * r["launches_per_step"] for r in rows)
     kernels = {k: {"ms_per_step": round(v[0] / pm, 4), "launches_per_step": round(v[1] / pm, 2)}
                for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+    other_us = 1e3 * sum(v[0] for v in prof.values()) / pm - conv_us
 
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; they come from
-    # separate rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
-    # committed under profiles/
-    traffic, traffic_src = None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
-            pmc = json.load(f)
-        if args.workload == "cfg3":
-            traffic = pmc["kernels"][roofs[0]["kernel"]]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, bytes per launch)"
-    except Exception:
-        pass
+    dom = max(rows, key=lambda r: r["us_per_step"]) if rows else None
+    roofline = None
+    if dom:
+        pipe = dom["pipe"].split("+")[0]
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; they come from separate
+        # rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), committed under profiles/
+        traffic, traffic_src = None, None
+        for rnd in ("r02", "r01"):
+            try:
+                with open(os.path.join(ROOT, "profiles", "%s_pmc.json" % rnd)) as f:
+                    pmc = json.load(f)
+                if args.workload == "cfg3" and dom["kernels"][0] in pmc["kernels"]:
+                    traffic = pmc["kernels"][dom["kernels"][0]]["hbm_bytes_per_launch"]
+                    traffic_src = "profiles/%s_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, bytes per launch)" % rnd
+                    break
+            except Exception:
+                pass
+        roofline = {"bound": "mfma", "kernel": dom["kernels"][0], "layer": dom["layer"], "achieved": dom["achieved_tflops"],
+                    "peak": round(PIPES[pipe][0], 1), "unit": "TFLOP/s", "frac": dom["frac"], "peak_basis": PIPES[pipe][1],
+                    "flops_per_launch": dom["gflop_per_launch"] * 1e9, "avg_launch_ms": round(dom["avg_launch_us"] / 1e3, 5),
+                    "launches_per_step": dom["launches_per_step"], "traffic": traffic, "traffic_source": traffic_src}
 
+    ch = int(np.prod(shape[2:]))
     out = {
-        "metric": "DDPG training steps/sec, %dx%dx%d pixel obs, batch=%d" % (shape[0], shape[1], int(np.prod(shape[2:])), B),
+        "metric": "%s training steps/sec, %dx%dx%d pixel obs, batch=%d" % ("DDPG" if kind == "ddpg" else "NAF", shape[0], shape[1], ch, B),
         "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": wgroups * BATCHES_PER_STEP,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "dtype_note": "f32 accumulation everywhere; where the kernel list shows *_f16x3, conv1 multiplies exact f16 operands (the replay "
-                      "store's pixels x three-piece f16 splits of the f32 weights / gradients) on the f16 MFMA pipes: every product exact, "
-                      "results within f32 rounding of the f32-MFMA kernels (DESIGN.md 4, 6; CPP_CONV_K16=0 selects those)",
-        "config": {"workload": "%s: DDPG pixel obs %dx%dx%d, batch=%d per GPU, replay %d rows/GPU in HBM (%s), "
+        "timed_region_ms": round(1e3 * elapsed, 2),
+        "dtype_note": "f32 accumulation everywhere; conv1 multiplies exact f16 operands (the replay store's pixels x three-piece f16 "
+                      "splits of the f32 weights / gradients), conv2 forward / dW three-piece bf16 splits of both f32 operands with all "
+                      "nine products: every product exact, results within f32 rounding of the f32-MFMA kernels (DESIGN.md 4, 6; see `control`)",
+        "config": {"workload": "%s: %s pixel obs %dx%dx%d, batch=%d per GPU, replay %d rows/GPU in HBM (%s), "
                                "target soft-update every %d minibatches%s" % (
-                                   args.workload, shape[0], shape[1], int(np.prod(shape[2:])), B, replay_rows, args.replay_store,
-                                   BATCHES_PER_STEP, ", --use-batch-norm" if args.use_batch_norm else ""),
-                   "parallelism": "dp%d (one learner per GPU, flat-gradient all-reduce per minibatch)" % world,
+                                   args.workload, "DDPG" if kind == "ddpg" else "NAF (shared trunk, Momentum)", shape[0], shape[1], ch, B,
+                                   replay_rows, args.replay_store, BATCHES_PER_STEP, ", --use-batch-norm" if args.use_batch_norm else ""),
+                   "parallelism": parallelism,
                    "global_steps_per_sec": round(steps / elapsed, 3),
                    "conv_gflop_per_step": round(conv_flops_step / 1e9, 3),
-                   "conv_roofline_frac_whole_step": round(conv_flops_step * steps / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                   "conv_roofline_frac_basis": "algorithmic conv FLOPs of the whole step / 157.3 TFLOP/s (f32-input MFMA peak)"},
-        "roofline": dict(roofs[0], traffic=traffic, traffic_source=traffic_src) if roofs else None,
-        "roofline_next": roofs[1:],
+                   "conv_bound_frac_whole_step": round(bound_us_step / (1e3 * ms_per_step), 4),
+                   "conv_bound_frac_basis": "sum over the conv launches of (algorithmic FLOPs / peak of the pipe the launch runs on) / measured "
+                                            "step time; pipes: " + "; ".join("%s = %.1f TFLOP/s (%s)" % (k, v[0], v[1]) for k, v in PIPES.items())},
+        "roofline": roofline,
+        "layers": rows,
+        "non_conv_us_per_step": round(other_us, 2),
         "kernels": kernels,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(shape, B)
-    elif rank == 0:
+    side = rank == 0 and world == 1 and not args.quick
+    if side and not args.no_cpu_baseline and kind == "ddpg":
+        out["cpu_baseline"] = cpu_baseline_torch(shape, B)
+        out["cpu_baseline_numpy"] = cpu_baseline_numpy(shape, B)
+        out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+    else:
         out["cpu_baseline"] = None
+    if learner is not None:
+        learner.close()
+    agent.close()
+    ctx.close()
+    if side and args.workload == "cfg3" and not args.use_batch_norm:
+        # the f32 twin of the headline: conv1 / conv2 on the f32-input MFMA kernels (ablation build of the library)
+        c = sub_bench(["--steps", "100", "--warmup", "10", "--workload", args.workload],
+                      env={"CARTPOLEPP_ABLATION": "1", "CPP_CONV_K16": "0", "CPP_CONV_B16": "0"})
+        out["control"] = {"what": "same step, conv1 and conv2 on the f32-input MFMA kernels (v_mfma_f32_16x16x4_f32 only)",
+                          "switches": "CARTPOLEPP_ABLATION=1 CPP_CONV_K16=0 CPP_CONV_B16=0 (libcartpolepp_hip_ablation.so)",
+                          "value": c.get("value"), "unit": "steps/s", "ms_per_step": c.get("ms_per_step"),
+                          "layers": [{k: r[k] for k in ("layer", "avg_launch_us", "pipe", "frac")} for r in c.get("layers", [])],
+                          "error": c.get("error")}
+        extra = {}
+        for wl, st in (("cfg2", 100), ("cfg4", 100), ("cfg5", 30)):
+            e = sub_bench(["--steps", str(st), "--warmup", "10", "--workload", wl])
+            extra[wl] = {"metric": e.get("metric"), "value": e.get("value"), "unit": "steps/s", "ms_per_step": e.get("ms_per_step"),
+                         "steps": e.get("steps"), "workload": (e.get("config") or {}).get("workload"),
+                         "roofline_frac": (e.get("roofline") or {}).get("frac"), "error": e.get("error")}
+        out["extra"] = extra
     sys.stdout.flush()
     try:                                   # RCCL's banner sits in the C stdio buffer: flush it to the redirected fd first
         import ctypes
@@ -264,7 +388,6 @@ def main():
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
-    agent.close()
     if use_dp:
         dist.destroy_process_group()
 

@@ -98,6 +98,7 @@ SIGNATURES = {
     "cpp_ddpg_train_step": (_I, [_P, _P, _I, _I, _P, _U64]),
     "cpp_ddpg_sample_and_compute": (_I, [_P, _P, _I, _U64]),
     "cpp_ddpg_last_stats": (_I, [_P, _P]),
+    "cpp_ddpg_last_values": (_I, [_P, _I, _P, _P, _P, _P]),
     "cpp_naf_create": (_I, [_P, _P, _P, _P, _P, _I, C.POINTER(NafHyper), _PP]),
     "cpp_naf_destroy": (_I, [_P]),
     "cpp_naf_action": (_I, [_P, _P, _I, _I, _P]),

@@ -6,6 +6,18 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Run-time kernel-selection switches (CPP_CONV_K16=0, CPP_FUSED_HEADS=0, ...) exist only in the ablation build
+// (-DCPP_ABLATION -> libcartpolepp_hip_ablation.so: A/B measurements and the parity tests of the fallback kernels).
+// The release library reads no environment variable: every switch below is a compile-time `false`.
+#ifdef CPP_ABLATION
+#include <cstdlib>
+inline bool cpp_switch_off(const char* name) { const char* v = getenv(name); return v != nullptr && atoi(v) == 0; }
+inline bool cpp_switch_set(const char* name) { return getenv(name) != nullptr; }
+#else
+constexpr bool cpp_switch_off(const char*) { return false; }
+constexpr bool cpp_switch_set(const char*) { return false; }
+#endif
+
 #define CPP_NOUT_MAX 16       // one MFMA N tile; the reference hard-codes 10 filters (base_network.py:103)
 #define CPP_MAX_CHANNELS 64
 

@@ -36,8 +36,8 @@ static void set_tiles(ConvArgs& a, int cin, int xtw) {
 }
 
 bool conv1_f16_pipes_ok(int cin, int H, int W, int B, bool batch_norm) {
-  static const bool off = (getenv("CPP_CONV_K16") != nullptr && atoi(getenv("CPP_CONV_K16")) == 0) ||
-                          (getenv("CPP_CONV_KYO") != nullptr && atoi(getenv("CPP_CONV_KYO")) == 0);
+  static const bool off = cpp_switch_off("CPP_CONV_K16") ||
+                          cpp_switch_off("CPP_CONV_KYO");
   if (off || B < 2 || H < 4) return false;
   ConvArgsN q; memset(&q, 0, sizeof(q));
   q.n = 1; q.a[0].H = H; q.a[0].W = W; q.a[0].B = B; q.a[0].nout = KYO_NO; q.a[0].in_bstride = (long)H * W * cin;
@@ -50,9 +50,9 @@ bool conv1_f16_pipes_ok(int cin, int H, int W, int B, bool batch_norm) {
 }
 
 bool conv12_b16_ok(int cin, int H, int W, int B) {
-  static const bool off = (getenv("CPP_CONV_K16") != nullptr && atoi(getenv("CPP_CONV_K16")) == 0) ||
-                          (getenv("CPP_CONV_KYO") != nullptr && atoi(getenv("CPP_CONV_KYO")) == 0) ||
-                          (getenv("CPP_CONV_B16") != nullptr && atoi(getenv("CPP_CONV_B16")) == 0);
+  static const bool off = cpp_switch_off("CPP_CONV_K16") ||
+                          cpp_switch_off("CPP_CONV_KYO") ||
+                          cpp_switch_off("CPP_CONV_B16");
   if (off || B < 2 || H < 4 || (H & 1) || (W & 1)) return false;
   ConvArgsN q; memset(&q, 0, sizeof(q));
   q.n = 1; q.a[0].H = H; q.a[0].W = W; q.a[0].B = B; q.a[0].nout = KYO_NO; q.a[0].in_bstride = (long)H * W * cin;
@@ -83,7 +83,7 @@ int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, i
   int rc;
   // (ky,o)-column kernel: the default for the pooled forward layers whose rows can be staged as aligned 16-byte
   // chunks (CPP_CONV_KYO=0 selects the (ky,(kx,c)) x o kernel for A/B measurements)
-  static const bool no_kyo = getenv("CPP_CONV_KYO") != nullptr && atoi(getenv("CPP_CONV_KYO")) == 0;
+  static const bool no_kyo = cpp_switch_off("CPP_CONV_KYO");
   const bool dx_mode = in_mode == IN_DY || in_mode == IN_F32_FLIP;      // dX passes: plain rows out
   const bool plain_fwd = epi == EPI_PLAIN && !dx_mode;                   // batch norm: plain conv output
   bool kyo = !no_kyo && a.nout <= 10 && a.H >= 2;
@@ -93,11 +93,11 @@ int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, i
     if (c == 0) kyo = false; else if (c < chb) chb = c;
   }
   // CPP_CONV_KYO23=0 keeps the narrow layers (conv2 / conv3) on the old kernel
-  static const bool no_kyo23 = getenv("CPP_CONV_KYO23") != nullptr && atoi(getenv("CPP_CONV_KYO23")) == 0;
+  static const bool no_kyo23 = cpp_switch_off("CPP_CONV_KYO23");
   if ((in_mode == IN_F32_PLAIN || dx_mode) && no_kyo23) kyo = false;
   // conv1 of f16 images: f16 matrix pipes with f32-exact operands (conv_k16.h); CPP_CONV_K16=0 keeps the f32 MFMA kernel.
   // (B = 1 stays on the f32 kernel: action_given is bit-identical to a row of cpp_net_forward_each)
-  static const bool no_k16 = getenv("CPP_CONV_K16") != nullptr && atoi(getenv("CPP_CONV_K16")) == 0;
+  static const bool no_k16 = cpp_switch_off("CPP_CONV_K16");
   if (!no_kyo && !no_k16 && in_mode == IN_F16_WHITEN && !dx_mode && a.B >= 2 && a.nout <= 10 && a.H >= 2) {
     bool handled = false;
     rc = conv_fwd_k16_dispatch(ctx, cin, ks, in_mode, plain_fwd, batch, &handled);
@@ -119,7 +119,7 @@ int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, i
   if (kyo) {
     // few workgroups (the dX passes carry two networks: one wave per SIMD): split the images into two bands of rows
     // (CPP_CONV_BANDS=0: whole images)
-    static const bool no_bands = getenv("CPP_CONV_BANDS") != nullptr && atoi(getenv("CPP_CONV_BANDS")) == 0;
+    static const bool no_bands = cpp_switch_off("CPP_CONV_BANDS");
     const int ipw = a.W > 32 ? 1 : (a.W > 16 ? 2 : 4);
     const int wgs = n * ((a.B + ipw - 1) / ipw);
     if (!no_bands && wgs <= ctx->num_cus && a.H >= 16 && (a.H % 4) == 0 && (in_mode == IN_F32_PLAIN || in_mode == IN_DY))
@@ -171,7 +171,7 @@ int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, co
   int grid = 0, rc;
   prof_begin(ctx);
   // (ky,o)-column kernel for the 5x5 layers (CPP_CONV_KYO=0: old kernel); dense dY rows (batch norm) only exist there
-  static const bool no_kyo = getenv("CPP_CONV_KYO") != nullptr && atoi(getenv("CPP_CONV_KYO")) == 0;
+  static const bool no_kyo = cpp_switch_off("CPP_CONV_KYO");
   const bool dense = batch.a[0].dy_dense != nullptr;
   bool kyo = dense || (!no_kyo && ks == 5 && nout <= 10 && (batch.a[0].H % 2) == 0 && batch.a[0].H >= 4);
   int chb = 16;
@@ -181,7 +181,7 @@ int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, co
   }
   bool handled = false;
   // conv1 of f16 images: f16 matrix pipes with f32-exact operands (conv_dw16.h); CPP_CONV_K16=0 keeps the f32 MFMA kernel
-  static const bool no_k16 = getenv("CPP_CONV_K16") != nullptr && atoi(getenv("CPP_CONV_K16")) == 0;
+  static const bool no_k16 = cpp_switch_off("CPP_CONV_K16");
   if (!no_kyo && !no_k16 && in_mode == IN_F16_WHITEN) {
     const bool ride_open = ctx->ride != nullptr && !ctx->ride_done;
     rc = conv_dw16_dispatch(ctx, cin, ks, in_mode, dense, batch, &grid, &handled);
@@ -189,7 +189,7 @@ int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, co
     if (handled && ride_open && ctx->ride_done) kid = K_CONV1_DW_GATHER;      // the next minibatch's sample pass left with it
   }
   // conv2 (f32 activations in): bf16 pipes, three exact pieces per operand (conv_dwb16.h); CPP_CONV_B16=0 keeps the f32 MFMA kernel
-  static const bool no_b16 = getenv("CPP_CONV_B16") != nullptr && atoi(getenv("CPP_CONV_B16")) == 0;
+  static const bool no_b16 = cpp_switch_off("CPP_CONV_B16");
   if (!handled && !no_kyo && !no_b16 && !dense && in_mode == IN_F32_PLAIN)
     rc = conv_dwb16_dispatch(ctx, cin, ks, in_mode, batch, &grid, &handled);
   if (!handled)

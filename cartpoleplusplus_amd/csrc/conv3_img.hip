@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void conv3_img_kernel(const ConvArgsN batch) {
 
 // CPP_CONV3_IMG=0 keeps the row-streaming kernel
 bool conv3_img_ok(int cin, int ks, int H, int W, int nout) {
-  static const bool off = getenv("CPP_CONV3_IMG") != nullptr && atoi(getenv("CPP_CONV3_IMG")) == 0;
+  static const bool off = cpp_switch_off("CPP_CONV3_IMG");
   return !off && cin == C3_C && ks == C3_KS && H == C3_H && W == C3_H && nout >= 1 && nout <= C3_NO;
 }
 

@@ -1,0 +1,105 @@
+// errors, the per-kernel HIP-event profile, contexts (cpp_ctx_*, cpp_sync, cpp_timer_*, cpp_prof_*)
+#include "rt_internal.h"
+
+// ---------------------------------------------------------------------------------------------
+// errors / profiling brackets
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+void cpp_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* cpp_last_error(void) { return g_err; }
+extern "C" int cpp_abi_version(void) { return CPP_ABI_VERSION; }
+
+void prof_begin(cpp_ctx* ctx) {
+  if (ctx->prof) (void)hipEventRecord(ctx->pe0, ctx->stream);
+}
+void prof_end(cpp_ctx* ctx, int kid) {
+  if (!ctx->prof) return;
+  if (ctx->pair && ((ctx->pair->layer == 2 && (kid == K_CONV3_DW || kid == K_CONV3_DX)) ||
+                    (ctx->pair->layer == 1 && (kid == K_CONV2_DW || kid == K_CONV2_DX)))) return;      // parked, not launched (conv*_bwd_pair.hip)
+  (void)hipEventRecord(ctx->pe1, ctx->stream);
+  (void)hipEventSynchronize(ctx->pe1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, ctx->pe0, ctx->pe1);
+  ctx->prof_ms[kid] += ms;
+  ctx->prof_n[kid] += 1;
+}
+
+static const char* kKernelNames[K_NUM_KERNELS] = {
+    "gather_stats", "stats_finalize", "stats_generic", "conv1_fwd", "conv2_fwd", "conv3_fwd",
+    "conv1_dw", "conv2_dw", "conv3_dw", "conv2_dx", "conv3_dx", "dw_reduce", "gemm", "elementwise",
+    "td", "sumsq", "clip_sgd", "soft_update", "replay_fill", "naf_head", "conv1_fwd_f16x3", "conv1_dw_f16x3", "heads", "conv3_bwd", "conv2_bwd", "reduce_gather", "conv1_dw_gather"};
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+extern "C" int cpp_ctx_create(int device_id, void* hip_stream, cpp_ctx** out) {
+  ARG_CHECK(out, "cpp_ctx_create: out is NULL");
+  int ndev = 0;
+  HIP_CHECK(hipGetDeviceCount(&ndev));
+  ARG_CHECK(device_id >= 0 && device_id < ndev, "cpp_ctx_create: device %d not in [0,%d)", device_id, ndev);
+  HIP_CHECK(hipSetDevice(device_id));
+  cpp_ctx* c = new cpp_ctx();
+  memset(c, 0, sizeof(*c));
+  c->device = device_id;
+  if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
+  else { HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+  HIP_CHECK(hipEventCreate(&c->t0));
+  HIP_CHECK(hipEventCreate(&c->t1));
+  HIP_CHECK(hipEventCreate(&c->pe0));
+  HIP_CHECK(hipEventCreate(&c->pe1));
+  HIP_CHECK(hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, device_id));
+  *out = c;
+  return CPP_OK;
+}
+
+extern "C" int cpp_ctx_destroy(cpp_ctx* c) {
+  if (!c) return CPP_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipEventDestroy(c->t0); (void)hipEventDestroy(c->t1);
+  (void)hipEventDestroy(c->pe0); (void)hipEventDestroy(c->pe1);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return CPP_OK;
+}
+
+extern "C" int cpp_sync(cpp_ctx* c) {
+  ARG_CHECK(c, "cpp_sync: ctx is NULL");
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  return CPP_OK;
+}
+
+extern "C" int cpp_timer_begin(cpp_ctx* c) {
+  ARG_CHECK(c, "ctx is NULL");
+  HIP_CHECK(hipEventRecord(c->t0, c->stream));
+  return CPP_OK;
+}
+extern "C" int cpp_timer_end(cpp_ctx* c, float* ms) {
+  ARG_CHECK(c && ms, "ctx/ms is NULL");
+  HIP_CHECK(hipEventRecord(c->t1, c->stream));
+  HIP_CHECK(hipEventSynchronize(c->t1));
+  HIP_CHECK(hipEventElapsedTime(ms, c->t0, c->t1));
+  return CPP_OK;
+}
+extern "C" int cpp_prof_enable(cpp_ctx* c, int on) { ARG_CHECK(c, "ctx is NULL"); c->prof = on != 0; return CPP_OK; }
+extern "C" int cpp_prof_reset(cpp_ctx* c) {
+  ARG_CHECK(c, "ctx is NULL");
+  memset(c->prof_ms, 0, sizeof(c->prof_ms)); memset(c->prof_n, 0, sizeof(c->prof_n));
+  return CPP_OK;
+}
+extern "C" int cpp_prof_num_kernels(void) { return K_NUM_KERNELS; }
+extern "C" const char* cpp_prof_kernel_name(int k) { return (k >= 0 && k < K_NUM_KERNELS) ? kKernelNames[k] : ""; }
+extern "C" int cpp_prof_read(cpp_ctx* c, int k, double* total_ms, int64_t* launches) {
+  ARG_CHECK(c && k >= 0 && k < K_NUM_KERNELS, "cpp_prof_read: bad kernel id %d", k);
+  if (total_ms) *total_ms = c->prof_ms[k];
+  if (launches) *launches = c->prof_n[k];
+  return CPP_OK;
+}
+

@@ -1,0 +1,688 @@
+// DDPG train ops, the fused inner step and its hipGraph, the data-parallel half steps (cpp_ddpg_*)
+#include "rt_internal.h"
+
+// ---------------------------------------------------------------------------------------------
+// DDPG
+// ---------------------------------------------------------------------------------------------
+
+struct cpp_ddpg {
+  cpp_ctx* ctx; cpp_net *actor, *critic, *tactor, *tcritic; cpp_ddpg_hyper hp;
+  int maxB; long nA, nC;
+  float* gradbuf; float *dq_da, *td, *dq, *loss_norms /* [0] loss [1] actor norm [2] critic norm */, *ones;
+  double* norm_part;
+  double* heads_part;                              // fused heads kernel: per-workgroup partial sums of td^2
+  int heads_grid, heads_B;                         // ... of the last graph built by compute_gradients (0: GEMM levels + td_kernel)
+  int loss_parts, loss_B;                          // how cpp_ddpg_last_stats finds the loss of the last call: partials to add, or loss_norms[0]
+  // graph replay of the full inner step
+  hipGraph_t graph; hipGraphExec_t gexec; bool graph_ok; int g_B, g_nb, g_size; uint64_t g_seed; cpp_replay* g_replay;   // g_size: rows in the replay when captured (the sampler's range is a kernel argument)
+  cpp_batch* step_batch;
+  // graph replay of the data-parallel half step (sample + both gradient sets)
+  // three variants: 0 samples its own minibatch; 1 / 2 find it presampled (by the previous call's rider, conv1_dw_gather.hip)
+  // in the second / first set of slot arrays.  One key for all three.
+  hipGraph_t hgraph[3]; hipGraphExec_t hexec[3]; bool hgraph_ok[3]; int h_B, h_size; uint64_t h_seed; cpp_replay* h_replay;
+  int h_next[3];           // variant the call after variant v must use (0: the rider did not leave)
+  int pre_variant;         // variant of the next cpp_ddpg_sample_and_compute call if its key still matches (0: sample)
+  int32_t* slot_set[2][2]; // the two sets of slot arrays of step_batch
+  Arena arena;
+};
+
+extern "C" int cpp_ddpg_create(cpp_ctx* ctx, cpp_net* actor, cpp_net* critic, cpp_net* tactor, cpp_net* tcritic,
+                               const cpp_ddpg_hyper* hp, cpp_ddpg** out) {
+  ARG_CHECK(ctx && actor && critic && tactor && tcritic && hp && out, "cpp_ddpg_create: NULL argument");
+  ARG_CHECK(actor->spec.kind == CPP_ACTOR && tactor->spec.kind == CPP_ACTOR, "cpp_ddpg_create: actor kinds");
+  ARG_CHECK(critic->spec.kind == CPP_CRITIC && tcritic->spec.kind == CPP_CRITIC, "cpp_ddpg_create: critic kinds");
+  ARG_CHECK(actor->nparams == tactor->nparams && critic->nparams == tcritic->nparams, "cpp_ddpg_create: target shapes differ");
+  ARG_CHECK(actor->state_elems == critic->state_elems && actor->spec.action_dim == critic->spec.action_dim,
+            "cpp_ddpg_create: actor/critic input shapes differ");
+  HIP_CHECK(hipSetDevice(ctx->device));
+  cpp_ddpg* d = new cpp_ddpg();
+  d->arena.stream = ctx->stream;
+  d->ctx = ctx; d->actor = actor; d->critic = critic; d->tactor = tactor; d->tcritic = tcritic; d->hp = *hp;
+  d->maxB = actor->maxB < critic->maxB ? actor->maxB : critic->maxB;
+  d->nA = actor->nparams; d->nC = critic->nparams;
+  d->graph = nullptr; d->gexec = nullptr; d->graph_ok = false; d->step_batch = nullptr; d->g_replay = nullptr;
+  for (int v = 0; v < 3; ++v) { d->hgraph[v] = nullptr; d->hexec[v] = nullptr; d->hgraph_ok[v] = false; d->h_next[v] = 0; }
+  d->h_replay = nullptr; d->pre_variant = 0; d->h_B = 0; d->h_size = 0; d->h_seed = 0;
+  memset(d->slot_set, 0, sizeof(d->slot_set));
+  d->heads_grid = d->heads_B = d->loss_parts = d->loss_B = 0;
+  const int A = actor->spec.action_dim;
+  int rc = dalloc(d->arena, &d->gradbuf, (size_t)(d->nA + d->nC));
+  if (!rc) rc = dalloc(d->arena, &d->dq_da, (size_t)d->maxB * A);
+  if (!rc) rc = dalloc(d->arena, &d->td, (size_t)d->maxB);
+  if (!rc) rc = dalloc(d->arena, &d->dq, (size_t)d->maxB);
+  if (!rc) rc = dalloc(d->arena, &d->ones, (size_t)d->maxB);
+  if (!rc) rc = dalloc(d->arena, &d->loss_norms, (size_t)4);
+  if (!rc) rc = dalloc(d->arena, &d->norm_part, (size_t)OPT_MAX_SEGS * NORM_PARTS);
+  if (!rc) rc = dalloc(d->arena, &d->heads_part, (size_t)DDPG_HEADS_MAX_WGS);
+  if (!rc) rc = launch_fill(ctx, d->ones, 1, 0, 1, d->maxB, 1.0f);
+  if (rc) { d->arena.release(); delete d; return rc; }
+  actor->grads = d->gradbuf; critic->grads = d->gradbuf + d->nA;
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  *out = d;
+  return CPP_OK;
+}
+
+extern "C" int cpp_ddpg_destroy(cpp_ddpg* d) {
+  if (!d) return CPP_OK;
+  (void)hipSetDevice(d->ctx->device);
+  (void)hipStreamSynchronize(d->ctx->stream);
+  if (d->gexec) (void)hipGraphExecDestroy(d->gexec);
+  if (d->graph) (void)hipGraphDestroy(d->graph);
+  for (int v = 0; v < 3; ++v) {
+    if (d->hexec[v]) (void)hipGraphExecDestroy(d->hexec[v]);
+    if (d->hgraph[v]) (void)hipGraphDestroy(d->hgraph[v]);
+  }
+  if (d->step_batch) cpp_batch_destroy(d->step_batch);
+  d->actor->grads = nullptr; d->critic->grads = nullptr;
+  d->arena.release(); delete d; return CPP_OK;
+}
+
+static int check_batch(cpp_ddpg* d, cpp_batch* b, const char* who) {
+  ARG_CHECK(d && b, "%s: NULL argument", who);
+  ARG_CHECK(b->B >= 1 && b->B <= d->maxB, "%s: batch size %d outside [1,%d]", who, b->B, d->maxB);
+  ARG_CHECK(b->elems == d->actor->state_elems && b->A == d->actor->spec.action_dim, "%s: batch shape does not match the networks", who);
+  return CPP_OK;
+}
+
+const float* white_of(cpp_batch* b, int which, int C) { return b->white + (long)which * 2 * C; }
+
+// critic "prefix": conv trunk + the fully connected layers in front of the action splice
+static int critic_prefix(cpp_net* c, const void* state, int dtype, const float* white, int B) {
+  RC(net_forward_trunk(c, c->ws[0], state, dtype, white, B));
+  if (c->cat_layer > 0) {
+    // run layers [0, cat) only
+    for (int l = 0; l < c->cat_layer; ++l) {
+      const FcL& L = c->fc[l];
+      RC(gemm(c->ctx, c->ws[0].fcin[l], L.n_in + 1, 1, c->params + L.w_off, L.n_out, 1, c->ws[0].fcin[l + 1],
+              c->fc[l + 1].n_in + 1, B, L.n_out, L.n_in + 1, L.act));
+    }
+  }
+  return CPP_OK;
+}
+
+// evaluate the critic head from the splice on, in workspace `wi`, with the given device action batch
+static int critic_head(cpp_net* c, int wi, const float* action, int B) {
+  const int cl = c->cat_layer, A = c->spec.action_dim;
+  if (wi == 1) {
+    const FcL& L = c->fc[cl];
+    RC(launch_copy_cols(c->ctx, c->ws[1].fcin[cl], L.n_in + 1, 0, c->ws[0].fcin[cl], L.n_in + 1, 0, L.n_in - A, B));
+  }
+  return net_forward_fc(c, c->ws[wi], cl, B, action);
+}
+
+// ddpg_cartpole.py:111-113 + :220-222.  critic_prefix_done: the critic prefix for batch.state_1 is
+// already in critic->ws[0] (fused step computes it once for both updates).
+static int actor_gradients(cpp_ddpg* d, cpp_batch* b, bool critic_prefix_done) {
+  cpp_net *a = d->actor, *c = d->critic;
+  const int B = b->B, C = a->spec.pixel ? a->spec.C : 0;
+  const float* w1 = white_of(b, 0, C);
+  RC(net_forward_trunk(a, a->ws[0], b->s[0], b->dtype, w1, B));
+  RC(net_forward_fc(a, a->ws[0], 0, B, nullptr));
+  if (!critic_prefix_done) RC(critic_prefix(c, b->s[0], b->dtype, w1, B));
+  RC(critic_head(c, 1, a->ws[0].out, B));
+  // d(sum_b Q)/da: dz of the linear q layer is 1
+  const int last = (int)c->fc.size() - 1;
+  RC(launch_copy_cols(d->ctx, c->ws[1].dz[last], 1, 0, d->ones, 1, 0, 1, B));
+  // walk back to the splice (hidden layers after the splice are ReLU)
+  for (int l = last; l > c->cat_layer; --l) {
+    const FcL& L = c->fc[l];
+    RC(gemm(d->ctx, c->ws[1].dz[l], L.n_out, 1, c->params + L.w_off, 1, L.n_out, c->ws[1].dz[l - 1], L.n_in, B, L.n_in,
+            L.n_out, GE_MUL_RELU_GRAD, c->ws[1].fcin[l], L.n_in + 1));
+  }
+  {
+    const FcL& L = c->fc[c->cat_layer];
+    const int A = c->spec.action_dim;
+    RC(gemm(d->ctx, c->ws[1].dz[c->cat_layer], L.n_out, 1, c->params + L.w_off + (long)(L.n_in - A) * L.n_out, 1, L.n_out,
+            d->dq_da, A, B, A, L.n_out, GE_NONE));
+  }
+  // grad_ys = -dQ/da through the tanh head, then the whole actor backward
+  const int alast = (int)a->fc.size() - 1;
+  RC(launch_actor_head_grad(d->ctx, a->ws[0].dz[alast], d->dq_da, a->ws[0].out, B * a->spec.action_dim));
+  RC(net_backward(a, a->ws[0], B, true, nullptr, b->s[0], b->dtype, w1));
+  return CPP_OK;
+}
+
+// ddpg_cartpole.py:199-214
+static int critic_gradients_impl(cpp_ddpg* d, cpp_batch* b, bool critic_prefix_done, bool backward);
+// backward == false is check_loss (ddpg_cartpole.py:239-248), which feeds IS_TRAINING False; the train op (:237) feeds
+// True for the whole graph, target networks included
+static int critic_gradients(cpp_ddpg* d, cpp_batch* b, bool critic_prefix_done, bool backward) {
+  cpp_net* nets[3] = {d->critic, d->tactor, d->tcritic};
+  for (cpp_net* n : nets) n->is_training = backward;
+  const int rc = critic_gradients_impl(d, b, critic_prefix_done, backward);
+  for (cpp_net* n : nets) n->is_training = true;
+  return rc;
+}
+static int critic_gradients_impl(cpp_ddpg* d, cpp_batch* b, bool critic_prefix_done, bool backward) {
+  cpp_net *c = d->critic, *ta = d->tactor, *tc = d->tcritic;
+  const int B = b->B, C = c->spec.pixel ? c->spec.C : 0;
+  const float *w1 = white_of(b, 0, C), *w2 = white_of(b, 1, C);
+  RC(net_forward_trunk(ta, ta->ws[0], b->s[1], b->dtype, w2, B));
+  RC(net_forward_fc(ta, ta->ws[0], 0, B, nullptr));
+  RC(critic_prefix(tc, b->s[1], b->dtype, w2, B));
+  RC(critic_head(tc, 0, ta->ws[0].out, B));
+  if (!critic_prefix_done) RC(critic_prefix(c, b->s[0], b->dtype, w1, B));
+  RC(critic_head(c, 0, b->a, B));
+  const int last = (int)c->fc.size() - 1;
+  RC(launch_td(d->ctx, c->ws[0].out, tc->ws[0].out, b->r, b->m, d->hp.discount, B, d->td,
+               backward ? c->ws[0].dz[last] : nullptr, d->loss_norms));
+  d->loss_parts = 0;
+  if (backward) RC(net_backward(c, c->ws[0], B, true, nullptr, b->s[0], b->dtype, w1));
+  return CPP_OK;
+}
+
+static int apply(cpp_ddpg* d, bool do_actor, bool do_critic, float grad_scale, uint64_t* bump = nullptr) {
+  OptSegs s; memset(&s, 0, sizeof(s));
+  s.bump = bump;
+  s.nseg = 2; s.kind = OPT_SGD;
+  s.p[0] = d->actor->params; s.g[0] = d->gradbuf; s.n[0] = do_actor ? d->nA : 0; s.lr[0] = d->hp.actor_learning_rate; s.group[0] = 0;
+  s.p[1] = d->critic->params; s.g[1] = d->gradbuf + d->nA; s.n[1] = do_critic ? d->nC : 0; s.lr[1] = d->hp.critic_learning_rate; s.group[1] = 1;
+  RC(launch_sumsq(d->ctx, s, grad_scale, d->norm_part, NORM_PARTS));
+  // norms_out[group] is only written for lists that were applied (n > 0)
+  RC(launch_opt_apply(d->ctx, s, grad_scale, d->hp.gradient_clip, d->norm_part, NORM_PARTS, d->loss_norms + 1));
+  return CPP_OK;
+}
+
+static int prep_batch(cpp_ddpg* d, cpp_batch* b) {
+  if (d->actor->spec.pixel) RC(batch_ensure_stats(b, d->actor->spec.C));
+  return CPP_OK;
+}
+
+extern "C" int cpp_ddpg_train_actor(cpp_ddpg* d, cpp_batch* b) {
+  RC(check_batch(d, b, "cpp_ddpg_train_actor"));
+  HIP_CHECK(hipSetDevice(d->ctx->device));
+  RC(prep_batch(d, b));
+  RC(actor_gradients(d, b, false));
+  RC(apply(d, true, false, 1.0f));
+  return CPP_OK;
+}
+
+extern "C" int cpp_ddpg_train_critic(cpp_ddpg* d, cpp_batch* b) {
+  RC(check_batch(d, b, "cpp_ddpg_train_critic"));
+  HIP_CHECK(hipSetDevice(d->ctx->device));
+  RC(prep_batch(d, b));
+  RC(critic_gradients(d, b, false, true));
+  RC(apply(d, false, true, 1.0f));
+  return CPP_OK;
+}
+
+extern "C" int cpp_ddpg_check_loss(cpp_ddpg* d, cpp_batch* b, float* loss, float* td, float* q) {
+  RC(check_batch(d, b, "cpp_ddpg_check_loss"));
+  HIP_CHECK(hipSetDevice(d->ctx->device));
+  RC(prep_batch(d, b));
+  RC(critic_gradients(d, b, false, false));
+  hipStream_t st = d->ctx->stream;
+  if (loss) HIP_CHECK(hipMemcpyAsync(loss, d->loss_norms, sizeof(float), hipMemcpyDeviceToHost, st));
+  if (td) HIP_CHECK(hipMemcpyAsync(td, d->td, (size_t)b->B * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (q) HIP_CHECK(hipMemcpyAsync(q, d->critic->ws[0].out, (size_t)b->B * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  return CPP_OK;
+}
+
+extern "C" int cpp_ddpg_q_gradients_wrt_actions(cpp_ddpg* d, cpp_batch* b, float* dq_da, float* actions, float* q) {
+  RC(check_batch(d, b, "cpp_ddpg_q_gradients_wrt_actions"));
+  HIP_CHECK(hipSetDevice(d->ctx->device));
+  RC(prep_batch(d, b));
+  RC(actor_gradients(d, b, false));
+  hipStream_t st = d->ctx->stream;
+  const int A = d->actor->spec.action_dim;
+  if (dq_da) HIP_CHECK(hipMemcpyAsync(dq_da, d->dq_da, (size_t)b->B * A * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (actions) HIP_CHECK(hipMemcpyAsync(actions, d->actor->ws[0].out, (size_t)b->B * A * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (q) HIP_CHECK(hipMemcpyAsync(q, d->critic->ws[1].out, (size_t)b->B * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  return CPP_OK;
+}
+
+// Both gradient sets of one minibatch (ddpg_cartpole.py:331-334) as one dependency graph: 4 conv trunk
+// forwards, the MLP GEMMs batched level by level, 2 conv trunk backwards.  The critic trunk + the layers in
+// front of the action splice run once for both uses of critic(s1, .).
+static int compute_gradients(cpp_ddpg* d, cpp_batch* b) {
+  cpp_ctx* ctx = d->ctx;
+  cpp_net *a = d->actor, *c = d->critic, *ta = d->tactor, *tc = d->tcritic;
+  const int B = b->B, A = a->spec.action_dim, C = a->spec.pixel ? a->spec.C : 0;
+  const float *w1 = white_of(b, 0, C), *w2 = white_of(b, 1, C);
+  const void *s1 = b->direct_store ? b->direct_store : b->s[0], *s2 = b->direct_store ? b->direct_store : b->s[1];
+  struct SlotScope {      // conv1 of the four networks addresses its images through the sampled slots while this graph runs
+    cpp_net* n[4];
+    SlotScope(cpp_net* a_, cpp_net* c_, cpp_net* ta_, cpp_net* tc_, cpp_batch* b_) : n{a_, c_, ta_, tc_} {
+      if (b_->direct_store) { a_->img_slot = c_->img_slot = b_->slot[0]; ta_->img_slot = tc_->img_slot = b_->slot[1]; }
+    }
+    ~SlotScope() { for (cpp_net* x : n) x->img_slot = nullptr; }
+  } slot_scope(a, c, ta, tc, b);
+  const int dt = b->dtype;
+  const int na = (int)a->fc.size(), nc = (int)c->fc.size(), cat = c->cat_layer;
+  const FcL& Lcat = c->fc[cat];
+  const long ldcat = Lcat.n_in + 1;
+  OpGraph G;
+
+  // ---- forward: the four conv trunks.  conv1 saturates the chip per network; the narrow conv2 / conv3 layers
+  // of all four networks share one launch each.
+  int tA, tC, tTA, tTC;
+  if (a->spec.pixel && !a->spec.use_batch_norm) {
+    cpp_net* nets[4] = {a, c, ta, tc};
+    const void* sts[4] = {s1, s1, s2, s2};
+    const float* whs[4] = {w1, w1, w2, w2};
+    const int t1 = G.fn([=] {
+      for (int k = 0; k < 4; ++k) nets[k]->use_b16 = trunk_b16(nets[k], dt, B, 0);
+      {
+        ConvArgs cl[4]; int mode = 0;
+        for (int k = 0; k < 4; ++k) cl[k] = conv_fwd_args(nets[k], nets[k]->ws[0], 0, sts[k], dt, whs[k], B, &mode);
+        // all four conv1 forwards in one launch as well: 16 tiles per persistent workgroup amortise the weight
+        // preload and the tail (measured 0.560 -> 0.526 ms per step for the four networks)
+        RC(launch_conv_fwd_multi(ctx, kFwdKid[0], a->conv[0].Cin, a->conv[0].ks, mode, EPI_RELU_POOL, cl, 4));
+      }
+      for (int i = 1; i < 3; ++i) {
+        ConvArgs cl[4]; int mode = 0;
+        for (int k = 0; k < 4; ++k) cl[k] = conv_fwd_args(nets[k], nets[k]->ws[0], i, sts[k], dt, whs[k], B, &mode);
+        RC(launch_conv_fwd_multi(ctx, kFwdKid[i], a->conv[i].Cin, a->conv[i].ks, mode, EPI_RELU_POOL, cl, 4));
+      }
+      return (int)CPP_OK; }, {});
+    tA = tC = tTA = tTC = t1;
+  } else if (a->spec.pixel) {       // batch norm (training mode for the whole graph, ddpg_cartpole.py:145,237)
+    cpp_net* nets[4] = {a, c, ta, tc};
+    const void* sts[4] = {s1, s1, s2, s2};
+    const float* whs[4] = {w1, w1, w2, w2};
+    const int t1 = G.fn([=] { return nets_forward_trunk_bn(ctx, nets, 4, sts, whs, dt, B); }, {});
+    tA = tC = tTA = tTC = t1;
+  } else {
+    tA = G.fn([=] { return net_forward_trunk(a, a->ws[0], s1, dt, w1, B); }, {});
+    tC = G.fn([=] { return net_forward_trunk(c, c->ws[0], s1, dt, w1, B); }, {});
+    tTA = G.fn([=] { return net_forward_trunk(ta, ta->ws[0], s2, dt, w2, B); }, {});
+    tTC = G.fn([=] { return net_forward_trunk(tc, tc->ws[0], s2, dt, w2, B); }, {});
+  }
+  // ---- fused heads (heads.hip): when the critic is "[prefix, action] -> relu layer -> linear q" and the actor ends in a tanh
+  // layer (the reference's networks, ddpg_cartpole.py:95-100, :166-171), everything from the actors' / critics' last hidden
+  // activations to the first backward layer is one row-local kernel instead of five dependent GEMM levels + TD + copies.
+  // CPP_FUSED_HEADS=0 keeps the GEMM levels.
+  static const bool no_heads = cpp_switch_off("CPP_FUSED_HEADS");
+  DdpgHeadsArgs hd; memset(&hd, 0, sizeof(hd));
+  bool fused = !no_heads && na >= 2 && cat >= 1 && nc - cat == 2 && a->fc[na - 1].act == GE_TANH && Lcat.act == GE_RELU &&
+               c->fc[nc - 1].n_out == 1 && c->fc[nc - 1].act == GE_NONE && a->fc[na - 1].n_out == A;
+  if (fused) {
+    const FcL& Lo = a->fc[na - 1];
+    hd.B = B; hd.A = A; hd.discount = d->hp.discount;
+    hd.h2a = a->ws[0].fcin[na - 1]; hd.h2ta = ta->ws[0].fcin[na - 1]; hd.ld_h2a = Lo.n_in + 1; hd.n2a = Lo.n_in;
+    hd.Wo = a->params + Lo.w_off; hd.Wo_t = ta->params + Lo.w_off;
+    hd.h2c = c->ws[0].fcin[cat]; hd.h2tc = tc->ws[0].fcin[cat]; hd.ld_h2c = (int)ldcat; hd.n2c = Lcat.n_in - A;
+    hd.W3 = c->params + Lcat.w_off; hd.W3_t = tc->params + Lcat.w_off; hd.n3 = Lcat.n_out;
+    hd.wq = c->params + c->fc[nc - 1].w_off; hd.wq_t = tc->params + c->fc[nc - 1].w_off;
+    hd.act = b->a; hd.r = b->r; hd.mask = b->m;
+    hd.a_out = a->ws[0].out; hd.dq_da = d->dq_da; hd.adz = a->ws[0].dz[na - 1]; hd.dz_h2a = a->ws[0].dz[na - 2];
+    hd.relu_x2 = relu_grad_epi(a, na - 2) == GE_MUL_RELU_GRAD_X2;
+    hd.cat_splice = c->ws[0].fcin[cat] + (Lcat.n_in - A);
+    hd.h3_out = c->ws[0].fcin[nc - 1]; hd.ld_h3 = Lcat.n_out + 1;
+    hd.q_out = c->ws[0].out; hd.tq_out = tc->ws[0].out; hd.td = d->td; hd.dzq = c->ws[0].dz[nc - 1];
+    hd.dz3 = c->ws[0].dz[cat]; hd.dz2c = c->ws[0].dz[cat - 1];
+    hd.loss_part = d->heads_part;
+    fused = ddpg_heads_supported(hd);
+    // the actors are one layer deeper than the critics' prefix (100-100-50 against 200-50): their last hidden layer joins the
+    // heads kernel so that both stacks reach it, and leave it, in the same number of GEMM levels.  CPP_HEADS_PRE=0: GEMMs.
+    static const bool no_pre = cpp_switch_off("CPP_HEADS_PRE");
+    if (fused && !no_pre && na >= 3 && !a->drop_counter && a->fc[na - 2].act == GE_RELU && a->fc[na - 3].act == GE_RELU) {
+      DdpgHeadsArgs hp = hd;
+      const FcL& L2 = a->fc[na - 2];
+      hp.h1a = a->ws[0].fcin[na - 2]; hp.h1ta = ta->ws[0].fcin[na - 2]; hp.ld_h1a = L2.n_in + 1; hp.n1a = L2.n_in;
+      hp.W2 = a->params + L2.w_off; hp.W2_t = ta->params + L2.w_off;
+      hp.h2a_out = a->ws[0].fcin[na - 1]; hp.dz_h1a = a->ws[0].dz[na - 3];
+      if (ddpg_heads_supported(hp)) hd = hp;
+    }
+  }
+  const int pre = (fused && hd.n1a > 0) ? 1 : 0;
+  d->heads_grid = fused ? (B + 3) / 4 : 0; d->heads_B = B;
+  d->loss_parts = d->heads_grid; d->loss_B = B;
+  int adz, cdz;
+  if (fused) {
+    int aF = tA, taF = tTA;
+    for (int l = 0; l < na - 1 - pre; ++l) {
+      aF = G.gemm(fc_fwd_args(a, a->ws[0], l, B), {aF});
+      taF = G.gemm(fc_fwd_args(ta, ta->ws[0], l, B), {taF});
+    }
+    if (a->drop_counter) {     // --use-dropout: this forward is counted once its layers have read the counter
+      G.fn([=] { return bump_dropout(a); }, {aF});
+      G.fn([=] { return bump_dropout(ta); }, {taF});
+    }
+    int cP = tC, tcP = tTC;
+    for (int l = 0; l < cat; ++l) {
+      cP = G.gemm(fc_fwd_args(c, c->ws[0], l, B), {cP});
+      tcP = G.gemm(fc_fwd_args(tc, tc->ws[0], l, B), {tcP});
+    }
+    const int hk = G.fn([=] { return launch_ddpg_heads(ctx, hd); }, {aF, taF, cP, tcP});
+    // ---- actor backward below its head (the head's dX is part of the fused kernel)
+    G.gemm(fc_dw_args(a, a->ws[0], na - 1, B, a->ws[0].dz[na - 1]), {hk});
+    adz = hk;
+    for (int l = na - 2; l >= 0; --l) {
+      const FcL& L = a->fc[l];
+      G.gemm(fc_dw_args(a, a->ws[0], l, B, a->ws[0].dz[l]), {adz});
+      if (pre && l == na - 2) continue;       // dz[l - 1] came out of the heads kernel
+      if (l > 0)
+        adz = G.gemm(fc_dx_args(a, l, B, a->ws[0].dz[l], L.n_out, 0, L.n_in, a->ws[0].dz[l - 1], L.n_in, relu_grad_epi(a, l - 1),
+                                a->ws[0].fcin[l], L.n_in + 1), {adz});
+      else if (a->spec.pixel)
+        adz = G.gemm(fc_dx_args(a, 0, B, a->ws[0].dz[0], L.n_out, 0, a->flat, a->ws[0].dpool[2], a->flat, GE_NONE, nullptr, 0), {adz});
+    }
+    // ---- critic backward below its concat layer
+    G.gemm(fc_dw_args(c, c->ws[0], nc - 1, B, c->ws[0].dz[nc - 1]), {hk});
+    G.gemm(fc_dw_args(c, c->ws[0], cat, B, c->ws[0].dz[cat]), {hk});
+    cdz = hk;
+    for (int l = cat - 1; l >= 0; --l) {
+      const FcL& L = c->fc[l];
+      G.gemm(fc_dw_args(c, c->ws[0], l, B, c->ws[0].dz[l]), {cdz});
+      if (l > 0)
+        cdz = G.gemm(fc_dx_args(c, l, B, c->ws[0].dz[l], L.n_out, 0, L.n_in, c->ws[0].dz[l - 1], L.n_in, GE_MUL_RELU_GRAD,
+                                c->ws[0].fcin[l], L.n_in + 1), {cdz});
+      else if (c->spec.pixel)
+        cdz = G.gemm(fc_dx_args(c, 0, B, c->ws[0].dz[0], L.n_out, 0, c->flat, c->ws[0].dpool[2], c->flat, GE_NONE, nullptr, 0), {cdz});
+    }
+  } else {
+  const int cb = G.fn([=] { return launch_copy_cols(ctx, c->ws[0].fcin[cat], ldcat, Lcat.n_in - A, b->a, A, 0, A, B); }, {});
+  int aF = tA, taF = tTA;
+  for (int l = 0; l < na; ++l) {
+    GemmArgs g = fc_fwd_args(a, a->ws[0], l, B), t = fc_fwd_args(ta, ta->ws[0], l, B);
+    if (l == na - 1) {      // actions land directly in the critics' splice columns as well
+      g.C2 = c->ws[1].fcin[cat] + (Lcat.n_in - A); g.ldc2 = ldcat;
+      t.C2 = tc->ws[0].fcin[cat] + (Lcat.n_in - A); t.ldc2 = ldcat;
+    }
+    aF = G.gemm(g, {aF}); taF = G.gemm(t, {taF});
+  }
+  if (a->drop_counter) {     // --use-dropout: this forward is counted once its layers have read the counter
+    G.fn([=] { return bump_dropout(a); }, {aF});
+    G.fn([=] { return bump_dropout(ta); }, {taF});
+  }
+  int cP = tC, tcP = tTC;
+  for (int l = 0; l < cat; ++l) {
+    GemmArgs g = fc_fwd_args(c, c->ws[0], l, B);
+    if (l == cat - 1) { g.C2 = c->ws[1].fcin[cat]; g.ldc2 = ldcat; }   // same prefix for the second evaluation
+    cP = G.gemm(g, {cP});
+    tcP = G.gemm(fc_fwd_args(tc, tc->ws[0], l, B), {tcP});
+  }
+  if (cat == 0)     // low-dim critic: the "prefix" is the converted state itself
+    cP = G.fn([=] { return launch_copy_cols(ctx, c->ws[1].fcin[0], ldcat, 0, c->ws[0].fcin[0], ldcat, 0, Lcat.n_in - A, B); }, {tC});
+  int c1 = -1, c0 = -1, tcH = -1;
+  for (int l = cat; l < nc; ++l) {
+    c1 = G.gemm(fc_fwd_args(c, c->ws[1], l, B), {l == cat ? cP : c1, l == cat ? aF : -1});
+    c0 = G.gemm(fc_fwd_args(c, c->ws[0], l, B), {l == cat ? cP : c0, l == cat ? cb : -1, l == cat ? tC : -1});
+    tcH = G.gemm(fc_fwd_args(tc, tc->ws[0], l, B), {l == cat ? tcP : tcH, l == cat ? taF : -1});
+  }
+
+  // ---- dQ/da at a = actor(s1): back through q_value .. splice on the second evaluation (dz of q is 1)
+  int g = c1;
+  for (int l = nc - 1; l > cat; --l) {
+    const FcL& L = c->fc[l];
+    const float* dz = (l == nc - 1) ? d->ones : c->ws[1].dz[l];
+    g = G.gemm(fc_dx_args(c, l, B, dz, L.n_out, 0, L.n_in, c->ws[1].dz[l - 1], L.n_in, GE_MUL_RELU_GRAD,
+                          c->ws[1].fcin[l], L.n_in + 1), {g});
+  }
+  {   // dQ/da (kept for cpp_ddpg_q_gradients_wrt_actions) and, in the same epilogue, the actor's head gradient
+    const float* dz = (cat == nc - 1) ? d->ones : c->ws[1].dz[cat];
+    GemmArgs ga = fc_dx_args(c, cat, B, dz, Lcat.n_out, Lcat.n_in - A, A, d->dq_da, A, GE_ACTOR_HEAD, a->ws[0].out, A);
+    ga.C2 = a->ws[0].dz[na - 1]; ga.ldc2 = A;
+    adz = G.gemm(ga, {g, aF});
+  }
+
+  // ---- actor backward
+  for (int l = na - 1; l >= 0; --l) {
+    const FcL& L = a->fc[l];
+    G.gemm(fc_dw_args(a, a->ws[0], l, B, a->ws[0].dz[l]), {adz});
+    if (l > 0)
+      adz = G.gemm(fc_dx_args(a, l, B, a->ws[0].dz[l], L.n_out, 0, L.n_in, a->ws[0].dz[l - 1], L.n_in, relu_grad_epi(a, l - 1),
+                              a->ws[0].fcin[l], L.n_in + 1), {adz});
+    else if (a->spec.pixel)
+      adz = G.gemm(fc_dx_args(a, 0, B, a->ws[0].dz[0], L.n_out, 0, a->flat, a->ws[0].dpool[2], a->flat, GE_NONE, nullptr, 0), {adz});
+  }
+
+  // ---- TD target + critic backward on the first evaluation (fed actions)
+  cdz = G.fn([=] { return launch_td(ctx, c->ws[0].out, tc->ws[0].out, b->r, b->m, d->hp.discount, B, d->td,
+                                        c->ws[0].dz[nc - 1], d->loss_norms); }, {c0, tcH});
+  for (int l = nc - 1; l >= 0; --l) {
+    const FcL& L = c->fc[l];
+    G.gemm(fc_dw_args(c, c->ws[0], l, B, c->ws[0].dz[l]), {cdz});
+    const int ncols = L.cat ? L.n_in - A : L.n_in;
+    if (l > 0)
+      cdz = G.gemm(fc_dx_args(c, l, B, c->ws[0].dz[l], L.n_out, 0, ncols, c->ws[0].dz[l - 1], ncols, GE_MUL_RELU_GRAD,
+                              c->ws[0].fcin[l], L.n_in + 1), {cdz});
+    else if (c->spec.pixel)
+      cdz = G.gemm(fc_dx_args(c, 0, B, c->ws[0].dz[0], L.n_out, 0, c->flat, c->ws[0].dpool[2], c->flat, GE_NONE, nullptr, 0), {cdz});
+  }
+  }
+  if (c->spec.pixel) {     // both conv backward passes, layer by layer, two networks per launch
+    cpp_net* bn[2] = {a, c};
+    G.fn([=] { return nets_backward_conv(ctx, bn, 2, B, s1, dt, w1); }, {adz, cdz});
+  }
+  RC(G.run(ctx));
+  return flush_dw_reduce(ctx);      // all six dW reductions (3 layers x 2 networks) in one launch
+}
+
+extern "C" int cpp_ddpg_compute_gradients(cpp_ddpg* d, cpp_batch* b) {
+  RC(check_batch(d, b, "cpp_ddpg_compute_gradients"));
+  HIP_CHECK(hipSetDevice(d->ctx->device));
+  RC(prep_batch(d, b));
+  return compute_gradients(d, b);
+}
+
+extern "C" int cpp_ddpg_grad_buffer(cpp_ddpg* d, void** p, int64_t* n) {
+  ARG_CHECK(d && p && n, "cpp_ddpg_grad_buffer: NULL argument");
+  *p = d->gradbuf; *n = d->nA + d->nC;
+  return CPP_OK;
+}
+
+extern "C" int cpp_ddpg_apply_gradients(cpp_ddpg* d, float grad_scale) {
+  ARG_CHECK(d, "cpp_ddpg_apply_gradients: NULL argument");
+  HIP_CHECK(hipSetDevice(d->ctx->device));
+  return apply(d, true, true, grad_scale);
+}
+
+extern "C" int cpp_ddpg_update_targets(cpp_ddpg* d) {
+  ARG_CHECK(d, "cpp_ddpg_update_targets: NULL argument");
+  HIP_CHECK(hipSetDevice(d->ctx->device));
+  return launch_soft_update(d->ctx, d->tactor->params, d->actor->params, d->nA, d->tcritic->params, d->critic->params,
+                            d->nC, d->hp.target_update_rate);
+}
+
+// The fused step does not need a gathered copy of the minibatch when conv1 runs on the f16-pipe kernels: they take the
+// replay store plus the sampled slots (the gather kernel then only reads -- statistics -- and writes 2 B ints).
+// CPP_DIRECT_REPLAY=0 keeps the copy.
+bool direct_replay_ok(cpp_net* a, cpp_replay* r, int B) {
+  static const bool off = cpp_switch_off("CPP_DIRECT_REPLAY");
+  if (off || !a->spec.pixel || r->store_dtype != CPP_F16) return false;
+  const int C = a->spec.C;
+  int g = 8, c = C; while (c) { int t = g % c; g = c; c = t; }
+  if (r->elems % 8 != 0 || C / g > 16 || r->elems % C != 0) return false;       // statistics come from the gather kernel
+  return conv1_f16_pipes_ok(C, a->conv[0].H, a->conv[0].W, B, a->spec.use_batch_norm != 0);
+}
+
+static int step_body(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int32_t* rows_dev, uint64_t seed) {
+  d->pre_variant = 0;        // (the half steps' presampled minibatch lives in the same step_batch)
+  const int C = d->actor->spec.pixel ? d->actor->spec.C : 0;
+  cpp_ctx* ctx = d->ctx;
+  const bool direct = direct_replay_ok(d->actor, r, B);
+  // The sample + statistics pass of minibatch i + 1 depends on nothing minibatch i computes: it rides in the launch of i's
+  // dW reductions (reduce_gather_kernel, replay.hip), keyed by the sampler's counter + 1 -- the counter itself moves in i's
+  // optimiser kernel as before, so the rows drawn are the same.  Conv trunks on f16 / u8 stores; CPP_RIDE_GATHER=0: in sequence.
+  static const bool no_ride = cpp_switch_off("CPP_RIDE_GATHER");
+  const bool ride_ok = !no_ride && C > 0 && (r->store_dtype == CPP_F16 || r->store_dtype == CPP_U8);
+  RC(replay_sample_device(r, B, rows_dev, seed, rows_dev ? nullptr : r->counter, C, d->step_batch, direct));
+  for (int i = 0; i < n_batches; ++i) {
+    GatherArgs ga; int Cg = 0;
+    const bool more = i + 1 < n_batches;
+    if (more && ride_ok) {
+      ga = replay_gather_args(r, B, rows_dev ? rows_dev + (size_t)(i + 1) * B : nullptr, seed, rows_dev ? nullptr : r->counter, C,
+                              d->step_batch, direct, &Cg);
+      ga.counter_add = 1;
+      // with the slots double-buffered the pass can leave as early as conv1's dW (MFMA-bound, HBM idle, and its second
+      // round of workgroups leaves the CUs half empty: conv1_dw_gather.hip); otherwise it waits for the dW reductions
+      static const bool no_dwride = cpp_switch_off("CPP_RIDE_DW");
+      ctx->ride_at_dw = direct && !no_dwride;
+      if (direct) { ga.out_slot[0] = d->step_batch->slot_alt[0]; ga.out_slot[1] = d->step_batch->slot_alt[1]; }
+      ctx->ride = &ga; ctx->ride_done = false; ctx->ride_dtype = r->store_dtype;
+    }
+    const int rc = compute_gradients(d, d->step_batch);
+    const bool rode = ctx->ride != nullptr && ctx->ride_done;
+    ctx->ride = nullptr;
+    if (rode && direct) { std::swap(d->step_batch->slot[0], d->step_batch->slot_alt[0]); std::swap(d->step_batch->slot[1], d->step_batch->slot_alt[1]); }
+    RC(rc);
+    RC(apply(d, true, true, 1.0f, rows_dev ? nullptr : r->counter));   // also advances the sampler's counter
+    if (more) {
+      if (rode) RC(replay_sample_finish(r, B, Cg, C, d->step_batch));
+      else RC(replay_sample_device(r, B, rows_dev ? rows_dev + (size_t)(i + 1) * B : nullptr, seed, rows_dev ? nullptr : r->counter, C,
+                                   d->step_batch, direct));
+    }
+  }
+  return cpp_ddpg_update_targets(d);
+}
+
+extern "C" int cpp_ddpg_train_step(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int32_t* idxs, uint64_t seed) {
+  ARG_CHECK(d && r, "cpp_ddpg_train_step: NULL argument");
+  ARG_CHECK(B >= 1 && B <= d->maxB, "cpp_ddpg_train_step: batch %d outside [1,%d]", B, d->maxB);
+  ARG_CHECK(n_batches >= 1 && (size_t)n_batches * B <= 65536, "cpp_ddpg_train_step: n_batches %d", n_batches);
+  ARG_CHECK(r->elems == d->actor->state_elems && r->A == d->actor->spec.action_dim, "cpp_ddpg_train_step: replay shape does not match the networks");
+  if (r->size <= 0) { cpp_set_error("cpp_ddpg_train_step: replay memory is empty"); return CPP_ERR_STATE; }
+  cpp_ctx* ctx = d->ctx;
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (!d->step_batch) RC(cpp_batch_create(ctx, d->maxB, r->elems, r->A, &d->step_batch));
+  if (idxs) {
+    for (int i = 0; i < n_batches * B; ++i)
+      ARG_CHECK(idxs[i] >= 0 && idxs[i] < r->size, "cpp_ddpg_train_step: index %d outside [0,%d)", idxs[i], r->size);
+    HIP_CHECK(hipMemcpyAsync(r->rows_in, idxs, (size_t)n_batches * B * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    return step_body(d, r, B, n_batches, r->rows_in, seed);
+  }
+  static const bool no_graph = cpp_switch_set("CPP_NO_GRAPH");   // plain in-order stream launches (A/B measurements)
+  if (ctx->prof || no_graph) return step_body(d, r, B, n_batches, nullptr, seed);
+  if (!d->graph_ok || d->g_B != B || d->g_nb != n_batches || d->g_seed != seed || d->g_replay != r || d->g_size != r->size) {
+    if (d->gexec) { (void)hipGraphExecDestroy(d->gexec); d->gexec = nullptr; }
+    if (d->graph) { (void)hipGraphDestroy(d->graph); d->graph = nullptr; }
+    d->graph_ok = false;
+    // one eager pass first: it sets every kernel's LDS attribute (not allowed during capture)
+    RC(step_body(d, r, B, n_batches, nullptr, seed));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    int rc = step_body(d, r, B, n_batches, nullptr, seed);
+    hipError_t e = hipStreamEndCapture(ctx->stream, &d->graph);
+    if (rc) return rc;
+    if (e != hipSuccess) { cpp_set_error("hipStreamEndCapture -> %s", hipGetErrorString(e)); return CPP_ERR_HIP; }
+    HIP_CHECK(hipGraphInstantiate(&d->gexec, d->graph, nullptr, nullptr, 0));
+    d->graph_ok = true; d->g_B = B; d->g_nb = n_batches; d->g_seed = seed; d->g_replay = r; d->g_size = r->size;
+    return CPP_OK;   // the eager pass above was this call's step
+  }
+  HIP_CHECK(hipGraphLaunch(d->gexec, ctx->stream));
+  d->loss_parts = d->heads_grid; d->loss_B = d->heads_B;
+  return CPP_OK;
+}
+
+// variant 0: sample + gather + statistics of this call's minibatch; 1 / 2: it was presampled by the previous call's rider into
+// slot set 1 / 0 (only its whitening tables are still to do).  Every variant tries to send the NEXT minibatch's sample pass
+// along with conv1's dW (the sampler's counter has been advanced by then, so the rider draws with the counter as it stands);
+// *next: the variant the following call must use.  CPP_RIDE_DP=0: always variant 0, no rider.
+static int half_step_body(cpp_ddpg* d, cpp_replay* r, int B, uint64_t seed, int variant, int* next) {
+  const int C = d->actor->spec.pixel ? d->actor->spec.C : 0;
+  cpp_ctx* ctx = d->ctx;
+  cpp_batch* b = d->step_batch;
+  const bool direct = direct_replay_ok(d->actor, r, B);
+  static const bool no_ride = cpp_switch_off("CPP_RIDE_DP");
+  const int cur = variant == 1 ? 1 : 0;
+  for (int k = 0; k < 2; ++k) { b->slot[k] = d->slot_set[cur][k]; b->slot_alt[k] = d->slot_set[1 - cur][k]; }
+  int Cg = 0;
+  GatherArgs ga = replay_gather_args(r, B, nullptr, seed, r->counter, C, b, direct, &Cg);
+  if (variant == 0) RC(launch_gather_stats(ctx, ga, r->store_dtype));
+  RC(replay_sample_finish(r, B, Cg, C, b));
+  RC(launch_counter_add(ctx, r->counter, 1));
+  const bool ride_ok = !no_ride && direct && Cg > 0 && r->store_dtype == CPP_F16;
+  if (ride_ok) {
+    ga.out_slot[0] = b->slot_alt[0]; ga.out_slot[1] = b->slot_alt[1];
+    ctx->ride = &ga; ctx->ride_done = false; ctx->ride_dtype = r->store_dtype; ctx->ride_at_dw = true;
+  }
+  const int rc = compute_gradients(d, b);
+  const bool rode = ctx->ride != nullptr && ctx->ride_done;
+  ctx->ride = nullptr;
+  *next = rode ? (cur == 0 ? 1 : 2) : 0;
+  return rc;
+}
+
+extern "C" int cpp_ddpg_sample_and_compute(cpp_ddpg* d, cpp_replay* r, int B, uint64_t seed) {
+  ARG_CHECK(d && r, "cpp_ddpg_sample_and_compute: NULL argument");
+  ARG_CHECK(B >= 1 && B <= d->maxB, "cpp_ddpg_sample_and_compute: batch %d outside [1,%d]", B, d->maxB);
+  ARG_CHECK(r->elems == d->actor->state_elems && r->A == d->actor->spec.action_dim, "cpp_ddpg_sample_and_compute: replay shape does not match the networks");
+  if (r->size <= 0) { cpp_set_error("cpp_ddpg_sample_and_compute: replay memory is empty"); return CPP_ERR_STATE; }
+  cpp_ctx* ctx = d->ctx;
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (!d->step_batch) {
+    RC(cpp_batch_create(ctx, d->maxB, r->elems, r->A, &d->step_batch));
+    for (int k = 0; k < 2; ++k) { d->slot_set[0][k] = d->step_batch->slot[k]; d->slot_set[1][k] = d->step_batch->slot_alt[k]; }
+  }
+  if (d->slot_set[0][0] == nullptr)
+    for (int k = 0; k < 2; ++k) { d->slot_set[0][k] = d->step_batch->slot[k]; d->slot_set[1][k] = d->step_batch->slot_alt[k]; }
+  const bool key_ok = d->h_B == B && d->h_seed == seed && d->h_replay == r && d->h_size == r->size;
+  if (!key_ok) {                                     // another batch size / seed / memory, or rows were added: start over
+    for (int v = 0; v < 3; ++v) {
+      if (d->hexec[v]) { (void)hipGraphExecDestroy(d->hexec[v]); d->hexec[v] = nullptr; }
+      if (d->hgraph[v]) { (void)hipGraphDestroy(d->hgraph[v]); d->hgraph[v] = nullptr; }
+      d->hgraph_ok[v] = false;
+    }
+    d->pre_variant = 0;
+    d->h_B = B; d->h_seed = seed; d->h_replay = r; d->h_size = r->size;
+  }
+  const int v = d->pre_variant;
+  d->pre_variant = 0;                                // (stays 0 if anything below fails)
+  int next = 0;
+  if (ctx->prof) { RC(half_step_body(d, r, B, seed, v, &next)); d->pre_variant = next; return CPP_OK; }
+  if (!d->hgraph_ok[v]) {
+    // this call's work is done by the captured graph's first launch: an eager pass first would consume the presampled batch
+    // and leave another one behind.  Kernel attributes: set by the first eager variant-0 pass below.
+    if (v == 0) {
+      RC(half_step_body(d, r, B, seed, 0, &next));            // eager pass: sets kernel attributes, is this call's work
+      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+      int nx = 0;
+      int rc = half_step_body(d, r, B, seed, 0, &nx);
+      hipError_t e = hipStreamEndCapture(ctx->stream, &d->hgraph[0]);
+      if (rc) return rc;
+      if (e != hipSuccess) { cpp_set_error("hipStreamEndCapture -> %s", hipGetErrorString(e)); return CPP_ERR_HIP; }
+      HIP_CHECK(hipGraphInstantiate(&d->hexec[0], d->hgraph[0], nullptr, nullptr, 0));
+      d->hgraph_ok[0] = true; d->h_next[0] = nx;
+      d->pre_variant = next;
+      return CPP_OK;
+    }
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    int nx = 0;
+    int rc = half_step_body(d, r, B, seed, v, &nx);
+    hipError_t e = hipStreamEndCapture(ctx->stream, &d->hgraph[v]);
+    if (rc) return rc;
+    if (e != hipSuccess) { cpp_set_error("hipStreamEndCapture -> %s", hipGetErrorString(e)); return CPP_ERR_HIP; }
+    HIP_CHECK(hipGraphInstantiate(&d->hexec[v], d->hgraph[v], nullptr, nullptr, 0));
+    d->hgraph_ok[v] = true; d->h_next[v] = nx;
+  }
+  HIP_CHECK(hipGraphLaunch(d->hexec[v], ctx->stream));
+  d->pre_variant = d->h_next[v];
+  d->loss_parts = d->heads_grid; d->loss_B = d->heads_B;
+  return CPP_OK;
+}
+
+extern "C" int cpp_ddpg_last_stats(cpp_ddpg* d, float out[3]) {
+  ARG_CHECK(d && out, "cpp_ddpg_last_stats: NULL argument");
+  HIP_CHECK(hipMemcpyAsync(out, d->loss_norms, 3 * sizeof(float), hipMemcpyDeviceToHost, d->ctx->stream));
+  double parts[DDPG_HEADS_MAX_WGS];
+  if (d->loss_parts > 0)
+    HIP_CHECK(hipMemcpyAsync(parts, d->heads_part, (size_t)d->loss_parts * sizeof(double), hipMemcpyDeviceToHost, d->ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(d->ctx->stream));
+  if (d->loss_parts > 0) {                          // fused heads kernel: mean(td^2) from its per-workgroup partials, fixed order
+    double s = 0.0;
+    for (int i = 0; i < d->loss_parts; ++i) s += parts[i];
+    out[0] = (float)(s / (double)d->loss_B);
+  }
+  return CPP_OK;
+}
+
+extern "C" int cpp_ddpg_last_values(cpp_ddpg* d, int B, float* actions, float* dq_da, float* q, float* td) {
+  ARG_CHECK(d, "cpp_ddpg_last_values: NULL argument");
+  ARG_CHECK(B >= 1 && B <= d->maxB, "cpp_ddpg_last_values: batch %d outside [1,%d]", B, d->maxB);
+  HIP_CHECK(hipSetDevice(d->ctx->device));
+  hipStream_t st = d->ctx->stream;
+  const int A = d->actor->spec.action_dim;
+  if (actions) HIP_CHECK(hipMemcpyAsync(actions, d->actor->ws[0].out, (size_t)B * A * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (dq_da) HIP_CHECK(hipMemcpyAsync(dq_da, d->dq_da, (size_t)B * A * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (q) HIP_CHECK(hipMemcpyAsync(q, d->critic->ws[0].out, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (td) HIP_CHECK(hipMemcpyAsync(td, d->td, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  return CPP_OK;
+}
+

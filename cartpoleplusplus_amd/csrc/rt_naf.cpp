@@ -1,0 +1,379 @@
+// NAF train ops and inner step (cpp_naf_*)
+#include "rt_internal.h"
+
+// ---------------------------------------------------------------------------------------------
+// NAF (naf_cartpole.py)
+// ---------------------------------------------------------------------------------------------
+struct cpp_naf {
+  cpp_ctx* ctx; cpp_net *value, *tvalue, *mu, *lv; int share; cpp_naf_hyper hp;
+  int maxB, A, NL; long nV, nM, nL;
+  float* gradbuf; float *m, *v;           // optimiser state over the same flat layout (Momentum / Adam)
+  float *adv, *q, *td, *stats;            // stats: [0] loss [1] norm
+  int* nonfinite; uint64_t* opt_step; double* norm_part;
+  hipGraph_t graph; hipGraphExec_t gexec; bool graph_ok; int g_B, g_nb, g_size; uint64_t g_seed; cpp_replay* g_replay;   // g_size: rows in the replay when captured (the sampler's range is a kernel argument)
+  cpp_batch* step_batch;
+  Arena arena;
+};
+
+extern "C" int cpp_naf_create(cpp_ctx* ctx, cpp_net* value, cpp_net* tvalue, cpp_net* mu, cpp_net* lv, int share,
+                              const cpp_naf_hyper* hp, cpp_naf** out) {
+  ARG_CHECK(ctx && value && tvalue && mu && lv && hp && out, "cpp_naf_create: NULL argument");
+  for (cpp_net* n : {value, tvalue, mu, lv}) ARG_CHECK(n->spec.kind == CPP_HEAD, "cpp_naf_create: networks must be CPP_HEAD");
+  ARG_CHECK(value->spec.head_out == 1 && tvalue->spec.head_out == 1 && value->nparams == tvalue->nparams,
+            "cpp_naf_create: value / target_value shapes");
+  const int A = mu->spec.head_out;
+  ARG_CHECK(A >= 1 && A <= 8 && lv->spec.head_out == A * (A + 1) / 2, "cpp_naf_create: mu has %d outputs, l_values %d (want A and A(A+1)/2)",
+            A, lv->spec.head_out);
+  ARG_CHECK(mu->spec.head_act == 2 && lv->spec.head_act == 0 && value->spec.head_act == 0, "cpp_naf_create: head activations");
+  ARG_CHECK(hp->optimiser >= CPP_OPT_SGD && hp->optimiser <= CPP_OPT_ADAM, "cpp_naf_create: optimiser %d", hp->optimiser);
+  const int rep = value->fc.back().n_in;
+  if (share) {
+    for (cpp_net* n : {mu, lv})
+      ARG_CHECK(!n->spec.pixel && n->fc.size() == 1 && n->fc[0].n_in == rep,
+                "cpp_naf_create: shared heads must be head-only nets over the %d-wide representation", rep);
+  } else {
+    for (cpp_net* n : {mu, lv}) ARG_CHECK(n->state_elems == value->state_elems, "cpp_naf_create: state shapes differ");
+  }
+  HIP_CHECK(hipSetDevice(ctx->device));
+  cpp_naf* f = new cpp_naf();
+  f->arena.stream = ctx->stream;
+  f->ctx = ctx; f->value = value; f->tvalue = tvalue; f->mu = mu; f->lv = lv; f->share = share; f->hp = *hp;
+  f->maxB = value->maxB; f->A = A; f->NL = A * (A + 1) / 2;
+  for (cpp_net* n : {tvalue, mu, lv}) if (n->maxB < f->maxB) f->maxB = n->maxB;
+  f->nV = value->nparams; f->nM = mu->nparams; f->nL = lv->nparams;
+  f->graph = nullptr; f->gexec = nullptr; f->graph_ok = false; f->step_batch = nullptr; f->g_replay = nullptr;
+  const size_t nall = (size_t)(f->nV + f->nM + f->nL);
+  int rc = dalloc(f->arena, &f->gradbuf, nall);
+  if (!rc) rc = dalloc(f->arena, &f->m, nall);
+  if (!rc) rc = dalloc(f->arena, &f->v, nall);
+  if (!rc) rc = dalloc(f->arena, &f->adv, (size_t)f->maxB);
+  if (!rc) rc = dalloc(f->arena, &f->q, (size_t)f->maxB);
+  if (!rc) rc = dalloc(f->arena, &f->td, (size_t)f->maxB);
+  if (!rc) rc = dalloc(f->arena, &f->stats, (size_t)4);
+  if (!rc) rc = dalloc(f->arena, &f->nonfinite, (size_t)1);
+  if (!rc) rc = dalloc(f->arena, &f->opt_step, (size_t)1);
+  if (!rc) rc = dalloc(f->arena, &f->norm_part, (size_t)OPT_MAX_SEGS * NORM_PARTS);
+  if (rc) { f->arena.release(); delete f; return rc; }
+  value->grads = f->gradbuf; mu->grads = f->gradbuf + f->nV; lv->grads = f->gradbuf + f->nV + f->nM;
+  if (share) {      // the heads read value's input_state_representation in place (naf_cartpole.py:151-152,176-177)
+    mu->ws[0].fcin[0] = value->ws[0].fcin.back();
+    lv->ws[0].fcin[0] = value->ws[0].fcin.back();
+  }
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  *out = f;
+  return CPP_OK;
+}
+
+extern "C" int cpp_naf_destroy(cpp_naf* f) {
+  if (!f) return CPP_OK;
+  (void)hipSetDevice(f->ctx->device);
+  (void)hipStreamSynchronize(f->ctx->stream);
+  if (f->gexec) (void)hipGraphExecDestroy(f->gexec);
+  if (f->graph) (void)hipGraphDestroy(f->graph);
+  if (f->step_batch) cpp_batch_destroy(f->step_batch);
+  f->value->grads = nullptr; f->mu->grads = nullptr; f->lv->grads = nullptr;
+  f->arena.release(); delete f; return CPP_OK;
+}
+
+static int naf_check_batch(cpp_naf* f, cpp_batch* b, const char* who) {
+  ARG_CHECK(f && b, "%s: NULL argument", who);
+  ARG_CHECK(b->B >= 1 && b->B <= f->maxB, "%s: batch size %d outside [1,%d]", who, b->B, f->maxB);
+  ARG_CHECK(b->elems == f->value->state_elems && b->A == f->A, "%s: batch shape does not match the networks", who);
+  if (f->value->spec.pixel) RC(batch_ensure_stats(b, f->value->spec.C));
+  return CPP_OK;
+}
+
+// value / mu / l_values on state_1 (device pointer), optionally V'(state_2)
+static int naf_forward(cpp_naf* f, const void* s1, const void* s2, int dtype, const float* w1, const float* w2, int B) {
+  cpp_net *v = f->value, *tv = f->tvalue;
+  RC(net_forward_trunk(v, v->ws[0], s1, dtype, w1, B));
+  RC(net_forward_fc(v, v->ws[0], 0, B, nullptr));
+  for (cpp_net* n : {f->mu, f->lv}) {
+    if (!f->share) RC(net_forward_trunk(n, n->ws[0], s1, dtype, w1, B));
+    RC(net_forward_fc(n, n->ws[0], 0, B, nullptr));
+  }
+  if (s2) {
+    RC(net_forward_trunk(tv, tv->ws[0], s2, dtype, w2, B));
+    RC(net_forward_fc(tv, tv->ws[0], 0, B, nullptr));
+  }
+  return CPP_OK;
+}
+
+static int naf_head(cpp_naf* f, cpp_batch* b, bool backward) {
+  NafHeadArgs a; memset(&a, 0, sizeof(a));
+  a.value = f->value->ws[0].out; a.mu = f->mu->ws[0].out; a.lv = f->lv->ws[0].out;
+  a.action = b->a; a.reward = b->r; a.mask = b->m; a.target_value = f->tvalue->ws[0].out;
+  a.discount = f->hp.discount; a.B = b->B; a.A = f->A;
+  a.adv = f->adv; a.q = f->q; a.td = f->td; a.loss = f->stats; a.nonfinite = f->nonfinite;
+  if (backward) {
+    a.d_value = f->value->ws[0].dz.back(); a.d_mu_z = f->mu->ws[0].dz.back(); a.d_l = f->lv->ws[0].dz.back();
+  }
+  return launch_naf_head(f->ctx, a);
+}
+
+// backward of the fully connected stack of a network without an action splice, from layer `start` down:
+// per layer {[dW;db], dX} as two independent GEMMs.  Returns the op that completes d(flat) (pixel) / dz[0].
+static int add_fc_backward(OpGraph& G, cpp_net* n, Workspace& w, int B, int start, int dep) {
+  for (int l = start; l >= 0; --l) {
+    const FcL& L = n->fc[l];
+    G.gemm(fc_dw_args(n, w, l, B, w.dz[l]), {dep});
+    if (l > 0)
+      dep = G.gemm(fc_dx_args(n, l, B, w.dz[l], L.n_out, 0, L.n_in, w.dz[l - 1], L.n_in, relu_grad_epi(n, l - 1), w.fcin[l], L.n_in + 1), {dep});
+    else if (n->spec.pixel)
+      dep = G.gemm(fc_dx_args(n, 0, B, w.dz[0], L.n_out, 0, n->flat, w.dpool[2], n->flat, GE_NONE, nullptr, 0), {dep});
+  }
+  return dep;
+}
+
+// One NAF minibatch (naf_cartpole.py:264-272 without the apply) as a dependency graph, batched like the DDPG
+// step: conv layers of the networks that run them share launches, independent GEMMs share launches.
+static int naf_compute_gradients(cpp_naf* f, cpp_batch* b) {
+  cpp_ctx* ctx = f->ctx;
+  cpp_net *v = f->value, *tv = f->tvalue, *mu = f->mu, *lv = f->lv;
+  const int B = b->B, C = v->spec.pixel ? v->spec.C : 0, dt = b->dtype;
+  const float *w1 = white_of(b, 0, C), *w2 = white_of(b, 1, C);
+  const void *s1 = b->direct_store ? b->direct_store : b->s[0], *s2 = b->direct_store ? b->direct_store : b->s[1];
+  struct SlotScope {      // conv1 addresses its images through the sampled slots while this graph runs
+    cpp_net* n[4];
+    SlotScope(cpp_net* v_, cpp_net* mu_, cpp_net* lv_, cpp_net* tv_, cpp_batch* b_) : n{v_, mu_, lv_, tv_} {
+      if (b_->direct_store) { v_->img_slot = mu_->img_slot = lv_->img_slot = b_->slot[0]; tv_->img_slot = b_->slot[1]; }
+    }
+    ~SlotScope() { for (cpp_net* x : n) x->img_slot = nullptr; }
+  } slot_scope(v, mu, lv, tv, b);
+  const bool share = f->share != 0;
+  OpGraph G;
+
+  // ---- forward trunks
+  cpp_net* tn[4]; const void* ts[4]; const float* tw[4]; int nt = 0;
+  tn[nt] = v; ts[nt] = s1; tw[nt] = w1; ++nt;
+  if (!share) { tn[nt] = mu; ts[nt] = s1; tw[nt] = w1; ++nt; tn[nt] = lv; ts[nt] = s1; tw[nt] = w1; ++nt; }
+  tn[nt] = tv; ts[nt] = s2; tw[nt] = w2; ++nt;
+  int t1;
+  if (v->spec.pixel && !v->spec.use_batch_norm) {
+    std::vector<cpp_net*> nets(tn, tn + nt); std::vector<const void*> sts(ts, ts + nt); std::vector<const float*> whs(tw, tw + nt);
+    t1 = G.fn([=] {
+      for (int k = 0; k < nt; ++k) nets[k]->use_b16 = trunk_b16(nets[k], dt, B, 0);
+      for (int i = 0; i < 3; ++i) {
+        ConvArgs cl[CONV_BATCH_MAX]; int mode = 0;
+        for (int k = 0; k < nt; ++k) cl[k] = conv_fwd_args(nets[k], nets[k]->ws[0], i, sts[k], dt, whs[k], B, &mode);
+        RC(launch_conv_fwd_multi(ctx, kFwdKid[i], v->conv[i].Cin, v->conv[i].ks, mode, EPI_RELU_POOL, cl, nt));
+      }
+      return (int)CPP_OK; }, {});
+  } else {
+    std::vector<cpp_net*> nets(tn, tn + nt); std::vector<const void*> sts(ts, ts + nt); std::vector<const float*> whs(tw, tw + nt);
+    t1 = G.fn([=] {        // low-dim states, or batch-norm trunks (training mode: naf_cartpole.py:271)
+      if (nets[0]->spec.pixel) return nets_forward_trunk_bn(ctx, nets.data(), nt, sts.data(), whs.data(), dt, B);
+      for (int k = 0; k < nt; ++k) RC(net_forward_trunk(nets[k], nets[k]->ws[0], sts[k], dt, whs[k], B));
+      return (int)CPP_OK; }, {});
+  }
+  // ---- forward MLPs
+  auto chain = [&](cpp_net* n, int from, int dep) {
+    for (int l = from; l < (int)n->fc.size(); ++l) dep = G.gemm(fc_fwd_args(n, n->ws[0], l, B), {dep});
+    return dep;
+  };
+  const int Lh = (int)v->fc.size() - 1;                 // value's 'fc' head
+  int vrep = t1;
+  for (int l = 0; l < Lh; ++l) vrep = G.gemm(fc_fwd_args(v, v->ws[0], l, B), {vrep});
+  const int vout = G.gemm(fc_fwd_args(v, v->ws[0], Lh, B), {vrep});
+  const int tvout = chain(tv, 0, t1);
+  const int muout = share ? chain(mu, 0, vrep) : chain(mu, 0, t1);
+  const int lvout = share ? chain(lv, 0, vrep) : chain(lv, 0, t1);
+  if (v->drop_counter) {     // --use-dropout: count this training-mode forward of every network with a hidden stack
+    G.fn([=] { return bump_dropout(v); }, {vout});
+    G.fn([=] { return bump_dropout(tv); }, {tvout});
+    if (!share) { G.fn([=] { return bump_dropout(mu); }, {muout}); G.fn([=] { return bump_dropout(lv); }, {lvout}); }
+  }
+  // ---- NAF head: L, advantage, TD loss and the gradients of the three head outputs
+  const int head = G.fn([=] { return naf_head(f, b, true); }, {vout, tvout, muout, lvout});
+
+  // ---- backward
+  if (!share) {
+    const int dv = add_fc_backward(G, v, v->ws[0], B, (int)v->fc.size() - 1, head);
+    const int dm = add_fc_backward(G, mu, mu->ws[0], B, (int)mu->fc.size() - 1, head);
+    const int dl = add_fc_backward(G, lv, lv->ws[0], B, (int)lv->fc.size() - 1, head);
+    if (v->spec.pixel) {
+      cpp_net* bn[3] = {v, mu, lv};
+      G.fn([=] { return nets_backward_conv(ctx, bn, 3, B, s1, dt, w1); }, {dv, dm, dl});
+    }
+  } else {
+    // shared representation: head gradients, then d(rep) = sum of the three heads' contributions
+    const FcL& hv = v->fc[Lh];
+    const int rep = hv.n_in;
+    struct Head { cpp_net* n; const FcL* L; const float* dz; };
+    Head heads[3] = {{v, &hv, v->ws[0].dz[Lh]}, {mu, &mu->fc[0], mu->ws[0].dz[0]}, {lv, &lv->fc[0], lv->ws[0].dz[0]}};
+    float* drep = nullptr; long ldd = rep; int final_epi = GE_NONE; const float* Y = nullptr; long ldy = 0;
+    if (Lh > 0) { drep = v->ws[0].dz[Lh - 1]; final_epi = relu_grad_epi(v, Lh - 1); Y = v->ws[0].fcin[Lh]; ldy = rep + 1; }
+    else if (v->spec.pixel) { drep = v->ws[0].dpool[2]; }
+    int dep = head;
+    for (int k = 0; k < 3; ++k) {
+      const Head& h = heads[k];
+      const float* x = v->ws[0].fcin[Lh];        // [rep, 1] rows, shared by the three heads
+      G.gemm(mk_gemm(x, 1, rep + 1, h.dz, h.L->n_out, 1, h.n->grads + h.L->w_off, h.L->n_out, rep + 1, h.L->n_out, B, GE_NONE), {head});
+      if (drep) {
+        GemmArgs g = mk_gemm(h.dz, h.L->n_out, 1, h.n->params + h.L->w_off, 1, h.L->n_out, drep, ldd, B, rep, h.L->n_out,
+                             k == 2 ? final_epi : GE_NONE, k == 2 ? Y : nullptr, ldy);
+        g.accumulate = k > 0;
+        dep = G.gemm(g, {dep});                  // accumulation order value -> mu -> l_values is fixed
+      }
+    }
+    const int dv = add_fc_backward(G, v, v->ws[0], B, Lh - 1, dep);
+    if (v->spec.pixel) G.fn([=] { return net_backward_conv(v, v->ws[0], B, s1, dt, w1); }, {dv});
+  }
+  RC(G.run(ctx));
+  return flush_dw_reduce(ctx);
+}
+
+static int naf_apply(cpp_naf* f, float grad_scale) {
+  OptSegs s; memset(&s, 0, sizeof(s));
+  s.nseg = 3; s.kind = f->hp.optimiser; s.momentum = f->hp.momentum; s.beta1 = f->hp.beta1; s.beta2 = f->hp.beta2;
+  s.epsilon = f->hp.epsilon; s.step = f->opt_step;
+  cpp_net* nets[3] = {f->value, f->mu, f->lv};
+  long off = 0;
+  for (int k = 0; k < 3; ++k) {
+    s.p[k] = nets[k]->params; s.g[k] = f->gradbuf + off; s.m[k] = f->m + off; s.v[k] = f->v + off;
+    s.n[k] = nets[k]->nparams; s.lr[k] = f->hp.learning_rate; s.group[k] = 0;      // ONE list, one global norm
+    off += nets[k]->nparams;
+  }
+  RC(launch_counter_add(f->ctx, f->opt_step, 1));
+  RC(launch_sumsq(f->ctx, s, grad_scale, f->norm_part, NORM_PARTS));
+  return launch_opt_apply(f->ctx, s, grad_scale, f->hp.gradient_clip, f->norm_part, NORM_PARTS, f->stats + 1);
+}
+
+extern "C" int cpp_naf_action(cpp_naf* f, const void* state, int dtype, int B, float* out) {
+  ARG_CHECK(f && state && out, "cpp_naf_action: NULL argument");
+  ARG_CHECK(B >= 1 && B <= f->maxB, "cpp_naf_action: batch %d outside [1,%d]", B, f->maxB);
+  ARG_CHECK(dtype == CPP_F32 || dtype == CPP_F16, "cpp_naf_action: dtype %d", dtype);
+  cpp_ctx* ctx = f->ctx;
+  cpp_net* n = f->share ? f->value : f->mu;       // the network whose trunk sees the state
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (!n->stage_state) {
+    RC(n->arena.alloc(&n->stage_state, (size_t)n->maxB * n->state_elems * sizeof(float), false));
+    RC(dalloc(n->arena, &n->stage_action, (size_t)n->maxB * f->A));
+  }
+  HIP_CHECK(hipMemcpyAsync(n->stage_state, state, (size_t)B * n->state_elems * (dtype == CPP_F16 ? 2 : 4), hipMemcpyHostToDevice, ctx->stream));
+  if (n->spec.pixel) RC(batch_stats(ctx, n->stage_state, nullptr, dtype, n->state_elems, B, n->spec.C, n->stats_part, n->white));
+  n->is_training = false; f->mu->is_training = false;  // IS_TRAINING: False (naf_cartpole.py:253)
+  int frc = net_forward_trunk(n, n->ws[0], n->stage_state, dtype, n->white, B);
+  if (!frc) frc = net_forward_fc(n, n->ws[0], 0, B, nullptr);
+  if (!frc && f->share) frc = net_forward_fc(f->mu, f->mu->ws[0], 0, B, nullptr);
+  n->is_training = true; f->mu->is_training = true;
+  if (frc) return frc;
+  HIP_CHECK(hipMemcpyAsync(out, f->mu->ws[0].out, (size_t)B * f->A * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return CPP_OK;
+}
+
+extern "C" int cpp_naf_compute_gradients(cpp_naf* f, cpp_batch* b) {
+  RC(naf_check_batch(f, b, "cpp_naf_compute_gradients"));
+  HIP_CHECK(hipSetDevice(f->ctx->device));
+  return naf_compute_gradients(f, b);
+}
+extern "C" int cpp_naf_grad_buffer(cpp_naf* f, void** p, int64_t* n) {
+  ARG_CHECK(f && p && n, "cpp_naf_grad_buffer: NULL argument");
+  *p = f->gradbuf; *n = f->nV + f->nM + f->nL;
+  return CPP_OK;
+}
+extern "C" int cpp_naf_apply_gradients(cpp_naf* f, float grad_scale) {
+  ARG_CHECK(f, "cpp_naf_apply_gradients: NULL argument");
+  HIP_CHECK(hipSetDevice(f->ctx->device));
+  return naf_apply(f, grad_scale);
+}
+extern "C" int cpp_naf_update_targets(cpp_naf* f) {
+  ARG_CHECK(f, "cpp_naf_update_targets: NULL argument");
+  HIP_CHECK(hipSetDevice(f->ctx->device));
+  return launch_soft_update(f->ctx, f->tvalue->params, f->value->params, f->nV, nullptr, nullptr, 0, f->hp.target_update_rate);
+}
+
+extern "C" int cpp_naf_train(cpp_naf* f, cpp_batch* b, float* loss) {
+  RC(naf_check_batch(f, b, "cpp_naf_train"));
+  cpp_ctx* ctx = f->ctx;
+  HIP_CHECK(hipSetDevice(ctx->device));
+  HIP_CHECK(hipMemsetAsync(f->nonfinite, 0, sizeof(int), ctx->stream));
+  RC(naf_compute_gradients(f, b));
+  int bad = 0; float l = 0.f;
+  HIP_CHECK(hipMemcpyAsync(&bad, f->nonfinite, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipMemcpyAsync(&l, f->stats, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (loss) *loss = l;
+  if (bad) { cpp_set_error("check_numerics: l_values / L / loss is not finite (naf_cartpole.py:242-245)"); return CPP_ERR_NUMERIC; }
+  return naf_apply(f, 1.0f);
+}
+
+extern "C" int cpp_naf_debug_values(cpp_naf* f, cpp_batch* b, float* l_values, float* loss, float* value, float* advantage,
+                                    float* target_value) {
+  RC(naf_check_batch(f, b, "cpp_naf_debug_values"));
+  cpp_ctx* ctx = f->ctx;
+  HIP_CHECK(hipSetDevice(ctx->device));
+  const int B = b->B, C = f->value->spec.pixel ? f->value->spec.C : 0;
+  for (cpp_net* n : {f->value, f->tvalue, f->mu, f->lv}) n->is_training = false;      // IS_TRAINING: False (naf_cartpole.py:282)
+  const int frc = naf_forward(f, b->s[0], b->s[1], b->dtype, white_of(b, 0, C), white_of(b, 1, C), B);
+  for (cpp_net* n : {f->value, f->tvalue, f->mu, f->lv}) n->is_training = true;
+  if (frc) return frc;
+  RC(naf_head(f, b, false));
+  hipStream_t st = ctx->stream;
+  if (l_values) HIP_CHECK(hipMemcpyAsync(l_values, f->lv->ws[0].out, (size_t)B * f->NL * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (loss) HIP_CHECK(hipMemcpyAsync(loss, f->stats, sizeof(float), hipMemcpyDeviceToHost, st));
+  if (value) HIP_CHECK(hipMemcpyAsync(value, f->value->ws[0].out, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (advantage) HIP_CHECK(hipMemcpyAsync(advantage, f->adv, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (target_value) HIP_CHECK(hipMemcpyAsync(target_value, f->tvalue->ws[0].out, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  return CPP_OK;
+}
+
+static int naf_step_body(cpp_naf* f, cpp_replay* r, int B, int n_batches, const int32_t* rows_dev, uint64_t seed) {
+  const int C = f->value->spec.pixel ? f->value->spec.C : 0;
+  for (int i = 0; i < n_batches; ++i) {
+    RC(replay_sample_device(r, B, rows_dev ? rows_dev + (size_t)i * B : nullptr, seed, rows_dev ? nullptr : r->counter, C, f->step_batch,
+                            direct_replay_ok(f->value, r, B)));
+    if (!rows_dev) RC(launch_counter_add(f->ctx, r->counter, 1));
+    RC(naf_compute_gradients(f, f->step_batch));
+    RC(naf_apply(f, 1.0f));
+  }
+  return cpp_naf_update_targets(f);
+}
+
+extern "C" int cpp_naf_train_step(cpp_naf* f, cpp_replay* r, int B, int n_batches, const int32_t* idxs, uint64_t seed) {
+  ARG_CHECK(f && r, "cpp_naf_train_step: NULL argument");
+  ARG_CHECK(B >= 1 && B <= f->maxB, "cpp_naf_train_step: batch %d outside [1,%d]", B, f->maxB);
+  ARG_CHECK(n_batches >= 1 && (size_t)n_batches * B <= 65536, "cpp_naf_train_step: n_batches %d", n_batches);
+  ARG_CHECK(r->elems == f->value->state_elems && r->A == f->A, "cpp_naf_train_step: replay shape does not match the networks");
+  if (r->size <= 0) { cpp_set_error("cpp_naf_train_step: replay memory is empty"); return CPP_ERR_STATE; }
+  cpp_ctx* ctx = f->ctx;
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (!f->step_batch) RC(cpp_batch_create(ctx, f->maxB, r->elems, r->A, &f->step_batch));
+  if (idxs) {
+    for (int i = 0; i < n_batches * B; ++i)
+      ARG_CHECK(idxs[i] >= 0 && idxs[i] < r->size, "cpp_naf_train_step: index %d outside [0,%d)", idxs[i], r->size);
+    HIP_CHECK(hipMemcpyAsync(r->rows_in, idxs, (size_t)n_batches * B * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    return naf_step_body(f, r, B, n_batches, r->rows_in, seed);
+  }
+  if (ctx->prof) return naf_step_body(f, r, B, n_batches, nullptr, seed);
+  if (!f->graph_ok || f->g_B != B || f->g_nb != n_batches || f->g_seed != seed || f->g_replay != r || f->g_size != r->size) {
+    if (f->gexec) { (void)hipGraphExecDestroy(f->gexec); f->gexec = nullptr; }
+    if (f->graph) { (void)hipGraphDestroy(f->graph); f->graph = nullptr; }
+    f->graph_ok = false;
+    RC(naf_step_body(f, r, B, n_batches, nullptr, seed));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    int rc = naf_step_body(f, r, B, n_batches, nullptr, seed);
+    hipError_t e = hipStreamEndCapture(ctx->stream, &f->graph);
+    if (rc) return rc;
+    if (e != hipSuccess) { cpp_set_error("hipStreamEndCapture -> %s", hipGetErrorString(e)); return CPP_ERR_HIP; }
+    HIP_CHECK(hipGraphInstantiate(&f->gexec, f->graph, nullptr, nullptr, 0));
+    f->graph_ok = true; f->g_B = B; f->g_nb = n_batches; f->g_seed = seed; f->g_replay = r; f->g_size = r->size;
+    return CPP_OK;
+  }
+  HIP_CHECK(hipGraphLaunch(f->gexec, ctx->stream));
+  return CPP_OK;
+}
+
+extern "C" int cpp_naf_last_stats(cpp_naf* f, float out[3]) {
+  ARG_CHECK(f && out, "cpp_naf_last_stats: NULL argument");
+  int bad = 0;
+  HIP_CHECK(hipMemcpyAsync(out, f->stats, 2 * sizeof(float), hipMemcpyDeviceToHost, f->ctx->stream));
+  HIP_CHECK(hipMemcpyAsync(&bad, f->nonfinite, sizeof(int), hipMemcpyDeviceToHost, f->ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
+  out[2] = (float)bad;
+  return CPP_OK;
+}
+

@@ -220,6 +220,15 @@ class _Trainer(object):
         check(lib.cpp_ddpg_last_stats(self.handle, ptr(out)))
         return out
 
+    def last_values(self, B):
+        """(actions, dq_da, q, td) of the last minibatch's gradient pass, as the device left them -- the values the
+        reference dumps under VERBOSE_DEBUG (ddpg_cartpole.py:339-349); also after a fused / graph-replayed train_step."""
+        B, A = int(B), self.action_dim
+        actions, dq_da = np.empty((B, A), np.float32), np.empty((B, A), np.float32)
+        q, td = np.empty((B, 1), np.float32), np.empty((B, 1), np.float32)
+        check(lib.cpp_ddpg_last_values(self.handle, B, ptr(actions), ptr(dq_da), ptr(q), ptr(td)))
+        return actions, dq_da, q, td
+
     def grad_buffer(self):
         p, n = C.c_void_p(), C.c_int64()
         check(lib.cpp_ddpg_grad_buffer(self.handle, C.byref(p), C.byref(n)))

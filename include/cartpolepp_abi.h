@@ -209,6 +209,12 @@ int cpp_ddpg_train_step(cpp_ddpg* ddpg, cpp_replay* replay, int B, int n_batches
 int cpp_ddpg_sample_and_compute(cpp_ddpg* ddpg, cpp_replay* replay, int B, uint64_t seed);
 /* scalars of the last minibatch: [0] td loss, [1] actor grad norm, [2] critic grad norm (pre-clip). */
 int cpp_ddpg_last_stats(cpp_ddpg* ddpg, float out[3]);
+/* The per-row values the last minibatch's gradient pass left on the device (whichever entry point ran it: the train ops,
+ * cpp_ddpg_compute_gradients, the fused / graph-replayed cpp_ddpg_train_step, cpp_ddpg_sample_and_compute): the actor's
+ * actions on state_1 (B, A), dQ/da at those actions (B, A), Q(state_1, fed action) (B) and the temporal difference (B) --
+ * what the reference prints under VERBOSE_DEBUG (ddpg_cartpole.py:339-349).  NULL pointers are skipped.  Parity tests read
+ * the fused step's values through this call. */
+int cpp_ddpg_last_values(cpp_ddpg* ddpg, int B, float* actions, float* dq_da, float* q, float* td);
 
 /* ---- NAF train ops (naf_cartpole.py:93-284, :365-373) ----------------------------------------- */
 typedef struct cpp_naf_hyper {

@@ -224,15 +224,17 @@ def conv_bwd(x, W, dz, need_dx, chunk=8):
     return dW.reshape(W.shape), dz.sum(axis=(0, 1, 2)), dx
 
 
-def relu_pool_fwd(z):
+def relu_pool_fwd(z, with_zmax=False):
     """relu then 2x2/2 VALID max-pool (base_network.py:107): pool(relu(z)) == relu(max z).
-    Returns pooled (B,H//2,W//2,C) and the window arg-max code dy*2+dx."""
+    Returns pooled (B,H//2,W//2,C) and the window arg-max code dy*2+dx (with_zmax: also the pre-ReLU window maximum)."""
     B, H, W, C = z.shape
     hp, wp = H // 2, W // 2
     win = z[:, :2 * hp, :2 * wp, :].reshape(B, hp, 2, wp, 2, C).transpose(0, 1, 3, 5, 2, 4)
     win = win.reshape(B, hp, wp, C, 4)
     amax = win.argmax(axis=-1)
     zmax = np.take_along_axis(win, amax[..., None], axis=-1)[..., 0]
+    if with_zmax:
+        return np.maximum(zmax, 0), amax.astype(np.uint8), zmax
     return np.maximum(zmax, 0), amax.astype(np.uint8)
 
 
@@ -247,10 +249,11 @@ def pool_window_margin(z):
     return part[..., 3] - part[..., 2]
 
 
-def relu_pool_bwd(dp, pooled, amax, H, W):
-    """route dp to the window arg-max where the pooled (post-relu) value is > 0."""
+def relu_pool_bwd(dp, pooled, amax, H, W, active=None):
+    """route dp to the window arg-max where the pooled (post-relu) value is > 0 (`active`: tests only -- another
+    implementation's ReLU decision for windows whose maximum is zero to rounding, see Net.relu_override)."""
     B, hp, wp, C = dp.shape
-    g = np.where(pooled > 0, dp, 0)
+    g = np.where(pooled > 0 if active is None else active, dp, 0)
     win = np.zeros((B, hp, wp, C, 4), dtype=dp.dtype)
     np.put_along_axis(win, amax[..., None].astype(np.int64), g[..., None], axis=-1)
     dz = np.zeros((B, H, W, C), dtype=dp.dtype)
@@ -283,6 +286,7 @@ class Net(object):
         self.spec, self.dt = spec, dt
         self.p = unflatten(spec, flat_params, dt)
         self.amax_override = None     # tests only: {conv name: arg-max codes} to route the pool gradient with
+        self.relu_override = None     # tests only: {conv name: bool (B,h,w,C)} which pooled outputs the ReLU lets gradient through
         self.drop_masks = None        # dropout keep masks {layer name: (B, units) of 0/1} for the next training forward
 
     def flat(self):
@@ -310,8 +314,10 @@ class Net(object):
                     z = (zhat + self.p[name + "/biases"]).astype(dt)
                 else:
                     z = conv_fwd(x, self.p[name + "/weights"], self.p[name + "/biases"])
-                pooled, amax = relu_pool_fwd(z)
+                pooled, amax, zmax = relu_pool_fwd(z, with_zmax=True)
+                c[name + ":zmax"] = zmax              # pre-ReLU window maximum (tests: tell ReLU-boundary flips from errors)
                 c[name + ":margin"] = pool_window_margin(z)
+                c[name + ":amax_own"] = amax          # this forward's own arg-max (tests: tell near-tie flips from errors)
                 if self.amax_override is not None and name in self.amax_override:
                     amax = np.asarray(self.amax_override[name]).astype(np.uint8).reshape(amax.shape)
                 c[name] = (x, pooled, amax, h, w)
@@ -341,7 +347,10 @@ class Net(object):
         for idx in range(len(CONV_DEFS) - 1, -1, -1):
             name = CONV_DEFS[idx][0]
             x, pooled, amax, h, w = c[name]
-            dz = relu_pool_bwd(dp, pooled, amax, h, w)
+            active = None
+            if self.relu_override is not None and name in self.relu_override:
+                active = np.asarray(self.relu_override[name], bool).reshape(pooled.shape)
+            dz = relu_pool_bwd(dp, pooled, amax, h, w, active)
             if sp.batch_norm:
                 zhat, inv, training = c[name + ":bn"]
                 dbeta = dz.sum(axis=(0, 1, 2))
@@ -464,7 +473,7 @@ class DDPG(object):
         loss = (td * td).mean(dtype=dt)
         grads, _ = self.critic.backward(cb, (dt(2.0) * td / dt(B)).astype(dt))
         return {"q": cb["out"], "td": td, "loss": loss, "target_q": tq["out"],
-                "target_actions": ta["out"],
+                "target_actions": ta["out"], "cache_critic": cb,
                 "grads": flatten(self.critic.spec, grads, self.dt)}
 
     def check_loss(self, batch):      # ddpg_cartpole.py:239-248 (IS_TRAINING: False)

@@ -144,3 +144,134 @@ def dropout_masks(namespace, hidden, B, step):
                 m[b, j] = philox4x32_10([b * units + j, layer, step & 0xFFFFFFFF, step >> 32], [seed, 0])[0] & 1
         out["h%d" % layer] = m
     return out
+
+
+def device_relu_active(net, B):
+    """which pooled conv outputs of the device network's last forward are > 0 (the cells its backward lets gradient through)."""
+    return {name: getattr(net, "pool%d" % (i + 1)).eval(B) > 0 for i, (name, _k, _co) in enumerate(O.CONV_DEFS)}
+
+
+def relu_flips_are_at_the_boundary(cache, device_active, tol=1e-5, what=""):
+    """a forward cache of the oracle vs the device's ReLU decisions on the pooled conv outputs: where they differ, the oracle's
+    own pre-activation maximum must be zero to rounding (|z| <= tol) -- max(z, 0) is continuous there but its gradient is not.
+    Returns the number of such cells."""
+    flips = 0
+    for name, _k, _co in O.CONV_DEFS:
+        _x, pooled, _amax, _h, _w = cache[name]
+        zmax = cache[name + ":zmax"]
+        diff = np.asarray(device_active[name]).reshape(pooled.shape) != (pooled > 0)
+        bad = diff & (np.abs(zmax) > tol)
+        assert not bad.any(), "%s: %s ReLU decision differs at %d cell(s) that are not at the boundary (largest |z| %.3e)" % (
+            what, name, int(bad.sum()), float(np.abs(zmax[bad]).max()))
+        flips += int(diff.sum())
+    return flips
+
+
+def pool_flips_are_near_ties(cache, device_codes, margin_tol=1e-5, what=""):
+    """a forward cache computed with `amax_override = device_codes`: wherever the device routed a pooling window to another
+    element than the oracle's own arg-max (and the pooled value is positive, i.e. the route carries gradient), the oracle
+    must itself see a near tie there -- two largest pre-activations within margin_tol (relative to max(1, |value|)).
+    Returns the number of such windows."""
+    flips = 0
+    for name, _k, _co in O.CONV_DEFS:
+        _x, pooled, _amax, _h, _w = cache[name]
+        own, margin = cache[name + ":amax_own"], cache[name + ":margin"]
+        diff = (np.asarray(device_codes[name]).reshape(own.shape) != own) & (pooled > 0)
+        bad = diff & (margin > margin_tol * np.maximum(1.0, np.abs(pooled)))
+        assert not bad.any(), "%s: %s arg-max differs at %d window(s) that are not near ties (largest margin %.3e)" % (
+            what, name, int(bad.sum()), float(margin[bad].max()))
+        flips += int(diff.sum())
+    return flips
+
+
+def fused_step_against_f64_oracle(shape, B, rows, replay_store="f16", replay_size=None, seed=0, graph=True,
+                                  atol=1e-5, grad_rel=2e-5, param_rel=2e-6, warm="philox", report_only=False):
+    """ONE minibatch of the fused inner step (cpp_ddpg_train_step, default kernels: f16-pipe conv1 reading the replay store
+    through the sampled slots, bf16-pipe conv2, fused heads, paired launches) -- with graph=True the hipGraph REPLAY of it,
+    on rows drawn by the device's Philox sampler -- against oracle.DDPG(float64) on the same rows and the same starting
+    parameters: actions / Q / TD / dQ/da at `atol` (north_star: 1e-5), both pre-clip gradient lists per variable at
+    `grad_rel` (pool routes: the device's, accepted only at near ties), the clipped SGD result and the target updates."""
+    import ctypes
+    from cartpoleplusplus_amd import _lib
+    agent, _ref, (aspec, cspec) = make_pair(shape, B, True, seed=seed, replay_size=replay_size or rows + 50,
+                                           replay_store=replay_store)
+    report = {}
+    try:
+        rm = agent.replay_memory
+        rm.fill_synthetic(rows, seed=21 + seed)
+        if graph or warm == "philox-eager":
+            agent.train_step(B, 1)                        # eager pass + capture
+        elif warm == "rows":
+            agent.train_step(B, 1, idxs=np.random.default_rng(seed + 77).integers(0, rows, B).astype(np.int32))
+        nets = (agent.actor, agent.critic, agent.target_actor, agent.target_critic)
+        P = [n.get_params() for n in nets]
+        if graph:
+            agent.train_step(B, 1)                        # hipGraph replay, device-drawn rows
+            idxs = np.empty(B, np.int32)
+            _lib.check(_lib.lib.cpp_replay_last_indexes(rm.handle, B, idxs.ctypes.data_as(ctypes.c_void_p)))
+        else:
+            idxs = np.random.default_rng(seed + 5).integers(0, rows, B).astype(np.int32)
+            agent.train_step(B, 1, idxs=idxs)             # same launch sequence, eager, caller's rows
+        assert idxs.min() >= 0 and idxs.max() < rows and len(np.unique(idxs)) > B // 2
+        actions, dq_da, q, td = agent.trainer.last_values(B)
+        g_a, g_c = agent.actor.get_grads(), agent.critic.get_grads()
+        stats = agent.trainer.last_stats()
+        Pn = [n.get_params() for n in nets]
+        codes_a, codes_c = device_pool_codes(agent.actor, B), device_pool_codes(agent.critic, B)
+        relu_a, relu_c = device_relu_active(agent.actor, B), device_relu_active(agent.critic, B)
+        # the minibatch, read back through paths that do not involve the gather kernel's state copy
+        s1, s2 = rm.state[rm.state_1_idx[idxs]], rm.state[rm.state_2_idx[idxs]]
+        hb = rm.batch(idxs=idxs)
+        a, r, m = hb.action, hb.reward, hb.terminal_mask
+        assert np.array_equal(m[:, 0], rm.terminal_mask[idxs, 0]) and np.array_equal(r[:, 0], rm.reward[idxs, 0])
+    finally:
+        agent.close()
+    ref = O.DDPG(aspec, cspec, P[0], P[1], np.float64)
+    ref.set_targets(P[2], P[3])
+    # the two discontinuities of the trunk's gradient -- which element of a 2x2 window carries it, and whether the ReLU lets it
+    # through -- are taken from the device and must coincide with the oracle's own except at rounding-level ties
+    ref.actor.amax_override, ref.critic.amax_override = codes_a, codes_c
+    ref.actor.relu_override, ref.critic.relu_override = relu_a, relu_c
+    t = (s1, a, r, m, s2)
+    ag = ref.actor_gradients(s1)
+    cg = ref.critic_gradients(t)
+    report["flips_actor"] = pool_flips_are_near_ties(ag["cache_actor"], codes_a, what="actor")
+    report["flips_critic"] = pool_flips_are_near_ties(cg["cache_critic"], codes_c, what="critic")
+    report["relu_flips_actor"] = relu_flips_are_at_the_boundary(ag["cache_actor"], relu_a, what="actor")
+    report["relu_flips_critic"] = relu_flips_are_at_the_boundary(cg["cache_critic"], relu_c, what="critic")
+    report["err_actions"] = float(np.abs(actions - ag["actions"]).max())
+    report["err_dq_da"] = float(np.abs(dq_da - ag["dq_da"]).max())
+    report["err_q"] = float(np.abs(q - cg["q"]).max())
+    report["err_td"] = float(np.abs(td - cg["td"]).max())
+    report["q_scale"] = float(np.abs(cg["q"]).max())
+    if report_only:
+        report["events"] = {k: report[k] for k in report if "flips" in k}
+        report["actor"] = [(n, "%.2e" % r_) for n, _m, r_ in per_var_report(aspec, g_a, ag["grads"])][:6]
+        report["critic"] = [(n, "%.2e" % r_) for n, _m, r_ in per_var_report(cspec, g_c, cg["grads"])][:6]
+        return report
+    assert report["err_actions"] < atol and report["err_dq_da"] < atol, report
+    assert report["err_q"] < atol and report["err_td"] < atol, report
+    assert abs(stats[0] - cg["loss"]) < atol * max(1.0, abs(cg["loss"])), (stats, cg["loss"])
+    assert_flat_close(aspec, g_a, ag["grads"], rel=grad_rel, what="actor pre-clip grads vs f64 oracle")
+    assert_flat_close(cspec, g_c, cg["grads"], rel=grad_rel, what="critic pre-clip grads vs f64 oracle")
+    report["rel_actor_grads"] = max(r_[2] for r_ in per_var_report(aspec, g_a, ag["grads"]))
+    report["rel_critic_grads"] = max(r_[2] for r_ in per_var_report(cspec, g_c, cg["grads"]))
+    na, nc = float(np.linalg.norm(ag["grads"])), float(np.linalg.norm(cg["grads"]))
+    assert abs(stats[1] - na) < 1e-4 * max(1.0, na) and abs(stats[2] - nc) < 1e-4 * max(1.0, nc), (stats, na, nc)
+    # clip + SGD (util.py:47-50, ddpg_cartpole.py:118-119,218) and the target updates (:336-337) on top of them
+    hp = O.DEFAULT_HYPER
+    ca, _ = O.clip_by_global_norm(ag["grads"], hp.gradient_clip, np.float64)
+    cc, _ = O.clip_by_global_norm(cg["grads"], hp.gradient_clip, np.float64)
+    want_a, want_c = P[0] - hp.actor_lr * ca, P[1] - hp.critic_lr * cc
+    assert_flat_close(aspec, Pn[0], want_a, rel=param_rel, what="actor params after the step")
+    assert_flat_close(cspec, Pn[1], want_c, rel=param_rel, what="critic params after the step")
+    assert_flat_close(aspec, Pn[2], O.soft_update(P[2], want_a, hp.target_update_rate, np.float64), rel=1e-6, what="target actor")
+    assert_flat_close(cspec, Pn[3], O.soft_update(P[3], want_c, hp.target_update_rate, np.float64), rel=1e-6, what="target critic")
+    # the update itself (not hidden behind the much larger parameters): delta vs -lr * clipped gradient
+    for name, new, old, want in (("actor", Pn[0], P[0], want_a), ("critic", Pn[1], P[1], want_c)):
+        d_got, d_want = new.astype(np.float64) - old, want - old
+        report["rel_delta_" + name] = float(np.linalg.norm(d_got - d_want) / np.linalg.norm(d_want))
+        # f32 parameters: storing theta - lr*g rounds at |theta| * 2^-24 per element, on top of the gradient's own error
+        bound = 2.0 ** -23 * np.linalg.norm(old) + 5e-5 * np.linalg.norm(d_want)
+        assert np.linalg.norm(d_got - d_want) < bound, (name, report, bound)
+    return report

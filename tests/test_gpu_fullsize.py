@@ -82,22 +82,40 @@ def test_full_size_fused_step_equals_unfused_ops_and_is_deterministic():
     assert np.isfinite(results[("fused", 2)][0]).all() and np.isfinite(results[("fused", 2)][1]).all()
 
 
-def test_full_size_critic_gradient_against_f32_oracle():
-    """one full-size minibatch: critic TD gradients vs the oracle (float32 twin, BLAS) on the same batch."""
-    agent, ref64, (aspec, cspec) = make_pair(SHAPE, B, True, replay_size=600)
+def test_full_size_train_ops_against_f64_oracle():
+    """one full-size minibatch through the op-by-op train ops (actor.train, critic.train: ddpg_cartpole.py:140-145, :230-237)
+    against the float64 oracle at north_star's bar: Q / TD / actions / dQ/da within 1e-5, both pre-clip gradient lists per
+    variable at 2e-5 (the pool routes and ReLU decisions are the device's; one that differs from the oracle's own must be a
+    rounding-level tie: with 2.6 M pooling windows per network a minibatch holds O(1) of them)."""
+    from tests.helpers import device_pool_codes, pool_flips_are_near_ties, device_relu_active, relu_flips_are_at_the_boundary
+    agent, _ref, (aspec, cspec) = make_pair(SHAPE, B, True, replay_size=600)
     try:
         agent.replay_memory.fill_synthetic(500, seed=8)
         batch = agent.replay_memory.batch(idxs=np.random.default_rng(4).integers(0, 500, B))
         t = (batch.state_1, batch.action, batch.reward, batch.terminal_mask, batch.state_2)
-        ref = O.DDPG(aspec, cspec, agent.actor.get_params(), agent.critic.get_params(), np.float32)
-        ref.set_targets(agent.target_actor.get_params(), agent.target_critic.get_params())
-        cg = ref.critic_gradients(t)
+        P = [n.get_params() for n in agent.networks()]
         loss, td, q = agent.critic.check_loss(batch)
-        assert np.abs(q - cg["q"]).max() < 2e-5 and np.abs(td - cg["td"]).max() < 2e-5
+        agent.actor.train(batch)
+        actions, dq_da, _q, _td = agent.trainer.last_values(B)
+        g_a, codes_a, relu_a = agent.actor.get_grads(), device_pool_codes(agent.actor, B), device_relu_active(agent.actor, B)
         agent.critic.train(batch)
-        assert_flat_close(cspec, agent.critic.get_grads(), cg["grads"], rel=2e-4, what="critic grads (f32 oracle)")
+        g_c, codes_c, relu_c = agent.critic.get_grads(), device_pool_codes(agent.critic, B), device_relu_active(agent.critic, B)
     finally:
         agent.close()
+    ref = O.DDPG(aspec, cspec, P[0], P[1], np.float64)
+    ref.set_targets(P[2], P[3])
+    ref.actor.amax_override, ref.critic.amax_override = codes_a, codes_c
+    ref.actor.relu_override, ref.critic.relu_override = relu_a, relu_c
+    ag, cg = ref.actor_gradients(t[0]), ref.critic_gradients(t)
+    pool_flips_are_near_ties(ag["cache_actor"], codes_a, what="actor")
+    pool_flips_are_near_ties(cg["cache_critic"], codes_c, what="critic")
+    relu_flips_are_at_the_boundary(ag["cache_actor"], relu_a, what="actor")
+    relu_flips_are_at_the_boundary(cg["cache_critic"], relu_c, what="critic")
+    assert np.abs(q - cg["q"]).max() < 1e-5 and np.abs(td - cg["td"]).max() < 1e-5
+    assert abs(loss - cg["loss"]) < 1e-5 * max(1.0, abs(cg["loss"]))
+    assert np.abs(actions - ag["actions"]).max() < 1e-5 and np.abs(dq_da - ag["dq_da"]).max() < 1e-5
+    assert_flat_close(aspec, g_a, ag["grads"], rel=2e-5, what="actor grads (f64 oracle)")
+    assert_flat_close(cspec, g_c, cg["grads"], rel=2e-5, what="critic grads (f64 oracle)")
 
 
 @pytest.mark.parametrize("shape,Bs", [((128, 128, 3, 2, 5), 2), ((64, 64, 3, 1, 3), 3)],

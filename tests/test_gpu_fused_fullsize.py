@@ -1,0 +1,36 @@
+"""The fused inner step at the sizes BASELINE.json's metric is quoted on, against the float64 oracle at north_star's bar
+(actions / Q / TD within 1e-5; pre-clip gradients of BOTH networks per variable at 2e-5) -- the path bench.py times: default
+kernels (f16x3 conv1 reading the replay store through the sampled slots, bf16x9 conv2, fused heads, paired launches), the
+hipGraph replay, device-drawn rows.  Match: ddpg_cartpole.py:329-337, base_network.py:95-127."""
+import numpy as np
+import pytest
+
+from tests.helpers import fused_step_against_f64_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cfg3_B256_graph_replayed_fused_step_against_f64_oracle():
+    rep = fused_step_against_f64_oracle((64, 64, 3, 2, 3), 256, rows=2500, graph=True)
+    print("cfg3 B=256 fused graph step vs f64 oracle:", rep)
+
+
+def test_cfg3_B256_fused_step_with_caller_rows_against_f64_oracle():
+    rep = fused_step_against_f64_oracle((64, 64, 3, 2, 3), 256, rows=2500, graph=False, seed=3)
+    print("cfg3 B=256 fused eager step vs f64 oracle:", rep)
+
+
+def test_cfg2_B256_graph_replayed_fused_step_against_f64_oracle():
+    rep = fused_step_against_f64_oracle((64, 64, 3, 1, 3), 256, rows=2500, graph=True, seed=1)
+    print("cfg2 B=256 fused graph step vs f64 oracle:", rep)
+
+
+def test_cfg3_B256_fused_step_from_the_8_bit_store_against_f64_oracle():
+    rep = fused_step_against_f64_oracle((64, 64, 3, 2, 3), 256, rows=2500, graph=True, seed=2, replay_store="u8")
+    print("cfg3 B=256 (u8 store) fused graph step vs f64 oracle:", rep)
+
+
+def test_cfg5_B512_graph_replayed_fused_step_against_f64_oracle():
+    """BASELINE configs[4] at its own batch size: 128x128x30, B = 512 (the oracle pass is ~100 GFLOP of float64 numpy)."""
+    rep = fused_step_against_f64_oracle((128, 128, 3, 2, 5), 512, rows=1500, graph=True, seed=4)
+    print("cfg5 B=512 fused graph step vs f64 oracle:", rep)
