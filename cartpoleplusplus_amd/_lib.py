@@ -10,7 +10,15 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("CARTPOLEPP_LIB") or os.path.join(_HERE, "lib", "libcartpolepp_hip.so")   # env: ablation builds only
+# The release library reads no environment variable and is the only one loaded by default.  CARTPOLEPP_ABLATION=1 selects the
+# ablation build of the SAME sources (lib/libcartpolepp_hip_ablation.so: the CPP_* kernel-selection switches compiled in; parity
+# tests of the fallback kernels, bench.py's f32 control run); CARTPOLEPP_ABLATION=<name> an in-tree experiment build
+# lib/libcartpolepp_hip_<name>.so (profiles/).  No path can be injected: the file must sit in this package's lib/ directory.
+_variant = os.environ.get("CARTPOLEPP_ABLATION", "")
+if _variant and not _variant.replace("_", "").isalnum():
+    raise ImportError("cartpoleplusplus_amd: CARTPOLEPP_ABLATION=%r is not a build name" % _variant)
+LIB_PATH = os.path.join(_HERE, "lib", "libcartpolepp_hip%s.so" % (
+    "" if _variant in ("", "0") else "_ablation" if _variant == "1" else "_" + _variant))
 
 CPP_F32, CPP_F16, CPP_U8 = 0, 1, 2
 CPP_ACTOR, CPP_CRITIC, CPP_HEAD = 0, 1, 2
@@ -99,6 +107,20 @@ SIGNATURES = {
     "cpp_ddpg_sample_and_compute": (_I, [_P, _P, _I, _U64]),
     "cpp_ddpg_last_stats": (_I, [_P, _P]),
     "cpp_ddpg_last_values": (_I, [_P, _I, _P, _P, _P, _P]),
+    "cpp_comm_unique_id": (_I, [_P, _I]),
+    "cpp_comm_create": (_I, [_P, _P, _I, _I, _PP]),
+    "cpp_comm_destroy": (_I, [_P]),
+    "cpp_comm_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),
+    "cpp_comm_allreduce": (_I, [_P, _P, _L, _I]),
+    "cpp_comm_max_double": (_I, [_P, C.POINTER(C.c_double)]),
+    "cpp_comm_barrier": (_I, [_P]),
+    "cpp_ddpg_allreduce_grads": (_I, [_P, _P]),
+    "cpp_ddpg_average_params": (_I, [_P, _P]),
+    "cpp_ddpg_dp_train_step": (_I, [_P, _P, _P, _I, _I, _U64, _I, _I]),
+    "cpp_naf_sample_and_compute": (_I, [_P, _P, _I, _U64]),
+    "cpp_naf_allreduce_grads": (_I, [_P, _P]),
+    "cpp_naf_average_params": (_I, [_P, _P]),
+    "cpp_naf_dp_train_step": (_I, [_P, _P, _P, _I, _I, _U64, _I]),
     "cpp_naf_create": (_I, [_P, _P, _P, _P, _P, _I, C.POINTER(NafHyper), _PP]),
     "cpp_naf_destroy": (_I, [_P]),
     "cpp_naf_action": (_I, [_P, _P, _I, _I, _P]),

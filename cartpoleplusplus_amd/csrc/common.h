@@ -193,6 +193,8 @@ struct GatherArgs {
   int counter_add;              // the draw is keyed by *counter + counter_add (a gather that runs before the step that bumps the counter)
   const __half* lut;            // u8 store: f16(k / 255) for the 256 pixel codes
   long elems; int B; int size; int action_dim; int C;
+  const int32_t* size_ptr;      // non-null: the sampler's range is read from here (device word kept by cpp_replay_set_size), so
+                                // that a captured launch keeps sampling the whole memory as it grows; `size` otherwise
 };
 int launch_gather_stats(cpp_ctx* ctx, const GatherArgs& a, int dtype);
 struct DwReduceBatch;
@@ -284,6 +286,13 @@ int launch_naf_head(cpp_ctx* ctx, const NafHeadArgs& a);
 // launch bookkeeping
 // ---------------------------------------------------------------------------------------------
 void cpp_set_error(const char* fmt, ...);
+// Device allocations of the library (rt_core.cpp: every Arena block sits between two 256-byte guard bands and is registered).
+// The f16-pipe conv1 kernels load 16-byte operand windows that may start up to `before` bytes in front of an image batch and
+// end up to `after` bytes behind it (masked out afterwards): their launchers refuse any pointer for which those bytes are not
+// inside a registered block -- nothing outside the library's own allocations can reach such a kernel.
+bool cpp_arena_covers(const void* p, size_t bytes, size_t before, size_t after);
+void cpp_arena_register(const void* raw, size_t bytes);
+void cpp_arena_unregister(const void* raw);
 void prof_begin(cpp_ctx* ctx);
 void prof_end(cpp_ctx* ctx, int kid);
 

@@ -35,6 +35,21 @@ static void set_tiles(ConvArgs& a, int cin, int xtw) {
   a.ntiles = a.B * a.tiles_x * a.tiles_y;
 }
 
+// The f16-pipe kernels' operand windows start up to 128 bytes in front of an image and end up to 256 bytes behind it
+// (conv_k16.h / conv_dw16.h; the overhang is masked): the image batch -- or, when images are addressed through replay slots,
+// the store it starts -- must be one of the library's own guard-banded allocations.
+static int guard_band_check(const ConvArgsN& batch, int cin, const char* who) {
+  for (int i = 0; i < batch.n; ++i) {
+    const ConvArgs& a = batch.a[i];
+    const size_t bytes = a.img_slot ? (size_t)a.in_bstride * 2 : (size_t)a.B * a.in_bstride * 2;    // slots: validated by the replay memory
+    if (!cpp_arena_covers(a.in, bytes, 128, 256)) {
+      cpp_set_error("%s on the f16 pipes: the state batch at %p is not inside a guard-banded allocation of this library", who, a.in);
+      return 1;
+    }
+  }
+  return 0;
+}
+
 bool conv1_f16_pipes_ok(int cin, int H, int W, int B, bool batch_norm) {
   static const bool off = cpp_switch_off("CPP_CONV_K16") ||
                           cpp_switch_off("CPP_CONV_KYO");
@@ -100,6 +115,7 @@ int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, i
   static const bool no_k16 = cpp_switch_off("CPP_CONV_K16");
   if (!no_kyo && !no_k16 && in_mode == IN_F16_WHITEN && !dx_mode && a.B >= 2 && a.nout <= 10 && a.H >= 2) {
     bool handled = false;
+    if (int grc = guard_band_check(batch, cin, "conv1 forward")) { prof_end(ctx, kid); return grc; }
     rc = conv_fwd_k16_dispatch(ctx, cin, ks, in_mode, plain_fwd, batch, &handled);
     if (handled) { prof_end(ctx, kid == K_CONV1_FWD ? K_CONV1_FWD_F16X3 : kid); return rc; }
   }
@@ -183,6 +199,7 @@ int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, co
   // conv1 of f16 images: f16 matrix pipes with f32-exact operands (conv_dw16.h); CPP_CONV_K16=0 keeps the f32 MFMA kernel
   static const bool no_k16 = cpp_switch_off("CPP_CONV_K16");
   if (!no_kyo && !no_k16 && in_mode == IN_F16_WHITEN) {
+    if (int grc = guard_band_check(batch, cin, "conv1 dW")) { prof_end(ctx, kid); return grc; }
     const bool ride_open = ctx->ride != nullptr && !ctx->ride_done;
     rc = conv_dw16_dispatch(ctx, cin, ks, in_mode, dense, batch, &grid, &handled);
     if (handled) kid = kid == K_CONV1_DW ? K_CONV1_DW_F16X3 : kid;

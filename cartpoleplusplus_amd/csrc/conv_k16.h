@@ -266,7 +266,8 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     coe[i] = (unsigned)(px * nout + o);
   }
   const __amdgpu_buffer_rsrc_t b16_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      a.out_b16 ? a.out_b16 + (long)sbimg * (Hp * Wp * nout) : (unsigned short*)a.out, 0, a.out_b16 ? 0x7FFFFFF0 : 0, 0x00020000);
+      a.out_b16 ? a.out_b16 + (long)sbimg * (Hp * Wp * nout) : (unsigned short*)a.out, 0,
+      a.out_b16 ? (int)(2 * a.out_b16_plane * 2 + (long)Hp * Wp * nout * 2) : 0, 0x00020000);      // this image in the three planes, no further
   const int b16_plane_bytes = (int)(a.out_b16_plane * 2);
   const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       a.out + (long)sbimg * a.out_bstride, 0, (PLAIN ? H * W : Hp * Wp) * nout * 4, 0x00020000);
@@ -276,7 +277,8 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   // ---- A operands: 16 bytes per lane and (tile, chunk) straight from the image row
   const int rowbytes = W * CIN * 2;
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)((const char*)(B16 ? (const void*)a.in_b16 : a.in) + ((long)(a.img_slot ? a.img_slot[sbimg] : sbimg) * a.in_bstride) * 2 - G::BIAS_BYTES), 0, B16 ? 0x7FFFFFF0 : H * rowbytes + G::BIAS_BYTES + 256, 0x00020000);
+      (void*)((const char*)(B16 ? (const void*)a.in_b16 : a.in) + ((long)(a.img_slot ? a.img_slot[sbimg] : sbimg) * a.in_bstride) * 2 - G::BIAS_BYTES), 0,
+      (B16 ? 2 * (int)a.plane_stride : 0) + H * rowbytes + G::BIAS_BYTES + 256, 0x00020000);      // this image (B16: in its three planes) + the masked overhang
   const int avoff0 = G::BIAS_BYTES + ((strip * G::SW + li - P) * CIN + 8 * lj) * 2;     // >= 128 - 2 P CIN
   const int avoff = ODD ? (avoff0 & ~3) : avoff0;
   const unsigned ashift = ODD ? (unsigned)(avoff0 & 2) : 0u;    // per-lane constant: 16 * m * CIN pixels further keeps the parity

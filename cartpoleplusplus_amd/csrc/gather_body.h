@@ -75,7 +75,7 @@ __device__ __forceinline__ void gather_stats_body(const GatherArgs& a, const int
   if (lane == 0) {
     if (a.s_idx[0] == nullptr) { row = b; slot = b; }       // statistics over an already gathered batch
     else {
-      row = a.rows ? a.rows[b] : sample_row(a.seed, (a.counter ? *a.counter : 0) + (uint64_t)a.counter_add, b, a.size);
+      row = a.rows ? a.rows[b] : sample_row(a.seed, (a.counter ? *a.counter : 0) + (uint64_t)a.counter_add, b, a.size_ptr ? *a.size_ptr : a.size);
       slot = a.s_idx[which][row];
     }
   }

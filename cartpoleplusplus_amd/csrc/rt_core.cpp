@@ -14,6 +14,29 @@ void cpp_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* cpp_last_error(void) { return g_err; }
+
+// registry of the library's device allocations (see common.h: cpp_arena_covers)
+#include <map>
+#include <mutex>
+static std::mutex g_arena_mu;
+static std::map<const char*, size_t> g_arena_blocks;       // block start -> bytes (guard bands included)
+void cpp_arena_register(const void* raw, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_arena_mu);
+  g_arena_blocks[(const char*)raw] = bytes;
+}
+void cpp_arena_unregister(const void* raw) {
+  std::lock_guard<std::mutex> lk(g_arena_mu);
+  g_arena_blocks.erase((const char*)raw);
+}
+bool cpp_arena_covers(const void* p, size_t bytes, size_t before, size_t after) {
+  std::lock_guard<std::mutex> lk(g_arena_mu);
+  const char* lo = (const char*)p - before;
+  const char* hi = (const char*)p + bytes + after;
+  auto it = g_arena_blocks.upper_bound(lo);
+  if (it == g_arena_blocks.begin()) return false;
+  --it;
+  return lo >= it->first && hi <= it->first + it->second;
+}
 extern "C" int cpp_abi_version(void) { return CPP_ABI_VERSION; }
 
 void prof_begin(cpp_ctx* ctx) {

@@ -14,13 +14,16 @@ struct cpp_ddpg {
   int heads_grid, heads_B;                         // ... of the last graph built by compute_gradients (0: GEMM levels + td_kernel)
   int loss_parts, loss_B;                          // how cpp_ddpg_last_stats finds the loss of the last call: partials to add, or loss_norms[0]
   // graph replay of the full inner step
-  hipGraph_t graph; hipGraphExec_t gexec; bool graph_ok; int g_B, g_nb, g_size; uint64_t g_seed; cpp_replay* g_replay;   // g_size: rows in the replay when captured (the sampler's range is a kernel argument)
+  hipGraph_t graph; hipGraphExec_t gexec; bool graph_ok; int g_B, g_nb; uint64_t g_seed, g_replay_uid;   // (the sampler's range is read from the replay's device size word: one graph survives growth)
   cpp_batch* step_batch;
   // graph replay of the data-parallel half step (sample + both gradient sets)
   // three variants: 0 samples its own minibatch; 1 / 2 find it presampled (by the previous call's rider, conv1_dw_gather.hip)
   // in the second / first set of slot arrays.  One key for all three.
-  hipGraph_t hgraph[3]; hipGraphExec_t hexec[3]; bool hgraph_ok[3]; int h_B, h_size; uint64_t h_seed; cpp_replay* h_replay;
-  int h_next[3];           // variant the call after variant v must use (0: the rider did not leave)
+  // hg[0]: the whole half step as one graph per variant; hg[1]: split at the conv backward (two graphs per variant) so that the
+  // all-reduce of the fully-connected layers' gradients can run beside the conv backward (cpp_ddpg_dp_train_step, overlap)
+  struct HalfGraphs { hipGraph_t g[3][2]; hipGraphExec_t e[3][2]; bool ok[3]; int next[3]; } hg[2];   // next: variant of the following call
+  int h_B; uint64_t h_seed, h_replay_uid;
+  uint64_t dp_local;       // minibatches applied locally since the last parameter averaging (periodic mode)
   int pre_variant;         // variant of the next cpp_ddpg_sample_and_compute call if its key still matches (0: sample)
   int32_t* slot_set[2][2]; // the two sets of slot arrays of step_batch
   Arena arena;
@@ -40,9 +43,9 @@ extern "C" int cpp_ddpg_create(cpp_ctx* ctx, cpp_net* actor, cpp_net* critic, cp
   d->ctx = ctx; d->actor = actor; d->critic = critic; d->tactor = tactor; d->tcritic = tcritic; d->hp = *hp;
   d->maxB = actor->maxB < critic->maxB ? actor->maxB : critic->maxB;
   d->nA = actor->nparams; d->nC = critic->nparams;
-  d->graph = nullptr; d->gexec = nullptr; d->graph_ok = false; d->step_batch = nullptr; d->g_replay = nullptr;
-  for (int v = 0; v < 3; ++v) { d->hgraph[v] = nullptr; d->hexec[v] = nullptr; d->hgraph_ok[v] = false; d->h_next[v] = 0; }
-  d->h_replay = nullptr; d->pre_variant = 0; d->h_B = 0; d->h_size = 0; d->h_seed = 0;
+  d->graph = nullptr; d->gexec = nullptr; d->graph_ok = false; d->step_batch = nullptr; d->g_replay_uid = 0;
+  memset(d->hg, 0, sizeof(d->hg)); d->dp_local = 0;
+  d->h_replay_uid = 0; d->pre_variant = 0; d->h_B = 0; d->h_seed = 0;
   memset(d->slot_set, 0, sizeof(d->slot_set));
   d->heads_grid = d->heads_B = d->loss_parts = d->loss_B = 0;
   const int A = actor->spec.action_dim;
@@ -62,16 +65,24 @@ extern "C" int cpp_ddpg_create(cpp_ctx* ctx, cpp_net* actor, cpp_net* critic, cp
   return CPP_OK;
 }
 
+static void drop_half_graphs(cpp_ddpg* d) {
+  for (auto& H : d->hg)
+    for (int v = 0; v < 3; ++v) {
+      for (int k = 0; k < 2; ++k) {
+        if (H.e[v][k]) { (void)hipGraphExecDestroy(H.e[v][k]); H.e[v][k] = nullptr; }
+        if (H.g[v][k]) { (void)hipGraphDestroy(H.g[v][k]); H.g[v][k] = nullptr; }
+      }
+      H.ok[v] = false; H.next[v] = 0;
+    }
+}
+
 extern "C" int cpp_ddpg_destroy(cpp_ddpg* d) {
   if (!d) return CPP_OK;
   (void)hipSetDevice(d->ctx->device);
   (void)hipStreamSynchronize(d->ctx->stream);
   if (d->gexec) (void)hipGraphExecDestroy(d->gexec);
   if (d->graph) (void)hipGraphDestroy(d->graph);
-  for (int v = 0; v < 3; ++v) {
-    if (d->hexec[v]) (void)hipGraphExecDestroy(d->hexec[v]);
-    if (d->hgraph[v]) (void)hipGraphDestroy(d->hgraph[v]);
-  }
+  drop_half_graphs(d);
   if (d->step_batch) cpp_batch_destroy(d->step_batch);
   d->actor->grads = nullptr; d->critic->grads = nullptr;
   d->arena.release(); delete d; return CPP_OK;
@@ -236,7 +247,9 @@ extern "C" int cpp_ddpg_q_gradients_wrt_actions(cpp_ddpg* d, cpp_batch* b, float
 // Both gradient sets of one minibatch (ddpg_cartpole.py:331-334) as one dependency graph: 4 conv trunk
 // forwards, the MLP GEMMs batched level by level, 2 conv trunk backwards.  The critic trunk + the layers in
 // front of the action splice run once for both uses of critic(s1, .).
-static int compute_gradients(cpp_ddpg* d, cpp_batch* b) {
+// phase 0: everything.  The data-parallel step can split the pass at the conv backward: phase 1 = everything before it (all
+// gradients of the fully connected layers are then final), phase 2 = the conv backward + the dW reductions.
+static int compute_gradients(cpp_ddpg* d, cpp_batch* b, int phase = 0) {
   cpp_ctx* ctx = d->ctx;
   cpp_net *a = d->actor, *c = d->critic, *ta = d->tactor, *tc = d->tcritic;
   const int B = b->B, A = a->spec.action_dim, C = a->spec.pixel ? a->spec.C : 0;
@@ -444,12 +457,17 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b) {
       cdz = G.gemm(fc_dx_args(c, 0, B, c->ws[0].dz[0], L.n_out, 0, c->flat, c->ws[0].dpool[2], c->flat, GE_NONE, nullptr, 0), {cdz});
   }
   }
+  int conv_bwd = -1;
   if (c->spec.pixel) {     // both conv backward passes, layer by layer, two networks per launch
     cpp_net* bn[2] = {a, c};
-    G.fn([=] { return nets_backward_conv(ctx, bn, 2, B, s1, dt, w1); }, {adz, cdz});
+    conv_bwd = G.fn([=] { return nets_backward_conv(ctx, bn, 2, B, s1, dt, w1); }, {adz, cdz});
   }
-  RC(G.run(ctx));
-  return flush_dw_reduce(ctx);      // all six dW reductions (3 layers x 2 networks) in one launch
+  if (phase == 2) {
+    if (conv_bwd >= 0) RC(G.ops[conv_bwd].fn());
+    return flush_dw_reduce(ctx);
+  }
+  RC(G.run(ctx, phase == 1 ? conv_bwd : -1));
+  return phase == 1 ? (int)CPP_OK : flush_dw_reduce(ctx);      // all six dW reductions (3 layers x 2 networks) in one launch
 }
 
 extern "C" int cpp_ddpg_compute_gradients(cpp_ddpg* d, cpp_batch* b) {
@@ -547,7 +565,7 @@ extern "C" int cpp_ddpg_train_step(cpp_ddpg* d, cpp_replay* r, int B, int n_batc
   }
   static const bool no_graph = cpp_switch_set("CPP_NO_GRAPH");   // plain in-order stream launches (A/B measurements)
   if (ctx->prof || no_graph) return step_body(d, r, B, n_batches, nullptr, seed);
-  if (!d->graph_ok || d->g_B != B || d->g_nb != n_batches || d->g_seed != seed || d->g_replay != r || d->g_size != r->size) {
+  if (!d->graph_ok || d->g_B != B || d->g_nb != n_batches || d->g_seed != seed || d->g_replay_uid != r->uid) {
     if (d->gexec) { (void)hipGraphExecDestroy(d->gexec); d->gexec = nullptr; }
     if (d->graph) { (void)hipGraphDestroy(d->graph); d->graph = nullptr; }
     d->graph_ok = false;
@@ -560,7 +578,7 @@ extern "C" int cpp_ddpg_train_step(cpp_ddpg* d, cpp_replay* r, int B, int n_batc
     if (rc) return rc;
     if (e != hipSuccess) { cpp_set_error("hipStreamEndCapture -> %s", hipGetErrorString(e)); return CPP_ERR_HIP; }
     HIP_CHECK(hipGraphInstantiate(&d->gexec, d->graph, nullptr, nullptr, 0));
-    d->graph_ok = true; d->g_B = B; d->g_nb = n_batches; d->g_seed = seed; d->g_replay = r; d->g_size = r->size;
+    d->graph_ok = true; d->g_B = B; d->g_nb = n_batches; d->g_seed = seed; d->g_replay_uid = r->uid;
     return CPP_OK;   // the eager pass above was this call's step
   }
   HIP_CHECK(hipGraphLaunch(d->gexec, ctx->stream));
@@ -571,8 +589,9 @@ extern "C" int cpp_ddpg_train_step(cpp_ddpg* d, cpp_replay* r, int B, int n_batc
 // variant 0: sample + gather + statistics of this call's minibatch; 1 / 2: it was presampled by the previous call's rider into
 // slot set 1 / 0 (only its whitening tables are still to do).  Every variant tries to send the NEXT minibatch's sample pass
 // along with conv1's dW (the sampler's counter has been advanced by then, so the rider draws with the counter as it stands);
-// *next: the variant the following call must use.  CPP_RIDE_DP=0: always variant 0, no rider.
-static int half_step_body(cpp_ddpg* d, cpp_replay* r, int B, uint64_t seed, int variant, int* next) {
+// *next: the variant the following call must use.  CPP_RIDE_DP=0 (ablation build): always variant 0, no rider.
+// phase 0: the whole half step; 1: up to the conv backward; 2: the conv backward (with the rider) + dW reductions.
+static int half_step_body(cpp_ddpg* d, cpp_replay* r, int B, uint64_t seed, int variant, int* next, int phase) {
   const int C = d->actor->spec.pixel ? d->actor->spec.C : 0;
   cpp_ctx* ctx = d->ctx;
   cpp_batch* b = d->step_batch;
@@ -582,79 +601,180 @@ static int half_step_body(cpp_ddpg* d, cpp_replay* r, int B, uint64_t seed, int 
   for (int k = 0; k < 2; ++k) { b->slot[k] = d->slot_set[cur][k]; b->slot_alt[k] = d->slot_set[1 - cur][k]; }
   int Cg = 0;
   GatherArgs ga = replay_gather_args(r, B, nullptr, seed, r->counter, C, b, direct, &Cg);
-  if (variant == 0) RC(launch_gather_stats(ctx, ga, r->store_dtype));
-  RC(replay_sample_finish(r, B, Cg, C, b));
-  RC(launch_counter_add(ctx, r->counter, 1));
+  if (phase != 2) {
+    if (variant == 0) RC(launch_gather_stats(ctx, ga, r->store_dtype));
+    RC(replay_sample_finish(r, B, Cg, C, b));
+    RC(launch_counter_add(ctx, r->counter, 1));
+  }
+  if (phase == 1) return compute_gradients(d, b, 1);
   const bool ride_ok = !no_ride && direct && Cg > 0 && r->store_dtype == CPP_F16;
   if (ride_ok) {
     ga.out_slot[0] = b->slot_alt[0]; ga.out_slot[1] = b->slot_alt[1];
     ctx->ride = &ga; ctx->ride_done = false; ctx->ride_dtype = r->store_dtype; ctx->ride_at_dw = true;
   }
-  const int rc = compute_gradients(d, b);
+  const int rc = compute_gradients(d, b, phase);
   const bool rode = ctx->ride != nullptr && ctx->ride_done;
   ctx->ride = nullptr;
   *next = rode ? (cur == 0 ? 1 : 2) : 0;
   return rc;
 }
 
-extern "C" int cpp_ddpg_sample_and_compute(cpp_ddpg* d, cpp_replay* r, int B, uint64_t seed) {
-  ARG_CHECK(d && r, "cpp_ddpg_sample_and_compute: NULL argument");
-  ARG_CHECK(B >= 1 && B <= d->maxB, "cpp_ddpg_sample_and_compute: batch %d outside [1,%d]", B, d->maxB);
-  ARG_CHECK(r->elems == d->actor->state_elems && r->A == d->actor->spec.action_dim, "cpp_ddpg_sample_and_compute: replay shape does not match the networks");
-  if (r->size <= 0) { cpp_set_error("cpp_ddpg_sample_and_compute: replay memory is empty"); return CPP_ERR_STATE; }
+static int capture_into(cpp_ctx* ctx, hipGraph_t* g, hipGraphExec_t* e, const std::function<int()>& body) {
+  HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  const int rc = body();
+  const hipError_t err = hipStreamEndCapture(ctx->stream, g);
+  if (rc) return rc;
+  if (err != hipSuccess) { cpp_set_error("hipStreamEndCapture -> %s", hipGetErrorString(err)); return CPP_ERR_HIP; }
+  HIP_CHECK(hipGraphInstantiate(e, *g, nullptr, nullptr, 0));
+  return CPP_OK;
+}
+
+// One half step: sample (or find presampled) a minibatch and leave both gradient sets in the flat buffer.  hipGraph replay after
+// the first call per (variant, B, seed, replay).  split: two graphs per variant, `between` is called on the host between their
+// launches (the data-parallel step starts the all-reduce of the fully connected layers' gradients there).
+static int half_step(cpp_ddpg* d, cpp_replay* r, int B, uint64_t seed, bool split, const std::function<int()>& between) {
   cpp_ctx* ctx = d->ctx;
-  HIP_CHECK(hipSetDevice(ctx->device));
-  if (!d->step_batch) {
-    RC(cpp_batch_create(ctx, d->maxB, r->elems, r->A, &d->step_batch));
-    for (int k = 0; k < 2; ++k) { d->slot_set[0][k] = d->step_batch->slot[k]; d->slot_set[1][k] = d->step_batch->slot_alt[k]; }
-  }
+  if (!d->step_batch) RC(cpp_batch_create(ctx, d->maxB, r->elems, r->A, &d->step_batch));
   if (d->slot_set[0][0] == nullptr)
     for (int k = 0; k < 2; ++k) { d->slot_set[0][k] = d->step_batch->slot[k]; d->slot_set[1][k] = d->step_batch->slot_alt[k]; }
-  const bool key_ok = d->h_B == B && d->h_seed == seed && d->h_replay == r && d->h_size == r->size;
-  if (!key_ok) {                                     // another batch size / seed / memory, or rows were added: start over
-    for (int v = 0; v < 3; ++v) {
-      if (d->hexec[v]) { (void)hipGraphExecDestroy(d->hexec[v]); d->hexec[v] = nullptr; }
-      if (d->hgraph[v]) { (void)hipGraphDestroy(d->hgraph[v]); d->hgraph[v] = nullptr; }
-      d->hgraph_ok[v] = false;
-    }
+  const bool key_ok = d->h_B == B && d->h_seed == seed && d->h_replay_uid == r->uid;
+  if (!key_ok) {                                     // another batch size / seed / memory: start over
+    drop_half_graphs(d);
     d->pre_variant = 0;
-    d->h_B = B; d->h_seed = seed; d->h_replay = r; d->h_size = r->size;
+    d->h_B = B; d->h_seed = seed; d->h_replay_uid = r->uid;
   }
+  cpp_ddpg::HalfGraphs& H = d->hg[split ? 1 : 0];
   const int v = d->pre_variant;
   d->pre_variant = 0;                                // (stays 0 if anything below fails)
+  auto eager = [&](int variant, int* nx) -> int {
+    if (!split) return half_step_body(d, r, B, seed, variant, nx, 0);
+    RC(half_step_body(d, r, B, seed, variant, nx, 1));
+    if (between) RC(between());
+    return half_step_body(d, r, B, seed, variant, nx, 2);
+  };
+  auto capture = [&](int variant, int* nx) -> int {
+    if (!split) return capture_into(ctx, &H.g[variant][0], &H.e[variant][0], [&] { return half_step_body(d, r, B, seed, variant, nx, 0); });
+    RC(capture_into(ctx, &H.g[variant][0], &H.e[variant][0], [&] { return half_step_body(d, r, B, seed, variant, nx, 1); }));
+    return capture_into(ctx, &H.g[variant][1], &H.e[variant][1], [&] { return half_step_body(d, r, B, seed, variant, nx, 2); });
+  };
   int next = 0;
-  if (ctx->prof) { RC(half_step_body(d, r, B, seed, v, &next)); d->pre_variant = next; return CPP_OK; }
-  if (!d->hgraph_ok[v]) {
-    // this call's work is done by the captured graph's first launch: an eager pass first would consume the presampled batch
-    // and leave another one behind.  Kernel attributes: set by the first eager variant-0 pass below.
+  if (ctx->prof) { RC(eager(v, &next)); d->pre_variant = next; return CPP_OK; }
+  if (!H.ok[v]) {
+    // Variants 1 / 2 consume a presampled minibatch: their work must be done by the captured graph's first launch (an eager
+    // pass would consume it and leave another one behind).  Kernel attributes (LDS sizes: not allowed during capture) are set
+    // by variant 0's eager pass, which is also that call's work.
+    int nx = 0;
     if (v == 0) {
-      RC(half_step_body(d, r, B, seed, 0, &next));            // eager pass: sets kernel attributes, is this call's work
+      RC(eager(0, &next));
       HIP_CHECK(hipStreamSynchronize(ctx->stream));
-      HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-      int nx = 0;
-      int rc = half_step_body(d, r, B, seed, 0, &nx);
-      hipError_t e = hipStreamEndCapture(ctx->stream, &d->hgraph[0]);
-      if (rc) return rc;
-      if (e != hipSuccess) { cpp_set_error("hipStreamEndCapture -> %s", hipGetErrorString(e)); return CPP_ERR_HIP; }
-      HIP_CHECK(hipGraphInstantiate(&d->hexec[0], d->hgraph[0], nullptr, nullptr, 0));
-      d->hgraph_ok[0] = true; d->h_next[0] = nx;
+      RC(capture(0, &nx));
+      H.ok[0] = true; H.next[0] = nx;
       d->pre_variant = next;
       return CPP_OK;
     }
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    int nx = 0;
-    int rc = half_step_body(d, r, B, seed, v, &nx);
-    hipError_t e = hipStreamEndCapture(ctx->stream, &d->hgraph[v]);
-    if (rc) return rc;
-    if (e != hipSuccess) { cpp_set_error("hipStreamEndCapture -> %s", hipGetErrorString(e)); return CPP_ERR_HIP; }
-    HIP_CHECK(hipGraphInstantiate(&d->hexec[v], d->hgraph[v], nullptr, nullptr, 0));
-    d->hgraph_ok[v] = true; d->h_next[v] = nx;
+    RC(capture(v, &nx));
+    H.ok[v] = true; H.next[v] = nx;
   }
-  HIP_CHECK(hipGraphLaunch(d->hexec[v], ctx->stream));
-  d->pre_variant = d->h_next[v];
+  HIP_CHECK(hipGraphLaunch(H.e[v][0], ctx->stream));
+  if (split) {
+    if (between) RC(between());
+    HIP_CHECK(hipGraphLaunch(H.e[v][1], ctx->stream));
+  }
+  d->pre_variant = H.next[v];
   d->loss_parts = d->heads_grid; d->loss_B = d->heads_B;
   return CPP_OK;
+}
+
+static int half_step_checks(cpp_ddpg* d, cpp_replay* r, int B, const char* who) {
+  ARG_CHECK(d && r, "%s: NULL argument", who);
+  ARG_CHECK(B >= 1 && B <= d->maxB, "%s: batch %d outside [1,%d]", who, B, d->maxB);
+  ARG_CHECK(r->elems == d->actor->state_elems && r->A == d->actor->spec.action_dim, "%s: replay shape does not match the networks", who);
+  if (r->size <= 0) { cpp_set_error("%s: replay memory is empty", who); return CPP_ERR_STATE; }
+  return CPP_OK;
+}
+
+extern "C" int cpp_ddpg_sample_and_compute(cpp_ddpg* d, cpp_replay* r, int B, uint64_t seed) {
+  RC(half_step_checks(d, r, B, "cpp_ddpg_sample_and_compute"));
+  HIP_CHECK(hipSetDevice(d->ctx->device));
+  return half_step(d, r, B, seed, false, nullptr);
+}
+
+// ---- collectives of the data-parallel learners (communicator: rt_comm.cpp) --------------------------------------
+// the flat gradient buffer is [actor conv | actor fc | critic conv | critic fc]: offsets of the two fc parts
+static long fc_start(const cpp_net* n) { return n->fc[0].w_off; }
+
+extern "C" int cpp_ddpg_allreduce_grads(cpp_ddpg* d, cpp_comm* c) {
+  ARG_CHECK(d && c, "cpp_ddpg_allreduce_grads: NULL argument");
+  ARG_CHECK(c->ctx == d->ctx, "cpp_ddpg_allreduce_grads: communicator and networks live on different contexts");
+  HIP_CHECK(hipSetDevice(d->ctx->device));
+  NCCL_CHECK(ncclAllReduce(d->gradbuf, d->gradbuf, (size_t)(d->nA + d->nC), ncclFloat, ncclSum, c->comm, d->ctx->stream));
+  return CPP_OK;
+}
+
+// periodic mode: replicas that took k local steps meet again at the mean of their parameters (targets included: they are
+// functions of the parameter history and would otherwise drift apart)
+extern "C" int cpp_ddpg_average_params(cpp_ddpg* d, cpp_comm* c) {
+  ARG_CHECK(d && c, "cpp_ddpg_average_params: NULL argument");
+  ARG_CHECK(c->ctx == d->ctx, "cpp_ddpg_average_params: communicator and networks live on different contexts");
+  HIP_CHECK(hipSetDevice(d->ctx->device));
+  cpp_net* nets[4] = {d->actor, d->critic, d->tactor, d->tcritic};
+  NCCL_CHECK(ncclGroupStart());
+  for (cpp_net* n : nets)
+    NCCL_CHECK(ncclAllReduce(n->params, n->params, (size_t)n->nparams, ncclFloat, ncclAvg, c->comm, d->ctx->stream));
+  NCCL_CHECK(ncclGroupEnd());
+  d->dp_local = 0;
+  return CPP_OK;
+}
+
+// The inner step ddpg_cartpole.py:331-337 for N synchronous learners (this rank's part).  Per minibatch: sample from the own
+// replay shard + both gradient sets (hipGraph) -> sum over the ranks of the flat gradient buffer -> clip + SGD on the mean on
+// every rank (identical inputs: the replicas stay bit-identical without a broadcast).  sync_every = k > 1 ("periodic"): k local
+// minibatch updates, then the parameters are averaged.  overlap: the gradients of the fully connected layers (93 % of the
+// buffer) are reduced on a second stream while the conv backward of the same minibatch runs; the conv layers' follow.
+// comm == NULL: a single learner taking the same path (tests).  Whitening statistics and target updates are local.
+extern "C" int cpp_ddpg_dp_train_step(cpp_ddpg* d, cpp_replay* r, cpp_comm* c, int B, int n_batches, uint64_t seed,
+                                      int sync_every, int overlap) {
+  RC(half_step_checks(d, r, B, "cpp_ddpg_dp_train_step"));
+  ARG_CHECK(n_batches >= 1 && sync_every >= 1, "cpp_ddpg_dp_train_step: n_batches %d, sync_every %d", n_batches, sync_every);
+  ARG_CHECK(!c || c->ctx == d->ctx, "cpp_ddpg_dp_train_step: communicator and networks live on different contexts");
+  cpp_ctx* ctx = d->ctx;
+  HIP_CHECK(hipSetDevice(ctx->device));
+  const float inv = c ? 1.0f / (float)c->world : 1.0f;
+  const long fa = fc_start(d->actor), fcr = fc_start(d->critic);
+  for (int i = 0; i < n_batches; ++i) {
+    if (sync_every > 1) {                           // local update; every k-th one is followed by the parameter averaging
+      RC(half_step(d, r, B, seed, false, nullptr));
+      RC(apply(d, true, true, 1.0f));
+      if (++d->dp_local >= (uint64_t)sync_every && c) RC(cpp_ddpg_average_params(d, c));
+      continue;
+    }
+    if (c && overlap) {
+      RC(half_step(d, r, B, seed, true, [&]() -> int {        // between the two graphs: the fc gradients are final
+        HIP_CHECK(hipEventRecord(c->ev_fc, ctx->stream));
+        HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_fc, 0));
+        NCCL_CHECK(ncclGroupStart());
+        NCCL_CHECK(ncclAllReduce(d->gradbuf + fa, d->gradbuf + fa, (size_t)(d->nA - fa), ncclFloat, ncclSum, c->comm, c->side));
+        NCCL_CHECK(ncclAllReduce(d->gradbuf + d->nA + fcr, d->gradbuf + d->nA + fcr, (size_t)(d->nC - fcr), ncclFloat, ncclSum, c->comm, c->side));
+        NCCL_CHECK(ncclGroupEnd());
+        return CPP_OK; }));
+      HIP_CHECK(hipEventRecord(c->ev_bwd, ctx->stream));      // conv backward + dW reductions done: the conv parts follow
+      HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_bwd, 0));
+      if (fa > 0 || fcr > 0) {
+        NCCL_CHECK(ncclGroupStart());
+        if (fa > 0) NCCL_CHECK(ncclAllReduce(d->gradbuf, d->gradbuf, (size_t)fa, ncclFloat, ncclSum, c->comm, c->side));
+        if (fcr > 0) NCCL_CHECK(ncclAllReduce(d->gradbuf + d->nA, d->gradbuf + d->nA, (size_t)fcr, ncclFloat, ncclSum, c->comm, c->side));
+        NCCL_CHECK(ncclGroupEnd());
+      }
+      HIP_CHECK(hipEventRecord(c->ev_done, c->side));
+      HIP_CHECK(hipStreamWaitEvent(ctx->stream, c->ev_done, 0));
+    } else {
+      RC(half_step(d, r, B, seed, false, nullptr));
+      if (c) RC(cpp_ddpg_allreduce_grads(d, c));
+    }
+    RC(apply(d, true, true, inv));
+  }
+  return cpp_ddpg_update_targets(d);
 }
 
 extern "C" int cpp_ddpg_last_stats(cpp_ddpg* d, float out[3]) {

@@ -13,6 +13,8 @@
 #include <string>
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #define ARG_CHECK(cond, ...)                \
   do {                                      \
     if (!(cond)) {                          \
@@ -40,11 +42,12 @@ struct Arena {
     void* raw = nullptr;
     HIP_CHECK(hipMalloc(&raw, bytes + 2 * GUARD));
     ptrs.push_back(raw);
+    cpp_arena_register(raw, bytes + 2 * GUARD);
     *p = (char*)raw + GUARD;
     if (zero) HIP_CHECK(hipMemsetAsync(raw, 0, bytes + 2 * GUARD, stream));
     return 0;
   }
-  void release() { for (void* p : ptrs) (void)hipFree(p); ptrs.clear(); }
+  void release() { for (void* p : ptrs) { cpp_arena_unregister(p); (void)hipFree(p); } ptrs.clear(); }
 };
 template <typename T> static int dalloc(Arena& a, T** p, size_t count, bool zero = true) {
   return a.alloc((void**)p, count * sizeof(T), zero);
@@ -109,7 +112,10 @@ struct cpp_replay {
   cpp_ctx* ctx; int rows, slots, A, size; long elems;
   int store_dtype;         // CPP_F16 (replay_memory.py:32) or CPP_U8 (pixel codes k, read back as f16(k/255): half the HBM)
   void* store; int32_t *s1, *s2, *rows_in, *rows_out; float *action, *reward, *mask;
-  uint64_t* counter;       // device-side Philox counter for graph replay
+  uint64_t* counter;       // device-side Philox counter of the train steps (graph replay)
+  uint64_t* counter_adhoc; // the same for cpp_replay_sample(idxs == NULL): inspection draws never move the training sampler
+  int32_t* size_dev;       // rows currently in the memory, on the device: the sampler's range of captured launches
+  uint64_t uid;            // unique per cpp_replay_create (graph keys: an address can be reused, this cannot)
   __half* lut; int* bad; uint16_t lut_host[256];      // CPP_U8: f16(k/255) table, "not a pixel image" flag
   void* stage; size_t stage_cap;                      // device staging of incoming states (conversion source)
   void* pinned; size_t pinned_cap; hipEvent_t pinned_free; bool pinned_busy;   // host staging: writes return before the copy ends
@@ -139,8 +145,10 @@ struct OpGraph {
     for (int d : deps) if (d >= 0) o.deps.push_back(d);
     ops.push_back(o); return (int)ops.size() - 1;
   }
-  int run(cpp_ctx* ctx) {
+  // skip >= 0: that op is left out (the caller runs it on its own later -- the data-parallel step's split at the conv backward)
+  int run(cpp_ctx* ctx, int skip = -1) {
     size_t remaining = ops.size();
+    if (skip >= 0 && skip < (int)ops.size() && !ops[skip].done) { ops[skip].done = true; --remaining; }
     std::vector<int> ready; std::vector<GemmArgs> batch;
     while (remaining) {
       ready.clear(); batch.clear();
@@ -206,3 +214,18 @@ int replay_sample_finish(cpp_replay* r, int B, int C, int channels, cpp_batch* o
 int replay_sample_device(cpp_replay* r, int B, const int32_t* rows_dev, uint64_t seed, const uint64_t* counter_dev, int channels, cpp_batch* out, bool direct = false);
 const float* white_of(cpp_batch* b, int which, int C);
 bool direct_replay_ok(cpp_net* a, cpp_replay* r, int B);
+
+// ---- communicator of the data-parallel learners (rt_comm.cpp): one rank per cpp_ctx, RCCL over xGMI
+struct cpp_comm {
+  cpp_ctx* ctx; ncclComm_t comm; int rank, world;
+  hipStream_t side;            // second stream: collectives that overlap the conv backward of the same minibatch
+  hipEvent_t ev_fc, ev_bwd, ev_done;
+};
+#define NCCL_CHECK(expr)                                                                   \
+  do {                                                                                     \
+    ncclResult_t _r = (expr);                                                              \
+    if (_r != ncclSuccess) {                                                               \
+      cpp_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, ncclGetErrorString(_r)); \
+      return CPP_ERR_HIP;                                                                  \
+    }                                                                                      \
+  } while (0)

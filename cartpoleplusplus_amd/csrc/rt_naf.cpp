@@ -10,7 +10,10 @@ struct cpp_naf {
   float* gradbuf; float *m, *v;           // optimiser state over the same flat layout (Momentum / Adam)
   float *adv, *q, *td, *stats;            // stats: [0] loss [1] norm
   int* nonfinite; uint64_t* opt_step; double* norm_part;
-  hipGraph_t graph; hipGraphExec_t gexec; bool graph_ok; int g_B, g_nb, g_size; uint64_t g_seed; cpp_replay* g_replay;   // g_size: rows in the replay when captured (the sampler's range is a kernel argument)
+  hipGraph_t graph; hipGraphExec_t gexec; bool graph_ok; int g_B, g_nb; uint64_t g_seed, g_replay_uid;
+  // the data-parallel half step (sample + gradients) as a graph of its own
+  hipGraph_t hgraph; hipGraphExec_t hexec; bool hgraph_ok; int h_B; uint64_t h_seed, h_replay_uid;
+  uint64_t dp_local;       // minibatches applied locally since the last parameter averaging (periodic mode)
   cpp_batch* step_batch;
   Arena arena;
 };
@@ -41,7 +44,8 @@ extern "C" int cpp_naf_create(cpp_ctx* ctx, cpp_net* value, cpp_net* tvalue, cpp
   f->maxB = value->maxB; f->A = A; f->NL = A * (A + 1) / 2;
   for (cpp_net* n : {tvalue, mu, lv}) if (n->maxB < f->maxB) f->maxB = n->maxB;
   f->nV = value->nparams; f->nM = mu->nparams; f->nL = lv->nparams;
-  f->graph = nullptr; f->gexec = nullptr; f->graph_ok = false; f->step_batch = nullptr; f->g_replay = nullptr;
+  f->graph = nullptr; f->gexec = nullptr; f->graph_ok = false; f->step_batch = nullptr; f->g_replay_uid = 0;
+  f->hgraph = nullptr; f->hexec = nullptr; f->hgraph_ok = false; f->h_B = 0; f->h_seed = 0; f->h_replay_uid = 0; f->dp_local = 0;
   const size_t nall = (size_t)(f->nV + f->nM + f->nL);
   int rc = dalloc(f->arena, &f->gradbuf, nall);
   if (!rc) rc = dalloc(f->arena, &f->m, nall);
@@ -68,6 +72,8 @@ extern "C" int cpp_naf_destroy(cpp_naf* f) {
   if (!f) return CPP_OK;
   (void)hipSetDevice(f->ctx->device);
   (void)hipStreamSynchronize(f->ctx->stream);
+  if (f->hexec) (void)hipGraphExecDestroy(f->hexec);
+  if (f->hgraph) (void)hipGraphDestroy(f->hgraph);
   if (f->gexec) (void)hipGraphExecDestroy(f->gexec);
   if (f->graph) (void)hipGraphDestroy(f->graph);
   if (f->step_batch) cpp_batch_destroy(f->step_batch);
@@ -348,7 +354,7 @@ extern "C" int cpp_naf_train_step(cpp_naf* f, cpp_replay* r, int B, int n_batche
     return naf_step_body(f, r, B, n_batches, r->rows_in, seed);
   }
   if (ctx->prof) return naf_step_body(f, r, B, n_batches, nullptr, seed);
-  if (!f->graph_ok || f->g_B != B || f->g_nb != n_batches || f->g_seed != seed || f->g_replay != r || f->g_size != r->size) {
+  if (!f->graph_ok || f->g_B != B || f->g_nb != n_batches || f->g_seed != seed || f->g_replay_uid != r->uid) {
     if (f->gexec) { (void)hipGraphExecDestroy(f->gexec); f->gexec = nullptr; }
     if (f->graph) { (void)hipGraphDestroy(f->graph); f->graph = nullptr; }
     f->graph_ok = false;
@@ -360,11 +366,99 @@ extern "C" int cpp_naf_train_step(cpp_naf* f, cpp_replay* r, int B, int n_batche
     if (rc) return rc;
     if (e != hipSuccess) { cpp_set_error("hipStreamEndCapture -> %s", hipGetErrorString(e)); return CPP_ERR_HIP; }
     HIP_CHECK(hipGraphInstantiate(&f->gexec, f->graph, nullptr, nullptr, 0));
-    f->graph_ok = true; f->g_B = B; f->g_nb = n_batches; f->g_seed = seed; f->g_replay = r; f->g_size = r->size;
+    f->graph_ok = true; f->g_B = B; f->g_nb = n_batches; f->g_seed = seed; f->g_replay_uid = r->uid;
     return CPP_OK;
   }
   HIP_CHECK(hipGraphLaunch(f->gexec, ctx->stream));
   return CPP_OK;
+}
+
+// ---- data-parallel learners: the halves of one minibatch of naf_cartpole.py:367-371 -------------------------
+static int naf_half_body(cpp_naf* f, cpp_replay* r, int B, uint64_t seed) {
+  const int C = f->value->spec.pixel ? f->value->spec.C : 0;
+  RC(replay_sample_device(r, B, nullptr, seed, r->counter, C, f->step_batch, direct_replay_ok(f->value, r, B)));
+  RC(launch_counter_add(f->ctx, r->counter, 1));
+  return naf_compute_gradients(f, f->step_batch);
+}
+
+static int naf_half_checks(cpp_naf* f, cpp_replay* r, int B, const char* who) {
+  ARG_CHECK(f && r, "%s: NULL argument", who);
+  ARG_CHECK(B >= 1 && B <= f->maxB, "%s: batch %d outside [1,%d]", who, B, f->maxB);
+  ARG_CHECK(r->elems == f->value->state_elems && r->A == f->A, "%s: replay shape does not match the networks", who);
+  if (r->size <= 0) { cpp_set_error("%s: replay memory is empty", who); return CPP_ERR_STATE; }
+  return CPP_OK;
+}
+
+// sample B rows on the device (Philox; the counter advances by one) and leave the gradients of the three networks in the flat
+// buffer [value | mu | l_values]; hipGraph-captured after the first call per (B, seed, replay)
+extern "C" int cpp_naf_sample_and_compute(cpp_naf* f, cpp_replay* r, int B, uint64_t seed) {
+  RC(naf_half_checks(f, r, B, "cpp_naf_sample_and_compute"));
+  cpp_ctx* ctx = f->ctx;
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (!f->step_batch) RC(cpp_batch_create(ctx, f->maxB, r->elems, r->A, &f->step_batch));
+  if (ctx->prof) return naf_half_body(f, r, B, seed);
+  if (!f->hgraph_ok || f->h_B != B || f->h_seed != seed || f->h_replay_uid != r->uid) {
+    if (f->hexec) { (void)hipGraphExecDestroy(f->hexec); f->hexec = nullptr; }
+    if (f->hgraph) { (void)hipGraphDestroy(f->hgraph); f->hgraph = nullptr; }
+    f->hgraph_ok = false;
+    RC(naf_half_body(f, r, B, seed));                // eager pass: sets kernel attributes, is this call's work
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = naf_half_body(f, r, B, seed);
+    const hipError_t e = hipStreamEndCapture(ctx->stream, &f->hgraph);
+    if (rc) return rc;
+    if (e != hipSuccess) { cpp_set_error("hipStreamEndCapture -> %s", hipGetErrorString(e)); return CPP_ERR_HIP; }
+    HIP_CHECK(hipGraphInstantiate(&f->hexec, f->hgraph, nullptr, nullptr, 0));
+    f->hgraph_ok = true; f->h_B = B; f->h_seed = seed; f->h_replay_uid = r->uid;
+    return CPP_OK;
+  }
+  HIP_CHECK(hipGraphLaunch(f->hexec, ctx->stream));
+  return CPP_OK;
+}
+
+extern "C" int cpp_naf_allreduce_grads(cpp_naf* f, cpp_comm* c) {
+  ARG_CHECK(f && c, "cpp_naf_allreduce_grads: NULL argument");
+  ARG_CHECK(c->ctx == f->ctx, "cpp_naf_allreduce_grads: communicator and networks live on different contexts");
+  HIP_CHECK(hipSetDevice(f->ctx->device));
+  NCCL_CHECK(ncclAllReduce(f->gradbuf, f->gradbuf, (size_t)(f->nV + f->nM + f->nL), ncclFloat, ncclSum, c->comm, f->ctx->stream));
+  return CPP_OK;
+}
+
+// periodic mode: parameters, the target and the optimiser slots (Momentum accumulators / Adam moments) of the replicas meet at
+// their mean
+extern "C" int cpp_naf_average_params(cpp_naf* f, cpp_comm* c) {
+  ARG_CHECK(f && c, "cpp_naf_average_params: NULL argument");
+  ARG_CHECK(c->ctx == f->ctx, "cpp_naf_average_params: communicator and networks live on different contexts");
+  HIP_CHECK(hipSetDevice(f->ctx->device));
+  const size_t nall = (size_t)(f->nV + f->nM + f->nL);
+  cpp_net* nets[4] = {f->value, f->mu, f->lv, f->tvalue};
+  NCCL_CHECK(ncclGroupStart());
+  for (cpp_net* n : nets)
+    NCCL_CHECK(ncclAllReduce(n->params, n->params, (size_t)n->nparams, ncclFloat, ncclAvg, c->comm, f->ctx->stream));
+  if (f->hp.optimiser != CPP_OPT_SGD) NCCL_CHECK(ncclAllReduce(f->m, f->m, nall, ncclFloat, ncclAvg, c->comm, f->ctx->stream));
+  if (f->hp.optimiser == CPP_OPT_ADAM) NCCL_CHECK(ncclAllReduce(f->v, f->v, nall, ncclFloat, ncclAvg, c->comm, f->ctx->stream));
+  NCCL_CHECK(ncclGroupEnd());
+  f->dp_local = 0;
+  return CPP_OK;
+}
+
+// the inner step naf_cartpole.py:367-373 for N synchronous learners (this rank's part); see cpp_ddpg_dp_train_step
+extern "C" int cpp_naf_dp_train_step(cpp_naf* f, cpp_replay* r, cpp_comm* c, int B, int n_batches, uint64_t seed, int sync_every) {
+  RC(naf_half_checks(f, r, B, "cpp_naf_dp_train_step"));
+  ARG_CHECK(n_batches >= 1 && sync_every >= 1, "cpp_naf_dp_train_step: n_batches %d, sync_every %d", n_batches, sync_every);
+  ARG_CHECK(!c || c->ctx == f->ctx, "cpp_naf_dp_train_step: communicator and networks live on different contexts");
+  const float inv = c ? 1.0f / (float)c->world : 1.0f;
+  for (int i = 0; i < n_batches; ++i) {
+    RC(cpp_naf_sample_and_compute(f, r, B, seed));
+    if (sync_every > 1) {
+      RC(naf_apply(f, 1.0f));
+      if (++f->dp_local >= (uint64_t)sync_every && c) RC(cpp_naf_average_params(f, c));
+    } else {
+      if (c) RC(cpp_naf_allreduce_grads(f, c));
+      RC(naf_apply(f, inv));
+    }
+  }
+  return cpp_naf_update_targets(f);
 }
 
 extern "C" int cpp_naf_last_stats(cpp_naf* f, float out[3]) {

@@ -117,6 +117,8 @@ static int replay_create(cpp_ctx* ctx, int buffer_size, int state_slots, int64_t
   if (!rc) rc = dalloc(r->arena, &r->reward, (size_t)buffer_size);
   if (!rc) rc = dalloc(r->arena, &r->mask, (size_t)buffer_size);
   if (!rc) rc = dalloc(r->arena, &r->counter, (size_t)1);
+  if (!rc) rc = dalloc(r->arena, &r->counter_adhoc, (size_t)1);
+  if (!rc) rc = dalloc(r->arena, &r->size_dev, (size_t)1);
   if (!rc) {
     rc = r->arena.alloc((void**)&r->lut, 256 * sizeof(__half), false);
     if (!rc) rc = r->arena.alloc((void**)&r->bad, sizeof(int), true);
@@ -126,7 +128,16 @@ static int replay_create(cpp_ctx* ctx, int buffer_size, int state_slots, int64_t
     }
   }
   if (rc) { r->arena.release(); delete r; return rc; }
+  static uint64_t next_uid = 1;
+  r->uid = next_uid++;
   *out = r;
+  return CPP_OK;
+}
+// rows in the memory: host copy (argument checks) + device word (the sampler's range, also of captured launches)
+static int replay_set_size(cpp_replay* r, int size) {
+  r->size = size;
+  HIP_CHECK(hipMemcpyAsync(r->size_dev, &r->size, sizeof(int32_t), hipMemcpyHostToDevice, r->ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(r->ctx->stream));
   return CPP_OK;
 }
 extern "C" int cpp_replay_create(cpp_ctx* ctx, int buffer_size, int state_slots, int64_t state_elems,
@@ -228,9 +239,9 @@ extern "C" int cpp_replay_write_rows(cpp_replay* r, const int32_t* rows, int n, 
 }
 
 extern "C" int cpp_replay_set_size(cpp_replay* r, int size) {
-  ARG_CHECK(r && size >= 0 && size <= r->rows, "cpp_replay_set_size: size %d", size);
-  r->size = size;
-  return CPP_OK;
+  ARG_CHECK(r && size >= 0 && size <= r->rows, "cpp_replay_set_size: size %d outside [0,%d]", size, r ? r->rows : 0);
+  HIP_CHECK(hipSetDevice(r->ctx->device));
+  return replay_set_size(r, size);
 }
 
 extern "C" int cpp_replay_read_states(cpp_replay* r, const int32_t* slots, int n, void* out_f16) {
@@ -273,7 +284,7 @@ GatherArgs replay_gather_args(cpp_replay* r, int B, const int32_t* rows_dev, uin
   out->direct_store = direct ? r->store : nullptr;
   a.out_action = out->a; a.out_reward = out->r; a.out_mask = out->m;
   a.part = out->part; a.seed = seed; a.counter = counter_dev;
-  a.elems = r->elems; a.B = B; a.size = r->size; a.action_dim = r->A; a.C = C;
+  a.elems = r->elems; a.B = B; a.size = r->size; a.size_ptr = r->size_dev; a.action_dim = r->A; a.C = C;
   *C_out = C;
   return a;
 }
@@ -312,9 +323,9 @@ extern "C" int cpp_replay_sample(cpp_replay* r, int B, const int32_t* idxs, uint
     HIP_CHECK(hipMemcpyAsync(r->rows_in, idxs, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, st));
     rows_dev = r->rows_in;
   } else {
-    HIP_CHECK(hipMemcpyAsync(r->counter, &counter, sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(r->counter_adhoc, &counter, sizeof(uint64_t), hipMemcpyHostToDevice, st));
   }
-  RC(replay_sample_device(r, B, rows_dev, seed, idxs ? nullptr : r->counter, channels, out));
+  RC(replay_sample_device(r, B, rows_dev, seed, idxs ? nullptr : r->counter_adhoc, channels, out));
   if (idxs) HIP_CHECK(hipStreamSynchronize(st));     // the caller's index array may go away after return
   return CPP_OK;
 }
@@ -334,7 +345,6 @@ extern "C" int cpp_replay_fill_synthetic(cpp_replay* r, int n_rows, uint64_t see
                         r->action, r->reward, r->mask, n_rows, r->A, seed));
   if (r->store_dtype == CPP_U8) RC(launch_replay_fill_u8(r->ctx, (uint8_t*)r->store, r->elems * (long)r->slots, seed));
   HIP_CHECK(hipStreamSynchronize(r->ctx->stream));
-  r->size = n_rows;
-  return CPP_OK;
+  return replay_set_size(r, n_rows);
 }
 

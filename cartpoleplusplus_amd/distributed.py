@@ -1,19 +1,119 @@
-"""Data-parallel actor-learners: one process per GPU, replicated weights, one flat-gradient all-reduce
-per minibatch over RCCL/xGMI (torch.distributed backend "nccl" == RCCL on ROCm).
+"""Data-parallel actor-learners: one process per GPU, replicated weights, an own replay shard and an own
+minibatch per learner, collectives on RCCL over xGMI.
 
 The reference is single-process (its only nod to this is the TODO "switch back to async training with
-multiple replicas", ddpg_cartpole.py:259).  Per minibatch every learner samples from its own replay
-shard and leaves [actor grads | critic grads] in ONE flat f32 buffer (cpp_ddpg_sample_and_compute); the
-buffer is summed across ranks, and every rank applies clip + SGD to the mean (cpp_ddpg_apply_gradients
-with grad_scale = 1/world) -- identical inputs on every rank, so the replicas stay bit-identical with no
-parameter broadcast.  Whitening statistics and target soft updates are local.
+multiple replicas", ddpg_cartpole.py:259 / naf_cartpole.py:294).  Two modes:
 
-torch is plumbing here: it owns the process group and the collective; the gradient buffer belongs to the
-HIP library and is exposed to torch zero-copy through __cuda_array_interface__.
+  sync_every = 1   per minibatch every learner leaves [actor grads | critic grads] in ONE flat f32 buffer, the buffer is
+                   summed across ranks, and every rank applies clip + SGD to the mean -- identical inputs on every rank, so
+                   the replicas stay bit-identical with no parameter broadcast.
+  sync_every = k   ("periodic") k local minibatch updates, then the parameters (targets and optimiser slots included) are
+                   averaged across ranks.
+Whitening statistics and target soft updates are local in both.
+
+The product path is `NativeLearner`: the whole step -- hipGraph-captured half steps, the ncclAllReduce calls, the optimiser
+kernels -- runs behind the C ABI (cpp_ddpg_dp_train_step / cpp_naf_dp_train_step with a cpp_comm); torch.distributed is only
+used to hand the 128-byte communicator id from rank 0 to the other ranks.  `DataParallelLearner` is the same protocol written
+out on the host with pluggable pieces: the world-size-2 gloo tests on CPU drive it, and `TorchCollectiveLearner` (the
+half-step entry points + a torch.distributed all-reduce of the library's gradient buffer) is the fallback bench.py takes if
+the library's own communicator cannot be created.
 """
 import ctypes as C
+import os
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# the library's communicator
+# ---------------------------------------------------------------------------------------------------------------------
+class Communicator(object):
+    """cpp_comm: this rank's end of an RCCL communicator on a Context's GPU."""
+    ID_BYTES = 128
+
+    def __init__(self, ctx, unique_id, rank, world):
+        from ._lib import lib, check
+        assert len(unique_id) == self.ID_BYTES
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), self.ID_BYTES)
+        check(lib.cpp_comm_create(ctx.handle, buf, int(rank), int(world), C.byref(h)))
+        self.handle, self.ctx, self.rank, self.world = h, ctx, int(rank), int(world)
+
+    @staticmethod
+    def new_unique_id():
+        from ._lib import lib, check
+        buf = C.create_string_buffer(Communicator.ID_BYTES)
+        check(lib.cpp_comm_unique_id(buf, Communicator.ID_BYTES))
+        return bytes(buf.raw)
+
+    @classmethod
+    def from_torch_distributed(cls, ctx, group=None):
+        """rank / world from the initialised torch.distributed group (any backend: only one small object is broadcast)."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.new_unique_id() if rank == 0 else None]
+        kw = {}
+        if dist.get_backend(group) == "nccl":
+            import torch
+            kw["device"] = torch.device("cuda", ctx.device_id)
+        dist.broadcast_object_list(box, src=0, group=group, **kw)
+        return cls(ctx, box[0], rank, world)
+
+    @classmethod
+    def single(cls, ctx):
+        return cls(ctx, cls.new_unique_id(), 0, 1)
+
+    def barrier(self):
+        from ._lib import lib, check
+        check(lib.cpp_comm_barrier(self.handle))
+
+    def max_over_ranks(self, value):
+        from ._lib import lib, check
+        v = C.c_double(float(value))
+        check(lib.cpp_comm_max_double(self.handle, C.byref(v)))
+        return v.value
+
+    def close(self):
+        if self.handle:
+            from ._lib import lib
+            lib.cpp_comm_destroy(self.handle)
+            self.handle = None
+
+
+class NativeLearner(object):
+    """the data-parallel inner step behind the C ABI (ddpg_cartpole.py:331-337 / naf_cartpole.py:367-373 for N learners)."""
+
+    def __init__(self, agent, batch_size, seed, comm=None, sync_every=1, overlap=False):
+        from ._lib import lib, check
+        self._lib, self._check = lib, check
+        self.agent, self.B, self.seed, self.comm = agent, int(batch_size), int(seed), comm
+        self.sync_every, self.overlap = int(sync_every), bool(overlap)
+        self.is_naf = hasattr(agent, "naf")
+        self.world = comm.world if comm is not None else 1
+
+    def train_step(self, batches_per_step):
+        rm, ch = self.agent.replay_memory, self.comm.handle if self.comm is not None else None
+        rm.stats[">batch"] += batches_per_step
+        if self.is_naf:
+            self._check(self._lib.cpp_naf_dp_train_step(self.agent.naf.handle, rm.handle, ch, self.B, int(batches_per_step),
+                                                        self.seed, self.sync_every))
+        else:
+            self._check(self._lib.cpp_ddpg_dp_train_step(self.agent.trainer.handle, rm.handle, ch, self.B, int(batches_per_step),
+                                                         self.seed, self.sync_every, 1 if self.overlap else 0))
+
+    def describe(self):
+        how = ("flat-gradient ncclAllReduce per minibatch%s" % (", fc gradients reduced beside the conv backward" if self.overlap else "")
+               if self.sync_every == 1 else "%d local minibatches between parameter averagings (ncclAvg)" % self.sync_every)
+        return "dp%d: one learner per GPU behind the C ABI (cpp_%s_dp_train_step), own replay shard, %s over RCCL" % (
+            self.world, "naf" if self.is_naf else "ddpg", how)
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the protocol on the host (CPU tests with gloo; fallback with torch's collective)
+# ---------------------------------------------------------------------------------------------------------------------
 class _DeviceBufferView(object):
     """zero-copy view of a device f32 buffer for torch.as_tensor(..., device='cuda')."""
 
@@ -23,12 +123,13 @@ class _DeviceBufferView(object):
 
 
 class GradAllReducer(object):
-    """sum-all-reduce of a flat gradient buffer.  `tensor` may be any torch tensor (CPU + gloo in the
-    unit tests; the HIP library's device buffer + RCCL in production)."""
+    """sum- / mean-all-reduce of flat buffers through torch.distributed.  `tensor` may be any torch tensor (CPU + gloo in
+    the unit tests; the HIP library's device buffer + RCCL in the fallback learner)."""
 
-    def __init__(self, tensor, group=None, stream=None):
+    def __init__(self, tensor, group=None, stream=None, param_tensors=()):
         import torch.distributed as dist
         self.dist, self.tensor, self.group, self.stream = dist, tensor, group, stream
+        self.param_tensors = list(param_tensors)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.always = False        # run the collective even at world size 1 (plumbing tests)
 
@@ -40,39 +141,55 @@ class GradAllReducer(object):
         assert t.data_ptr() == p and t.numel() == n
         return cls(t, group, torch_stream)
 
-    def allreduce_sum(self):
+    def _run(self, fn):
         if self.world == 1 and not self.always:
             return
         if self.stream is not None:
             import torch
             with torch.cuda.stream(self.stream):
-                self.dist.all_reduce(self.tensor, op=self.dist.ReduceOp.SUM, group=self.group)
+                fn()
         else:
-            self.dist.all_reduce(self.tensor, op=self.dist.ReduceOp.SUM, group=self.group)
+            fn()
+
+    def allreduce_sum(self):
+        self._run(lambda: self.dist.all_reduce(self.tensor, op=self.dist.ReduceOp.SUM, group=self.group))
+
+    def average_params(self):
+        def fn():
+            for t in self.param_tensors:
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+                t.mul_(1.0 / self.world)
+        self._run(fn)
 
 
 class DataParallelLearner(object):
-    """the inner train step (ddpg_cartpole.py:331-337) for N synchronous learners.
-
-    `ops` supplies the three device-side pieces so that the protocol can be unit-tested on CPU:
+    """the inner train step (ddpg_cartpole.py:331-337) for N synchronous learners -- the same sequence as
+    cpp_ddpg_dp_train_step, with the device-side pieces supplied by `ops` so that it can be unit-tested on CPU:
       ops.sample_and_compute()   -> fills the flat gradient buffer
       ops.apply(grad_scale)      -> clip + SGD on grad_scale * buffer
       ops.update_targets()
-    """
+    sync_every = k > 1: k local updates (grad_scale 1), then reducer.average_params()."""
 
-    def __init__(self, ops, reducer):
-        self.ops, self.reducer = ops, reducer
+    def __init__(self, ops, reducer, sync_every=1):
+        self.ops, self.reducer, self.sync_every, self._local = ops, reducer, int(sync_every), 0
 
     def train_step(self, batches_per_step):
         for _ in range(batches_per_step):
             self.ops.sample_and_compute()
-            self.reducer.allreduce_sum()
-            self.ops.apply(1.0 / self.reducer.world)
+            if self.sync_every > 1:
+                self.ops.apply(1.0)
+                self._local += 1
+                if self._local >= self.sync_every:
+                    self.reducer.average_params()
+                    self._local = 0
+            else:
+                self.reducer.allreduce_sum()
+                self.ops.apply(1.0 / self.reducer.world)
         self.ops.update_targets()
 
 
 class AgentOps(object):
-    """DataParallelLearner ops of a real agent (HIP path)."""
+    """DataParallelLearner ops of a real DDPG agent (HIP path, half-step entry points)."""
 
     def __init__(self, agent, batch_size, seed):
         from ._lib import lib, check
@@ -89,3 +206,39 @@ class AgentOps(object):
 
     def update_targets(self):
         self._check(self._lib.cpp_ddpg_update_targets(self.trainer.handle))
+
+
+class TorchCollectiveLearner(DataParallelLearner):
+    """fallback: the library's half steps + torch.distributed's all-reduce of its gradient buffer (zero-copy view)."""
+
+    def __init__(self, agent, batch_size, seed, torch_stream, always=False):
+        reducer = GradAllReducer.for_trainer(agent.trainer, torch_stream)
+        reducer.always = always
+        super(TorchCollectiveLearner, self).__init__(AgentOps(agent, batch_size, seed), reducer)
+        self.world = reducer.world
+
+    def describe(self):
+        return ("dp%d: one learner per GPU, half steps behind the C ABI + torch.distributed all_reduce (nccl = RCCL) of the flat "
+                "gradient buffer per minibatch [fallback: the library's own communicator could not be created]" % self.world)
+
+    def close(self):
+        pass
+
+
+def make_learner(agent, batch_size, seed, sync_every=1, overlap=False, always=False, torch_stream=None):
+    """the learner bench.py / the agents' --data-parallel mode use: NativeLearner over a cpp_comm whose id travels through the
+    initialised torch.distributed group (or a world of one)."""
+    import torch.distributed as dist
+    ctx = (agent.naf if hasattr(agent, "naf") else agent.trainer).ctx
+    try:
+        if dist.is_available() and dist.is_initialized():
+            comm = Communicator.from_torch_distributed(ctx)
+        else:
+            comm = Communicator.single(ctx) if always else None
+        return NativeLearner(agent, batch_size, seed, comm, sync_every, overlap)
+    except Exception as e:      # noqa: BLE001
+        if hasattr(agent, "naf") or sync_every != 1 or torch_stream is None or os.environ.get("CARTPOLEPP_NO_FALLBACK"):
+            raise
+        import sys
+        sys.stderr.write("cartpoleplusplus_amd: cpp_comm_create failed (%s); falling back to torch.distributed's all_reduce\n" % e)
+        return TorchCollectiveLearner(agent, batch_size, seed, torch_stream, always)

@@ -15,6 +15,7 @@ when that column is read.
 """
 import collections
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -30,9 +31,13 @@ class Batch(object):
     the device on first access (fresh host copies the caller owns, like np.copy in :134-138)."""
     _fields = _FIELDS
 
-    def __init__(self, device_batch, state_shape, idxs=None, s1_idx=None, s2_idx=None, empty=False):
+    def __init__(self, device_batch, state_shape, idxs=None, s1_idx=None, s2_idx=None, empty=False, memory=None):
         self._dev, self._shape, self._cache, self._empty = device_batch, tuple(state_shape), {}, empty
         self.idxs, self.state_1_idx, self.state_2_idx = idxs, s1_idx, s2_idx
+        # the device buffer behind this Batch is shared with the next batch() of the same size: `memory` detaches this
+        # Batch (see _detach) before it resamples, so that the columns read later are still THIS draw's (np.copy semantics
+        # of replay_memory.py:134-138)
+        self._memory, self._detached, self._small, self._store_gen = memory, False, None, None
 
     @classmethod
     def empty(cls, state_shape, action_dim):
@@ -44,8 +49,30 @@ class Batch(object):
                     "state_2": np.empty((0,) + tuple(state_shape), np.float16)}
         return b
 
+    def _detach(self):
+        """the owner is about to overwrite the shared device buffer: keep this draw readable.  The three small columns are
+        copied now (a few KB); the state columns are re-read on demand from the replay store through the slots recorded at
+        sample time -- valid as long as no state has been written to the memory since (otherwise reading them raises)."""
+        if self._cache or self._empty or self._detached:
+            return
+        d = self._dev
+        B = d.size
+        a, r, m = np.empty((B, d.action_dim), np.float32), np.empty((B, 1), np.float32), np.empty((B, 1), np.float32)
+        check(lib.cpp_batch_download(d.handle, None, None, ptr(a), ptr(r), ptr(m)))
+        self._small = {"action": a, "reward": r, "terminal_mask": m}
+        self._store_gen = self._memory._write_gen
+        self._detached, self._dev = True, None
+
     def _fetch(self):
         if self._cache or self._empty:
+            return
+        if self._detached:
+            rm = self._memory
+            if rm._write_gen != self._store_gen or rm.handle is None:
+                raise RuntimeError("this Batch was not read before its device buffer was resampled AND states have been "
+                                   "written to the replay memory since: its state columns are gone (read a column, or "
+                                   "finish with the Batch, before the next batch() / add_episode())")
+            self._cache = dict(self._small, state_1=rm.state[self.state_1_idx], state_2=rm.state[self.state_2_idx])
             return
         d = self._dev
         B = d.size
@@ -167,6 +194,9 @@ class ReplayMemory(object):
         self.handle = h
         self.state = _StateStoreView(self)
         self._batches = {}
+        self._live = {}              # batch size -> weakref of the Batch that currently shares that DeviceBatch
+        self._write_gen = 0          # bumped by every write of states (add_episode, fill_synthetic)
+        self._adhoc_counter = 0      # sample_on_device draws (separate from the train steps' device counter)
         # pixel states (H, W, 3, cameras, repeats): channel count for the fused whitening statistics
         self.channels = int(np.prod(self.state_shape[2:])) if len(self.state_shape) == 5 else 0
 
@@ -186,10 +216,27 @@ class ReplayMemory(object):
         rows = np.empty(n, np.int32)
         s1 = np.empty(n, np.int32)
         s2 = np.empty(n, np.int32)
+        # host bookkeeping is committed only once the device writes have succeeded: a slot store that runs dry mid-episode
+        # or a write the device refuses (a non-image state for the 8-bit store) leaves the memory exactly as it was
+        saved = dict(insert=self.insert, full=self.full, free=collections.deque(self.state_free_slots), rows=[],
+                     stats=collections.Counter(self.stats))
+        try:
+            self._add_episode_locked(initial_state, seq, n, slots, rows, s1, s2, saved)
+        except Exception:
+            for row, vals in reversed(saved["rows"]):
+                (self.state_1_idx[row], self.action[row], self.reward[row], self.terminal_mask[row], self.state_2_idx[row]) = vals
+            self.state_free_slots = saved["free"]
+            self.insert, self.full, self.stats = saved["insert"], saved["full"], saved["stats"]
+            self.stats[">add_episode"] += 1
+            raise
+
+    def _add_episode_locked(self, initial_state, seq, n, slots, rows, s1, s2, saved):
         slots[0] = self._pop_slot()
         for k in range(n):
             self.stats[">add"] += 1
             row = self.insert
+            saved["rows"].append((row, (int(self.state_1_idx[row]), self.action[row].copy(), self.reward[row].copy(),
+                                       self.terminal_mask[row].copy(), int(self.state_2_idx[row]))))
             if self.full:
                 self.state_free_slots.append(int(self.state_1_idx[row]))            # :84
                 if self.terminal_mask[row] == 0:                                     # :89-91
@@ -224,6 +271,7 @@ class ReplayMemory(object):
                                         ptr(np.ascontiguousarray(self.reward[rows])),
                                         ptr(np.ascontiguousarray(self.terminal_mask[rows]))))
         check(lib.cpp_replay_set_size(self.handle, self.size()))
+        self._write_gen += 1
 
     def size(self):
         return self.buffer_size if self.full else self.insert
@@ -238,7 +286,16 @@ class ReplayMemory(object):
     def _device_batch(self, B):
         if B not in self._batches:
             self._batches[B] = DeviceBatch(B, self.state_elems, self.action_dim, self.ctx)
+        prev = self._live.pop(B, None)
+        prev = prev() if prev is not None else None
+        if prev is not None:         # an earlier Batch of this size is still alive: it keeps its own draw
+            prev._detach()
         return self._batches[B]
+
+    def _new_batch(self, dev, idxs):
+        b = Batch(dev, self.state_shape, idxs, self.state_1_idx[idxs], self.state_2_idx[idxs], memory=self)
+        self._live[len(idxs)] = weakref.ref(b)
+        return b
 
     def batch(self, batch_size=None, idxs=None):
         """replay_memory.py:131-138.  Rows come from numpy's global RNG exactly like the reference
@@ -251,23 +308,30 @@ class ReplayMemory(object):
             return Batch.empty(self.state_shape, self.action_dim)
         dev = self._device_batch(len(idxs))
         check(lib.cpp_replay_sample(self.handle, len(idxs), ptr(idxs), 0, 0, self.channels, dev.handle))
-        return Batch(dev, self.state_shape, idxs, self.state_1_idx[idxs], self.state_2_idx[idxs])
+        return self._new_batch(dev, idxs)
 
-    def sample_on_device(self, batch_size, seed=0, counter=0):
-        """Device-side Philox draw (no host RNG, no host copies) -- what the fused train step uses."""
+    def sample_on_device(self, batch_size, seed=0, counter=None):
+        """Device-side Philox draw (no host RNG, no host copies) -- the sampler of the fused train step, for inspection:
+        it has its own device counter word, so calling it between train steps does not rewind or advance the training
+        sampler.  counter=None: an auto-incrementing host count (successive calls draw different rows); an explicit
+        counter reproduces a draw."""
         self.stats[">batch"] += 1
+        if counter is None:
+            counter = self._adhoc_counter
+            self._adhoc_counter += 1
         dev = self._device_batch(int(batch_size))
         check(lib.cpp_replay_sample(self.handle, int(batch_size), None, int(seed), int(counter),
                                     self.channels, dev.handle))
         idxs = np.empty(int(batch_size), np.int32)
         check(lib.cpp_replay_last_indexes(self.handle, int(batch_size), ptr(idxs)))
-        return Batch(dev, self.state_shape, idxs, self.state_1_idx[idxs], self.state_2_idx[idxs])
+        return self._new_batch(dev, idxs)
 
     def fill_synthetic(self, n_rows, seed=1234):
         """bench/test helper: synthetic transitions generated on the device.  The host
         bookkeeping is advanced to match (fixed 50-step episodes, chain slot layout)."""
         n_rows = int(n_rows)
         check(lib.cpp_replay_fill_synthetic(self.handle, n_rows, int(seed)))
+        self._write_gen += 1
         i = np.arange(n_rows)
         self.state_1_idx[:n_rows] = i + i // 50
         self.state_2_idx[:n_rows] = i + i // 50 + 1

@@ -15,8 +15,18 @@
  *   - host pointers are read/written only for the duration of the call.
  *   - a cpp_ctx is one GPU + one HIP stream; calls on one ctx are serialised by the caller
  *     (the reference is single-threaded: one implicit tf.Session).
- *   - all arithmetic is IEEE f32 (f32-input MFMA); replay states are stored as f16 exactly like
- *     replay_memory.py:32; indices are int32.
+ *   - results are f32-grade: IEEE f32 accumulation of EXACT products of the reference's f32 / f16 operands.  Where an
+ *     operand already is an f16 number (conv1's input: the replay store's pixels, replay_memory.py:32) the other, f32, operand
+ *     is split into three f16 pieces whose sum is the f32 value, and the three exact f16 x f16 products are accumulated in f32
+ *     (v_mfma_f32_16x16x32_f16); conv2's forward and dW split BOTH f32 operands into three bf16 pieces and issue all nine exact
+ *     products (v_mfma_f32_16x16x32_bf16); everything else multiplies f32 operands directly (v_mfma_f32_16x16x4_f32).  No
+ *     operand is ever rounded to a narrower type, no product is dropped.  f32 states, odd layouts and
+ *     B = 1 run on the f32-input MFMA kernels throughout.  The release library has no run-time kernel switches; the ablation
+ *     build (libcartpolepp_hip_ablation.so, CARTPOLEPP_ABLATION=1) can force the f32-input kernels everywhere
+ *     (CPP_CONV_K16=0 CPP_CONV_B16=0) -- bench.py's `control` run.
+ *   - replay states are stored as f16 exactly like replay_memory.py:32 (or as their 8-bit pixel codes); indices are int32.
+ *   - state batches handed to the conv kernels always live in the library's own guard-banded device allocations (host
+ *     pointers are copied in first); the f16-pipe kernels refuse anything else.
  *   - flat parameter order = TF variable creation order "<scope>/weights", "<scope>/biases":
  *     conv1, conv2, conv3, then the fully connected layers.
  */
@@ -44,6 +54,7 @@ typedef struct cpp_batch cpp_batch;
 typedef struct cpp_replay cpp_replay;
 typedef struct cpp_ddpg cpp_ddpg;
 typedef struct cpp_naf cpp_naf;
+typedef struct cpp_comm cpp_comm;
 
 /* ---- library / context ------------------------------------------------------------------- */
 int cpp_abi_version(void);
@@ -204,8 +215,8 @@ int cpp_ddpg_train_step(cpp_ddpg* ddpg, cpp_replay* replay, int B, int n_batches
                         const int32_t* idxs, uint64_t seed);
 /* Data-parallel learners: the first half of one minibatch of the inner step -- sample B rows on the
  * device (Philox; the counter advances by one) and leave both gradient sets in the flat gradient
- * buffer.  The host then all-reduces that buffer (RCCL) and calls cpp_ddpg_apply_gradients(1/N).
- * hipGraph-captured after the first call per (B, seed, replay). */
+ * buffer.  cpp_ddpg_allreduce_grads + cpp_ddpg_apply_gradients(1/N) finish the minibatch
+ * (cpp_ddpg_dp_train_step does all three).  hipGraph-captured after the first call per (B, seed, replay). */
 int cpp_ddpg_sample_and_compute(cpp_ddpg* ddpg, cpp_replay* replay, int B, uint64_t seed);
 /* scalars of the last minibatch: [0] td loss, [1] actor grad norm, [2] critic grad norm (pre-clip). */
 int cpp_ddpg_last_stats(cpp_ddpg* ddpg, float out[3]);
@@ -215,6 +226,41 @@ int cpp_ddpg_last_stats(cpp_ddpg* ddpg, float out[3]);
  * what the reference prints under VERBOSE_DEBUG (ddpg_cartpole.py:339-349).  NULL pointers are skipped.  Parity tests read
  * the fused step's values through this call. */
 int cpp_ddpg_last_values(cpp_ddpg* ddpg, int B, float* actions, float* dq_da, float* q, float* td);
+
+/* ---- data-parallel actor-learners (the reference's TODO "switch back to async training with multiple replicas",
+ * ddpg_cartpole.py:259, naf_cartpole.py:294; its exps only launch independent processes, exps/run_87.sh:12-36) ------------
+ * One learner per GPU = one process with one cpp_ctx; replicated weights, an own replay shard and an own minibatch per
+ * learner; RCCL collectives over xGMI issued by the library on the context's stream.  Rank 0 makes the id, the host
+ * distributes its CPP_COMM_ID_BYTES bytes to the other ranks by any means (bench.py: a torch.distributed / gloo broadcast),
+ * every rank then calls cpp_comm_create. */
+#define CPP_COMM_ID_BYTES 128
+int cpp_comm_unique_id(void* out, int cap);                       /* ncclGetUniqueId */
+int cpp_comm_create(cpp_ctx* ctx, const void* unique_id, int rank, int world, cpp_comm** out);   /* ncclCommInitRank */
+int cpp_comm_destroy(cpp_comm* comm);
+int cpp_comm_info(const cpp_comm* comm, int* rank, int* world);
+/* in-place sum (average != 0: mean) over the ranks of n floats at a DEVICE address, on the context's stream */
+int cpp_comm_allreduce(cpp_comm* comm, void* device_f32, int64_t n, int average);
+/* max over the ranks of one host double / a barrier (bench.py's timed region: max-over-ranks time between two barriers) */
+int cpp_comm_max_double(cpp_comm* comm, double* value);
+int cpp_comm_barrier(cpp_comm* comm);
+/* sum over the ranks of the flat gradient buffer [actor grads | critic grads] left by cpp_ddpg_sample_and_compute /
+ * cpp_ddpg_compute_gradients; cpp_ddpg_apply_gradients(1 / world) then gives every rank the same update. */
+int cpp_ddpg_allreduce_grads(cpp_ddpg* ddpg, cpp_comm* comm);
+/* periodic mode: the mean over the ranks of all four networks' parameters */
+int cpp_ddpg_average_params(cpp_ddpg* ddpg, cpp_comm* comm);
+/* This rank's part of the inner step ddpg_cartpole.py:331-337 for N synchronous learners: n_batches x {sample from the own
+ * shard + both gradient sets (hipGraph) -> all-reduce -> clip + SGD on the mean}, then the (local) target updates.
+ * sync_every = k > 1: k local minibatch updates between parameter averagings instead of a gradient all-reduce per minibatch.
+ * overlap != 0: the gradients of the fully connected layers are reduced on a second stream while the conv backward of the
+ * same minibatch runs.  comm == NULL: one learner on the same code path. */
+int cpp_ddpg_dp_train_step(cpp_ddpg* ddpg, cpp_replay* replay, cpp_comm* comm, int B, int n_batches, uint64_t seed,
+                           int sync_every, int overlap);
+/* the same for NAF (naf_cartpole.py:367-373): flat buffer [value | mu | l_values]; the averaging includes the optimiser slots */
+int cpp_naf_sample_and_compute(cpp_naf* naf, cpp_replay* replay, int B, uint64_t seed);
+int cpp_naf_allreduce_grads(cpp_naf* naf, cpp_comm* comm);
+int cpp_naf_average_params(cpp_naf* naf, cpp_comm* comm);
+int cpp_naf_dp_train_step(cpp_naf* naf, cpp_replay* replay, cpp_comm* comm, int B, int n_batches, uint64_t seed,
+                          int sync_every);
 
 /* ---- NAF train ops (naf_cartpole.py:93-284, :365-373) ----------------------------------------- */
 typedef struct cpp_naf_hyper {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """conv1 forward ablation: time the kernel (HIP events) for library variants built with
 -DCONV_ABLATE_NOMFMA (staging + epilogue only) / -DCONV_ABLATE_NOSTAGE (MFMA phase only).
-usage: CARTPOLEPP_LIB=<variant.so> python profiles/ablate_conv1.py"""
+usage: CARTPOLEPP_ABLATION=<variant name> python profiles/ablate_conv1.py"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""conv1 dW ablation (see ablate_conv1.py): CARTPOLEPP_LIB=<variant.so> python profiles/ablate_conv1_dw.py"""
+"""conv1 dW ablation (see ablate_conv1.py): CARTPOLEPP_ABLATION=<variant name> python profiles/ablate_conv1_dw.py"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -28,7 +28,7 @@ def run(kernel, names):
     for name in ["BASE"] + names:
         env = dict(os.environ)
         if name != "BASE":
-            env["CARTPOLEPP_LIB"] = os.path.join(LIB, "ablate_%s.so" % name)
+            env["CARTPOLEPP_ABLATION"] = "ablate_%s" % name
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "50", "--warmup", "10"],
                              env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
         try:

@@ -20,7 +20,7 @@ if len(sys.argv) > 1:
     np.savez(sys.argv[1], g=g, p1=p1, codes=codes)
 else:
     for k in ("0", "1"):
-        env = dict(os.environ, CPP_CONV_KYO=k)
+        env = dict(os.environ, CARTPOLEPP_ABLATION="1", CPP_CONV_KYO=k)
         subprocess.check_call([sys.executable, __file__, "/tmp/kyo%s.npz" % k], env=env, stderr=subprocess.DEVNULL)
     a, b = np.load("/tmp/kyo0.npz"), np.load("/tmp/kyo1.npz")
     print("pool1 maxabs diff", np.abs(a["p1"] - b["p1"]).max())

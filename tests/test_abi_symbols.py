@@ -61,3 +61,18 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_release_library_reads_no_environment_variable():
+    """the CPP_* kernel-selection switches exist only in the ablation build (csrc/common.h: cpp_switch_off): the release
+    library must not even import getenv; the ablation library, built from the same sources, does."""
+    import subprocess
+    from cartpoleplusplus_amd import _lib
+    nm = "/opt/rocm/lib/llvm/bin/llvm-nm" if os.path.exists("/opt/rocm/lib/llvm/bin/llvm-nm") else "nm"
+    rel = subprocess.check_output([nm, "-D", "--undefined-only", _lib.LIB_PATH]).decode()
+    assert "getenv" not in rel
+    abl = os.path.join(os.path.dirname(_lib.LIB_PATH), "libcartpolepp_hip_ablation.so")
+    assert "getenv" in subprocess.check_output([nm, "-D", "--undefined-only", abl]).decode()
+    for src in os.listdir(os.path.join(ROOT, "cartpoleplusplus_amd", "csrc")):
+        if src.endswith((".hip", ".cpp", ".h")) and src != "common.h":
+            assert "getenv" not in open(os.path.join(ROOT, "cartpoleplusplus_amd", "csrc", src)).read(), src

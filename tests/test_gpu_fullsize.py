@@ -154,7 +154,7 @@ def test_earlier_conv_kernels_stay_parity_green_when_selected():
     shapes whose rows cannot be staged as 16-byte chunks): the cfg3 / cfg2-shape parity cases must pass on them too."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CPP_CONV_KYO="0")
+    env = dict(os.environ, CARTPOLEPP_ABLATION="1", CPP_CONV_KYO="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
                         "-k", "64x64 and (forward or gradients or fused)"], cwd=root, env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=600)
@@ -188,7 +188,7 @@ def test_f16x3_conv1_is_as_close_to_the_f64_oracle_as_the_f32_mfma_kernel():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     errs = {}
     for k16 in ("1", "0"):
-        r = subprocess.run([sys.executable, "-c", _CONV1_ERR_SNIPPET], cwd=root, env=dict(os.environ, CPP_CONV_K16=k16),
+        r = subprocess.run([sys.executable, "-c", _CONV1_ERR_SNIPPET], cwd=root, env=dict(os.environ, CARTPOLEPP_ABLATION="1", CPP_CONV_K16=k16),
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
         m = re.search(r"CONV1ERR (\S+) (\S+)", r.stdout.decode())
         assert r.returncode == 0 and m, r.stdout.decode()[-1500:]
@@ -205,7 +205,7 @@ def test_f32_mfma_conv1_stays_parity_green_when_selected():
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
-                        "-k", "64x64 and (forward or gradients or fused)"], cwd=root, env=dict(os.environ, CPP_CONV_K16="0"),
+                        "-k", "64x64 and (forward or gradients or fused)"], cwd=root, env=dict(os.environ, CARTPOLEPP_ABLATION="1", CPP_CONV_K16="0"),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     tail = r.stdout.decode()[-1500:]
     assert r.returncode == 0 and " passed" in tail, tail
@@ -218,7 +218,7 @@ def test_gemm_level_heads_stay_parity_green_when_selected(switch):
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
-                        "-k", "fused or gradients or train_ops"], cwd=root, env=dict(os.environ, **{switch: "0"}),
+                        "-k", "fused or gradients or train_ops"], cwd=root, env=dict(os.environ, CARTPOLEPP_ABLATION="1", **{switch: "0"}),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     tail = r.stdout.decode()[-1500:]
     assert r.returncode == 0 and " passed" in tail, tail
@@ -252,7 +252,7 @@ def test_f16x3_conv1_dw_is_as_close_to_the_f64_oracle_as_the_f32_mfma_kernel():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     errs = {}
     for k16 in ("1", "0"):
-        r = subprocess.run([sys.executable, "-c", _CONV1_DW_ERR_SNIPPET], cwd=root, env=dict(os.environ, CPP_CONV_K16=k16),
+        r = subprocess.run([sys.executable, "-c", _CONV1_DW_ERR_SNIPPET], cwd=root, env=dict(os.environ, CARTPOLEPP_ABLATION="1", CPP_CONV_K16=k16),
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
         m = dict(re.findall(r"DWERR (\S+) (\S+)", r.stdout.decode()))
         assert r.returncode == 0 and "weights" in m, r.stdout.decode()[-1500:]
@@ -292,7 +292,7 @@ def test_bf16_nine_product_conv2_is_as_close_to_the_f64_oracle_as_the_f32_mfma_k
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     for b16 in ("1", "0"):
-        r = subprocess.run([sys.executable, "-c", _CONV2_ERR_SNIPPET], cwd=root, env=dict(os.environ, CPP_CONV_B16=b16),
+        r = subprocess.run([sys.executable, "-c", _CONV2_ERR_SNIPPET], cwd=root, env=dict(os.environ, CARTPOLEPP_ABLATION="1", CPP_CONV_B16=b16),
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
         out = r.stdout.decode()
         f, d = re.search(r"C2FWD (\S+) (\S+)", out), re.search(r"C2DW (\S+)", out)

@@ -216,3 +216,89 @@ def test_u8_synthetic_fill_matches_the_f16_fill():
     sa, sb = a.sample_on_device(48, seed=2, counter=1), b.sample_on_device(48, seed=2, counter=1)
     assert np.array_equal(sa.idxs, sb.idxs) and np.array_equal(sa.state_1, sb.state_1) and np.array_equal(sa.state_2, sb.state_2)
     a.close(); b.close()
+
+
+def test_two_batches_of_one_size_are_independent_snapshots():
+    """replay_memory.py:134-138 returns np.copy snapshots: a Batch must keep ITS draw when the next batch() of the same size
+    reuses the shared device buffer -- whether its columns were read before or only after the second draw."""
+    from cartpoleplusplus_amd.replay_memory import ReplayMemory
+    rng = np.random.default_rng(3)
+    rm = ReplayMemory(60, (4, 4, 3, 1, 2), 2)
+    orm = OracleReplayMemory(60, (4, 4, 3, 1, 2), 2)
+    for _ in range(8):
+        n = int(rng.integers(3, 8))
+        mk = lambda: rng.integers(0, 256, (4, 4, 3, 1, 2)).astype(np.float16) / np.float16(255)
+        s0, seq = mk(), [(rng.uniform(-1, 1, (1, 2)).astype(np.float32), float(rng.integers(0, 9)), mk()) for _ in range(n)]
+        rm.add_episode(s0, seq); orm.add_episode(s0, seq)
+    i1, i2 = rng.integers(0, rm.size(), 13), rng.integers(0, rm.size(), 13)
+    b1 = rm.batch(idxs=i1)
+    early = b1.reward.copy()                      # (reading one column fetches all five: b1 is a host snapshot from here on)
+    b2 = rm.batch(idxs=i2)
+    b3 = rm.batch(idxs=i1)                        # b2 has NOT been read when its buffer is resampled
+    for b, idx in ((b1, i1), (b2, i2), (b3, i1)):
+        ob = orm.batch(idxs=idx)
+        for f in ("state_1", "action", "reward", "terminal_mask", "state_2"):
+            assert np.array_equal(getattr(b, f), getattr(ob, f)), f
+        assert np.array_equal(b.idxs, idx)
+    assert np.array_equal(early, b1.reward)
+    # a detached Batch whose states were overwritten in the meantime fails loudly instead of returning another draw's rows
+    b4 = rm.batch(idxs=i1)
+    b5 = rm.batch(idxs=i2)                        # detaches b4
+    rm.add_episode(s0, seq)
+    with pytest.raises(RuntimeError):
+        b4.state_1
+    assert np.array_equal(b4.idxs, i1) and b5.device is not None and b4.device is None
+    rm.close()
+
+
+def test_inspection_draws_do_not_move_the_training_sampler():
+    """sample_on_device between train steps must neither rewind nor advance the sampler of cpp_ddpg_train_step, and
+    successive inspection draws differ (auto-incrementing counter) unless a counter is given."""
+    import ctypes
+    from cartpoleplusplus_amd import _lib
+    from tests.helpers import make_pair
+    shape, B = (16, 16, 3, 1, 2), 16
+    seen = {}
+    for peek in (False, True):
+        agent, _ref, _ = make_pair(shape, B, True, replay_size=300)
+        try:
+            rm = agent.replay_memory
+            rm.fill_synthetic(250, seed=5)
+            rows = []
+            for _ in range(4):
+                agent.train_step(B, 2)
+                idxs = np.empty(B, np.int32)
+                _lib.check(_lib.lib.cpp_replay_last_indexes(rm.handle, B, idxs.ctypes.data_as(ctypes.c_void_p)))
+                rows.append(idxs.copy())
+                if peek:
+                    a, b = rm.sample_on_device(B, seed=9), rm.sample_on_device(B, seed=9)
+                    assert not np.array_equal(a.idxs, b.idxs)
+                    assert np.array_equal(rm.sample_on_device(B, seed=9, counter=0).idxs, rm.sample_on_device(B, seed=9, counter=0).idxs)
+            seen[peek] = (np.concatenate(rows), agent.actor.get_params())
+        finally:
+            agent.close()
+    assert np.array_equal(seen[False][0], seen[True][0]) and np.array_equal(seen[False][1], seen[True][1])
+
+
+def test_failed_add_episode_leaves_the_memory_unchanged():
+    """a write the device refuses (a non-image state offered to the 8-bit store) must not leave the host bookkeeping
+    (insert, free list, index columns) ahead of the device."""
+    from cartpoleplusplus_amd.replay_memory import ReplayMemory
+    rng = np.random.default_rng(1)
+    shape = (4, 4, 3, 1, 2)
+    rm = ReplayMemory(20, shape, 2, store_dtype="u8")
+    mk = lambda: rng.integers(0, 256, shape).astype(np.float16) / np.float16(255)
+    good = [(rng.uniform(-1, 1, (1, 2)).astype(np.float32), 1.0, mk()) for _ in range(5)]
+    rm.add_episode(mk(), good)
+    before = (rm.insert, rm.full, list(rm.state_free_slots), rm.state_1_idx.copy(), rm.state_2_idx.copy(), rm.size())
+    bad = list(good)
+    bad[3] = (bad[3][0], 1.0, np.full(shape, 0.123, np.float16))          # not f16(k/255)
+    with pytest.raises(RuntimeError):
+        rm.add_episode(mk(), bad)
+    assert (rm.insert, rm.full, list(rm.state_free_slots), rm.size()) == (before[0], before[1], before[2], before[5])
+    assert np.array_equal(rm.state_1_idx[:5], before[3][:5]) and np.array_equal(rm.state_2_idx[:5], before[4][:5])
+    rm.add_episode(mk(), good)                     # and the memory keeps working
+    assert rm.size() == 10
+    b = rm.batch(idxs=np.arange(10))
+    assert np.array_equal(b.state_2[:4], np.stack([g[2] for g in good[:4]]))
+    rm.close()
