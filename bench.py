@@ -100,27 +100,33 @@ def cpu_baseline_numpy(shape, B, budget_s=10.0, max_reps=4):
                       "numpy f32 with OpenBLAS on %d threads, %.1f s wall" % (reps, B, threads, dt)}
 
 
-def cpu_baseline_torch(shape, B, budget_s=12.0, max_reps=40):
-    """the same update on torch's CPU kernels (oneDNN conv, autograd), all host cores: SURVEY 8(d)'s proxy for the
-    reference's TF-CPU path (TensorFlow 0.x cannot be installed)."""
+def cpu_baseline_torch(shape, B, budget_s=25.0):
+    """the same update on torch's CPU kernels (oneDNN conv, autograd): SURVEY 8(d)'s proxy for the reference's TF-CPU path
+    (TensorFlow 0.x cannot be installed).  Thread counts 16, 64 and all cores are tried within the budget (a 10-filter conv
+    does not scale to hundreds of threads) and the best is reported."""
     import torch
     from oracle.ddpg_torch import TorchDDPG   # baseline only
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     rng = np.random.default_rng(0)
     O, aspec, cspec, af, cf = _oracle_agent(shape, rng)
     agent = TorchDDPG(aspec, cspec, af, cf)
     batch = O.synthetic_batch(rng, B, shape, 2, True)
-    agent.train_minibatch(batch)              # warm-up (thread pool, oneDNN primitive cache)
-    reps, t0 = 0, time.time()
-    while reps < max_reps and (reps == 0 or time.time() - t0 < budget_s):
-        agent.train_minibatch(batch)
-        reps += 1
-    dt = time.time() - t0
-    return {"value": round(reps / dt, 4), "unit": "steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
+    tried, t_all = {}, time.time()
+    for threads in sorted({min(cores, 16), min(cores, 64), cores}):
+        if tried and time.time() - t_all > budget_s:
+            break
+        torch.set_num_threads(threads)
+        agent.train_minibatch(batch)          # warm-up (thread pool, oneDNN primitive cache)
+        reps, t0 = 0, time.time()
+        while reps < 3 and (reps == 0 or time.time() - t0 < budget_s / 4):
+            agent.train_minibatch(batch)
+            reps += 1
+        tried[threads] = reps / (time.time() - t0)
+    best = max(tried, key=tried.get)
+    return {"value": round(tried[best], 4), "unit": "steps/s", "cores": int(best), "kind": "port",
             "impl": "oracle/ddpg_torch.py (torch %s CPU: oneDNN convolutions + autograd) -- proxy for the reference's TF-CPU kernels" % torch.__version__,
-            "sample": "%d full minibatch update(s) after 1 warm-up (B=%d, same shapes as the GPU workload), float32, "
-                      "torch.set_num_threads(%d), %.1f s wall" % (reps, B, cores, dt)}
+            "sample": "full minibatch updates after 1 warm-up (B=%d, same shapes as the GPU workload), float32; steps/s by thread count "
+                      "%s on a %d-core host; %.1f s wall" % (B, {k: round(v, 3) for k, v in tried.items()}, cores, time.time() - t_all)}
 
 
 def sub_bench(extra_args, env=None, timeout=420):
@@ -151,6 +157,7 @@ def main():
     ap.add_argument("--replay-store", default="f16", choices=["f16", "u8"],
                     help="informational: u8 = the 8-bit replay store (same batches, half the gather reads)")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel learner path (RCCL all-reduce) even at world size 1")
+    ap.add_argument("--overlap", action="store_true", help="data-parallel: reduce the fully connected layers' gradients beside the conv backward")
     ap.add_argument("--sync-every", type=int, default=1, help="data-parallel: k local minibatches between parameter averagings (1: gradient all-reduce per minibatch)")
     args = ap.parse_args()
 
@@ -218,7 +225,8 @@ def main():
         parallelism = "single learner: fused inner step (one hipGraph replay per %d minibatches), no collective" % BATCHES_PER_STEP
     else:
         from cartpoleplusplus_amd.distributed import make_learner
-        learner = make_learner(agent, B, seed=1234 + rank, sync_every=args.sync_every, always=args.force_dp)
+        learner = make_learner(agent, B, seed=1234 + rank, sync_every=args.sync_every, overlap=args.overlap, always=args.force_dp,
+                               torch_stream=stream)
 
         def run(g, t):
             for _ in range(g):

@@ -136,17 +136,19 @@ int launch_stats_generic(cpp_ctx* ctx, const void* x, int dtype, long npix, int 
 // ---------------------------------------------------------------------------------------------
 // synthetic fill (bench / tests): SURVEY 8d inputs generated on the device
 // ---------------------------------------------------------------------------------------------
+// (grid-stride loops: a store of tens of GB has more 16-element blocks than one launch may have threads -- 2^32)
+constexpr unsigned FILL_GRID = 1u << 20;
 __global__ void replay_fill_states_kernel(__half* store, long total, uint64_t seed) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // 16 elements per thread
-  if (i * 16 >= total) return;
-  u32x4 c = {(uint32_t)i, (uint32_t)(i >> 32), 0x5eedu, 1u};
-  const u32x4 r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-  for (int e = 0; e < 16; ++e) {
-    const long idx = i * 16 + e;
-    if (idx < total) {
-      const uint32_t k = (w[e >> 2] >> (8 * (e & 3))) & 0xffu;
-      store[idx] = __float2half((float)k / 255.0f);             // f16(k/255): bullet_cartpole.py:239-243
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i * 16 < total; i += (long)gridDim.x * blockDim.x) {   // 16 elements per step
+    u32x4 c = {(uint32_t)i, (uint32_t)(i >> 32), 0x5eedu, 1u};
+    const u32x4 r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+    for (int e = 0; e < 16; ++e) {
+      const long idx = i * 16 + e;
+      if (idx < total) {
+        const uint32_t k = (w[e >> 2] >> (8 * (e & 3))) & 0xffu;
+        store[idx] = __float2half((float)k / 255.0f);             // f16(k/255): bullet_cartpole.py:239-243
+      }
     }
   }
 }
@@ -174,7 +176,8 @@ int launch_replay_fill(cpp_ctx* ctx, __half* store, long elems, int slots, int32
   const long nthreads = (total + 15) / 16;
   prof_begin(ctx);
   if (store) {                                       // (nullptr: the caller fills a CPP_U8 store itself)
-    hipLaunchKernelGGL(replay_fill_states_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0,
+    const long nblk = (nthreads + 255) / 256;
+    hipLaunchKernelGGL(replay_fill_states_kernel, dim3(nblk < (long)FILL_GRID ? (unsigned)nblk : FILL_GRID), dim3(256), 0,
                        ctx->stream, store, total, seed);
     LAUNCH_CHECK();
   }
@@ -231,20 +234,21 @@ int launch_u8_to_f16(cpp_ctx* ctx, __half* dst, const uint8_t* src, long n, cons
 }
 
 __global__ void replay_fill_u8_kernel(uint8_t* store, long total, uint64_t seed) {      // same codes as replay_fill_states_kernel
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i * 16 >= total) return;
-  u32x4 c = {(uint32_t)i, (uint32_t)(i >> 32), 0x5eedu, 1u};
-  const u32x4 r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-  for (int e = 0; e < 16; ++e) {
-    const long idx = i * 16 + e;
-    if (idx < total) store[idx] = (uint8_t)((w[e >> 2] >> (8 * (e & 3))) & 0xffu);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i * 16 < total; i += (long)gridDim.x * blockDim.x) {
+    u32x4 c = {(uint32_t)i, (uint32_t)(i >> 32), 0x5eedu, 1u};
+    const u32x4 r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+    for (int e = 0; e < 16; ++e) {
+      const long idx = i * 16 + e;
+      if (idx < total) store[idx] = (uint8_t)((w[e >> 2] >> (8 * (e & 3))) & 0xffu);
+    }
   }
 }
 
 int launch_replay_fill_u8(cpp_ctx* ctx, uint8_t* store, long total, uint64_t seed) {
   const long nthreads = (total + 15) / 16;
-  hipLaunchKernelGGL(replay_fill_u8_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, ctx->stream, store, total, seed);
+  const long nblk = (nthreads + 255) / 256;
+  hipLaunchKernelGGL(replay_fill_u8_kernel, dim3(nblk < (long)FILL_GRID ? (unsigned)nblk : FILL_GRID), dim3(256), 0, ctx->stream, store, total, seed);
   LAUNCH_CHECK();
   return 0;
 }

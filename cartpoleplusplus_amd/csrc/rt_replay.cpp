@@ -164,6 +164,7 @@ extern "C" int cpp_replay_destroy(cpp_replay* r) {
 extern "C" int cpp_replay_write_states(cpp_replay* r, const int32_t* slots, int n, const void* states, int dtype) {
   ARG_CHECK(r && slots && states, "cpp_replay_write_states: NULL argument");
   ARG_CHECK(dtype == CPP_F32 || dtype == CPP_F16 || dtype == CPP_U8, "cpp_replay_write_states: dtype %d", dtype);
+  ARG_CHECK(n >= 1 && (double)n * (double)r->elems < 4.0e9, "cpp_replay_write_states: %d states of %ld elements in one call (the conversion kernels run one thread per element: split the episode)", n, r ? r->elems : 0);
   hipStream_t st = r->ctx->stream;
   HIP_CHECK(hipSetDevice(r->ctx->device));
   for (int i = 0; i < n; ++i)

@@ -275,3 +275,27 @@ def fused_step_against_f64_oracle(shape, B, rows, replay_store="f16", replay_siz
         bound = 2.0 ** -23 * np.linalg.norm(old) + 5e-5 * np.linalg.norm(d_want)
         assert np.linalg.norm(d_got - d_want) < bound, (name, report, bound)
     return report
+
+
+def philox4x32_10_np(c0, c1, c2, c3, k0, k1):
+    """vectorised Philox4x32-10: uint64 numpy arrays (values < 2^32) in, four uint32 words out."""
+    M0, M1, W0, W1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), 0x9E3779B9, 0xBB67AE85, np.uint64(0xFFFFFFFF)
+    c0, c1, c2, c3 = (np.asarray(x, np.uint64) for x in (c0, c1, c2, c3))
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        c0, c1, c2, c3 = ((p1 >> np.uint64(32)) ^ c1 ^ np.uint64(k0)) & MASK, p1 & MASK, ((p0 >> np.uint64(32)) ^ c3 ^ np.uint64(k1)) & MASK, p0 & MASK
+        k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
+def synthetic_state_codes(slot, elems, seed):
+    """the 8-bit pixel codes cpp_replay_fill_synthetic writes into state slot `slot` (csrc/replay.hip: byte e of the Philox block
+    of flat position // 16, key = seed), regenerated on the host -- an independent witness for gathers from anywhere in a store
+    of any size (64-bit positions)."""
+    first = int(slot) * int(elems)
+    blocks = np.arange(first // 16, (first + elems + 15) // 16, dtype=np.uint64)
+    w = philox4x32_10_np(blocks & np.uint64(0xFFFFFFFF), blocks >> np.uint64(32), np.full_like(blocks, 0x5eed), np.full_like(blocks, 1),
+                         seed & 0xFFFFFFFF, seed >> 32)
+    by = np.stack([(w[e >> 2] >> np.uint64(8 * (e & 3))) & np.uint64(0xFF) for e in range(16)], axis=1).astype(np.uint8).ravel()
+    off = first - int(blocks[0]) * 16
+    return by[off:off + elems]
