@@ -471,3 +471,28 @@ extern "C" int cpp_naf_last_stats(cpp_naf* f, float out[3]) {
   return CPP_OK;
 }
 
+
+// optimiser slots for checkpoints (util.py:88-90: tf.train.Saver saves the Momentum / Adam slot variables too)
+extern "C" int64_t cpp_naf_opt_state_size(const cpp_naf* f) { return f ? (int64_t)(f->nV + f->nM + f->nL) : -1; }
+extern "C" int cpp_naf_get_opt_state(cpp_naf* f, float* m, float* v, int64_t n, uint64_t* step) {
+  ARG_CHECK(f, "cpp_naf_get_opt_state: NULL argument");
+  ARG_CHECK(n == f->nV + f->nM + f->nL, "cpp_naf_get_opt_state: asked %ld values, the optimiser has %ld", (long)n, f->nV + f->nM + f->nL);
+  hipStream_t st = f->ctx->stream;
+  HIP_CHECK(hipSetDevice(f->ctx->device));
+  if (m) HIP_CHECK(hipMemcpyAsync(m, f->m, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (v) HIP_CHECK(hipMemcpyAsync(v, f->v, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (step) HIP_CHECK(hipMemcpyAsync(step, f->opt_step, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  return CPP_OK;
+}
+extern "C" int cpp_naf_set_opt_state(cpp_naf* f, const float* m, const float* v, int64_t n, uint64_t step) {
+  ARG_CHECK(f, "cpp_naf_set_opt_state: NULL argument");
+  ARG_CHECK(n == f->nV + f->nM + f->nL, "cpp_naf_set_opt_state: got %ld values, the optimiser has %ld", (long)n, f->nV + f->nM + f->nL);
+  hipStream_t st = f->ctx->stream;
+  HIP_CHECK(hipSetDevice(f->ctx->device));
+  if (m) HIP_CHECK(hipMemcpyAsync(f->m, m, (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
+  if (v) HIP_CHECK(hipMemcpyAsync(f->v, v, (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipMemcpyAsync(f->opt_step, &step, sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  return CPP_OK;
+}

@@ -211,6 +211,18 @@ class NafNetwork(base_network.Network):
         check(lib.cpp_naf_last_stats(self.handle, ptr(out)))
         return out
 
+    def get_optimiser_state(self):
+        """the optimiser's slot variables {m, v, step} (what tf.train.Saver checkpoints besides the weights, util.py:88-90)."""
+        n = int(lib.cpp_naf_opt_state_size(self.handle))
+        m, v, step = np.empty(n, np.float32), np.empty(n, np.float32), C.c_uint64()
+        check(lib.cpp_naf_get_opt_state(self.handle, ptr(m), ptr(v), n, C.byref(step)))
+        return {"m": m, "v": v, "step": np.uint64(step.value)}
+
+    def set_optimiser_state(self, state):
+        m = np.ascontiguousarray(state["m"], np.float32)
+        v = np.ascontiguousarray(state["v"], np.float32)
+        check(lib.cpp_naf_set_opt_state(self.handle, ptr(m), ptr(v), len(m), int(state["step"])))
+
     def close(self):
         for b in self._upload.values():
             b.close()

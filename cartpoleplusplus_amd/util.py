@@ -85,7 +85,11 @@ class SaverUtil(object):
     checkpointed (util.py:91).  The reference hands a tf.Session to tf.train.Saver; here the first argument is
     the agent (anything with `.networks()` -> [Network] and `.initialise_variables()`), and a checkpoint is one
     `.npz` with the flat f32 buffer of every namespace (variable names and shapes stored alongside and checked
-    on restore).  The `checkpoint` index file keeps TF's `model_checkpoint_path: "<name>"` line."""
+    on restore) plus, for agents whose optimiser has slot variables (NAF with Momentum / Adam: `agent.naf`), those slots
+    and the update count -- tf.train.Saver saves them too (util.py:88-90), and a resumed run must not restart Adam's bias
+    correction.  The `checkpoint` index file keeps TF's `model_checkpoint_path: "<name>"` line.  Both files are written to
+    a temporary name and renamed, so a crash never leaves the index pointing at a partial checkpoint.  The format is this
+    package's own: it is not a TensorFlow checkpoint."""
 
     def __init__(self, agent, ckpt_dir="/tmp", save_freq=60):
         self.agent, self.ckpt_dir = agent, ckpt_dir
@@ -109,6 +113,11 @@ class SaverUtil(object):
                 layout = "|".join("%s%s" % (v.name, tuple(v.shape)) for v in net.trainable_model_vars())
                 assert str(data[net.namespace + "::layout"]) == layout, "checkpoint does not match %s" % net.namespace
                 net.set_params(data[net.namespace])
+            opt = getattr(self.agent, "naf", None)
+            if opt is not None and "optimiser::m" in data:
+                opt.set_optimiser_state({"m": data["optimiser::m"], "v": data["optimiser::v"], "step": data["optimiser::step"]})
+            elif opt is not None:
+                sys.stderr.write("checkpoint %s holds no optimiser slots: Momentum / Adam restart from zero\n" % most_recent_ckpt)
             self.next_scheduled_save_time = time.time() + self.save_freq
         else:
             sys.stderr.write("no latest ckpt in %s, just initing vars...\n" % self.ckpt_dir)
@@ -125,9 +134,17 @@ class SaverUtil(object):
             blob[net.namespace] = net.get_params()
             blob[net.namespace + "::layout"] = np.array(
                 "|".join("%s%s" % (v.name, tuple(v.shape)) for v in net.trainable_model_vars()))
-        np.savez("%s/%s.npz" % (self.ckpt_dir, name), **blob)
-        with open(self._index(), "w") as f:
+        opt = getattr(self.agent, "naf", None)
+        if opt is not None:
+            for k, v in opt.get_optimiser_state().items():
+                blob["optimiser::" + k] = v
+        final = "%s/%s.npz" % (self.ckpt_dir, name)
+        with open(final + ".tmp", "wb") as f:          # (a file object: np.savez would append ".npz" to a temporary NAME)
+            np.savez(f, **blob)
+        os.replace(final + ".tmp", final)
+        with open(self._index() + ".tmp", "w") as f:
             f.write('model_checkpoint_path: "%s"\n' % name)
+        os.replace(self._index() + ".tmp", self._index())
         print("save_took", time.time() - start_time)
         self.next_scheduled_save_time = time.time() + self.save_freq
 

@@ -302,6 +302,13 @@ int cpp_naf_train_step(cpp_naf* naf, cpp_replay* replay, int B, int n_batches, c
                        uint64_t seed);
 /* [0] loss of the last minibatch, [1] pre-clip global gradient norm, [2] non-finite flag (sticky). */
 int cpp_naf_last_stats(cpp_naf* naf, float out[3]);
+/* The optimiser's slot variables, which tf.train.Saver checkpoints with everything else (util.py:88-90): Momentum accumulators
+ * / Adam first moments `m` and Adam second moments `v`, each n = params(value) + params(mu) + params(l_values) floats in the
+ * flat order [value | mu | l_values], and the number of applied updates `step` (Adam's beta powers are beta^step).  NULL
+ * pointers are skipped. */
+int64_t cpp_naf_opt_state_size(const cpp_naf* naf);
+int cpp_naf_get_opt_state(cpp_naf* naf, float* m, float* v, int64_t n, uint64_t* step);
+int cpp_naf_set_opt_state(cpp_naf* naf, const float* m, const float* v, int64_t n, uint64_t step);
 
 #ifdef __cplusplus
 }

@@ -177,3 +177,48 @@ def test_check_numerics_raises_and_leaves_parameters_untouched():
         assert np.array_equal(before, params_of(agent))
     finally:
         agent.close()
+
+
+def test_checkpoint_resume_restores_the_adam_slots(tmp_path):
+    """util.SaverUtil must checkpoint the optimiser's slot variables like tf.train.Saver does (util.py:88-90): a run resumed
+    from a checkpoint continues bit for bit like the uninterrupted one (Adam: moments + beta powers)."""
+    import json
+    from cartpoleplusplus_amd import naf_cartpole as F, util
+    from tests.helpers import FakeEnv
+    shape, B = (16, 16, 3, 1, 2), 8
+
+    def make():
+        F.set_opts(F.default_opts(use_raw_pixels=True, render_height=16, render_width=16, num_cameras=1, action_repeats=2,
+                                  batch_size=B, replay_memory_size=200, share_input_state_representation=True,
+                                  optimiser="Adam", optimiser_args=json.dumps({"learning_rate": 0.001})))
+        return F.NormalizedAdvantageFunctionAgent(FakeEnv(shape))
+    idxs = np.random.default_rng(0).integers(0, 150, (6, 2 * B))
+    a = make()
+    try:
+        a.initialise_variables(seed=4); a.post_var_init_setup()
+        a.replay_memory.fill_synthetic(150, seed=9)
+        for k in range(3):
+            a.train_step(B, 2, idxs=idxs[k])
+        saver = util.SaverUtil.__new__(util.SaverUtil)            # (no restore-or-init: save this agent as it is)
+        saver.agent, saver.ckpt_dir, saver.save_freq = a, str(tmp_path), 3600
+        saver.force_save()
+        for k in range(3, 6):
+            a.train_step(B, 2, idxs=idxs[k])
+        want = [n.get_params() for n in a.networks()]
+        st = a.naf.get_optimiser_state()
+        assert int(st["step"]) == 12 and np.abs(st["m"]).max() > 0 and np.abs(st["v"]).max() > 0
+    finally:
+        a.close()
+    b = make()
+    try:
+        util.SaverUtil(b, str(tmp_path), 3600)                    # restores the latest checkpoint
+        # (no post_var_init_setup here: it would clobber the restored target with the value network, naf_cartpole.py:300-303)
+        assert int(b.naf.get_optimiser_state()["step"]) == 6
+        b.replay_memory.fill_synthetic(150, seed=9)
+        for k in range(3, 6):
+            b.train_step(B, 2, idxs=idxs[k])
+        got = [n.get_params() for n in b.networks()]
+    finally:
+        b.close()
+    for x, y in zip(want, got):
+        assert np.array_equal(x, y)
