@@ -78,6 +78,21 @@ struct K16Geom {
   static __host__ __device__ constexpr bool vgpr_may_be_synthetic(int ch, int v) {       // any lane group: not both real
     return 32 * ch + 8 * 3 + 2 * v + 1 >= KROW;
   }
+  // can dword v of chunk ch in M tile m (of any strip, any lane) ever hold an element that must be cleared or replaced?  The
+  // synthetic k values (ones channel, zero fill), a tap left of the image (kx < P: only a strip's first tile can touch x < 0)
+  // or a tap right of it (kx > P: any tile, the image may end anywhere in a strip).
+  static __host__ __device__ constexpr bool vgpr_may_need_mask(int ch, int m, int v) {
+    if (vgpr_may_be_synthetic(ch, v)) return true;
+    for (int g = 0; g < 4; ++g)
+      for (int h = 0; h < 2; ++h) {
+        const int k = 32 * ch + 8 * g + 2 * v + h;
+        if (k >= KROW) return true;
+        const int kx = k / CIN;
+        if (kx > P) return true;
+        if (kx < P && m == 0) return true;
+      }
+    return false;
+  }
 };
 
 #ifndef K16_WGS
@@ -214,24 +229,16 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     }
   }
 
-  // ---- operand masks.  amask / acst: the synthetic k values of this lane's group (ones channel, zero fill) -- every
-  // tile.  bmask: additionally the SAME padding (pixel x + kx - P outside [0, W)) -- only tiles that touch a border.
-  unsigned amask[NCH][4], acst[NCH][XT][4], bmask[NCH][XT][4];
-  bool border[XT];
-#pragma unroll
-  for (int m = 0; m < XT; ++m) {
-    const int x0 = sstrip * G::SW + m * 16;            // wave-uniform
-    border[m] = x0 < P || x0 + 15 + (KS - 1 - P) >= W;
-  }
+  // ---- operand masks: dword v of a lane's 16-byte window of chunk ch in tile m becomes (u & emask) | ecst.  emask clears the
+  // synthetic k values of the lane's group (ones channel, zero fill) and the taps of the SAME padding (pixel x + kx - P outside
+  // [0, W)); ecst puts f16 1.0 into the ones channel where its pixel is inside the image.  Applied unconditionally wherever
+  // K16Geom::vgpr_may_need_mask says a mask can matter at all (20 of the 24 dwords of a row for 5x5x18; a run-time "is this a
+  // border tile" made the compiler compute both variants and select: 48 VALU per row).
+  unsigned emask[NCH][XT][4], ecst[NCH][XT][4];
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      unsigned mk = 0u;
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-        if (32 * ch + 8 * lj + 2 * v + h < G::KROW) mk |= 0xFFFFu << (16 * h);
-      amask[ch][v] = mk;
+    for (int v = 0; v < 4; ++v)
 #pragma unroll
       for (int m = 0; m < XT; ++m) {
         unsigned cs = 0u, bm = 0u;
@@ -244,10 +251,9 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
           if (k < G::KROW && inside) bm |= 0xFFFFu << (16 * h);
           if (k >= G::KROW && k < G::KAUG && inside) cs |= 0x3C00u << (16 * h);      // f16 1.0
         }
-        acst[ch][m][v] = cs;
-        bmask[ch][m][v] = bm;
+        ecst[ch][m][v] = cs;
+        emask[ch][m][v] = bm;
       }
-    }
 
   // ---- pooled-row writer: a lane owns PAIRS (o, o+1) of the wave's 8*XT pooled columns (nout is even: dispatch) -- one
   // 8-byte value store, one 2-byte code store and three 4-byte bf16-plane stores per pair
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #pragma unroll
     for (int m = 0; m < XT; ++m) {
 #ifdef K16_ABL_NOLDSA
-      av[0][ch][m] = (k16_u32x4){amask[NCH - 1][1], acst[NCH - 1][0][1], amask[NCH - 1][2], (unsigned)y};
+      av[0][ch][m] = (k16_u32x4){emask[NCH - 1][0][1], ecst[NCH - 1][0][1], emask[NCH - 1][0][2], (unsigned)y};
 #else
 #pragma unroll
       for (int pa = 0; pa < NPA; ++pa) {
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #pragma unroll
       for (int pc = 0; pc < NPC; ++pc) {
 #ifdef K16_ABL_NOLDSB
-        bv[set][t][pc] = __builtin_bit_cast(f16x8, (k16_u32x4){amask[NCH - 1][1], acst[NCH - 1][0][1], amask[NCH - 1][2], wa[t]});
+        bv[set][t][pc] = __builtin_bit_cast(f16x8, (k16_u32x4){emask[NCH - 1][0][1], ecst[NCH - 1][0][1], emask[NCH - 1][0][2], wa[t]});
 #else
         bv[set][t][pc] = lds_load<f16x8>(wa[t], (ch * NPC + pc) * G::SLAB);
 #endif
@@ -330,6 +336,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #ifdef K16_CLOCK_PROBE
   const unsigned long long pc0 = __builtin_readcyclecounter(), pr0 = __builtin_amdgcn_s_memrealtime();
 #endif
+  const bool wr_f32 = PLAIN || a.out != nullptr, wr_code = a.out_amax != nullptr;     // target networks of the fused step: bf16 planes only
   for (int q0 = 0; q0 < H + P; q0 += KS) {
 #pragma unroll
     for (int sq = 0; sq < KS; ++sq) {
@@ -357,14 +364,9 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
                               __builtin_amdgcn_alignbyte(u[3], u[2], ashift), __builtin_amdgcn_alignbyte(x4, u[3], ashift)};
 #endif
             }
-            if (border[m]) {                         // wave-uniform
 #pragma unroll
-              for (int v = 0; v < 4; ++v) u[v] = (u[v] & bmask[ch][m][v]) | acst[ch][m][v];
-            } else {
-#pragma unroll
-              for (int v = 0; v < 4; ++v)
-                if (G::vgpr_may_be_synthetic(ch, v)) u[v] = (u[v] & amask[ch][v]) | acst[ch][m][v];
-            }
+            for (int v = 0; v < 4; ++v)
+              if (G::vgpr_may_need_mask(ch, m, v)) u[v] = (u[v] & emask[ch][m][v]) | ecst[ch][m][v];
             af[pa][m] = u;
           }
 #pragma unroll
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
               code[e] = lower ? 2 + __float_as_int(bot[2 * e + 1]) : __float_as_int(top[2 * e + 1]);
               pv[e] = mx > 0.f ? mx * inv : 0.f;
             }
-            __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(pv[0]), __float_as_uint(pv[1])}, out_rsrc, (int)(coe[i] * 4), orow * 4, 0);
+            if (wr_f32) __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(pv[0]), __float_as_uint(pv[1])}, out_rsrc, (int)(coe[i] * 4), orow * 4, 0);
             if (a.out_b16) {                         // the next layer's A operand: three bf16 planes of the same tensor
               // truncating split (cheaper than round-to-nearest in this MFMA-issue-bound loop, equally exact: the pieces are
               // the value's three consecutive byte-groups of significand, x = h + m + l)
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
               __builtin_amdgcn_raw_buffer_store_b32((mb[0] >> 16) | mb[1], b16_rsrc, (int)(coe[i] * 2), b16_plane_bytes + orow * 2, 0);
               __builtin_amdgcn_raw_buffer_store_b32((lb[0] >> 16) | (lb[1] & 0xFFFF0000u), b16_rsrc, (int)(coe[i] * 2), 2 * b16_plane_bytes + orow * 2, 0);
             }
-            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(code[0] | (code[1] << 8)), amax_rsrc, (int)coe[i], orow, 0);
+            if (wr_code) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(code[0] | (code[1] << 8)), amax_rsrc, (int)coe[i], orow, 0);
           }
         }
         __builtin_amdgcn_wave_barrier();

@@ -280,6 +280,10 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b, int phase = 0) {
       {
         ConvArgs cl[4]; int mode = 0;
         for (int k = 0; k < 4; ++k) cl[k] = conv_fwd_args(nets[k], nets[k]->ws[0], 0, sts[k], dt, whs[k], B, &mode);
+        // the target networks have no backward pass: when their conv2 reads the bf16 planes of pool1, the f32 copy and the
+        // arg-max codes of pool1 are dead (26 MB of writes per minibatch at 64x64x18) -- the kernel skips null outputs
+        for (int k = 2; k < 4; ++k)
+          if (nets[k]->use_b16 && cl[k].out_b16) { cl[k].out = nullptr; cl[k].out_amax = nullptr; }
         // all four conv1 forwards in one launch as well: 16 tiles per persistent workgroup amortise the weight
         // preload and the tail (measured 0.560 -> 0.526 ms per step for the four networks)
         RC(launch_conv_fwd_multi(ctx, kFwdKid[0], a->conv[0].Cin, a->conv[0].ks, mode, EPI_RELU_POOL, cl, 4));

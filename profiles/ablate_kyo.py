@@ -5,7 +5,7 @@
   python profiles/ablate_kyo.py run KERNEL NAME ...                               (on the GPU box; KERNEL e.g. conv1_fwd)
 
 Each variant is the shipped library with that one object file rebuilt with extra -D flags
-(cartpoleplusplus_amd/lib/ablate_<NAME>.so, git-ignored).  BASE = the shipped library.
+(cartpoleplusplus_amd/lib/libcartpolepp_hip_ablate_<NAME>.so, git-ignored; loaded with CARTPOLEPP_ABLATION=ablate_<NAME>).  BASE = the shipped library.
 """
 import glob, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,8 +20,8 @@ def build(unit, specs):
         procs.append((name, obj, subprocess.Popen(["hipcc"] + FLAGS + flags.split(",") + ["-c", os.path.join(ROOT, "cartpoleplusplus_amd/csrc/%s.hip" % unit), "-o", obj])))
     for name, obj, p in procs:
         assert p.wait() == 0, name
-        objs = [o for o in glob.glob(os.path.join(LIB, "obj", "*.o")) if os.path.basename(o) != unit + ".o"]
-        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(LIB, "ablate_%s.so" % name)] + objs + [obj])
+        objs = [o for o in glob.glob(os.path.join(LIB, "obj", "*.o")) if os.path.basename(o) != unit + ".o" and not os.path.basename(o).startswith("abl_")]
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(LIB, "libcartpolepp_hip_ablate_%s.so" % name)] + objs + [obj, "-L/opt/rocm/lib", "-lrccl"])
         print("built", name)
 
 def run(kernel, names):
@@ -29,7 +29,7 @@ def run(kernel, names):
         env = dict(os.environ)
         if name != "BASE":
             env["CARTPOLEPP_ABLATION"] = "ablate_%s" % name
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "50", "--warmup", "10"],
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--quick", "--steps", "100", "--warmup", "10"],
                              env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
         try:
             d = json.loads(out.strip().splitlines()[-1])
