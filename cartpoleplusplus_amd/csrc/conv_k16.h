@@ -50,6 +50,28 @@ __device__ __forceinline__ void k16_split3(float x, unsigned short& h, unsigned 
   h = (unsigned short)hb; m = (unsigned short)mb; l = (unsigned short)(__float_as_uint(r2) >> 16);     // r2 has <= 8 significant bits
 }
 
+// ---- A-operand loads the compiler does not see (K16_ASYNC_A).  The compiler's own s_waitcnt placement for this loop is
+// vmcnt(0) in front of every chunk's first operand use: the pooled-row writer's stores are issued under per-lane / uniform
+// conditions, so the pass cannot count them, and a wave sat out the full round trip of ten stores every second row.  With the
+// loads issued from inline asm the pass has nothing to wait for; the waits are placed by hand as vmcnt(N), N = the number of
+// vector-memory instructions issued AFTER the loads that are needed (they retire in order) -- which is a compile-time number
+// because every such instruction is issued unconditionally (disabled / out-of-image stores are dropped by their buffer
+// descriptor's range check instead of being branched around).
+typedef int k16_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ k16_i32x4 k16_raw_desc(const void* base, int num_records) {      // raw buffer, stride 0 (as make_buffer_rsrc)
+  const unsigned long long b = (unsigned long long)base;
+  return (k16_i32x4){(int)(unsigned)b, (int)((b >> 32) & 0xFFFFu), num_records, 0x00020000};
+}
+__device__ __forceinline__ void k16_issue_b128(k16_u32x4& dst, const k16_i32x4& desc, int voff, int soff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(desc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void k16_issue_b32(unsigned& dst, const k16_i32x4& desc, int voff, int soff) {
+  asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(desc), "s"(soff) : "memory");
+}
+// s_waitcnt vmcnt(N) that the uses of `x...` cannot be moved in front of
+template <int N> __device__ __forceinline__ void k16_wait_vm(k16_u32x4& x) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x) : "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void k16_wait_vm(unsigned& x) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x) : "n"(N) : "memory"); }
+
 template <int CIN, int KS, int XT, int IPW, bool B16 = false>
 struct K16Geom {
   static constexpr int NO = KYO_NO;
@@ -269,22 +291,26 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     const int px = ((sstrip * G::SW) >> 1) + xl;
     cact[i] = idx < 8 * XT * hn && px < Wp;
     cadr[i] = keep_in_vgpr(lds_addr(ev + (cact[i] ? xl * NO + o : 0)));
-    coe[i] = (unsigned)(px * nout + o);
+    coe[i] = cact[i] ? (unsigned)(px * nout + o) : 0x3FFFFFFCu;      // inactive lanes: beyond every descriptor's range (x 1, 2, 4)
   }
+  constexpr int ST = NC * 5;                          // vector-memory stores of one writer pass (all issued; see k16_issue_b128)
   const __amdgpu_buffer_rsrc_t b16_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       a.out_b16 ? a.out_b16 + (long)sbimg * (Hp * Wp * nout) : (unsigned short*)a.out, 0,
       a.out_b16 ? (int)(2 * a.out_b16_plane * 2 + (long)Hp * Wp * nout * 2) : 0, 0x00020000);      // this image in the three planes, no further
   const int b16_plane_bytes = (int)(a.out_b16_plane * 2);
+  // (a null output -- the target networks' f32 pool1 and codes in the fused step -- gets an empty range: its stores are issued
+  // and dropped, so the number of vector-memory instructions per writer pass does not depend on the network)
   const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      a.out + (long)sbimg * a.out_bstride, 0, (PLAIN ? H * W : Hp * Wp) * nout * 4, 0x00020000);
+      a.out ? a.out + (long)sbimg * a.out_bstride : (float*)a.out_b16, 0, a.out ? (PLAIN ? H * W : Hp * Wp) * nout * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t amax_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      a.out_amax + (long)sbimg * Hp * Wp * nout, 0, Hp * Wp * nout, 0x00020000);
+      a.out_amax ? a.out_amax + (long)sbimg * Hp * Wp * nout : (uint8_t*)a.out_b16, 0, a.out_amax ? Hp * Wp * nout : 0, 0x00020000);
 
   // ---- A operands: 16 bytes per lane and (tile, chunk) straight from the image row
   const int rowbytes = W * CIN * 2;
-  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)((const char*)(B16 ? (const void*)a.in_b16 : a.in) + ((long)(a.img_slot ? a.img_slot[sbimg] : sbimg) * a.in_bstride) * 2 - G::BIAS_BYTES), 0,
-      (B16 ? 2 * (int)a.plane_stride : 0) + H * rowbytes + G::BIAS_BYTES + 256, 0x00020000);      // this image (B16: in its three planes) + the masked overhang
+  void* const in_base = (void*)((const char*)(B16 ? (const void*)a.in_b16 : a.in) + ((long)(a.img_slot ? a.img_slot[sbimg] : sbimg) * a.in_bstride) * 2 - G::BIAS_BYTES);
+  const int in_records = (B16 ? 2 * (int)a.plane_stride : 0) + H * rowbytes + G::BIAS_BYTES + 256;      // this image (B16: in its three planes) + the masked overhang
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(in_base, 0, in_records, 0x00020000);
+  const k16_i32x4 in_desc = k16_raw_desc(in_base, in_records);      // the same descriptor for the inline-asm loads
   const int avoff0 = G::BIAS_BYTES + ((strip * G::SW + li - P) * CIN + 8 * lj) * 2;     // >= 128 - 2 P CIN
   const int avoff = ODD ? (avoff0 & ~3) : avoff0;
   const unsigned ashift = ODD ? (unsigned)(avoff0 & 2) : 0u;    // per-lane constant: 16 * m * CIN pixels further keeps the parity
@@ -292,9 +318,22 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   k16_u32x4 av[NPA][NCH][XT];
   unsigned ax[NCH][XT];                               // ODD: the fifth dword of the window
   const int plane_bytes = B16 ? (int)a.plane_stride : 0;      // bytes between the bf16 planes of the input
+#ifdef K16_NO_ASYNC_A
+  constexpr bool ASYNC_A = false;
+#else
+  constexpr bool ASYNC_A = !PLAIN;                    // (the plain-output epilogue stores a data-dependent number of rows)
+#endif
+  constexpr int LPC = XT * NPA + (ODD ? XT : 0);      // vector-memory loads per chunk and row
   auto load_a = [&](int ch, int y) {
 #pragma unroll
     for (int m = 0; m < XT; ++m) {
+      if (ASYNC_A) {
+#pragma unroll
+        for (int pa = 0; pa < NPA; ++pa)
+          k16_issue_b128(av[pa][ch][m], in_desc, avoff, pa * plane_bytes + y * rowbytes + (m * 16 * CIN + 32 * ch) * 2);
+        if (ODD) k16_issue_b32(ax[ch][m], in_desc, avoff, y * rowbytes + (m * 16 * CIN + 32 * ch) * 2 + 16);
+        continue;
+      }
 #ifdef K16_ABL_NOLDSA
       av[0][ch][m] = (k16_u32x4){emask[NCH - 1][0][1], ecst[NCH - 1][0][1], emask[NCH - 1][0][2], (unsigned)y};
 #else
@@ -316,6 +355,11 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) load_a(ch, 0);
+  const __amdgpu_buffer_rsrc_t null_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0, 0x00020000);      // empty range: stores are dropped
+  if (ASYNC_A) {                                      // row 0 sees the same sequence as every other row: its loads, then ST stores
+#pragma unroll
+    for (int i = 0; i < ST; ++i) __builtin_amdgcn_raw_buffer_store_b32(0u, null_rsrc, 64 * i, 0, 0);   // (distinct, non-adjacent addresses: identical or adjacent stores would be merged)
+  }
 
   // B operands of one k chunk; two sets: the loads of chunk ch+1 are in flight under the MFMAs of ch
   f16x8 bv[2][NT][NPC];
@@ -348,9 +392,26 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
           if (ch + 1 < NCH) load_b(ch + 1, (ch + 1) & 1, wadr[sq]);
+#ifndef K16_NO_PIN_B
+          // keep the next chunk's B reads in front of this chunk's MFMAs: left to itself the scheduler sinks them to the end of
+          // the chunk (shorter live ranges) and the next chunk opens with s_waitcnt lgkmcnt on reads issued two MFMAs earlier
+          __builtin_amdgcn_sched_barrier(0);
+#endif
 #ifdef K16_PRIO
           __builtin_amdgcn_s_setprio(K16_PRIO);
 #endif
+          if (ASYNC_A) {
+            // this chunk's operands were requested one row ago; issued since: the other chunks' loads and the ST stores every row
+            // ends with (the writer's, or as many dropped ones: ONE wait count, no second code path around the wait)
+            k16_wait_vm<(NCH - 1) * LPC + ST>(av[0][ch][0]);
+#pragma unroll
+            for (int pa = 0; pa < NPA; ++pa)
+#pragma unroll
+              for (int m = 0; m < XT; ++m) {
+                asm volatile("" : "+v"(av[pa][ch][m]));
+                if (ODD) asm volatile("" : "+v"(ax[ch][m]));
+              }
+          }
           k16_u32x4 af[NPA][XT];
 #pragma unroll
           for (int pa = 0; pa < NPA; ++pa)
@@ -388,7 +449,9 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #ifdef K16_PRIO
           __builtin_amdgcn_s_setprio(0);
 #endif
-          if (q + 1 < H) load_a(ch, q + 1);          // this chunk's operands of the next row, a whole row period ahead
+          if (ASYNC_A || q + 1 < H) load_a(ch, q + 1);   // this chunk's operands of the next row, a whole row period ahead (ASYNC_A:
+                                                         // also behind the last row -- masked by the descriptor, never used -- so
+                                                         // that the hand-counted waits see the same sequence in every row)
         }
       }
       if (q + 1 < H) {                               // chunk 0 of the next row loads under the epilogue
@@ -436,14 +499,19 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
           }
         }
       }
-      if (!PLAIN && y >= 0 && par == 1 && (y >> 1) < Hp) {
+      const bool writer_row = !PLAIN && y >= 0 && par == 1 && (y >> 1) < Hp;
+      if (ASYNC_A && !writer_row && q < H) {
+#pragma unroll
+        for (int i = 0; i < ST; ++i) __builtin_amdgcn_raw_buffer_store_b32(0u, null_rsrc, 64 * i, 0, 0);   // (distinct, non-adjacent addresses: identical or adjacent stores would be merged)
+      }
+      if (writer_row) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int orow = (y >> 1) * Wp * nout;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
-          if (cact[i]) {
+          if (ASYNC_A || cact[i]) {
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             const f32x4 top = lds_load<f32x4>(cadr[i], 0), bot = lds_load<f32x4>(cadr[i], (8 * XT * NO) * 8);   // (value, code) x 2
             float pv[2]; int code[2];
@@ -454,8 +522,8 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
               code[e] = lower ? 2 + __float_as_int(bot[2 * e + 1]) : __float_as_int(top[2 * e + 1]);
               pv[e] = mx > 0.f ? mx * inv : 0.f;
             }
-            if (wr_f32) __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(pv[0]), __float_as_uint(pv[1])}, out_rsrc, (int)(coe[i] * 4), orow * 4, 0);
-            if (a.out_b16) {                         // the next layer's A operand: three bf16 planes of the same tensor
+            if (ASYNC_A || wr_f32) __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(pv[0]), __float_as_uint(pv[1])}, out_rsrc, (int)(coe[i] * 4), orow * 4, 0);
+            if (ASYNC_A || a.out_b16) {              // the next layer's A operand: three bf16 planes of the same tensor
               // truncating split (cheaper than round-to-nearest in this MFMA-issue-bound loop, equally exact: the pieces are
               // the value's three consecutive byte-groups of significand, x = h + m + l)
               unsigned hb[2], mb[2], lb[2];
@@ -470,13 +538,14 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
               __builtin_amdgcn_raw_buffer_store_b32((mb[0] >> 16) | mb[1], b16_rsrc, (int)(coe[i] * 2), b16_plane_bytes + orow * 2, 0);
               __builtin_amdgcn_raw_buffer_store_b32((lb[0] >> 16) | (lb[1] & 0xFFFF0000u), b16_rsrc, (int)(coe[i] * 2), 2 * b16_plane_bytes + orow * 2, 0);
             }
-            if (wr_code) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(code[0] | (code[1] << 8)), amax_rsrc, (int)coe[i], orow, 0);
+            if (ASYNC_A || wr_code) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(code[0] | (code[1] << 8)), amax_rsrc, (int)coe[i], orow, 0);
           }
         }
         __builtin_amdgcn_wave_barrier();
       }
     }
   }
+  if (ASYNC_A) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the look-ahead loads behind the last row)
 #ifdef K16_CLOCK_PROBE
   if (lane == 0 && (blockIdx.x % 97) == 5 && blockIdx.y == 1 && wave == 0) {
     const unsigned long long pc1 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();

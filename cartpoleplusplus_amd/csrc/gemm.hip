@@ -13,6 +13,9 @@
 // 4x shorter chain matter more than tiling).  Partial tiles are combined through LDS in fixed order.
 // A(m,k) = A[m*sAm + k*sAk], B(k,n) = B[k*sBk + n*sBn]: the strides express the transposes of the
 // backward passes (dX = dz W^T, dW = x^T dz) without materialising them.
+#ifndef GEMM_R
+#define GEMM_R 1      // rounds of a wave whose loads are in flight together.  Measured (six MLP levels of a step): 1 -> 0.0440 ms, 2 -> 0.0439, 4 -> 0.0457 (120 VGPRs), 6 -> 0.0525 (168), 11 -> 0.1112 (290: one workgroup per CU): the levels are bound by the operand traffic through L1 / the texture path, not by a chain of round trips
+#endif
 #ifndef GEMM_U
 #define GEMM_U 4      // k values per wave and round = 4 U (sweep 4 / 8 / 12 / 16 with 16-byte loads: 0.057 / 0.058 / 0.064 / 0.064 ms for the six MLP levels)
 #endif
@@ -34,29 +37,42 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, float (*r
   static_assert(U % 4 == 0, "whole float4s per lane");
   typedef float gemm_f4 __attribute__((ext_vector_type(4), aligned(4)));
   const bool va = g.sAk == 1, vb = g.sBk == 1;       // uniform
-  for (int k0 = wave * 4 * U; k0 < g.K; k0 += 4 * 4 * U) {
-    float av[U], bv[U];
-    const int kb = k0 + U * lj;
+  // A wave's rounds are independent until the MFMAs: ALL operand loads of up to GEMM_R rounds are issued before the first
+  // one is used (one round trip to L2 per GEMM_R rounds instead of one per round: the K = 641 layers were ten dependent round
+  // trips of ~1 us each -- the "fixed cost per level" of the MLP heads).  Same k order, same summation order as the plain loop.
+  constexpr int R = GEMM_R;
+  for (int kr = wave * 4 * U; kr < g.K; kr += R * 4 * 4 * U) {
+    float av[R][U], bv[R][U];
 #pragma unroll
-    for (int q = 0; q < U / 4; ++q) {
-      const int k = kb + 4 * q;
-      if (va && mv && k + 3 < g.K) {
-        const gemm_f4 v = *reinterpret_cast<const gemm_f4*>(ap + k);
-        av[4 * q] = v[0]; av[4 * q + 1] = v[1]; av[4 * q + 2] = v[2]; av[4 * q + 3] = v[3];
-      } else {
+    for (int r = 0; r < R; ++r) {
+      const int k0 = kr + r * 4 * 4 * U;
+      const int kb = k0 + U * lj;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) av[4 * q + e] = (mv && k + e < g.K) ? ap[(long)(k + e) * g.sAk] : 0.f;
-      }
-      if (vb && nv && k + 3 < g.K) {
-        const gemm_f4 v = *reinterpret_cast<const gemm_f4*>(bp + k);
-        bv[4 * q] = v[0]; bv[4 * q + 1] = v[1]; bv[4 * q + 2] = v[2]; bv[4 * q + 3] = v[3];
-      } else {
+      for (int q = 0; q < U / 4; ++q) {
+        const int k = kb + 4 * q;
+        if (va && mv && k + 3 < g.K) {
+          const gemm_f4 v = *reinterpret_cast<const gemm_f4*>(ap + k);
+          av[r][4 * q] = v[0]; av[r][4 * q + 1] = v[1]; av[r][4 * q + 2] = v[2]; av[r][4 * q + 3] = v[3];
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bv[4 * q + e] = (nv && k + e < g.K) ? bp[(long)(k + e) * g.sBk] : 0.f;
+          for (int e = 0; e < 4; ++e) av[r][4 * q + e] = (mv && k + e < g.K) ? ap[(long)(k + e) * g.sAk] : 0.f;
+        }
+        if (vb && nv && k + 3 < g.K) {
+          const gemm_f4 v = *reinterpret_cast<const gemm_f4*>(bp + k);
+          bv[r][4 * q] = v[0]; bv[r][4 * q + 1] = v[1]; bv[r][4 * q + 2] = v[2]; bv[r][4 * q + 3] = v[3];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bv[r][4 * q + e] = (nv && k + e < g.K) ? bp[(long)(k + e) * g.sBk] : 0.f;
+        }
       }
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) acc = MFMA16(av[u], bv[u], acc);
+    for (int r = 0; r < R; ++r) {
+      if (kr + r * 4 * 4 * U < g.K) {                  // (uniform; rounds past K hold zeros anyway)
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = MFMA16(av[r][u], bv[r][u], acc);
+      }
+    }
   }
   if (wave > 0) {
 #pragma unroll
