@@ -40,7 +40,8 @@ enum KernelId {
 };
 
 // deferred second-stage reductions of the conv dW partials (flushed in one launch)
-struct DwReduceDesc { const float* partial; int nblocks, pstride, nw, nout; float* grad_w; float* grad_b; };
+struct DwReduceDesc { const float* partial; int nblocks, pstride, nw, nout; float* grad_w; float* grad_b;
+                      double* sq_part; };      // non-null: reduction block b also leaves the sum of squares of its 64 gradients in sq_part[b]
 #define DW_REDUCE_MAX 8
 
 struct cpp_ctx {
@@ -60,7 +61,13 @@ struct cpp_ctx {
   const struct GatherArgs* ride;  // non-null: the next minibatch's sample + statistics kernel rides in the dW reduction's launch
   bool ride_done; int ride_dtype;
   bool ride_at_dw;                // the rider may already leave with conv1's dW (its slots are double-buffered: direct replay)
+  // Global-norm partials folded into the kernels that write the gradients (fused single-learner step): every dW GEMM tile and every
+  // conv dW reduction block leaves the f64 sum of squares of its outputs in sq_part (one region of SQ_REGION slots per gradient
+  // list); the optimiser kernel adds a list's partials in slot order.  sq_n: slots handed out so far, -1: folding off (the sumsq
+  // kernel runs instead: data-parallel steps, whose gradients change in the all-reduce; batch norm; NAF).
+  double* sq_part; int sq_n[2]; int sq_conv_group[4];
 };
+#define SQ_REGION 2048
 
 // ---------------------------------------------------------------------------------------------
 // conv kernels (conv.hip)
@@ -162,6 +169,7 @@ struct GemmArgs {
   int accumulate;               // C = C + A*B before the epilogue (sums several heads' d(representation))
   float* C2; long ldc2;         // optional second copy of the output (e.g. actions straight into the critic's input)
   const uint64_t* drop_counter; uint32_t drop_seed, drop_layer;   // GE_RELU_DROPOUT
+  double* sq_part;              // non-null: tile t also leaves the f64 sum of squares of its outputs in sq_part[t] (see cpp_ctx::sq_part)
 };
 #define GEMM_BATCH_MAX 8
 struct GemmBatch { GemmArgs g[GEMM_BATCH_MAX]; int tile_start[GEMM_BATCH_MAX + 1]; int n; };
@@ -238,6 +246,7 @@ struct OptSegs {
   float* p[OPT_MAX_SEGS]; const float* g[OPT_MAX_SEGS]; float* m[OPT_MAX_SEGS]; float* v[OPT_MAX_SEGS];
   long n[OPT_MAX_SEGS]; float lr[OPT_MAX_SEGS]; int group[OPT_MAX_SEGS];
   int nseg; int kind; float momentum, beta1, beta2, epsilon;
+  const double* sq; int sq_begin[2], sq_count[2];   // sq != nullptr: group g's squared norm = sum of sq[sq_begin[g] .. + sq_count[g]) instead of `part`
   const uint64_t* step;        // Adam: number of applies so far INCLUDING this one (device counter)
   uint64_t* bump;              // optional: device counter incremented once by this launch (the replay sampler's Philox counter)
 };

@@ -231,6 +231,13 @@ int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, co
     DwReduceDesc& d = ctx->pending[ctx->npending++];
     d.partial = batch.a[i].partial; d.nblocks = grid; d.pstride = nw + nout; d.nw = nw; d.nout = nout;
     d.grad_w = grad_w[i]; d.grad_b = grad_b[i];
+    d.sq_part = nullptr;
+    const int grp = ctx->sq_conv_group[i];
+    if (ctx->sq_part && grp >= 0 && ctx->sq_n[grp] >= 0) {
+      const int nb = (nw + nout + 63) / 64;
+      if (ctx->sq_n[grp] + nb <= SQ_REGION) { d.sq_part = ctx->sq_part + grp * SQ_REGION + ctx->sq_n[grp]; ctx->sq_n[grp] += nb; }
+      else ctx->sq_n[grp] = -1;                      // (cannot happen for the reference's layer sizes; the caller falls back to sumsq)
+    }
   }
   return 0;
 }

@@ -691,11 +691,18 @@ __device__ __forceinline__ void conv_dw_reduce_body(const DwReduceBatch& rb, con
     red[slice][el] = s;
   }
   __syncthreads();
-  if (tslice == 0 && e < n) {
+  if (tslice == 0) {
     float t = 0.f;
+    if (e < n) {
 #pragma unroll
-    for (int k = 0; k < NS; ++k) t += red[k][el];     // fixed order
-    if (e < d.nw) d.grad_w[e] = t; else d.grad_b[e - d.nw] = t;
+      for (int k = 0; k < NS; ++k) t += red[k][el];     // fixed order
+      if (e < d.nw) d.grad_w[e] = t; else d.grad_b[e - d.nw] = t;
+    }
+    if (d.sq_part) {                                 // (uniform) the block's share of the gradient list's squared norm
+      double sq = (double)t * (double)t;
+      for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+      if (el == 0) d.sq_part[bx - rb.block_start[p]] = sq;
+    }
   }
 }
 int launch_dw_reduce_batch(cpp_ctx* ctx, const DwReduceBatch& rb);

@@ -79,11 +79,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, float (*r
     for (int i = 0; i < 4; ++i) red[wave - 1][lane * 4 + i] = acc[i];
   }
   __syncthreads();
-  if (wave != 0 || !nv) return;
+  if (wave != 0) return;
+  double sq = 0.0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = tm * 16 + 4 * lj + i;
-    if (row < g.M) {
+    if (nv && row < g.M) {
       float v = ((acc[i] + red[0][lane * 4 + i]) + red[1][lane * 4 + i]) + red[2][lane * 4 + i];
       if (g.accumulate) v += g.C[(long)row * g.ldc + n];
       if (g.epi == GE_RELU) v = fmaxf(v, 0.f);
@@ -100,9 +101,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, float (*r
       }
       else if (g.epi == GE_MUL_TANH_GRAD) { const float y = g.Y[(long)row * g.ldy + n]; v = v * (1.f - y * y); }
       g.C[(long)row * g.ldc + n] = v;
+      sq += (double)v * (double)v;
       if (g.epi == GE_ACTOR_HEAD) { const float y = g.Y[(long)row * g.ldy + n]; g.C2[(long)row * g.ldc2 + n] = -v * (1.f - y * y); }
       else if (g.C2) g.C2[(long)row * g.ldc2 + n] = v;
     }
+  }
+  if (g.sq_part) {                                   // (uniform) this tile's share of the gradient list's squared norm, fixed order
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if (lane == 0) g.sq_part[tile] = sq;
   }
 }
 

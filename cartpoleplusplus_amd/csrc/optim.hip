@@ -59,9 +59,15 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_apply_kernel(const OptSegs s,
   // fixed-order butterfly) -- a one-thread loop over them was most of this kernel's time
   double tot = 0.0;
   if (threadIdx.x < 64) {
-    for (int k = 0; k < s.nseg; ++k)
-      if (s.group[k] == s.group[seg])
-        for (int i = threadIdx.x; i < nparts; i += 64) tot += part[k * nparts + i];
+    if (s.sq) {          // partials left by the kernels that wrote the gradients (cpp_ctx::sq_part), slot order
+      const int gr = s.group[seg];
+      const double* q = s.sq + s.sq_begin[gr];
+      for (int i = threadIdx.x; i < s.sq_count[gr]; i += 64) tot += q[i];
+    } else {
+      for (int k = 0; k < s.nseg; ++k)
+        if (s.group[k] == s.group[seg])
+          for (int i = threadIdx.x; i < nparts; i += 64) tot += part[k * nparts + i];
+    }
     for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
   }
   if (threadIdx.x == 0) {

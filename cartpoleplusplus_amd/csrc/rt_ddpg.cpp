@@ -24,6 +24,7 @@ struct cpp_ddpg {
   struct HalfGraphs { hipGraph_t g[3][2]; hipGraphExec_t e[3][2]; bool ok[3]; int next[3]; } hg[2];   // next: variant of the following call
   int h_B; uint64_t h_seed, h_replay_uid;
   uint64_t dp_local;       // minibatches applied locally since the last parameter averaging (periodic mode)
+  int sq_cnt[2];           // norm partials the last gradient pass left per list in cpp_ctx::sq_part (<= 0: none, run the sumsq kernel)
   int pre_variant;         // variant of the next cpp_ddpg_sample_and_compute call if its key still matches (0: sample)
   int32_t* slot_set[2][2]; // the two sets of slot arrays of step_batch
   Arena arena;
@@ -44,7 +45,7 @@ extern "C" int cpp_ddpg_create(cpp_ctx* ctx, cpp_net* actor, cpp_net* critic, cp
   d->maxB = actor->maxB < critic->maxB ? actor->maxB : critic->maxB;
   d->nA = actor->nparams; d->nC = critic->nparams;
   d->graph = nullptr; d->gexec = nullptr; d->graph_ok = false; d->step_batch = nullptr; d->g_replay_uid = 0;
-  memset(d->hg, 0, sizeof(d->hg)); d->dp_local = 0;
+  memset(d->hg, 0, sizeof(d->hg)); d->dp_local = 0; d->sq_cnt[0] = d->sq_cnt[1] = 0;
   d->h_replay_uid = 0; d->pre_variant = 0; d->h_B = 0; d->h_seed = 0;
   memset(d->slot_set, 0, sizeof(d->slot_set));
   d->heads_grid = d->heads_B = d->loss_parts = d->loss_B = 0;
@@ -182,13 +183,19 @@ static int critic_gradients_impl(cpp_ddpg* d, cpp_batch* b, bool critic_prefix_d
   return CPP_OK;
 }
 
-static int apply(cpp_ddpg* d, bool do_actor, bool do_critic, float grad_scale, uint64_t* bump = nullptr) {
+// folded: take the lists' squared norms from the partials the gradient pass left (compute_gradients: sq_scope) instead of running
+// the sumsq kernel -- only for gradients that are applied as computed (both lists, no scaling, nothing in between)
+static int apply(cpp_ddpg* d, bool do_actor, bool do_critic, float grad_scale, uint64_t* bump = nullptr, bool folded = false) {
   OptSegs s; memset(&s, 0, sizeof(s));
   s.bump = bump;
   s.nseg = 2; s.kind = OPT_SGD;
   s.p[0] = d->actor->params; s.g[0] = d->gradbuf; s.n[0] = do_actor ? d->nA : 0; s.lr[0] = d->hp.actor_learning_rate; s.group[0] = 0;
   s.p[1] = d->critic->params; s.g[1] = d->gradbuf + d->nA; s.n[1] = do_critic ? d->nC : 0; s.lr[1] = d->hp.critic_learning_rate; s.group[1] = 1;
-  RC(launch_sumsq(d->ctx, s, grad_scale, d->norm_part, NORM_PARTS));
+  if (folded && do_actor && do_critic && grad_scale == 1.0f && d->sq_cnt[0] > 0 && d->sq_cnt[1] > 0) {
+    s.sq = d->ctx->sq_part; s.sq_begin[0] = 0; s.sq_begin[1] = SQ_REGION; s.sq_count[0] = d->sq_cnt[0]; s.sq_count[1] = d->sq_cnt[1];
+  } else {
+    RC(launch_sumsq(d->ctx, s, grad_scale, d->norm_part, NORM_PARTS));
+  }
   // norms_out[group] is only written for lists that were applied (n > 0)
   RC(launch_opt_apply(d->ctx, s, grad_scale, d->hp.gradient_clip, d->norm_part, NORM_PARTS, d->loss_norms + 1));
   return CPP_OK;
@@ -267,6 +274,26 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b, int phase = 0) {
   const FcL& Lcat = c->fc[cat];
   const long ldcat = Lcat.n_in + 1;
   OpGraph G;
+  // The kernels that write the gradients also leave their share of the two lists' squared norms (cpp_ctx::sq_part): list 0 = actor,
+  // list 1 = critic.  Not with batch norm (dbeta comes out of the BN backward kernels) and not for a split pass.
+  struct SqScope {
+    cpp_ctx* c; cpp_ddpg* d;
+    SqScope(cpp_ctx* c_, cpp_ddpg* d_, bool on) : c(c_), d(d_) {
+      d->sq_cnt[0] = d->sq_cnt[1] = 0;
+      if (on) { c->sq_n[0] = c->sq_n[1] = 0; c->sq_conv_group[0] = 0; c->sq_conv_group[1] = 1; }
+    }
+    ~SqScope() {
+      if (c->sq_n[0] > 0 && c->sq_n[1] > 0) { d->sq_cnt[0] = c->sq_n[0]; d->sq_cnt[1] = c->sq_n[1]; }
+      c->sq_n[0] = c->sq_n[1] = -1;
+      for (int& g : c->sq_conv_group) g = -1;
+    }
+  } sq_scope(ctx, d, phase == 0 && !a->spec.use_batch_norm && !c->spec.use_batch_norm);
+  auto sqg = [&](int list, GemmArgs g) {
+    const int tiles = ((g.M + 15) / 16) * ((g.N + 15) / 16);
+    if (ctx->sq_n[list] >= 0 && ctx->sq_n[list] + tiles <= SQ_REGION) { g.sq_part = ctx->sq_part + list * SQ_REGION + ctx->sq_n[list]; ctx->sq_n[list] += tiles; }
+    else ctx->sq_n[list] = -1;
+    return g;
+  };
 
   // ---- forward: the four conv trunks.  conv1 saturates the chip per network; the narrow conv2 / conv3 layers
   // of all four networks share one launch each.
@@ -365,11 +392,11 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b, int phase = 0) {
     }
     const int hk = G.fn([=] { return launch_ddpg_heads(ctx, hd); }, {aF, taF, cP, tcP});
     // ---- actor backward below its head (the head's dX is part of the fused kernel)
-    G.gemm(fc_dw_args(a, a->ws[0], na - 1, B, a->ws[0].dz[na - 1]), {hk});
+    G.gemm(sqg(0, fc_dw_args(a, a->ws[0], na - 1, B, a->ws[0].dz[na - 1])), {hk});
     adz = hk;
     for (int l = na - 2; l >= 0; --l) {
       const FcL& L = a->fc[l];
-      G.gemm(fc_dw_args(a, a->ws[0], l, B, a->ws[0].dz[l]), {adz});
+      G.gemm(sqg(0, fc_dw_args(a, a->ws[0], l, B, a->ws[0].dz[l])), {adz});
       if (pre && l == na - 2) continue;       // dz[l - 1] came out of the heads kernel
       if (l > 0)
         adz = G.gemm(fc_dx_args(a, l, B, a->ws[0].dz[l], L.n_out, 0, L.n_in, a->ws[0].dz[l - 1], L.n_in, relu_grad_epi(a, l - 1),
@@ -378,12 +405,12 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b, int phase = 0) {
         adz = G.gemm(fc_dx_args(a, 0, B, a->ws[0].dz[0], L.n_out, 0, a->flat, a->ws[0].dpool[2], a->flat, GE_NONE, nullptr, 0), {adz});
     }
     // ---- critic backward below its concat layer
-    G.gemm(fc_dw_args(c, c->ws[0], nc - 1, B, c->ws[0].dz[nc - 1]), {hk});
-    G.gemm(fc_dw_args(c, c->ws[0], cat, B, c->ws[0].dz[cat]), {hk});
+    G.gemm(sqg(1, fc_dw_args(c, c->ws[0], nc - 1, B, c->ws[0].dz[nc - 1])), {hk});
+    G.gemm(sqg(1, fc_dw_args(c, c->ws[0], cat, B, c->ws[0].dz[cat])), {hk});
     cdz = hk;
     for (int l = cat - 1; l >= 0; --l) {
       const FcL& L = c->fc[l];
-      G.gemm(fc_dw_args(c, c->ws[0], l, B, c->ws[0].dz[l]), {cdz});
+      G.gemm(sqg(1, fc_dw_args(c, c->ws[0], l, B, c->ws[0].dz[l])), {cdz});
       if (l > 0)
         cdz = G.gemm(fc_dx_args(c, l, B, c->ws[0].dz[l], L.n_out, 0, L.n_in, c->ws[0].dz[l - 1], L.n_in, GE_MUL_RELU_GRAD,
                                 c->ws[0].fcin[l], L.n_in + 1), {cdz});
@@ -439,7 +466,7 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b, int phase = 0) {
   // ---- actor backward
   for (int l = na - 1; l >= 0; --l) {
     const FcL& L = a->fc[l];
-    G.gemm(fc_dw_args(a, a->ws[0], l, B, a->ws[0].dz[l]), {adz});
+    G.gemm(sqg(0, fc_dw_args(a, a->ws[0], l, B, a->ws[0].dz[l])), {adz});
     if (l > 0)
       adz = G.gemm(fc_dx_args(a, l, B, a->ws[0].dz[l], L.n_out, 0, L.n_in, a->ws[0].dz[l - 1], L.n_in, relu_grad_epi(a, l - 1),
                               a->ws[0].fcin[l], L.n_in + 1), {adz});
@@ -452,7 +479,7 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b, int phase = 0) {
                                         c->ws[0].dz[nc - 1], d->loss_norms); }, {c0, tcH});
   for (int l = nc - 1; l >= 0; --l) {
     const FcL& L = c->fc[l];
-    G.gemm(fc_dw_args(c, c->ws[0], l, B, c->ws[0].dz[l]), {cdz});
+    G.gemm(sqg(1, fc_dw_args(c, c->ws[0], l, B, c->ws[0].dz[l])), {cdz});
     const int ncols = L.cat ? L.n_in - A : L.n_in;
     if (l > 0)
       cdz = G.gemm(fc_dx_args(c, l, B, c->ws[0].dz[l], L.n_out, 0, ncols, c->ws[0].dz[l - 1], ncols, GE_MUL_RELU_GRAD,
@@ -542,7 +569,7 @@ static int step_body(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int
     ctx->ride = nullptr;
     if (rode && direct) { std::swap(d->step_batch->slot[0], d->step_batch->slot_alt[0]); std::swap(d->step_batch->slot[1], d->step_batch->slot_alt[1]); }
     RC(rc);
-    RC(apply(d, true, true, 1.0f, rows_dev ? nullptr : r->counter));   // also advances the sampler's counter
+    RC(apply(d, true, true, 1.0f, rows_dev ? nullptr : r->counter, true));   // also advances the sampler's counter
     if (more) {
       if (rode) RC(replay_sample_finish(r, B, Cg, C, d->step_batch));
       else RC(replay_sample_device(r, B, rows_dev ? rows_dev + (size_t)(i + 1) * B : nullptr, seed, rows_dev ? nullptr : r->counter, C,
