@@ -361,21 +361,23 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     for (int i = 0; i < ST; ++i) __builtin_amdgcn_raw_buffer_store_b32(0u, null_rsrc, 64 * i, 0, 0);   // (distinct, non-adjacent addresses: identical or adjacent stores would be merged)
   }
 
-  // B operands of one k chunk; two sets: the loads of chunk ch+1 are in flight under the MFMAs of ch
-  f16x8 bv[2][NT][NPC];
-  auto load_b = [&](int ch, int set, const uint32_t* wa) {
+  // B operands of ONE k chunk.  The pieces are consumed small-to-large (pc = NPC-1 .. 0); as soon as the MFMAs of a piece are
+  // issued its registers are reloaded with the same piece of the NEXT chunk (the next row's first chunk after the last one), so
+  // every read has the other pieces' MFMAs (>= 16 x 16 cycles) to land: the latency cover of a second register set without
+  // its 48 VGPRs (and without the register-to-register moves an odd chunk count needed).
+  f16x8 bv[NT][NPC];
+  auto load_b_piece = [&](int ch, int pc, const uint32_t* wa) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int pc = 0; pc < NPC; ++pc) {
+    for (int t = 0; t < NT; ++t) {
 #ifdef K16_ABL_NOLDSB
-        bv[set][t][pc] = __builtin_bit_cast(f16x8, (k16_u32x4){emask[NCH - 1][0][1], ecst[NCH - 1][0][1], emask[NCH - 1][0][2], wa[t]});
+      bv[t][pc] = __builtin_bit_cast(f16x8, (k16_u32x4){emask[NCH - 1][0][1], ecst[NCH - 1][0][1], emask[NCH - 1][0][2], wa[t]});
 #else
-        bv[set][t][pc] = lds_load<f16x8>(wa[t], (ch * NPC + pc) * G::SLAB);
+      bv[t][pc] = lds_load<f16x8>(wa[t], (ch * NPC + pc) * G::SLAB);
 #endif
-      }
+    }
   };
-  load_b(0, 0, wadr[0]);
+#pragma unroll
+  for (int pc = 0; pc < NPC; ++pc) load_b_piece(0, pc, wadr[0]);
 
 #ifdef K16_CLOCK_PROBE
   const unsigned long long pc0 = __builtin_readcyclecounter(), pr0 = __builtin_amdgcn_s_memrealtime();
@@ -391,12 +393,6 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
       if (q < H) {
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
-          if (ch + 1 < NCH) load_b(ch + 1, (ch + 1) & 1, wadr[sq]);
-#ifndef K16_NO_PIN_B
-          // keep the next chunk's B reads in front of this chunk's MFMAs: left to itself the scheduler sinks them to the end of
-          // the chunk (shorter live ranges) and the next chunk opens with s_waitcnt lgkmcnt on reads issued two MFMAs earlier
-          __builtin_amdgcn_sched_barrier(0);
-#endif
 #ifdef K16_PRIO
           __builtin_amdgcn_s_setprio(K16_PRIO);
 #endif
@@ -431,21 +427,24 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
             af[pa][m] = u;
           }
 #pragma unroll
-          for (int pa = NPA - 1; pa >= 0; --pa)
-#ifdef K16_ABL_1PC
-          for (int pc = 0; pc >= 0; --pc)
-#else
+          for (int pc = NPC - 1; pc >= 0; --pc) {    // small pieces first; XT*NT independent accumulators between the pieces
 #pragma unroll
-          for (int pc = NPC - 1; pc >= 0; --pc)      // small pieces first; XT*NT independent accumulators between the pieces
-#endif
+            for (int pa = NPA - 1; pa >= 0; --pa)
 #pragma unroll
-            for (int m = 0; m < XT; ++m)
+              for (int m = 0; m < XT; ++m)
 #pragma unroll
-              for (int t = 0; t < NT; ++t) {
-                if (B16) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(k16_bf16x8, af[pa][m]),
-                                                                            __builtin_bit_cast(k16_bf16x8, bv[ch & 1][t][pc]), acc[m][t], 0, 0, 0);
-                else acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[pa][m]), bv[ch & 1][t][pc], acc[m][t], 0, 0, 0);
-              }
+                for (int t = 0; t < NT; ++t) {
+                  if (B16) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(k16_bf16x8, af[pa][m]),
+                                                                              __builtin_bit_cast(k16_bf16x8, bv[t][pc]), acc[m][t], 0, 0, 0);
+                  else acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[pa][m]), bv[t][pc], acc[m][t], 0, 0, 0);
+                }
+            // this piece's registers: the same piece of the next chunk (pinned here: the scheduler would sink the reads to the
+            // end of the chunk and the next chunk would open waiting for them)
+            __builtin_amdgcn_sched_barrier(0);
+            if (ch + 1 < NCH) load_b_piece(ch + 1, pc, wadr[sq]);
+            else if (q + 1 < H) load_b_piece(0, pc, wadr[(sq + 1) % KS]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
 #ifdef K16_PRIO
           __builtin_amdgcn_s_setprio(0);
 #endif
@@ -454,16 +453,6 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
                                                          // that the hand-counted waits see the same sequence in every row)
         }
       }
-      if (q + 1 < H) {                               // chunk 0 of the next row loads under the epilogue
-        load_b(0, NCH & 1, wadr[(sq + 1) % KS]);
-        if (NCH & 1) {
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int pc = 0; pc < NPC; ++pc) bv[0][t][pc] = bv[1][t][pc];
-        }
-      }
-
 #ifdef K16_ABL_NOEPI
       const int y = (q == H + P - 1) ? q - P : -1;
 #else
