@@ -115,6 +115,8 @@ def cpu_baseline_torch(shape, B, budget_s=25.0):
     for threads in sorted({min(cores, 16), min(cores, 64), cores}):
         if tried and time.time() - t_all > budget_s:
             break
+        if len(tried) >= 2 and list(tried.values())[-1] < list(tried.values())[-2]:
+            break           # more threads already made it slower (at 256 threads one update of this 10-filter net takes 27 s)
         torch.set_num_threads(threads)
         agent.train_minibatch(batch)          # warm-up (thread pool, oneDNN primitive cache)
         reps, t0 = 0, time.time()

@@ -41,10 +41,43 @@ def short(name):
     return None
 
 
-def db_of(d):
+def db_of(d, must=True):
     f = glob.glob(os.path.join(ROOT, "gpurun_out", d, "**", "*.db"), recursive=True)
+    if not f and not must:
+        return None
     assert f, "no rocpd database under gpurun_out/%s" % d
     return sqlite3.connect(f[0])
+
+
+def other_configs(rnd):
+    """profiles/<round>_configs.md: bench line + rocprofv3 kernel stats of every other configuration run_profiles.sh ran."""
+    names = sorted(os.path.basename(p)[len("bench_%s_" % rnd):-len(".json")]
+                   for p in glob.glob(os.path.join(ROOT, "gpurun_out", "bench_%s_*.json" % rnd)))
+    if not names:
+        return
+    with open(os.path.join(ROOT, "profiles", "%s_configs.md" % rnd), "w") as f:
+        f.write("# Round %s: the other configurations (profiles/run_profiles.sh), one MI355X\n\n" % rnd[1:])
+        f.write("Every number quoted in README.md / DESIGN.md for a configuration other than cfg3 comes from this file.  Per\n"
+                "configuration: the `bench.py --quick` JSON line (un-profiled run) and the `rocprofv3 --kernel-trace --stats` kernel\n"
+                "table of the same command.\n\n")
+        for name in names:
+            line = open(os.path.join(ROOT, "gpurun_out", "bench_%s_%s.json" % (rnd, name))).read().strip()
+            try:
+                d = json.loads(line)
+                f.write("## %s -- %s steps/s (%s ms/step)\n\n%s\n\n" % (name, d["value"], d["ms_per_step"], d["config"]["workload"]))
+                f.write("parallelism: %s\n\n" % d["config"]["parallelism"])
+                f.write("| layer | kernels | us / launch | pipe | fraction of the pipe's bound |\n|---|---|---|---|---|\n")
+                for r in d.get("layers", []):
+                    f.write("| %s | %s | %s | %s | %s |\n" % (r["layer"], ", ".join(r["kernels"]), r["avg_launch_us"], r["pipe"], r["frac"]))
+                f.write("\n```\n%s\n```\n\n" % line)
+            except Exception as e:      # noqa: BLE001
+                f.write("## %s\n\n(no parsable bench line: %s)\n\n" % (name, e))
+            con = db_of("prof_%s_%s" % (rnd, name), must=False)
+            if con is not None:
+                f.write("| kernel | calls | total us | avg us | % |\n|---|---|---|---|---|\n")
+                for kname, calls, tot, avg, pct in con.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()[:14]:
+                    f.write("| `%s` | %d | %.1f | %.3f | %.2f |\n" % (kname[:110], calls, tot, avg, pct))
+                f.write("\n")
 
 
 def counters(con):
@@ -64,7 +97,7 @@ def main(rnd):
     with open(os.path.join(ROOT, "profiles", "%s_kernel_stats.md" % rnd), "w") as f:
         f.write("# Round %s profile: bench.py (cfg3, 64x64x18, B=256), MI355X\n\n" % rnd[1:])
         f.write("Command (profiles/run_profiles.sh): `rocprofv3 --kernel-trace --stats -d gpurun_out/prof_%s -o k -- python bench.py "
-                "--steps 50 --warmup 10 --no-cpu-baseline --profile-steps 5`\n\n" % rnd)
+                "--quick --steps 50 --warmup 10 --profile-steps 5`\n\n" % rnd)
         f.write("70 minibatch steps in total (warm-up, hipGraph-replayed timed steps, and the eager HIP-event pass); durations in\n"
                 "microseconds, from the rocpd database's `top_kernels` view (profiles/make_profiles.py).  One `conv_fwd_k16_kernel<18,5,2,2>`\n"
                 "launch computes conv1 of all four networks of a minibatch (blockIdx.y = network); likewise conv2/conv3 forward;\n"
@@ -96,14 +129,15 @@ def main(rnd):
             e["hbm_write_bytes"] = 1024.0 * e["WRITE_SIZE_KB"]
             e["hbm_bytes_per_launch"] = e["hbm_read_bytes_corrected"] + e["hbm_write_bytes"]
         kernels[k] = e
-    blob = {"source": "profiles/run_profiles.sh: rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --steps 10 --warmup 5 "
-                      "--no-cpu-baseline --profile-steps 5 (three separate passes: SQ_*, FETCH_SIZE, WRITE_SIZE)",
+    blob = {"source": "profiles/run_profiles.sh: rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --quick --steps 10 --warmup 5 "
+                      "--profile-steps 5 (three separate passes: SQ_*, FETCH_SIZE, WRITE_SIZE)",
             "note": "means per dispatch; FETCH_SIZE (KB) doubled per the gfx950 correction for 16-byte coalesced reads; conv*_fwd "
                     "launches carry four networks, conv*_dw / conv*_dx launches two",
             "kernels": kernels}
     with open(os.path.join(ROOT, "profiles", "%s_pmc.json" % rnd), "w") as f:
         json.dump(blob, f, indent=1)
     print(json.dumps({k: {"hbm": v.get("hbm_bytes_per_launch"), "split": v.get("wave_time_split")} for k, v in kernels.items()}, indent=1))
+    other_configs(rnd)
 
 
 if __name__ == "__main__":
