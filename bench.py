@@ -298,7 +298,9 @@ def main():
         row("conv1 forward (f32 MFMA)", ["conv1_fwd"], [(gf(L1, nfwd), "f32")]),
         row("conv1 dW", ["conv1_dw_f16x3", "conv1_dw_gather"], [(gf(L1, nb), "f16x3")]),
         row("conv1 dW (f32 MFMA)", ["conv1_dw"], [(gf(L1, nb), "f32")]),
-        row("conv2 forward", ["conv2_fwd"], [(gf(L2, nfwd), "bf16x9" if "conv1_fwd_f16x3" in prof else "f32")]),
+        # (when conv3 + pool3 ride as the tail of conv2's workgroups there is no conv3_fwd launch: its FLOPs belong to this row)
+        row("conv2 forward" + ("" if "conv3_fwd" in prof else " + conv3 forward"), ["conv2_fwd"],
+            [(gf(L2, nfwd), "bf16x9" if "conv1_fwd_f16x3" in prof else "f32")] + ([] if "conv3_fwd" in prof else [(gf(L3, nfwd), "f32")])),
         row("conv2 dW + dX", ["conv2_bwd"], [(gf(L2, nb), "bf16x9"), (gf(L2, nb), "f32")]),
         row("conv2 dW", ["conv2_dw"], [(gf(L2, nb), "f32")]),
         row("conv2 dX", ["conv2_dx"], [(gf(L2, nb), "f32")]),

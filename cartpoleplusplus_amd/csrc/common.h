@@ -106,6 +106,9 @@ struct ConvArgs {
   const unsigned short* in_b16; long plane_stride;   // conv_fwd_k16_kernel in B16 mode: the input as three bf16 planes (stride in bytes; in_bstride: halves per image)
   unsigned short* out_b16; long out_b16_plane;   // conv_fwd_k16_kernel: also write the pooled output as three bf16 planes (plane stride in halves)
   const int32_t* img_slot;   // conv1 on the f16 pipes only: image b is row img_slot[b] of `in` (the replay store itself: no gathered copy)
+  // conv2 forward on the bf16 pipes only (n3_w != nullptr): the workgroup also runs conv3 + pool3 of its two images from the
+  // pooled rows it has just produced (kept in LDS as zero-haloed 16x16 images: conv3_img.h) -- conv3's launch disappears
+  const float* n3_w; const float* n3_bias; float* n3_out; long n3_out_bstride; uint8_t* n3_amax;
 };
 
 // Same-geometry convolutions of several networks in ONE launch (blockIdx.y selects the descriptor): the
@@ -125,6 +128,8 @@ struct ConvPairSlot { int layer; bool have_dw, have_dx; ConvArgsN dw, dx; int dw
 int launch_conv3_bwd_pair(cpp_ctx* ctx, const ConvPairSlot& slot);
 int launch_conv2_bwd_pair(cpp_ctx* ctx, const ConvPairSlot& slot);
 bool conv3_img_ok(int cin, int ks, int H, int W, int nout);
+// true if conv2 forward of this geometry runs on conv_k16.h's B16 instance that can carry conv3 as its tail
+bool conv23_fuse_ok(int H2, int W2, int B, int nout);
 int launch_conv3_img(cpp_ctx* ctx, const struct ConvArgsN& batch);
 int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, const ConvArgs* list, int n,
                          float* const* grad_w, float* const* grad_b);

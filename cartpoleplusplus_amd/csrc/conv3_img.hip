@@ -5,14 +5,7 @@
 //   wave = (image, upper / lower half); per pair of rows y, y + 1: 23 k-steps of v_mfma_f32_16x16x4_f32 on two independent
 //   accumulators (M = the 16 pixels of a row, N = filters, k = (ky, kx, c) in steps of 4), B operands (the weights) held in
 //   registers for the whole kernel, A operands one ds_read_b32 per step from the zero-haloed image.
-#include "common.h"
-
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-
-constexpr int C3_H = 16, C3_C = 10, C3_NO = 10, C3_KS = 3, C3_K = C3_KS * C3_KS * C3_C;      // 90
-constexpr int C3_STEPS = (C3_K + 3) / 4;                                                      // 23
-constexpr int C3_PW = C3_H + 2, C3_IMGF = C3_PW * C3_PW * C3_C;                               // padded image: 3240 floats
-constexpr int C3_IPW = 2;                                                                     // images per workgroup
+#include "conv3_img.h"
 
 __global__ __launch_bounds__(256) void conv3_img_kernel(const ConvArgsN batch) {
   const ConvArgs& a = batch.a[blockIdx.y];
@@ -36,19 +29,8 @@ __global__ __launch_bounds__(256) void conv3_img_kernel(const ConvArgsN batch) {
     iv[n] = (u32x4){0u, 0u, 0u, 0u};
     if (ch < NV && im < nimg) iv[n] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)((long)im * a.in_bstride * 4) + j * 16, 0, 0);
   }
-  float bw[C3_STEPS];                                          // B operands: W[k = 4 st + lj][o = li]
-  int offk[C3_STEPS];                                          // float offset of k's tap (ky, kx, c) from the window's corner
-#pragma unroll
-  for (int st = 0; st < C3_STEPS; ++st) {
-    const int k = 4 * st + lj;
-    const bool ok = k < C3_K && li < a.nout;
-    bw[st] = a.w[ok ? k * a.nout + li : 0];
-    if (!ok) bw[st] = 0.f;
-    const int kc = k < C3_K ? k : 0;
-    const int ky = kc / (C3_KS * C3_C), r = kc - ky * (C3_KS * C3_C);
-    offk[st] = (ky * C3_PW) * C3_C + r;                        // (kx, c) are contiguous in a padded row
-  }
-  const float bias = li < a.nout ? a.bias[li] : 0.f;
+  Conv3Ops ops;
+  conv3_load_ops(ops, a.w, a.bias, a.nout, li, lj);
 
   // ---- the padded images: zeros, then the interiors
   for (int i = tid; i < C3_IPW * C3_IMGF / 4; i += 256) reinterpret_cast<float4*>(img)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -69,38 +51,8 @@ __global__ __launch_bounds__(256) void conv3_img_kernel(const ConvArgsN batch) {
   // ---- one wave per half image: four pairs of rows
   const int im = wave >> 1, half = wave & 1;
   if (im >= nimg) return;
-  const float* base = img + im * C3_IMGF + li * C3_C;          // window corner of pixel x = li in padded row 0
-  const int Hp = C3_H / 2;
-  float* out = a.out + (long)(b0 + im) * a.out_bstride;
-  uint8_t* amax = a.out_amax + (long)(b0 + im) * Hp * Hp * a.nout;
-#pragma unroll 1
-  for (int pp = 0; pp < 4; ++pp) {
-    const int py = half * 4 + pp, y = 2 * py;
-    const float* r0 = base + y * C3_PW * C3_C;                 // output row y reads padded rows y .. y + 2
-    f32x4 acc0 = {bias, bias, bias, bias}, acc1 = {bias, bias, bias, bias};
-#pragma unroll
-    for (int st = 0; st < C3_STEPS; ++st) {
-      const float a0 = r0[offk[st]], a1 = r0[offk[st] + C3_PW * C3_C];
-      acc0 = MFMA16(a0, bw[st], acc0);
-      acc1 = MFMA16(a1, bw[st], acc1);
-    }
-    // lane (filter li, pixels 4 lj .. 4 lj + 3) of rows y (acc0) and y + 1 (acc1): the two pooled pixels 2 lj, 2 lj + 1.
-    // Same selection rules as the row kernels: the later candidate wins only when strictly greater.
-    if (li < a.nout) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const float t0 = acc0[2 * h], t1 = acc0[2 * h + 1], u0 = acc1[2 * h], u1 = acc1[2 * h + 1];
-        const float top = t1 > t0 ? t1 : t0, bot = u1 > u0 ? u1 : u0;
-        const int ct = t1 > t0 ? 1 : 0, cb = u1 > u0 ? 1 : 0;
-        const bool lower = bot > top;
-        const float mx = lower ? bot : top;
-        const int code = lower ? 2 + cb : ct;
-        const int px = 2 * lj + h;
-        out[(py * Hp + px) * a.nout + li] = mx > 0.f ? mx : 0.f;
-        amax[(py * Hp + px) * a.nout + li] = (uint8_t)code;
-      }
-    }
-  }
+  conv3_img_half(ops, img + im * C3_IMGF, half, a.out + (long)(b0 + im) * a.out_bstride,
+                 a.out_amax + (long)(b0 + im) * (C3_H / 2) * (C3_H / 2) * a.nout, a.nout, li, lj);
 }
 
 // CPP_CONV3_IMG=0 keeps the row-streaming kernel

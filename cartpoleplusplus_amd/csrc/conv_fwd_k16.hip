@@ -37,3 +37,10 @@ int conv_fwd_kb16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const Con
   KB16_CASE(1, 2) KB16_CASE(1, 4) KB16_CASE(2, 2)
   return 0;
 }
+
+// conv2 forward of 32x32x10 inputs (two images x two 16-pixel strips per workgroup) can run conv3 + pool3 as its tail
+bool conv23_fuse_ok(int H2, int W2, int B, int nout) {
+  static const bool off = cpp_switch_off("CPP_CONV23_FUSE") || cpp_switch_off("CPP_CONV3_IMG") || cpp_switch_off("CPP_CONV_B16") ||
+                          cpp_switch_off("CPP_CONV_K16") || cpp_switch_off("CPP_CONV_KYO");
+  return !off && H2 == 2 * C3_H && W2 == 2 * C3_H && (B % 2) == 0 && nout == KYO_NO;
+}

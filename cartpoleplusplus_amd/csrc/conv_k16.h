@@ -29,6 +29,7 @@
 // waves' border tiles apply; reads may touch up to 128 bytes before and 256 after an image (the arena pads).
 #pragma once
 #include "conv_kyo.h"
+#include "conv3_img.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 k16_bf16x8 __attribute__((ext_vector_type(8)));
@@ -94,7 +95,9 @@ struct K16Geom {
 #endif
   static constexpr int WLB = NCH * NPC * SLAB;             // bytes
   static constexpr int EF = 2 * 8 * XT * NO * 2;           // floats per wave: (value, code) of the two rows of a pool pair
-  static constexpr int LDS_BYTES = WLB + 4 * EF * 4 + 64;
+  // conv2's instance for 32x32 inputs can run conv3 as its tail: the two pooled 16x16 images of the workgroup, zero-haloed
+  static constexpr int N3 = (B16 && XT == 1 && IPW == 2) ? C3_IPW * C3_IMGF * 4 + 16 : 0;
+  static constexpr int LDS_BYTES = WLB + 4 * EF * 4 + 64 + N3;
   static constexpr int BIAS_BYTES = 128;                   // the buffer descriptor starts this far before the image
   // element e of lane group g in chunk ch is k = 32 ch + 8 g + e
   static __host__ __device__ constexpr bool vgpr_may_be_synthetic(int ch, int v) {       // any lane group: not both real
@@ -133,6 +136,10 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   unsigned char* wl = lds_raw;                                    // weight image
   float2* ebuf = reinterpret_cast<float2*>(lds_raw + G::WLB);     // [4 waves][2 parities][8*XT][NO]
   float* red = reinterpret_cast<float*>(lds_raw + G::WLB + 4 * G::EF * 4);
+  float* img3 = reinterpret_cast<float*>(lds_raw + G::WLB + 4 * G::EF * 4 + 64);      // (G::N3 > 0 only)
+  const bool fuse3 = G::N3 > 0 && a.n3_w != nullptr;                                  // uniform; the launcher checked the geometry
+  if (fuse3)
+    for (int i = threadIdx.x; i < C3_IPW * C3_IMGF / 4; i += CONV_THREADS) reinterpret_cast<float4*>(img3)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lj = lane >> 4;
   const int strip = wave % G::STRIPS;
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   // ---- pooled-row writer: a lane owns PAIRS (o, o+1) of the wave's 8*XT pooled columns (nout is even: dispatch) -- one
   // 8-byte value store, one 2-byte code store and three 4-byte bf16-plane stores per pair
   constexpr int NC = (8 * XT * (NO / 2) + 63) / 64;
-  uint32_t cadr[NC];
+  uint32_t cadr[NC], c3adr[NC];
   bool cact[NC];
   unsigned coe[NC];
 #pragma unroll
@@ -292,6 +299,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     cact[i] = idx < 8 * XT * hn && px < Wp;
     cadr[i] = keep_in_vgpr(lds_addr(ev + (cact[i] ? xl * NO + o : 0)));
     coe[i] = cact[i] ? (unsigned)(px * nout + o) : 0x3FFFFFFCu;      // inactive lanes: beyond every descriptor's range (x 1, 2, 4)
+    c3adr[i] = lds_addr(cact[i] ? img3 + simg * C3_IMGF + (C3_PW + px + 1) * C3_C + o : img3 + C3_IPW * C3_IMGF);   // (junk pair behind the images)
   }
   constexpr int ST = NC * 5;                          // vector-memory stores of one writer pass (all issued; see k16_issue_b128)
   const __amdgpu_buffer_rsrc_t b16_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -511,6 +519,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
               code[e] = lower ? 2 + __float_as_int(bot[2 * e + 1]) : __float_as_int(top[2 * e + 1]);
               pv[e] = mx > 0.f ? mx * inv : 0.f;
             }
+            if (fuse3) lds_store(c3adr[i], (y >> 1) * (C3_PW * C3_C * 4), (f32x2){pv[0], pv[1]});      // conv3's input row, in LDS
             if (ASYNC_A || wr_f32) __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(pv[0]), __float_as_uint(pv[1])}, out_rsrc, (int)(coe[i] * 4), orow * 4, 0);
             if (ASYNC_A || a.out_b16) {              // the next layer's A operand: three bf16 planes of the same tensor
               // truncating split (cheaper than round-to-nearest in this MFMA-issue-bound loop, equally exact: the pieces are
@@ -535,6 +544,14 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     }
   }
   if (ASYNC_A) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the look-ahead loads behind the last row)
+  if (fuse3) {      // conv3 + pool3 of the workgroup's two images (all four waves are here: the launcher required B % IPW == 0)
+    Conv3Ops ops;
+    conv3_load_ops(ops, a.n3_w, a.n3_bias, nout, li, lj);
+    __syncthreads();
+    const int im3 = wave >> 1;
+    conv3_img_half(ops, img3 + im3 * C3_IMGF, wave & 1, a.n3_out + (long)(b0 + im3) * a.n3_out_bstride,
+                   a.n3_amax + (long)(b0 + im3) * (C3_H / 2) * (C3_H / 2) * nout, nout, li, lj);
+  }
 #ifdef K16_CLOCK_PROBE
   if (lane == 0 && (blockIdx.x % 97) == 5 && blockIdx.y == 1 && wave == 0) {
     const unsigned long long pc1 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();

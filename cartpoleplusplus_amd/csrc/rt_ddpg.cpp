@@ -315,9 +315,20 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b, int phase = 0) {
         // preload and the tail (measured 0.560 -> 0.526 ms per step for the four networks)
         RC(launch_conv_fwd_multi(ctx, kFwdKid[0], a->conv[0].Cin, a->conv[0].ks, mode, EPI_RELU_POOL, cl, 4));
       }
+      // conv2 (bf16 pipes, 32x32 inputs) carries conv3 + pool3 as its tail when the geometry allows: one launch less
+      bool fuse23 = conv23_fuse_ok(a->conv[1].H, a->conv[1].W, B, kConvOut);
+      for (int k = 0; k < 4; ++k) fuse23 = fuse23 && nets[k]->use_b16;
       for (int i = 1; i < 3; ++i) {
+        if (i == 2 && fuse23) break;
         ConvArgs cl[4]; int mode = 0;
-        for (int k = 0; k < 4; ++k) cl[k] = conv_fwd_args(nets[k], nets[k]->ws[0], i, sts[k], dt, whs[k], B, &mode);
+        for (int k = 0; k < 4; ++k) {
+          cl[k] = conv_fwd_args(nets[k], nets[k]->ws[0], i, sts[k], dt, whs[k], B, &mode);
+          if (i == 1 && fuse23) {
+            int m3 = 0;
+            const ConvArgs c3 = conv_fwd_args(nets[k], nets[k]->ws[0], 2, sts[k], dt, whs[k], B, &m3);
+            cl[k].n3_w = c3.w; cl[k].n3_bias = c3.bias; cl[k].n3_out = c3.out; cl[k].n3_out_bstride = c3.out_bstride; cl[k].n3_amax = c3.out_amax;
+          }
+        }
         RC(launch_conv_fwd_multi(ctx, kFwdKid[i], a->conv[i].Cin, a->conv[i].ks, mode, EPI_RELU_POOL, cl, 4));
       }
       return (int)CPP_OK; }, {});
