@@ -546,7 +546,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   if (ASYNC_A) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the look-ahead loads behind the last row)
   if (fuse3) {      // conv3 + pool3 of the workgroup's two images (all four waves are here: the launcher required B % IPW == 0)
     Conv3Ops ops;
-    conv3_load_ops(ops, a.n3_w, a.n3_bias, nout, li, lj);
+    conv3_load_ops(ops, a.n3_w, a.n3_bias, nout, li, lj);      // (requested here: carried through the row loop they would cost 24 VGPRs)
     __syncthreads();
     const int im3 = wave >> 1;
     conv3_img_half(ops, img3 + im3 * C3_IMGF, wave & 1, a.n3_out + (long)(b0 + im3) * a.n3_out_bstride,

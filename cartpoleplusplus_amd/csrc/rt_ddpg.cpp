@@ -327,6 +327,7 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b, int phase = 0) {
             int m3 = 0;
             const ConvArgs c3 = conv_fwd_args(nets[k], nets[k]->ws[0], 2, sts[k], dt, whs[k], B, &m3);
             cl[k].n3_w = c3.w; cl[k].n3_bias = c3.bias; cl[k].n3_out = c3.out; cl[k].n3_out_bstride = c3.out_bstride; cl[k].n3_amax = c3.out_amax;
+            if (k >= 2) { cl[k].out = nullptr; cl[k].out_amax = nullptr; }      // targets: pool2 only feeds conv3, which reads it from LDS
           }
         }
         RC(launch_conv_fwd_multi(ctx, kFwdKid[i], a->conv[i].Cin, a->conv[i].ks, mode, EPI_RELU_POOL, cl, 4));
