@@ -158,6 +158,9 @@ def main():
     ap.add_argument("--use-batch-norm", action="store_true", help="informational: the networks of exps/run_8x / run_9x (--use-batch-norm)")
     ap.add_argument("--replay-store", default="f16", choices=["f16", "u8"],
                     help="informational: u8 = the 8-bit replay store (same batches, half the gather reads)")
+    ap.add_argument("--diag-states", default="random", choices=["random", "blocks", "flat"],
+                    help="diagnostic only (never the benchmark): overwrite the synthetic U{0..255} pixels with 8x8 constant blocks / one grey level "
+                         "to see how much of a kernel's time is the chip's clock under operand toggling")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel learner path (RCCL all-reduce) even at world size 1")
     ap.add_argument("--overlap", action="store_true", help="data-parallel: reduce the fully connected layers' gradients beside the conv backward")
     ap.add_argument("--sync-every", type=int, default=1, help="data-parallel: k local minibatches between parameter averagings (1: gradient all-reduce per minibatch)")
@@ -213,6 +216,20 @@ def main():
     agent.initialise_variables(seed=42)                 # identical replicas on every rank
     agent.post_var_init_setup()
     agent.replay_memory.fill_synthetic(replay_rows, seed=1234 + rank)   # own replay shard per learner
+    if args.diag_states != "random":
+        import ctypes as C_
+        rm = agent.replay_memory
+        H_, W_, ch_ = shape[0], shape[1], int(np.prod(shape[2:]))
+        yy, xx, cc = np.meshgrid(np.arange(H_), np.arange(W_), np.arange(ch_), indexing="ij")
+        used = replay_rows + replay_rows // 50 + 1
+        for s0 in range(0, used, 256):
+            slots = np.arange(s0, min(used, s0 + 256), dtype=np.int32)
+            if args.diag_states == "flat":
+                st = np.full((len(slots), H_ * W_ * ch_), 128, np.uint8)
+            else:
+                st = np.stack([((xx // 8) * 5 + (yy // 8) * 17 + cc * 7 + int(k) * 3) % 256 for k in slots]).astype(np.uint8).reshape(len(slots), -1)
+            _lib.check(_lib.lib.cpp_replay_write_states(rm.handle, slots.ctypes.data_as(C_.c_void_p), len(slots), st.ctypes.data_as(C_.c_void_p), _lib.CPP_U8))
+        ctx.sync()
 
     groups, tail = divmod(args.steps, BATCHES_PER_STEP)
     wgroups = max(1, -(-args.warmup // BATCHES_PER_STEP))

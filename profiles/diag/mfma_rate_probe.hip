@@ -1,0 +1,86 @@
+// Cycles per MFMA on one SIMD for the instruction shapes conv_k16.h could use (gfx950), with and without fillers between them.
+//   hipcc --offload-arch=gfx950 -O3 -o cartpoleplusplus_amd/lib/mfma_rate_probe profiles/diag/mfma_rate_probe.hip && cartpoleplusplus_amd/lib/mfma_rate_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// MODE 0: 16x16x32, NACC accumulators round-robin.  MODE 1: 32x32x16, NACC accumulators round-robin.
+// FILL: 0 none; 1: one ds_read_b128 per MFMA16 pair / per MFMA32; 2: + one VALU
+template <int MODE, int NACC, int FILL>
+__global__ __launch_bounds__(512) void probe(float* out, unsigned long long* cyc, int iters) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[32768];
+  for (int i = threadIdx.x; i < 8192; i += blockDim.x) reinterpret_cast<unsigned*>(lds)[i] = 0x3C003C00u;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  f16x8 a = {1, 1, 1, 1, 1, 1, 1, 1};
+  f16x8 b[4];
+  for (int i = 0; i < 4; ++i) b[i] = a;
+  f32x4 acc4[8]; f32x16 acc16[4];
+  for (int i = 0; i < 8; ++i) acc4[i] = (f32x4){0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc16[i][j] = 0.f;
+  unsigned m0 = 0xFFFFFFFFu, v0 = lane;
+  const unsigned ladr = (unsigned)(size_t)lds + lane * 16;
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {       // 16 x (2 MFMA16 | 1 MFMA32) = the same pipe time in both modes
+      if (MODE == 0) {
+        acc4[(2 * s) % NACC] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[s & 3], acc4[(2 * s) % NACC], 0, 0, 0);
+        acc4[(2 * s + 1) % NACC] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[s & 3], acc4[(2 * s + 1) % NACC], 0, 0, 0);
+      } else {
+        acc16[s % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[s & 3], acc16[s % NACC], 0, 0, 0);
+      }
+      if (FILL >= 1) {
+        u32x4 r;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(ladr), "n"(0));
+        b[s & 3] = __builtin_bit_cast(f16x8, r);
+      }
+      if (FILL >= 2) { v0 = (v0 & m0) | 1u; asm volatile("" : "+v"(v0)); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (FILL >= 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  float s = 0.f;
+  for (int i = 0; i < 8; ++i) s += acc4[i][0];
+  for (int i = 0; i < 4; ++i) s += acc16[i][0];
+  if (s == 123.456f || v0 == 0xDEADBEEF) out[0] = s;
+  if (lane == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+template <int MODE, int NACC, int FILL>
+void run(const char* name, int waves_per_simd) {
+  float* out; unsigned long long* cyc;
+  hipMalloc(&out, 4); hipMalloc(&cyc, 8 * 8 * 256);
+  const int iters = 2000, threads = 256 * waves_per_simd;
+  hipLaunchKernelGGL((probe<MODE, NACC, FILL>), dim3(256), dim3(threads), 0, 0, out, cyc, iters);
+  hipDeviceSynchronize();
+  hipLaunchKernelGGL((probe<MODE, NACC, FILL>), dim3(256), dim3(threads), 0, 0, out, cyc, iters);
+  hipDeviceSynchronize();
+  std::vector<unsigned long long> h(threads / 64);
+  hipMemcpy(h.data(), cyc, 8 * h.size(), hipMemcpyDeviceToHost);
+  double mx = 0; for (auto c : h) mx = c > mx ? (double)c : mx;
+  // pipe time per SIMD: waves_per_simd * iters * 16 * 32 cycles at full rate
+  printf("%-44s waves/SIMD %d: %.1f cycles per 32-cycle pipe slot (1 MFMA32 or 2 MFMA16) per SIMD\n", name, waves_per_simd, mx / ((double)iters * 16 * waves_per_simd));
+  hipFree(out); hipFree(cyc);
+}
+
+int main() {
+  for (int w = 1; w <= 2; ++w) {
+    run<0, 8, 0>("16x16x32 f16, 8 acc", w);
+    run<0, 4, 0>("16x16x32 f16, 4 acc", w);
+    run<1, 2, 0>("32x32x16 f16, 2 acc", w);
+    run<1, 4, 0>("32x32x16 f16, 4 acc", w);
+    run<1, 1, 0>("32x32x16 f16, 1 acc (dependent chain)", w);
+    run<0, 8, 1>("16x16x32 f16, 8 acc + ds_read/pair", w);
+    run<0, 8, 2>("16x16x32 f16, 8 acc + ds_read + valu/pair", w);
+    run<1, 2, 1>("32x32x16 f16, 2 acc + ds_read", w);
+    run<1, 2, 2>("32x32x16 f16, 2 acc + ds_read + valu", w);
+    run<1, 4, 2>("32x32x16 f16, 4 acc + ds_read + valu", w);
+  }
+  return 0;
+}
