@@ -222,3 +222,57 @@ def test_checkpoint_resume_restores_the_adam_slots(tmp_path):
         b.close()
     for x, y in zip(want, got):
         assert np.array_equal(x, y)
+
+
+def test_cfg4_B256_graph_replayed_naf_step_against_f64_oracle():
+    """cfg4 at the size the metric is quoted on (64x64x18, B = 256, shared trunk, Momentum as in exps/run_93.sh): the hipGraph REPLAY
+    of the fused NAF step (naf_cartpole.py:365-373) on rows drawn by the device's sampler against oracle.NAF(float64) started from the
+    same parameters and Momentum slots: loss at 1e-5, the pre-clip gradient list per variable at 2e-5 (the trunk's two
+    discontinuities -- pool route, ReLU -- taken from the device and accepted only at rounding-level ties), the clipped Momentum
+    update and the target update."""
+    import ctypes
+    from cartpoleplusplus_amd import _lib
+    from tests.helpers import (device_pool_codes, device_relu_active, pool_flips_are_near_ties, relu_flips_are_at_the_boundary)
+    shape, B, rows = (64, 64, 3, 2, 3), 256, 700
+    oargs = {"learning_rate": 0.01, "momentum": 0.9}
+    agent, _ref, specs = make_naf(shape, B, True, "Momentum", oargs, seed=4, replay_size=rows + 50)
+    try:
+        rm = agent.replay_memory
+        rm.fill_synthetic(rows, seed=33)
+        agent.train_step(B, 1)                                    # eager pass + capture (also fills the Momentum slots)
+        nets = (agent.value_net, agent.naf.mu_net, agent.naf.l_net, agent.target_value_net)
+        P = [n.get_params() for n in nets]
+        opt = agent.naf.get_optimiser_state()
+        agent.train_step(B, 1)                                    # hipGraph replay, device-drawn rows
+        idxs = np.empty(B, np.int32)
+        _lib.check(_lib.lib.cpp_replay_last_indexes(rm.handle, B, idxs.ctypes.data_as(ctypes.c_void_p)))
+        assert idxs.min() >= 0 and idxs.max() < rows and len(np.unique(idxs)) > B // 2
+        grads, stats = agent.naf.get_grads(), agent.naf.last_stats()
+        Pn = [n.get_params() for n in nets]
+        codes, relu = device_pool_codes(agent.value_net, B), device_relu_active(agent.value_net, B)
+        s1, s2 = rm.state[rm.state_1_idx[idxs]], rm.state[rm.state_2_idx[idxs]]
+        hb = rm.batch(idxs=idxs)
+        batch = (s1, hb.action, hb.reward, hb.terminal_mask, s2)
+    finally:
+        agent.close()
+    vspec, mspec, lspec = specs
+    ref = N.NAF(vspec, mspec, lspec, P[0], P[1], P[2], True, 2, np.float64, gradient_clip=5.0,
+                optimiser=N.make_optimiser("Momentum", oargs))
+    ref.target_value = O.Net(vspec, P[3], np.float64)
+    ref.m = opt["m"].astype(np.float64)
+    ref.value.amax_override, ref.value.relu_override = codes, relu
+    out = ref.forward_backward(batch)
+    cache = ref.value.forward(s1, white=ref._white(ref.value, s1), training=True)
+    flips = pool_flips_are_near_ties(cache, codes, what="value trunk")
+    rflips = relu_flips_are_at_the_boundary(cache, relu, what="value trunk")
+    assert abs(stats[0] - out["loss"]) < ATOL * max(1.0, abs(out["loss"])) and stats[2] == 0, (stats, out["loss"])
+    cat = CatSpec(specs)
+    assert_flat_close(cat, grads, out["grads"], rel=2e-5, what="NAF pre-clip grads vs f64 oracle (flips %d / %d)" % (flips, rflips))
+    before = ref.flat()
+    ref.apply(out["grads"])
+    ref.update_targets()
+    got = np.concatenate(Pn[:3])
+    assert_flat_close(cat, got, ref.flat(), rel=2e-6, what="NAF params after the step")
+    assert_flat_close(vspec, Pn[3], ref.target_value.flat(), rel=1e-6, what="target value net")
+    d_got, d_want = got.astype(np.float64) - before, ref.flat() - before
+    assert np.linalg.norm(d_got - d_want) < 2.0 ** -23 * np.linalg.norm(before) + 5e-5 * np.linalg.norm(d_want)
