@@ -5,7 +5,10 @@
 A "step" is one minibatch update of the hot path: fused sample + gather of B transitions from the
 HBM-resident replay memory, actor update, critic update (4 conv-trunk forwards, 2 backwards), global-norm
 clip + SGD for both nets, with both target soft updates after every 5th minibatch
-(ddpg_cartpole.py:331-337).  Inputs are resident in HBM when the timed region starts.
+(ddpg_cartpole.py:331-337).  Inputs are resident in HBM when the timed region starts.  The timed region is exactly --steps
+minibatches; in front of it run --warmup untimed ones and as many more as it takes to reach 200 (`warmup_steps_run` in the
+JSON line): the chip's clock needs tens of milliseconds of load to settle, and a 20-step region started 10 steps after idle
+reports the ramp, not the rate (measured 3-7 % low).
 
 Prints ONE JSON line (rank 0).  Besides the contract keys it carries
   roofline       : the dominant kernel (conv1 forward) against the matrix-pipe peak of the instruction it issues, launch
@@ -44,6 +47,7 @@ WORKLOADS = {
 REPLAY_ROWS_BY = {"cfg5": 6000}          # 9000 state slots x 983 KB = 8.8 GB (--replay-rows overrides; 125 000 rows = one GPU's shard of configs[4])
 BATCHES_PER_STEP = 5                     # --batches-per-step default (ddpg_cartpole.py:30)
 REPLAY_ROWS = 22000                      # --replay-memory-size default (ddpg_cartpole.py:46)
+SETTLE_STEPS = 200                       # untimed minibatches in front of the timed region, at least (see main)
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_F16_MFMA_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak
 CONV_DEFS = ((5, 10), (5, 10), (3, 10))
@@ -263,6 +267,13 @@ def main():
     # warm-up (also captures the hipGraphs for both call shapes)
     run(wgroups, tail)
     run(1, tail)
+    # ... and the chip's clock / power state: it takes tens of milliseconds of load to settle (measured, K = 20: 0.435-0.454 ms per
+    # step when the timed region starts 10 minibatches after idle, 0.423 after 200 -- the steady state a 200-step region reports
+    # whatever its warm-up).  So at least SETTLE_STEPS untimed minibatches precede the timed region whatever --warmup says (the same
+    # number on every rank: the data-parallel step is collective); the JSON line says how many were run.
+    settle_groups = max(0, SETTLE_STEPS // BATCHES_PER_STEP - wgroups - 1)
+    run(settle_groups, 0)
+    warmup_steps_run = (wgroups + 1 + settle_groups) * BATCHES_PER_STEP + 2 * tail
     full_sync()
     t0 = time.perf_counter()
     run(groups, tail)
@@ -361,7 +372,7 @@ def main():
         "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": wgroups * BATCHES_PER_STEP,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "timed_region_ms": round(1e3 * elapsed, 2),
+        "timed_region_ms": round(1e3 * elapsed, 2), "warmup_steps_run": warmup_steps_run,
         "dtype_note": "f32 accumulation everywhere; conv1 multiplies exact f16 operands (the replay store's pixels x three-piece f16 "
                       "splits of the f32 weights / gradients), conv2 forward / dW three-piece bf16 splits of both f32 operands with all "
                       "nine products: every product exact, results within f32 rounding of the f32-MFMA kernels (DESIGN.md 4, 6; see `control`)",
