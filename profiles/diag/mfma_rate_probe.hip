@@ -1,4 +1,5 @@
-// Cycles per MFMA on one SIMD for the instruction shapes conv_k16.h could use (gfx950), with and without fillers between them.
+// Cycles per MFMA on one SIMD for the instruction shapes conv_k16.h could use (gfx950), with and without fillers between them,
+// with constant and with pseudo-random operands (the chip clocks to its power budget: operands that toggle cost clock).
 //   hipcc --offload-arch=gfx950 -O3 -o cartpoleplusplus_amd/lib/mfma_rate_probe profiles/diag/mfma_rate_probe.hip && cartpoleplusplus_amd/lib/mfma_rate_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -10,7 +11,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // MODE 0: 16x16x32, NACC accumulators round-robin.  MODE 1: 32x32x16, NACC accumulators round-robin.
 // FILL: 0 none; 1: one ds_read_b128 per MFMA16 pair / per MFMA32; 2: + one VALU
-template <int MODE, int NACC, int FILL>
+template <int MODE, int NACC, int FILL, int RANDOM = 0>
 __global__ __launch_bounds__(512) void probe(float* out, unsigned long long* cyc, int iters) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[32768];
   for (int i = threadIdx.x; i < 8192; i += blockDim.x) reinterpret_cast<unsigned*>(lds)[i] = 0x3C003C00u;
@@ -19,11 +20,18 @@ __global__ __launch_bounds__(512) void probe(float* out, unsigned long long* cyc
   f16x8 a = {1, 1, 1, 1, 1, 1, 1, 1};
   f16x8 b[4];
   for (int i = 0; i < 4; ++i) b[i] = a;
+  if (RANDOM) {      // operands that toggle like real data: pseudo-random f16 in (-2, 2), different in every lane and register
+    unsigned h = (blockIdx.x * 977u + threadIdx.x) * 2654435761u + 12345u;
+    auto rnd = [&]() { h = h * 1664525u + 1013904223u; return (_Float16)(((int)(h >> 16) % 4096 - 2048) / 1024.0f); };
+    for (int e = 0; e < 8; ++e) a[e] = rnd();
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 8; ++e) b[i][e] = rnd();
+  }
   f32x4 acc4[8]; f32x16 acc16[4];
   for (int i = 0; i < 8; ++i) acc4[i] = (f32x4){0, 0, 0, 0};
   for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc16[i][j] = 0.f;
   unsigned m0 = 0xFFFFFFFFu, v0 = lane;
   const unsigned ladr = (unsigned)(size_t)lds + lane * 16;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
   const unsigned long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -45,27 +53,38 @@ __global__ __launch_bounds__(512) void probe(float* out, unsigned long long* cyc
     if (FILL >= 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   const unsigned long long t1 = __builtin_readcyclecounter();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
   float s = 0.f;
   for (int i = 0; i < 8; ++i) s += acc4[i][0];
   for (int i = 0; i < 4; ++i) s += acc16[i][0];
   if (s == 123.456f || v0 == 0xDEADBEEF) out[0] = s;
   if (lane == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+  if (threadIdx.x == 0 && blockIdx.x == 7) { cyc[8 * 256] = r1 - r0; cyc[8 * 256 + 1] = t1 - t0; }
 }
 
-template <int MODE, int NACC, int FILL>
+template <int MODE, int NACC, int FILL, int RANDOM = 0>
 void run(const char* name, int waves_per_simd) {
   float* out; unsigned long long* cyc;
-  hipMalloc(&out, 4); hipMalloc(&cyc, 8 * 8 * 256);
-  const int iters = 2000, threads = 256 * waves_per_simd;
-  hipLaunchKernelGGL((probe<MODE, NACC, FILL>), dim3(256), dim3(threads), 0, 0, out, cyc, iters);
+  hipMalloc(&out, 4); hipMalloc(&cyc, 8 * 8 * 256 + 16);
+  const int iters = 20000, threads = 256 * waves_per_simd;
+  hipLaunchKernelGGL((probe<MODE, NACC, FILL, RANDOM>), dim3(256), dim3(threads), 0, 0, out, cyc, iters);
   hipDeviceSynchronize();
-  hipLaunchKernelGGL((probe<MODE, NACC, FILL>), dim3(256), dim3(threads), 0, 0, out, cyc, iters);
+  hipLaunchKernelGGL((probe<MODE, NACC, FILL, RANDOM>), dim3(256), dim3(threads), 0, 0, out, cyc, iters);
   hipDeviceSynchronize();
   std::vector<unsigned long long> h(threads / 64);
   hipMemcpy(h.data(), cyc, 8 * h.size(), hipMemcpyDeviceToHost);
   double mx = 0; for (auto c : h) mx = c > mx ? (double)c : mx;
+  unsigned long long tc[2] = {0, 0}; hipMemcpy(tc, cyc + 8 * 256, 16, hipMemcpyDeviceToHost);
+  const unsigned long long ticks = tc[0];
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0, 0);
+  hipLaunchKernelGGL((probe<MODE, NACC, FILL, RANDOM>), dim3(256), dim3(threads), 0, 0, out, cyc, iters);
+  hipEventRecord(e1, 0); hipEventSynchronize(e1);
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1);
   // pipe time per SIMD: waves_per_simd * iters * 16 * 32 cycles at full rate
-  printf("%-44s waves/SIMD %d: %.1f cycles per 32-cycle pipe slot (1 MFMA32 or 2 MFMA16) per SIMD\n", name, waves_per_simd, mx / ((double)iters * 16 * waves_per_simd));
+  const double slots = (double)iters * 16 * waves_per_simd;
+  printf("%-52s waves/SIMD %d: %.1f counter cycles per 32-cycle pipe slot; shader clock (one wave: cycle counter / 100 MHz counter) %.2f GHz; wall %.3f ms = %.2f ns per slot = %.0f TFLOP/s\n",
+         name, waves_per_simd, mx / slots, ticks ? (double)tc[1] / (10.0 * (double)ticks) : 0.0, ms, 1e6 * ms / slots, 1024.0 * slots * 32768.0 / (ms * 1e-3) / 1e12);
   hipFree(out); hipFree(cyc);
 }
 
@@ -81,6 +100,9 @@ int main() {
     run<1, 2, 1>("32x32x16 f16, 2 acc + ds_read", w);
     run<1, 2, 2>("32x32x16 f16, 2 acc + ds_read + valu", w);
     run<1, 4, 2>("32x32x16 f16, 4 acc + ds_read + valu", w);
+    run<0, 8, 0, 1>("16x16x32 f16, 8 acc, RANDOM operands", w);
+    run<1, 2, 0, 1>("32x32x16 f16, 2 acc, RANDOM operands", w);
+    run<0, 8, 2, 1>("16x16x32 f16, 8 acc + ds_read + valu, RANDOM", w);
   }
   return 0;
 }
