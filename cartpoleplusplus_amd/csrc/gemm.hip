@@ -14,20 +14,19 @@
 // A(m,k) = A[m*sAm + k*sAk], B(k,n) = B[k*sBk + n*sBn]: the strides express the transposes of the
 // backward passes (dX = dz W^T, dW = x^T dz) without materialising them.
 #ifndef GEMM_R
-#define GEMM_R 1      // rounds of a wave whose loads are in flight together.  Measured (six MLP levels of a step): 1 -> 0.0440 ms, 2 -> 0.0439, 4 -> 0.0457 (120 VGPRs), 6 -> 0.0525 (168), 11 -> 0.1112 (290: one workgroup per CU): the levels are bound by the operand traffic through L1 / the texture path, not by a chain of round trips
+#define GEMM_R 1      // rounds of a wave whose loads are in flight together.  Measured (six MLP levels of a step, round 1's branchy loads): 1 -> 0.0440 ms, 2 -> 0.0439, 4 -> 0.0457 (120 VGPRs), 6 -> 0.0525 (168), 11 -> 0.1112 (290: one workgroup per CU); with the branch-free loads below (four levels): 1 -> 0.0431, 2 -> 0.0430, 3 -> 0.0437, 5 -> 0.0452 (previous loads on the same box: 0.0441) -- the levels are not a chain of round trips
 #endif
 #ifndef GEMM_U
 #define GEMM_U 4      // k values per wave and round = 4 U (sweep 4 / 8 / 12 / 16 with 16-byte loads: 0.057 / 0.058 / 0.064 / 0.064 ms for the six MLP levels)
 #endif
-__device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, float (*red)[256]) {
+template <bool VA, bool VB>
+__device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (*red)[256]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lj = lane >> 4;
   const int tiles_n = (g.N + 15) >> 4;
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int m = tm * 16 + li, n = tn * 16 + li;
   const bool mv = m < g.M, nv = n < g.N;
-  const float* ap = g.A + (long)m * g.sAm;
-  const float* bp = g.B + (long)n * g.sBn;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   constexpr int U = GEMM_U;
   // k order inside a round of 4 U values: lane group lj takes k0 + U lj + u (u = MFMA step), so an operand that is contiguous
@@ -35,42 +34,55 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, float (*r
   // a quarter of the load instructions and of the cache lines the texture path walks (the rounds are bound by that walk:
   // in-kernel probe, 1.6-2.4 us per round with 4-byte loads).  Any k order works as long as A and B agree.
   static_assert(U % 4 == 0, "whole float4s per lane");
-  typedef float gemm_f4 __attribute__((ext_vector_type(4), aligned(4)));
-  const bool va = g.sAk == 1, vb = g.sBk == 1;       // uniform
+  constexpr bool va = VA, vb = VB;                   // (compile-time: one straight-line loop body per combination; gemm_tile below)
+  // No branch around any load: an operand is read through a buffer descriptor that ends with its last element, and an
+  // element outside the matrix (row >= M, column >= N, k >= K) is requested at an offset behind that end -- it comes back as
+  // zero.  (With `in range ? load : 0` every load sat in a basic block of its own and the zero of the other path had to wait
+  // for the load before it could overwrite the register: two dependent round trips per round, and GEMM_R > 1 could not put a
+  // second round in flight.)  A 16-byte load that straddles k = K is in range as a whole; its tail is cleared by selects.
+  typedef unsigned gemm_u4 __attribute__((ext_vector_type(4)));
+  constexpr int OOB = 0x7FFFFF00;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g.A), 0, (int)((((long)(g.M - 1) * g.sAm + (long)(g.K - 1) * g.sAk) + 1) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g.B), 0, (int)((((long)(g.K - 1) * g.sBk + (long)(g.N - 1) * g.sBn) + 1) * 4), 0x00020000);
+  const int abase = (int)((long)m * g.sAm * 4), bbase = (int)((long)n * g.sBn * 4);
+  const int ask = (int)(g.sAk * 4), bsk = (int)(g.sBk * 4);
   // A wave's rounds are independent until the MFMAs: ALL operand loads of up to GEMM_R rounds are issued before the first
-  // one is used (one round trip to L2 per GEMM_R rounds instead of one per round: the K = 641 layers were ten dependent round
-  // trips of ~1 us each -- the "fixed cost per level" of the MLP heads).  Same k order, same summation order as the plain loop.
+  // one is used (one round trip per GEMM_R rounds instead of one per round).  Same k order, same summation order as a plain loop.
   constexpr int R = GEMM_R;
   for (int kr = wave * 4 * U; kr < g.K; kr += R * 4 * 4 * U) {
-    float av[R][U], bv[R][U];
+    gemm_u4 av[R][U / 4], bv[R][U / 4];              // (16-byte register tuples on both paths: no copies behind the loads)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int k0 = kr + r * 4 * 4 * U;
-      const int kb = k0 + U * lj;
+      const int kb = kr + r * 4 * 4 * U + U * lj;
 #pragma unroll
       for (int q = 0; q < U / 4; ++q) {
         const int k = kb + 4 * q;
-        if (va && mv && k + 3 < g.K) {
-          const gemm_f4 v = *reinterpret_cast<const gemm_f4*>(ap + k);
-          av[r][4 * q] = v[0]; av[r][4 * q + 1] = v[1]; av[r][4 * q + 2] = v[2]; av[r][4 * q + 3] = v[3];
-        } else {
+        if (va) av[r][q] = __builtin_amdgcn_raw_buffer_load_b128(ra, (mv & (k < g.K)) ? abase + k * 4 : OOB, 0, 0);
+        else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) av[r][4 * q + e] = (mv && k + e < g.K) ? ap[(long)(k + e) * g.sAk] : 0.f;
+          for (int e = 0; e < 4; ++e) av[r][q][e] = __builtin_amdgcn_raw_buffer_load_b32(ra, (mv & (k + e < g.K)) ? abase + (k + e) * ask : OOB, 0, 0);
         }
-        if (vb && nv && k + 3 < g.K) {
-          const gemm_f4 v = *reinterpret_cast<const gemm_f4*>(bp + k);
-          bv[r][4 * q] = v[0]; bv[r][4 * q + 1] = v[1]; bv[r][4 * q + 2] = v[2]; bv[r][4 * q + 3] = v[3];
-        } else {
+        if (vb) bv[r][q] = __builtin_amdgcn_raw_buffer_load_b128(rb, (nv & (k < g.K)) ? bbase + k * 4 : OOB, 0, 0);
+        else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) bv[r][4 * q + e] = (nv && k + e < g.K) ? bp[(long)(k + e) * g.sBk] : 0.f;
+          for (int e = 0; e < 4; ++e) bv[r][q][e] = __builtin_amdgcn_raw_buffer_load_b32(rb, (nv & (k + e < g.K)) ? bbase + (k + e) * bsk : OOB, 0, 0);
         }
       }
     }
+    __builtin_amdgcn_sched_barrier(0);               // (the scheduler would pull the selects below up to their loads)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if (kr + r * 4 * 4 * U < g.K) {                  // (uniform; rounds past K hold zeros anyway)
+        const int kb = kr + r * 4 * 4 * U + U * lj;
 #pragma unroll
-        for (int u = 0; u < U; ++u) acc = MFMA16(av[r][u], bv[r][u], acc);
+        for (int u = 0; u < U; ++u) {
+          // (behind ALL loads of the group: a select placed next to its load would wait for it before the next load is issued)
+          const float x = (va && kb + u >= g.K) ? 0.f : __uint_as_float(av[r][u >> 2][u & 3]);
+          const float y = (vb && kb + u >= g.K) ? 0.f : __uint_as_float(bv[r][u >> 2][u & 3]);
+          acc = MFMA16(x, y, acc);
+        }
       }
     }
   }
@@ -110,6 +122,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, float (*r
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
     if (lane == 0) g.sq_part[tile] = sq;
   }
+}
+
+// an operand that is contiguous in k is read with 16-byte loads (uniform per problem)
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, float (*red)[256]) {
+  const bool va = g.sAk == 1, vb = g.sBk == 1;
+  if (va && vb) gemm_tile_t<true, true>(g, tile, red);
+  else if (va) gemm_tile_t<true, false>(g, tile, red);
+  else if (vb) gemm_tile_t<false, true>(g, tile, red);
+  else gemm_tile_t<false, false>(g, tile, red);
 }
 
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs g) {
