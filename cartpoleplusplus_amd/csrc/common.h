@@ -178,6 +178,12 @@ struct GemmArgs {
 };
 #define GEMM_BATCH_MAX 8
 struct GemmBatch { GemmArgs g[GEMM_BATCH_MAX]; int tile_start[GEMM_BATCH_MAX + 1]; int n; };
+// sub-tiles per workgroup edge (gemm.hip: 2 x 2 tiles of 16 x 16 where K is long enough for operand traffic to bound the level)
+#ifndef GEMM_SUB_MIN_K
+#define GEMM_SUB_MIN_K 100000      // (2 x 2 measured slower: 0.0565 vs 0.0433 ms for the four levels -- a quarter of the workgroups, each four times as long)
+#endif
+static inline __host__ __device__ int gemm_sub(int M, int N, int K) { return (K >= GEMM_SUB_MIN_K && M > 16 && N > 16) ? 2 : 1; }
+static inline int gemm_tiles(int M, int N, int K) { const int e = 16 * gemm_sub(M, N, K); return ((M + e - 1) / e) * ((N + e - 1) / e); }
 int launch_gemm(cpp_ctx* ctx, const GemmArgs& g);
 int launch_gemm_batch(cpp_ctx* ctx, const GemmArgs* list, int n);   // independent GEMMs in one launch
 int launch_copy_cols(cpp_ctx* ctx, float* dst, long ldd, int dcol0, const float* src, long lds_,

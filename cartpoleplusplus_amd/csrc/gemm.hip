@@ -7,6 +7,7 @@
 #include "common.h"
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define GEMM_RED (4 * 256)      // floats per wave in the cross-wave reduction: up to 2 x 2 sub-tiles
 
 // One 4-wave workgroup per 16x16 output tile, K split across the waves in interleaved chunks of 64 (the
 // matrices are tiny and L2 resident, so the kernel is a latency chain: 32 loads in flight per lane and a
@@ -19,55 +20,76 @@
 #ifndef GEMM_U
 #define GEMM_U 4      // k values per wave and round = 4 U (sweep 4 / 8 / 12 / 16 with 16-byte loads: 0.057 / 0.058 / 0.064 / 0.064 ms for the six MLP levels)
 #endif
-template <bool VA, bool VB>
-__device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (*red)[256]) {
+// S x S sub-tiles of 16 x 16 per workgroup (gemm_sub(): always 1 as shipped).  With one tile per workgroup every k value of an
+// operand row is fetched once per tile that needs it: the K = 641 level moves 52 MB through L1 for 2 MB of matrices and runs at
+// 0.87 us per round in every workgroup at once (in-kernel probe, -DGEMM_CLOCK).  2 x 2 sub-tiles share each operand fragment
+// between two MFMAs and halve that traffic -- and are SLOWER (0.0565 vs 0.0433 ms for the four levels; -DGEMM_SUB_MIN_K=256): a
+// quarter of the workgroups, each four times as long, on a chip the 1 x 1 tiling does not fill either.  Kept for the record and for
+// larger problems.  Every output sums its products in the same order in both (same K split over the waves, same k order inside a
+// round): bit-identical results.
+template <bool VA, bool VB, int S>
+__device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (*red)[GEMM_RED]) {
+#ifdef GEMM_CLOCK
+  const unsigned long long c0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lj = lane >> 4;
-  const int tiles_n = (g.N + 15) >> 4;
+  const int tiles_n = (g.N + 16 * S - 1) / (16 * S);
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-  const int m = tm * 16 + li, n = tn * 16 + li;
-  const bool mv = m < g.M, nv = n < g.N;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int mrow[S], ncol[S]; bool mv[S], nv[S];
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    mrow[i] = (tm * S + i) * 16 + li; mv[i] = mrow[i] < g.M;
+    ncol[i] = (tn * S + i) * 16 + li; nv[i] = ncol[i] < g.N;
+  }
+  f32x4 acc[S][S];
+#pragma unroll
+  for (int i = 0; i < S; ++i)
+#pragma unroll
+    for (int j = 0; j < S; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   constexpr int U = GEMM_U;
   // k order inside a round of 4 U values: lane group lj takes k0 + U lj + u (u = MFMA step), so an operand that is contiguous
   // in k (activations / dz in the forward and dX passes: sAk == 1; W^T in dX: sBk == 1) is read with 16-byte loads --
-  // a quarter of the load instructions and of the cache lines the texture path walks (the rounds are bound by that walk:
-  // in-kernel probe, 1.6-2.4 us per round with 4-byte loads).  Any k order works as long as A and B agree.
+  // a quarter of the load instructions and of the cache lines the texture path walks.  Any k order works as long as A and B agree.
   static_assert(U % 4 == 0, "whole float4s per lane");
   constexpr bool va = VA, vb = VB;                   // (compile-time: one straight-line loop body per combination; gemm_tile below)
   // No branch around any load: an operand is read through a buffer descriptor that ends with its last element, and an
   // element outside the matrix (row >= M, column >= N, k >= K) is requested at an offset behind that end -- it comes back as
   // zero.  (With `in range ? load : 0` every load sat in a basic block of its own and the zero of the other path had to wait
-  // for the load before it could overwrite the register: two dependent round trips per round, and GEMM_R > 1 could not put a
-  // second round in flight.)  A 16-byte load that straddles k = K is in range as a whole; its tail is cleared by selects.
+  // for the load before it could overwrite the register: two dependent round trips per round.)  A 16-byte load that straddles
+  // k = K is in range as a whole; its tail is cleared by selects.
   typedef unsigned gemm_u4 __attribute__((ext_vector_type(4)));
   constexpr int OOB = 0x7FFFFF00;
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(g.A), 0, (int)((((long)(g.M - 1) * g.sAm + (long)(g.K - 1) * g.sAk) + 1) * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(g.B), 0, (int)((((long)(g.K - 1) * g.sBk + (long)(g.N - 1) * g.sBn) + 1) * 4), 0x00020000);
-  const int abase = (int)((long)m * g.sAm * 4), bbase = (int)((long)n * g.sBn * 4);
+  int abase[S], bbase[S];
+#pragma unroll
+  for (int i = 0; i < S; ++i) { abase[i] = (int)((long)mrow[i] * g.sAm * 4); bbase[i] = (int)((long)ncol[i] * g.sBn * 4); }
   const int ask = (int)(g.sAk * 4), bsk = (int)(g.sBk * 4);
   // A wave's rounds are independent until the MFMAs: ALL operand loads of up to GEMM_R rounds are issued before the first
-  // one is used (one round trip per GEMM_R rounds instead of one per round).  Same k order, same summation order as a plain loop.
+  // one is used.  Same k order, same summation order as a plain loop.
   constexpr int R = GEMM_R;
   for (int kr = wave * 4 * U; kr < g.K; kr += R * 4 * 4 * U) {
-    gemm_u4 av[R][U / 4], bv[R][U / 4];              // (16-byte register tuples on both paths: no copies behind the loads)
+    gemm_u4 av[R][S][U / 4], bv[R][S][U / 4];        // (16-byte register tuples on both paths: no copies behind the loads)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int kb = kr + r * 4 * 4 * U + U * lj;
 #pragma unroll
+      for (int i = 0; i < S; ++i)
+#pragma unroll
       for (int q = 0; q < U / 4; ++q) {
         const int k = kb + 4 * q;
-        if (va) av[r][q] = __builtin_amdgcn_raw_buffer_load_b128(ra, (mv & (k < g.K)) ? abase + k * 4 : OOB, 0, 0);
+        if (va) av[r][i][q] = __builtin_amdgcn_raw_buffer_load_b128(ra, (mv[i] & (k < g.K)) ? abase[i] + k * 4 : OOB, 0, 0);
         else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) av[r][q][e] = __builtin_amdgcn_raw_buffer_load_b32(ra, (mv & (k + e < g.K)) ? abase + (k + e) * ask : OOB, 0, 0);
+          for (int e = 0; e < 4; ++e) av[r][i][q][e] = __builtin_amdgcn_raw_buffer_load_b32(ra, (mv[i] & (k + e < g.K)) ? abase[i] + (k + e) * ask : OOB, 0, 0);
         }
-        if (vb) bv[r][q] = __builtin_amdgcn_raw_buffer_load_b128(rb, (nv & (k < g.K)) ? bbase + k * 4 : OOB, 0, 0);
+        if (vb) bv[r][i][q] = __builtin_amdgcn_raw_buffer_load_b128(rb, (nv[i] & (k < g.K)) ? bbase[i] + k * 4 : OOB, 0, 0);
         else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) bv[r][q][e] = __builtin_amdgcn_raw_buffer_load_b32(rb, (nv & (k + e < g.K)) ? bbase + (k + e) * bsk : OOB, 0, 0);
+          for (int e = 0; e < 4; ++e) bv[r][i][q][e] = __builtin_amdgcn_raw_buffer_load_b32(rb, (nv[i] & (k + e < g.K)) ? bbase[i] + (k + e) * bsk : OOB, 0, 0);
         }
       }
     }
@@ -79,25 +101,47 @@ __device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           // (behind ALL loads of the group: a select placed next to its load would wait for it before the next load is issued)
-          const float x = (va && kb + u >= g.K) ? 0.f : __uint_as_float(av[r][u >> 2][u & 3]);
-          const float y = (vb && kb + u >= g.K) ? 0.f : __uint_as_float(bv[r][u >> 2][u & 3]);
-          acc = MFMA16(x, y, acc);
+          float x[S], y[S];
+#pragma unroll
+          for (int i = 0; i < S; ++i) {
+            x[i] = (va && kb + u >= g.K) ? 0.f : __uint_as_float(av[r][i][u >> 2][u & 3]);
+            y[i] = (vb && kb + u >= g.K) ? 0.f : __uint_as_float(bv[r][i][u >> 2][u & 3]);
+          }
+#pragma unroll
+          for (int i = 0; i < S; ++i)
+#pragma unroll
+            for (int j = 0; j < S; ++j) acc[i][j] = MFMA16(x[i], y[j], acc[i][j]);
         }
       }
     }
   }
+#ifdef GEMM_CLOCK
+  const unsigned long long c1 = __builtin_amdgcn_s_memrealtime();
+#endif
   if (wave > 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) red[wave - 1][lane * 4 + i] = acc[i];
+    for (int i = 0; i < S; ++i)
+#pragma unroll
+      for (int j = 0; j < S; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave - 1][(i * S + j) * 256 + lane * 4 + e] = acc[i][j][e];
   }
   __syncthreads();
+#ifdef GEMM_CLOCK
+  const unsigned long long c2 = __builtin_amdgcn_s_memrealtime();
+#endif
   if (wave != 0) return;
   double sq = 0.0;
 #pragma unroll
+  for (int ti = 0; ti < S; ++ti)
+#pragma unroll
+  for (int tj = 0; tj < S; ++tj)
+#pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int row = tm * 16 + 4 * lj + i;
-    if (nv && row < g.M) {
-      float v = ((acc[i] + red[0][lane * 4 + i]) + red[1][lane * 4 + i]) + red[2][lane * 4 + i];
+    const int row = (tm * S + ti) * 16 + 4 * lj + i, n = ncol[tj];
+    if (nv[tj] && row < g.M) {
+      const int ri = (ti * S + tj) * 256 + lane * 4 + i;
+      float v = ((acc[ti][tj][i] + red[0][ri]) + red[1][ri]) + red[2][ri];
       if (g.accumulate) v += g.C[(long)row * g.ldc + n];
       if (g.epi == GE_RELU) v = fmaxf(v, 0.f);
       else if (g.epi == GE_TANH) v = tanhf(v);
@@ -118,36 +162,66 @@ __device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (
       else if (g.C2) g.C2[(long)row * g.ldc2 + n] = v;
     }
   }
-  if (g.sq_part) {                                   // (uniform) this tile's share of the gradient list's squared norm, fixed order
+#ifdef GEMM_CLOCK
+  if (lane == 0 && g.K > 600 && (tile % 37) == 5)
+    printf("GEMMCLK M %d N %d K %d tile %d (blk %d): loop %.2f us, reduce+barrier %.2f, epilogue %.2f (start tick %llu)\n", g.M, g.N, g.K, tile, (int)blockIdx.x,
+           (c1 - c0) / 100.0, (c2 - c1) / 100.0, (__builtin_amdgcn_s_memrealtime() - c2) / 100.0, c0 % 100000000ull);
+#endif
+  if (g.sq_part) {                                   // (uniform) this workgroup's share of the gradient list's squared norm, fixed order
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
     if (lane == 0) g.sq_part[tile] = sq;
   }
 }
 
-// an operand that is contiguous in k is read with 16-byte loads (uniform per problem)
-__device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, float (*red)[256]) {
+// an operand that is contiguous in k is read with 16-byte loads; long-K problems take 2 x 2 sub-tiles (uniform per problem)
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, float (*red)[GEMM_RED]) {
   const bool va = g.sAk == 1, vb = g.sBk == 1;
-  if (va && vb) gemm_tile_t<true, true>(g, tile, red);
-  else if (va) gemm_tile_t<true, false>(g, tile, red);
-  else if (vb) gemm_tile_t<false, true>(g, tile, red);
-  else gemm_tile_t<false, false>(g, tile, red);
+  if (gemm_sub(g.M, g.N, g.K) == 2) {
+    if (va && vb) gemm_tile_t<true, true, 2>(g, tile, red);
+    else if (va) gemm_tile_t<true, false, 2>(g, tile, red);
+    else if (vb) gemm_tile_t<false, true, 2>(g, tile, red);
+    else gemm_tile_t<false, false, 2>(g, tile, red);
+    return;
+  }
+  if (va && vb) gemm_tile_t<true, true, 1>(g, tile, red);
+  else if (va) gemm_tile_t<true, false, 1>(g, tile, red);
+  else if (vb) gemm_tile_t<false, true, 1>(g, tile, red);
+  else gemm_tile_t<false, false, 1>(g, tile, red);
+}
+
+// Workgroup -> tile, XCD-aware: workgroup b of a launch runs on XCD b mod 8 (round-robin dispatch), each XCD has its own L2, and
+// both operands were written by earlier kernels, so every XCD fills its L2 with whatever its workgroups touch.  With tile = local
+// index every XCD touches every row of A and every column of B; here the workgroups of one XCD take CONSECUTIVE tiles (row-major
+// over (tm, tn)): an eighth of A's rows and all of B.  `first` = the launch-wide index of the problem's first workgroup.
+// (Measured: 0.0431 vs 0.0439 ms for the four levels -- the fills are not what bounds a level either.)
+#ifndef GEMM_XCD
+#define GEMM_XCD 8
+#endif
+__device__ __forceinline__ int gemm_xcd_tile(int b, int first, int T) {
+  if (GEMM_XCD <= 1) return b - first;
+  const int lb = b - first, x = b % GEMM_XCD;
+  // local workgroups on XCD x: lb = o, o + 8, ... with o = (x - first) mod 8; XCDs are ranked by o so that the ranks' tile ranges tile [0, T)
+  const int o = ((x - first) % GEMM_XCD + GEMM_XCD) % GEMM_XCD;
+  const int j = (lb - o) / GEMM_XCD;                          // this workgroup's position among its XCD's
+  const int q = T / GEMM_XCD, rem = T % GEMM_XCD;             // rank o owns q (+ 1 if o < rem) local workgroups
+  return o * q + (o < rem ? o : rem) + j;
 }
 
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs g) {
-  __shared__ float red[3][256];
-  gemm_tile(g, blockIdx.x, red);
+  __shared__ float red[3][GEMM_RED];
+  gemm_tile(g, gemm_xcd_tile(blockIdx.x, 0, gridDim.x), red);
 }
 
 // several independent GEMMs in one launch: workgroup -> (problem, tile) through a prefix table
 __global__ __launch_bounds__(256) void gemm_batch_kernel(const GemmBatch gb) {
-  __shared__ float red[3][256];
+  __shared__ float red[3][GEMM_RED];
   int p = 0;
   while (p + 1 < gb.n && (int)blockIdx.x >= gb.tile_start[p + 1]) ++p;
-  gemm_tile(gb.g[p], blockIdx.x - gb.tile_start[p], red);
+  gemm_tile(gb.g[p], gemm_xcd_tile(blockIdx.x, gb.tile_start[p], gb.tile_start[p + 1] - gb.tile_start[p]), red);
 }
 
 int launch_gemm(cpp_ctx* ctx, const GemmArgs& g) {
-  const int tiles = ((g.M + 15) / 16) * ((g.N + 15) / 16);
+  const int tiles = gemm_tiles(g.M, g.N, g.K);
   prof_begin(ctx);
   hipLaunchKernelGGL(gemm_mfma_kernel, dim3(tiles), dim3(256), 0, ctx->stream, g);
   LAUNCH_CHECK();
@@ -163,7 +237,7 @@ int launch_gemm_batch(cpp_ctx* ctx, const GemmArgs* list, int n) {
     gb.n = cnt; gb.tile_start[0] = 0;
     for (int i = 0; i < cnt; ++i) {
       gb.g[i] = list[i0 + i];
-      gb.tile_start[i + 1] = gb.tile_start[i] + ((gb.g[i].M + 15) / 16) * ((gb.g[i].N + 15) / 16);
+      gb.tile_start[i + 1] = gb.tile_start[i] + gemm_tiles(gb.g[i].M, gb.g[i].N, gb.g[i].K);
     }
     prof_begin(ctx);
     hipLaunchKernelGGL(gemm_batch_kernel, dim3(gb.tile_start[cnt]), dim3(256), 0, ctx->stream, gb);

@@ -289,7 +289,7 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b, int phase = 0) {
     }
   } sq_scope(ctx, d, phase == 0 && !a->spec.use_batch_norm && !c->spec.use_batch_norm);
   auto sqg = [&](int list, GemmArgs g) {
-    const int tiles = ((g.M + 15) / 16) * ((g.N + 15) / 16);
+    const int tiles = gemm_tiles(g.M, g.N, g.K);
     if (ctx->sq_n[list] >= 0 && ctx->sq_n[list] + tiles <= SQ_REGION) { g.sq_part = ctx->sq_part + list * SQ_REGION + ctx->sq_n[list]; ctx->sq_n[list] += tiles; }
     else ctx->sq_n[list] = -1;
     return g;
