@@ -7,7 +7,11 @@
 #include "common.h"
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-#define GEMM_RED (4 * 256)      // floats per wave in the cross-wave reduction: up to 2 x 2 sub-tiles
+#if GEMM_SUB_MIN_K < 100000
+#define GEMM_RED (4 * 256)      // floats per wave in the cross-wave reduction: 2 x 2 sub-tiles
+#else
+#define GEMM_RED 256
+#endif
 
 // One 4-wave workgroup per 16x16 output tile, K split across the waves in interleaved chunks of 64 (the
 // matrices are tiny and L2 resident, so the kernel is a latency chain: 32 loads in flight per lane and a
@@ -176,6 +180,7 @@ __device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (
 // an operand that is contiguous in k is read with 16-byte loads; long-K problems take 2 x 2 sub-tiles (uniform per problem)
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, float (*red)[GEMM_RED]) {
   const bool va = g.sAk == 1, vb = g.sBk == 1;
+#if GEMM_SUB_MIN_K < 100000      // (not instantiated in the shipped build: gemm_sub() is 1 for every problem)
   if (gemm_sub(g.M, g.N, g.K) == 2) {
     if (va && vb) gemm_tile_t<true, true, 2>(g, tile, red);
     else if (va) gemm_tile_t<true, false, 2>(g, tile, red);
@@ -183,6 +188,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, float (*r
     else gemm_tile_t<false, false, 2>(g, tile, red);
     return;
   }
+#endif
   if (va && vb) gemm_tile_t<true, true, 1>(g, tile, red);
   else if (va) gemm_tile_t<true, false, 1>(g, tile, red);
   else if (vb) gemm_tile_t<false, true, 1>(g, tile, red);
