@@ -34,3 +34,11 @@ def test_cfg5_B512_graph_replayed_fused_step_against_f64_oracle():
     """BASELINE configs[4] at its own batch size: 128x128x30, B = 512 (the oracle pass is ~100 GFLOP of float64 numpy)."""
     rep = fused_step_against_f64_oracle((128, 128, 3, 2, 5), 512, rows=1500, graph=True, seed=4)
     print("cfg5 B=512 fused graph step vs f64 oracle:", rep)
+
+
+def test_reference_default_render_B128_graph_replayed_fused_step_against_f64_oracle():
+    """the reference's OWN default render (bullet_cartpole.py: --render-width / --render-height 50) with 2 cameras x 3 action repeats
+    = 18 channels, at its default batch size (ddpg_cartpole.py:29: 128): rows that are not 16-byte multiples (1800 bytes) and odd pooled sizes (25 -> 12 -> 6,
+    'VALID' drops the last row and column)."""
+    rep = fused_step_against_f64_oracle((50, 50, 3, 2, 3), 128, rows=1500, graph=True, seed=6)
+    print("50x50x18 B=128 fused graph step vs f64 oracle:", rep)
