@@ -36,9 +36,10 @@ def test_cfg5_B512_graph_replayed_fused_step_against_f64_oracle():
     print("cfg5 B=512 fused graph step vs f64 oracle:", rep)
 
 
-def test_reference_default_render_B128_graph_replayed_fused_step_against_f64_oracle():
-    """the reference's OWN default render (bullet_cartpole.py: --render-width / --render-height 50) with 2 cameras x 3 action repeats
-    = 18 channels, at its default batch size (ddpg_cartpole.py:29: 128): rows that are not 16-byte multiples (1800 bytes) and odd pooled sizes (25 -> 12 -> 6,
-    'VALID' drops the last row and column)."""
-    rep = fused_step_against_f64_oracle((50, 50, 3, 2, 3), 128, rows=1500, graph=True, seed=6)
-    print("50x50x18 B=128 fused graph step vs f64 oracle:", rep)
+@pytest.mark.parametrize("shape", [(50, 50, 3, 1, 2), (50, 50, 3, 2, 3)], ids=["50x50x6-all-defaults", "50x50x18"])
+def test_reference_default_render_B128_graph_replayed_fused_step_against_f64_oracle(shape):
+    """the reference's OWN defaults: 50 x 50 render (bullet_cartpole.py:33-36), one camera x two action repeats = 6 channels
+    (:21,:25), batch 128 (ddpg_cartpole.py:29) -- and the same render with the 18 channels of the benchmark: rows that are not
+    16-byte multiples and odd pooled sizes (25 -> 12 -> 6: 'VALID' drops the last row and column)."""
+    rep = fused_step_against_f64_oracle(shape, 128, rows=1500, graph=True, seed=6)
+    print("%dx%dx%d B=128 fused graph step vs f64 oracle:" % (shape[0], shape[1], int(np.prod(shape[2:]))), rep)
