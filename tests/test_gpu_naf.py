@@ -224,18 +224,21 @@ def test_checkpoint_resume_restores_the_adam_slots(tmp_path):
         assert np.array_equal(x, y)
 
 
-def test_cfg4_B256_graph_replayed_naf_step_against_f64_oracle():
+@pytest.mark.parametrize("shape,B,share", [((64, 64, 3, 2, 3), 256, True), ((50, 50, 3, 1, 2), 128, False)],
+                         ids=["cfg4-64x64x18-B256-shared-trunk", "reference-defaults-50x50x6-B128-own-trunks"])
+def test_cfg4_B256_graph_replayed_naf_step_against_f64_oracle(shape, B, share):
     """cfg4 at the size the metric is quoted on (64x64x18, B = 256, shared trunk, Momentum as in exps/run_93.sh): the hipGraph REPLAY
     of the fused NAF step (naf_cartpole.py:365-373) on rows drawn by the device's sampler against oracle.NAF(float64) started from the
     same parameters and Momentum slots: loss at 1e-5, the pre-clip gradient list per variable at 2e-5 (the trunk's two
     discontinuities -- pool route, ReLU -- taken from the device and accepted only at rounding-level ties), the clipped Momentum
-    update and the target update."""
+    update and the target update.  Second case: the reference's own defaults (50 x 50 x 6 render, batch 128,
+    naf_cartpole.py's three networks on trunks of their own)."""
     import ctypes
     from cartpoleplusplus_amd import _lib
     from tests.helpers import (device_pool_codes, device_relu_active, pool_flips_are_near_ties, relu_flips_are_at_the_boundary)
-    shape, B, rows = (64, 64, 3, 2, 3), 256, 700
+    rows = 700
     oargs = {"learning_rate": 0.01, "momentum": 0.9}
-    agent, _ref, specs = make_naf(shape, B, True, "Momentum", oargs, seed=4, replay_size=rows + 50)
+    agent, _ref, specs = make_naf(shape, B, share, "Momentum", oargs, seed=4, replay_size=rows + 50)
     try:
         rm = agent.replay_memory
         rm.fill_synthetic(rows, seed=33)
@@ -249,22 +252,27 @@ def test_cfg4_B256_graph_replayed_naf_step_against_f64_oracle():
         assert idxs.min() >= 0 and idxs.max() < rows and len(np.unique(idxs)) > B // 2
         grads, stats = agent.naf.get_grads(), agent.naf.last_stats()
         Pn = [n.get_params() for n in nets]
-        codes, relu = device_pool_codes(agent.value_net, B), device_relu_active(agent.value_net, B)
+        trunks = [agent.value_net] if share else [agent.value_net, agent.naf.mu_net, agent.naf.l_net]
+        codes, relu = [device_pool_codes(n, B) for n in trunks], [device_relu_active(n, B) for n in trunks]
         s1, s2 = rm.state[rm.state_1_idx[idxs]], rm.state[rm.state_2_idx[idxs]]
         hb = rm.batch(idxs=idxs)
         batch = (s1, hb.action, hb.reward, hb.terminal_mask, s2)
     finally:
         agent.close()
     vspec, mspec, lspec = specs
-    ref = N.NAF(vspec, mspec, lspec, P[0], P[1], P[2], True, 2, np.float64, gradient_clip=5.0,
+    ref = N.NAF(vspec, mspec, lspec, P[0], P[1], P[2], share, 2, np.float64, gradient_clip=5.0,
                 optimiser=N.make_optimiser("Momentum", oargs))
     ref.target_value = O.Net(vspec, P[3], np.float64)
     ref.m = opt["m"].astype(np.float64)
-    ref.value.amax_override, ref.value.relu_override = codes, relu
+    rnets = [ref.value] if share else [ref.value, ref.mu, ref.l]
+    for net, cd, rl in zip(rnets, codes, relu):
+        net.amax_override, net.relu_override = cd, rl
     out = ref.forward_backward(batch)
-    cache = ref.value.forward(s1, white=ref._white(ref.value, s1), training=True)
-    flips = pool_flips_are_near_ties(cache, codes, what="value trunk")
-    rflips = relu_flips_are_at_the_boundary(cache, relu, what="value trunk")
+    flips = rflips = 0
+    for net, cd, rl, what in zip(rnets, codes, relu, ("value", "mu", "l")):
+        cache = net.forward(s1, white=ref._white(net, s1), training=True)
+        flips += pool_flips_are_near_ties(cache, cd, what=what + " trunk")
+        rflips += relu_flips_are_at_the_boundary(cache, rl, what=what + " trunk")
     assert abs(stats[0] - out["loss"]) < ATOL * max(1.0, abs(out["loss"])) and stats[2] == 0, (stats, out["loss"])
     cat = CatSpec(specs)
     assert_flat_close(cat, grads, out["grads"], rel=2e-5, what="NAF pre-clip grads vs f64 oracle (flips %d / %d)" % (flips, rflips))
