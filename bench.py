@@ -166,6 +166,8 @@ def main():
     ap.add_argument("--diag-states", default="random", choices=["random", "blocks", "flat"],
                     help="diagnostic only (never the benchmark): overwrite the synthetic U{0..255} pixels with 8x8 constant blocks / one grey level "
                          "to see how much of a kernel's time is the chip's clock under operand toggling")
+    ap.add_argument("--diag-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="diagnostic only: torch.distributed backend of an N > 1 run (gloo: several ranks may share one GPU)")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel learner path (RCCL all-reduce) even at world size 1")
     ap.add_argument("--overlap", action="store_true", help="data-parallel: reduce the fully connected layers' gradients beside the conv backward")
     ap.add_argument("--sync-every", type=int, default=1, help="data-parallel: k local minibatches between parameter averagings (1: gradient all-reduce per minibatch)")
@@ -187,13 +189,18 @@ def main():
     replay_rows = args.replay_rows or REPLAY_ROWS_BY.get(args.workload, REPLAY_ROWS)
 
     import torch
+    if args.diag_backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
     use_dp = world > 1 or args.force_dp
     if use_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.diag_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:       # diagnostic: the multi-process harness on a box with fewer GPUs than ranks (the library's RCCL communicator cannot be
+            dist.init_process_group(args.diag_backend, rank=rank, world_size=world)     # created there: the torch fallback learner runs)
 
     from cartpoleplusplus_amd import _lib
 

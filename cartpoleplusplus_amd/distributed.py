@@ -218,8 +218,11 @@ class TorchCollectiveLearner(DataParallelLearner):
         self.world = reducer.world
 
     def describe(self):
-        return ("dp%d: one learner per GPU, half steps behind the C ABI + torch.distributed all_reduce (nccl = RCCL) of the flat "
-                "gradient buffer per minibatch [fallback: the library's own communicator could not be created]" % self.world)
+        import torch.distributed as dist
+        be = dist.get_backend() if dist.is_initialized() else "none"
+        return ("dp%d: one learner per GPU, half steps behind the C ABI + torch.distributed all_reduce (backend %s%s) of the flat "
+                "gradient buffer per minibatch [fallback: the library's own communicator could not be created]"
+                % (self.world, be, " = RCCL" if be == "nccl" else ""))
 
     def close(self):
         pass
