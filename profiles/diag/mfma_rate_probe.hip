@@ -9,7 +9,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// MODE 0: 16x16x32, NACC accumulators round-robin.  MODE 1: 32x32x16, NACC accumulators round-robin.
+// MODE 0: 16x16x32 f16, NACC accumulators round-robin.  MODE 1: 32x32x16 f16.  MODE 2: 16x16x32 bf16.  MODE 3: 16x16x4 f32 (32-cycle MFMAs:
+// one per slot).
 // FILL: 0 none; 1: one ds_read_b128 per MFMA16 pair / per MFMA32; 2: + one VALU
 template <int MODE, int NACC, int FILL, int RANDOM = 0>
 __global__ __launch_bounds__(512) void probe(float* out, unsigned long long* cyc, int iters) {
@@ -39,8 +40,16 @@ __global__ __launch_bounds__(512) void probe(float* out, unsigned long long* cyc
       if (MODE == 0) {
         acc4[(2 * s) % NACC] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[s & 3], acc4[(2 * s) % NACC], 0, 0, 0);
         acc4[(2 * s + 1) % NACC] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[s & 3], acc4[(2 * s + 1) % NACC], 0, 0, 0);
-      } else {
+      } else if (MODE == 1) {
         acc16[s % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[s & 3], acc16[s % NACC], 0, 0, 0);
+      } else if (MODE == 2) {
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        acc4[(2 * s) % NACC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b[s & 3]), acc4[(2 * s) % NACC], 0, 0, 0);
+        acc4[(2 * s + 1) % NACC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b[s & 3]), acc4[(2 * s + 1) % NACC], 0, 0, 0);
+      } else {
+        const float fa = __builtin_bit_cast(float, (unsigned)(__builtin_bit_cast(u32x4, a)[s & 3] & 0xBFFFFFFFu));      // (finite: exponent MSB cleared)
+        const float fb = __builtin_bit_cast(float, (unsigned)(__builtin_bit_cast(u32x4, b[s & 3])[s & 3] & 0xBFFFFFFFu));
+        acc4[s % NACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, acc4[s % NACC], 0, 0, 0);
       }
       if (FILL >= 1) {
         u32x4 r;
@@ -84,7 +93,7 @@ void run(const char* name, int waves_per_simd) {
   // pipe time per SIMD: waves_per_simd * iters * 16 * 32 cycles at full rate
   const double slots = (double)iters * 16 * waves_per_simd;
   printf("%-52s waves/SIMD %d: %.1f counter cycles per 32-cycle pipe slot; shader clock (one wave: cycle counter / 100 MHz counter) %.2f GHz; wall %.3f ms = %.2f ns per slot = %.0f TFLOP/s\n",
-         name, waves_per_simd, mx / slots, ticks ? (double)tc[1] / (10.0 * (double)ticks) : 0.0, ms, 1e6 * ms / slots, 1024.0 * slots * 32768.0 / (ms * 1e-3) / 1e12);
+         name, waves_per_simd, mx / slots, ticks ? (double)tc[1] / (10.0 * (double)ticks) : 0.0, ms, 1e6 * ms / slots, 1024.0 * slots * (MODE == 3 ? 2048.0 : 32768.0) / (ms * 1e-3) / 1e12);
   hipFree(out); hipFree(cyc);
 }
 
@@ -103,6 +112,10 @@ int main() {
     run<0, 8, 0, 1>("16x16x32 f16, 8 acc, RANDOM operands", w);
     run<1, 2, 0, 1>("32x32x16 f16, 2 acc, RANDOM operands", w);
     run<0, 8, 2, 1>("16x16x32 f16, 8 acc + ds_read + valu, RANDOM", w);
+    run<2, 8, 0>("16x16x32 bf16, 8 acc", w);
+    run<2, 8, 0, 1>("16x16x32 bf16, 8 acc, RANDOM operands", w);
+    run<3, 8, 0>("16x16x4 f32, 8 acc", w);
+    run<3, 8, 0, 1>("16x16x4 f32, 8 acc, RANDOM operands", w);
   }
   return 0;
 }
