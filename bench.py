@@ -45,7 +45,7 @@ WORKLOADS = {
     "r50": ((50, 50, 3, 2, 3), 256, "ddpg"),     # the reference's default 50x50 render (exps/run_98.sh: 2 cameras, 3 repeats)
 }
 REPLAY_ROWS_BY = {"cfg5": 6000}          # 9000 state slots x 983 KB = 8.8 GB (--replay-rows overrides; 125 000 rows = one GPU's shard of configs[4])
-BATCHES_PER_STEP = 5                     # --batches-per-step default (ddpg_cartpole.py:30)
+BATCHES_PER_STEP = 5                     # --batches-per-step default (ddpg_cartpole.py:30); main() rebinds it from the flag of the same name
 REPLAY_ROWS = 22000                      # --replay-memory-size default (ddpg_cartpole.py:46)
 SETTLE_STEPS = 200                       # untimed minibatches in front of the timed region, at least (see main)
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: dense f32-input MFMA peak
@@ -151,12 +151,15 @@ def sub_bench(extra_args, env=None, timeout=420):
 
 
 def main():
+    global BATCHES_PER_STEP
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--replay-rows", type=int, default=0, help="rows of the replay shard (default: 22000; cfg5: 6000)")
+    ap.add_argument("--batches-per-step", type=int, default=BATCHES_PER_STEP,
+                    help="minibatches per train-step call = per target soft update (ddpg_cartpole.py:30; 1: the per-minibatch-target-update variant of SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quick", action="store_true", help="headline + roofline only: no cpu baseline, control or extra runs")
     ap.add_argument("--profile-steps", type=int, default=10, help="minibatches of the per-kernel HIP-event pass")
@@ -172,6 +175,7 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="data-parallel: reduce the fully connected layers' gradients beside the conv backward")
     ap.add_argument("--sync-every", type=int, default=1, help="data-parallel: k local minibatches between parameter averagings (1: gradient all-reduce per minibatch)")
     args = ap.parse_args()
+    BATCHES_PER_STEP = max(1, args.batches_per_step)
 
     # keep real stdout for the ONE JSON line: RCCL / libraries print banners to fd 1
     sys.stdout.flush()
@@ -433,6 +437,11 @@ def main():
             extra[wl] = {"metric": e.get("metric"), "value": e.get("value"), "unit": "steps/s", "ms_per_step": e.get("ms_per_step"),
                          "steps": e.get("steps"), "workload": (e.get("config") or {}).get("workload"),
                          "roofline_frac": (e.get("roofline") or {}).get("frac"), "error": e.get("error")}
+        e = sub_bench(["--steps", "100", "--warmup", "10", "--workload", args.workload, "--batches-per-step", "1"])
+        extra["cfg3_target_update_every_minibatch"] = {
+            "what": "the same workload with --batches-per-step 1: both target soft updates after EVERY minibatch (SURVEY 8d's second variant); one "
+                    "train-step call, one hipGraph replay and one stand-alone sample pass per minibatch",
+            "value": e.get("value"), "unit": "steps/s", "ms_per_step": e.get("ms_per_step"), "steps": e.get("steps"), "error": e.get("error")}
         out["extra"] = extra
     sys.stdout.flush()
     try:                                   # RCCL's banner sits in the C stdio buffer: flush it to the redirected fd first
