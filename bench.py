@@ -386,6 +386,17 @@ def main():
                                               "1.9-2.0 GHz on two boxes, %d taken (2354-2453 at 2.4 GHz with constant operands; 32x32x16: 1595-1719), "
                                               "/ 3 pieces; profiles/r02_mfma_rate_probe.txt" % SUSTAINED_F16_MFMA_TFLOPS_RANDOM_OPERANDS}
 
+    # the fully connected heads (reported separately, never in a roofline numerator): per image and minibatch the actor's
+    # layers run forward once and backward twice (dX, dW), the critic's forward twice and backward twice, each target network forward once
+    mlp_gflop = None
+    if kind == "ddpg":
+        hp, wp = shape[0], shape[1]
+        for _ in CONV_DEFS:
+            hp, wp = hp // 2, wp // 2
+        flat = hp * wp * CONV_DEFS[-1][1]
+        actor_macs = flat * 100 + 100 * 100 + 100 * 50 + 50 * 2            # ddpg_cartpole.py:95-100 ("100,100,50", action_dim 2)
+        critic_macs = flat * 200 + 200 * 50 + (50 + 2) * 50 + 50 * 1       # :166-184
+        mlp_gflop = round(2.0 * B * (4 * actor_macs + 5 * critic_macs) / 1e9, 3)
     ch = int(np.prod(shape[2:]))
     out = {
         "metric": "%s training steps/sec, %dx%dx%d pixel obs, batch=%d" % ("DDPG" if kind == "ddpg" else "NAF", shape[0], shape[1], ch, B),
@@ -403,6 +414,8 @@ def main():
                    "parallelism": parallelism,
                    "global_steps_per_sec": round(steps / elapsed, 3),
                    "conv_gflop_per_step": round(conv_flops_step / 1e9, 3),
+                   "conv_gflop_per_step_as_the_reference_executes_it": (round(2.0 * B * (5 * F + 2 * Bk) / 1e9, 3) if kind == "ddpg" else None),
+                   "mlp_gflop_per_step": mlp_gflop,
                    "conv_bound_frac_whole_step": round(bound_us_step / (1e3 * ms_per_step), 4),
                    "conv_bound_frac_basis": "sum over the conv launches of (algorithmic FLOPs / peak of the pipe the launch runs on) / measured "
                                             "step time; pipes: " + "; ".join("%s = %.1f TFLOP/s (%s)" % (k, v[0], v[1]) for k, v in PIPES.items())},
