@@ -20,16 +20,18 @@ def _close_params(a, b, tol=1e-6):
         assert np.abs(x - y).max() < tol, float(np.abs(x - y).max())
 
 
-@pytest.mark.parametrize("mode", ["gradient-allreduce", "overlap", "periodic-3", "no-communicator"])
-def test_native_learner_at_world_size_one_equals_the_fused_step(mode):
+@pytest.mark.parametrize("mode,shape,B", [("gradient-allreduce", (16, 16, 3, 2, 3), 16), ("overlap", (16, 16, 3, 2, 3), 16),
+                                          ("periodic-3", (16, 16, 3, 2, 3), 16), ("no-communicator", (16, 16, 3, 2, 3), 16),
+                                          ("gradient-allreduce", (64, 64, 3, 2, 3), 256), ("overlap", (64, 64, 3, 2, 3), 256)],
+                         ids=["gradient-allreduce", "overlap", "periodic-3", "no-communicator", "gradient-allreduce-cfg3-B256", "overlap-cfg3-B256"])
+def test_native_learner_at_world_size_one_equals_the_fused_step(mode, shape, B):
     from cartpoleplusplus_amd import ddpg_cartpole as D
     from cartpoleplusplus_amd.distributed import Communicator, NativeLearner
-    shape, B = (16, 16, 3, 2, 3), 16
     res = []
     for which in ("fused", "dp"):
-        agent, _ref, _ = make_pair(shape, B, True, replay_size=300)
+        agent, _ref, _ = make_pair(shape, B, True, replay_size=max(300, 4 * B))
         try:
-            agent.replay_memory.fill_synthetic(200, seed=11)
+            agent.replay_memory.fill_synthetic(max(200, 3 * B), seed=11)
             if which == "fused":
                 for _ in range(5):
                     agent.train_step(B, 3)
