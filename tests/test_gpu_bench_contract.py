@@ -1,0 +1,37 @@
+"""bench.py prints ONE JSON line with the contract's keys (the driver parses it): run the quick variant on the GPU and check the
+line's shape.  (The full variant adds cpu_baseline / control / extra and takes minutes; profiles/r02_kernel_stats.md keeps one.)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_quick_line_has_the_contract_keys():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "5", "--quick"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines                               # exactly one line on stdout: library banners go to stderr
+    d = json.loads(lines[0])
+    assert d["metric"] == "DDPG training steps/sec, 64x64x18 pixel obs, batch=256" and d["unit"] == "steps/s"
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 5 and d["warmup_steps_run"] >= 200
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-3          # N = 1: value = 1 / step time
+    assert d["config"]["workload"].startswith("cfg3") and "model" not in d["config"]
+    assert d["config"]["conv_gflop_per_step"] == pytest.approx(68.053, abs=1e-3)
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["kernel"] == "conv1_fwd_f16x3"
+    assert rf["peak"] == pytest.approx(2500.0 / 3, abs=0.1) and 0.0 < rf["frac"] < 1.0
+    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-3)
+    assert rf["flops_per_launch"] == pytest.approx(2 * 256 * 4096 * 4500 * 4, rel=1e-4)          # four networks' conv1, algorithmic (GFLOP rounded to 3 places)
+    assert rf["achieved"] == pytest.approx(rf["flops_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e12, rel=1e-3)
+    assert rf["traffic"] is None or rf["traffic"] > 1e8
+    for row in d["layers"]:
+        assert 0.0 < row["frac"] <= 1.0, row
+    assert d["cpu_baseline"] is None                            # --quick
