@@ -43,3 +43,18 @@ def test_synthetic_env_shapes():
     assert np.array_equal(s, s.astype(np.float16).astype(np.float32))   # f16(k/255) values
     s2, r, done, _ = env.step(np.zeros((1, 2)))
     assert s2.shape == s.shape and r == 1.0
+
+
+def test_bench_flop_accounting_matches_the_survey():
+    """conv FLOPs per step = 2 B (4 F + 2 Bk) with F / Bk the unpadded per-image MACs -- cfg2 39.74, cfg3 68.05,
+    cfg5 846.4 GFLOP (the numerators of every roofline figure bench.py prints)."""
+    import bench
+    want = {"cfg2": (12006400, 14796800, 39.74), "cfg3": (21222400, 24012800, 68.05), "cfg5": (134041600, 145203200, 846.4)}
+    for wl, (F_, Bk_, gf) in want.items():
+        shape, B, kind = bench.WORKLOADS[wl]
+        F, Bk, per_layer = bench.conv_macs(shape)
+        assert (F, Bk) == (F_, Bk_) and kind == "ddpg"
+        assert abs(2.0 * B * (4 * F + 2 * Bk) / 1e9 - gf) < 0.05 * max(1.0, gf / 100)
+    F50 = bench.conv_macs((50, 50, 3, 1, 2))[0]                          # the default render: 5.44 MMAC per image (SURVEY 8a, row a7)
+    assert abs(F50 / 1e6 - 5.44) < 0.01
+    assert bench.PIPES["f16x3"][0] == bench.PEAK_F16_MFMA_TFLOPS / 3.0 and bench.PIPES["bf16x9"][0] == bench.PEAK_F16_MFMA_TFLOPS / 9.0
