@@ -236,8 +236,10 @@ struct BnBatch { BnNet n[CONV_BATCH_MAX]; int count; int B, H, W, C; };
 size_t bn_part_doubles(int C);
 int launch_bn_forward(cpp_ctx* ctx, const BnBatch& bb, double eps);
 int launch_bn_backward(cpp_ctx* ctx, const BnBatch& bb);
+// bump: a device counter the kernel's first thread advances by one (the sampler's counter, which otherwise costs the data-parallel
+// half step a launch of its own right behind this one)
 int launch_stats_finalize(cpp_ctx* ctx, const double* part, int nparts, int which_count, int C,
-                          double count, float* white, double eps = 1e-6);
+                          double count, float* white, double eps = 1e-6, uint64_t* bump = nullptr);
 int launch_stats_generic(cpp_ctx* ctx, const void* x, int dtype, long npix, int C, float* white, double eps = 1e-6);
 int launch_replay_fill(cpp_ctx* ctx, __half* store, long elems, int slots, int32_t* s1, int32_t* s2,
                        float* action, float* reward, float* mask, int rows, int action_dim,

@@ -69,8 +69,9 @@ int launch_gather_stats(cpp_ctx* ctx, const GatherArgs& a, int dtype) {
 // one 64-lane wave per (state column, channel): lanes stride over the per-row partials, fixed-order
 // butterfly combine (deterministic)
 __global__ __launch_bounds__(64) void stats_finalize_kernel(const double* part, int nparts, int which_count,
-                                                            int C, double count, float* white, double eps) {
+                                                            int C, double count, float* white, double eps, uint64_t* bump) {
   const int w = blockIdx.x / C, c = blockIdx.x - w * C;
+  if (bump && blockIdx.x == 0 && threadIdx.x == 0) *bump += 1;
   double s = 0.0, ss = 0.0;
 #pragma unroll 4
   for (int b = threadIdx.x; b < nparts; b += 64) {
@@ -88,10 +89,10 @@ __global__ __launch_bounds__(64) void stats_finalize_kernel(const double* part, 
 }
 
 int launch_stats_finalize(cpp_ctx* ctx, const double* part, int nparts, int which_count, int C,
-                          double count, float* white, double eps) {
+                          double count, float* white, double eps, uint64_t* bump) {
   prof_begin(ctx);
   hipLaunchKernelGGL(stats_finalize_kernel, dim3(which_count * C), dim3(64), 0, ctx->stream, part, nparts,
-                     which_count, C, count, white, eps);
+                     which_count, C, count, white, eps, bump);
   LAUNCH_CHECK();
   prof_end(ctx, K_STATS_FINALIZE);
   return 0;

@@ -646,8 +646,9 @@ static int half_step_body(cpp_ddpg* d, cpp_replay* r, int B, uint64_t seed, int 
   GatherArgs ga = replay_gather_args(r, B, nullptr, seed, r->counter, C, b, direct, &Cg);
   if (phase != 2) {
     if (variant == 0) RC(launch_gather_stats(ctx, ga, r->store_dtype));
-    RC(replay_sample_finish(r, B, Cg, C, b));
-    RC(launch_counter_add(ctx, r->counter, 1));
+    bool bumped = false;
+    RC(replay_sample_finish(r, B, Cg, C, b, r->counter, &bumped));
+    if (!bumped) RC(launch_counter_add(ctx, r->counter, 1));
   }
   if (phase == 1) return compute_gradients(d, b, 1);
   const bool ride_ok = !no_ride && direct && Cg > 0 && r->store_dtype == CPP_F16;

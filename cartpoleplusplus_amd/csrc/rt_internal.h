@@ -210,8 +210,9 @@ GemmArgs fc_dx_args(cpp_net* n, int l, int B, const float* dz, long dz_ld, int c
 int batch_stats(cpp_ctx* ctx, const void* s0, const void* s1, int dtype, long elems, int B, int C, double* part, float* white);
 int batch_ensure_stats(cpp_batch* b, int C);
 GatherArgs replay_gather_args(cpp_replay* r, int B, const int32_t* rows_dev, uint64_t seed, const uint64_t* counter_dev, int channels, cpp_batch* out, bool direct, int* C_out);
-int replay_sample_finish(cpp_replay* r, int B, int C, int channels, cpp_batch* out);
-int replay_sample_device(cpp_replay* r, int B, const int32_t* rows_dev, uint64_t seed, const uint64_t* counter_dev, int channels, cpp_batch* out, bool direct = false);
+int replay_sample_finish(cpp_replay* r, int B, int C, int channels, cpp_batch* out, uint64_t* bump = nullptr, bool* bumped = nullptr);
+int replay_sample_device(cpp_replay* r, int B, const int32_t* rows_dev, uint64_t seed, const uint64_t* counter_dev, int channels, cpp_batch* out, bool direct = false,
+                         uint64_t* bump = nullptr, bool* bumped = nullptr);
 const float* white_of(cpp_batch* b, int which, int C);
 bool direct_replay_ok(cpp_net* a, cpp_replay* r, int B);
 

@@ -329,9 +329,10 @@ extern "C" int cpp_naf_debug_values(cpp_naf* f, cpp_batch* b, float* l_values, f
 static int naf_step_body(cpp_naf* f, cpp_replay* r, int B, int n_batches, const int32_t* rows_dev, uint64_t seed) {
   const int C = f->value->spec.pixel ? f->value->spec.C : 0;
   for (int i = 0; i < n_batches; ++i) {
+    bool bumped = false;     // device-drawn rows: the sampler's counter moves on behind the draw (by the statistics kernel when there is one)
     RC(replay_sample_device(r, B, rows_dev ? rows_dev + (size_t)i * B : nullptr, seed, rows_dev ? nullptr : r->counter, C, f->step_batch,
-                            direct_replay_ok(f->value, r, B)));
-    if (!rows_dev) RC(launch_counter_add(f->ctx, r->counter, 1));
+                            direct_replay_ok(f->value, r, B), rows_dev ? nullptr : r->counter, &bumped));
+    if (!rows_dev && !bumped) RC(launch_counter_add(f->ctx, r->counter, 1));
     RC(naf_compute_gradients(f, f->step_batch));
     RC(naf_apply(f, 1.0f));
   }
@@ -376,8 +377,9 @@ extern "C" int cpp_naf_train_step(cpp_naf* f, cpp_replay* r, int B, int n_batche
 // ---- data-parallel learners: the halves of one minibatch of naf_cartpole.py:367-371 -------------------------
 static int naf_half_body(cpp_naf* f, cpp_replay* r, int B, uint64_t seed) {
   const int C = f->value->spec.pixel ? f->value->spec.C : 0;
-  RC(replay_sample_device(r, B, nullptr, seed, r->counter, C, f->step_batch, direct_replay_ok(f->value, r, B)));
-  RC(launch_counter_add(f->ctx, r->counter, 1));
+  bool bumped = false;       // (the statistics kernel advances the sampler's counter when there is one: replay_sample_finish)
+  RC(replay_sample_device(r, B, nullptr, seed, r->counter, C, f->step_batch, direct_replay_ok(f->value, r, B), r->counter, &bumped));
+  if (!bumped) RC(launch_counter_add(f->ctx, r->counter, 1));
   return naf_compute_gradients(f, f->step_batch);
 }
 

@@ -290,10 +290,14 @@ GatherArgs replay_gather_args(cpp_replay* r, int B, const int32_t* rows_dev, uin
   return a;
 }
 // what follows the gather kernel: the batch's bookkeeping and the whitening tables
-int replay_sample_finish(cpp_replay* r, int B, int C, int channels, cpp_batch* out) {
+// bump (optional): the sampler's counter, to be advanced by one behind this minibatch's draw -- done by the statistics kernel
+// when there is one (*bumped = true), left to the caller otherwise
+int replay_sample_finish(cpp_replay* r, int B, int C, int channels, cpp_batch* out, uint64_t* bump, bool* bumped) {
   out->B = B; out->dtype = CPP_F16; out->stats_C = 0;
+  if (bumped) *bumped = false;
   if (C > 0) {
-    RC(launch_stats_finalize(r->ctx, out->part, B, 2, C, (double)B * (double)(r->elems / C), out->white));
+    RC(launch_stats_finalize(r->ctx, out->part, B, 2, C, (double)B * (double)(r->elems / C), out->white, 1e-6, bump));
+    if (bumped && bump) *bumped = true;
     out->stats_C = C;
   } else if (channels > 0) {
     RC(batch_ensure_stats(out, channels));
@@ -301,11 +305,11 @@ int replay_sample_finish(cpp_replay* r, int B, int C, int channels, cpp_batch* o
   return CPP_OK;
 }
 int replay_sample_device(cpp_replay* r, int B, const int32_t* rows_dev, uint64_t seed, const uint64_t* counter_dev,
-                                int channels, cpp_batch* out, bool direct) {
+                                int channels, cpp_batch* out, bool direct, uint64_t* bump, bool* bumped) {
   int C = 0;
   const GatherArgs a = replay_gather_args(r, B, rows_dev, seed, counter_dev, channels, out, direct, &C);
   RC(launch_gather_stats(r->ctx, a, r->store_dtype));      // a CPP_U8 store gathers to f16 as well
-  return replay_sample_finish(r, B, C, channels, out);
+  return replay_sample_finish(r, B, C, channels, out, bump, bumped);
 }
 
 extern "C" int cpp_replay_sample(cpp_replay* r, int B, const int32_t* idxs, uint64_t seed, uint64_t counter,
