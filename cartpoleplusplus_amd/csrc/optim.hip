@@ -4,6 +4,7 @@
 // target-network soft update (base_network.py:20-33).  All gradient lists are handled by one launch each
 // (blockIdx.y = segment).  Reductions are two-stage and fixed-order.
 #include "common.h"
+#include "stats_body.h"
 
 constexpr int OPT_THREADS = 256;
 
@@ -55,6 +56,11 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_apply_kernel(const OptSegs s,
                                                                 int nparts, float* norms_out) {
   __shared__ float sh_scale, sh_lr;
   const int seg = blockIdx.y;
+  if (seg == s.nseg) {                               // the rider's grid row (uniform per workgroup)
+    const int job = (int)blockIdx.x * (OPT_THREADS / 64) + (int)(threadIdx.x >> 6);
+    if (job < s.st_jobs) stats_finalize_wave(s.st_part, s.st_nparts, s.st_C, s.st_count, s.st_white, s.st_eps, job, (int)(threadIdx.x & 63));
+    return;
+  }
   // squared norm of the segment's group: the first wave adds the partials (one load per lane and segment in flight, then a
   // fixed-order butterfly) -- a one-thread loop over them was most of this kernel's time
   double tot = 0.0;
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_apply_kernel(const OptSegs s,
 int launch_opt_apply(cpp_ctx* ctx, const OptSegs& s, float grad_scale, float clip, const double* part,
                      int nparts, float* norms_out) {
   prof_begin(ctx);
-  hipLaunchKernelGGL(opt_apply_kernel, dim3(128, s.nseg), dim3(OPT_THREADS), 0, ctx->stream, s, grad_scale,
+  hipLaunchKernelGGL(opt_apply_kernel, dim3(128, s.nseg + (s.st_part ? 1 : 0)), dim3(OPT_THREADS), 0, ctx->stream, s, grad_scale,
                      clip, part, nparts, norms_out);
   LAUNCH_CHECK();
   prof_end(ctx, K_CLIP_SGD);

@@ -11,6 +11,7 @@
 // combined in fixed order by stats_finalize_kernel (deterministic).
 #include "conv_impl.h"
 #include "gather_body.h"
+#include "stats_body.h"
 
 template <typename T>
 __global__ __launch_bounds__(256) void gather_stats_kernel(const GatherArgs a) {
@@ -66,26 +67,10 @@ int launch_gather_stats(cpp_ctx* ctx, const GatherArgs& a, int dtype) {
 }
 
 // white[w][0][c] = rsqrt(var + 1e-6), white[w][1][c] = -mean * rsqrt(var + 1e-6)   (base_network.py:97-99)
-// one 64-lane wave per (state column, channel): lanes stride over the per-row partials, fixed-order
-// butterfly combine (deterministic)
 __global__ __launch_bounds__(64) void stats_finalize_kernel(const double* part, int nparts, int which_count,
                                                             int C, double count, float* white, double eps, uint64_t* bump) {
-  const int w = blockIdx.x / C, c = blockIdx.x - w * C;
   if (bump && blockIdx.x == 0 && threadIdx.x == 0) *bump += 1;
-  double s = 0.0, ss = 0.0;
-#pragma unroll 4
-  for (int b = threadIdx.x; b < nparts; b += 64) {
-    const double* p = part + ((long)w * nparts + b) * 2 * C;
-    s += p[c]; ss += p[C + c];
-  }
-  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
-  if (threadIdx.x == 0) {
-    const double mean = s / count;
-    const double var = ss / count - mean * mean;     // one-pass form of tf.nn.moments (r0.9-r0.11)
-    const double inv = 1.0 / sqrt(var + eps);
-    white[(long)w * 2 * C + c] = (float)inv;
-    white[(long)w * 2 * C + C + c] = (float)(-mean * inv);
-  }
+  stats_finalize_wave(part, nparts, C, count, white, eps, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 int launch_stats_finalize(cpp_ctx* ctx, const double* part, int nparts, int which_count, int C,

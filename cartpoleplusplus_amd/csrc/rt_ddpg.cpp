@@ -185,9 +185,16 @@ static int critic_gradients_impl(cpp_ddpg* d, cpp_batch* b, bool critic_prefix_d
 
 // folded: take the lists' squared norms from the partials the gradient pass left (compute_gradients: sq_scope) instead of running
 // the sumsq kernel -- only for gradients that are applied as computed (both lists, no scaling, nothing in between)
-static int apply(cpp_ddpg* d, bool do_actor, bool do_critic, float grad_scale, uint64_t* bump = nullptr, bool folded = false) {
+// next: the minibatch whose sample pass has already run (its per-row statistics are in next->part): its whitening tables are
+// computed by this launch's rider instead of a stats_finalize launch behind it
+static int apply(cpp_ddpg* d, bool do_actor, bool do_critic, float grad_scale, uint64_t* bump = nullptr, bool folded = false,
+                 const cpp_batch* next = nullptr, int next_B = 0, int next_C = 0, long elems = 0) {
   OptSegs s; memset(&s, 0, sizeof(s));
   s.bump = bump;
+  if (next && next_C > 0) {
+    s.st_part = next->part; s.st_white = next->white; s.st_nparts = next_B; s.st_jobs = 2 * next_C; s.st_C = next_C;
+    s.st_count = (double)next_B * (double)(elems / next_C); s.st_eps = 1e-6;
+  }
   s.nseg = 2; s.kind = OPT_SGD;
   s.p[0] = d->actor->params; s.g[0] = d->gradbuf; s.n[0] = do_actor ? d->nA : 0; s.lr[0] = d->hp.actor_learning_rate; s.group[0] = 0;
   s.p[1] = d->critic->params; s.g[1] = d->gradbuf + d->nA; s.n[1] = do_critic ? d->nC : 0; s.lr[1] = d->hp.critic_learning_rate; s.group[1] = 1;
@@ -581,9 +588,13 @@ static int step_body(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int
     ctx->ride = nullptr;
     if (rode && direct) { std::swap(d->step_batch->slot[0], d->step_batch->slot_alt[0]); std::swap(d->step_batch->slot[1], d->step_batch->slot_alt[1]); }
     RC(rc);
-    RC(apply(d, true, true, 1.0f, rows_dev ? nullptr : r->counter, true));   // also advances the sampler's counter
+    // (also advances the sampler's counter and, when the next minibatch's sample pass rode along above, finishes its statistics)
+    static const bool no_stats_ride = cpp_switch_off("CPP_RIDE_STATS");
+    const bool stats_ride = rode && Cg > 0 && !no_stats_ride;
+    RC(apply(d, true, true, 1.0f, rows_dev ? nullptr : r->counter, true, stats_ride ? d->step_batch : nullptr, B, Cg, r->elems));
     if (more) {
-      if (rode) RC(replay_sample_finish(r, B, Cg, C, d->step_batch));
+      if (stats_ride) { d->step_batch->B = B; d->step_batch->dtype = CPP_F16; d->step_batch->stats_C = Cg; }     // (replay_sample_finish's bookkeeping)
+      else if (rode) RC(replay_sample_finish(r, B, Cg, C, d->step_batch));
       else RC(replay_sample_device(r, B, rows_dev ? rows_dev + (size_t)(i + 1) * B : nullptr, seed, rows_dev ? nullptr : r->counter, C,
                                    d->step_batch, direct));
     }
