@@ -22,7 +22,7 @@ struct cpp_ddpg {
   // hg[0]: the whole half step as one graph per variant; hg[1]: split at the conv backward (two graphs per variant) so that the
   // all-reduce of the fully-connected layers' gradients can run beside the conv backward (cpp_ddpg_dp_train_step, overlap)
   struct HalfGraphs { hipGraph_t g[3][2]; hipGraphExec_t e[3][2]; bool ok[3]; int next[3]; } hg[2];   // next: variant of the following call
-  int h_B; uint64_t h_seed, h_replay_uid;
+  int h_B; uint64_t h_seed, h_replay_uid, h_write_gen;
   uint64_t dp_local;       // minibatches applied locally since the last parameter averaging (periodic mode)
   int sq_cnt[2];           // norm partials the last gradient pass left per list in cpp_ctx::sq_part (<= 0: none, run the sumsq kernel)
   int pre_variant;         // variant of the next cpp_ddpg_sample_and_compute call if its key still matches (0: sample)
@@ -46,7 +46,7 @@ extern "C" int cpp_ddpg_create(cpp_ctx* ctx, cpp_net* actor, cpp_net* critic, cp
   d->nA = actor->nparams; d->nC = critic->nparams;
   d->graph = nullptr; d->gexec = nullptr; d->graph_ok = false; d->step_batch = nullptr; d->g_replay_uid = 0;
   memset(d->hg, 0, sizeof(d->hg)); d->dp_local = 0; d->sq_cnt[0] = d->sq_cnt[1] = 0;
-  d->h_replay_uid = 0; d->pre_variant = 0; d->h_B = 0; d->h_seed = 0;
+  d->h_replay_uid = 0; d->h_write_gen = 0; d->pre_variant = 0; d->h_B = 0; d->h_seed = 0;
   memset(d->slot_set, 0, sizeof(d->slot_set));
   d->heads_grid = d->heads_B = d->loss_parts = d->loss_B = 0;
   const int A = actor->spec.action_dim;
@@ -698,6 +698,9 @@ static int half_step(cpp_ddpg* d, cpp_replay* r, int B, uint64_t seed, bool spli
     d->pre_variant = 0;
     d->h_B = B; d->h_seed = seed; d->h_replay_uid = r->uid;
   }
+  // a minibatch the previous call's rider presampled is only good while the memory is as it was: an episode added since may have
+  // overwritten its rows or recycled their state slots (the slots are read at step time).  Draw again (same counter, new contents).
+  if (d->h_write_gen != r->write_gen) { d->pre_variant = 0; d->h_write_gen = r->write_gen; }
   cpp_ddpg::HalfGraphs& H = d->hg[split ? 1 : 0];
   const int v = d->pre_variant;
   d->pre_variant = 0;                                // (stays 0 if anything below fails)

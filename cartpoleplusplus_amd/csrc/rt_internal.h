@@ -116,6 +116,7 @@ struct cpp_replay {
   uint64_t* counter_adhoc; // the same for cpp_replay_sample(idxs == NULL): inspection draws never move the training sampler
   int32_t* size_dev;       // rows currently in the memory, on the device: the sampler's range of captured launches
   uint64_t uid;            // unique per cpp_replay_create (graph keys: an address can be reused, this cannot)
+  uint64_t write_gen;      // bumped by every call that changes rows, states or the size: a minibatch presampled before it is stale
   __half* lut; int* bad; uint16_t lut_host[256];      // CPP_U8: f16(k/255) table, "not a pixel image" flag
   void* stage; size_t stage_cap;                      // device staging of incoming states (conversion source)
   void* pinned; size_t pinned_cap; hipEvent_t pinned_free; bool pinned_busy;   // host staging: writes return before the copy ends

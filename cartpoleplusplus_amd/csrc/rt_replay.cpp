@@ -162,6 +162,7 @@ extern "C" int cpp_replay_destroy(cpp_replay* r) {
 // as soon as they are copied there: the H2D transfer and the conversions run on the context's stream, in order with
 // everything launched later (rendered frames straight into replay slots, no stall of the rollout loop).
 extern "C" int cpp_replay_write_states(cpp_replay* r, const int32_t* slots, int n, const void* states, int dtype) {
+  if (r) ++r->write_gen;
   ARG_CHECK(r && slots && states, "cpp_replay_write_states: NULL argument");
   ARG_CHECK(dtype == CPP_F32 || dtype == CPP_F16 || dtype == CPP_U8, "cpp_replay_write_states: dtype %d", dtype);
   ARG_CHECK(n >= 1 && (double)n * (double)r->elems < 4.0e9, "cpp_replay_write_states: %d states of %ld elements in one call (the conversion kernels run one thread per element: split the episode)", n, r ? r->elems : 0);
@@ -219,6 +220,7 @@ extern "C" int cpp_replay_write_states(cpp_replay* r, const int32_t* slots, int 
 
 extern "C" int cpp_replay_write_rows(cpp_replay* r, const int32_t* rows, int n, const int32_t* s1, const int32_t* s2,
                                      const float* action, const float* reward, const float* mask) {
+  if (r) ++r->write_gen;
   ARG_CHECK(r && rows && s1 && s2 && action && reward && mask, "cpp_replay_write_rows: NULL argument");
   hipStream_t st = r->ctx->stream;
   HIP_CHECK(hipSetDevice(r->ctx->device));
@@ -240,6 +242,7 @@ extern "C" int cpp_replay_write_rows(cpp_replay* r, const int32_t* rows, int n, 
 }
 
 extern "C" int cpp_replay_set_size(cpp_replay* r, int size) {
+  if (r) ++r->write_gen;
   ARG_CHECK(r && size >= 0 && size <= r->rows, "cpp_replay_set_size: size %d outside [0,%d]", size, r ? r->rows : 0);
   HIP_CHECK(hipSetDevice(r->ctx->device));
   return replay_set_size(r, size);
@@ -343,6 +346,7 @@ extern "C" int cpp_replay_last_indexes(cpp_replay* r, int B, int32_t* out) {
 }
 
 extern "C" int cpp_replay_fill_synthetic(cpp_replay* r, int n_rows, uint64_t seed) {
+  if (r) ++r->write_gen;
   ARG_CHECK(r && n_rows >= 1 && n_rows <= r->rows, "cpp_replay_fill_synthetic: rows %d", n_rows);
   ARG_CHECK(n_rows + n_rows / 50 + 1 <= r->slots, "cpp_replay_fill_synthetic: not enough state slots");
   HIP_CHECK(hipSetDevice(r->ctx->device));
