@@ -43,3 +43,11 @@ def test_reference_default_render_B128_graph_replayed_fused_step_against_f64_ora
     16-byte multiples and odd pooled sizes (25 -> 12 -> 6: 'VALID' drops the last row and column)."""
     rep = fused_step_against_f64_oracle(shape, 128, rows=1500, graph=True, seed=6)
     print("%dx%dx%d B=128 fused graph step vs f64 oracle:" % (shape[0], shape[1], int(np.prod(shape[2:]))), rep)
+
+
+@pytest.mark.parametrize("B", [255, 17, 1])
+def test_cfg3_geometry_at_odd_batch_sizes_against_f64_oracle(B):
+    """batch sizes that do not fill the kernels' image groups (two / four images per workgroup; conv3 can only ride in conv2's
+    launch with an even count): the same graph-replayed step, the same bar."""
+    rep = fused_step_against_f64_oracle((64, 64, 3, 2, 3), B, rows=1200, graph=True, seed=9)
+    print("cfg3 geometry, B=%d:" % B, rep)
