@@ -178,6 +178,9 @@ struct GemmArgs {
 };
 #define GEMM_BATCH_MAX 8
 struct GemmBatch { GemmArgs g[GEMM_BATCH_MAX]; int tile_start[GEMM_BATCH_MAX + 1]; int n; };
+// kernel attributes (dynamic LDS size) are set once per kernel AND device: the launchers keep one flag per device slot
+#define CPP_MAX_DEVICES 16
+static inline int cpp_dev_slot(const cpp_ctx* ctx) { return ctx->device >= 0 && ctx->device < CPP_MAX_DEVICES ? ctx->device : 0; }
 // sub-tiles per workgroup edge (gemm.hip: 2 x 2 tiles of 16 x 16 where K is long enough for operand traffic to bound the level)
 #ifndef GEMM_SUB_MIN_K
 #define GEMM_SUB_MIN_K 100000      // (2 x 2 measured slower: 0.0565 vs 0.0433 ms for the four levels -- a quarter of the workgroups, each four times as long)

@@ -25,10 +25,10 @@ __global__ __launch_bounds__(CONV_THREADS, DW16_WGS) void conv1_dw_gather_kernel
 }
 
 int launch_conv1_dw_gather(cpp_ctx* ctx, const ConvArgsN& batch, int upi, int band, int grid, size_t lds_bytes, const GatherArgs& g) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[CPP_MAX_DEVICES] = {};          // (kernel attributes are per device: one cpp_ctx per GPU may share the process)
+  if (!attr_done[cpp_dev_slot(ctx)]) {
     HIP_CHECK(hipFuncSetAttribute((const void*)conv1_dw_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_done = true;
+    attr_done[cpp_dev_slot(ctx)] = true;
   }
   hipLaunchKernelGGL(conv1_dw_gather_kernel, dim3(grid * batch.n + 2 * g.B), dim3(CONV_THREADS), lds_bytes, ctx->stream, batch, upi, band, grid, g);
   LAUNCH_CHECK();

@@ -20,7 +20,8 @@ int launch_conv3_bwd_pair(cpp_ctx* ctx, const ConvPairSlot& slot) {
   const int ndx = slot.have_dx ? slot.dx_gx * slot.dx.n : 0, ndw = slot.have_dw ? slot.dw_gx * slot.dw.n : 0;
   if (ndx + ndw == 0) return 0;
   const size_t lds = (slot.have_dx ? slot.dx_lds : 0) > (slot.have_dw ? slot.dw_lds : 0) ? slot.dx_lds : slot.dw_lds;
-  static size_t attr = 0;
+  static size_t attr_dev[CPP_MAX_DEVICES] = {};      // (kernel attributes are per device)
+  size_t& attr = attr_dev[cpp_dev_slot(ctx)];
   if (lds > attr) {
     HIP_CHECK(hipFuncSetAttribute((const void*)conv3_bwd_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = lds;

@@ -289,10 +289,10 @@ static inline int conv_dwb16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int*
   const ConvArgs& a = batch.a[0];
   const size_t lds_bytes = (size_t)G::LDS_BYTES;
   auto kern = conv_dwb16_kernel<CIN, KS, NCHK>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[CPP_MAX_DEVICES] = {};          // (kernel attributes are per device: one cpp_ctx per GPU may share the process)
+  if (!attr_done[cpp_dev_slot(ctx)]) {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_done = true;
+    attr_done[cpp_dev_slot(ctx)] = true;
   }
   const int capacity = ctx->num_cus * 4 / batch.n;   // <= conv_dw_kyo_grid: the partial buffers are sized for that
   int band = (a.H + 1) & ~1;

@@ -713,11 +713,11 @@ static inline int conv_fwd_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
   constexpr int TR = conv_th(CIN, XTW) + KS - 1, TC = 16 * XTW + KS - 1;
   const size_t lds_bytes = (size_t)(TR * TC * CIN + CONV_LDS_PAD + 2 * CIN) * sizeof(float);
   auto kern = conv_fwd_kernel<CIN, KS, XTW, IN_MODE, EPI>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[CPP_MAX_DEVICES] = {};          // (kernel attributes are per device: one cpp_ctx per GPU may share the process)
+  if (!attr_done[cpp_dev_slot(ctx)]) {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds_bytes));
-    attr_done = true;
+    attr_done[cpp_dev_slot(ctx)] = true;
   }
   const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
   const int grid = conv_grid_x(ctx->num_cus * per_cu, batch.n, a.ntiles);
@@ -748,11 +748,11 @@ static inline int conv_dw_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int* gr
   if (fl < (size_t)NT * 256 + 64) fl = (size_t)NT * 256 + 64;
   const size_t lds_bytes = fl * sizeof(float);
   auto kern = conv_dw_kernel<CIN, KS, XTW, IN_MODE>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[CPP_MAX_DEVICES] = {};          // (kernel attributes are per device: one cpp_ctx per GPU may share the process)
+  if (!attr_done[cpp_dev_slot(ctx)]) {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds_bytes));
-    attr_done = true;
+    attr_done[cpp_dev_slot(ctx)] = true;
   }
   const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
   const int grid = conv_grid_x(ctx->num_cus * per_cu, batch.n, a.ntiles);

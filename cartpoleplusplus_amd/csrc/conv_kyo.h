@@ -534,10 +534,10 @@ static inline int conv_fwd_kyo_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
   const ConvArgs& a = batch.a[0];
   const size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
   auto kern = conv_fwd_kyo_kernel<CIN, KS, XT, IPW, IN_MODE, CHB, PLAIN>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[CPP_MAX_DEVICES] = {};          // (kernel attributes are per device: one cpp_ctx per GPU may share the process)
+  if (!attr_done[cpp_dev_slot(ctx)]) {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_done = true;
+    attr_done[cpp_dev_slot(ctx)] = true;
   }
   const int grid = ((a.B + IPW - 1) / IPW) * (a.nbands > 1 ? a.nbands : 1);
   if (ctx->pair && CIN == 10 && IN_MODE == IN_DY && CHB == 16 && !PLAIN && XT == 1 &&

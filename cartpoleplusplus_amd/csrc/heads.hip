@@ -298,10 +298,11 @@ int launch_ddpg_heads(cpp_ctx* ctx, const DdpgHeadsArgs& h) {
   static const kern_t kerns[6] = {ddpg_heads_kernel<1, true>, ddpg_heads_kernel<2, true>, ddpg_heads_kernel<4, true>,
                                   ddpg_heads_kernel<8, true>, ddpg_heads_kernel<4, false>, ddpg_heads_kernel<8, false>};
   const int ki = h.A == 1 ? 0 : h.A == 2 ? 1 : h.A == 4 ? 2 : h.A == 8 ? 3 : h.A == 3 ? 4 : 5;
-  static size_t attr[6] = {0, 0, 0, 0, 0, 0};
-  if (lds > attr[ki]) {
+  static size_t attr[CPP_MAX_DEVICES][6] = {};      // (kernel attributes are per device)
+  size_t& have = attr[cpp_dev_slot(ctx)][ki];
+  if (lds > have) {
     HIP_CHECK(hipFuncSetAttribute((const void*)kerns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr[ki] = lds;
+    have = lds;
   }
   prof_begin(ctx);
   hipLaunchKernelGGL(kerns[ki], dim3((h.B + HEADS_ROWS - 1) / HEADS_ROWS), dim3(HEADS_THREADS), lds, ctx->stream, h);
