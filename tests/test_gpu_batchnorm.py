@@ -13,6 +13,7 @@ CASES = [
     pytest.param((12, 10, 3, 1, 3), 3, id="12x10x9-B3-oddpool"),
     pytest.param((64, 64, 3, 2, 3), 2, id="64x64x18-B2-cfg3-shape"),
     pytest.param((50, 50, 3, 2, 3), 2, id="50x50x18-B2-exps-run_98-shape"),     # 1800-byte f16 rows: 8-byte staging chunks
+    pytest.param((32, 32, 3, 2, 3), 3, id="32x32x18-B3"),                      # 18 channels on the narrow (<= 32 columns) dW instance
 ]
 
 
