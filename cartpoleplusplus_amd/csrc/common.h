@@ -137,6 +137,14 @@ int launch_conv_dw(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, ConvArgs
                    float* grad_b);
 size_t conv_dw_partial_floats(cpp_ctx* ctx, int cin, int ks, int nout);
 int flush_dw_reduce(cpp_ctx* ctx);     // one launch for every dW reduction queued by launch_conv_dw
+// A backward pass that fails half way (a geometry without a kernel, a launch error) must not leave its queued reductions behind:
+// they point into that network's buffers, which may be gone by the time the next pass flushes the queue.
+struct DwPendingGuard {
+  cpp_ctx* ctx; bool armed;
+  explicit DwPendingGuard(cpp_ctx* c) : ctx(c), armed(true) {}
+  void keep() { armed = false; }         // (the queue is handed on on purpose: the split half step's first phase)
+  ~DwPendingGuard() { if (armed) ctx->npending = 0; }
+};
 
 // Philox4x32-10 (Salmon et al., SC'11): the replay sampler's and the dropout masks' counter-based generator
 struct u32x4 { uint32_t x, y, z, w; };

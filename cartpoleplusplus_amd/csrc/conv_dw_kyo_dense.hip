@@ -18,6 +18,7 @@ int conv_dw_kyo_dispatch_dense(cpp_ctx* ctx, int cin, int ks, int in_mode, int c
   DWD_CASE(18, 5, 8, IN_F16_WHITEN, 16) DWD_CASE(18, 5, 8, IN_F32_WHITEN, 16)      // 18 channels at widths <= 32
   DWD_CASE(9, 5, 8, IN_F16_WHITEN, 4) DWD_CASE(9, 5, 8, IN_F32_WHITEN, 8) DWD_CASE(9, 5, 16, IN_F16_WHITEN, 16)
   DWD_CASE(30, 5, 32, IN_F16_WHITEN, 16)
+  DWD_CASE(18, 5, 32, IN_F16_WHITEN, 16) DWD_CASE(6, 5, 32, IN_F16_WHITEN, 16)      // 18 / 6 channels at widths 65 .. 128
   // conv2 / conv3 (f32 pooled activations in)
   DWD_CASE(10, 5, 8, IN_F32_PLAIN, 16) DWD_CASE(10, 5, 8, IN_F32_PLAIN, 8) DWD_CASE(10, 5, 16, IN_F32_PLAIN, 16)
   DWD_CASE(10, 3, 8, IN_F32_PLAIN, 16) DWD_CASE(10, 3, 8, IN_F32_PLAIN, 8) DWD_CASE(10, 3, 16, IN_F32_PLAIN, 16)

@@ -512,12 +512,14 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b, int phase = 0) {
     cpp_net* bn[2] = {a, c};
     conv_bwd = G.fn([=] { return nets_backward_conv(ctx, bn, 2, B, s1, dt, w1); }, {adz, cdz});
   }
+  DwPendingGuard pending(ctx);      // (a failure below drops what was queued)
   if (phase == 2) {
     if (conv_bwd >= 0) RC(G.ops[conv_bwd].fn());
     return flush_dw_reduce(ctx);
   }
   RC(G.run(ctx, phase == 1 ? conv_bwd : -1));
-  return phase == 1 ? (int)CPP_OK : flush_dw_reduce(ctx);      // all six dW reductions (3 layers x 2 networks) in one launch
+  if (phase == 1) { pending.keep(); return CPP_OK; }
+  return flush_dw_reduce(ctx);      // all six dW reductions (3 layers x 2 networks) in one launch
 }
 
 extern "C" int cpp_ddpg_compute_gradients(cpp_ddpg* d, cpp_batch* b) {

@@ -225,6 +225,7 @@ static int naf_compute_gradients(cpp_naf* f, cpp_batch* b) {
     const int dv = add_fc_backward(G, v, v->ws[0], B, Lh - 1, dep);
     if (v->spec.pixel) G.fn([=] { return net_backward_conv(v, v->ws[0], B, s1, dt, w1); }, {dv});
   }
+  DwPendingGuard pending(ctx);      // (a failure below drops what was queued)
   RC(G.run(ctx));
   return flush_dw_reduce(ctx);
 }

@@ -462,6 +462,7 @@ int net_backward(cpp_net* n, Workspace& w, int B, bool want_params, float* d_act
     }
   }
   if (!want_params || !n->spec.pixel) return CPP_OK;
+  DwPendingGuard pending(ctx);      // (a failure below drops what was queued)
   RC(net_backward_conv(n, w, B, state, dtype, white));
   return flush_dw_reduce(ctx);
 }

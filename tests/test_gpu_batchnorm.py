@@ -14,6 +14,7 @@ CASES = [
     pytest.param((64, 64, 3, 2, 3), 2, id="64x64x18-B2-cfg3-shape"),
     pytest.param((50, 50, 3, 2, 3), 2, id="50x50x18-B2-exps-run_98-shape"),     # 1800-byte f16 rows: 8-byte staging chunks
     pytest.param((32, 32, 3, 2, 3), 3, id="32x32x18-B3"),                      # 18 channels on the narrow (<= 32 columns) dW instance
+    pytest.param((84, 84, 3, 1, 2), 2, id="84x84x6-B2"),                       # 6 channels on the wide (65 .. 128 columns) dW instance
 ]
 
 
@@ -140,3 +141,25 @@ def test_cli_with_batch_norm(capsys):
     out = capsys.readouterr().out
     stats = [json.loads(l.split("\t", 1)[1]) for l in out.splitlines() if l.startswith("STATS")]
     assert len(stats) >= 4 and any(np.isfinite(s["mean_losses"]) for s in stats)
+
+
+def test_a_refused_geometry_leaves_the_context_usable():
+    """batch norm has no dense-dY dW instance for 3 channels: the step is refused with an error -- and must not leave the dW
+    reductions it had already queued behind (they point into that agent's buffers; the next agent on the context used to flush them
+    into freed memory: a GPU memory fault)."""
+    shape, B = (32, 32, 3, 1, 1), 4
+    agent, _ref, _ = make_pair(shape, B, True, replay_size=60, use_batch_norm=True)
+    try:
+        agent.replay_memory.fill_synthetic(40, seed=1)
+        with pytest.raises(RuntimeError, match="no kernel for"):
+            agent.train_step(B, 2)
+    finally:
+        agent.close()
+    agent, _ref, _ = make_pair((32, 32, 3, 2, 3), B, True, replay_size=60)
+    try:
+        agent.replay_memory.fill_synthetic(40, seed=1)
+        agent.train_step(B, 2); agent.train_step(B, 2)
+        agent.actor.ctx.sync()
+        assert np.isfinite(agent.critic.get_params()).all() and np.isfinite(agent.actor.get_params()).all()
+    finally:
+        agent.close()
