@@ -13,7 +13,7 @@ int conv_dw_dispatch_l1(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, con
     cpp_set_error("conv1 dW: unsupported geometry ks=%d xtw=%d", ks, xtw);
     return 1;
   }
-  DW1_CASE(6) DW1_CASE(9) DW1_CASE(18) DW1_CASE(30) DW1_CASE(3) DW1_CASE(12) DW1_CASE(24)
-  cpp_set_error("conv1 dW: unsupported channel count %d (built: 3, 6, 9, 12, 18, 24, 30)", cin);
+  DW1_CASE(6) DW1_CASE(9) DW1_CASE(18) DW1_CASE(30) DW1_CASE(3) DW1_CASE(12) DW1_CASE(24) DW1_CASE(15)
+  cpp_set_error("conv1 dW: unsupported channel count %d (built: 3, 6, 9, 12, 15, 18, 24, 30)", cin);
   return 1;
 }

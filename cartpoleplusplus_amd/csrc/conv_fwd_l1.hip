@@ -17,7 +17,7 @@ int conv_fwd_dispatch_l1(cpp_ctx* ctx, int cin, int ks, int xtw, int in_mode, in
     cpp_set_error("conv1 forward: unsupported geometry ks=%d xtw=%d", ks, xtw);
     return 1;
   }
-  L1_CASE(6) L1_CASE(9) L1_CASE(18) L1_CASE(30) L1_CASE(3) L1_CASE(12) L1_CASE(24)
-  cpp_set_error("conv1 forward: unsupported channel count %d (built: 3, 6, 9, 12, 18, 24, 30)", cin);
+  L1_CASE(6) L1_CASE(9) L1_CASE(18) L1_CASE(30) L1_CASE(3) L1_CASE(12) L1_CASE(24) L1_CASE(15)
+  cpp_set_error("conv1 forward: unsupported channel count %d (built: 3, 6, 9, 12, 15, 18, 24, 30)", cin);
   return 1;
 }

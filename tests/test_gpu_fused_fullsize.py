@@ -51,3 +51,12 @@ def test_cfg3_geometry_at_odd_batch_sizes_against_f64_oracle(B):
     launch with an even count): the same graph-replayed step, the same bar."""
     rep = fused_step_against_f64_oracle((64, 64, 3, 2, 3), B, rows=1200, graph=True, seed=9)
     print("cfg3 geometry, B=%d:" % B, rep)
+
+
+@pytest.mark.parametrize("cams,reps", [(1, 1), (1, 2), (1, 3), (2, 2), (1, 4), (1, 5), (2, 3), (2, 4), (2, 5)],
+                         ids=lambda v: str(v))
+def test_every_channel_count_the_flags_can_produce(cams, reps):
+    """--num-cameras 1..2 x --action-repeats 1..5 (bullet_cartpole.py:21-26, :121-123): 3, 6, 9, 12, 15, 18, 24, 30 channels, at a
+    render the generic and the f16-pipe kernels both see (40 x 40, odd pooled sizes further down)."""
+    rep = fused_step_against_f64_oracle((40, 40, 3, cams, reps), 6, rows=150, graph=True, seed=cams + 3 * reps)
+    print("%d channels:" % (3 * cams * reps), rep)
