@@ -302,3 +302,44 @@ def test_failed_add_episode_leaves_the_memory_unchanged():
     b = rm.batch(idxs=np.arange(10))
     assert np.array_equal(b.state_2[:4], np.stack([g[2] for g in good[:4]]))
     rm.close()
+
+
+@pytest.mark.parametrize("buffer_size,load_factor,seed", [(3, 2.0, 0), (7, 1.5, 1), (20, 1.5, 2), (43, 1.5, 3), (5, 3.0, 4)])
+def test_random_episodes_differential_against_the_oracle_memory(buffer_size, load_factor, seed):
+    """random episode streams (lengths 1..12, so longer than the small buffers: several wraps inside one add_episode) into the device
+    memory and into oracle/replay_np.py (the line-by-line restatement of replay_memory.py:63-118): after every episode the host
+    mirrors -- insert, full, both index columns, action / reward / mask, the FIFO of free state slots -- and the batch of ALL rows
+    gathered on the device must be identical."""
+    from cartpoleplusplus_amd.replay_memory import ReplayMemory
+    rng = np.random.default_rng(100 + seed)
+    shape, A = (4, 4, 3, 1, 2), 2
+    rm = ReplayMemory(buffer_size=buffer_size, state_shape=shape, action_dim=A, load_factor=load_factor)
+    orm = OracleReplayMemory(buffer_size, shape, A, load_factor=load_factor)
+    try:
+        for ep in range(60):
+            n = int(rng.integers(1, 13))
+            mk = lambda: (rng.integers(0, 256, shape).astype(np.float16) / np.float16(255))
+            s0 = mk()
+            seq = [(rng.uniform(-1, 1, (1, A)).astype(np.float32), float(rng.integers(-3, 4)), mk()) for _ in range(n)]
+            try:
+                orm.add_episode(s0, seq)
+            except (AssertionError, IndexError):
+                # the reference fails (assert / pop from the empty free list, replay_memory.py:65,77-79,104) when an episode needs
+                # more state slots than are free -- half way through, so its own state is no longer comparable.  The device memory
+                # must refuse the episode too (and, unlike the reference, stays as it was: test_failed_add_episode_...)
+                with pytest.raises(Exception):
+                    rm.add_episode(s0, seq)
+                break
+            rm.add_episode(s0, seq)
+            assert (rm.insert, rm.full, rm.size()) == (orm.insert, orm.full, orm.size())
+            k = orm.size()
+            assert np.array_equal(rm.state_1_idx[:k], orm.state_1_idx[:k]) and np.array_equal(rm.state_2_idx[:k], orm.state_2_idx[:k])
+            assert np.array_equal(rm.action[:k], orm.action[:k]) and np.array_equal(rm.reward[:k], orm.reward[:k])
+            assert np.array_equal(rm.terminal_mask[:k], orm.terminal_mask[:k])
+            assert list(rm.state_free_slots) == list(orm.state_free_slots)
+            idxs = np.arange(k)
+            b, ob = rm.batch(idxs=idxs), orm.batch(idxs=idxs)
+            for x, y in zip((b.state_1, b.action, b.reward, b.terminal_mask, b.state_2), (ob.state_1, ob.action, ob.reward, ob.terminal_mask, ob.state_2)):
+                assert np.array_equal(np.asarray(x), np.asarray(y))
+    finally:
+        rm.close()
