@@ -20,6 +20,7 @@ import collections
 import ctypes as C
 import datetime
 import json
+import os
 import sys
 import time
 
@@ -76,6 +77,13 @@ def build_parser():
     a('--replay-store', type=str, default="f16", choices=["f16", "u8"],
       help="element type of the replay memory's state store: f16 as the reference, or u8 pixel codes "
            "(identical batches for rendered frames, half the memory)")
+    a('--data-parallel', action='store_true',
+      help="one actor-learner per GPU (launch with torch.distributed.run): own environment and replay shard per process, the "
+           "gradients of every minibatch all-reduced over RCCL (cartpoleplusplus_amd/distributed.py)")
+    a('--sync-every', type=int, default=1,
+      help="--data-parallel: 1 = gradient all-reduce per minibatch; k > 1 = k local minibatch updates, then parameter averaging")
+    a('--overlap-allreduce', action='store_true',
+      help="--data-parallel: reduce the fully connected layers' gradients beside the conv backward")
     a('--synthetic-env', action='store_true', help="random-frame stand-in env (pybullet stays optional)")
     return parser
 
@@ -380,6 +388,10 @@ class DeepDeterministicPolicyGradientAgent(object):
         the first call): batches_per_step x {sample+gather, actor update, critic update}, then both
         target soft updates.  idxs: optional (batches_per_step*batch_size) rows instead of Philox."""
         t = self.trainer
+        if idxs is None and getattr(opts, "data_parallel", False):      # one learner of N: the collective step (distributed.py)
+            self._dp_learner(batch_size).train_step(batches_per_step)
+            self.train_steps += 1
+            return
         rows = None
         if idxs is not None:
             rows = np.ascontiguousarray(np.asarray(idxs).reshape(-1), dtype=np.int32)
@@ -388,6 +400,15 @@ class DeepDeterministicPolicyGradientAgent(object):
         check(lib.cpp_ddpg_train_step(t.handle, self.replay_memory.handle, int(batch_size),
                                       int(batches_per_step), ptr(rows), int(opts.sample_seed)))
         self.train_steps += 1
+
+    def _dp_learner(self, batch_size):
+        cur = getattr(self, "_learner", None)
+        if cur is None or cur.B != int(batch_size):
+            from . import distributed
+            if cur is not None:
+                cur.close()
+            self._learner = distributed.learner_for_agent(self, opts, batch_size)
+        return self._learner
 
     def run_training(self, max_num_actions, max_run_time, batch_size, batches_per_step, saver_util):
         start_time = time.time()
@@ -471,6 +492,9 @@ class DeepDeterministicPolicyGradientAgent(object):
         sys.stdout.flush()
 
     def close(self):
+        if getattr(self, "_learner", None) is not None:
+            self._learner.close()
+            self._learner = None
         if self.critic._ddpg is not None:
             self.critic._ddpg.close()
         for net in (self.actor, self.critic, self.target_actor, self.target_critic):
@@ -497,7 +521,7 @@ def main(argv=None):
     agent = DeepDeterministicPolicyGradientAgent(env=env)
     # either load the latest ckpt or init variables (ddpg_cartpole.py:419-424)
     saver_util = None
-    if opts.ckpt_dir is not None:
+    if opts.ckpt_dir is not None and not (opts.data_parallel and int(os.environ.get("RANK", "0")) != 0):      # rank 0 keeps the checkpoints
         saver_util = util.SaverUtil(agent, opts.ckpt_dir, opts.ckpt_freq)
     else:
         agent.initialise_variables()

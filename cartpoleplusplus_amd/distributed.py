@@ -245,3 +245,23 @@ def make_learner(agent, batch_size, seed, sync_every=1, overlap=False, always=Fa
         import sys
         sys.stderr.write("cartpoleplusplus_amd: cpp_comm_create failed (%s); falling back to torch.distributed's all_reduce\n" % e)
         return TorchCollectiveLearner(agent, batch_size, seed, torch_stream, always)
+
+
+def learner_for_agent(agent, opts, batch_size):
+    """the learner behind `--data-parallel` of ddpg_cartpole.py / naf_cartpole.py: one actor-learner per process (launched by
+    torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE in the environment; a plain run is a world of one), own environment and
+    own replay shard, the sampler seeded per rank.  torch.distributed only carries the communicator id (NativeLearner)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = 0
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+            torch.cuda.set_device(local_rank)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        rank = dist.get_rank()
+    return make_learner(agent, batch_size, seed=int(opts.sample_seed) + rank, sync_every=int(opts.sync_every),
+                        overlap=bool(opts.overlap_allreduce), always=True)

@@ -12,6 +12,7 @@ the loss is not finite.
 """
 import argparse
 import collections
+import os
 import ctypes as C
 import datetime
 import json
@@ -61,6 +62,13 @@ def build_parser():
     a('--replay-store', type=str, default="f16", choices=["f16", "u8"],
       help="element type of the replay memory's state store: f16 as the reference, or u8 pixel codes "
            "(identical batches for rendered frames, half the memory)")
+    a('--data-parallel', action='store_true',
+      help="one actor-learner per GPU (launch with torch.distributed.run): own environment and replay shard per process, the "
+           "gradients of every minibatch all-reduced over RCCL (cartpoleplusplus_amd/distributed.py)")
+    a('--sync-every', type=int, default=1,
+      help="--data-parallel: 1 = gradient all-reduce per minibatch; k > 1 = k local minibatch updates, then parameter averaging")
+    a('--overlap-allreduce', action='store_true',
+      help="--data-parallel: reduce the fully connected layers' gradients beside the conv backward")
     a('--synthetic-env', action='store_true', help="random-frame stand-in env")
     return parser
 
@@ -263,6 +271,15 @@ class NormalizedAdvantageFunctionAgent(object):
 
     def train_step(self, batch_size, batches_per_step, idxs=None):
         """the inner step naf_cartpole.py:367-373 as one device-side sequence (hipGraph after the first call)."""
+        if idxs is None and getattr(opts, "data_parallel", False):      # one learner of N: the collective step (distributed.py)
+            cur = getattr(self, "_learner", None)
+            if cur is None or cur.B != int(batch_size):
+                from . import distributed
+                if cur is not None:
+                    cur.close()
+                self._learner = distributed.learner_for_agent(self, opts, batch_size)
+            self._learner.train_step(batches_per_step)
+            return
         rows = None
         if idxs is not None:
             rows = np.ascontiguousarray(np.asarray(idxs).reshape(-1), dtype=np.int32)
@@ -343,6 +360,9 @@ class NormalizedAdvantageFunctionAgent(object):
         sys.stdout.flush()
 
     def close(self):
+        if getattr(self, "_learner", None) is not None:
+            self._learner.close()
+            self._learner = None
         self.naf.close()
         self.value_net.close()
         self.target_value_net.close()
@@ -356,7 +376,7 @@ def main(argv=None):
     env = make_env(opts)
     agent = NormalizedAdvantageFunctionAgent(env=env)
     saver_util = None
-    if opts.ckpt_dir is not None:
+    if opts.ckpt_dir is not None and not (opts.data_parallel and int(os.environ.get("RANK", "0")) != 0):      # rank 0 keeps the checkpoints
         saver_util = util.SaverUtil(agent, opts.ckpt_dir, opts.ckpt_freq)
     else:
         agent.initialise_variables()

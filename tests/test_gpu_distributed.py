@@ -150,3 +150,22 @@ def test_communicator_in_a_fresh_process(torch_first):
         "assert c.max_over_ranks(2.25) == 2.25; c.barrier(); c.close(); print('COMM_OK')\n")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert r.returncode == 0 and "COMM_OK" in r.stdout.decode(), r.stdout.decode()[-1500:]
+
+
+@pytest.mark.parametrize("which,extra", [("ddpg", []), ("ddpg", ["--sync-every", "3"]), ("ddpg", ["--overlap-allreduce"]), ("naf", [])],
+                         ids=["ddpg", "ddpg-periodic", "ddpg-overlap", "naf"])
+def test_cli_data_parallel_mode_as_a_world_of_one(which, extra, capsys):
+    """`--data-parallel` of the agents' own main(): rollouts on the stand-in env, the replay shard in HBM, every inner step through the
+    collective learner (a plain run is a world of one: real RCCL calls, no torch.distributed)."""
+    import json
+    if which == "ddpg":
+        from cartpoleplusplus_amd import ddpg_cartpole as M
+    else:
+        from cartpoleplusplus_amd import naf_cartpole as M
+    M.main(["--synthetic-env", "--use-raw-pixels", "--render-width", "16", "--render-height", "16", "--batch-size", "8",
+            "--replay-memory-size", "120", "--replay-memory-burn-in", "20", "--max-episode-len", "12", "--max-num-actions", "70",
+            "--data-parallel"] + extra)
+    out = capsys.readouterr().out
+    stats = [json.loads(l.split("\t", 1)[1]) for l in out.splitlines() if l.startswith("STATS")]
+    assert len(stats) >= 4 and any(np.isfinite(s["mean_losses"]) for s in stats), out[-500:]
+    assert stats[-1]["replay_memory_stats"][">batch"] > 0
