@@ -1,0 +1,19 @@
+"""random interleavings of the public operations on one agent (profiles/diag/op_fuzz.py): episodes added with evictions, fused steps
+at changing batch sizes, data-parallel steps, the reference's op-by-op calls, inference, debug fetches -- nothing may fault, raise or
+go non-finite, and the replay bookkeeping follows the oracle memory throughout."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_operation_fuzz(seed):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "diag", "op_fuzz.py"), str(seed)], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "FUZZ seed %d" % seed in out and " ok " in out.splitlines()[-1], out[-1500:]
