@@ -18,3 +18,12 @@ def test_operation_fuzz(seed):
     out = r.stdout.decode()
     done = [l for l in out.splitlines() if l.startswith("FUZZ seed %d " % seed)]
     assert r.returncode == 0 and len(done) == 1 and " ok " in done[0], out[-1500:]
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_operation_fuzz_naf(seed):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "diag", "op_fuzz_naf.py"), str(seed)], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode()
+    done = [l for l in out.splitlines() if l.startswith("FUZZNAF seed %d " % seed)]
+    assert r.returncode == 0 and len(done) == 1 and " ok " in done[0], out[-1500:]
