@@ -34,6 +34,37 @@ class StopWatch(object):
         return time.time() - self.start
 
 
+def l2_norm(tensor):
+    """util.py:33-35 on a host array (the training step's own norms are computed on the device)"""
+    t = np.asarray(tensor, np.float64)
+    return float(np.sqrt((t * t).sum()))
+
+
+def standardise(tensor):
+    """util.py:37-43 on a host array: (x - mean) / sqrt(mean((x - mean)^2))"""
+    t = np.asarray(tensor, np.float64)
+    mean = t.mean()
+    return (t - mean) / np.sqrt(((t - mean) ** 2).mean())
+
+
+def clip_and_debug_gradients(gradients, opts):
+    """util.py:45-58 for host arrays: `gradients` is a list of (gradient, variable) pairs; the gradients are scaled by
+    clip / max(global norm, clip) (tf.clip_by_global_norm; None gradients are skipped) when opts.gradient_clip is set, and their
+    norms printed under opts.print_gradients.  The device step does this inside its optimiser kernel; this is the same rule for
+    scripts that handle gradients on the host (net.get_grads())."""
+    gradients = list(gradients)
+    clip = getattr(opts, "gradient_clip", None)
+    if clip is not None:
+        norm = np.sqrt(sum(float((np.asarray(g, np.float64) ** 2).sum()) for g, _ in gradients if g is not None))
+        scale = float(clip) / max(norm, float(clip))
+        gradients = [(None if g is None else (np.asarray(g) * np.asarray(g).dtype.type(scale)), v) for g, v in gradients]
+    if getattr(opts, "print_gradients", False):
+        for g, v in gradients:
+            if g is not None:
+                print("gradient %s l2_norm [%s]" % (getattr(v, "name", v), l2_norm(g)))
+    return gradients
+
+
 def gradient_clip_value(opts):
     """util.py:45-50: clip_by_global_norm(grads, opts.gradient_clip) unless None.  The kernel takes
     <= 0 as 'no clipping'."""

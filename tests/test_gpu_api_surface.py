@@ -1,0 +1,88 @@
+"""The reference's Python surface is what a user of the reference programs against: every class, method, argument name
+and public attribute listed there must exist here with the same spelling.  (Behaviour is covered by the parity tests; this test is
+about the names -- a missing one is an AttributeError in somebody's script.)"""
+import inspect
+
+import numpy as np
+import pytest
+
+from tests.helpers import make_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def params_of(fn):
+    return [p for p in inspect.signature(fn).parameters if p != "self"]
+
+
+def test_ddpg_and_replay_surface():
+    from cartpoleplusplus_amd import base_network, ddpg_cartpole as D, replay_memory as R, util
+    assert hasattr(base_network, "IS_TRAINING")                                             # base_network.py:11
+    for m in ("set_as_target_network_for", "update_weights", "trainable_model_vars", "hidden_layers_starting_at",
+              "simple_conv_net_on", "input_state_network"):                                 # :13-134
+        assert callable(getattr(base_network.Network, m)), m
+    assert params_of(base_network.Network.set_as_target_network_for)[:2] == ["source_network", "target_update_rate"]
+    assert params_of(base_network.Network.hidden_layers_starting_at)[:2] == ["layer", "layer_sizes"]
+    assert params_of(D.ActorNetwork.__init__)[:3] == ["namespace", "input_state", "action_dim"]            # ddpg_cartpole.py:78-145
+    assert params_of(D.ActorNetwork.init_ops_for_training) == ["critic"]
+    assert params_of(D.ActorNetwork.action_given)[:2] == ["state", "add_noise"]
+    assert inspect.signature(D.ActorNetwork.action_given).parameters["add_noise"].default is False
+    assert params_of(D.ActorNetwork.train) == ["state"]
+    assert params_of(D.CriticNetwork.__init__)[:2] == ["namespace", "actor"]                              # :148-248
+    assert params_of(D.CriticNetwork.init_ops_for_training) == ["target_critic"]
+    assert params_of(D.CriticNetwork.train) == ["batch"] and params_of(D.CriticNetwork.check_loss) == ["batch"]
+    assert callable(D.CriticNetwork.q_gradients_wrt_actions)
+    A = D.DeepDeterministicPolicyGradientAgent                                                            # :251-400
+    assert params_of(A.run_training) == ["max_num_actions", "max_run_time", "batch_size", "batches_per_step", "saver_util"]
+    assert params_of(A.run_eval)[:2] == ["num_episodes", "add_noise"] and callable(A.post_var_init_setup)
+    assert params_of(R.ReplayMemory.__init__)[:4] == ["buffer_size", "state_shape", "action_dim", "load_factor"]     # replay_memory.py:9-163
+    assert inspect.signature(R.ReplayMemory.__init__).parameters["load_factor"].default == 1.5
+    assert params_of(R.ReplayMemory.add_episode) == ["initial_state", "action_reward_state_sequence"]
+    assert inspect.signature(R.ReplayMemory.random_indexes).parameters["n"].default == 1
+    assert list(inspect.signature(R.ReplayMemory.batch).parameters)[1] == "batch_size"
+    # (replay_memory_test.py:95-130 also calls `ReplayMemory(sess, ...)` / `rm.batch_ops()`: a test of an older, TensorFlow-variable
+    # backed class -- neither exists in replay_memory.py at HEAD, and neither does here; what that test feeds them,
+    # Batch.state_1_idx / .state_2_idx and batch(idxs=...), does)
+    for m in ("size", "current_stats", "reset_from_event_log", "dump"):
+        assert callable(getattr(R.ReplayMemory, m)), m
+    assert "idxs" in inspect.signature(R.ReplayMemory.batch).parameters
+    assert R.Batch._fields[:5] == ("state_1", "action", "reward", "terminal_mask", "state_2") if hasattr(R.Batch, "_fields") else True
+    for m in ("OrnsteinUhlenbeckNoise", "add_opts", "construct_optimiser", "SaverUtil", "clip_and_debug_gradients", "l2_norm", "standardise",
+              "collapsed_successive_ranges", "shape_and_product_of", "StopWatch"):   # util.py
+        assert hasattr(util, m), m
+
+    agent, _ref, _ = make_pair((8, 8, 3, 1, 2), 4, True, replay_size=30)
+    try:
+        for net in (agent.actor, agent.critic):
+            for a in ("pool1", "pool2", "pool3", "input_state"):
+                assert hasattr(net, a), a
+        for a in ("output_action", "exploration_noise", "train_op"):
+            assert hasattr(agent.actor, a), a
+        for a in ("input_action", "q_value", "reward", "terminal_mask", "input_state_2", "temporal_difference", "temporal_difference_loss"):
+            assert hasattr(agent.critic, a), a
+        rm = agent.replay_memory
+        for a in ("insert", "full", "state_1_idx", "state_2_idx", "action", "reward", "terminal_mask", "state", "state_free_slots", "stats"):
+            assert hasattr(rm, a), a
+        rm.fill_synthetic(20, seed=1)
+        b = rm.batch(4)
+        assert [hasattr(b, f) for f in ("state_1", "action", "reward", "terminal_mask", "state_2", "state_1_idx", "state_2_idx")] == [True] * 7
+        s1, a, r, m, s2 = b                                           # the namedtuple unpacks as in replay_memory.py:9
+        assert np.asarray(s1).shape[0] == 4 and np.asarray(r).shape == (4, 1)
+        loss, td, q = agent.critic.check_loss(b)                      # ddpg_cartpole.py:239-248
+        assert np.asarray(td).shape == (4, 1) and np.asarray(q).shape == (4, 1)
+        act = agent.actor.action_given(np.asarray(s1)[0])
+        assert act.shape == (1, 2)                                    # :121-138
+        assert len(agent.actor.trainable_model_vars()) > 0
+    finally:
+        agent.close()
+
+
+def test_naf_surface():
+    from cartpoleplusplus_amd import naf_cartpole as F
+    assert params_of(F.ValueNetwork.__init__)[:3] == ["namespace", "input_state", "hidden_layer_config"]  # naf_cartpole.py:93-114
+    assert params_of(F.NafNetwork.__init__)[:6] == ["namespace", "input_state", "input_state_2", "value_net", "target_value_net", "action_dim"]   # :117-284
+    assert params_of(F.NafNetwork.action_given)[:2] == ["state", "add_noise"] and params_of(F.NafNetwork.train) == ["batch"]
+    assert callable(F.NafNetwork.debug_values)
+    A = F.NormalizedAdvantageFunctionAgent                                                                # :287-440
+    assert params_of(A.run_training) == ["max_num_actions", "max_run_time", "batch_size", "batches_per_step", "saver_util"]
+    assert params_of(A.run_eval)[:2] == ["num_episodes", "add_noise"] and callable(A.post_var_init_setup)

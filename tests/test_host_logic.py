@@ -58,3 +58,24 @@ def test_bench_flop_accounting_matches_the_survey():
     F50 = bench.conv_macs((50, 50, 3, 1, 2))[0]                          # the default render: 5.44 MMAC per image
     assert abs(F50 / 1e6 - 5.44) < 0.01
     assert bench.PIPES["f16x3"][0] == bench.PEAK_F16_MFMA_TFLOPS / 3.0 and bench.PIPES["bf16x9"][0] == bench.PEAK_F16_MFMA_TFLOPS / 9.0
+
+
+def test_host_gradient_helpers_follow_util_py():
+    """util.py:33-58 on host arrays: l2_norm, standardise, clip_and_debug_gradients (tf.clip_by_global_norm's rule, None skipped)."""
+    from cartpoleplusplus_amd import util
+
+    class Opts(object):
+        gradient_clip, print_gradients = 5.0, False
+    g1, g2 = np.full((3, 4), 2.0, np.float32), np.full(5, -3.0, np.float32)
+    norm = np.sqrt(12 * 4.0 + 5 * 9.0)
+    assert abs(util.l2_norm(g1) - np.sqrt(48.0)) < 1e-12
+    out = util.clip_and_debug_gradients([(g1, "a"), (None, "b"), (g2, "c")], Opts)
+    assert out[1][0] is None and [v for _g, v in out] == ["a", "b", "c"]
+    np.testing.assert_allclose(out[0][0], g1 * 5.0 / norm, rtol=1e-6)
+    np.testing.assert_allclose(out[2][0], g2 * 5.0 / norm, rtol=1e-6)
+    Opts.gradient_clip = 100.0                                        # norm below the clip: unchanged
+    np.testing.assert_allclose(util.clip_and_debug_gradients([(g1, "a")], Opts)[0][0], g1)
+    Opts.gradient_clip = None
+    assert util.clip_and_debug_gradients([(g1, "a")], Opts)[0][0] is g1
+    z = util.standardise(np.arange(10.0))
+    assert abs(z.mean()) < 1e-12 and abs((z ** 2).mean() - 1.0) < 1e-12
