@@ -34,6 +34,28 @@ np.set_printoptions(precision=5, threshold=10000, suppress=True, linewidth=10000
 VERBOSE_DEBUG = False
 
 
+def toggle_verbose_debug(signal, frame):           # SIGUSR1 (the reference installs the same two handlers at import)
+    global VERBOSE_DEBUG
+    VERBOSE_DEBUG = not VERBOSE_DEBUG
+
+
+DUMP_WEIGHTS = False
+
+
+def set_dump_weights(signal, frame):               # SIGUSR2: run_training dumps the weights after the current episode
+    global DUMP_WEIGHTS
+    DUMP_WEIGHTS = True
+
+
+def _install_signal_handlers():
+    import signal
+    try:
+        signal.signal(signal.SIGUSR1, toggle_verbose_debug)
+        signal.signal(signal.SIGUSR2, set_dump_weights)
+    except ValueError:                             # not the main thread (an embedding application): the toggles stay callable
+        pass
+
+
 def build_parser():
     parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
     a = parser.add_argument
@@ -466,6 +488,10 @@ class DeepDeterministicPolicyGradientAgent(object):
                 saver_util.save_if_required()
             if VERBOSE_DEBUG or n % 10 == 0:
                 self.run_eval(1)
+            global DUMP_WEIGHTS
+            if DUMP_WEIGHTS:
+                self.debug_dump_network_weights()
+                DUMP_WEIGHTS = False
 
             num_actions_taken += len(rewards)
             if max_num_actions > 0 and num_actions_taken > max_num_actions:
@@ -474,6 +500,17 @@ class DeepDeterministicPolicyGradientAgent(object):
                 break
             if opts.dont_do_rollouts and max_num_actions <= 0 and max_run_time <= 0:
                 break
+
+    def debug_dump_network_weights(self):
+        fn = "/tmp/weights.%s" % time.time()
+        with open(fn, "w") as f:
+            f.write("DUMP time %s\n" % time.time())
+            for net in self.networks():
+                for var in net.trainable_model_vars():
+                    f.write("VAR %s %s\n" % (var.name, tuple(var.get_shape())))
+                    f.write("%s\n" % var.eval())
+        print("weights written to", fn)
+        return fn
 
     def run_eval(self, num_episodes, add_noise=False):
         """ run num_episodes of eval and output episode length and rewards """
@@ -515,6 +552,7 @@ def make_env(o):
 
 
 def main(argv=None):
+    _install_signal_handlers()
     set_opts(build_parser().parse_args(argv))
     sys.stderr.write("%s\n" % opts)
     env = make_env(opts)

@@ -27,6 +27,28 @@ from ._lib import lib, check, ptr
 VERBOSE_DEBUG = False
 
 
+def toggle_verbose_debug(signal, frame):           # SIGUSR1 (the reference installs the same two handlers at import)
+    global VERBOSE_DEBUG
+    VERBOSE_DEBUG = not VERBOSE_DEBUG
+
+
+DUMP_WEIGHTS = False
+
+
+def set_dump_weights(signal, frame):               # SIGUSR2: run_training dumps the weights after the current episode
+    global DUMP_WEIGHTS
+    DUMP_WEIGHTS = True
+
+
+def _install_signal_handlers():
+    import signal
+    try:
+        signal.signal(signal.SIGUSR1, toggle_verbose_debug)
+        signal.signal(signal.SIGUSR2, set_dump_weights)
+    except ValueError:                             # not the main thread (an embedding application): the toggles stay callable
+        pass
+
+
 def build_parser():
     parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
     a = parser.add_argument
@@ -57,6 +79,9 @@ def build_parser():
     a('--use-raw-pixels', action='store_true', help="use raw pixels as state instead of poses")
     a('--render-width', type=int, default=50, help="if --use-raw-pixels render with this width")
     a('--render-height', type=int, default=50, help="if --use-raw-pixels render with this height")
+    a('--gpu-mem-fraction', type=float, default=None,
+      help="accepted for command-line compatibility and ignored (a TensorFlow session option in the reference: "
+           "the replay memory and the networks size their own HBM allocations here)")
     a('--host-rng-sampling', action='store_true', help="draw minibatch rows with numpy's RNG like the reference")
     a('--sample-seed', type=int, default=0, help="seed of the device-side minibatch sampler")
     a('--replay-store', type=str, default="f16", choices=["f16", "u8"],
@@ -338,6 +363,10 @@ class NormalizedAdvantageFunctionAgent(object):
                 saver_util.save_if_required()
             if VERBOSE_DEBUG or n % 10 == 0:
                 self.run_eval(1)
+            global DUMP_WEIGHTS
+            if DUMP_WEIGHTS:
+                self.debug_dump_network_weights()
+                DUMP_WEIGHTS = False
             num_actions_taken += len(rewards)
             if max_num_actions > 0 and num_actions_taken > max_num_actions:
                 break
@@ -345,6 +374,17 @@ class NormalizedAdvantageFunctionAgent(object):
                 break
             if opts.dont_do_rollouts and max_num_actions <= 0 and max_run_time <= 0:
                 break
+
+    def debug_dump_network_weights(self):
+        fn = "/tmp/weights.%s" % time.time()
+        with open(fn, "w") as f:
+            f.write("DUMP time %s\n" % time.time())
+            for net in self.networks():
+                for var in net.trainable_model_vars():
+                    f.write("VAR %s %s\n" % (var.name, tuple(var.get_shape())))
+                    f.write("%s\n" % var.eval())
+        print("weights written to", fn)
+        return fn
 
     def run_eval(self, num_episodes, add_noise=False):
         for i in range(num_episodes):
@@ -370,6 +410,7 @@ class NormalizedAdvantageFunctionAgent(object):
 
 
 def main(argv=None):
+    _install_signal_handlers()
     set_opts(build_parser().parse_args(argv))
     sys.stderr.write("%s\n" % opts)
     from .ddpg_cartpole import make_env

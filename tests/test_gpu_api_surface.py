@@ -86,3 +86,30 @@ def test_naf_surface():
     A = F.NormalizedAdvantageFunctionAgent                                                                # :287-440
     assert params_of(A.run_training) == ["max_num_actions", "max_run_time", "batch_size", "batches_per_step", "saver_util"]
     assert params_of(A.run_eval)[:2] == ["num_episodes", "add_noise"] and callable(A.post_var_init_setup)
+
+
+def test_debug_toggles_and_weight_dump(tmp_path):
+    """ddpg_cartpole.py:65-75,373-376,402-409: SIGUSR1 flips VERBOSE_DEBUG, SIGUSR2 requests a weight dump, which run_training
+    writes after the current episode; --gpu-mem-fraction (naf_cartpole.py:64) is accepted."""
+    import os
+    import signal
+    import time
+    from cartpoleplusplus_amd import ddpg_cartpole as D, naf_cartpole as F
+    assert F.build_parser().parse_args(["--gpu-mem-fraction", "0.5"]).gpu_mem_fraction == 0.5
+    D._install_signal_handlers()
+    before = D.VERBOSE_DEBUG
+    os.kill(os.getpid(), signal.SIGUSR1); time.sleep(0.05)
+    assert D.VERBOSE_DEBUG is (not before)
+    os.kill(os.getpid(), signal.SIGUSR1); time.sleep(0.05)
+    assert D.VERBOSE_DEBUG is before
+    os.kill(os.getpid(), signal.SIGUSR2); time.sleep(0.05)
+    assert D.DUMP_WEIGHTS is True
+    D.DUMP_WEIGHTS = False
+    agent, _ref, _ = make_pair((8, 8, 3, 1, 2), 4, True, replay_size=30)
+    try:
+        fn = agent.debug_dump_network_weights()
+        text = open(fn).read()
+        os.remove(fn)
+        assert text.startswith("DUMP time ") and "VAR actor/conv1/weights:0 (5, 5, 6, 10)" in text and "VAR target_critic/q_value/biases:0 (1,)" in text
+    finally:
+        agent.close()
