@@ -72,6 +72,13 @@ class Variable(object):
         self.net.set_params(flat)
 
 
+def _forward_for_debug(net, state):
+    fwd = getattr(net, "forward", None)
+    if fwd is None:
+        raise NotImplementedError("%s has no host-fed forward(states)" % type(net).__name__)
+    fwd(np.asarray(state)[None])
+
+
 class Network(object):
     """Common class for handling ops for making / updating target networks."""
 
@@ -211,6 +218,24 @@ class Network(object):
             out.append(Variable(self, "%s/%s:0" % (self.namespace, name.value.decode()),
                                 [shape[k] for k in range(rank.value)], off.value))
         return out
+
+    # ---- debug renderings (base_network.py:136-154) ----------------------------------------------------------------------------
+    def render_convnet_activations(self, activations, filename_base):
+        from . import util
+        activations = np.array(activations, np.float32)
+        _batch, height, width, num_filters = activations.shape
+        for f_idx in range(num_filters):
+            single_channel = activations[0, :, :, f_idx]
+            peak = np.max(single_channel)
+            single_channel = single_channel / peak if peak > 0 else single_channel
+            util.write_img_to_png_file(np.repeat(single_channel[:, :, None], 3, axis=2), "%s_f%02d.png" % (filename_base, f_idx))
+
+    def render_all_convnet_activations(self, step, input_state_placeholder, state):
+        """the three pooled activations of ONE state (inference mode), one grey PNG per filter under /tmp"""
+        _forward_for_debug(self, state)
+        filename_base = "/tmp/activation_s%03d" % step
+        for k, pool in enumerate((self.pool1, self.pool2, self.pool3)):
+            self.render_convnet_activations(pool.eval(1), filename_base + "_p%d" % k)
 
     def close(self):
         if self.handle:

@@ -198,3 +198,40 @@ class OrnsteinUhlenbeckNoise(object):
         self.state += self.sigma * np.random.randn(self.dim)
         self.state = np.minimum(self.max_magnitude, self.state)
         return np.copy(self.state)
+
+
+# ---- debug renderings (util.py:159-194; the reference calls them from a disabled branch of naf_cartpole.run_eval) -----------------
+def write_img_to_png_file(img, filename):
+    """img: (height, width, 3) floats in [0, 1] (what plt.imsave takes in the reference) or uint8"""
+    from .event_log import rgb_to_png
+    a = np.asarray(img)
+    a = a.astype(np.float64) / 255.0 if a.dtype == np.uint8 else np.nan_to_num(a.astype(np.float64))
+    print("writing", filename)
+    with open(filename, "wb") as f:
+        f.write(rgb_to_png(a))
+
+
+def render_state_to_png(step, state, split_channels=False):
+    state = np.asarray(state, np.float32)
+    height, width, num_channels, num_cameras, num_repeats = state.shape
+    for c_idx in range(num_cameras):
+        for r_idx in range(num_repeats):
+            if split_channels:
+                for channel in range(num_channels):
+                    img = np.zeros((height, width, 3))
+                    img[:, :, channel] = state[:, :, channel, c_idx, r_idx]
+                    write_img_to_png_file(img, "/tmp/state_s%03d_ch%s_c%s_r%s.png" % (step, channel, c_idx, r_idx))
+            else:
+                write_img_to_png_file(state[:, :, 0:3, c_idx, r_idx], "/tmp/state_s%03d_c%s_r%s.png" % (step, c_idx, r_idx))
+
+
+def render_action_to_png(step, action):
+    """a 50 x 50 grey tile with a black line from the centre to 25 (1 + action) -- drawn without PIL"""
+    img = np.full((50, 50, 3), 50, np.uint8)
+    lx, ly = int(25 + (action[0][0] * 25)), int(25 + (action[0][1] * 25))
+    n = max(abs(lx - 25), abs(ly - 25), 1)
+    for i in range(n + 1):
+        x, y = int(round(25 + (lx - 25) * i / n)), int(round(25 + (ly - 25) * i / n))
+        if 0 <= x < 50 and 0 <= y < 50:
+            img[y, x] = 0
+    write_img_to_png_file(img, "/tmp/action_%03d.png" % step)

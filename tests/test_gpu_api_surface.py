@@ -113,3 +113,29 @@ def test_debug_toggles_and_weight_dump(tmp_path):
         assert text.startswith("DUMP time ") and "VAR actor/conv1/weights:0 (5, 5, 6, 10)" in text and "VAR target_critic/q_value/biases:0 (1,)" in text
     finally:
         agent.close()
+
+
+def test_debug_renderings(tmp_path, capsys):
+    """base_network.py:136-154 / util.py:159-194: PNGs of the pooled activations, of a state and of an action under /tmp."""
+    import glob
+    import os
+    from cartpoleplusplus_amd import util
+    from cartpoleplusplus_amd.event_log import png_to_rgb
+    agent, _ref, _ = make_pair((16, 16, 3, 2, 2), 4, True, replay_size=30)
+    made = []
+    try:
+        agent.replay_memory.fill_synthetic(10, seed=1)
+        state = np.asarray(agent.replay_memory.state[0], np.float32)
+        agent.actor.render_all_convnet_activations(991, None, state)
+        util.render_state_to_png(991, state)
+        util.render_action_to_png(991, np.array([[0.5, -0.5]], np.float32))
+        made = glob.glob("/tmp/activation_s991_p*_f*.png") + glob.glob("/tmp/state_s991_c*_r*.png") + ["/tmp/action_991.png"]
+        assert len(glob.glob("/tmp/activation_s991_p0_f*.png")) == 10 and len(glob.glob("/tmp/state_s991_c*_r*.png")) == 4
+        img = png_to_rgb(open("/tmp/state_s991_c1_r0.png", "rb").read())
+        np.testing.assert_allclose(img[:, :, :3], state[:, :, :, 1, 0], atol=1.0 / 255)
+        assert png_to_rgb(open("/tmp/activation_s991_p0_f03.png", "rb").read()).shape[:2] == (8, 8)
+    finally:
+        for f in made:
+            if os.path.exists(f):
+                os.remove(f)
+        agent.close()
