@@ -9,7 +9,9 @@ PNG bytes are read / written by a small zlib-based codec for the 8-bit RGB(A), n
 matplotlib's imsave produces (event_log.py:10-14), so neither matplotlib nor PIL is required.
 """
 import gzip
+import os
 import struct
+import sys
 import zlib
 
 import numpy as np
@@ -191,3 +193,71 @@ class EventLogReader(object):
             episode = Episode()
             episode.ParseFromString(self.log_file.read(struct.unpack('=l', head)[0]))
             yield episode
+
+
+def make_dir(d):
+    if not os.path.exists(d):
+        os.makedirs(d)
+
+
+def _draw_line(img, x0, y0, x1, y1):
+    n = int(max(abs(x1 - x0), abs(y1 - y0), 1))
+    for i in range(n + 1):
+        x, y = int(round(x0 + (x1 - x0) * i / n)), int(round(y0 + (y1 - y0) * i / n))
+        if 0 <= y < img.shape[0] and 0 <= x < img.shape[1]:
+            img[y, x, :3] = 0.0
+
+
+def main(argv=None):
+    """the log inspector at the bottom of the reference's event_log.py (:118-190): `--echo` prints the episodes, `--img-output-dir DIR`
+    writes every render to DIR/ep_NNNNN/cK/eNNNNN_rK.png (at the render's own size: the reference upscales to 200 x 200 with PIL),
+    `--img-debug-overlay` draws the action as a line inside a box at (40, 40) (the reference also prints the episode / event numbers
+    as text), `--episodes 0,3` restricts both."""
+    import argparse
+    parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    parser.add_argument('--log-file', type=str, default=None)
+    parser.add_argument('--echo', action='store_true', help="write event to stdout")
+    parser.add_argument('--episodes', type=str, default=None,
+                        help="if set only process these specific episodes (comma separated list)")
+    parser.add_argument('--img-output-dir', type=str, default=None,
+                        help="if set output all renders to this DIR/e_NUM/s_NUM.png")
+    parser.add_argument('--img-debug-overlay', action='store_true', help="if set overlay image with debug info")
+    o = parser.parse_args(argv)
+    whitelist = None if o.episodes is None else set(map(int, o.episodes.split(",")))
+    if o.img_output_dir is not None:
+        make_dir(o.img_output_dir)
+    n_episodes = n_events = 0
+    for episode_id, episode in enumerate(EventLogReader(o.log_file).entries()):
+        if whitelist is not None and episode_id not in whitelist:
+            continue
+        if o.echo:
+            print("-----", episode_id)
+            print(episode)
+        n_episodes += 1
+        n_events += len(episode.event)
+        if o.img_output_dir is not None:
+            d = "%s/ep_%05d" % (o.img_output_dir, episode_id)
+            for sub in ("", "/c0", "/c1"):
+                make_dir(d + sub)
+            for event_id, event in enumerate(episode.event):
+                for state_id, state in enumerate(event.state):
+                    for camera_id, render in enumerate(state.render):
+                        assert camera_id in [0, 1], "two cameras at most"
+                        png = render.png_bytes
+                        if o.img_debug_overlay:
+                            img = np.array(png_to_rgb(png), np.float64)
+                            bx, by, bw = 40, 40, 10
+                            for (x0, y0, x1, y1) in ((bx - bw, by - bw, bx + bw, by - bw), (bx + bw, by - bw, bx + bw, by + bw),
+                                                     (bx + bw, by + bw, bx - bw, by + bw), (bx - bw, by + bw, bx - bw, by - bw)):
+                                _draw_line(img, x0, y0, x1, y1)
+                            if len(event.action) >= 2:
+                                _draw_line(img, bx, by, bx + event.action[0] * bw, by + event.action[1] * bw)
+                            png = rgb_to_png(img[:, :, :3])
+                        with open("%s/c%d/e%05d_r%d.png" % (d, camera_id, event_id, state_id), "wb") as f:
+                            f.write(png)
+    print("read", n_episodes, "episodes for a total of", n_events, "events", file=sys.stderr)
+    return n_episodes, n_events
+
+
+if __name__ == "__main__":
+    main()

@@ -76,3 +76,29 @@ def test_lowdim_episode_round_trip(tmp_path):
     for k, ev in enumerate(epi.event):
         assert np.array_equal(E.read_state_from_event(ev).astype(np.float32), states[k])
     assert list(epi.event[2].action) == [0.75, 0.125]
+
+
+def test_log_inspector_cli(tmp_path, capsys):
+    """the reader script at the bottom of event_log.py (:118-190): --echo, --episodes, --img-output-dir, --img-debug-overlay"""
+    import os
+    from cartpoleplusplus_amd import event_log as E
+    path = str(tmp_path / "events")
+    rng = np.random.default_rng(0)
+    log = E.EventLog(path, use_raw_pixels=True)
+    shape = (50, 50, 3, 2, 2)
+    for _ep in range(3):
+        log.reset()
+        log.add_just_state(rng.integers(0, 256, shape).astype(np.float32) / 255)
+        for _ in range(4):
+            log.add(rng.integers(0, 256, shape).astype(np.float32) / 255, rng.uniform(-1, 1, (1, 2)).astype(np.float32), 1.0)
+    log.close()
+    out_dir = str(tmp_path / "imgs")
+    n_ep, n_ev = E.main(["--log-file", path, "--echo", "--episodes", "0,2", "--img-output-dir", out_dir, "--img-debug-overlay"])
+    assert (n_ep, n_ev) == (2, 10)
+    text = capsys.readouterr().out
+    assert "----- 0" in text and "----- 2" in text and "----- 1" not in text
+    assert sorted(os.listdir(out_dir)) == ["ep_00000", "ep_00002"]
+    files = sorted(os.listdir(out_dir + "/ep_00002/c1"))
+    assert len(files) == 5 * 2 and files[0] == "e00000_r0.png"
+    img = E.png_to_rgb(open(out_dir + "/ep_00002/c1/e00003_r1.png", "rb").read())
+    assert img.shape[:2] == (50, 50) and (np.asarray(img)[30, 30:51, :3] == 0).all()      # the overlay's box edge
