@@ -92,6 +92,17 @@ def build_parser():
     a('--use-raw-pixels', action='store_true', help="use raw pixels as state instead of poses")
     a('--render-width', type=int, default=50, help="if --use-raw-pixels render with this width")
     a('--render-height', type=int, default=50, help="if --use-raw-pixels render with this height")
+    # the rest of bullet_cartpole.add_opts (bullet_cartpole.py:13-38): read by the reference's pybullet environment when it is on
+    # sys.path (make_env); --event-log-out is also honoured by the stand-in environment
+    a('--gui', action='store_true', help="pybullet GUI")
+    a('--delay', type=float, default=0.0, help="seconds to sleep per simulation step")
+    a('--action-force', type=float, default=50.0, help="magnitude of action force applied per step")
+    a('--initial-force', type=float, default=55.0, help="magnitude of initial push, in random direction")
+    a('--no-random-theta', action='store_true', help="initial push always in the same direction")
+    a('--steps-per-repeat', type=int, default=5, help="number of sim steps per repeat")
+    a('--event-log-out', type=str, default=None, help="path to record event log.")
+    a('--reward-calc', type=str, default='fixed',
+      help="'fixed': 1 per step. 'angle': 2*max_angle - ox - oy. 'action': 1.5 - |action|. 'angle_action': both")
     # additions of this build
     a('--host-rng-sampling', action='store_true',
       help="draw minibatch rows with numpy's RNG on the host like the reference (default: Philox on the GPU)")
@@ -576,6 +587,8 @@ def main(argv=None):
             saver_util.force_save()
     env.reset()
     agent.close()
+    if hasattr(env, "close"):
+        env.close()
 
 
 if __name__ == "__main__":

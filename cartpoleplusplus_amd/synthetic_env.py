@@ -28,6 +28,10 @@ class SyntheticCartpole(object):
         self.observation_space = _Space(shape)
         self.action_space = _Space((1, 2))
         self.steps = 0
+        self.event_log = None
+        if getattr(opts, "event_log_out", None):        # bullet_cartpole.py:90-94: every episode goes to the log as it is played
+            from .event_log import EventLog
+            self.event_log = EventLog(opts.event_log_out, self.use_raw_pixels)
 
     def _obs(self):
         shape = self.observation_space.shape
@@ -40,10 +44,25 @@ class SyntheticCartpole(object):
     def reset(self):
         self.steps = 0
         self.episode_len = int(self.rng.randint(5, self.max_episode_len + 1))
-        return self._obs()
+        state = self._obs()
+        if self.event_log:                              # :283-285
+            self.event_log.reset()
+            self.event_log.add_just_state(state)
+        return state
 
     def step(self, action):
         assert np.asarray(action).shape == (1, 2)
         self.steps += 1
         done = self.steps >= self.episode_len
-        return self._obs(), 1.0, done, {}
+        state = self._obs()
+        if self.event_log:                              # :221-222
+            self.event_log.add(state, action, 1.0)
+        return state, 1.0, done, {}
+
+    def close(self):
+        if self.event_log:
+            ep = self.event_log.episode_entry
+            if ep is not None and len(ep.event) <= 1:   # only an initial state (main()'s closing env.reset()): nothing to keep
+                self.event_log.episode_entry = None
+            self.event_log.close()                      # writes the episode in progress
+            self.event_log = None

@@ -33,3 +33,20 @@ def test_cli_runs_and_trains(which, args, capsys):
     stats = [json.loads(l.split("\t", 1)[1]) for l in out.splitlines() if l.startswith("STATS")]
     assert len(stats) >= 4 and any(np.isfinite(s["mean_losses"]) for s in stats), out[-400:]
     assert stats[-1]["replay_memory_stats"][">add"] >= 60
+
+
+def test_record_an_event_log_then_train_from_it_offline(tmp_path, capsys):
+    """the workflow of exps/run_81-84: one run plays and records (--event-log-out, bullet_cartpole.py:27,90-94), the next trains from
+    the log alone (--event-log-in --dont-do-rollouts)."""
+    from cartpoleplusplus_amd import ddpg_cartpole as D, event_log as E
+    path = str(tmp_path / "played.log")
+    D.main(PIXELS + ["--event-log-out", path])
+    capsys.readouterr()
+    episodes = list(E.EventLogReader(path).entries())
+    assert len(episodes) >= 5 and all(len(ep.event) >= 2 for ep in episodes)
+    assert len(episodes[0].event[0].action) == 0 and len(episodes[0].event[1].action) == 2          # first event: just the state
+    D.main(["--use-raw-pixels", "--render-width", "16", "--render-height", "16", "--batch-size", "8", "--replay-memory-size", "400",
+            "--replay-memory-burn-in", "20", "--max-episode-len", "12", "--max-num-actions", "1", "--max-run-time", "1", "--synthetic-env", "--event-log-in", path, "--dont-do-rollouts"])
+    out = capsys.readouterr().out
+    last = json.loads([l for l in out.splitlines() if l.startswith("STATS")][-1].split("\t", 1)[1])
+    assert last["replay_memory_stats"][">add_episode"] == len(episodes) and np.isfinite(last["mean_losses"])
