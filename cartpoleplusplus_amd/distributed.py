@@ -263,5 +263,28 @@ def learner_for_agent(agent, opts, batch_size):
             os.environ.setdefault("MASTER_PORT", "29500")
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         rank = dist.get_rank()
+        if not getattr(agent, "_replicas_synced", False):             # once per agent: a learner rebuilt for a new batch size keeps them
+            sync_replicas_from_rank0(agent, dist, device=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+            agent._replicas_synced = True
     return make_learner(agent, batch_size, seed=int(opts.sample_seed) + rank, sync_every=int(opts.sync_every),
                         overlap=bool(opts.overlap_allreduce), always=True)
+
+
+def sync_replicas_from_rank0(agent, dist, device=None):
+    """every process built its networks from its own random numbers (or, rank 0, from a checkpoint): the synchronous step keeps
+    replicas identical only if they START identical, so rank 0's parameters -- target networks and optimiser slots included -- go to
+    every rank once, as host arrays through torch.distributed (a few MB)."""
+    rank = dist.get_rank()
+    nets = list(agent.networks())
+    opt_owner = getattr(agent, "naf", None)
+    payload = [None]
+    if rank == 0:
+        payload = [{"params": [n.get_params() for n in nets],
+                    "opt": opt_owner.get_optimiser_state() if opt_owner is not None and hasattr(opt_owner, "get_optimiser_state") else None}]
+    kw = {"device": device} if device is not None and dist.get_backend() == "nccl" else {}
+    dist.broadcast_object_list(payload, src=0, **kw)
+    if rank != 0:
+        for n, p in zip(nets, payload[0]["params"]):
+            n.set_params(p)
+        if payload[0]["opt"] is not None:
+            opt_owner.set_optimiser_state(payload[0]["opt"])

@@ -117,3 +117,71 @@ def test_periodic_mode_takes_local_steps_and_meets_at_the_parameter_mean():
         assert np.allclose(s0[k], want[k][0], rtol=1e-6, atol=1e-7) and np.allclose(s1[k], want[k][1], rtol=1e-6, atol=1e-7)
     assert not np.array_equal(s0[0], s1[0])          # after 5 minibatches the replicas are 2 local steps apart
     assert np.array_equal(s0[2], s1[2])              # after 15 (a multiple of 3) they have just met
+
+
+class _FakeNet(object):
+    def __init__(self, rng, n):
+        self.p = rng.standard_normal(n).astype(np.float32)
+
+    def get_params(self):
+        return self.p.copy()
+
+    def set_params(self, p):
+        assert p.shape == self.p.shape
+        self.p = np.asarray(p, np.float32).copy()
+
+
+class _FakeNaf(object):
+    def __init__(self, rng):
+        self.state = {"m": rng.standard_normal(7).astype(np.float32), "v": rng.random(7).astype(np.float32), "step": np.uint64(rng.integers(1, 99))}
+
+    def get_optimiser_state(self):
+        return dict(self.state)
+
+    def set_optimiser_state(self, s):
+        self.state = dict(s)
+
+
+class _FakeAgent(object):
+    def __init__(self, seed, with_opt):
+        rng = np.random.default_rng(seed)
+        self.nets = [_FakeNet(rng, n) for n in (11, 5, 11, 5)]
+        if with_opt:
+            self.naf = _FakeNaf(rng)
+
+    def networks(self):
+        return self.nets
+
+
+def _sync_worker(rank, world, port, out):
+    from cartpoleplusplus_amd.distributed import sync_replicas_from_rank0
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = []
+    for with_opt in (False, True):
+        agent = _FakeAgent(100 + rank, with_opt)              # every process draws its own weights, as the CLI's agents do
+        sync_replicas_from_rank0(agent, dist)
+        res.append(([n.get_params() for n in agent.nets], agent.naf.state if with_opt else None))
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_replicas_start_from_rank_zeros_parameters_and_optimiser_slots():
+    """the CLI's --data-parallel agents draw their own initial weights (and only rank 0 restores the checkpoint): before the first
+    collective step every rank takes rank 0's networks and, for NAF, the optimiser slots and step count."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_sync_worker, args=(2, port, out), nprocs=2, join=True)
+    want = _FakeAgent(100, True)
+    for k, with_opt in enumerate((False, True)):
+        ref = _FakeAgent(100, with_opt)
+        for r in range(2):
+            params, st = out[r][k]
+            assert all(np.array_equal(a, n.p) for a, n in zip(params, ref.nets))
+            if with_opt:
+                assert np.array_equal(st["m"], ref.naf.state["m"]) and np.array_equal(st["v"], ref.naf.state["v"])
+                assert int(st["step"]) == int(ref.naf.state["step"])
+    assert not np.array_equal(_FakeAgent(101, True).nets[0].p, want.nets[0].p)
