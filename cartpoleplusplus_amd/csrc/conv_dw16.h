@@ -51,6 +51,7 @@ struct Dw16Geom {
 #ifndef DW16_WGS
 #define DW16_WGS 3
 #endif
+
 // DENSE: dY comes as dense f32 rows (a.dy_dense: batch norm's dz) instead of being rebuilt from the pooled gradient
 // (bx, by, gx): the workgroup's place in a (gx, networks) grid (its own launch, or a slice of a shared one: conv1_dw_gather.hip)
 template <int CIN, int KS, int NCHK, bool DENSE = false>
@@ -84,6 +85,9 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
     *reinterpret_cast<unsigned short*>(inring + s * ROWB + 2 * (CP * (x + P) + CIN)) = (unsigned short)0x3C00u;      // 1.0
   }
 
+  // (the epilogue's whitening scale / shift are requested here: in the epilogue the load was one more L2 round trip per workgroup)
+  float wsc_s = 0.f, wsc_t = 0.f;
+  if (tid < CIN) { wsc_s = a.scale[tid]; wsc_t = a.shift[tid]; }
   // ---- 2^S: the largest |pooled gradient| among the pooled rows this workgroup's units touch lands in [2^14, 2^15)
   float sc, inv;
   {
@@ -107,18 +111,18 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
         for (; e < e1; e += CONV_THREADS) vmax = fmaxf(vmax, fabsf(dp[e]));
       } else {
         const int py0 = max(0, (q_lo - P) >> 1), py1 = min(Hp - 1, (q_lo + rows - 1 + P) >> 1);
-        const float* dp = a.dy.dpool + (long)b * a.dy.dpool_bstride;
         const int e1 = (py1 + 1) * Wp * nout;
-        int e = py0 * Wp * nout + tid;
-        for (; e + 7 * CONV_THREADS < e1; e += 8 * CONV_THREADS) {      // 8 loads in flight (a 1-load loop pays the latency per trip)
-          float t[8];
+        // the rows come from another kernel's L2 (1.5-2 us a trip): 24 loads in flight per trip -- one trip for a half image of
+        // the headline shape -- through a descriptor that ends at e1 (reads past it return 0)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.dy.dpool + (long)b * a.dy.dpool_bstride), 0, e1 * 4, 0x00020000);
+        for (int e = py0 * Wp * nout + tid; e < e1; e += 24 * CONV_THREADS) {
+          float t[24];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) t[u] = dp[e + u * CONV_THREADS];
+          for (int u = 0; u < 24; ++u) t[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (e + u * CONV_THREADS) * 4, 0, 0));
 #pragma unroll
-          for (int u = 0; u < 8; ++u) vmax = fmaxf(vmax, fabsf(t[u]));
+          for (int u = 0; u < 24; ++u) vmax = fmaxf(vmax, fabsf(t[u]));
         }
-#pragma unroll 4
-        for (; e < e1; e += CONV_THREADS) vmax = fmaxf(vmax, fabsf(dp[e]));
       }
     }
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
@@ -144,22 +148,25 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
     sdst[i] = keep_in_vgpr(lds_addr(inring + 2 * (CP * (x + P) + (ODD ? w : 2 * w))));
   }
   const int rowbytes = W * CIN * 2;
-  auto in_load = [&](const __amdgpu_buffer_rsrc_t& rs, int q) {
+  unsigned sv2[G::NVIN];                              // (the unit prologue has two rows in flight)
+  auto in_load_to = [&](unsigned (&dst)[G::NVIN], const __amdgpu_buffer_rsrc_t& rs, int q) {
 #pragma unroll
     for (int i = 0; i < G::NVIN; ++i)
       if (sact[i]) {
-        if (ODD) sv[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, (tid + CONV_THREADS * i) * 2, q * rowbytes, 0);
-        else sv[i] = __builtin_amdgcn_raw_buffer_load_b32(rs, (tid + CONV_THREADS * i) * 4, q * rowbytes, 0);
+        if (ODD) dst[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, (tid + CONV_THREADS * i) * 2, q * rowbytes, 0);
+        else dst[i] = __builtin_amdgcn_raw_buffer_load_b32(rs, (tid + CONV_THREADS * i) * 4, q * rowbytes, 0);
       }
   };
-  auto in_store = [&](int slot) {
+  auto in_store_from = [&](const unsigned (&src)[G::NVIN], int slot) {
 #pragma unroll
     for (int i = 0; i < G::NVIN; ++i)
       if (sact[i]) {
-        if (ODD) lds_store(sdst[i], slot * ROWB, (unsigned short)sv[i]);
-        else lds_store(sdst[i], slot * ROWB, sv[i]);
+        if (ODD) lds_store(sdst[i], slot * ROWB, (unsigned short)src[i]);
+        else lds_store(sdst[i], slot * ROWB, src[i]);
       }
   };
+  auto in_load = [&](const __amdgpu_buffer_rsrc_t& rs, int q) { in_load_to(sv, rs, q); };
+  auto in_store = [&](int slot) { in_store_from(sv, slot); };
 
   // ---- dY staging: a thread owns pooled cells idx = px * nout + o of a pooled row (the same cells for every row); the
   // masked gradient is scaled, split into three f16 pieces and written to both image rows of the pooled row.
@@ -313,18 +320,19 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
         if (d - P < rows) { in_load(in_rs, y0 + d); in_store(d % G::RING_IN); }
       if (2 < rows) in_load(in_rs, q_lo + 2);
     } else {
+    // (the first two input rows are requested together: one L2 round trip, not two -- in-kernel clock: the prologue was 4 us)
     if (0 < rows) in_load(in_rs, q_lo);
+    if (1 < rows) in_load_to(sv2, in_rs, q_lo + 1);
     dy_issue(rp, rd, rc, y0 >> 1, 0);
     dy_issue(rp, rd, rc, (y0 >> 1) + 1, 1);
     dy_issue(rp, rd, rc, (y0 >> 1) + 2, 2);
     if (0 < rows) in_store(P % G::RING_IN);
-    if (1 < rows) in_load(in_rs, q_lo + 1);
+    if (2 < rows) in_load(in_rs, q_lo + 2);
     dy_conv(0, in_band(y0));
     dy_store(0, 0); dy_store(1, 1);
     dy_conv(1, in_band(y0 + 2));
     dy_store(2, 0); dy_store(3, 1);
-    if (1 < rows) in_store((P + 1) % G::RING_IN);
-    if (2 < rows) in_load(in_rs, q_lo + 2);
+    if (1 < rows) in_store_from(sv2, (P + 1) % G::RING_IN);
     dy_conv(2, in_band(y0 + 4));
     dy_store(4, 0);                                   // position 5 (same cells) is stored by the first step
     }
@@ -362,10 +370,18 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
         for (int ch = 0; ch < NCHK; ++ch) {
           f16x8 bq[NPC];
 #pragma unroll
-          for (int pc = 0; pc < NPC; ++pc) bq[pc] = lds_load<f16x8>(badr[sq], pc * G::DPC + ch * 64);
+          for (int pc = 0; pc < NPC; ++pc) {
+#ifdef DW16_ABL_NOB
+            if (pc > 0) { bq[pc] = bq[0]; continue; }
+#endif
+            bq[pc] = lds_load<f16x8>(badr[sq], pc * G::DPC + ch * 64);
+          }
           k16_u32x4 av[MT];
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
+#ifdef DW16_ABL_NOA
+            if (mt > 0) { av[mt] = av[0]; continue; }
+#endif
             const int off = islot * ROWB + ch * (2 * CP * 32) + mt * 32;
             const dw16_v4s r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                 reinterpret_cast<__attribute__((address_space(3))) dw16_v4s*>((uintptr_t)(aadr + (uint32_t)off)));
@@ -398,7 +414,7 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
   // whitening scale / shift through LDS: read per (tile, row) below (global loads there were a chain of L2 round trips:
   // 8.4 us per workgroup, in-kernel probe)
   float* wsc = dbs + CONV_THREADS * NCELL;           // [CIN] scale, [CIN] shift (behind the bias-gradient scratch)
-  if (tid < CIN) { wsc[tid] = a.scale[tid]; wsc[CIN + tid] = a.shift[tid]; }
+  if (tid < CIN) { wsc[tid] = wsc_s; wsc[CIN + tid] = wsc_t; }
   __syncthreads();
 #pragma unroll
   for (int kx = 0; kx < KS; ++kx) {
@@ -429,7 +445,16 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
   __syncthreads();
   if (tid < nout) {
     float s = 0.f;
-    for (int idx = tid; idx < Wp * nout; idx += nout) s += dbs[(idx / CONV_THREADS) * CONV_THREADS + (idx % CONV_THREADS)];
+    const int nidx = Wp * nout;
+    int idx = tid;
+    for (; idx + 7 * nout < nidx; idx += 8 * nout) {      // (same order as a one-by-one loop; its LDS reads were a chain of 32 round trips)
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int i = idx + u * nout; t[u] = dbs[(i / CONV_THREADS) * CONV_THREADS + (i % CONV_THREADS)]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; idx < nidx; idx += nout) s += dbs[(idx / CONV_THREADS) * CONV_THREADS + (idx % CONV_THREADS)];
     part[nw + tid] = s;
   }
 #ifdef DW16_CLOCK
