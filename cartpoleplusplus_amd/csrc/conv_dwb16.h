@@ -85,22 +85,25 @@ __device__ __forceinline__ void conv_dwb16_body(const ConvArgsN& batch, int unit
     sv[i] = 0.f;
   }
   const int rowbytes = W * CIN * 4;
-  auto in_load = [&](const __amdgpu_buffer_rsrc_t& rs, int q) {
+  float sv2[G::NVIN];                                 // (the unit prologue has two rows in flight: one L2 round trip instead of two)
+  auto in_load_to = [&](float (&dst)[G::NVIN], const __amdgpu_buffer_rsrc_t& rs, int q) {
 #pragma unroll
     for (int i = 0; i < G::NVIN; ++i)
-      if (sact[i]) sv[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (tid + CONV_THREADS * i) * 4, q * rowbytes, 0));
+      if (sact[i]) dst[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (tid + CONV_THREADS * i) * 4, q * rowbytes, 0));
   };
-  auto in_store = [&](int slot) {
+  auto in_load = [&](const __amdgpu_buffer_rsrc_t& rs, int q) { in_load_to(sv, rs, q); };
+  auto in_store_from = [&](const float (&src)[G::NVIN], int slot) {
 #pragma unroll
     for (int i = 0; i < G::NVIN; ++i)
       if (sact[i]) {
         unsigned short h, m, l;
-        dwb_split3(sv[i], h, m, l);
+        dwb_split3(src[i], h, m, l);
         lds_store(sdst[i], slot * SLOTB, h);
         lds_store(sdst[i], slot * SLOTB + ROWB, m);
         lds_store(sdst[i], slot * SLOTB + 2 * ROWB, l);
       }
   };
+  auto in_store = [&](int slot) { in_store_from(sv, slot); };
 
   // ---- dY staging (as conv_dw16.h; bf16 pieces, no scaling)
   constexpr int NCELL = G::NCELL;
@@ -193,17 +196,17 @@ __device__ __forceinline__ void conv_dwb16_body(const ConvArgsN& batch, int unit
     const int y0 = q_lo - P;
     auto in_band = [&](int y) { return y >= q_lo && y < q_lo + rows; };
     if (0 < rows) in_load(in_rs, q_lo);
+    if (1 < rows) in_load_to(sv2, in_rs, q_lo + 1);
     dy_issue(rp, rd, rc, y0 >> 1, 0);
     dy_issue(rp, rd, rc, (y0 >> 1) + 1, 1);
     dy_issue(rp, rd, rc, (y0 >> 1) + 2, 2);
     if (0 < rows) in_store(P % G::RING_IN);
-    if (1 < rows) in_load(in_rs, q_lo + 1);
+    if (2 < rows) in_load(in_rs, q_lo + 2);
     dy_conv(0, in_band(y0));
     dy_store(0, 0); dy_store(1, 1);
     dy_conv(1, in_band(y0 + 2));
     dy_store(2, 0); dy_store(3, 1);
-    if (1 < rows) in_store((P + 1) % G::RING_IN);
-    if (2 < rows) in_load(in_rs, q_lo + 2);
+    if (1 < rows) in_store_from(sv2, (P + 1) % G::RING_IN);
     dy_conv(2, in_band(y0 + 4));
     dy_store(4, 0);
     __syncthreads();
@@ -273,7 +276,16 @@ __device__ __forceinline__ void conv_dwb16_body(const ConvArgsN& batch, int unit
   __syncthreads();
   if (tid < nout) {
     float s = 0.f;
-    for (int idx = tid; idx < Wp * nout; idx += nout) s += dbs[(idx / CONV_THREADS) * CONV_THREADS + (idx % CONV_THREADS)];
+    const int nidx = Wp * nout;
+    int idx = tid;
+    for (; idx + 7 * nout < nidx; idx += 8 * nout) {      // (same order as a one-by-one loop, 8 LDS reads in flight)
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int i = idx + u * nout; t[u] = dbs[(i / CONV_THREADS) * CONV_THREADS + (i % CONV_THREADS)]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; idx < nidx; idx += nout) s += dbs[(idx / CONV_THREADS) * CONV_THREADS + (idx % CONV_THREADS)];
     part[nw + tid] = s;
   }
 }
