@@ -146,6 +146,13 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   const int b0 = blockIdx.x * IPW;
   const int H = a.H, W = a.W, Hp = H >> 1, Wp = W >> 1, nout = a.nout;
 
+  // (the accumulators' bias is requested with the weights: after the weight image it was one more L2 round trip, ~1 us, in-kernel clock)
+  float braw[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int j = 16 * t + li;
+    braw[t] = (!PLAIN && j < KS * NO && j % NO < nout) ? a.bias[j % NO] : 0.f;
+  }
   // ---- one-time setup: the split weight image
   float sc, inv;                                      // 2^S, 2^-S
   {
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     const int j = 16 * t + li;
     const bool valid = j < KS * NO;
     const int o = j % NO;
-    biast[t] = (!PLAIN && valid && o < nout) ? a.bias[o] * sc : 0.f;
+    biast[t] = braw[t] * sc;
     eadr[t] = PLAIN ? (uint32_t)(((sstrip * G::SW + 4 * lj) * nout + o) * 4)
                     : keep_in_vgpr(lds_addr(ev + (lj * 2) * NO + o));
     const int p = valid ? j / NO : 0;

@@ -4,7 +4,7 @@
 L=cartpoleplusplus_amd/lib
 cp $L/libcartpolepp_hip_ablation.so /tmp/abl_keep.so
 export CARTPOLEPP_ABLATION=1
-for round in 1; do
+for round in 1 2 3; do
 for v in $L/libexp_*.so; do
   cp $v $L/libcartpolepp_hip_ablation.so
   echo "== $(basename $v)"
