@@ -416,6 +416,9 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
   float* wsc = dbs + CONV_THREADS * NCELL;           // [CIN] scale, [CIN] shift (behind the bias-gradient scratch)
   if (tid < CIN) { wsc[tid] = wsc_s; wsc[CIN + tid] = wsc_t; }
   __syncthreads();
+#ifdef DW16_CLOCK
+  const unsigned long long cq1 = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
   for (int kx = 0; kx < KS; ++kx) {
     const int m = CP * kx + CIN;                      // compile-time
@@ -424,6 +427,9 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef DW16_ABL_NOPART
+  float ablsum = 0.f;
+#endif
   if (nvalid && no < nout) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -433,13 +439,26 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
         const int kx = m / CP, c = m - kx * CP;
         if (kx < KS && c < CIN) {
           const float t = tx[kx * 16 + li];
+#ifdef DW16_ABL_NOPART
+          ablsum += inv * (wsc[c] * acc[mt][r] + wsc[CIN + c] * t);
+#else
           part[(nky * G::KROW + kx * CIN + c) * nout + no] = inv * (wsc[c] * acc[mt][r] + wsc[CIN + c] * t);
+#endif
         }
       }
     }
   }
+#ifdef DW16_ABL_NOPART
+  if (ablsum == 123.456f) part[tid] = ablsum;
+#endif
   // bias gradient: per-thread cell sums -> LDS -> one thread per channel adds them in fixed order
+#ifdef DW16_CLOCK
+  const unsigned long long cq2 = __builtin_amdgcn_s_memrealtime();
+#endif
   __syncthreads();
+#ifdef DW16_CLOCK
+  const unsigned long long cq3 = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
   for (int c = 0; c < NCELL; ++c) dbs[c * CONV_THREADS + tid] = cact[c] ? dbsum[c] : 0.f;
   __syncthreads();
@@ -458,7 +477,7 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
     part[nw + tid] = s;
   }
 #ifdef DW16_CLOCK
-  if (tid == 0 && (bx % 211) == 7 && by == 0) printf("DW16CLK block %d: setup %llu, units (prologue %llu) %llu, epilogue %llu ticks\n", bx, ce1 - ce0, cpro, ce2 - ce1, __builtin_amdgcn_s_memrealtime() - ce2);
+  if (tid == 0 && (bx % 211) == 7 && by == 0) printf("DW16CLK block %d: setup %llu, units (prologue %llu) %llu, epilogue %llu ticks (first barrier %llu, partial stores %llu, barrier %llu, bias %llu)\n", bx, ce1 - ce0, cpro, ce2 - ce1, __builtin_amdgcn_s_memrealtime() - ce2, cq1 - ce2, cq2 - cq1, cq3 - cq2, __builtin_amdgcn_s_memrealtime() - cq3);
 #endif
 }
 
