@@ -123,12 +123,15 @@ struct K16Geom {
 #ifndef K16_WGS
 #define K16_WGS 2
 #endif
+#ifndef K16_ROTATE_PRIO
+#define K16_ROTATE_PRIO 1
+#endif
 template <int CIN, int KS, int XT, int IPW, bool PLAIN = false, bool B16 = false>
 __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(const ConvArgsN batch) {
   typedef K16Geom<CIN, KS, XT, IPW, B16> G;
   constexpr int P = G::P, NT = G::NT, NCH = G::NCH, NPC = G::NPC, NPA = G::NPA, NO = KYO_NO;
   constexpr bool ODD = (CIN & 1) != 0;            // 2-byte aligned operand windows: 20 bytes from the aligned address below + a funnel shift
-#ifdef K16_CLOCK_PROBE
+#if defined(K16_CLOCK_PROBE) || defined(K16_SPAN_PROBE)
   const unsigned long long pe0 = __builtin_amdgcn_s_memrealtime();
 #endif
   const ConvArgs& a = batch.a[blockIdx.y];
@@ -394,11 +397,20 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #pragma unroll
   for (int pc = 0; pc < NPC; ++pc) load_b_piece(0, pc, wadr[0]);
 
-#ifdef K16_CLOCK_PROBE
+#if defined(K16_CLOCK_PROBE) || defined(K16_SPAN_PROBE)
   const unsigned long long pc0 = __builtin_readcyclecounter(), pr0 = __builtin_amdgcn_s_memrealtime();
 #endif
   const bool wr_f32 = PLAIN || a.out != nullptr, wr_code = a.out_amax != nullptr;     // target networks of the fused step: bf16 planes only
   for (int q0 = 0; q0 < H + P; q0 += KS) {
+#if K16_ROTATE_PRIO
+    {  // issue arbitration is by priority, then age: the workgroups of the networks launched first ran ahead of their co-resident
+       // partners (in-kernel span probe: 104 vs 125 us of a 119 us launch, 50 vs 67 us for conv2) and the younger ones finished
+       // alone at half the pipe utilisation; rotating the priority every KS rows keeps the two waves of a SIMD level (conv_kyo.h)
+      const int pr = ((int)blockIdx.y + q0 / KS) & 3;     // (every 2 KS / 4 KS rows, every row, every second row: all slower)
+      if (pr == 0) __builtin_amdgcn_s_setprio(0); else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+      else if (pr == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
+    }
+#endif
 #pragma unroll
     for (int sq = 0; sq < KS; ++sq) {
       const int q = q0 + sq;
@@ -559,6 +571,10 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     conv3_img_half(ops, img3 + im3 * C3_IMGF, wave & 1, a.n3_out + (long)(b0 + im3) * a.n3_out_bstride,
                    a.n3_amax + (long)(b0 + im3) * (C3_H / 2) * (C3_H / 2) * nout, nout, li, lj);
   }
+#ifdef K16_SPAN_PROBE
+  if (lane == 0 && wave == 0 && (blockIdx.x % 16) == 1 && (int)blockIdx.y >= K16_SPAN_PROBE)
+    printf("K16SPAN cin %d y %d x %d start %llu loop %llu end %llu\n", CIN, (int)blockIdx.y, (int)blockIdx.x, (unsigned long long)pe0, (unsigned long long)pr0, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 #ifdef K16_CLOCK_PROBE
   if (lane == 0 && (blockIdx.x % 97) == 5 && blockIdx.y == 1 && wave == 0) {
     const unsigned long long pc1 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
