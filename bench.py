@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: DDPG training steps/sec on synthetic 64x64x18 pixel minibatches, batch 256
-(BASELINE.json metric).  One process per GPU; N > 1 is launched by torch.distributed.run.
+(BASELINE.json metric).  One process per GPU; N > 1 runs under torch.distributed.run -- `python bench.py --gpus N` as a
+plain command launches its own N ranks that way.
 
 A "step" is one minibatch update of the hot path: fused sample + gather of B transitions from the
 HBM-resident replay memory, actor update, critic update (4 conv-trunk forwards, 2 backwards), global-norm
@@ -150,6 +151,20 @@ def sub_bench(extra_args, env=None, timeout=420):
         return {"error": repr(e)}
 
 
+def self_launch(n):
+    """re-run this command line as n ranks: python -m torch.distributed.run --nnodes=1 --nproc-per-node n bench.py <same flags>."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, cwd=ROOT, env=env)
+
+
 def main():
     global BATCHES_PER_STEP
     ap = argparse.ArgumentParser()
@@ -185,10 +200,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as a plain command: start the N ranks ourselves (one process per GPU under torch.distributed.run,
+        # exactly the driver's launch form) and hand rank 0's ONE JSON line through
+        os.dup2(real_stdout, 1)
+        sys.exit(self_launch(args.gpus))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     shape, B, kind = WORKLOADS[args.workload]
     replay_rows = args.replay_rows or REPLAY_ROWS_BY.get(args.workload, REPLAY_ROWS)
 
@@ -261,7 +279,7 @@ def main():
     else:
         from cartpoleplusplus_amd.distributed import make_learner
         learner = make_learner(agent, B, seed=1234 + rank, sync_every=args.sync_every, overlap=args.overlap, always=args.force_dp,
-                               torch_stream=stream)
+                               torch_stream=stream, collective="rccl" if args.diag_backend == "nccl" else "torch")
 
         def run(g, t):
             for _ in range(g):
@@ -291,11 +309,14 @@ def main():
     run(groups, tail)
     full_sync()
     elapsed = time.perf_counter() - t0
+    steps = groups * BATCHES_PER_STEP + tail
+    per_rank = [round(steps / elapsed, 3)]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % local_rank)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    steps = groups * BATCHES_PER_STEP + tail
+        every = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)
+        per_rank = [round(steps / float(t.item()), 3) for t in every]
+        elapsed = max(float(t.item()) for t in every)         # the MAX over the ranks is the job's time
     ms_per_step = 1e3 * elapsed / steps
     value = world * steps / elapsed
 
@@ -413,6 +434,7 @@ def main():
                                    replay_rows, args.replay_store, BATCHES_PER_STEP, ", --use-batch-norm" if args.use_batch_norm else ""),
                    "parallelism": parallelism,
                    "global_steps_per_sec": round(steps / elapsed, 3),
+                   "per_rank_steps_per_sec": per_rank,
                    "conv_gflop_per_step": round(conv_flops_step / 1e9, 3),
                    "conv_gflop_per_step_as_the_reference_executes_it": (round(2.0 * B * (5 * F + 2 * Bk) / 1e9, 3) if kind == "ddpg" else None),
                    "mlp_gflop_per_step": mlp_gflop,

@@ -88,6 +88,7 @@ SIGNATURES = {
     "cpp_replay_destroy": (_I, [_P]),
     "cpp_replay_write_states": (_I, [_P, _P, _I, _P, _I]),
     "cpp_replay_write_rows": (_I, [_P, _P, _I, _P, _P, _P, _P, _P]),
+    "cpp_replay_read_rows": (_I, [_P, _P, _I, _P, _P, _P, _P, _P]),
     "cpp_replay_set_size": (_I, [_P, _I]),
     "cpp_replay_read_states": (_I, [_P, _P, _I, _P]),
     "cpp_replay_sample": (_I, [_P, _I, _P, _U64, _U64, _I, _P]),
@@ -104,6 +105,7 @@ SIGNATURES = {
     "cpp_ddpg_apply_gradients": (_I, [_P, _F]),
     "cpp_ddpg_update_targets": (_I, [_P]),
     "cpp_ddpg_train_step": (_I, [_P, _P, _I, _I, _P, _U64]),
+    "cpp_ddpg_train_rows": (_I, [_P, _P, _I, _P]),
     "cpp_ddpg_sample_and_compute": (_I, [_P, _P, _I, _U64]),
     "cpp_ddpg_last_stats": (_I, [_P, _P]),
     "cpp_ddpg_last_values": (_I, [_P, _I, _P, _P, _P, _P]),
@@ -113,6 +115,7 @@ SIGNATURES = {
     "cpp_comm_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),
     "cpp_comm_allreduce": (_I, [_P, _P, _L, _I]),
     "cpp_comm_max_double": (_I, [_P, C.POINTER(C.c_double)]),
+    "cpp_comm_max_doubles": (_I, [_P, C.POINTER(C.c_double), _I]),
     "cpp_comm_barrier": (_I, [_P]),
     "cpp_ddpg_allreduce_grads": (_I, [_P, _P]),
     "cpp_ddpg_average_params": (_I, [_P, _P]),
@@ -131,6 +134,7 @@ SIGNATURES = {
     "cpp_naf_apply_gradients": (_I, [_P, _F]),
     "cpp_naf_update_targets": (_I, [_P]),
     "cpp_naf_train_step": (_I, [_P, _P, _I, _I, _P, _U64]),
+    "cpp_naf_train_rows": (_I, [_P, _P, _I, _P, C.POINTER(_F)]),
     "cpp_naf_last_stats": (_I, [_P, _P]),
     "cpp_naf_opt_state_size": (_L, [_P]),
     "cpp_naf_get_opt_state": (_I, [_P, _P, _P, _L, C.POINTER(_U64)]),

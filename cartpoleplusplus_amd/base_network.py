@@ -86,11 +86,26 @@ class Network(object):
         self.namespace = namespace
         self.target_update_op = None
         self.update_weights_op = None        # the reference never initialises this
-        self.handle = None
+        self._handle = None
+        self._before_use = None              # a deferred update of THIS network that must land before anyone touches it (see handle)
         self.ctx = None
         self._conv_input = None              # (H, W, C) once simple_conv_net_on ran
         self._hidden = []
         self._state_elems = 0
+
+    @property
+    def handle(self):
+        """the cpp_net.  Every use of the network from Python goes through this attribute, so an update that was deferred (the
+        actor's half of the reference's `actor.train(batch.state_1); critic.train(batch)` pair, ddpg_cartpole.py:333-334, waits
+        for the critic's call to run both as one fused device sequence) is flushed before anything can observe the network."""
+        hook = self._before_use
+        if hook is not None:
+            hook()
+        return self._handle
+
+    @handle.setter
+    def handle(self, h):
+        self._handle = h
 
     # ------------------------------------------------------------------ graph-building surface
     def hidden_layers_starting_at(self, layer, layer_sizes, opts=None):
@@ -238,6 +253,7 @@ class Network(object):
             self.render_convnet_activations(pool.eval(1), filename_base + "_p%d" % k)
 
     def close(self):
-        if self.handle:
-            lib.cpp_net_destroy(self.handle)
-            self.handle = None
+        if self._handle:
+            h = self.handle               # (flushes a deferred update first)
+            lib.cpp_net_destroy(h)
+            self._handle = None

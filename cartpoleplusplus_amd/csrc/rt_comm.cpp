@@ -36,6 +36,7 @@ extern "C" int cpp_comm_destroy(cpp_comm* c) {
   (void)hipStreamSynchronize(c->ctx->stream);
   (void)hipStreamSynchronize(c->side);
   (void)ncclCommDestroy(c->comm);
+  if (c->scratch) (void)hipFree(c->scratch);
   (void)hipEventDestroy(c->ev_fc); (void)hipEventDestroy(c->ev_bwd); (void)hipEventDestroy(c->ev_done);
   (void)hipStreamDestroy(c->side);
   delete c;
@@ -57,21 +58,22 @@ extern "C" int cpp_comm_allreduce(cpp_comm* c, void* device_f32, int64_t n, int 
   return CPP_OK;
 }
 
-// max over the ranks of one host double (bench.py: the slowest rank's time), via a device word
-extern "C" int cpp_comm_max_double(cpp_comm* c, double* value) {
-  ARG_CHECK(c && value, "cpp_comm_max_double: NULL argument");
+// max over the ranks of n (<= 8) host doubles, element-wise, via the communicator's device scratch words: bench.py's slowest
+// rank's time, and the agents' per-iteration loop agreement under --data-parallel ("every rank past burn-in?", "every rank done?":
+// ddpg_cartpole.py:329,379-383 decided per rank would leave the other ranks blocked in the next ncclAllReduce)
+extern "C" int cpp_comm_max_doubles(cpp_comm* c, double* values, int n) {
+  ARG_CHECK(c && values && n >= 1 && n <= CPP_COMM_SCRATCH_WORDS, "cpp_comm_max_doubles: need 1..%d values", CPP_COMM_SCRATCH_WORDS);
   HIP_CHECK(hipSetDevice(c->ctx->device));
-  double* dev = nullptr;
-  HIP_CHECK(hipMalloc((void**)&dev, sizeof(double)));
-  hipError_t e = hipMemcpyAsync(dev, value, sizeof(double), hipMemcpyHostToDevice, c->ctx->stream);
-  ncclResult_t r = e == hipSuccess ? ncclAllReduce(dev, dev, 1, ncclDouble, ncclMax, c->comm, c->ctx->stream) : ncclSuccess;
-  if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(value, dev, sizeof(double), hipMemcpyDeviceToHost, c->ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->ctx->stream);
-  (void)hipFree(dev);
-  if (r != ncclSuccess) { cpp_set_error("cpp_comm_max_double: %s", ncclGetErrorString(r)); return CPP_ERR_HIP; }
-  if (e != hipSuccess) { cpp_set_error("cpp_comm_max_double: %s", hipGetErrorString(e)); return CPP_ERR_HIP; }
+  if (!c->scratch) HIP_CHECK(hipMalloc((void**)&c->scratch, CPP_COMM_SCRATCH_WORDS * sizeof(double)));
+  hipStream_t st = c->ctx->stream;
+  HIP_CHECK(hipMemcpyAsync(c->scratch, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+  NCCL_CHECK(ncclAllReduce(c->scratch, c->scratch, (size_t)n, ncclDouble, ncclMax, c->comm, st));
+  HIP_CHECK(hipMemcpyAsync(values, c->scratch, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
   return CPP_OK;
 }
+
+extern "C" int cpp_comm_max_double(cpp_comm* c, double* value) { return cpp_comm_max_doubles(c, value, 1); }
 
 // barrier: a one-word all-reduce, then wait for it (bench.py brackets its timed region with this + cpp_sync)
 extern "C" int cpp_comm_barrier(cpp_comm* c) {

@@ -16,6 +16,8 @@ struct cpp_ddpg {
   // graph replay of the full inner step
   hipGraph_t graph; hipGraphExec_t gexec; bool graph_ok; int g_B, g_nb; uint64_t g_seed, g_replay_uid;   // (the sampler's range is read from the replay's device size word: one graph survives growth)
   cpp_batch* step_batch;
+  // graph replay of ONE minibatch on host-drawn rows, no target update (cpp_ddpg_train_rows: the reference's literal loop)
+  hipGraph_t rgraph; hipGraphExec_t rgexec; bool rgraph_ok; int rg_B; uint64_t rg_replay_uid;
   // graph replay of the data-parallel half step (sample + both gradient sets)
   // three variants: 0 samples its own minibatch; 1 / 2 find it presampled (by the previous call's rider, conv1_dw_gather.hip)
   // in the second / first set of slot arrays.  One key for all three.
@@ -45,6 +47,7 @@ extern "C" int cpp_ddpg_create(cpp_ctx* ctx, cpp_net* actor, cpp_net* critic, cp
   d->maxB = actor->maxB < critic->maxB ? actor->maxB : critic->maxB;
   d->nA = actor->nparams; d->nC = critic->nparams;
   d->graph = nullptr; d->gexec = nullptr; d->graph_ok = false; d->step_batch = nullptr; d->g_replay_uid = 0;
+  d->rgraph = nullptr; d->rgexec = nullptr; d->rgraph_ok = false; d->rg_B = 0; d->rg_replay_uid = 0;
   memset(d->hg, 0, sizeof(d->hg)); d->dp_local = 0; d->sq_cnt[0] = d->sq_cnt[1] = 0;
   d->h_replay_uid = 0; d->h_write_gen = 0; d->pre_variant = 0; d->h_B = 0; d->h_seed = 0;
   memset(d->slot_set, 0, sizeof(d->slot_set));
@@ -83,6 +86,8 @@ extern "C" int cpp_ddpg_destroy(cpp_ddpg* d) {
   (void)hipStreamSynchronize(d->ctx->stream);
   if (d->gexec) (void)hipGraphExecDestroy(d->gexec);
   if (d->graph) (void)hipGraphDestroy(d->graph);
+  if (d->rgexec) (void)hipGraphExecDestroy(d->rgexec);
+  if (d->rgraph) (void)hipGraphDestroy(d->rgraph);
   drop_half_graphs(d);
   if (d->step_batch) cpp_batch_destroy(d->step_batch);
   d->actor->grads = nullptr; d->critic->grads = nullptr;
@@ -560,7 +565,8 @@ bool direct_replay_ok(cpp_net* a, cpp_replay* r, int B) {
   return conv1_f16_pipes_ok(C, a->conv[0].H, a->conv[0].W, B, a->spec.use_batch_norm != 0);
 }
 
-static int step_body(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int32_t* rows_dev, uint64_t seed) {
+static int capture_into(cpp_ctx* ctx, hipGraph_t* g, hipGraphExec_t* e, const std::function<int()>& body);
+static int step_body(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int32_t* rows_dev, uint64_t seed, bool targets = true) {
   d->pre_variant = 0;        // (the half steps' presampled minibatch lives in the same step_batch)
   const int C = d->actor->spec.pixel ? d->actor->spec.C : 0;
   cpp_ctx* ctx = d->ctx;
@@ -601,7 +607,40 @@ static int step_body(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int
                                    d->step_batch, direct));
     }
   }
-  return cpp_ddpg_update_targets(d);
+  return targets ? cpp_ddpg_update_targets(d) : CPP_OK;
+}
+
+// ddpg_cartpole.py:332-334 for ONE minibatch whose rows the HOST drew (replay_memory.random_indexes: numpy's RNG, :123-129):
+// sample + gather of exactly those rows, actor update, critic update -- the fused minibatch of cpp_ddpg_train_step, without the
+// target updates (the caller's loop runs them after `batches_per_step` minibatches, :336-337: cpp_net_soft_update).  This is what
+// `actor.train(batch.state_1); critic.train(batch)` of the reference's loop becomes (cartpoleplusplus_amd/ddpg_cartpole.py defers the
+// actor's call until the critic's arrives).  One hipGraph per (B, replay); the rows travel through pinned memory, so the call
+// returns while the previous minibatch is still running.
+extern "C" int cpp_ddpg_train_rows(cpp_ddpg* d, cpp_replay* r, int B, const int32_t* idxs) {
+  ARG_CHECK(d && r && idxs, "cpp_ddpg_train_rows: NULL argument");
+  ARG_CHECK(B >= 1 && B <= d->maxB, "cpp_ddpg_train_rows: batch %d outside [1,%d]", B, d->maxB);
+  ARG_CHECK(r->elems == d->actor->state_elems && r->A == d->actor->spec.action_dim, "cpp_ddpg_train_rows: replay shape does not match the networks");
+  if (r->size <= 0) { cpp_set_error("cpp_ddpg_train_rows: replay memory is empty"); return CPP_ERR_STATE; }
+  cpp_ctx* ctx = d->ctx;
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (!d->step_batch) RC(cpp_batch_create(ctx, d->maxB, r->elems, r->A, &d->step_batch));
+  RC(replay_stage_rows(r, idxs, B, "cpp_ddpg_train_rows"));
+  static const bool no_graph = cpp_switch_set("CPP_NO_GRAPH");
+  if (ctx->prof || no_graph) return step_body(d, r, B, 1, r->rows_in, 0, false);
+  if (!d->rgraph_ok || d->rg_B != B || d->rg_replay_uid != r->uid) {
+    if (d->rgexec) { (void)hipGraphExecDestroy(d->rgexec); d->rgexec = nullptr; }
+    if (d->rgraph) { (void)hipGraphDestroy(d->rgraph); d->rgraph = nullptr; }
+    d->rgraph_ok = false;
+    RC(step_body(d, r, B, 1, r->rows_in, 0, false));          // eager pass: kernel attributes; it is also this call's minibatch
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    RC(capture_into(ctx, &d->rgraph, &d->rgexec, [&] { return step_body(d, r, B, 1, r->rows_in, 0, false); }));
+    d->rgraph_ok = true; d->rg_B = B; d->rg_replay_uid = r->uid;
+    return CPP_OK;
+  }
+  HIP_CHECK(hipGraphLaunch(d->rgexec, ctx->stream));
+  d->pre_variant = 0;
+  d->loss_parts = d->heads_grid; d->loss_B = d->heads_B;
+  return CPP_OK;
 }
 
 extern "C" int cpp_ddpg_train_step(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int32_t* idxs, uint64_t seed) {

@@ -108,6 +108,8 @@ struct cpp_batch {
   Arena arena;
 };
 
+#define CPP_ROWS_RING 8
+#define CPP_ROWS_RING_SLOT 4096      // ints per slot (larger draws take the synchronous copy)
 struct cpp_replay {
   cpp_ctx* ctx; int rows, slots, A, size; long elems;
   int store_dtype;         // CPP_F16 (replay_memory.py:32) or CPP_U8 (pixel codes k, read back as f16(k/255): half the HBM)
@@ -120,6 +122,9 @@ struct cpp_replay {
   __half* lut; int* bad; uint16_t lut_host[256];      // CPP_U8: f16(k/255) table, "not a pixel image" flag
   void* stage; size_t stage_cap;                      // device staging of incoming states (conversion source)
   void* pinned; size_t pinned_cap; hipEvent_t pinned_free; bool pinned_busy;   // host staging: writes return before the copy ends
+  // host-drawn minibatch rows on their way to rows_in (cpp_ddpg_train_rows / cpp_naf_train_rows): a ring of pinned slots, so that the
+  // call returns while the previous minibatch is still running (a pageable hipMemcpyAsync would wait for the stream)
+  int32_t* rows_pin; hipEvent_t rows_pin_ev[CPP_ROWS_RING]; bool rows_pin_used[CPP_ROWS_RING]; int rows_pin_k;
   Arena arena;
 };
 static size_t replay_esz(const cpp_replay* r) { return r->store_dtype == CPP_U8 ? 1 : sizeof(__half); }
@@ -214,6 +219,7 @@ GatherArgs replay_gather_args(cpp_replay* r, int B, const int32_t* rows_dev, uin
 int replay_sample_finish(cpp_replay* r, int B, int C, int channels, cpp_batch* out, uint64_t* bump = nullptr, bool* bumped = nullptr);
 int replay_sample_device(cpp_replay* r, int B, const int32_t* rows_dev, uint64_t seed, const uint64_t* counter_dev, int channels, cpp_batch* out, bool direct = false,
                          uint64_t* bump = nullptr, bool* bumped = nullptr);
+int replay_stage_rows(cpp_replay* r, const int32_t* idxs, int n, const char* who);
 const float* white_of(cpp_batch* b, int which, int C);
 bool direct_replay_ok(cpp_net* a, cpp_replay* r, int B);
 
@@ -222,7 +228,9 @@ struct cpp_comm {
   cpp_ctx* ctx; ncclComm_t comm; int rank, world;
   hipStream_t side;            // second stream: collectives that overlap the conv backward of the same minibatch
   hipEvent_t ev_fc, ev_bwd, ev_done;
+  double* scratch;             // CPP_COMM_SCRATCH_WORDS device doubles of cpp_comm_max_doubles (allocated on first use)
 };
+#define CPP_COMM_SCRATCH_WORDS 8
 #define NCCL_CHECK(expr)                                                                   \
   do {                                                                                     \
     ncclResult_t _r = (expr);                                                              \

@@ -13,6 +13,8 @@ struct cpp_naf {
   hipGraph_t graph; hipGraphExec_t gexec; bool graph_ok; int g_B, g_nb; uint64_t g_seed, g_replay_uid;
   // the data-parallel half step (sample + gradients) as a graph of its own
   hipGraph_t hgraph; hipGraphExec_t hexec; bool hgraph_ok; int h_B; uint64_t h_seed, h_replay_uid;
+  // ONE minibatch on host-drawn rows up to (not including) the optimiser (cpp_naf_train_rows)
+  hipGraph_t rgraph; hipGraphExec_t rgexec; bool rgraph_ok; int rg_B; uint64_t rg_replay_uid;
   uint64_t dp_local;       // minibatches applied locally since the last parameter averaging (periodic mode)
   cpp_batch* step_batch;
   Arena arena;
@@ -45,6 +47,7 @@ extern "C" int cpp_naf_create(cpp_ctx* ctx, cpp_net* value, cpp_net* tvalue, cpp
   for (cpp_net* n : {tvalue, mu, lv}) if (n->maxB < f->maxB) f->maxB = n->maxB;
   f->nV = value->nparams; f->nM = mu->nparams; f->nL = lv->nparams;
   f->graph = nullptr; f->gexec = nullptr; f->graph_ok = false; f->step_batch = nullptr; f->g_replay_uid = 0;
+  f->rgraph = nullptr; f->rgexec = nullptr; f->rgraph_ok = false; f->rg_B = 0; f->rg_replay_uid = 0;
   f->hgraph = nullptr; f->hexec = nullptr; f->hgraph_ok = false; f->h_B = 0; f->h_seed = 0; f->h_replay_uid = 0; f->dp_local = 0;
   const size_t nall = (size_t)(f->nV + f->nM + f->nL);
   int rc = dalloc(f->arena, &f->gradbuf, nall);
@@ -74,6 +77,8 @@ extern "C" int cpp_naf_destroy(cpp_naf* f) {
   (void)hipStreamSynchronize(f->ctx->stream);
   if (f->hexec) (void)hipGraphExecDestroy(f->hexec);
   if (f->hgraph) (void)hipGraphDestroy(f->hgraph);
+  if (f->rgexec) (void)hipGraphExecDestroy(f->rgexec);
+  if (f->rgraph) (void)hipGraphDestroy(f->rgraph);
   if (f->gexec) (void)hipGraphExecDestroy(f->gexec);
   if (f->graph) (void)hipGraphDestroy(f->graph);
   if (f->step_batch) cpp_batch_destroy(f->step_batch);
@@ -373,6 +378,52 @@ extern "C" int cpp_naf_train_step(cpp_naf* f, cpp_replay* r, int B, int n_batche
   }
   HIP_CHECK(hipGraphLaunch(f->gexec, ctx->stream));
   return CPP_OK;
+}
+
+// naf_cartpole.py:367-371 for ONE minibatch whose rows the HOST drew: `batch = replay_memory.batch(B); loss = naf.train(batch)` without a
+// gathered copy of the minibatch crossing PCIe or HBM twice -- the sample pass reads the replay store through those rows.  Like
+// cpp_naf_train: gradients, then the loss and the check_numerics flag come back (one stream sync: the reference's train() returns the
+// loss), then the optimiser -- which does not run when the flag is set.  The gradient half is one hipGraph per (B, replay).
+static int naf_rows_body(cpp_naf* f, cpp_replay* r, int B) {
+  const int C = f->value->spec.pixel ? f->value->spec.C : 0;
+  HIP_CHECK(hipMemsetAsync(f->nonfinite, 0, sizeof(int), f->ctx->stream));
+  RC(replay_sample_device(r, B, r->rows_in, 0, nullptr, C, f->step_batch, direct_replay_ok(f->value, r, B)));
+  return naf_compute_gradients(f, f->step_batch);
+}
+extern "C" int cpp_naf_train_rows(cpp_naf* f, cpp_replay* r, int B, const int32_t* idxs, float* loss) {
+  ARG_CHECK(f && r && idxs, "cpp_naf_train_rows: NULL argument");
+  ARG_CHECK(B >= 1 && B <= f->maxB, "cpp_naf_train_rows: batch %d outside [1,%d]", B, f->maxB);
+  ARG_CHECK(r->elems == f->value->state_elems && r->A == f->A, "cpp_naf_train_rows: replay shape does not match the networks");
+  if (r->size <= 0) { cpp_set_error("cpp_naf_train_rows: replay memory is empty"); return CPP_ERR_STATE; }
+  cpp_ctx* ctx = f->ctx;
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (!f->step_batch) RC(cpp_batch_create(ctx, f->maxB, r->elems, r->A, &f->step_batch));
+  RC(replay_stage_rows(r, idxs, B, "cpp_naf_train_rows"));
+  if (ctx->prof) {
+    RC(naf_rows_body(f, r, B));
+  } else if (!f->rgraph_ok || f->rg_B != B || f->rg_replay_uid != r->uid) {
+    if (f->rgexec) { (void)hipGraphExecDestroy(f->rgexec); f->rgexec = nullptr; }
+    if (f->rgraph) { (void)hipGraphDestroy(f->rgraph); f->rgraph = nullptr; }
+    f->rgraph_ok = false;
+    RC(naf_rows_body(f, r, B));                      // eager pass: sets kernel attributes, is this call's work
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = naf_rows_body(f, r, B);
+    const hipError_t e = hipStreamEndCapture(ctx->stream, &f->rgraph);
+    if (rc) return rc;
+    if (e != hipSuccess) { cpp_set_error("hipStreamEndCapture -> %s", hipGetErrorString(e)); return CPP_ERR_HIP; }
+    HIP_CHECK(hipGraphInstantiate(&f->rgexec, f->rgraph, nullptr, nullptr, 0));
+    f->rgraph_ok = true; f->rg_B = B; f->rg_replay_uid = r->uid;
+  } else {
+    HIP_CHECK(hipGraphLaunch(f->rgexec, ctx->stream));
+  }
+  int bad = 0; float l = 0.f;
+  HIP_CHECK(hipMemcpyAsync(&bad, f->nonfinite, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipMemcpyAsync(&l, f->stats, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (loss) *loss = l;
+  if (bad) { cpp_set_error("check_numerics: l_values / L / loss is not finite (naf_cartpole.py:242-245)"); return CPP_ERR_NUMERIC; }
+  return naf_apply(f, 1.0f);
 }
 
 // ---- data-parallel learners: the halves of one minibatch of naf_cartpole.py:367-371 -------------------------

@@ -106,6 +106,7 @@ static int replay_create(cpp_ctx* ctx, int buffer_size, int state_slots, int64_t
   r->arena.stream = ctx->stream;
   r->ctx = ctx; r->rows = buffer_size; r->slots = state_slots; r->A = action_dim; r->size = 0; r->elems = state_elems;
   r->store_dtype = store_dtype;
+  r->rows_pin = nullptr; r->rows_pin_k = 0; memset(r->rows_pin_used, 0, sizeof(r->rows_pin_used)); memset(r->rows_pin_ev, 0, sizeof(r->rows_pin_ev));
   r->stage = nullptr; r->stage_cap = 0; r->pinned = nullptr; r->pinned_cap = 0; r->pinned_busy = false; r->lut = nullptr; r->bad = nullptr;
   HIP_CHECK(hipEventCreateWithFlags(&r->pinned_free, hipEventDisableTiming));
   int rc = r->arena.alloc(&r->store, (size_t)state_slots * state_elems * replay_esz(r), false);
@@ -154,6 +155,8 @@ extern "C" int cpp_replay_destroy(cpp_replay* r) {
   (void)hipStreamSynchronize(r->ctx->stream);
   if (r->stage) (void)hipFree(r->stage);
   if (r->pinned) (void)hipHostFree(r->pinned);
+  if (r->rows_pin) (void)hipHostFree(r->rows_pin);
+  for (hipEvent_t e : r->rows_pin_ev) if (e) (void)hipEventDestroy(e);
   (void)hipEventDestroy(r->pinned_free);
   r->arena.release(); delete r; return CPP_OK;
 }
@@ -241,6 +244,29 @@ extern "C" int cpp_replay_write_rows(cpp_replay* r, const int32_t* rows, int n, 
   return CPP_OK;
 }
 
+// the event columns of n rows, as the device holds them (debug / parity; fill_synthetic's host mirrors).  NULL outputs are skipped.
+extern "C" int cpp_replay_read_rows(cpp_replay* r, const int32_t* rows, int n, int32_t* s1, int32_t* s2, float* action, float* reward,
+                                    float* mask) {
+  ARG_CHECK(r && rows && n >= 0, "cpp_replay_read_rows: bad argument");
+  hipStream_t st = r->ctx->stream;
+  HIP_CHECK(hipSetDevice(r->ctx->device));
+  int i = 0;
+  while (i < n) {          // contiguous runs of rows come back as one copy per column
+    ARG_CHECK(rows[i] >= 0 && rows[i] < r->rows, "cpp_replay_read_rows: row %d outside [0,%d)", rows[i], r->rows);
+    int j = i + 1;
+    while (j < n && rows[j] == rows[j - 1] + 1) ++j;
+    const int cnt = j - i, r0 = rows[i];
+    if (s1) HIP_CHECK(hipMemcpyAsync(s1 + i, r->s1 + r0, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (s2) HIP_CHECK(hipMemcpyAsync(s2 + i, r->s2 + r0, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (action) HIP_CHECK(hipMemcpyAsync(action + (size_t)i * r->A, r->action + (size_t)r0 * r->A, (size_t)cnt * r->A * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (reward) HIP_CHECK(hipMemcpyAsync(reward + i, r->reward + r0, cnt * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (mask) HIP_CHECK(hipMemcpyAsync(mask + i, r->mask + r0, cnt * sizeof(float), hipMemcpyDeviceToHost, st));
+    i = j;
+  }
+  HIP_CHECK(hipStreamSynchronize(st));
+  return CPP_OK;
+}
+
 extern "C" int cpp_replay_set_size(cpp_replay* r, int size) {
   if (r) ++r->write_gen;
   ARG_CHECK(r && size >= 0 && size <= r->rows, "cpp_replay_set_size: size %d outside [0,%d]", size, r ? r->rows : 0);
@@ -266,6 +292,33 @@ extern "C" int cpp_replay_read_states(cpp_replay* r, const int32_t* slots, int n
     uint16_t* o = (uint16_t*)out_f16;
     for (size_t i = 0; i < codes.size(); ++i) o[i] = r->lut_host[codes[i]];
   }
+  return CPP_OK;
+}
+
+// n host-drawn row indexes (replay_memory.py:123-129: numpy's RNG on the host) -> r->rows_in, checked, without waiting for the
+// stream: through a ring of pinned slots (slot k is reused once the copy that read it has completed)
+int replay_stage_rows(cpp_replay* r, const int32_t* idxs, int n, const char* who) {
+  ARG_CHECK(n >= 1 && n <= 65536, "%s: %d rows", who, n);
+  for (int i = 0; i < n; ++i)
+    ARG_CHECK(idxs[i] >= 0 && idxs[i] < r->size, "%s: index %d outside [0,%d)", who, idxs[i], r->size);
+  hipStream_t st = r->ctx->stream;
+  if (n > CPP_ROWS_RING_SLOT) {
+    HIP_CHECK(hipMemcpyAsync(r->rows_in, idxs, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    return CPP_OK;
+  }
+  if (!r->rows_pin) {
+    HIP_CHECK(hipHostMalloc((void**)&r->rows_pin, (size_t)CPP_ROWS_RING * CPP_ROWS_RING_SLOT * sizeof(int32_t), hipHostMallocDefault));
+    for (hipEvent_t& e : r->rows_pin_ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const int k = r->rows_pin_k;
+  r->rows_pin_k = (k + 1) % CPP_ROWS_RING;
+  if (r->rows_pin_used[k]) HIP_CHECK(hipEventSynchronize(r->rows_pin_ev[k]));
+  int32_t* slot = r->rows_pin + (size_t)k * CPP_ROWS_RING_SLOT;
+  memcpy(slot, idxs, (size_t)n * sizeof(int32_t));
+  HIP_CHECK(hipMemcpyAsync(r->rows_in, slot, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipEventRecord(r->rows_pin_ev[k], st));
+  r->rows_pin_used[k] = true;
   return CPP_OK;
 }
 

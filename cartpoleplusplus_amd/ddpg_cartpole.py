@@ -16,10 +16,7 @@ B2 pixel critic flattens pool3 before hidden1; B4 the np.clip(1, -1, actions) qu
 (upper bound only); B10 mean_losses is filled from the last minibatch's TD loss.
 """
 import argparse
-import collections
 import ctypes as C
-import datetime
-import json
 import os
 import sys
 import time
@@ -117,6 +114,9 @@ def build_parser():
       help="--data-parallel: 1 = gradient all-reduce per minibatch; k > 1 = k local minibatch updates, then parameter averaging")
     a('--overlap-allreduce', action='store_true',
       help="--data-parallel: reduce the fully connected layers' gradients beside the conv backward")
+    a('--async-rollouts', action='store_true',
+      help="play the episodes on a rollout thread while the learner trains back to back (training_loop.py): the learner -- and, with "
+           "--data-parallel, every other rank -- never waits for this process's environment once it is past burn-in")
     a('--synthetic-env', action='store_true', help="random-frame stand-in env (pybullet stays optional)")
     return parser
 
@@ -218,6 +218,14 @@ class ActorNetwork(base_network.Network):
         if self.critic is None:
             raise Exception("init_ops_for_training not called")
         trainer = self.critic._trainer()
+        # the reference's loop calls `actor.train(batch.state_1)` and then `critic.train(batch)` (:333-334).  When `state` is the
+        # state_1 COLUMN of a replay Batch, the update is deferred: if the critic's call on the same Batch follows, both run as the
+        # fused device sequence of train_step on those rows (legal: the critic's update never reads the live actor and the actor's
+        # never writes the critic); anything else that touches the actor or the trainer first runs it on its own (_Trainer.flush).
+        if (isinstance(state, replay_memory.StateColumn) and state.field == "state_1" and state.batch.in_replay()
+                and self.critic.target_critic is not None):
+            trainer.defer_actor(self, state.batch)
+            return
         dev = trainer.device_batch_for(state, state_only=True)
         check(lib.cpp_ddpg_train_actor(trainer.handle, dev.handle))
         if opts.print_gradients:
@@ -235,13 +243,54 @@ class _Trainer(object):
         h = C.c_void_p()
         check(lib.cpp_ddpg_create(actor.ctx.handle, actor.handle, critic.handle, target_actor.handle,
                                   target_critic.handle, C.byref(hp), C.byref(h)))
-        self.handle, self.ctx = h, actor.ctx
+        self._h, self.ctx = h, actor.ctx
         self.nets = (actor, critic, target_actor, target_critic)
         self.state_elems = int(actor._state_elems)
         self.action_dim = int(actor.action_dim)
         self._upload = {}
+        self._pending = None         # (actor network, Batch) of a deferred actor.train(batch.state_1)
+        self.fused_pairs = 0         # actor.train + critic.train pairs that ran as one fused sequence (tests, profiles)
+
+    @property
+    def handle(self):
+        """the cpp_ddpg; a deferred actor update lands first (every trainer op but the fused pair goes through here)."""
+        self.flush()
+        return self._h
+
+    def defer_actor(self, actor, batch):
+        self.flush()
+        self._pending = (actor, batch)
+        actor._before_use = self.flush
+
+    def flush(self):
+        """run a deferred actor.train now, on its own (ddpg_cartpole.py:140-145)."""
+        if self._pending is None:
+            return
+        (actor, batch), self._pending = self._pending, None
+        actor._before_use = None
+        check(lib.cpp_ddpg_train_actor(self._h, batch.device.handle))
+        if opts.print_gradients:
+            print("gradient %s l2_norm %s" % (actor.namespace, self.last_stats()[1]))
+
+    def train_pair(self, batch):
+        """critic.train(batch) arriving right behind the deferred actor.train(batch.state_1) of the SAME draw: both updates as the
+        fused minibatch of cpp_ddpg_train_step on the draw's rows (cpp_ddpg_train_rows); False if that is not the situation."""
+        if self._pending is None or self._pending[1] is not batch or not batch.in_replay():
+            return False
+        (actor, _), self._pending = self._pending, None
+        actor._before_use = None
+        rm = batch._memory
+        check(lib.cpp_ddpg_train_rows(self._h, rm.handle, len(batch.idxs), ptr(batch.idxs)))
+        self.fused_pairs += 1
+        if opts.print_gradients:
+            st = self.last_stats()
+            print("gradient %s l2_norm %s" % (actor.namespace, st[1]))
+            print("gradient %s l2_norm %s" % (self.nets[1].namespace, st[2]))
+        return True
 
     def device_batch_for(self, batch, state_only=False):
+        if isinstance(batch, replay_memory.StateColumn):          # a state column of a replay Batch: its rows, gathered on the device
+            batch = batch.batch
         if isinstance(batch, replay_memory.Batch) and batch.device is not None:
             return batch.device
         if state_only:
@@ -276,11 +325,13 @@ class _Trainer(object):
         return p.value, n.value
 
     def close(self):
+        if self._h:
+            self.flush()
         for b in self._upload.values():
             b.close()
-        if self.handle:
-            lib.cpp_ddpg_destroy(self.handle)
-            self.handle = None
+        if self._h:
+            lib.cpp_ddpg_destroy(self._h)
+            self._h = None
 
 
 class CriticNetwork(base_network.Network):
@@ -356,6 +407,8 @@ class CriticNetwork(base_network.Network):
         if self.target_critic is None:
             raise Exception("init_ops_for_training not called")
         trainer = self._trainer()
+        if isinstance(batch, replay_memory.Batch) and trainer.train_pair(batch):
+            return                  # ran together with the actor's deferred update (ActorNetwork.train)
         dev = trainer.device_batch_for(batch)
         check(lib.cpp_ddpg_train_critic(trainer.handle, dev.handle))
         if opts.print_gradients:
@@ -435,82 +488,61 @@ class DeepDeterministicPolicyGradientAgent(object):
         self.train_steps += 1
 
     def _dp_learner(self, batch_size):
-        cur = getattr(self, "_learner", None)
-        if cur is None or cur.B != int(batch_size):
-            from . import distributed
-            if cur is not None:
-                cur.close()
-            self._learner = distributed.learner_for_agent(self, opts, batch_size)
-        return self._learner
+        from . import distributed
+        return distributed.setup_data_parallel(self, opts, batch_size)
+
+    def _action(self, state, add_noise):
+        """action_given under the context lock of --async-rollouts (the rollout thread and the learner thread share one stream)."""
+        lock = getattr(self, "device_lock", None)
+        if lock is None:
+            return self.actor.action_given(state, add_noise)
+        with lock:
+            return self.actor.action_given(state, add_noise)
+
+    def _train_once(self, batch_size, batches_per_step):
+        """the inner step ddpg_cartpole.py:331-337; returns the losses it logs (B10: the last minibatch's TD loss)."""
+        if opts.host_rng_sampling:
+            for _ in range(batches_per_step):
+                batch = self.replay_memory.batch(batch_size)
+                self.actor.train(batch.state_1)
+                self.critic.train(batch)
+            self.target_actor.update_weights()
+            self.target_critic.update_weights()
+        else:
+            self.train_step(batch_size, batches_per_step)
+        return [float(self.trainer.last_stats()[0])]
+
+    def _verbose_after_train(self, batch_size):
+        if VERBOSE_DEBUG:                          # ddpg_cartpole.py:339-349
+            batch = self.replay_memory.batch(batch_size)
+            td_loss, td, q_value = self.critic.check_loss(batch)
+            print("-----")
+            print("temporal_difference_loss", td_loss)
+            print("temporal_difference", td.T)
+            print("q_value", q_value.T)
 
     def run_training(self, max_num_actions, max_run_time, batch_size, batches_per_step, saver_util):
-        start_time = time.time()
-        num_actions_taken = 0
-        n = 0
-        while True:
-            rewards = []
-            losses = []
-            if not opts.dont_do_rollouts:
-                # run an episode (physics + rendering stay on the host)
-                state_1 = self.env.reset()
-                initial_state = np.copy(state_1)
-                action_reward_state_sequence = []
-                done = False
-                while not done:
-                    action = self.actor.action_given(state_1, add_noise=True)
-                    state_2, reward, done, _ = self.env.step(action)
-                    rewards.append(reward)
-                    action_reward_state_sequence.append((action, reward, np.copy(state_2)))
-                    state_1 = state_2
-                self.replay_memory.add_episode(initial_state, action_reward_state_sequence)
+        """ddpg_cartpole.py:291-383.  The loop itself -- episode, add_episode, train after burn-in, STATS, checkpoint, eval every 10th,
+        exit tests -- is training_loop.TrainingLoop, shared with the NAF agent; under --data-parallel it takes the train / stop
+        decisions collectively, with --async-rollouts the episodes come from a rollout thread."""
+        from . import training_loop
+        agreement = None
+        if getattr(opts, "data_parallel", False):
+            agreement = self._dp_learner(batch_size).agreement()
+        if getattr(opts, "async_rollouts", False) and getattr(self, "device_lock", None) is None:
+            self.device_lock = training_loop.FairLock()
 
-            # do a training step (after waiting for buffer to fill a bit...)
-            if self.replay_memory.size() > opts.replay_memory_burn_in:
-                if opts.host_rng_sampling:
-                    for _ in range(batches_per_step):
-                        batch = self.replay_memory.batch(batch_size)
-                        self.actor.train(batch)
-                        self.critic.train(batch)
-                    self.target_actor.update_weights()
-                    self.target_critic.update_weights()
-                else:
-                    self.train_step(batch_size, batches_per_step)
-                losses.append(float(self.trainer.last_stats()[0]))
-                if VERBOSE_DEBUG:
-                    batch = self.replay_memory.batch(batch_size)
-                    td_loss, td, q_value = self.critic.check_loss(batch)
-                    print("-----")
-                    print("temporal_difference_loss", td_loss)
-                    print("temporal_difference", td.T)
-                    print("q_value", q_value.T)
-
-            stats = collections.OrderedDict()
-            stats["time"] = time.time()
-            stats["n"] = n
-            stats["mean_losses"] = float(np.mean(losses)) if losses else float("nan")
-            stats["total_reward"] = float(np.sum(rewards))
-            stats["episode_len"] = len(rewards)
-            stats["replay_memory_stats"] = self.replay_memory.current_stats()
-            print("STATS %s\t%s" % (datetime.datetime.now().strftime('%Y-%m-%d %H:%M:%S'), json.dumps(stats)))
-            sys.stdout.flush()
-            n += 1
-
-            if saver_util is not None:
-                saver_util.save_if_required()
-            if VERBOSE_DEBUG or n % 10 == 0:
-                self.run_eval(1)
+        def dump_requested():
             global DUMP_WEIGHTS
             if DUMP_WEIGHTS:
-                self.debug_dump_network_weights()
                 DUMP_WEIGHTS = False
-
-            num_actions_taken += len(rewards)
-            if max_num_actions > 0 and num_actions_taken > max_num_actions:
-                break
-            if max_run_time > 0 and time.time() > start_time + max_run_time:
-                break
-            if opts.dont_do_rollouts and max_num_actions <= 0 and max_run_time <= 0:
-                break
+                return True
+            return False
+        loop = training_loop.TrainingLoop(self, opts, act=lambda s: self._action(s, True), train=self._train_once,
+                                          agreement=agreement, verbose=lambda: VERBOSE_DEBUG,
+                                          after_train=self._verbose_after_train, dump_weights_requested=dump_requested)
+        loop.run(max_num_actions, max_run_time, batch_size, batches_per_step, saver_util)
+        return loop
 
     def debug_dump_network_weights(self):
         fn = "/tmp/weights.%s" % time.time()
@@ -531,7 +563,7 @@ class DeepDeterministicPolicyGradientAgent(object):
             steps = 0
             done = False
             while not done:
-                action = self.actor.action_given(state, add_noise)
+                action = self._action(state, add_noise)
                 state, reward, done, _ = self.env.step(action)
                 print("EVALSTEP r%s %s %s %s %s" % (i, steps, np.squeeze(action), np.linalg.norm(action), reward))
                 total_reward += reward
@@ -578,6 +610,10 @@ def main(argv=None):
         for v in net.trainable_model_vars():
             sys.stderr.write("%s %s\n" % (v.name, util.shape_and_product_of(v.shape)))
     agent.post_var_init_setup()
+    if opts.data_parallel and opts.num_eval <= 0:
+        # process group, rank 0's parameters to every rank, RCCL communicator: collective, so at the same point on every rank
+        from . import distributed
+        distributed.setup_data_parallel(agent, opts, opts.batch_size)
     if opts.num_eval > 0:
         agent.run_eval(opts.num_eval, opts.eval_action_noise)
     else:
@@ -587,6 +623,9 @@ def main(argv=None):
             saver_util.force_save()
     env.reset()
     agent.close()
+    if opts.data_parallel:
+        from . import distributed
+        distributed.shutdown_data_parallel()
     if hasattr(env, "close"):
         env.close()
 

@@ -11,11 +11,8 @@ tf.check_numerics (:242-245) becomes a device flag: `train` raises FloatingPoint
 the loss is not finite.
 """
 import argparse
-import collections
 import os
 import ctypes as C
-import datetime
-import json
 import sys
 import time
 
@@ -105,6 +102,8 @@ def build_parser():
       help="--data-parallel: 1 = gradient all-reduce per minibatch; k > 1 = k local minibatch updates, then parameter averaging")
     a('--overlap-allreduce', action='store_true',
       help="--data-parallel: reduce the fully connected layers' gradients beside the conv backward")
+    a('--async-rollouts', action='store_true',
+      help="play the episodes on a rollout thread while the learner trains back to back (training_loop.py)")
     a('--synthetic-env', action='store_true', help="random-frame stand-in env")
     return parser
 
@@ -209,6 +208,8 @@ class NafNetwork(base_network.Network):
     def _device_batch(self, batch):
         if isinstance(batch, replay_memory.Batch) and batch.device is not None:
             return batch.device
+        if isinstance(batch, replay_memory.Batch):
+            raise RuntimeError("empty batch")
         B = np.asarray(batch.state_1).shape[0]
         if B not in self._upload:
             self._upload[B] = replay_memory.DeviceBatch(B, self._state_elems, self.action_dim, self.ctx)
@@ -228,9 +229,14 @@ class NafNetwork(base_network.Network):
         return actions
 
     def train(self, batch):
-        dev = self._device_batch(batch)
         loss = C.c_float()
-        rc = lib.cpp_naf_train(self.handle, dev.handle, C.byref(loss))
+        if isinstance(batch, replay_memory.Batch) and batch.in_replay():
+            # a draw of the replay memory (naf_cartpole.py:367-371): the device samples those rows where they lie -- the B row
+            # indexes are all that crosses PCIe
+            rc = lib.cpp_naf_train_rows(self.handle, batch._memory.handle, len(batch.idxs), ptr(batch.idxs), C.byref(loss))
+        else:
+            dev = self._device_batch(batch)
+            rc = lib.cpp_naf_train(self.handle, dev.handle, C.byref(loss))
         if rc == 4:          # CPP_ERR_NUMERIC: the reference raises InvalidArgumentError from tf.check_numerics
             raise FloatingPointError(lib.cpp_last_error().decode())
         check(rc)
@@ -308,13 +314,7 @@ class NormalizedAdvantageFunctionAgent(object):
     def train_step(self, batch_size, batches_per_step, idxs=None):
         """the inner step naf_cartpole.py:367-373 as one device-side sequence (hipGraph after the first call)."""
         if idxs is None and getattr(opts, "data_parallel", False):      # one learner of N: the collective step (distributed.py)
-            cur = getattr(self, "_learner", None)
-            if cur is None or cur.B != int(batch_size):
-                from . import distributed
-                if cur is not None:
-                    cur.close()
-                self._learner = distributed.learner_for_agent(self, opts, batch_size)
-            self._learner.train_step(batches_per_step)
+            self._dp_learner(batch_size).train_step(batches_per_step)
             return
         rows = None
         if idxs is not None:
@@ -323,68 +323,59 @@ class NormalizedAdvantageFunctionAgent(object):
         check(lib.cpp_naf_train_step(self.naf.handle, self.replay_memory.handle, int(batch_size),
                                      int(batches_per_step), ptr(rows), int(opts.sample_seed)))
 
+    def _dp_learner(self, batch_size):
+        from . import distributed
+        return distributed.setup_data_parallel(self, opts, batch_size)
+
+    def _action(self, state, add_noise):
+        """action_given under the context lock of --async-rollouts (the rollout thread and the learner thread share one stream)."""
+        lock = getattr(self, "device_lock", None)
+        if lock is None:
+            return self.naf.action_given(state, add_noise)
+        with lock:
+            return self.naf.action_given(state, add_noise)
+
+    def _train_once(self, batch_size, batches_per_step):
+        """the inner step naf_cartpole.py:365-373; returns the losses it logs."""
+        losses = []
+        if opts.host_rng_sampling:
+            for _ in range(batches_per_step):
+                batch_start = time.time()
+                batch = self.replay_memory.batch(batch_size)
+                losses.append(self.naf.train(batch))
+                print("batch_took", time.time() - batch_start)
+            self.target_value_net.update_weights()
+        else:
+            batch_start = time.time()
+            self.train_step(batch_size, batches_per_step)
+            st = self.naf.last_stats()
+            if st[2] != 0:
+                raise FloatingPointError("check_numerics: non-finite l_values / L / loss")
+            losses.append(float(st[0]))
+            print("batch_took", (time.time() - batch_start) / batches_per_step)
+        return losses
+
     def run_training(self, max_num_actions, max_run_time, batch_size, batches_per_step, saver_util):
-        start_time = time.time()
-        num_actions_taken, n = 0, 0
-        while True:
-            rewards, losses = [], []
-            if not opts.dont_do_rollouts:
-                state_1 = self.env.reset()
-                initial_state = np.copy(state_1)
-                action_reward_state_sequence = []
-                episode_start = time.time()
-                done = False
-                while not done:
-                    action = self.naf.action_given(state_1, add_noise=True)
-                    state_2, reward, done, _ = self.env.step(action)
-                    rewards.append(reward)
-                    action_reward_state_sequence.append((action, reward, np.copy(state_2)))
-                    state_1 = state_2
-                print("episode_took", time.time() - episode_start, len(rewards))
-                replay_add_start = time.time()
-                self.replay_memory.add_episode(initial_state, action_reward_state_sequence)
-                print("replay_took", time.time() - replay_add_start)
-            if self.replay_memory.size() > opts.replay_memory_burn_in:
-                if opts.host_rng_sampling:
-                    for _ in range(batches_per_step):
-                        batch_start = time.time()
-                        batch = self.replay_memory.batch(batch_size)
-                        losses.append(self.naf.train(batch))
-                        print("batch_took", time.time() - batch_start)
-                    self.target_value_net.update_weights()
-                else:
-                    batch_start = time.time()
-                    self.train_step(batch_size, batches_per_step)
-                    st = self.naf.last_stats()
-                    if st[2] != 0:
-                        raise FloatingPointError("check_numerics: non-finite l_values / L / loss")
-                    losses.append(float(st[0]))
-                    print("batch_took", (time.time() - batch_start) / batches_per_step)
-            stats = collections.OrderedDict()
-            stats["time"] = time.time()
-            stats["n"] = n
-            stats["mean_losses"] = float(np.mean(losses)) if losses else float("nan")
-            stats["total_reward"] = float(np.sum(rewards))
-            stats["episode_len"] = len(rewards)
-            stats["replay_memory_stats"] = self.replay_memory.current_stats()
-            print("STATS %s\t%s" % (datetime.datetime.now().strftime('%Y-%m-%d %H:%M:%S'), json.dumps(stats)))
-            sys.stdout.flush()
-            n += 1
-            if saver_util is not None:
-                saver_util.save_if_required()
-            if VERBOSE_DEBUG or n % 10 == 0:
-                self.run_eval(1)
+        """naf_cartpole.py:323-389; the loop is training_loop.TrainingLoop, shared with the DDPG agent (rank agreement under
+        --data-parallel, rollout thread with --async-rollouts)."""
+        from . import training_loop
+        agreement = None
+        if getattr(opts, "data_parallel", False):
+            agreement = self._dp_learner(batch_size).agreement()
+        if getattr(opts, "async_rollouts", False) and getattr(self, "device_lock", None) is None:
+            self.device_lock = training_loop.FairLock()
+
+        def dump_requested():
             global DUMP_WEIGHTS
             if DUMP_WEIGHTS:
-                self.debug_dump_network_weights()
                 DUMP_WEIGHTS = False
-            num_actions_taken += len(rewards)
-            if max_num_actions > 0 and num_actions_taken > max_num_actions:
-                break
-            if max_run_time > 0 and time.time() > start_time + max_run_time:
-                break
-            if opts.dont_do_rollouts and max_num_actions <= 0 and max_run_time <= 0:
-                break
+                return True
+            return False
+        loop = training_loop.TrainingLoop(self, opts, act=lambda s: self._action(s, True), train=self._train_once,
+                                          agreement=agreement, verbose=lambda: VERBOSE_DEBUG, timing_prints=True,
+                                          dump_weights_requested=dump_requested)
+        loop.run(max_num_actions, max_run_time, batch_size, batches_per_step, saver_util)
+        return loop
 
     def debug_dump_network_weights(self):
         fn = "/tmp/weights.%s" % time.time()
@@ -402,7 +393,7 @@ class NormalizedAdvantageFunctionAgent(object):
             state = self.env.reset()
             total_reward, steps, done = 0, 0, False
             while not done:
-                action = self.naf.action_given(state, add_noise)
+                action = self._action(state, add_noise)
                 state, reward, done, _ = self.env.step(action)
                 print("EVALSTEP e%d s%d action=%s (l2=%s) => reward %s" % (i, steps, action, np.linalg.norm(action), reward))
                 total_reward += reward
@@ -433,6 +424,9 @@ def main(argv=None):
     else:
         agent.initialise_variables()
     agent.post_var_init_setup()
+    if opts.data_parallel and opts.num_eval <= 0:
+        from . import distributed        # collective set-up at the same point on every rank (see ddpg_cartpole.main)
+        distributed.setup_data_parallel(agent, opts, opts.batch_size)
     if opts.num_eval > 0:
         agent.run_eval(opts.num_eval, opts.eval_action_noise)
     else:
@@ -441,6 +435,9 @@ def main(argv=None):
             saver_util.force_save()
     env.reset()
     agent.close()
+    if opts.data_parallel:
+        from . import distributed
+        distributed.shutdown_data_parallel()
     if hasattr(env, "close"):
         env.close()
 

@@ -9,9 +9,11 @@ own test still expects (replay_memory_test.py:84,129).
 
 What is different underneath: the f16 state store (replay_memory.py:32) lives in HBM behind
 cpp_replay_*; only the slot bookkeeping (FIFO free list, eviction -- replay_memory.py:66,84,90,104)
-runs on the host so its order is exactly the reference's.  `batch()` is the fused sample + gather
-kernel; the returned Batch keeps the minibatch on the device and only copies a column to the host
-when that column is read.
+runs on the host so its order is exactly the reference's.  `batch()` draws the rows (numpy's RNG, as the
+reference) and returns a Batch whose two state columns are `StateColumn`s: still in HBM, downloaded only
+if numpy reads them, and recognised by the agents' train ops, which run the fused sample + gather +
+update sequence on the device rows (the reference's literal loop ddpg_cartpole.py:331-334 moves B row
+indexes over PCIe per minibatch, not 75 MB of pixels).
 """
 import collections
 import ctypes as C
@@ -25,70 +27,135 @@ from ._lib import lib, check, ptr
 _FIELDS = ("state_1", "action", "reward", "terminal_mask", "state_2")
 
 
+def _delegate(name):
+    def op(self, *args):
+        return getattr(self._array(), name)(*args)
+    op.__name__ = name
+    return op
+
+
+class StateColumn(object):
+    """`batch.state_1` / `batch.state_2`: the (B, *state_shape) f16 column of a Batch, still resident in HBM.
+
+    The reference's Batch holds host copies (replay_memory.py:134-138) that its training loop hands straight back to the device
+    (`actor.train(batch.state_1)`, ddpg_cartpole.py:333 -- 2 x 37.7 MB per minibatch at 64x64x18).  This column has the array's
+    `shape` / `dtype` / `len`, converts on demand (`np.asarray(col)`, indexing, arithmetic, any ndarray attribute: ONE download, then
+    cached), and is recognised by the network classes, which take its Batch's device rows instead: nothing crosses PCIe unless
+    numpy actually looks at the pixels."""
+    __slots__ = ("_batch", "_field")
+    __array_priority__ = 100.0
+
+    def __init__(self, batch, field):
+        self._batch, self._field = batch, field
+
+    @property
+    def batch(self):
+        return self._batch
+
+    @property
+    def field(self):
+        return self._field
+
+    @property
+    def shape(self):
+        return (len(self._batch.idxs),) + self._batch._shape
+
+    dtype = np.dtype(np.float16)
+
+    @property
+    def ndim(self):
+        return 1 + len(self._batch._shape)
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape))
+
+    def _array(self):
+        return self._batch._host_states()[self._field]
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._array()
+        if dtype is not None and np.dtype(dtype) != a.dtype:
+            return a.astype(dtype)
+        return a.copy() if copy else a
+
+    def __len__(self):
+        return len(self._batch.idxs)
+
+    def __getattr__(self, name):          # any other ndarray attribute / method (astype, reshape, T, mean, ...)
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return getattr(self._array(), name)
+
+    def __repr__(self):
+        return "<StateColumn %s %s f16 of a device-resident Batch>" % (self._field, self.shape)
+
+
+for _n in ("__getitem__", "__iter__", "__eq__", "__ne__", "__lt__", "__le__", "__gt__", "__ge__", "__add__", "__radd__", "__sub__",
+           "__rsub__", "__mul__", "__rmul__", "__truediv__", "__rtruediv__", "__neg__", "__abs__", "__pow__", "__matmul__"):
+    setattr(StateColumn, _n, _delegate(_n))
+StateColumn.__hash__ = None
+
+
 class Batch(object):
     """replay_memory.py:9 `Batch = namedtuple("Batch", "state_1 action reward terminal_mask state_2")`.
-    Tuple protocol preserved (len 5, indexing, iteration, attribute names); columns are fetched from
-    the device on first access (fresh host copies the caller owns, like np.copy in :134-138)."""
+    Tuple protocol preserved (len 5, indexing, iteration, attribute names).  A Batch is a DRAW: the row indexes, the state slots
+    they pointed to and host copies of the three small columns, all taken at batch() time.  The two state columns stay in the
+    replay store (`StateColumn`) until somebody reads them; `device` gathers the draw into a device minibatch for the train ops
+    that want one.  Both work as long as no state has been written to the memory since the draw (or the column was read before);
+    after that they raise instead of returning another draw's pixels."""
     _fields = _FIELDS
 
-    def __init__(self, device_batch, state_shape, idxs=None, s1_idx=None, s2_idx=None, empty=False, memory=None):
-        self._dev, self._shape, self._cache, self._empty = device_batch, tuple(state_shape), {}, empty
+    def __init__(self, memory, state_shape, idxs, s1_idx, s2_idx, small):
+        self._memory, self._shape = memory, tuple(state_shape)
         self.idxs, self.state_1_idx, self.state_2_idx = idxs, s1_idx, s2_idx
-        # the device buffer behind this Batch is shared with the next batch() of the same size: `memory` detaches this
-        # Batch (see _detach) before it resamples, so that the columns read later are still THIS draw's (np.copy semantics
-        # of replay_memory.py:134-138)
-        self._memory, self._detached, self._small, self._store_gen = memory, False, None, None
+        self._small = small                       # {"action", "reward", "terminal_mask"}: host arrays this Batch owns
+        self._states = None                       # {"state_1", "state_2"} once downloaded
+        self._gen = memory._write_gen if memory is not None else None
+        self._cols = {}
 
     @classmethod
     def empty(cls, state_shape, action_dim):
-        b = cls(None, state_shape, empty=True)
-        b._cache = {"state_1": np.empty((0,) + tuple(state_shape), np.float16),
-                    "action": np.empty((0, action_dim), np.float32),
-                    "reward": np.empty((0, 1), np.float32),
-                    "terminal_mask": np.empty((0, 1), np.float32),
-                    "state_2": np.empty((0,) + tuple(state_shape), np.float16)}
+        b = cls(None, state_shape, np.empty(0, np.int32), np.empty(0, np.int32), np.empty(0, np.int32),
+                {"action": np.empty((0, action_dim), np.float32), "reward": np.empty((0, 1), np.float32),
+                 "terminal_mask": np.empty((0, 1), np.float32)})
+        b._states = {"state_1": np.empty((0,) + tuple(state_shape), np.float16),
+                     "state_2": np.empty((0,) + tuple(state_shape), np.float16)}
         return b
 
-    def _detach(self):
-        """the owner is about to overwrite the shared device buffer: keep this draw readable.  The three small columns are
-        copied now (a few KB); the state columns are re-read on demand from the replay store through the slots recorded at
-        sample time -- valid as long as no state has been written to the memory since (otherwise reading them raises)."""
-        if self._cache or self._empty or self._detached:
-            return
-        d = self._dev
-        B = d.size
-        a, r, m = np.empty((B, d.action_dim), np.float32), np.empty((B, 1), np.float32), np.empty((B, 1), np.float32)
-        check(lib.cpp_batch_download(d.handle, None, None, ptr(a), ptr(r), ptr(m)))
-        self._small = {"action": a, "reward": r, "terminal_mask": m}
-        self._store_gen = self._memory._write_gen
-        self._detached, self._dev = True, None
+    def in_replay(self):
+        """True while the rows of this draw are still what the replay memory holds (no write since batch())."""
+        rm = self._memory
+        return rm is not None and rm.handle is not None and rm._write_gen == self._gen
 
-    def _fetch(self):
-        if self._cache or self._empty:
-            return
-        if self._detached:
+    def _gone(self):
+        return RuntimeError("states have been written to the replay memory since this Batch was drawn and its state columns were "
+                            "never read: they are gone (read a column, or finish with the Batch, before the next add_episode())")
+
+    def _host_states(self):
+        if self._states is None:
             rm = self._memory
-            if rm._write_gen != self._store_gen or rm.handle is None:
-                raise RuntimeError("this Batch was not read before its device buffer was resampled AND states have been "
-                                   "written to the replay memory since: its state columns are gone (read a column, or "
-                                   "finish with the Batch, before the next batch() / add_episode())")
-            self._cache = dict(self._small, state_1=rm.state[self.state_1_idx], state_2=rm.state[self.state_2_idx])
-            return
-        d = self._dev
-        B = d.size
-        dt = np.float16 if d.state_dtype == _lib.CPP_F16 else np.float32
-        s1 = np.empty((B,) + self._shape, dt)
-        s2 = np.empty((B,) + self._shape, dt)
-        a = np.empty((B, d.action_dim), np.float32)
-        r = np.empty((B, 1), np.float32)
-        m = np.empty((B, 1), np.float32)
-        check(lib.cpp_batch_download(d.handle, ptr(s1), ptr(s2), ptr(a), ptr(r), ptr(m)))
-        self._cache = {"state_1": s1, "action": a, "reward": r, "terminal_mask": m, "state_2": s2}
+            dev = rm._batches.get(len(self.idxs)) if rm is not None and rm.handle is not None else None
+            if dev is not None and dev.owner() is self:          # gathered already: one copy of both columns
+                B = len(self.idxs)
+                s1, s2 = np.empty((B,) + self._shape, np.float16), np.empty((B,) + self._shape, np.float16)
+                check(lib.cpp_batch_download(dev.handle, ptr(s1), ptr(s2), None, None, None))
+                self._states = {"state_1": s1, "state_2": s2}
+            elif self.in_replay():
+                self._states = {"state_1": rm.state[self.state_1_idx], "state_2": rm.state[self.state_2_idx]}
+            else:
+                raise self._gone()
+        return self._states
 
     def __getattr__(self, name):
-        if name in _FIELDS:
-            self._fetch()
-            return self._cache[name]
+        if name in ("state_1", "state_2"):
+            if self._states is not None:
+                return self._states[name]
+            if name not in self._cols:
+                self._cols[name] = StateColumn(self, name)
+            return self._cols[name]
+        if name in ("action", "reward", "terminal_mask"):
+            return self._small[name]
         raise AttributeError(name)
 
     def __len__(self):
@@ -102,8 +169,25 @@ class Batch(object):
 
     @property
     def device(self):
-        """the DeviceBatch behind this Batch (None for the empty batch)."""
-        return self._dev
+        """this draw as a DeviceBatch (None for the empty batch).  The device buffer is shared by all Batches of one size and
+        remembers whose draw it holds: a Batch that is not the owner gathers (or uploads) its rows again."""
+        rm = self._memory
+        if rm is None or len(self.idxs) == 0:
+            return None
+        if rm.handle is None:
+            raise self._gone()
+        B = len(self.idxs)
+        dev = rm._device_batch(B)
+        if dev.owner() is not self:
+            if self.in_replay():
+                check(lib.cpp_replay_sample(rm.handle, B, ptr(self.idxs), 0, 0, rm.channels, dev.handle))
+            elif self._states is not None:
+                dev.upload(self._states["state_1"], self._small["action"], self._small["reward"], self._small["terminal_mask"],
+                           self._states["state_2"])
+            else:
+                raise self._gone()
+            dev.set_owner(self)
+        return dev
 
 
 class DeviceBatch(object):
@@ -115,6 +199,13 @@ class DeviceBatch(object):
         h = C.c_void_p()
         check(lib.cpp_batch_create(self.ctx.handle, self.max_batch, self.state_elems, self.action_dim, C.byref(h)))
         self.handle = h
+        self._owner = None           # weakref of the Batch whose draw the buffer holds (replay_memory.Batch.device)
+
+    def owner(self):
+        return self._owner() if self._owner is not None else None
+
+    def set_owner(self, batch):
+        self._owner = weakref.ref(batch) if batch is not None else None
 
     @property
     def size(self):
@@ -135,6 +226,7 @@ class DeviceBatch(object):
         a, r, m = f32(action, self.action_dim), f32(reward, 1), f32(terminal_mask, 1)
         assert s1.size == B * self.state_elems, (s1.shape, self.state_elems)
         check(lib.cpp_batch_upload(self.handle, B, ptr(s1), ptr(s2), dt, ptr(a), ptr(r), ptr(m)))
+        self._owner = None
         return self
 
     def close(self):
@@ -194,7 +286,6 @@ class ReplayMemory(object):
         self.handle = h
         self.state = _StateStoreView(self)
         self._batches = {}
-        self._live = {}              # batch size -> weakref of the Batch that currently shares that DeviceBatch
         self._write_gen = 0          # bumped by every write of states (add_episode, fill_synthetic)
         self._adhoc_counter = 0      # sample_on_device draws (separate from the train steps' device counter)
         # pixel states (H, W, 3, cameras, repeats): channel count for the fused whitening statistics
@@ -228,6 +319,7 @@ class ReplayMemory(object):
             self.state_free_slots = saved["free"]
             self.insert, self.full, self.stats = saved["insert"], saved["full"], saved["stats"]
             self.stats[">add_episode"] += 1
+            self._write_gen += 1         # (a device write may have happened: Batches drawn before this call do not re-read the store)
             raise
 
     def _add_episode_locked(self, initial_state, seq, n, slots, rows, s1, s2, saved):
@@ -265,6 +357,12 @@ class ReplayMemory(object):
             states[k + 1] = np.asarray(seq[k][2]).reshape(-1)
         if dt == _lib.CPP_F32:
             states, dt = states.astype(np.float16), _lib.CPP_F16
+        if self.store_dtype == "u8" and dt == _lib.CPP_F16:
+            # the 8-bit store only holds f16(k/255) images: refuse anything else BEFORE a slot is written (the slots popped above may
+            # be the ones this very episode's evictions freed -- a device-side refusal would come after they were overwritten)
+            codes = (np.arange(256) / 255.0).astype(np.float16).view(np.uint16)
+            if not np.isin(states.view(np.uint16), codes).all():
+                raise RuntimeError("replay memory (8-bit store): a state is not an image of f16(k/255) pixels")
         check(lib.cpp_replay_write_states(self.handle, ptr(slots), n + 1, ptr(states), dt))
         check(lib.cpp_replay_write_rows(self.handle, ptr(rows), n, ptr(s1), ptr(s2),
                                         ptr(np.ascontiguousarray(self.action[rows])),
@@ -286,29 +384,27 @@ class ReplayMemory(object):
     def _device_batch(self, B):
         if B not in self._batches:
             self._batches[B] = DeviceBatch(B, self.state_elems, self.action_dim, self.ctx)
-        prev = self._live.pop(B, None)
-        prev = prev() if prev is not None else None
-        if prev is not None:         # an earlier Batch of this size is still alive: it keeps its own draw
-            prev._detach()
         return self._batches[B]
 
-    def _new_batch(self, dev, idxs):
-        b = Batch(dev, self.state_shape, idxs, self.state_1_idx[idxs], self.state_2_idx[idxs], memory=self)
-        self._live[len(idxs)] = weakref.ref(b)
-        return b
+    def _new_batch(self, idxs):
+        """the draw `idxs` as a Batch: slots and the three small columns are copied from the host mirrors now (np.copy semantics of
+        replay_memory.py:134-138 for everything that is cheap), the states stay where they are."""
+        small = {"action": self.action[idxs], "reward": self.reward[idxs], "terminal_mask": self.terminal_mask[idxs]}
+        return Batch(self, self.state_shape, idxs, self.state_1_idx[idxs], self.state_2_idx[idxs], small)
 
     def batch(self, batch_size=None, idxs=None):
-        """replay_memory.py:131-138.  Rows come from numpy's global RNG exactly like the reference
-        (`idxs=` overrides, as replay_memory_test.py:84 expects); the gather runs on the device."""
+        """replay_memory.py:131-138.  Rows come from numpy's global RNG exactly like the reference (`idxs=` overrides, as
+        replay_memory_test.py:84 expects).  No device work happens here: the returned Batch is the draw, its state columns are
+        read (or trained on) where they lie."""
         self.stats[">batch"] += 1
         if idxs is None:
             idxs = self.random_indexes(batch_size)
         idxs = np.ascontiguousarray(np.asarray(idxs, dtype=np.int64).astype(np.int32))
         if len(idxs) == 0:
             return Batch.empty(self.state_shape, self.action_dim)
-        dev = self._device_batch(len(idxs))
-        check(lib.cpp_replay_sample(self.handle, len(idxs), ptr(idxs), 0, 0, self.channels, dev.handle))
-        return self._new_batch(dev, idxs)
+        if len(idxs) and (idxs.min() < 0 or idxs.max() >= max(self.size(), 1)):
+            raise RuntimeError("batch: index outside [0,%d)" % self.size())
+        return self._new_batch(idxs)
 
     def sample_on_device(self, batch_size, seed=0, counter=None):
         """Device-side Philox draw (no host RNG, no host copies) -- the sampler of the fused train step, for inspection:
@@ -320,23 +416,27 @@ class ReplayMemory(object):
             counter = self._adhoc_counter
             self._adhoc_counter += 1
         dev = self._device_batch(int(batch_size))
+        dev.set_owner(None)
         check(lib.cpp_replay_sample(self.handle, int(batch_size), None, int(seed), int(counter),
                                     self.channels, dev.handle))
         idxs = np.empty(int(batch_size), np.int32)
         check(lib.cpp_replay_last_indexes(self.handle, int(batch_size), ptr(idxs)))
-        return self._new_batch(dev, idxs)
+        b = self._new_batch(idxs)
+        dev.set_owner(b)
+        return b
 
     def fill_synthetic(self, n_rows, seed=1234):
-        """bench/test helper: synthetic transitions generated on the device.  The host
-        bookkeeping is advanced to match (fixed 50-step episodes, chain slot layout)."""
+        """bench/test helper: synthetic transitions generated on the device.  The host bookkeeping is advanced to
+        match (fixed 50-step episodes, chain slot layout) and the host mirrors of the event columns are read back."""
         n_rows = int(n_rows)
         check(lib.cpp_replay_fill_synthetic(self.handle, n_rows, int(seed)))
         self._write_gen += 1
-        i = np.arange(n_rows)
-        self.state_1_idx[:n_rows] = i + i // 50
-        self.state_2_idx[:n_rows] = i + i // 50 + 1
-        self.reward[:n_rows] = 1.0
-        self.terminal_mask[:n_rows, 0] = np.where(i % 50 == 49, 0.0, 1.0)
+        rows = np.arange(n_rows, dtype=np.int32)
+        s1, s2 = np.empty(n_rows, np.int32), np.empty(n_rows, np.int32)
+        a, r, m = np.empty((n_rows, self.action_dim), np.float32), np.empty((n_rows, 1), np.float32), np.empty((n_rows, 1), np.float32)
+        check(lib.cpp_replay_read_rows(self.handle, ptr(rows), n_rows, ptr(s1), ptr(s2), ptr(a), ptr(r), ptr(m)))
+        self.state_1_idx[:n_rows], self.state_2_idx[:n_rows] = s1, s2
+        self.action[:n_rows], self.reward[:n_rows], self.terminal_mask[:n_rows] = a, r, m
         used = n_rows + n_rows // 50 + 1
         self.state_free_slots = collections.deque(range(used, self.state_buffer_size))
         self.insert, self.full = (0, True) if n_rows == self.buffer_size else (n_rows, False)

@@ -161,6 +161,10 @@ int cpp_replay_write_states(cpp_replay* replay, const int32_t* slots, int n, con
 int cpp_replay_write_rows(cpp_replay* replay, const int32_t* rows, int n, const int32_t* state_1_idx,
                           const int32_t* state_2_idx, const float* action, const float* reward,
                           const float* terminal_mask);
+/* the same columns read back from the device for n rows (any of the outputs may be NULL) -- replay_memory.py's public attributes
+ * state_1_idx / action / reward / terminal_mask / state_2_idx (:22-29) as the sampler sees them */
+int cpp_replay_read_rows(cpp_replay* replay, const int32_t* rows, int n, int32_t* s1_idx, int32_t* s2_idx, float* action,
+                         float* reward, float* terminal_mask);
 int cpp_replay_set_size(cpp_replay* replay, int size);          /* ReplayMemory.size(), :120 */
 int cpp_replay_read_states(cpp_replay* replay, const int32_t* slots, int n, void* out_f16);
 /* random_indexes + batch (replay_memory.py:123-138) fused: idxs == NULL draws B uniform rows on the
@@ -213,6 +217,12 @@ int cpp_ddpg_update_targets(cpp_ddpg* ddpg);
  * when idxs == NULL and profiling is off. */
 int cpp_ddpg_train_step(cpp_ddpg* ddpg, cpp_replay* replay, int B, int n_batches,
                         const int32_t* idxs, uint64_t seed);
+/* ddpg_cartpole.py:332-334 for ONE minibatch on B rows the HOST drew (replay_memory.py:123-129, numpy's RNG):
+ *     batch = self.replay_memory.batch(batch_size); self.actor.train(batch.state_1); self.critic.train(batch)
+ * as the same fused device sequence as one minibatch of cpp_ddpg_train_step -- no gathered copy of the states, no PCIe traffic
+ * but the B row indexes -- WITHOUT the target updates (:336-337 stay the caller's: cpp_net_soft_update).  hipGraph-replayed after
+ * the first call per (B, replay); returns while the minibatch is still running. */
+int cpp_ddpg_train_rows(cpp_ddpg* ddpg, cpp_replay* replay, int B, const int32_t* idxs);
 /* Data-parallel learners: the first half of one minibatch of the inner step -- sample B rows on the
  * device (Philox; the counter advances by one) and leave both gradient sets in the flat gradient
  * buffer.  cpp_ddpg_allreduce_grads + cpp_ddpg_apply_gradients(1/N) finish the minibatch
@@ -242,6 +252,10 @@ int cpp_comm_info(const cpp_comm* comm, int* rank, int* world);
 int cpp_comm_allreduce(cpp_comm* comm, void* device_f32, int64_t n, int average);
 /* max over the ranks of one host double / a barrier (bench.py's timed region: max-over-ranks time between two barriers) */
 int cpp_comm_max_double(cpp_comm* comm, double* value);
+/* element-wise max over the ranks of n (1..8) host doubles.  The agents' --data-parallel loops decide "train this iteration" and
+ * "leave the loop" with it once per outer iteration (the per-process tests of ddpg_cartpole.py:329 and :379-383 / naf_cartpole.py:
+ * 365,386-389 in front of a collective step would leave the slower ranks blocked in ncclAllReduce). */
+int cpp_comm_max_doubles(cpp_comm* comm, double* values, int n);
 int cpp_comm_barrier(cpp_comm* comm);
 /* sum over the ranks of the flat gradient buffer [actor grads | critic grads] left by cpp_ddpg_sample_and_compute /
  * cpp_ddpg_compute_gradients; cpp_ddpg_apply_gradients(1 / world) then gives every rank the same update. */
@@ -300,6 +314,10 @@ int cpp_naf_update_targets(cpp_naf* naf);
  * A non-finite minibatch sets a sticky flag that cpp_naf_last_stats reports (out[2] != 0). */
 int cpp_naf_train_step(cpp_naf* naf, cpp_replay* replay, int B, int n_batches, const int32_t* idxs,
                        uint64_t seed);
+/* naf_cartpole.py:367-371 for ONE minibatch on B rows the HOST drew: `batch = replay_memory.batch(B); loss = naf.train(batch)` with the
+ * sample pass reading the replay store through those rows (no gathered copy).  *loss = the minibatch's loss; CPP_ERR_NUMERIC (the
+ * optimiser does not run) when l_values, L or the loss is not finite, like cpp_naf_train.  No target update (:373 stays the caller's). */
+int cpp_naf_train_rows(cpp_naf* naf, cpp_replay* replay, int B, const int32_t* idxs, float* loss);
 /* [0] loss of the last minibatch, [1] pre-clip global gradient norm, [2] non-finite flag (sticky). */
 int cpp_naf_last_stats(cpp_naf* naf, float out[3]);
 /* The optimiser's slot variables, which tf.train.Saver checkpoints with everything else (util.py:88-90): Momentum accumulators

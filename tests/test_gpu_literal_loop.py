@@ -1,0 +1,150 @@
+"""The reference's inner loop, written as the reference writes it (ddpg_cartpole.py:331-337, naf_cartpole.py:365-373), must be the
+fused device sequence: `batch.state_1` is a device-resident column, `actor.train(batch.state_1)` waits for `critic.train(batch)`
+and both run as cpp_ddpg_train_rows on the draw's rows -- bit-identical to `agent.train_step(..., idxs=)` on the same rows, with
+no state bytes over PCIe.  Anything that looks at the actor in between gets the unfused update first."""
+import collections
+
+import numpy as np
+import pytest
+
+from tests.helpers import make_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _twin_agents(shape, B, pixel, rows, seed=3, **kw):
+    out = []
+    for _ in range(2):
+        agent, _ref, _ = make_pair(shape, B, pixel, seed=seed, replay_size=rows + 40, **kw)
+        agent.replay_memory.fill_synthetic(rows, seed=21)
+        out.append(agent)
+    return out
+
+
+@pytest.mark.parametrize("shape,B,pixel", [((32, 32, 3, 2, 3), 32, True), ((16, 16, 3, 1, 2), 8, True), ((2, 2, 7), 16, False)])
+def test_reference_loop_verbatim_is_the_fused_step_bit_for_bit(shape, B, pixel):
+    lit, fused = _twin_agents(shape, B, pixel, rows=200)
+    try:
+        np.random.seed(1234)
+        drawn = []
+        batches_per_step = 5
+        for _step in range(2):
+            # ---- ddpg_cartpole.py:331-337, verbatim (self -> lit)
+            for _ in range(batches_per_step):
+                batch = lit.replay_memory.batch(B)
+                lit.actor.train(batch.state_1)
+                lit.critic.train(batch)
+                drawn.append(batch)
+            lit.target_actor.update_weights()
+            lit.target_critic.update_weights()
+        assert lit.trainer.fused_pairs == 10
+        assert all(b._states is None for b in drawn), "a state column crossed PCIe"
+        idxs = np.concatenate([b.idxs for b in drawn])
+        for k in range(2):
+            fused.train_step(B, batches_per_step, idxs=idxs[k * 5 * B:(k + 1) * 5 * B])
+        for a, b in zip(lit.networks(), fused.networks()):
+            assert np.array_equal(a.get_params(), b.get_params()), a.namespace
+        assert np.array_equal(lit.trainer.last_stats(), fused.trainer.last_stats())
+        # the columns are still readable afterwards (one download, from the replay store) and are the draw's pixels
+        s1 = np.asarray(drawn[-1].state_1)
+        assert s1.shape == (B,) + tuple(shape) and s1.dtype == np.float16
+        assert np.array_equal(s1, lit.replay_memory.state[drawn[-1].state_1_idx])
+    finally:
+        lit.close(); fused.close()
+
+
+def test_a_deferred_actor_update_lands_before_anything_observes_the_actor():
+    shape, B = (16, 16, 3, 1, 2), 8
+    a1, a2 = _twin_agents(shape, B, True, rows=100)
+    try:
+        idx = np.arange(3, 3 + B)
+        # reference order with host arrays: the unfused ops
+        hb = a2.replay_memory.batch(idxs=idx)
+        s1_host = np.asarray(hb.state_1)
+        a2.actor.train(s1_host)
+        want_actor = a2.actor.get_params()
+        # deferred, then observed
+        b = a1.replay_memory.batch(idxs=idx)
+        before = a1.actor._handle
+        a1.actor.train(b.state_1)
+        assert a1.trainer._pending is not None and a1.actor._handle == before
+        got = a1.actor.get_params()                         # flushes
+        assert a1.trainer._pending is None and a1.trainer.fused_pairs == 0
+        assert np.array_equal(got, want_actor)
+        # a critic.train on ANOTHER draw does not fuse with the pending actor update
+        b1, b2 = a1.replay_memory.batch(idxs=idx), a1.replay_memory.batch(idxs=idx + 20)
+        h1, h2 = a2.replay_memory.batch(idxs=idx), a2.replay_memory.batch(idxs=idx + 20)
+        a1.actor.train(b1.state_1); a1.critic.train(b2)
+        a2.actor.train(np.asarray(h1.state_1)); a2.critic.train(h2)
+        assert a1.trainer.fused_pairs == 0
+        for x, y in zip(a1.networks(), a2.networks()):
+            assert np.array_equal(x.get_params(), y.get_params()), x.namespace
+        # action_given (the rollout) between the two calls sees the updated actor
+        b3, h3 = a1.replay_memory.batch(idxs=idx + 40), a2.replay_memory.batch(idxs=idx + 40)
+        a1.actor.train(b3.state_1)
+        a2.actor.train(np.asarray(h3.state_1))
+        st = np.asarray(h3.state_1)[0]
+        assert np.array_equal(a1.actor.action_given(st), a2.actor.action_given(st))
+    finally:
+        a1.close(); a2.close()
+
+
+def test_an_older_batch_trains_on_its_own_rows_after_a_second_draw():
+    """b1 read, then b2 = batch() of the same size -- training on b1 must use b1's rows, not the shared device buffer's."""
+    shape, B = (16, 16, 3, 1, 2), 8
+    a1, a2 = _twin_agents(shape, B, True, rows=100)
+    try:
+        i1, i2 = np.arange(B), np.arange(50, 50 + B)
+        b1 = a1.replay_memory.batch(idxs=i1)
+        _ = b1.reward, np.asarray(b1.state_1)               # read
+        b2 = a1.replay_memory.batch(idxs=i2)
+        assert b2.device is not None                        # the shared buffer now holds b2's draw
+        a1.actor.train(b1); a1.critic.train(b1)             # whole-Batch form: the unfused ops on b1.device
+        h1 = a2.replay_memory.batch(idxs=i1)
+        a2.actor.train(h1); a2.critic.train(h1)
+        for x, y in zip(a1.networks(), a2.networks()):
+            assert np.array_equal(x.get_params(), y.get_params()), x.namespace
+        # ... and after a write to the memory b1 trains from its cached host columns, an unread Batch refuses
+        b3 = a1.replay_memory.batch(idxs=i2)
+        frame = np.asarray(b1.state_1)[0]
+        a1.replay_memory.add_episode(frame, [(np.zeros((1, 2), np.float32), 1.0, frame)])
+        a2.replay_memory.add_episode(frame, [(np.zeros((1, 2), np.float32), 1.0, frame)])
+        a1.critic.train(b1)
+        HostBatch = collections.namedtuple("HostBatch", "state_1 action reward terminal_mask state_2")      # replay_memory.py:9
+        a2.critic.train(HostBatch(np.asarray(b1.state_1), b1.action, b1.reward, b1.terminal_mask, np.asarray(b1.state_2)))
+        assert np.array_equal(a1.critic.get_params(), a2.critic.get_params())
+        with pytest.raises(RuntimeError):
+            a1.critic.train(b3)
+    finally:
+        a1.close(); a2.close()
+
+
+def test_naf_reference_loop_verbatim_trains_on_the_device_rows():
+    from cartpoleplusplus_amd import naf_cartpole as N
+    from tests.helpers import FakeEnv, make_opts
+    shape, B = (32, 32, 3, 2, 3), 32
+    agents = []
+    for _ in range(2):
+        make_opts(N, shape, B, True, replay_memory_size=240, share_input_state_representation=True)
+        ag = N.NormalizedAdvantageFunctionAgent(FakeEnv(shape))
+        ag.initialise_variables(seed=5)
+        ag.post_var_init_setup()
+        ag.replay_memory.fill_synthetic(200, seed=4)
+        agents.append(ag)
+    lit, fused = agents
+    try:
+        np.random.seed(7)
+        losses, drawn = [], []
+        # ---- naf_cartpole.py:365-373, verbatim
+        for _ in range(5):
+            batch = lit.replay_memory.batch(B)
+            losses.append(lit.naf.train(batch))
+            drawn.append(batch)
+        lit.target_value_net.update_weights()
+        assert all(b._states is None for b in drawn)
+        fused.train_step(B, 5, idxs=np.concatenate([b.idxs for b in drawn]))
+        for a, b in zip(lit.networks(), fused.networks()):
+            assert np.array_equal(a.get_params(), b.get_params()), a.namespace
+        assert np.isfinite(losses).all() and abs(losses[-1] - float(fused.naf.last_stats()[0])) == 0.0
+    finally:
+        lit.close(); fused.close()

@@ -232,22 +232,28 @@ def test_two_batches_of_one_size_are_independent_snapshots():
         rm.add_episode(s0, seq); orm.add_episode(s0, seq)
     i1, i2 = rng.integers(0, rm.size(), 13), rng.integers(0, rm.size(), 13)
     b1 = rm.batch(idxs=i1)
-    early = b1.reward.copy()                      # (reading one column fetches all five: b1 is a host snapshot from here on)
+    early = b1.reward.copy()
     b2 = rm.batch(idxs=i2)
-    b3 = rm.batch(idxs=i1)                        # b2 has NOT been read when its buffer is resampled
+    assert b2.device is not None                  # b2's draw is gathered into the shared device buffer ...
+    b3 = rm.batch(idxs=i1)
+    assert b3.device is not None                  # ... which b3 takes over before b2 has been read
     for b, idx in ((b1, i1), (b2, i2), (b3, i1)):
         ob = orm.batch(idxs=idx)
         for f in ("state_1", "action", "reward", "terminal_mask", "state_2"):
             assert np.array_equal(getattr(b, f), getattr(ob, f)), f
         assert np.array_equal(b.idxs, idx)
     assert np.array_equal(early, b1.reward)
-    # a detached Batch whose states were overwritten in the meantime fails loudly instead of returning another draw's rows
+    # a Batch whose states were overwritten before anybody read them fails loudly instead of returning another draw's rows
     b4 = rm.batch(idxs=i1)
-    b5 = rm.batch(idxs=i2)                        # detaches b4
+    b5 = rm.batch(idxs=i2)
+    b5_s1 = np.asarray(b5.state_1).copy()         # read: b5 owns host copies from here on
     rm.add_episode(s0, seq)
     with pytest.raises(RuntimeError):
-        b4.state_1
-    assert np.array_equal(b4.idxs, i1) and b5.device is not None and b4.device is None
+        np.asarray(b4.state_1)
+    with pytest.raises(RuntimeError):
+        b4.device
+    assert np.array_equal(b4.idxs, i1) and np.array_equal(np.asarray(b5.state_1), b5_s1)
+    assert b5.device is not None                  # (uploaded from its host columns)
     rm.close()
 
 

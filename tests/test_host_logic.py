@@ -1,5 +1,6 @@
 """CPU tests of host-side logic that needs no GPU: flags, exploration noise, helper functions."""
 import numpy as np
+import pytest
 
 from cartpoleplusplus_amd import util
 
@@ -79,3 +80,126 @@ def test_host_gradient_helpers_follow_util_py():
     assert util.clip_and_debug_gradients([(g1, "a")], Opts)[0][0] is g1
     z = util.standardise(np.arange(10.0))
     assert abs(z.mean()) < 1e-12 and abs((z ** 2).mean() - 1.0) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# training_loop.py: the agents' outer loop (ddpg_cartpole.py:291-383) with stubs -- no device, no process group
+# ---------------------------------------------------------------------------------------------------------------------
+class _LoopAgent(object):
+    def __init__(self, episode_len):
+        import collections
+
+        class Env(object):
+            def __init__(self):
+                self.t = 0
+
+            def reset(self):
+                self.t = 0
+                return np.zeros(3, np.float32)
+
+            def step(self, action):
+                self.t += 1
+                return np.full(3, self.t, np.float32), 1.0, self.t >= episode_len, {}
+
+        class Mem(object):
+            def __init__(self):
+                self.rows, self.stats = 0, collections.Counter()
+
+            def add_episode(self, s0, seq):
+                self.rows += len(seq)
+                self.stats[">add_episode"] += 1
+
+            def size(self):
+                return self.rows
+
+            def current_stats(self):
+                return dict(self.stats)
+        self.env, self.replay_memory, self.evals, self.trained = Env(), Mem(), 0, []
+
+    def run_eval(self, n, add_noise=False):
+        self.evals += n
+
+
+def _loop_opts(**kw):
+    import types
+    o = types.SimpleNamespace(dont_do_rollouts=False, replay_memory_burn_in=10, async_rollouts=False)
+    o.__dict__.update(kw)
+    return o
+
+
+def test_training_loop_follows_the_reference_order_of_events():
+    import io
+    from cartpoleplusplus_amd.training_loop import TrainingLoop
+    agent, out = _LoopAgent(4), io.StringIO()
+
+    def train(batch_size, batches_per_step):
+        agent.trained.append(agent.replay_memory.size())
+        return [0.5]
+    loop = TrainingLoop(agent, _loop_opts(), act=lambda s: np.zeros((1, 2), np.float32), train=train, out=out)
+    loop.run(max_num_actions=45, max_run_time=0, batch_size=8, batches_per_step=5, saver_util=None)
+    # 4 actions per episode: training starts once size() > 10 (3rd episode), the loop leaves once actions > 45 (12th episode)
+    assert loop.iterations == 12 and agent.trained == [12 + 4 * k for k in range(10)]
+    lines = [l for l in out.getvalue().splitlines() if l.startswith("STATS")]
+    assert len(lines) == 12 and agent.evals == 1                                  # eval after the 10th episode (n % 10 == 0)
+    import json
+    first, last = json.loads(lines[0].split("\t")[1]), json.loads(lines[-1].split("\t")[1])
+    assert np.isnan(first["mean_losses"]) and last["mean_losses"] == 0.5 and last["episode_len"] == 4 and last["n"] == 11
+
+
+def test_training_loop_without_rollouts_runs_exactly_one_iteration_when_no_budget_is_given():
+    import io
+    from cartpoleplusplus_amd.training_loop import TrainingLoop
+    agent = _LoopAgent(4)
+    agent.replay_memory.rows = 100
+    loop = TrainingLoop(agent, _loop_opts(dont_do_rollouts=True), act=None, train=lambda b, n: [1.0], out=io.StringIO())
+    loop.run(0, 0, 8, 5, None)
+    assert loop.iterations == 1 and loop.train_calls == 1                         # ddpg_cartpole.py: --dont-do-rollouts one-shot
+
+
+def test_async_rollouts_keep_training_while_episodes_are_played_and_surface_env_errors():
+    import io
+    import time as _time
+    from cartpoleplusplus_amd.training_loop import TrainingLoop
+    agent = _LoopAgent(5)
+    slow_step = agent.env.step
+
+    def step(action):
+        _time.sleep(0.002)
+        return slow_step(action)
+    agent.env.step = step
+    loop = TrainingLoop(agent, _loop_opts(async_rollouts=True), act=lambda s: np.zeros((1, 2), np.float32),
+                        train=lambda b, n: [0.0], out=io.StringIO())
+    loop.run(max_num_actions=60, max_run_time=0, batch_size=8, batches_per_step=5, saver_util=None)
+    assert agent.replay_memory.rows > 60
+    assert loop.train_calls > agent.replay_memory.stats[">add_episode"]           # the learner did not wait for episodes
+    # an exception in the environment reaches the caller of run()
+    bad = _LoopAgent(5)
+
+    def boom(action):
+        raise ValueError("physics exploded")
+    bad.env.step = boom
+    loop = TrainingLoop(bad, _loop_opts(async_rollouts=True), act=lambda s: 0, train=lambda b, n: [0.0], out=io.StringIO())
+    with pytest.raises(ValueError):
+        loop.run(60, 0, 8, 5, None)
+
+
+def test_fair_lock_serves_in_arrival_order():
+    import threading
+    import time as _time
+    from cartpoleplusplus_amd.training_loop import FairLock
+    lock, order = FairLock(), []
+
+    def greedy():
+        for _ in range(50):
+            with lock:
+                order.append("L")
+                _time.sleep(0.0005)
+
+    def occasional():
+        for _ in range(5):
+            _time.sleep(0.002)
+            with lock:
+                order.append("R")
+    ts = [threading.Thread(target=greedy), threading.Thread(target=occasional)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert order.count("R") == 5 and order.index("R") < 15 and "R" in order[:40]
