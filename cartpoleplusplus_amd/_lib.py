@@ -89,6 +89,7 @@ SIGNATURES = {
     "cpp_replay_write_states": (_I, [_P, _P, _I, _P, _I]),
     "cpp_replay_write_rows": (_I, [_P, _P, _I, _P, _P, _P, _P, _P]),
     "cpp_replay_read_rows": (_I, [_P, _P, _I, _P, _P, _P, _P, _P]),
+    "cpp_replay_set_stats_channels": (_I, [_P, _I]),
     "cpp_replay_set_size": (_I, [_P, _I]),
     "cpp_replay_read_states": (_I, [_P, _P, _I, _P]),
     "cpp_replay_sample": (_I, [_P, _I, _P, _U64, _U64, _I, _P]),

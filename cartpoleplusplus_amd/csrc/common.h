@@ -219,6 +219,8 @@ struct GatherArgs {
   int32_t* out_slot[2];         // store row of every sampled state (nullptr: not wanted): conv1 can read the store itself
   float* out_action; float* out_reward; float* out_mask;
   double* part;                 // [2][B][2*C] per-row partial sums
+  const double* slot_stats;     // non-null (and no copy wanted): [slots][2*C] sums the store keeps per state (cpp_replay_set_stats_channels) --
+                                // a sampled row's partial is COPIED from there instead of re-reading its pixels
   uint64_t seed; const uint64_t* counter;
   int counter_add;              // the draw is keyed by *counter + counter_add (a gather that runs before the step that bumps the counter)
   const __half* lut;            // u8 store: f16(k / 255) for the 256 pixel codes
@@ -227,6 +229,10 @@ struct GatherArgs {
                                 // that a captured launch keeps sampling the whole memory as it grows; `size` otherwise
 };
 int launch_gather_stats(cpp_ctx* ctx, const GatherArgs& a, int dtype);
+// per-state sufficient statistics of store rows [first, first + n) (slots == nullptr) or of the n rows listed in `slots` (device): the very
+// sums a gather of that state would leave in GatherArgs::part, computed once when the state is written
+int launch_slot_stats(cpp_ctx* ctx, const void* store, int dtype, long elems, int C, double* slot_stats, const int32_t* slots, int first, int n,
+                      const __half* lut);
 struct DwReduceBatch;
 int launch_reduce_gather(cpp_ctx* ctx, const DwReduceBatch& rb, const GatherArgs& a, int dtype);      // f16 / u8 store; replay.hip   // dtype of the store: CPP_F32 / CPP_F16 / CPP_U8 (gathers to f16)
 int launch_u8_to_f16(cpp_ctx* ctx, __half* dst, const uint8_t* src, long n, const __half* lut);

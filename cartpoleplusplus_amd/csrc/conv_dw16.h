@@ -45,6 +45,7 @@ struct Dw16Geom {
   static constexpr int NVIN = (CIN % 2 ? WPAD * CIN : WPAD * CIN / 2) / CONV_THREADS + 1;   // dwords (odd CIN: halves) of an input row per thread
   static constexpr int IN_BYTES = RING_IN * ROWB, DY_BYTES = RING_DY * DSLOT;
   static constexpr int LDS_BYTES = ((IN_BYTES + 15) & ~15) + DY_BYTES + 64;       // (the epilogue scratch reuses the dY ring)
+  static constexpr int LDS_BYTES2 = ((IN_BYTES + 15) & ~15) + 2 * DY_BYTES + 64;  // two networks per workgroup: one input ring, two dY rings
   static_assert(DY_BYTES >= CONV_THREADS * NCELL * 4 + 4 * KS * 16 * 4 + 2 * CIN * 4, "epilogue scratch fits the dY ring");
 };
 
@@ -54,30 +55,35 @@ struct Dw16Geom {
 
 // DENSE: dY comes as dense f32 rows (a.dy_dense: batch norm's dz) instead of being rebuilt from the pooled gradient
 // (bx, by, gx): the workgroup's place in a (gx, networks) grid (its own launch, or a slice of a shared one: conv1_dw_gather.hip)
-template <int CIN, int KS, int NCHK, bool DENSE = false>
+// NNET = 2: ONE workgroup serves networks by and by + 1, which read the SAME images (the actor and the critic both take state_1:
+// ddpg_cartpole.py:333-334) -- the raw row is staged once, every A fragment is read from LDS once and multiplied with both networks' dY
+// (two dY rings, two accumulator sets, two partials).  Half the input staging and half the A reads per MFMA; the joint launch is 512
+// workgroups = one resident round instead of 1024 on 768 slots.
+template <int CIN, int KS, int NCHK, bool DENSE = false, int NNET = 1>
 __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units_per_img, int band, const int bx, const int by, const int gx) {
   typedef Dw16Geom<CIN, KS, NCHK> G;
   constexpr int P = G::P, NO = G::NO, MT = G::MT, CP = G::CP, NPC = G::NPC, ROWB = G::ROWB, DSLOT = G::DSLOT;
   static_assert((KS * NO + 15) / 16 == 4, "one column tile per wave");
+  static_assert(NNET == 1 || NNET == 2, "one or two networks per workgroup");
+  static_assert(NNET == 1 || !DENSE, "the two-network workgroup rebuilds dY from the pooled gradient");
   constexpr bool ODD = (CIN & 1) != 0;               // pixels are only 2-byte aligned in memory: rows are staged half by half
+  constexpr int DYB = G::DY_BYTES;                   // network k's dY ring sits k * DYB bytes behind network 0's
 #ifdef DW16_CLOCK
   const unsigned long long ce0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long cpro = 0, cloop = 0;
 #endif
-  const ConvArgs& a = batch.a[by];
+  const ConvArgs& a = batch.a[by];                   // geometry, the images and their whitening: shared by the NNET networks
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   unsigned char* inring = lds_raw;                                         // [3][ROWB]
-  unsigned char* dyring = lds_raw + ((G::IN_BYTES + 15) & ~15);            // [6][DSLOT]
-  float* red = reinterpret_cast<float*>(dyring + G::DY_BYTES);
-  float* texch = reinterpret_cast<float*>(dyring);                         // epilogue (after the last row barrier): [4 waves][KS][16]
-  float* dbs = texch + 4 * KS * 16;                                        // bias-gradient scratch [NCELL][256]
+  unsigned char* dyring = lds_raw + ((G::IN_BYTES + 15) & ~15);            // [NNET][6][DSLOT]
+  float* red = reinterpret_cast<float*>(dyring + NNET * DYB);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lj = lane >> 4;
   const int H = a.H, W = a.W, Hp = H >> 1, Wp = W >> 1, nout = a.nout;
   const int units = a.B * units_per_img;
 
-  // ---- zero both rings; the ones channel of the in-image pixels of every input slot (staging never touches it)
-  for (int i = tid; i < (int)(((G::IN_BYTES + 15) & ~15) + G::DY_BYTES) / 16; i += CONV_THREADS)
+  // ---- zero the rings; the ones channel of the in-image pixels of every input slot (staging never touches it)
+  for (int i = tid; i < (int)(((G::IN_BYTES + 15) & ~15) + NNET * DYB) / 16; i += CONV_THREADS)
     reinterpret_cast<float4*>(lds_raw)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
   for (int i = tid; i < G::RING_IN * W; i += CONV_THREADS) {
@@ -88,10 +94,12 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
   // (the epilogue's whitening scale / shift are requested here: in the epilogue the load was one more L2 round trip per workgroup)
   float wsc_s = 0.f, wsc_t = 0.f;
   if (tid < CIN) { wsc_s = a.scale[tid]; wsc_t = a.shift[tid]; }
-  // ---- 2^S: the largest |pooled gradient| among the pooled rows this workgroup's units touch lands in [2^14, 2^15)
-  float sc, inv;
+  // ---- 2^S: the largest |pooled gradient| among the pooled rows this workgroup's units touch lands in [2^14, 2^15) (per network)
+  float sc[NNET], inv[NNET];
   {
-    float vmax = 0.f;
+    float vmax[NNET];
+#pragma unroll
+    for (int k = 0; k < NNET; ++k) vmax[k] = 0.f;
     for (int unit = bx; unit < units; unit += gx) {
       const int b = unit / units_per_img;
       const int q_lo = (unit - b * units_per_img) * band;
@@ -106,33 +114,45 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
 #pragma unroll
           for (int u = 0; u < 8; ++u) t[u] = dp[e + u * CONV_THREADS];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) vmax = fmaxf(vmax, fabsf(t[u]));
+          for (int u = 0; u < 8; ++u) vmax[0] = fmaxf(vmax[0], fabsf(t[u]));
         }
-        for (; e < e1; e += CONV_THREADS) vmax = fmaxf(vmax, fabsf(dp[e]));
+        for (; e < e1; e += CONV_THREADS) vmax[0] = fmaxf(vmax[0], fabsf(dp[e]));
       } else {
         const int py0 = max(0, (q_lo - P) >> 1), py1 = min(Hp - 1, (q_lo + rows - 1 + P) >> 1);
         const int e1 = (py1 + 1) * Wp * nout;
-        // the rows come from another kernel's L2 (1.5-2 us a trip): 24 loads in flight per trip -- one trip for a half image of
-        // the headline shape -- through a descriptor that ends at e1 (reads past it return 0)
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(a.dy.dpool + (long)b * a.dy.dpool_bstride), 0, e1 * 4, 0x00020000);
+        // the rows come from another kernel's L2 (1.5-2 us a trip): 24 loads in flight per trip and network -- one trip for a half image
+        // of the headline shape -- through descriptors that end at e1 (reads past it return 0)
+        __amdgpu_buffer_rsrc_t rs[NNET];
+#pragma unroll
+        for (int k = 0; k < NNET; ++k)
+          rs[k] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(batch.a[by + k].dy.dpool + (long)b * batch.a[by + k].dy.dpool_bstride), 0, e1 * 4, 0x00020000);
         for (int e = py0 * Wp * nout + tid; e < e1; e += 24 * CONV_THREADS) {
-          float t[24];
+          float t[NNET][24];
 #pragma unroll
-          for (int u = 0; u < 24; ++u) t[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (e + u * CONV_THREADS) * 4, 0, 0));
+          for (int k = 0; k < NNET; ++k)
 #pragma unroll
-          for (int u = 0; u < 24; ++u) vmax = fmaxf(vmax, fabsf(t[u]));
+            for (int u = 0; u < 24; ++u) t[k][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs[k], (e + u * CONV_THREADS) * 4, 0, 0));
+#pragma unroll
+          for (int k = 0; k < NNET; ++k)
+#pragma unroll
+            for (int u = 0; u < 24; ++u) vmax[k] = fmaxf(vmax[k], fabsf(t[k][u]));
         }
       }
     }
-    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-    if (lane == 0) red[wave] = vmax;
+#pragma unroll
+    for (int k = 0; k < NNET; ++k) {
+      for (int o = 32; o > 0; o >>= 1) vmax[k] = fmaxf(vmax[k], __shfl_xor(vmax[k], o));
+      if (lane == 0) red[4 * k + wave] = vmax[k];
+    }
     __syncthreads();
-    vmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    int S = 0;
-    if (vmax > 0.f && vmax < 3.0e38f) S = 14 - ilogbf(vmax);
-    S = S > 100 ? 100 : (S < -100 ? -100 : S);
-    sc = ldexpf(1.f, S); inv = ldexpf(1.f, -S);
+#pragma unroll
+    for (int k = 0; k < NNET; ++k) {
+      const float vm = fmaxf(fmaxf(red[4 * k], red[4 * k + 1]), fmaxf(red[4 * k + 2], red[4 * k + 3]));
+      int S = 0;
+      if (vm > 0.f && vm < 3.0e38f) S = 14 - ilogbf(vm);
+      S = S > 100 ? 100 : (S < -100 ? -100 : S);
+      sc[k] = ldexpf(1.f, S); inv[k] = ldexpf(1.f, -S);
+    }
   }
 
   // ---- input row staging: raw dwords (two channels; odd CIN: single halves) of the f16 row -> pixel pitch CP
@@ -168,15 +188,15 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
   auto in_load = [&](const __amdgpu_buffer_rsrc_t& rs, int q) { in_load_to(sv, rs, q); };
   auto in_store = [&](int slot) { in_store_from(sv, slot); };
 
-  // ---- dY staging: a thread owns pooled cells idx = px * nout + o of a pooled row (the same cells for every row); the
+  // ---- dY staging: a thread owns pooled cells idx = px * nout + o of a pooled row (the same cells for every row and network); the
   // masked gradient is scaled, split into three f16 pieces and written to both image rows of the pooled row.
   // pixel x = 32 ch + w sits in lane group g = 2 ((w >> 1) & 1) + (w >> 4), element e = 4 (w & 1) + ((w >> 2) & 3)
   constexpr int NCELL = G::NCELL;
   bool cact[NCELL];
   uint32_t cdst[NCELL];
-  float cg[NCELL], dbsum[NCELL];
-  unsigned short cpc[NCELL][NPC];
-  int ccode[NCELL];
+  float cg[NNET][NCELL], dbsum[NNET][NCELL];
+  unsigned short cpc[NNET][NCELL][NPC];
+  int ccode[NNET][NCELL];
 #pragma unroll
   for (int c = 0; c < NCELL; ++c) {
     const int idx = tid + CONV_THREADS * c;
@@ -185,54 +205,63 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
     const int x = 2 * px, ch = x >> 5, w = x & 31;
     const int g = 2 * ((w >> 1) & 1) + (w >> 4), e = (w >> 2) & 3;
     cdst[c] = keep_in_vgpr(lds_addr(dyring + o * G::DOST + ch * 64 + g * 16 + e * 2));
-    cg[c] = 0.f; ccode[c] = 0; dbsum[c] = 0.f;
 #pragma unroll
-    for (int pc = 0; pc < NPC; ++pc) cpc[c][pc] = 0;
+    for (int k = 0; k < NNET; ++k) {
+      cg[k][c] = 0.f; ccode[k][c] = 0; dbsum[k][c] = 0.f;
+#pragma unroll
+      for (int pc = 0; pc < NPC; ++pc) cpc[k][c][pc] = 0;
+    }
   }
-  float rpv[3][NCELL], rdv[3][NCELL];             // (set 2: only the unit prologue, so that its three requests are in flight together)
-  int rcd[3][NCELL];
-  auto dy_issue = [&](const __amdgpu_buffer_rsrc_t& rp, const __amdgpu_buffer_rsrc_t& rd,
-                      const __amdgpu_buffer_rsrc_t& rc, int py, int set) {
+  float rpv[NNET][3][NCELL], rdv[NNET][3][NCELL];   // (set 2: only the unit prologue, so that its three requests are in flight together)
+  int rcd[NNET][3][NCELL];
+  __amdgpu_buffer_rsrc_t rp[NNET], rd[NNET], rc[NNET];
+  auto dy_issue = [&](int py, int set) {
     const bool rowok = py >= 0 && py < Hp;           // uniform
 #pragma unroll
-    for (int c = 0; c < NCELL; ++c) {
-      rpv[set][c] = 0.f; rdv[set][c] = 0.f; rcd[set][c] = 0;
-      if (rowok && cact[c]) {
-        const int vo = (tid + CONV_THREADS * c) * 4, so = py * Wp * nout * 4;
-        rpv[set][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rp, vo, so, 0));
-        rdv[set][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, vo, so, 0));
-        rcd[set][c] = __builtin_amdgcn_raw_buffer_load_b8(rc, vo >> 2, so >> 2, 0);
+    for (int k = 0; k < NNET; ++k)
+#pragma unroll
+      for (int c = 0; c < NCELL; ++c) {
+        rpv[k][set][c] = 0.f; rdv[k][set][c] = 0.f; rcd[k][set][c] = 0;
+        if (rowok && cact[c]) {
+          const int vo = (tid + CONV_THREADS * c) * 4, so = py * Wp * nout * 4;
+          rpv[k][set][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rp[k], vo, so, 0));
+          rdv[k][set][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd[k], vo, so, 0));
+          rcd[k][set][c] = __builtin_amdgcn_raw_buffer_load_b8(rc[k], vo >> 2, so >> 2, 0);
+        }
       }
-    }
   };
   auto dy_conv = [&](int set, bool count) {
 #pragma unroll
-    for (int c = 0; c < NCELL; ++c) {
-      cg[c] = rpv[set][c] > 0.f ? rdv[set][c] : 0.f;
-      ccode[c] = rcd[set][c];
-      if (count) dbsum[c] += cg[c];
-      const float v = cg[c] * sc;
-      const _Float16 h = (_Float16)v;
-      const float r1 = v - (float)h;
-      const _Float16 m = (_Float16)r1;
-      const _Float16 l = (_Float16)(r1 - (float)m);
-      cpc[c][0] = __builtin_bit_cast(unsigned short, h);
-      cpc[c][1] = __builtin_bit_cast(unsigned short, m);
-      cpc[c][2] = __builtin_bit_cast(unsigned short, l);
-    }
+    for (int k = 0; k < NNET; ++k)
+#pragma unroll
+      for (int c = 0; c < NCELL; ++c) {
+        cg[k][c] = rpv[k][set][c] > 0.f ? rdv[k][set][c] : 0.f;
+        ccode[k][c] = rcd[k][set][c];
+        if (count) dbsum[k][c] += cg[k][c];
+        const float v = cg[k][c] * sc[k];
+        const _Float16 h = (_Float16)v;
+        const float r1 = v - (float)h;
+        const _Float16 m = (_Float16)r1;
+        const _Float16 l = (_Float16)(r1 - (float)m);
+        cpc[k][c][0] = __builtin_bit_cast(unsigned short, h);
+        cpc[k][c][1] = __builtin_bit_cast(unsigned short, m);
+        cpc[k][c][2] = __builtin_bit_cast(unsigned short, l);
+      }
   };
-  auto dy_store = [&](int slot, int ry) {            // image row with parity ry of the pooled row -> ring slot
+  auto dy_store = [&](int slot, int ry) {            // image row with parity ry of the pooled row -> ring slot (of every network)
 #pragma unroll
-    for (int c = 0; c < NCELL; ++c) {
-      if (cact[c]) {
-        const bool s0 = ccode[c] == 2 * ry, s1 = ccode[c] == 2 * ry + 1;
+    for (int k = 0; k < NNET; ++k)
 #pragma unroll
-        for (int pc = 0; pc < NPC; ++pc) {
-          lds_store(cdst[c], slot * DSLOT + pc * G::DPC, (unsigned short)(s0 ? cpc[c][pc] : 0));
-          lds_store(cdst[c], slot * DSLOT + pc * G::DPC + 8, (unsigned short)(s1 ? cpc[c][pc] : 0));
+      for (int c = 0; c < NCELL; ++c) {
+        if (cact[c]) {
+          const bool s0 = ccode[k][c] == 2 * ry, s1 = ccode[k][c] == 2 * ry + 1;
+#pragma unroll
+          for (int pc = 0; pc < NPC; ++pc) {
+            lds_store(cdst[c], k * DYB + slot * DSLOT + pc * G::DPC, (unsigned short)(s0 ? cpc[k][c][pc] : 0));
+            lds_store(cdst[c], k * DYB + slot * DSLOT + pc * G::DPC + 8, (unsigned short)(s1 ? cpc[k][c][pc] : 0));
+          }
         }
       }
-    }
   };
 
   // ---- dense dY rows (DENSE): a thread owns elements idx = x * nout + o of a row; scaled, split, same LDS layout
@@ -260,7 +289,7 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
 #pragma unroll
     for (int c = 0; c < NDC; ++c) {
       if (dact[c]) {
-        const float v = dreg[c] * sc;
+        const float v = dreg[c] * sc[0];
         const _Float16 h = (_Float16)v;
         const float r1 = v - (float)h;
         const _Float16 m = (_Float16)r1;
@@ -284,9 +313,11 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
     const int slot = (sq - nky + P + G::RING_DY) % G::RING_DY;            // ring slot of dY position t - ky + P, t = sq (mod 6)
     badr[sq] = keep_in_vgpr(lds_addr(dyring + slot * DSLOT + no * G::DOST + lj * 16));
   }
-  f32x4 acc[MT];
+  f32x4 acc[NNET][MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < NNET; ++k)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[k][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   __syncthreads();
 #ifdef DW16_CLOCK
@@ -302,12 +333,13 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
     const int rows = min(band, H - q_lo);            // band and q_lo are even
     const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<__half*>((const __half*)a.in + (long)(a.img_slot ? a.img_slot[b] : b) * a.in_bstride), 0, H * rowbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.dy.pool + (long)b * a.dy.pool_bstride), 0, Hp * Wp * nout * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.dy.dpool + (long)b * a.dy.dpool_bstride), 0, Hp * Wp * nout * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint8_t*>(a.dy.amax + (long)b * Hp * Wp * nout), 0, Hp * Wp * nout, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < NNET; ++k) {
+      const ConvArgs& ak = batch.a[by + k];
+      rp[k] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ak.dy.pool + (long)b * ak.dy.pool_bstride), 0, Hp * Wp * nout * 4, 0x00020000);
+      rd[k] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ak.dy.dpool + (long)b * ak.dy.dpool_bstride), 0, Hp * Wp * nout * 4, 0x00020000);
+      rc[k] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(ak.dy.amax + (long)b * Hp * Wp * nout), 0, Hp * Wp * nout, 0x00020000);
+    }
     // position d of the band's stream <-> image row q_lo - P + d (conv_dw_kyo.h)
     const int y0 = q_lo - P;
     auto in_band = [&](int y) { return y >= q_lo && y < q_lo + rows; };
@@ -323,9 +355,9 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
     // (the first two input rows are requested together: one L2 round trip, not two -- in-kernel clock: the prologue was 4 us)
     if (0 < rows) in_load(in_rs, q_lo);
     if (1 < rows) in_load_to(sv2, in_rs, q_lo + 1);
-    dy_issue(rp, rd, rc, y0 >> 1, 0);
-    dy_issue(rp, rd, rc, (y0 >> 1) + 1, 1);
-    dy_issue(rp, rd, rc, (y0 >> 1) + 2, 2);
+    dy_issue(y0 >> 1, 0);
+    dy_issue((y0 >> 1) + 1, 1);
+    dy_issue((y0 >> 1) + 2, 2);
     if (0 < rows) in_store(P % G::RING_IN);
     if (2 < rows) in_load(in_rs, q_lo + 2);
     dy_conv(0, in_band(y0));
@@ -356,7 +388,7 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
           } else {
             if ((d & 1) == 0) dy_conv(0, in_band(y));                     // requested one step ago
             dy_store((sq + P + 1) % G::RING_DY, (sq + P + 1) & 1);
-            if ((d & 1) == 1) dy_issue(rp, rd, rc, (y + 1) >> 1, 0);      // next pooled row, used from the next step on
+            if ((d & 1) == 1) dy_issue((y + 1) >> 1, 0);                  // next pooled row, used from the next step on
           }
 #endif
 #ifndef DW16_ABL_NOIN
@@ -364,18 +396,20 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
           if (t + 3 - P < rows) in_load(in_rs, y0 + t + 3);
 #endif
         }
-        // multiply input position t with dY positions t - P .. t + P
+        // multiply input position t with dY positions t - P .. t + P (of every network: the A fragments are read once)
         const int islot = sq % G::RING_IN;
 #pragma unroll
         for (int ch = 0; ch < NCHK; ++ch) {
-          f16x8 bq[NPC];
+          f16x8 bq[NNET][NPC];
 #pragma unroll
-          for (int pc = 0; pc < NPC; ++pc) {
+          for (int k = 0; k < NNET; ++k)
+#pragma unroll
+            for (int pc = 0; pc < NPC; ++pc) {
 #ifdef DW16_ABL_NOB
-            if (pc > 0) { bq[pc] = bq[0]; continue; }
+              if (pc > 0) { bq[k][pc] = bq[k][0]; continue; }
 #endif
-            bq[pc] = lds_load<f16x8>(badr[sq], pc * G::DPC + ch * 64);
-          }
+              bq[k][pc] = lds_load<f16x8>(badr[sq], k * DYB + pc * G::DPC + ch * 64);
+            }
           k16_u32x4 av[MT];
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
@@ -391,10 +425,12 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
             av[mt] = (k16_u32x4){u0.x, u0.y, u1.x, u1.y};
           }
 #pragma unroll
-          for (int pc = NPC - 1; pc >= 0; --pc)
+          for (int k = 0; k < NNET; ++k)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mt]), bq[pc], acc[mt], 0, 0, 0);
+            for (int pc = NPC - 1; pc >= 0; --pc)
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt)
+                acc[k][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mt]), bq[k][pc], acc[k][mt], 0, 0, 0);
         }
 #ifndef DW16_ABL_NOBAR
         __syncthreads();
@@ -406,23 +442,26 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
 #ifdef DW16_CLOCK
   const unsigned long long ce2 = __builtin_amdgcn_s_memrealtime();
 #endif
-  // ---- one partial per workgroup.  D tile mt holds rows m = 16 mt + 4 lj + r = CP kx + c', column n = (ky, o);
+  // ---- one partial per workgroup and network.  D tile mt holds rows m = 16 mt + 4 lj + r = CP kx + c', column n = (ky, o);
   // row c' = CIN of every kx is T: it goes through a wave-private LDS table, then dW = 2^-S (s_c G + t_c T)
-  float* part = a.partial + (long)bx * a.pstride;
+  // (the epilogue scratch of network k reuses its own dY ring: texch [4 waves][KS][16], then the bias-gradient scratch [NCELL][256])
   const int nw = KS * G::KROW * nout;
-  float* tx = texch + wave * (KS * 16);
+  float* wsc = reinterpret_cast<float*>(dyring) + 4 * KS * 16 + CONV_THREADS * NCELL;           // [CIN] scale, [CIN] shift (ring 0, behind its scratch)
   // whitening scale / shift through LDS: read per (tile, row) below (global loads there were a chain of L2 round trips:
   // 8.4 us per workgroup, in-kernel probe)
-  float* wsc = dbs + CONV_THREADS * NCELL;           // [CIN] scale, [CIN] shift (behind the bias-gradient scratch)
   if (tid < CIN) { wsc[tid] = wsc_s; wsc[CIN + tid] = wsc_t; }
   __syncthreads();
 #ifdef DW16_CLOCK
   const unsigned long long cq1 = __builtin_amdgcn_s_memrealtime();
 #endif
 #pragma unroll
-  for (int kx = 0; kx < KS; ++kx) {
-    const int m = CP * kx + CIN;                      // compile-time
-    if (lj == ((m & 15) >> 2)) tx[kx * 16 + li] = acc[m >> 4][m & 3];
+  for (int k = 0; k < NNET; ++k) {
+    float* tx = reinterpret_cast<float*>(dyring + k * DYB) + wave * (KS * 16);
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) {
+      const int m = CP * kx + CIN;                      // compile-time
+      if (lj == ((m & 15) >> 2)) tx[kx * 16 + li] = acc[k][m >> 4][m & 3];
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -430,27 +469,32 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
 #ifdef DW16_ABL_NOPART
   float ablsum = 0.f;
 #endif
-  if (nvalid && no < nout) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+  for (int k = 0; k < NNET; ++k) {
+    float* part = batch.a[by + k].partial + (long)bx * batch.a[by + k].pstride;
+    const float* tx = reinterpret_cast<const float*>(dyring + k * DYB) + wave * (KS * 16);
+    if (nvalid && no < nout) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = 16 * mt + 4 * lj + r;
-        const int kx = m / CP, c = m - kx * CP;
-        if (kx < KS && c < CIN) {
-          const float t = tx[kx * 16 + li];
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 16 * mt + 4 * lj + r;
+          const int kx = m / CP, c = m - kx * CP;
+          if (kx < KS && c < CIN) {
+            const float t = tx[kx * 16 + li];
 #ifdef DW16_ABL_NOPART
-          ablsum += inv * (wsc[c] * acc[mt][r] + wsc[CIN + c] * t);
+            ablsum += inv[k] * (wsc[c] * acc[k][mt][r] + wsc[CIN + c] * t);
 #else
-          part[(nky * G::KROW + kx * CIN + c) * nout + no] = inv * (wsc[c] * acc[mt][r] + wsc[CIN + c] * t);
+            part[(nky * G::KROW + kx * CIN + c) * nout + no] = inv[k] * (wsc[c] * acc[k][mt][r] + wsc[CIN + c] * t);
 #endif
+          }
         }
       }
     }
-  }
 #ifdef DW16_ABL_NOPART
-  if (ablsum == 123.456f) part[tid] = ablsum;
+    if (ablsum == 123.456f) part[tid] = ablsum;
 #endif
+  }
   // bias gradient: per-thread cell sums -> LDS -> one thread per channel adds them in fixed order
 #ifdef DW16_CLOCK
   const unsigned long long cq2 = __builtin_amdgcn_s_memrealtime();
@@ -460,12 +504,18 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
   const unsigned long long cq3 = __builtin_amdgcn_s_memrealtime();
 #endif
 #pragma unroll
-  for (int c = 0; c < NCELL; ++c) dbs[c * CONV_THREADS + tid] = cact[c] ? dbsum[c] : 0.f;
+  for (int k = 0; k < NNET; ++k) {
+    float* dbs = reinterpret_cast<float*>(dyring + k * DYB) + 4 * KS * 16;
+#pragma unroll
+    for (int c = 0; c < NCELL; ++c) dbs[c * CONV_THREADS + tid] = cact[c] ? dbsum[k][c] : 0.f;
+  }
   __syncthreads();
-  if (tid < nout) {
+  if (tid < NNET * 64 && (tid & 63) < nout) {           // (one wave per network)
+    const int k = tid >> 6, o = tid & 63;
+    const float* dbs = reinterpret_cast<const float*>(dyring + k * DYB) + 4 * KS * 16;
     float s = 0.f;
     const int nidx = Wp * nout;
-    int idx = tid;
+    int idx = o;
     for (; idx + 7 * nout < nidx; idx += 8 * nout) {      // (same order as a one-by-one loop; its LDS reads were a chain of 32 round trips)
       float t[8];
 #pragma unroll
@@ -474,7 +524,7 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
       for (int u = 0; u < 8; ++u) s += t[u];
     }
     for (; idx < nidx; idx += nout) s += dbs[(idx / CONV_THREADS) * CONV_THREADS + (idx % CONV_THREADS)];
-    part[nw + tid] = s;
+    (batch.a[by + k].partial + (long)bx * batch.a[by + k].pstride)[nw + o] = s;
   }
 #ifdef DW16_CLOCK
   if (tid == 0 && (bx % 211) == 7 && by == 0) printf("DW16CLK block %d: setup %llu, units (prologue %llu) %llu, epilogue %llu ticks (first barrier %llu, partial stores %llu, barrier %llu, bias %llu)\n", bx, ce1 - ce0, cpro, ce2 - ce1, __builtin_amdgcn_s_memrealtime() - ce2, cq1 - ce2, cq2 - cq1, cq3 - cq2, __builtin_amdgcn_s_memrealtime() - cq3);
@@ -485,18 +535,35 @@ template <int CIN, int KS, int NCHK, bool DENSE = false>
 __global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 : DW16_WGS)) void conv_dw16_kernel(const ConvArgsN batch, int units_per_img, int band) {
   conv_dw16_body<CIN, KS, NCHK, DENSE>(batch, units_per_img, band, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
 }
+// two networks that read the same images per workgroup (blockIdx.y selects the PAIR: networks 2y and 2y + 1)
+template <int CIN, int KS, int NCHK>
+__global__ __launch_bounds__(CONV_THREADS, 2) void conv_dw16_pair_kernel(const ConvArgsN batch, int units_per_img, int band) {
+  conv_dw16_body<CIN, KS, NCHK, false, 2>(batch, units_per_img, band, (int)blockIdx.x, 2 * (int)blockIdx.y, (int)gridDim.x);
+}
 // conv1 dW of the headline shape with the next minibatch's sample + statistics pass behind it in the same grid (conv1_dw_gather.hip)
-int launch_conv1_dw_gather(cpp_ctx* ctx, const ConvArgsN& batch, int upi, int band, int grid, size_t lds_bytes, const GatherArgs& g);
+int launch_conv1_dw_gather(cpp_ctx* ctx, const ConvArgsN& batch, int upi, int band, int grid, size_t lds_bytes, const GatherArgs& g, bool pair);
 
-template <int CIN, int KS, int NCHK, bool DENSE = false>
+// networks 2j and 2j + 1 of the batch read the same images with the same whitening: one workgroup can serve both
+static inline bool conv_dw16_pairable(const ConvArgsN& batch) {
+  if (batch.n < 2 || (batch.n & 1)) return false;
+  for (int j = 0; j + 1 < batch.n; j += 2) {
+    const ConvArgs &x = batch.a[j], &y = batch.a[j + 1];
+    if (x.in != y.in || x.in_bstride != y.in_bstride || x.img_slot != y.img_slot || x.scale != y.scale || x.shift != y.shift ||
+        x.dy_dense || y.dy_dense || x.pstride != y.pstride)
+      return false;
+  }
+  return true;
+}
+
+template <int CIN, int KS, int NCHK, bool DENSE = false, bool PAIR = false>
 static inline int conv_dw16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int* grid_out) {
   typedef Dw16Geom<CIN, KS, NCHK> G;
   const ConvArgs& a = batch.a[0];
-  const size_t lds_bytes = (size_t)G::LDS_BYTES;
-  auto kern = conv_dw16_kernel<CIN, KS, NCHK, DENSE>;
+  const size_t lds_bytes = PAIR ? (size_t)G::LDS_BYTES2 : (size_t)G::LDS_BYTES;
   static bool attr_done[CPP_MAX_DEVICES] = {};          // (kernel attributes are per device: one cpp_ctx per GPU may share the process)
   if (!attr_done[cpp_dev_slot(ctx)]) {
-    HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if constexpr (PAIR) HIP_CHECK(hipFuncSetAttribute((const void*)conv_dw16_pair_kernel<CIN, KS, NCHK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    else HIP_CHECK(hipFuncSetAttribute((const void*)conv_dw16_kernel<CIN, KS, NCHK, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_done[cpp_dev_slot(ctx)] = true;
   }
 #ifndef DW16_CAP
@@ -511,9 +578,10 @@ static inline int conv_dw16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int* 
   if (ctx->ride && !ctx->ride_done && ctx->ride_at_dw && ctx->ride_dtype == 1 && CIN == 18 && KS == 5 && NCHK == 2 && !DENSE) {
     ctx->ride_done = true;
     *grid_out = grid;
-    return launch_conv1_dw_gather(ctx, batch, upi, band, grid, lds_bytes, *ctx->ride);
+    return launch_conv1_dw_gather(ctx, batch, upi, band, grid, lds_bytes, *ctx->ride, PAIR);
   }
-  hipLaunchKernelGGL(kern, dim3(grid, batch.n), dim3(CONV_THREADS), lds_bytes, ctx->stream, batch, upi, band);
+  if constexpr (PAIR) hipLaunchKernelGGL((conv_dw16_pair_kernel<CIN, KS, NCHK>), dim3(grid, batch.n / 2), dim3(CONV_THREADS), lds_bytes, ctx->stream, batch, upi, band);
+  else hipLaunchKernelGGL((conv_dw16_kernel<CIN, KS, NCHK, DENSE>), dim3(grid, batch.n), dim3(CONV_THREADS), lds_bytes, ctx->stream, batch, upi, band);
   LAUNCH_CHECK();
   *grid_out = grid;
   return 0;
@@ -521,3 +589,5 @@ static inline int conv_dw16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int* 
 
 // conv1 dW of f16 image batches with one whitening table (white_bstride == 0), pooled dY (no batch norm), 5x5, even CIN and W
 int conv_dw16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool dense, const ConvArgsN& a, int* grid, bool* handled);
+// the instances that serve two networks per workgroup (conv_dw16_pair.hip); *handled stays false for a geometry without one
+int conv_dw16_pair_dispatch(cpp_ctx* ctx, int cin, int nchk, const ConvArgsN& a, int* grid, bool* handled);

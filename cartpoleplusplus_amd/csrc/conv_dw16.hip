@@ -15,6 +15,12 @@ int conv_dw16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool dense, c
     if (((uintptr_t)a.a[i].in & 3) || (a.a[i].in_bstride & 1)) return 0;        // dword row staging
   }
   const int nchk = W > 64 ? 4 : (W > 32 ? 2 : 1);
+  // the actor's and the critic's conv1 dW of one minibatch: one workgroup per image band serves both (CPP_DW16_PAIR=0: one each)
+  static const bool no_pair = cpp_switch_off("CPP_DW16_PAIR");
+  if (!no_pair && !dense && ctx && conv_dw16_pairable(a)) {
+    const int rc = conv_dw16_pair_dispatch(ctx, cin, nchk, a, grid, handled);
+    if (*handled) return rc;
+  }
   DW16_CASE_DENSE(18, 2) DW16_CASE_DENSE(6, 2) DW16_CASE_DENSE(12, 2)
   DW16_CASE(18, 2) DW16_CASE(18, 1) DW16_CASE(6, 2) DW16_CASE(6, 1) DW16_CASE(12, 2) DW16_CASE(30, 4) DW16_CASE(18, 4) DW16_CASE(9, 2) DW16_CASE(9, 1) DW16_CASE(3, 2) DW16_CASE(3, 1)
   return 0;

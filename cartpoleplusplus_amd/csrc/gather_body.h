@@ -95,6 +95,13 @@ __device__ __forceinline__ void gather_stats_body(const GatherArgs& a, const int
   const long nvec = a.elems >> 3;
   const int C = a.C;
 
+  // The store already holds this state's sums (computed by this same function when the state was written: launch_slot_stats) and
+  // nobody wants a copy of the pixels (conv1 reads the store through out_slot): the sampled row costs 2 C doubles, not the image.
+  if (a.slot_stats != nullptr && dst == nullptr && C > 0) {
+    if (tid < 2 * C) a.part[((long)which * a.B + b) * 2 * C + tid] = a.slot_stats[(long)slot * 2 * C + tid];
+    return;
+  }
+
   if (C <= 0) {                                   // gather only (low-dim states)
     for (long v = tid; v < nvec; v += 256) { Vec8<T> x; vec_init(x, lut); x.load(src + v * 8); if (dst) x.store(dst + v * 8); }
     for (long e = nvec * 8 + tid; e < a.elems; e += 256) if (dst) dst[e] = elem_convert<T, OutT>(src[e], lut);

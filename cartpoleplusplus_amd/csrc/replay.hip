@@ -9,6 +9,7 @@
 // v = lane (mod P), P = C / gcd(8, C), so the 8 elements of every vector it loads belong to the same 8
 // channels and the accumulators are plain registers.  Row partials leave the kernel in f64 and are
 // combined in fixed order by stats_finalize_kernel (deterministic).
+#include <cstring>
 #include "conv_impl.h"
 #include "gather_body.h"
 #include "stats_body.h"
@@ -47,6 +48,30 @@ int launch_reduce_gather(cpp_ctx* ctx, const DwReduceBatch& rb, const GatherArgs
   else hipLaunchKernelGGL(reduce_gather_kernel<__half>, grid, dim3(256), 0, ctx->stream, rb, a);
   LAUNCH_CHECK();
   prof_end(ctx, K_REDUCE_GATHER);
+  return 0;
+}
+
+// One workgroup per state: gather_stats_body in its "statistics over rows that are already in place" mode (s_idx == nullptr: row b of
+// the store is state b), so a state's stored sums are bit for bit what a gather of that state computes.
+template <typename T>
+__global__ __launch_bounds__(256) void slot_stats_kernel(const GatherArgs a, const int32_t* slots, int first) {
+  __shared__ float sh[256 * 16];
+  __shared__ double dsh[CPP_MAX_CHANNELS * 16];
+  __shared__ float lut[256];
+  const int slot = slots ? slots[blockIdx.x] : first + (int)blockIdx.x;
+  gather_stats_body<T>(a, slot, 0, sh, dsh, lut);
+}
+
+int launch_slot_stats(cpp_ctx* ctx, const void* store, int dtype, long elems, int C, double* slot_stats, const int32_t* slots, int first, int n,
+                      const __half* lut) {
+  if (n <= 0) return 0;
+  GatherArgs a; memset(&a, 0, sizeof(a));
+  a.store[0] = store; a.part = slot_stats; a.elems = elems; a.C = C; a.B = 0; a.lut = lut;      // (which = 0: part index = slot * 2C + tid)
+  prof_begin(ctx);
+  if (dtype == 2) hipLaunchKernelGGL(slot_stats_kernel<uint8_t>, dim3(n), dim3(256), 0, ctx->stream, a, slots, first);
+  else hipLaunchKernelGGL(slot_stats_kernel<__half>, dim3(n), dim3(256), 0, ctx->stream, a, slots, first);
+  LAUNCH_CHECK();
+  prof_end(ctx, K_GATHER_STATS);
   return 0;
 }
 

@@ -120,6 +120,8 @@ struct cpp_replay {
   uint64_t uid;            // unique per cpp_replay_create (graph keys: an address can be reused, this cannot)
   uint64_t write_gen;      // bumped by every call that changes rows, states or the size: a minibatch presampled before it is stale
   __half* lut; int* bad; uint16_t lut_host[256];      // CPP_U8: f16(k/255) table, "not a pixel image" flag
+  // per-state whitening sums (cpp_replay_set_stats_channels): [slots][2 * stats_C] doubles, kept current by every call that writes states
+  double* slot_stats; int stats_C; int32_t* slot_list; size_t slot_list_cap;
   void* stage; size_t stage_cap;                      // device staging of incoming states (conversion source)
   void* pinned; size_t pinned_cap; hipEvent_t pinned_free; bool pinned_busy;   // host staging: writes return before the copy ends
   // host-drawn minibatch rows on their way to rows_in (cpp_ddpg_train_rows / cpp_naf_train_rows): a ring of pinned slots, so that the

@@ -106,6 +106,7 @@ static int replay_create(cpp_ctx* ctx, int buffer_size, int state_slots, int64_t
   r->arena.stream = ctx->stream;
   r->ctx = ctx; r->rows = buffer_size; r->slots = state_slots; r->A = action_dim; r->size = 0; r->elems = state_elems;
   r->store_dtype = store_dtype;
+  r->slot_stats = nullptr; r->stats_C = 0; r->slot_list = nullptr; r->slot_list_cap = 0;
   r->rows_pin = nullptr; r->rows_pin_k = 0; memset(r->rows_pin_used, 0, sizeof(r->rows_pin_used)); memset(r->rows_pin_ev, 0, sizeof(r->rows_pin_ev));
   r->stage = nullptr; r->stage_cap = 0; r->pinned = nullptr; r->pinned_cap = 0; r->pinned_busy = false; r->lut = nullptr; r->bad = nullptr;
   HIP_CHECK(hipEventCreateWithFlags(&r->pinned_free, hipEventDisableTiming));
@@ -154,11 +155,38 @@ extern "C" int cpp_replay_destroy(cpp_replay* r) {
   (void)hipSetDevice(r->ctx->device);
   (void)hipStreamSynchronize(r->ctx->stream);
   if (r->stage) (void)hipFree(r->stage);
+  if (r->slot_list) (void)hipFree(r->slot_list);
   if (r->pinned) (void)hipHostFree(r->pinned);
   if (r->rows_pin) (void)hipHostFree(r->rows_pin);
   for (hipEvent_t e : r->rows_pin_ev) if (e) (void)hipEventDestroy(e);
   (void)hipEventDestroy(r->pinned_free);
   r->arena.release(); delete r; return CPP_OK;
+}
+
+// Keep, per state slot, the per-channel sums sum(x), sum(x^2) over the state's pixels for `channels` interleaved channels (NHWC:
+// base_network.py:88-96 whitens over (batch, height, width)).  A minibatch's whitening statistics are then the sum of 2 B stored rows of
+// 2 C doubles instead of a pass over 2 B images (75 MB per minibatch at 64x64x18, B = 256): the fused steps, whose conv1 reads the store
+// itself, never touch the pixels for the sample.  The sums are (re)computed here for every slot and kept current by
+// cpp_replay_write_states / cpp_replay_fill_synthetic.  channels = 0, or a channel count the vector statistics path cannot take, turns
+// them off (the gather then reads the images, as before).
+extern "C" int cpp_replay_set_stats_channels(cpp_replay* r, int channels) {
+  ARG_CHECK(r && channels >= 0 && channels <= CPP_MAX_CHANNELS, "cpp_replay_set_stats_channels: channels %d", channels);
+  HIP_CHECK(hipSetDevice(r->ctx->device));
+  int C = channels;
+  if (C > 0) {
+    int g = 8, c = C; while (c) { int t = g % c; g = c; c = t; }
+    if (r->elems % 8 != 0 || C / g > 16 || r->elems % C != 0) C = 0;
+  }
+  ++r->write_gen;              // (a minibatch presampled under the old setting is stale)
+  if (C == 0) { r->stats_C = 0; return CPP_OK; }          // (the buffer, if any, stays allocated and unused)
+  if (!r->slot_stats || r->stats_C < C) {
+    HIP_CHECK(hipStreamSynchronize(r->ctx->stream));
+    RC(dalloc(r->arena, &r->slot_stats, (size_t)r->slots * 2 * C));
+  }
+  r->stats_C = C;
+  RC(launch_slot_stats(r->ctx, r->store, r->store_dtype, r->elems, C, r->slot_stats, nullptr, 0, r->slots, r->lut));
+  HIP_CHECK(hipStreamSynchronize(r->ctx->stream));
+  return CPP_OK;
 }
 
 // self.state[idx] = s (replay_memory.py:67,106).  The host rows go through a pinned staging buffer, so the call returns
@@ -175,12 +203,14 @@ extern "C" int cpp_replay_write_states(cpp_replay* r, const int32_t* slots, int 
     ARG_CHECK(slots[i] >= 0 && slots[i] < r->slots, "cpp_replay_write_states: slot %d outside [0,%d)", slots[i], r->slots);
   const size_t esz = dtype == CPP_U8 ? 1 : dtype == CPP_F16 ? sizeof(__half) : sizeof(float);
   const size_t need = (size_t)n * r->elems * esz;
+  const size_t need_ids = ((need + 15) & ~(size_t)15) + (size_t)n * sizeof(int32_t);     // the slot numbers ride behind the payload
   if (r->pinned_busy) { HIP_CHECK(hipEventSynchronize(r->pinned_free)); r->pinned_busy = false; }   // previous transfer done
-  if (need > r->pinned_cap) {
+  if (need_ids > r->pinned_cap) {
     if (r->pinned) HIP_CHECK(hipHostFree(r->pinned));
-    HIP_CHECK(hipHostMalloc(&r->pinned, need, hipHostMallocDefault)); r->pinned_cap = need;
+    HIP_CHECK(hipHostMalloc(&r->pinned, need_ids, hipHostMallocDefault)); r->pinned_cap = need_ids;
   }
   memcpy(r->pinned, states, need);
+  memcpy((char*)r->pinned + ((need + 15) & ~(size_t)15), slots, (size_t)n * sizeof(int32_t));
   const bool direct = dtype == r->store_dtype;       // no conversion (f16 -> f16, camera bytes -> 8-bit store): copy into the slots
   bool checked = false;
   if (direct) {
@@ -204,6 +234,16 @@ extern "C" int cpp_replay_write_states(cpp_replay* r, const int32_t* slots, int 
       else
         RC(launch_f32_to_f16(r->ctx, (__half*)r->store + (size_t)slots[i] * r->elems, (const float*)src, r->elems));
     }
+  }
+  if (r->slot_stats) {       // the new states' whitening sums (what a gather of them would compute), once, here
+    if ((size_t)n > r->slot_list_cap) {
+      HIP_CHECK(hipStreamSynchronize(st));
+      if (r->slot_list) HIP_CHECK(hipFree(r->slot_list));
+      r->slot_list_cap = (size_t)n < 256 ? 256 : (size_t)n;
+      HIP_CHECK(hipMalloc((void**)&r->slot_list, r->slot_list_cap * sizeof(int32_t)));
+    }
+    HIP_CHECK(hipMemcpyAsync(r->slot_list, (const char*)r->pinned + ((need + 15) & ~(size_t)15), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    RC(launch_slot_stats(r->ctx, r->store, r->store_dtype, r->elems, r->stats_C, r->slot_stats, r->slot_list, 0, n, r->lut));
   }
   HIP_CHECK(hipEventRecord(r->pinned_free, st));
   r->pinned_busy = true;
@@ -339,6 +379,7 @@ GatherArgs replay_gather_args(cpp_replay* r, int B, const int32_t* rows_dev, uin
   a.out_state[0] = direct ? nullptr : out->s[0]; a.out_state[1] = direct ? nullptr : out->s[1];
   a.out_slot[0] = direct ? out->slot[0] : nullptr; a.out_slot[1] = direct ? out->slot[1] : nullptr;
   out->direct_store = direct ? r->store : nullptr;
+  a.slot_stats = (direct && C > 0 && r->slot_stats && r->stats_C == C) ? r->slot_stats : nullptr;
   a.out_action = out->a; a.out_reward = out->r; a.out_mask = out->m;
   a.part = out->part; a.seed = seed; a.counter = counter_dev;
   a.elems = r->elems; a.B = B; a.size = r->size; a.size_ptr = r->size_dev; a.action_dim = r->A; a.C = C;
@@ -406,6 +447,7 @@ extern "C" int cpp_replay_fill_synthetic(cpp_replay* r, int n_rows, uint64_t see
   RC(launch_replay_fill(r->ctx, r->store_dtype == CPP_U8 ? nullptr : (__half*)r->store, r->elems, r->slots, r->s1, r->s2,
                         r->action, r->reward, r->mask, n_rows, r->A, seed));
   if (r->store_dtype == CPP_U8) RC(launch_replay_fill_u8(r->ctx, (uint8_t*)r->store, r->elems * (long)r->slots, seed));
+  if (r->slot_stats) RC(launch_slot_stats(r->ctx, r->store, r->store_dtype, r->elems, r->stats_C, r->slot_stats, nullptr, 0, r->slots, r->lut));
   HIP_CHECK(hipStreamSynchronize(r->ctx->stream));
   return replay_set_size(r, n_rows);
 }

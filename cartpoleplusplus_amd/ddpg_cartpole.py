@@ -289,6 +289,7 @@ class _Trainer(object):
         return True
 
     def device_batch_for(self, batch, state_only=False):
+        self.flush()          # (a deferred actor update gathers ITS draw into the shared minibatch buffer: before this one's, not after)
         if isinstance(batch, replay_memory.StateColumn):          # a state column of a replay Batch: its rows, gathered on the device
             batch = batch.batch
         if isinstance(batch, replay_memory.Batch) and batch.device is not None:

@@ -102,8 +102,9 @@ class Batch(object):
     Tuple protocol preserved (len 5, indexing, iteration, attribute names).  A Batch is a DRAW: the row indexes, the state slots
     they pointed to and host copies of the three small columns, all taken at batch() time.  The two state columns stay in the
     replay store (`StateColumn`) until somebody reads them; `device` gathers the draw into a device minibatch for the train ops
-    that want one.  Both work as long as no state has been written to the memory since the draw (or the column was read before);
-    after that they raise instead of returning another draw's pixels."""
+    that want one.  A Batch that is still alive and unread when the memory is about to be written (add_episode) or closed is
+    preserved first -- a device-to-device gather into the minibatch buffer of its size, a download only when that buffer is needed
+    by a second such Batch -- so it keeps the np.copy semantics of replay_memory.py:134-138 whatever the caller does with it."""
     _fields = _FIELDS
 
     def __init__(self, memory, state_shape, idxs, s1_idx, s2_idx, small):
@@ -127,6 +128,22 @@ class Batch(object):
         """True while the rows of this draw are still what the replay memory holds (no write since batch())."""
         rm = self._memory
         return rm is not None and rm.handle is not None and rm._write_gen == self._gen
+
+    def _preserve(self, to_host=False):
+        """called by the memory before the rows of this draw can change: keep the draw readable (see the class docstring)."""
+        if self._states is not None or len(self.idxs) == 0:
+            return
+        if to_host:
+            self._host_states()
+            return
+        rm = self._memory
+        dev = rm._device_batch(len(self.idxs))
+        other = dev.owner()
+        if other is self:
+            return
+        if other is not None and other._states is None:
+            other._host_states()                  # the buffer's current draw moves to the host, this one takes the buffer
+        self.device                               # (gathers: this Batch owns the buffer from here on)
 
     def _gone(self):
         return RuntimeError("states have been written to the replay memory since this Batch was drawn and its state columns were "
@@ -287,9 +304,12 @@ class ReplayMemory(object):
         self.state = _StateStoreView(self)
         self._batches = {}
         self._write_gen = 0          # bumped by every write of states (add_episode, fill_synthetic)
+        self._drawn = weakref.WeakSet()   # Batches drawn since the last write (preserved before the next one, see Batch)
         self._adhoc_counter = 0      # sample_on_device draws (separate from the train steps' device counter)
         # pixel states (H, W, 3, cameras, repeats): channel count for the fused whitening statistics
         self.channels = int(np.prod(self.state_shape[2:])) if len(self.state_shape) == 5 else 0
+        if self.channels > 0:        # per-state whitening sums, kept by the store: sampling never re-reads the pixels for them
+            check(lib.cpp_replay_set_stats_channels(self.handle, self.channels))
 
     # --- host-side slot bookkeeping: exactly replay_memory.py:63-118 ---------------------------
     def _pop_slot(self):
@@ -299,6 +319,7 @@ class ReplayMemory(object):
         return self.state_free_slots.popleft()
 
     def add_episode(self, initial_state, action_reward_state_sequence):
+        self._preserve_draws()
         self.stats[">add_episode"] += 1
         seq = list(action_reward_state_sequence)
         assert len(seq) > 0
@@ -362,7 +383,7 @@ class ReplayMemory(object):
             # be the ones this very episode's evictions freed -- a device-side refusal would come after they were overwritten)
             codes = (np.arange(256) / 255.0).astype(np.float16).view(np.uint16)
             if not np.isin(states.view(np.uint16), codes).all():
-                raise RuntimeError("replay memory (8-bit store): a state is not an image of f16(k/255) pixels")
+                raise RuntimeError("replay memory (8-bit store): pixel images only -- a state holds a value that is not f16(k/255)")
         check(lib.cpp_replay_write_states(self.handle, ptr(slots), n + 1, ptr(states), dt))
         check(lib.cpp_replay_write_rows(self.handle, ptr(rows), n, ptr(s1), ptr(s2),
                                         ptr(np.ascontiguousarray(self.action[rows])),
@@ -390,7 +411,15 @@ class ReplayMemory(object):
         """the draw `idxs` as a Batch: slots and the three small columns are copied from the host mirrors now (np.copy semantics of
         replay_memory.py:134-138 for everything that is cheap), the states stay where they are."""
         small = {"action": self.action[idxs], "reward": self.reward[idxs], "terminal_mask": self.terminal_mask[idxs]}
-        return Batch(self, self.state_shape, idxs, self.state_1_idx[idxs], self.state_2_idx[idxs], small)
+        b = Batch(self, self.state_shape, idxs, self.state_1_idx[idxs], self.state_2_idx[idxs], small)
+        self._drawn.add(b)
+        return b
+
+    def _preserve_draws(self, to_host=False):
+        for b in list(self._drawn):
+            if b.in_replay():
+                b._preserve(to_host)
+        self._drawn.clear()
 
     def batch(self, batch_size=None, idxs=None):
         """replay_memory.py:131-138.  Rows come from numpy's global RNG exactly like the reference (`idxs=` overrides, as
@@ -429,6 +458,7 @@ class ReplayMemory(object):
         """bench/test helper: synthetic transitions generated on the device.  The host bookkeeping is advanced to
         match (fixed 50-step episodes, chain slot layout) and the host mirrors of the event columns are read back."""
         n_rows = int(n_rows)
+        self._preserve_draws()
         check(lib.cpp_replay_fill_synthetic(self.handle, n_rows, int(seed)))
         self._write_gen += 1
         rows = np.arange(n_rows, dtype=np.int32)
@@ -488,6 +518,8 @@ class ReplayMemory(object):
                          % (log_file, num_episodes, num_events, time.time() - start))
 
     def close(self):
+        if self.handle:
+            self._preserve_draws(to_host=True)
         for b in self._batches.values():
             b.close()
         self._batches = {}

@@ -165,6 +165,10 @@ int cpp_replay_write_rows(cpp_replay* replay, const int32_t* rows, int n, const 
  * state_1_idx / action / reward / terminal_mask / state_2_idx (:22-29) as the sampler sees them */
 int cpp_replay_read_rows(cpp_replay* replay, const int32_t* rows, int n, int32_t* s1_idx, int32_t* s2_idx, float* action,
                          float* reward, float* terminal_mask);
+/* Keep per-state whitening sums (sum x, sum x^2 per channel, f64) in the store for `channels` interleaved channels: the statistics of
+ * base_network.py:95-96 for a sampled minibatch then cost 2 B rows of 2 C doubles instead of a pass over 2 B images.  Results are
+ * bit-identical (the same per-image sums, added in the same order).  0 turns them off. */
+int cpp_replay_set_stats_channels(cpp_replay* replay, int channels);
 int cpp_replay_set_size(cpp_replay* replay, int size);          /* ReplayMemory.size(), :120 */
 int cpp_replay_read_states(cpp_replay* replay, const int32_t* slots, int n, void* out_f16);
 /* random_indexes + batch (replay_memory.py:123-138) fused: idxs == NULL draws B uniform rows on the

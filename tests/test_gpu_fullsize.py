@@ -302,3 +302,36 @@ def test_bf16_nine_product_conv2_is_as_close_to_the_f64_oracle_as_the_f32_mfma_k
     assert f16e < 1e-5 * max(1.0, mag) and f32e < 1e-5 * max(1.0, mag), res
     assert f16e <= 1.5 * f32e + 1e-7 * max(1.0, mag), res
     assert d16e < 5e-6 and d32e < 5e-6 and d16e <= 1.5 * d32e + 1e-8, res
+
+
+_PAIR_DW_SNIPPET = r"""
+import hashlib
+import numpy as np
+from tests.helpers import make_pair
+for SHAPE, B in (((64, 64, 3, 2, 3), 256), ((64, 64, 3, 1, 3), 64), ((32, 32, 3, 2, 3), 32), ((50, 50, 3, 2, 3), 16)):
+    agent, _ref, _ = make_pair(SHAPE, B, True, replay_size=400, seed=2)
+    agent.replay_memory.fill_synthetic(300, seed=5)
+    idx = np.random.default_rng(1).integers(0, 300, 2 * B)
+    agent.train_step(B, 2, idxs=idx)
+    h = hashlib.sha256()
+    for net in agent.networks():
+        h.update(net.get_params().tobytes())
+    h.update(agent.actor.get_grads().tobytes()); h.update(agent.critic.get_grads().tobytes())
+    print("PAIRDW %s %s" % ("x".join(map(str, SHAPE)), h.hexdigest()))
+    agent.close()
+"""
+
+
+def test_two_network_conv1_dw_workgroups_give_the_single_network_kernels_bits():
+    """conv_dw16.h with NNET = 2 (the actor's and the critic's conv1 dW from one staged image row, default for DDPG) must leave the
+    very partials of the one-network-per-workgroup kernel (CPP_DW16_PAIR=0): the same scale, the same MFMA order per accumulator."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = {}
+    for pair in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", _PAIR_DW_SNIPPET], cwd=root, env=dict(os.environ, CARTPOLEPP_ABLATION="1", CPP_DW16_PAIR=pair),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        out = r.stdout.decode()
+        seen[pair] = re.findall(r"PAIRDW (\S+) (\S+)", out)
+        assert r.returncode == 0 and len(seen[pair]) == 4, out[-1500:]
+    assert seen["1"] == seen["0"], seen

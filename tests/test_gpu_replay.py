@@ -243,18 +243,21 @@ def test_two_batches_of_one_size_are_independent_snapshots():
             assert np.array_equal(getattr(b, f), getattr(ob, f)), f
         assert np.array_equal(b.idxs, idx)
     assert np.array_equal(early, b1.reward)
-    # a Batch whose states were overwritten before anybody read them fails loudly instead of returning another draw's rows
+    # Batches that are alive and unread when the memory is written keep their draw (np.copy semantics, replay_memory.py:134-138):
+    # the last one by a device-side gather into the minibatch buffer, an earlier one of the same size by a download
     b4 = rm.batch(idxs=i1)
     b5 = rm.batch(idxs=i2)
-    b5_s1 = np.asarray(b5.state_1).copy()         # read: b5 owns host copies from here on
-    rm.add_episode(s0, seq)
-    with pytest.raises(RuntimeError):
-        np.asarray(b4.state_1)
-    with pytest.raises(RuntimeError):
-        b4.device
-    assert np.array_equal(b4.idxs, i1) and np.array_equal(np.asarray(b5.state_1), b5_s1)
-    assert b5.device is not None                  # (uploaded from its host columns)
-    rm.close()
+    o4, o5 = orm.batch(idxs=i1), orm.batch(idxs=i2)
+    rm.add_episode(s0, seq); orm.add_episode(s0, seq)
+    assert not b4.in_replay() and not b5.in_replay()
+    assert (b4._states is None) != (b5._states is None)      # one lives on in the device buffer, the other on the host
+    for b, ob in ((b4, o4), (b5, o5)):
+        for f in ("state_1", "action", "reward", "terminal_mask", "state_2"):
+            assert np.array_equal(getattr(b, f), getattr(ob, f)), f
+    b6 = rm.batch(idxs=i1)
+    o6 = orm.batch(idxs=i1)
+    rm.close()                                    # closing the memory moves unread draws to the host
+    assert np.array_equal(np.asarray(b6.state_2), o6.state_2)
 
 
 def test_inspection_draws_do_not_move_the_training_sampler():
@@ -349,3 +352,38 @@ def test_random_episodes_differential_against_the_oracle_memory(buffer_size, loa
                 assert np.array_equal(np.asarray(x), np.asarray(y))
     finally:
         rm.close()
+
+
+def test_stored_whitening_sums_equal_a_pass_over_the_pixels():
+    """cpp_replay_set_stats_channels: the store keeps sum(x), sum(x^2) per state and channel; a sampled minibatch's whitening tables
+    built from those rows (the fused steps' sample pass) must be bit for bit the tables of a gather that reads the images --
+    for states written by add_episode (f16 and camera bytes), by the synthetic fill, and in the 8-bit store."""
+    import ctypes as C
+    from cartpoleplusplus_amd import _lib, ddpg_cartpole as D
+    from cartpoleplusplus_amd.replay_memory import ReplayMemory
+    from tests.helpers import FakeEnv, make_opts
+    shape, B = (16, 16, 3, 2, 3), 16
+    rng = np.random.default_rng(8)
+    for store in ("f16", "u8"):
+        make_opts(D, shape, B, True, replay_memory_size=120, replay_store=store)
+        agent = D.DeepDeterministicPolicyGradientAgent(FakeEnv(shape))
+        agent.initialise_variables(seed=1); agent.post_var_init_setup()
+        rm = agent.replay_memory
+        rm.fill_synthetic(60, seed=3)
+        for ep in range(3):          # episodes over the synthetic rows: f16 frames, then raw camera bytes
+            mk = (lambda: rng.integers(0, 256, shape).astype(np.float16) / np.float16(255)) if ep < 2 else (lambda: rng.integers(0, 256, shape).astype(np.uint8))
+            rm.add_episode(mk(), [(rng.uniform(-1, 1, (1, 2)).astype(np.float32), 1.0, mk()) for _ in range(7)])
+        idx = rng.integers(0, rm.size(), 2 * B).astype(np.int32)
+
+        def params_after(stats_on):
+            a2 = D.DeepDeterministicPolicyGradientAgent(FakeEnv(shape))
+            a2.initialise_variables(seed=1); a2.post_var_init_setup()
+            _lib.check(_lib.lib.cpp_replay_set_stats_channels(rm.handle, rm.channels if stats_on else 0))
+            _lib.check(_lib.lib.cpp_ddpg_train_step(a2.trainer.handle, rm.handle, B, 2, idx.ctypes.data_as(C.c_void_p), 0))
+            out = [n.get_params() for n in a2.networks()]
+            a2.close()
+            return out
+        with_sums, from_pixels = params_after(True), params_after(False)
+        for x, y in zip(with_sums, from_pixels):
+            assert np.array_equal(x, y), store
+        agent.close()
