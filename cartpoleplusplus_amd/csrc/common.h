@@ -13,10 +13,30 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #include <cstdlib>
 inline bool cpp_switch_off(const char* name) { const char* v = getenv(name); return v != nullptr && atoi(v) == 0; }
 inline bool cpp_switch_set(const char* name) { return getenv(name) != nullptr; }
+inline int cpp_switch_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 #else
 constexpr bool cpp_switch_off(const char*) { return false; }
 constexpr bool cpp_switch_set(const char*) { return false; }
+constexpr int cpp_switch_int(const char*, int dflt) { return dflt; }
 #endif
+
+// Two kernel bodies in one grid (conv2_bwd_pair.hip, conv3_bwd_pair.hip): which body workgroup i of (na + nb) runs.  The dispatcher
+// hands out workgroups in index order, so the order decides who starts first: order 0 = all of a, then b; 1 = all of b, then a;
+// 2 = b spread evenly through a.  Returns true for body b; *idx = the workgroup's index within its own body's grid.
+__host__ __device__ inline bool pair_grid_place(int i, int na, int nb, int order, int* idx) {
+  if (order == 1) { if (i < nb) { *idx = i; return true; } *idx = i - nb; return false; }
+  if (order == 2 && nb > 0 && na > 0) {
+    const int k = (na + nb) / nb;                       // every k-th workgroup of the first nb * k is one of b
+    const int head = nb * k;
+    if (i < head) {
+      if (i % k == 0) { *idx = i / k; return true; }
+      *idx = i - i / k - 1; return false;
+    }
+    *idx = i - nb; return false;
+  }
+  if (i < na) { *idx = i; return false; }
+  *idx = i - na; return true;
+}
 
 #define CPP_NOUT_MAX 16       // one MFMA N tile; the reference hard-codes 10 filters (base_network.py:103)
 #define CPP_MAX_CHANNELS 64

@@ -1,15 +1,17 @@
 // conv2's dW (nine-product bf16 kernel) and dX (row kernel in dX mode) in ONE launch, as for conv3 (conv3_bwd_pair.hip): both read
 // the pooled gradient conv3's dX left, neither needs the other.  Workgroups [0, dX grid) run dX, the rest dW.
 #include <cstring>
+#ifndef PAIR_ORDER_DEFAULT
+#define PAIR_ORDER_DEFAULT 1
+#endif
 #include "conv_kyo.h"
 #include "conv_dwb16.h"
 
-__global__ __launch_bounds__(CONV_THREADS, 2) void conv2_bwd_pair_kernel(const ConvArgsN dx, int dx_gx, const ConvArgsN dw, int dw_gx, int upi, int band) {
-  const int ndx = dx_gx * dx.n;
-  if ((int)blockIdx.x < ndx) {
-    conv_fwd_kyo_body<10, 5, 1, 2, IN_DY, 16, false>(dx, (int)blockIdx.x % dx_gx, (int)blockIdx.x / dx_gx);
+__global__ __launch_bounds__(CONV_THREADS, 2) void conv2_bwd_pair_kernel(const ConvArgsN dx, int dx_gx, const ConvArgsN dw, int dw_gx, int upi, int band, int order) {
+  int i;
+  if (!pair_grid_place((int)blockIdx.x, dx_gx * dx.n, dw_gx * dw.n, order, &i)) {
+    conv_fwd_kyo_body<10, 5, 1, 2, IN_DY, 16, false>(dx, i % dx_gx, i / dx_gx);
   } else {
-    const int i = (int)blockIdx.x - ndx;
     conv_dwb16_body<10, 5, 1>(dw, upi, band, i % dw_gx, i / dw_gx, dw_gx);
   }
 }
@@ -27,9 +29,12 @@ int launch_conv2_bwd_pair(cpp_ctx* ctx, const ConvPairSlot& slot) {
   ConvArgsN dx = slot.dx, dw = slot.dw;
   if (!slot.have_dx) { memset(&dx, 0, sizeof(dx)); dx.n = 0; }
   if (!slot.have_dw) { memset(&dw, 0, sizeof(dw)); dw.n = 0; }
+  // the dW workgroups are few, long serial chains (a band of rows each): dispatched behind the dX grid they start when dX is nearly
+  // done and the launch takes dX + dW; dispatched first they run beside it (CPP_PAIR_ORDER: 0 dX first, 1 dW first, 2 interleaved)
+  static const int order = cpp_switch_int("CPP_PAIR_ORDER", PAIR_ORDER_DEFAULT);
   prof_begin(ctx);
   hipLaunchKernelGGL(conv2_bwd_pair_kernel, dim3(ndx + ndw), dim3(CONV_THREADS), lds, ctx->stream, dx, slot.have_dx ? slot.dx_gx : 1,
-                     dw, slot.have_dw ? slot.dw_gx : 1, slot.upi, slot.band);
+                     dw, slot.have_dw ? slot.dw_gx : 1, slot.upi, slot.band, order);
   LAUNCH_CHECK();
   prof_end(ctx, K_CONV2_BWD);
   return 0;

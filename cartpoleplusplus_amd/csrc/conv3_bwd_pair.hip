@@ -3,15 +3,17 @@
 // than it hides on this runtime, two kernels in one grid do not: workgroups [0, dX grid) run the row kernel in
 // dX mode, the rest the dW kernel -- the unchanged kernel bodies, told their place in a grid of their own.
 #include <cstring>
+#ifndef PAIR_ORDER_DEFAULT
+#define PAIR_ORDER_DEFAULT 1
+#endif
 #include "conv_impl.h"
 #include "conv_kyo.h"
 
-__global__ __launch_bounds__(CONV_THREADS, 2) void conv3_bwd_pair_kernel(const ConvArgsN dx, int dx_gx, const ConvArgsN dw, int dw_gx) {
-  const int ndx = dx_gx * dx.n;
-  if ((int)blockIdx.x < ndx) {
-    conv_fwd_kyo_body<10, 3, 1, 4, IN_DY, 16, false>(dx, (int)blockIdx.x % dx_gx, (int)blockIdx.x / dx_gx);
+__global__ __launch_bounds__(CONV_THREADS, 2) void conv3_bwd_pair_kernel(const ConvArgsN dx, int dx_gx, const ConvArgsN dw, int dw_gx, int order) {
+  int i;
+  if (!pair_grid_place((int)blockIdx.x, dx_gx * dx.n, dw_gx * dw.n, order, &i)) {
+    conv_fwd_kyo_body<10, 3, 1, 4, IN_DY, 16, false>(dx, i % dx_gx, i / dx_gx);
   } else {
-    const int i = (int)blockIdx.x - ndx;
     conv_dw_body<10, 3, 1, IN_F32_PLAIN>(dw, i % dw_gx, i / dw_gx, dw_gx);
   }
 }
@@ -29,9 +31,10 @@ int launch_conv3_bwd_pair(cpp_ctx* ctx, const ConvPairSlot& slot) {
   ConvArgsN dx = slot.dx, dw = slot.dw;
   if (!slot.have_dx) { memset(&dx, 0, sizeof(dx)); dx.n = 0; }
   if (!slot.have_dw) { memset(&dw, 0, sizeof(dw)); dw.n = 0; }
+  static const int order = cpp_switch_int("CPP_PAIR_ORDER", PAIR_ORDER_DEFAULT);      // see conv2_bwd_pair.hip
   prof_begin(ctx);
   hipLaunchKernelGGL(conv3_bwd_pair_kernel, dim3(ndx + ndw), dim3(CONV_THREADS), lds, ctx->stream, dx, slot.have_dx ? slot.dx_gx : 1,
-                     dw, slot.have_dw ? slot.dw_gx : 1);
+                     dw, slot.have_dw ? slot.dw_gx : 1, order);
   LAUNCH_CHECK();
   prof_end(ctx, K_CONV3_BWD);
   return 0;

@@ -314,37 +314,9 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b, int phase = 0) {
     cpp_net* nets[4] = {a, c, ta, tc};
     const void* sts[4] = {s1, s1, s2, s2};
     const float* whs[4] = {w1, w1, w2, w2};
-    const int t1 = G.fn([=] {
-      for (int k = 0; k < 4; ++k) nets[k]->use_b16 = trunk_b16(nets[k], dt, B, 0);
-      {
-        ConvArgs cl[4]; int mode = 0;
-        for (int k = 0; k < 4; ++k) cl[k] = conv_fwd_args(nets[k], nets[k]->ws[0], 0, sts[k], dt, whs[k], B, &mode);
-        // the target networks have no backward pass: when their conv2 reads the bf16 planes of pool1, the f32 copy and the
-        // arg-max codes of pool1 are dead (26 MB of writes per minibatch at 64x64x18) -- the kernel skips null outputs
-        for (int k = 2; k < 4; ++k)
-          if (nets[k]->use_b16 && cl[k].out_b16) { cl[k].out = nullptr; cl[k].out_amax = nullptr; }
-        // all four conv1 forwards in one launch as well: 16 tiles per persistent workgroup amortise the weight
-        // preload and the tail (measured 0.560 -> 0.526 ms per step for the four networks)
-        RC(launch_conv_fwd_multi(ctx, kFwdKid[0], a->conv[0].Cin, a->conv[0].ks, mode, EPI_RELU_POOL, cl, 4));
-      }
-      // conv2 (bf16 pipes, 32x32 inputs) carries conv3 + pool3 as its tail when the geometry allows: one launch less
-      bool fuse23 = conv23_fuse_ok(a->conv[1].H, a->conv[1].W, B, kConvOut);
-      for (int k = 0; k < 4; ++k) fuse23 = fuse23 && nets[k]->use_b16;
-      for (int i = 1; i < 3; ++i) {
-        if (i == 2 && fuse23) break;
-        ConvArgs cl[4]; int mode = 0;
-        for (int k = 0; k < 4; ++k) {
-          cl[k] = conv_fwd_args(nets[k], nets[k]->ws[0], i, sts[k], dt, whs[k], B, &mode);
-          if (i == 1 && fuse23) {
-            int m3 = 0;
-            const ConvArgs c3 = conv_fwd_args(nets[k], nets[k]->ws[0], 2, sts[k], dt, whs[k], B, &m3);
-            cl[k].n3_w = c3.w; cl[k].n3_bias = c3.bias; cl[k].n3_out = c3.out; cl[k].n3_out_bstride = c3.out_bstride; cl[k].n3_amax = c3.out_amax;
-            if (k >= 2) { cl[k].out = nullptr; cl[k].out_amax = nullptr; }      // targets: pool2 only feeds conv3, which reads it from LDS
-          }
-        }
-        RC(launch_conv_fwd_multi(ctx, kFwdKid[i], a->conv[i].Cin, a->conv[i].ks, mode, EPI_RELU_POOL, cl, 4));
-      }
-      return (int)CPP_OK; }, {});
+    // conv1 / conv2 (+ conv3 as conv2's tail) of the four networks in one launch per layer; the two target networks have no
+    // backward pass (nets_forward_trunk_fused, rt_net.cpp)
+    const int t1 = G.fn([=] { return nets_forward_trunk_fused(ctx, nets, 4, sts, whs, 2, dt, B); }, {});
     tA = tC = tTA = tTC = t1;
   } else if (a->spec.pixel) {       // batch norm (training mode for the whole graph, ddpg_cartpole.py:145,237)
     cpp_net* nets[4] = {a, c, ta, tc};

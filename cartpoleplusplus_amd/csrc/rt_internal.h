@@ -202,6 +202,7 @@ BnNet bn_net_desc(cpp_net* n, Workspace& w, int i);
 BnBatch bn_batch(cpp_net* const* nets, int nn, int i, int B);
 bool trunk_b16(const cpp_net* n, int dtype, int B, long white_bstride);
 int net_forward_trunk(cpp_net* n, Workspace& w, const void* state, int dtype, const float* white, int B, long white_bstride = 0);
+int nets_forward_trunk_fused(cpp_ctx* ctx, cpp_net* const* nets, int nn, const void* const* sts, const float* const* whs, int first_target, int dt, int B);
 int nets_forward_trunk_bn(cpp_ctx* ctx, cpp_net* const* nets, int nn, const void* const* states, const float* const* whites, int dtype, int B);
 GemmArgs mk_gemm(const float* A, long sAm, long sAk, const float* Bm, long sBk, long sBn, float* C, long ldc, int M, int N, int K, int epi);
 GemmArgs mk_gemm(const float* A, long sAm, long sAk, const float* Bm, long sBk, long sBn, float* C, long ldc, int M, int N, int K, int epi, const float* Y, long ldy);

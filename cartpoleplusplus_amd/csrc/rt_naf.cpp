@@ -162,14 +162,8 @@ static int naf_compute_gradients(cpp_naf* f, cpp_batch* b) {
   int t1;
   if (v->spec.pixel && !v->spec.use_batch_norm) {
     std::vector<cpp_net*> nets(tn, tn + nt); std::vector<const void*> sts(ts, ts + nt); std::vector<const float*> whs(tw, tw + nt);
-    t1 = G.fn([=] {
-      for (int k = 0; k < nt; ++k) nets[k]->use_b16 = trunk_b16(nets[k], dt, B, 0);
-      for (int i = 0; i < 3; ++i) {
-        ConvArgs cl[CONV_BATCH_MAX]; int mode = 0;
-        for (int k = 0; k < nt; ++k) cl[k] = conv_fwd_args(nets[k], nets[k]->ws[0], i, sts[k], dt, whs[k], B, &mode);
-        RC(launch_conv_fwd_multi(ctx, kFwdKid[i], v->conv[i].Cin, v->conv[i].ks, mode, EPI_RELU_POOL, cl, nt));
-      }
-      return (int)CPP_OK; }, {});
+    // one launch per conv layer for all trunks, conv3 as conv2's tail, the target network forward-only (rt_net.cpp)
+    t1 = G.fn([=] { return nets_forward_trunk_fused(ctx, nets.data(), nt, sts.data(), whs.data(), nt - 1, dt, B); }, {});
   } else {
     std::vector<cpp_net*> nets(tn, tn + nt); std::vector<const void*> sts(ts, ts + nt); std::vector<const float*> whs(tw, tw + nt);
     t1 = G.fn([=] {        // low-dim states, or batch-norm trunks (training mode: naf_cartpole.py:271)
@@ -228,7 +222,10 @@ static int naf_compute_gradients(cpp_naf* f, cpp_batch* b) {
       }
     }
     const int dv = add_fc_backward(G, v, v->ws[0], B, Lh - 1, dep);
-    if (v->spec.pixel) G.fn([=] { return net_backward_conv(v, v->ws[0], B, s1, dt, w1); }, {dv});
+    if (v->spec.pixel) {     // conv3's and conv2's dW + dX as one launch each, like the DDPG step (nets_backward_conv)
+      cpp_net* bn[1] = {v};
+      G.fn([=] { return nets_backward_conv(ctx, bn, 1, B, s1, dt, w1); }, {dv});
+    }
   }
   DwPendingGuard pending(ctx);      // (a failure below drops what was queued)
   RC(G.run(ctx));

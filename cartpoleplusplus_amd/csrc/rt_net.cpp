@@ -384,6 +384,45 @@ int net_backward_conv(cpp_net* n, Workspace& w, int B, const void* state, int dt
 }
 
 // the same for several networks with identical geometry, every layer's kernels batched into one launch
+// The conv trunks (no batch norm) of nn same-shaped networks, one launch per layer: networks [0, first_target) will run a backward
+// pass, networks [first_target, nn) are forward-only (target networks: base_network.py:35-49).
+//  * conv1 of all of them is ONE launch: 16 tiles per persistent workgroup amortise the weight preload and the tail (measured
+//    0.560 -> 0.526 ms per step for DDPG's four networks);
+//  * a forward-only network whose conv2 reads the bf16 planes of pool1 never reads pool1's f32 copy or its arg-max codes (26 MB of
+//    writes per minibatch at 64x64x18): null outputs, which the kernel skips;
+//  * conv2 (bf16 pipes, 32x32 inputs) carries conv3 + pool3 as its tail when the geometry allows (conv23_fuse_ok): one launch
+//    less, and the forward-only networks' pool2 never leaves LDS.
+int nets_forward_trunk_fused(cpp_ctx* ctx, cpp_net* const* nets, int nn, const void* const* sts, const float* const* whs, int first_target,
+                             int dt, int B) {
+  if (nn < 1 || nn > CONV_BATCH_MAX) { cpp_set_error("conv trunks: batch of %d networks", nn); return CPP_ERR_ARG; }
+  cpp_net* a = nets[0];
+  for (int k = 0; k < nn; ++k) nets[k]->use_b16 = trunk_b16(nets[k], dt, B, 0);
+  {
+    ConvArgs cl[CONV_BATCH_MAX]; int mode = 0;
+    for (int k = 0; k < nn; ++k) cl[k] = conv_fwd_args(nets[k], nets[k]->ws[0], 0, sts[k], dt, whs[k], B, &mode);
+    for (int k = first_target; k < nn; ++k)
+      if (nets[k]->use_b16 && cl[k].out_b16) { cl[k].out = nullptr; cl[k].out_amax = nullptr; }
+    RC(launch_conv_fwd_multi(ctx, kFwdKid[0], a->conv[0].Cin, a->conv[0].ks, mode, EPI_RELU_POOL, cl, nn));
+  }
+  bool fuse23 = conv23_fuse_ok(a->conv[1].H, a->conv[1].W, B, kConvOut);
+  for (int k = 0; k < nn; ++k) fuse23 = fuse23 && nets[k]->use_b16;
+  for (int i = 1; i < 3; ++i) {
+    if (i == 2 && fuse23) break;
+    ConvArgs cl[CONV_BATCH_MAX]; int mode = 0;
+    for (int k = 0; k < nn; ++k) {
+      cl[k] = conv_fwd_args(nets[k], nets[k]->ws[0], i, sts[k], dt, whs[k], B, &mode);
+      if (i == 1 && fuse23) {
+        int m3 = 0;
+        const ConvArgs c3 = conv_fwd_args(nets[k], nets[k]->ws[0], 2, sts[k], dt, whs[k], B, &m3);
+        cl[k].n3_w = c3.w; cl[k].n3_bias = c3.bias; cl[k].n3_out = c3.out; cl[k].n3_out_bstride = c3.out_bstride; cl[k].n3_amax = c3.out_amax;
+        if (k >= first_target) { cl[k].out = nullptr; cl[k].out_amax = nullptr; }      // pool2 only feeds conv3, which reads it from LDS
+      }
+    }
+    RC(launch_conv_fwd_multi(ctx, kFwdKid[i], a->conv[i].Cin, a->conv[i].ks, mode, EPI_RELU_POOL, cl, nn));
+  }
+  return CPP_OK;
+}
+
 int nets_backward_conv(cpp_ctx* ctx, cpp_net* const* nets, int nn, int B, const void* state, int dtype, const float* white) {
   if (nets[0]->spec.use_batch_norm) {                 // dense dz per layer, then dW / dX of all networks in one launch each
     for (int i = 2; i >= 0; --i) {
