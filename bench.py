@@ -108,7 +108,7 @@ def cpu_baseline_numpy(shape, B, budget_s=10.0, max_reps=4):
 
 def cpu_baseline_torch(shape, B, budget_s=25.0):
     """the same update on torch's CPU kernels (oneDNN conv, autograd): SURVEY 8(d)'s proxy for the reference's TF-CPU path
-    (TensorFlow 0.x cannot be installed).  Thread counts 16, 64 and all cores are tried within the budget (a 10-filter conv
+    (TensorFlow 0.x cannot be installed).  Thread counts 8, 16, 32 and 64 are tried within the budget (a 10-filter conv
     does not scale to hundreds of threads) and the best is reported."""
     import torch
     from oracle.ddpg_torch import TorchDDPG   # baseline only
@@ -118,15 +118,15 @@ def cpu_baseline_torch(shape, B, budget_s=25.0):
     agent = TorchDDPG(aspec, cspec, af, cf)
     batch = O.synthetic_batch(rng, B, shape, 2, True)
     tried, t_all = {}, time.time()
-    for threads in sorted({min(cores, 16), min(cores, 64), cores}):
+    for threads in sorted({min(cores, 8), min(cores, 16), min(cores, 32), min(cores, 64)}):
         if tried and time.time() - t_all > budget_s:
             break
-        if len(tried) >= 2 and list(tried.values())[-1] < list(tried.values())[-2]:
-            break           # more threads already made it slower (at 256 threads one update of this 10-filter net takes 27 s)
+        if len(tried) >= 3 and list(tried.values())[-1] < list(tried.values())[-2] < list(tried.values())[-3]:
+            break           # twice slower in a row with more threads (at 256 threads one update of this 10-filter net takes 27 s)
         torch.set_num_threads(threads)
         agent.train_minibatch(batch)          # warm-up (thread pool, oneDNN primitive cache)
         reps, t0 = 0, time.time()
-        while reps < 3 and (reps == 0 or time.time() - t0 < budget_s / 4):
+        while reps < 3 and (reps == 0 or time.time() - t0 < budget_s / 6):
             agent.train_minibatch(batch)
             reps += 1
         tried[threads] = reps / (time.time() - t0)
@@ -371,6 +371,9 @@ def main():
         row("conv3 dX", ["conv3_dx"], [(gf(L3, nb), "f32")])) if r]
     for r in rows:
         assert r["frac"] <= 1.0, "roofline accounting error: %r" % (r,)
+    mapped = {k for r in rows for k in r["kernels"]}
+    unmapped_conv = sorted(k for k in prof if k.startswith("conv") and k not in mapped)
+    # (reported, not asserted: a kernel id without a `layers` row understates conv_bound_frac_whole_step, it does not invalidate the line)
     conv_us = sum(r["us_per_step"] for r in rows)
     bound_us_step = sum(r["bound_us"] * r["launches_per_step"] for r in rows)
     kernels = {k: {"ms_per_step": round(v[0] / pm, 4), "launches_per_step": round(v[1] / pm, 2)}
@@ -384,7 +387,7 @@ def main():
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; they come from separate
         # rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), committed under profiles/
         traffic, traffic_src = None, None
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             try:
                 with open(os.path.join(ROOT, "profiles", "%s_pmc.json" % rnd)) as f:
                     pmc = json.load(f)
@@ -396,6 +399,9 @@ def main():
                 pass
         roofline = {"bound": "mfma", "kernel": dom["kernels"][0], "layer": dom["layer"], "achieved": dom["achieved_tflops"],
                     "peak": round(PIPES[pipe][0], 1), "unit": "TFLOP/s", "frac": dom["frac"], "peak_basis": PIPES[pipe][1],
+                    # SURVEY 8(d) named the f32-input MFMA peak as the bounding roofline before conv1 moved to exact f16 pieces: the
+                    # same achieved rate against THAT denominator (> 1 is possible and means nothing but "not an f32-MFMA kernel")
+                    "frac_vs_f32_mfma": round(dom["achieved_tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
                     "flops_per_launch": dom["gflop_per_launch"] * 1e9, "avg_launch_ms": round(dom["avg_launch_us"] / 1e3, 5),
                     "launches_per_step": dom["launches_per_step"], "traffic": traffic, "traffic_source": traffic_src}
         if pipe == "f16x3":
@@ -444,6 +450,7 @@ def main():
         "roofline": roofline,
         "layers": rows,
         "non_conv_us_per_step": round(other_us, 2),
+        "conv_kernels_without_a_layers_row": unmapped_conv,
         "kernels": kernels,
     }
     side = rank == 0 and world == 1 and not args.quick

@@ -136,6 +136,8 @@ SIGNATURES = {
     "cpp_naf_update_targets": (_I, [_P]),
     "cpp_naf_train_step": (_I, [_P, _P, _I, _I, _P, _U64]),
     "cpp_naf_train_rows": (_I, [_P, _P, _I, _P, C.POINTER(_F)]),
+    "cpp_naf_train_rows_async": (_I, [_P, _P, _I, _P, C.POINTER(_U64)]),
+    "cpp_naf_loss_wait": (_I, [_P, _U64, C.POINTER(_F)]),
     "cpp_naf_last_stats": (_I, [_P, _P]),
     "cpp_naf_opt_state_size": (_L, [_P]),
     "cpp_naf_get_opt_state": (_I, [_P, _P, _P, _L, C.POINTER(_U64)]),

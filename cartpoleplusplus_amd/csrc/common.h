@@ -299,6 +299,8 @@ struct OptSegs {
   const double* sq; int sq_begin[2], sq_count[2];   // sq != nullptr: group g's squared norm = sum of sq[sq_begin[g] .. + sq_count[g]) instead of `part`
   const uint64_t* step;        // Adam: number of applies so far INCLUDING this one (device counter)
   uint64_t* bump;              // optional: device counter incremented once by this launch (the replay sampler's Philox counter)
+  const int* skip_if;          // optional: device flag; non-zero = leave the parameters alone (NAF's check_numerics flag: tf.check_numerics
+                               // raises before the train op runs, naf_cartpole.py:242-245 -- decided on the device when nobody waits for the loss)
   // optional rider (st_part != nullptr): the whitening tables of the NEXT minibatch, whose sample pass has already run beside this
   // one's conv1 dW -- stats_finalize_kernel's work (stats_body.h) in st_jobs = columns x channels waves of an extra grid row
   const double* st_part; float* st_white; int st_nparts, st_jobs, st_C; double st_count, st_eps;

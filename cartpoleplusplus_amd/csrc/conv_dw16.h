@@ -41,7 +41,10 @@ struct Dw16Geom {
   static constexpr int DPC = NO * DOST;
   static constexpr int DSLOT = ((NPC * DPC - 192 + 255) / 256) * 256 + 192;            // = 192 (mod 256): B reads 1.17 accesses per bank quad
   static constexpr int RING_IN = 3, RING_DY = 6, UNROLL = 6;
-  static constexpr int NCELL = (16 * NCHK * NO + CONV_THREADS - 1) / CONV_THREADS;     // pooled cells of a row per thread
+  // dY staging: a thread's TASK is two pooled cells (px, o), (px + 2, o) whose f16 pieces are neighbours in the LDS layout (one 4-byte
+  // store per piece and x parity instead of two 2-byte ones): NO x NCHK x 4 lane groups x 2 pairs tasks per pooled row
+  static constexpr int NTASK = (NO * NCHK * 8 + CONV_THREADS - 1) / CONV_THREADS;
+  static constexpr int NCELL = 2 * NTASK;                     // pooled cells of a row per thread
   static constexpr int NVIN = (CIN % 2 ? WPAD * CIN : WPAD * CIN / 2) / CONV_THREADS + 1;   // dwords (odd CIN: halves) of an input row per thread
   static constexpr int IN_BYTES = RING_IN * ROWB, DY_BYTES = RING_DY * DSLOT;
   static constexpr int LDS_BYTES = ((IN_BYTES + 15) & ~15) + DY_BYTES + 64;       // (the epilogue scratch reuses the dY ring)
@@ -191,25 +194,35 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
   // ---- dY staging: a thread owns pooled cells idx = px * nout + o of a pooled row (the same cells for every row and network); the
   // masked gradient is scaled, split into three f16 pieces and written to both image rows of the pooled row.
   // pixel x = 32 ch + w sits in lane group g = 2 ((w >> 1) & 1) + (w >> 4), element e = 4 (w & 1) + ((w >> 2) & 3)
-  constexpr int NCELL = G::NCELL;
-  bool cact[NCELL];
-  uint32_t cdst[NCELL];
+  constexpr int NCELL = G::NCELL, NTASK = G::NTASK;
+  bool cact[NCELL], tact[NTASK];
+  uint32_t cdst[NTASK];
+  int cvo[NCELL];                                    // byte offset of the cell's f32 in a pooled row (pool / dpool; / 4: arg-max code)
   float cg[NNET][NCELL], dbsum[NNET][NCELL];
   unsigned short cpc[NNET][NCELL][NPC];
   int ccode[NNET][NCELL];
 #pragma unroll
-  for (int c = 0; c < NCELL; ++c) {
-    const int idx = tid + CONV_THREADS * c;
-    const int px = idx / nout, o = idx - px * nout;
-    cact[c] = idx < Wp * nout;
-    const int x = 2 * px, ch = x >> 5, w = x & 31;
-    const int g = 2 * ((w >> 1) & 1) + (w >> 4), e = (w >> 2) & 3;
-    cdst[c] = keep_in_vgpr(lds_addr(dyring + o * G::DOST + ch * 64 + g * 16 + e * 2));
+  for (int tk = 0; tk < NTASK; ++tk) {
+    // task T: o fastest (neighbouring lanes load neighbouring floats), then the pair, the lane group, the chunk
+    const int T = tid + CONV_THREADS * tk;
+    const int o = T % nout, rest = T / nout;
+    const int jp = rest & 1, g = (rest >> 1) & 3, ch = rest >> 3;
+    tact[tk] = ch < NCHK;
+    // lane group g of chunk ch holds pixels w = 16 (g & 1) + 2 (g >> 1) + {0, 1} + 4 j, j = 0..3: pooled cells px0 + 2 j
+    const int px0 = 16 * ch + 8 * (g & 1) + (g >> 1);
+    cdst[tk] = keep_in_vgpr(lds_addr(dyring + (tact[tk] ? o * G::DOST + ch * 64 + g * 16 + (2 * jp) * 2 : 0)));
 #pragma unroll
-    for (int k = 0; k < NNET; ++k) {
-      cg[k][c] = 0.f; ccode[k][c] = 0; dbsum[k][c] = 0.f;
+    for (int j = 0; j < 2; ++j) {
+      const int c = 2 * tk + j;
+      const int px = px0 + 2 * (2 * jp + j);
+      cact[c] = tact[tk] && px < Wp;
+      cvo[c] = cact[c] ? (px * nout + o) * 4 : 0;
 #pragma unroll
-      for (int pc = 0; pc < NPC; ++pc) cpc[k][c][pc] = 0;
+      for (int k = 0; k < NNET; ++k) {
+        cg[k][c] = 0.f; ccode[k][c] = 0; dbsum[k][c] = 0.f;
+#pragma unroll
+        for (int pc = 0; pc < NPC; ++pc) cpc[k][c][pc] = 0;
+      }
     }
   }
   float rpv[NNET][3][NCELL], rdv[NNET][3][NCELL];   // (set 2: only the unit prologue, so that its three requests are in flight together)
@@ -223,7 +236,7 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
       for (int c = 0; c < NCELL; ++c) {
         rpv[k][set][c] = 0.f; rdv[k][set][c] = 0.f; rcd[k][set][c] = 0;
         if (rowok && cact[c]) {
-          const int vo = (tid + CONV_THREADS * c) * 4, so = py * Wp * nout * 4;
+          const int vo = cvo[c], so = py * Wp * nout * 4;
           rpv[k][set][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rp[k], vo, so, 0));
           rdv[k][set][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd[k], vo, so, 0));
           rcd[k][set][c] = __builtin_amdgcn_raw_buffer_load_b8(rc[k], vo >> 2, so >> 2, 0);
@@ -252,13 +265,17 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
 #pragma unroll
     for (int k = 0; k < NNET; ++k)
 #pragma unroll
-      for (int c = 0; c < NCELL; ++c) {
-        if (cact[c]) {
-          const bool s0 = ccode[k][c] == 2 * ry, s1 = ccode[k][c] == 2 * ry + 1;
+      for (int tk = 0; tk < NTASK; ++tk) {
+        if (tact[tk]) {
+          const int c0 = 2 * tk, c1 = 2 * tk + 1;
 #pragma unroll
-          for (int pc = 0; pc < NPC; ++pc) {
-            lds_store(cdst[c], k * DYB + slot * DSLOT + pc * G::DPC, (unsigned short)(s0 ? cpc[k][c][pc] : 0));
-            lds_store(cdst[c], k * DYB + slot * DSLOT + pc * G::DPC + 8, (unsigned short)(s1 ? cpc[k][c][pc] : 0));
+          for (int s = 0; s < 2; ++s) {              // x parity: elements e and e + 4 of the 16-byte group
+            const bool on0 = ccode[k][c0] == 2 * ry + s, on1 = ccode[k][c1] == 2 * ry + s;
+#pragma unroll
+            for (int pc = 0; pc < NPC; ++pc) {
+              const unsigned v = (on0 ? (unsigned)cpc[k][c0][pc] : 0u) | ((on1 ? (unsigned)cpc[k][c1][pc] : 0u) << 16);
+              lds_store(cdst[tk], k * DYB + slot * DSLOT + pc * G::DPC + 8 * s, v);
+            }
           }
         }
       }
@@ -510,20 +527,27 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
     for (int c = 0; c < NCELL; ++c) dbs[c * CONV_THREADS + tid] = cact[c] ? dbsum[k][c] : 0.f;
   }
   __syncthreads();
-  if (tid < NNET * 64 && (tid & 63) < nout) {           // (one wave per network)
+  if (tid < NNET * 64 && (tid & 63) < nout) {           // (one wave per network; channel o = the tasks T = o (mod nout), in task order)
     const int k = tid >> 6, o = tid & 63;
     const float* dbs = reinterpret_cast<const float*>(dyring + k * DYB) + 4 * KS * 16;
     float s = 0.f;
-    const int nidx = Wp * nout;
-    int idx = o;
-    for (; idx + 7 * nout < nidx; idx += 8 * nout) {      // (same order as a one-by-one loop; its LDS reads were a chain of 32 round trips)
+    const int ntask = nout * NCHK * 8;
+    int T = o;
+    for (; T + 3 * nout < ntask; T += 4 * nout) {         // (same order as a one-by-one loop; 8 LDS reads in flight)
       float t[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const int i = idx + u * nout; t[u] = dbs[(i / CONV_THREADS) * CONV_THREADS + (i % CONV_THREADS)]; }
+      for (int u = 0; u < 4; ++u) {
+        const int Tu = T + u * nout, tk = Tu / CONV_THREADS, th = Tu % CONV_THREADS;
+        t[2 * u] = dbs[(2 * tk) * CONV_THREADS + th]; t[2 * u + 1] = dbs[(2 * tk + 1) * CONV_THREADS + th];
+      }
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += t[u];
     }
-    for (; idx < nidx; idx += nout) s += dbs[(idx / CONV_THREADS) * CONV_THREADS + (idx % CONV_THREADS)];
+    for (; T < ntask; T += nout) {
+      const int tk = T / CONV_THREADS, th = T % CONV_THREADS;
+      s += dbs[(2 * tk) * CONV_THREADS + th];
+      s += dbs[(2 * tk + 1) * CONV_THREADS + th];
+    }
     (batch.a[by + k].partial + (long)bx * batch.a[by + k].pstride)[nw + o] = s;
   }
 #ifdef DW16_CLOCK

@@ -61,6 +61,7 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_apply_kernel(const OptSegs s,
     if (job < s.st_jobs) stats_finalize_wave(s.st_part, s.st_nparts, s.st_C, s.st_count, s.st_white, s.st_eps, job, (int)(threadIdx.x & 63));
     return;
   }
+  if (s.skip_if && *s.skip_if) return;               // (uniform)
   // squared norm of the segment's group: the first wave adds the partials (one load per lane and segment in flight, then a
   // fixed-order butterfly) -- a one-thread loop over them was most of this kernel's time
   double tot = 0.0;

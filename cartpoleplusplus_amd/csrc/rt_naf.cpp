@@ -15,6 +15,9 @@ struct cpp_naf {
   hipGraph_t hgraph; hipGraphExec_t hexec; bool hgraph_ok; int h_B; uint64_t h_seed, h_replay_uid;
   // ONE minibatch on host-drawn rows up to (not including) the optimiser (cpp_naf_train_rows)
   hipGraph_t rgraph; hipGraphExec_t rgexec; bool rgraph_ok; int rg_B; uint64_t rg_replay_uid;
+  // ... and including it, the loss coming back later (cpp_naf_train_rows_async / cpp_naf_loss_wait): pinned (loss, flag) slots
+  hipGraph_t agraph; hipGraphExec_t agexec; bool agraph_ok; int ag_B; uint64_t ag_replay_uid;
+  float* res_pin; hipEvent_t res_ev[CPP_NAF_TICKETS]; uint64_t next_ticket;
   uint64_t dp_local;       // minibatches applied locally since the last parameter averaging (periodic mode)
   cpp_batch* step_batch;
   Arena arena;
@@ -48,6 +51,8 @@ extern "C" int cpp_naf_create(cpp_ctx* ctx, cpp_net* value, cpp_net* tvalue, cpp
   f->nV = value->nparams; f->nM = mu->nparams; f->nL = lv->nparams;
   f->graph = nullptr; f->gexec = nullptr; f->graph_ok = false; f->step_batch = nullptr; f->g_replay_uid = 0;
   f->rgraph = nullptr; f->rgexec = nullptr; f->rgraph_ok = false; f->rg_B = 0; f->rg_replay_uid = 0;
+  f->agraph = nullptr; f->agexec = nullptr; f->agraph_ok = false; f->ag_B = 0; f->ag_replay_uid = 0;
+  f->res_pin = nullptr; f->next_ticket = 0; memset(f->res_ev, 0, sizeof(f->res_ev));
   f->hgraph = nullptr; f->hexec = nullptr; f->hgraph_ok = false; f->h_B = 0; f->h_seed = 0; f->h_replay_uid = 0; f->dp_local = 0;
   const size_t nall = (size_t)(f->nV + f->nM + f->nL);
   int rc = dalloc(f->arena, &f->gradbuf, nall);
@@ -79,6 +84,10 @@ extern "C" int cpp_naf_destroy(cpp_naf* f) {
   if (f->hgraph) (void)hipGraphDestroy(f->hgraph);
   if (f->rgexec) (void)hipGraphExecDestroy(f->rgexec);
   if (f->rgraph) (void)hipGraphDestroy(f->rgraph);
+  if (f->agexec) (void)hipGraphExecDestroy(f->agexec);
+  if (f->agraph) (void)hipGraphDestroy(f->agraph);
+  if (f->res_pin) (void)hipHostFree(f->res_pin);
+  for (hipEvent_t e : f->res_ev) if (e) (void)hipEventDestroy(e);
   if (f->gexec) (void)hipGraphExecDestroy(f->gexec);
   if (f->graph) (void)hipGraphDestroy(f->graph);
   if (f->step_batch) cpp_batch_destroy(f->step_batch);
@@ -232,8 +241,9 @@ static int naf_compute_gradients(cpp_naf* f, cpp_batch* b) {
   return flush_dw_reduce(ctx);
 }
 
-static int naf_apply(cpp_naf* f, float grad_scale) {
+static int naf_apply(cpp_naf* f, float grad_scale, bool unless_nonfinite = false) {
   OptSegs s; memset(&s, 0, sizeof(s));
+  if (unless_nonfinite) s.skip_if = f->nonfinite;
   s.nseg = 3; s.kind = f->hp.optimiser; s.momentum = f->hp.momentum; s.beta1 = f->hp.beta1; s.beta2 = f->hp.beta2;
   s.epsilon = f->hp.epsilon; s.step = f->opt_step;
   cpp_net* nets[3] = {f->value, f->mu, f->lv};
@@ -421,6 +431,66 @@ extern "C" int cpp_naf_train_rows(cpp_naf* f, cpp_replay* r, int B, const int32_
   if (loss) *loss = l;
   if (bad) { cpp_set_error("check_numerics: l_values / L / loss is not finite (naf_cartpole.py:242-245)"); return CPP_ERR_NUMERIC; }
   return naf_apply(f, 1.0f);
+}
+
+// The same minibatch without the host in the loop: gradients AND the optimiser in one hipGraph -- the optimiser kernel itself stands
+// down when the check_numerics flag is set -- and the (loss, flag) pair copied into a pinned slot behind it.  The call returns a
+// ticket at once; cpp_naf_loss_wait(ticket) is the sync the reference's `loss = naf.train(batch)` implies, taken when somebody
+// reads the loss (the agents only log its mean) -- so a loop of train calls keeps the GPU fed like cpp_naf_train_step does.
+// At most CPP_NAF_TICKETS results are outstanding: a slot is reused CPP_NAF_TICKETS calls later.
+static int naf_rows_apply_body(cpp_naf* f, cpp_replay* r, int B) {
+  RC(naf_rows_body(f, r, B));
+  return naf_apply(f, 1.0f, true);
+}
+extern "C" int cpp_naf_train_rows_async(cpp_naf* f, cpp_replay* r, int B, const int32_t* idxs, uint64_t* ticket) {
+  ARG_CHECK(f && r && idxs && ticket, "cpp_naf_train_rows_async: NULL argument");
+  ARG_CHECK(B >= 1 && B <= f->maxB, "cpp_naf_train_rows_async: batch %d outside [1,%d]", B, f->maxB);
+  ARG_CHECK(r->elems == f->value->state_elems && r->A == f->A, "cpp_naf_train_rows_async: replay shape does not match the networks");
+  if (r->size <= 0) { cpp_set_error("cpp_naf_train_rows_async: replay memory is empty"); return CPP_ERR_STATE; }
+  cpp_ctx* ctx = f->ctx;
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (!f->step_batch) RC(cpp_batch_create(ctx, f->maxB, r->elems, r->A, &f->step_batch));
+  if (!f->res_pin) {
+    HIP_CHECK(hipHostMalloc((void**)&f->res_pin, CPP_NAF_TICKETS * 2 * sizeof(float), hipHostMallocDefault));
+    for (hipEvent_t& e : f->res_ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  RC(replay_stage_rows(r, idxs, B, "cpp_naf_train_rows_async"));
+  if (ctx->prof) {
+    RC(naf_rows_apply_body(f, r, B));
+  } else if (!f->agraph_ok || f->ag_B != B || f->ag_replay_uid != r->uid) {
+    if (f->agexec) { (void)hipGraphExecDestroy(f->agexec); f->agexec = nullptr; }
+    if (f->agraph) { (void)hipGraphDestroy(f->agraph); f->agraph = nullptr; }
+    f->agraph_ok = false;
+    RC(naf_rows_apply_body(f, r, B));                // eager pass: sets kernel attributes, is this call's work
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = naf_rows_apply_body(f, r, B);
+    const hipError_t e = hipStreamEndCapture(ctx->stream, &f->agraph);
+    if (rc) return rc;
+    if (e != hipSuccess) { cpp_set_error("hipStreamEndCapture -> %s", hipGetErrorString(e)); return CPP_ERR_HIP; }
+    HIP_CHECK(hipGraphInstantiate(&f->agexec, f->agraph, nullptr, nullptr, 0));
+    f->agraph_ok = true; f->ag_B = B; f->ag_replay_uid = r->uid;
+  } else {
+    HIP_CHECK(hipGraphLaunch(f->agexec, ctx->stream));
+  }
+  const uint64_t t = f->next_ticket++;
+  float* slot = f->res_pin + (t % CPP_NAF_TICKETS) * 2;
+  HIP_CHECK(hipMemcpyAsync(slot, f->stats, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipMemcpyAsync(slot + 1, f->nonfinite, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipEventRecord(f->res_ev[t % CPP_NAF_TICKETS], ctx->stream));
+  *ticket = t;
+  return CPP_OK;
+}
+extern "C" int cpp_naf_loss_wait(cpp_naf* f, uint64_t ticket, float* loss) {
+  ARG_CHECK(f && f->res_pin, "cpp_naf_loss_wait: no asynchronous train call has been made");
+  ARG_CHECK(ticket < f->next_ticket && ticket + CPP_NAF_TICKETS >= f->next_ticket, "cpp_naf_loss_wait: ticket %llu is not one of the last %d",
+            (unsigned long long)ticket, CPP_NAF_TICKETS);
+  HIP_CHECK(hipEventSynchronize(f->res_ev[ticket % CPP_NAF_TICKETS]));
+  const float* slot = f->res_pin + (ticket % CPP_NAF_TICKETS) * 2;
+  if (loss) *loss = slot[0];
+  int bad; memcpy(&bad, slot + 1, sizeof(int));
+  if (bad) { cpp_set_error("check_numerics: l_values / L / loss is not finite (naf_cartpole.py:242-245)"); return CPP_ERR_NUMERIC; }
+  return CPP_OK;
 }
 
 // ---- data-parallel learners: the halves of one minibatch of naf_cartpole.py:367-371 -------------------------

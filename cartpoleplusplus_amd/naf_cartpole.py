@@ -11,6 +11,7 @@ tf.check_numerics (:242-245) becomes a device flag: `train` raises FloatingPoint
 the loss is not finite.
 """
 import argparse
+import collections
 import os
 import ctypes as C
 import sys
@@ -168,6 +169,56 @@ class _HeadNetwork(base_network.Network):
         self._build_native(_lib.CPP_HEAD, head_out, max(int(opts.batch_size), 1), head_out=head_out, head_act=head_act)
 
 
+class DeferredLoss(object):
+    """the loss `naf.train(batch)` returns for a replay draw: a number that is fetched from the device when somebody looks at it
+    (float(), arithmetic, comparison, printing).  The reference's loop only appends the losses to a list and logs their mean
+    (naf_cartpole.py:369-371, :377): waiting for every minibatch's loss before launching the next would leave the GPU idle for a
+    host round trip per minibatch.  A non-finite minibatch (tf.check_numerics, :242-245) raises FloatingPointError when its loss is
+    looked at, and at the latest two train calls later; its optimiser step never ran (the device checks the flag itself)."""
+    __slots__ = ("_net", "_ticket", "_value", "_error", "__weakref__")
+
+    def __init__(self, net, ticket):
+        self._net, self._ticket, self._value, self._error = net, int(ticket), None, None
+
+    def resolve(self):
+        if self._value is None and self._error is None:
+            loss = C.c_float()
+            rc = lib.cpp_naf_loss_wait(self._net.handle, self._ticket, C.byref(loss))
+            self._value = float(loss.value)
+            if rc == 4:
+                self._error = FloatingPointError(lib.cpp_last_error().decode())
+            elif rc:
+                self._error = RuntimeError(lib.cpp_last_error().decode())
+        if self._error is not None:
+            raise self._error
+        return self._value
+
+    def __float__(self):
+        return self.resolve()
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self.resolve(), dtype=dtype or np.float32)
+
+    def __repr__(self):
+        return repr(self.resolve())
+
+    def __format__(self, spec):
+        return format(self.resolve(), spec)
+
+
+def _deferred_op(name):
+    def op(self, *args):
+        return getattr(self.resolve(), name)(*[float(a) if isinstance(a, DeferredLoss) else a for a in args])
+    op.__name__ = name
+    return op
+
+
+for _n in ("__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__", "__truediv__", "__rtruediv__", "__neg__", "__abs__",
+           "__lt__", "__le__", "__gt__", "__ge__", "__eq__", "__ne__", "__pow__", "__rpow__", "__bool__", "__int__", "__round__"):
+    setattr(DeferredLoss, _n, _deferred_op(_n))
+DeferredLoss.__hash__ = None
+
+
 class NafNetwork(base_network.Network):
     def __init__(self, namespace, input_state, input_state_2, value_net, target_value_net, action_dim):
         super(NafNetwork, self).__init__(namespace)
@@ -232,8 +283,15 @@ class NafNetwork(base_network.Network):
         loss = C.c_float()
         if isinstance(batch, replay_memory.Batch) and batch.in_replay():
             # a draw of the replay memory (naf_cartpole.py:367-371): the device samples those rows where they lie -- the B row
-            # indexes are all that crosses PCIe
-            rc = lib.cpp_naf_train_rows(self.handle, batch._memory.handle, len(batch.idxs), ptr(batch.idxs), C.byref(loss))
+            # indexes are all that crosses PCIe -- and nobody waits for the minibatch: the loss comes back when it is looked at
+            ticket = C.c_uint64()
+            check(lib.cpp_naf_train_rows_async(self.handle, batch._memory.handle, len(batch.idxs), ptr(batch.idxs), C.byref(ticket)))
+            out = DeferredLoss(self, ticket.value)
+            pending = self.__dict__.setdefault("_losses", collections.deque())
+            pending.append(out)
+            while len(pending) > 2:              # (a ticket stays readable for 8 calls; a numeric error surfaces two calls late at most)
+                pending.popleft().resolve()
+            return out
         else:
             dev = self._device_batch(batch)
             rc = lib.cpp_naf_train(self.handle, dev.handle, C.byref(loss))
@@ -274,6 +332,11 @@ class NafNetwork(base_network.Network):
         check(lib.cpp_naf_set_opt_state(self.handle, ptr(m), ptr(v), len(m), int(state["step"])))
 
     def close(self):
+        for d in self.__dict__.get("_losses", ()):
+            try:
+                d.resolve()
+            except Exception:       # noqa: BLE001 -- closing; the error was the caller's to look at
+                pass
         for b in self._upload.values():
             b.close()
         if self.handle:

@@ -196,6 +196,7 @@ class Batch(object):
         B = len(self.idxs)
         dev = rm._device_batch(B)
         if dev.owner() is not self:
+            dev.evict_owner()
             if self.in_replay():
                 check(lib.cpp_replay_sample(rm.handle, B, ptr(self.idxs), 0, 0, rm.channels, dev.handle))
             elif self._states is not None:
@@ -223,6 +224,14 @@ class DeviceBatch(object):
 
     def set_owner(self, batch):
         self._owner = weakref.ref(batch) if batch is not None else None
+
+    def evict_owner(self):
+        """the buffer is about to take another draw: if it is the ONLY copy of its current owner's states (a Batch preserved here when
+        the memory was written, never read), that Batch moves to the host first."""
+        o = self.owner()
+        if o is not None and o._states is None and not o.in_replay():
+            o._host_states()
+        self._owner = None
 
     @property
     def size(self):
@@ -445,7 +454,7 @@ class ReplayMemory(object):
             counter = self._adhoc_counter
             self._adhoc_counter += 1
         dev = self._device_batch(int(batch_size))
-        dev.set_owner(None)
+        dev.evict_owner()
         check(lib.cpp_replay_sample(self.handle, int(batch_size), None, int(seed), int(counter),
                                     self.channels, dev.handle))
         idxs = np.empty(int(batch_size), np.int32)

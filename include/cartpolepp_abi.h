@@ -322,6 +322,13 @@ int cpp_naf_train_step(cpp_naf* naf, cpp_replay* replay, int B, int n_batches, c
  * sample pass reading the replay store through those rows (no gathered copy).  *loss = the minibatch's loss; CPP_ERR_NUMERIC (the
  * optimiser does not run) when l_values, L or the loss is not finite, like cpp_naf_train.  No target update (:373 stays the caller's). */
 int cpp_naf_train_rows(cpp_naf* naf, cpp_replay* replay, int B, const int32_t* idxs, float* loss);
+/* The same minibatch without waiting for it: gradients and optimiser are enqueued (the optimiser kernel stands down by itself when
+ * the check_numerics flag is set), *ticket names the call.  cpp_naf_loss_wait(ticket, &loss) waits for THAT minibatch and returns
+ * its loss, or CPP_ERR_NUMERIC; a ticket stays readable until CPP_NAF_TICKETS later calls have been made.  The reference's
+ * `losses.append(naf.train(batch))` (naf_cartpole.py:369-371) only ever averages the losses for its STATS line. */
+#define CPP_NAF_TICKETS 8
+int cpp_naf_train_rows_async(cpp_naf* naf, cpp_replay* replay, int B, const int32_t* idxs, uint64_t* ticket);
+int cpp_naf_loss_wait(cpp_naf* naf, uint64_t ticket, float* loss);
 /* [0] loss of the last minibatch, [1] pre-clip global gradient norm, [2] non-finite flag (sticky). */
 int cpp_naf_last_stats(cpp_naf* naf, float out[3]);
 /* The optimiser's slot variables, which tf.train.Saver checkpoints with everything else (util.py:88-90): Momentum accumulators

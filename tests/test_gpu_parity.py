@@ -29,6 +29,7 @@ PIXEL_CASES = [
     pytest.param((24, 40, 3, 2, 2), 3, id="24x40x12-B3"),
 ]
 LOWDIM_CASE = pytest.param((2, 2, 7), 5, id="lowdim-28-B5-cfg1")
+LOWDIM_FULL = pytest.param((2, 2, 7), 256, id="lowdim-28-B256-cfg1-full-size")      # BASELINE configs[0] at its own batch size
 
 
 def _batch(rng, B, shape, pixel):
@@ -95,7 +96,7 @@ def test_gradients_dq_da_and_check_loss(shape, B):
         agent.close()
 
 
-@pytest.mark.parametrize("shape,B", PIXEL_CASES[:2] + PIXEL_CASES[3:4] + [LOWDIM_CASE])
+@pytest.mark.parametrize("shape,B", PIXEL_CASES[:2] + PIXEL_CASES[3:4] + [LOWDIM_CASE, LOWDIM_FULL])
 def test_train_ops_update_parameters_like_the_oracle(shape, B):
     """actor.train + critic.train + both target updates (ddpg_cartpole.py:331-337) vs the oracle."""
     pixel = len(shape) == 5
@@ -152,7 +153,7 @@ def _fill_pair(agent, oracle_rm, rng, shape, episodes, pixel=True):
         oracle_rm.add_episode(s0, seq)
 
 
-@pytest.mark.parametrize("shape,B", [PIXEL_CASES[0], PIXEL_CASES[3], LOWDIM_CASE])
+@pytest.mark.parametrize("shape,B", [PIXEL_CASES[0], PIXEL_CASES[3], LOWDIM_CASE, LOWDIM_FULL])
 def test_fused_train_step_matches_oracle_and_unfused_ops(shape, B):
     """cpp_ddpg_train_step with caller rows: replay gather + both updates x n_batches + target updates."""
     pixel = len(shape) == 5

@@ -203,3 +203,36 @@ def test_fair_lock_serves_in_arrival_order():
     ts = [threading.Thread(target=greedy), threading.Thread(target=occasional)]
     [t.start() for t in ts]; [t.join() for t in ts]
     assert order.count("R") == 5 and order.index("R") < 15 and "R" in order[:40]
+
+
+def test_deferred_naf_loss_behaves_like_the_float_the_reference_logs(monkeypatch):
+    """naf.train(batch) on a replay draw returns a DeferredLoss: resolved once, on first use; usable wherever the reference uses the
+    float (losses.append(...), np.mean(losses), json, formatting, comparisons); a check_numerics hit raises when looked at."""
+    import json
+    from cartpoleplusplus_amd import naf_cartpole as N
+
+    class FakeLib(object):
+        def __init__(self):
+            self.waits = []
+
+        def cpp_naf_loss_wait(self, handle, ticket, loss_ref):
+            self.waits.append(int(ticket))
+            loss_ref._obj.value = 0.5 * (int(ticket) + 1)
+            return 4 if int(ticket) == 7 else 0
+
+        def cpp_last_error(self):
+            return b"check_numerics: loss is not finite"
+    fake = FakeLib()
+    monkeypatch.setattr(N, "lib", fake)
+    net = type("Net", (), {"handle": "h"})()
+    losses = [N.DeferredLoss(net, t) for t in range(3)]
+    assert fake.waits == []                                   # nothing fetched yet
+    assert float(np.mean(losses)) == 1.0 and sorted(fake.waits) == [0, 1, 2]
+    assert float(losses[1]) == 1.0 and sorted(fake.waits) == [0, 1, 2]      # cached
+    assert losses[0] + 1 == 1.5 and 2 * losses[2] == 3.0 and losses[0] < losses[1] and "%.2f" % losses[2] == "1.50"
+    assert json.dumps({"mean_losses": float(np.mean(losses))}) == '{"mean_losses": 1.0}'
+    bad = N.DeferredLoss(net, 7)
+    with pytest.raises(FloatingPointError):
+        float(bad)
+    with pytest.raises(FloatingPointError):                   # and again: the error sticks to the minibatch
+        bad + 1
