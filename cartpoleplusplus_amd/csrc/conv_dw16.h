@@ -85,78 +85,10 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
   const int H = a.H, W = a.W, Hp = H >> 1, Wp = W >> 1, nout = a.nout;
   const int units = a.B * units_per_img;
 
-  // ---- zero the rings; the ones channel of the in-image pixels of every input slot (staging never touches it)
-  for (int i = tid; i < (int)(((G::IN_BYTES + 15) & ~15) + NNET * DYB) / 16; i += CONV_THREADS)
-    reinterpret_cast<float4*>(lds_raw)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
-  for (int i = tid; i < G::RING_IN * W; i += CONV_THREADS) {
-    const int s = i / W, x = i - s * W;
-    *reinterpret_cast<unsigned short*>(inring + s * ROWB + 2 * (CP * (x + P) + CIN)) = (unsigned short)0x3C00u;      // 1.0
-  }
-
   // (the epilogue's whitening scale / shift are requested here: in the epilogue the load was one more L2 round trip per workgroup)
   float wsc_s = 0.f, wsc_t = 0.f;
   if (tid < CIN) { wsc_s = a.scale[tid]; wsc_t = a.shift[tid]; }
-  // ---- 2^S: the largest |pooled gradient| among the pooled rows this workgroup's units touch lands in [2^14, 2^15) (per network)
-  float sc[NNET], inv[NNET];
-  {
-    float vmax[NNET];
-#pragma unroll
-    for (int k = 0; k < NNET; ++k) vmax[k] = 0.f;
-    for (int unit = bx; unit < units; unit += gx) {
-      const int b = unit / units_per_img;
-      const int q_lo = (unit - b * units_per_img) * band;
-      const int rows = min(band, H - q_lo);
-      if (DENSE) {
-        const int r0 = max(0, q_lo - P), r1 = min(H - 1, q_lo + rows - 1 + P);
-        const float* dp = a.dy_dense + (long)b * a.dy_dense_bstride;
-        const int e1 = (r1 + 1) * W * nout;
-        int e = r0 * W * nout + tid;
-        for (; e + 7 * CONV_THREADS < e1; e += 8 * CONV_THREADS) {      // 8 loads in flight (a 1-load loop pays the latency per trip)
-          float t[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) t[u] = dp[e + u * CONV_THREADS];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) vmax[0] = fmaxf(vmax[0], fabsf(t[u]));
-        }
-        for (; e < e1; e += CONV_THREADS) vmax[0] = fmaxf(vmax[0], fabsf(dp[e]));
-      } else {
-        const int py0 = max(0, (q_lo - P) >> 1), py1 = min(Hp - 1, (q_lo + rows - 1 + P) >> 1);
-        const int e1 = (py1 + 1) * Wp * nout;
-        // the rows come from another kernel's L2 (1.5-2 us a trip): 24 loads in flight per trip and network -- one trip for a half image
-        // of the headline shape -- through descriptors that end at e1 (reads past it return 0)
-        __amdgpu_buffer_rsrc_t rs[NNET];
-#pragma unroll
-        for (int k = 0; k < NNET; ++k)
-          rs[k] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(batch.a[by + k].dy.dpool + (long)b * batch.a[by + k].dy.dpool_bstride), 0, e1 * 4, 0x00020000);
-        for (int e = py0 * Wp * nout + tid; e < e1; e += 24 * CONV_THREADS) {
-          float t[NNET][24];
-#pragma unroll
-          for (int k = 0; k < NNET; ++k)
-#pragma unroll
-            for (int u = 0; u < 24; ++u) t[k][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs[k], (e + u * CONV_THREADS) * 4, 0, 0));
-#pragma unroll
-          for (int k = 0; k < NNET; ++k)
-#pragma unroll
-            for (int u = 0; u < 24; ++u) vmax[k] = fmaxf(vmax[k], fabsf(t[k][u]));
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < NNET; ++k) {
-      for (int o = 32; o > 0; o >>= 1) vmax[k] = fmaxf(vmax[k], __shfl_xor(vmax[k], o));
-      if (lane == 0) red[4 * k + wave] = vmax[k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NNET; ++k) {
-      const float vm = fmaxf(fmaxf(red[4 * k], red[4 * k + 1]), fmaxf(red[4 * k + 2], red[4 * k + 3]));
-      int S = 0;
-      if (vm > 0.f && vm < 3.0e38f) S = 14 - ilogbf(vm);
-      S = S > 100 ? 100 : (S < -100 ? -100 : S);
-      sc[k] = ldexpf(1.f, S); inv[k] = ldexpf(1.f, -S);
-    }
-  }
+  float sc[NNET], inv[NNET];                        // 2^S, 2^-S per network: set by the pre-scan below, once the first loads are in flight
 
   // ---- input row staging: raw dwords (two channels; odd CIN: single halves) of the f16 row -> pixel pitch CP
   unsigned sv[G::NVIN];
@@ -198,9 +130,10 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
   bool cact[NCELL], tact[NTASK];
   uint32_t cdst[NTASK];
   int cvo[NCELL];                                    // byte offset of the cell's f32 in a pooled row (pool / dpool; / 4: arg-max code)
-  float cg[NNET][NCELL], dbsum[NNET][NCELL];
-  unsigned short cpc[NNET][NCELL][NPC];
-  int ccode[NNET][NCELL];
+  float dbsum[NNET][NCELL];
+  // per task and network, for the pooled row in work: the three f16 pieces of its two cells packed (low half = cell 0), and for each
+  // (image-row parity ry, x parity s) the 32-bit mask that keeps a cell's half where its arg-max code is 2 ry + s
+  unsigned tpc[NNET][NTASK][NPC], tmask[NNET][NTASK][4];
 #pragma unroll
   for (int tk = 0; tk < NTASK; ++tk) {
     // task T: o fastest (neighbouring lanes load neighbouring floats), then the pair, the lane group, the chunk
@@ -218,11 +151,14 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
       cact[c] = tact[tk] && px < Wp;
       cvo[c] = cact[c] ? (px * nout + o) * 4 : 0;
 #pragma unroll
-      for (int k = 0; k < NNET; ++k) {
-        cg[k][c] = 0.f; ccode[k][c] = 0; dbsum[k][c] = 0.f;
+      for (int k = 0; k < NNET; ++k) dbsum[k][c] = 0.f;
+    }
 #pragma unroll
-        for (int pc = 0; pc < NPC; ++pc) cpc[k][c][pc] = 0;
-      }
+    for (int k = 0; k < NNET; ++k) {
+#pragma unroll
+      for (int pc = 0; pc < NPC; ++pc) tpc[k][tk][pc] = 0u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tmask[k][tk][q] = 0u;
     }
   }
   float rpv[NNET][3][NCELL], rdv[NNET][3][NCELL];   // (set 2: only the unit prologue, so that its three requests are in flight together)
@@ -247,18 +183,27 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
 #pragma unroll
     for (int k = 0; k < NNET; ++k)
 #pragma unroll
-      for (int c = 0; c < NCELL; ++c) {
-        cg[k][c] = rpv[k][set][c] > 0.f ? rdv[k][set][c] : 0.f;
-        ccode[k][c] = rcd[k][set][c];
-        if (count) dbsum[k][c] += cg[k][c];
-        const float v = cg[k][c] * sc[k];
-        const _Float16 h = (_Float16)v;
-        const float r1 = v - (float)h;
-        const _Float16 m = (_Float16)r1;
-        const _Float16 l = (_Float16)(r1 - (float)m);
-        cpc[k][c][0] = __builtin_bit_cast(unsigned short, h);
-        cpc[k][c][1] = __builtin_bit_cast(unsigned short, m);
-        cpc[k][c][2] = __builtin_bit_cast(unsigned short, l);
+      for (int tk = 0; tk < NTASK; ++tk) {
+        unsigned pk[2][NPC];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int c = 2 * tk + j;
+          const float g = rpv[k][set][c] > 0.f ? rdv[k][set][c] : 0.f;
+          if (count) dbsum[k][c] += g;
+          const float v = g * sc[k];
+          const _Float16 h = (_Float16)v;
+          const float r1 = v - (float)h;
+          const _Float16 m = (_Float16)r1;
+          const _Float16 l = (_Float16)(r1 - (float)m);
+          pk[j][0] = __builtin_bit_cast(unsigned short, h);
+          pk[j][1] = __builtin_bit_cast(unsigned short, m);
+          pk[j][2] = __builtin_bit_cast(unsigned short, l);
+        }
+#pragma unroll
+        for (int pc = 0; pc < NPC; ++pc) tpc[k][tk][pc] = pk[0][pc] | (pk[1][pc] << 16);
+        const int c0 = rcd[k][set][2 * tk], c1 = rcd[k][set][2 * tk + 1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tmask[k][tk][q] = (c0 == q ? 0x0000FFFFu : 0u) | (c1 == q ? 0xFFFF0000u : 0u);
       }
   };
   auto dy_store = [&](int slot, int ry) {            // image row with parity ry of the pooled row -> ring slot (of every network)
@@ -267,16 +212,11 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
 #pragma unroll
       for (int tk = 0; tk < NTASK; ++tk) {
         if (tact[tk]) {
-          const int c0 = 2 * tk, c1 = 2 * tk + 1;
 #pragma unroll
-          for (int s = 0; s < 2; ++s) {              // x parity: elements e and e + 4 of the 16-byte group
-            const bool on0 = ccode[k][c0] == 2 * ry + s, on1 = ccode[k][c1] == 2 * ry + s;
+          for (int s = 0; s < 2; ++s)                // x parity: elements e and e + 4 of the 16-byte group
 #pragma unroll
-            for (int pc = 0; pc < NPC; ++pc) {
-              const unsigned v = (on0 ? (unsigned)cpc[k][c0][pc] : 0u) | ((on1 ? (unsigned)cpc[k][c1][pc] : 0u) << 16);
-              lds_store(cdst[tk], k * DYB + slot * DSLOT + pc * G::DPC + 8 * s, v);
-            }
-          }
+            for (int pc = 0; pc < NPC; ++pc)
+              lds_store(cdst[tk], k * DYB + slot * DSLOT + pc * G::DPC + 8 * s, tpc[k][tk][pc] & tmask[k][tk][2 * ry + s]);
         }
       }
   };
@@ -336,6 +276,106 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[k][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // ---- per-unit state and the requests a unit opens with
+  int ub = 0, q_lo = 0, rows = 0, y0 = 0;
+  __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, 0, 0x00020000);
+  auto unit_begin = [&](int unit) {
+    ub = unit / units_per_img;
+    q_lo = (unit - ub * units_per_img) * band;
+    rows = min(band, H - q_lo);                        // band and q_lo are even
+    in_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__half*>((const __half*)a.in + (long)(a.img_slot ? a.img_slot[ub] : ub) * a.in_bstride), 0, H * rowbytes, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < NNET; ++k) {
+      const ConvArgs& ak = batch.a[by + k];
+      rp[k] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ak.dy.pool + (long)ub * ak.dy.pool_bstride), 0, Hp * Wp * nout * 4, 0x00020000);
+      rd[k] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ak.dy.dpool + (long)ub * ak.dy.dpool_bstride), 0, Hp * Wp * nout * 4, 0x00020000);
+      rc[k] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(ak.dy.amax + (long)ub * Hp * Wp * nout), 0, Hp * Wp * nout, 0x00020000);
+    }
+    y0 = q_lo - P;                                     // position d of the band's stream <-> image row q_lo - P + d (conv_dw_kyo.h)
+  };
+  // (the first two input rows and the first three pooled dY rows are requested together: one L2 round trip, not five)
+  auto unit_requests = [&]() {
+    if (0 < rows) in_load(in_rs, q_lo);
+    if (1 < rows) in_load_to(sv2, in_rs, q_lo + 1);
+    dy_issue(y0 >> 1, 0);
+    dy_issue((y0 >> 1) + 1, 1);
+    dy_issue((y0 >> 1) + 2, 2);
+  };
+  // The workgroup's first unit sends its requests NOW, in front of the set-up below (ring zeroing, scale pre-scan, two barriers:
+  // 5 us by the in-kernel clock): the unit prologue used to wait a full round trip (4 us) for them after the set-up.
+  bool primed = false;
+  if (!DENSE && bx < units) { unit_begin(bx); unit_requests(); primed = true; }
+
+  // ---- zero the rings; the ones channel of the in-image pixels of every input slot (staging never touches it)
+  for (int i = tid; i < (int)(((G::IN_BYTES + 15) & ~15) + NNET * DYB) / 16; i += CONV_THREADS)
+    reinterpret_cast<float4*>(lds_raw)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  for (int i = tid; i < G::RING_IN * W; i += CONV_THREADS) {
+    const int s = i / W, x = i - s * W;
+    *reinterpret_cast<unsigned short*>(inring + s * ROWB + 2 * (CP * (x + P) + CIN)) = (unsigned short)0x3C00u;      // 1.0
+  }
+
+  // ---- 2^S: the largest |pooled gradient| among the pooled rows this workgroup's units touch lands in [2^14, 2^15) (per network)
+  {
+    float vmax[NNET];
+#pragma unroll
+    for (int k = 0; k < NNET; ++k) vmax[k] = 0.f;
+    for (int unit = bx; unit < units; unit += gx) {
+      const int b = unit / units_per_img;
+      const int q_lo = (unit - b * units_per_img) * band;
+      const int rows = min(band, H - q_lo);
+      if (DENSE) {
+        const int r0 = max(0, q_lo - P), r1 = min(H - 1, q_lo + rows - 1 + P);
+        const float* dp = a.dy_dense + (long)b * a.dy_dense_bstride;
+        const int e1 = (r1 + 1) * W * nout;
+        int e = r0 * W * nout + tid;
+        for (; e + 7 * CONV_THREADS < e1; e += 8 * CONV_THREADS) {      // 8 loads in flight (a 1-load loop pays the latency per trip)
+          float t[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t[u] = dp[e + u * CONV_THREADS];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) vmax[0] = fmaxf(vmax[0], fabsf(t[u]));
+        }
+        for (; e < e1; e += CONV_THREADS) vmax[0] = fmaxf(vmax[0], fabsf(dp[e]));
+      } else {
+        const int py0 = max(0, (q_lo - P) >> 1), py1 = min(Hp - 1, (q_lo + rows - 1 + P) >> 1);
+        const int e1 = (py1 + 1) * Wp * nout;
+        // the rows come from another kernel's L2 (1.5-2 us a trip): 24 loads in flight per trip and network -- one trip for a half image
+        // of the headline shape -- through descriptors that end at e1 (reads past it return 0)
+        __amdgpu_buffer_rsrc_t rs[NNET];
+#pragma unroll
+        for (int k = 0; k < NNET; ++k)
+          rs[k] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(batch.a[by + k].dy.dpool + (long)b * batch.a[by + k].dy.dpool_bstride), 0, e1 * 4, 0x00020000);
+        for (int e = py0 * Wp * nout + tid; e < e1; e += 24 * CONV_THREADS) {
+          float t[NNET][24];
+#pragma unroll
+          for (int k = 0; k < NNET; ++k)
+#pragma unroll
+            for (int u = 0; u < 24; ++u) t[k][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs[k], (e + u * CONV_THREADS) * 4, 0, 0));
+#pragma unroll
+          for (int k = 0; k < NNET; ++k)
+#pragma unroll
+            for (int u = 0; u < 24; ++u) vmax[k] = fmaxf(vmax[k], fabsf(t[k][u]));
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NNET; ++k) {
+      for (int o = 32; o > 0; o >>= 1) vmax[k] = fmaxf(vmax[k], __shfl_xor(vmax[k], o));
+      if (lane == 0) red[4 * k + wave] = vmax[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NNET; ++k) {
+      const float vm = fmaxf(fmaxf(red[4 * k], red[4 * k + 1]), fmaxf(red[4 * k + 2], red[4 * k + 3]));
+      int S = 0;
+      if (vm > 0.f && vm < 3.0e38f) S = 14 - ilogbf(vm);
+      S = S > 100 ? 100 : (S < -100 ? -100 : S);
+      sc[k] = ldexpf(1.f, S); inv[k] = ldexpf(1.f, -S);
+    }
+  }
+
   __syncthreads();
 #ifdef DW16_CLOCK
   const unsigned long long ce1 = __builtin_amdgcn_s_memrealtime();
@@ -345,20 +385,9 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
 #ifdef DW16_CLOCK
     const unsigned long long cu0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    const int b = unit / units_per_img;
-    const int q_lo = (unit - b * units_per_img) * band;
-    const int rows = min(band, H - q_lo);            // band and q_lo are even
-    const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<__half*>((const __half*)a.in + (long)(a.img_slot ? a.img_slot[b] : b) * a.in_bstride), 0, H * rowbytes, 0x00020000);
-#pragma unroll
-    for (int k = 0; k < NNET; ++k) {
-      const ConvArgs& ak = batch.a[by + k];
-      rp[k] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ak.dy.pool + (long)b * ak.dy.pool_bstride), 0, Hp * Wp * nout * 4, 0x00020000);
-      rd[k] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ak.dy.dpool + (long)b * ak.dy.dpool_bstride), 0, Hp * Wp * nout * 4, 0x00020000);
-      rc[k] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(ak.dy.amax + (long)b * Hp * Wp * nout), 0, Hp * Wp * nout, 0x00020000);
-    }
-    // position d of the band's stream <-> image row q_lo - P + d (conv_dw_kyo.h)
-    const int y0 = q_lo - P;
+    if (!primed) { unit_begin(unit); if (!DENSE) unit_requests(); }
+    primed = false;
+    const int b = ub;
     auto in_band = [&](int y) { return y >= q_lo && y < q_lo + rows; };
     const __amdgpu_buffer_rsrc_t rdense = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(DENSE ? a.dy_dense + (long)b * a.dy_dense_bstride : a.dy.dpool), 0, DENSE ? H * W * nout * 4 : 0, 0x00020000);
@@ -369,12 +398,6 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
         if (d - P < rows) { in_load(in_rs, y0 + d); in_store(d % G::RING_IN); }
       if (2 < rows) in_load(in_rs, q_lo + 2);
     } else {
-    // (the first two input rows are requested together: one L2 round trip, not two -- in-kernel clock: the prologue was 4 us)
-    if (0 < rows) in_load(in_rs, q_lo);
-    if (1 < rows) in_load_to(sv2, in_rs, q_lo + 1);
-    dy_issue(y0 >> 1, 0);
-    dy_issue((y0 >> 1) + 1, 1);
-    dy_issue((y0 >> 1) + 2, 2);
     if (0 < rows) in_store(P % G::RING_IN);
     if (2 < rows) in_load(in_rs, q_lo + 2);
     dy_conv(0, in_band(y0));
