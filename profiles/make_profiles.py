@@ -31,7 +31,9 @@ SHORT = [("void conv_fwd_kernel<18, 5, 4, 0, 0>", "conv1_fwd"), ("void conv_dw_k
          # bf16 pipes (conv2), whole-image conv3 forward, the fused heads, and the launches that carry two kernels
          ("void conv_fwd_k16_kernel<10, 5", "conv2_fwd"), ("void conv_dwb16_kernel<10, 5", "conv2_dw"), ("conv3_img_kernel", "conv3_fwd"),
          ("void ddpg_heads_kernel", "heads"), ("conv3_bwd_pair_kernel", "conv3_bwd"), ("conv2_bwd_pair_kernel", "conv2_bwd"),
-         ("void reduce_gather_kernel<__half>", "reduce_gather"), ("conv1_dw_gather_kernel", "conv1_dw_gather")]
+         ("void reduce_gather_kernel<__half>", "reduce_gather"), ("conv1_dw_gather_kernel", "conv1_dw_gather"),
+         # round 3: two networks per conv1-dW workgroup (conv_dw16.h NNET = 2)
+         ("conv1_dw_pair_gather_kernel", "conv1_dw_gather"), ("void conv_dw16_pair_kernel<18, 5", "conv1_dw_f16x3")]
 
 
 def short(name):
@@ -103,7 +105,9 @@ def main(rnd):
                 "launch computes conv1 of all four networks of a minibatch (blockIdx.y = network); likewise conv2/conv3 forward;\n"
                 "the dW / dX launches carry the actor and the critic together -- conv2's and conv3's dW and dX share one launch each\n"
                 "(`conv2_bwd_pair_kernel`, `conv3_bwd_pair_kernel`), and conv1's dW shares its launch with the next minibatch's\n"
-                "sample + statistics pass (`conv1_dw_gather_kernel`; `conv_dw16_kernel` alone closes each 5-minibatch graph).\n\n")
+                "sample pass (`conv1_dw_gather_kernel`, from round 3 `conv1_dw_pair_gather_kernel`: one workgroup serves the actor AND the\n"
+                "critic, and the sample pass copies the store's per-state sums instead of reading pixels; `conv_dw16_kernel` /\n"
+                "`conv_dw16_pair_kernel` alone closes each 5-minibatch graph).\n\n")
         f.write("| kernel | calls | total us | avg us | % |\n|---|---|---|---|---|\n")
         for name, calls, tot, avg, pct in rows:
             f.write("| `%s` | %d | %.1f | %.3f | %.2f |\n" % (name, calls, tot, avg, pct))

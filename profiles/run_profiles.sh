@@ -5,7 +5,7 @@
 # other BASELINE configs (cfg2, cfg4 = NAF, cfg5 with 6000 rows and with one GPU's 125 000-row u8 shard, r50, batch norm).
 # Outputs under gpurun_out/; profiles/make_profiles.py turns them into the committed summaries.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 python bench.py > $OUT/bench_$R.json 2> $OUT/bench_$R.err
@@ -32,6 +32,9 @@ run_cfg cfg5_shard --workload cfg5 --steps 30 --warmup 10 --replay-rows 125000 -
 run_cfg r50 --workload r50 --steps 100 --warmup 10
 run_cfg cfg3_bn --workload cfg3 --steps 50 --warmup 10 --use-batch-norm
 run_cfg cfg3_dp1 --workload cfg3 --steps 100 --warmup 10 --force-dp
+# the reference's literal loop against the fused step (profiles/bench_host_path.py), and N = 2 as a plain command (gloo diagnostic)
+bash $REPO/profiles/run_host_path.sh > /dev/null 2>&1
+(cd $REPO && timeout 600 python bench.py --gpus 2 --diag-backend gloo --quick --steps 20 --warmup 5 > $OUT/bench_${R}_gpus2_gloo_diag.json 2> $OUT/bench_${R}_gpus2_gloo_diag.err)
 # keep the merge-back small: only the databases
 find $OUT/prof_${R}* $OUT/pmc_${R}_* -type f ! -name '*.db' -delete 2>/dev/null
 ls $OUT | grep $R | head -40
