@@ -44,8 +44,10 @@ void prof_begin(cpp_ctx* ctx) {
 }
 void prof_end(cpp_ctx* ctx, int kid) {
   if (!ctx->prof) return;
-  if (ctx->pair && ((ctx->pair->layer == 2 && (kid == K_CONV3_DW || kid == K_CONV3_DX)) ||
-                    (ctx->pair->layer == 1 && (kid == K_CONV2_DW || kid == K_CONV2_DX)))) return;      // parked, not launched (conv*_bwd_pair.hip)
+  // a dW / dX that its launcher parked in the open pair slot was not launched (conv*_bwd_pair.hip times the joint launch); one that the
+  // slot did not take -- a geometry without a pair instance: cfg5's 64x64 conv2, the 25x25 conv2 of the 50x50 render -- was, and counts
+  if (ctx->pair && (((kid == K_CONV3_DW || kid == K_CONV2_DW) && ctx->pair->have_dw) ||
+                    ((kid == K_CONV3_DX || kid == K_CONV2_DX) && ctx->pair->have_dx))) return;
   (void)hipEventRecord(ctx->pe1, ctx->stream);
   (void)hipEventSynchronize(ctx->pe1);
   float ms = 0.f;
