@@ -1,9 +1,32 @@
 // conv1 forward on the f16 matrix pipes with f32-exact operands (conv_k16.h): instantiations + geometry selection.
+#include <cstdlib>
 #include "conv_k16.h"
+
+// Two bands of output rows per image when whole images would leave half of the workgroup slots empty (NAF's two trunks, a single
+// network's forward): the first band's height r0 is even (pool pairs) with r0 - 2 a multiple of 5 (the band's row walk starts two
+// input rows early and must start on the unrolled loop's period), as close to H / 2 as that allows.  0: no such height.
+static int k16_band_rows(int H) {
+  int best = 0;
+  for (int r0 = 2; r0 < H; r0 += 2)
+    if ((r0 - 2) % 5 == 0 && (best == 0 || abs(2 * r0 - H) < abs(2 * best - H))) best = r0;
+  return (best >= 8 && H - best >= 8) ? best : 0;
+}
+static ConvArgsN k16_with_bands(cpp_ctx* ctx, const ConvArgsN& a, int ipw) {
+  static const bool no_bands = cpp_switch_off("CPP_CONV_BANDS");
+  ConvArgsN b = a;
+  for (int i = 0; i < b.n; ++i) { b.a[i].nbands = 0; b.a[i].band_rows = 0; }
+  if (!ctx || no_bands || a.a[0].H < 32) return b;
+  const int wgs = a.n * ((a.a[0].B + ipw - 1) / ipw);
+  for (int i = 0; i < a.n; ++i) if (a.a[i].n3_w) return b;          // conv3 rides in this launch: whole images per workgroup
+  const int r0 = k16_band_rows(a.a[0].H);
+  if (wgs > ctx->num_cus || r0 == 0) return b;
+  for (int i = 0; i < b.n; ++i) { b.a[i].nbands = 2; b.a[i].band_rows = r0; }
+  return b;
+}
 
 #define K16_CASE(CIN_, XT_, IPW_, PLAIN_)                                                                    \
   if (cin == CIN_ && xt == XT_ && ipw == IPW_ && plain == PLAIN_) { *handled = true; if (!ctx) return 0;      \
-    return conv_fwd_k16_launch_t<CIN_, 5, XT_, IPW_, PLAIN_>(ctx, a); }
+    return conv_fwd_k16_launch_t<CIN_, 5, XT_, IPW_, PLAIN_>(ctx, k16_with_bands(ctx, a, IPW_)); }
 
 int conv_fwd_k16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool plain, const ConvArgsN& a, bool* handled) {
   *handled = false;
@@ -24,7 +47,7 @@ int conv_fwd_k16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool plain
 
 #define KB16_CASE(XT_, IPW_)                                                                                 \
   if (xt == XT_ && ipw == IPW_) { *handled = true; if (!ctx) return 0;                                       \
-    return conv_fwd_k16_launch_t<10, 5, XT_, IPW_, false, true>(ctx, a); }
+    return conv_fwd_k16_launch_t<10, 5, XT_, IPW_, false, true>(ctx, k16_with_bands(ctx, a, IPW_)); }
 
 int conv_fwd_kb16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArgsN& a, bool* handled) {
   *handled = false;

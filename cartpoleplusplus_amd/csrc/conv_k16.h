@@ -146,8 +146,16 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lj = lane >> 4;
   const int strip = wave % G::STRIPS;
-  const int b0 = blockIdx.x * IPW;
+  // bands of output rows (launcher: a.nbands = 2 when a launch would leave half of the workgroup slots empty): band k of an image
+  // computes output rows [k band_rows, (k + 1) band_rows); its row walk starts P input rows earlier -- band_rows - P is a multiple of KS,
+  // so the unrolled loop's static ring positions hold -- and the output rows in front of the band complete as partial sums and are dropped
+  const int nbands = a.nbands > 1 ? a.nbands : 1;
+  const int band = (int)blockIdx.x % nbands;
+  const int b0 = ((int)blockIdx.x / nbands) * IPW;
   const int H = a.H, W = a.W, Hp = H >> 1, Wp = W >> 1, nout = a.nout;
+  const int ymin = band * a.band_rows;                                  // first output row of the band (0 without bands)
+  const int qbeg = band > 0 ? ymin - P : 0;                             // first input row walked (a multiple of KS)
+  const int qend = (nbands > 1 && band + 1 < nbands ? ymin + a.band_rows : H) + P;      // one past the last step
 
   // (the accumulators' bias is requested with the weights: after the weight image it was one more L2 round trip, ~1 us, in-kernel clock)
   float braw[NT];
@@ -372,7 +380,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     for (int t = 0; t < NT; ++t) acc[m][t] = (f32x4){biast[t], biast[t], biast[t], biast[t]};
 
 #pragma unroll
-  for (int ch = 0; ch < NCH; ++ch) load_a(ch, 0);
+  for (int ch = 0; ch < NCH; ++ch) load_a(ch, qbeg);
   const __amdgpu_buffer_rsrc_t null_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0, 0x00020000);      // empty range: stores are dropped
   if (ASYNC_A) {                                      // row 0 sees the same sequence as every other row: its loads, then ST stores
 #pragma unroll
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   const unsigned long long pc0 = __builtin_readcyclecounter(), pr0 = __builtin_amdgcn_s_memrealtime();
 #endif
   const bool wr_f32 = PLAIN || a.out != nullptr, wr_code = a.out_amax != nullptr;     // target networks of the fused step: bf16 planes only
-  for (int q0 = 0; q0 < H + P; q0 += KS) {
+  for (int q0 = qbeg; q0 < qend; q0 += KS) {
 #if K16_ROTATE_PRIO
     {  // issue arbitration is by priority, then age: the workgroups of the networks launched first ran ahead of their co-resident
        // partners (in-kernel span probe: 104 vs 125 us of a 119 us launch, 50 vs 67 us for conv2) and the younger ones finished
@@ -414,7 +422,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #pragma unroll
     for (int sq = 0; sq < KS; ++sq) {
       const int q = q0 + sq;
-      if (q >= H + P) break;                         // uniform
+      if (q >= qend) break;                          // uniform
       constexpr int PD_BASE = (KS - P) % KS;
       const int pdone = (PD_BASE + sq) % KS;
       if (q < H) {
@@ -483,7 +491,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #ifdef K16_ABL_NOEPI
       const int y = (q == H + P - 1) ? q - P : -1;
 #else
-      const int y = q - P;
+      const int y = q - P >= ymin ? q - P : -1;      // (rows in front of the band: partial sums, dropped like the rows above the image)
 #endif
       const int par = y & 1;
 #pragma unroll
@@ -595,7 +603,7 @@ static inline int conv_fwd_k16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_done[cpp_dev_slot(ctx)] = true;
   }
-  const int grid = (a.B + IPW - 1) / IPW;
+  const int grid = ((a.B + IPW - 1) / IPW) * (a.nbands > 1 ? a.nbands : 1);
   hipLaunchKernelGGL(kern, dim3(grid, batch.n), dim3(CONV_THREADS), lds_bytes, ctx->stream, batch);
   LAUNCH_CHECK();
   return 0;
