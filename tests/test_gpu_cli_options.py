@@ -19,10 +19,13 @@ CASES = [
     ("naf", PIXELS + ["--optimiser", "Adam", "--optimiser-args", '{"learning_rate": 0.001}', "--share-input-state-representation"]),
     ("naf", PIXELS + ["--use-batch-norm"]),
     ("naf", PIXELS + ["--host-rng-sampling"]),
+    ("ddpg", PIXELS + ["--async-rollouts"]),                          # episodes on a rollout thread, the learner trains back to back
+    ("naf", PIXELS + ["--async-rollouts", "--data-parallel"]),        # ... as one learner of a world of one (RCCL agreement per iteration)
 ]
 
 
-@pytest.mark.parametrize("which,args", CASES, ids=["ddpg-host-rng", "ddpg-u8-bn", "ddpg-dropout", "ddpg-lowdim", "naf-adam-shared", "naf-bn", "naf-host-rng"])
+@pytest.mark.parametrize("which,args", CASES, ids=["ddpg-host-rng", "ddpg-u8-bn", "ddpg-dropout", "ddpg-lowdim", "naf-adam-shared", "naf-bn", "naf-host-rng",
+                              "ddpg-async-rollouts", "naf-async-rollouts-dp1"])
 def test_cli_runs_and_trains(which, args, capsys):
     if which == "ddpg":
         from cartpoleplusplus_amd import ddpg_cartpole as M
@@ -33,6 +36,8 @@ def test_cli_runs_and_trains(which, args, capsys):
     stats = [json.loads(l.split("\t", 1)[1]) for l in out.splitlines() if l.startswith("STATS")]
     assert len(stats) >= 4 and any(np.isfinite(s["mean_losses"]) for s in stats), out[-400:]
     assert stats[-1]["replay_memory_stats"][">add"] >= 60
+    if "--async-rollouts" in args:       # the learner did not wait for episodes: more train calls than STATS lines since burn-in
+        assert stats[-1]["train_calls"] >= len([s for s in stats if np.isfinite(s["mean_losses"])])
 
 
 def test_record_an_event_log_then_train_from_it_offline(tmp_path, capsys):
