@@ -335,3 +335,18 @@ def test_two_network_conv1_dw_workgroups_give_the_single_network_kernels_bits():
         seen[pair] = re.findall(r"PAIRDW (\S+) (\S+)", out)
         assert r.returncode == 0 and len(seen[pair]) == 4, out[-1500:]
     assert seen["1"] == seen["0"], seen
+
+
+def test_two_network_conv1_forward_workgroups_give_the_single_network_kernels_bits():
+    """conv_k16_pair.h (actor + critic, and the two targets, per workgroup: 100 of 112 columns, one A operand for both) accumulates
+    every output in the order of the one-network kernel (CPP_K16_PAIR=0): whole train steps must agree bit for bit."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = {}
+    for pair in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", _PAIR_DW_SNIPPET], cwd=root, env=dict(os.environ, CARTPOLEPP_ABLATION="1", CPP_K16_PAIR=pair),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        out = r.stdout.decode()
+        seen[pair] = re.findall(r"PAIRDW (\S+) (\S+)", out)
+        assert r.returncode == 0 and len(seen[pair]) == 4, out[-1500:]
+    assert seen["1"] == seen["0"], seen
