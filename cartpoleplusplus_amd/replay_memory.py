@@ -165,6 +165,8 @@ class Batch(object):
         return self._states
 
     def __getattr__(self, name):
+        if name.startswith("_"):                  # (never resolve private names here: copy / pickle probe them before __init__ ran)
+            raise AttributeError(name)
         if name in ("state_1", "state_2"):
             if self._states is not None:
                 return self._states[name]
