@@ -55,6 +55,9 @@ struct Dw16Geom {
 #ifndef DW16_WGS
 #define DW16_WGS 3
 #endif
+#ifndef DW16_CAP
+#define DW16_CAP 4
+#endif
 
 // DENSE: dY comes as dense f32 rows (a.dy_dense: batch norm's dz) instead of being rebuilt from the pooled gradient
 // (bx, by, gx): the workgroup's place in a (gx, networks) grid (its own launch, or a slice of a shared one: conv1_dw_gather.hip)

@@ -15,11 +15,20 @@ int conv_dw16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool dense, c
     if (((uintptr_t)a.a[i].in & 3) || (a.a[i].in_bstride & 1)) return 0;        // dword row staging
   }
   const int nchk = W > 64 ? 4 : (W > 32 ? 2 : 1);
-  // the actor's and the critic's conv1 dW of one minibatch: one workgroup per image band serves both (CPP_DW16_PAIR=0: one each)
+  // the actor's and the critic's conv1 dW of one minibatch: one workgroup per image band serves both (CPP_DW16_PAIR=0: one each) --
+  // where that was measured to pay: 18 channels at two chunks per row, and enough bands that the joint launch still puts two
+  // workgroups on every CU (cfg3: 79 vs 83 us; the 50x50 render has 256 whole-image units: 82 vs 62 us; 9 channels: 57 vs 49 us --
+  // profiles/experiments/r03_pairs.txt)
   static const bool no_pair = cpp_switch_off("CPP_DW16_PAIR");
-  if (!no_pair && !dense && ctx && conv_dw16_pairable(a)) {
-    const int rc = conv_dw16_pair_dispatch(ctx, cin, nchk, a, grid, handled);
-    if (*handled) return rc;
+  if (!no_pair && !dense && ctx && cin == 18 && nchk == 2 && conv_dw16_pairable(a)) {
+    const int capacity = ctx->num_cus * DW16_CAP / a.n;
+    int band = (H + 1) & ~1;
+    while (a.a[0].B * ((H + band - 1) / band) < capacity && band > 8 && (band / 2) % 2 == 0) band /= 2;
+    const int units = a.a[0].B * ((H + band - 1) / band);
+    if ((units < capacity ? units : capacity) >= 2 * ctx->num_cus) {
+      const int rc = conv_dw16_pair_dispatch(ctx, cin, nchk, a, grid, handled);
+      if (*handled) return rc;
+    }
   }
   DW16_CASE_DENSE(18, 2) DW16_CASE_DENSE(6, 2) DW16_CASE_DENSE(12, 2)
   DW16_CASE(18, 2) DW16_CASE(18, 1) DW16_CASE(6, 2) DW16_CASE(6, 1) DW16_CASE(12, 2) DW16_CASE(30, 4) DW16_CASE(18, 4) DW16_CASE(9, 2) DW16_CASE(9, 1) DW16_CASE(3, 2) DW16_CASE(3, 1)
