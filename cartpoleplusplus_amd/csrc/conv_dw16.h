@@ -619,9 +619,23 @@ static inline int conv_dw16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int* 
 #ifndef DW16_CAP
 #define DW16_CAP 4
 #endif
-  const int capacity = ctx->num_cus * DW16_CAP / batch.n;   // <= conv_dw_kyo_grid: the partial buffers are sized for that
+  // Units = (image, band of rows).  The bands are as short as ONE resident round of workgroups allows: a second, partial round runs
+  // with the pipes half empty (cfg3 one-network: 1024 workgroups on 768 slots 81.3 us, 512 on 512 76.6 us; NAF's single trunk 51.8 ->
+  // 47.1 us), fewer, longer units waste slots (9 channels fit four workgroups per CU: 1024 units 51.1 us, 512 units 61.0 us --
+  // profiles/experiments/r03_dw16_cap_sweep.txt).  Slots per CU: what the runtime says for this instance and its LDS.
+  static int wgs_per_cu[CPP_MAX_DEVICES] = {};
+  if (wgs_per_cu[cpp_dev_slot(ctx)] == 0) {
+    int nb = 0;
+    hipError_t oe;
+    if constexpr (PAIR) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_dw16_pair_kernel<CIN, KS, NCHK>, CONV_THREADS, lds_bytes);
+    else oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_dw16_kernel<CIN, KS, NCHK, DENSE>, CONV_THREADS, lds_bytes);
+    wgs_per_cu[cpp_dev_slot(ctx)] = (oe == hipSuccess && nb >= 1) ? (nb > DW16_CAP ? DW16_CAP : nb) : 2;
+    (void)hipGetLastError();
+  }
+  const int launches = PAIR ? batch.n / 2 : batch.n;          // grid rows
+  const int capacity = ctx->num_cus * wgs_per_cu[cpp_dev_slot(ctx)] / launches;   // <= num_cus * 4 / n: the partial buffers are sized for that
   int band = (a.H + 1) & ~1;
-  while (a.B * ((a.H + band - 1) / band) < capacity && band > 8 && (band / 2) % 2 == 0) band /= 2;
+  while (band > 8 && (band / 2) % 2 == 0 && a.B * ((a.H + band / 2 - 1) / (band / 2)) <= capacity) band /= 2;
   const int upi = (a.H + band - 1) / band;
   const int units = a.B * upi;
   const int grid = units < capacity ? units : capacity;

@@ -21,11 +21,12 @@ int conv_dw16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool dense, c
   // profiles/experiments/r03_pairs.txt)
   static const bool no_pair = cpp_switch_off("CPP_DW16_PAIR");
   if (!no_pair && !dense && ctx && cin == 18 && nchk == 2 && conv_dw16_pairable(a)) {
-    const int capacity = ctx->num_cus * DW16_CAP / a.n;
+    // (the pair kernel runs two workgroups per CU; its bands are chosen by the same one-round rule in conv_dw16_launch_t)
+    const int capacity = ctx->num_cus * 2 / (a.n / 2);
     int band = (H + 1) & ~1;
-    while (a.a[0].B * ((H + band - 1) / band) < capacity && band > 8 && (band / 2) % 2 == 0) band /= 2;
+    while (band > 8 && (band / 2) % 2 == 0 && a.a[0].B * ((H + band / 2 - 1) / (band / 2)) <= capacity) band /= 2;
     const int units = a.a[0].B * ((H + band - 1) / band);
-    if ((units < capacity ? units : capacity) >= 2 * ctx->num_cus) {
+    if (units >= 2 * ctx->num_cus) {
       const int rc = conv_dw16_pair_dispatch(ctx, cin, nchk, a, grid, handled);
       if (*handled) return rc;
     }
