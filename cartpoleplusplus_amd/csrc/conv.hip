@@ -138,8 +138,11 @@ int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, i
     static const bool no_bands = cpp_switch_off("CPP_CONV_BANDS");
     const int ipw = a.W > 32 ? 1 : (a.W > 16 ? 2 : 4);
     const int wgs = n * ((a.B + ipw - 1) / ipw);
-    if (!no_bands && wgs <= ctx->num_cus && a.H >= 16 && (a.H % 4) == 0 && (in_mode == IN_F32_PLAIN || in_mode == IN_DY))
-      for (int i = 0; i < n; ++i) { batch.a[i].nbands = 2; batch.a[i].band_rows = a.H / 2; }
+    static const int nb_want = cpp_switch_int("CPP_CONV_NBANDS", 2);
+    if (!no_bands && wgs <= ctx->num_cus && a.H >= 16 && (a.H % 4) == 0 && (in_mode == IN_F32_PLAIN || in_mode == IN_DY)) {
+      const int nb = (nb_want == 4 && (a.H % 8) == 0 && a.H >= 32) ? 4 : 2;
+      for (int i = 0; i < n; ++i) { batch.a[i].nbands = nb; batch.a[i].band_rows = a.H / nb; }
+    }
     bool handled = false;
     rc = plain_fwd ? conv_fwd_kyo_dispatch_plain(ctx, cin, ks, in_mode, chb, batch, &handled)
        : (in_mode == IN_F32_PLAIN || dx_mode) ? conv_fwd_kyo_dispatch_l23(ctx, cin, ks, in_mode, chb, batch, &handled)

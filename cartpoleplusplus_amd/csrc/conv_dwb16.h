@@ -295,6 +295,9 @@ __global__ __launch_bounds__(CONV_THREADS, 3) void conv_dwb16_kernel(const ConvA
   conv_dwb16_body<CIN, KS, NCHK>(batch, units_per_img, band, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
+#ifndef DWB16_CAP
+#define DWB16_CAP 4
+#endif
 template <int CIN, int KS, int NCHK>
 static inline int conv_dwb16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int* grid_out) {
   typedef Dwb16Geom<CIN, KS, NCHK> G;
@@ -306,9 +309,10 @@ static inline int conv_dwb16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int*
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_done[cpp_dev_slot(ctx)] = true;
   }
-  const int capacity = ctx->num_cus * 4 / batch.n;   // <= conv_dw_kyo_grid: the partial buffers are sized for that
+  static const int cap = cpp_switch_int("CPP_DWB16_CAP", DWB16_CAP);      // resident workgroups per CU the bands are chosen for
+  const int capacity = ctx->num_cus * cap / batch.n;   // <= conv_dw_kyo_grid (4 per CU): the partial buffers are sized for that
   int band = (a.H + 1) & ~1;
-  while (a.B * ((a.H + band - 1) / band) < capacity && band > 8 && (band / 2) % 2 == 0) band /= 2;
+  while (band > 8 && (band / 2) % 2 == 0 && a.B * ((a.H + band / 2 - 1) / (band / 2)) <= capacity) band /= 2;
   const int upi = (a.H + band - 1) / band;
   const int units = a.B * upi;
   const int grid = units < capacity ? units : capacity;
