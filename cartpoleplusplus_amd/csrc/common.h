@@ -156,6 +156,9 @@ int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, co
 int launch_conv_dw(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, ConvArgs a, float* grad_w,
                    float* grad_b);
 size_t conv_dw_partial_floats(cpp_ctx* ctx, int cin, int ks, int nout);
+bool conv3_bwd_img_ok(int cin, int ks, int H, int W, int nout);
+int launch_conv3_bwd_img(cpp_ctx* ctx, const struct ConvArgsN& dxb, const struct ConvArgsN& dwb, int* grid);
+int launch_conv3_bwd_whole(cpp_ctx* ctx, const ConvArgs* dw_list, const ConvArgs* dx_list, int n, float* const* grad_w, float* const* grad_b);
 int flush_dw_reduce(cpp_ctx* ctx);     // one launch for every dW reduction queued by launch_conv_dw
 // A backward pass that fails half way (a geometry without a kernel, a launch error) must not leave its queued reductions behind:
 // they point into that network's buffers, which may be gone by the time the next pass flushes the queue.

@@ -169,6 +169,24 @@ size_t conv_dw_partial_floats(cpp_ctx* ctx, int cin, int ks, int nout) {
   return (size_t)(ctx->num_cus * 4) * (size_t)(ks * ks * cin * nout + nout);   // one partial per resident workgroup
 }
 
+// the per-workgroup partials of a dW launch are summed by conv_dw_reduce_kernel: queued here, sent by flush_dw_reduce
+static int queue_dw_reductions(cpp_ctx* ctx, const ConvArgsN& batch, int grid, int nw, int nout, float* const* grad_w, float* const* grad_b) {
+  for (int i = 0; i < batch.n; ++i) {
+    if (ctx->npending == DW_REDUCE_MAX) { const int rc = flush_dw_reduce(ctx); if (rc) return rc; }
+    DwReduceDesc& d = ctx->pending[ctx->npending++];
+    d.partial = batch.a[i].partial; d.nblocks = grid; d.pstride = nw + nout; d.nw = nw; d.nout = nout;
+    d.grad_w = grad_w[i]; d.grad_b = grad_b[i];
+    d.sq_part = nullptr;
+    const int grp = ctx->sq_conv_group[i];
+    if (ctx->sq_part && grp >= 0 && ctx->sq_n[grp] >= 0) {
+      const int nb = (nw + nout + 63) / 64;
+      if (ctx->sq_n[grp] + nb <= SQ_REGION) { d.sq_part = ctx->sq_part + grp * SQ_REGION + ctx->sq_n[grp]; ctx->sq_n[grp] += nb; }
+      else ctx->sq_n[grp] = -1;                      // (cannot happen for the reference's layer sizes; the caller falls back to sumsq)
+    }
+  }
+  return 0;
+}
+
 int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, const ConvArgs* list, int n,
                          float* const* grad_w, float* const* grad_b) {
   if (n < 1 || n > CONV_BATCH_MAX) { cpp_set_error("conv dW: batch of %d networks", n); return 1; }
@@ -230,20 +248,23 @@ int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, co
     rc = conv_dw_dispatch_l23(ctx, cin, ks, xtw, in_mode, batch, &grid);
   prof_end(ctx, kid);
   if (rc) return rc;
+  return queue_dw_reductions(ctx, batch, grid, nw, nout, grad_w, grad_b);
+}
+
+// conv3's whole backward pass (dW, db, dX) of 16x16 inputs as ONE whole-image kernel (conv3_bwd_img.hip)
+int launch_conv3_bwd_whole(cpp_ctx* ctx, const ConvArgs* dw_list, const ConvArgs* dx_list, int n, float* const* grad_w, float* const* grad_b) {
+  if (n < 1 || n > CONV_BATCH_MAX) { cpp_set_error("conv3 backward: batch of %d networks", n); return 1; }
+  const int nout = dw_list[0].nout, nw = 3 * 3 * nout * nout;
+  ConvArgsN dwb, dxb; dwb.n = dxb.n = n;
   for (int i = 0; i < n; ++i) {
-    if (ctx->npending == DW_REDUCE_MAX) { rc = flush_dw_reduce(ctx); if (rc) return rc; }
-    DwReduceDesc& d = ctx->pending[ctx->npending++];
-    d.partial = batch.a[i].partial; d.nblocks = grid; d.pstride = nw + nout; d.nw = nw; d.nout = nout;
-    d.grad_w = grad_w[i]; d.grad_b = grad_b[i];
-    d.sq_part = nullptr;
-    const int grp = ctx->sq_conv_group[i];
-    if (ctx->sq_part && grp >= 0 && ctx->sq_n[grp] >= 0) {
-      const int nb = (nw + nout + 63) / 64;
-      if (ctx->sq_n[grp] + nb <= SQ_REGION) { d.sq_part = ctx->sq_part + grp * SQ_REGION + ctx->sq_n[grp]; ctx->sq_n[grp] += nb; }
-      else ctx->sq_n[grp] = -1;                      // (cannot happen for the reference's layer sizes; the caller falls back to sumsq)
-    }
+    dwb.a[i] = dw_list[i]; dwb.a[i].pstride = nw + nout;
+    dxb.a[i] = dx_list[i];
+    if (dwb.a[i].B != dw_list[0].B) { cpp_set_error("conv3 backward: batched networks differ in geometry"); return 1; }
   }
-  return 0;
+  int grid = 0;
+  const int rc = launch_conv3_bwd_img(ctx, dxb, dwb, &grid);
+  if (rc) return rc;
+  return queue_dw_reductions(ctx, dwb, grid, nw, nout, grad_w, grad_b);
 }
 
 int launch_conv_dw(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, ConvArgs a, float* grad_w,

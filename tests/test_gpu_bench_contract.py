@@ -35,3 +35,21 @@ def test_bench_quick_line_has_the_contract_keys():
     for row in d["layers"]:
         assert 0.0 < row["frac"] <= 1.0, row
     assert d["cpu_baseline"] is None                            # --quick
+
+
+def test_bench_gpus_2_as_a_plain_command_launches_its_own_ranks():
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment is the driver's form: it must start its N ranks itself
+    (torch.distributed.run), and rank 0's ONE JSON line must say n_gpus = N with the whole-job rate.  On a one-GPU box the two ranks
+    share GPU 0 through the gloo diagnostic backend (RCCL refuses two ranks on one device): plumbing, not a measurement."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--diag-backend", "gloo", "--steps", "10",
+                        "--warmup", "5", "--quick"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["scaling"] == "weak"
+    per_rank = d["config"]["per_rank_steps_per_sec"]
+    assert len(per_rank) == 2 and all(x > 0 for x in per_rank)
+    assert d["value"] == pytest.approx(2 * d["config"]["global_steps_per_sec"], rel=1e-3)
+    assert "dp2" in d["config"]["parallelism"]
