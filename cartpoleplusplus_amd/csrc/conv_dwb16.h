@@ -245,10 +245,12 @@ __device__ __forceinline__ void conv_dwb16_body(const ConvArgsN& batch, int unit
               av[mt] = (k16_u32x4){u0.x, u0.y, u1.x, u1.y};
             }
 #pragma unroll
-            for (int pc = NPC - 1; pc >= 0; --pc)
+            for (int pc = NPC - 1; pc >= 0; --pc) {
+              if (pa + pc > B16_MAX_ORDER) continue;
 #pragma unroll
               for (int mt = 0; mt < MT; ++mt)
                 acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dwb_bf16x8, av[mt]), bq[pc], acc[mt], 0, 0, 0);
+            }
           }
         }
         __syncthreads();

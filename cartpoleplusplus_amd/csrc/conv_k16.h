@@ -39,6 +39,10 @@ typedef unsigned k16_u32x4 __attribute__((ext_vector_type(4)));
 // exponent range: no scaling); the previous layer's epilogue writes its pooled output as three bf16 planes next to the
 // f32 tensor, this kernel loads the planes like conv1 loads pixels, the weights are split the same way and all 3 x 3 exact
 // products are issued (nine 16-cycle MFMAs instead of eight 32-cycle ones per 32 k values; no ones channel, no whitening).
+// B16_MAX_ORDER: products h/m/l piece i of one operand x piece j of the other are issued while i + j <= B16_MAX_ORDER (4: all nine).
+#ifndef B16_MAX_ORDER
+#define B16_MAX_ORDER 4
+#endif
 __device__ __forceinline__ unsigned k16_bf16_bits(float x) {        // round-to-nearest-even bf16 of a finite f32
   const unsigned u = __float_as_uint(x);
   return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
@@ -464,7 +468,8 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #pragma unroll
           for (int pc = NPC - 1; pc >= 0; --pc) {    // small pieces first; XT*NT independent accumulators between the pieces
 #pragma unroll
-            for (int pa = NPA - 1; pa >= 0; --pa)
+            for (int pa = NPA - 1; pa >= 0; --pa) {
+              if (B16 && pa + pc > B16_MAX_ORDER) continue;
 #pragma unroll
               for (int m = 0; m < XT; ++m)
 #pragma unroll
@@ -473,6 +478,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
                                                                               __builtin_bit_cast(k16_bf16x8, bv[t][pc]), acc[m][t], 0, 0, 0);
                   else acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[pa][m]), bv[t][pc], acc[m][t], 0, 0, 0);
                 }
+            }
             // this piece's registers: the same piece of the next chunk (pinned here: the scheduler would sink the reads to the
             // end of the chunk and the next chunk would open waiting for them)
             __builtin_amdgcn_sched_barrier(0);

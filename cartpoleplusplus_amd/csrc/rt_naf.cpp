@@ -1,4 +1,5 @@
 // NAF train ops and inner step (cpp_naf_*)
+#include <utility>
 #include "rt_internal.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -241,9 +242,17 @@ static int naf_compute_gradients(cpp_naf* f, cpp_batch* b) {
   return flush_dw_reduce(ctx);
 }
 
-static int naf_apply(cpp_naf* f, float grad_scale, bool unless_nonfinite = false) {
+// bump: the replay sampler's counter, advanced by this launch; next (+ next_B, next_C, elems): the minibatch whose sample pass has
+// already run -- its whitening tables are finished by this launch's extra grid row (as in the DDPG step, rt_ddpg.cpp: apply)
+static int naf_apply(cpp_naf* f, float grad_scale, bool unless_nonfinite = false, uint64_t* bump = nullptr,
+                     const cpp_batch* next = nullptr, int next_B = 0, int next_C = 0, long elems = 0) {
   OptSegs s; memset(&s, 0, sizeof(s));
   if (unless_nonfinite) s.skip_if = f->nonfinite;
+  s.bump = bump;
+  if (next && next_C > 0) {
+    s.st_part = next->part; s.st_white = next->white; s.st_nparts = next_B; s.st_jobs = 2 * next_C; s.st_C = next_C;
+    s.st_count = (double)next_B * (double)(elems / next_C); s.st_eps = 1e-6;
+  }
   s.nseg = 3; s.kind = f->hp.optimiser; s.momentum = f->hp.momentum; s.beta1 = f->hp.beta1; s.beta2 = f->hp.beta2;
   s.epsilon = f->hp.epsilon; s.step = f->opt_step;
   cpp_net* nets[3] = {f->value, f->mu, f->lv};
@@ -339,15 +348,41 @@ extern "C" int cpp_naf_debug_values(cpp_naf* f, cpp_batch* b, float* l_values, f
   return CPP_OK;
 }
 
+// The inner step naf_cartpole.py:367-373.  As in the DDPG step (rt_ddpg.cpp: step_body) the sample pass of minibatch i + 1 depends on
+// nothing minibatch i computes: it rides in the launch of i's conv1 dW (or of its dW reductions), keyed by the sampler's counter + 1
+// -- the counter itself moves in i's optimiser launch, which also finishes the whitening tables of i + 1.  CPP_RIDE_GATHER=0: in sequence.
 static int naf_step_body(cpp_naf* f, cpp_replay* r, int B, int n_batches, const int32_t* rows_dev, uint64_t seed) {
   const int C = f->value->spec.pixel ? f->value->spec.C : 0;
+  cpp_ctx* ctx = f->ctx;
+  const bool direct = direct_replay_ok(f->value, r, B);
+  static const bool no_ride = cpp_switch_off("CPP_RIDE_GATHER");
+  const bool ride_ok = !no_ride && C > 0 && !f->value->spec.use_batch_norm && (r->store_dtype == CPP_F16 || r->store_dtype == CPP_U8);
+  RC(replay_sample_device(r, B, rows_dev, seed, rows_dev ? nullptr : r->counter, C, f->step_batch, direct));
   for (int i = 0; i < n_batches; ++i) {
-    bool bumped = false;     // device-drawn rows: the sampler's counter moves on behind the draw (by the statistics kernel when there is one)
-    RC(replay_sample_device(r, B, rows_dev ? rows_dev + (size_t)i * B : nullptr, seed, rows_dev ? nullptr : r->counter, C, f->step_batch,
-                            direct_replay_ok(f->value, r, B), rows_dev ? nullptr : r->counter, &bumped));
-    if (!rows_dev && !bumped) RC(launch_counter_add(f->ctx, r->counter, 1));
-    RC(naf_compute_gradients(f, f->step_batch));
-    RC(naf_apply(f, 1.0f));
+    GatherArgs ga; int Cg = 0;
+    const bool more = i + 1 < n_batches;
+    if (more && ride_ok) {
+      ga = replay_gather_args(r, B, rows_dev ? rows_dev + (size_t)(i + 1) * B : nullptr, seed, rows_dev ? nullptr : r->counter, C,
+                              f->step_batch, direct, &Cg);
+      ga.counter_add = 1;
+      static const bool no_dwride = cpp_switch_off("CPP_RIDE_DW");
+      ctx->ride_at_dw = direct && !no_dwride;
+      if (direct) { ga.out_slot[0] = f->step_batch->slot_alt[0]; ga.out_slot[1] = f->step_batch->slot_alt[1]; }
+      ctx->ride = &ga; ctx->ride_done = false; ctx->ride_dtype = r->store_dtype;
+    }
+    const int rc = naf_compute_gradients(f, f->step_batch);
+    const bool rode = ctx->ride != nullptr && ctx->ride_done;
+    ctx->ride = nullptr;
+    if (rode && direct) { std::swap(f->step_batch->slot[0], f->step_batch->slot_alt[0]); std::swap(f->step_batch->slot[1], f->step_batch->slot_alt[1]); }
+    RC(rc);
+    const bool stats_ride = rode && Cg > 0;
+    RC(naf_apply(f, 1.0f, false, rows_dev ? nullptr : r->counter, stats_ride ? f->step_batch : nullptr, B, Cg, r->elems));
+    if (more) {
+      if (stats_ride) { f->step_batch->B = B; f->step_batch->dtype = CPP_F16; f->step_batch->stats_C = Cg; }     // (replay_sample_finish's bookkeeping)
+      else if (rode) RC(replay_sample_finish(r, B, Cg, C, f->step_batch));
+      else RC(replay_sample_device(r, B, rows_dev ? rows_dev + (size_t)(i + 1) * B : nullptr, seed, rows_dev ? nullptr : r->counter, C,
+                                   f->step_batch, direct));
+    }
   }
   return cpp_naf_update_targets(f);
 }

@@ -33,7 +33,7 @@ run_cfg r50 --workload r50 --steps 100 --warmup 10
 run_cfg cfg3_bn --workload cfg3 --steps 50 --warmup 10 --use-batch-norm
 run_cfg cfg3_dp1 --workload cfg3 --steps 100 --warmup 10 --force-dp
 # the reference's literal loop against the fused step (profiles/bench_host_path.py), and N = 2 as a plain command (gloo diagnostic)
-bash $REPO/profiles/run_host_path.sh > /dev/null 2>&1
+(cd $REPO && bash profiles/run_host_path.sh > /dev/null 2>&1)
 (cd $REPO && timeout 600 python bench.py --gpus 2 --diag-backend gloo --quick --steps 20 --warmup 5 > $OUT/bench_${R}_gpus2_gloo_diag.json 2> $OUT/bench_${R}_gpus2_gloo_diag.err)
 # keep the merge-back small: only the databases
 find $OUT/prof_${R}* $OUT/pmc_${R}_* -type f ! -name '*.db' -delete 2>/dev/null

@@ -143,27 +143,41 @@ def test_naf_reference_loop_verbatim_trains_on_the_device_rows():
     from tests.helpers import FakeEnv, make_opts
     shape, B = (32, 32, 3, 2, 3), 32
     agents = []
-    for _ in range(2):
+    for _ in range(4):
         make_opts(N, shape, B, True, replay_memory_size=240, share_input_state_representation=True)
         ag = N.NormalizedAdvantageFunctionAgent(FakeEnv(shape))
         ag.initialise_variables(seed=5)
         ag.post_var_init_setup()
         ag.replay_memory.fill_synthetic(200, seed=4)
         agents.append(ag)
-    lit, fused = agents
     try:
-        np.random.seed(7)
-        losses, drawn = [], []
-        # ---- naf_cartpole.py:365-373, verbatim
-        for _ in range(5):
-            batch = lit.replay_memory.batch(B)
-            losses.append(lit.naf.train(batch))
-            drawn.append(batch)
-        lit.target_value_net.update_weights()
-        assert all(b._states is None for b in drawn)
-        fused.train_step(B, 5, idxs=np.concatenate([b.idxs for b in drawn]))
-        for a, b in zip(lit.networks(), fused.networks()):
-            assert np.array_equal(a.get_params(), b.get_params()), a.namespace
-        assert np.isfinite(losses).all() and abs(losses[-1] - float(fused.naf.last_stats()[0])) == 0.0
+        for k, (batches_per_step, steps) in enumerate(((1, 4), (5, 1))):
+            lit, fused = agents[2 * k], agents[2 * k + 1]
+            np.random.seed(7)
+            losses, drawn = [], []
+            for _step in range(steps):
+                # ---- naf_cartpole.py:365-373, verbatim
+                for _ in range(batches_per_step):
+                    batch = lit.replay_memory.batch(B)
+                    losses.append(lit.naf.train(batch))
+                    drawn.append(batch)
+                lit.target_value_net.update_weights()
+            assert all(b._states is None for b in drawn)
+            idxs = np.concatenate([b.idxs for b in drawn])
+            n = batches_per_step * B
+            for j in range(steps):
+                fused.train_step(B, batches_per_step, idxs=idxs[j * n:(j + 1) * n])
+            # one minibatch per step: the same kernels on the same rows, bit for bit; five: train_step sends minibatch i + 1's sample
+            # pass along with minibatch i's backward kernels, which moves last bits (as in the DDPG loop above)
+            for a, b in zip(lit.networks(), fused.networks()):
+                pa, pb = a.get_params(), b.get_params()
+                if batches_per_step == 1:
+                    assert np.array_equal(pa, pb), a.namespace
+                else:
+                    assert _maxrel(pa, pb) < 2e-6, (a.namespace, _maxrel(pa, pb))
+            assert np.isfinite(losses).all()
+            last = float(fused.naf.last_stats()[0])
+            assert abs(losses[-1] - last) <= (0.0 if batches_per_step == 1 else 1e-5 * abs(last))
     finally:
-        lit.close(); fused.close()
+        for ag in agents:
+            ag.close()

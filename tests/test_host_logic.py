@@ -236,3 +236,31 @@ def test_deferred_naf_loss_behaves_like_the_float_the_reference_logs(monkeypatch
         float(bad)
     with pytest.raises(FloatingPointError):                   # and again: the error sticks to the minibatch
         bad + 1
+
+
+def test_bench_self_launch_builds_the_drivers_torchrun_command(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE re-runs itself as N ranks: python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <the same flags>."""
+    import importlib.util
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, cwd=None, env=None):
+        seen.update(cmd=cmd, cwd=cwd, env=env)
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    assert bench.self_launch(8) == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    i = cmd.index(os.path.join(root, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
