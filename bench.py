@@ -21,7 +21,7 @@ Prints ONE JSON line (rank 0).  Besides the contract keys it carries
   cpu_baseline   : the same minibatch update on this host's cores: torch-CPU restatement (oracle/ddpg_torch.py, the
                    stand-in for the reference's TF-CPU kernels) -- and `cpu_baseline_numpy`, the numpy oracle
   control        : the same step with conv1 / conv2 forced onto the f32-input MFMA kernels (ablation build of the library,
-                   CPP_CONV_K16=0 CPP_CONV_B16=0): the f32 twin of the f16x3 / bf16x9 numbers
+                   CPP_CONV_K16=0 CPP_CONV_B16=0): the f32 twin of the f16x3 / bf16x6 numbers
   extra          : short runs of the other BASELINE configs (cfg2, cfg4 = NAF, cfg5), steps/s each
 (N = 1, rank 0 only for the last three; --quick skips them.)
 """
@@ -56,7 +56,7 @@ CONV_DEFS = ((5, 10), (5, 10), (3, 10))
 SUSTAINED_F16_MFMA_TFLOPS_RANDOM_OPERANDS = 2000      # measured 1914-2056 on two boxes: profiles/r02_mfma_rate_probe.txt (informational, see roofline["sustained"])
 PIPES = {
     "f16x3": (PEAK_F16_MFMA_TFLOPS / 3.0, "f16 MFMA, 3 exact f16 x f16 products per f32 product (2500 / 3)"),
-    "bf16x9": (PEAK_F16_MFMA_TFLOPS / 9.0, "bf16 MFMA, 9 exact bf16 x bf16 products per f32 product (2500 / 9)"),
+    "bf16x6": (PEAK_F16_MFMA_TFLOPS / 6.0, "bf16 MFMA, 6 bf16 x bf16 piece products per f32 product (2500 / 6)"),
     "f32": (PEAK_F32_MFMA_TFLOPS, "f32-input MFMA"),
 }
 
@@ -361,8 +361,8 @@ def main():
         row("conv1 dW (f32 MFMA)", ["conv1_dw"], [(gf(L1, nb), "f32")]),
         # (when conv3 + pool3 ride as the tail of conv2's workgroups there is no conv3_fwd launch: its FLOPs belong to this row)
         row("conv2 forward" + ("" if "conv3_fwd" in prof else " + conv3 forward"), ["conv2_fwd"],
-            [(gf(L2, nfwd), "bf16x9" if "conv1_fwd_f16x3" in prof else "f32")] + ([] if "conv3_fwd" in prof else [(gf(L3, nfwd), "f32")])),
-        row("conv2 dW + dX", ["conv2_bwd"], [(gf(L2, nb), "bf16x9"), (gf(L2, nb), "f32")]),
+            [(gf(L2, nfwd), "bf16x6" if "conv1_fwd_f16x3" in prof else "f32")] + ([] if "conv3_fwd" in prof else [(gf(L3, nfwd), "f32")])),
+        row("conv2 dW + dX", ["conv2_bwd"], [(gf(L2, nb), "bf16x6"), (gf(L2, nb), "f32")]),
         row("conv2 dW", ["conv2_dw"], [(gf(L2, nb), "f32")]),
         row("conv2 dX", ["conv2_dx"], [(gf(L2, nb), "f32")]),
         row("conv3 forward", ["conv3_fwd"], [(gf(L3, nfwd), "f32")]),
@@ -432,8 +432,9 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "timed_region_ms": round(1e3 * elapsed, 2), "warmup_steps_run": warmup_steps_run,
         "dtype_note": "f32 accumulation everywhere; conv1 multiplies exact f16 operands (the replay store's pixels x three-piece f16 "
-                      "splits of the f32 weights / gradients), conv2 forward / dW three-piece bf16 splits of both f32 operands with all "
-                      "nine products: every product exact, results within f32 rounding of the f32-MFMA kernels (DESIGN.md 4, 6; see `control`)",
+                      "splits of the f32 weights / gradients), conv2 forward / dW three-piece bf16 splits of both f32 operands with the "
+                      "six products above 2^-26 of the result: as close to the float64 oracle as the f32-MFMA kernels and as all nine "
+                      "products (DESIGN.md 4, 6; see `control`)",
         "config": {"workload": "%s: %s pixel obs %dx%dx%d, batch=%d per GPU, replay %d rows/GPU in HBM (%s), "
                                "target soft-update every %d minibatches%s" % (
                                    args.workload, "DDPG" if kind == "ddpg" else "NAF (shared trunk, Momentum)", shape[0], shape[1], ch, B,

@@ -1,4 +1,4 @@
-// conv2's dW (nine-product bf16 kernel) and dX (row kernel in dX mode) in ONE launch, as for conv3 (conv3_bwd_pair.hip): both read
+// conv2's dW (bf16 kernel, conv_dwb16.h) and dX (row kernel in dX mode) in ONE launch, as for conv3 (conv3_bwd_pair.hip): both read
 // the pooled gradient conv3's dX left, neither needs the other.  Workgroups [0, dX grid) run dX, the rest dW.
 #include <cstring>
 #ifndef PAIR_ORDER_DEFAULT
@@ -7,12 +7,13 @@
 #include "conv_kyo.h"
 #include "conv_dwb16.h"
 
+template <int ORDER>
 __global__ __launch_bounds__(CONV_THREADS, 2) void conv2_bwd_pair_kernel(const ConvArgsN dx, int dx_gx, const ConvArgsN dw, int dw_gx, int upi, int band, int order) {
   int i;
   if (!pair_grid_place((int)blockIdx.x, dx_gx * dx.n, dw_gx * dw.n, order, &i)) {
     conv_fwd_kyo_body<10, 5, 1, 2, IN_DY, 16, false>(dx, i % dx_gx, i / dx_gx);
   } else {
-    conv_dwb16_body<10, 5, 1>(dw, upi, band, i % dw_gx, i / dw_gx, dw_gx);
+    conv_dwb16_body<10, 5, 1, ORDER>(dw, upi, band, i % dw_gx, i / dw_gx, dw_gx);
   }
 }
 
@@ -20,10 +21,14 @@ int launch_conv2_bwd_pair(cpp_ctx* ctx, const ConvPairSlot& slot) {
   const int ndx = slot.have_dx ? slot.dx_gx * slot.dx.n : 0, ndw = slot.have_dw ? slot.dw_gx * slot.dw.n : 0;
   if (ndx + ndw == 0) return 0;
   const size_t lds = (slot.have_dx ? slot.dx_lds : 0) > (slot.have_dw ? slot.dw_lds : 0) ? slot.dx_lds : slot.dw_lds;
+  auto kern = conv2_bwd_pair_kernel<B16_SIX>;
+#ifdef CPP_ABLATION
+  if (b16_order() == B16_NINE) kern = conv2_bwd_pair_kernel<B16_NINE>;
+#endif
   static size_t attr_dev[CPP_MAX_DEVICES] = {};      // (kernel attributes are per device)
   size_t& attr = attr_dev[cpp_dev_slot(ctx)];
   if (lds > attr) {
-    HIP_CHECK(hipFuncSetAttribute((const void*)conv2_bwd_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = lds;
   }
   ConvArgsN dx = slot.dx, dw = slot.dw;
@@ -33,7 +38,7 @@ int launch_conv2_bwd_pair(cpp_ctx* ctx, const ConvPairSlot& slot) {
   // done and the launch takes dX + dW; dispatched first they run beside it (CPP_PAIR_ORDER: 0 dX first, 1 dW first, 2 interleaved)
   static const int order = cpp_switch_int("CPP_PAIR_ORDER", PAIR_ORDER_DEFAULT);
   prof_begin(ctx);
-  hipLaunchKernelGGL(conv2_bwd_pair_kernel, dim3(ndx + ndw), dim3(CONV_THREADS), lds, ctx->stream, dx, slot.have_dx ? slot.dx_gx : 1,
+  hipLaunchKernelGGL(kern, dim3(ndx + ndw), dim3(CONV_THREADS), lds, ctx->stream, dx, slot.have_dx ? slot.dx_gx : 1,
                      dw, slot.have_dw ? slot.dw_gx : 1, slot.upi, slot.band, order);
   LAUNCH_CHECK();
   prof_end(ctx, K_CONV2_BWD);

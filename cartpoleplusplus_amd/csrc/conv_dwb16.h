@@ -53,7 +53,7 @@ struct Dwb16Geom {
 };
 
 // (bx, by, gx): the workgroup's place in a (gx, networks) grid (its own launch, or a slice of a shared one: conv2_bwd_pair.hip)
-template <int CIN, int KS, int NCHK>
+template <int CIN, int KS, int NCHK, int ORDER = B16_SIX>
 __device__ __forceinline__ void conv_dwb16_body(const ConvArgsN& batch, int units_per_img, int band, const int bx, const int by, const int gx) {
   typedef Dwb16Geom<CIN, KS, NCHK> G;
   constexpr int P = G::P, NO = G::NO, MT = G::MT, CP = G::CP, NPC = G::NPC, NPA = G::NPA, ROWB = G::ROWB, DSLOT = G::DSLOT;
@@ -246,7 +246,7 @@ __device__ __forceinline__ void conv_dwb16_body(const ConvArgsN& batch, int unit
             }
 #pragma unroll
             for (int pc = NPC - 1; pc >= 0; --pc) {
-              if (pa + pc > B16_MAX_ORDER) continue;
+              if (pa + pc > ORDER) continue;
 #pragma unroll
               for (int mt = 0; mt < MT; ++mt)
                 acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dwb_bf16x8, av[mt]), bq[pc], acc[mt], 0, 0, 0);
@@ -292,20 +292,20 @@ __device__ __forceinline__ void conv_dwb16_body(const ConvArgsN& batch, int unit
   }
 }
 
-template <int CIN, int KS, int NCHK>
+template <int CIN, int KS, int NCHK, int ORDER = B16_SIX>
 __global__ __launch_bounds__(CONV_THREADS, 3) void conv_dwb16_kernel(const ConvArgsN batch, int units_per_img, int band) {
-  conv_dwb16_body<CIN, KS, NCHK>(batch, units_per_img, band, blockIdx.x, blockIdx.y, gridDim.x);
+  conv_dwb16_body<CIN, KS, NCHK, ORDER>(batch, units_per_img, band, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 #ifndef DWB16_CAP
 #define DWB16_CAP 4
 #endif
-template <int CIN, int KS, int NCHK>
+template <int CIN, int KS, int NCHK, int ORDER = B16_SIX>
 static inline int conv_dwb16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int* grid_out) {
   typedef Dwb16Geom<CIN, KS, NCHK> G;
   const ConvArgs& a = batch.a[0];
   const size_t lds_bytes = (size_t)G::LDS_BYTES;
-  auto kern = conv_dwb16_kernel<CIN, KS, NCHK>;
+  auto kern = conv_dwb16_kernel<CIN, KS, NCHK, ORDER>;
   static bool attr_done[CPP_MAX_DEVICES] = {};          // (kernel attributes are per device: one cpp_ctx per GPU may share the process)
   if (!attr_done[cpp_dev_slot(ctx)]) {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

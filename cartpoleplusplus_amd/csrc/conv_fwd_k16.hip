@@ -54,9 +54,15 @@ int conv_fwd_k16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool plain
   return 0;
 }
 
+#ifdef CPP_ABLATION
+#define KB16_NINE(XT_, IPW_) if (b16_order() == B16_NINE) return conv_fwd_k16_launch_t<10, 5, XT_, IPW_, false, B16_NINE>(ctx, k16_with_bands(ctx, a, IPW_));
+#else
+#define KB16_NINE(XT_, IPW_)
+#endif
 #define KB16_CASE(XT_, IPW_)                                                                                 \
   if (xt == XT_ && ipw == IPW_) { *handled = true; if (!ctx) return 0;                                       \
-    return conv_fwd_k16_launch_t<10, 5, XT_, IPW_, false, true>(ctx, k16_with_bands(ctx, a, IPW_)); }
+    KB16_NINE(XT_, IPW_)                                                                                       \
+    return conv_fwd_k16_launch_t<10, 5, XT_, IPW_, false, B16_SIX>(ctx, k16_with_bands(ctx, a, IPW_)); }
 
 int conv_fwd_kb16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArgsN& a, bool* handled) {
   *handled = false;

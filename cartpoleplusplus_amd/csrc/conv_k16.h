@@ -39,10 +39,18 @@ typedef unsigned k16_u32x4 __attribute__((ext_vector_type(4)));
 // exponent range: no scaling); the previous layer's epilogue writes its pooled output as three bf16 planes next to the
 // f32 tensor, this kernel loads the planes like conv1 loads pixels, the weights are split the same way and all 3 x 3 exact
 // products are issued (nine 16-cycle MFMAs instead of eight 32-cycle ones per 32 k values; no ones channel, no whitening).
-// B16_MAX_ORDER: products h/m/l piece i of one operand x piece j of the other are issued while i + j <= B16_MAX_ORDER (4: all nine).
-#ifndef B16_MAX_ORDER
-#define B16_MAX_ORDER 4
-#endif
+// Which of the nine piece products are issued.  With round-to-nearest pieces |m| <= 2^-9 |x| and |l| <= 2^-18 |x|, so the products
+// m*l, l*m and l*l together are below 2^-26 of the product -- a quarter of the rounding of ONE f32 accumulation step, of which every
+// output takes K = 250 -- and against the float64 oracle the six-product result is as close as the nine-product one (pooled conv2
+// output 4.47e-6 / 4.47e-6 abs at magnitude 7.5, weight gradient 5.8e-7 / 6.0e-7 rel; the f32-input MFMA kernels: 4.77e-6, 7.5e-7;
+// profiles/experiments/r03_b16_products.txt).  The kernels' B16 / ORDER template value is the largest i + j (h = 0, m = 1, l = 2)
+// still issued: B16_SIX everywhere; B16_NINE instances exist in the ablation build (CPP_B16_PRODUCTS=9).
+#define B16_SIX 2
+#define B16_NINE 4
+static inline int b16_order() {
+  static const int o = cpp_switch_int("CPP_B16_PRODUCTS", 6) == 9 ? B16_NINE : B16_SIX;
+  return o;
+}
 __device__ __forceinline__ unsigned k16_bf16_bits(float x) {        // round-to-nearest-even bf16 of a finite f32
   const unsigned u = __float_as_uint(x);
   return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
@@ -77,7 +85,7 @@ __device__ __forceinline__ void k16_issue_b32(unsigned& dst, const k16_i32x4& de
 template <int N> __device__ __forceinline__ void k16_wait_vm(k16_u32x4& x) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x) : "n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void k16_wait_vm(unsigned& x) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x) : "n"(N) : "memory"); }
 
-template <int CIN, int KS, int XT, int IPW, bool B16 = false>
+template <int CIN, int KS, int XT, int IPW, bool B16 = false>      // (geometry: B16 mode or not)
 struct K16Geom {
   static constexpr int NO = KYO_NO;
   static constexpr int P = KS / 2;
@@ -130,9 +138,9 @@ struct K16Geom {
 #ifndef K16_ROTATE_PRIO
 #define K16_ROTATE_PRIO 1
 #endif
-template <int CIN, int KS, int XT, int IPW, bool PLAIN = false, bool B16 = false>
+template <int CIN, int KS, int XT, int IPW, bool PLAIN = false, int B16 = 0>      // B16: 0, or B16_SIX / B16_NINE
 __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(const ConvArgsN batch) {
-  typedef K16Geom<CIN, KS, XT, IPW, B16> G;
+  typedef K16Geom<CIN, KS, XT, IPW, (B16 != 0)> G;
   constexpr int P = G::P, NT = G::NT, NCH = G::NCH, NPC = G::NPC, NPA = G::NPA, NO = KYO_NO;
   constexpr bool ODD = (CIN & 1) != 0;            // 2-byte aligned operand windows: 20 bytes from the aligned address below + a funnel shift
 #if defined(K16_CLOCK_PROBE) || defined(K16_SPAN_PROBE)
@@ -469,7 +477,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
           for (int pc = NPC - 1; pc >= 0; --pc) {    // small pieces first; XT*NT independent accumulators between the pieces
 #pragma unroll
             for (int pa = NPA - 1; pa >= 0; --pa) {
-              if (B16 && pa + pc > B16_MAX_ORDER) continue;
+              if (B16 && pa + pc > B16) continue;
 #pragma unroll
               for (int m = 0; m < XT; ++m)
 #pragma unroll
@@ -598,9 +606,9 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #endif
 }
 
-template <int CIN, int KS, int XT, int IPW, bool PLAIN = false, bool B16 = false>
+template <int CIN, int KS, int XT, int IPW, bool PLAIN = false, int B16 = 0>      // B16: 0, or B16_SIX / B16_NINE
 static inline int conv_fwd_k16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
-  typedef K16Geom<CIN, KS, XT, IPW, B16> G;
+  typedef K16Geom<CIN, KS, XT, IPW, (B16 != 0)> G;
   const ConvArgs& a = batch.a[0];
   const size_t lds_bytes = (size_t)G::LDS_BYTES;
   auto kern = conv_fwd_k16_kernel<CIN, KS, XT, IPW, PLAIN, B16>;

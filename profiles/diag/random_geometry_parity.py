@@ -15,5 +15,5 @@ for i in range(int(sys.argv[2]) if len(sys.argv) > 2 else 25):
         print("GEO", shape, "B", B, "ok errq %.1e relc %.1e" % (rep["err_q"], rep["rel_critic_grads"]), flush=True)
     except Exception as e:
         bad += 1
-        print("GEO", shape, "B", B, "FAIL", str(e).replace("\n", " | ")[:400], flush=True)
+        print("GEO", shape, "B", B, "FAIL", str(e).replace("\n", " | ")[:1600], flush=True)
 print("GEODONE bad", bad, flush=True)

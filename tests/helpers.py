@@ -64,10 +64,13 @@ def per_var_report(spec, got, want):
     return rows
 
 
-def assert_flat_close(spec, got, want, rel=2e-5, what=""):
+def assert_flat_close(spec, got, want, rel=2e-5, what="", abs_floor=0.0):
+    """abs_floor: an absolute error one-element variables are not held below (the critic's q_value bias gradient is 2 mean(td), a
+    sum with cancellation: it cannot be closer to the oracle than the Q values that make up td)."""
     rows = per_var_report(spec, got, want)
+    single = set(name for name, shp in spec.layout() if int(np.prod(shp)) == 1)
     scale = float(np.linalg.norm(np.asarray(want, np.float64))) / np.sqrt(len(want)) + 1e-30
-    bad = [r for r in rows if r[2] > rel and r[1] > rel * scale]
+    bad = [r for r in rows if r[2] > rel and r[1] > rel * scale and not (r[0] in single and r[1] <= abs_floor)]
     msg = "\n".join("%-28s max_abs=%.3e rel_l2=%.3e" % r for r in rows)
     assert not bad, "%s mismatch (rel tol %g):\n%s" % (what, rel, msg)
 
@@ -253,7 +256,8 @@ def fused_step_against_f64_oracle(shape, B, rows, replay_store="f16", replay_siz
     assert report["err_q"] < atol and report["err_td"] < atol, report
     assert abs(stats[0] - cg["loss"]) < atol * max(1.0, abs(cg["loss"])), (stats, cg["loss"])
     assert_flat_close(aspec, g_a, ag["grads"], rel=grad_rel, what="actor pre-clip grads vs f64 oracle")
-    assert_flat_close(cspec, g_c, cg["grads"], rel=grad_rel, what="critic pre-clip grads vs f64 oracle")
+    assert_flat_close(cspec, g_c, cg["grads"], rel=grad_rel, what="critic pre-clip grads vs f64 oracle",
+                      abs_floor=2.0 * report["err_td"])
     report["rel_actor_grads"] = max(r_[2] for r_ in per_var_report(aspec, g_a, ag["grads"]))
     report["rel_critic_grads"] = max(r_[2] for r_ in per_var_report(cspec, g_c, cg["grads"]))
     na, nc = float(np.linalg.norm(ag["grads"])), float(np.linalg.norm(cg["grads"]))

@@ -285,23 +285,28 @@ agent.close()
 """
 
 
-def test_bf16_nine_product_conv2_is_as_close_to_the_f64_oracle_as_the_f32_mfma_kernels():
-    """conv2 forward / dW from three exact bf16 pieces per operand (conv_k16.h B16 mode, conv_dwb16.h) against
-    CPP_CONV_B16=0 (f32-input MFMA): pooled conv2 output and conv2 weight gradient vs the float64 oracle."""
+def test_bf16_conv2_is_as_close_to_the_f64_oracle_as_the_f32_mfma_kernels():
+    """conv2 forward / dW from three bf16 pieces per operand (conv_k16.h B16 mode, conv_dwb16.h) -- the six piece products above
+    2^-26 of the result (the shipped kernels), all nine (CPP_B16_PRODUCTS=9, ablation build) -- against CPP_CONV_B16=0 (f32-input
+    MFMA): pooled conv2 output and conv2 weight gradient vs the float64 oracle."""
     import os, re, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for b16 in ("1", "0"):
-        r = subprocess.run([sys.executable, "-c", _CONV2_ERR_SNIPPET], cwd=root, env=dict(os.environ, CARTPOLEPP_ABLATION="1", CPP_CONV_B16=b16),
+    for name, extra in (("six", {}), ("nine", {"CPP_B16_PRODUCTS": "9"}), ("f32", {"CPP_CONV_B16": "0"})):
+        r = subprocess.run([sys.executable, "-c", _CONV2_ERR_SNIPPET], cwd=root, env=dict(os.environ, CARTPOLEPP_ABLATION="1", **extra),
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
         out = r.stdout.decode()
         f, d = re.search(r"C2FWD (\S+) (\S+)", out), re.search(r"C2DW (\S+)", out)
         assert r.returncode == 0 and f and d, out[-1500:]
-        res[b16] = (float(f.group(1)), float(f.group(2)), float(d.group(1)))
-    (f16e, mag, d16e), (f32e, _, d32e) = res["1"], res["0"]
-    assert f16e < 1e-5 * max(1.0, mag) and f32e < 1e-5 * max(1.0, mag), res
-    assert f16e <= 1.5 * f32e + 1e-7 * max(1.0, mag), res
-    assert d16e < 5e-6 and d32e < 5e-6 and d16e <= 1.5 * d32e + 1e-8, res
+        res[name] = (float(f.group(1)), float(f.group(2)), float(d.group(1)))
+    (f32e, mag, d32e) = res["f32"]
+    assert f32e < 1e-5 * max(1.0, mag) and d32e < 5e-6, res
+    for name in ("six", "nine"):
+        fe, _, de = res[name]
+        assert fe < 1e-5 * max(1.0, mag) and fe <= 1.5 * f32e + 1e-7 * max(1.0, mag), (name, res)
+        assert de < 5e-6 and de <= 1.5 * d32e + 1e-8, (name, res)
+    # dropping the three smallest products costs nothing measurable against the oracle
+    assert res["six"][0] <= 1.1 * res["nine"][0] + 1e-8 * max(1.0, mag) and res["six"][2] <= 1.1 * res["nine"][2] + 1e-9, res
 
 
 _PAIR_DW_SNIPPET = r"""
