@@ -21,7 +21,8 @@ Prints ONE JSON line (rank 0).  Besides the contract keys it carries
   cpu_baseline   : the same minibatch update on this host's cores: torch-CPU restatement (oracle/ddpg_torch.py, the
                    stand-in for the reference's TF-CPU kernels) -- and `cpu_baseline_numpy`, the numpy oracle
   control        : the same step with conv1 / conv2 forced onto the f32-input MFMA kernels (ablation build of the library,
-                   CPP_CONV_K16=0 CPP_CONV_B16=0): the f32 twin of the f16x3 / bf16x6 numbers
+                   CPP_CONV_K16=0 CPP_CONV_B16=0): the f32 twin of the f16x2 / bf16x6 numbers
+  control_exact_products : the same step from libcartpolepp_hip_exact.so (three f16 pieces, nine bf16 products: every product exact)
   extra          : short runs of the other BASELINE configs (cfg2, cfg4 = NAF, cfg5), steps/s each
 (N = 1, rank 0 only for the last three; --quick skips them.)
 """
@@ -54,8 +55,14 @@ PEAK_F16_MFMA_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense f16 / bf16
 CONV_DEFS = ((5, 10), (5, 10), (3, 10))
 # matrix pipe of a profiled kernel name -> (peak TFLOP/s for ALGORITHMIC flops, description)
 SUSTAINED_F16_MFMA_TFLOPS_RANDOM_OPERANDS = 2000      # measured 1914-2056 on two boxes: profiles/r02_mfma_rate_probe.txt (informational, see roofline["sustained"])
+# the library this process loads: the release build multiplies two f16 pieces of conv1's f32 operand and six bf16 piece products in
+# conv2; libcartpolepp_hip_exact.so (CARTPOLEPP_ABLATION=exact) three and nine -- every product exact (conv_k16.h)
+EXACT_PRODUCTS = os.environ.get("CARTPOLEPP_ABLATION", "") == "exact"
+F16_PIPE, B16_PIPE = ("f16x3", "bf16x9") if EXACT_PRODUCTS else ("f16x2", "bf16x6")
 PIPES = {
+    "f16x2": (PEAK_F16_MFMA_TFLOPS / 2.0, "f16 MFMA, 2 f16 x f16 piece products per f32 product (2500 / 2)"),
     "f16x3": (PEAK_F16_MFMA_TFLOPS / 3.0, "f16 MFMA, 3 exact f16 x f16 products per f32 product (2500 / 3)"),
+    "bf16x9": (PEAK_F16_MFMA_TFLOPS / 9.0, "bf16 MFMA, 9 exact bf16 x bf16 products per f32 product (2500 / 9)"),
     "bf16x6": (PEAK_F16_MFMA_TFLOPS / 6.0, "bf16 MFMA, 6 bf16 x bf16 piece products per f32 product (2500 / 6)"),
     "f32": (PEAK_F32_MFMA_TFLOPS, "f32-input MFMA"),
 }
@@ -337,7 +344,7 @@ def main():
     gf = lambda macs, nets: 2.0 * B * macs * nets          # algorithmic FLOPs of one launch over the whole minibatch
 
     # One row per conv launch of the fused step.  A row may be served by several profiled kernel names (the same kernel with
-    # and without the next minibatch's sample pass riding along: conv1_dw_f16x3 / conv1_dw_gather): their times and launches
+    # and without the next minibatch's sample pass riding along: conv1_dw_f16 / conv1_dw_gather): their times and launches
     # are merged, and the FLOPs per launch are a constant of the launch (2 * B * MACs * networks), never derived from counts.
     # parts: [(algorithmic flops per launch, pipe)] -- a paired launch (dW + dX) is bounded by the sum of its parts' times.
     def row(label, names, parts):
@@ -355,14 +362,14 @@ def main():
     L1, L2, L3 = per_layer
     nb = nbwd
     rows = [r for r in (
-        row("conv1 forward", ["conv1_fwd_f16x3"], [(gf(L1, nfwd), "f16x3")]),
+        row("conv1 forward", ["conv1_fwd_f16"], [(gf(L1, nfwd), F16_PIPE)]),
         row("conv1 forward (f32 MFMA)", ["conv1_fwd"], [(gf(L1, nfwd), "f32")]),
-        row("conv1 dW", ["conv1_dw_f16x3", "conv1_dw_gather"], [(gf(L1, nb), "f16x3")]),
+        row("conv1 dW", ["conv1_dw_f16", "conv1_dw_gather"], [(gf(L1, nb), F16_PIPE)]),
         row("conv1 dW (f32 MFMA)", ["conv1_dw"], [(gf(L1, nb), "f32")]),
         # (when conv3 + pool3 ride as the tail of conv2's workgroups there is no conv3_fwd launch: its FLOPs belong to this row)
         row("conv2 forward" + ("" if "conv3_fwd" in prof else " + conv3 forward"), ["conv2_fwd"],
-            [(gf(L2, nfwd), "bf16x6" if "conv1_fwd_f16x3" in prof else "f32")] + ([] if "conv3_fwd" in prof else [(gf(L3, nfwd), "f32")])),
-        row("conv2 dW + dX", ["conv2_bwd"], [(gf(L2, nb), "bf16x6"), (gf(L2, nb), "f32")]),
+            [(gf(L2, nfwd), B16_PIPE if "conv1_fwd_f16" in prof else "f32")] + ([] if "conv3_fwd" in prof else [(gf(L3, nfwd), "f32")])),
+        row("conv2 dW + dX", ["conv2_bwd"], [(gf(L2, nb), B16_PIPE), (gf(L2, nb), "f32")]),
         row("conv2 dW", ["conv2_dw"], [(gf(L2, nb), "f32")]),
         row("conv2 dX", ["conv2_dx"], [(gf(L2, nb), "f32")]),
         row("conv3 forward", ["conv3_fwd"], [(gf(L3, nfwd), "f32")]),
@@ -404,14 +411,15 @@ def main():
                     "frac_vs_f32_mfma": round(dom["achieved_tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
                     "flops_per_launch": dom["gflop_per_launch"] * 1e9, "avg_launch_ms": round(dom["avg_launch_us"] / 1e3, 5),
                     "launches_per_step": dom["launches_per_step"], "traffic": traffic, "traffic_source": traffic_src}
-        if pipe == "f16x3":
+        if pipe == F16_PIPE:
             # informational, next to (never instead of) `peak` / `frac`: what the f16 pipes sustain on operands that toggle like image
             # data -- the chip clocks to its power budget (profiles/diag/mfma_rate_probe.hip, profiles/r02_mfma_rate_probe.txt)
-            sus = SUSTAINED_F16_MFMA_TFLOPS_RANDOM_OPERANDS / 3.0
+            npieces = 3 if EXACT_PRODUCTS else 2
+            sus = SUSTAINED_F16_MFMA_TFLOPS_RANDOM_OPERANDS / float(npieces)
             roofline["sustained"] = {"peak": round(sus, 1), "frac": round(dom["achieved_tflops"] / sus, 4),
                                      "basis": "v_mfma_f32_16x16x32_f16 issued back to back by every SIMD with pseudo-random operands: 1914-2056 TFLOP/s at "
                                               "1.9-2.0 GHz on two boxes, %d taken (2354-2453 at 2.4 GHz with constant operands; 32x32x16: 1595-1719), "
-                                              "/ 3 pieces; profiles/r02_mfma_rate_probe.txt" % SUSTAINED_F16_MFMA_TFLOPS_RANDOM_OPERANDS}
+                                              "/ %d pieces; profiles/r02_mfma_rate_probe.txt" % (SUSTAINED_F16_MFMA_TFLOPS_RANDOM_OPERANDS, npieces)}
 
     # the fully connected heads (reported separately, never in a roofline numerator): per image and minibatch the actor's
     # layers run forward once and backward twice (dX, dW), the critic's forward twice and backward twice, each target network forward once
@@ -431,10 +439,14 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "timed_region_ms": round(1e3 * elapsed, 2), "warmup_steps_run": warmup_steps_run,
-        "dtype_note": "f32 accumulation everywhere; conv1 multiplies exact f16 operands (the replay store's pixels x three-piece f16 "
-                      "splits of the f32 weights / gradients), conv2 forward / dW three-piece bf16 splits of both f32 operands with the "
-                      "six products above 2^-26 of the result: as close to the float64 oracle as the f32-MFMA kernels and as all nine "
-                      "products (DESIGN.md 4, 6; see `control`)",
+        "dtype_note": ("f32 accumulation everywhere; conv1 multiplies exact f16 operands (the replay store's pixels x three-piece f16 splits "
+                       "of the f32 weights / gradients), conv2 forward / dW three-piece bf16 splits of both f32 operands with all nine "
+                       "products: every product exact (libcartpolepp_hip_exact.so)" if EXACT_PRODUCTS else
+                       "f32 accumulation everywhere; conv1 multiplies the replay store's f16 pixels (exact) by a two-piece f16 split of the "
+                       "f32 weight / gradient (within one f32 ulp of it), conv2 forward / dW three-piece bf16 splits of both f32 operands with "
+                       "the six largest piece products (the dropped three are at most half an f32 ulp of the product): measured as close to "
+                       "the float64 oracle as the exact-product build (`control_exact_products`) and closer than the f32-input MFMA kernels "
+                       "(`control`); DESIGN.md 4, 6"),
         "config": {"workload": "%s: %s pixel obs %dx%dx%d, batch=%d per GPU, replay %d rows/GPU in HBM (%s), "
                                "target soft-update every %d minibatches%s" % (
                                    args.workload, "DDPG" if kind == "ddpg" else "NAF (shared trunk, Momentum)", shape[0], shape[1], ch, B,
@@ -474,6 +486,13 @@ def main():
                           "value": c.get("value"), "unit": "steps/s", "ms_per_step": c.get("ms_per_step"),
                           "layers": [{k: r[k] for k in ("layer", "avg_launch_us", "pipe", "frac")} for r in c.get("layers", [])],
                           "error": c.get("error")}
+        # the exact-product twin: three f16 pieces / nine bf16 products (what rounds 1-2 shipped)
+        c = sub_bench(["--steps", "100", "--warmup", "10", "--workload", args.workload], env={"CARTPOLEPP_ABLATION": "exact"})
+        out["control_exact_products"] = {
+            "what": "same step from libcartpolepp_hip_exact.so: three f16 pieces of conv1's f32 operand, all nine bf16 piece products in conv2 "
+                    "(every product exact)", "switches": "CARTPOLEPP_ABLATION=exact",
+            "value": c.get("value"), "unit": "steps/s", "ms_per_step": c.get("ms_per_step"),
+            "layers": [{k: r[k] for k in ("layer", "avg_launch_us", "pipe", "frac")} for r in c.get("layers", [])], "error": c.get("error")}
         extra = {}
         for wl, st in (("cfg2", 100), ("cfg4", 100), ("cfg5", 30)):
             e = sub_bench(["--steps", str(st), "--warmup", "10", "--workload", wl])

@@ -12,7 +12,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # The release library reads no environment variable and is the only one loaded by default.  CARTPOLEPP_ABLATION=1 selects the
 # ablation build of the SAME sources (lib/libcartpolepp_hip_ablation.so: the CPP_* kernel-selection switches compiled in; parity
-# tests of the fallback kernels, bench.py's f32 control run); CARTPOLEPP_ABLATION=<name> an in-tree experiment build
+# tests of the fallback kernels, bench.py's f32 control run); CARTPOLEPP_ABLATION=exact the exact-products build (three f16 pieces / nine
+# bf16 products: lib/libcartpolepp_hip_exact.so, csrc/Makefile); CARTPOLEPP_ABLATION=<name> an in-tree experiment build
 # lib/libcartpolepp_hip_<name>.so (profiles/).  No path can be injected: the file must sit in this package's lib/ directory.
 _variant = os.environ.get("CARTPOLEPP_ABLATION", "")
 if _variant and not _variant.replace("_", "").isalnum():

@@ -27,7 +27,7 @@ typedef unsigned dw16_u32x2 __attribute__((ext_vector_type(2)));
 
 template <int CIN, int KS, int NCHK>
 struct Dw16Geom {
-  static constexpr int P = KS / 2, NO = KYO_NO, NPC = 3;
+  static constexpr int P = KS / 2, NO = KYO_NO, NPC = F16_PIECES;
   // channel pitch of a pixel in LDS (halves): CIN + the ones channel, rounded to 8 bytes; a pitch of 0 (mod 8) dwords would
   // put the 8 pixel quads of a transpose read on the same banks, so those get 4 more halves (30 channels -> 36)
   static constexpr int CP0 = (CIN + 1 + 3) & ~3;
@@ -200,7 +200,7 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
           const _Float16 l = (_Float16)(r1 - (float)m);
           pk[j][0] = __builtin_bit_cast(unsigned short, h);
           pk[j][1] = __builtin_bit_cast(unsigned short, m);
-          pk[j][2] = __builtin_bit_cast(unsigned short, l);
+          if (NPC > 2) pk[j][NPC - 1] = __builtin_bit_cast(unsigned short, l);
         }
 #pragma unroll
         for (int pc = 0; pc < NPC; ++pc) tpc[k][tk][pc] = pk[0][pc] | (pk[1][pc] << 16);
@@ -256,7 +256,7 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
         const _Float16 l = (_Float16)(r1 - (float)m);
         lds_store(ddst[c], slot * DSLOT, __builtin_bit_cast(unsigned short, h));
         lds_store(ddst[c], slot * DSLOT + G::DPC, __builtin_bit_cast(unsigned short, m));
-        lds_store(ddst[c], slot * DSLOT + 2 * G::DPC, __builtin_bit_cast(unsigned short, l));
+        if (NPC > 2) lds_store(ddst[c], slot * DSLOT + 2 * G::DPC, __builtin_bit_cast(unsigned short, l));
       }
     }
   };

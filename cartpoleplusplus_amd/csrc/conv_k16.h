@@ -39,16 +39,30 @@ typedef unsigned k16_u32x4 __attribute__((ext_vector_type(4)));
 // exponent range: no scaling); the previous layer's epilogue writes its pooled output as three bf16 planes next to the
 // f32 tensor, this kernel loads the planes like conv1 loads pixels, the weights are split the same way and all 3 x 3 exact
 // products are issued (nine 16-cycle MFMAs instead of eight 32-cycle ones per 32 k values; no ones channel, no whitening).
-// Which of the nine piece products are issued.  With round-to-nearest pieces |m| <= 2^-9 |x| and |l| <= 2^-18 |x|, so the products
-// m*l, l*m and l*l together are below 2^-26 of the product -- a quarter of the rounding of ONE f32 accumulation step, of which every
-// output takes K = 250 -- and against the float64 oracle the six-product result is as close as the nine-product one (pooled conv2
-// output 4.47e-6 / 4.47e-6 abs at magnitude 7.5, weight gradient 5.8e-7 / 6.0e-7 rel; the f32-input MFMA kernels: 4.77e-6, 7.5e-7;
+// Which of the nine piece products are issued.  With round-to-nearest pieces x = h + m + l has |m| <= 2^-8 |x| and |l| <= 2^-17 |x|
+// (a piece's remainder is at most half its last place), so the products m*l, l*m and l*l together are at most 2^-24 |x y| -- half an
+// f32 ulp of the product, worst case; each output then takes K = 250 f32 accumulation steps that round by as much of the running sum.
+// Against the float64 oracle the six-product result is as close as the nine-product one (pooled conv2 output 4.47e-6 / 4.47e-6 abs
+// at magnitude 7.5, weight gradient 5.8e-7 / 6.0e-7 rel; the f32-input MFMA kernels: 4.77e-6, 7.5e-7;
 // profiles/experiments/r03_b16_products.txt).  The kernels' B16 / ORDER template value is the largest i + j (h = 0, m = 1, l = 2)
-// still issued: B16_SIX everywhere; B16_NINE instances exist in the ablation build (CPP_B16_PRODUCTS=9).
+// still issued: B16_SIX in the release build; B16_NINE instances exist in the ablation builds (CPP_B16_PRODUCTS=9; the default of
+// libcartpolepp_hip_exact.so).
+//
+// F16_PIECES: f16 pieces of conv1's f32 operand (weights in the forward kernel, dY in conv_dw16.h; the other operand is the raw f16
+// pixel, exact).  Two round-to-nearest pieces h + m leave |x - h - m| <= 2^-23 |x|: the operand is within ONE f32 ulp (the sign of m
+// is the 23rd bit; a third piece holds what is left, at most one bit).  Against the float64 oracle at 64x64x18, B = 256: pooled conv1
+// output 3.2e-6 (two) / 3.7e-6 (three) / 7.0e-6 (f32-input MFMA) max abs at magnitude 7.1, conv1 weight gradient 1.22e-6 / 1.19e-6 /
+// 1.69e-6 rel (profiles/experiments/r03_f16_pieces.txt).  Release: 2; libcartpolepp_hip_exact.so: 3 (every product exact).
+#ifndef F16_PIECES
+#define F16_PIECES 2
+#endif
+#ifndef B16_DEFAULT_PRODUCTS
+#define B16_DEFAULT_PRODUCTS 6
+#endif
 #define B16_SIX 2
 #define B16_NINE 4
 static inline int b16_order() {
-  static const int o = cpp_switch_int("CPP_B16_PRODUCTS", 6) == 9 ? B16_NINE : B16_SIX;
+  static const int o = cpp_switch_int("CPP_B16_PRODUCTS", B16_DEFAULT_PRODUCTS) == 9 ? B16_NINE : B16_SIX;
   return o;
 }
 __device__ __forceinline__ unsigned k16_bf16_bits(float x) {        // round-to-nearest-even bf16 of a finite f32
@@ -95,7 +109,7 @@ struct K16Geom {
   static constexpr int KAUG = B16 ? KROW : KROW + KS;      // + the ones channel (kx)
   static constexpr int NPA = B16 ? 3 : 1;                  // planes of the A operand
   static constexpr int NCH = (KAUG + 31) / 32;             // MFMA k chunks per row
-  static constexpr int NPC = 3;                            // f16 pieces of a weight
+  static constexpr int NPC = B16 ? 3 : F16_PIECES;         // f16 / bf16 pieces of a weight
   // weight image in LDS: slab (chunk, piece) holds the 16-byte operand (ky, lane group g, o) at ky*PS + g*GS + o*16;
   // the padded strides keep the rotating per-lane reads of a ds_read_b128 at 1.2 accesses per bank quad (2.45 compact)
 #ifdef K16_MID_LAYOUT
@@ -253,7 +267,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
         unsigned char* dst = wl + ky * G::PS + g * G::GS + o * 16 + e * 2;
         *reinterpret_cast<unsigned short*>(dst + (ch * NPC + 0) * G::SLAB) = h;
         *reinterpret_cast<unsigned short*>(dst + (ch * NPC + 1) * G::SLAB) = m;
-        *reinterpret_cast<unsigned short*>(dst + (ch * NPC + 2) * G::SLAB) = l;
+        if (NPC > 2) *reinterpret_cast<unsigned short*>(dst + (ch * NPC + 2) * G::SLAB) = l;
       }
     }
   }

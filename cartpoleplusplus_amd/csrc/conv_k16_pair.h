@@ -137,7 +137,7 @@ __global__ __launch_bounds__(CONV_THREADS, 1) void conv_fwd_k16_pair_kernel(cons
           unsigned char* dst = wl + k * G::WLB + ky * G::PS + g * G::GS + o * 16 + e * 2;
           *reinterpret_cast<unsigned short*>(dst + (ch * NPC + 0) * G::SLAB) = __builtin_bit_cast(unsigned short, hh);
           *reinterpret_cast<unsigned short*>(dst + (ch * NPC + 1) * G::SLAB) = __builtin_bit_cast(unsigned short, mm);
-          *reinterpret_cast<unsigned short*>(dst + (ch * NPC + 2) * G::SLAB) = __builtin_bit_cast(unsigned short, ll);
+          if (NPC > 2) *reinterpret_cast<unsigned short*>(dst + (ch * NPC + 2) * G::SLAB) = __builtin_bit_cast(unsigned short, ll);
         }
       }
     }

@@ -59,7 +59,7 @@ void prof_end(cpp_ctx* ctx, int kid) {
 static const char* kKernelNames[K_NUM_KERNELS] = {
     "gather_stats", "stats_finalize", "stats_generic", "conv1_fwd", "conv2_fwd", "conv3_fwd",
     "conv1_dw", "conv2_dw", "conv3_dw", "conv2_dx", "conv3_dx", "dw_reduce", "gemm", "elementwise",
-    "td", "sumsq", "clip_sgd", "soft_update", "replay_fill", "naf_head", "conv1_fwd_f16x3", "conv1_dw_f16x3", "heads", "conv3_bwd", "conv2_bwd", "reduce_gather", "conv1_dw_gather"};
+    "td", "sumsq", "clip_sgd", "soft_update", "replay_fill", "naf_head", "conv1_fwd_f16", "conv1_dw_f16", "heads", "conv3_bwd", "conv2_bwd", "reduce_gather", "conv1_dw_gather"};
 
 // ---------------------------------------------------------------------------------------------
 // context

@@ -27,13 +27,13 @@ SHORT = [("void conv_fwd_kernel<18, 5, 4, 0, 0>", "conv1_fwd"), ("void conv_dw_k
          ("void conv_fwd_kyo_kernel<10, 3, 1, 4, 2,", "conv3_fwd"), ("void conv_dw_kyo_kernel<18, 5", "conv1_dw"),
          ("void conv_fwd_kyo_kernel<10, 5, 1, 2, 3,", "conv2_dx"), ("void conv_dw_kyo_kernel<10, 5", "conv2_dw"),
          # f16 pipes with f32-exact operands
-         ("void conv_fwd_k16_kernel<18, 5", "conv1_fwd_f16x3"), ("void conv_dw16_kernel<18, 5", "conv1_dw_f16x3"),
+         ("void conv_fwd_k16_kernel<18, 5", "conv1_fwd_f16"), ("void conv_dw16_kernel<18, 5", "conv1_dw_f16"),
          # bf16 pipes (conv2), whole-image conv3 forward, the fused heads, and the launches that carry two kernels
          ("void conv_fwd_k16_kernel<10, 5", "conv2_fwd"), ("void conv_dwb16_kernel<10, 5", "conv2_dw"), ("conv3_img_kernel", "conv3_fwd"),
          ("void ddpg_heads_kernel", "heads"), ("conv3_bwd_pair_kernel", "conv3_bwd"), ("conv2_bwd_pair_kernel", "conv2_bwd"), ("void conv2_bwd_pair_kernel", "conv2_bwd"),
          ("void reduce_gather_kernel<__half>", "reduce_gather"), ("conv1_dw_gather_kernel", "conv1_dw_gather"),
          # round 3: two networks per conv1-dW workgroup (conv_dw16.h NNET = 2)
-         ("conv1_dw_pair_gather_kernel", "conv1_dw_gather"), ("void conv_dw16_pair_kernel<18, 5", "conv1_dw_f16x3")]
+         ("conv1_dw_pair_gather_kernel", "conv1_dw_gather"), ("void conv_dw16_pair_kernel<18, 5", "conv1_dw_f16")]
 
 
 def short(name):

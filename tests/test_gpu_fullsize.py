@@ -181,22 +181,29 @@ agent.close()
 """
 
 
-def test_f16x3_conv1_is_as_close_to_the_f64_oracle_as_the_f32_mfma_kernel():
-    """conv_k16.h claims f32-grade results (exact f16 x f16 products of the same operands, f32 accumulation): its pooled
-    conv1 output must sit as close to the float64 oracle as the f32-MFMA kernel's (CPP_CONV_K16=0), far inside 1e-5."""
+_F16_BUILDS = (("two", {"CARTPOLEPP_ABLATION": "1"}), ("three", {"CARTPOLEPP_ABLATION": "exact"}),
+               ("f32", {"CARTPOLEPP_ABLATION": "1", "CPP_CONV_K16": "0"}))
+
+
+def test_f16_piece_conv1_is_as_close_to_the_f64_oracle_as_the_f32_mfma_kernel():
+    """conv_k16.h claims f32-grade results (f16 x f16 products, exact; f32 accumulation) from two f16 pieces of each weight (the
+    shipped kernels: the weight to within one f32 ulp) and from three (libcartpolepp_hip_exact.so: the weight itself): the pooled conv1
+    output must sit as close to the float64 oracle as the f32-MFMA kernel's (CPP_CONV_K16=0), far inside 1e-5."""
     import os, re, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     errs = {}
-    for k16 in ("1", "0"):
-        r = subprocess.run([sys.executable, "-c", _CONV1_ERR_SNIPPET], cwd=root, env=dict(os.environ, CARTPOLEPP_ABLATION="1", CPP_CONV_K16=k16),
+    for name, env in _F16_BUILDS:
+        r = subprocess.run([sys.executable, "-c", _CONV1_ERR_SNIPPET], cwd=root, env=dict(os.environ, **env),
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
         m = re.search(r"CONV1ERR (\S+) (\S+)", r.stdout.decode())
         assert r.returncode == 0 and m, r.stdout.decode()[-1500:]
-        errs[k16] = (float(m.group(1)), float(m.group(2)))
-    (e16, mag), (e32, _) = errs["1"], errs["0"]
+        errs[name] = (float(m.group(1)), float(m.group(2)))
+    (e32, mag) = errs["f32"]
     assert mag > 0.5                                   # outputs of order one and more
-    assert e16 < 1e-5 and e32 < 1e-5, errs             # (measured: 3.7e-6 vs 7.0e-6 at |z| up to 7.1)
-    assert e16 <= 1.25 * e32 + 1e-7, errs
+    assert e32 < 1e-5, errs                            # (measured: two 3.2e-6, three 3.7e-6, f32 7.0e-6 at |z| up to 7.1)
+    for name in ("two", "three"):
+        assert errs[name][0] < 1e-5 and errs[name][0] <= 1.25 * e32 + 1e-7, (name, errs)
+    assert errs["two"][0] <= 1.25 * errs["three"][0] + 1e-7, errs
 
 
 def test_f32_mfma_conv1_stays_parity_green_when_selected():
@@ -245,20 +252,21 @@ agent.close()
 """
 
 
-def test_f16x3_conv1_dw_is_as_close_to_the_f64_oracle_as_the_f32_mfma_kernel():
-    """conv_dw16.h: conv1's weight gradient from exact f16 x f16 products must match the float64 oracle (with the
-    device's pooling routes) at least as well as the f32-MFMA kernel does."""
+def test_f16_piece_conv1_dw_is_as_close_to_the_f64_oracle_as_the_f32_mfma_kernel():
+    """conv_dw16.h: conv1's weight gradient from f16 x f16 products of the raw pixels and two (shipped) / three (exact build) f16
+    pieces of dY must match the float64 oracle (with the device's pooling routes) at least as well as the f32-MFMA kernel does."""
     import os, re, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     errs = {}
-    for k16 in ("1", "0"):
-        r = subprocess.run([sys.executable, "-c", _CONV1_DW_ERR_SNIPPET], cwd=root, env=dict(os.environ, CARTPOLEPP_ABLATION="1", CPP_CONV_K16=k16),
+    for name, env in _F16_BUILDS:
+        r = subprocess.run([sys.executable, "-c", _CONV1_DW_ERR_SNIPPET], cwd=root, env=dict(os.environ, **env),
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
         m = dict(re.findall(r"DWERR (\S+) (\S+)", r.stdout.decode()))
         assert r.returncode == 0 and "weights" in m, r.stdout.decode()[-1500:]
-        errs[k16] = float(m["weights"])
-    assert errs["1"] < 5e-6 and errs["0"] < 5e-6, errs
-    assert errs["1"] <= 1.25 * errs["0"] + 1e-8, errs
+        errs[name] = float(m["weights"])
+    assert max(errs.values()) < 5e-6, errs             # (measured: two 1.22e-6, three 1.19e-6, f32 1.69e-6)
+    assert errs["two"] <= 1.25 * errs["f32"] + 1e-8 and errs["three"] <= 1.25 * errs["f32"] + 1e-8, errs
+    assert errs["two"] <= 1.25 * errs["three"] + 1e-8, errs
 
 
 _CONV2_ERR_SNIPPET = r"""
@@ -292,8 +300,9 @@ def test_bf16_conv2_is_as_close_to_the_f64_oracle_as_the_f32_mfma_kernels():
     import os, re, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for name, extra in (("six", {}), ("nine", {"CPP_B16_PRODUCTS": "9"}), ("f32", {"CPP_CONV_B16": "0"})):
-        r = subprocess.run([sys.executable, "-c", _CONV2_ERR_SNIPPET], cwd=root, env=dict(os.environ, CARTPOLEPP_ABLATION="1", **extra),
+    for name, extra in (("six", {"CARTPOLEPP_ABLATION": "1"}), ("nine", {"CARTPOLEPP_ABLATION": "1", "CPP_B16_PRODUCTS": "9"}),
+                        ("f32", {"CARTPOLEPP_ABLATION": "1", "CPP_CONV_B16": "0"}), ("exact", {"CARTPOLEPP_ABLATION": "exact"})):
+        r = subprocess.run([sys.executable, "-c", _CONV2_ERR_SNIPPET], cwd=root, env=dict(os.environ, **extra),
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
         out = r.stdout.decode()
         f, d = re.search(r"C2FWD (\S+) (\S+)", out), re.search(r"C2DW (\S+)", out)
@@ -301,7 +310,7 @@ def test_bf16_conv2_is_as_close_to_the_f64_oracle_as_the_f32_mfma_kernels():
         res[name] = (float(f.group(1)), float(f.group(2)), float(d.group(1)))
     (f32e, mag, d32e) = res["f32"]
     assert f32e < 1e-5 * max(1.0, mag) and d32e < 5e-6, res
-    for name in ("six", "nine"):
+    for name in ("six", "nine", "exact"):      # (exact: nine products behind a three-piece conv1)
         fe, _, de = res[name]
         assert fe < 1e-5 * max(1.0, mag) and fe <= 1.5 * f32e + 1e-7 * max(1.0, mag), (name, res)
         assert de < 5e-6 and de <= 1.5 * d32e + 1e-8, (name, res)

@@ -1,6 +1,6 @@
 """The fused inner step at the sizes BASELINE.json's metric is quoted on, against the float64 oracle at north_star's bar
 (actions / Q / TD within 1e-5; pre-clip gradients of BOTH networks per variable at 2e-5) -- the path bench.py times: default
-kernels (f16x3 conv1 reading the replay store through the sampled slots, bf16x6 conv2, fused heads, paired launches), the
+kernels (f16x2 conv1 reading the replay store through the sampled slots, bf16x6 conv2, fused heads, paired launches), the
 hipGraph replay, device-drawn rows.  Match: ddpg_cartpole.py:329-337, base_network.py:95-127."""
 import numpy as np
 import pytest

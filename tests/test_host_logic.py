@@ -58,7 +58,7 @@ def test_bench_flop_accounting_matches_the_survey():
         assert abs(2.0 * B * (4 * F + 2 * Bk) / 1e9 - gf) < 0.05 * max(1.0, gf / 100)
     F50 = bench.conv_macs((50, 50, 3, 1, 2))[0]                          # the default render: 5.44 MMAC per image
     assert abs(F50 / 1e6 - 5.44) < 0.01
-    assert bench.PIPES["f16x3"][0] == bench.PEAK_F16_MFMA_TFLOPS / 3.0 and bench.PIPES["bf16x6"][0] == bench.PEAK_F16_MFMA_TFLOPS / 6.0
+    assert bench.PIPES["f16x2"][0] == bench.PEAK_F16_MFMA_TFLOPS / 2.0 and bench.PIPES["f16x3"][0] == bench.PEAK_F16_MFMA_TFLOPS / 3.0 and bench.PIPES["bf16x6"][0] == bench.PEAK_F16_MFMA_TFLOPS / 6.0
 
 
 def test_host_gradient_helpers_follow_util_py():
