@@ -614,7 +614,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #ifdef K16_CLOCK_PROBE
   if (lane == 0 && (blockIdx.x % 97) == 5 && blockIdx.y == 1 && wave == 0) {
     const unsigned long long pc1 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
-    printf("K16CLK block %d: %llu core cycles, %llu ref ticks (100 MHz) in the row loop -> %.3f GHz; weight image %llu ticks, setup to loop %llu ticks\n", (int)blockIdx.x, pc1 - pc0, pr1 - pr0,
+    printf("K16CLK cin %d block %d: %llu core cycles, %llu ref ticks (100 MHz) in the row loop -> %.3f GHz; weight image %llu ticks, setup to loop %llu ticks\n", CIN, (int)blockIdx.x, pc1 - pc0, pr1 - pr0,
            (double)(pc1 - pc0) / (10.0 * (double)(pr1 - pr0)), pe1 - pe0, pr0 - pe1);
   }
 #endif

@@ -1,6 +1,6 @@
 #!/bin/bash
 # conv2 forward / dW on the bf16 pipes with six of the nine piece products (B16_MAX_ORDER=2: h*h, h*m, m*h, h*l, m*m, l*h; the dropped
-# m*l, l*m, l*l are <= 2^-26 of the product with round-to-nearest pieces) against all nine and against the f32-input MFMA kernels:
+# m*l, l*m, l*l are <= 2^-24 of the product with round-to-nearest pieces) against all nine and against the f32-input MFMA kernels:
 # error against the float64 oracle (pooled conv2 output, conv2 weight gradient) and steps/s on the same box.
 # build first: UNITS="conv conv2_bwd_pair conv_dwb16 conv_fwd_k16" bash profiles/experiments/build_dw16_variants.sh six "-DB16_MAX_ORDER=2"
 cd "$(dirname "$0")/../.."

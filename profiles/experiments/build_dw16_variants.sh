@@ -16,6 +16,7 @@ while [ $# -ge 2 ]; do
   objs=""
   for o in $(ls $OBJ/*.o); do
     b=$(basename $o .o)
+    case $b in exact_*) continue;; esac      # (the exact-products library's objects)
     skip=0; for f in $UNITS; do if [ "$b" = "$f" ] || [ "$b" = "abl_$f" ]; then skip=1; fi; done
     [ $skip = 1 ] && continue
     # release objects that have an ablation twin are dropped in favour of the twin

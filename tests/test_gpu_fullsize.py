@@ -294,8 +294,8 @@ agent.close()
 
 
 def test_bf16_conv2_is_as_close_to_the_f64_oracle_as_the_f32_mfma_kernels():
-    """conv2 forward / dW from three bf16 pieces per operand (conv_k16.h B16 mode, conv_dwb16.h) -- the six piece products above
-    2^-26 of the result (the shipped kernels), all nine (CPP_B16_PRODUCTS=9, ablation build) -- against CPP_CONV_B16=0 (f32-input
+    """conv2 forward / dW from three bf16 pieces per operand (conv_k16.h B16 mode, conv_dwb16.h) -- the six largest piece products
+    (the shipped kernels; the dropped three are at most 2^-24 of the product), all nine (CPP_B16_PRODUCTS=9, ablation build) -- against CPP_CONV_B16=0 (f32-input
     MFMA): pooled conv2 output and conv2 weight gradient vs the float64 oracle."""
     import os, re, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
