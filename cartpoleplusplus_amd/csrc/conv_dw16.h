@@ -1,12 +1,13 @@
-// conv1 weight / bias gradient on the f16 matrix pipes with f32-exact operands ("dw16"): v_mfma_f32_16x16x32_f16.
+// conv1 weight / bias gradient on the f16 matrix pipes with f32-grade operands ("dw16"): v_mfma_f32_16x16x32_f16.
 //
 //   dW[ky][kx][c][o] = sum_{b,q,x} xw[b, q, x + kx - P, c] * dY[b, q - ky + P, x, o],   xw = x * s_c + t_c inside the image, 0 in the padding
 //                    = s_c * G[ky][kx][c][o] + t_c * T[ky][kx][o]
 //   G = the same correlation with the RAW f16 pixel x (exact in f16: replay_memory.py:32), T = the same with the "ones" channel
 //   (1 inside the image) -- both come out of ONE MFMA stream whose A rows are (kx, c'), c' = 0..CIN-1 the pixel channels, CIN the
-//   ones channel.  dY (f32) is split into three f16 pieces dY 2^S = h + m + l (S from the largest |pooled gradient| the
-//   workgroup will see), every f16 x f16 product is exact, the accumulators are f32: the f32-MFMA kernel's arithmetic
-//   (conv_dw_kyo.h) with exact products, three 16-cycle MFMAs per 32 pixels instead of eight 32-cycle ones.
+//   ones channel.  dY (f32) is split into F16_PIECES f16 pieces dY 2^S = h + m (+ l) (S from the largest |pooled gradient| the
+//   workgroup will see; conv_k16.h: two pieces = dY to within one f32 ulp, release; three = dY itself, exact build), every
+//   f16 x f16 product is exact, the accumulators are f32: the f32-MFMA kernel's arithmetic (conv_dw_kyo.h), two / three 16-cycle
+//   MFMAs per 32 pixels instead of eight 32-cycle ones.
 //
 // Formulation as conv_dw_kyo.h: per input row q,  D[m = (kx,c'), n = (ky,o)] += A[m, pixel] * B[pixel, n]; wave w owns column
 // tile w of (ky,o) and all MT row tiles; units = (image, band of rows); one partial per workgroup (whitening applied to it:

@@ -1,4 +1,4 @@
-// conv1 forward on the f16 matrix pipes with f32-exact operands ("k16"): v_mfma_f32_16x16x32_f16.
+// conv1 forward on the f16 matrix pipes with f32-grade operands ("k16"): v_mfma_f32_16x16x32_f16.
 //
 // The images of this path are 8-bit renders held as f16 (replay_memory.py:32, bullet_cartpole.py:239-243), so the A
 // operand of conv1 is EXACT in f16 as long as it is the raw pixel.  The whitening of base_network.py:95-99 is affine
@@ -8,12 +8,13 @@
 //
 // where 1[.] is a "ones" channel that is 1 inside the image and 0 in the padding -- the shift term with exactly the
 // zero-padding semantics of the whitened tensor, as CIN+.. extra k values (KS per input row: 90 + 5 = 95 <= 96 for the
-// 5x5x18 layer, no extra MFMA).  The f32 weights V = W s (and the ones weights) are split into three f16 pieces
-// V 2^S = h + m + l (h = f16(V 2^S), m = f16(rest), l = f16(rest); S puts the largest |V| just under 2^15), every
-// f16 x f16 product is exact in the f32 accumulator, and the three MFMAs of a k chunk add  x * (h + m + l): the
-// result is the f32-accumulated sum of exact products of the SAME operands the f32 kernel uses -- no operand is
-// rounded to fewer than its 24 bits (pieces below the f16 normal range keep an absolute 2^-24-S floor, < 1e-9 of the
-// largest weight).  Three 16-cycle MFMAs replace eight 32-cycle ones per 32 k values.
+// 5x5x18 layer, no extra MFMA).  The f32 weights V = W s (and the ones weights) are split into F16_PIECES f16 pieces
+// V 2^S = h + m (+ l) (h = f16(V 2^S), m = f16(rest), l = f16(rest); S puts the largest |V| just under 2^15), every
+// f16 x f16 product is exact in the f32 accumulator, and the MFMAs of a k chunk add  x * (h + m (+ l)).  With three pieces
+// (libcartpolepp_hip_exact.so) that is the f32-accumulated sum of exact products of the SAME operands the f32 kernel uses -- no
+// operand rounded to fewer than its 24 bits (pieces below the f16 normal range keep an absolute 2^-24-S floor, < 1e-9 of the
+// largest weight); with two (the release library) every weight is within one f32 ulp of itself (F16_PIECES below).  Two / three
+// 16-cycle MFMAs replace eight 32-cycle ones per 32 k values.
 //
 // Everything else is the (ky,o)-column formulation of conv_kyo.h: one input row per step, KS in-flight output rows
 // in the accumulators, rotating weights read from LDS at per-lane addresses, bias folded into the accumulator reset

@@ -15,15 +15,18 @@
  *   - host pointers are read/written only for the duration of the call.
  *   - a cpp_ctx is one GPU + one HIP stream; calls on one ctx are serialised by the caller
  *     (the reference is single-threaded: one implicit tf.Session).
- *   - results are f32-grade: IEEE f32 accumulation of EXACT products of the reference's f32 / f16 operands.  Where an
- *     operand already is an f16 number (conv1's input: the replay store's pixels, replay_memory.py:32) the other, f32, operand
- *     is split into three f16 pieces whose sum is the f32 value, and the three exact f16 x f16 products are accumulated in f32
- *     (v_mfma_f32_16x16x32_f16); conv2's forward and dW split BOTH f32 operands into three bf16 pieces and issue all nine exact
- *     products (v_mfma_f32_16x16x32_bf16); everything else multiplies f32 operands directly (v_mfma_f32_16x16x4_f32).  No
- *     operand is ever rounded to a narrower type, no product is dropped.  f32 states, odd layouts and
- *     B = 1 run on the f32-input MFMA kernels throughout.  The release library has no run-time kernel switches; the ablation
- *     build (libcartpolepp_hip_ablation.so, CARTPOLEPP_ABLATION=1) can force the f32-input kernels everywhere
- *     (CPP_CONV_K16=0 CPP_CONV_B16=0) -- bench.py's `control` run.
+ *   - results are f32-grade: IEEE f32 accumulation of products of the reference's f32 / f16 operands, far inside the 1e-5 the
+ *     parity tests allow and measured as close to a float64 evaluation as f32-input matrix instructions get.  Where an operand
+ *     already is an f16 number (conv1's input: the replay store's pixels, replay_memory.py:32) the other, f32, operand is split by
+ *     round-to-nearest into f16 pieces and the f16 x f16 products -- each exact -- are accumulated in f32 (v_mfma_f32_16x16x32_f16):
+ *     two pieces in the release library (the operand to within one f32 ulp), three in libcartpolepp_hip_exact.so (the operand
+ *     itself).  conv2's forward and dW split BOTH f32 operands into three bf16 pieces (exactly) and issue the six largest of the
+ *     nine piece products (release: the dropped three are at most half an f32 ulp of the product) or all nine (exact build)
+ *     (v_mfma_f32_16x16x32_bf16); everything else multiplies f32 operands directly (v_mfma_f32_16x16x4_f32).  DESIGN.md section 4.
+ *     f32 states, odd layouts and B = 1 run on the f32-input MFMA kernels throughout.  The release library has no run-time kernel
+ *     switches; the ablation build (libcartpolepp_hip_ablation.so, CARTPOLEPP_ABLATION=1) can force the f32-input kernels
+ *     everywhere (CPP_CONV_K16=0 CPP_CONV_B16=0) -- bench.py's `control` run; CARTPOLEPP_ABLATION=exact loads the exact-product
+ *     build -- bench.py's `control_exact_products` run.
  *   - replay states are stored as f16 exactly like replay_memory.py:32 (or as their 8-bit pixel codes); indices are int32.
  *   - state batches handed to the conv kernels always live in the library's own guard-banded device allocations (host
  *     pointers are copied in first); the f16-pipe kernels refuse anything else.
