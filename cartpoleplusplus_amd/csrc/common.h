@@ -86,6 +86,7 @@ struct cpp_ctx {
   // list); the optimiser kernel adds a list's partials in slot order.  sq_n: slots handed out so far, -1: folding off (the sumsq
   // kernel runs instead: data-parallel steps, whose gradients change in the all-reduce; batch norm; NAF).
   double* sq_part; int sq_n[2]; int sq_conv_group[4];
+  unsigned* gemm_chain;           // GEMM_CHAIN_SLOTS counters of the chained GEMM launches (zero between launches)
 };
 #define SQ_REGION 2048
 
@@ -206,9 +207,15 @@ struct GemmArgs {
   float* C2; long ldc2;         // optional second copy of the output (e.g. actions straight into the critic's input)
   const uint64_t* drop_counter; uint32_t drop_seed, drop_layer;   // GE_RELU_DROPOUT
   double* sq_part;              // non-null: tile t also leaves the f64 sum of squares of its outputs in sq_part[t] (see cpp_ctx::sq_part)
+  // chained launch (launch_gemm_chain): a problem whose operands are written by problems of the SAME launch waits until
+  // chain[wait_slot[i]] == wait_cnt[i] (every tile of that producer has stored and released its outputs); a producer's tiles
+  // add one to chain[signal_slot] when they are done.  Slots are >= 1; 0 = none.
+  int wait_slot[2], wait_cnt[2], signal_slot;
 };
-#define GEMM_BATCH_MAX 8
-struct GemmBatch { GemmArgs g[GEMM_BATCH_MAX]; int tile_start[GEMM_BATCH_MAX + 1]; int n; };
+#define GEMM_BATCH_MAX 16
+#define GEMM_CHAIN_SLOTS 32     // cpp_ctx::gemm_chain: [0] consumer tiles that passed their wait, [1 ..] producer counters
+// chain: non-null for a chained launch; chain_consumers = number of tiles that wait (the last one to pass resets the counters)
+struct GemmBatch { GemmArgs g[GEMM_BATCH_MAX]; int tile_start[GEMM_BATCH_MAX + 1]; int n; unsigned* chain; int chain_consumers, chain_slots; };
 // kernel attributes (dynamic LDS size) are set once per kernel AND device: the launchers keep one flag per device slot
 #define CPP_MAX_DEVICES 16
 static inline int cpp_dev_slot(const cpp_ctx* ctx) { return ctx->device >= 0 && ctx->device < CPP_MAX_DEVICES ? ctx->device : 0; }
@@ -220,6 +227,9 @@ static inline __host__ __device__ int gemm_sub(int M, int N, int K) { return (K 
 static inline int gemm_tiles(int M, int N, int K) { const int e = 16 * gemm_sub(M, N, K); return ((M + e - 1) / e) * ((N + e - 1) / e); }
 int launch_gemm(cpp_ctx* ctx, const GemmArgs& g);
 int launch_gemm_batch(cpp_ctx* ctx, const GemmArgs* list, int n);   // independent GEMMs in one launch
+// two dependent levels of GEMMs in ONE launch: list[0 .. n) in dispatch order (producers first); list[i].wait_slot / wait_cnt /
+// signal_slot describe the dependencies inside the launch.  Needs n <= GEMM_BATCH_MAX.
+int launch_gemm_chain(cpp_ctx* ctx, const GemmArgs* list, int n, int nslots);
 int launch_copy_cols(cpp_ctx* ctx, float* dst, long ldd, int dcol0, const float* src, long lds_,
                      int scol0, int ncols, int rows);
 int launch_fill(cpp_ctx* ctx, float* dst, long ld, int col0, int ncols, int rows, float v);

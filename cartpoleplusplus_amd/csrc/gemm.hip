@@ -31,7 +31,7 @@
 // quarter of the workgroups, each four times as long, on a chip the 1 x 1 tiling does not fill either.  Kept for the record and for
 // larger problems.  Every output sums its products in the same order in both (same K split over the waves, same k order inside a
 // round): bit-identical results.
-template <bool VA, bool VB, int S>
+template <bool VA, bool VB, int S, bool COH = false>
 __device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (*red)[GEMM_RED]) {
 #ifdef GEMM_CLOCK
   const unsigned long long c0 = __builtin_amdgcn_s_memrealtime();
@@ -64,6 +64,11 @@ __device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (
   // k = K is in range as a whole; its tail is cleared by selects.
   typedef unsigned gemm_u4 __attribute__((ext_vector_type(4)));
   constexpr int OOB = 0x7FFFFF00;
+  // COH (a producer problem of a chained launch, gemm_chain_kernel): the outputs are written through with sc1 stores.  The consumers'
+  // loads stay plain: no L2 / L1 can hold a line of a producer's output before the producer is complete (caches are invalidated at
+  // the launch boundary and nobody reads those buffers before the counter is full), so the first touch fetches the written-through
+  // data.  (sc1 on the consumers' loads sends ALL their operand traffic past the L2: 60 us per launch instead of 16 for two levels.)
+  constexpr int AUX = 0;
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(g.A), 0, (int)((((long)(g.M - 1) * g.sAm + (long)(g.K - 1) * g.sAk) + 1) * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
@@ -85,15 +90,15 @@ __device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (
 #pragma unroll
       for (int q = 0; q < U / 4; ++q) {
         const int k = kb + 4 * q;
-        if (va) av[r][i][q] = __builtin_amdgcn_raw_buffer_load_b128(ra, (mv[i] & (k < g.K)) ? abase[i] + k * 4 : OOB, 0, 0);
+        if (va) av[r][i][q] = __builtin_amdgcn_raw_buffer_load_b128(ra, (mv[i] & (k < g.K)) ? abase[i] + k * 4 : OOB, 0, AUX);
         else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) av[r][i][q][e] = __builtin_amdgcn_raw_buffer_load_b32(ra, (mv[i] & (k + e < g.K)) ? abase[i] + (k + e) * ask : OOB, 0, 0);
+          for (int e = 0; e < 4; ++e) av[r][i][q][e] = __builtin_amdgcn_raw_buffer_load_b32(ra, (mv[i] & (k + e < g.K)) ? abase[i] + (k + e) * ask : OOB, 0, AUX);
         }
-        if (vb) bv[r][i][q] = __builtin_amdgcn_raw_buffer_load_b128(rb, (nv[i] & (k < g.K)) ? bbase[i] + k * 4 : OOB, 0, 0);
+        if (vb) bv[r][i][q] = __builtin_amdgcn_raw_buffer_load_b128(rb, (nv[i] & (k < g.K)) ? bbase[i] + k * 4 : OOB, 0, AUX);
         else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) bv[r][i][q][e] = __builtin_amdgcn_raw_buffer_load_b32(rb, (nv[i] & (k + e < g.K)) ? bbase[i] + (k + e) * bsk : OOB, 0, 0);
+          for (int e = 0; e < 4; ++e) bv[r][i][q][e] = __builtin_amdgcn_raw_buffer_load_b32(rb, (nv[i] & (k + e < g.K)) ? bbase[i] + (k + e) * bsk : OOB, 0, AUX);
         }
       }
     }
@@ -160,10 +165,14 @@ __device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (
         }
       }
       else if (g.epi == GE_MUL_TANH_GRAD) { const float y = g.Y[(long)row * g.ldy + n]; v = v * (1.f - y * y); }
-      g.C[(long)row * g.ldc + n] = v;
+      if (COH) __hip_atomic_store(g.C + ((long)row * g.ldc + n), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else g.C[(long)row * g.ldc + n] = v;
       sq += (double)v * (double)v;
       if (g.epi == GE_ACTOR_HEAD) { const float y = g.Y[(long)row * g.ldy + n]; g.C2[(long)row * g.ldc2 + n] = -v * (1.f - y * y); }
-      else if (g.C2) g.C2[(long)row * g.ldc2 + n] = v;
+      else if (g.C2) {
+        if (COH) __hip_atomic_store(g.C2 + ((long)row * g.ldc2 + n), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else g.C2[(long)row * g.ldc2 + n] = v;
+      }
     }
   }
 #ifdef GEMM_CLOCK
@@ -178,6 +187,7 @@ __device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (
 }
 
 // an operand that is contiguous in k is read with 16-byte loads; long-K problems take 2 x 2 sub-tiles (uniform per problem)
+template <bool COH = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, float (*red)[GEMM_RED]) {
   const bool va = g.sAk == 1, vb = g.sBk == 1;
 #if GEMM_SUB_MIN_K < 100000      // (not instantiated in the shipped build: gemm_sub() is 1 for every problem)
@@ -189,10 +199,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, float (*r
     return;
   }
 #endif
-  if (va && vb) gemm_tile_t<true, true, 1>(g, tile, red);
-  else if (va) gemm_tile_t<true, false, 1>(g, tile, red);
-  else if (vb) gemm_tile_t<false, true, 1>(g, tile, red);
-  else gemm_tile_t<false, false, 1>(g, tile, red);
+  if (va && vb) gemm_tile_t<true, true, 1, COH>(g, tile, red);
+  else if (va) gemm_tile_t<true, false, 1, COH>(g, tile, red);
+  else if (vb) gemm_tile_t<false, true, 1, COH>(g, tile, red);
+  else gemm_tile_t<false, false, 1, COH>(g, tile, red);
 }
 
 // Workgroup -> tile, XCD-aware: workgroup b of a launch runs on XCD b mod 8 (round-robin dispatch), each XCD has its own L2, and
@@ -224,6 +234,73 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(const GemmBatch gb) {
   int p = 0;
   while (p + 1 < gb.n && (int)blockIdx.x >= gb.tile_start[p + 1]) ++p;
   gemm_tile(gb.g[p], gemm_xcd_tile(blockIdx.x, gb.tile_start[p], gb.tile_start[p + 1] - gb.tile_start[p]), red);
+}
+
+// Two dependent levels of GEMMs in one launch -- an EXPERIMENT, off unless CPP_GEMM_CHAIN=1 in the ablation build (OpGraph::run).
+// Producers come first in the grid, so they are dispatched first (a workgroup is never dispatched before one with a lower index
+// on its XCD): a consumer that spins holds its slot only after every producer that shares its XCD's queue has one.  A producer
+// tile writes its outputs through (sc1 stores), waits for their acknowledgement and adds one to its problem's counter; a
+// consumer tile waits for its producers' counters to reach their tile counts and runs.  The counters are zero between launches:
+// the last consumer tile to pass its wait clears them.  Same tiles, same order of sums as the separate launches: bit-identical
+// outputs (tests/test_gpu_fullsize.py::test_chained_gemm_levels_...).
+// Measured (cfg3, four levels = 42.7 us per minibatch as separate launches; profiles/experiments/r03_gemm_chain.txt):
+//   agent-scope fence pair per tile (buffer_wbl2 sc1 / buffer_inv sc1: each walks the XCD's L2)   2 launches, 212 us
+//   sc1 stores + sc1 operand loads, no fences (all consumer operand traffic past the L2)           2 launches, 121 us
+//   sc1 stores, plain loads (this code)                                                           2 launches, 110 us
+//   ... the same without the waits (wrong results; signals kept)                                  40.4 us
+//   ... without waits and signals                                                                 33.1 us
+//   ... and with plain stores: the tiles of two levels side by side, no dependency at all         29.0 us
+// i.e. even a free synchronisation would win 14 us of 351, and the real one loses: ~1500 resident consumer workgroups polling one
+// address serialise at the memory side (~10-20 ns per device-scope access to one line; a longer s_sleep changes nothing), and
+// the producers' ~800 counter updates cost 7 us for the same reason.  A level is not "mostly its start and its end": its tiles
+// are.  Kept for the record; one launch per level stays.
+__global__ __launch_bounds__(256) void gemm_chain_kernel(const GemmBatch gb) {
+  __shared__ float red[3][GEMM_RED];
+  int p = 0;
+  while (p + 1 < gb.n && (int)blockIdx.x >= gb.tile_start[p + 1]) ++p;
+  const GemmArgs& g = gb.g[p];
+  if (g.wait_slot[0]) {                                // (uniform per workgroup)
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        if (g.wait_slot[i])
+          while (__hip_atomic_load(gb.chain + g.wait_slot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)g.wait_cnt[i])
+            __builtin_amdgcn_s_sleep(4);
+      const unsigned passed = __hip_atomic_fetch_add(gb.chain, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (passed + 1u == (unsigned)gb.chain_consumers)
+        for (int i = 0; i <= gb.chain_slots; ++i) __hip_atomic_store(gb.chain + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (orders the operand loads behind the wait; coherence is the loads' own sc1)
+  }
+  const int tile = gemm_xcd_tile(blockIdx.x, gb.tile_start[p], gb.tile_start[p + 1] - gb.tile_start[p]);
+  // An agent-scope fence pair (buffer_wbl2 sc1 / buffer_inv sc1 per tile) walks the XCD's whole L2 each time: measured 100 us per
+  // launch.  Instead the producers' outputs are written through (sc1 stores); the release is then only "my stores have been
+  // acknowledged" (vmcnt(0)) in front of the counter's atomic add.
+  if (g.signal_slot) gemm_tile<true>(g, tile, red);
+  else gemm_tile<false>(g, tile, red);
+  if (g.signal_slot && threadIdx.x < 64) {             // wave 0 stored the tile (gemm_tile_t's epilogue); the others returned early
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);                     // (vmcnt(0): every store of this wave is acknowledged)
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(gb.chain + g.signal_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+int launch_gemm_chain(cpp_ctx* ctx, const GemmArgs* list, int n, int nslots) {
+  if (n > GEMM_BATCH_MAX || nslots + 1 > GEMM_CHAIN_SLOTS || !ctx->gemm_chain) { cpp_set_error("launch_gemm_chain: %d problems / %d counters", n, nslots); return 1; }
+  GemmBatch gb;
+  gb.n = n; gb.tile_start[0] = 0; gb.chain = ctx->gemm_chain; gb.chain_consumers = 0; gb.chain_slots = nslots;
+  for (int i = 0; i < n; ++i) {
+    gb.g[i] = list[i];
+    const int t = gemm_tiles(list[i].M, list[i].N, list[i].K);
+    gb.tile_start[i + 1] = gb.tile_start[i] + t;
+    if (list[i].wait_slot[0]) gb.chain_consumers += t;
+  }
+  prof_begin(ctx);
+  hipLaunchKernelGGL(gemm_chain_kernel, dim3(gb.tile_start[n]), dim3(256), 0, ctx->stream, gb);
+  LAUNCH_CHECK();
+  prof_end(ctx, K_GEMM);
+  return 0;
 }
 
 int launch_gemm(cpp_ctx* ctx, const GemmArgs& g) {
