@@ -358,6 +358,26 @@ struct NafHeadArgs {
   int* nonfinite;                                   // set to 1 when l_values / L / loss are not finite
 };
 int launch_naf_head(cpp_ctx* ctx, const NafHeadArgs& a);
+// NAF with the shared representation (naf_cartpole.py:151-152, :176-177), everything between the last hidden layer and the layer
+// below it in ONE row-local launch (gemm.hip: naf_heads_kernel): the four head layers (value, mu, l_values on state_1, the target
+// value on state_2), naf_head_kernel's body, and d(representation) = the three heads' contributions in the order value, mu,
+// l_values, masked by the hidden layer's ReLU -- instead of a forward GEMM level, the head kernel and three dependent GEMM levels.
+struct NafHeadsArgs {
+  int B, A, rep; float discount;
+  const float *x, *xt; long ldx;                     // value's / target value's input_state_representation rows, [rep values, 1.0]
+  const float *Wv, *Wmu, *Wl, *Wvt;                  // [(rep + 1)][1 | A | A(A+1)/2 | 1]
+  const float *action, *reward, *mask;
+  float *value, *mu, *lv, *target_value;             // head outputs (B x 1 | A | NL | 1)
+  float *adv, *q, *td, *loss;                        // loss[0]
+  float *d_value, *d_mu_z, *d_l;                     // gradients at the heads' pre-activations
+  float* drep; long ldd; const float* Y; long ldy; int epi;   // d(rep) (GE_NONE | GE_MUL_RELU_GRAD | GE_MUL_RELU_GRAD_X2 on Y)
+  int* nonfinite;
+  double* part; unsigned* ticket;                    // per-workgroup sums of td^2 (and bad flags behind them), arrival counter
+  unsigned long long* step_bump;                     // non-null: += 1 (the optimiser's step counter: nobody reads it before the optimiser launch)
+};
+#define NAF_HEADS_MAX_WGS 64
+bool naf_heads_supported(const NafHeadsArgs& a);
+int launch_naf_heads(cpp_ctx* ctx, const NafHeadsArgs& a);
 
 // ---------------------------------------------------------------------------------------------
 // launch bookkeeping

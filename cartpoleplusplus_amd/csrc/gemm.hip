@@ -518,3 +518,273 @@ int launch_naf_head(cpp_ctx* ctx, const NafHeadArgs& a) {
   prof_end(ctx, K_NAF_HEAD);
   return 0;
 }
+
+
+// ---- NAF heads, fused (NafHeadsArgs, common.h).  One lane per batch row, 256 rows per workgroup (one workgroup for the
+// reference's batch sizes: no cross-workgroup step for the loss).  The rows of the representation (live and target) are staged
+// through LDS (coalesced 16-byte loads, every global load of the kernel issued before the first one is used), the four weight
+// matrices sit in LDS; the head arithmetic is naf_head_kernel's with action_dim a template value (registers, no scratch);
+// d(representation) leaves the kernel as the lane's own 16-byte pieces.
+// Measured (cfg4, rocprofv3): 14.5 us per launch against 5.2 (naf_head_kernel) + a forward GEMM level + three backward levels
+// of ~6.7 us each.  In-kernel clock: 1.4 us to issue the loads, 2.5 until the rows are staged, 2.0 forward, 0.8 head, 2.5 backward:
+// the two dot-product phases are bound by the CU's one LDS pipe (a 16-byte read costs 8 cycles even when every lane reads the same
+// address).  A variant with the rows in registers (per-lane 16-byte loads, no LDS) and the weights through the scalar cache was
+// slower (16 us: 64 cache lines per load instruction, a scalar round trip per chunk of weights).
+// loss = mean(td^2): with several workgroups each writes its partial through and the last one to arrive adds them in order.
+constexpr int NAFH_ROWS = 256, NAFH_THREADS = 256, NAFH_XI = 16, NAFH_WL = 4;
+typedef float nafh_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned nafh_u4 __attribute__((ext_vector_type(4)));
+template <int AT>
+__global__ __launch_bounds__(NAFH_THREADS) void naf_heads_kernel(const NafHeadsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float nl[];
+  constexpr int A = AT, NL = A * (A + 1) / 2, NO = 1 + A + NL, NO4 = (NO + 3) / 4;
+  static_assert(NO + 1 <= 16, "head values per row");
+  constexpr int OOB = 0x7FFFFF00;
+  const int K = a.rep + 1, KP = (K + 3) & ~3, Q = KP >> 2;      // Q <= 16 (naf_heads_supported)
+  float* xs = nl;                       float* xts = xs + NAFH_ROWS * KP;      // [256][KP]
+  float* wT = xts + NAFH_ROWS * KP;     // [16][KP]: row o = output o's weights over k (o = NO: the target value's), zero from K on
+  float* wB = wT + 16 * KP;             // [KP][16]: unit j's weights towards the NO outputs (rows rep .. KP - 1 and columns NO .. 15: zero)
+  __shared__ double lred[NAFH_THREADS / 64];
+  __shared__ int lbad;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row0 = blockIdx.x * NAFH_ROWS, b = row0 + tid;
+  const bool rv = b < a.B;
+  if (tid == 0) lbad = 0;
+  if (tid == 0 && blockIdx.x == 0 && a.step_bump) *a.step_bump += 1ull;
+  // ---- every global load, up front
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)((long)a.B * a.ldx * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rxt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xt), 0, (int)((long)a.B * a.ldx * 4), 0x00020000);
+  const int rpi = 64 / Q, rsub = lane / Q, q = lane - rsub * Q;          // rows per wave instruction; this lane's row in it, its 16-byte chunk
+  const bool lv_ = rsub < rpi;
+  nafh_u4 xv[NAFH_XI], xtv[NAFH_XI];
+#pragma unroll
+  for (int it = 0; it < NAFH_XI; ++it) {
+    const int rr = wave * 64 + it * rpi + rsub;                          // (it * rpi + rsub < 64 for the lanes that count: rpi >= 4)
+    const bool in = lv_ && it * rpi + rsub < 64;
+    const int off = in ? (int)(((long)(row0 + rr) * a.ldx + 4 * q) * 4) : OOB;
+    xv[it] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+    xtv[it] = __builtin_amdgcn_raw_buffer_load_b128(rxt, off, 0, 0);
+  }
+  const __amdgpu_buffer_rsrc_t rwv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wv), 0, K * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wvt), 0, K * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wmu), 0, K * A * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wl), 0, K * NL * 4, 0x00020000);
+  const float wv_r = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rwv, tid * 4, 0, 0));       // K <= 64 < 256
+  const float wvt_r = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rwt, tid * 4, 0, 0));
+  float wm_r[NAFH_WL], wl_r[NAFH_WL];
+#pragma unroll
+  for (int n = 0; n < NAFH_WL; ++n) {
+    wm_r[n] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rwm, (tid + n * NAFH_THREADS) * 4, 0, 0));
+    wl_r[n] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rwl, (tid + n * NAFH_THREADS) * 4, 0, 0));
+  }
+  float act[A];
+#pragma unroll
+  for (int i = 0; i < A; ++i) act[i] = rv ? a.action[(long)b * A + i] : 0.f;
+  const float rew = rv ? a.reward[b] : 0.f, msk = rv ? a.mask[b] : 0.f;
+  // ---- into LDS
+  for (int i = tid; i < 32 * KP; i += NAFH_THREADS) wT[i] = 0.f;         // wT and wB (wT: rows NO + 1 .. 15 and k >= K stay zero)
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < NAFH_XI; ++it) {
+    const int rl = it * rpi + rsub;
+    if (lv_ && rl < 64) {
+      nafh_u4 v = xv[it], vt = xtv[it];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (4 * q + e >= K) { v[e] = 0u; vt[e] = 0u; }       // (the chunk's tail belongs to the next row)
+      *reinterpret_cast<nafh_u4*>(xs + (wave * 64 + rl) * KP + 4 * q) = v;
+      *reinterpret_cast<nafh_u4*>(xts + (wave * 64 + rl) * KP + 4 * q) = vt;
+    }
+  }
+  if (tid < K) { wT[tid] = wv_r; wT[NO * KP + tid] = wvt_r; if (tid < a.rep) wB[tid * 16] = wv_r; }
+#pragma unroll
+  for (int n = 0; n < NAFH_WL; ++n) {
+    const int e = tid + n * NAFH_THREADS;
+    if (e < K * A) { const int k = e / A, i = e - k * A; wT[(1 + i) * KP + k] = wm_r[n]; if (k < a.rep) wB[k * 16 + 1 + i] = wm_r[n]; }
+    if (e < K * NL) { const int k = e / NL, j = e - k * NL; wT[(1 + A + j) * KP + k] = wl_r[n]; if (k < a.rep) wB[k * 16 + 1 + A + j] = wl_r[n]; }
+  }
+  __syncthreads();
+  // ---- forward heads of this lane's row: NO outputs from the live row, the target value from the target's row
+  float hv[NO + 1];
+  {
+    float acc[NO + 1];
+#pragma unroll
+    for (int o = 0; o <= NO; ++o) acc[o] = 0.f;
+    const float* xr = xs + tid * KP; const float* xtr = xts + tid * KP;
+#pragma unroll 2
+    for (int k = 0; k < KP; k += 4) {
+      const nafh_f4 x4 = *reinterpret_cast<const nafh_f4*>(xr + k), t4 = *reinterpret_cast<const nafh_f4*>(xtr + k);
+#pragma unroll
+      for (int o = 0; o <= NO; ++o) {
+        const nafh_f4 w4 = *reinterpret_cast<const nafh_f4*>(wT + o * KP + k);       // (one address for the whole wave)
+        const nafh_f4 u4 = o == NO ? t4 : x4;
+        acc[o] = fmaf(u4[0], w4[0], acc[o]); acc[o] = fmaf(u4[1], w4[1], acc[o]);
+        acc[o] = fmaf(u4[2], w4[2], acc[o]); acc[o] = fmaf(u4[3], w4[3], acc[o]);
+      }
+    }
+#pragma unroll
+    for (int o = 0; o <= NO; ++o) hv[o] = acc[o];
+  }
+  // ---- naf_head_kernel's row (naf_cartpole.py:186-230)
+  double s2 = 0.0;
+  float dzr[4 * NO4];
+#pragma unroll
+  for (int i = 0; i < 4 * NO4; ++i) dzr[i] = 0.f;
+  if (rv) {
+    const float value = hv[0], tvalue = hv[NO];
+    float mu[A], L[A][A], d[A], z[A];
+    int mybad = 0;
+#pragma unroll
+    for (int i = 0; i < A; ++i) mu[i] = tanhf(hv[1 + i]);
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+      const int off = i * (i + 1) / 2;
+#pragma unroll
+      for (int j = 0; j < A; ++j) L[i][j] = 0.f;
+#pragma unroll
+      for (int j = 0; j < i; ++j) { L[i][j] = hv[1 + A + off + j]; if (!isfinite(L[i][j])) mybad = 1; }
+      L[i][i] = expf(hv[1 + A + off + i]);
+      if (!isfinite(hv[1 + A + off + i]) || !isfinite(L[i][i])) mybad = 1;
+      d[i] = act[i] - mu[i];
+    }
+    float zz = 0.f;
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = j; i < A; ++i) t += L[i][j] * d[i];
+      z[j] = t; zz += t * t;
+    }
+    const float adv = -0.5f * zz, qv = value + adv;
+    const float y = rew + (msk * a.discount) * tvalue;
+    const float td = qv - y;
+    a.value[b] = value; a.target_value[b] = tvalue;
+#pragma unroll
+    for (int i = 0; i < A; ++i) a.mu[(long)b * A + i] = mu[i];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) a.lv[(long)b * NL + j] = hv[1 + A + j];
+    if (a.adv) a.adv[b] = adv;
+    if (a.q) a.q[b] = qv;
+    if (a.td) a.td[b] = td;
+    s2 = (double)td * (double)td;
+    const float dq = td * (2.f / (float)a.B);
+    a.d_value[b] = dq;
+    float dz[A];
+#pragma unroll
+    for (int j = 0; j < A; ++j) dz[j] = -z[j] * dq;
+    dzr[0] = dq;
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+      const int off = i * (i + 1) / 2;
+      float dd = 0.f;
+#pragma unroll
+      for (int j = 0; j <= i; ++j) dd += L[i][j] * dz[j];
+#pragma unroll
+      for (int j = 0; j < i; ++j) dzr[1 + A + off + j] = d[i] * dz[j];
+      dzr[1 + A + off + i] = d[i] * dz[i] * L[i][i];
+      dzr[1 + i] = -dd * (1.f - mu[i] * mu[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < A; ++i) a.d_mu_z[(long)b * A + i] = dzr[1 + i];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) a.d_l[(long)b * NL + j] = dzr[1 + A + j];
+    if (mybad) atomicOr(&lbad, 1);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+  if (lane == 0) lred[wave] = s2;
+  // ---- d(representation) of this lane's row: contributions in the order value, mu, l_values; ReLU mask from the live row; out as
+  // the lane's own 16-byte pieces (rows are 4-byte aligned: buffer stores take that; the last piece of a row element by element).
+  // Four chunks of units per round, every LDS read of a round in front of its arithmetic (one wave per SIMD: nothing else hides
+  // the LDS latency); the last round repeats the last chunk.
+  {
+    const float* xr = xs + tid * KP;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(a.drep, 0, (int)((long)a.B * a.ldd * 4), 0x00020000);
+    const int dbase = (int)((long)b * a.ldd * 4);
+    const float two = a.epi == GE_MUL_RELU_GRAD_X2 ? 2.f : 1.f;
+    for (int c0 = 0; c0 < Q; c0 += 4) {
+      nafh_f4 x4[4], w4[4][4][NO4];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int c = c0 + cc < Q ? c0 + cc : Q - 1;
+        x4[cc] = *reinterpret_cast<const nafh_f4*>(xr + 4 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < NO4; ++i) w4[cc][e][i] = *reinterpret_cast<const nafh_f4*>(wB + (4 * c + e) * 16 + 4 * i);   // (rows rep .. KP - 1: zero)
+      }
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int c = c0 + cc < Q ? c0 + cc : Q - 1;
+        nafh_u4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float acc = dzr[0] * w4[cc][e][0][0];
+#pragma unroll
+          for (int o = 1; o < NO; ++o) acc = fmaf(dzr[o], w4[cc][e][o >> 2][o & 3], acc);
+          o4[e] = __float_as_uint(x4[cc][e] > 0.f ? two * acc : 0.f);
+        }
+        if (4 * c + 3 < a.rep) __builtin_amdgcn_raw_buffer_store_b128(o4, rd, rv ? dbase + 16 * c : OOB, 0, 0);
+        else {
+#pragma unroll
+          for (int e = 0; e < 3; ++e)
+            if (4 * c + e < a.rep) __builtin_amdgcn_raw_buffer_store_b32(o4[e], rd, rv ? dbase + 16 * c + 4 * e : OOB, 0, 0);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- loss: this workgroup's partial; with several workgroups it is written through and the last one to arrive adds them in order
+  if (tid == 0) {
+    double p = 0.0;
+    for (int i = 0; i < NAFH_THREADS / 64; ++i) p += lred[i];
+    double sum = p; int bad = lbad; bool last = gridDim.x == 1;
+    if (!last) {
+      __hip_atomic_store(a.part + blockIdx.x, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.part + NAF_HEADS_MAX_WGS + blockIdx.x, lbad ? 1.0 : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_s_waitcnt(0);
+      const unsigned t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t + 1u == gridDim.x) {
+        last = true; sum = 0.0; bad = 0;
+        for (unsigned i = 0; i < gridDim.x; ++i) {
+          sum += __hip_atomic_load(a.part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bad |= __hip_atomic_load(a.part + NAF_HEADS_MAX_WGS + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0;
+        }
+        __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (last) {
+      const float loss = (float)(sum / (double)a.B);
+      a.loss[0] = loss;
+      if (a.nonfinite && (bad || !isfinite(loss))) a.nonfinite[0] = 1;
+    }
+  }
+}
+
+static size_t naf_heads_lds(const NafHeadsArgs& a) {
+  const size_t K = a.rep + 1, KP = (K + 3) & ~(size_t)3;
+  return (2 * NAFH_ROWS * KP + 16 * KP + KP * 16) * sizeof(float);
+}
+
+bool naf_heads_supported(const NafHeadsArgs& a) {
+  const int NLx = a.A * (a.A + 1) / 2, K = a.rep + 1;
+  return a.A >= 1 && a.A <= 4 && a.rep >= 1 && K <= 64 && K * NLx <= NAFH_WL * NAFH_THREADS && a.drep && a.Y == a.x && a.ldy == a.ldx &&
+         (a.B + NAFH_ROWS - 1) / NAFH_ROWS <= NAF_HEADS_MAX_WGS && naf_heads_lds(a) <= 150 * 1024;
+}
+
+int launch_naf_heads(cpp_ctx* ctx, const NafHeadsArgs& a) {
+  const size_t lds = naf_heads_lds(a);
+  typedef void (*kern_t)(const NafHeadsArgs);
+  static const kern_t kerns[4] = {naf_heads_kernel<1>, naf_heads_kernel<2>, naf_heads_kernel<3>, naf_heads_kernel<4>};
+  if (a.A < 1 || a.A > 4) { cpp_set_error("naf heads: action_dim %d", a.A); return 1; }
+  static size_t attr[CPP_MAX_DEVICES][4] = {};
+  size_t& have = attr[cpp_dev_slot(ctx)][a.A - 1];
+  if (lds > have) {
+    HIP_CHECK(hipFuncSetAttribute((const void*)kerns[a.A - 1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    have = lds;
+  }
+  prof_begin(ctx);
+  hipLaunchKernelGGL(kerns[a.A - 1], dim3((a.B + NAFH_ROWS - 1) / NAFH_ROWS), dim3(NAFH_THREADS), lds, ctx->stream, a);
+  LAUNCH_CHECK();
+  prof_end(ctx, K_NAF_HEAD);
+  return 0;
+}

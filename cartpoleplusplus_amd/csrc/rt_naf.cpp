@@ -11,6 +11,9 @@ struct cpp_naf {
   float* gradbuf; float *m, *v;           // optimiser state over the same flat layout (Momentum / Adam)
   float *adv, *q, *td, *stats;            // stats: [0] loss [1] norm
   int* nonfinite; uint64_t* opt_step; double* norm_part;
+  double* heads_part; unsigned* heads_ticket;      // fused heads kernel (naf_heads_kernel): per-workgroup td^2 sums + bad flags, arrival counter
+  int sq_cnt;              // norm partials the last folded gradient pass left in cpp_ctx::sq_part (<= 0: none, run the sumsq kernel)
+  bool step_bumped;        // the last gradient pass advanced opt_step in its heads kernel (the next apply must not)
   hipGraph_t graph; hipGraphExec_t gexec; bool graph_ok; int g_B, g_nb; uint64_t g_seed, g_replay_uid;
   // the data-parallel half step (sample + gradients) as a graph of its own
   hipGraph_t hgraph; hipGraphExec_t hexec; bool hgraph_ok; int h_B; uint64_t h_seed, h_replay_uid;
@@ -51,6 +54,7 @@ extern "C" int cpp_naf_create(cpp_ctx* ctx, cpp_net* value, cpp_net* tvalue, cpp
   for (cpp_net* n : {tvalue, mu, lv}) if (n->maxB < f->maxB) f->maxB = n->maxB;
   f->nV = value->nparams; f->nM = mu->nparams; f->nL = lv->nparams;
   f->graph = nullptr; f->gexec = nullptr; f->graph_ok = false; f->step_batch = nullptr; f->g_replay_uid = 0;
+  f->sq_cnt = 0; f->step_bumped = false;
   f->rgraph = nullptr; f->rgexec = nullptr; f->rgraph_ok = false; f->rg_B = 0; f->rg_replay_uid = 0;
   f->agraph = nullptr; f->agexec = nullptr; f->agraph_ok = false; f->ag_B = 0; f->ag_replay_uid = 0;
   f->res_pin = nullptr; f->next_ticket = 0; memset(f->res_ev, 0, sizeof(f->res_ev));
@@ -66,6 +70,8 @@ extern "C" int cpp_naf_create(cpp_ctx* ctx, cpp_net* value, cpp_net* tvalue, cpp
   if (!rc) rc = dalloc(f->arena, &f->nonfinite, (size_t)1);
   if (!rc) rc = dalloc(f->arena, &f->opt_step, (size_t)1);
   if (!rc) rc = dalloc(f->arena, &f->norm_part, (size_t)OPT_MAX_SEGS * NORM_PARTS);
+  if (!rc) rc = dalloc(f->arena, &f->heads_part, (size_t)2 * NAF_HEADS_MAX_WGS);
+  if (!rc) rc = dalloc(f->arena, &f->heads_ticket, (size_t)1);
   if (rc) { f->arena.release(); delete f; return rc; }
   value->grads = f->gradbuf; mu->grads = f->gradbuf + f->nV; lv->grads = f->gradbuf + f->nV + f->nM;
   if (share) {      // the heads read value's input_state_representation in place (naf_cartpole.py:151-152,176-177)
@@ -134,10 +140,11 @@ static int naf_head(cpp_naf* f, cpp_batch* b, bool backward) {
 
 // backward of the fully connected stack of a network without an action splice, from layer `start` down:
 // per layer {[dW;db], dX} as two independent GEMMs.  Returns the op that completes d(flat) (pixel) / dz[0].
-static int add_fc_backward(OpGraph& G, cpp_net* n, Workspace& w, int B, int start, int dep) {
+static int add_fc_backward(OpGraph& G, cpp_net* n, Workspace& w, int B, int start, int dep,
+                           const std::function<GemmArgs(GemmArgs)>& dw = [](GemmArgs g) { return g; }) {
   for (int l = start; l >= 0; --l) {
     const FcL& L = n->fc[l];
-    G.gemm(fc_dw_args(n, w, l, B, w.dz[l]), {dep});
+    G.gemm(dw(fc_dw_args(n, w, l, B, w.dz[l])), {dep});
     if (l > 0)
       dep = G.gemm(fc_dx_args(n, l, B, w.dz[l], L.n_out, 0, L.n_in, w.dz[l - 1], L.n_in, relu_grad_epi(n, l - 1), w.fcin[l], L.n_in + 1), {dep});
     else if (n->spec.pixel)
@@ -148,8 +155,29 @@ static int add_fc_backward(OpGraph& G, cpp_net* n, Workspace& w, int B, int star
 
 // One NAF minibatch (naf_cartpole.py:264-272 without the apply) as a dependency graph, batched like the DDPG
 // step: conv layers of the networks that run them share launches, independent GEMMs share launches.
-static int naf_compute_gradients(cpp_naf* f, cpp_batch* b) {
+// fold (the fused single-learner step only: the gradients are applied as computed): the kernels that write the gradients leave
+// their share of the list's squared norm in cpp_ctx::sq_part (as the DDPG step, rt_ddpg.cpp) and the heads kernel advances the
+// optimiser's step counter -- naf_apply then runs neither the sumsq nor the counter kernel
+static int naf_compute_gradients(cpp_naf* f, cpp_batch* b, bool fold = false) {
   cpp_ctx* ctx = f->ctx;
+  f->sq_cnt = 0; f->step_bumped = false;
+  struct SqScope {
+    cpp_ctx* c; cpp_naf* f;
+    SqScope(cpp_ctx* c_, cpp_naf* f_, bool on) : c(c_), f(f_) {
+      if (on) { c->sq_n[0] = 0; c->sq_n[1] = -1; for (int& g : c->sq_conv_group) g = 0; }
+    }
+    ~SqScope() {
+      if (c->sq_n[0] > 0) f->sq_cnt = c->sq_n[0];
+      c->sq_n[0] = c->sq_n[1] = -1;
+      for (int& g : c->sq_conv_group) g = -1;
+    }
+  } sq_scope(ctx, f, fold && !f->value->spec.use_batch_norm);
+  auto sqg = [ctx](GemmArgs g) {
+    const int tiles = gemm_tiles(g.M, g.N, g.K);
+    if (ctx->sq_n[0] >= 0 && ctx->sq_n[0] + tiles <= SQ_REGION) { g.sq_part = ctx->sq_part + ctx->sq_n[0]; ctx->sq_n[0] += tiles; }
+    else ctx->sq_n[0] = -1;
+    return g;
+  };
   cpp_net *v = f->value, *tv = f->tvalue, *mu = f->mu, *lv = f->lv;
   const int B = b->B, C = v->spec.pixel ? v->spec.C : 0, dt = b->dtype;
   const float *w1 = white_of(b, 0, C), *w2 = white_of(b, 1, C);
@@ -189,23 +217,52 @@ static int naf_compute_gradients(cpp_naf* f, cpp_batch* b) {
   const int Lh = (int)v->fc.size() - 1;                 // value's 'fc' head
   int vrep = t1;
   for (int l = 0; l < Lh; ++l) vrep = G.gemm(fc_fwd_args(v, v->ws[0], l, B), {vrep});
-  const int vout = G.gemm(fc_fwd_args(v, v->ws[0], Lh, B), {vrep});
-  const int tvout = chain(tv, 0, t1);
-  const int muout = share ? chain(mu, 0, vrep) : chain(mu, 0, t1);
-  const int lvout = share ? chain(lv, 0, vrep) : chain(lv, 0, t1);
+  // Shared representation with a hidden stack (the reference's pixel NAF, naf_cartpole.py:151-152): the four head layers, the
+  // head arithmetic and d(representation) are ONE row-local launch (naf_heads_kernel, gemm.hip) instead of a forward GEMM level,
+  // the head kernel and three dependent GEMM levels.  CPP_NAF_HEADS=0 (ablation build): the GEMM levels.
+  static const bool no_fused_heads = cpp_switch_off("CPP_NAF_HEADS");
+  NafHeadsArgs nh; memset(&nh, 0, sizeof(nh));
+  bool fused = share && Lh > 0 && !no_fused_heads;
+  if (fused) {
+    const FcL& hv = v->fc[Lh];
+    nh.B = B; nh.A = f->A; nh.rep = hv.n_in; nh.discount = f->hp.discount;
+    nh.x = v->ws[0].fcin[Lh]; nh.xt = tv->ws[0].fcin[Lh]; nh.ldx = hv.n_in + 1;
+    nh.Wv = v->params + hv.w_off; nh.Wmu = mu->params + mu->fc[0].w_off; nh.Wl = lv->params + lv->fc[0].w_off; nh.Wvt = tv->params + tv->fc[Lh].w_off;
+    nh.action = b->a; nh.reward = b->r; nh.mask = b->m;
+    nh.value = v->ws[0].out; nh.mu = mu->ws[0].out; nh.lv = lv->ws[0].out; nh.target_value = tv->ws[0].out;
+    nh.adv = f->adv; nh.q = f->q; nh.td = f->td; nh.loss = f->stats; nh.nonfinite = f->nonfinite;
+    nh.d_value = v->ws[0].dz[Lh]; nh.d_mu_z = mu->ws[0].dz[0]; nh.d_l = lv->ws[0].dz[0];
+    nh.drep = v->ws[0].dz[Lh - 1]; nh.ldd = hv.n_in; nh.epi = relu_grad_epi(v, Lh - 1); nh.Y = v->ws[0].fcin[Lh]; nh.ldy = hv.n_in + 1;
+    nh.part = f->heads_part; nh.ticket = f->heads_ticket;
+    nh.step_bump = fold ? (unsigned long long*)f->opt_step : nullptr;
+    fused = naf_heads_supported(nh) && (nh.epi == GE_MUL_RELU_GRAD || nh.epi == GE_MUL_RELU_GRAD_X2);
+  }
+  int vout, tvout, muout, lvout;
+  if (fused) {
+    f->step_bumped = nh.step_bump != nullptr;
+    int tvrep = t1;
+    for (int l = 0; l < Lh; ++l) tvrep = G.gemm(fc_fwd_args(tv, tv->ws[0], l, B), {tvrep});
+    vout = vrep; tvout = tvrep; muout = lvout = vrep;
+  } else {
+    vout = G.gemm(fc_fwd_args(v, v->ws[0], Lh, B), {vrep});
+    tvout = chain(tv, 0, t1);
+    muout = share ? chain(mu, 0, vrep) : chain(mu, 0, t1);
+    lvout = share ? chain(lv, 0, vrep) : chain(lv, 0, t1);
+  }
   if (v->drop_counter) {     // --use-dropout: count this training-mode forward of every network with a hidden stack
     G.fn([=] { return bump_dropout(v); }, {vout});
     G.fn([=] { return bump_dropout(tv); }, {tvout});
     if (!share) { G.fn([=] { return bump_dropout(mu); }, {muout}); G.fn([=] { return bump_dropout(lv); }, {lvout}); }
   }
   // ---- NAF head: L, advantage, TD loss and the gradients of the three head outputs
-  const int head = G.fn([=] { return naf_head(f, b, true); }, {vout, tvout, muout, lvout});
+  const int head = fused ? G.fn([=] { return launch_naf_heads(ctx, nh); }, {vout, tvout})
+                         : G.fn([=] { return naf_head(f, b, true); }, {vout, tvout, muout, lvout});
 
   // ---- backward
   if (!share) {
-    const int dv = add_fc_backward(G, v, v->ws[0], B, (int)v->fc.size() - 1, head);
-    const int dm = add_fc_backward(G, mu, mu->ws[0], B, (int)mu->fc.size() - 1, head);
-    const int dl = add_fc_backward(G, lv, lv->ws[0], B, (int)lv->fc.size() - 1, head);
+    const int dv = add_fc_backward(G, v, v->ws[0], B, (int)v->fc.size() - 1, head, sqg);
+    const int dm = add_fc_backward(G, mu, mu->ws[0], B, (int)mu->fc.size() - 1, head, sqg);
+    const int dl = add_fc_backward(G, lv, lv->ws[0], B, (int)lv->fc.size() - 1, head, sqg);
     if (v->spec.pixel) {
       cpp_net* bn[3] = {v, mu, lv};
       G.fn([=] { return nets_backward_conv(ctx, bn, 3, B, s1, dt, w1); }, {dv, dm, dl});
@@ -223,15 +280,15 @@ static int naf_compute_gradients(cpp_naf* f, cpp_batch* b) {
     for (int k = 0; k < 3; ++k) {
       const Head& h = heads[k];
       const float* x = v->ws[0].fcin[Lh];        // [rep, 1] rows, shared by the three heads
-      G.gemm(mk_gemm(x, 1, rep + 1, h.dz, h.L->n_out, 1, h.n->grads + h.L->w_off, h.L->n_out, rep + 1, h.L->n_out, B, GE_NONE), {head});
-      if (drep) {
+      G.gemm(sqg(mk_gemm(x, 1, rep + 1, h.dz, h.L->n_out, 1, h.n->grads + h.L->w_off, h.L->n_out, rep + 1, h.L->n_out, B, GE_NONE)), {head});
+      if (drep && !fused) {
         GemmArgs g = mk_gemm(h.dz, h.L->n_out, 1, h.n->params + h.L->w_off, 1, h.L->n_out, drep, ldd, B, rep, h.L->n_out,
                              k == 2 ? final_epi : GE_NONE, k == 2 ? Y : nullptr, ldy);
         g.accumulate = k > 0;
         dep = G.gemm(g, {dep});                  // accumulation order value -> mu -> l_values is fixed
       }
     }
-    const int dv = add_fc_backward(G, v, v->ws[0], B, Lh - 1, dep);
+    const int dv = add_fc_backward(G, v, v->ws[0], B, Lh - 1, dep, sqg);
     if (v->spec.pixel) {     // conv3's and conv2's dW + dX as one launch each, like the DDPG step (nets_backward_conv)
       cpp_net* bn[1] = {v};
       G.fn([=] { return nets_backward_conv(ctx, bn, 1, B, s1, dt, w1); }, {dv});
@@ -245,7 +302,7 @@ static int naf_compute_gradients(cpp_naf* f, cpp_batch* b) {
 // bump: the replay sampler's counter, advanced by this launch; next (+ next_B, next_C, elems): the minibatch whose sample pass has
 // already run -- its whitening tables are finished by this launch's extra grid row (as in the DDPG step, rt_ddpg.cpp: apply)
 static int naf_apply(cpp_naf* f, float grad_scale, bool unless_nonfinite = false, uint64_t* bump = nullptr,
-                     const cpp_batch* next = nullptr, int next_B = 0, int next_C = 0, long elems = 0) {
+                     const cpp_batch* next = nullptr, int next_B = 0, int next_C = 0, long elems = 0, bool folded = false) {
   OptSegs s; memset(&s, 0, sizeof(s));
   if (unless_nonfinite) s.skip_if = f->nonfinite;
   s.bump = bump;
@@ -262,8 +319,11 @@ static int naf_apply(cpp_naf* f, float grad_scale, bool unless_nonfinite = false
     s.n[k] = nets[k]->nparams; s.lr[k] = f->hp.learning_rate; s.group[k] = 0;      // ONE list, one global norm
     off += nets[k]->nparams;
   }
-  RC(launch_counter_add(f->ctx, f->opt_step, 1));
-  RC(launch_sumsq(f->ctx, s, grad_scale, f->norm_part, NORM_PARTS));
+  const bool bumped = f->step_bumped; const int sq_cnt = f->sq_cnt;
+  f->step_bumped = false; f->sq_cnt = 0;
+  if (!bumped) RC(launch_counter_add(f->ctx, f->opt_step, 1));
+  if (folded && sq_cnt > 0 && grad_scale == 1.0f) { s.sq = f->ctx->sq_part; s.sq_begin[0] = 0; s.sq_count[0] = sq_cnt; }
+  else RC(launch_sumsq(f->ctx, s, grad_scale, f->norm_part, NORM_PARTS));
   return launch_opt_apply(f->ctx, s, grad_scale, f->hp.gradient_clip, f->norm_part, NORM_PARTS, f->stats + 1);
 }
 
@@ -370,13 +430,13 @@ static int naf_step_body(cpp_naf* f, cpp_replay* r, int B, int n_batches, const 
       if (direct) { ga.out_slot[0] = f->step_batch->slot_alt[0]; ga.out_slot[1] = f->step_batch->slot_alt[1]; }
       ctx->ride = &ga; ctx->ride_done = false; ctx->ride_dtype = r->store_dtype;
     }
-    const int rc = naf_compute_gradients(f, f->step_batch);
+    const int rc = naf_compute_gradients(f, f->step_batch, true);
     const bool rode = ctx->ride != nullptr && ctx->ride_done;
     ctx->ride = nullptr;
     if (rode && direct) { std::swap(f->step_batch->slot[0], f->step_batch->slot_alt[0]); std::swap(f->step_batch->slot[1], f->step_batch->slot_alt[1]); }
     RC(rc);
     const bool stats_ride = rode && Cg > 0;
-    RC(naf_apply(f, 1.0f, false, rows_dev ? nullptr : r->counter, stats_ride ? f->step_batch : nullptr, B, Cg, r->elems));
+    RC(naf_apply(f, 1.0f, false, rows_dev ? nullptr : r->counter, stats_ride ? f->step_batch : nullptr, B, Cg, r->elems, true));
     if (more) {
       if (stats_ride) { f->step_batch->B = B; f->step_batch->dtype = CPP_F16; f->step_batch->stats_C = Cg; }     // (replay_sample_finish's bookkeeping)
       else if (rode) RC(replay_sample_finish(r, B, Cg, C, f->step_batch));
@@ -426,11 +486,11 @@ extern "C" int cpp_naf_train_step(cpp_naf* f, cpp_replay* r, int B, int n_batche
 // gathered copy of the minibatch crossing PCIe or HBM twice -- the sample pass reads the replay store through those rows.  Like
 // cpp_naf_train: gradients, then the loss and the check_numerics flag come back (one stream sync: the reference's train() returns the
 // loss), then the optimiser -- which does not run when the flag is set.  The gradient half is one hipGraph per (B, replay).
-static int naf_rows_body(cpp_naf* f, cpp_replay* r, int B) {
+static int naf_rows_body(cpp_naf* f, cpp_replay* r, int B, bool fold = false) {
   const int C = f->value->spec.pixel ? f->value->spec.C : 0;
   HIP_CHECK(hipMemsetAsync(f->nonfinite, 0, sizeof(int), f->ctx->stream));
   RC(replay_sample_device(r, B, r->rows_in, 0, nullptr, C, f->step_batch, direct_replay_ok(f->value, r, B)));
-  return naf_compute_gradients(f, f->step_batch);
+  return naf_compute_gradients(f, f->step_batch, fold);
 }
 extern "C" int cpp_naf_train_rows(cpp_naf* f, cpp_replay* r, int B, const int32_t* idxs, float* loss) {
   ARG_CHECK(f && r && idxs, "cpp_naf_train_rows: NULL argument");
@@ -474,8 +534,8 @@ extern "C" int cpp_naf_train_rows(cpp_naf* f, cpp_replay* r, int B, const int32_
 // reads the loss (the agents only log its mean) -- so a loop of train calls keeps the GPU fed like cpp_naf_train_step does.
 // At most CPP_NAF_TICKETS results are outstanding: a slot is reused CPP_NAF_TICKETS calls later.
 static int naf_rows_apply_body(cpp_naf* f, cpp_replay* r, int B) {
-  RC(naf_rows_body(f, r, B));
-  return naf_apply(f, 1.0f, true);
+  RC(naf_rows_body(f, r, B, true));        // (gradients and optimiser in ONE captured body: the fold's host-side state is consistent)
+  return naf_apply(f, 1.0f, true, nullptr, nullptr, 0, 0, 0, true);
 }
 extern "C" int cpp_naf_train_rows_async(cpp_naf* f, cpp_replay* r, int B, const int32_t* idxs, uint64_t* ticket) {
   ARG_CHECK(f && r && idxs && ticket, "cpp_naf_train_rows_async: NULL argument");
