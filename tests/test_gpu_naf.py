@@ -78,6 +78,7 @@ CASES = [
     pytest.param((64, 64, 3, 2, 3), 2, True, id="64x64x18-share-cfg4"),
     pytest.param((2, 2, 7), 6, True, id="lowdim-share"),
     pytest.param((2, 2, 7), 6, False, id="lowdim-own"),
+    pytest.param((2, 2, 7), 300, True, id="lowdim-share-B300-two-workgroups-of-the-heads-kernel"),
 ]
 
 
@@ -131,9 +132,12 @@ def test_naf_optimisers_over_several_steps(optimiser, args):
         agent.close()
 
 
-def test_naf_fused_train_step_matches_oracle():
+@pytest.mark.parametrize("optimiser,oargs", [("Momentum", {"learning_rate": 0.01, "momentum": 0.9}), ("Adam", {"learning_rate": 0.001})])
+def test_naf_fused_train_step_matches_oracle(optimiser, oargs):
+    """the fused step (gradients' norm partials folded into their producers, the optimiser's step counter advanced by the heads
+    kernel -- Adam's bias correction reads it) against the oracle's loop of train() calls"""
     shape, B = (16, 16, 3, 2, 1), 6
-    agent, ref, specs = make_naf(shape, B, True, "Momentum", {"learning_rate": 0.01, "momentum": 0.9}, replay_size=30)
+    agent, ref, specs = make_naf(shape, B, True, optimiser, oargs, replay_size=30)
     rng = np.random.default_rng(12)
     orm = OracleReplayMemory(30, shape, 2)
     try:
