@@ -211,7 +211,13 @@ struct GemmArgs {
   // chain[wait_slot[i]] == wait_cnt[i] (every tile of that producer has stored and released its outputs); a producer's tiles
   // add one to chain[signal_slot] when they are done.  Slots are >= 1; 0 = none.
   int wait_slot[2], wait_cnt[2], signal_slot;
+  // next layer's partial products (forward, GE_RELU): the tile that finishes columns [16 tn, 16 tn + 16) of this layer's output h
+  // also leaves next_part[(tn * M + row) * next_N + n] = sum over those columns k of h[row][k] * next_W[k * next_N + n] -- the
+  // slice of the NEXT fully connected layer's sum this tile can see.  Whoever consumes that layer adds the tiles_n slices in
+  // tile order, the bias row and the activation (ddpg_heads_kernel): a dependent GEMM level less.  next_N <= 16 * GEMM_NEXT_TILES.
+  const float* next_W; float* next_part; int next_N, next_K;     // next_K: rows of next_W that may be read (this layer's N)
 };
+#define GEMM_NEXT_TILES 7
 #define GEMM_BATCH_MAX 16
 #define GEMM_CHAIN_SLOTS 32     // cpp_ctx::gemm_chain: [0] consumer tiles that passed their wait, [1 ..] producer counters
 // chain: non-null for a chained launch; chain_consumers = number of tiles that wait (the last one to pass resets the counters)
@@ -343,7 +349,14 @@ struct DdpgHeadsArgs {
   const float *h1a, *h1ta; int ld_h1a, n1a;        // B x (n1a + 1)
   const float *W2, *W2_t;                          // [(n1a + 1)][n2a]
   float *h2a_out, *dz_h1a;                         // B x ld_h2a (first n2a columns), B x n1a
+  // optional (with n1a > 0): the inputs h1a / h1ta / h2c / h2tc are not there yet -- the layers that produce them were left by the
+  // level in front of them as np1 / np2 slices per row (GemmArgs::next_part, slice-major), which this kernel adds in slice order,
+  // plus the bias row, ReLU; the live networks' activations are written where the backward GEMMs read them (h1a_w, h2c_w).
+  const float *p1a, *p1ta, *b1a, *b1ta; int np1; float* h1a_w;     // [np1][B][n1a], bias [n1a]
+  const float *p2c, *p2tc, *b2c, *b2tc; int np2; float* h2c_w;     // [np2][B][n2c], bias [n2c]
 };
+#define HEADS_NP1_MAX 7
+#define HEADS_NP2_MAX 13
 #define DDPG_HEADS_MAX_WGS 256
 size_t ddpg_heads_lds_bytes(const DdpgHeadsArgs& h);
 bool ddpg_heads_supported(const DdpgHeadsArgs& h);

@@ -31,7 +31,7 @@
 // quarter of the workgroups, each four times as long, on a chip the 1 x 1 tiling does not fill either.  Kept for the record and for
 // larger problems.  Every output sums its products in the same order in both (same K split over the waves, same k order inside a
 // round): bit-identical results.
-template <bool VA, bool VB, int S, bool COH = false>
+template <bool VA, bool VB, int S, bool COH = false, bool NEXT = false>
 __device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (*red)[GEMM_RED]) {
 #ifdef GEMM_CLOCK
   const unsigned long long c0 = __builtin_amdgcn_s_memrealtime();
@@ -77,6 +77,20 @@ __device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (
 #pragma unroll
   for (int i = 0; i < S; ++i) { abase[i] = (int)((long)mrow[i] * g.sAm * 4); bbase[i] = (int)((long)ncol[i] * g.sBn * 4); }
   const int ask = (int)(g.sAk * 4), bsk = (int)(g.sBk * 4);
+  // next layer's slice (GemmArgs::next_part): wave 0 requests the 16 rows of next_W it will need in front of everything else
+  // (step s of column tile c: row 16 tn + 4 s + lj, column 16 c + li; rows / columns outside the matrix come back as zero)
+  unsigned nxt[(NEXT && S == 1) ? GEMM_NEXT_TILES : 1][4];
+  const bool do_next = NEXT && S == 1 && g.next_W != nullptr && wave == 0;          // (uniform per wave; NEXT: only gemm_batch_next_kernel carries the registers)
+  if (NEXT && S == 1 && do_next) {
+    const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.next_W), 0, g.next_K * g.next_N * 4, 0x00020000);
+#pragma unroll
+    for (int c = 0; c < GEMM_NEXT_TILES; ++c)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int kk = tn * 16 + 4 * s + lj, nn = c * 16 + li;
+        nxt[c][s] = __builtin_amdgcn_raw_buffer_load_b32(rn, (kk < g.next_K && nn < g.next_N) ? (kk * g.next_N + nn) * 4 : OOB, 0, 0);
+      }
+  }
   // A wave's rounds are independent until the MFMAs: ALL operand loads of up to GEMM_R rounds are issued before the first
   // one is used.  Same k order, same summation order as a plain loop.
   constexpr int R = GEMM_R;
@@ -141,6 +155,7 @@ __device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (
 #endif
   if (wave != 0) return;
   double sq = 0.0;
+  float tile_v[4] = {0.f, 0.f, 0.f, 0.f};             // (S == 1) this lane's outputs as stored, zero outside the matrix
 #pragma unroll
   for (int ti = 0; ti < S; ++ti)
 #pragma unroll
@@ -168,6 +183,7 @@ __device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (
       if (COH) __hip_atomic_store(g.C + ((long)row * g.ldc + n), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else g.C[(long)row * g.ldc + n] = v;
       sq += (double)v * (double)v;
+      if (NEXT && S == 1) tile_v[i] = v;
       if (g.epi == GE_ACTOR_HEAD) { const float y = g.Y[(long)row * g.ldy + n]; g.C2[(long)row * g.ldc2 + n] = -v * (1.f - y * y); }
       else if (g.C2) {
         if (COH) __hip_atomic_store(g.C2 + ((long)row * g.ldc2 + n), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -180,6 +196,34 @@ __device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (
     printf("GEMMCLK M %d N %d K %d tile %d (blk %d): loop %.2f us, reduce+barrier %.2f, epilogue %.2f (start tick %llu)\n", g.M, g.N, g.K, tile, (int)blockIdx.x,
            (c1 - c0) / 100.0, (c2 - c1) / 100.0, (__builtin_amdgcn_s_memrealtime() - c2) / 100.0, c0 % 100000000ull);
 #endif
+  if (NEXT && S == 1 && do_next) {
+    // the tile sits in the accumulator layout (row 4 lj + i, column li); as the A operand of the next layer it is wanted as
+    // (row li, k = 4 s + lj): once through LDS (the cross-wave reduction's buffer is free: the other waves are gone)
+    float* tb = &red[0][0];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tb[(4 * lj + i) * 16 + li] = tile_v[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float av[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) av[s] = tb[li * 16 + 4 * s + lj];
+    const int ctiles = (g.next_N + 15) >> 4;
+#pragma unroll
+    for (int c = 0; c < GEMM_NEXT_TILES; ++c) {
+      if (c < ctiles) {                                // (uniform)
+        f32x4 pa = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) pa = MFMA16(av[s], __uint_as_float(nxt[c][s]), pa);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = tm * 16 + 4 * lj + i, nn = c * 16 + li;
+          if (row < g.M && nn < g.next_N) g.next_part[((long)tn * g.M + row) * g.next_N + nn] = pa[i];
+        }
+      }
+    }
+  }
   if (g.sq_part) {                                   // (uniform) this workgroup's share of the gradient list's squared norm, fixed order
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
     if (lane == 0) g.sq_part[tile] = sq;
@@ -187,7 +231,7 @@ __device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (
 }
 
 // an operand that is contiguous in k is read with 16-byte loads; long-K problems take 2 x 2 sub-tiles (uniform per problem)
-template <bool COH = false>
+template <bool COH = false, bool NEXT = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, float (*red)[GEMM_RED]) {
   const bool va = g.sAk == 1, vb = g.sBk == 1;
 #if GEMM_SUB_MIN_K < 100000      // (not instantiated in the shipped build: gemm_sub() is 1 for every problem)
@@ -199,10 +243,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, float (*r
     return;
   }
 #endif
-  if (va && vb) gemm_tile_t<true, true, 1, COH>(g, tile, red);
-  else if (va) gemm_tile_t<true, false, 1, COH>(g, tile, red);
-  else if (vb) gemm_tile_t<false, true, 1, COH>(g, tile, red);
-  else gemm_tile_t<false, false, 1, COH>(g, tile, red);
+  if (va && vb) gemm_tile_t<true, true, 1, COH, NEXT>(g, tile, red);
+  else if (va) gemm_tile_t<true, false, 1, COH, NEXT>(g, tile, red);
+  else if (vb) gemm_tile_t<false, true, 1, COH, NEXT>(g, tile, red);
+  else gemm_tile_t<false, false, 1, COH, NEXT>(g, tile, red);
 }
 
 // Workgroup -> tile, XCD-aware: workgroup b of a launch runs on XCD b mod 8 (round-robin dispatch), each XCD has its own L2, and
@@ -303,6 +347,15 @@ int launch_gemm_chain(cpp_ctx* ctx, const GemmArgs* list, int n, int nslots) {
   return 0;
 }
 
+// ... with GemmArgs::next_part: the tiles also leave their slice of the next layer's sum (an experiment, CPP_FC_NEXT=1 in the
+// ablation build: rt_ddpg.cpp)
+__global__ __launch_bounds__(256) void gemm_batch_next_kernel(const GemmBatch gb) {
+  __shared__ float red[3][GEMM_RED];
+  int p = 0;
+  while (p + 1 < gb.n && (int)blockIdx.x >= gb.tile_start[p + 1]) ++p;
+  gemm_tile<false, true>(gb.g[p], gemm_xcd_tile(blockIdx.x, gb.tile_start[p], gb.tile_start[p + 1] - gb.tile_start[p]), red);
+}
+
 int launch_gemm(cpp_ctx* ctx, const GemmArgs& g) {
   const int tiles = gemm_tiles(g.M, g.N, g.K);
   prof_begin(ctx);
@@ -315,15 +368,19 @@ int launch_gemm(cpp_ctx* ctx, const GemmArgs& g) {
 int launch_gemm_batch(cpp_ctx* ctx, const GemmArgs* list, int n) {
   for (int i0 = 0; i0 < n; i0 += GEMM_BATCH_MAX) {
     const int cnt = n - i0 < GEMM_BATCH_MAX ? n - i0 : GEMM_BATCH_MAX;
-    if (cnt == 1) { int rc = launch_gemm(ctx, list[i0]); if (rc) return rc; continue; }
+    bool next = false;
+    for (int i = 0; i < cnt; ++i) next = next || list[i0 + i].next_W != nullptr;
+    if (cnt == 1 && !next) { int rc = launch_gemm(ctx, list[i0]); if (rc) return rc; continue; }
     GemmBatch gb;
     gb.n = cnt; gb.tile_start[0] = 0;
     for (int i = 0; i < cnt; ++i) {
       gb.g[i] = list[i0 + i];
       gb.tile_start[i + 1] = gb.tile_start[i] + gemm_tiles(gb.g[i].M, gb.g[i].N, gb.g[i].K);
     }
+    gb.chain = nullptr; gb.chain_consumers = gb.chain_slots = 0;
     prof_begin(ctx);
-    hipLaunchKernelGGL(gemm_batch_kernel, dim3(gb.tile_start[cnt]), dim3(256), 0, ctx->stream, gb);
+    if (next) hipLaunchKernelGGL(gemm_batch_next_kernel, dim3(gb.tile_start[cnt]), dim3(256), 0, ctx->stream, gb);
+    else hipLaunchKernelGGL(gemm_batch_kernel, dim3(gb.tile_start[cnt]), dim3(256), 0, ctx->stream, gb);
     LAUNCH_CHECK();
     prof_end(ctx, K_GEMM);
   }

@@ -11,6 +11,8 @@ struct cpp_ddpg {
   float* gradbuf; float *dq_da, *td, *dq, *loss_norms /* [0] loss [1] actor norm [2] critic norm */, *ones;
   double* norm_part;
   double* heads_part;                              // fused heads kernel: per-workgroup partial sums of td^2
+  float* fc_part[4];                               // slices of the layers in front of the heads kernel (GemmArgs::next_part): actor, target actor, critic, target critic
+  size_t fc_part_floats;
   int heads_grid, heads_B;                         // ... of the last graph built by compute_gradients (0: GEMM levels + td_kernel)
   int loss_parts, loss_B;                          // how cpp_ddpg_last_stats finds the loss of the last call: partials to add, or loss_norms[0]
   // graph replay of the full inner step
@@ -52,6 +54,7 @@ extern "C" int cpp_ddpg_create(cpp_ctx* ctx, cpp_net* actor, cpp_net* critic, cp
   d->h_replay_uid = 0; d->h_write_gen = 0; d->pre_variant = 0; d->h_B = 0; d->h_seed = 0;
   memset(d->slot_set, 0, sizeof(d->slot_set));
   d->heads_grid = d->heads_B = d->loss_parts = d->loss_B = 0;
+  memset(d->fc_part, 0, sizeof(d->fc_part)); d->fc_part_floats = 0;
   const int A = actor->spec.action_dim;
   int rc = dalloc(d->arena, &d->gradbuf, (size_t)(d->nA + d->nC));
   if (!rc) rc = dalloc(d->arena, &d->dq_da, (size_t)d->maxB * A);
@@ -367,24 +370,56 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b, int phase = 0) {
       if (ddpg_heads_supported(hp)) hd = hp;
     }
   }
+  // ... and the layers in FRONT of those (the actors' second hidden layer, the critics' layer in front of the concat layer) leave the
+  // GEMM levels too: the tiles of the first fully connected layer add their slice of the next layer's sum (GemmArgs::next_part) and the
+  // heads kernel finishes it -- one dependent level less.  For the reference's stacks (actor 3 hidden layers, critic prefix of 2).
+  // An EXPERIMENT, off unless CPP_FC_NEXT=1 in the ablation build: parity-green, and worth nothing -- the level that disappears (8.4 us)
+  // comes back as 2 us more per tile in the level in front of it (slice loads, a transpose through LDS, 28 MFMAs and 28 stores on each
+  // tile's last wave) and the launch it saves: 2790-2793 -> 2792-2808 steps/s in alternating runs (profiles/experiments/r03_fc_next.txt).
+  static const bool no_next = !cpp_switch_set("CPP_FC_NEXT");
+  bool nextp = false;
+  if (fused && hd.n1a > 0 && !no_next && na == 4 && cat == 2 && a->fc[1].act == GE_RELU && c->fc[1].act == GE_RELU &&
+      a->fc[0].act == GE_RELU && c->fc[0].act == GE_RELU && !a->drop_counter) {
+    const int n0a = a->fc[0].n_out, n1a_ = a->fc[1].n_out, n0c = c->fc[0].n_out, n1c = c->fc[1].n_out;
+    const int np1 = (n0a + 15) / 16, np2 = (n0c + 15) / 16;
+    if (np1 <= HEADS_NP1_MAX && np2 <= HEADS_NP2_MAX && n1a_ <= 16 * GEMM_NEXT_TILES && n1c <= 16 * GEMM_NEXT_TILES && n1a_ == hd.n1a && n1c == hd.n2c) {
+      const size_t need = (size_t)d->maxB * ((size_t)np1 * n1a_ > (size_t)np2 * n1c ? (size_t)np1 * n1a_ : (size_t)np2 * n1c);
+      if (d->fc_part_floats < need) {
+        int rc = 0;
+        for (int k = 0; k < 4 && !rc; ++k) rc = dalloc(d->arena, &d->fc_part[k], need, false);
+        if (rc) return rc;
+        d->fc_part_floats = need;
+      }
+      DdpgHeadsArgs hn = hd;
+      hn.p1a = d->fc_part[0]; hn.p1ta = d->fc_part[1]; hn.np1 = np1; hn.h1a_w = a->ws[0].fcin[2];
+      hn.b1a = a->params + a->fc[1].w_off + (long)n0a * n1a_; hn.b1ta = ta->params + a->fc[1].w_off + (long)n0a * n1a_;
+      hn.p2c = d->fc_part[2]; hn.p2tc = d->fc_part[3]; hn.np2 = np2; hn.h2c_w = c->ws[0].fcin[2];
+      hn.b2c = c->params + c->fc[1].w_off + (long)n0c * n1c; hn.b2tc = tc->params + c->fc[1].w_off + (long)n0c * n1c;
+      if (ddpg_heads_supported(hn)) { hd = hn; nextp = true; }
+    }
+  }
+  auto with_next = [&](GemmArgs g, cpp_net* n, float* part) {      // layer 0's GEMM of network n also leaves layer 1's slices
+    g.next_W = n->params + n->fc[1].w_off; g.next_N = n->fc[1].n_out; g.next_K = n->fc[0].n_out; g.next_part = part;
+    return g;
+  };
   const int pre = (fused && hd.n1a > 0) ? 1 : 0;
   d->heads_grid = fused ? (B + 3) / 4 : 0; d->heads_B = B;
   d->loss_parts = d->heads_grid; d->loss_B = B;
   int adz, cdz;
   if (fused) {
     int aF = tA, taF = tTA;
-    for (int l = 0; l < na - 1 - pre; ++l) {
-      aF = G.gemm(fc_fwd_args(a, a->ws[0], l, B), {aF});
-      taF = G.gemm(fc_fwd_args(ta, ta->ws[0], l, B), {taF});
+    for (int l = 0; l < na - 1 - pre - (nextp ? 1 : 0); ++l) {
+      aF = G.gemm(nextp ? with_next(fc_fwd_args(a, a->ws[0], l, B), a, d->fc_part[0]) : fc_fwd_args(a, a->ws[0], l, B), {aF});
+      taF = G.gemm(nextp ? with_next(fc_fwd_args(ta, ta->ws[0], l, B), ta, d->fc_part[1]) : fc_fwd_args(ta, ta->ws[0], l, B), {taF});
     }
     if (a->drop_counter) {     // --use-dropout: this forward is counted once its layers have read the counter
       G.fn([=] { return bump_dropout(a); }, {aF});
       G.fn([=] { return bump_dropout(ta); }, {taF});
     }
     int cP = tC, tcP = tTC;
-    for (int l = 0; l < cat; ++l) {
-      cP = G.gemm(fc_fwd_args(c, c->ws[0], l, B), {cP});
-      tcP = G.gemm(fc_fwd_args(tc, tc->ws[0], l, B), {tcP});
+    for (int l = 0; l < cat - (nextp ? 1 : 0); ++l) {
+      cP = G.gemm(nextp ? with_next(fc_fwd_args(c, c->ws[0], l, B), c, d->fc_part[2]) : fc_fwd_args(c, c->ws[0], l, B), {cP});
+      tcP = G.gemm(nextp ? with_next(fc_fwd_args(tc, tc->ws[0], l, B), tc, d->fc_part[3]) : fc_fwd_args(tc, tc->ws[0], l, B), {tcP});
     }
     const int hk = G.fn([=] { return launch_ddpg_heads(ctx, hd); }, {aF, taF, cP, tcP});
     // ---- actor backward below its head (the head's dX is part of the fused kernel)

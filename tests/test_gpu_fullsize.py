@@ -407,3 +407,16 @@ def test_chained_gemm_levels_are_bit_identical_to_one_launch_per_level():
         assert r.returncode == 0 and m, r.stdout.decode()[-1500:]
         out[name] = m.group(1)
     assert out["chained"] == out["levels"] == out["release"], out
+
+
+def test_next_layer_slices_in_the_first_fc_level_stay_parity_green_when_selected():
+    """CPP_FC_NEXT=1 (ablation build; an experiment that measured no gain): the tiles of the first fully connected layer leave their slices
+    of the next layer's sum and ddpg_heads_kernel finishes that layer -- one GEMM level less.  Same parity cases, incl. the full-size fused step."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"),
+                        os.path.join(root, "tests", "test_gpu_fused_fullsize.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "fused or gradients or train_ops or cfg3"], cwd=root, env=dict(os.environ, CARTPOLEPP_ABLATION="1", CPP_FC_NEXT="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    tail = r.stdout.decode()[-1500:]
+    assert r.returncode == 0 and " passed" in tail, tail
