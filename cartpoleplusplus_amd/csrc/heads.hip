@@ -13,6 +13,13 @@
 // left as one partial per workgroup; whoever reads the loss adds them in order.
 #include "common.h"
 
+// the slices path (DdpgHeadsArgs::p1a / p2c: an experiment, rt_ddpg.cpp CPP_FC_NEXT) exists in the ablation build only: compiled into the
+// release kernel it cost 1.1 us per launch without ever running (12.5 vs 11.4 us under rocprofv3)
+#ifdef CPP_ABLATION
+constexpr bool HEADS_SLICES = true;
+#else
+constexpr bool HEADS_SLICES = false;
+#endif
 constexpr int HEADS_THREADS = 256, HEADS_TEAM = 64, HEADS_ROWS = HEADS_THREADS / HEADS_TEAM, HEADS_AMAX = 8;
 constexpr int HEADS_NW4 = 5;                           // 16-byte chunks of [W3; b3] per thread: (n2c + A + 1) * n3 + slack <= 20 * 256
 constexpr int HEADS_NW4P = 5;                          // the same for [W2; b2] of the optional actor layer
@@ -104,7 +111,7 @@ __global__ __launch_bounds__(HEADS_THREADS) void ddpg_heads_kernel(const DdpgHea
       w2v[n] = __builtin_amdgcn_raw_buffer_load_b128(rw, i * 16, 0, 0);
       w2tv[n] = __builtin_amdgcn_raw_buffer_load_b128(rwt, i * 16, 0, 0);
     }
-    if (h.p1a) {   // the layer that produces h1a / h1ta was left as np1 slices per row by the level in front of it (GemmArgs::next_part).
+    if (HEADS_SLICES && h.p1a) {   // the layer that produces h1a / h1ta was left as np1 slices per row by the level in front of it (GemmArgs::next_part).
       // Branch-free loads through bounded descriptors (a slice index >= np1, a row >= B or a unit >= n1a asks behind the end and gets
       // zero): with `in range ? load : 0` every load sat in a basic block of its own behind an s_waitcnt vmcnt(0) -- 54 round trips.
       const int OOB = 0x7FFFFF00;
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(HEADS_THREADS) void ddpg_heads_kernel(const DdpgHea
     xtav = (rv && t < n2a) ? h.h2ta[(long)row * h.ld_h2a + t] : 0.f;
   }
   float xcv = 0.f, xtcv = 0.f;
-  if (h.p2c) {     // likewise the critics' layer in front of the concat layer: np2 slices per row
+  if (HEADS_SLICES && h.p2c) {     // likewise the critics' layer in front of the concat layer: np2 slices per row
     const int OOB = 0x7FFFFF00;
     const bool ok = rv && t < n2c;
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(h.p2c), 0, h.np2 * h.B * n2c * 4, 0x00020000);
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(HEADS_THREADS) void ddpg_heads_kernel(const DdpgHea
     const int i = tid + n * HEADS_THREADS;
     wov[n] = i < (n2a + 1) * A ? h.Wo[i] : 0.f; wotv[n] = i < (n2a + 1) * A ? h.Wo_t[i] : 0.f;
   }
-  if (h.p1a) {     // (every load of the kernel has been issued) the slices' sums in slice order, bias, ReLU; the live networks' activations go
+  if (HEADS_SLICES && h.p1a) {     // (every load of the kernel has been issued) the slices' sums in slice order, bias, ReLU; the live networks' activations go
                    // where the backward GEMMs read them
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
@@ -347,7 +354,7 @@ size_t ddpg_heads_lds_bytes(const DdpgHeadsArgs& h) {
 }
 
 bool ddpg_heads_supported(const DdpgHeadsArgs& h) {
-  if ((h.p1a || h.p2c) && !(h.n1a > 0 && h.p1a && h.p2c && h.np1 >= 1 && h.np1 <= HEADS_NP1_MAX && h.np2 >= 1 && h.np2 <= HEADS_NP2_MAX)) return false;
+  if ((h.p1a || h.p2c) && !(HEADS_SLICES && h.n1a > 0 && h.p1a && h.p2c && h.np1 >= 1 && h.np1 <= HEADS_NP1_MAX && h.np2 >= 1 && h.np2 <= HEADS_NP2_MAX)) return false;
   if (h.n1a && !(h.n1a <= HEADS_N1MAX && (h.n2a & 1) == 0 &&
                  (h.n1a + 1) * h.n2a + HEADS_WSLACK + 4 <= 4 * HEADS_NW4P * HEADS_THREADS)) return false;
   return h.A <= HEADS_AMAX && h.n3 <= HEADS_N3P && h.n2a <= HEADS_TEAM && h.n2c <= HEADS_TEAM &&
