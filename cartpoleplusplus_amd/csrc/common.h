@@ -389,6 +389,17 @@ struct NafHeadsArgs {
   unsigned long long* step_bump;                     // non-null: += 1 (the optimiser's step counter: nobody reads it before the optimiser launch)
 };
 #define NAF_HEADS_MAX_WGS 64
+// ... and with TWO hidden layers (the reference's 100, 50) the second one as well, forward and backward, on the matrix pipes
+// (gemm.hip: naf_mlp_kernel): h = the heads' arguments (x / xt / Y unused: the representation is computed here; drep = dz of layer 1)
+struct NafMlpArgs {
+  NafHeadsArgs h;
+  const float *x0, *x0t; long ld0; int n0;           // first hidden layer's activations [n0 values, 1.0], live and target
+  const float *W1, *W1t;                             // [(n0 + 1)][rep]
+  float* h1_out; long ld1;                           // the live representation, where the heads' dW GEMMs read it (B x (rep + 1))
+  float* dz0;                                        // B x n0: dz of the first hidden layer
+};
+bool naf_mlp_supported(const NafMlpArgs& m);
+int launch_naf_mlp(cpp_ctx* ctx, const NafMlpArgs& m);
 bool naf_heads_supported(const NafHeadsArgs& a);
 int launch_naf_heads(cpp_ctx* ctx, const NafHeadsArgs& a);
 

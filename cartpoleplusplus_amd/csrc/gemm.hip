@@ -845,3 +845,292 @@ int launch_naf_heads(cpp_ctx* ctx, const NafHeadsArgs& a) {
   prof_end(ctx, K_NAF_HEAD);
   return 0;
 }
+
+// ---- NAF, shared representation with TWO hidden layers (the reference's pixel NAF: 100, 50): everything between the first hidden
+// layer's activations and the one backward GEMM level that is left, row-local, on the matrix pipes (NafMlpArgs, common.h).
+// A workgroup owns 16 batch rows (grid = ceil(B / 16)); its four waves each own one 16-column tile:
+//   1. h1 = relu([h0, 1] [W1; b1]) for the live and the target network (26 MFMA steps each, operands straight from global memory);
+//   2. the four head layers from h1 (through LDS: accumulator layout -> A-operand layout), 13 steps (wave 0: value, mu, l_values;
+//      wave 1: the target's value);
+//   3. naf_head_kernel's arithmetic, one lane per row (wave 0);
+//   4. dz1 = relu'(h1) (dz_heads [Wv | Wmu | Wl]^T) -- the contributions in the MFMA's k order value, mu.., l.. -- and
+//   5. dz0 = relu'(h0) (dz1 W1^T), 13 steps per tile, two tiles per wave.
+// Every global load is issued before the first use.  loss = mean(td^2): a partial per workgroup, written through; the last workgroup
+// to arrive adds them in order (at most B / 16 of them).
+constexpr int NAFM_S1 = 26, NAFM_S2 = 13, NAFM_LD = 52, NAFM_XS = 105, NAFM_XL = 7;   // XL: ceil(16 * 104 / 256) staged elements per thread
+// S1, S2:      // k steps of layer 1 (n0 + 1 <= 104) and of the heads / dX (n1 + 1 <= 52); LDS row stride
+template <int AT>
+__global__ __launch_bounds__(256) void naf_mlp_kernel(const NafMlpArgs m) {
+  const NafHeadsArgs& a = m.h;
+  constexpr int A = AT, NL = A * (A + 1) / 2, NO = 1 + A + NL;
+  static_assert(NO <= 15, "head values per row");
+  constexpr int OOB = 0x7FFFFF00;
+  __shared__ __attribute__((aligned(16))) float h1s[16][NAFM_LD], h1ts[16][NAFM_LD], dz1s[16][NAFM_LD], outs[16][16], dzs[16][16], outt[16];
+  __shared__ float x0s[16][NAFM_XS], x0ts[16][NAFM_XS];      // h0 rows; odd stride: the A-operand reads of 16 rows fall on different banks
+  __shared__ int lbad;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lj = lane >> 4, r0 = blockIdx.x * 16;
+  const int n0 = m.n0, n1 = a.rep, K1 = n0 + 1, K2 = n1 + 1;
+  if (tid == 0) lbad = 0;
+  if (tid == 0 && blockIdx.x == 0 && a.step_bump) *a.step_bump += 1ull;
+  // ---- every global load, up front
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(m.x0), 0, (int)((long)a.B * m.ld0 * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rxt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(m.x0t), 0, (int)((long)a.B * m.ld0 * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(m.W1), 0, K1 * n1 * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(m.W1t), 0, K1 * n1 * 4, 0x00020000);
+  // the 16 rows of h0 (live, target) go through LDS once per workgroup (each wave needs all of them as its A operand: read straight
+  // from global memory by every wave, the 26 + 26 four-byte loads per lane touched 16 cache lines each -- 4.7 us of the CU's one
+  // address path)
+  float xg[NAFM_XL], xgt[NAFM_XL];
+#pragma unroll
+  for (int u = 0; u < NAFM_XL; ++u) {
+    const int e = tid + 256 * u, rr = e / K1, k = e - rr * K1;
+    const int ao = rr < 16 ? ((r0 + rr) * m.ld0 + k) * 4 : OOB;                    // (rows past the batch are behind the descriptor's end)
+    xg[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, ao, 0, 0));
+    xgt[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rxt, ao, 0, 0));
+  }
+  float b1[NAFM_S1], b1t[NAFM_S1];
+  const int ncol = 16 * w + li;                              // this lane's column of layer 1 / unit of the representation
+#pragma unroll
+  for (int s = 0; s < NAFM_S1; ++s) {
+    const int k = 4 * s + lj;
+    const int bo = (k < K1 && ncol < n1) ? (k * n1 + ncol) * 4 : OOB;
+    b1[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, bo, 0, 0));
+    b1t[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rwt, bo, 0, 0));
+  }
+  // head weights as the B operand [k][o = li]: wave 0 the live heads, wave 1 the target's value (column 0 only).  A lane's column lives in
+  // ONE of the four matrices; every lane asks all of them through bounded descriptors, with an offset behind the end where the matrix is
+  // not its own (zero comes back), and adds what arrives: no branch around a load (as `cond ? p[i] : q[j]` each of the 13 loads sat in a
+  // basic block of its own behind s_waitcnt vmcnt(0): 13 round trips, most of this kernel's first version).
+  const __amdgpu_buffer_rsrc_t rv_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wv), 0, K2 * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rvt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wvt), 0, K2 * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rmu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wmu), 0, K2 * A * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wl), 0, K2 * NL * 4, 0x00020000);
+  const bool is_v = w == 0 && li == 0, is_vt = w == 1 && li == 0, is_mu = w == 0 && li >= 1 && li < 1 + A, is_l = w == 0 && li >= 1 + A && li < NO;
+  float bh[NAFM_S2];
+#pragma unroll
+  for (int s = 0; s < NAFM_S2; ++s) {
+    const int k = 4 * s + lj;
+    const bool kin = k < K2;
+    const float v0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rv_, (is_v && kin) ? k * 4 : OOB, 0, 0));
+    const float v1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rvt, (is_vt && kin) ? k * 4 : OOB, 0, 0));
+    const float v2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rmu, (is_mu && kin) ? (k * A + li - 1) * 4 : OOB, 0, 0));
+    const float v3 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rl, (is_l && kin) ? (k * NL + li - 1 - A) * 4 : OOB, 0, 0));
+    bh[s] = (v0 + v1) + (v2 + v3);                          // (three of the four are zero)
+  }
+  // dz1's B operand [k = o][n = unit j]: the heads' weights of unit j = ncol, the same way
+  float bd[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int o = 4 * s + lj;
+    const bool jin = ncol < n1;
+    const float v0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rv_, (jin && o == 0) ? ncol * 4 : OOB, 0, 0));
+    const float v2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rmu, (jin && o >= 1 && o < 1 + A) ? (ncol * A + o - 1) * 4 : OOB, 0, 0));
+    const float v3 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rl, (jin && o >= 1 + A && o < NO) ? (ncol * NL + o - 1 - A) * 4 : OOB, 0, 0));
+    bd[s] = v0 + (v2 + v3);
+  }
+  // dz0's B operand [k = unit j][n = input unit mm] = W1[mm][j], two column tiles per wave; and h0 in the accumulator layout (the mask)
+  float bx[2][NAFM_S2];
+#pragma unroll
+  for (int t2 = 0; t2 < 2; ++t2) {
+    const int mm = 16 * (w + 4 * t2) + li;
+#pragma unroll
+    for (int s = 0; s < NAFM_S2; ++s) {
+      const int j = 4 * s + lj;
+      bx[t2][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, (mm < n0 && j < n1) ? (mm * n1 + j) * 4 : OOB, 0, 0));
+    }
+  }
+  const int hrow = r0 + (lane & 15);
+  const bool hrv = w == 0 && lane < 16 && hrow < a.B;        // the lanes that run the head arithmetic
+  float act[A];
+#pragma unroll
+  for (int i = 0; i < A; ++i) act[i] = hrv ? a.action[(long)hrow * A + i] : 0.f;
+  const float rew = hrv ? a.reward[hrow] : 0.f, msk = hrv ? a.mask[hrow] : 0.f;
+  // LDS: zero, the bias inputs
+  for (int i = tid; i < 16 * NAFM_LD; i += 256) {
+    const float one = (i % NAFM_LD) == n1 ? 1.f : 0.f;
+    (&h1s[0][0])[i] = one; (&h1ts[0][0])[i] = one; (&dz1s[0][0])[i] = 0.f;
+  }
+  (&dzs[0][0])[tid] = 0.f; (&outs[0][0])[tid] = 0.f;
+  if (tid < 16) outt[tid] = 0.f;
+#pragma unroll
+  for (int u = 0; u < NAFM_XL; ++u) {
+    const int e = tid + 256 * u, rr = e / K1, k = e - rr * K1;
+    if (rr < 16) { x0s[rr][k] = xg[u]; x0ts[rr][k] = xgt[u]; }
+  }
+  if (tid < 16) for (int k = K1; k < 4 * NAFM_S1; ++k) { x0s[tid][k] = 0.f; x0ts[tid][k] = 0.f; }      // (k steps past the row: zero)
+  __syncthreads();
+  // ---- 1. layer 1, live and target
+  f32x4 c1 = (f32x4){0.f, 0.f, 0.f, 0.f}, c1t = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < NAFM_S1; ++s) { c1 = MFMA16(x0s[li][4 * s + lj], b1[s], c1); c1t = MFMA16(x0ts[li][4 * s + lj], b1t[s], c1t); }
+  float h1v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 4 * lj + i;
+    h1v[i] = fmaxf(c1[i], 0.f);
+    if (ncol < n1) {
+      h1s[row][ncol] = h1v[i]; h1ts[row][ncol] = fmaxf(c1t[i], 0.f);
+      if (r0 + row < a.B) m.h1_out[(long)(r0 + row) * m.ld1 + ncol] = h1v[i];
+    }
+  }
+  __syncthreads();
+  // ---- 2. the head layers
+  if (w < 2) {
+    const float (*src)[NAFM_LD] = w == 0 ? h1s : h1ts;
+    f32x4 ch = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NAFM_S2; ++s) ch = MFMA16(src[li][4 * s + lj], bh[s], ch);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (w == 0) outs[4 * lj + i][li] = ch[i];
+      else if (li == 0) outt[4 * lj + i] = ch[i];
+    }
+  }
+  __syncthreads();
+  // ---- 3. naf_head_kernel's row (naf_cartpole.py:186-230), one lane per row
+  double s2 = 0.0;
+  if (hrv) {
+    const int b = hrow, l = lane;
+    float hv[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const f32x4 v4 = *reinterpret_cast<const f32x4*>(&outs[l][4 * i]); hv[4 * i] = v4[0]; hv[4 * i + 1] = v4[1]; hv[4 * i + 2] = v4[2]; hv[4 * i + 3] = v4[3]; }
+    const float value = hv[0], tvalue = outt[l];
+    float mu[A], L[A][A], d[A], z[A];
+    int mybad = 0;
+#pragma unroll
+    for (int i = 0; i < A; ++i) mu[i] = tanhf(hv[1 + i]);
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+      const int off = i * (i + 1) / 2;
+#pragma unroll
+      for (int j = 0; j < A; ++j) L[i][j] = 0.f;
+#pragma unroll
+      for (int j = 0; j < i; ++j) { L[i][j] = hv[1 + A + off + j]; if (!isfinite(L[i][j])) mybad = 1; }
+      L[i][i] = expf(hv[1 + A + off + i]);
+      if (!isfinite(hv[1 + A + off + i]) || !isfinite(L[i][i])) mybad = 1;
+      d[i] = act[i] - mu[i];
+    }
+    float zz = 0.f;
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = j; i < A; ++i) t += L[i][j] * d[i];
+      z[j] = t; zz += t * t;
+    }
+    const float adv = -0.5f * zz, qv = value + adv;
+    const float y = rew + (msk * a.discount) * tvalue;
+    const float td = qv - y;
+    a.value[b] = value; a.target_value[b] = tvalue;
+#pragma unroll
+    for (int i = 0; i < A; ++i) a.mu[(long)b * A + i] = mu[i];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) a.lv[(long)b * NL + j] = hv[1 + A + j];
+    if (a.adv) a.adv[b] = adv;
+    if (a.q) a.q[b] = qv;
+    if (a.td) a.td[b] = td;
+    s2 = (double)td * (double)td;
+    const float dq = td * (2.f / (float)a.B);
+    a.d_value[b] = dq;
+    float dz[A], dzr[NO];
+#pragma unroll
+    for (int j = 0; j < A; ++j) dz[j] = -z[j] * dq;
+    dzr[0] = dq;
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+      const int off = i * (i + 1) / 2;
+      float dd = 0.f;
+#pragma unroll
+      for (int j = 0; j <= i; ++j) dd += L[i][j] * dz[j];
+#pragma unroll
+      for (int j = 0; j < i; ++j) dzr[1 + A + off + j] = d[i] * dz[j];
+      dzr[1 + A + off + i] = d[i] * dz[i] * L[i][i];
+      dzr[1 + i] = -dd * (1.f - mu[i] * mu[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < A; ++i) a.d_mu_z[(long)b * A + i] = dzr[1 + i];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) a.d_l[(long)b * NL + j] = dzr[1 + A + j];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) dzs[l][o] = dzr[o];
+    if (mybad) atomicOr(&lbad, 1);
+  }
+  if (w == 0) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);       // (lanes 16 .. 63 hold zero)
+  }
+  __syncthreads();
+  // ---- 4. dz1
+  {
+    f32x4 cd = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) cd = MFMA16(dzs[li][4 * s + lj], bd[s], cd);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 4 * lj + i;
+      const float v = h1v[i] > 0.f ? cd[i] : 0.f;
+      if (ncol < n1) {
+        dz1s[row][ncol] = v;
+        if (r0 + row < a.B) a.drep[(long)(r0 + row) * a.ldd + ncol] = v;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 5. dz0
+#pragma unroll
+  for (int t2 = 0; t2 < 2; ++t2) {
+    const int mm = 16 * (w + 4 * t2) + li;
+    if (16 * (w + 4 * t2) < n0) {                            // (uniform per wave)
+      f32x4 cx = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NAFM_S2; ++s) cx = MFMA16(dz1s[li][4 * s + lj], bx[t2][s], cx);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = r0 + 4 * lj + i;
+        if (mm < n0 && row < a.B) m.dz0[(long)row * n0 + mm] = x0s[4 * lj + i][mm] > 0.f ? cx[i] : 0.f;
+      }
+    }
+  }
+  // ---- loss: this workgroup's partial, written through; the last workgroup to arrive adds them in order
+  if (tid == 0) {
+    double sum = s2; int bad = lbad; bool last = gridDim.x == 1;
+    if (!last) {
+      __hip_atomic_store(a.part + blockIdx.x, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.part + NAF_HEADS_MAX_WGS + blockIdx.x, lbad ? 1.0 : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_s_waitcnt(0);
+      const unsigned t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t + 1u == gridDim.x) {
+        last = true; sum = 0.0; bad = 0;
+        for (unsigned i = 0; i < gridDim.x; ++i) {
+          sum += __hip_atomic_load(a.part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bad |= __hip_atomic_load(a.part + NAF_HEADS_MAX_WGS + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0;
+        }
+        __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (last) {
+      const float loss = (float)(sum / (double)a.B);
+      a.loss[0] = loss;
+      if (a.nonfinite && (bad || !isfinite(loss))) a.nonfinite[0] = 1;
+    }
+  }
+}
+
+bool naf_mlp_supported(const NafMlpArgs& m) {
+  const NafHeadsArgs& a = m.h;
+  return a.A >= 1 && a.A <= 4 && a.rep >= 1 && a.rep + 1 <= 4 * NAFM_S2 && a.rep <= 64 && m.n0 >= 1 && m.n0 + 1 <= 4 * NAFM_S1 && 16 * (m.n0 + 1) <= 256 * NAFM_XL && m.n0 <= 128 &&
+         a.drep && m.dz0 && m.h1_out && a.ldd == a.rep && (a.B + 15) / 16 <= NAF_HEADS_MAX_WGS;
+}
+
+int launch_naf_mlp(cpp_ctx* ctx, const NafMlpArgs& m) {
+  typedef void (*kern_t)(const NafMlpArgs);
+  static const kern_t kerns[4] = {naf_mlp_kernel<1>, naf_mlp_kernel<2>, naf_mlp_kernel<3>, naf_mlp_kernel<4>};
+  const int A = m.h.A;
+  if (A < 1 || A > 4) { cpp_set_error("naf mlp: action_dim %d", A); return 1; }
+  prof_begin(ctx);
+  hipLaunchKernelGGL(kerns[A - 1], dim3((m.h.B + 15) / 16), dim3(256), 0, ctx->stream, m);
+  LAUNCH_CHECK();
+  prof_end(ctx, K_NAF_HEAD);
+  return 0;
+}

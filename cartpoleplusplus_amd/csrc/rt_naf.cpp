@@ -215,8 +215,6 @@ static int naf_compute_gradients(cpp_naf* f, cpp_batch* b, bool fold = false) {
     return dep;
   };
   const int Lh = (int)v->fc.size() - 1;                 // value's 'fc' head
-  int vrep = t1;
-  for (int l = 0; l < Lh; ++l) vrep = G.gemm(fc_fwd_args(v, v->ws[0], l, B), {vrep});
   // Shared representation with a hidden stack (the reference's pixel NAF, naf_cartpole.py:151-152): the four head layers, the
   // head arithmetic and d(representation) are ONE row-local launch (naf_heads_kernel, gemm.hip) instead of a forward GEMM level,
   // the head kernel and three dependent GEMM levels.  CPP_NAF_HEADS=0 (ablation build): the GEMM levels.
@@ -237,11 +235,26 @@ static int naf_compute_gradients(cpp_naf* f, cpp_batch* b, bool fold = false) {
     nh.step_bump = fold ? (unsigned long long*)f->opt_step : nullptr;
     fused = naf_heads_supported(nh) && (nh.epi == GE_MUL_RELU_GRAD || nh.epi == GE_MUL_RELU_GRAD_X2);
   }
+  // ... and with exactly two hidden layers (the reference's 100, 50) the second one joins that launch, forward and backward, on the
+  // matrix pipes (naf_mlp_kernel): one forward and one backward GEMM level are left.  CPP_NAF_MLP=0 (ablation build): naf_heads_kernel.
+  static const bool no_mlp = cpp_switch_off("CPP_NAF_MLP");
+  NafMlpArgs nm; memset(&nm, 0, sizeof(nm));
+  bool mlp = fused && !no_mlp && Lh == 2 && v->fc[0].act == GE_RELU && v->fc[1].act == GE_RELU && tv->fc[1].act == GE_RELU &&
+             relu_grad_epi(v, 0) == GE_MUL_RELU_GRAD && relu_grad_epi(v, 1) == GE_MUL_RELU_GRAD && !v->drop_counter;
+  if (mlp) {
+    nm.h = nh;
+    nm.x0 = v->ws[0].fcin[1]; nm.x0t = tv->ws[0].fcin[1]; nm.ld0 = v->fc[1].n_in + 1; nm.n0 = v->fc[1].n_in;
+    nm.W1 = v->params + v->fc[1].w_off; nm.W1t = tv->params + tv->fc[1].w_off;
+    nm.h1_out = v->ws[0].fcin[2]; nm.ld1 = v->fc[2].n_in + 1; nm.dz0 = v->ws[0].dz[0];
+    mlp = naf_mlp_supported(nm);
+  }
+  int vrep = t1;
+  for (int l = 0; l < Lh - (mlp ? 1 : 0); ++l) vrep = G.gemm(fc_fwd_args(v, v->ws[0], l, B), {vrep});
   int vout, tvout, muout, lvout;
   if (fused) {
     f->step_bumped = nh.step_bump != nullptr;
     int tvrep = t1;
-    for (int l = 0; l < Lh; ++l) tvrep = G.gemm(fc_fwd_args(tv, tv->ws[0], l, B), {tvrep});
+    for (int l = 0; l < Lh - (mlp ? 1 : 0); ++l) tvrep = G.gemm(fc_fwd_args(tv, tv->ws[0], l, B), {tvrep});
     vout = vrep; tvout = tvrep; muout = lvout = vrep;
   } else {
     vout = G.gemm(fc_fwd_args(v, v->ws[0], Lh, B), {vrep});
@@ -255,7 +268,8 @@ static int naf_compute_gradients(cpp_naf* f, cpp_batch* b, bool fold = false) {
     if (!share) { G.fn([=] { return bump_dropout(mu); }, {muout}); G.fn([=] { return bump_dropout(lv); }, {lvout}); }
   }
   // ---- NAF head: L, advantage, TD loss and the gradients of the three head outputs
-  const int head = fused ? G.fn([=] { return launch_naf_heads(ctx, nh); }, {vout, tvout})
+  const int head = mlp ? G.fn([=] { return launch_naf_mlp(ctx, nm); }, {vout, tvout})
+                 : fused ? G.fn([=] { return launch_naf_heads(ctx, nh); }, {vout, tvout})
                          : G.fn([=] { return naf_head(f, b, true); }, {vout, tvout, muout, lvout});
 
   // ---- backward
@@ -288,7 +302,8 @@ static int naf_compute_gradients(cpp_naf* f, cpp_batch* b, bool fold = false) {
         dep = G.gemm(g, {dep});                  // accumulation order value -> mu -> l_values is fixed
       }
     }
-    const int dv = add_fc_backward(G, v, v->ws[0], B, Lh - 1, dep, sqg);
+    if (mlp) G.gemm(sqg(fc_dw_args(v, v->ws[0], 1, B, v->ws[0].dz[1])), {head});      // (dz[1] and dz[0] came out of naf_mlp_kernel)
+    const int dv = add_fc_backward(G, v, v->ws[0], B, mlp ? 0 : Lh - 1, dep, sqg);
     if (v->spec.pixel) {     // conv3's and conv2's dW + dX as one launch each, like the DDPG step (nets_backward_conv)
       cpp_net* bn[1] = {v};
       G.fn([=] { return nets_backward_conv(ctx, bn, 1, B, s1, dt, w1); }, {dv});

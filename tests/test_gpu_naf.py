@@ -290,15 +290,17 @@ def test_cfg4_B256_graph_replayed_naf_step_against_f64_oracle(shape, B, share):
     assert np.linalg.norm(d_got - d_want) < 2.0 ** -23 * np.linalg.norm(before) + 5e-5 * np.linalg.norm(d_want)
 
 
-def test_gemm_level_naf_heads_stay_parity_green_when_selected():
-    """CPP_NAF_HEADS=0 (ablation build) keeps the shared-trunk NAF heads as GEMM levels + naf_head_kernel (the path of networks the
-    fused naf_heads_kernel does not cover: no hidden stack, action_dim > 4, wide representations): the same parity cases must pass
-    on it, and the loss and gradients of the two paths must agree at rounding level."""
+@pytest.mark.parametrize("switch", ["CPP_NAF_MLP", "CPP_NAF_HEADS"])
+def test_the_other_naf_head_paths_stay_parity_green_when_selected(switch):
+    """The shared-trunk NAF step runs everything between the first hidden layer and the one backward GEMM level that is left in
+    naf_mlp_kernel (two hidden layers, the reference's 100, 50).  CPP_NAF_MLP=0 (ablation build) leaves the second hidden layer to GEMM
+    levels and the heads to naf_heads_kernel (the path of one or three hidden layers); CPP_NAF_HEADS=0 keeps GEMM levels + naf_head_kernel
+    (no hidden stack, action_dim > 4, wide representations).  The same parity cases must pass on both."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_naf.py"), "-q", "-x", "-m", "gpu",
                         "-k", "forward_gradients or fused_train_step or cfg4"], cwd=root,
-                       env=dict(os.environ, CARTPOLEPP_ABLATION="1", CPP_NAF_HEADS="0"), stdout=subprocess.PIPE,
+                       env=dict(os.environ, CARTPOLEPP_ABLATION="1", **{switch: "0"}), stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=900)
     tail = r.stdout.decode()[-1500:]
     assert r.returncode == 0 and " passed" in tail, tail
