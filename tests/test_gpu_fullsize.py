@@ -420,3 +420,17 @@ def test_next_layer_slices_in_the_first_fc_level_stay_parity_green_when_selected
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     tail = r.stdout.decode()[-1500:]
     assert r.returncode == 0 and " passed" in tail, tail
+
+
+def test_ddpg_core_kernel_stays_parity_green_when_selected():
+    """CPP_DDPG_CORE=1 (ablation build; an experiment that measured slower): ONE kernel on the matrix pipes for everything between the
+    first fully connected layers and the backward GEMM level (ddpg_core.hip) instead of ddpg_heads_kernel and two GEMM levels.  Same
+    parity cases, incl. the full-size fused step against the float64 oracle."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"),
+                        os.path.join(root, "tests", "test_gpu_fused_fullsize.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "fused or gradients or train_ops or cfg3"], cwd=root, env=dict(os.environ, CARTPOLEPP_ABLATION="1", CPP_DDPG_CORE="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    tail = r.stdout.decode()[-1500:]
+    assert r.returncode == 0 and " passed" in tail, tail
