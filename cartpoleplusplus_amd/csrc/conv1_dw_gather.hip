@@ -20,7 +20,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv1_dw_pair_gather_kernel(c
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double* dsh = reinterpret_cast<double*>(lds_raw);
     float* sh = reinterpret_cast<float*>(lds_raw + CPP_MAX_CHANNELS * 16 * 8);
-    float* lut = sh + 256 * 16;
+    float* lut = sh + 256 * GATHER_SH;
     const int i = (int)blockIdx.x - ndw;
     gather_stats_body<__half>(g, i % g.B, i / g.B, sh, dsh, lut);
   }
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(CONV_THREADS, DW16_WGS) void conv1_dw_gather_kernel
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double* dsh = reinterpret_cast<double*>(lds_raw);
     float* sh = reinterpret_cast<float*>(lds_raw + CPP_MAX_CHANNELS * 16 * 8);
-    float* lut = sh + 256 * 16;
+    float* lut = sh + 256 * GATHER_SH;
     const int i = (int)blockIdx.x - ndw;
     gather_stats_body<__half>(g, i % g.B, i / g.B, sh, dsh, lut);
   }

@@ -1,10 +1,16 @@
 // The fused uniform-sample + minibatch-gather + whitening-statistics pass as a device function (replay_memory.py:123-138 +
 // base_network.py:95-96): gather_stats_kernel (replay.hip) is a wrapper around it, and so are the launches it shares with another
-// kernel (reduce_gather_kernel, conv1_dw_gather_kernel).  The caller provides its LDS: sh [256 * 16] floats, dsh
+// kernel (reduce_gather_kernel, conv1_dw_gather_kernel).  The caller provides its LDS: sh [256 * GATHER_SH] floats, dsh
 // [CPP_MAX_CHANNELS * 16] doubles, lut [256] floats.
+//
+// The sums are EXACT for pixel states (round 4): var = E[x^2] - mu^2 cancels 20-80 x on a render's near-constant channels (a sky, a
+// floor), where the f32 per-lane chains of rounds 1-3 (36 terms each, 1e-7 relative) moved the whitening scale by 2e-6 relative --
+// 5e-5 absolute on conv1 outputs of magnitude 13 (profiles/experiments/r04_render_probe.txt).  A lane now carries both sums in f64 (the square of an f16 has 22 bits, a
+// lane adds <= ~10^2 of them: exact); they cross LDS as (hi, lo) float pairs and are combined in f64 as before.
 #pragma once
 #include "common.h"
-constexpr int GATHER_LDS_BYTES = 256 * 16 * 4 + CPP_MAX_CHANNELS * 16 * 8 + 256 * 4;
+constexpr int GATHER_SH = 16;      // floats per thread: (hi, lo) of one statistic's 8 element sums
+constexpr int GATHER_LDS_BYTES = 256 * GATHER_SH * 4 + CPP_MAX_CHANNELS * 16 * 8 + 256 * 4;
 
 __device__ __forceinline__ int sample_row(uint64_t seed, uint64_t counter, int b, int size) {
   u32x4 c = {(uint32_t)b, 0u, (uint32_t)counter, (uint32_t)(counter >> 32)};
@@ -110,9 +116,9 @@ __device__ __forceinline__ void gather_stats_body(const GatherArgs& a, const int
 
   const int P = C / gcd_int(8, C);
   const int act = (64 / P) * P;                   // lanes in use per wave: multiple of the period
-  float s[8], ss[8];
+  double s[8], ss[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+  for (int e = 0; e < 8; ++e) { s[e] = 0.0; ss[e] = 0.0; }
   if (lane < act) {
     // GU row vectors per thread in flight (one 16-byte load each is far too little to cover the HBM latency with two
     // workgroups per CU); the accumulation order per lane is unchanged
@@ -127,7 +133,7 @@ __device__ __forceinline__ void gather_stats_body(const GatherArgs& a, const int
       for (int u = 0; u < GU; ++u) {
         if (dst) x[u].store(dst + (v + u * stride) * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float f = x[u].get(e); s[e] += f; ss[e] = fmaf(f, f, ss[e]); }
+        for (int e = 0; e < 8; ++e) { const double f = (double)x[u].get(e); s[e] += f; ss[e] = fma(f, f, ss[e]); }
       }
     }
     for (; v < nvec; v += stride) {
@@ -136,23 +142,33 @@ __device__ __forceinline__ void gather_stats_body(const GatherArgs& a, const int
       x.load(src + v * 8);
       if (dst) x.store(dst + v * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { const float f = x.get(e); s[e] += f; ss[e] = fmaf(f, f, ss[e]); }
+      for (int e = 0; e < 8; ++e) { const double f = (double)x.get(e); s[e] += f; ss[e] = fma(f, f, ss[e]); }
     }
   }
+  // stage 2: per (class q, element e): sum the lanes of that class over the 4 waves, in f64.  One statistic at a time, each f64
+  // lane sum crossing LDS as a (hi, lo) float pair (48 bits of a sum of <= ~10^2 terms of <= 22 bits: nothing is lost)
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { sh[tid * 16 + e] = s[e]; sh[tid * 16 + 8 + e] = ss[e]; }
-  __syncthreads();
-  // stage 2: per (class q, element e): sum the lanes of that class over the 4 waves, in f64
-  if (tid < P * 16) {
-    const int q = tid >> 4, e = tid & 15;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;    // one chain per wave: four LDS reads in flight instead of one
-    for (int l = q; l < act; l += P) {
-      a0 += (double)sh[(0 * 64 + l) * 16 + e]; a1 += (double)sh[(1 * 64 + l) * 16 + e];
-      a2 += (double)sh[(2 * 64 + l) * 16 + e]; a3 += (double)sh[(3 * 64 + l) * 16 + e];
+  for (int stat = 0; stat < 2; ++stat) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const double v = stat ? ss[e] : s[e];
+      const float hi = (float)v;
+      sh[tid * GATHER_SH + e] = hi; sh[tid * GATHER_SH + 8 + e] = (float)(v - (double)hi);
     }
-    dsh[q * 16 + e] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (tid < P * 8) {
+      const int q = tid >> 3, e = tid & 7;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;    // one chain per wave: four LDS reads in flight instead of one
+      for (int l = q; l < act; l += P) {
+        a0 += (double)sh[(0 * 64 + l) * GATHER_SH + e] + (double)sh[(0 * 64 + l) * GATHER_SH + 8 + e];
+        a1 += (double)sh[(1 * 64 + l) * GATHER_SH + e] + (double)sh[(1 * 64 + l) * GATHER_SH + 8 + e];
+        a2 += (double)sh[(2 * 64 + l) * GATHER_SH + e] + (double)sh[(2 * 64 + l) * GATHER_SH + 8 + e];
+        a3 += (double)sh[(3 * 64 + l) * GATHER_SH + e] + (double)sh[(3 * 64 + l) * GATHER_SH + 8 + e];
+      }
+      dsh[q * 16 + stat * 8 + e] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
   }
-  __syncthreads();
   // stage 3: per channel: the (q, e) pairs with (8q + e) % C == c
   if (tid < 2 * C) {
     const int stat = tid / C, c = tid - stat * C;

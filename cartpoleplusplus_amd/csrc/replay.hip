@@ -16,7 +16,7 @@
 
 template <typename T>
 __global__ __launch_bounds__(256) void gather_stats_kernel(const GatherArgs a) {
-  __shared__ float sh[256 * 16];
+  __shared__ float sh[256 * GATHER_SH];
   __shared__ double dsh[CPP_MAX_CHANNELS * 16];
   __shared__ float lut[256];
   gather_stats_body<T>(a, (int)blockIdx.x, (int)blockIdx.y, sh, dsh, lut);
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void reduce_gather_kernel(const DwReduceBatch 
     __shared__ float red[4][64];
     conv_dw_reduce_body<4>(rb, (int)blockIdx.x, red);
   } else {
-    __shared__ float sh[256 * 16];
+    __shared__ float sh[256 * GATHER_SH];
     __shared__ double dsh[CPP_MAX_CHANNELS * 16];
     __shared__ float lut[256];
     const int i = (int)blockIdx.x - nred;
@@ -55,7 +55,7 @@ int launch_reduce_gather(cpp_ctx* ctx, const DwReduceBatch& rb, const GatherArgs
 // the store is state b), so a state's stored sums are bit for bit what a gather of that state computes.
 template <typename T>
 __global__ __launch_bounds__(256) void slot_stats_kernel(const GatherArgs a, const int32_t* slots, int first) {
-  __shared__ float sh[256 * 16];
+  __shared__ float sh[256 * GATHER_SH];
   __shared__ double dsh[CPP_MAX_CHANNELS * 16];
   __shared__ float lut[256];
   const int slot = slots ? slots[blockIdx.x] : first + (int)blockIdx.x;
@@ -124,13 +124,7 @@ __global__ __launch_bounds__(256) void stats_generic_kernel(const T* x, long npi
     if (threadIdx.x < o) { r0[threadIdx.x] += r0[threadIdx.x + o]; r1[threadIdx.x] += r1[threadIdx.x + o]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    const double mean = r0[0] / (double)npix;
-    const double var = r1[0] / (double)npix - mean * mean;
-    const double inv = 1.0 / sqrt(var + eps);
-    white[c] = (float)inv;
-    white[C + c] = (float)(-mean * inv);
-  }
+  if (threadIdx.x == 0) white_from_moments(r0[0], r1[0], (double)npix, eps, &white[c], &white[C + c]);
 }
 
 int launch_stats_generic(cpp_ctx* ctx, const void* x, int dtype, long npix, int C, float* white, double eps) {

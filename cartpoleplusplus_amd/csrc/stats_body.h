@@ -5,6 +5,27 @@
 #pragma once
 #include "common.h"
 
+// (scale, shift) of one channel from its sums over `count` pixels: y = x * scale + shift.
+//
+// A channel that is CONSTANT over the minibatch (a camera that sees one colour: bullet_cartpole.py:227-236 renders whatever is in
+// front of it) has variance 0, scale rsqrt(1e-6) = 1000 and a whitened value of exactly 0 at every pixel -- as the difference of
+// two numbers near 1000 mu.  Kernels that fold the affine map into their weights (conv_k16.h, conv_dw16.h) would carry those two
+// numbers through f32 accumulators and keep their rounding noise (measured, round 4: 4e-4 on conv1 outputs, 3e-3 relative on conv1
+// weight gradients; profiles/experiments/r04_render_probe.txt).  The table of such a channel is therefore (0, 0): x * 0 + 0 is the
+// exact value of (x - mu) * 1000 on this minibatch whichever way a kernel evaluates it, and its weight gradient is exactly 0, as
+// in exact arithmetic.  "Constant" = the variance is zero to the rounding of its own f64 evaluation (the sums themselves are exact
+// for 8-bit pixels, gather_body.h; the smallest variance a non-constant 8-bit channel can have, one pixel off by one code in
+// 8.4 M, is 1.8e-12 -- seven orders above the threshold).
+__device__ __forceinline__ void white_from_moments(double s, double ss, double count, double eps, float* scale, float* shift) {
+  const double mean = s / count;
+  const double m2 = ss / count;
+  const double var = m2 - mean * mean;               // one-pass form of tf.nn.moments (r0.9-r0.11)
+  if (var <= 64.0 * 2.220446049250313e-16 * m2) { *scale = 0.f; *shift = 0.f; return; }
+  const double inv = 1.0 / sqrt(var + eps);
+  *scale = (float)inv;
+  *shift = (float)(-mean * inv);
+}
+
 __device__ __forceinline__ void stats_finalize_wave(const double* part, int nparts, int C, double count, float* white, double eps,
                                                     int job, int lane) {
   const int w = job / C, c = job - w * C;
@@ -15,11 +36,5 @@ __device__ __forceinline__ void stats_finalize_wave(const double* part, int npar
     s += p[c]; ss += p[C + c];
   }
   for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
-  if (lane == 0) {
-    const double mean = s / count;
-    const double var = ss / count - mean * mean;     // one-pass form of tf.nn.moments (r0.9-r0.11)
-    const double inv = 1.0 / sqrt(var + eps);
-    white[(long)w * 2 * C + c] = (float)inv;
-    white[(long)w * 2 * C + C + c] = (float)(-mean * inv);
-  }
+  if (lane == 0) white_from_moments(s, ss, count, eps, &white[(long)w * 2 * C + c], &white[(long)w * 2 * C + C + c]);
 }

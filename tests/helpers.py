@@ -187,8 +187,24 @@ def pool_flips_are_near_ties(cache, device_codes, margin_tol=1e-5, what=""):
     return flips
 
 
+def fill_with_rendered_episodes(agent, shape, rows, seed=0, blind_camera=False, as_u8=False, glint=0.0):
+    """`rows` transitions of random-policy episodes of the software-rasterised cart and pole (synthetic_env.RasterCartpole: flat
+    backgrounds, R nearly identical repeat frames, optionally a camera that sees one colour only) into the agent's replay memory,
+    through ReplayMemory.add_episode as the reference's rollout loop does (ddpg_cartpole.py:315-326)."""
+    from cartpoleplusplus_amd import ddpg_cartpole as D
+    from cartpoleplusplus_amd.synthetic_env import RasterCartpole, play_episodes
+    env = RasterCartpole(D.opts, seed=seed + 1, blind_camera=blind_camera, glint=glint)
+    for first, seq in play_episodes(env, rows, np.random.default_rng(seed + 2)):
+        if as_u8:
+            first = np.rint(first * 255).astype(np.uint8)
+            seq = [(a, r, np.rint(s2 * 255).astype(np.uint8)) for a, r, s2 in seq]
+        agent.replay_memory.add_episode(first, seq)
+    assert agent.replay_memory.size() == rows
+
+
 def fused_step_against_f64_oracle(shape, B, rows, replay_store="f16", replay_size=None, seed=0, graph=True,
-                                  atol=1e-5, grad_rel=2e-5, param_rel=2e-6, warm="philox", report_only=False):
+                                  atol=1e-5, grad_rel=2e-5, param_rel=2e-6, warm="philox", report_only=False,
+                                  fill="noise", f32_twin=False):
     """ONE minibatch of the fused inner step (cpp_ddpg_train_step, default kernels: f16-pipe conv1 reading the replay store
     through the sampled slots, bf16-pipe conv2, fused heads, paired launches) -- with graph=True the hipGraph REPLAY of it,
     on rows drawn by the device's Philox sampler -- against oracle.DDPG(float64) on the same rows and the same starting
@@ -201,7 +217,12 @@ def fused_step_against_f64_oracle(shape, B, rows, replay_store="f16", replay_siz
     report = {}
     try:
         rm = agent.replay_memory
-        rm.fill_synthetic(rows, seed=21 + seed)
+        if fill == "noise":
+            rm.fill_synthetic(rows, seed=21 + seed)
+        else:
+            assert fill in ("render", "render-blind", "render-glint"), fill
+            fill_with_rendered_episodes(agent, shape, rows, seed=seed, blind_camera=(fill != "render"),
+                                        glint=0.02 if fill == "render-glint" else 0.0)
         if graph or warm == "philox-eager":
             agent.train_step(B, 1)                        # eager pass + capture
         elif warm == "rows":
@@ -222,6 +243,7 @@ def fused_step_against_f64_oracle(shape, B, rows, replay_store="f16", replay_siz
         Pn = [n.get_params() for n in nets]
         codes_a, codes_c = device_pool_codes(agent.actor, B), device_pool_codes(agent.critic, B)
         relu_a, relu_c = device_relu_active(agent.actor, B), device_relu_active(agent.critic, B)
+        pools_c = [getattr(agent.critic, "pool%d" % i).eval(B) for i in (1, 2, 3)]
         # the minibatch, read back through paths that do not involve the gather kernel's state copy
         s1, s2 = rm.state[rm.state_1_idx[idxs]], rm.state[rm.state_2_idx[idxs]]
         hb = rm.batch(idxs=idxs)
@@ -238,15 +260,39 @@ def fused_step_against_f64_oracle(shape, B, rows, replay_store="f16", replay_siz
     t = (s1, a, r, m, s2)
     ag = ref.actor_gradients(s1)
     cg = ref.critic_gradients(t)
-    report["flips_actor"] = pool_flips_are_near_ties(ag["cache_actor"], codes_a, what="actor")
-    report["flips_critic"] = pool_flips_are_near_ties(cg["cache_critic"], codes_c, what="critic")
-    report["relu_flips_actor"] = relu_flips_are_at_the_boundary(ag["cache_actor"], relu_a, what="actor")
-    report["relu_flips_critic"] = relu_flips_are_at_the_boundary(cg["cache_critic"], relu_c, what="critic")
+    for key, fn, args in (("flips_actor", pool_flips_are_near_ties, (ag["cache_actor"], codes_a)),
+                          ("flips_critic", pool_flips_are_near_ties, (cg["cache_critic"], codes_c)),
+                          ("relu_flips_actor", relu_flips_are_at_the_boundary, (ag["cache_actor"], relu_a)),
+                          ("relu_flips_critic", relu_flips_are_at_the_boundary, (cg["cache_critic"], relu_c))):
+        try:
+            report[key] = fn(*args, what=key.split("_")[-1])
+        except AssertionError as e:
+            if not report_only:
+                raise
+            report[key] = "FAILED: %s" % e
     report["err_actions"] = float(np.abs(actions - ag["actions"]).max())
     report["err_dq_da"] = float(np.abs(dq_da - ag["dq_da"]).max())
     report["err_q"] = float(np.abs(q - cg["q"]).max())
     report["err_td"] = float(np.abs(td - cg["td"]).max())
     report["q_scale"] = float(np.abs(cg["q"]).max())
+    for i, (name, _k, _co) in enumerate(O.CONV_DEFS):
+        want = cg["cache_critic"][name][1]
+        report["err_pool%d" % (i + 1)] = float(np.abs(pools_c[i].reshape(want.shape) - want).max())
+        report["mag_pool%d" % (i + 1)] = float(np.abs(want).max())
+    if f32_twin:
+        # the same evaluation in float32 numpy (the rounding an f32 implementation such as the reference's TF CPU kernels is
+        # entitled to): how far IT sits from the float64 values on these inputs
+        ref32 = O.DDPG(aspec, cspec, P[0], P[1], np.float32)
+        ref32.set_targets(P[2], P[3])
+        ag32, cg32 = ref32.actor_gradients(s1), ref32.critic_gradients(t)
+        report["f32_err_actions"] = float(np.abs(ag32["actions"] - ag["actions"]).max())
+        report["f32_err_dq_da"] = float(np.abs(ag32["dq_da"] - ag["dq_da"]).max())
+        report["f32_err_q"] = float(np.abs(cg32["q"] - cg["q"]).max())
+        report["f32_err_td"] = float(np.abs(cg32["td"] - cg["td"]).max())
+        for i, (name, _k, _co) in enumerate(O.CONV_DEFS):
+            report["f32_err_pool%d" % (i + 1)] = float(np.abs(cg32["cache_critic"][name][1] - cg["cache_critic"][name][1]).max())
+        report["white_scale_max"] = float(np.max(cg["cache_critic"]["white"][0]))
+        report["white_scale_min"] = float(np.min(cg["cache_critic"]["white"][0]))
     if report_only:
         report["events"] = {k: report[k] for k in report if "flips" in k}
         report["actor"] = [(n, "%.2e" % r_) for n, _m, r_ in per_var_report(aspec, g_a, ag["grads"])][:6]
