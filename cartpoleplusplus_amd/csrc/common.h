@@ -157,9 +157,6 @@ int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, co
 int launch_conv_dw(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, ConvArgs a, float* grad_w,
                    float* grad_b);
 size_t conv_dw_partial_floats(cpp_ctx* ctx, int cin, int ks, int nout);
-bool conv3_bwd_img_ok(int cin, int ks, int H, int W, int nout);
-int launch_conv3_bwd_img(cpp_ctx* ctx, const struct ConvArgsN& dxb, const struct ConvArgsN& dwb, int* grid);
-int launch_conv3_bwd_whole(cpp_ctx* ctx, const ConvArgs* dw_list, const ConvArgs* dx_list, int n, float* const* grad_w, float* const* grad_b);
 int flush_dw_reduce(cpp_ctx* ctx);     // one launch for every dW reduction queued by launch_conv_dw
 // A backward pass that fails half way (a geometry without a kernel, a launch error) must not leave its queued reductions behind:
 // they point into that network's buffers, which may be gone by the time the next pass flushes the queue.
@@ -361,24 +358,6 @@ struct DdpgHeadsArgs {
 size_t ddpg_heads_lds_bytes(const DdpgHeadsArgs& h);
 bool ddpg_heads_supported(const DdpgHeadsArgs& h);
 int launch_ddpg_heads(cpp_ctx* ctx, const DdpgHeadsArgs& h);
-
-// the DDPG core kernel (ddpg_core.hip): the reference's stacks between the first fully connected layers and the one backward GEMM level
-struct DdpgCoreArgs {
-  int B, A; float discount;
-  const float *h0a, *h0ta; int ld0a, n0a, n1a, n2a;          // actors: first hidden activations B x (n0a + 1) (last column 1.0)
-  const float *W1a, *W1ta, *W2a, *W2ta, *Woa, *Wota;         // [(n0a + 1)][n1a], [(n1a + 1)][n2a], [(n2a + 1)][A]
-  const float *h0c, *h0tc; int ld0c, n0c, n1c, n3;           // critics: B x (n0c + 1)
-  const float *W1c, *W1tc, *W3, *W3t, *wq, *wqt;             // [(n0c + 1)][n1c], [(n1c + A + 1)][n3], [(n3 + 1)]
-  const float *act, *r, *mask;
-  float *h1a_w; int ld1a; float *h2a_w; int ld2a;            // the live networks' activations where the dW GEMMs read them
-  float *h1c_w; int ld1c; float *h3_w; int ld3;              // (h1c_w: also the fed actions in columns n1c .. n1c + A)
-  float *a_out, *dq_da, *q_out, *tq_out, *td;
-  float *adz, *dz2a, *dz1a, *dz0a;                           // B x A | n2a | n1a | n0a
-  float *dzq, *dz3, *dz1c, *dz0c;                            // B | B x n3 | n1c | n0c
-  double* loss_part;                                         // per-workgroup sums of td^2 (16 rows each)
-};
-bool ddpg_core_supported(const DdpgCoreArgs& g);
-int launch_ddpg_core(cpp_ctx* ctx, const DdpgCoreArgs& g);
 
 struct NafHeadArgs {
   const float* value; const float* mu; const float* lv; const float* action; const float* reward;

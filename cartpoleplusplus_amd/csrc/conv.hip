@@ -251,22 +251,6 @@ int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, co
   return queue_dw_reductions(ctx, batch, grid, nw, nout, grad_w, grad_b);
 }
 
-// conv3's whole backward pass (dW, db, dX) of 16x16 inputs as ONE whole-image kernel (conv3_bwd_img.hip)
-int launch_conv3_bwd_whole(cpp_ctx* ctx, const ConvArgs* dw_list, const ConvArgs* dx_list, int n, float* const* grad_w, float* const* grad_b) {
-  if (n < 1 || n > CONV_BATCH_MAX) { cpp_set_error("conv3 backward: batch of %d networks", n); return 1; }
-  const int nout = dw_list[0].nout, nw = 3 * 3 * nout * nout;
-  ConvArgsN dwb, dxb; dwb.n = dxb.n = n;
-  for (int i = 0; i < n; ++i) {
-    dwb.a[i] = dw_list[i]; dwb.a[i].pstride = nw + nout;
-    dxb.a[i] = dx_list[i];
-    if (dwb.a[i].B != dw_list[0].B) { cpp_set_error("conv3 backward: batched networks differ in geometry"); return 1; }
-  }
-  int grid = 0;
-  const int rc = launch_conv3_bwd_img(ctx, dxb, dwb, &grid);
-  if (rc) return rc;
-  return queue_dw_reductions(ctx, dwb, grid, nw, nout, grad_w, grad_b);
-}
-
 int launch_conv_dw(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, ConvArgs a, float* grad_w,
                    float* grad_b) {
   return launch_conv_dw_multi(ctx, kid, cin, ks, in_mode, &a, 1, &grad_w, &grad_b);

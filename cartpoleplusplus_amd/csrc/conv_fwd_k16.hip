@@ -1,6 +1,6 @@
 // conv1 forward on the f16 matrix pipes with f32-exact operands (conv_k16.h): instantiations + geometry selection.
 #include <cstdlib>
-#include "conv_k16_pair.h"
+#include "conv_k16.h"
 
 // Two bands of output rows per image when whole images would leave half of the workgroup slots empty (NAF's two trunks, a single
 // network's forward): the first band's height r0 is even (pool pairs) with r0 - 2 a multiple of 5 (the band's row walk starts two
@@ -11,13 +11,12 @@ static int k16_band_rows(int H) {
     if ((r0 - 2) % 5 == 0 && (best == 0 || abs(2 * r0 - H) < abs(2 * best - H))) best = r0;
   return (best >= 8 && H - best >= 8) ? best : 0;
 }
-static ConvArgsN k16_with_bands(cpp_ctx* ctx, const ConvArgsN& a, int ipw, int nets_per_wg = 1) {
+static ConvArgsN k16_with_bands(cpp_ctx* ctx, const ConvArgsN& a, int ipw) {
   static const bool no_bands = cpp_switch_off("CPP_CONV_BANDS");
   ConvArgsN b = a;
   for (int i = 0; i < b.n; ++i) { b.a[i].nbands = 0; b.a[i].band_rows = 0; }
   if (!ctx || no_bands || a.a[0].H < 32) return b;
-  // (one-network workgroups: two resident per CU; two-network workgroups: one)
-  const int wgs = nets_per_wg * (a.n / nets_per_wg) * ((a.a[0].B + ipw - 1) / ipw);
+  const int wgs = a.n * ((a.a[0].B + ipw - 1) / ipw);          // (two workgroups are resident per CU)
   for (int i = 0; i < a.n; ++i) if (a.a[i].n3_w) return b;          // conv3 rides in this launch: whole images per workgroup
   const int r0 = k16_band_rows(a.a[0].H);
   if (wgs > ctx->num_cus || r0 == 0) return b;
@@ -39,14 +38,6 @@ int conv_fwd_k16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool plain
   }
   const int xt = W > 16 ? 2 : 1;
   const int ipw = W > 64 ? 1 : (W > 32 ? 2 : 4);
-  // actor + critic (and the two targets) on the same images: one workgroup for both networks -- MEASURED SLOWER (134.8 vs 118.9 us at
-  // cfg3: one wave per SIMD cannot cover its own epilogue; profiles/experiments/r03_k16_pair.txt), so it is off unless the ablation
-  // build is told CPP_K16_PAIR=1 (the bit-identity test does)
-  static const bool use_pair = cpp_switch_int("CPP_K16_PAIR", 0) != 0;
-  if (use_pair && !plain && ctx && conv_fwd_k16_pairable(a)) {
-    const int rc = conv_fwd_k16_pair_dispatch(ctx, cin, xt, ipw, k16_with_bands(ctx, a, ipw, 2), handled);
-    if (*handled) return rc;
-  }
   K16_CASE(18, 2, 2, false) K16_CASE(18, 2, 2, true) K16_CASE(18, 1, 4, false) K16_CASE(18, 2, 4, false) K16_CASE(18, 2, 1, false)
   K16_CASE(6, 1, 4, false) K16_CASE(6, 2, 4, false) K16_CASE(6, 2, 2, false)
   K16_CASE(12, 2, 2, false) K16_CASE(30, 2, 1, false)

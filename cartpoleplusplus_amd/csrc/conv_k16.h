@@ -2,13 +2,27 @@
 //
 // The images of this path are 8-bit renders held as f16 (replay_memory.py:32, bullet_cartpole.py:239-243), so the A
 // operand of conv1 is EXACT in f16 as long as it is the raw pixel.  The whitening of base_network.py:95-99 is affine
-// per channel, x_w = x * s_c + t_c inside the image and 0 in the SAME padding, so it moves into the B operand:
+// per channel, x_w = s_c (x - mu_c) inside the image (mu_c = -t_c / s_c of the f32 table) and 0 in the SAME padding, so it
+// moves into the B operand -- CHUNK BY CHUNK (round 4).  An MFMA contracts 32 k values; a chunk holds RK = 30 real k = (kx, c)
+// of an input row and two synthetic "ones" slots whose A value is a constant 2^T and whose weights are minus the chunk's own
+// sum_k V'_k mu_c(k):
 //
-//   z[y,x,o] = b_o + sum_{ky,kx,c} (W[ky,kx,c,o] s_c) x[y+ky-P, x+kx-P, c]  +  sum_{ky,kx} (sum_c W[ky,kx,c,o] t_c) 1[y+ky-P, x+kx-P]
+//   z[y,x,o] = b_o + sum_{ky} sum_{chunks} [ sum_{k in chunk} V'_k x~_k  -  sum_{k in chunk} V'_k mu_c(k) ],   V' = the pieces of W s
 //
-// where 1[.] is a "ones" channel that is 1 inside the image and 0 in the padding -- the shift term with exactly the
-// zero-padding semantics of the whitened tensor, as CIN+.. extra k values (KS per input row: 90 + 5 = 95 <= 96 for the
-// 5x5x18 layer, no extra MFMA).  The f32 weights V = W s (and the ones weights) are split into F16_PIECES f16 pieces
+// Every MFMA therefore adds a sum of WHITENED terms V' (x - mu) to the f32 accumulator -- the partial sums stay of the size
+// of the result, as in a convolution of the whitened tensor (which is what the reference's TF kernels accumulate), instead of
+// growing to sum |V mu| and cancelling once per row: on a render's near-constant channels (a sky: s = 9, a blind camera
+// with one glint: s = 990) that intermediate reaches 10^1 ... 10^3 times the result and its roundings stay in it (rounds 1-3
+// kept ONE ones channel per row behind k = 90: 3.8e-4 on conv1 outputs where float32 numpy is 1.0e-4 from float64, r04_render_probe.txt).
+// 3 x 30 = 90 = KS * CIN for the 5x5x18 layer, no extra MFMA (two chunks less than the 32 + ones layout for 6 and 12 channels);
+// chunk starts stay 4-byte aligned (60 bytes).  The ones weights are computed in f64 FROM THE ROUNDED PIECES V' (so the two
+// halves of a chunk cancel to the rounding of V', not of W s) and carry four pieces: slot 30 the first two (three) of
+// -sum V' mu 2^(S-T), slot 31 the next -- 44 bits of a number that can be 10^3 times a weight.
+// The SAME padding: a tap left / right of the image must contribute V' * 0, but its ones share is already in the chunk; the A
+// element of such a tap is therefore the PIVOT p_c = f16(mu_c) instead of 0 (same mask instruction: and + or), which leaves
+// V'_k (p_c - mu_c), at most 2^-12 of a chunk term -- and that remainder is data independent: E[row class][x class][o], a
+// 5 x 4 x NO table the epilogue subtracts from the four border columns.  Rows outside the image are not walked at all.
+// The f32 weights V = W s are split into F16_PIECES f16 pieces
 // V 2^S = h + m (+ l) (h = f16(V 2^S), m = f16(rest), l = f16(rest); S puts the largest |V| just under 2^15), every
 // f16 x f16 product is exact in the f32 accumulator, and the MFMAs of a k chunk add  x * (h + m (+ l)).  With three pieces
 // (libcartpolepp_hip_exact.so) that is the f32-accumulated sum of exact products of the SAME operands the f32 kernel uses -- no
@@ -107,9 +121,9 @@ struct K16Geom {
   static constexpr int NT = (KS * NO + 15) / 16;
   static constexpr int STRIPS = 4 / IPW, SW = 16 * XT, WPAD = STRIPS * SW;
   static constexpr int KROW = KS * CIN;                    // real k = (kx, c) of one input row
-  static constexpr int KAUG = B16 ? KROW : KROW + KS;      // + the ones channel (kx)
+  static constexpr int RK = B16 ? 32 : 30;                 // real k values per MFMA chunk; f16 mode: slots 30, 31 of every chunk are the ones slots
   static constexpr int NPA = B16 ? 3 : 1;                  // planes of the A operand
-  static constexpr int NCH = (KAUG + 31) / 32;             // MFMA k chunks per row
+  static constexpr int NCH = (KROW + RK - 1) / RK;         // MFMA k chunks per row
   static constexpr int NPC = B16 ? 3 : F16_PIECES;         // f16 / bf16 pieces of a weight
   // weight image in LDS: slab (chunk, piece) holds the 16-byte operand (ky, lane group g, o) at ky*PS + g*GS + o*16;
   // the padded strides keep the rotating per-lane reads of a ds_read_b128 at 1.2 accesses per bank quad (2.45 compact)
@@ -124,20 +138,21 @@ struct K16Geom {
   static constexpr int EF = 2 * 8 * XT * NO * 2;           // floats per wave: (value, code) of the two rows of a pool pair
   // conv2's instance for 32x32 inputs can run conv3 as its tail: the two pooled 16x16 images of the workgroup, zero-haloed
   static constexpr int N3 = (B16 && XT == 1 && IPW == 2) ? C3_IPW * C3_IMGF * 4 + 16 : 0;
-  static constexpr int LDS_BYTES = WLB + 4 * EF * 4 + 64 + N3;
+  // f16 mode: the border table E [2 P + 1 row classes][NO][x = 0, 1, W - 2, W - 1] (floats, in accumulator units) and the pivots [CIN] (halves)
+  static constexpr int NRC = 2 * P + 1;
+  static constexpr int CT_BYTES = B16 ? 0 : NRC * NO * 16 + ((CIN * 2 + 15) & ~15);
+  static constexpr int LDS_BYTES = WLB + 4 * EF * 4 + 64 + N3 + CT_BYTES;
   static constexpr int BIAS_BYTES = 128;                   // the buffer descriptor starts this far before the image
-  // element e of lane group g in chunk ch is k = 32 ch + 8 g + e
-  static __host__ __device__ constexpr bool vgpr_may_be_synthetic(int ch, int v) {       // any lane group: not both real
-    return 32 * ch + 8 * 3 + 2 * v + 1 >= KROW;
-  }
+  // element e of lane group g in chunk ch is slot kl = 8 g + e of the chunk: real k = RK ch + kl if kl < RK (and k < KROW)
   // can dword v of chunk ch in M tile m (of any strip, any lane) ever hold an element that must be cleared or replaced?  The
-  // synthetic k values (ones channel, zero fill), a tap left of the image (kx < P: only a strip's first tile can touch x < 0)
+  // synthetic slots (ones, zero fill), a tap left of the image (kx < P: only a strip's first tile can touch x < 0)
   // or a tap right of it (kx > P: any tile, the image may end anywhere in a strip).
   static __host__ __device__ constexpr bool vgpr_may_need_mask(int ch, int m, int v) {
-    if (vgpr_may_be_synthetic(ch, v)) return true;
     for (int g = 0; g < 4; ++g)
       for (int h = 0; h < 2; ++h) {
-        const int k = 32 * ch + 8 * g + 2 * v + h;
+        const int kl = 8 * g + 2 * v + h;
+        if (kl >= RK) return true;
+        const int k = RK * ch + kl;
         if (k >= KROW) return true;
         const int kx = k / CIN;
         if (kx > P) return true;
@@ -156,6 +171,7 @@ struct K16Geom {
 template <int CIN, int KS, int XT, int IPW, bool PLAIN = false, int B16 = 0>      // B16: 0, or B16_SIX / B16_NINE
 __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(const ConvArgsN batch) {
   typedef K16Geom<CIN, KS, XT, IPW, (B16 != 0)> G;
+  static_assert(B16 != 0 || KS == 5, "the border table of the f16 mode is written for 5x5 (P = 2)");
   constexpr int P = G::P, NT = G::NT, NCH = G::NCH, NPC = G::NPC, NPA = G::NPA, NO = KYO_NO;
   constexpr bool ODD = (CIN & 1) != 0;            // 2-byte aligned operand windows: 20 bytes from the aligned address below + a funnel shift
 #if defined(K16_CLOCK_PROBE) || defined(K16_SPAN_PROBE)
@@ -193,45 +209,37 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   }
   // ---- one-time setup: the split weight image
   float sc, inv;                                      // 2^S, 2^-S
+  int onesT = 0;                                      // f16 mode: the ones slots' A value is 2^T
+  float* ctab = reinterpret_cast<float*>(lds_raw + G::WLB + 4 * G::EF * 4 + 64 + G::N3);      // [NRC][NO][4] (f16 mode)
+  unsigned short* pivot = reinterpret_cast<unsigned short*>(ctab + G::NRC * NO * 4);            // [CIN] f16 bits
   {
-    constexpr int NV = KS * NCH * 32 * NO;            // (ky, k, o), o fastest
+    constexpr int NV = KS * NCH * 32 * NO;            // (ky, slot of the image = 32 ch + kl, o), o fastest
     constexpr int NW = (NV + CONV_THREADS - 1) / CONV_THREADS;
     float wv[NW];
     float vmax = 0.f;
-    // branch-free: every load of the build is in flight before the first use (divergent branches around the ones-channel
-    // sums serialised their round trips: 8.5 us of the kernel; in-kernel probe)
-    float* onesw = reinterpret_cast<float*>(ebuf);    // [KS][KS][NO] scratch (the pool-pair buffers are not in use yet)
+    // branch-free: every load of the build is in flight before the first use
+    double* mu = reinterpret_cast<double*>(ebuf);     // scratch in the pool-pair buffers (not in use yet): mu_c [CIN], then
+    double* osum = mu + ((CIN + 1) & ~1);             // the ones sums [KS][NCH][NO] and the border sums e [KS][4][NO]
+    double* esum = osum + KS * NCH * NO;
 #pragma unroll
     for (int n = 0; n < NW; ++n) {
       const int i = tid + n * CONV_THREADS;
       const int o = i % NO, r = i / NO;
-      const int k = r % (NCH * 32), ky = r / (NCH * 32);
-      const bool real = i < NV && o < nout && k < G::KROW;
+      const int ks = r % (NCH * 32), ky = r / (NCH * 32);
+      const int k = G::RK * (ks >> 5) + (ks & 31);
+      const bool real = i < NV && o < nout && (ks & 31) < G::RK && k < G::KROW;
       const float w = a.w[real ? (ky * G::KROW + k) * nout + o : 0], sck = B16 ? 1.f : a.scale[real ? k % CIN : 0];
-      wv[n] = real ? w * sck : 0.f;
-    }
-    if (!B16) {
-      const int o = tid % NO, kk = tid / NO;           // kk = ky * KS + kx
-      const bool act = tid < KS * KS * NO && o < nout;
-      float wq[CIN], sh[CIN];
-#pragma unroll
-      for (int c = 0; c < CIN; ++c) { wq[c] = a.w[act ? (kk * CIN + c) * nout + o : 0]; sh[c] = a.shift[c]; }
-      float sacc = 0.f;
-#pragma unroll
-      for (int c = 0; c < CIN; ++c) sacc += wq[c] * sh[c];
-      if (tid < KS * KS * NO) onesw[tid] = act ? sacc : 0.f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int n = 0; n < NW; ++n) {
-      const int i = tid + n * CONV_THREADS;
-      const int o = i % NO, r = i / NO;
-      const int k = r % (NCH * 32), ky = r / (NCH * 32);
-      float v = wv[n];
-      if (i < NV && k >= G::KROW && k < G::KAUG) v = onesw[(ky * KS + (k - G::KROW)) * NO + o];      // ones channel: sum_c W t_c
+      float v = real ? w * sck : 0.f;
       if (a.wscale != 0.f) v *= a.wscale;
       wv[n] = v;
       vmax = fmaxf(vmax, fabsf(v));
+    }
+    if (!B16 && tid < CIN) {                          // mu_c = -t_c / s_c: x s + t = s (x - mu); a constant channel (table (0, 0): stats_body.h) has V' = 0
+      const float s_c = a.scale[tid], t_c = a.shift[tid];
+      const double m_c = s_c != 0.f ? -(double)t_c / (double)s_c : 0.0;
+      const _Float16 p_c = (_Float16)(float)m_c;
+      mu[tid] = m_c;
+      pivot[tid] = __builtin_bit_cast(unsigned short, p_c);
     }
 #ifdef K16_CLOCK_PROBE
     const unsigned long long pq0 = __builtin_amdgcn_s_memrealtime();
@@ -271,6 +279,76 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
         if (NPC > 2) *reinterpret_cast<unsigned short*>(dst + (ch * NPC + 2) * G::SLAB) = l;
       }
     }
+    if (!B16) {
+      // ---- the ones slots and the border table, in f64 from the pieces just written (V' = (h + m (+ l)) 2^-S, exactly)
+      __syncthreads();
+      auto vprime = [&](int ky, int k, int o) -> double {      // V'_k 2^S
+        const int ch = k / G::RK, kl = k - ch * G::RK;
+        const unsigned char* src = wl + ky * G::PS + (kl >> 3) * G::GS + o * 16 + (kl & 7) * 2;
+        double v = 0.0;
+#pragma unroll
+        for (int pc = 0; pc < NPC; ++pc)
+          v += (double)(float)__builtin_bit_cast(_Float16, *reinterpret_cast<const unsigned short*>(src + (ch * NPC + pc) * G::SLAB));
+        return v;
+      };
+      constexpr int NJ1 = KS * NCH * NO, NJ = NJ1 + KS * 4 * NO;
+      double omax = 0.0;
+      for (int job = tid; job < NJ; job += CONV_THREADS) {
+        if (job < NJ1) {                               // -sum_{k in chunk} V'_k mu_c(k)
+          const int o = job % NO, ch = (job / NO) % NCH, ky = job / (NO * NCH);
+          double acc = 0.0;
+          for (int kl = 0; kl < G::RK; ++kl) {
+            const int k = G::RK * ch + kl;
+            if (k < G::KROW) acc -= vprime(ky, k, o) * mu[k % CIN];
+          }
+          osum[job] = acc;
+          omax = fmax(omax, fabs(acc));
+        } else {                                       // e[ky][kx in {0, 1, KS-2, KS-1}][o] = sum_c V'[ky,kx,c,o] (p_c - mu_c)
+          const int j2 = job - NJ1;
+          const int o = j2 % NO, xi = (j2 / NO) % 4, ky = j2 / (NO * 4);
+          const int kx = xi < 2 ? xi : KS - 4 + xi;
+          double acc = 0.0;
+          for (int c = 0; c < CIN; ++c)
+            acc += vprime(ky, kx * CIN + c, o) * ((double)(float)__builtin_bit_cast(_Float16, pivot[c]) - mu[c]);
+          esum[j2] = acc;
+        }
+      }
+      for (int o = 32; o > 0; o >>= 1) omax = fmax(omax, __shfl_xor(omax, o));
+      if (lane == 0) red[4 + wave] = (float)omax;      // (an upper bound is all that is needed: rounded up below)
+      __syncthreads();
+      const float om = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])) * 1.0001f;
+      onesT = (om > 0.f && om < 3.0e38f) ? ilogbf(om) - 14 : 0;      // |ones weight| 2^-T < 2^15
+      onesT = onesT < 0 ? 0 : (onesT > 15 ? 15 : onesT);      // (T > 15: |mu| > 2^10 -- not an image; the pieces saturate to inf and the output says so)
+      for (int job = tid; job < NJ1; job += CONV_THREADS) {
+        const int o = job % NO, ch = (job / NO) % NCH, ky = job / (NO * NCH);
+        double v = ldexp(osum[job], -onesT);
+        unsigned char* dst = wl + ky * G::PS + 3 * G::GS + o * 16 + 6 * 2;      // slot 30 = (lane group 3, element 6), slot 31 behind it
+#pragma unroll
+        for (int slot = 0; slot < 2; ++slot)
+#pragma unroll
+          for (int pc = 0; pc < NPC; ++pc) {
+            const _Float16 hh = (_Float16)(float)v;
+            v -= (double)(float)hh;
+            *reinterpret_cast<unsigned short*>(dst + slot * 2 + (ch * NPC + pc) * G::SLAB) = __builtin_bit_cast(unsigned short, hh);
+          }
+      }
+      // border table: output row class rc (rows 0 .. P-1, interior, rows H-P .. H-1) sees the input rows ky with 0 <= y + ky - P < H
+      for (int job = tid; job < G::NRC * NO * 4; job += CONV_THREADS) {
+        const int xi = job & 3, o = (job >> 2) % NO, rc = job / (4 * NO);
+        double acc = 0.0;
+        for (int ky = 0; ky < KS; ++ky) {
+          const bool seen = rc < P ? ky >= P - rc : (rc > P ? ky <= KS - 1 - (rc - P) : true);
+          if (!seen) continue;
+          const double* e = esum + ky * 4 * NO;
+          // x = 0: taps kx = 0, 1 are left of the image; x = 1: kx = 0; x = W - 2: kx = KS - 1; x = W - 1: kx = KS - 2, KS - 1   (P = 2)
+          if (xi == 0) acc += e[0 * NO + o] + e[1 * NO + o];
+          else if (xi == 1) acc += e[0 * NO + o];
+          else if (xi == 2) acc += e[3 * NO + o];
+          else acc += e[2 * NO + o] + e[3 * NO + o];
+        }
+        ctab[job] = (float)acc;
+      }
+    }
   }
   __syncthreads();                                   // weight image visible; no barrier after this one
 #ifdef K16_CLOCK_PROBE
@@ -304,11 +382,13 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   }
 
   // ---- operand masks: dword v of a lane's 16-byte window of chunk ch in tile m becomes (u & emask) | ecst.  emask clears the
-  // synthetic k values of the lane's group (ones channel, zero fill) and the taps of the SAME padding (pixel x + kx - P outside
-  // [0, W)); ecst puts f16 1.0 into the ones channel where its pixel is inside the image.  Applied unconditionally wherever
-  // K16Geom::vgpr_may_need_mask says a mask can matter at all (20 of the 24 dwords of a row for 5x5x18; a run-time "is this a
+  // synthetic slots of the lane's group (ones, zero fill) and the taps of the SAME padding (pixel x + kx - P outside [0, W));
+  // ecst puts the ones slots' constant 2^T there, and the channel's pivot p_c = f16(mu_c) into the padding taps (f16 mode: the
+  // chunk's ones slots subtract V' mu for every k of the chunk, the pivot leaves V' (p_c - mu_c), the epilogue's table removes that).
+  // Applied unconditionally wherever K16Geom::vgpr_may_need_mask says a mask can matter at all (a run-time "is this a
   // border tile" made the compiler compute both variants and select: 48 VALU per row).
   unsigned emask[NCH][XT][4], ecst[NCH][XT][4];
+  const unsigned ones_bits = (unsigned)(15 + onesT) << 10;      // f16 2^T
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
@@ -318,16 +398,37 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
         unsigned cs = 0u, bm = 0u;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int k = 32 * ch + 8 * lj + 2 * v + h;
-          const int kx = k < G::KROW ? k / CIN : k - G::KROW;
+          const int kl = 8 * lj + 2 * v + h;
+          const int k = G::RK * ch + kl;
+          if (kl >= G::RK) { if (!B16) cs |= ones_bits << (16 * h); continue; }
+          if (k >= G::KROW) continue;
+          const int kx = k / CIN;
           const int xi = strip * G::SW + m * 16 + li + kx - P;
           const bool inside = xi >= 0 && xi < W;
-          if (k < G::KROW && inside) bm |= 0xFFFFu << (16 * h);
-          if (k >= G::KROW && k < G::KAUG && inside) cs |= 0x3C00u << (16 * h);      // f16 1.0
+          if (inside) bm |= 0xFFFFu << (16 * h);
+          else if (!B16) cs |= (unsigned)pivot[k % CIN] << (16 * h);
         }
         ecst[ch][m][v] = cs;
         emask[ch][m][v] = bm;
       }
+  // ---- f16 mode: the border columns' table (see the file comment).  Accumulator element r of tile m is pixel x = strip SW + 16 m + 4 lj + r;
+  // pool pair h = r / 2.  Left: x = 0, 1 = (strip 0, m 0, lj 0, h 0); right: x = W - 2, W - 1 = (strip xr / SW, m (xr % SW) / 16, lj (xr % 16) / 4,
+  // h (xr % 4) / 2), xr = W - 2 (W is even).  fl / fr[m][h]: 1.0 on the lanes that hold such a pair, else 0.0 -- the epilogue
+  // subtracts f * E with an FMA instead of branching.
+  uint32_t ctadr[NT];
+  float fl = 0.f, fr[XT][2];
+  {
+    const int xr = W - 2;
+    const bool lgrp = !B16 && sstrip == 0 && lj == 0;
+    const bool rgrp = !B16 && sstrip == xr / G::SW && lj == (xr % 16) / 4;
+    fl = lgrp ? 1.f : 0.f;
+#pragma unroll
+    for (int m = 0; m < XT; ++m)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) fr[m][h] = (rgrp && m == (xr % G::SW) / 16 && h == (xr % 4) / 2) ? 1.f : 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) ctadr[t] = keep_in_vgpr(lds_addr(ctab + (((16 * t + li) % NO) << 2)));
+  }
 
   // ---- pooled-row writer: a lane owns PAIRS (o, o+1) of the wave's 8*XT pooled columns (nout is even: dispatch) -- one
   // 8-byte value store, one 2-byte code store and three 4-byte bf16-plane stores per pair
@@ -383,8 +484,8 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
       if (ASYNC_A) {
 #pragma unroll
         for (int pa = 0; pa < NPA; ++pa)
-          k16_issue_b128(av[pa][ch][m], in_desc, avoff, pa * plane_bytes + y * rowbytes + (m * 16 * CIN + 32 * ch) * 2);
-        if (ODD) k16_issue_b32(ax[ch][m], in_desc, avoff, y * rowbytes + (m * 16 * CIN + 32 * ch) * 2 + 16);
+          k16_issue_b128(av[pa][ch][m], in_desc, avoff, pa * plane_bytes + y * rowbytes + (m * 16 * CIN + G::RK * ch) * 2);
+        if (ODD) k16_issue_b32(ax[ch][m], in_desc, avoff, y * rowbytes + (m * 16 * CIN + G::RK * ch) * 2 + 16);
         continue;
       }
 #ifdef K16_ABL_NOLDSA
@@ -392,10 +493,10 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #else
 #pragma unroll
       for (int pa = 0; pa < NPA; ++pa) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, avoff + (m * 16 * CIN + 32 * ch) * 2, pa * plane_bytes + y * rowbytes, 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, avoff + (m * 16 * CIN + G::RK * ch) * 2, pa * plane_bytes + y * rowbytes, 0);
         av[pa][ch][m] = (k16_u32x4){v.x, v.y, v.z, v.w};
       }
-      if (ODD) ax[ch][m] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, avoff + (m * 16 * CIN + 32 * ch) * 2 + 16, y * rowbytes, 0);
+      if (ODD) ax[ch][m] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, avoff + (m * 16 * CIN + G::RK * ch) * 2 + 16, y * rowbytes, 0);
 #endif
     }
   };
@@ -452,6 +553,16 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
       if (q >= qend) break;                          // uniform
       constexpr int PD_BASE = (KS - P) % KS;
       const int pdone = (PD_BASE + sq) % KS;
+      f32x4 ctv[NT];                                 // f16 mode: E[row class of the output row this step completes][o][x = 0, 1, W - 2, W - 1]
+      if (!B16) {
+        const int yc = q - P;                        // (rows in front of a band are dropped below: any class will do)
+        const int rc = yc < P ? (yc < 0 ? 0 : yc) : (yc >= H - P ? 2 * P - (H - 1 - yc) : P);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int clo = pdone * NO - 16 * t, chi = pdone * NO + NO - 1 - 16 * t;
+          if (chi >= 0 && clo <= 15) ctv[t] = lds_load<f32x4>(ctadr[t] + (uint32_t)(rc * NO * 16), 0);
+        }
+      }
       if (q < H) {
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
@@ -531,19 +642,28 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
           if (inr) {
 #pragma unroll
             for (int m = 0; m < XT; ++m) {
+              // f16 mode: the border columns' data-independent remainder (file comment), requested from LDS before the row's MFMAs
+              f32x4 zc = acc[m][t];
+              if (!B16 && y >= 0) {
+                if (m == 0) { zc[0] = fmaf(-fl, ctv[t][0], zc[0]); zc[1] = fmaf(-fl, ctv[t][1], zc[1]); }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                  zc[2 * h] = fmaf(-fr[m][h], ctv[t][2], zc[2 * h]); zc[2 * h + 1] = fmaf(-fr[m][h], ctv[t][3], zc[2 * h + 1]);
+                }
+              }
               if (PLAIN) {
                 if (y >= 0) {
 #pragma unroll
                   for (int r = 0; r < 4; ++r)
                     if (sstrip * G::SW + m * 16 + 4 * lj + r < W)
-                      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][t][r] * inv), out_rsrc,
+                      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(zc[r] * inv), out_rsrc,
                                                             (int)eadr[t] + ((m * 16 + r) * NO) * 4, y * W * nout * 4, 0);
                 }
               } else if (y >= 0) {
                 const uint32_t ea = eadr[t] + (uint32_t)(par * (8 * XT * NO) * 8);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                  const float z0 = acc[m][t][2 * h], z1 = acc[m][t][2 * h + 1];
+                  const float z0 = zc[2 * h], z1 = zc[2 * h + 1];
                   lds_store(ea, ((m * 8 + h) * NO) * 8, (f32x2){z1 > z0 ? z1 : z0, __int_as_float(z1 > z0 ? 1 : 0)});
                 }
               }

@@ -370,114 +370,24 @@ static int compute_gradients(cpp_ddpg* d, cpp_batch* b, int phase = 0) {
       if (ddpg_heads_supported(hp)) hd = hp;
     }
   }
-  // ... and the layers in FRONT of those (the actors' second hidden layer, the critics' layer in front of the concat layer) leave the
-  // GEMM levels too: the tiles of the first fully connected layer add their slice of the next layer's sum (GemmArgs::next_part) and the
-  // heads kernel finishes it -- one dependent level less.  For the reference's stacks (actor 3 hidden layers, critic prefix of 2).
-  // An EXPERIMENT, off unless CPP_FC_NEXT=1 in the ablation build: parity-green, and worth nothing -- the level that disappears (8.4 us)
-  // comes back as 2 us more per tile in the level in front of it (slice loads, a transpose through LDS, 28 MFMAs and 28 stores on each
-  // tile's last wave) and the launch it saves: 2790-2793 -> 2792-2808 steps/s in alternating runs (profiles/experiments/r03_fc_next.txt).
-  static const bool no_next = !cpp_switch_set("CPP_FC_NEXT");
-  bool nextp = false;
-  if (fused && hd.n1a > 0 && !no_next && na == 4 && cat == 2 && a->fc[1].act == GE_RELU && c->fc[1].act == GE_RELU &&
-      a->fc[0].act == GE_RELU && c->fc[0].act == GE_RELU && !a->drop_counter) {
-    const int n0a = a->fc[0].n_out, n1a_ = a->fc[1].n_out, n0c = c->fc[0].n_out, n1c = c->fc[1].n_out;
-    const int np1 = (n0a + 15) / 16, np2 = (n0c + 15) / 16;
-    if (np1 <= HEADS_NP1_MAX && np2 <= HEADS_NP2_MAX && n1a_ <= 16 * GEMM_NEXT_TILES && n1c <= 16 * GEMM_NEXT_TILES && n1a_ == hd.n1a && n1c == hd.n2c) {
-      const size_t need = (size_t)d->maxB * ((size_t)np1 * n1a_ > (size_t)np2 * n1c ? (size_t)np1 * n1a_ : (size_t)np2 * n1c);
-      if (d->fc_part_floats < need) {
-        int rc = 0;
-        for (int k = 0; k < 4 && !rc; ++k) rc = dalloc(d->arena, &d->fc_part[k], need, false);
-        if (rc) return rc;
-        d->fc_part_floats = need;
-      }
-      DdpgHeadsArgs hn = hd;
-      hn.p1a = d->fc_part[0]; hn.p1ta = d->fc_part[1]; hn.np1 = np1; hn.h1a_w = a->ws[0].fcin[2];
-      hn.b1a = a->params + a->fc[1].w_off + (long)n0a * n1a_; hn.b1ta = ta->params + a->fc[1].w_off + (long)n0a * n1a_;
-      hn.p2c = d->fc_part[2]; hn.p2tc = d->fc_part[3]; hn.np2 = np2; hn.h2c_w = c->ws[0].fcin[2];
-      hn.b2c = c->params + c->fc[1].w_off + (long)n0c * n1c; hn.b2tc = tc->params + c->fc[1].w_off + (long)n0c * n1c;
-      if (ddpg_heads_supported(hn)) { hd = hn; nextp = true; }
-    }
-  }
-  auto with_next = [&](GemmArgs g, cpp_net* n, float* part) {      // layer 0's GEMM of network n also leaves layer 1's slices
-    g.next_W = n->params + n->fc[1].w_off; g.next_N = n->fc[1].n_out; g.next_K = n->fc[0].n_out; g.next_part = part;
-    return g;
-  };
-  // ... or, for exactly the reference's stacks, ONE kernel on the matrix pipes for everything between the first fully connected layers
-  // and the backward level (ddpg_core.hip, the scheme of naf_mlp_kernel on twelve layers): one forward GEMM level, the core kernel, one
-  // backward GEMM level.  An EXPERIMENT, off unless CPP_DDPG_CORE=1 in the ablation build: parity-green at full size, and slower -- the
-  // kernel takes 36-43 us (sixteen workgroups, twelve dependent stages, ~500 B-operand loads per lane against a 63-deep counter) where
-  // the heads kernel and the two levels it replaces take 29: 2935 -> 2821 steps/s (profiles/experiments/r03_ddpg_core.txt).
-  static const bool no_core = !cpp_switch_set("CPP_DDPG_CORE");
-  DdpgCoreArgs cg; memset(&cg, 0, sizeof(cg));
-  bool core = fused && hd.n1a > 0 && !nextp && !no_core && na == 4 && nc == 4 && cat == 2 && !a->drop_counter && !hd.relu_x2;
-  if (core) {
-    for (int l = 0; l < 3; ++l) core = core && a->fc[l].act == GE_RELU && relu_grad_epi(a, l) == GE_MUL_RELU_GRAD;
-    for (int l = 0; l < 2; ++l) core = core && c->fc[l].act == GE_RELU;
-    core = core && Lcat.act == GE_RELU && a->spec.pixel == c->spec.pixel;
-  }
-  if (core) {
-    cg.B = B; cg.A = A; cg.discount = d->hp.discount;
-    cg.h0a = a->ws[0].fcin[1]; cg.h0ta = ta->ws[0].fcin[1]; cg.ld0a = a->fc[1].n_in + 1; cg.n0a = a->fc[1].n_in; cg.n1a = a->fc[1].n_out; cg.n2a = a->fc[2].n_out;
-    cg.W1a = a->params + a->fc[1].w_off; cg.W1ta = ta->params + a->fc[1].w_off; cg.W2a = a->params + a->fc[2].w_off; cg.W2ta = ta->params + a->fc[2].w_off;
-    cg.Woa = a->params + a->fc[3].w_off; cg.Wota = ta->params + a->fc[3].w_off;
-    cg.h0c = c->ws[0].fcin[1]; cg.h0tc = tc->ws[0].fcin[1]; cg.ld0c = c->fc[1].n_in + 1; cg.n0c = c->fc[1].n_in; cg.n1c = c->fc[1].n_out; cg.n3 = Lcat.n_out;
-    cg.W1c = c->params + c->fc[1].w_off; cg.W1tc = tc->params + c->fc[1].w_off; cg.W3 = c->params + Lcat.w_off; cg.W3t = tc->params + Lcat.w_off;
-    cg.wq = c->params + c->fc[3].w_off; cg.wqt = tc->params + c->fc[3].w_off;
-    cg.act = b->a; cg.r = b->r; cg.mask = b->m;
-    cg.h1a_w = a->ws[0].fcin[2]; cg.ld1a = a->fc[2].n_in + 1; cg.h2a_w = a->ws[0].fcin[3]; cg.ld2a = a->fc[3].n_in + 1;
-    cg.h1c_w = c->ws[0].fcin[2]; cg.ld1c = (int)ldcat; cg.h3_w = c->ws[0].fcin[3]; cg.ld3 = Lcat.n_out + 1;
-    cg.a_out = a->ws[0].out; cg.dq_da = d->dq_da; cg.q_out = c->ws[0].out; cg.tq_out = tc->ws[0].out; cg.td = d->td;
-    cg.adz = a->ws[0].dz[3]; cg.dz2a = a->ws[0].dz[2]; cg.dz1a = a->ws[0].dz[1]; cg.dz0a = a->ws[0].dz[0];
-    cg.dzq = c->ws[0].dz[3]; cg.dz3 = c->ws[0].dz[2]; cg.dz1c = c->ws[0].dz[1]; cg.dz0c = c->ws[0].dz[0];
-    cg.loss_part = d->heads_part;
-    core = Lcat.n_in == cg.n1c + A && a->fc[2].n_in == cg.n1a && a->fc[3].n_in == cg.n2a && a->fc[3].n_out == A && c->fc[3].n_in == cg.n3 && ddpg_core_supported(cg);
-  }
-  if (core) {
-    d->heads_grid = (B + 15) / 16; d->heads_B = B; d->loss_parts = d->heads_grid; d->loss_B = B;
-    const int aF = G.gemm(fc_fwd_args(a, a->ws[0], 0, B), {tA}), taF = G.gemm(fc_fwd_args(ta, ta->ws[0], 0, B), {tTA});
-    const int cP = G.gemm(fc_fwd_args(c, c->ws[0], 0, B), {tC}), tcP = G.gemm(fc_fwd_args(tc, tc->ws[0], 0, B), {tTC});
-    const int ck = G.fn([=] { return launch_ddpg_core(ctx, cg); }, {aF, taF, cP, tcP});
-    for (int l = 3; l >= 0; --l) {
-      G.gemm(sqg(0, fc_dw_args(a, a->ws[0], l, B, a->ws[0].dz[l])), {ck});
-      G.gemm(sqg(1, fc_dw_args(c, c->ws[0], l, B, c->ws[0].dz[l])), {ck});
-    }
-    int adz_ = ck, cdz_ = ck;
-    if (a->spec.pixel) {
-      adz_ = G.gemm(fc_dx_args(a, 0, B, a->ws[0].dz[0], a->fc[0].n_out, 0, a->flat, a->ws[0].dpool[2], a->flat, GE_NONE, nullptr, 0), {ck});
-      cdz_ = G.gemm(fc_dx_args(c, 0, B, c->ws[0].dz[0], c->fc[0].n_out, 0, c->flat, c->ws[0].dpool[2], c->flat, GE_NONE, nullptr, 0), {ck});
-    }
-    int conv_bwd = -1;
-    if (c->spec.pixel) {
-      cpp_net* bn[2] = {a, c};
-      conv_bwd = G.fn([=] { return nets_backward_conv(ctx, bn, 2, B, s1, dt, w1); }, {adz_, cdz_});
-    }
-    DwPendingGuard pending(ctx);
-    if (phase == 2) {
-      if (conv_bwd >= 0) RC(G.ops[conv_bwd].fn());
-      return flush_dw_reduce(ctx);
-    }
-    RC(G.run(ctx, phase == 1 ? conv_bwd : -1));
-    if (phase == 1) { pending.keep(); return CPP_OK; }
-    return flush_dw_reduce(ctx);
-  }
   const int pre = (fused && hd.n1a > 0) ? 1 : 0;
   d->heads_grid = fused ? (B + 3) / 4 : 0; d->heads_B = B;
   d->loss_parts = d->heads_grid; d->loss_B = B;
   int adz, cdz;
   if (fused) {
     int aF = tA, taF = tTA;
-    for (int l = 0; l < na - 1 - pre - (nextp ? 1 : 0); ++l) {
-      aF = G.gemm(nextp ? with_next(fc_fwd_args(a, a->ws[0], l, B), a, d->fc_part[0]) : fc_fwd_args(a, a->ws[0], l, B), {aF});
-      taF = G.gemm(nextp ? with_next(fc_fwd_args(ta, ta->ws[0], l, B), ta, d->fc_part[1]) : fc_fwd_args(ta, ta->ws[0], l, B), {taF});
+    for (int l = 0; l < na - 1 - pre; ++l) {
+      aF = G.gemm(fc_fwd_args(a, a->ws[0], l, B), {aF});
+      taF = G.gemm(fc_fwd_args(ta, ta->ws[0], l, B), {taF});
     }
     if (a->drop_counter) {     // --use-dropout: this forward is counted once its layers have read the counter
       G.fn([=] { return bump_dropout(a); }, {aF});
       G.fn([=] { return bump_dropout(ta); }, {taF});
     }
     int cP = tC, tcP = tTC;
-    for (int l = 0; l < cat - (nextp ? 1 : 0); ++l) {
-      cP = G.gemm(nextp ? with_next(fc_fwd_args(c, c->ws[0], l, B), c, d->fc_part[2]) : fc_fwd_args(c, c->ws[0], l, B), {cP});
-      tcP = G.gemm(nextp ? with_next(fc_fwd_args(tc, tc->ws[0], l, B), tc, d->fc_part[3]) : fc_fwd_args(tc, tc->ws[0], l, B), {tcP});
+    for (int l = 0; l < cat; ++l) {
+      cP = G.gemm(fc_fwd_args(c, c->ws[0], l, B), {cP});
+      tcP = G.gemm(fc_fwd_args(tc, tc->ws[0], l, B), {tcP});
     }
     const int hk = G.fn([=] { return launch_ddpg_heads(ctx, hd); }, {aF, taF, cP, tcP});
     // ---- actor backward below its head (the head's dX is part of the fused kernel)

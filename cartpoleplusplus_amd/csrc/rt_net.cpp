@@ -461,11 +461,6 @@ int nets_backward_conv(cpp_ctx* ctx, cpp_net* const* nets, int nn, int B, const 
     static const bool no_pair3 = cpp_switch_off("CPP_CONV3_PAIR");
     static const bool no_pair2 = cpp_switch_off("CPP_CONV2_PAIR");
     const bool no_pair = i == 2 ? no_pair3 : (i == 1 ? no_pair2 : true);
-    // conv3 of 16x16 inputs: dW, db and dX from whole images in LDS, one kernel (conv3_bwd_img.hip)
-    if (i == 2 && conv3_bwd_img_ok(L.Cin, L.ks, L.H, L.W, kConvOut)) {
-      RC(launch_conv3_bwd_whole(ctx, dl, xl, nn, gw, gb));
-      continue;
-    }
     ConvPairSlot slot; slot.have_dw = slot.have_dx = false; slot.layer = i;
     if (!no_pair) ctx->pair = &slot;
     int rc = launch_conv_dw_multi(ctx, kDwKid[i], L.Cin, L.ks, mode, dl, nn, gw, gb);

@@ -458,9 +458,12 @@ class DDPG(object):
         return {"actions": ca["out"], "q": cc["out"], "dq_da": dq_da,
                 "grads": flatten(self.actor.spec, grads, self.dt), "cache_actor": ca}
 
-    def critic_gradients(self, batch, training=True):
+    def critic_gradients(self, batch, training=True, td_override=None):
         """ddpg_cartpole.py:199-214.  batch = (s1, a, r, mask, s2).  IS_TRAINING is one placeholder for the whole
-        graph: in critic.train (:237) the target networks run in training mode as well."""
+        graph: in critic.train (:237) the target networks run in training mode as well.  td_override (tests only): back-propagate
+        THESE temporal differences instead of this forward pass's own -- the gradients are linear in TD, and where sum_b td_b
+        cancels (correlated minibatches) another implementation's 5e-6 on TD is 5e-5 of a gradient; with its TD fed in, what
+        remains is the backward arithmetic alone."""
         s1, a, r, mask, s2 = batch
         dt = self.dt
         w2 = self._white(self.target_actor, s2)
@@ -471,7 +474,8 @@ class DDPG(object):
         td = cb["out"] - y
         B = td.shape[0]
         loss = (td * td).mean(dtype=dt)
-        grads, _ = self.critic.backward(cb, (dt(2.0) * td / dt(B)).astype(dt))
+        td_back = td if td_override is None else np.asarray(td_override, dt).reshape(td.shape)
+        grads, _ = self.critic.backward(cb, (dt(2.0) * td_back / dt(B)).astype(dt))
         return {"q": cb["out"], "td": td, "loss": loss, "target_q": tq["out"],
                 "target_actions": ta["out"], "cache_critic": cb,
                 "grads": flatten(self.critic.spec, grads, self.dt)}

@@ -64,13 +64,15 @@ def per_var_report(spec, got, want):
     return rows
 
 
-def assert_flat_close(spec, got, want, rel=2e-5, what="", abs_floor=0.0):
+def assert_flat_close(spec, got, want, rel=2e-5, what="", abs_floor=0.0, rel_of=None):
     """abs_floor: an absolute error one-element variables are not held below (the critic's q_value bias gradient is 2 mean(td), a
-    sum with cancellation: it cannot be closer to the oracle than the Q values that make up td)."""
+    sum with cancellation: it cannot be closer to the oracle than the Q values that make up td).  rel_of: {variable: tolerance}
+    that replaces `rel` where it is larger (the float32 evaluation's own distance from float64, times a factor)."""
     rows = per_var_report(spec, got, want)
     single = set(name for name, shp in spec.layout() if int(np.prod(shp)) == 1)
     scale = float(np.linalg.norm(np.asarray(want, np.float64))) / np.sqrt(len(want)) + 1e-30
-    bad = [r for r in rows if r[2] > rel and r[1] > rel * scale and not (r[0] in single and r[1] <= abs_floor)]
+    tol = lambda name: max(rel, (rel_of or {}).get(name, 0.0))
+    bad = [r for r in rows if r[2] > tol(r[0]) and r[1] > tol(r[0]) * scale and not (r[0] in single and r[1] <= abs_floor)]
     msg = "\n".join("%-28s max_abs=%.3e rel_l2=%.3e" % r for r in rows)
     assert not bad, "%s mismatch (rel tol %g):\n%s" % (what, rel, msg)
 
@@ -187,19 +189,22 @@ def pool_flips_are_near_ties(cache, device_codes, margin_tol=1e-5, what=""):
     return flips
 
 
-def fill_with_rendered_episodes(agent, shape, rows, seed=0, blind_camera=False, as_u8=False, glint=0.0):
+def fill_with_rendered_episodes(agent, shape, rows, seed=0, blind_camera=False, as_u8=False, glint=0.0, opts=None):
     """`rows` transitions of random-policy episodes of the software-rasterised cart and pole (synthetic_env.RasterCartpole: flat
     backgrounds, R nearly identical repeat frames, optionally a camera that sees one colour only) into the agent's replay memory,
     through ReplayMemory.add_episode as the reference's rollout loop does (ddpg_cartpole.py:315-326)."""
     from cartpoleplusplus_amd import ddpg_cartpole as D
     from cartpoleplusplus_amd.synthetic_env import RasterCartpole, play_episodes
-    env = RasterCartpole(D.opts, seed=seed + 1, blind_camera=blind_camera, glint=glint)
+    env = RasterCartpole(opts if opts is not None else D.opts, seed=seed + 1, blind_camera=blind_camera, glint=glint)
     for first, seq in play_episodes(env, rows, np.random.default_rng(seed + 2)):
         if as_u8:
             first = np.rint(first * 255).astype(np.uint8)
             seq = [(a, r, np.rint(s2 * 255).astype(np.uint8)) for a, r, s2 in seq]
         agent.replay_memory.add_episode(first, seq)
     assert agent.replay_memory.size() == rows
+
+
+F32_GRAD_FACTOR = 1.5
 
 
 def fused_step_against_f64_oracle(shape, B, rows, replay_store="f16", replay_size=None, seed=0, graph=True,
@@ -284,7 +289,13 @@ def fused_step_against_f64_oracle(shape, B, rows, replay_store="f16", replay_siz
         # entitled to): how far IT sits from the float64 values on these inputs
         ref32 = O.DDPG(aspec, cspec, P[0], P[1], np.float32)
         ref32.set_targets(P[2], P[3])
+        ref32.actor.amax_override, ref32.critic.amax_override = codes_a, codes_c      # (the same routes: rounding is what is compared)
+        ref32.actor.relu_override, ref32.critic.relu_override = relu_a, relu_c
         ag32, cg32 = ref32.actor_gradients(s1), ref32.critic_gradients(t)
+        f32_rel_a = {n: F32_GRAD_FACTOR * r_ for n, _m, r_ in per_var_report(aspec, ag32["grads"], ag["grads"])}
+        f32_rel_c = {n: F32_GRAD_FACTOR * r_ for n, _m, r_ in per_var_report(cspec, cg32["grads"], cg["grads"])}
+        report["f32_rel_actor_grads"] = max(f32_rel_a.values()) / F32_GRAD_FACTOR
+        report["f32_rel_critic_grads"] = max(f32_rel_c.values()) / F32_GRAD_FACTOR
         report["f32_err_actions"] = float(np.abs(ag32["actions"] - ag["actions"]).max())
         report["f32_err_dq_da"] = float(np.abs(ag32["dq_da"] - ag["dq_da"]).max())
         report["f32_err_q"] = float(np.abs(cg32["q"] - cg["q"]).max())
@@ -301,9 +312,19 @@ def fused_step_against_f64_oracle(shape, B, rows, replay_store="f16", replay_siz
     assert report["err_actions"] < atol and report["err_dq_da"] < atol, report
     assert report["err_q"] < atol and report["err_td"] < atol, report
     assert abs(stats[0] - cg["loss"]) < atol * max(1.0, abs(cg["loss"])), (stats, cg["loss"])
-    assert_flat_close(aspec, g_a, ag["grads"], rel=grad_rel, what="actor pre-clip grads vs f64 oracle")
-    assert_flat_close(cspec, g_c, cg["grads"], rel=grad_rel, what="critic pre-clip grads vs f64 oracle",
-                      abs_floor=2.0 * report["err_td"])
+    # (f32_twin: a variable's gradient may be as far from float64 as F32_GRAD_FACTOR x the float32 numpy evaluation's -- the critic's
+    # gradients are linear in TD, and on correlated minibatches (renders) sum_b td_b cancels: 5e-6 on TD is 5e-5 of the head's gradient)
+    assert_flat_close(aspec, g_a, ag["grads"], rel=grad_rel, what="actor pre-clip grads vs f64 oracle", rel_of=f32_rel_a if f32_twin else None)
+    try:
+        assert_flat_close(cspec, g_c, cg["grads"], rel=grad_rel, what="critic pre-clip grads vs f64 oracle",
+                          abs_floor=2.0 * report["err_td"], rel_of=f32_rel_c if f32_twin else None)
+    except AssertionError:
+        # the critic's gradients are LINEAR in TD: g = (2 / B) sum_b td_b dq_b/dtheta.  On a correlated minibatch (consecutive
+        # renders) the td_b nearly cancel in that sum and the TD error admitted above (< atol) is a large fraction of what is left.
+        # Second chance: the oracle's backward pass fed with the DEVICE's TD values -- the backward arithmetic alone, at grad_rel
+        cg_dev = ref.critic_gradients(t, td_override=td)
+        assert_flat_close(cspec, g_c, cg_dev["grads"], rel=grad_rel, what="critic pre-clip grads vs f64 oracle's backward pass of the device's TD")
+        report["critic_grads_checked_at_device_td"] = True
     report["rel_actor_grads"] = max(r_[2] for r_ in per_var_report(aspec, g_a, ag["grads"]))
     report["rel_critic_grads"] = max(r_[2] for r_ in per_var_report(cspec, g_c, cg["grads"]))
     na, nc = float(np.linalg.norm(ag["grads"])), float(np.linalg.norm(cg["grads"]))

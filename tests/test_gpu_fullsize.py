@@ -366,15 +366,6 @@ def test_two_network_conv1_dw_workgroups_agree_with_the_single_network_kernel(tm
             assert h1 == h0, shape
 
 
-def test_two_network_conv1_forward_workgroups_give_the_single_network_kernels_bits(tmp_path):
-    """conv_k16_pair.h (actor + critic, and the two targets, per workgroup: 100 of 112 columns, one A operand for both; an ablation,
-    measured slower) accumulates every output in the order of the one-network kernel (CPP_K16_PAIR=0): whole train steps must agree
-    bit for bit."""
-    got = _run_pair_snippet(tmp_path, {"pair": {"CPP_K16_PAIR": "1"}, "single": {"CPP_K16_PAIR": "0"}})
-    for shape in got["pair"]:
-        assert got["pair"][shape][0] == got["single"][shape][0], shape
-
-
 _CHAIN_SNIPPET = r"""
 import hashlib
 import numpy as np
@@ -409,28 +400,3 @@ def test_chained_gemm_levels_are_bit_identical_to_one_launch_per_level():
     assert out["chained"] == out["levels"] == out["release"], out
 
 
-def test_next_layer_slices_in_the_first_fc_level_stay_parity_green_when_selected():
-    """CPP_FC_NEXT=1 (ablation build; an experiment that measured no gain): the tiles of the first fully connected layer leave their slices
-    of the next layer's sum and ddpg_heads_kernel finishes that layer -- one GEMM level less.  Same parity cases, incl. the full-size fused step."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"),
-                        os.path.join(root, "tests", "test_gpu_fused_fullsize.py"), "-q", "-x", "-m", "gpu",
-                        "-k", "fused or gradients or train_ops or cfg3"], cwd=root, env=dict(os.environ, CARTPOLEPP_ABLATION="1", CPP_FC_NEXT="1"),
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
-    tail = r.stdout.decode()[-1500:]
-    assert r.returncode == 0 and " passed" in tail, tail
-
-
-def test_ddpg_core_kernel_stays_parity_green_when_selected():
-    """CPP_DDPG_CORE=1 (ablation build; an experiment that measured slower): ONE kernel on the matrix pipes for everything between the
-    first fully connected layers and the backward GEMM level (ddpg_core.hip) instead of ddpg_heads_kernel and two GEMM levels.  Same
-    parity cases, incl. the full-size fused step against the float64 oracle."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"),
-                        os.path.join(root, "tests", "test_gpu_fused_fullsize.py"), "-q", "-x", "-m", "gpu",
-                        "-k", "fused or gradients or train_ops or cfg3"], cwd=root, env=dict(os.environ, CARTPOLEPP_ABLATION="1", CPP_DDPG_CORE="1"),
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
-    tail = r.stdout.decode()[-1500:]
-    assert r.returncode == 0 and " passed" in tail, tail

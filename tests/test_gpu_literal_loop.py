@@ -25,7 +25,8 @@ def _maxrel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
-@pytest.mark.parametrize("shape,B,pixel", [((32, 32, 3, 2, 3), 32, True), ((16, 16, 3, 1, 2), 8, True), ((2, 2, 7), 16, False)])
+@pytest.mark.parametrize("shape,B,pixel", [((32, 32, 3, 2, 3), 32, True), ((16, 16, 3, 1, 2), 8, True), ((2, 2, 7), 16, False),
+                                           ((64, 64, 3, 2, 3), 256, True)], ids=["32x32x18-B32", "16x16x6-B8", "lowdim-B16", "cfg3-B256"])
 def test_reference_loop_verbatim_is_the_fused_step(shape, B, pixel):
     """ddpg_cartpole.py:331-337 verbatim for 10 minibatches: every actor.train / critic.train pair runs as ONE fused device sequence
     (cpp_ddpg_train_rows) and no state column crosses PCIe.  With --batches-per-step 1 the loop is bit-identical to

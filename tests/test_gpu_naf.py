@@ -231,6 +231,10 @@ def test_checkpoint_resume_restores_the_adam_slots(tmp_path):
 @pytest.mark.parametrize("shape,B,share", [((64, 64, 3, 2, 3), 256, True), ((50, 50, 3, 1, 2), 128, False)],
                          ids=["cfg4-64x64x18-B256-shared-trunk", "reference-defaults-50x50x6-B128-own-trunks"])
 def test_cfg4_B256_graph_replayed_naf_step_against_f64_oracle(shape, B, share):
+    naf_fused_step_against_f64_oracle(shape, B, share)
+
+
+def naf_fused_step_against_f64_oracle(shape, B, share, fill="noise"):
     """cfg4 at the size the metric is quoted on (64x64x18, B = 256, shared trunk, Momentum as in exps/run_93.sh): the hipGraph REPLAY
     of the fused NAF step (naf_cartpole.py:365-373) on rows drawn by the device's sampler against oracle.NAF(float64) started from the
     same parameters and Momentum slots: loss at 1e-5, the pre-clip gradient list per variable at 2e-5 (the trunk's two
@@ -245,7 +249,12 @@ def test_cfg4_B256_graph_replayed_naf_step_against_f64_oracle(shape, B, share):
     agent, _ref, specs = make_naf(shape, B, share, "Momentum", oargs, seed=4, replay_size=rows + 50)
     try:
         rm = agent.replay_memory
-        rm.fill_synthetic(rows, seed=33)
+        if fill == "noise":
+            rm.fill_synthetic(rows, seed=33)
+        else:      # rendered episodes through add_episode (tests/test_gpu_render_inputs.py)
+            from cartpoleplusplus_amd import naf_cartpole as F
+            from tests.helpers import fill_with_rendered_episodes
+            fill_with_rendered_episodes(agent, shape, rows, seed=33, blind_camera=(fill == "render-blind"), opts=F.opts)
         agent.train_step(B, 1)                                    # eager pass + capture (also fills the Momentum slots)
         nets = (agent.value_net, agent.naf.mu_net, agent.naf.l_net, agent.target_value_net)
         P = [n.get_params() for n in nets]

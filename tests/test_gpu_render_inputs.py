@@ -1,0 +1,135 @@
+"""Parity on the inputs the reference actually trains on: RENDERS (bullet_cartpole.py:227-257) -- a cart and a pole on flat sky /
+ground levels, R action-repeat frames per camera that differ by a few pixels, state_2 of a transition = state_1 of the next, and
+optionally a camera that sees one colour only.  Uniform pixel noise (every other GPU test) has none of this: no near-constant
+channel (whitening scales of 9 ... 1000 instead of 3.45, base_network.py:95-99), no large regions of EXACT pooling ties on positive
+values (base_network.py:107), no repeated frames.  The frames come from synthetic_env.RasterCartpole, a small software rasteriser
+with that structure, and enter the replay memory through add_episode as the reference's rollouts do (ddpg_cartpole.py:315-326).
+
+Bars: north_star's 1e-5 on actions / Q / TD and 2e-5 per variable on pre-clip gradients wherever a float32 evaluation can meet them;
+on inputs with NEARLY constant channels (scale ~ 1000 on values that do not cancel exactly) no float32 evaluation can -- there the
+bar is relative to the float32 numpy evaluation of the same step (the rounding the reference's TF CPU kernels are entitled to):
+err_device <= F32_FACTOR * err_f32_oracle + 1e-7."""
+import numpy as np
+import pytest
+
+from oracle import ddpg_np as O
+from tests.helpers import fused_step_against_f64_oracle, make_pair, fill_with_rendered_episodes, device_pool_codes
+
+pytestmark = pytest.mark.gpu
+CFG3 = (64, 64, 3, 2, 3)
+F32_FACTOR = 1.5
+
+
+@pytest.mark.parametrize("fill", ["render", "render-blind"])
+def test_cfg3_B256_graph_replayed_fused_step_on_rendered_episodes(fill):
+    """the release kernels (two f16 pieces / six bf16 products), the hipGraph replay, device-drawn rows: every bar of the noise-input
+    test (tests/test_gpu_fused_fullsize.py) holds on renders, with and without a blind camera (three channels of zero variance)."""
+    rep = fused_step_against_f64_oracle(CFG3, 256, rows=600, graph=True, seed=11, fill=fill, f32_twin=True)
+    print("cfg3 B=256 fused graph step on %s inputs vs f64 oracle:" % fill, rep)
+    if fill == "render-blind":
+        assert rep["white_scale_max"] == 1000.0              # (the oracle's table: rsqrt(0 + 1e-6))
+    else:
+        assert rep["white_scale_max"] > 2.0 * rep["white_scale_min"]      # near-constant channels: a sky, a floor
+    for k in ("actions", "dq_da", "q", "td", "pool1", "pool2", "pool3"):
+        assert rep["err_" + k] <= F32_FACTOR * rep["f32_err_" + k] + 1e-6, (k, rep)      # no further from float64 than float32 numpy is
+
+
+def test_cfg3_B256_fused_step_on_rendered_episodes_from_the_8_bit_store():
+    rep = fused_step_against_f64_oracle(CFG3, 256, rows=600, graph=True, seed=12, fill="render", replay_store="u8", f32_twin=True)
+    print("cfg3 B=256 (u8 store) on render inputs:", rep)
+
+
+def test_cfg2_B256_fused_step_on_rendered_episodes():
+    rep = fused_step_against_f64_oracle((64, 64, 3, 1, 3), 256, rows=600, graph=True, seed=13, fill="render", f32_twin=True)
+    print("cfg2 B=256 on render inputs:", rep)
+
+
+def test_reference_default_render_50x50x6_B128_on_rendered_episodes():
+    rep = fused_step_against_f64_oracle((50, 50, 3, 1, 2), 128, rows=500, graph=True, seed=14, fill="render", f32_twin=True)
+    print("50x50x6 B=128 on render inputs:", rep)
+
+
+@pytest.mark.parametrize("fill", ["render", "render-blind"])
+def test_cfg4_B256_naf_step_on_rendered_episodes(fill):
+    from tests.test_gpu_naf import naf_fused_step_against_f64_oracle
+    naf_fused_step_against_f64_oracle(CFG3, 256, True, fill=fill)
+
+
+def test_nearly_constant_channels_stay_within_the_float32_evaluation():
+    """a blind camera with a rare single off-colour pixel: three channels with scale ~ 990 whose whitened values do NOT cancel
+    exactly (a glint whitens to ~400, the rest to -4e-4).  Conv outputs reach ~100 and Q ~6; float32 numpy itself is 1e-4 away
+    from float64 here, so the bar is the float32-relative one."""
+    rep = fused_step_against_f64_oracle(CFG3, 256, rows=600, graph=True, seed=11, fill="render-glint", f32_twin=True, report_only=True)
+    print("cfg3 B=256 on render-glint inputs:", rep)
+    assert 300.0 < rep["white_scale_max"] < 1000.0
+    for k in ("flips_actor", "flips_critic", "relu_flips_actor", "relu_flips_critic"):
+        assert not isinstance(rep[k], str), (k, rep[k])
+    for k in ("actions", "q", "td", "pool1", "pool2", "pool3"):
+        assert rep["err_" + k] <= F32_FACTOR * rep["f32_err_" + k] + 1e-7, (k, rep)
+
+
+def _flat_images(B, shape, rng):
+    """B states whose every channel is flat inside each image but differs between images: conv outputs are translation
+    invariant away from the border, so EVERY interior pooling window of every layer is an exact four-way tie."""
+    H, W = shape[0], shape[1]
+    C = int(np.prod(shape[2:]))
+    codes = rng.integers(20, 236, (B, 1, 1, C))
+    x = np.broadcast_to(codes, (B, H, W, C)).astype(np.float64) / 255.0
+    return x.astype(np.float16).reshape((B,) + tuple(shape))
+
+
+def test_exact_positive_pooling_ties_route_to_the_first_maximum():
+    """base_network.py:107 (slim.max_pool2d) on windows whose four pre-activations are EQUAL and positive: TF's max-pool gradient goes
+    to the first maximum in window order (y, x) -- np.argmax in the oracle, strict `>` in the kernels' pool epilogues.  Forward: the
+    device's arg-max code is 0 in every such window of every layer.  Backward: the device's gradients equal the oracle's with ITS
+    OWN routing (no override), and are measurably different from an oracle that routes ties to the LAST maximum -- so the comparison
+    is sensitive to the rule."""
+    shape, B = (32, 32, 3, 2, 3), 16
+    agent, ref, (aspec, cspec) = make_pair(shape, B, True, seed=8)
+    rng = np.random.default_rng(3)
+
+    class HB(object):
+        pass
+    hb = HB()
+    s1 = _flat_images(B, shape, rng)
+    # half of each image gets a second flat level: ties everywhere except along the seam, and gradient routes that matter there
+    s1[:, :, shape[1] // 2:] = _flat_images(B, shape, rng)[:, :, shape[1] // 2:]
+    t = O.synthetic_batch(rng, B, shape, 2, True)
+    hb.state_1, hb.action, hb.reward, hb.terminal_mask, hb.state_2 = s1, t[1], t[2], t[3], s1[::-1].copy()
+    try:
+        agent.critic.train(hb)
+        got = agent.critic.get_grads()
+        codes = device_pool_codes(agent.critic, B)
+    finally:
+        agent.close()
+    batch = (hb.state_1, hb.action, hb.reward, hb.terminal_mask, hb.state_2)
+    cg = ref.critic_gradients(batch)
+    cache = cg["cache_critic"]
+    n_ties = 0
+    for name, _k, _co in O.CONV_DEFS:
+        _x, pooled, amax, _h, _w = cache[name]
+        tie = (cache[name + ":margin"] == 0.0) & (pooled > 0)          # exact ties on positive values, as the float64 oracle sees them
+        # (a window the oracle sees as an exact tie is one whose four inputs are translates of each other: equal on the device too)
+        assert tie.sum() > 50, (name, int(tie.sum()))
+        # np.argmax = the FIRST of the equal maxima: code 0 in a four-way tie (the flat interior), 2 where only the window's lower
+        # row ties at the top (an image's first rows see the SAME padding), 1 / 0 likewise at the left edge
+        dev = codes[name].reshape(amax.shape)
+        assert (dev[tie] == amax[tie]).all(), "%s: %d exact positive ties not routed to the first maximum" % (
+            name, int((dev[tie] != amax[tie]).sum()))
+        assert (amax[tie] == 0).sum() > 50 and (dev[tie] == 0).sum() == (amax[tie] == 0).sum()
+        n_ties += int(tie.sum())
+    from tests.helpers import per_var_report
+    rel_first = max(r[2] for r in per_var_report(cspec, got, cg["grads"]))
+    # the same oracle with ties routed to the LAST maximum
+    last = {}
+    for name, _k, _co in O.CONV_DEFS:
+        _x, pooled, amax, _h, _w = cache[name]
+        tie = cache[name + ":margin"] == 0.0
+        last[name] = np.where(tie, 3, amax).astype(np.uint8)
+    ref.critic.amax_override = last
+    try:
+        rel_last = max(r[2] for r in per_var_report(cspec, got, ref.critic_gradients(batch)["grads"]))
+    finally:
+        ref.critic.amax_override = None
+    print("exact positive ties: %d windows; gradient rel err vs first-max oracle %.2e, vs last-max oracle %.2e" % (n_ties, rel_first, rel_last))
+    assert rel_first < 2e-5 and rel_last > 50 * rel_first, (rel_first, rel_last)
