@@ -64,6 +64,10 @@ struct DwReduceDesc { const float* partial; int nblocks, pstride, nw, nout; floa
                       double* sq_part; };      // non-null: reduction block b also leaves the sum of squares of its 64 gradients in sq_part[b]
 #define DW_REDUCE_MAX 8
 
+#ifndef CPP_PRECISION_FAST
+#define CPP_PRECISION_FAST 0      /* (include/cartpolepp_abi.h) */
+#define CPP_PRECISION_EXACT 1
+#endif
 struct cpp_ctx {
   int device;
   hipStream_t stream;
@@ -87,6 +91,8 @@ struct cpp_ctx {
   // kernel runs instead: data-parallel steps, whose gradients change in the all-reduce; batch norm; NAF).
   double* sq_part; int sq_n[2]; int sq_conv_group[4];
   unsigned* gemm_chain;           // GEMM_CHAIN_SLOTS counters of the chained GEMM launches (zero between launches)
+  int precision;                  // CPP_PRECISION_FAST / CPP_PRECISION_EXACT (cpp_ctx_set_precision; conv_k16.h)
+  int n_trainers;                 // live cpp_ddpg / cpp_naf objects: their captured graphs pin the precision mode
 };
 #define SQ_REGION 2048
 

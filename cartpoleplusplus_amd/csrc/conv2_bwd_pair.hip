@@ -21,12 +21,10 @@ int launch_conv2_bwd_pair(cpp_ctx* ctx, const ConvPairSlot& slot) {
   const int ndx = slot.have_dx ? slot.dx_gx * slot.dx.n : 0, ndw = slot.have_dw ? slot.dw_gx * slot.dw.n : 0;
   if (ndx + ndw == 0) return 0;
   const size_t lds = (slot.have_dx ? slot.dx_lds : 0) > (slot.have_dw ? slot.dw_lds : 0) ? slot.dx_lds : slot.dw_lds;
-  auto kern = conv2_bwd_pair_kernel<B16_SIX>;
-#ifdef CPP_ABLATION
-  if (b16_order() == B16_NINE) kern = conv2_bwd_pair_kernel<B16_NINE>;
-#endif
-  static size_t attr_dev[CPP_MAX_DEVICES] = {};      // (kernel attributes are per device)
-  size_t& attr = attr_dev[cpp_dev_slot(ctx)];
+  const bool nine = b16_order(ctx) == B16_NINE;      // (cpp_ctx_set_precision: every product of the bf16 pieces)
+  auto kern = nine ? conv2_bwd_pair_kernel<B16_NINE> : conv2_bwd_pair_kernel<B16_SIX>;
+  static size_t attr_dev[CPP_MAX_DEVICES][2] = {};   // (kernel attributes are per device and per kernel)
+  size_t& attr = attr_dev[cpp_dev_slot(ctx)][nine ? 1 : 0];
   if (lds > attr) {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = lds;

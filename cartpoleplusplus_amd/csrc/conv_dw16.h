@@ -26,9 +26,9 @@
 typedef short dw16_v4s __attribute__((__vector_size__(4 * sizeof(short))));
 typedef unsigned dw16_u32x2 __attribute__((ext_vector_type(2)));
 
-template <int CIN, int KS, int NCHK>
+template <int CIN, int KS, int NCHK, int NPCS = F16_PIECES>
 struct Dw16Geom {
-  static constexpr int P = KS / 2, NO = KYO_NO, NPC = F16_PIECES;
+  static constexpr int P = KS / 2, NO = KYO_NO, NPC = NPCS;
   // channel pitch of a pixel in LDS (halves): CIN + the ones channel, rounded to 8 bytes; a pitch of 0 (mod 8) dwords would
   // put the 8 pixel quads of a transpose read on the same banks, so those get 4 more halves (30 channels -> 36)
   static constexpr int CP0 = (CIN + 1 + 3) & ~3;
@@ -66,9 +66,9 @@ struct Dw16Geom {
 // ddpg_cartpole.py:333-334) -- the raw row is staged once, every A fragment is read from LDS once and multiplied with both networks' dY
 // (two dY rings, two accumulator sets, two partials).  Half the input staging and half the A reads per MFMA; the joint launch is 512
 // workgroups = one resident round instead of 1024 on 768 slots.
-template <int CIN, int KS, int NCHK, bool DENSE = false, int NNET = 1>
+template <int CIN, int KS, int NCHK, bool DENSE = false, int NNET = 1, int NPCS = F16_PIECES>
 __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units_per_img, int band, const int bx, const int by, const int gx) {
-  typedef Dw16Geom<CIN, KS, NCHK> G;
+  typedef Dw16Geom<CIN, KS, NCHK, NPCS> G;
   constexpr int P = G::P, NO = G::NO, MT = G::MT, CP = G::CP, NPC = G::NPC, ROWB = G::ROWB, DSLOT = G::DSLOT;
   static_assert((KS * NO + 15) / 16 == 4, "one column tile per wave");
   static_assert(NNET == 1 || NNET == 2, "one or two networks per workgroup");
@@ -582,17 +582,17 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
 #endif
 }
 
-template <int CIN, int KS, int NCHK, bool DENSE = false>
-__global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK>::MT > 8 ? 2 : DW16_WGS)) void conv_dw16_kernel(const ConvArgsN batch, int units_per_img, int band) {
-  conv_dw16_body<CIN, KS, NCHK, DENSE>(batch, units_per_img, band, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+template <int CIN, int KS, int NCHK, bool DENSE = false, int NPCS = F16_PIECES>
+__global__ __launch_bounds__(CONV_THREADS, (Dw16Geom<CIN, KS, NCHK, NPCS>::MT > 8 ? 2 : DW16_WGS)) void conv_dw16_kernel(const ConvArgsN batch, int units_per_img, int band) {
+  conv_dw16_body<CIN, KS, NCHK, DENSE, 1, NPCS>(batch, units_per_img, band, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
 }
 // two networks that read the same images per workgroup (blockIdx.y selects the PAIR: networks 2y and 2y + 1)
-template <int CIN, int KS, int NCHK>
+template <int CIN, int KS, int NCHK, int NPCS = F16_PIECES>
 __global__ __launch_bounds__(CONV_THREADS, 2) void conv_dw16_pair_kernel(const ConvArgsN batch, int units_per_img, int band) {
-  conv_dw16_body<CIN, KS, NCHK, false, 2>(batch, units_per_img, band, (int)blockIdx.x, 2 * (int)blockIdx.y, (int)gridDim.x);
+  conv_dw16_body<CIN, KS, NCHK, false, 2, NPCS>(batch, units_per_img, band, (int)blockIdx.x, 2 * (int)blockIdx.y, (int)gridDim.x);
 }
 // conv1 dW of the headline shape with the next minibatch's sample + statistics pass behind it in the same grid (conv1_dw_gather.hip)
-int launch_conv1_dw_gather(cpp_ctx* ctx, const ConvArgsN& batch, int upi, int band, int grid, size_t lds_bytes, const GatherArgs& g, bool pair);
+int launch_conv1_dw_gather(cpp_ctx* ctx, const ConvArgsN& batch, int upi, int band, int grid, size_t lds_bytes, const GatherArgs& g, bool pair, bool exact);
 
 // networks 2j and 2j + 1 of the batch read the same images with the same whitening: one workgroup can serve both
 static inline bool conv_dw16_pairable(const ConvArgsN& batch) {
@@ -606,15 +606,15 @@ static inline bool conv_dw16_pairable(const ConvArgsN& batch) {
   return true;
 }
 
-template <int CIN, int KS, int NCHK, bool DENSE = false, bool PAIR = false>
+template <int CIN, int KS, int NCHK, bool DENSE = false, bool PAIR = false, int NPCS = F16_PIECES>
 static inline int conv_dw16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int* grid_out) {
-  typedef Dw16Geom<CIN, KS, NCHK> G;
+  typedef Dw16Geom<CIN, KS, NCHK, NPCS> G;
   const ConvArgs& a = batch.a[0];
   const size_t lds_bytes = PAIR ? (size_t)G::LDS_BYTES2 : (size_t)G::LDS_BYTES;
   static bool attr_done[CPP_MAX_DEVICES] = {};          // (kernel attributes are per device: one cpp_ctx per GPU may share the process)
   if (!attr_done[cpp_dev_slot(ctx)]) {
-    if constexpr (PAIR) HIP_CHECK(hipFuncSetAttribute((const void*)conv_dw16_pair_kernel<CIN, KS, NCHK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    else HIP_CHECK(hipFuncSetAttribute((const void*)conv_dw16_kernel<CIN, KS, NCHK, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if constexpr (PAIR) HIP_CHECK(hipFuncSetAttribute((const void*)conv_dw16_pair_kernel<CIN, KS, NCHK, NPCS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    else HIP_CHECK(hipFuncSetAttribute((const void*)conv_dw16_kernel<CIN, KS, NCHK, DENSE, NPCS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_done[cpp_dev_slot(ctx)] = true;
   }
 #ifndef DW16_CAP
@@ -628,8 +628,8 @@ static inline int conv_dw16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int* 
   if (wgs_per_cu[cpp_dev_slot(ctx)] == 0) {
     int nb = 0;
     hipError_t oe;
-    if constexpr (PAIR) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_dw16_pair_kernel<CIN, KS, NCHK>, CONV_THREADS, lds_bytes);
-    else oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_dw16_kernel<CIN, KS, NCHK, DENSE>, CONV_THREADS, lds_bytes);
+    if constexpr (PAIR) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_dw16_pair_kernel<CIN, KS, NCHK, NPCS>, CONV_THREADS, lds_bytes);
+    else oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_dw16_kernel<CIN, KS, NCHK, DENSE, NPCS>, CONV_THREADS, lds_bytes);
     wgs_per_cu[cpp_dev_slot(ctx)] = (oe == hipSuccess && nb >= 1) ? (nb > DW16_CAP ? DW16_CAP : nb) : 2;
     (void)hipGetLastError();
   }
@@ -643,10 +643,10 @@ static inline int conv_dw16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch, int* 
   if (ctx->ride && !ctx->ride_done && ctx->ride_at_dw && ctx->ride_dtype == 1 && CIN == 18 && KS == 5 && NCHK == 2 && !DENSE) {
     ctx->ride_done = true;
     *grid_out = grid;
-    return launch_conv1_dw_gather(ctx, batch, upi, band, grid, lds_bytes, *ctx->ride, PAIR);
+    return launch_conv1_dw_gather(ctx, batch, upi, band, grid, lds_bytes, *ctx->ride, PAIR, NPCS == F16_PIECES_EXACT);
   }
-  if constexpr (PAIR) hipLaunchKernelGGL((conv_dw16_pair_kernel<CIN, KS, NCHK>), dim3(grid, batch.n / 2), dim3(CONV_THREADS), lds_bytes, ctx->stream, batch, upi, band);
-  else hipLaunchKernelGGL((conv_dw16_kernel<CIN, KS, NCHK, DENSE>), dim3(grid, batch.n), dim3(CONV_THREADS), lds_bytes, ctx->stream, batch, upi, band);
+  if constexpr (PAIR) hipLaunchKernelGGL((conv_dw16_pair_kernel<CIN, KS, NCHK, NPCS>), dim3(grid, batch.n / 2), dim3(CONV_THREADS), lds_bytes, ctx->stream, batch, upi, band);
+  else hipLaunchKernelGGL((conv_dw16_kernel<CIN, KS, NCHK, DENSE, NPCS>), dim3(grid, batch.n), dim3(CONV_THREADS), lds_bytes, ctx->stream, batch, upi, band);
   LAUNCH_CHECK();
   *grid_out = grid;
   return 0;

@@ -1,10 +1,15 @@
 // conv1 dW / db on the f16 matrix pipes with f32-exact operands (conv_dw16.h): instantiations + geometry selection.
 #include "conv_dw16.h"
 
+// (cpp_ctx_set_precision: three f16 pieces of dY instead of two)
 #define DW16_CASE(CIN_, NCHK_)                                                                               \
-  if (cin == CIN_ && nchk == NCHK_ && !dense) { *handled = true; if (!ctx) return 0; return conv_dw16_launch_t<CIN_, 5, NCHK_>(ctx, a, grid); }
+  if (cin == CIN_ && nchk == NCHK_ && !dense) { *handled = true; if (!ctx) return 0;                         \
+    if (f16_exact(ctx)) return conv_dw16_launch_t<CIN_, 5, NCHK_, false, false, F16_PIECES_EXACT>(ctx, a, grid); \
+    return conv_dw16_launch_t<CIN_, 5, NCHK_>(ctx, a, grid); }
 #define DW16_CASE_DENSE(CIN_, NCHK_)                                                                         \
-  if (cin == CIN_ && nchk == NCHK_ && dense) { *handled = true; if (!ctx) return 0; return conv_dw16_launch_t<CIN_, 5, NCHK_, true>(ctx, a, grid); }
+  if (cin == CIN_ && nchk == NCHK_ && dense) { *handled = true; if (!ctx) return 0;                          \
+    if (f16_exact(ctx)) return conv_dw16_launch_t<CIN_, 5, NCHK_, true, false, F16_PIECES_EXACT>(ctx, a, grid); \
+    return conv_dw16_launch_t<CIN_, 5, NCHK_, true>(ctx, a, grid); }
 
 int conv_dw16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool dense, const ConvArgsN& a, int* grid, bool* handled) {
   *handled = false;

@@ -4,7 +4,9 @@
 #include "conv_dw16.h"
 
 #define DW16_PAIR_CASE(CIN_, NCHK_)                                                                               \
-  if (cin == CIN_ && nchk == NCHK_) { *handled = true; if (!ctx) return 0; return conv_dw16_launch_t<CIN_, 5, NCHK_, false, true>(ctx, a, grid); }
+  if (cin == CIN_ && nchk == NCHK_) { *handled = true; if (!ctx) return 0;                                      \
+    if (f16_exact(ctx)) return conv_dw16_launch_t<CIN_, 5, NCHK_, false, true, F16_PIECES_EXACT>(ctx, a, grid);   \
+    return conv_dw16_launch_t<CIN_, 5, NCHK_, false, true>(ctx, a, grid); }
 
 int conv_dw16_pair_dispatch(cpp_ctx* ctx, int cin, int nchk, const ConvArgsN& a, int* grid, bool* handled) {
   *handled = false;

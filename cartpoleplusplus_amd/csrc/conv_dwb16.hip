@@ -1,11 +1,7 @@
 // conv2 dW / db on the bf16 matrix pipes with f32-exact operands (conv_dwb16.h): instantiations + geometry selection.
 #include "conv_dwb16.h"
 
-#ifdef CPP_ABLATION
-#define DWB16_NINE(CIN_, NCHK_) if (b16_order() == B16_NINE) return conv_dwb16_launch_t<CIN_, 5, NCHK_, B16_NINE>(ctx, a, grid);
-#else
-#define DWB16_NINE(CIN_, NCHK_)
-#endif
+#define DWB16_NINE(CIN_, NCHK_) if (b16_order(ctx) == B16_NINE) return conv_dwb16_launch_t<CIN_, 5, NCHK_, B16_NINE>(ctx, a, grid);
 #define DWB16_CASE(CIN_, NCHK_)                                                                              \
   if (cin == CIN_ && nchk == NCHK_) { *handled = true; DWB16_NINE(CIN_, NCHK_) return conv_dwb16_launch_t<CIN_, 5, NCHK_>(ctx, a, grid); }
 

@@ -26,6 +26,7 @@ static ConvArgsN k16_with_bands(cpp_ctx* ctx, const ConvArgsN& a, int ipw) {
 
 #define K16_CASE(CIN_, XT_, IPW_, PLAIN_)                                                                    \
   if (cin == CIN_ && xt == XT_ && ipw == IPW_ && plain == PLAIN_) { *handled = true; if (!ctx) return 0;      \
+    if (f16_exact(ctx)) return conv_fwd_k16_launch_t<CIN_, 5, XT_, IPW_, PLAIN_, 0, F16_PIECES_EXACT>(ctx, k16_with_bands(ctx, a, IPW_)); \
     return conv_fwd_k16_launch_t<CIN_, 5, XT_, IPW_, PLAIN_>(ctx, k16_with_bands(ctx, a, IPW_)); }
 
 int conv_fwd_k16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool plain, const ConvArgsN& a, bool* handled) {
@@ -45,11 +46,7 @@ int conv_fwd_k16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool plain
   return 0;
 }
 
-#ifdef CPP_ABLATION
-#define KB16_NINE(XT_, IPW_) if (b16_order() == B16_NINE) return conv_fwd_k16_launch_t<10, 5, XT_, IPW_, false, B16_NINE>(ctx, k16_with_bands(ctx, a, IPW_));
-#else
-#define KB16_NINE(XT_, IPW_)
-#endif
+#define KB16_NINE(XT_, IPW_) if (b16_order(ctx) == B16_NINE) return conv_fwd_k16_launch_t<10, 5, XT_, IPW_, false, B16_NINE>(ctx, k16_with_bands(ctx, a, IPW_));
 #define KB16_CASE(XT_, IPW_)                                                                                 \
   if (xt == XT_ && ipw == IPW_) { *handled = true; if (!ctx) return 0;                                       \
     KB16_NINE(XT_, IPW_)                                                                                       \

@@ -68,18 +68,18 @@ typedef unsigned k16_u32x4 __attribute__((ext_vector_type(4)));
 // is the 23rd bit; a third piece holds what is left, at most one bit).  Against the float64 oracle at 64x64x18, B = 256: pooled conv1
 // output 3.2e-6 (two) / 3.7e-6 (three) / 7.0e-6 (f32-input MFMA) max abs at magnitude 7.1, conv1 weight gradient 1.22e-6 / 1.19e-6 /
 // 1.69e-6 rel (profiles/experiments/r03_f16_pieces.txt).  Release: 2; libcartpolepp_hip_exact.so: 3 (every product exact).
-#ifndef F16_PIECES
+//
+// Both arithmetic contracts are in the release library; cpp_ctx_set_precision (include/cartpolepp_abi.h) chooses per context:
+// CPP_PRECISION_FAST (default): two f16 pieces, six bf16 products; CPP_PRECISION_EXACT: three / nine -- every product exact.
 #define F16_PIECES 2
-#endif
-#ifndef B16_DEFAULT_PRODUCTS
-#define B16_DEFAULT_PRODUCTS 6
-#endif
+#define F16_PIECES_EXACT 3
 #define B16_SIX 2
 #define B16_NINE 4
-static inline int b16_order() {
-  static const int o = cpp_switch_int("CPP_B16_PRODUCTS", B16_DEFAULT_PRODUCTS) == 9 ? B16_NINE : B16_SIX;
-  return o;
+static inline int b16_order(const cpp_ctx* ctx) {
+  static const int sw = cpp_switch_int("CPP_B16_PRODUCTS", 6) == 9 ? B16_NINE : B16_SIX;      // (ablation build only)
+  return (ctx && ctx->precision == CPP_PRECISION_EXACT) ? B16_NINE : sw;
 }
+static inline bool f16_exact(const cpp_ctx* ctx) { return ctx && ctx->precision == CPP_PRECISION_EXACT; }
 __device__ __forceinline__ unsigned k16_bf16_bits(float x) {        // round-to-nearest-even bf16 of a finite f32
   const unsigned u = __float_as_uint(x);
   return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
@@ -114,7 +114,7 @@ __device__ __forceinline__ void k16_issue_b32(unsigned& dst, const k16_i32x4& de
 template <int N> __device__ __forceinline__ void k16_wait_vm(k16_u32x4& x) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x) : "n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void k16_wait_vm(unsigned& x) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x) : "n"(N) : "memory"); }
 
-template <int CIN, int KS, int XT, int IPW, bool B16 = false>      // (geometry: B16 mode or not)
+template <int CIN, int KS, int XT, int IPW, bool B16 = false, int NPCS = F16_PIECES>      // (geometry: B16 mode or not; f16 pieces of a weight)
 struct K16Geom {
   static constexpr int NO = KYO_NO;
   static constexpr int P = KS / 2;
@@ -124,7 +124,7 @@ struct K16Geom {
   static constexpr int RK = B16 ? 32 : 30;                 // real k values per MFMA chunk; f16 mode: slots 30, 31 of every chunk are the ones slots
   static constexpr int NPA = B16 ? 3 : 1;                  // planes of the A operand
   static constexpr int NCH = (KROW + RK - 1) / RK;         // MFMA k chunks per row
-  static constexpr int NPC = B16 ? 3 : F16_PIECES;         // f16 / bf16 pieces of a weight
+  static constexpr int NPC = B16 ? 3 : NPCS;               // f16 / bf16 pieces of a weight
   // weight image in LDS: slab (chunk, piece) holds the 16-byte operand (ky, lane group g, o) at ky*PS + g*GS + o*16;
   // the padded strides keep the rotating per-lane reads of a ds_read_b128 at 1.2 accesses per bank quad (2.45 compact)
 #ifdef K16_MID_LAYOUT
@@ -168,9 +168,9 @@ struct K16Geom {
 #ifndef K16_ROTATE_PRIO
 #define K16_ROTATE_PRIO 1
 #endif
-template <int CIN, int KS, int XT, int IPW, bool PLAIN = false, int B16 = 0>      // B16: 0, or B16_SIX / B16_NINE
+template <int CIN, int KS, int XT, int IPW, bool PLAIN = false, int B16 = 0, int NPCS = F16_PIECES>      // B16: 0, or B16_SIX / B16_NINE
 __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(const ConvArgsN batch) {
-  typedef K16Geom<CIN, KS, XT, IPW, (B16 != 0)> G;
+  typedef K16Geom<CIN, KS, XT, IPW, (B16 != 0), NPCS> G;
   static_assert(B16 != 0 || KS == 5, "the border table of the f16 mode is written for 5x5 (P = 2)");
   constexpr int P = G::P, NT = G::NT, NCH = G::NCH, NPC = G::NPC, NPA = G::NPA, NO = KYO_NO;
   constexpr bool ODD = (CIN & 1) != 0;            // 2-byte aligned operand windows: 20 bytes from the aligned address below + a funnel shift
@@ -741,12 +741,12 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #endif
 }
 
-template <int CIN, int KS, int XT, int IPW, bool PLAIN = false, int B16 = 0>      // B16: 0, or B16_SIX / B16_NINE
+template <int CIN, int KS, int XT, int IPW, bool PLAIN = false, int B16 = 0, int NPCS = F16_PIECES>      // B16: 0, or B16_SIX / B16_NINE
 static inline int conv_fwd_k16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
-  typedef K16Geom<CIN, KS, XT, IPW, (B16 != 0)> G;
+  typedef K16Geom<CIN, KS, XT, IPW, (B16 != 0), NPCS> G;
   const ConvArgs& a = batch.a[0];
   const size_t lds_bytes = (size_t)G::LDS_BYTES;
-  auto kern = conv_fwd_k16_kernel<CIN, KS, XT, IPW, PLAIN, B16>;
+  auto kern = conv_fwd_k16_kernel<CIN, KS, XT, IPW, PLAIN, B16, NPCS>;
   static bool attr_done[CPP_MAX_DEVICES] = {};          // (kernel attributes are per device: one cpp_ctx per GPU may share the process)
   if (!attr_done[cpp_dev_slot(ctx)]) {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

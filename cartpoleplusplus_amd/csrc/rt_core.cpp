@@ -90,6 +90,21 @@ extern "C" int cpp_ctx_create(int device_id, void* hip_stream, cpp_ctx** out) {
   return CPP_OK;
 }
 
+extern "C" int cpp_ctx_set_precision(cpp_ctx* c, int mode) {
+  ARG_CHECK(c, "cpp_ctx_set_precision: ctx is NULL");
+  ARG_CHECK(mode == CPP_PRECISION_FAST || mode == CPP_PRECISION_EXACT, "cpp_ctx_set_precision: mode %d is neither CPP_PRECISION_FAST nor CPP_PRECISION_EXACT", mode);
+  ARG_CHECK(c->n_trainers == 0 || mode == c->precision,
+            "cpp_ctx_set_precision: %d trainer(s) exist on this ctx (their step graphs hold the kernels of the current mode): set the mode first", c->n_trainers);
+  c->precision = mode;
+  return CPP_OK;
+}
+
+extern "C" int cpp_ctx_get_precision(cpp_ctx* c, int* mode) {
+  ARG_CHECK(c && mode, "cpp_ctx_get_precision: NULL argument");
+  *mode = c->precision;
+  return CPP_OK;
+}
+
 extern "C" int cpp_ctx_destroy(cpp_ctx* c) {
   if (!c) return CPP_OK;
   (void)hipSetDevice(c->device);

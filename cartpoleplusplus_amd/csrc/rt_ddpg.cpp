@@ -68,6 +68,7 @@ extern "C" int cpp_ddpg_create(cpp_ctx* ctx, cpp_net* actor, cpp_net* critic, cp
   if (rc) { d->arena.release(); delete d; return rc; }
   actor->grads = d->gradbuf; critic->grads = d->gradbuf + d->nA;
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->n_trainers += 1;
   *out = d;
   return CPP_OK;
 }
@@ -94,6 +95,7 @@ extern "C" int cpp_ddpg_destroy(cpp_ddpg* d) {
   drop_half_graphs(d);
   if (d->step_batch) cpp_batch_destroy(d->step_batch);
   d->actor->grads = nullptr; d->critic->grads = nullptr;
+  d->ctx->n_trainers -= 1;
   d->arena.release(); delete d; return CPP_OK;
 }
 

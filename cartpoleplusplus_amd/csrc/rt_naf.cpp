@@ -79,6 +79,7 @@ extern "C" int cpp_naf_create(cpp_ctx* ctx, cpp_net* value, cpp_net* tvalue, cpp
     lv->ws[0].fcin[0] = value->ws[0].fcin.back();
   }
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->n_trainers += 1;
   *out = f;
   return CPP_OK;
 }
@@ -99,6 +100,7 @@ extern "C" int cpp_naf_destroy(cpp_naf* f) {
   if (f->graph) (void)hipGraphDestroy(f->graph);
   if (f->step_batch) cpp_batch_destroy(f->step_batch);
   f->value->grads = nullptr; f->mu->grads = nullptr; f->lv->grads = nullptr;
+  f->ctx->n_trainers -= 1;
   f->arena.release(); delete f; return CPP_OK;
 }
 

@@ -113,7 +113,6 @@ class Batch(object):
         self._small = small                       # {"action", "reward", "terminal_mask"}: host arrays this Batch owns
         self._states = None                       # {"state_1", "state_2"} once downloaded
         self._gen = memory._write_gen if memory is not None else None
-        self._cols = {}
 
     @classmethod
     def empty(cls, state_shape, action_dim):
@@ -170,9 +169,10 @@ class Batch(object):
         if name in ("state_1", "state_2"):
             if self._states is not None:
                 return self._states[name]
-            if name not in self._cols:
-                self._cols[name] = StateColumn(self, name)
-            return self._cols[name]
+            # a fresh column per access: the column refers to its Batch, so a Batch that kept its columns would be a reference
+            # cycle -- alive until a gc pass, found by the next add_episode() in ReplayMemory._drawn and preserved (a device gather,
+            # and a 2 x 37.7 MB download for every such Batch but the last) although nobody can read it any more
+            return StateColumn(self, name)
         if name in ("action", "reward", "terminal_mask"):
             return self._small[name]
         raise AttributeError(name)

@@ -71,6 +71,23 @@ int cpp_ctx_create(int device_id, void* hip_stream, cpp_ctx** out);
 int cpp_ctx_destroy(cpp_ctx* ctx);
 int cpp_sync(cpp_ctx* ctx);
 
+/* The arithmetic contract of the conv kernels that run on the f16 / bf16 matrix pipes (conv1 forward and dW, conv2 forward and
+ * dW; everything else is f32-input MFMA or f32 VALU whatever the mode).  Accumulation is f32 and every issued product is exact
+ * in both modes; the modes differ in how much of an f32 OPERAND reaches the multiplier:
+ *   CPP_PRECISION_FAST  (default)  conv1's f32 operand (W s, dY) as two f16 pieces: the operand to within 2^-22 relative (~ one
+ *                                  f32 ulp); conv2's operands as three bf16 pieces each with the six largest of the nine piece
+ *                                  products (the dropped three: <= 2^-23 of a product).  Against the float64 oracle it is as
+ *                                  close as the f32-input MFMA kernels (tests/test_gpu_fullsize.py, tests/test_gpu_render_inputs.py).
+ *   CPP_PRECISION_EXACT            three f16 pieces / all nine products: no operand bit is dropped, the result is the
+ *                                  f32-accumulated sum of the exact products of the f32 operands (rounds 1-2; ~0.87 x the speed).
+ * The reference's TF CPU kernels multiply and accumulate in f32 (base_network.py:103-123 -> Eigen): both modes sit inside what
+ * one f32 FMA chain rounds.  Must be called before a trainer (cpp_ddpg / cpp_naf) is created on the ctx -- captured step graphs
+ * hold the kernels of the mode they were captured in -- and fails with CPP_ERR_ARG afterwards. */
+#define CPP_PRECISION_FAST 0
+#define CPP_PRECISION_EXACT 1
+int cpp_ctx_set_precision(cpp_ctx* ctx, int mode);
+int cpp_ctx_get_precision(cpp_ctx* ctx, int* mode);
+
 /* HIP-event stopwatch on the ctx stream (bench.py; the reference only has util.StopWatch, util.py:22). */
 int cpp_timer_begin(cpp_ctx* ctx);
 int cpp_timer_end(cpp_ctx* ctx, float* elapsed_ms);

@@ -209,7 +209,7 @@ F32_GRAD_FACTOR = 1.5
 
 def fused_step_against_f64_oracle(shape, B, rows, replay_store="f16", replay_size=None, seed=0, graph=True,
                                   atol=1e-5, grad_rel=2e-5, param_rel=2e-6, warm="philox", report_only=False,
-                                  fill="noise", f32_twin=False):
+                                  fill="noise", f32_twin=False, flip_tol=1e-5):
     """ONE minibatch of the fused inner step (cpp_ddpg_train_step, default kernels: f16-pipe conv1 reading the replay store
     through the sampled slots, bf16-pipe conv2, fused heads, paired launches) -- with graph=True the hipGraph REPLAY of it,
     on rows drawn by the device's Philox sampler -- against oracle.DDPG(float64) on the same rows and the same starting
@@ -270,7 +270,7 @@ def fused_step_against_f64_oracle(shape, B, rows, replay_store="f16", replay_siz
                           ("relu_flips_actor", relu_flips_are_at_the_boundary, (ag["cache_actor"], relu_a)),
                           ("relu_flips_critic", relu_flips_are_at_the_boundary, (cg["cache_critic"], relu_c))):
         try:
-            report[key] = fn(*args, what=key.split("_")[-1])
+            report[key] = fn(*args, flip_tol, what=key.split("_")[-1])
         except AssertionError as e:
             if not report_only:
                 raise

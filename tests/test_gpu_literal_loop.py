@@ -182,3 +182,49 @@ def test_naf_reference_loop_verbatim_trains_on_the_device_rows():
     finally:
         for ag in agents:
             ag.close()
+
+
+def test_finished_batches_of_the_literal_loop_cost_the_next_add_episode_nothing():
+    """a Batch that cached its StateColumns was a reference cycle -- after the loop body's `batch` name was rebound the old
+    draw stayed alive until a gc pass, add_episode() found it in ReplayMemory._drawn and PRESERVED it (a device gather each, and a
+    2 x state-column download for all but the last).  With the cycle gone, reference counting frees a finished draw at once: the
+    reference's loop followed by add_episode() -- no gc pass in between -- makes no gather and no download."""
+    import gc
+    from cartpoleplusplus_amd import _lib
+    shape, B = (32, 32, 3, 2, 3), 32
+    lit, other = _twin_agents(shape, B, True, rows=200)
+    other.close()
+    calls = collections.Counter()
+    real = {name: getattr(_lib.lib, name) for name in ("cpp_batch_download", "cpp_replay_sample")}
+
+    def counting(name):
+        def f(*args):
+            calls[name] += 1
+            return real[name](*args)
+        return f
+    gc.collect()
+    gc.disable()
+    try:
+        for _ in range(5):                                    # ddpg_cartpole.py:331-334
+            batch = lit.replay_memory.batch(B)
+            lit.actor.train(batch.state_1)
+            lit.critic.train(batch)
+        del batch
+        assert len(lit.replay_memory._drawn) == 0, "finished draws are still alive without a gc pass"
+        for name in real:
+            setattr(_lib.lib, name, counting(name))
+        rng = np.random.default_rng(0)
+        frames = [(rng.integers(0, 256, shape).astype(np.float16) / np.float16(255)) for _ in range(4)]
+        lit.replay_memory.add_episode(frames[0], [(np.zeros((1, 2), np.float32), 1.0, f) for f in frames[1:]])
+        assert not calls, dict(calls)
+        # ... while a draw somebody still holds IS preserved (one gather, no download) and stays readable
+        held = lit.replay_memory.batch(B)
+        want = lit.replay_memory.state[held.state_1_idx]
+        lit.replay_memory.add_episode(frames[0], [(np.zeros((1, 2), np.float32), 1.0, f) for f in frames[1:]])
+        assert calls["cpp_replay_sample"] == 1 and calls["cpp_batch_download"] == 0, dict(calls)
+        assert np.array_equal(np.asarray(held.state_1), want)
+    finally:
+        gc.enable()
+        for name, fn in real.items():
+            setattr(_lib.lib, name, fn)
+        lit.close()
