@@ -22,7 +22,7 @@ Prints ONE JSON line (rank 0).  Besides the contract keys it carries
                    stand-in for the reference's TF-CPU kernels) -- and `cpu_baseline_numpy`, the numpy oracle
   control        : the same step with conv1 / conv2 forced onto the f32-input MFMA kernels (ablation build of the library,
                    CPP_CONV_K16=0 CPP_CONV_B16=0): the f32 twin of the f16x2 / bf16x6 numbers
-  control_exact_products : the same step from libcartpolepp_hip_exact.so (three f16 pieces, nine bf16 products: every product exact)
+  control_exact_products : the same step with --precision exact (three f16 pieces, nine bf16 products: every product exact)
   extra          : short runs of the other BASELINE configs (cfg2, cfg4 = NAF, cfg5), steps/s each
 (N = 1, rank 0 only for the last three; --quick skips them.)
 """
@@ -55,9 +55,9 @@ PEAK_F16_MFMA_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense f16 / bf16
 CONV_DEFS = ((5, 10), (5, 10), (3, 10))
 # matrix pipe of a profiled kernel name -> (peak TFLOP/s for ALGORITHMIC flops, description)
 SUSTAINED_F16_MFMA_TFLOPS_RANDOM_OPERANDS = 2000      # measured 1914-2056 on two boxes: profiles/r02_mfma_rate_probe.txt (informational, see roofline["sustained"])
-# the library this process loads: the release build multiplies two f16 pieces of conv1's f32 operand and six bf16 piece products in
-# conv2; libcartpolepp_hip_exact.so (CARTPOLEPP_ABLATION=exact) three and nine -- every product exact (conv_k16.h)
-EXACT_PRODUCTS = os.environ.get("CARTPOLEPP_ABLATION", "") == "exact"
+# --precision: the release library multiplies two f16 pieces of conv1's f32 operand and six bf16 piece products in conv2 ("fast", the
+# default) or three and nine -- every product exact ("exact"; cpp_ctx_set_precision, conv_k16.h)
+EXACT_PRODUCTS = "exact" in [a.split("=")[-1] for i, a in enumerate(sys.argv) if a.startswith("--precision=") or (i and sys.argv[i - 1] == "--precision")]
 F16_PIPE, B16_PIPE = ("f16x3", "bf16x9") if EXACT_PRODUCTS else ("f16x2", "bf16x6")
 PIPES = {
     "f16x2": (PEAK_F16_MFMA_TFLOPS / 2.0, "f16 MFMA, 2 f16 x f16 piece products per f32 product (2500 / 2)"),
@@ -186,6 +186,9 @@ def main():
     ap.add_argument("--quick", action="store_true", help="headline + roofline only: no cpu baseline, control or extra runs")
     ap.add_argument("--profile-steps", type=int, default=10, help="minibatches of the per-kernel HIP-event pass")
     ap.add_argument("--use-batch-norm", action="store_true", help="informational: the networks of exps/run_8x / run_9x (--use-batch-norm)")
+    ap.add_argument("--precision", default="fast", choices=["fast", "exact"],
+                    help="arithmetic contract of conv1 / conv2 on the f16 / bf16 pipes (cpp_ctx_set_precision): operands to within one f32 ulp "
+                         "(two f16 pieces, six bf16 products) or every operand bit (three, nine)")
     ap.add_argument("--replay-store", default="f16", choices=["f16", "u8"],
                     help="informational: u8 = the 8-bit replay store (same batches, half the gather reads)")
     ap.add_argument("--diag-states", default="random", choices=["random", "blocks", "flat"],
@@ -244,7 +247,8 @@ def main():
 
     common = dict(use_raw_pixels=True, render_height=shape[0], render_width=shape[1], num_cameras=shape[3],
                   action_repeats=shape[4], batch_size=B, replay_memory_size=replay_rows,
-                  use_batch_norm=bool(args.use_batch_norm), replay_store=args.replay_store)
+                  use_batch_norm=bool(args.use_batch_norm), replay_store=args.replay_store,
+                  exact_products=(args.precision == "exact"))
     if kind == "ddpg":
         from cartpoleplusplus_amd import ddpg_cartpole as D
         D.set_opts(D.default_opts(sample_seed=1234 + rank, **common))
@@ -437,11 +441,11 @@ def main():
         "metric": "%s training steps/sec, %dx%dx%d pixel obs, batch=%d" % ("DDPG" if kind == "ddpg" else "NAF", shape[0], shape[1], ch, B),
         "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": wgroups * BATCHES_PER_STEP,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32-acc/f16x3,bf16x9" if EXACT_PRODUCTS else "f32-acc/f16x2,bf16x6", "data": "synthetic",
         "timed_region_ms": round(1e3 * elapsed, 2), "warmup_steps_run": warmup_steps_run,
         "dtype_note": ("f32 accumulation everywhere; conv1 multiplies exact f16 operands (the replay store's pixels x three-piece f16 splits "
                        "of the f32 weights / gradients), conv2 forward / dW three-piece bf16 splits of both f32 operands with all nine "
-                       "products: every product exact (libcartpolepp_hip_exact.so)" if EXACT_PRODUCTS else
+                       "products: every product exact (--precision exact)" if EXACT_PRODUCTS else
                        "f32 accumulation everywhere; conv1 multiplies the replay store's f16 pixels (exact) by a two-piece f16 split of the "
                        "f32 weight / gradient (within one f32 ulp of it), conv2 forward / dW three-piece bf16 splits of both f32 operands with "
                        "the six largest piece products (the dropped three are at most half an f32 ulp of the product): measured as close to "
@@ -487,10 +491,10 @@ def main():
                           "layers": [{k: r[k] for k in ("layer", "avg_launch_us", "pipe", "frac")} for r in c.get("layers", [])],
                           "error": c.get("error")}
         # the exact-product twin: three f16 pieces / nine bf16 products (what rounds 1-2 shipped)
-        c = sub_bench(["--steps", "100", "--warmup", "10", "--workload", args.workload], env={"CARTPOLEPP_ABLATION": "exact"})
+        c = sub_bench(["--steps", "100", "--warmup", "10", "--workload", args.workload, "--precision", "exact"])
         out["control_exact_products"] = {
-            "what": "same step from libcartpolepp_hip_exact.so: three f16 pieces of conv1's f32 operand, all nine bf16 piece products in conv2 "
-                    "(every product exact)", "switches": "CARTPOLEPP_ABLATION=exact",
+            "what": "same step, same library, cpp_ctx_set_precision(CPP_PRECISION_EXACT): three f16 pieces of conv1's f32 operand, all nine bf16 "
+                    "piece products in conv2 (every product exact)", "switches": "bench.py --precision exact",
             "value": c.get("value"), "unit": "steps/s", "ms_per_step": c.get("ms_per_step"),
             "layers": [{k: r[k] for k in ("layer", "avg_launch_us", "pipe", "frac")} for r in c.get("layers", [])], "error": c.get("error")}
         extra = {}

@@ -12,8 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # The release library reads no environment variable and is the only one loaded by default.  CARTPOLEPP_ABLATION=1 selects the
 # ablation build of the SAME sources (lib/libcartpolepp_hip_ablation.so: the CPP_* kernel-selection switches compiled in; parity
-# tests of the fallback kernels, bench.py's f32 control run); CARTPOLEPP_ABLATION=exact the exact-products build (three f16 pieces / nine
-# bf16 products: lib/libcartpolepp_hip_exact.so, csrc/Makefile); CARTPOLEPP_ABLATION=<name> an in-tree experiment build
+# tests of the fallback kernels, bench.py's f32 control run); CARTPOLEPP_ABLATION=<name> an in-tree experiment build
 # lib/libcartpolepp_hip_<name>.so (profiles/).  No path can be injected: the file must sit in this package's lib/ directory.
 _variant = os.environ.get("CARTPOLEPP_ABLATION", "")
 if _variant and not _variant.replace("_", "").isalnum():
@@ -24,6 +23,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcartpolepp_hip%s.so" % (
 CPP_F32, CPP_F16, CPP_U8 = 0, 1, 2
 CPP_ACTOR, CPP_CRITIC, CPP_HEAD = 0, 1, 2
 CPP_OPT_SGD, CPP_OPT_MOMENTUM, CPP_OPT_ADAM = 0, 1, 2
+CPP_PRECISION_FAST, CPP_PRECISION_EXACT = 0, 1      # cpp_ctx_set_precision
 
 
 class NetSpec(C.Structure):
@@ -59,6 +59,8 @@ SIGNATURES = {
     "cpp_ctx_create": (_I, [_I, _P, _PP]),
     "cpp_ctx_destroy": (_I, [_P]),
     "cpp_sync": (_I, [_P]),
+    "cpp_ctx_set_precision": (_I, [_P, _I]),
+    "cpp_ctx_get_precision": (_I, [_P, C.POINTER(_I)]),
     "cpp_timer_begin": (_I, [_P]),
     "cpp_timer_end": (_I, [_P, C.POINTER(_F)]),
     "cpp_prof_enable": (_I, [_P, _I]),
@@ -195,6 +197,22 @@ class Context(object):
 
     def sync(self):
         check(lib.cpp_sync(self.handle))
+
+    def set_precision(self, mode):
+        """'fast' (default: two f16 pieces / six bf16 products) or 'exact' (three / nine: every product exact) -- the arithmetic
+        contract of the conv kernels on the f16 / bf16 matrix pipes (include/cartpolepp_abi.h, cpp_ctx_set_precision).  Before the
+        agents' trainers exist."""
+        modes = {"fast": CPP_PRECISION_FAST, "exact": CPP_PRECISION_EXACT, CPP_PRECISION_FAST: CPP_PRECISION_FAST,
+                 CPP_PRECISION_EXACT: CPP_PRECISION_EXACT}
+        if mode not in modes:
+            raise ValueError("precision %r is neither 'fast' nor 'exact'" % (mode,))
+        check(lib.cpp_ctx_set_precision(self.handle, modes[mode]))
+
+    @property
+    def precision(self):
+        m = C.c_int()
+        check(lib.cpp_ctx_get_precision(self.handle, C.byref(m)))
+        return "exact" if m.value == CPP_PRECISION_EXACT else "fast"
 
     def timer_begin(self):
         check(lib.cpp_timer_begin(self.handle))

@@ -104,6 +104,9 @@ def build_parser():
     a('--host-rng-sampling', action='store_true',
       help="draw minibatch rows with numpy's RNG on the host like the reference (default: Philox on the GPU)")
     a('--sample-seed', type=int, default=0, help="seed of the device-side minibatch sampler")
+    a('--exact-products', action='store_true',
+      help="conv1 / conv2 on the f16 / bf16 matrix pipes with EVERY operand bit (three f16 pieces, nine bf16 products) instead of "
+           "operands to within one f32 ulp (two / six): ~0.87 x the speed (cpp_ctx_set_precision)")
     a('--replay-store', type=str, default="f16", choices=["f16", "u8"],
       help="element type of the replay memory's state store: f16 as the reference, or u8 pixel codes "
            "(identical batches for rendered frames, half the memory)")
@@ -433,6 +436,7 @@ class DeepDeterministicPolicyGradientAgent(object):
         self.env = env
         state_shape = self.env.observation_space.shape
         action_dim = self.env.action_space.shape[1]
+        _lib.default_context().set_precision("exact" if getattr(opts, "exact_products", False) else "fast")
         # replay memory: f16 state store resident in HBM (ddpg_cartpole.py:257-261)
         self.replay_memory = replay_memory.ReplayMemory(opts.replay_memory_size, state_shape, action_dim,
                                                        store_dtype=opts.replay_store)

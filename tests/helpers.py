@@ -27,7 +27,10 @@ class FakeEnv(object):
 def make_pair(shape, B, pixel, seed=0, replay_size=64, perturb=True, dt=np.float64, **optkw):
     """returns (agent, oracle DDPG, specs).  Parameters are perturbed away from the near-zero actor
     head / zero biases so every path carries signal."""
+    import os
     from cartpoleplusplus_amd import ddpg_cartpole as D
+    if os.environ.get("TEST_EXACT_PRODUCTS") == "1":      # (test snippets run in subprocesses: the TEST's switch for --exact-products)
+        optkw.setdefault("exact_products", True)
     make_opts(D, shape, B, pixel, replay_memory_size=replay_size, **optkw)
     agent = D.DeepDeterministicPolicyGradientAgent(FakeEnv(shape))
     agent.initialise_variables(seed=seed)

@@ -21,7 +21,7 @@ def test_bench_quick_line_has_the_contract_keys():
     assert d["metric"] == "DDPG training steps/sec, 64x64x18 pixel obs, batch=256" and d["unit"] == "steps/s"
     assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 5 and d["warmup_steps_run"] >= 200
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
-    assert d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["dtype"] == "f32-acc/f16x2,bf16x6" and d["data"] == "synthetic"      # (f32 accumulation; operand pieces of the default precision)
     assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-3          # N = 1: value = 1 / step time
     assert d["config"]["workload"].startswith("cfg3") and "model" not in d["config"]
     assert d["config"]["conv_gflop_per_step"] == pytest.approx(68.053, abs=1e-3)

@@ -181,13 +181,13 @@ agent.close()
 """
 
 
-_F16_BUILDS = (("two", {"CARTPOLEPP_ABLATION": "1"}), ("three", {"CARTPOLEPP_ABLATION": "exact"}),
+_F16_BUILDS = (("two", {}), ("three", {"TEST_EXACT_PRODUCTS": "1"}),      # (release library: cpp_ctx_set_precision fast / exact)
                ("f32", {"CARTPOLEPP_ABLATION": "1", "CPP_CONV_K16": "0"}))
 
 
 def test_f16_piece_conv1_is_as_close_to_the_f64_oracle_as_the_f32_mfma_kernel():
     """conv_k16.h claims f32-grade results (f16 x f16 products, exact; f32 accumulation) from two f16 pieces of each weight (the
-    shipped kernels: the weight to within one f32 ulp) and from three (libcartpolepp_hip_exact.so: the weight itself): the pooled conv1
+    shipped kernels: the weight to within one f32 ulp) and from three (--exact-products / cpp_ctx_set_precision: the weight itself): the pooled conv1
     output must sit as close to the float64 oracle as the f32-MFMA kernel's (CPP_CONV_K16=0), far inside 1e-5."""
     import os, re, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -253,7 +253,7 @@ agent.close()
 
 
 def test_f16_piece_conv1_dw_is_as_close_to_the_f64_oracle_as_the_f32_mfma_kernel():
-    """conv_dw16.h: conv1's weight gradient from f16 x f16 products of the raw pixels and two (shipped) / three (exact build) f16
+    """conv_dw16.h: conv1's weight gradient from f16 x f16 products of the raw pixels and two (shipped) / three (--exact-products) f16
     pieces of dY must match the float64 oracle (with the device's pooling routes) at least as well as the f32-MFMA kernel does."""
     import os, re, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -301,7 +301,7 @@ def test_bf16_conv2_is_as_close_to_the_f64_oracle_as_the_f32_mfma_kernels():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     for name, extra in (("six", {"CARTPOLEPP_ABLATION": "1"}), ("nine", {"CARTPOLEPP_ABLATION": "1", "CPP_B16_PRODUCTS": "9"}),
-                        ("f32", {"CARTPOLEPP_ABLATION": "1", "CPP_CONV_B16": "0"}), ("exact", {"CARTPOLEPP_ABLATION": "exact"})):
+                        ("f32", {"CARTPOLEPP_ABLATION": "1", "CPP_CONV_B16": "0"}), ("exact", {"TEST_EXACT_PRODUCTS": "1"})):
         r = subprocess.run([sys.executable, "-c", _CONV2_ERR_SNIPPET], cwd=root, env=dict(os.environ, **extra),
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
         out = r.stdout.decode()
