@@ -135,13 +135,16 @@ struct K16Geom {
   static constexpr int PS = PADDED ? 1120 : 4 * NO * 16, GS = PADDED ? 256 : NO * 16, SLAB = PADDED ? 5632 : KS * 4 * NO * 16;
 #endif
   static constexpr int WLB = NCH * NPC * SLAB;             // bytes
-  static constexpr int EF = 2 * 8 * XT * NO * 2;           // floats per wave: (value, code) of the two rows of a pool pair
+  static constexpr int EF = 2 * 2 * 8 * XT * NO * 2;       // floats per wave: (value, code) of the two rows of a pool pair, two pairs (the writer of pair r runs under the rows of pair r + 1)
   // conv2's instance for 32x32 inputs can run conv3 as its tail: the two pooled 16x16 images of the workgroup, zero-haloed
   static constexpr int N3 = (B16 && XT == 1 && IPW == 2) ? C3_IPW * C3_IMGF * 4 + 16 : 0;
   // f16 mode: the border table E [2 P + 1 row classes][NO][x = 0, 1, W - 2, W - 1] (floats, in accumulator units) and the pivots [CIN] (halves)
   static constexpr int NRC = 2 * P + 1;
   static constexpr int CT_BYTES = B16 ? 0 : NRC * NO * 16 + ((CIN * 2 + 15) & ~15);
-  static constexpr int LDS_BYTES = WLB + 4 * EF * 4 + 64 + N3 + CT_BYTES;
+#ifndef K16_LDS_PAD
+#define K16_LDS_PAD 0      // (occupancy experiments: bytes of LDS nobody uses)
+#endif
+  static constexpr int LDS_BYTES = WLB + 4 * EF * 4 + 64 + N3 + CT_BYTES + (B16 ? 0 : K16_LDS_PAD);
   static constexpr int BIAS_BYTES = 128;                   // the buffer descriptor starts this far before the image
   // element e of lane group g in chunk ch is slot kl = 8 g + e of the chunk: real k = RK ch + kl if kl < RK (and k < KROW)
   // can dword v of chunk ch in M tile m (of any strip, any lane) ever hold an element that must be cleared or replaced?  The
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   const ConvArgs& a = batch.a[blockIdx.y];
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   unsigned char* wl = lds_raw;                                    // weight image
-  float2* ebuf = reinterpret_cast<float2*>(lds_raw + G::WLB);     // [4 waves][2 parities][8*XT][NO]
+  float2* ebuf = reinterpret_cast<float2*>(lds_raw + G::WLB);     // [4 waves][2 pairs][2 parities][8*XT][NO]
   float* red = reinterpret_cast<float*>(lds_raw + G::WLB + 4 * G::EF * 4);
   float* img3 = reinterpret_cast<float*>(lds_raw + G::WLB + 4 * G::EF * 4 + 64);      // (G::N3 > 0 only)
   const bool fuse3 = G::N3 > 0 && a.n3_w != nullptr;                                  // uniform; the launcher checked the geometry
@@ -208,6 +211,13 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     braw[t] = (!PLAIN && j < KS * NO && j % NO < nout) ? a.bias[j % NO] : 0.f;
   }
   // ---- one-time setup: the split weight image
+#ifdef K16_SETUP_PROBE
+  unsigned long long sp[6] = {0, 0, 0, 0, 0, 0};
+#define K16_STAMP(i) sp[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define K16_STAMP(i)
+#endif
+  K16_STAMP(0);
   float sc, inv;                                      // 2^S, 2^-S
   int onesT = 0;                                      // f16 mode: the ones slots' A value is 2^T
   float* ctab = reinterpret_cast<float*>(lds_raw + G::WLB + 4 * G::EF * 4 + 64 + G::N3);      // [NRC][NO][4] (f16 mode)
@@ -250,6 +260,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #ifdef K16_CLOCK_PROBE
     if (tid == 0 && (blockIdx.x % 97) == 5 && blockIdx.y == 1) printf("K16PRE loads+max %llu, to sync %llu\n", pq0 - pe0, __builtin_amdgcn_s_memrealtime() - pe0);
 #endif
+    K16_STAMP(1);
     vmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     int S = 0;
     if (!B16 && vmax > 0.f && vmax < 3.0e38f) S = 14 - ilogbf(vmax);       // vmax 2^S in [2^14, 2^15); bf16 pieces need no scale
@@ -282,6 +293,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     if (!B16) {
       // ---- the ones slots and the border table, in f64 from the pieces just written (V' = (h + m (+ l)) 2^-S, exactly)
       __syncthreads();
+      K16_STAMP(2);
       auto vprime = [&](int ky, int k, int o) -> double {      // V'_k 2^S
         const int ch = k / G::RK, kl = k - ch * G::RK;
         const unsigned char* src = wl + ky * G::PS + (kl >> 3) * G::GS + o * 16 + (kl & 7) * 2;
@@ -316,6 +328,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
       for (int o = 32; o > 0; o >>= 1) omax = fmax(omax, __shfl_xor(omax, o));
       if (lane == 0) red[4 + wave] = (float)omax;      // (an upper bound is all that is needed: rounded up below)
       __syncthreads();
+      K16_STAMP(3);
       const float om = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])) * 1.0001f;
       onesT = (om > 0.f && om < 3.0e38f) ? ilogbf(om) - 14 : 0;      // |ones weight| 2^-T < 2^15
       onesT = onesT < 0 ? 0 : (onesT > 15 ? 15 : onesT);      // (T > 15: |mu| > 2^10 -- not an image; the pieces saturate to inf and the output says so)
@@ -350,7 +363,13 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
       }
     }
   }
+  K16_STAMP(4);
   __syncthreads();                                   // weight image visible; no barrier after this one
+  K16_STAMP(5);
+#ifdef K16_SETUP_PROBE
+  if (tid == 0 && (blockIdx.x % 37) == 5 && !B16)
+    printf("K16SETUP cin %d: loads+vmax %llu, split %llu, sums %llu, slots+table %llu, sync %llu (10 ns ticks)\n", CIN, sp[1] - sp[0], sp[2] - sp[1], sp[3] - sp[2], sp[4] - sp[3], sp[5] - sp[4]);
+#endif
 #ifdef K16_CLOCK_PROBE
   const unsigned long long pe1 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -364,7 +383,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   uint32_t wadr[KS][NT];
   uint32_t eadr[NT];
   float biast[NT];
-  float2* ev = ebuf + swave * (2 * 8 * XT * NO);
+  float2* ev = ebuf + swave * (2 * 2 * 8 * XT * NO);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int j = 16 * t + li;
@@ -447,17 +466,22 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     coe[i] = cact[i] ? (unsigned)(px * nout + o) : 0x3FFFFFFCu;      // inactive lanes: beyond every descriptor's range (x 1, 2, 4)
     c3adr[i] = lds_addr(cact[i] ? img3 + simg * C3_IMGF + (C3_PW + px + 1) * C3_C + o : img3 + C3_IPW * C3_IMGF);   // (junk pair behind the images)
   }
-  constexpr int ST = NC * 5;                          // vector-memory stores of one writer pass (all issued; see k16_issue_b128)
+  constexpr int SH = 5;                               // vector-memory stores of one writer HALF (all issued, every row; see k16_issue_b128)
+#ifdef K16_ABL_NOSTORE      // (timing experiment: every pooled-row store is issued and dropped)
+#define K16_RANGE(x) 0
+#else
+#define K16_RANGE(x) (x)
+#endif
   const __amdgpu_buffer_rsrc_t b16_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       a.out_b16 ? a.out_b16 + (long)sbimg * (Hp * Wp * nout) : (unsigned short*)a.out, 0,
-      a.out_b16 ? (int)(2 * a.out_b16_plane * 2 + (long)Hp * Wp * nout * 2) : 0, 0x00020000);      // this image in the three planes, no further
+      K16_RANGE(a.out_b16 ? (int)(2 * a.out_b16_plane * 2 + (long)Hp * Wp * nout * 2) : 0), 0x00020000);      // this image in the three planes, no further
   const int b16_plane_bytes = (int)(a.out_b16_plane * 2);
   // (a null output -- the target networks' f32 pool1 and codes in the fused step -- gets an empty range: its stores are issued
   // and dropped, so the number of vector-memory instructions per writer pass does not depend on the network)
   const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      a.out ? a.out + (long)sbimg * a.out_bstride : (float*)a.out_b16, 0, a.out ? (PLAIN ? H * W : Hp * Wp) * nout * 4 : 0, 0x00020000);
+      a.out ? a.out + (long)sbimg * a.out_bstride : (float*)a.out_b16, 0, K16_RANGE(a.out ? (PLAIN ? H * W : Hp * Wp) * nout * 4 : 0), 0x00020000);
   const __amdgpu_buffer_rsrc_t amax_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      a.out_amax ? a.out_amax + (long)sbimg * Hp * Wp * nout : (uint8_t*)a.out_b16, 0, a.out_amax ? Hp * Wp * nout : 0, 0x00020000);
+      a.out_amax ? a.out_amax + (long)sbimg * Hp * Wp * nout : (uint8_t*)a.out_b16, 0, K16_RANGE(a.out_amax ? Hp * Wp * nout : 0), 0x00020000);
 
   // ---- A operands: 16 bytes per lane and (tile, chunk) straight from the image row
   const int rowbytes = W * CIN * 2;
@@ -510,10 +534,69 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) load_a(ch, qbeg);
   const __amdgpu_buffer_rsrc_t null_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0, 0x00020000);      // empty range: stores are dropped
-  if (ASYNC_A) {                                      // row 0 sees the same sequence as every other row: its loads, then ST stores
+  const bool wr_f32 = PLAIN || a.out != nullptr, wr_code = a.out_amax != nullptr;     // target networks of the fused step: bf16 planes only
+  // ---- the pooled-row writer, one HALF per row (round 4).  Pair r of output rows is complete at the end of step 2 r + 1; its pooled
+  // row is written under the MFMAs of the next two rows: lane set i = 0 (64 of the 8 XT NO / 2 channel pairs) right behind chunk 0's
+  // MFMAs of step 2 r + 2, set i = 1 (the rest) behind chunk 0's of step 2 r + 3 -- in the shadow of 16 MFMAs the wave has just
+  // issued, instead of as a phase between two rows in which the wave issues none (26 us of the 107 us launch; -DK16_ABL_NOEPI),
+  // and every row issues exactly SH stores: no dummy stores to keep the hand-counted waits static (7.5 us; -DK16_ABL_NODUMMY).
+  // The (value, code) pairs of a pair of rows therefore live for two more rows: two buffer sets, alternating.
+  // half: 0 / 1 = the parity of the output row this step completes; pr: the pooled row (< 0: none -- the stores go to an
+  // out-of-range offset and are dropped, the instruction count stays).
+  f32x4 wtop = {0.f, 0.f, 0.f, 0.f}, wbot = {0.f, 0.f, 0.f, 0.f};      // the half's (value, code) x 2 of the pair's two rows, requested at the top of the step
+  auto writer_load = [&](const int half, const int pr) {
+    if (PLAIN || half >= NC) return;
+    const int i = half < NC ? half : 0;
+    const int prs = (pr >= 0 && pr < Hp) ? pr : 0;
+    const uint32_t ca = cadr[i] + (uint32_t)((prs & 1) * (2 * 8 * XT * NO) * 8);
+    wtop = lds_load<f32x4>(ca, 0); wbot = lds_load<f32x4>(ca, (8 * XT * NO) * 8);
+  };
+  auto writer_half = [&](const int half, const int pr) {
+    if (PLAIN) return;
+    const bool live = pr >= 0 && pr < Hp;           // uniform
+    if (half >= NC) {                               // (one lane set per pooled row: the other row's stores are dummies)
+      if (ASYNC_A) {
 #pragma unroll
-    for (int i = 0; i < ST; ++i) __builtin_amdgcn_raw_buffer_store_b32(0u, null_rsrc, 64 * i, 0, 0);   // (distinct, non-adjacent addresses: identical or adjacent stores would be merged)
-  }
+        for (int i = 0; i < SH; ++i) __builtin_amdgcn_raw_buffer_store_b32(0u, null_rsrc, 64 * i, 0, 0);   // (distinct, non-adjacent addresses: identical or adjacent stores would be merged)
+      }
+      return;
+    }
+    if (!ASYNC_A && !live) return;
+    const int i = half < NC ? half : 0;
+    if (ASYNC_A || cact[i]) {
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const int prs = live ? pr : 0;
+      const f32x4 top = wtop, bot = wbot;            // (writer_load)
+      const unsigned co = live ? coe[i] : 0x3FFFFFFCu;
+      const int orow = prs * Wp * nout;
+      float pv[2]; int code[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const bool lower = bot[2 * e] > top[2 * e];
+        const float mx = lower ? bot[2 * e] : top[2 * e];
+        code[e] = lower ? 2 + __float_as_int(bot[2 * e + 1]) : __float_as_int(top[2 * e + 1]);
+        pv[e] = mx > 0.f ? mx * inv : 0.f;
+      }
+      if (fuse3 && live) lds_store(c3adr[i], prs * (C3_PW * C3_C * 4), (f32x2){pv[0], pv[1]});      // conv3's input row, in LDS
+      if (ASYNC_A || wr_f32) __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(pv[0]), __float_as_uint(pv[1])}, out_rsrc, (int)(co * 4), orow * 4, 0);
+      if (ASYNC_A || a.out_b16) {              // the next layer's A operand: three bf16 planes of the same tensor
+        // truncating split (cheaper than round-to-nearest in this MFMA-issue-bound loop, equally exact: the pieces are
+        // the value's three consecutive byte-groups of significand, x = h + m + l)
+        unsigned hb[2], mb[2], lb[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          hb[e] = __float_as_uint(pv[e]) & 0xFFFF0000u;
+          const float r1 = pv[e] - __uint_as_float(hb[e]);
+          mb[e] = __float_as_uint(r1) & 0xFFFF0000u;
+          lb[e] = __float_as_uint(r1 - __uint_as_float(mb[e]));
+        }
+        __builtin_amdgcn_raw_buffer_store_b32((hb[0] >> 16) | hb[1], b16_rsrc, (int)(co * 2), orow * 2, 0);
+        __builtin_amdgcn_raw_buffer_store_b32((mb[0] >> 16) | mb[1], b16_rsrc, (int)(co * 2), b16_plane_bytes + orow * 2, 0);
+        __builtin_amdgcn_raw_buffer_store_b32((lb[0] >> 16) | (lb[1] & 0xFFFF0000u), b16_rsrc, (int)(co * 2), 2 * b16_plane_bytes + orow * 2, 0);
+      }
+      if (ASYNC_A || wr_code) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(code[0] | (code[1] << 8)), amax_rsrc, (int)co, orow, 0);
+    }
+  };
 
   // B operands of ONE k chunk.  The pieces are consumed small-to-large (pc = NPC-1 .. 0); as soon as the MFMAs of a piece are
   // issued its registers are reloaded with the same piece of the NEXT chunk (the next row's first chunk after the last one), so
@@ -523,6 +606,9 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   auto load_b_piece = [&](int ch, int pc, const uint32_t* wa) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+#ifdef K16_ABL_HALFB      // (timing experiment: only piece 0 is read from LDS, the other pieces' MFMAs reuse its registers -- wrong results)
+      if (pc > 0) { bv[t][pc] = bv[t][0]; continue; }
+#endif
 #ifdef K16_ABL_NOLDSB
       bv[t][pc] = __builtin_bit_cast(f16x8, (k16_u32x4){emask[NCH - 1][0][1], ecst[NCH - 1][0][1], emask[NCH - 1][0][2], wa[t]});
 #else
@@ -536,7 +622,6 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #if defined(K16_CLOCK_PROBE) || defined(K16_SPAN_PROBE)
   const unsigned long long pc0 = __builtin_readcyclecounter(), pr0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  const bool wr_f32 = PLAIN || a.out != nullptr, wr_code = a.out_amax != nullptr;     // target networks of the fused step: bf16 planes only
   for (int q0 = qbeg; q0 < qend; q0 += KS) {
 #if K16_ROTATE_PRIO
     {  // issue arbitration is by priority, then age: the workgroups of the networks launched first ran ahead of their co-resident
@@ -563,6 +648,11 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
           if (chi >= 0 && clo <= 15) ctv[t] = lds_load<f32x4>(ctadr[t] + (uint32_t)(rc * NO * 16), 0);
         }
       }
+      const int wy = q - P >= ymin ? q - P : -1;     // the output row this step completes (rows in front of the band: none)
+      const int wlo = ymin >> 1;                     // first pooled row of the band
+      const int wpr = (wy >= 0 && (wy >> 1) - 1 >= wlo) ? (wy >> 1) - 1 : -1;
+      writer_load(wy & 1, wpr);                      // (its LDS reads land under chunk 0's MFMAs)
+      if (q >= H) writer_half(wy & 1, wpr);          // (the steps behind the image: no MFMAs to hide under)
       if (q < H) {
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
@@ -570,9 +660,10 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
           __builtin_amdgcn_s_setprio(K16_PRIO);
 #endif
           if (ASYNC_A) {
-            // this chunk's operands were requested one row ago; issued since: the other chunks' loads and the ST stores every row
-            // ends with (the writer's, or as many dropped ones: ONE wait count, no second code path around the wait)
-            k16_wait_vm<(NCH - 1) * LPC + ST>(av[0][ch][0]);
+            // this chunk's operands were requested one row ago; issued since: the other chunks' loads and -- between chunk 0's
+            // MFMAs and its loads -- the SH stores of the writer half every row carries (real or dropped: ONE wait count per chunk)
+            if (ch == 0) k16_wait_vm<(NCH - 1) * LPC>(av[0][ch][0]);
+            else k16_wait_vm<(NCH - 1) * LPC + SH>(av[0][ch][0]);
 #pragma unroll
             for (int pa = 0; pa < NPA; ++pa)
 #pragma unroll
@@ -596,7 +687,9 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
             }
 #pragma unroll
             for (int v = 0; v < 4; ++v)
+#ifndef K16_ABL_NOMASK
               if (G::vgpr_may_need_mask(ch, m, v)) u[v] = (u[v] & emask[ch][m][v]) | ecst[ch][m][v];
+#endif
             af[pa][m] = u;
           }
 #pragma unroll
@@ -623,6 +716,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #ifdef K16_PRIO
           __builtin_amdgcn_s_setprio(0);
 #endif
+          if (ch == 0) writer_half(wy & 1, wpr);
           if (ASYNC_A || q + 1 < H) load_a(ch, q + 1);   // this chunk's operands of the next row, a whole row period ahead (ASYNC_A:
                                                          // also behind the last row -- masked by the descriptor, never used -- so
                                                          // that the hand-counted waits see the same sequence in every row)
@@ -660,7 +754,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
                                                             (int)eadr[t] + ((m * 16 + r) * NO) * 4, y * W * nout * 4, 0);
                 }
               } else if (y >= 0) {
-                const uint32_t ea = eadr[t] + (uint32_t)(par * (8 * XT * NO) * 8);
+                const uint32_t ea = eadr[t] + (uint32_t)((((y >> 1) & 1) * 2 + par) * (8 * XT * NO) * 8);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                   const float z0 = zc[2 * h], z1 = zc[2 * h + 1];
@@ -672,51 +766,19 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
           }
         }
       }
-      const bool writer_row = !PLAIN && y >= 0 && par == 1 && (y >> 1) < Hp;
-      if (ASYNC_A && !writer_row && q < H) {
+      // (a wave's LDS instructions execute in order: the writer half of a later step reads what this step's lanes stored without a
+      // wait in between; the compiler must only keep the order)
+      if (!PLAIN && y >= 0) { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+    }
+  }
+  {  // the last pair(s): the two steps behind the loop would have carried their writer halves
+    const int ylast = qend - 1 - P;                  // last output row of this workgroup's band
 #pragma unroll
-        for (int i = 0; i < ST; ++i) __builtin_amdgcn_raw_buffer_store_b32(0u, null_rsrc, 64 * i, 0, 0);   // (distinct, non-adjacent addresses: identical or adjacent stores would be merged)
-      }
-      if (writer_row) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int orow = (y >> 1) * Wp * nout;
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-          if (ASYNC_A || cact[i]) {
-            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            const f32x4 top = lds_load<f32x4>(cadr[i], 0), bot = lds_load<f32x4>(cadr[i], (8 * XT * NO) * 8);   // (value, code) x 2
-            float pv[2]; int code[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-              const bool lower = bot[2 * e] > top[2 * e];
-              const float mx = lower ? bot[2 * e] : top[2 * e];
-              code[e] = lower ? 2 + __float_as_int(bot[2 * e + 1]) : __float_as_int(top[2 * e + 1]);
-              pv[e] = mx > 0.f ? mx * inv : 0.f;
-            }
-            if (fuse3) lds_store(c3adr[i], (y >> 1) * (C3_PW * C3_C * 4), (f32x2){pv[0], pv[1]});      // conv3's input row, in LDS
-            if (ASYNC_A || wr_f32) __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(pv[0]), __float_as_uint(pv[1])}, out_rsrc, (int)(coe[i] * 4), orow * 4, 0);
-            if (ASYNC_A || a.out_b16) {              // the next layer's A operand: three bf16 planes of the same tensor
-              // truncating split (cheaper than round-to-nearest in this MFMA-issue-bound loop, equally exact: the pieces are
-              // the value's three consecutive byte-groups of significand, x = h + m + l)
-              unsigned hb[2], mb[2], lb[2];
-#pragma unroll
-              for (int e = 0; e < 2; ++e) {
-                hb[e] = __float_as_uint(pv[e]) & 0xFFFF0000u;
-                const float r1 = pv[e] - __uint_as_float(hb[e]);
-                mb[e] = __float_as_uint(r1) & 0xFFFF0000u;
-                lb[e] = __float_as_uint(r1 - __uint_as_float(mb[e]));
-              }
-              __builtin_amdgcn_raw_buffer_store_b32((hb[0] >> 16) | hb[1], b16_rsrc, (int)(coe[i] * 2), orow * 2, 0);
-              __builtin_amdgcn_raw_buffer_store_b32((mb[0] >> 16) | mb[1], b16_rsrc, (int)(coe[i] * 2), b16_plane_bytes + orow * 2, 0);
-              __builtin_amdgcn_raw_buffer_store_b32((lb[0] >> 16) | (lb[1] & 0xFFFF0000u), b16_rsrc, (int)(coe[i] * 2), 2 * b16_plane_bytes + orow * 2, 0);
-            }
-            if (ASYNC_A || wr_code) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(code[0] | (code[1] << 8)), amax_rsrc, (int)coe[i], orow, 0);
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
+    for (int k = 1; k <= 2; ++k) {
+      const int wy = ylast + k, pr = (wy >> 1) - 1;
+      // (half 0 of pair pr ran at step wy = 2 pr + 2, half 1 at 2 pr + 3: what has not run yet is wy > ylast; a pair exists if its second row does)
+      const int prl = (pr >= (ymin >> 1) && 2 * pr + 1 <= ylast) ? pr : -1;
+      if (ASYNC_A || prl >= 0) { writer_load(wy & 1, prl); writer_half(wy & 1, prl); }
     }
   }
   if (ASYNC_A) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the look-ahead loads behind the last row)
