@@ -223,33 +223,60 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   float* ctab = reinterpret_cast<float*>(lds_raw + G::WLB + 4 * G::EF * 4 + 64 + G::N3);      // [NRC][NO][4] (f16 mode)
   unsigned short* pivot = reinterpret_cast<unsigned short*>(ctab + G::NRC * NO * 4);            // [CIN] f16 bits
   {
-    constexpr int NV = KS * NCH * 32 * NO;            // (ky, slot of the image = 32 ch + kl, o), o fastest
-    constexpr int NW = (NV + CONV_THREADS - 1) / CONV_THREADS;
-    float wv[NW];
+    // A thread owns UNITS: the 8 consecutive slots kl = 8 g + e of one (ky, chunk, lane group g, o) -- the 16 bytes one lane's
+    // ds_read_b128 fetches.  It loads their weights, splits them, stores each piece with ONE 16-byte LDS write, and (f16 mode) keeps
+    // the pieces' exact sum V' in registers for its share of the chunk's ones sum and of the border sums: nothing is read back.
+    // (Round 4's first version wrote 2-byte pieces and re-read them in a serial f64 loop per sum: 12.9 us of setup per workgroup,
+    // 2.7 us of it the split and 4.5 us the sums -- -DK16_SETUP_PROBE.)
+    constexpr int NU = KS * NCH * 4 * NO;             // units, o fastest, then g, chunk, ky
+    constexpr int NUW = (NU + CONV_THREADS - 1) / CONV_THREADS;
+    float wv[NUW][8];
     float vmax = 0.f;
+    // scratch in the pool-pair buffers (not in use yet): mu_c [CIN], the units' ones partials [NU] (f64) and border partials [NU][2]
+    constexpr int NB = 7 / CIN + 2;                   // taps kx a unit's 8 consecutive k values can touch (2 from 8 channels up)
+    double* mu = reinterpret_cast<double*>(ebuf);
+    double* opart = mu + ((CIN + 1) & ~1);
+    float* bpart = reinterpret_cast<float*>(opart + (B16 ? 0 : NU));      // [NU][NB]
+    float* scl = bpart + (B16 ? 0 : NU * NB);         // [CIN] whitening scale, [CIN] p_c - mu_c
+    float* dmu = scl + CIN;
+    static_assert(B16 || (((CIN + 1) & ~1) + NU) * 8 + (NU * NB + 2 * CIN) * 4 <= 4 * G::EF * 4, "the setup's scratch fits the pool-pair buffers");
     // branch-free: every load of the build is in flight before the first use
-    double* mu = reinterpret_cast<double*>(ebuf);     // scratch in the pool-pair buffers (not in use yet): mu_c [CIN], then
-    double* osum = mu + ((CIN + 1) & ~1);             // the ones sums [KS][NCH][NO] and the border sums e [KS][4][NO]
-    double* esum = osum + KS * NCH * NO;
 #pragma unroll
-    for (int n = 0; n < NW; ++n) {
-      const int i = tid + n * CONV_THREADS;
-      const int o = i % NO, r = i / NO;
-      const int ks = r % (NCH * 32), ky = r / (NCH * 32);
-      const int k = G::RK * (ks >> 5) + (ks & 31);
-      const bool real = i < NV && o < nout && (ks & 31) < G::RK && k < G::KROW;
-      const float w = a.w[real ? (ky * G::KROW + k) * nout + o : 0], sck = B16 ? 1.f : a.scale[real ? k % CIN : 0];
-      float v = real ? w * sck : 0.f;
-      if (a.wscale != 0.f) v *= a.wscale;
-      wv[n] = v;
-      vmax = fmaxf(vmax, fabsf(v));
+    for (int n = 0; n < NUW; ++n) {
+      const int u = tid + n * CONV_THREADS;
+      const int o = u % NO, g = (u / NO) & 3, ch = (u / (4 * NO)) % NCH, ky = u / (4 * NO * NCH);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int kl = 8 * g + e, k = G::RK * ch + kl;
+        const bool real = u < NU && o < nout && kl < G::RK && k < G::KROW;
+        const float w = a.w[real ? (ky * G::KROW + k) * nout + o : 0];
+        wv[n][e] = real ? w : 0.f;
+      }
     }
-    if (!B16 && tid < CIN) {                          // mu_c = -t_c / s_c: x s + t = s (x - mu); a constant channel (table (0, 0): stats_body.h) has V' = 0
-      const float s_c = a.scale[tid], t_c = a.shift[tid];
-      const double m_c = s_c != 0.f ? -(double)t_c / (double)s_c : 0.0;
-      const _Float16 p_c = (_Float16)(float)m_c;
-      mu[tid] = m_c;
-      pivot[tid] = __builtin_bit_cast(unsigned short, p_c);
+    if (!B16) {
+      if (tid < CIN) {                                // mu_c = -t_c / s_c: x s + t = s (x - mu); a constant channel (table (0, 0): stats_body.h) has V' = 0
+        const float s_c = a.scale[tid], t_c = a.shift[tid];
+        const double m_c = s_c != 0.f ? -(double)t_c / (double)s_c : 0.0;
+        const _Float16 p_c = (_Float16)(float)m_c;
+        mu[tid] = m_c;
+        pivot[tid] = __builtin_bit_cast(unsigned short, p_c);
+        scl[tid] = s_c;
+        dmu[tid] = (float)((double)(float)p_c - m_c);
+      }
+      __syncthreads();                                // (the weight loads are still in flight: 24 scattered scale loads per thread less)
+    }
+#pragma unroll
+    for (int n = 0; n < NUW; ++n) {
+      const int u = tid + n * CONV_THREADS;
+      const int g = (u / NO) & 3, ch = (u / (4 * NO)) % NCH;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = wv[n][e];
+        if (!B16) v *= scl[(G::RK * ch + 8 * g + e) % CIN];      // (slots past the row: w = 0)
+        if (a.wscale != 0.f) v *= a.wscale;
+        wv[n][e] = v;
+        vmax = fmaxf(vmax, fabsf(v));
+      }
     }
 #ifdef K16_CLOCK_PROBE
     const unsigned long long pq0 = __builtin_amdgcn_s_memrealtime();
@@ -267,63 +294,97 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     S = S > 100 ? 100 : (S < -100 ? -100 : S);
     sc = ldexpf(1.f, S); inv = ldexpf(1.f, -S);
 #pragma unroll
-    for (int n = 0; n < NW; ++n) {
-      const int i = tid + n * CONV_THREADS;
-      if (i < NV) {
-        const int o = i % NO, r = i / NO;
-        const int k = r % (NCH * 32), ky = r / (NCH * 32);
-        const int ch = k >> 5, g = (k >> 3) & 3, e = k & 7;
-        const float v = wv[n] * sc;
-        unsigned short h, m, l;
-        if (B16) k16_split3(v, h, m, l);
+    for (int n = 0; n < NUW; ++n) {
+      const int u = tid + n * CONV_THREADS;
+      const int o = u % NO, g = (u / NO) & 3, ch = (u / (4 * NO)) % NCH, ky = u / (4 * NO * NCH);
+      unsigned short pcs[3][8];
+      double po = 0.0;                                // - sum_e V'_e mu_c(e)            (2^S units)
+      float pb[NB];                                   // sum_e V'_e (p_c - mu_c) per tap kx the unit touches (first tap: kx0)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) pb[b] = 0.f;
+      const int kx0 = (G::RK * ch + 8 * g) / CIN;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = wv[n][e] * sc;
+        if (B16) k16_split3(v, pcs[0][e], pcs[1][e], pcs[2][e]);
         else {
           const _Float16 hh = (_Float16)v;
           const float r1 = v - (float)hh;
           const _Float16 mm = (_Float16)r1;
           const float r2 = r1 - (float)mm;
           const _Float16 ll = (_Float16)r2;
-          h = __builtin_bit_cast(unsigned short, hh); m = __builtin_bit_cast(unsigned short, mm); l = __builtin_bit_cast(unsigned short, ll);
+          pcs[0][e] = __builtin_bit_cast(unsigned short, hh); pcs[1][e] = __builtin_bit_cast(unsigned short, mm); pcs[2][e] = __builtin_bit_cast(unsigned short, ll);
+          const int kl = 8 * g + e, k = G::RK * ch + kl;
+          if (kl < G::RK && k < G::KROW) {            // (uniform per e within a (ch, g) class; padded o / u: V' = 0)
+            const double vp = NPC > 2 ? ((double)(float)hh + (double)(float)mm) + (double)(float)ll : (double)(float)hh + (double)(float)mm;      // exact
+            const int c = k % CIN;
+            po -= vp * mu[c];
+            const float d = (float)vp * dmu[c];
+            const int b = k / CIN - kx0;
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) pb[bb] += bb == b ? d : 0.f;
+          }
         }
-        unsigned char* dst = wl + ky * G::PS + g * G::GS + o * 16 + e * 2;
-        *reinterpret_cast<unsigned short*>(dst + (ch * NPC + 0) * G::SLAB) = h;
-        *reinterpret_cast<unsigned short*>(dst + (ch * NPC + 1) * G::SLAB) = m;
-        if (NPC > 2) *reinterpret_cast<unsigned short*>(dst + (ch * NPC + 2) * G::SLAB) = l;
+      }
+      if (u < NU) {
+        const uint32_t dst = lds_addr(wl + ky * G::PS + g * G::GS + o * 16);
+#pragma unroll
+        for (int pc = 0; pc < NPC; ++pc)
+          lds_store(dst, (ch * NPC + pc) * G::SLAB, (k16_u32x4){(unsigned)pcs[pc][0] | ((unsigned)pcs[pc][1] << 16), (unsigned)pcs[pc][2] | ((unsigned)pcs[pc][3] << 16),
+                                                               (unsigned)pcs[pc][4] | ((unsigned)pcs[pc][5] << 16), (unsigned)pcs[pc][6] | ((unsigned)pcs[pc][7] << 16)});
+        if (!B16) {
+          opart[u] = po;
+#pragma unroll
+          for (int b = 0; b < NB; ++b) bpart[NB * u + b] = pb[b];
+        }
       }
     }
     if (!B16) {
-      // ---- the ones slots and the border table, in f64 from the pieces just written (V' = (h + m (+ l)) 2^-S, exactly)
+      // ---- the ones slots and the border table from the units' partials, in a fixed order (g = 0 .. 3; chunk, g ascending)
       __syncthreads();
       K16_STAMP(2);
-      auto vprime = [&](int ky, int k, int o) -> double {      // V'_k 2^S
-        const int ch = k / G::RK, kl = k - ch * G::RK;
-        const unsigned char* src = wl + ky * G::PS + (kl >> 3) * G::GS + o * 16 + (kl & 7) * 2;
-        double v = 0.0;
-#pragma unroll
-        for (int pc = 0; pc < NPC; ++pc)
-          v += (double)(float)__builtin_bit_cast(_Float16, *reinterpret_cast<const unsigned short*>(src + (ch * NPC + pc) * G::SLAB));
-        return v;
-      };
-      constexpr int NJ1 = KS * NCH * NO, NJ = NJ1 + KS * 4 * NO;
+      constexpr int NJ1 = KS * NCH * NO;
+      constexpr int NJW = (NJ1 + CONV_THREADS - 1) / CONV_THREADS;
+      double osumv[NJW];                              // this thread's ones sums (job = tid + k * 256), kept for the slot writes below
       double omax = 0.0;
-      for (int job = tid; job < NJ; job += CONV_THREADS) {
-        if (job < NJ1) {                               // -sum_{k in chunk} V'_k mu_c(k)
-          const int o = job % NO, ch = (job / NO) % NCH, ky = job / (NO * NCH);
-          double acc = 0.0;
-          for (int kl = 0; kl < G::RK; ++kl) {
-            const int k = G::RK * ch + kl;
-            if (k < G::KROW) acc -= vprime(ky, k, o) * mu[k % CIN];
-          }
-          osum[job] = acc;
+#pragma unroll
+      for (int jk = 0; jk < NJW; ++jk) {              // -sum_{k in chunk} V'_k mu_c(k)
+        const int job = tid + jk * CONV_THREADS;
+        osumv[jk] = 0.0;
+        if (job < NJ1) {
+          const int o = job % NO, cy = job / NO;      // cy = ky * NCH + ch
+          const double* pp = opart + (cy * 4) * NO + o;
+          const double acc = ((pp[0] + pp[NO]) + pp[2 * NO]) + pp[3 * NO];
+          osumv[jk] = acc;
           omax = fmax(omax, fabs(acc));
-        } else {                                       // e[ky][kx in {0, 1, KS-2, KS-1}][o] = sum_c V'[ky,kx,c,o] (p_c - mu_c)
-          const int j2 = job - NJ1;
-          const int o = j2 % NO, xi = (j2 / NO) % 4, ky = j2 / (NO * 4);
-          const int kx = xi < 2 ? xi : KS - 4 + xi;
-          double acc = 0.0;
-          for (int c = 0; c < CIN; ++c)
-            acc += vprime(ky, kx * CIN + c, o) * ((double)(float)__builtin_bit_cast(_Float16, pivot[c]) - mu[c]);
-          esum[j2] = acc;
         }
+      }
+      // border table E[rc][o][xi] (accumulator units): output row class rc (rows 0 .. P-1, interior, rows H-P .. H-1) sees the input
+      // rows ky with 0 <= y + ky - P < H; x = 0: taps kx = 0, 1 are left of the image; x = 1: kx = 0; x = W - 2: kx = KS - 1;
+      // x = W - 1: kx = KS - 2, KS - 1 (P = 2).  Each is the sum over those (ky, kx) of sum_c V'[ky,kx,c,o] (p_c - mu_c), i.e. of the
+      // units' border partials that belong to tap kx.
+      for (int job = tid; job < G::NRC * NO * 4; job += CONV_THREADS) {
+        const int xi = job & 3, o = (job >> 2) % NO, rc = job / (4 * NO);
+        const int kxlo = xi == 0 ? 0 : (xi == 1 ? 0 : (xi == 2 ? KS - 1 : KS - 2)), kxhi = xi == 0 ? 1 : (xi == 1 ? 0 : KS - 1);
+        float acc = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+          const bool seen = rc < P ? ky >= P - rc : (rc > P ? ky <= KS - 1 - (rc - P) : true);
+          float kacc = 0.f;
+          { float& acc = kacc;
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int kxa = (G::RK * ch + 8 * g) / CIN;      // (compile-time: the unit's first tap)
+              const float* bp = bpart + NB * ((((ky * NCH + ch) * 4) + g) * NO + o);
+#pragma unroll
+              for (int b = 0; b < NB; ++b) acc += (kxa + b >= kxlo && kxa + b <= kxhi) ? bp[b] : 0.f;      // (selects, not branches: every load in flight)
+            }
+          }
+          acc += seen ? kacc : 0.f;
+        }
+        ctab[job] = acc;
       }
       for (int o = 32; o > 0; o >>= 1) omax = fmax(omax, __shfl_xor(omax, o));
       if (lane == 0) red[4 + wave] = (float)omax;      // (an upper bound is all that is needed: rounded up below)
@@ -332,34 +393,22 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
       const float om = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])) * 1.0001f;
       onesT = (om > 0.f && om < 3.0e38f) ? ilogbf(om) - 14 : 0;      // |ones weight| 2^-T < 2^15
       onesT = onesT < 0 ? 0 : (onesT > 15 ? 15 : onesT);      // (T > 15: |mu| > 2^10 -- not an image; the pieces saturate to inf and the output says so)
-      for (int job = tid; job < NJ1; job += CONV_THREADS) {
-        const int o = job % NO, ch = (job / NO) % NCH, ky = job / (NO * NCH);
-        double v = ldexp(osum[job], -onesT);
-        unsigned char* dst = wl + ky * G::PS + 3 * G::GS + o * 16 + 6 * 2;      // slot 30 = (lane group 3, element 6), slot 31 behind it
 #pragma unroll
-        for (int slot = 0; slot < 2; ++slot)
+      for (int jk = 0; jk < NJW; ++jk) {
+        const int job = tid + jk * CONV_THREADS;
+        if (job < NJ1) {
+          const int o = job % NO, ch = (job / NO) % NCH, ky = job / (NO * NCH);
+          double v = ldexp(osumv[jk], -onesT);
+          unsigned char* dst = wl + ky * G::PS + 3 * G::GS + o * 16 + 6 * 2;      // slot 30 = (lane group 3, element 6), slot 31 behind it
 #pragma unroll
-          for (int pc = 0; pc < NPC; ++pc) {
-            const _Float16 hh = (_Float16)(float)v;
-            v -= (double)(float)hh;
-            *reinterpret_cast<unsigned short*>(dst + slot * 2 + (ch * NPC + pc) * G::SLAB) = __builtin_bit_cast(unsigned short, hh);
-          }
-      }
-      // border table: output row class rc (rows 0 .. P-1, interior, rows H-P .. H-1) sees the input rows ky with 0 <= y + ky - P < H
-      for (int job = tid; job < G::NRC * NO * 4; job += CONV_THREADS) {
-        const int xi = job & 3, o = (job >> 2) % NO, rc = job / (4 * NO);
-        double acc = 0.0;
-        for (int ky = 0; ky < KS; ++ky) {
-          const bool seen = rc < P ? ky >= P - rc : (rc > P ? ky <= KS - 1 - (rc - P) : true);
-          if (!seen) continue;
-          const double* e = esum + ky * 4 * NO;
-          // x = 0: taps kx = 0, 1 are left of the image; x = 1: kx = 0; x = W - 2: kx = KS - 1; x = W - 1: kx = KS - 2, KS - 1   (P = 2)
-          if (xi == 0) acc += e[0 * NO + o] + e[1 * NO + o];
-          else if (xi == 1) acc += e[0 * NO + o];
-          else if (xi == 2) acc += e[3 * NO + o];
-          else acc += e[2 * NO + o] + e[3 * NO + o];
+          for (int slot = 0; slot < 2; ++slot)
+#pragma unroll
+            for (int pc = 0; pc < NPC; ++pc) {
+              const _Float16 hh = (_Float16)(float)v;
+              v -= (double)(float)hh;
+              *reinterpret_cast<unsigned short*>(dst + slot * 2 + (ch * NPC + pc) * G::SLAB) = __builtin_bit_cast(unsigned short, hh);
+            }
         }
-        ctab[job] = (float)acc;
       }
     }
   }
