@@ -20,6 +20,7 @@ struct cpp_ddpg {
   cpp_batch* step_batch;
   // graph replay of ONE minibatch on host-drawn rows, no target update (cpp_ddpg_train_rows: the reference's literal loop)
   hipGraph_t rgraph; hipGraphExec_t rgexec; bool rgraph_ok; int rg_B; uint64_t rg_replay_uid;
+  hipGraph_t dgraph; hipGraphExec_t dgexec; bool dgraph_ok; int dg_B, dg_nb; uint64_t dg_seed, dg_replay_uid; cpp_comm* dg_comm;   // the data-parallel step (default mode)
   // graph replay of the data-parallel half step (sample + both gradient sets)
   // three variants: 0 samples its own minibatch; 1 / 2 find it presampled (by the previous call's rider, conv1_dw_gather.hip)
   // in the second / first set of slot arrays.  One key for all three.
@@ -50,6 +51,7 @@ extern "C" int cpp_ddpg_create(cpp_ctx* ctx, cpp_net* actor, cpp_net* critic, cp
   d->nA = actor->nparams; d->nC = critic->nparams;
   d->graph = nullptr; d->gexec = nullptr; d->graph_ok = false; d->step_batch = nullptr; d->g_replay_uid = 0;
   d->rgraph = nullptr; d->rgexec = nullptr; d->rgraph_ok = false; d->rg_B = 0; d->rg_replay_uid = 0;
+  d->dgraph = nullptr; d->dgexec = nullptr; d->dgraph_ok = false; d->dg_B = d->dg_nb = 0; d->dg_seed = d->dg_replay_uid = 0; d->dg_comm = nullptr;
   memset(d->hg, 0, sizeof(d->hg)); d->dp_local = 0; d->sq_cnt[0] = d->sq_cnt[1] = 0;
   d->h_replay_uid = 0; d->h_write_gen = 0; d->pre_variant = 0; d->h_B = 0; d->h_seed = 0;
   memset(d->slot_set, 0, sizeof(d->slot_set));
@@ -90,6 +92,8 @@ extern "C" int cpp_ddpg_destroy(cpp_ddpg* d) {
   (void)hipStreamSynchronize(d->ctx->stream);
   if (d->gexec) (void)hipGraphExecDestroy(d->gexec);
   if (d->graph) (void)hipGraphDestroy(d->graph);
+  if (d->dgexec) (void)hipGraphExecDestroy(d->dgexec);
+  if (d->dgraph) (void)hipGraphDestroy(d->dgraph);
   if (d->rgexec) (void)hipGraphExecDestroy(d->rgexec);
   if (d->rgraph) (void)hipGraphDestroy(d->rgraph);
   drop_half_graphs(d);
@@ -543,7 +547,11 @@ bool direct_replay_ok(cpp_net* a, cpp_replay* r, int B) {
 }
 
 static int capture_into(cpp_ctx* ctx, hipGraph_t* g, hipGraphExec_t* e, const std::function<int()>& body);
-static int step_body(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int32_t* rows_dev, uint64_t seed, bool targets = true) {
+// dp: this rank's part of the data-parallel step (cpp_ddpg_dp_train_step): between a minibatch's gradients and its update the flat
+// gradient buffer is summed over the ranks (comm; NULL: a single learner on the same path) and the update takes the mean -- the
+// all-reduce is issued on the context's stream, i.e. it is PART OF THE CAPTURED GRAPH (RCCL's kernels capture like any other).
+static int step_body(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int32_t* rows_dev, uint64_t seed, bool targets = true,
+                     bool dp = false, cpp_comm* comm = nullptr) {
   d->pre_variant = 0;        // (the half steps' presampled minibatch lives in the same step_batch)
   const int C = d->actor->spec.pixel ? d->actor->spec.C : 0;
   cpp_ctx* ctx = d->ctx;
@@ -576,7 +584,10 @@ static int step_body(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int
     // (also advances the sampler's counter and, when the next minibatch's sample pass rode along above, finishes its statistics)
     static const bool no_stats_ride = cpp_switch_off("CPP_RIDE_STATS");
     const bool stats_ride = rode && Cg > 0 && !no_stats_ride;
-    RC(apply(d, true, true, 1.0f, rows_dev ? nullptr : r->counter, true, stats_ride ? d->step_batch : nullptr, B, Cg, r->elems));
+    if (dp && comm) NCCL_CHECK(ncclAllReduce(d->gradbuf, d->gradbuf, (size_t)(d->nA + d->nC), ncclFloat, ncclSum, comm->comm, ctx->stream));
+    // (dp: the norm is the reduced gradient's -- the partials the gradient kernels folded in are this rank's only: sumsq runs)
+    RC(apply(d, true, true, (dp && comm) ? 1.0f / (float)comm->world : 1.0f, rows_dev ? nullptr : r->counter, !dp,
+             stats_ride ? d->step_batch : nullptr, B, Cg, r->elems));
     if (more) {
       if (stats_ride) { d->step_batch->B = B; d->step_batch->dtype = CPP_F16; d->step_batch->stats_C = Cg; }     // (replay_sample_finish's bookkeeping)
       else if (rode) RC(replay_sample_finish(r, B, Cg, C, d->step_batch));
@@ -818,6 +829,30 @@ extern "C" int cpp_ddpg_dp_train_step(cpp_ddpg* d, cpp_replay* r, cpp_comm* c, i
   HIP_CHECK(hipSetDevice(ctx->device));
   const float inv = c ? 1.0f / (float)c->world : 1.0f;
   const long fa = fc_start(d->actor), fcr = fc_start(d->critic);
+  static const bool no_dp_graph = cpp_switch_off("CPP_DP_GRAPH");
+  if (sync_every == 1 && !overlap && !no_dp_graph) {
+    // The default mode as ONE hipGraph per outer step (round 4): sample -> gradients -> ncclAllReduce -> norm -> clip + SGD for each of
+    // the n_batches minibatches, then the target updates -- the single learner's fused step (step_body) with the collective and the
+    // norm of the REDUCED gradient inside.  No host launch, copy or fill per minibatch; the sample pass of minibatch i + 1 rides in
+    // i's conv1 dW as in the fused step.  (Rounds 2-3: one graph per half step, the all-reduce, sumsq and the optimiser as host
+    // launches per minibatch: 0.946 of the fused step at world size 1.)
+    if (!d->step_batch) RC(cpp_batch_create(ctx, d->maxB, r->elems, r->A, &d->step_batch));
+    if (ctx->prof) return step_body(d, r, B, n_batches, nullptr, seed, true, true, c);
+    if (!d->dgraph_ok || d->dg_B != B || d->dg_nb != n_batches || d->dg_seed != seed || d->dg_replay_uid != r->uid || d->dg_comm != c) {
+      if (d->dgexec) { (void)hipGraphExecDestroy(d->dgexec); d->dgexec = nullptr; }
+      if (d->dgraph) { (void)hipGraphDestroy(d->dgraph); d->dgraph = nullptr; }
+      d->dgraph_ok = false;
+      RC(step_body(d, r, B, n_batches, nullptr, seed, true, true, c));      // eager pass: kernel attributes; it is also this call's step
+      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      RC(capture_into(ctx, &d->dgraph, &d->dgexec, [&] { return step_body(d, r, B, n_batches, nullptr, seed, true, true, c); }));
+      d->dgraph_ok = true; d->dg_B = B; d->dg_nb = n_batches; d->dg_seed = seed; d->dg_replay_uid = r->uid; d->dg_comm = c;
+      return CPP_OK;
+    }
+    HIP_CHECK(hipGraphLaunch(d->dgexec, ctx->stream));
+    d->pre_variant = 0;
+    d->loss_parts = d->heads_grid; d->loss_B = d->heads_B;
+    return CPP_OK;
+  }
   for (int i = 0; i < n_batches; ++i) {
     if (sync_every > 1) {                           // local update; every k-th one is followed by the parameter averaging
       RC(half_step(d, r, B, seed, false, nullptr));

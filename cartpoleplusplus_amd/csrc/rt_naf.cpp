@@ -19,6 +19,7 @@ struct cpp_naf {
   hipGraph_t hgraph; hipGraphExec_t hexec; bool hgraph_ok; int h_B; uint64_t h_seed, h_replay_uid;
   // ONE minibatch on host-drawn rows up to (not including) the optimiser (cpp_naf_train_rows)
   hipGraph_t rgraph; hipGraphExec_t rgexec; bool rgraph_ok; int rg_B; uint64_t rg_replay_uid;
+  hipGraph_t dgraph; hipGraphExec_t dgexec; bool dgraph_ok; int dg_B, dg_nb; uint64_t dg_seed, dg_replay_uid; cpp_comm* dg_comm;   // the data-parallel step
   // ... and including it, the loss coming back later (cpp_naf_train_rows_async / cpp_naf_loss_wait): pinned (loss, flag) slots
   hipGraph_t agraph; hipGraphExec_t agexec; bool agraph_ok; int ag_B; uint64_t ag_replay_uid;
   float* res_pin; hipEvent_t res_ev[CPP_NAF_TICKETS]; uint64_t next_ticket;
@@ -56,6 +57,7 @@ extern "C" int cpp_naf_create(cpp_ctx* ctx, cpp_net* value, cpp_net* tvalue, cpp
   f->graph = nullptr; f->gexec = nullptr; f->graph_ok = false; f->step_batch = nullptr; f->g_replay_uid = 0;
   f->sq_cnt = 0; f->step_bumped = false;
   f->rgraph = nullptr; f->rgexec = nullptr; f->rgraph_ok = false; f->rg_B = 0; f->rg_replay_uid = 0;
+  f->dgraph = nullptr; f->dgexec = nullptr; f->dgraph_ok = false; f->dg_B = f->dg_nb = 0; f->dg_seed = f->dg_replay_uid = 0; f->dg_comm = nullptr;
   f->agraph = nullptr; f->agexec = nullptr; f->agraph_ok = false; f->ag_B = 0; f->ag_replay_uid = 0;
   f->res_pin = nullptr; f->next_ticket = 0; memset(f->res_ev, 0, sizeof(f->res_ev));
   f->hgraph = nullptr; f->hexec = nullptr; f->hgraph_ok = false; f->h_B = 0; f->h_seed = 0; f->h_replay_uid = 0; f->dp_local = 0;
@@ -90,6 +92,8 @@ extern "C" int cpp_naf_destroy(cpp_naf* f) {
   (void)hipStreamSynchronize(f->ctx->stream);
   if (f->hexec) (void)hipGraphExecDestroy(f->hexec);
   if (f->hgraph) (void)hipGraphDestroy(f->hgraph);
+  if (f->dgexec) (void)hipGraphExecDestroy(f->dgexec);
+  if (f->dgraph) (void)hipGraphDestroy(f->dgraph);
   if (f->rgexec) (void)hipGraphExecDestroy(f->rgexec);
   if (f->rgraph) (void)hipGraphDestroy(f->rgraph);
   if (f->agexec) (void)hipGraphExecDestroy(f->agexec);
@@ -428,7 +432,8 @@ extern "C" int cpp_naf_debug_values(cpp_naf* f, cpp_batch* b, float* l_values, f
 // The inner step naf_cartpole.py:367-373.  As in the DDPG step (rt_ddpg.cpp: step_body) the sample pass of minibatch i + 1 depends on
 // nothing minibatch i computes: it rides in the launch of i's conv1 dW (or of its dW reductions), keyed by the sampler's counter + 1
 // -- the counter itself moves in i's optimiser launch, which also finishes the whitening tables of i + 1.  CPP_RIDE_GATHER=0: in sequence.
-static int naf_step_body(cpp_naf* f, cpp_replay* r, int B, int n_batches, const int32_t* rows_dev, uint64_t seed) {
+// dp / comm: as rt_ddpg.cpp's step_body -- the gradient all-reduce sits between a minibatch's gradients and its update, inside the graph
+static int naf_step_body(cpp_naf* f, cpp_replay* r, int B, int n_batches, const int32_t* rows_dev, uint64_t seed, bool dp = false, cpp_comm* comm = nullptr) {
   const int C = f->value->spec.pixel ? f->value->spec.C : 0;
   cpp_ctx* ctx = f->ctx;
   const bool direct = direct_replay_ok(f->value, r, B);
@@ -453,7 +458,8 @@ static int naf_step_body(cpp_naf* f, cpp_replay* r, int B, int n_batches, const 
     if (rode && direct) { std::swap(f->step_batch->slot[0], f->step_batch->slot_alt[0]); std::swap(f->step_batch->slot[1], f->step_batch->slot_alt[1]); }
     RC(rc);
     const bool stats_ride = rode && Cg > 0;
-    RC(naf_apply(f, 1.0f, false, rows_dev ? nullptr : r->counter, stats_ride ? f->step_batch : nullptr, B, Cg, r->elems, true));
+    if (dp && comm) NCCL_CHECK(ncclAllReduce(f->gradbuf, f->gradbuf, (size_t)(f->nV + f->nM + f->nL), ncclFloat, ncclSum, comm->comm, ctx->stream));
+    RC(naf_apply(f, (dp && comm) ? 1.0f / (float)comm->world : 1.0f, false, rows_dev ? nullptr : r->counter, stats_ride ? f->step_batch : nullptr, B, Cg, r->elems, !dp));
     if (more) {
       if (stats_ride) { f->step_batch->B = B; f->step_batch->dtype = CPP_F16; f->step_batch->stats_C = Cg; }     // (replay_sample_finish's bookkeeping)
       else if (rode) RC(replay_sample_finish(r, B, Cg, C, f->step_batch));
@@ -681,6 +687,30 @@ extern "C" int cpp_naf_dp_train_step(cpp_naf* f, cpp_replay* r, cpp_comm* c, int
   ARG_CHECK(n_batches >= 1 && sync_every >= 1, "cpp_naf_dp_train_step: n_batches %d, sync_every %d", n_batches, sync_every);
   ARG_CHECK(!c || c->ctx == f->ctx, "cpp_naf_dp_train_step: communicator and networks live on different contexts");
   const float inv = c ? 1.0f / (float)c->world : 1.0f;
+  static const bool no_dp_graph = cpp_switch_off("CPP_DP_GRAPH");
+  if (sync_every == 1 && !no_dp_graph) {             // ONE hipGraph per outer step, the all-reduce inside (see cpp_ddpg_dp_train_step)
+    cpp_ctx* ctx = f->ctx;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    if (!f->step_batch) RC(cpp_batch_create(ctx, f->maxB, r->elems, r->A, &f->step_batch));
+    if (ctx->prof) return naf_step_body(f, r, B, n_batches, nullptr, seed, true, c);
+    if (!f->dgraph_ok || f->dg_B != B || f->dg_nb != n_batches || f->dg_seed != seed || f->dg_replay_uid != r->uid || f->dg_comm != c) {
+      if (f->dgexec) { (void)hipGraphExecDestroy(f->dgexec); f->dgexec = nullptr; }
+      if (f->dgraph) { (void)hipGraphDestroy(f->dgraph); f->dgraph = nullptr; }
+      f->dgraph_ok = false;
+      RC(naf_step_body(f, r, B, n_batches, nullptr, seed, true, c));
+      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+      const int rc = naf_step_body(f, r, B, n_batches, nullptr, seed, true, c);
+      const hipError_t e = hipStreamEndCapture(ctx->stream, &f->dgraph);
+      if (rc) return rc;
+      if (e != hipSuccess) { cpp_set_error("hipStreamEndCapture -> %s", hipGetErrorString(e)); return CPP_ERR_HIP; }
+      HIP_CHECK(hipGraphInstantiate(&f->dgexec, f->dgraph, nullptr, nullptr, 0));
+      f->dgraph_ok = true; f->dg_B = B; f->dg_nb = n_batches; f->dg_seed = seed; f->dg_replay_uid = r->uid; f->dg_comm = c;
+      return CPP_OK;
+    }
+    HIP_CHECK(hipGraphLaunch(f->dgexec, ctx->stream));
+    return CPP_OK;
+  }
   for (int i = 0; i < n_batches; ++i) {
     RC(cpp_naf_sample_and_compute(f, r, B, seed));
     if (sync_every > 1) {
