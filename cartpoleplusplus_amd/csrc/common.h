@@ -304,7 +304,7 @@ int launch_replay_fill(cpp_ctx* ctx, __half* store, long elems, int slots, int32
                        float* action, float* reward, float* mask, int rows, int action_dim,
                        uint64_t seed);
 int launch_f32_to_f16(cpp_ctx* ctx, __half* dst, const float* src, long n);
-int launch_counter_add(cpp_ctx* ctx, uint64_t* counter, uint64_t inc);
+int launch_counter_add(cpp_ctx* ctx, uint64_t* counter, uint64_t inc, const int* unless = nullptr);
 
 // ---------------------------------------------------------------------------------------------
 // optimiser (optim.hip)

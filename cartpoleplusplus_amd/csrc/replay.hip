@@ -258,10 +258,11 @@ int launch_replay_fill_u8(cpp_ctx* ctx, uint8_t* store, long total, uint64_t see
   return 0;
 }
 
-__global__ void counter_add_kernel(uint64_t* counter, uint64_t inc) { *counter += inc; }
+// (unless: non-null and set -> the counter stays: an optimiser step that stands down is not counted)
+__global__ void counter_add_kernel(uint64_t* counter, uint64_t inc, const int* unless) { if (!unless || !*unless) *counter += inc; }
 
-int launch_counter_add(cpp_ctx* ctx, uint64_t* counter, uint64_t inc) {
-  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, ctx->stream, counter, inc);
+int launch_counter_add(cpp_ctx* ctx, uint64_t* counter, uint64_t inc, const int* unless) {
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, ctx->stream, counter, inc, unless);
   LAUNCH_CHECK();
   return 0;
 }

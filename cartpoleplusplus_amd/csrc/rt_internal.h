@@ -119,10 +119,11 @@ struct cpp_replay {
   uint64_t* counter_adhoc; // the same for cpp_replay_sample(idxs == NULL): inspection draws never move the training sampler
   int32_t* size_dev;       // rows currently in the memory, on the device: the sampler's range of captured launches
   uint64_t uid;            // unique per cpp_replay_create (graph keys: an address can be reused, this cannot)
+  bool sampled;            // a sample pass has been built on this memory since the uid was issued: captured step graphs may hold its slot_stats pointer
   uint64_t write_gen;      // bumped by every call that changes rows, states or the size: a minibatch presampled before it is stale
   __half* lut; int* bad; uint16_t lut_host[256];      // CPP_U8: f16(k/255) table, "not a pixel image" flag
   // per-state whitening sums (cpp_replay_set_stats_channels): [slots][2 * stats_C] doubles, kept current by every call that writes states
-  double* slot_stats; int stats_C; int32_t* slot_list; size_t slot_list_cap;
+  double* slot_stats; int stats_C, stats_cap; int32_t* slot_list; size_t slot_list_cap;
   void* stage; size_t stage_cap;                      // device staging of incoming states (conversion source)
   void* pinned; size_t pinned_cap; hipEvent_t pinned_free; bool pinned_busy;   // host staging: writes return before the copy ends
   // host-drawn minibatch rows on their way to rows_in (cpp_ddpg_train_rows / cpp_naf_train_rows): a ring of pinned slots, so that the
@@ -258,6 +259,7 @@ GemmArgs fc_dw_args(cpp_net* n, Workspace& w, int l, int B, const float* dz);
 GemmArgs fc_dx_args(cpp_net* n, int l, int B, const float* dz, long dz_ld, int col0, int ncols, float* C, long ldc, int epi, const float* Y, long ldy);
 int batch_stats(cpp_ctx* ctx, const void* s0, const void* s1, int dtype, long elems, int B, int C, double* part, float* white);
 int batch_ensure_stats(cpp_batch* b, int C);
+uint64_t replay_next_uid();      // graph keys: a fresh uid per cpp_replay_create and per change of a sampled memory's statistics setting
 GatherArgs replay_gather_args(cpp_replay* r, int B, const int32_t* rows_dev, uint64_t seed, const uint64_t* counter_dev, int channels, cpp_batch* out, bool direct, int* C_out);
 int replay_sample_finish(cpp_replay* r, int B, int C, int channels, cpp_batch* out, uint64_t* bump = nullptr, bool* bumped = nullptr);
 int replay_sample_device(cpp_replay* r, int B, const int32_t* rows_dev, uint64_t seed, const uint64_t* counter_dev, int channels, cpp_batch* out, bool direct = false,

@@ -164,7 +164,8 @@ static int add_fc_backward(OpGraph& G, cpp_net* n, Workspace& w, int B, int star
 // fold (the fused single-learner step only: the gradients are applied as computed): the kernels that write the gradients leave
 // their share of the list's squared norm in cpp_ctx::sq_part (as the DDPG step, rt_ddpg.cpp) and the heads kernel advances the
 // optimiser's step counter -- naf_apply then runs neither the sumsq nor the counter kernel
-static int naf_compute_gradients(cpp_naf* f, cpp_batch* b, bool fold = false) {
+// bump_step: the heads kernel also advances the optimiser's step counter (only where no check_numerics flag can stand the update down)
+static int naf_compute_gradients(cpp_naf* f, cpp_batch* b, bool fold = false, bool bump_step = true) {
   cpp_ctx* ctx = f->ctx;
   f->sq_cnt = 0; f->step_bumped = false;
   struct SqScope {
@@ -238,7 +239,7 @@ static int naf_compute_gradients(cpp_naf* f, cpp_batch* b, bool fold = false) {
     nh.d_value = v->ws[0].dz[Lh]; nh.d_mu_z = mu->ws[0].dz[0]; nh.d_l = lv->ws[0].dz[0];
     nh.drep = v->ws[0].dz[Lh - 1]; nh.ldd = hv.n_in; nh.epi = relu_grad_epi(v, Lh - 1); nh.Y = v->ws[0].fcin[Lh]; nh.ldy = hv.n_in + 1;
     nh.part = f->heads_part; nh.ticket = f->heads_ticket;
-    nh.step_bump = fold ? (unsigned long long*)f->opt_step : nullptr;
+    nh.step_bump = (fold && bump_step) ? (unsigned long long*)f->opt_step : nullptr;
     fused = naf_heads_supported(nh) && (nh.epi == GE_MUL_RELU_GRAD || nh.epi == GE_MUL_RELU_GRAD_X2);
   }
   // ... and with exactly two hidden layers (the reference's 100, 50) the second one joins that launch, forward and backward, on the
@@ -342,7 +343,9 @@ static int naf_apply(cpp_naf* f, float grad_scale, bool unless_nonfinite = false
   }
   const bool bumped = f->step_bumped; const int sq_cnt = f->sq_cnt;
   f->step_bumped = false; f->sq_cnt = 0;
-  if (!bumped) RC(launch_counter_add(f->ctx, f->opt_step, 1));
+  // (unless_nonfinite: a skipped update must not count as an optimiser step -- Adam's bias correction reads the count; the heads
+  // kernel's bump was undone below by never happening: naf_compute_gradients leaves it to this launch when the flag can stand the update down)
+  if (!bumped) RC(launch_counter_add(f->ctx, f->opt_step, 1, unless_nonfinite ? f->nonfinite : nullptr));
   if (folded && sq_cnt > 0 && grad_scale == 1.0f) { s.sq = f->ctx->sq_part; s.sq_begin[0] = 0; s.sq_count[0] = sq_cnt; }
   else RC(launch_sumsq(f->ctx, s, grad_scale, f->norm_part, NORM_PARTS));
   return launch_opt_apply(f->ctx, s, grad_scale, f->hp.gradient_clip, f->norm_part, NORM_PARTS, f->stats + 1);
@@ -509,11 +512,14 @@ extern "C" int cpp_naf_train_step(cpp_naf* f, cpp_replay* r, int B, int n_batche
 // gathered copy of the minibatch crossing PCIe or HBM twice -- the sample pass reads the replay store through those rows.  Like
 // cpp_naf_train: gradients, then the loss and the check_numerics flag come back (one stream sync: the reference's train() returns the
 // loss), then the optimiser -- which does not run when the flag is set.  The gradient half is one hipGraph per (B, replay).
-static int naf_rows_body(cpp_naf* f, cpp_replay* r, int B, bool fold = false) {
+// sticky: the check_numerics flag is NOT cleared (cpp_naf_train_rows_async: the host learns of a non-finite minibatch up to two calls
+// later; until it has, every later optimiser launch must stand down as the first one did -- the reference's check_numerics stops
+// training before any further train op, naf_cartpole.py:242-245,265)
+static int naf_rows_body(cpp_naf* f, cpp_replay* r, int B, bool fold = false, bool sticky = false) {
   const int C = f->value->spec.pixel ? f->value->spec.C : 0;
-  HIP_CHECK(hipMemsetAsync(f->nonfinite, 0, sizeof(int), f->ctx->stream));
+  if (!sticky) HIP_CHECK(hipMemsetAsync(f->nonfinite, 0, sizeof(int), f->ctx->stream));
   RC(replay_sample_device(r, B, r->rows_in, 0, nullptr, C, f->step_batch, direct_replay_ok(f->value, r, B)));
-  return naf_compute_gradients(f, f->step_batch, fold);
+  return naf_compute_gradients(f, f->step_batch, fold, !sticky);
 }
 extern "C" int cpp_naf_train_rows(cpp_naf* f, cpp_replay* r, int B, const int32_t* idxs, float* loss) {
   ARG_CHECK(f && r && idxs, "cpp_naf_train_rows: NULL argument");
@@ -557,7 +563,7 @@ extern "C" int cpp_naf_train_rows(cpp_naf* f, cpp_replay* r, int B, const int32_
 // reads the loss (the agents only log its mean) -- so a loop of train calls keeps the GPU fed like cpp_naf_train_step does.
 // At most CPP_NAF_TICKETS results are outstanding: a slot is reused CPP_NAF_TICKETS calls later.
 static int naf_rows_apply_body(cpp_naf* f, cpp_replay* r, int B) {
-  RC(naf_rows_body(f, r, B, true));        // (gradients and optimiser in ONE captured body: the fold's host-side state is consistent)
+  RC(naf_rows_body(f, r, B, true, true));  // (gradients and optimiser in ONE captured body: the fold's host-side state is consistent)
   return naf_apply(f, 1.0f, true, nullptr, nullptr, 0, 0, 0, true);
 }
 extern "C" int cpp_naf_train_rows_async(cpp_naf* f, cpp_replay* r, int B, const int32_t* idxs, uint64_t* ticket) {

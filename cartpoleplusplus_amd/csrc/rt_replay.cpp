@@ -106,7 +106,7 @@ static int replay_create(cpp_ctx* ctx, int buffer_size, int state_slots, int64_t
   r->arena.stream = ctx->stream;
   r->ctx = ctx; r->rows = buffer_size; r->slots = state_slots; r->A = action_dim; r->size = 0; r->elems = state_elems;
   r->store_dtype = store_dtype;
-  r->slot_stats = nullptr; r->stats_C = 0; r->slot_list = nullptr; r->slot_list_cap = 0;
+  r->slot_stats = nullptr; r->stats_C = 0; r->stats_cap = 0; r->sampled = false; r->slot_list = nullptr; r->slot_list_cap = 0;
   r->rows_pin = nullptr; r->rows_pin_k = 0; memset(r->rows_pin_used, 0, sizeof(r->rows_pin_used)); memset(r->rows_pin_ev, 0, sizeof(r->rows_pin_ev));
   r->stage = nullptr; r->stage_cap = 0; r->pinned = nullptr; r->pinned_cap = 0; r->pinned_busy = false; r->lut = nullptr; r->bad = nullptr;
   HIP_CHECK(hipEventCreateWithFlags(&r->pinned_free, hipEventDisableTiming));
@@ -130,8 +130,7 @@ static int replay_create(cpp_ctx* ctx, int buffer_size, int state_slots, int64_t
     }
   }
   if (rc) { r->arena.release(); delete r; return rc; }
-  static uint64_t next_uid = 1;
-  r->uid = next_uid++;
+  r->uid = replay_next_uid();
   *out = r;
   return CPP_OK;
 }
@@ -169,6 +168,8 @@ extern "C" int cpp_replay_destroy(cpp_replay* r) {
 // itself, never touch the pixels for the sample.  The sums are (re)computed here for every slot and kept current by
 // cpp_replay_write_states / cpp_replay_fill_synthetic.  channels = 0, or a channel count the vector statistics path cannot take, turns
 // them off (the gather then reads the images, as before).
+uint64_t replay_next_uid() { static uint64_t next_uid = 1; return next_uid++; }
+
 extern "C" int cpp_replay_set_stats_channels(cpp_replay* r, int channels) {
   ARG_CHECK(r && channels >= 0 && channels <= CPP_MAX_CHANNELS, "cpp_replay_set_stats_channels: channels %d", channels);
   HIP_CHECK(hipSetDevice(r->ctx->device));
@@ -177,11 +178,17 @@ extern "C" int cpp_replay_set_stats_channels(cpp_replay* r, int channels) {
     int g = 8, c = C; while (c) { int t = g % c; g = c; c = t; }
     if (r->elems % 8 != 0 || C / g > 16 || r->elems % C != 0) C = 0;
   }
+  // the captured step graphs (rt_ddpg.cpp / rt_naf.cpp, keyed on batch size and memory) have the slot_stats pointer and the
+  // direct-store decision baked in.  Their keys compare the memory's uid: a memory whose setting changes after it has been
+  // sampled takes a NEW uid, and every such graph is captured again at its next use.
+  if (C == r->stats_C && (C == 0 || r->slot_stats)) return CPP_OK;
+  if (r->sampled) { r->uid = replay_next_uid(); r->sampled = false; }
   ++r->write_gen;              // (a minibatch presampled under the old setting is stale)
   if (C == 0) { r->stats_C = 0; return CPP_OK; }          // (the buffer, if any, stays allocated and unused)
-  if (!r->slot_stats || r->stats_C < C) {
+  if (!r->slot_stats || r->stats_cap < C) {          // (switching off and on again reuses the buffer)
     HIP_CHECK(hipStreamSynchronize(r->ctx->stream));
     RC(dalloc(r->arena, &r->slot_stats, (size_t)r->slots * 2 * C));
+    r->stats_cap = C;
   }
   r->stats_C = C;
   RC(launch_slot_stats(r->ctx, r->store, r->store_dtype, r->elems, C, r->slot_stats, nullptr, 0, r->slots, r->lut));
@@ -235,7 +242,7 @@ extern "C" int cpp_replay_write_states(cpp_replay* r, const int32_t* slots, int 
         RC(launch_f32_to_f16(r->ctx, (__half*)r->store + (size_t)slots[i] * r->elems, (const float*)src, r->elems));
     }
   }
-  if (r->slot_stats) {       // the new states' whitening sums (what a gather of them would compute), once, here
+  if (r->slot_stats && r->stats_C > 0) {       // the new states' whitening sums (what a gather of them would compute), once, here
     if ((size_t)n > r->slot_list_cap) {
       HIP_CHECK(hipStreamSynchronize(st));
       if (r->slot_list) HIP_CHECK(hipFree(r->slot_list));
@@ -367,6 +374,7 @@ int replay_stage_rows(cpp_replay* r, const int32_t* idxs, int n, const char* who
 GatherArgs replay_gather_args(cpp_replay* r, int B, const int32_t* rows_dev, uint64_t seed, const uint64_t* counter_dev,
                                      int channels, cpp_batch* out, bool direct, int* C_out) {
   int C = channels;
+  r->sampled = true;
   if (C > 0) {
     int g = 8, c = C; while (c) { int t = g % c; g = c; c = t; }
     if (r->elems % 8 != 0 || C / g > 16 || r->elems % C != 0) C = 0;    // statistics via the generic path below
@@ -447,7 +455,7 @@ extern "C" int cpp_replay_fill_synthetic(cpp_replay* r, int n_rows, uint64_t see
   RC(launch_replay_fill(r->ctx, r->store_dtype == CPP_U8 ? nullptr : (__half*)r->store, r->elems, r->slots, r->s1, r->s2,
                         r->action, r->reward, r->mask, n_rows, r->A, seed));
   if (r->store_dtype == CPP_U8) RC(launch_replay_fill_u8(r->ctx, (uint8_t*)r->store, r->elems * (long)r->slots, seed));
-  if (r->slot_stats) RC(launch_slot_stats(r->ctx, r->store, r->store_dtype, r->elems, r->stats_C, r->slot_stats, nullptr, 0, r->slots, r->lut));
+  if (r->slot_stats && r->stats_C > 0) RC(launch_slot_stats(r->ctx, r->store, r->store_dtype, r->elems, r->stats_C, r->slot_stats, nullptr, 0, r->slots, r->lut));
   HIP_CHECK(hipStreamSynchronize(r->ctx->stream));
   return replay_set_size(r, n_rows);
 }

@@ -602,6 +602,10 @@ def make_env(o):
 def main(argv=None):
     _install_signal_handlers()
     set_opts(build_parser().parse_args(argv))
+    if opts.data_parallel and opts.host_rng_sampling:
+        # the host-RNG path is the reference's literal loop: local actor.train / critic.train calls with no all-reduce -- N learners
+        # would agree on when to train (LoopAgreement) and silently train N different networks
+        raise SystemExit("--data-parallel draws minibatches with the device sampler inside the collective step: it cannot be combined with --host-rng-sampling")
     sys.stderr.write("%s\n" % opts)
     env = make_env(opts)
     agent = DeepDeterministicPolicyGradientAgent(env=env)

@@ -335,10 +335,15 @@ class NafNetwork(base_network.Network):
         check(lib.cpp_naf_set_opt_state(self.handle, ptr(m), ptr(v), len(m), int(state["step"])))
 
     def close(self):
+        # a loss nobody has looked at may be a non-finite minibatch (check_numerics, naf_cartpole.py:242-245): closing does not hide
+        # it -- the device is released first, then the first such error is raised
+        unresolved = None
         for d in self.__dict__.get("_losses", ()):
             try:
                 d.resolve()
-            except Exception:       # noqa: BLE001 -- closing; the error was the caller's to look at
+            except FloatingPointError as e:
+                unresolved = unresolved or e
+            except Exception:       # noqa: BLE001 -- a ticket that has expired, a handle already gone: nothing the caller can act on
                 pass
         for b in self._upload.values():
             b.close()
@@ -347,6 +352,8 @@ class NafNetwork(base_network.Network):
             self.handle = None
         self.mu_net.close()
         self.l_net.close()
+        if unresolved is not None:
+            raise unresolved
 
 
 class NormalizedAdvantageFunctionAgent(object):
@@ -481,6 +488,10 @@ class NormalizedAdvantageFunctionAgent(object):
 def main(argv=None):
     _install_signal_handlers()
     set_opts(build_parser().parse_args(argv))
+    if opts.data_parallel and opts.host_rng_sampling:
+        # the host-RNG path is the reference's literal loop: local actor.train / critic.train calls with no all-reduce -- N learners
+        # would agree on when to train (LoopAgreement) and silently train N different networks
+        raise SystemExit("--data-parallel draws minibatches with the device sampler inside the collective step: it cannot be combined with --host-rng-sampling")
     sys.stderr.write("%s\n" % opts)
     from .ddpg_cartpole import make_env
     env = make_env(opts)

@@ -40,19 +40,31 @@ class FairLock(object):
     def __init__(self):
         self._cv = threading.Condition()
         self._next, self._serving = 0, 0
+        self._abandoned = set()
 
     def __enter__(self):
         with self._cv:
             ticket = self._next
             self._next += 1
-            while self._serving != ticket:
-                self._cv.wait()
+            try:
+                while self._serving != ticket:
+                    self._cv.wait()
+            except BaseException:            # KeyboardInterrupt while queued: this ticket would block everybody behind it for ever
+                self._abandoned.add(ticket)
+                self._skip_abandoned()
+                raise
         return self
+
+    def _skip_abandoned(self):
+        while self._serving in self._abandoned:
+            self._abandoned.discard(self._serving)
+            self._serving += 1
+        self._cv.notify_all()
 
     def __exit__(self, *exc):
         with self._cv:
             self._serving += 1
-            self._cv.notify_all()
+            self._skip_abandoned()
         return False
 
 
@@ -132,12 +144,15 @@ class AsyncRollouts(object):
 
     def stop(self):
         self._stop.set()
-        while self.thread.is_alive():           # unblock a put() on a full queue
+        deadline = time.time() + 30.0           # (an episode in flight finishes first; a thread that is stuck is left to the daemon flag)
+        while self.thread.is_alive() and time.time() < deadline:           # unblock a put() on a full queue
             try:
                 self.queue.get_nowait()
             except queue.Empty:
                 pass
             self.thread.join(timeout=0.05)
+        if self.thread.is_alive():
+            sys.stderr.write("AsyncRollouts.stop: the rollout thread did not finish within 30 s; leaving it behind\n")
 
 
 class TrainingLoop(object):

@@ -183,6 +183,41 @@ def test_check_numerics_raises_and_leaves_parameters_untouched():
         agent.close()
 
 
+def test_a_non_finite_minibatch_of_the_literal_loop_stops_every_later_update_and_is_not_counted():
+    """`naf.train(batch)` on a replay draw returns at once (cpp_naf_train_rows_async); the check_numerics flag of a
+    non-finite minibatch reaches the host up to two calls later.  Until then the device must behave as the reference does after
+    tf.check_numerics raised (naf_cartpole.py:242-245,265): NO further optimiser step runs (the flag is sticky), the skipped update
+    is not counted as an Adam step, and close() does not swallow an error nobody looked at."""
+    import json
+    from cartpoleplusplus_amd import naf_cartpole as F
+    from tests.helpers import FakeEnv
+    shape, B = (2, 2, 7), 4
+    F.set_opts(F.default_opts(use_raw_pixels=False, action_repeats=2, batch_size=B, replay_memory_size=64,
+                              share_input_state_representation=True, optimiser="Adam", optimiser_args=json.dumps({"learning_rate": 0.01})))
+    agent = F.NormalizedAdvantageFunctionAgent(FakeEnv(shape))
+    agent.initialise_variables(seed=2)
+    agent.post_var_init_setup()
+    agent.replay_memory.fill_synthetic(40, seed=3)
+    try:
+        np.random.seed(5)
+        for _ in range(3):                              # three good minibatches
+            float(agent.naf.train(agent.replay_memory.batch(B)))
+        step0 = agent.naf.get_optimiser_state()["step"]
+        assert step0 == 3
+        agent.naf.l_net.set_params(agent.naf.l_net.get_params() * 0 + 1e4)         # exp(l) overflows (naf_cartpole.py:208)
+        before = params_of(agent)
+        losses = [agent.naf.train(agent.replay_memory.batch(B)) for _ in range(2)]      # the bad one and one more, nobody looks
+        assert np.array_equal(before, params_of(agent)), "an optimiser step ran behind a non-finite minibatch"
+        assert agent.naf.get_optimiser_state()["step"] == step0, "a skipped update was counted as an optimiser step"
+        with pytest.raises(FloatingPointError):
+            float(losses[0])
+        with pytest.raises(FloatingPointError):         # ... and the second loss is still unresolved: close() raises it
+            agent.naf.close()
+        agent.naf.handle = None
+    finally:
+        agent.value_net.close(); agent.target_value_net.close(); agent.replay_memory.close()
+
+
 def test_checkpoint_resume_restores_the_adam_slots(tmp_path):
     """util.SaverUtil must checkpoint the optimiser's slot variables like tf.train.Saver does (util.py:88-90): a run resumed
     from a checkpoint continues bit for bit like the uninterrupted one (Adam: moments + beta powers)."""

@@ -264,3 +264,48 @@ def test_bench_self_launch_builds_the_drivers_torchrun_command(monkeypatch):
     i = cmd.index(os.path.join(root, "bench.py"))
     assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def test_fair_lock_skips_the_ticket_of_an_interrupted_waiter():
+    """a waiter that is interrupted (Ctrl-C) between taking its ticket and being served left a ticket nobody would ever
+    serve: every later __enter__ -- AsyncRollouts.stop()'s included -- waited for ever."""
+    import threading
+    from cartpoleplusplus_amd.training_loop import FairLock
+    lock = FairLock()
+    lock.__enter__()                                   # ticket 0 is being served
+    hit = []
+
+    class Interrupt(BaseException):
+        pass
+    real_wait = lock._cv.wait
+
+    def wait_then_interrupt(*a, **k):                  # the queued waiter is interrupted inside its wait
+        hit.append(1)
+        raise Interrupt()
+    lock._cv.wait = wait_then_interrupt
+    try:
+        lock.__enter__()                               # ticket 1: queued behind ticket 0, interrupted
+    except Interrupt:
+        pass
+    lock._cv.wait = real_wait
+    assert hit
+    lock.__exit__(None, None, None)                    # ticket 0 leaves: ticket 1 was abandoned and must be skipped
+    done = threading.Event()
+
+    def later():
+        with lock:
+            done.set()
+    t = threading.Thread(target=later, daemon=True)
+    t.start()
+    assert done.wait(5.0), "a ticket taken by an interrupted waiter blocks the lock"
+
+
+@pytest.mark.parametrize("mod", ["ddpg_cartpole", "naf_cartpole"])
+def test_data_parallel_refuses_host_rng_sampling(mod):
+    """--data-parallel --host-rng-sampling ran the local literal loop with no all-reduce while LoopAgreement kept the ranks'
+    train / stop decisions collective: replicas that silently diverge.  The combination is an error before anything is built."""
+    import importlib
+    m = importlib.import_module("cartpoleplusplus_amd." + mod)
+    with pytest.raises(SystemExit) as e:
+        m.main(["--data-parallel", "--host-rng-sampling", "--synthetic-env"])
+    assert "host-rng-sampling" in str(e.value)
