@@ -90,7 +90,6 @@ struct cpp_ctx {
   // list); the optimiser kernel adds a list's partials in slot order.  sq_n: slots handed out so far, -1: folding off (the sumsq
   // kernel runs instead: data-parallel steps, whose gradients change in the all-reduce; batch norm; NAF).
   double* sq_part; int sq_n[2]; int sq_conv_group[4];
-  unsigned* gemm_chain;           // GEMM_CHAIN_SLOTS counters of the chained GEMM launches (zero between launches)
   int precision;                  // CPP_PRECISION_FAST / CPP_PRECISION_EXACT (cpp_ctx_set_precision; conv_k16.h)
   int n_trainers;                 // live cpp_ddpg / cpp_naf objects: their captured graphs pin the precision mode
 };
@@ -210,21 +209,9 @@ struct GemmArgs {
   float* C2; long ldc2;         // optional second copy of the output (e.g. actions straight into the critic's input)
   const uint64_t* drop_counter; uint32_t drop_seed, drop_layer;   // GE_RELU_DROPOUT
   double* sq_part;              // non-null: tile t also leaves the f64 sum of squares of its outputs in sq_part[t] (see cpp_ctx::sq_part)
-  // chained launch (launch_gemm_chain): a problem whose operands are written by problems of the SAME launch waits until
-  // chain[wait_slot[i]] == wait_cnt[i] (every tile of that producer has stored and released its outputs); a producer's tiles
-  // add one to chain[signal_slot] when they are done.  Slots are >= 1; 0 = none.
-  int wait_slot[2], wait_cnt[2], signal_slot;
-  // next layer's partial products (forward, GE_RELU): the tile that finishes columns [16 tn, 16 tn + 16) of this layer's output h
-  // also leaves next_part[(tn * M + row) * next_N + n] = sum over those columns k of h[row][k] * next_W[k * next_N + n] -- the
-  // slice of the NEXT fully connected layer's sum this tile can see.  Whoever consumes that layer adds the tiles_n slices in
-  // tile order, the bias row and the activation (ddpg_heads_kernel): a dependent GEMM level less.  next_N <= 16 * GEMM_NEXT_TILES.
-  const float* next_W; float* next_part; int next_N, next_K;     // next_K: rows of next_W that may be read (this layer's N)
 };
-#define GEMM_NEXT_TILES 7
 #define GEMM_BATCH_MAX 16
-#define GEMM_CHAIN_SLOTS 32     // cpp_ctx::gemm_chain: [0] consumer tiles that passed their wait, [1 ..] producer counters
-// chain: non-null for a chained launch; chain_consumers = number of tiles that wait (the last one to pass resets the counters)
-struct GemmBatch { GemmArgs g[GEMM_BATCH_MAX]; int tile_start[GEMM_BATCH_MAX + 1]; int n; unsigned* chain; int chain_consumers, chain_slots; };
+struct GemmBatch { GemmArgs g[GEMM_BATCH_MAX]; int tile_start[GEMM_BATCH_MAX + 1]; int n; };
 // kernel attributes (dynamic LDS size) are set once per kernel AND device: the launchers keep one flag per device slot
 #define CPP_MAX_DEVICES 16
 static inline int cpp_dev_slot(const cpp_ctx* ctx) { return ctx->device >= 0 && ctx->device < CPP_MAX_DEVICES ? ctx->device : 0; }
@@ -236,9 +223,6 @@ static inline __host__ __device__ int gemm_sub(int M, int N, int K) { return (K 
 static inline int gemm_tiles(int M, int N, int K) { const int e = 16 * gemm_sub(M, N, K); return ((M + e - 1) / e) * ((N + e - 1) / e); }
 int launch_gemm(cpp_ctx* ctx, const GemmArgs& g);
 int launch_gemm_batch(cpp_ctx* ctx, const GemmArgs* list, int n);   // independent GEMMs in one launch
-// two dependent levels of GEMMs in ONE launch: list[0 .. n) in dispatch order (producers first); list[i].wait_slot / wait_cnt /
-// signal_slot describe the dependencies inside the launch.  Needs n <= GEMM_BATCH_MAX.
-int launch_gemm_chain(cpp_ctx* ctx, const GemmArgs* list, int n, int nslots);
 int launch_copy_cols(cpp_ctx* ctx, float* dst, long ldd, int dcol0, const float* src, long lds_,
                      int scol0, int ncols, int rows);
 int launch_fill(cpp_ctx* ctx, float* dst, long ld, int col0, int ncols, int rows, float v);
@@ -352,14 +336,7 @@ struct DdpgHeadsArgs {
   const float *h1a, *h1ta; int ld_h1a, n1a;        // B x (n1a + 1)
   const float *W2, *W2_t;                          // [(n1a + 1)][n2a]
   float *h2a_out, *dz_h1a;                         // B x ld_h2a (first n2a columns), B x n1a
-  // optional (with n1a > 0): the inputs h1a / h1ta / h2c / h2tc are not there yet -- the layers that produce them were left by the
-  // level in front of them as np1 / np2 slices per row (GemmArgs::next_part, slice-major), which this kernel adds in slice order,
-  // plus the bias row, ReLU; the live networks' activations are written where the backward GEMMs read them (h1a_w, h2c_w).
-  const float *p1a, *p1ta, *b1a, *b1ta; int np1; float* h1a_w;     // [np1][B][n1a], bias [n1a]
-  const float *p2c, *p2tc, *b2c, *b2tc; int np2; float* h2c_w;     // [np2][B][n2c], bias [n2c]
 };
-#define HEADS_NP1_MAX 7
-#define HEADS_NP2_MAX 13
 #define DDPG_HEADS_MAX_WGS 256
 size_t ddpg_heads_lds_bytes(const DdpgHeadsArgs& h);
 bool ddpg_heads_supported(const DdpgHeadsArgs& h);

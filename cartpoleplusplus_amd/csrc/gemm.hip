@@ -31,7 +31,7 @@
 // quarter of the workgroups, each four times as long, on a chip the 1 x 1 tiling does not fill either.  Kept for the record and for
 // larger problems.  Every output sums its products in the same order in both (same K split over the waves, same k order inside a
 // round): bit-identical results.
-template <bool VA, bool VB, int S, bool COH = false, bool NEXT = false>
+template <bool VA, bool VB, int S>
 __device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (*red)[GEMM_RED]) {
 #ifdef GEMM_CLOCK
   const unsigned long long c0 = __builtin_amdgcn_s_memrealtime();
@@ -64,10 +64,6 @@ __device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (
   // k = K is in range as a whole; its tail is cleared by selects.
   typedef unsigned gemm_u4 __attribute__((ext_vector_type(4)));
   constexpr int OOB = 0x7FFFFF00;
-  // COH (a producer problem of a chained launch, gemm_chain_kernel): the outputs are written through with sc1 stores.  The consumers'
-  // loads stay plain: no L2 / L1 can hold a line of a producer's output before the producer is complete (caches are invalidated at
-  // the launch boundary and nobody reads those buffers before the counter is full), so the first touch fetches the written-through
-  // data.  (sc1 on the consumers' loads sends ALL their operand traffic past the L2: 60 us per launch instead of 16 for two levels.)
   constexpr int AUX = 0;
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(g.A), 0, (int)((((long)(g.M - 1) * g.sAm + (long)(g.K - 1) * g.sAk) + 1) * 4), 0x00020000);
@@ -77,20 +73,6 @@ __device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (
 #pragma unroll
   for (int i = 0; i < S; ++i) { abase[i] = (int)((long)mrow[i] * g.sAm * 4); bbase[i] = (int)((long)ncol[i] * g.sBn * 4); }
   const int ask = (int)(g.sAk * 4), bsk = (int)(g.sBk * 4);
-  // next layer's slice (GemmArgs::next_part): wave 0 requests the 16 rows of next_W it will need in front of everything else
-  // (step s of column tile c: row 16 tn + 4 s + lj, column 16 c + li; rows / columns outside the matrix come back as zero)
-  unsigned nxt[(NEXT && S == 1) ? GEMM_NEXT_TILES : 1][4];
-  const bool do_next = NEXT && S == 1 && g.next_W != nullptr && wave == 0;          // (uniform per wave; NEXT: only gemm_batch_next_kernel carries the registers)
-  if (NEXT && S == 1 && do_next) {
-    const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.next_W), 0, g.next_K * g.next_N * 4, 0x00020000);
-#pragma unroll
-    for (int c = 0; c < GEMM_NEXT_TILES; ++c)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int kk = tn * 16 + 4 * s + lj, nn = c * 16 + li;
-        nxt[c][s] = __builtin_amdgcn_raw_buffer_load_b32(rn, (kk < g.next_K && nn < g.next_N) ? (kk * g.next_N + nn) * 4 : OOB, 0, 0);
-      }
-  }
   // A wave's rounds are independent until the MFMAs: ALL operand loads of up to GEMM_R rounds are issued before the first
   // one is used.  Same k order, same summation order as a plain loop.
   constexpr int R = GEMM_R;
@@ -155,7 +137,6 @@ __device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (
 #endif
   if (wave != 0) return;
   double sq = 0.0;
-  float tile_v[4] = {0.f, 0.f, 0.f, 0.f};             // (S == 1) this lane's outputs as stored, zero outside the matrix
 #pragma unroll
   for (int ti = 0; ti < S; ++ti)
 #pragma unroll
@@ -180,15 +161,10 @@ __device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (
         }
       }
       else if (g.epi == GE_MUL_TANH_GRAD) { const float y = g.Y[(long)row * g.ldy + n]; v = v * (1.f - y * y); }
-      if (COH) __hip_atomic_store(g.C + ((long)row * g.ldc + n), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else g.C[(long)row * g.ldc + n] = v;
+      g.C[(long)row * g.ldc + n] = v;
       sq += (double)v * (double)v;
-      if (NEXT && S == 1) tile_v[i] = v;
       if (g.epi == GE_ACTOR_HEAD) { const float y = g.Y[(long)row * g.ldy + n]; g.C2[(long)row * g.ldc2 + n] = -v * (1.f - y * y); }
-      else if (g.C2) {
-        if (COH) __hip_atomic_store(g.C2 + ((long)row * g.ldc2 + n), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else g.C2[(long)row * g.ldc2 + n] = v;
-      }
+      else if (g.C2) g.C2[(long)row * g.ldc2 + n] = v;
     }
   }
 #ifdef GEMM_CLOCK
@@ -196,34 +172,6 @@ __device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (
     printf("GEMMCLK M %d N %d K %d tile %d (blk %d): loop %.2f us, reduce+barrier %.2f, epilogue %.2f (start tick %llu)\n", g.M, g.N, g.K, tile, (int)blockIdx.x,
            (c1 - c0) / 100.0, (c2 - c1) / 100.0, (__builtin_amdgcn_s_memrealtime() - c2) / 100.0, c0 % 100000000ull);
 #endif
-  if (NEXT && S == 1 && do_next) {
-    // the tile sits in the accumulator layout (row 4 lj + i, column li); as the A operand of the next layer it is wanted as
-    // (row li, k = 4 s + lj): once through LDS (the cross-wave reduction's buffer is free: the other waves are gone)
-    float* tb = &red[0][0];
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) tb[(4 * lj + i) * 16 + li] = tile_v[i];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float av[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) av[s] = tb[li * 16 + 4 * s + lj];
-    const int ctiles = (g.next_N + 15) >> 4;
-#pragma unroll
-    for (int c = 0; c < GEMM_NEXT_TILES; ++c) {
-      if (c < ctiles) {                                // (uniform)
-        f32x4 pa = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) pa = MFMA16(av[s], __uint_as_float(nxt[c][s]), pa);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = tm * 16 + 4 * lj + i, nn = c * 16 + li;
-          if (row < g.M && nn < g.next_N) g.next_part[((long)tn * g.M + row) * g.next_N + nn] = pa[i];
-        }
-      }
-    }
-  }
   if (g.sq_part) {                                   // (uniform) this workgroup's share of the gradient list's squared norm, fixed order
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
     if (lane == 0) g.sq_part[tile] = sq;
@@ -231,7 +179,6 @@ __device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (
 }
 
 // an operand that is contiguous in k is read with 16-byte loads; long-K problems take 2 x 2 sub-tiles (uniform per problem)
-template <bool COH = false, bool NEXT = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, float (*red)[GEMM_RED]) {
   const bool va = g.sAk == 1, vb = g.sBk == 1;
 #if GEMM_SUB_MIN_K < 100000      // (not instantiated in the shipped build: gemm_sub() is 1 for every problem)
@@ -243,10 +190,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile, float (*r
     return;
   }
 #endif
-  if (va && vb) gemm_tile_t<true, true, 1, COH, NEXT>(g, tile, red);
-  else if (va) gemm_tile_t<true, false, 1, COH, NEXT>(g, tile, red);
-  else if (vb) gemm_tile_t<false, true, 1, COH, NEXT>(g, tile, red);
-  else gemm_tile_t<false, false, 1, COH, NEXT>(g, tile, red);
+  if (va && vb) gemm_tile_t<true, true, 1>(g, tile, red);
+  else if (va) gemm_tile_t<true, false, 1>(g, tile, red);
+  else if (vb) gemm_tile_t<false, true, 1>(g, tile, red);
+  else gemm_tile_t<false, false, 1>(g, tile, red);
 }
 
 // Workgroup -> tile, XCD-aware: workgroup b of a launch runs on XCD b mod 8 (round-robin dispatch), each XCD has its own L2, and
@@ -280,82 +227,6 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(const GemmBatch gb) {
   gemm_tile(gb.g[p], gemm_xcd_tile(blockIdx.x, gb.tile_start[p], gb.tile_start[p + 1] - gb.tile_start[p]), red);
 }
 
-// Two dependent levels of GEMMs in one launch -- an EXPERIMENT, off unless CPP_GEMM_CHAIN=1 in the ablation build (OpGraph::run).
-// Producers come first in the grid, so they are dispatched first (a workgroup is never dispatched before one with a lower index
-// on its XCD): a consumer that spins holds its slot only after every producer that shares its XCD's queue has one.  A producer
-// tile writes its outputs through (sc1 stores), waits for their acknowledgement and adds one to its problem's counter; a
-// consumer tile waits for its producers' counters to reach their tile counts and runs.  The counters are zero between launches:
-// the last consumer tile to pass its wait clears them.  Same tiles, same order of sums as the separate launches: bit-identical
-// outputs (tests/test_gpu_fullsize.py::test_chained_gemm_levels_...).
-// Measured (cfg3, four levels = 42.7 us per minibatch as separate launches; profiles/experiments/r03_gemm_chain.txt):
-//   agent-scope fence pair per tile (buffer_wbl2 sc1 / buffer_inv sc1: each walks the XCD's L2)   2 launches, 212 us
-//   sc1 stores + sc1 operand loads, no fences (all consumer operand traffic past the L2)           2 launches, 121 us
-//   sc1 stores, plain loads (this code)                                                           2 launches, 110 us
-//   ... the same without the waits (wrong results; signals kept)                                  40.4 us
-//   ... without waits and signals                                                                 33.1 us
-//   ... and with plain stores: the tiles of two levels side by side, no dependency at all         29.0 us
-// i.e. even a free synchronisation would win 14 us of 351, and the real one loses: ~1500 resident consumer workgroups polling one
-// address serialise at the memory side (~10-20 ns per device-scope access to one line; a longer s_sleep changes nothing), and
-// the producers' ~800 counter updates cost 7 us for the same reason.  A level is not "mostly its start and its end": its tiles
-// are.  Kept for the record; one launch per level stays.
-__global__ __launch_bounds__(256) void gemm_chain_kernel(const GemmBatch gb) {
-  __shared__ float red[3][GEMM_RED];
-  int p = 0;
-  while (p + 1 < gb.n && (int)blockIdx.x >= gb.tile_start[p + 1]) ++p;
-  const GemmArgs& g = gb.g[p];
-  if (g.wait_slot[0]) {                                // (uniform per workgroup)
-    if (threadIdx.x == 0) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        if (g.wait_slot[i])
-          while (__hip_atomic_load(gb.chain + g.wait_slot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)g.wait_cnt[i])
-            __builtin_amdgcn_s_sleep(4);
-      const unsigned passed = __hip_atomic_fetch_add(gb.chain, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (passed + 1u == (unsigned)gb.chain_consumers)
-        for (int i = 0; i <= gb.chain_slots; ++i) __hip_atomic_store(gb.chain + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (orders the operand loads behind the wait; coherence is the loads' own sc1)
-  }
-  const int tile = gemm_xcd_tile(blockIdx.x, gb.tile_start[p], gb.tile_start[p + 1] - gb.tile_start[p]);
-  // An agent-scope fence pair (buffer_wbl2 sc1 / buffer_inv sc1 per tile) walks the XCD's whole L2 each time: measured 100 us per
-  // launch.  Instead the producers' outputs are written through (sc1 stores); the release is then only "my stores have been
-  // acknowledged" (vmcnt(0)) in front of the counter's atomic add.
-  if (g.signal_slot) gemm_tile<true>(g, tile, red);
-  else gemm_tile<false>(g, tile, red);
-  if (g.signal_slot && threadIdx.x < 64) {             // wave 0 stored the tile (gemm_tile_t's epilogue); the others returned early
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);                     // (vmcnt(0): every store of this wave is acknowledged)
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(gb.chain + g.signal_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-int launch_gemm_chain(cpp_ctx* ctx, const GemmArgs* list, int n, int nslots) {
-  if (n > GEMM_BATCH_MAX || nslots + 1 > GEMM_CHAIN_SLOTS || !ctx->gemm_chain) { cpp_set_error("launch_gemm_chain: %d problems / %d counters", n, nslots); return 1; }
-  GemmBatch gb;
-  gb.n = n; gb.tile_start[0] = 0; gb.chain = ctx->gemm_chain; gb.chain_consumers = 0; gb.chain_slots = nslots;
-  for (int i = 0; i < n; ++i) {
-    gb.g[i] = list[i];
-    const int t = gemm_tiles(list[i].M, list[i].N, list[i].K);
-    gb.tile_start[i + 1] = gb.tile_start[i] + t;
-    if (list[i].wait_slot[0]) gb.chain_consumers += t;
-  }
-  prof_begin(ctx);
-  hipLaunchKernelGGL(gemm_chain_kernel, dim3(gb.tile_start[n]), dim3(256), 0, ctx->stream, gb);
-  LAUNCH_CHECK();
-  prof_end(ctx, K_GEMM);
-  return 0;
-}
-
-// ... with GemmArgs::next_part: the tiles also leave their slice of the next layer's sum (an experiment, CPP_FC_NEXT=1 in the
-// ablation build: rt_ddpg.cpp)
-__global__ __launch_bounds__(256) void gemm_batch_next_kernel(const GemmBatch gb) {
-  __shared__ float red[3][GEMM_RED];
-  int p = 0;
-  while (p + 1 < gb.n && (int)blockIdx.x >= gb.tile_start[p + 1]) ++p;
-  gemm_tile<false, true>(gb.g[p], gemm_xcd_tile(blockIdx.x, gb.tile_start[p], gb.tile_start[p + 1] - gb.tile_start[p]), red);
-}
-
 int launch_gemm(cpp_ctx* ctx, const GemmArgs& g) {
   const int tiles = gemm_tiles(g.M, g.N, g.K);
   prof_begin(ctx);
@@ -368,19 +239,15 @@ int launch_gemm(cpp_ctx* ctx, const GemmArgs& g) {
 int launch_gemm_batch(cpp_ctx* ctx, const GemmArgs* list, int n) {
   for (int i0 = 0; i0 < n; i0 += GEMM_BATCH_MAX) {
     const int cnt = n - i0 < GEMM_BATCH_MAX ? n - i0 : GEMM_BATCH_MAX;
-    bool next = false;
-    for (int i = 0; i < cnt; ++i) next = next || list[i0 + i].next_W != nullptr;
-    if (cnt == 1 && !next) { int rc = launch_gemm(ctx, list[i0]); if (rc) return rc; continue; }
+    if (cnt == 1) { int rc = launch_gemm(ctx, list[i0]); if (rc) return rc; continue; }
     GemmBatch gb;
     gb.n = cnt; gb.tile_start[0] = 0;
     for (int i = 0; i < cnt; ++i) {
       gb.g[i] = list[i0 + i];
       gb.tile_start[i + 1] = gb.tile_start[i] + gemm_tiles(gb.g[i].M, gb.g[i].N, gb.g[i].K);
     }
-    gb.chain = nullptr; gb.chain_consumers = gb.chain_slots = 0;
     prof_begin(ctx);
-    if (next) hipLaunchKernelGGL(gemm_batch_next_kernel, dim3(gb.tile_start[cnt]), dim3(256), 0, ctx->stream, gb);
-    else hipLaunchKernelGGL(gemm_batch_kernel, dim3(gb.tile_start[cnt]), dim3(256), 0, ctx->stream, gb);
+    hipLaunchKernelGGL(gemm_batch_kernel, dim3(gb.tile_start[cnt]), dim3(256), 0, ctx->stream, gb);
     LAUNCH_CHECK();
     prof_end(ctx, K_GEMM);
   }

@@ -13,13 +13,6 @@
 // left as one partial per workgroup; whoever reads the loss adds them in order.
 #include "common.h"
 
-// the slices path (DdpgHeadsArgs::p1a / p2c: an experiment, rt_ddpg.cpp CPP_FC_NEXT) exists in the ablation build only: compiled into the
-// release kernel it cost 1.1 us per launch without ever running (12.5 vs 11.4 us under rocprofv3)
-#ifdef CPP_ABLATION
-constexpr bool HEADS_SLICES = true;
-#else
-constexpr bool HEADS_SLICES = false;
-#endif
 constexpr int HEADS_THREADS = 256, HEADS_TEAM = 64, HEADS_ROWS = HEADS_THREADS / HEADS_TEAM, HEADS_AMAX = 8;
 constexpr int HEADS_NW4 = 5;                           // 16-byte chunks of [W3; b3] per thread: (n2c + A + 1) * n3 + slack <= 20 * 256
 constexpr int HEADS_NW4P = 5;                          // the same for [W2; b2] of the optional actor layer
@@ -99,8 +92,6 @@ __global__ __launch_bounds__(HEADS_THREADS) void ddpg_heads_kernel(const DdpgHea
   }
   heads_u4 w2v[HEADS_NW4P], w2tv[HEADS_NW4P];
   float x1v[2] = {0.f, 0.f}, x1tv[2] = {0.f, 0.f};
-  float p1v[2][HEADS_NP1_MAX], p1tv[2][HEADS_NP1_MAX], b1v[2], b1tv[2];       // (slices of the layer in front: summed below, behind ALL loads)
-  float p2v[HEADS_NP2_MAX], p2tv[HEADS_NP2_MAX], b2v = 0.f, b2tv = 0.f;
   float xav = 0.f, xtav = 0.f;                         // n2a, n2c <= 64: one element per lane
   if (n1a) {
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(h.W2), 0, (n1a + 1) * n2a * 4, 0x00020000);
@@ -111,56 +102,18 @@ __global__ __launch_bounds__(HEADS_THREADS) void ddpg_heads_kernel(const DdpgHea
       w2v[n] = __builtin_amdgcn_raw_buffer_load_b128(rw, i * 16, 0, 0);
       w2tv[n] = __builtin_amdgcn_raw_buffer_load_b128(rwt, i * 16, 0, 0);
     }
-    if (HEADS_SLICES && h.p1a) {   // the layer that produces h1a / h1ta was left as np1 slices per row by the level in front of it (GemmArgs::next_part).
-      // Branch-free loads through bounded descriptors (a slice index >= np1, a row >= B or a unit >= n1a asks behind the end and gets
-      // zero): with `in range ? load : 0` every load sat in a basic block of its own behind an s_waitcnt vmcnt(0) -- 54 round trips.
-      const int OOB = 0x7FFFFF00;
-      const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(h.p1a), 0, h.np1 * h.B * n1a * 4, 0x00020000);
-      const __amdgpu_buffer_rsrc_t r1t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(h.p1ta), 0, h.np1 * h.B * n1a * 4, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rb1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(h.b1a), 0, n1a * 4, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rb1t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(h.b1ta), 0, n1a * 4, 0x00020000);
-#pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        const int j = t + n * HEADS_TEAM;
-        const bool ok = rv && j < n1a;
-        b1v[n] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb1, ok ? j * 4 : OOB, 0, 0));
-        b1tv[n] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb1t, ok ? j * 4 : OOB, 0, 0));
-#pragma unroll
-        for (int p = 0; p < HEADS_NP1_MAX; ++p) {
-          const int off = ok ? ((p * h.B + row) * n1a + j) * 4 : OOB;
-          p1v[n][p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1, off, 0, 0));
-          p1tv[n][p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1t, off, 0, 0));
-        }
-      }
-    } else {
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
       const int j = t + n * HEADS_TEAM;
       x1v[n] = (rv && j < n1a) ? h.h1a[(long)row * h.ld_h1a + j] : 0.f;
       x1tv[n] = (rv && j < n1a) ? h.h1ta[(long)row * h.ld_h1a + j] : 0.f;
     }
-    }
   } else {
     xav = (rv && t < n2a) ? h.h2a[(long)row * h.ld_h2a + t] : 0.f;
     xtav = (rv && t < n2a) ? h.h2ta[(long)row * h.ld_h2a + t] : 0.f;
   }
   float xcv = 0.f, xtcv = 0.f;
-  if (HEADS_SLICES && h.p2c) {     // likewise the critics' layer in front of the concat layer: np2 slices per row
-    const int OOB = 0x7FFFFF00;
-    const bool ok = rv && t < n2c;
-    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(h.p2c), 0, h.np2 * h.B * n2c * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r2t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(h.p2tc), 0, h.np2 * h.B * n2c * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(h.b2c), 0, n2c * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb2t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(h.b2tc), 0, n2c * 4, 0x00020000);
-    b2v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb2, ok ? t * 4 : OOB, 0, 0));
-    b2tv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb2t, ok ? t * 4 : OOB, 0, 0));
-#pragma unroll
-    for (int p = 0; p < HEADS_NP2_MAX; ++p) {
-      const int off = ok ? ((p * h.B + row) * n2c + t) * 4 : OOB;
-      p2v[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r2, off, 0, 0));
-      p2tv[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r2t, off, 0, 0));
-    }
-  } else {
+  {
     xcv = (rv && t < n2c) ? h.h2c[(long)row * h.ld_h2c + t] : 0.f;
     xtcv = (rv && t < n2c) ? h.h2tc[(long)row * h.ld_h2c + t] : 0.f;
   }
@@ -175,24 +128,6 @@ __global__ __launch_bounds__(HEADS_THREADS) void ddpg_heads_kernel(const DdpgHea
   for (int n = 0; n < 2; ++n) {
     const int i = tid + n * HEADS_THREADS;
     wov[n] = i < (n2a + 1) * A ? h.Wo[i] : 0.f; wotv[n] = i < (n2a + 1) * A ? h.Wo_t[i] : 0.f;
-  }
-  if (HEADS_SLICES && h.p1a) {     // (every load of the kernel has been issued) the slices' sums in slice order, bias, ReLU; the live networks' activations go
-                   // where the backward GEMMs read them
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      float sa = p1v[n][0], sta = p1tv[n][0];
-#pragma unroll
-      for (int p = 1; p < HEADS_NP1_MAX; ++p) { sa += p1v[n][p]; sta += p1tv[n][p]; }
-      x1v[n] = fmaxf(sa + b1v[n], 0.f); x1tv[n] = fmaxf(sta + b1tv[n], 0.f);
-      const int j = t + n * HEADS_TEAM;
-      if (rv && j < n1a) h.h1a_w[(long)row * h.ld_h1a + j] = x1v[n];
-    }
-    const bool ok = rv && t < n2c;
-    float sc_ = p2v[0], stc_ = p2tv[0];
-#pragma unroll
-    for (int p = 1; p < HEADS_NP2_MAX; ++p) { sc_ += p2v[p]; stc_ += p2tv[p]; }
-    xcv = ok ? fmaxf(sc_ + b2v, 0.f) : 0.f; xtcv = ok ? fmaxf(stc_ + b2tv, 0.f) : 0.f;
-    if (ok) h.h2c_w[(long)row * h.ld_h2c + t] = xcv;
   }
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
@@ -354,7 +289,6 @@ size_t ddpg_heads_lds_bytes(const DdpgHeadsArgs& h) {
 }
 
 bool ddpg_heads_supported(const DdpgHeadsArgs& h) {
-  if ((h.p1a || h.p2c) && !(HEADS_SLICES && h.n1a > 0 && h.p1a && h.p2c && h.np1 >= 1 && h.np1 <= HEADS_NP1_MAX && h.np2 >= 1 && h.np2 <= HEADS_NP2_MAX)) return false;
   if (h.n1a && !(h.n1a <= HEADS_N1MAX && (h.n2a & 1) == 0 &&
                  (h.n1a + 1) * h.n2a + HEADS_WSLACK + 4 <= 4 * HEADS_NW4P * HEADS_THREADS)) return false;
   return h.A <= HEADS_AMAX && h.n3 <= HEADS_N3P && h.n2a <= HEADS_TEAM && h.n2c <= HEADS_TEAM &&

@@ -82,8 +82,6 @@ extern "C" int cpp_ctx_create(int device_id, void* hip_stream, cpp_ctx** out) {
   HIP_CHECK(hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, device_id));
   HIP_CHECK(hipMalloc((void**)&c->sq_part, 2 * SQ_REGION * sizeof(double)));
   HIP_CHECK(hipMemsetAsync(c->sq_part, 0, 2 * SQ_REGION * sizeof(double), c->stream));
-  HIP_CHECK(hipMalloc((void**)&c->gemm_chain, GEMM_CHAIN_SLOTS * sizeof(unsigned)));
-  HIP_CHECK(hipMemsetAsync(c->gemm_chain, 0, GEMM_CHAIN_SLOTS * sizeof(unsigned), c->stream));
   c->sq_n[0] = c->sq_n[1] = -1;
   for (int& g : c->sq_conv_group) g = -1;
   *out = c;
@@ -112,7 +110,6 @@ extern "C" int cpp_ctx_destroy(cpp_ctx* c) {
   (void)hipEventDestroy(c->t0); (void)hipEventDestroy(c->t1);
   (void)hipEventDestroy(c->pe0); (void)hipEventDestroy(c->pe1);
   if (c->sq_part) (void)hipFree(c->sq_part);
-  if (c->gemm_chain) (void)hipFree(c->gemm_chain);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return CPP_OK;

@@ -11,8 +11,6 @@ struct cpp_ddpg {
   float* gradbuf; float *dq_da, *td, *dq, *loss_norms /* [0] loss [1] actor norm [2] critic norm */, *ones;
   double* norm_part;
   double* heads_part;                              // fused heads kernel: per-workgroup partial sums of td^2
-  float* fc_part[4];                               // slices of the layers in front of the heads kernel (GemmArgs::next_part): actor, target actor, critic, target critic
-  size_t fc_part_floats;
   int heads_grid, heads_B;                         // ... of the last graph built by compute_gradients (0: GEMM levels + td_kernel)
   int loss_parts, loss_B;                          // how cpp_ddpg_last_stats finds the loss of the last call: partials to add, or loss_norms[0]
   // graph replay of the full inner step
@@ -56,7 +54,6 @@ extern "C" int cpp_ddpg_create(cpp_ctx* ctx, cpp_net* actor, cpp_net* critic, cp
   d->h_replay_uid = 0; d->h_write_gen = 0; d->pre_variant = 0; d->h_B = 0; d->h_seed = 0;
   memset(d->slot_set, 0, sizeof(d->slot_set));
   d->heads_grid = d->heads_B = d->loss_parts = d->loss_B = 0;
-  memset(d->fc_part, 0, sizeof(d->fc_part)); d->fc_part_floats = 0;
   const int A = actor->spec.action_dim;
   int rc = dalloc(d->arena, &d->gradbuf, (size_t)(d->nA + d->nC));
   if (!rc) rc = dalloc(d->arena, &d->dq_da, (size_t)d->maxB * A);

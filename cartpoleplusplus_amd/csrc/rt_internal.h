@@ -181,47 +181,8 @@ struct OpGraph {
       for (int i : ready) if (!ops[i].is_gemm) RC(ops[i].fn());
       for (int i : ready) ops[i].done = true;
       remaining -= ready.size();
-      // EXPERIMENT (CPP_GEMM_CHAIN=1, ablation build; measured slower, gemm.hip): the GEMMs that become ready once this level's
-      // GEMMs are done join this level's launch (launch_gemm_chain: the dependency is kept per problem by counters inside it).
-      static const bool no_chain = !cpp_switch_set("CPP_GEMM_CHAIN");
-      std::vector<int> g1, g2;
-      for (int i : ready) if (ops[i].is_gemm) g1.push_back(i);
-      if (!no_chain && !g1.empty()) {
-        bool ok = true;
-        for (size_t i = 0; i < ops.size() && ok; ++i) {
-          if (ops[i].done || !ops[i].is_gemm) continue;
-          bool rdy = true; int from_g1 = 0;
-          for (int d : ops[i].deps) {
-            if (!ops[d].done) { rdy = false; break; }
-            if (ops[d].is_gemm && std::find(g1.begin(), g1.end(), d) != g1.end()) ++from_g1;
-          }
-          if (!rdy) continue;
-          if (from_g1 > 2) ok = false; else g2.push_back((int)i);      // (none: it waited for a non-GEMM op of this level, already in the stream)
-        }
-        if (!ok || g1.size() + g2.size() > GEMM_BATCH_MAX) g2.clear();
-      }
-      if (!g2.empty()) {
-        std::vector<int> slot(ops.size(), 0); int nslots = 0;
-        for (int c : g2) for (int d : ops[c].deps) if (ops[d].is_gemm && std::find(g1.begin(), g1.end(), d) != g1.end() && !slot[d]) slot[d] = ++nslots;
-        if (nslots + 1 > GEMM_CHAIN_SLOTS) g2.clear();
-        else {
-          for (int pass = 0; pass < 2; ++pass)            // producers first in the grid
-            for (int i : g1) if ((slot[i] != 0) == (pass == 0)) { GemmArgs g = ops[i].g; g.signal_slot = slot[i]; g.wait_slot[0] = g.wait_slot[1] = 0; batch.push_back(g); }
-          for (int c : g2) {
-            GemmArgs g = ops[c].g; g.signal_slot = 0; g.wait_slot[0] = g.wait_slot[1] = 0; int nw = 0;
-            for (int d : ops[c].deps) if (slot[d]) { g.wait_slot[nw] = slot[d]; g.wait_cnt[nw] = gemm_tiles(ops[d].g.M, ops[d].g.N, ops[d].g.K); ++nw; }
-            batch.push_back(g);
-          }
-          if (dbg) fprintf(stderr, "[opgraph] chained: %zu + %zu gemms, %d counters\n", g1.size(), g2.size(), nslots);
-          RC(launch_gemm_chain(ctx, batch.data(), (int)batch.size(), nslots));
-          for (int c : g2) ops[c].done = true;
-          remaining -= g2.size();
-        }
-      }
-      if (g2.empty()) {
-        for (int i : g1) batch.push_back(ops[i].g);
-        if (!batch.empty()) RC(launch_gemm_batch(ctx, batch.data(), (int)batch.size()));
-      }
+      for (int i : ready) if (ops[i].is_gemm) batch.push_back(ops[i].g);
+      if (!batch.empty()) RC(launch_gemm_batch(ctx, batch.data(), (int)batch.size()));
     }
     return CPP_OK;
   }

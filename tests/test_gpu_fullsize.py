@@ -366,37 +366,3 @@ def test_two_network_conv1_dw_workgroups_agree_with_the_single_network_kernel(tm
             assert h1 == h0, shape
 
 
-_CHAIN_SNIPPET = r"""
-import hashlib
-import numpy as np
-from tests.helpers import make_pair
-SHAPE, B = (64, 64, 3, 2, 3), 64
-agent, ref, _ = make_pair(SHAPE, B, True, replay_size=400)
-agent.replay_memory.fill_synthetic(300, seed=9)
-for i in range(3):
-    agent.train_step(B, 2)
-h = hashlib.sha256()
-for net in (agent.actor, agent.critic, agent.target_actor, agent.target_critic):
-    h.update(np.ascontiguousarray(net.get_params()).tobytes())
-print("CHAINSHA %s %.9g" % (h.hexdigest(), agent.trainer.last_stats()[0]))
-agent.close()
-"""
-
-
-def test_chained_gemm_levels_are_bit_identical_to_one_launch_per_level():
-    """launch_gemm_chain (an experiment kept in the ablation build, CPP_GEMM_CHAIN=1: two dependent levels of the MLP's GEMMs in one
-    launch, counters inside the launch keep the dependency) computes the same tiles with the same order of sums: six fused minibatch
-    updates must leave exactly the parameters that one launch per level leaves, in the ablation build and in the release build."""
-    import os, re, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = {}
-    for name, env in (("chained", {"CARTPOLEPP_ABLATION": "1", "CPP_GEMM_CHAIN": "1"}), ("levels", {"CARTPOLEPP_ABLATION": "1"}),
-                      ("release", {})):
-        r = subprocess.run([sys.executable, "-c", _CHAIN_SNIPPET], cwd=root, env=dict(os.environ, **env),
-                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
-        m = re.search(r"CHAINSHA (\S+) (\S+)", r.stdout.decode())
-        assert r.returncode == 0 and m, r.stdout.decode()[-1500:]
-        out[name] = m.group(1)
-    assert out["chained"] == out["levels"] == out["release"], out
-
-
