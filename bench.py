@@ -398,7 +398,7 @@ def main():
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; they come from separate
         # rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), committed under profiles/
         traffic, traffic_src = None, None
-        for rnd in ("r03", "r02", "r01"):
+        for rnd in ("r04", "r03", "r02", "r01"):
             try:
                 with open(os.path.join(ROOT, "profiles", "%s_pmc.json" % rnd)) as f:
                     pmc = json.load(f)

@@ -81,8 +81,7 @@ class RasterCartpole(SyntheticCartpole):
         channels that are ALMOST constant -- scales of several hundred on values that do not cancel exactly),
       * state_2 of a transition is state_1 of the next one (the env returns np.copy(self.state) each step).
 
-    Still a stand-in (a point-mass cart with a damped pole, no contact physics) for tests, smoke runs and bench.py's
-    `--inputs render`; the accelerated path never looks at how a frame was made.  Pixel values are f16(k/255) of 8-bit colours,
+    Still a stand-in (a point-mass cart with a damped pole, no contact physics) for tests and smoke runs; the accelerated path never looks at how a frame was made.  Pixel values are f16(k/255) of 8-bit colours,
     exactly what render_rgb produces (:239-243)."""
     SKY, GROUND, CART, POLE, BLIND = (135, 206, 235), (96, 96, 96), (200, 30, 30), (240, 200, 40), (222, 222, 222)
 

@@ -5,7 +5,7 @@
 # other BASELINE configs (cfg2, cfg4 = NAF, cfg5 with 6000 rows and with one GPU's 125 000-row u8 shard, r50, batch norm).
 # Outputs under gpurun_out/; profiles/make_profiles.py turns them into the committed summaries.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 python bench.py > $OUT/bench_$R.json 2> $OUT/bench_$R.err
@@ -29,6 +29,8 @@ run_cfg cfg2 --workload cfg2 --steps 100 --warmup 10
 run_cfg cfg4 --workload cfg4 --steps 100 --warmup 10
 run_cfg cfg5 --workload cfg5 --steps 30 --warmup 10
 run_cfg cfg5_shard --workload cfg5 --steps 30 --warmup 10 --replay-rows 125000 --replay-store u8
+# one GPU's share of configs[4]'s 10^6-row replay as the reference's own f16 store: 187 500 states x 983 040 B = 184 GB of the 288 GB
+run_cfg cfg5_shard_f16 --workload cfg5 --steps 30 --warmup 10 --replay-rows 125000 --replay-store f16
 run_cfg r50 --workload r50 --steps 100 --warmup 10
 run_cfg cfg3_bn --workload cfg3 --steps 50 --warmup 10 --use-batch-norm
 run_cfg cfg3_dp1 --workload cfg3 --steps 100 --warmup 10 --force-dp
