@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const BnBatch bb) {
     if (v3 > m) { m = v3; code = 3; }
     const long e = ((long)py * Wp + px) * C + o;
     nb.pool[(long)b * nb.pool_bstride + e] = m > 0.f ? m : 0.f;
-    nb.amax[(long)b * Hp * Wp * C + e] = (uint8_t)code;
+    nb.amax[(long)b * Hp * Wp * C + e] = (uint8_t)(code | (m > 0.f ? 4 : 0));      // (bit 2: POOL_ACTIVE, conv_kyo.h)
   }
 }
 
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const BnBatch bb) {
     const int py = y >> 1, px = x >> 1;
     if (py < Hp && px < Wp) {
       const long e = ((long)py * Wp + px) * C + o;
-      if (nb.pool[(long)b * nb.pool_bstride + e] > 0.f && nb.amax[(long)b * Hp * Wp * C + e] == (uint8_t)((y & 1) * 2 + (x & 1)))
+      if (nb.amax[(long)b * Hp * Wp * C + e] == (uint8_t)(4 | ((y & 1) * 2 + (x & 1))))      // (bit 2: the pooled output is > 0)
         dy = nb.dpool[(long)b * nb.dpool_bstride + e];
     }
     *zp = inv * ((dy - nb.means[o]) - zhat * nb.means[C + o]);

@@ -101,8 +101,10 @@ struct cpp_ctx {
 enum ConvInMode { IN_F16_WHITEN = 0, IN_F32_WHITEN = 1, IN_F32_PLAIN = 2, IN_DY = 3, IN_F32_FLIP = 4 };
 enum ConvEpi { EPI_RELU_POOL = 0, EPI_PLAIN = 1 };
 
+// (the arg-max code byte of a pooled cell: bits 0-1 = window position dy * 2 + dx of the first maximum, bit 2 = the pooled output is > 0)
+constexpr int POOL_ACTIVE = 4;
 // How to rebuild the gradient w.r.t. a conv's pre-activation output from the pooled-resolution
-// gradient: dY[b,y,x,o] = dpool[b,y/2,x/2,o] if amax == (y&1)*2+(x&1) and pool > 0 else 0.
+// gradient: dY[b,y,x,o] = dpool[b,y/2,x/2,o] if amax == (POOL_ACTIVE | (y&1)*2+(x&1)) else 0  (`pool` is no longer read by any backward kernel).
 struct DyDesc {
   const float* dpool; const float* pool; const uint8_t* amax;
   long dpool_bstride, pool_bstride;       // elements between images

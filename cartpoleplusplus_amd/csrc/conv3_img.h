@@ -54,7 +54,7 @@ __device__ __forceinline__ void conv3_img_half(const Conv3Ops& o, const float* i
         const int code = lower ? 2 + cb : ct;
         const int px = 2 * lj + h;
         out[(py * Hp + px) * nout + li] = mx > 0.f ? mx : 0.f;
-        amax[(py * Hp + px) * nout + li] = (uint8_t)code;
+        amax[(py * Hp + px) * nout + li] = (uint8_t)(code | (mx > 0.f ? POOL_ACTIVE : 0));
       }
     }
   }

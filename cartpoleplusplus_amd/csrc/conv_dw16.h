@@ -165,19 +165,18 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
       for (int q = 0; q < 4; ++q) tmask[k][tk][q] = 0u;
     }
   }
-  float rpv[NNET][3][NCELL], rdv[NNET][3][NCELL];   // (set 2: only the unit prologue, so that its three requests are in flight together)
+  float rdv[NNET][3][NCELL];   // (set 2: only the unit prologue, so that its three requests are in flight together)
   int rcd[NNET][3][NCELL];
-  __amdgpu_buffer_rsrc_t rp[NNET], rd[NNET], rc[NNET];
+  __amdgpu_buffer_rsrc_t rd[NNET], rc[NNET];
   auto dy_issue = [&](int py, int set) {
     const bool rowok = py >= 0 && py < Hp;           // uniform
 #pragma unroll
     for (int k = 0; k < NNET; ++k)
 #pragma unroll
       for (int c = 0; c < NCELL; ++c) {
-        rpv[k][set][c] = 0.f; rdv[k][set][c] = 0.f; rcd[k][set][c] = 0;
+        rdv[k][set][c] = 0.f; rcd[k][set][c] = 0;
         if (rowok && cact[c]) {
           const int vo = cvo[c], so = py * Wp * nout * 4;
-          rpv[k][set][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rp[k], vo, so, 0));
           rdv[k][set][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd[k], vo, so, 0));
           rcd[k][set][c] = __builtin_amdgcn_raw_buffer_load_b8(rc[k], vo >> 2, so >> 2, 0);
         }
@@ -192,7 +191,7 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int c = 2 * tk + j;
-          const float g = rpv[k][set][c] > 0.f ? rdv[k][set][c] : 0.f;
+          const float g = (rcd[k][set][c] & 4) ? rdv[k][set][c] : 0.f;      // bit 2 of the code byte: the pooled output was > 0 (conv_kyo.h: POOL_ACTIVE)
           if (count) dbsum[k][c] += g;
           const float v = g * sc[k];
           const _Float16 h = (_Float16)v;
@@ -205,7 +204,7 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
         }
 #pragma unroll
         for (int pc = 0; pc < NPC; ++pc) tpc[k][tk][pc] = pk[0][pc] | (pk[1][pc] << 16);
-        const int c0 = rcd[k][set][2 * tk], c1 = rcd[k][set][2 * tk + 1];
+        const int c0 = rcd[k][set][2 * tk] & 3, c1 = rcd[k][set][2 * tk + 1] & 3;
 #pragma unroll
         for (int q = 0; q < 4; ++q) tmask[k][tk][q] = (c0 == q ? 0x0000FFFFu : 0u) | (c1 == q ? 0xFFFF0000u : 0u);
       }
@@ -292,7 +291,6 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
 #pragma unroll
     for (int k = 0; k < NNET; ++k) {
       const ConvArgs& ak = batch.a[by + k];
-      rp[k] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ak.dy.pool + (long)ub * ak.dy.pool_bstride), 0, Hp * Wp * nout * 4, 0x00020000);
       rd[k] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ak.dy.dpool + (long)ub * ak.dy.dpool_bstride), 0, Hp * Wp * nout * 4, 0x00020000);
       rc[k] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(ak.dy.amax + (long)ub * Hp * Wp * nout), 0, Hp * Wp * nout, 0x00020000);
     }

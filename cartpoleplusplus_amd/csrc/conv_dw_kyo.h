@@ -162,17 +162,16 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_dw_kyo_kernel(const Conv
   // request the cells of pooled row py (zero outside the image) into raw register set `set`; dy_conv turns them into
   // (masked gradient, code) one step later, so the global latency hides under a step's MFMAs.  Each cell is counted
   // once for the bias gradient.
-  float rpv[2][NCELL], rdv[2][NCELL];
+  float rdv[2][NCELL];
   int rcd[2][NCELL];
   auto dy_issue = [&](const __amdgpu_buffer_rsrc_t& rp, const __amdgpu_buffer_rsrc_t& rd,
                       const __amdgpu_buffer_rsrc_t& rc, int py, int set) {
     const bool rowok = py >= 0 && py < Hp;           // uniform
 #pragma unroll
     for (int c = 0; c < NCELL; ++c) {
-      rpv[set][c] = 0.f; rdv[set][c] = 0.f; rcd[set][c] = 0;
+      rdv[set][c] = 0.f; rcd[set][c] = 0;
       if (rowok && cact[c]) {
         const int vo = (tid + CONV_THREADS * c) * 4, so = py * Wp * nout * 4;
-        rpv[set][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rp, vo, so, 0));
         rdv[set][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, vo, so, 0));
         rcd[set][c] = __builtin_amdgcn_raw_buffer_load_b8(rc, vo >> 2, so >> 2, 0);
       }
@@ -181,8 +180,8 @@ __global__ __launch_bounds__(CONV_THREADS, 4) void conv_dw_kyo_kernel(const Conv
   auto dy_conv = [&](int set, bool count) {
 #pragma unroll
     for (int c = 0; c < NCELL; ++c) {
-      cg[c] = rpv[set][c] > 0.f ? rdv[set][c] : 0.f;
-      ccode[c] = rcd[set][c];
+      cg[c] = (rcd[set][c] & 4) ? rdv[set][c] : 0.f;      // bit 2 of the code byte: the pooled output was > 0
+      ccode[c] = rcd[set][c] & 3;
       if (count) dbsum[c] += cg[c];
     }
   };

@@ -124,17 +124,16 @@ __device__ __forceinline__ void conv_dwb16_body(const ConvArgsN& batch, int unit
 #pragma unroll
     for (int pc = 0; pc < NPC; ++pc) cpc[c][pc] = 0;
   }
-  float rpv[3][NCELL], rdv[3][NCELL];
+  float rdv[3][NCELL];
   int rcd[3][NCELL];
   auto dy_issue = [&](const __amdgpu_buffer_rsrc_t& rp, const __amdgpu_buffer_rsrc_t& rd,
                       const __amdgpu_buffer_rsrc_t& rc, int py, int set) {
     const bool rowok = py >= 0 && py < Hp;           // uniform
 #pragma unroll
     for (int c = 0; c < NCELL; ++c) {
-      rpv[set][c] = 0.f; rdv[set][c] = 0.f; rcd[set][c] = 0;
+      rdv[set][c] = 0.f; rcd[set][c] = 0;
       if (rowok && cact[c]) {
         const int vo = (tid + CONV_THREADS * c) * 4, so = py * Wp * nout * 4;
-        rpv[set][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rp, vo, so, 0));
         rdv[set][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, vo, so, 0));
         rcd[set][c] = __builtin_amdgcn_raw_buffer_load_b8(rc, vo >> 2, so >> 2, 0);
       }
@@ -143,8 +142,8 @@ __device__ __forceinline__ void conv_dwb16_body(const ConvArgsN& batch, int unit
   auto dy_conv = [&](int set, bool count) {
 #pragma unroll
     for (int c = 0; c < NCELL; ++c) {
-      cg[c] = rpv[set][c] > 0.f ? rdv[set][c] : 0.f;
-      ccode[c] = rcd[set][c];
+      cg[c] = (rcd[set][c] & 4) ? rdv[set][c] : 0.f;      // bit 2 of the code byte: the pooled output was > 0
+      ccode[c] = rcd[set][c] & 3;
       if (count) dbsum[c] += cg[c];
       dwb_split3(cg[c], cpc[c][0], cpc[c][1], cpc[c][2]);
     }

@@ -65,10 +65,9 @@ __device__ __forceinline__ float dy_value(const DyDesc& d, int b, int y, int x, 
   const int py = y >> 1, px = x >> 1;
   if (py >= d.Hp || px >= d.Wp) return 0.f;
   const long e = (long)(py * d.Wp + px) * nch + ch;
-  const float pv = d.pool[(long)b * d.pool_bstride + e];
   const float g = d.dpool[(long)b * d.dpool_bstride + e];
   const int code = d.amax[(long)b * d.Hp * d.Wp * nch + e];
-  return (pv > 0.f && code == ((y & 1) * 2 + (x & 1))) ? g : 0.f;
+  return code == (4 | ((y & 1) * 2 + (x & 1))) ? g : 0.f;      // (bit 2: the pooled output was > 0 -- POOL_ACTIVE, conv_kyo.h)
 }
 
 template <int CIN, int KS, int XTW, int IN_MODE>
@@ -91,9 +90,9 @@ __device__ __forceinline__ void conv_stage_tile(float* lds, const ConvArgs& a, i
       float gmv = 0.f; int code = -1;
       if (py >= 0 && py < d.Hp && px >= 0 && px < d.Wp) {
         const long e = (long)(py * d.Wp + px) * CIN + c;
-        const float pv = d.pool[(long)b * d.pool_bstride + e];
-        gmv = pv > 0.f ? d.dpool[(long)b * d.dpool_bstride + e] : 0.f;
-        code = d.amax[(long)b * d.Hp * d.Wp * CIN + e];
+        const int raw = d.amax[(long)b * d.Hp * d.Wp * CIN + e];
+        gmv = (raw & 4) ? d.dpool[(long)b * d.dpool_bstride + e] : 0.f;      // (bit 2: POOL_ACTIVE, conv_kyo.h)
+        code = raw & 3;
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -385,7 +384,7 @@ __global__ __launch_bounds__(CONV_THREADS, conv_wps(CIN, KS, XTW)) void conv_fwd
               if (px < Wp) {
                 const long e = (long)(py * Wp + px) * a.nout + li;
                 a.out[(long)b * a.out_bstride + e] = fmaxf(m, 0.f);
-                a.out_amax[(long)b * Hp * Wp * a.nout + e] = (uint8_t)code;
+                a.out_amax[(long)b * Hp * Wp * a.nout + e] = (uint8_t)(code | (m > 0.f ? 4 : 0));      // (bit 2: POOL_ACTIVE, conv_kyo.h)
               }
             }
           }
@@ -465,8 +464,9 @@ struct DyStager {
       if (pr < PR && py < d.Hp && px < d.Wp) {
         const long e = (long)(py * d.Wp + px) * a.nout + o;
         g[i] = d.dpool[(long)b * d.dpool_bstride + e];
-        pv[i] = d.pool[(long)b * d.pool_bstride + e];
-        code[i] = d.amax[(long)b * d.Hp * d.Wp * a.nout + e];
+        const int raw = d.amax[(long)b * d.Hp * d.Wp * a.nout + e];
+        pv[i] = (raw & 4) ? 1.f : 0.f;      // (bit 2: POOL_ACTIVE, conv_kyo.h)
+        code[i] = raw & 3;
       }
     }
   }
@@ -560,9 +560,9 @@ __device__ __forceinline__ void conv_dw_body(const ConvArgsN& batch, const int b
         float gv = 0.f; int cd = 255;
         if (py < a.dy.Hp && px < a.dy.Wp) {
           const long e = (long)(py * a.dy.Wp + px) * a.nout + o;
-          const float pvv = a.dy.pool[(long)b * a.dy.pool_bstride + e];
-          gv = pvv > 0.f ? a.dy.dpool[(long)b * a.dy.dpool_bstride + e] : 0.f;
-          cd = a.dy.amax[(long)b * a.dy.Hp * a.dy.Wp * a.nout + e];
+          const int raw = a.dy.amax[(long)b * a.dy.Hp * a.dy.Wp * a.nout + e];
+          gv = (raw & 4) ? a.dy.dpool[(long)b * a.dy.dpool_bstride + e] : 0.f;      // (bit 2: POOL_ACTIVE, conv_kyo.h)
+          cd = raw & 3;
         }
         gm[pp * DW_GP + o] = gv; gc[pp * DW_GP + o] = (unsigned char)cd;
       }

@@ -623,7 +623,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
       for (int e = 0; e < 2; ++e) {
         const bool lower = bot[2 * e] > top[2 * e];
         const float mx = lower ? bot[2 * e] : top[2 * e];
-        code[e] = lower ? 2 + __float_as_int(bot[2 * e + 1]) : __float_as_int(top[2 * e + 1]);
+        code[e] = (lower ? 2 + __float_as_int(bot[2 * e + 1]) : __float_as_int(top[2 * e + 1])) | (mx > 0.f ? POOL_ACTIVE : 0);
         pv[e] = mx > 0.f ? mx * inv : 0.f;
       }
       if (fuse3 && live) lds_store(c3adr[i], prs * (C3_PW * C3_C * 4), (f32x2){pv[0], pv[1]});      // conv3's input row, in LDS

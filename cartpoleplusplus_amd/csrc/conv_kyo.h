@@ -39,6 +39,9 @@ __device__ __forceinline__ void lds_store(uint32_t addr, int byte_off, const T& 
   *reinterpret_cast<__attribute__((address_space(3))) T*>((uintptr_t)(addr + (uint32_t)byte_off)) = v;
 }
 
+// Arg-max code byte of a pooled cell: bits 0-1 = the window position dy * 2 + dx of the first maximum, bit 2 (POOL_ACTIVE) = the pooled
+// output is > 0, i.e. the ReLU lets the cell's gradient through -- the backward kernels rebuild dY from (pooled gradient, code) and never
+// read the pooled OUTPUT again (round 4; rounds 1-3 read it for this one bit: 21 MB per conv1-dW launch at cfg3).
 constexpr int KYO_NO = 10;                         // filters per layer (base_network.py:103,111,119)
 
 template <int CIN, int KS, int XT, int IPW>
@@ -169,7 +172,7 @@ __device__ __forceinline__ void conv_fwd_kyo_body(const ConvArgsN& batch, const 
   // (masked gradient, code) pair serves the two dY rows of its pooled row (requested one row ahead)
   constexpr int NCELL = DX ? (IPW * (G::WPAD / 2) * NO + CONV_THREADS - 1) / CONV_THREADS : 1;
   bool qact[NCELL]; uint32_t qdst[NCELL]; int qvo[NCELL], qvd[NCELL], qco[NCELL];
-  float qg[NCELL], qpv[NCELL], qdv[NCELL]; int qcode[NCELL], qrc[NCELL];
+  float qg[NCELL], qdv[NCELL]; int qcode[NCELL], qrc[NCELL];
   const int dyWp = W >> 1, dyHp = H >> 1;
   const __amdgpu_buffer_rsrc_t rs_pool = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.dy.pool + (DX ? (long)b0 * a.dy.pool_bstride : 0)), 0, DX ? (int)(nimg * a.dy.pool_bstride * 4) : 0, 0x00020000);
@@ -189,17 +192,16 @@ __device__ __forceinline__ void conv_fwd_kyo_body(const ConvArgsN& batch, const 
       qvo[c] = (int)((long)im * a.dy.pool_bstride + e) * 4;
       qvd[c] = (int)((long)im * a.dy.dpool_bstride + e) * 4;
       qco[c] = im * dyHp * dyWp * CIN + e;
-      qg[c] = 0.f; qcode[c] = 0; qpv[c] = 0.f; qdv[c] = 0.f; qrc[c] = 0;
+      qg[c] = 0.f; qcode[c] = 0; qdv[c] = 0.f; qrc[c] = 0;
     }
   }
   auto dy_issue = [&](int py) {
     const bool rowok = py >= 0 && py < dyHp;         // uniform
 #pragma unroll
     for (int c = 0; c < NCELL; ++c) {
-      qpv[c] = 0.f; qdv[c] = 0.f; qrc[c] = 0;
+      qdv[c] = 0.f; qrc[c] = 0;
       if (rowok && qact[c]) {
         const int so = py * dyWp * CIN;
-        qpv[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_pool, qvo[c], so * 4, 0));
         qdv[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_dpool, qvd[c], so * 4, 0));
         qrc[c] = __builtin_amdgcn_raw_buffer_load_b8(rs_amax, qco[c], so, 0);
       }
@@ -207,7 +209,7 @@ __device__ __forceinline__ void conv_fwd_kyo_body(const ConvArgsN& batch, const 
   };
   auto dy_conv = [&]() {
 #pragma unroll
-    for (int c = 0; c < NCELL; ++c) { qg[c] = qpv[c] > 0.f ? qdv[c] : 0.f; qcode[c] = qrc[c]; }
+    for (int c = 0; c < NCELL; ++c) { qg[c] = (qrc[c] & POOL_ACTIVE) ? qdv[c] : 0.f; qcode[c] = qrc[c] & 3; }
   };
   auto dy_store = [&](int slot, int ry) {
 #pragma unroll
@@ -503,7 +505,7 @@ __device__ __forceinline__ void conv_fwd_kyo_body(const ConvArgsN& batch, const 
 #if defined(KYO_ABL_NOSTORE) || defined(KYO_ABL_NOCODE)
             if (mx == 123.456f)
 #endif
-            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)code, amax_rsrc, (int)coe[i], orow, 0);
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(code | (mx > 0.f ? POOL_ACTIVE : 0)), amax_rsrc, (int)coe[i], orow, 0);
           }
         }
         __builtin_amdgcn_wave_barrier();

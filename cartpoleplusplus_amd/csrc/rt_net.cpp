@@ -648,7 +648,7 @@ extern "C" int cpp_net_get_pool(cpp_net* n, int which, int B, float* out) {
     std::vector<uint8_t> tmp(cnt);
     HIP_CHECK(hipMemcpyAsync(tmp.data(), n->ws[0].amax[which - 11], cnt, hipMemcpyDeviceToHost, n->ctx->stream));
     HIP_CHECK(hipStreamSynchronize(n->ctx->stream));
-    for (size_t i = 0; i < cnt; ++i) out[i] = (float)tmp[i];
+    for (size_t i = 0; i < cnt; ++i) out[i] = (float)(tmp[i] & 3);      // (bit 2 of the byte: "the pooled output is > 0", conv_kyo.h POOL_ACTIVE)
     return CPP_OK;
   }
   ARG_CHECK(n->spec.pixel && which >= 1 && which <= 3, "cpp_net_get_pool: which=%d (pixel nets, 1..3)", which);
