@@ -135,7 +135,12 @@ struct K16Geom {
   static constexpr int PS = PADDED ? 1120 : 4 * NO * 16, GS = PADDED ? 256 : NO * 16, SLAB = PADDED ? 5632 : KS * 4 * NO * 16;
 #endif
   static constexpr int WLB = NCH * NPC * SLAB;             // bytes
-  static constexpr int EF = 2 * 2 * 8 * XT * NO * 2;       // floats per wave: (value, code) of the two rows of a pool pair, two pairs (the writer of pair r runs under the rows of pair r + 1)
+#ifdef K16_ABL_OCC3      // (occupancy experiment, WRONG results: one pair-buffer set so that three workgroups fit a CU's LDS)
+#define K16_SETS 1
+#else
+#define K16_SETS 2
+#endif
+  static constexpr int EF = K16_SETS * 2 * 8 * XT * NO * 2;       // floats per wave: (value, code) of the two rows of a pool pair, two pairs (the writer of pair r runs under the rows of pair r + 1)
   // conv2's instance for 32x32 inputs can run conv3 as its tail: the two pooled 16x16 images of the workgroup, zero-haloed
   static constexpr int N3 = (B16 && XT == 1 && IPW == 2) ? C3_IPW * C3_IMGF * 4 + 16 : 0;
   // f16 mode: the border table E [2 P + 1 row classes][NO][x = 0, 1, W - 2, W - 1] (floats, in accumulator units) and the pivots [CIN] (halves)
@@ -239,7 +244,9 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     float* bpart = reinterpret_cast<float*>(opart + (B16 ? 0 : NU));      // [NU][NB]
     float* scl = bpart + (B16 ? 0 : NU * NB);         // [CIN] whitening scale, [CIN] p_c - mu_c
     float* dmu = scl + CIN;
+#ifndef K16_ABL_OCC3
     static_assert(B16 || (((CIN + 1) & ~1) + NU) * 8 + (NU * NB + 2 * CIN) * 4 <= 4 * G::EF * 4, "the setup's scratch fits the pool-pair buffers");
+#endif
     // branch-free: every load of the build is in flight before the first use
 #pragma unroll
     for (int n = 0; n < NUW; ++n) {
@@ -432,7 +439,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   uint32_t wadr[KS][NT];
   uint32_t eadr[NT];
   float biast[NT];
-  float2* ev = ebuf + swave * (2 * 2 * 8 * XT * NO);
+  float2* ev = ebuf + swave * (K16_SETS * 2 * 8 * XT * NO);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int j = 16 * t + li;
@@ -597,7 +604,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     if (PLAIN || half >= NC) return;
     const int i = half < NC ? half : 0;
     const int prs = (pr >= 0 && pr < Hp) ? pr : 0;
-    const uint32_t ca = cadr[i] + (uint32_t)((prs & 1) * (2 * 8 * XT * NO) * 8);
+    const uint32_t ca = cadr[i] + (uint32_t)((prs & (K16_SETS - 1)) * (2 * 8 * XT * NO) * 8);
     wtop = lds_load<f32x4>(ca, 0); wbot = lds_load<f32x4>(ca, (8 * XT * NO) * 8);
   };
   auto writer_half = [&](const int half, const int pr) {
@@ -737,7 +744,9 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #pragma unroll
             for (int v = 0; v < 4; ++v)
 #ifndef K16_ABL_NOMASK
+#ifndef K16_ABL_NOMASK
               if (G::vgpr_may_need_mask(ch, m, v)) u[v] = (u[v] & emask[ch][m][v]) | ecst[ch][m][v];
+#endif
 #endif
             af[pa][m] = u;
           }
@@ -803,7 +812,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
                                                             (int)eadr[t] + ((m * 16 + r) * NO) * 4, y * W * nout * 4, 0);
                 }
               } else if (y >= 0) {
-                const uint32_t ea = eadr[t] + (uint32_t)((((y >> 1) & 1) * 2 + par) * (8 * XT * NO) * 8);
+                const uint32_t ea = eadr[t] + (uint32_t)((((y >> 1) & (K16_SETS - 1)) * 2 + par) * (8 * XT * NO) * 8);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                   const float z0 = zc[2 * h], z1 = zc[2 * h + 1];

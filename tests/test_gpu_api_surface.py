@@ -139,3 +139,34 @@ def test_debug_renderings(tmp_path, capsys):
             if os.path.exists(f):
                 os.remove(f)
         agent.close()
+
+
+def test_precision_knob_selects_the_exact_product_kernels_and_is_frozen_once_a_trainer_exists():
+    """include/cartpolepp_abi.h, cpp_ctx_set_precision: FAST (two f16 pieces / six bf16 products) and EXACT (three / nine) are both
+    in the RELEASE library.  The two modes give different last bits (they are different kernels), both within the parity bar of the
+    float64 oracle; the mode cannot change under a trainer whose captured graphs hold the other mode's kernels."""
+    import numpy as np
+    from cartpoleplusplus_amd import _lib
+    from tests.helpers import make_pair
+    shape, B = (32, 32, 3, 2, 3), 16
+    out = {}
+    for mode in ("fast", "exact"):
+        agent, ref, _ = make_pair(shape, B, True, seed=4, replay_size=200, exact_products=(mode == "exact"))
+        try:
+            assert agent.actor.ctx.precision == mode
+            agent.replay_memory.fill_synthetic(150, seed=9)
+            idx = np.random.default_rng(2).integers(0, 150, B).astype(np.int32)
+            agent.train_step(B, 1, idxs=idx)
+            out[mode] = np.concatenate([n.get_params() for n in agent.networks()])
+            other = "exact" if mode == "fast" else "fast"
+            try:
+                agent.actor.ctx.set_precision(other)
+                raise AssertionError("the precision mode changed under a live trainer")
+            except RuntimeError as e:
+                assert "trainer" in str(e)
+            agent.actor.ctx.set_precision(mode)           # (the current mode again: accepted)
+        finally:
+            agent.close()
+    d = np.abs(out["fast"] - out["exact"])
+    assert d.max() > 0 and d.max() < 1e-5 * max(1.0, float(np.abs(out["exact"]).max())), float(d.max())
+    _lib.default_context().set_precision("fast")
