@@ -18,7 +18,7 @@ struct cpp_ddpg {
   cpp_batch* step_batch;
   // graph replay of ONE minibatch on host-drawn rows, no target update (cpp_ddpg_train_rows: the reference's literal loop)
   hipGraph_t rgraph; hipGraphExec_t rgexec; bool rgraph_ok; int rg_B; uint64_t rg_replay_uid;
-  hipGraph_t dgraph; hipGraphExec_t dgexec; bool dgraph_ok; int dg_B, dg_nb; uint64_t dg_seed, dg_replay_uid; cpp_comm* dg_comm;   // the data-parallel step (default mode)
+  hipGraph_t dgraph; hipGraphExec_t dgexec; bool dgraph_ok; int dg_B, dg_nb; uint64_t dg_seed, dg_replay_uid; cpp_comm* dg_comm; bool dgraph_refused;   // the data-parallel step (default mode)
   // graph replay of the data-parallel half step (sample + both gradient sets)
   // three variants: 0 samples its own minibatch; 1 / 2 find it presampled (by the previous call's rider, conv1_dw_gather.hip)
   // in the second / first set of slot arrays.  One key for all three.
@@ -49,7 +49,7 @@ extern "C" int cpp_ddpg_create(cpp_ctx* ctx, cpp_net* actor, cpp_net* critic, cp
   d->nA = actor->nparams; d->nC = critic->nparams;
   d->graph = nullptr; d->gexec = nullptr; d->graph_ok = false; d->step_batch = nullptr; d->g_replay_uid = 0;
   d->rgraph = nullptr; d->rgexec = nullptr; d->rgraph_ok = false; d->rg_B = 0; d->rg_replay_uid = 0;
-  d->dgraph = nullptr; d->dgexec = nullptr; d->dgraph_ok = false; d->dg_B = d->dg_nb = 0; d->dg_seed = d->dg_replay_uid = 0; d->dg_comm = nullptr;
+  d->dgraph = nullptr; d->dgexec = nullptr; d->dgraph_ok = false; d->dg_B = d->dg_nb = 0; d->dg_seed = d->dg_replay_uid = 0; d->dg_comm = nullptr; d->dgraph_refused = false;
   memset(d->hg, 0, sizeof(d->hg)); d->dp_local = 0; d->sq_cnt[0] = d->sq_cnt[1] = 0;
   d->h_replay_uid = 0; d->h_write_gen = 0; d->pre_variant = 0; d->h_B = 0; d->h_seed = 0;
   memset(d->slot_set, 0, sizeof(d->slot_set));
@@ -835,13 +835,24 @@ extern "C" int cpp_ddpg_dp_train_step(cpp_ddpg* d, cpp_replay* r, cpp_comm* c, i
     // launches per minibatch: 0.946 of the fused step at world size 1.)
     if (!d->step_batch) RC(cpp_batch_create(ctx, d->maxB, r->elems, r->A, &d->step_batch));
     if (ctx->prof) return step_body(d, r, B, n_batches, nullptr, seed, true, true, c);
+    if (d->dgraph_refused) return step_body(d, r, B, n_batches, nullptr, seed, true, true, c);
     if (!d->dgraph_ok || d->dg_B != B || d->dg_nb != n_batches || d->dg_seed != seed || d->dg_replay_uid != r->uid || d->dg_comm != c) {
       if (d->dgexec) { (void)hipGraphExecDestroy(d->dgexec); d->dgexec = nullptr; }
       if (d->dgraph) { (void)hipGraphDestroy(d->dgraph); d->dgraph = nullptr; }
       d->dgraph_ok = false;
       RC(step_body(d, r, B, n_batches, nullptr, seed, true, true, c));      // eager pass: kernel attributes; it is also this call's step
       HIP_CHECK(hipStreamSynchronize(ctx->stream));
-      RC(capture_into(ctx, &d->dgraph, &d->dgexec, [&] { return step_body(d, r, B, n_batches, nullptr, seed, true, true, c); }));
+      if (d->dgraph_refused) return CPP_OK;           // (capture failed once on this trainer: every step takes the eager sequence above)
+      // No N > 1 box has run this yet: if the runtime or RCCL refuses to capture / instantiate the step with the collective inside,
+      // the trainer keeps the SAME sequence as plain stream launches (identical arithmetic on every rank, no graph) instead of failing.
+      if (capture_into(ctx, &d->dgraph, &d->dgexec, [&] { return step_body(d, r, B, n_batches, nullptr, seed, true, true, c); }) != CPP_OK) {
+        (void)hipGetLastError();
+        if (d->dgexec) { (void)hipGraphExecDestroy(d->dgexec); d->dgexec = nullptr; }
+        if (d->dgraph) { (void)hipGraphDestroy(d->dgraph); d->dgraph = nullptr; }
+        d->dgraph_refused = true;
+        fprintf(stderr, "cartpolepp: the data-parallel step could not be captured as a hipGraph (%s); running it as stream launches\n", cpp_last_error());
+        return CPP_OK;
+      }
       d->dgraph_ok = true; d->dg_B = B; d->dg_nb = n_batches; d->dg_seed = seed; d->dg_replay_uid = r->uid; d->dg_comm = c;
       return CPP_OK;
     }

@@ -19,7 +19,7 @@ struct cpp_naf {
   hipGraph_t hgraph; hipGraphExec_t hexec; bool hgraph_ok; int h_B; uint64_t h_seed, h_replay_uid;
   // ONE minibatch on host-drawn rows up to (not including) the optimiser (cpp_naf_train_rows)
   hipGraph_t rgraph; hipGraphExec_t rgexec; bool rgraph_ok; int rg_B; uint64_t rg_replay_uid;
-  hipGraph_t dgraph; hipGraphExec_t dgexec; bool dgraph_ok; int dg_B, dg_nb; uint64_t dg_seed, dg_replay_uid; cpp_comm* dg_comm;   // the data-parallel step
+  hipGraph_t dgraph; hipGraphExec_t dgexec; bool dgraph_ok; int dg_B, dg_nb; uint64_t dg_seed, dg_replay_uid; cpp_comm* dg_comm; bool dgraph_refused;   // the data-parallel step
   // ... and including it, the loss coming back later (cpp_naf_train_rows_async / cpp_naf_loss_wait): pinned (loss, flag) slots
   hipGraph_t agraph; hipGraphExec_t agexec; bool agraph_ok; int ag_B; uint64_t ag_replay_uid;
   float* res_pin; hipEvent_t res_ev[CPP_NAF_TICKETS]; uint64_t next_ticket;
@@ -57,7 +57,7 @@ extern "C" int cpp_naf_create(cpp_ctx* ctx, cpp_net* value, cpp_net* tvalue, cpp
   f->graph = nullptr; f->gexec = nullptr; f->graph_ok = false; f->step_batch = nullptr; f->g_replay_uid = 0;
   f->sq_cnt = 0; f->step_bumped = false;
   f->rgraph = nullptr; f->rgexec = nullptr; f->rgraph_ok = false; f->rg_B = 0; f->rg_replay_uid = 0;
-  f->dgraph = nullptr; f->dgexec = nullptr; f->dgraph_ok = false; f->dg_B = f->dg_nb = 0; f->dg_seed = f->dg_replay_uid = 0; f->dg_comm = nullptr;
+  f->dgraph = nullptr; f->dgexec = nullptr; f->dgraph_ok = false; f->dg_B = f->dg_nb = 0; f->dg_seed = f->dg_replay_uid = 0; f->dg_comm = nullptr; f->dgraph_refused = false;
   f->agraph = nullptr; f->agexec = nullptr; f->agraph_ok = false; f->ag_B = 0; f->ag_replay_uid = 0;
   f->res_pin = nullptr; f->next_ticket = 0; memset(f->res_ev, 0, sizeof(f->res_ev));
   f->hgraph = nullptr; f->hexec = nullptr; f->hgraph_ok = false; f->h_B = 0; f->h_seed = 0; f->h_replay_uid = 0; f->dp_local = 0;
@@ -699,18 +699,28 @@ extern "C" int cpp_naf_dp_train_step(cpp_naf* f, cpp_replay* r, cpp_comm* c, int
     HIP_CHECK(hipSetDevice(ctx->device));
     if (!f->step_batch) RC(cpp_batch_create(ctx, f->maxB, r->elems, r->A, &f->step_batch));
     if (ctx->prof) return naf_step_body(f, r, B, n_batches, nullptr, seed, true, c);
+    if (f->dgraph_refused) return naf_step_body(f, r, B, n_batches, nullptr, seed, true, c);
     if (!f->dgraph_ok || f->dg_B != B || f->dg_nb != n_batches || f->dg_seed != seed || f->dg_replay_uid != r->uid || f->dg_comm != c) {
       if (f->dgexec) { (void)hipGraphExecDestroy(f->dgexec); f->dgexec = nullptr; }
       if (f->dgraph) { (void)hipGraphDestroy(f->dgraph); f->dgraph = nullptr; }
       f->dgraph_ok = false;
       RC(naf_step_body(f, r, B, n_batches, nullptr, seed, true, c));
       HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      if (f->dgraph_refused) return CPP_OK;
+      // (as cpp_ddpg_dp_train_step: a runtime / RCCL that refuses the capture leaves the same sequence as plain stream launches)
       HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
       const int rc = naf_step_body(f, r, B, n_batches, nullptr, seed, true, c);
       const hipError_t e = hipStreamEndCapture(ctx->stream, &f->dgraph);
-      if (rc) return rc;
-      if (e != hipSuccess) { cpp_set_error("hipStreamEndCapture -> %s", hipGetErrorString(e)); return CPP_ERR_HIP; }
-      HIP_CHECK(hipGraphInstantiate(&f->dgexec, f->dgraph, nullptr, nullptr, 0));
+      hipError_t ei = hipSuccess;
+      if (!rc && e == hipSuccess) ei = hipGraphInstantiate(&f->dgexec, f->dgraph, nullptr, nullptr, 0);
+      if (rc || e != hipSuccess || ei != hipSuccess) {
+        (void)hipGetLastError();
+        if (f->dgexec) { (void)hipGraphExecDestroy(f->dgexec); f->dgexec = nullptr; }
+        if (f->dgraph) { (void)hipGraphDestroy(f->dgraph); f->dgraph = nullptr; }
+        f->dgraph_refused = true;
+        fprintf(stderr, "cartpolepp: the data-parallel NAF step could not be captured as a hipGraph; running it as stream launches\n");
+        return CPP_OK;
+      }
       f->dgraph_ok = true; f->dg_B = B; f->dg_nb = n_batches; f->dg_seed = seed; f->dg_replay_uid = r->uid; f->dg_comm = c;
       return CPP_OK;
     }
