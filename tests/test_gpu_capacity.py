@@ -99,3 +99,40 @@ def test_run_98_memory_of_200000_rows_feeds_conv1_through_slots_at_the_top():
         assert np.abs(fused[1] - P0[1]).max() > 0 and np.isfinite(fused[0]).all()
     finally:
         agent.close()
+
+
+def test_cfg5_shard_as_the_reference_f16_store_allocates_and_trains_from_the_top():
+    """one GPU's share of configs[4]'s 10^6-row replay as the reference's OWN store type (f16,
+    replay_memory.py:32): 187 500 states x 983 040 B = 184 GB of the 288 GB.  The fused step reads conv1's images straight from the
+    store through the sampled slots (no materialised f16 minibatch, unlike the 8-bit shard): it must allocate, sample the whole
+    range, read the top of the store bit-exactly and train -- equal to the op-by-op path on a gathered copy of the same rows."""
+    import ctypes
+    from cartpoleplusplus_amd import _lib
+    shape, rows, B, seed = (128, 128, 3, 2, 5), 125000, 512, 5
+    agent, _ref, (aspec, cspec) = make_pair(shape, B, True, replay_size=rows)
+    try:
+        rm = agent.replay_memory
+        elems = rm.state_elems
+        assert rm.state_buffer_size == 187500 and rm.state_buffer_size * elems * 2 > 180e9
+        rm.fill_synthetic(rows, seed=seed)
+        top_slot = int(rm.state_2_idx[rows - 1])
+        assert top_slot * elems * 2 > 2 ** 37                           # byte offset of the last states: > 137 GB
+        assert np.array_equal(rm.state[top_slot].reshape(-1), LEVELS[synthetic_state_codes(top_slot, elems, seed)])
+        P0 = [n.get_params() for n in agent.networks()]
+        agent.train_step(B, 1)
+        idxs = np.empty(B, np.int32)
+        _lib.check(_lib.lib.cpp_replay_last_indexes(rm.handle, B, idxs.ctypes.data_as(ctypes.c_void_p)))
+        assert idxs.max() > 0.9 * rows and idxs.min() < 0.1 * rows
+        fused = [n.get_params() for n in agent.networks()]
+        for n, p in zip(agent.networks(), P0):
+            n.set_params(p)
+        batch = rm.batch(idxs=idxs)
+        agent.actor.train(batch); agent.critic.train(batch)
+        agent.target_actor.update_weights(); agent.target_critic.update_weights()
+        unfused = [n.get_params() for n in agent.networks()]
+        for spec, a, b in ((aspec, fused[0], unfused[0]), (cspec, fused[1], unfused[1]), (aspec, fused[2], unfused[2]), (cspec, fused[3], unfused[3])):
+            assert_flat_close(spec, a, b, rel=1e-5, what="fused step on the 184 GB f16 shard vs train ops on the gathered rows")
+            assert np.isfinite(a).all()
+        assert np.abs(fused[1] - P0[1]).max() > 0
+    finally:
+        agent.close()
