@@ -299,11 +299,11 @@ def main():
                 learner.train_step(t)
         parallelism = learner.describe()
 
-    def full_sync():
-        ctx.sync()
-        torch.cuda.synchronize()
+    def full_sync():      # stream idle, barrier, device idle (the barrier's own collective kernel included: with the barrier LAST its tail ran into
+        ctx.sync()        # the first steps of the timed region -- 1 ms of a 36 ms region, measured against the same steps without a barrier)
         if use_dp:
             dist.barrier()
+        torch.cuda.synchronize()
 
     # warm-up (also captures the hipGraphs for both call shapes)
     run(wgroups, tail)
@@ -316,10 +316,24 @@ def main():
     run(settle_groups, 0)
     warmup_steps_run = (wgroups + 1 + settle_groups) * BATCHES_PER_STEP + 2 * tail
     full_sync()
+    if use_dp:
+        # the barrier is a host-side collective of about a millisecond during which the chip idles and its clock drops: the first steps
+        # behind it ran 10-20 % slow (1.2 ms of a 36 ms region; the same steps without a barrier, or in the alternating blocks below,
+        # do not show it; one outer step behind the barrier was not enough, the clock takes tens of milliseconds to come back).  The settle
+        # steps run again behind the barrier -- themselves collective, so the ranks stay aligned -- and a device sync re-opens the region.
+        run(SETTLE_STEPS // BATCHES_PER_STEP, 0)
+        warmup_steps_run += SETTLE_STEPS // BATCHES_PER_STEP * BATCHES_PER_STEP
+        ctx.sync()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(groups, tail)
-    full_sync()
+    # this rank's K steps are done when its stream is idle; the closing barrier follows the clock read and the job's time is the MAX over
+    # the ranks of these local times (all ranks left the opening barrier together).  (Reading the clock behind the barrier added the
+    # collective's own host latency, ~1 ms at world size 1 = 2.7 % of a 100-step region, to every rank's time.)
+    ctx.sync()
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    full_sync()
     steps = groups * BATCHES_PER_STEP + tail
     per_rank = [round(steps / elapsed, 3)]
     if world > 1:
@@ -330,6 +344,31 @@ def main():
         elapsed = max(float(t.item()) for t in every)         # the MAX over the ranks is the job's time
     ms_per_step = 1e3 * elapsed / steps
     value = world * steps / elapsed
+
+    # ---- --force-dp at world size 1: the data-parallel graph against the single learner's fused graph IN THIS PROCESS, in alternating
+    # blocks (the two bench lines of a profile run come from two processes on a chip whose clock state drifts by a few per cent: paired
+    # runs gave 0.957 ... 0.990; the kernels differ by one sumsq launch, rocprof: 1782 vs 1770 us per five minibatches)
+    dp_vs_fused = None
+    if use_dp and world == 1 and learner is not None and args.sync_every == 1 and not args.overlap and hasattr(agent, "train_step"):
+        agent.train_step(B, BATCHES_PER_STEP); agent.train_step(B, BATCHES_PER_STEP)      # (captures the fused graph)
+        blocks, bg = 8, max(20, groups)
+        t_dp, t_fused = [], []
+        for blk in range(blocks):
+            for which in ((0, 1) if blk % 2 == 0 else (1, 0)):
+                ctx.sync()
+                tb = time.perf_counter()
+                for _ in range(bg):
+                    if which == 0:
+                        learner.train_step(BATCHES_PER_STEP)
+                    else:
+                        agent.train_step(B, BATCHES_PER_STEP)
+                ctx.sync()
+                (t_dp if which == 0 else t_fused).append(time.perf_counter() - tb)
+        n_blk = bg * BATCHES_PER_STEP
+        dp_vs_fused = {"dp_steps_per_sec": round(n_blk * blocks / sum(t_dp), 1), "fused_steps_per_sec": round(n_blk * blocks / sum(t_fused), 1),
+                       "ratio": round(sum(t_fused) / sum(t_dp), 4), "ratio_per_block_pair": [round(f / d, 4) for d, f in zip(t_dp, t_fused)],
+                       "blocks": blocks, "minibatches_per_block": n_blk,
+                       "how": "alternating blocks of the two hipGraphs on the same trainer, replay and stream, order swapped every pair"}
 
     # ---- per-kernel HIP-event pass (rank 0 reports) -> roofline of the dominant kernel, per-layer table
     ctx.prof_reset()
@@ -458,6 +497,7 @@ def main():
                    "parallelism": parallelism,
                    "global_steps_per_sec": round(steps / elapsed, 3),
                    "per_rank_steps_per_sec": per_rank,
+                   "dp_vs_fused_same_process": dp_vs_fused,
                    "conv_gflop_per_step": round(conv_flops_step / 1e9, 3),
                    "conv_gflop_per_step_as_the_reference_executes_it": (round(2.0 * B * (5 * F + 2 * Bk) / 1e9, 3) if kind == "ddpg" else None),
                    "mlp_gflop_per_step": mlp_gflop,

@@ -8,9 +8,13 @@ set -u
 R=${1:-r04}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
-python bench.py > $OUT/bench_$R.json 2> $OUT/bench_$R.err
 REPO=$PWD
+# ONLY=<config name> (environment): re-run one of the run_cfg configurations below and nothing else
+if [ -z "${ONLY:-}" ]; then
+python bench.py > $OUT/bench_$R.json 2> $OUT/bench_$R.err
+fi
 cd /tmp && export TMPDIR=/tmp
+if [ -z "${ONLY:-}" ]; then
 BENCH="python $REPO/bench.py --quick --steps 50 --warmup 10 --profile-steps 5"
 rm -rf $OUT/prof_$R $OUT/pmc_${R}_sq $OUT/pmc_${R}_fetch $OUT/pmc_${R}_write
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_$R -o k -- $BENCH > $OUT/prof_$R.json 2> $OUT/prof_$R.err
@@ -18,9 +22,11 @@ PB="python $REPO/bench.py --quick --steps 10 --warmup 5 --profile-steps 5"
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc_${R}_sq -o p -- $PB > /dev/null 2> $OUT/pmc_${R}_sq.err
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_${R}_fetch -o p -- $PB > /dev/null 2> $OUT/pmc_${R}_fetch.err
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_${R}_write -o p -- $PB > /dev/null 2> $OUT/pmc_${R}_write.err
+fi
 # the other configurations: one bench line and one kernel trace each
 run_cfg() {   # name, bench flags
   local name=$1; shift
+  if [ -n "${ONLY:-}" ] && [ "$ONLY" != "$name" ]; then return; fi
   python $REPO/bench.py --quick "$@" > $OUT/bench_${R}_$name.json 2> $OUT/bench_${R}_$name.err
   rm -rf $OUT/prof_${R}_$name
   timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_${R}_$name -o k -- python $REPO/bench.py --quick --profile-steps 5 "$@" > /dev/null 2> $OUT/prof_${R}_$name.err
@@ -34,9 +40,11 @@ run_cfg cfg5_shard_f16 --workload cfg5 --steps 30 --warmup 10 --replay-rows 1250
 run_cfg r50 --workload r50 --steps 100 --warmup 10
 run_cfg cfg3_bn --workload cfg3 --steps 50 --warmup 10 --use-batch-norm
 run_cfg cfg3_dp1 --workload cfg3 --steps 100 --warmup 10 --force-dp
+if [ -z "${ONLY:-}" ]; then
 # the reference's literal loop against the fused step (profiles/bench_host_path.py), and N = 2 as a plain command (gloo diagnostic)
 (cd $REPO && bash profiles/run_host_path.sh > /dev/null 2>&1)
 (cd $REPO && timeout 600 python bench.py --gpus 2 --diag-backend gloo --quick --steps 20 --warmup 5 > $OUT/bench_${R}_gpus2_gloo_diag.json 2> $OUT/bench_${R}_gpus2_gloo_diag.err)
+fi
 # keep the merge-back small: only the databases
 find $OUT/prof_${R}* $OUT/pmc_${R}_* -type f ! -name '*.db' -delete 2>/dev/null
 ls $OUT | grep $R | head -40
