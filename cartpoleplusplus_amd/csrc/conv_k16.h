@@ -43,6 +43,7 @@
 // (left / right SAME padding, the over-read past k = KROW) are cleared with per-lane AND masks, which only the
 // waves' border tiles apply; reads may touch up to 128 bytes before and 256 after an image (the arena pads).
 #pragma once
+#include <type_traits>
 #include "conv_kyo.h"
 #include "conv3_img.h"
 
@@ -430,6 +431,13 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   const unsigned long long pe1 = __builtin_amdgcn_s_memrealtime();
 #endif
 
+#ifdef K16_STAGGER      // (phase experiment: the waves in the odd wave slots of their SIMD start the row loop K16_STAGGER x 64 cycles late)
+  {
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    if (hwid & 1u) __builtin_amdgcn_s_sleep(K16_STAGGER);
+  }
+#endif
   const int swave = __builtin_amdgcn_readfirstlane(wave);
   const int simg = swave / G::STRIPS, sstrip = swave % G::STRIPS;
   const int sbimg = b0 + simg;
@@ -600,16 +608,16 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   // half: 0 / 1 = the parity of the output row this step completes; pr: the pooled row (< 0: none -- the stores go to an
   // out-of-range offset and are dropped, the instruction count stays).
   f32x4 wtop = {0.f, 0.f, 0.f, 0.f}, wbot = {0.f, 0.f, 0.f, 0.f};      // the half's (value, code) x 2 of the pair's two rows, requested at the top of the step
-  auto writer_load = [&](const int half, const int pr) {
+  auto writer_load = [&](const int half, const int pr, const bool sure = false) {      // sure: 0 <= pr < Hp is known (interior rows)
     if (PLAIN || half >= NC) return;
     const int i = half < NC ? half : 0;
-    const int prs = (pr >= 0 && pr < Hp) ? pr : 0;
+    const int prs = (sure || (pr >= 0 && pr < Hp)) ? pr : 0;
     const uint32_t ca = cadr[i] + (uint32_t)((prs & (K16_SETS - 1)) * (2 * 8 * XT * NO) * 8);
     wtop = lds_load<f32x4>(ca, 0); wbot = lds_load<f32x4>(ca, (8 * XT * NO) * 8);
   };
-  auto writer_half = [&](const int half, const int pr) {
+  auto writer_half = [&](const int half, const int pr, const bool sure = false) {
     if (PLAIN) return;
-    const bool live = pr >= 0 && pr < Hp;           // uniform
+    const bool live = sure || (pr >= 0 && pr < Hp);           // uniform
     if (half >= NC) {                               // (one lane set per pooled row: the other row's stores are dummies)
       if (ASYNC_A) {
 #pragma unroll
@@ -678,7 +686,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #if defined(K16_CLOCK_PROBE) || defined(K16_SPAN_PROBE)
   const unsigned long long pc0 = __builtin_readcyclecounter(), pr0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  for (int q0 = qbeg; q0 < qend; q0 += KS) {
+  auto block = [&](auto itag, const int q0) {
 #if K16_ROTATE_PRIO
     {  // issue arbitration is by priority, then age: the workgroups of the networks launched first ran ahead of their co-resident
        // partners (in-kernel span probe: 104 vs 125 us of a 119 us launch, 50 vs 67 us for conv2) and the younger ones finished
@@ -688,31 +696,35 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
       else if (pr == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
     }
 #endif
+    // INTERIOR rows (round 4): KS steps in which every output row completed is an interior row of the band (row class P, its pooled
+    // pair and the writer's pooled row exist, the next input row exists) -- the scalar bookkeeping of the general step (row class,
+    // band / image limits, dropped-store offsets: ~45 of its ~80 SALU instructions and 6 of its 11 branches) folds away.
+    constexpr bool IN = decltype(itag)::value;
 #pragma unroll
     for (int sq = 0; sq < KS; ++sq) {
       const int q = q0 + sq;
-      if (q >= qend) break;                          // uniform
+      if (!IN && q >= qend) break;                   // uniform
       constexpr int PD_BASE = (KS - P) % KS;
       const int pdone = (PD_BASE + sq) % KS;
       f32x4 ctv[NT];                                 // f16 mode: E[row class of the output row this step completes][o][x = 0, 1, W - 2, W - 1]
       if (!B16) {
         const int yc = q - P;                        // (rows in front of a band are dropped below: any class will do)
-        const int rc = yc < P ? (yc < 0 ? 0 : yc) : (yc >= H - P ? 2 * P - (H - 1 - yc) : P);
+        const int rc = IN ? P : (yc < P ? (yc < 0 ? 0 : yc) : (yc >= H - P ? 2 * P - (H - 1 - yc) : P));
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int clo = pdone * NO - 16 * t, chi = pdone * NO + NO - 1 - 16 * t;
           if (chi >= 0 && clo <= 15) ctv[t] = lds_load<f32x4>(ctadr[t] + (uint32_t)(rc * NO * 16), 0);
         }
       }
-      const int wy = q - P >= ymin ? q - P : -1;     // the output row this step completes (rows in front of the band: none)
+      const int wy = (IN || q - P >= ymin) ? q - P : -1;     // the output row this step completes (rows in front of the band: none)
       const int wlo = ymin >> 1;                     // first pooled row of the band
-      const int wpr = (wy >= 0 && (wy >> 1) - 1 >= wlo) ? (wy >> 1) - 1 : -1;
-      writer_load(wy & 1, wpr);                      // (its LDS reads land under chunk 0's MFMAs)
-      if (q >= H) writer_half(wy & 1, wpr);          // (the steps behind the image: no MFMAs to hide under)
-      if (q < H) {
+      const int wpr = (IN || (wy >= 0 && (wy >> 1) - 1 >= wlo)) ? (wy >> 1) - 1 : -1;
+      writer_load(wy & 1, wpr, IN);                  // (its LDS reads land under chunk 0's MFMAs)
+      if (!IN && q >= H) writer_half(wy & 1, wpr);   // (the steps behind the image: no MFMAs to hide under)
+      if (IN || q < H) {
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
-#ifdef K16_PRIO
+#ifdef K16_PRIO      // (experiments: priority K16_PRIO during a chunk's MFMAs, K16_PRIO_OUT outside)
           __builtin_amdgcn_s_setprio(K16_PRIO);
 #endif
           if (ASYNC_A) {
@@ -755,6 +767,9 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #pragma unroll
             for (int pa = NPA - 1; pa >= 0; --pa) {
               if (B16 && pa + pc > B16) continue;
+#ifdef K16_ABL_MFMA_PIECES      // (timing experiment, wrong results: only the first K16_ABL_MFMA_PIECES pieces' MFMAs are issued -- 0: none)
+              if (pc >= K16_ABL_MFMA_PIECES) continue;
+#endif
 #pragma unroll
               for (int m = 0; m < XT; ++m)
 #pragma unroll
@@ -768,13 +783,16 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
             // end of the chunk and the next chunk would open waiting for them)
             __builtin_amdgcn_sched_barrier(0);
             if (ch + 1 < NCH) load_b_piece(ch + 1, pc, wadr[sq]);
-            else if (q + 1 < H) load_b_piece(0, pc, wadr[(sq + 1) % KS]);
+            else if (IN || q + 1 < H) load_b_piece(0, pc, wadr[(sq + 1) % KS]);
             __builtin_amdgcn_sched_barrier(0);
           }
 #ifdef K16_PRIO
-          __builtin_amdgcn_s_setprio(0);
+#ifndef K16_PRIO_OUT
+#define K16_PRIO_OUT 0
 #endif
-          if (ch == 0) writer_half(wy & 1, wpr);
+          __builtin_amdgcn_s_setprio(K16_PRIO_OUT);
+#endif
+          if (ch == 0) writer_half(wy & 1, wpr, IN);
           if (ASYNC_A || q + 1 < H) load_a(ch, q + 1);   // this chunk's operands of the next row, a whole row period ahead (ASYNC_A:
                                                          // also behind the last row -- masked by the descriptor, never used -- so
                                                          // that the hand-counted waits see the same sequence in every row)
@@ -783,7 +801,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #ifdef K16_ABL_NOEPI
       const int y = (q == H + P - 1) ? q - P : -1;
 #else
-      const int y = q - P >= ymin ? q - P : -1;      // (rows in front of the band: partial sums, dropped like the rows above the image)
+      const int y = (IN || q - P >= ymin) ? q - P : -1;      // (rows in front of the band: partial sums, dropped like the rows above the image)
 #endif
       const int par = y & 1;
 #pragma unroll
@@ -796,7 +814,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
             for (int m = 0; m < XT; ++m) {
               // f16 mode: the border columns' data-independent remainder (file comment), requested from LDS before the row's MFMAs
               f32x4 zc = acc[m][t];
-              if (!B16 && y >= 0) {
+              if (!B16 && (IN || y >= 0)) {
                 if (m == 0) { zc[0] = fmaf(-fl, ctv[t][0], zc[0]); zc[1] = fmaf(-fl, ctv[t][1], zc[1]); }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -811,7 +829,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
                       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(zc[r] * inv), out_rsrc,
                                                             (int)eadr[t] + ((m * 16 + r) * NO) * 4, y * W * nout * 4, 0);
                 }
-              } else if (y >= 0) {
+              } else if (IN || y >= 0) {
                 const uint32_t ea = eadr[t] + (uint32_t)((((y >> 1) & (K16_SETS - 1)) * 2 + par) * (8 * XT * NO) * 8);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -826,8 +844,17 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
       }
       // (a wave's LDS instructions execute in order: the writer half of a later step reads what this step's lanes stored without a
       // wait in between; the compiler must only keep the order)
-      if (!PLAIN && y >= 0) { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+      if (!PLAIN && (IN || y >= 0)) { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
     }
+  };
+  {
+    auto interior = [&](const int q0) { return !PLAIN && q0 >= ymin + P + 2 && q0 >= 2 * P && q0 + KS < H && q0 + KS <= qend; };
+    int q0 = qbeg;
+#ifndef K16_NO_INTERIOR
+    for (; q0 < qend && !interior(q0); q0 += KS) block(std::false_type{}, q0);      // the band's first rows
+    for (; q0 < qend && interior(q0); q0 += KS) block(std::true_type{}, q0);
+#endif
+    for (; q0 < qend; q0 += KS) block(std::false_type{}, q0);                       // ... and its last ones
   }
   {  // the last pair(s): the two steps behind the loop would have carried their writer halves
     const int ylast = qend - 1 - P;                  // last output row of this workgroup's band
