@@ -549,7 +549,11 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 
   // ---- A operands: 16 bytes per lane and (tile, chunk) straight from the image row
   const int rowbytes = W * CIN * 2;
+#ifdef K16_ABL_SAMEIMG      // (timing experiment, wrong results: every workgroup reads image 0 / 1 -- the A operands come from L2, never from HBM)
+  void* const in_base = (void*)((const char*)(B16 ? (const void*)a.in_b16 : a.in) + ((long)(a.img_slot ? a.img_slot[sbimg & 1] : (sbimg & 1)) * a.in_bstride) * 2 - G::BIAS_BYTES);
+#else
   void* const in_base = (void*)((const char*)(B16 ? (const void*)a.in_b16 : a.in) + ((long)(a.img_slot ? a.img_slot[sbimg] : sbimg) * a.in_bstride) * 2 - G::BIAS_BYTES);
+#endif
   const int in_records = (B16 ? 2 * (int)a.plane_stride : 0) + H * rowbytes + G::BIAS_BYTES + 256;      // this image (B16: in its three planes) + the masked overhang
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(in_base, 0, in_records, 0x00020000);
   const k16_i32x4 in_desc = k16_raw_desc(in_base, in_records);      // the same descriptor for the inline-asm loads
@@ -851,8 +855,11 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     auto interior = [&](const int q0) { return !PLAIN && q0 >= ymin + P + 2 && q0 >= 2 * P && q0 + KS < H && q0 + KS <= qend; };
     int q0 = qbeg;
 #ifndef K16_NO_INTERIOR
-    for (; q0 < qend && !interior(q0); q0 += KS) block(std::false_type{}, q0);      // the band's first rows
-    for (; q0 < qend && interior(q0); q0 += KS) block(std::true_type{}, q0);
+    // (five chunks per row -- 30 channels -- sit at 254 VGPRs with the general step alone: the second copy of the loop spilled, 1125 -> 1173 us)
+    if constexpr (NCH <= 3) {
+      for (; q0 < qend && !interior(q0); q0 += KS) block(std::false_type{}, q0);      // the band's first rows
+      for (; q0 < qend && interior(q0); q0 += KS) block(std::true_type{}, q0);
+    }
 #endif
     for (; q0 < qend; q0 += KS) block(std::false_type{}, q0);                       // ... and its last ones
   }

@@ -84,12 +84,22 @@ def other_configs(rnd):
 
 def counters(con):
     out = {}
-    for name, ctr, n, mean in con.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
-                                          "group by kernel_name, counter_name"):
+    if isinstance(con, dict):      # agg.json of profiles/shrink_pmc.py
+        rows = [(name, ctr, v[0], v[1]) for name, cs in con.items() for ctr, v in cs.items()]
+    else:
+        rows = con.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name")
+    for name, ctr, n, mean in rows:
         s = short(name)
         if s:
             out.setdefault(s, {})[ctr] = (n, mean)
     return out
+
+
+def pmc_of(name):
+    agg = os.path.join(ROOT, "gpurun_out", name, "agg.json")
+    if os.path.exists(agg):
+        return json.load(open(agg))
+    return db_of(name)
 
 
 def main(rnd):
@@ -112,7 +122,7 @@ def main(rnd):
         for name, calls, tot, avg, pct in rows:
             f.write("| `%s` | %d | %.1f | %.3f | %.2f |\n" % (name, calls, tot, avg, pct))
         f.write("\n## bench.py JSON line of the same build (un-profiled default run, same box)\n\n```\n%s\n```\n" % bench_line)
-    sq, fe, wr = counters(db_of("pmc_%s_sq" % rnd)), counters(db_of("pmc_%s_fetch" % rnd)), counters(db_of("pmc_%s_write" % rnd))
+    sq, fe, wr = counters(pmc_of("pmc_%s_sq" % rnd)), counters(pmc_of("pmc_%s_fetch" % rnd)), counters(pmc_of("pmc_%s_write" % rnd))
     kernels = {}
     for k in sq:
         e = {"dispatches_sampled": sq[k]["SQ_WAVE_CYCLES"][0]}

@@ -22,6 +22,7 @@ PB="python $REPO/bench.py --quick --steps 10 --warmup 5 --profile-steps 5"
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc_${R}_sq -o p -- $PB > /dev/null 2> $OUT/pmc_${R}_sq.err
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_${R}_fetch -o p -- $PB > /dev/null 2> $OUT/pmc_${R}_fetch.err
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_${R}_write -o p -- $PB > /dev/null 2> $OUT/pmc_${R}_write.err
+python $REPO/profiles/shrink_pmc.py $OUT/pmc_${R}_sq $OUT/pmc_${R}_fetch $OUT/pmc_${R}_write      # (45 MB databases -> agg.json)
 fi
 # the other configurations: one bench line and one kernel trace each
 run_cfg() {   # name, bench flags
@@ -46,6 +47,6 @@ if [ -z "${ONLY:-}" ]; then
 (cd $REPO && timeout 600 python bench.py --gpus 2 --diag-backend gloo --quick --steps 20 --warmup 5 > $OUT/bench_${R}_gpus2_gloo_diag.json 2> $OUT/bench_${R}_gpus2_gloo_diag.err)
 fi
 # keep the merge-back small: only the databases
-find $OUT/prof_${R}* $OUT/pmc_${R}_* -type f ! -name '*.db' -delete 2>/dev/null
+find $OUT/prof_${R}* $OUT/pmc_${R}_* -type f ! -name '*.db' ! -name 'agg.json' -delete 2>/dev/null
 ls $OUT | grep $R | head -40
 cat $OUT/bench_$R.json | head -c 3000
