@@ -53,3 +53,20 @@ def test_bench_gpus_2_as_a_plain_command_launches_its_own_ranks():
     assert len(per_rank) == 2 and all(x > 0 for x in per_rank)
     assert d["value"] == pytest.approx(2 * d["config"]["global_steps_per_sec"], rel=1e-3)
     assert "dp2" in d["config"]["parallelism"]
+
+
+def test_bench_force_dp_compares_the_two_graphs_in_one_process():
+    """the data-parallel step (ncclAllReduce, norm and optimiser inside ONE hipGraph per outer step) against the single
+    learner's fused graph at world size 1 -- alternating blocks in the SAME process (two processes on one chip differ by its clock state).
+    The bar is the verdict's 0.98; measured 0.992-0.994 (profiles/r04_configs.md cfg3_dp1)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--quick", "--force-dp"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert "dp1" in d["config"]["parallelism"] and "RCCL" in d["config"]["parallelism"]
+    ab = d["config"]["dp_vs_fused_same_process"]
+    assert ab["blocks"] == 8 and len(ab["ratio_per_block_pair"]) == 8
+    assert ab["ratio"] >= 0.98, ab
+    assert d["value"] >= 0.97 * ab["dp_steps_per_sec"], (d["value"], ab)      # the timed region behind the barrier is not a slower one
