@@ -100,6 +100,9 @@ __device__ __forceinline__ void k16_split3(float x, unsigned short& h, unsigned 
 // vector-memory instructions issued AFTER the loads that are needed (they retire in order) -- which is a compile-time number
 // because every such instruction is issued unconditionally (disabled / out-of-image stores are dropped by their buffer
 // descriptor's range check instead of being branched around).
+// THE COUNTS HOLD FOR THE INSTRUCTION ORDER OF LLVM'S DEFAULT SCHEDULER.  Built with -mllvm -amdgpu-sched-strategy=iterative-ilp this
+// translation unit gives results that differ from run to run (4 of 10 runs of tests/test_gpu_distributed.py's cfg3 comparison;
+// profiles/experiments/r04_sched_strategy.txt): do not change the scheduling strategy of conv_fwd_k16.hip without re-deriving them.
 typedef int k16_i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ k16_i32x4 k16_raw_desc(const void* base, int num_records) {      // raw buffer, stride 0 (as make_buffer_rsrc)
   const unsigned long long b = (unsigned long long)base;
