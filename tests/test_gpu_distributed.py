@@ -169,3 +169,24 @@ def test_cli_data_parallel_mode_as_a_world_of_one(which, extra, capsys):
     stats = [json.loads(l.split("\t", 1)[1]) for l in out.splitlines() if l.startswith("STATS")]
     assert len(stats) >= 4 and any(np.isfinite(s["mean_losses"]) for s in stats), out[-500:]
     assert stats[-1]["replay_memory_stats"][">batch"] > 0
+
+
+def test_the_fused_cfg3_step_is_bit_reproducible_from_run_to_run():
+    """No kernel of the step may depend on timing (no float atomics, no reads that race a write): the same 30 minibatches from the same
+    state give the same parameter BITS, three times.  (Round 4: conv_fwd_k16.hip built under another LLVM scheduling strategy broke its
+    hand-counted vmcnt waits: the fused-vs-data-parallel comparison above differed in 4 of 10 runs, this test caught it in 1 of 6 at half
+    the length -- profiles/experiments/r04_sched_strategy.txt.)"""
+    runs = []
+    for _ in range(3):
+        agent, _ref, _ = make_pair((64, 64, 3, 2, 3), 256, True, replay_size=1024)
+        try:
+            agent.replay_memory.fill_synthetic(768, seed=11)
+            for _ in range(10):
+                agent.train_step(256, 3)
+            agent.actor.ctx.sync()
+            runs.append(_params(agent))
+        finally:
+            agent.close()
+    for other in runs[1:]:
+        for x, y in zip(runs[0], other):
+            assert np.array_equal(x, y), float(np.abs(x - y).max())
