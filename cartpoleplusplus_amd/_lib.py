@@ -17,6 +17,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _variant = os.environ.get("CARTPOLEPP_ABLATION", "")
 if _variant and not _variant.replace("_", "").isalnum():
     raise ImportError("cartpoleplusplus_amd: CARTPOLEPP_ABLATION=%r is not a build name" % _variant)
+if _variant == "exact":
+    raise ImportError("cartpoleplusplus_amd: CARTPOLEPP_ABLATION=exact names a build that no longer exists -- the exact-product "
+                      "arithmetic is a mode of the release library (Context.set_precision('exact'), --exact-products, "
+                      "bench.py --precision exact)")
 LIB_PATH = os.path.join(_HERE, "lib", "libcartpolepp_hip%s.so" % (
     "" if _variant in ("", "0") else "_ablation" if _variant == "1" else "_" + _variant))
 
@@ -128,6 +132,9 @@ SIGNATURES = {
     "cpp_naf_allreduce_grads": (_I, [_P, _P]),
     "cpp_naf_average_params": (_I, [_P, _P]),
     "cpp_naf_dp_train_step": (_I, [_P, _P, _P, _I, _I, _U64, _I]),
+    "cpp_naf_clear_numeric_error": (_I, [_P]),
+    "cpp_ddpg_dp_status": (_I, [_P, C.POINTER(_I), C.c_char_p, _I]),
+    "cpp_naf_dp_status": (_I, [_P, C.POINTER(_I), C.c_char_p, _I]),
     "cpp_naf_create": (_I, [_P, _P, _P, _P, _P, _I, C.POINTER(NafHyper), _PP]),
     "cpp_naf_destroy": (_I, [_P]),
     "cpp_naf_action": (_I, [_P, _P, _I, _I, _P]),

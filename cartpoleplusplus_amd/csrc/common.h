@@ -137,6 +137,7 @@ struct ConvArgs {
   // conv2 forward on the bf16 pipes only (n3_w != nullptr): the workgroup also runs conv3 + pool3 of its two images from the
   // pooled rows it has just produced (kept in LDS as zero-haloed 16x16 images: conv3_img.h) -- conv3's launch disappears
   const float* n3_w; const float* n3_bias; float* n3_out; long n3_out_bstride; uint8_t* n3_amax;
+  const void* wimg;          // conv1 on the f16 pipes: the network's prebuilt operand image (conv_rs16.h: conv1_image_kernel), or nullptr
 };
 
 // Same-geometry convolutions of several networks in ONE launch (blockIdx.y selects the descriptor): the
@@ -164,6 +165,7 @@ int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, co
 int launch_conv_dw(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, ConvArgs a, float* grad_w,
                    float* grad_b);
 size_t conv_dw_partial_floats(cpp_ctx* ctx, int cin, int ks, int nout);
+size_t conv_rs16_image_bytes();     // a network's conv1 operand image (conv_rs16.h)
 int flush_dw_reduce(cpp_ctx* ctx);     // one launch for every dW reduction queued by launch_conv_dw
 // A backward pass that fails half way (a geometry without a kernel, a launch error) must not leave its queued reductions behind:
 // they point into that network's buffers, which may be gone by the time the next pass flushes the queue.

@@ -116,6 +116,8 @@ int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, i
   if (!no_kyo && !no_k16 && in_mode == IN_F16_WHITEN && !dx_mode && a.B >= 2 && a.nout <= 10 && a.H >= 2) {
     bool handled = false;
     if (int grc = guard_band_check(batch, cin, "conv1 forward")) { prof_end(ctx, kid); return grc; }
+    rc = conv_fwd_rs16_dispatch(ctx, cin, ks, in_mode, plain_fwd, batch, &handled);
+    if (handled) { prof_end(ctx, kid == K_CONV1_FWD ? K_CONV1_FWD_F16X3 : kid); return rc; }
     rc = conv_fwd_k16_dispatch(ctx, cin, ks, in_mode, plain_fwd, batch, &handled);
     if (handled) { prof_end(ctx, kid == K_CONV1_FWD ? K_CONV1_FWD_F16X3 : kid); return rc; }
   }

@@ -1,0 +1,36 @@
+// conv1 forward, row-streaming with the weights in registers (conv_rs16.h): instantiations + geometry selection.
+#include <cstring>
+#include "conv_rs16.h"
+
+// 64 pixels wide (two 32-pixel strips, each with one image border), 18 channels (three 30-k chunks per row: 120 weight registers),
+// pooled output, one whitening table for the batch, FAST precision (two f16 pieces); everything else stays on conv_k16.h.
+int conv_fwd_rs16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool plain, const ConvArgsN& a, bool* handled) {
+  *handled = false;
+  static const bool off = cpp_switch_off("CPP_CONV_RS16");
+  const ConvArgs& a0 = a.a[0];
+  if (off || plain || cin != 18 || ks != 5 || in_mode != IN_F16_WHITEN || a0.W != 64 || a0.H < 16 || (a0.H & 1) || a0.nout != KYO_NO) return 0;
+  if (ctx && ctx->precision == CPP_PRECISION_EXACT) return 0;
+  for (int i = 0; i < a.n; ++i) {
+    if (a.a[i].white_bstride != 0 || a.a[i].wimg == nullptr) return 0;
+    if (((uintptr_t)a.a[i].in & 15) || (a.a[i].in_bstride & 7)) return 0;      // (16-byte row segments start 8-byte aligned)
+  }
+  *handled = true;
+  if (!ctx) return 0;
+  typedef Rs16Geom<18> G;
+  Conv1ImageArgsN ia; memset(&ia, 0, sizeof(ia)); ia.n = a.n;
+  for (int i = 0; i < a.n; ++i)
+    ia.a[i] = Conv1ImageArgs{a.a[i].w, a.a[i].bias, a.a[i].scale, a.a[i].shift, a.a[i].wscale, a.a[i].nout,
+                             reinterpret_cast<unsigned char*>(const_cast<void*>(a.a[i].wimg))};
+  constexpr int ilds = Rs16ImageLds<18>::BYTES;
+  static bool attr_done[CPP_MAX_DEVICES] = {};
+  if (!attr_done[cpp_dev_slot(ctx)]) {
+    HIP_CHECK(hipFuncSetAttribute((const void*)conv1_image_kernel<18>, hipFuncAttributeMaxDynamicSharedMemorySize, ilds));
+    attr_done[cpp_dev_slot(ctx)] = true;
+  }
+  hipLaunchKernelGGL(conv1_image_kernel<18>, dim3(a.n), dim3(CONV_THREADS), ilds, ctx->stream, ia);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(conv_fwd_rs16_kernel<18>, dim3((a0.B + 1) / 2, a.n), dim3(CONV_THREADS), 0, ctx->stream, a);
+  LAUNCH_CHECK();
+  return 0;
+}
+size_t conv_rs16_image_bytes() { return Rs16Geom<18>::REC_BYTES; }

@@ -25,9 +25,9 @@
 // The f32 weights V = W s are split into F16_PIECES f16 pieces
 // V 2^S = h + m (+ l) (h = f16(V 2^S), m = f16(rest), l = f16(rest); S puts the largest |V| just under 2^15), every
 // f16 x f16 product is exact in the f32 accumulator, and the MFMAs of a k chunk add  x * (h + m (+ l)).  With three pieces
-// (libcartpolepp_hip_exact.so) that is the f32-accumulated sum of exact products of the SAME operands the f32 kernel uses -- no
+// (CPP_PRECISION_EXACT) that is the f32-accumulated sum of exact products of the SAME operands the f32 kernel uses -- no
 // operand rounded to fewer than its 24 bits (pieces below the f16 normal range keep an absolute 2^-24-S floor, < 1e-9 of the
-// largest weight); with two (the release library) every weight is within one f32 ulp of itself (F16_PIECES below).  Two / three
+// largest weight); with two (CPP_PRECISION_FAST, the default) every weight is within 2^-22 of itself, about one f32 ulp (F16_PIECES below).  Two / three
 // 16-cycle MFMAs replace eight 32-cycle ones per 32 k values.
 //
 // Everything else is the (ky,o)-column formulation of conv_kyo.h: one input row per step, KS in-flight output rows
@@ -61,14 +61,13 @@ typedef unsigned k16_u32x4 __attribute__((ext_vector_type(4)));
 // Against the float64 oracle the six-product result is as close as the nine-product one (pooled conv2 output 4.47e-6 / 4.47e-6 abs
 // at magnitude 7.5, weight gradient 5.8e-7 / 6.0e-7 rel; the f32-input MFMA kernels: 4.77e-6, 7.5e-7;
 // profiles/experiments/r03_b16_products.txt).  The kernels' B16 / ORDER template value is the largest i + j (h = 0, m = 1, l = 2)
-// still issued: B16_SIX in the release build; B16_NINE instances exist in the ablation builds (CPP_B16_PRODUCTS=9; the default of
-// libcartpolepp_hip_exact.so).
+// still issued: B16_SIX under CPP_PRECISION_FAST, B16_NINE under CPP_PRECISION_EXACT (and with CPP_B16_PRODUCTS=9 in the ablation build).
 //
 // F16_PIECES: f16 pieces of conv1's f32 operand (weights in the forward kernel, dY in conv_dw16.h; the other operand is the raw f16
-// pixel, exact).  Two round-to-nearest pieces h + m leave |x - h - m| <= 2^-23 |x|: the operand is within ONE f32 ulp (the sign of m
-// is the 23rd bit; a third piece holds what is left, at most one bit).  Against the float64 oracle at 64x64x18, B = 256: pooled conv1
+// pixel, exact).  Two round-to-nearest pieces h + m leave |x - h - m| <= 2^-22 |x| (11 + 11 significand bits; the sign of m is one more):
+// the operand to within about ONE f32 ulp; a third piece holds what is left, at most two bits.  Against the float64 oracle at 64x64x18, B = 256: pooled conv1
 // output 3.2e-6 (two) / 3.7e-6 (three) / 7.0e-6 (f32-input MFMA) max abs at magnitude 7.1, conv1 weight gradient 1.22e-6 / 1.19e-6 /
-// 1.69e-6 rel (profiles/experiments/r03_f16_pieces.txt).  Release: 2; libcartpolepp_hip_exact.so: 3 (every product exact).
+// 1.69e-6 rel (profiles/experiments/r03_f16_pieces.txt).  CPP_PRECISION_FAST: 2; CPP_PRECISION_EXACT: 3 (every product exact).
 //
 // Both arithmetic contracts are in the release library; cpp_ctx_set_precision (include/cartpolepp_abi.h) chooses per context:
 // CPP_PRECISION_FAST (default): two f16 pieces, six bf16 products; CPP_PRECISION_EXACT: three / nine -- every product exact.
@@ -917,5 +916,8 @@ static inline int conv_fwd_k16_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
 
 // conv1 of f16 image batches with one whitening table for the batch (white_bstride == 0), even CIN and W, 5x5
 int conv_fwd_k16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool plain, const ConvArgsN& a, bool* handled);
+// conv1 of 64-pixel-wide 18-channel f16 image batches on conv_rs16.h (a.wimg: every network's operand image buffer)
+int conv_fwd_rs16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool plain, const ConvArgsN& a, bool* handled);
+size_t conv_rs16_image_bytes();
 // conv2 forward from the bf16 planes conv1 left (a.in_b16): 10 channels, 5x5, even W <= 64
 int conv_fwd_kb16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArgsN& a, bool* handled);

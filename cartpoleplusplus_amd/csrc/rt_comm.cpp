@@ -18,6 +18,8 @@ extern "C" int cpp_comm_create(cpp_ctx* ctx, const void* unique_id, int rank, in
   cpp_comm* c = new cpp_comm();
   memset(c, 0, sizeof(*c));
   c->ctx = ctx; c->rank = rank; c->world = world;
+  static uint64_t next_uid = 1;
+  c->uid = next_uid++;
   ncclUniqueId id;
   memcpy(&id, unique_id, sizeof(id));
   ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);

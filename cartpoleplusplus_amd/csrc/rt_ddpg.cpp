@@ -18,7 +18,7 @@ struct cpp_ddpg {
   cpp_batch* step_batch;
   // graph replay of ONE minibatch on host-drawn rows, no target update (cpp_ddpg_train_rows: the reference's literal loop)
   hipGraph_t rgraph; hipGraphExec_t rgexec; bool rgraph_ok; int rg_B; uint64_t rg_replay_uid;
-  hipGraph_t dgraph; hipGraphExec_t dgexec; bool dgraph_ok; int dg_B, dg_nb; uint64_t dg_seed, dg_replay_uid; cpp_comm* dg_comm; bool dgraph_refused;   // the data-parallel step (default mode)
+  hipGraph_t dgraph; hipGraphExec_t dgexec; bool dgraph_ok; int dg_B, dg_nb; uint64_t dg_seed, dg_replay_uid; uint64_t dg_comm_uid; bool dgraph_refused; char dg_reason[256];   // the data-parallel step (default mode)
   // graph replay of the data-parallel half step (sample + both gradient sets)
   // three variants: 0 samples its own minibatch; 1 / 2 find it presampled (by the previous call's rider, conv1_dw_gather.hip)
   // in the second / first set of slot arrays.  One key for all three.
@@ -49,7 +49,7 @@ extern "C" int cpp_ddpg_create(cpp_ctx* ctx, cpp_net* actor, cpp_net* critic, cp
   d->nA = actor->nparams; d->nC = critic->nparams;
   d->graph = nullptr; d->gexec = nullptr; d->graph_ok = false; d->step_batch = nullptr; d->g_replay_uid = 0;
   d->rgraph = nullptr; d->rgexec = nullptr; d->rgraph_ok = false; d->rg_B = 0; d->rg_replay_uid = 0;
-  d->dgraph = nullptr; d->dgexec = nullptr; d->dgraph_ok = false; d->dg_B = d->dg_nb = 0; d->dg_seed = d->dg_replay_uid = 0; d->dg_comm = nullptr; d->dgraph_refused = false;
+  d->dgraph = nullptr; d->dgexec = nullptr; d->dgraph_ok = false; d->dg_B = d->dg_nb = 0; d->dg_seed = d->dg_replay_uid = 0; d->dg_comm_uid = 0; d->dgraph_refused = false; d->dg_reason[0] = 0;
   memset(d->hg, 0, sizeof(d->hg)); d->dp_local = 0; d->sq_cnt[0] = d->sq_cnt[1] = 0;
   d->h_replay_uid = 0; d->h_write_gen = 0; d->pre_variant = 0; d->h_B = 0; d->h_seed = 0;
   memset(d->slot_set, 0, sizeof(d->slot_set));
@@ -836,7 +836,7 @@ extern "C" int cpp_ddpg_dp_train_step(cpp_ddpg* d, cpp_replay* r, cpp_comm* c, i
     if (!d->step_batch) RC(cpp_batch_create(ctx, d->maxB, r->elems, r->A, &d->step_batch));
     if (ctx->prof) return step_body(d, r, B, n_batches, nullptr, seed, true, true, c);
     if (d->dgraph_refused) return step_body(d, r, B, n_batches, nullptr, seed, true, true, c);
-    if (!d->dgraph_ok || d->dg_B != B || d->dg_nb != n_batches || d->dg_seed != seed || d->dg_replay_uid != r->uid || d->dg_comm != c) {
+    if (!d->dgraph_ok || d->dg_B != B || d->dg_nb != n_batches || d->dg_seed != seed || d->dg_replay_uid != r->uid || d->dg_comm_uid != (c ? c->uid : 0)) {
       if (d->dgexec) { (void)hipGraphExecDestroy(d->dgexec); d->dgexec = nullptr; }
       if (d->dgraph) { (void)hipGraphDestroy(d->dgraph); d->dgraph = nullptr; }
       d->dgraph_ok = false;
@@ -849,11 +849,14 @@ extern "C" int cpp_ddpg_dp_train_step(cpp_ddpg* d, cpp_replay* r, cpp_comm* c, i
         (void)hipGetLastError();
         if (d->dgexec) { (void)hipGraphExecDestroy(d->dgexec); d->dgexec = nullptr; }
         if (d->dgraph) { (void)hipGraphDestroy(d->dgraph); d->dgraph = nullptr; }
+        // (the very same calls have just run eagerly and returned CPP_OK: whatever fails here fails BECAUSE of the capture -- the
+        // runtime's or RCCL's refusal.  The reason is kept for cpp_ddpg_dp_status; a failure of the eager pass above is returned.)
         d->dgraph_refused = true;
-        fprintf(stderr, "cartpolepp: the data-parallel step could not be captured as a hipGraph (%s); running it as stream launches\n", cpp_last_error());
+        snprintf(d->dg_reason, sizeof(d->dg_reason), "%s", cpp_last_error());
+        fprintf(stderr, "cartpolepp: the data-parallel step could not be captured as a hipGraph (%s); running it as stream launches\n", d->dg_reason);
         return CPP_OK;
       }
-      d->dgraph_ok = true; d->dg_B = B; d->dg_nb = n_batches; d->dg_seed = seed; d->dg_replay_uid = r->uid; d->dg_comm = c;
+      d->dgraph_ok = true; d->dg_B = B; d->dg_nb = n_batches; d->dg_seed = seed; d->dg_replay_uid = r->uid; d->dg_comm_uid = c ? c->uid : 0;
       return CPP_OK;
     }
     HIP_CHECK(hipGraphLaunch(d->dgexec, ctx->stream));
@@ -894,6 +897,15 @@ extern "C" int cpp_ddpg_dp_train_step(cpp_ddpg* d, cpp_replay* r, cpp_comm* c, i
     RC(apply(d, true, true, inv));
   }
   return cpp_ddpg_update_targets(d);
+}
+
+// which form the default data-parallel step of this trainer takes: 0 = none run yet, 1 = one hipGraph replay per outer step (the
+// collective inside), 2 = the same sequence as stream launches (the capture was refused; `reason` says by what)
+extern "C" int cpp_ddpg_dp_status(const cpp_ddpg* d, int* mode, char* reason, int cap) {
+  ARG_CHECK(d && mode, "cpp_ddpg_dp_status: NULL argument");
+  *mode = d->dgraph_refused ? 2 : (d->dgraph_ok ? 1 : 0);
+  if (reason && cap > 0) snprintf(reason, (size_t)cap, "%s", d->dg_reason);
+  return CPP_OK;
 }
 
 extern "C" int cpp_ddpg_last_stats(cpp_ddpg* d, float out[3]) {

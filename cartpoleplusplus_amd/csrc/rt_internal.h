@@ -84,6 +84,7 @@ struct cpp_net {
   float* params; float* grads; float* own_grads;
   Workspace ws[2];
   bool use_b16;             // this forward: conv1 (f16 pipes) leaves bf16 planes of pool1, conv2 forward reads them
+  void* wimg;               // conv1's operand image on the f16 pipes (conv_rs16.h: rebuilt in front of every forward that uses it)
   const int32_t* img_slot;  // conv1 reads image b from row img_slot[b] of the state pointer (the replay store); nullptr: b
   float* white;            // [2][C] statistics for cpp_net_forward
   float* white_rows;       // [maxB][2][C]: per-image statistics for cpp_net_forward_each
@@ -232,6 +233,7 @@ bool direct_replay_ok(cpp_net* a, cpp_replay* r, int B);
 // ---- communicator of the data-parallel learners (rt_comm.cpp): one rank per cpp_ctx, RCCL over xGMI
 struct cpp_comm {
   cpp_ctx* ctx; ncclComm_t comm; int rank, world;
+  uint64_t uid;                // unique per cpp_comm_create (graph keys: an address can be reused by the allocator, this cannot)
   hipStream_t side;            // second stream: collectives that overlap the conv backward of the same minibatch
   hipEvent_t ev_fc, ev_bwd, ev_done;
   double* scratch;             // CPP_COMM_SCRATCH_WORDS device doubles of cpp_comm_max_doubles (allocated on first use)

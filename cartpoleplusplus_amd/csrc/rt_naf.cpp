@@ -19,7 +19,7 @@ struct cpp_naf {
   hipGraph_t hgraph; hipGraphExec_t hexec; bool hgraph_ok; int h_B; uint64_t h_seed, h_replay_uid;
   // ONE minibatch on host-drawn rows up to (not including) the optimiser (cpp_naf_train_rows)
   hipGraph_t rgraph; hipGraphExec_t rgexec; bool rgraph_ok; int rg_B; uint64_t rg_replay_uid;
-  hipGraph_t dgraph; hipGraphExec_t dgexec; bool dgraph_ok; int dg_B, dg_nb; uint64_t dg_seed, dg_replay_uid; cpp_comm* dg_comm; bool dgraph_refused;   // the data-parallel step
+  hipGraph_t dgraph; hipGraphExec_t dgexec; bool dgraph_ok; int dg_B, dg_nb; uint64_t dg_seed, dg_replay_uid; uint64_t dg_comm_uid; bool dgraph_refused; char dg_reason[256];   // the data-parallel step
   // ... and including it, the loss coming back later (cpp_naf_train_rows_async / cpp_naf_loss_wait): pinned (loss, flag) slots
   hipGraph_t agraph; hipGraphExec_t agexec; bool agraph_ok; int ag_B; uint64_t ag_replay_uid;
   float* res_pin; hipEvent_t res_ev[CPP_NAF_TICKETS]; uint64_t next_ticket;
@@ -57,7 +57,7 @@ extern "C" int cpp_naf_create(cpp_ctx* ctx, cpp_net* value, cpp_net* tvalue, cpp
   f->graph = nullptr; f->gexec = nullptr; f->graph_ok = false; f->step_batch = nullptr; f->g_replay_uid = 0;
   f->sq_cnt = 0; f->step_bumped = false;
   f->rgraph = nullptr; f->rgexec = nullptr; f->rgraph_ok = false; f->rg_B = 0; f->rg_replay_uid = 0;
-  f->dgraph = nullptr; f->dgexec = nullptr; f->dgraph_ok = false; f->dg_B = f->dg_nb = 0; f->dg_seed = f->dg_replay_uid = 0; f->dg_comm = nullptr; f->dgraph_refused = false;
+  f->dgraph = nullptr; f->dgexec = nullptr; f->dgraph_ok = false; f->dg_B = f->dg_nb = 0; f->dg_seed = f->dg_replay_uid = 0; f->dg_comm_uid = 0; f->dgraph_refused = false; f->dg_reason[0] = 0;
   f->agraph = nullptr; f->agexec = nullptr; f->agraph_ok = false; f->ag_B = 0; f->ag_replay_uid = 0;
   f->res_pin = nullptr; f->next_ticket = 0; memset(f->res_ev, 0, sizeof(f->res_ev));
   f->hgraph = nullptr; f->hexec = nullptr; f->hgraph_ok = false; f->h_B = 0; f->h_seed = 0; f->h_replay_uid = 0; f->dp_local = 0;
@@ -688,6 +688,13 @@ extern "C" int cpp_naf_average_params(cpp_naf* f, cpp_comm* c) {
 }
 
 // the inner step naf_cartpole.py:367-373 for N synchronous learners (this rank's part); see cpp_ddpg_dp_train_step
+extern "C" int cpp_naf_dp_status(const cpp_naf* f, int* mode, char* reason, int cap) {      // (see cpp_ddpg_dp_status)
+  ARG_CHECK(f && mode, "cpp_naf_dp_status: NULL argument");
+  *mode = f->dgraph_refused ? 2 : (f->dgraph_ok ? 1 : 0);
+  if (reason && cap > 0) snprintf(reason, (size_t)cap, "%s", f->dg_reason);
+  return CPP_OK;
+}
+
 extern "C" int cpp_naf_dp_train_step(cpp_naf* f, cpp_replay* r, cpp_comm* c, int B, int n_batches, uint64_t seed, int sync_every) {
   RC(naf_half_checks(f, r, B, "cpp_naf_dp_train_step"));
   ARG_CHECK(n_batches >= 1 && sync_every >= 1, "cpp_naf_dp_train_step: n_batches %d, sync_every %d", n_batches, sync_every);
@@ -700,7 +707,7 @@ extern "C" int cpp_naf_dp_train_step(cpp_naf* f, cpp_replay* r, cpp_comm* c, int
     if (!f->step_batch) RC(cpp_batch_create(ctx, f->maxB, r->elems, r->A, &f->step_batch));
     if (ctx->prof) return naf_step_body(f, r, B, n_batches, nullptr, seed, true, c);
     if (f->dgraph_refused) return naf_step_body(f, r, B, n_batches, nullptr, seed, true, c);
-    if (!f->dgraph_ok || f->dg_B != B || f->dg_nb != n_batches || f->dg_seed != seed || f->dg_replay_uid != r->uid || f->dg_comm != c) {
+    if (!f->dgraph_ok || f->dg_B != B || f->dg_nb != n_batches || f->dg_seed != seed || f->dg_replay_uid != r->uid || f->dg_comm_uid != (c ? c->uid : 0)) {
       if (f->dgexec) { (void)hipGraphExecDestroy(f->dgexec); f->dgexec = nullptr; }
       if (f->dgraph) { (void)hipGraphDestroy(f->dgraph); f->dgraph = nullptr; }
       f->dgraph_ok = false;
@@ -718,10 +725,11 @@ extern "C" int cpp_naf_dp_train_step(cpp_naf* f, cpp_replay* r, cpp_comm* c, int
         if (f->dgexec) { (void)hipGraphExecDestroy(f->dgexec); f->dgexec = nullptr; }
         if (f->dgraph) { (void)hipGraphDestroy(f->dgraph); f->dgraph = nullptr; }
         f->dgraph_refused = true;
-        fprintf(stderr, "cartpolepp: the data-parallel NAF step could not be captured as a hipGraph; running it as stream launches\n");
+        snprintf(f->dg_reason, sizeof(f->dg_reason), "%s", rc ? cpp_last_error() : hipGetErrorString(e != hipSuccess ? e : ei));
+        fprintf(stderr, "cartpolepp: the data-parallel NAF step could not be captured as a hipGraph (%s); running it as stream launches\n", f->dg_reason);
         return CPP_OK;
       }
-      f->dgraph_ok = true; f->dg_B = B; f->dg_nb = n_batches; f->dg_seed = seed; f->dg_replay_uid = r->uid; f->dg_comm = c;
+      f->dgraph_ok = true; f->dg_B = B; f->dg_nb = n_batches; f->dg_seed = seed; f->dg_replay_uid = r->uid; f->dg_comm_uid = c ? c->uid : 0;
       return CPP_OK;
     }
     HIP_CHECK(hipGraphLaunch(f->dgexec, ctx->stream));
@@ -772,6 +780,16 @@ extern "C" int cpp_naf_set_opt_state(cpp_naf* f, const float* m, const float* v,
   if (m) HIP_CHECK(hipMemcpyAsync(f->m, m, (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
   if (v) HIP_CHECK(hipMemcpyAsync(f->v, v, (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
   HIP_CHECK(hipMemcpyAsync(f->opt_step, &step, sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  // a restored checkpoint is a fresh start: the sticky check_numerics flag of cpp_naf_train_rows_async goes with the state it condemned
+  HIP_CHECK(hipMemsetAsync(f->nonfinite, 0, sizeof(int), st));
   HIP_CHECK(hipStreamSynchronize(st));
+  return CPP_OK;
+}
+// After CPP_ERR_NUMERIC on the asynchronous path every later update of this trainer stands down (the reference's check_numerics ends the
+// run, naf_cartpole.py:242-245,265).  A caller that has repaired the parameters (cpp_net_set_params of a checkpoint) says so here.
+extern "C" int cpp_naf_clear_numeric_error(cpp_naf* f) {
+  ARG_CHECK(f, "cpp_naf_clear_numeric_error: NULL argument");
+  HIP_CHECK(hipSetDevice(f->ctx->device));
+  HIP_CHECK(hipMemsetAsync(f->nonfinite, 0, sizeof(int), f->ctx->stream));
   return CPP_OK;
 }

@@ -105,7 +105,7 @@ extern "C" int cpp_net_create(cpp_ctx* ctx, const cpp_net_spec* spec, int max_ba
   n->ctx = ctx; n->spec = *spec; n->maxB = max_batch; n->arena.stream = ctx->stream;
   n->grads = nullptr; n->own_grads = nullptr; n->stage_state = nullptr; n->stage_action = nullptr;
   n->stage_out = nullptr; n->dw_partial[0] = n->dw_partial[1] = n->dw_partial[2] = nullptr; n->white = nullptr; n->white_rows = nullptr; n->stats_part = nullptr;
-  n->img_slot = nullptr; n->use_b16 = false;
+  n->img_slot = nullptr; n->use_b16 = false; n->wimg = nullptr;
   n->is_training = true; n->drop_counter = nullptr; n->bn_part = nullptr; n->bn_means = nullptr; n->bn_scratch = nullptr;
   int rc = net_build(n);
   if (rc) { delete n; return rc; }
@@ -123,6 +123,7 @@ extern "C" int cpp_net_create(cpp_ctx* ctx, const cpp_net_spec* spec, int max_ba
   if (spec->pixel) {
     for (int i = 0; i < 3; ++i)
       if ((rc = dalloc(n->arena, &n->dw_partial[i], conv_dw_partial_floats(ctx, n->conv[i].Cin, n->conv[i].ks, kConvOut)))) return fail(rc);
+    if ((rc = n->arena.alloc(&n->wimg, conv_rs16_image_bytes(), true))) return fail(rc);
     if ((rc = dalloc(n->arena, &n->white, (size_t)2 * spec->C))) return fail(rc);
     if ((rc = dalloc(n->arena, &n->white_rows, (size_t)max_batch * 2 * spec->C))) return fail(rc);
     if ((rc = dalloc(n->arena, &n->stats_part, (size_t)2 * max_batch * 2 * spec->C))) return fail(rc);
@@ -207,7 +208,7 @@ ConvArgs conv_fwd_args(cpp_net* n, Workspace& w, int i, const void* state, int d
   const ConvL& L = n->conv[i];
   ConvArgs a; memset(&a, 0, sizeof(a));
   if (i == 0) { a.in = state; a.in_bstride = n->state_elems; a.scale = white; a.shift = white + n->spec.C; a.white_bstride = white_bstride;
-                a.img_slot = n->img_slot;
+                a.img_slot = n->img_slot; a.wimg = n->wimg;
                 *mode = dtype == CPP_F16 ? IN_F16_WHITEN : IN_F32_WHITEN; }
   else { a.in = w.pool[i - 1]; a.in_bstride = (long)L.H * L.W * L.Cin; *mode = IN_F32_PLAIN; }
   a.w = n->params + L.w_off; a.bias = n->params + L.b_off;

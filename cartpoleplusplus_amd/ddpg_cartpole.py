@@ -436,7 +436,10 @@ class DeepDeterministicPolicyGradientAgent(object):
         self.env = env
         state_shape = self.env.observation_space.shape
         action_dim = self.env.action_space.shape[1]
-        _lib.default_context().set_precision("exact" if getattr(opts, "exact_products", False) else "fast")
+        # (--exact-products asks for the exact arithmetic contract; without the flag the context keeps whatever mode its owner chose --
+        # an explicit Context.set_precision("exact") is not undone, and a second agent on the shared context does not fight the first)
+        if getattr(opts, "exact_products", False) and _lib.default_context().precision != "exact":
+            _lib.default_context().set_precision("exact")
         # replay memory: f16 state store resident in HBM (ddpg_cartpole.py:257-261)
         self.replay_memory = replay_memory.ReplayMemory(opts.replay_memory_size, state_shape, action_dim,
                                                        store_dtype=opts.replay_store)

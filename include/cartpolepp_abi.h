@@ -19,14 +19,15 @@
  *     parity tests allow and measured as close to a float64 evaluation as f32-input matrix instructions get.  Where an operand
  *     already is an f16 number (conv1's input: the replay store's pixels, replay_memory.py:32) the other, f32, operand is split by
  *     round-to-nearest into f16 pieces and the f16 x f16 products -- each exact -- are accumulated in f32 (v_mfma_f32_16x16x32_f16):
- *     two pieces in the release library (the operand to within one f32 ulp), three in libcartpolepp_hip_exact.so (the operand
- *     itself).  conv2's forward and dW split BOTH f32 operands into three bf16 pieces (exactly) and issue the six largest of the
- *     nine piece products (release: the dropped three are at most half an f32 ulp of the product) or all nine (exact build)
- *     (v_mfma_f32_16x16x32_bf16); everything else multiplies f32 operands directly (v_mfma_f32_16x16x4_f32).  DESIGN.md section 4.
+ *     two pieces under CPP_PRECISION_FAST (the default: the operand to within 2^-22 relative, about one f32 ulp), three under
+ *     CPP_PRECISION_EXACT (the operand itself).  conv2's forward and dW split BOTH f32 operands into three bf16 pieces (exactly) and
+ *     issue the six largest of the nine piece products (FAST: the dropped three are at most half an f32 ulp of the product) or all
+ *     nine (EXACT) (v_mfma_f32_16x16x32_bf16); everything else multiplies f32 operands directly (v_mfma_f32_16x16x4_f32).  Both
+ *     modes are in the one release library: cpp_ctx_set_precision below.  DESIGN.md section 4.
  *     f32 states, odd layouts and B = 1 run on the f32-input MFMA kernels throughout.  The release library has no run-time kernel
  *     switches; the ablation build (libcartpolepp_hip_ablation.so, CARTPOLEPP_ABLATION=1) can force the f32-input kernels
- *     everywhere (CPP_CONV_K16=0 CPP_CONV_B16=0) -- bench.py's `control` run; CARTPOLEPP_ABLATION=exact loads the exact-product
- *     build -- bench.py's `control_exact_products` run.
+ *     everywhere (CPP_CONV_K16=0 CPP_CONV_B16=0) -- bench.py's `control` run; bench.py's `control_exact_products` run is the
+ *     release library under CPP_PRECISION_EXACT.
  *   - replay states are stored as f16 exactly like replay_memory.py:32 (or as their 8-bit pixel codes); indices are int32.
  *   - state batches handed to the conv kernels always live in the library's own guard-banded device allocations (host
  *     pointers are copied in first); the f16-pipe kernels refuse anything else.
@@ -299,6 +300,12 @@ int cpp_naf_allreduce_grads(cpp_naf* naf, cpp_comm* comm);
 int cpp_naf_average_params(cpp_naf* naf, cpp_comm* comm);
 int cpp_naf_dp_train_step(cpp_naf* naf, cpp_replay* replay, cpp_comm* comm, int B, int n_batches, uint64_t seed,
                           int sync_every);
+/* Which form the default data-parallel step (sync_every 1, no overlap) of this trainer takes -- the reference has no counterpart
+ * (ddpg_cartpole.py:259 / naf_cartpole.py:294 are its "TODO: distributed" notes); *mode: 0 = none run yet, 1 = one hipGraph replay
+ * per outer step with the all-reduce inside, 2 = the same launches issued on the stream because the runtime or RCCL refused the
+ * capture (`reason`, if given, receives what it said). */
+int cpp_ddpg_dp_status(const cpp_ddpg* ddpg, int* mode, char* reason, int cap);
+int cpp_naf_dp_status(const cpp_naf* naf, int* mode, char* reason, int cap);
 
 /* ---- NAF train ops (naf_cartpole.py:93-284, :365-373) ----------------------------------------- */
 typedef struct cpp_naf_hyper {
@@ -358,6 +365,10 @@ int cpp_naf_last_stats(cpp_naf* naf, float out[3]);
 int64_t cpp_naf_opt_state_size(const cpp_naf* naf);
 int cpp_naf_get_opt_state(cpp_naf* naf, float* m, float* v, int64_t n, uint64_t* step);
 int cpp_naf_set_opt_state(cpp_naf* naf, const float* m, const float* v, int64_t n, uint64_t step);
+/* cpp_naf_train_rows_async keeps the check_numerics flag of a non-finite minibatch set: every later update stands down, as the
+ * reference's run ends there (naf_cartpole.py:242-245,265).  cpp_naf_set_opt_state (a restored checkpoint) clears it; so does this
+ * call, for a caller that has put good parameters back with cpp_net_set_params. */
+int cpp_naf_clear_numeric_error(cpp_naf* naf);
 
 #ifdef __cplusplus
 }
