@@ -65,6 +65,8 @@ SIGNATURES = {
     "cpp_sync": (_I, [_P]),
     "cpp_ctx_set_precision": (_I, [_P, _I]),
     "cpp_ctx_get_precision": (_I, [_P, C.POINTER(_I)]),
+    "cpp_ctx_set_route_threshold": (_I, [_P, _F]),
+    "cpp_ctx_get_route": (_I, [_P, C.POINTER(_I), C.POINTER(_F)]),
     "cpp_timer_begin": (_I, [_P]),
     "cpp_timer_end": (_I, [_P, C.POINTER(_F)]),
     "cpp_prof_enable": (_I, [_P, _I]),
@@ -214,6 +216,17 @@ class Context(object):
         if mode not in modes:
             raise ValueError("precision %r is neither 'fast' nor 'exact'" % (mode,))
         check(lib.cpp_ctx_set_precision(self.handle, modes[mode]))
+
+    def set_route_threshold(self, threshold):
+        """whitening scale above which the next training steps run conv1 on the f32-input kernels (nearly constant channels;
+        include/cartpolepp_abi.h, cpp_ctx_set_route_threshold); 0 disables the switch."""
+        check(lib.cpp_ctx_set_route_threshold(self.handle, float(threshold)))
+
+    def route(self):
+        """(conv1 currently on the f32-input kernels?, largest whitening scale of the last finished step)"""
+        f, m = C.c_int(), C.c_float()
+        check(lib.cpp_ctx_get_route(self.handle, C.byref(f), C.byref(m)))
+        return bool(f.value), float(m.value)
 
     @property
     def precision(self):

@@ -56,6 +56,8 @@ enum KernelId {
   K_CONV2_BWD,            // conv2's dW and dX in one launch (conv2_bwd_pair.hip)
   K_REDUCE_GATHER,        // the dW reductions of a minibatch + sample / statistics of the next one in one launch (replay.hip)
   K_CONV1_DW_GATHER,      // conv1 dW (f16 pipes) + sample / statistics of the next minibatch in one launch (conv1_dw_gather.hip)
+  K_ALLREDUCE,            // the data-parallel step's gradient all-reduce (RCCL), as the stream sees it between the gradient kernels and the update
+  K_CONV1_IMAGE,          // conv1's operand images as a launch of their own (conv_rs16.h; in the fused step they ride in the optimiser's launch)
   K_NUM_KERNELS
 };
 
@@ -68,6 +70,9 @@ struct DwReduceDesc { const float* partial; int nblocks, pstride, nw, nout; floa
 #define CPP_PRECISION_FAST 0      /* (include/cartpolepp_abi.h) */
 #define CPP_PRECISION_EXACT 1
 #endif
+// The whitening tables of the NEXT minibatch as a rider of the dW reductions' launch (conv_dw_reduce_kernel): its sample pass has left with
+// conv1's dW (conv1_dw_gather.hip), so its per-row sums are complete when the reductions start -- one wave per (state column, channel)
+struct StatsRide { const double* part; float* white; int nparts, jobs, C; double count, eps; unsigned* wmax; };
 struct cpp_ctx {
   int device;
   hipStream_t stream;
@@ -85,12 +90,21 @@ struct cpp_ctx {
   const struct GatherArgs* ride;  // non-null: the next minibatch's sample + statistics kernel rides in the dW reduction's launch
   bool ride_done; int ride_dtype;
   bool ride_at_dw;                // the rider may already leave with conv1's dW (its slots are double-buffered: direct replay)
+  const StatsRide* st_ride; bool st_ride_done;      // non-null: flush_dw_reduce may finish that pass's statistics (sets st_ride_done)
   // Global-norm partials folded into the kernels that write the gradients (fused single-learner step): every dW GEMM tile and every
   // conv dW reduction block leaves the f64 sum of squares of its outputs in sq_part (one region of SQ_REGION slots per gradient
   // list); the optimiser kernel adds a list's partials in slot order.  sq_n: slots handed out so far, -1: folding off (the sumsq
   // kernel runs instead: data-parallel steps, whose gradients change in the all-reduce; batch norm; NAF).
   double* sq_part; int sq_n[2]; int sq_conv_group[4];
   int precision;                  // CPP_PRECISION_FAST / CPP_PRECISION_EXACT (cpp_ctx_set_precision; conv_k16.h)
+  // Nearly constant channels (a blind camera with a rare off-colour pixel: whitening scale ~ 10^3 on values that do not cancel exactly):
+  // the f16-pipe conv1 kernels multiply RAW pixels and cancel inside the MFMA, which on such a table sits ~4 x further from float64 than
+  // whitening each element first, as the f32-input kernels (and the reference's TF graph, base_network.py:95-99) do.  The statistics
+  // kernels keep the largest scale of the step in white_max_dev; every training step ends with its copy to pinned host memory and a
+  // reset; the NEXT step's entry point reads the host word without waiting for anything and, above route_threshold, runs conv1 (forward
+  // and dW) and conv2 forward on the f32-input kernels until the scale is back under half of it.  kernel_epoch: bumped by every flip --
+  // the trainers' captured graphs are keyed on it.
+  unsigned* white_max_dev; unsigned* white_max_host; bool conv1_f32; uint64_t kernel_epoch; float route_threshold;
   int n_trainers;                 // live cpp_ddpg / cpp_naf objects: their captured graphs pin the precision mode
 };
 #define SQ_REGION 2048
@@ -137,7 +151,8 @@ struct ConvArgs {
   // conv2 forward on the bf16 pipes only (n3_w != nullptr): the workgroup also runs conv3 + pool3 of its two images from the
   // pooled rows it has just produced (kept in LDS as zero-haloed 16x16 images: conv3_img.h) -- conv3's launch disappears
   const float* n3_w; const float* n3_bias; float* n3_out; long n3_out_bstride; uint8_t* n3_amax;
-  const void* wimg;          // conv1 on the f16 pipes: the network's prebuilt operand image (conv_rs16.h: conv1_image_kernel), or nullptr
+  const void* wimg;          // conv1 on the f16 pipes: the network's operand image buffer (conv_rs16.h: conv1_image_kernel), or nullptr
+  const float* wimg_key;     // == scale: the image in wimg was built by the optimiser's launch for this very table and these weights
 };
 
 // Same-geometry convolutions of several networks in ONE launch (blockIdx.y selects the descriptor): the
@@ -146,9 +161,9 @@ struct ConvArgs {
 struct ConvArgsN { ConvArgs a[CONV_BATCH_MAX]; int n; };
 
 // true if conv1 forward (plain: batch norm) and dW (dense dY: batch norm) of this geometry run on conv_k16.h / conv_dw16.h
-bool conv1_f16_pipes_ok(int cin, int H, int W, int B, bool batch_norm);
+bool conv1_f16_pipes_ok(const cpp_ctx* ctx, int cin, int H, int W, int B, bool batch_norm);
 // true if conv1 forward runs on conv_k16.h (and can leave bf16 planes of its output) and conv2 forward has a B16 instance
-bool conv12_b16_ok(int cin, int H, int W, int B);
+bool conv12_b16_ok(const cpp_ctx* ctx, int cin, int H, int W, int B);
 int launch_conv_fwd(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi, ConvArgs a);
 int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, int epi, const ConvArgs* list, int n);
 // conv3 forward of 16x16 inputs with the whole image in LDS (conv3_img.hip)
@@ -166,6 +181,7 @@ int launch_conv_dw(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, ConvArgs
                    float* grad_b);
 size_t conv_dw_partial_floats(cpp_ctx* ctx, int cin, int ks, int nout);
 size_t conv_rs16_image_bytes();     // a network's conv1 operand image (conv_rs16.h)
+bool conv_rs16_ok(cpp_ctx* ctx, int cin, int H, int W, int nout);
 int flush_dw_reduce(cpp_ctx* ctx);     // one launch for every dW reduction queued by launch_conv_dw
 // A backward pass that fails half way (a geometry without a kernel, a launch error) must not leave its queued reductions behind:
 // they point into that network's buffers, which may be gone by the time the next pass flushes the queue.
@@ -285,8 +301,11 @@ int launch_bn_forward(cpp_ctx* ctx, const BnBatch& bb, double eps);
 int launch_bn_backward(cpp_ctx* ctx, const BnBatch& bb);
 // bump: a device counter the kernel's first thread advances by one (the sampler's counter, which otherwise costs the data-parallel
 // half step a launch of its own right behind this one)
+// (the next step's choice of conv1 kernels: reads the pinned word, flips cpp_ctx::conv1_f32; and the step's closing copy + reset)
+void ctx_route_update(cpp_ctx* ctx);
+int ctx_route_publish(cpp_ctx* ctx);
 int launch_stats_finalize(cpp_ctx* ctx, const double* part, int nparts, int which_count, int C,
-                          double count, float* white, double eps = 1e-6, uint64_t* bump = nullptr);
+                          double count, float* white, double eps = 1e-6, uint64_t* bump = nullptr, unsigned* wmax = nullptr);
 int launch_stats_generic(cpp_ctx* ctx, const void* x, int dtype, long npix, int C, float* white, double eps = 1e-6);
 int launch_replay_fill(cpp_ctx* ctx, __half* store, long elems, int slots, int32_t* s1, int32_t* s2,
                        float* action, float* reward, float* mask, int rows, int action_dim,
@@ -313,8 +332,18 @@ struct OptSegs {
                                // raises before the train op runs, naf_cartpole.py:242-245 -- decided on the device when nobody waits for the loss)
   // optional rider (st_part != nullptr): the whitening tables of the NEXT minibatch, whose sample pass has already run beside this
   // one's conv1 dW -- stats_finalize_kernel's work (stats_body.h) in st_jobs = columns x channels waves of an extra grid row
-  const double* st_part; float* st_white; int st_nparts, st_jobs, st_C; double st_count, st_eps;
+  const double* st_part; float* st_white; int st_nparts, st_jobs, st_C; double st_count, st_eps; unsigned* st_wmax;
+  // second optional rider (img_n > 0; needs the first one's inputs or finished tables): conv1's operand images for the NEXT minibatch's forward (conv_rs16.h) -- one
+  // workgroup per network recomputes its conv1 weights as this launch updates them (gw == nullptr: a target network, untouched), its
+  // state column's whitening table as the first rider computes it, and builds the image: conv1_image_kernel's launch disappears
+  int img_n;
+  long img_skip[OPT_MAX_SEGS];   // leading parameters of a segment (conv1's weights and biases) that its image workgroup updates itself
+  struct { float* w; float* bias; const float* gw; const float* gb; unsigned char* rec; int seg, col, nout;
+           const float* white; } img[4];      // white != nullptr: the column's table is already in memory (the dW reductions' launch computed it)
 };
+// the SGD update of one parameter, p - lr * (g * scale), with its roundings pinned (one product, one fused multiply-add): opt_apply_kernel
+// writes it, the conv1 image rider of the same launch recomputes it, and both must hold the same bits whatever the compiler contracts
+__host__ __device__ inline float sgd_update(float p, float g, float scale, float lr) { return __builtin_fmaf(-lr, g * scale, p); }
 int launch_sumsq(cpp_ctx* ctx, const OptSegs& s, float grad_scale, double* part, int nparts);
 int launch_opt_apply(cpp_ctx* ctx, const OptSegs& s, float grad_scale, float clip, const double* part,
                      int nparts, float* norms_out);

@@ -50,7 +50,8 @@ static int guard_band_check(const ConvArgsN& batch, int cin, const char* who) {
   return 0;
 }
 
-bool conv1_f16_pipes_ok(int cin, int H, int W, int B, bool batch_norm) {
+bool conv1_f16_pipes_ok(const cpp_ctx* ctx, int cin, int H, int W, int B, bool batch_norm) {
+  if (ctx && ctx->conv1_f32) return false;      // (nearly constant channels: the f32-input kernels, cpp_ctx::conv1_f32)
   static const bool off = cpp_switch_off("CPP_CONV_K16") ||
                           cpp_switch_off("CPP_CONV_KYO");
   if (off || B < 2 || H < 4) return false;
@@ -64,7 +65,8 @@ bool conv1_f16_pipes_ok(int cin, int H, int W, int B, bool batch_norm) {
   return f && d;
 }
 
-bool conv12_b16_ok(int cin, int H, int W, int B) {
+bool conv12_b16_ok(const cpp_ctx* ctx, int cin, int H, int W, int B) {
+  if (ctx && ctx->conv1_f32) return false;
   static const bool off = cpp_switch_off("CPP_CONV_K16") ||
                           cpp_switch_off("CPP_CONV_KYO") ||
                           cpp_switch_off("CPP_CONV_B16");
@@ -113,7 +115,7 @@ int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, i
   // conv1 of f16 images: f16 matrix pipes with f32-exact operands (conv_k16.h); CPP_CONV_K16=0 keeps the f32 MFMA kernel.
   // (B = 1 stays on the f32 kernel: action_given is bit-identical to a row of cpp_net_forward_each)
   static const bool no_k16 = cpp_switch_off("CPP_CONV_K16");
-  if (!no_kyo && !no_k16 && in_mode == IN_F16_WHITEN && !dx_mode && a.B >= 2 && a.nout <= 10 && a.H >= 2) {
+  if (!no_kyo && !no_k16 && !ctx->conv1_f32 && in_mode == IN_F16_WHITEN && !dx_mode && a.B >= 2 && a.nout <= 10 && a.H >= 2) {
     bool handled = false;
     if (int grc = guard_band_check(batch, cin, "conv1 forward")) { prof_end(ctx, kid); return grc; }
     rc = conv_fwd_rs16_dispatch(ctx, cin, ks, in_mode, plain_fwd, batch, &handled);
@@ -221,7 +223,7 @@ int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, co
   bool handled = false;
   // conv1 of f16 images: f16 matrix pipes with f32-exact operands (conv_dw16.h); CPP_CONV_K16=0 keeps the f32 MFMA kernel
   static const bool no_k16 = cpp_switch_off("CPP_CONV_K16");
-  if (!no_kyo && !no_k16 && in_mode == IN_F16_WHITEN) {
+  if (!no_kyo && !no_k16 && !ctx->conv1_f32 && in_mode == IN_F16_WHITEN) {
     if (int grc = guard_band_check(batch, cin, "conv1 dW")) { prof_end(ctx, kid); return grc; }
     const bool ride_open = ctx->ride != nullptr && !ctx->ride_done;
     rc = conv_dw16_dispatch(ctx, cin, ks, in_mode, dense, batch, &grid, &handled);
@@ -271,8 +273,12 @@ int flush_dw_reduce(cpp_ctx* ctx) {
     ctx->ride_done = true;
     return launch_reduce_gather(ctx, rb, *ctx->ride, ctx->ride_dtype);
   }
+  // the statistics of a sample pass that has ALREADY left (with conv1's dW) can be finished here: the tables are then in memory before
+  // the optimiser's launch starts, whose conv1 image rider needs them
+  const StatsRide* st = (ctx->st_ride && !ctx->st_ride_done && (!ctx->ride || ctx->ride_done)) ? ctx->st_ride : nullptr;
+  if (st) ctx->st_ride_done = true;
   prof_begin(ctx);
-  int rc = launch_dw_reduce_batch(ctx, rb);
+  int rc = launch_dw_reduce_batch(ctx, rb, st);
   prof_end(ctx, K_DW_REDUCE);
   return rc;
 }

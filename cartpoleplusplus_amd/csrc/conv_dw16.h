@@ -423,7 +423,6 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
         if (t >= rows + P) break;
         {  // stage ahead: dY position t + P + 1 (its slot held position t - P - 1), input position t + 2
           const int d = t + P + 1, y = y0 + d;
-#ifndef DW16_ABL_NODY
           if (DENSE) {
             dense_store((sq + P + 1) % G::RING_DY);                       // requested one step ago
             dense_load(rdense, y + 1);
@@ -432,11 +431,8 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
             dy_store((sq + P + 1) % G::RING_DY, (sq + P + 1) & 1);
             if ((d & 1) == 1) dy_issue((y + 1) >> 1, 0);                  // next pooled row, used from the next step on
           }
-#endif
-#ifndef DW16_ABL_NOIN
           if (t + 2 - P < rows) in_store((sq + 2) % G::RING_IN);
           if (t + 3 - P < rows) in_load(in_rs, y0 + t + 3);
-#endif
         }
         // multiply input position t with dY positions t - P .. t + P (of every network: the A fragments are read once)
         const int islot = sq % G::RING_IN;
@@ -447,17 +443,11 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
           for (int k = 0; k < NNET; ++k)
 #pragma unroll
             for (int pc = 0; pc < NPC; ++pc) {
-#ifdef DW16_ABL_NOB
-              if (pc > 0) { bq[k][pc] = bq[k][0]; continue; }
-#endif
               bq[k][pc] = lds_load<f16x8>(badr[sq], k * DYB + pc * G::DPC + ch * 64);
             }
           k16_u32x4 av[MT];
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
-#ifdef DW16_ABL_NOA
-            if (mt > 0) { av[mt] = av[0]; continue; }
-#endif
             const int off = islot * ROWB + ch * (2 * CP * 32) + mt * 32;
             const dw16_v4s r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                 reinterpret_cast<__attribute__((address_space(3))) dw16_v4s*>((uintptr_t)(aadr + (uint32_t)off)));
@@ -474,9 +464,7 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
               for (int mt = 0; mt < MT; ++mt)
                 acc[k][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mt]), bq[k][pc], acc[k][mt], 0, 0, 0);
         }
-#ifndef DW16_ABL_NOBAR
         __syncthreads();
-#endif
       }
     }
   }
@@ -508,9 +496,6 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#ifdef DW16_ABL_NOPART
-  float ablsum = 0.f;
-#endif
 #pragma unroll
   for (int k = 0; k < NNET; ++k) {
     float* part = batch.a[by + k].partial + (long)bx * batch.a[by + k].pstride;
@@ -524,18 +509,11 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
           const int kx = m / CP, c = m - kx * CP;
           if (kx < KS && c < CIN) {
             const float t = tx[kx * 16 + li];
-#ifdef DW16_ABL_NOPART
-            ablsum += inv[k] * (wsc[c] * acc[k][mt][r] + wsc[CIN + c] * t);
-#else
             part[(nky * G::KROW + kx * CIN + c) * nout + no] = inv[k] * (wsc[c] * acc[k][mt][r] + wsc[CIN + c] * t);
-#endif
           }
         }
       }
     }
-#ifdef DW16_ABL_NOPART
-    if (ablsum == 123.456f) part[tid] = ablsum;
-#endif
   }
   // bias gradient: per-thread cell sums -> LDS -> one thread per channel adds them in fixed order
 #ifdef DW16_CLOCK

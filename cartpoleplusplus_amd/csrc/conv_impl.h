@@ -705,7 +705,7 @@ __device__ __forceinline__ void conv_dw_reduce_body(const DwReduceBatch& rb, con
     }
   }
 }
-int launch_dw_reduce_batch(cpp_ctx* ctx, const DwReduceBatch& rb);
+int launch_dw_reduce_batch(cpp_ctx* ctx, const DwReduceBatch& rb, const StatsRide* st = nullptr);
 
 template <int CIN, int KS, int XTW, int IN_MODE, int EPI>
 static inline int conv_fwd_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {

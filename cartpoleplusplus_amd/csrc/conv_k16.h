@@ -130,29 +130,16 @@ struct K16Geom {
   static constexpr int NPC = B16 ? 3 : NPCS;               // f16 / bf16 pieces of a weight
   // weight image in LDS: slab (chunk, piece) holds the 16-byte operand (ky, lane group g, o) at ky*PS + g*GS + o*16;
   // the padded strides keep the rotating per-lane reads of a ds_read_b128 at 1.2 accesses per bank quad (2.45 compact)
-#ifdef K16_MID_LAYOUT
-  static constexpr bool PADDED = true;
-  static constexpr int PS = 784, GS = 160, SLAB = 3840;      // 1.6 accesses per bank quad, 34.5 KB for conv1
-#else
   static constexpr bool PADDED = NCH * NPC * 5632 <= 64 * 1024;
   static constexpr int PS = PADDED ? 1120 : 4 * NO * 16, GS = PADDED ? 256 : NO * 16, SLAB = PADDED ? 5632 : KS * 4 * NO * 16;
-#endif
   static constexpr int WLB = NCH * NPC * SLAB;             // bytes
-#ifdef K16_ABL_OCC3      // (occupancy experiment, WRONG results: one pair-buffer set so that three workgroups fit a CU's LDS)
-#define K16_SETS 1
-#else
-#define K16_SETS 2
-#endif
-  static constexpr int EF = K16_SETS * 2 * 8 * XT * NO * 2;       // floats per wave: (value, code) of the two rows of a pool pair, two pairs (the writer of pair r runs under the rows of pair r + 1)
+  static constexpr int EF = 2 * 2 * 8 * XT * NO * 2;       // floats per wave: (value, code) of the two rows of a pool pair, two pairs (the writer of pair r runs under the rows of pair r + 1)
   // conv2's instance for 32x32 inputs can run conv3 as its tail: the two pooled 16x16 images of the workgroup, zero-haloed
   static constexpr int N3 = (B16 && XT == 1 && IPW == 2) ? C3_IPW * C3_IMGF * 4 + 16 : 0;
   // f16 mode: the border table E [2 P + 1 row classes][NO][x = 0, 1, W - 2, W - 1] (floats, in accumulator units) and the pivots [CIN] (halves)
   static constexpr int NRC = 2 * P + 1;
   static constexpr int CT_BYTES = B16 ? 0 : NRC * NO * 16 + ((CIN * 2 + 15) & ~15);
-#ifndef K16_LDS_PAD
-#define K16_LDS_PAD 0      // (occupancy experiments: bytes of LDS nobody uses)
-#endif
-  static constexpr int LDS_BYTES = WLB + 4 * EF * 4 + 64 + N3 + CT_BYTES + (B16 ? 0 : K16_LDS_PAD);
+  static constexpr int LDS_BYTES = WLB + 4 * EF * 4 + 64 + N3 + CT_BYTES;
   static constexpr int BIAS_BYTES = 128;                   // the buffer descriptor starts this far before the image
   // element e of lane group g in chunk ch is slot kl = 8 g + e of the chunk: real k = RK ch + kl if kl < RK (and k < KROW)
   // can dword v of chunk ch in M tile m (of any strip, any lane) ever hold an element that must be cleared or replaced?  The
@@ -185,7 +172,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   static_assert(B16 != 0 || KS == 5, "the border table of the f16 mode is written for 5x5 (P = 2)");
   constexpr int P = G::P, NT = G::NT, NCH = G::NCH, NPC = G::NPC, NPA = G::NPA, NO = KYO_NO;
   constexpr bool ODD = (CIN & 1) != 0;            // 2-byte aligned operand windows: 20 bytes from the aligned address below + a funnel shift
-#if defined(K16_CLOCK_PROBE) || defined(K16_SPAN_PROBE)
+#if defined(K16_CLOCK_PROBE)
   const unsigned long long pe0 = __builtin_amdgcn_s_memrealtime();
 #endif
   const ConvArgs& a = batch.a[blockIdx.y];
@@ -219,13 +206,6 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     braw[t] = (!PLAIN && j < KS * NO && j % NO < nout) ? a.bias[j % NO] : 0.f;
   }
   // ---- one-time setup: the split weight image
-#ifdef K16_SETUP_PROBE
-  unsigned long long sp[6] = {0, 0, 0, 0, 0, 0};
-#define K16_STAMP(i) sp[i] = __builtin_amdgcn_s_memrealtime()
-#else
-#define K16_STAMP(i)
-#endif
-  K16_STAMP(0);
   float sc, inv;                                      // 2^S, 2^-S
   int onesT = 0;                                      // f16 mode: the ones slots' A value is 2^T
   float* ctab = reinterpret_cast<float*>(lds_raw + G::WLB + 4 * G::EF * 4 + 64 + G::N3);      // [NRC][NO][4] (f16 mode)
@@ -247,9 +227,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     float* bpart = reinterpret_cast<float*>(opart + (B16 ? 0 : NU));      // [NU][NB]
     float* scl = bpart + (B16 ? 0 : NU * NB);         // [CIN] whitening scale, [CIN] p_c - mu_c
     float* dmu = scl + CIN;
-#ifndef K16_ABL_OCC3
     static_assert(B16 || (((CIN + 1) & ~1) + NU) * 8 + (NU * NB + 2 * CIN) * 4 <= 4 * G::EF * 4, "the setup's scratch fits the pool-pair buffers");
-#endif
     // branch-free: every load of the build is in flight before the first use
 #pragma unroll
     for (int n = 0; n < NUW; ++n) {
@@ -297,7 +275,6 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #ifdef K16_CLOCK_PROBE
     if (tid == 0 && (blockIdx.x % 97) == 5 && blockIdx.y == 1) printf("K16PRE loads+max %llu, to sync %llu\n", pq0 - pe0, __builtin_amdgcn_s_memrealtime() - pe0);
 #endif
-    K16_STAMP(1);
     vmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     int S = 0;
     if (!B16 && vmax > 0.f && vmax < 3.0e38f) S = 14 - ilogbf(vmax);       // vmax 2^S in [2^14, 2^15); bf16 pieces need no scale
@@ -352,7 +329,6 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     if (!B16) {
       // ---- the ones slots and the border table from the units' partials, in a fixed order (g = 0 .. 3; chunk, g ascending)
       __syncthreads();
-      K16_STAMP(2);
       constexpr int NJ1 = KS * NCH * NO;
       constexpr int NJW = (NJ1 + CONV_THREADS - 1) / CONV_THREADS;
       double osumv[NJW];                              // this thread's ones sums (job = tid + k * 256), kept for the slot writes below
@@ -399,7 +375,6 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
       for (int o = 32; o > 0; o >>= 1) omax = fmax(omax, __shfl_xor(omax, o));
       if (lane == 0) red[4 + wave] = (float)omax;      // (an upper bound is all that is needed: rounded up below)
       __syncthreads();
-      K16_STAMP(3);
       const float om = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])) * 1.0001f;
       onesT = (om > 0.f && om < 3.0e38f) ? ilogbf(om) - 14 : 0;      // |ones weight| 2^-T < 2^15
       onesT = onesT < 0 ? 0 : (onesT > 15 ? 15 : onesT);      // (T > 15: |mu| > 2^10 -- not an image; the pieces saturate to inf and the output says so)
@@ -422,24 +397,11 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
       }
     }
   }
-  K16_STAMP(4);
   __syncthreads();                                   // weight image visible; no barrier after this one
-  K16_STAMP(5);
-#ifdef K16_SETUP_PROBE
-  if (tid == 0 && (blockIdx.x % 37) == 5 && !B16)
-    printf("K16SETUP cin %d: loads+vmax %llu, split %llu, sums %llu, slots+table %llu, sync %llu (10 ns ticks)\n", CIN, sp[1] - sp[0], sp[2] - sp[1], sp[3] - sp[2], sp[4] - sp[3], sp[5] - sp[4]);
-#endif
 #ifdef K16_CLOCK_PROBE
   const unsigned long long pe1 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-#ifdef K16_STAGGER      // (phase experiment: the waves in the odd wave slots of their SIMD start the row loop K16_STAGGER x 64 cycles late)
-  {
-    unsigned hwid;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    if (hwid & 1u) __builtin_amdgcn_s_sleep(K16_STAGGER);
-  }
-#endif
   const int swave = __builtin_amdgcn_readfirstlane(wave);
   const int simg = swave / G::STRIPS, sstrip = swave % G::STRIPS;
   const int sbimg = b0 + simg;
@@ -449,7 +411,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   uint32_t wadr[KS][NT];
   uint32_t eadr[NT];
   float biast[NT];
-  float2* ev = ebuf + swave * (K16_SETS * 2 * 8 * XT * NO);
+  float2* ev = ebuf + swave * (2 * 2 * 8 * XT * NO);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int j = 16 * t + li;
@@ -533,29 +495,20 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     c3adr[i] = lds_addr(cact[i] ? img3 + simg * C3_IMGF + (C3_PW + px + 1) * C3_C + o : img3 + C3_IPW * C3_IMGF);   // (junk pair behind the images)
   }
   constexpr int SH = 5;                               // vector-memory stores of one writer HALF (all issued, every row; see k16_issue_b128)
-#ifdef K16_ABL_NOSTORE      // (timing experiment: every pooled-row store is issued and dropped)
-#define K16_RANGE(x) 0
-#else
-#define K16_RANGE(x) (x)
-#endif
   const __amdgpu_buffer_rsrc_t b16_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       a.out_b16 ? a.out_b16 + (long)sbimg * (Hp * Wp * nout) : (unsigned short*)a.out, 0,
-      K16_RANGE(a.out_b16 ? (int)(2 * a.out_b16_plane * 2 + (long)Hp * Wp * nout * 2) : 0), 0x00020000);      // this image in the three planes, no further
+      a.out_b16 ? (int)(2 * a.out_b16_plane * 2 + (long)Hp * Wp * nout * 2) : 0, 0x00020000);      // this image in the three planes, no further
   const int b16_plane_bytes = (int)(a.out_b16_plane * 2);
   // (a null output -- the target networks' f32 pool1 and codes in the fused step -- gets an empty range: its stores are issued
   // and dropped, so the number of vector-memory instructions per writer pass does not depend on the network)
   const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      a.out ? a.out + (long)sbimg * a.out_bstride : (float*)a.out_b16, 0, K16_RANGE(a.out ? (PLAIN ? H * W : Hp * Wp) * nout * 4 : 0), 0x00020000);
+      a.out ? a.out + (long)sbimg * a.out_bstride : (float*)a.out_b16, 0, (a.out ? (PLAIN ? H * W : Hp * Wp) * nout * 4 : 0), 0x00020000);
   const __amdgpu_buffer_rsrc_t amax_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      a.out_amax ? a.out_amax + (long)sbimg * Hp * Wp * nout : (uint8_t*)a.out_b16, 0, K16_RANGE(a.out_amax ? Hp * Wp * nout : 0), 0x00020000);
+      a.out_amax ? a.out_amax + (long)sbimg * Hp * Wp * nout : (uint8_t*)a.out_b16, 0, (a.out_amax ? Hp * Wp * nout : 0), 0x00020000);
 
   // ---- A operands: 16 bytes per lane and (tile, chunk) straight from the image row
   const int rowbytes = W * CIN * 2;
-#ifdef K16_ABL_SAMEIMG      // (timing experiment, wrong results: every workgroup reads image 0 / 1 -- the A operands come from L2, never from HBM)
-  void* const in_base = (void*)((const char*)(B16 ? (const void*)a.in_b16 : a.in) + ((long)(a.img_slot ? a.img_slot[sbimg & 1] : (sbimg & 1)) * a.in_bstride) * 2 - G::BIAS_BYTES);
-#else
   void* const in_base = (void*)((const char*)(B16 ? (const void*)a.in_b16 : a.in) + ((long)(a.img_slot ? a.img_slot[sbimg] : sbimg) * a.in_bstride) * 2 - G::BIAS_BYTES);
-#endif
   const int in_records = (B16 ? 2 * (int)a.plane_stride : 0) + H * rowbytes + G::BIAS_BYTES + 256;      // this image (B16: in its three planes) + the masked overhang
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(in_base, 0, in_records, 0x00020000);
   const k16_i32x4 in_desc = k16_raw_desc(in_base, in_records);      // the same descriptor for the inline-asm loads
@@ -582,16 +535,12 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
         if (ODD) k16_issue_b32(ax[ch][m], in_desc, avoff, y * rowbytes + (m * 16 * CIN + G::RK * ch) * 2 + 16);
         continue;
       }
-#ifdef K16_ABL_NOLDSA
-      av[0][ch][m] = (k16_u32x4){emask[NCH - 1][0][1], ecst[NCH - 1][0][1], emask[NCH - 1][0][2], (unsigned)y};
-#else
 #pragma unroll
       for (int pa = 0; pa < NPA; ++pa) {
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, avoff + (m * 16 * CIN + G::RK * ch) * 2, pa * plane_bytes + y * rowbytes, 0);
         av[pa][ch][m] = (k16_u32x4){v.x, v.y, v.z, v.w};
       }
       if (ODD) ax[ch][m] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, avoff + (m * 16 * CIN + G::RK * ch) * 2 + 16, y * rowbytes, 0);
-#endif
     }
   };
 
@@ -618,7 +567,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     if (PLAIN || half >= NC) return;
     const int i = half < NC ? half : 0;
     const int prs = (sure || (pr >= 0 && pr < Hp)) ? pr : 0;
-    const uint32_t ca = cadr[i] + (uint32_t)((prs & (K16_SETS - 1)) * (2 * 8 * XT * NO) * 8);
+    const uint32_t ca = cadr[i] + (uint32_t)((prs & 1) * (2 * 8 * XT * NO) * 8);
     wtop = lds_load<f32x4>(ca, 0); wbot = lds_load<f32x4>(ca, (8 * XT * NO) * 8);
   };
   auto writer_half = [&](const int half, const int pr, const bool sure = false) {
@@ -676,20 +625,13 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   auto load_b_piece = [&](int ch, int pc, const uint32_t* wa) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-#ifdef K16_ABL_HALFB      // (timing experiment: only piece 0 is read from LDS, the other pieces' MFMAs reuse its registers -- wrong results)
-      if (pc > 0) { bv[t][pc] = bv[t][0]; continue; }
-#endif
-#ifdef K16_ABL_NOLDSB
-      bv[t][pc] = __builtin_bit_cast(f16x8, (k16_u32x4){emask[NCH - 1][0][1], ecst[NCH - 1][0][1], emask[NCH - 1][0][2], wa[t]});
-#else
       bv[t][pc] = lds_load<f16x8>(wa[t], (ch * NPC + pc) * G::SLAB);
-#endif
     }
   };
 #pragma unroll
   for (int pc = 0; pc < NPC; ++pc) load_b_piece(0, pc, wadr[0]);
 
-#if defined(K16_CLOCK_PROBE) || defined(K16_SPAN_PROBE)
+#if defined(K16_CLOCK_PROBE)
   const unsigned long long pc0 = __builtin_readcyclecounter(), pr0 = __builtin_amdgcn_s_memrealtime();
 #endif
   auto block = [&](auto itag, const int q0) {
@@ -730,9 +672,6 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
       if (IN || q < H) {
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
-#ifdef K16_PRIO      // (experiments: priority K16_PRIO during a chunk's MFMAs, K16_PRIO_OUT outside)
-          __builtin_amdgcn_s_setprio(K16_PRIO);
-#endif
           if (ASYNC_A) {
             // this chunk's operands were requested one row ago; issued since: the other chunks' loads and -- between chunk 0's
             // MFMAs and its loads -- the SH stores of the writer half every row carries (real or dropped: ONE wait count per chunk)
@@ -753,19 +692,13 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
           for (int m = 0; m < XT; ++m) {
             k16_u32x4 u = av[pa][ch][m];
             if (ODD) {
-#ifndef K16_ABL_NOLDSA
               const unsigned x4 = ax[ch][m];
               u = (k16_u32x4){__builtin_amdgcn_alignbyte(u[1], u[0], ashift), __builtin_amdgcn_alignbyte(u[2], u[1], ashift),
                               __builtin_amdgcn_alignbyte(u[3], u[2], ashift), __builtin_amdgcn_alignbyte(x4, u[3], ashift)};
-#endif
             }
 #pragma unroll
             for (int v = 0; v < 4; ++v)
-#ifndef K16_ABL_NOMASK
-#ifndef K16_ABL_NOMASK
               if (G::vgpr_may_need_mask(ch, m, v)) u[v] = (u[v] & emask[ch][m][v]) | ecst[ch][m][v];
-#endif
-#endif
             af[pa][m] = u;
           }
 #pragma unroll
@@ -773,9 +706,6 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #pragma unroll
             for (int pa = NPA - 1; pa >= 0; --pa) {
               if (B16 && pa + pc > B16) continue;
-#ifdef K16_ABL_MFMA_PIECES      // (timing experiment, wrong results: only the first K16_ABL_MFMA_PIECES pieces' MFMAs are issued -- 0: none)
-              if (pc >= K16_ABL_MFMA_PIECES) continue;
-#endif
 #pragma unroll
               for (int m = 0; m < XT; ++m)
 #pragma unroll
@@ -792,23 +722,14 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
             else if (IN || q + 1 < H) load_b_piece(0, pc, wadr[(sq + 1) % KS]);
             __builtin_amdgcn_sched_barrier(0);
           }
-#ifdef K16_PRIO
-#ifndef K16_PRIO_OUT
-#define K16_PRIO_OUT 0
-#endif
-          __builtin_amdgcn_s_setprio(K16_PRIO_OUT);
-#endif
           if (ch == 0) writer_half(wy & 1, wpr, IN);
           if (ASYNC_A || q + 1 < H) load_a(ch, q + 1);   // this chunk's operands of the next row, a whole row period ahead (ASYNC_A:
                                                          // also behind the last row -- masked by the descriptor, never used -- so
                                                          // that the hand-counted waits see the same sequence in every row)
+          if (!ASYNC_A) __builtin_amdgcn_sched_barrier(0);      // (compiler-counted loads stay where they are issued: left alone, the scheduler sinks them to their first use)
         }
       }
-#ifdef K16_ABL_NOEPI
-      const int y = (q == H + P - 1) ? q - P : -1;
-#else
       const int y = (IN || q - P >= ymin) ? q - P : -1;      // (rows in front of the band: partial sums, dropped like the rows above the image)
-#endif
       const int par = y & 1;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -836,7 +757,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
                                                             (int)eadr[t] + ((m * 16 + r) * NO) * 4, y * W * nout * 4, 0);
                 }
               } else if (IN || y >= 0) {
-                const uint32_t ea = eadr[t] + (uint32_t)((((y >> 1) & (K16_SETS - 1)) * 2 + par) * (8 * XT * NO) * 8);
+                const uint32_t ea = eadr[t] + (uint32_t)((((y >> 1) & 1) * 2 + par) * (8 * XT * NO) * 8);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                   const float z0 = zc[2 * h], z1 = zc[2 * h + 1];
@@ -856,13 +777,11 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   {
     auto interior = [&](const int q0) { return !PLAIN && q0 >= ymin + P + 2 && q0 >= 2 * P && q0 + KS < H && q0 + KS <= qend; };
     int q0 = qbeg;
-#ifndef K16_NO_INTERIOR
     // (five chunks per row -- 30 channels -- sit at 254 VGPRs with the general step alone: the second copy of the loop spilled, 1125 -> 1173 us)
     if constexpr (NCH <= 3) {
       for (; q0 < qend && !interior(q0); q0 += KS) block(std::false_type{}, q0);      // the band's first rows
       for (; q0 < qend && interior(q0); q0 += KS) block(std::true_type{}, q0);
     }
-#endif
     for (; q0 < qend; q0 += KS) block(std::false_type{}, q0);                       // ... and its last ones
   }
   {  // the last pair(s): the two steps behind the loop would have carried their writer halves
@@ -884,10 +803,6 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     conv3_img_half(ops, img3 + im3 * C3_IMGF, wave & 1, a.n3_out + (long)(b0 + im3) * a.n3_out_bstride,
                    a.n3_amax + (long)(b0 + im3) * (C3_H / 2) * (C3_H / 2) * nout, nout, li, lj);
   }
-#ifdef K16_SPAN_PROBE
-  if (lane == 0 && wave == 0 && (blockIdx.x % 16) == 1 && (int)blockIdx.y >= K16_SPAN_PROBE)
-    printf("K16SPAN cin %d y %d x %d start %llu loop %llu end %llu\n", CIN, (int)blockIdx.y, (int)blockIdx.x, (unsigned long long)pe0, (unsigned long long)pr0, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-#endif
 #ifdef K16_CLOCK_PROBE
   if (lane == 0 && (blockIdx.x % 97) == 5 && blockIdx.y == 1 && wave == 0) {
     const unsigned long long pc1 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();

@@ -40,7 +40,13 @@ struct Rs16Geom {
 
 // ---- the operand image of one network: conv_k16.h's setup, value for value (same f32 / f64 operations in the same order), written
 // once to global memory.  One workgroup per network.
-struct Conv1ImageArgs { const float* w; const float* bias; const float* scale; const float* shift; float wscale; int nout; unsigned char* rec; };
+struct Conv1ImageArgs {
+  const float* w; const float* bias; const float* scale; const float* shift; float wscale; int nout; unsigned char* rec;
+  // optional (the builder riding in the optimiser's launch, optim.hip): the weights are the ones THIS launch's SGD update is about to
+  // write, w - lr * (gw * gscale), recomputed with the update's own operations -- the builder waits for nobody
+  const float* gw; const float* gb; float lr, gscale;
+  float* w_out; float* b_out;     // ... and written by THIS workgroup (the update's own workgroups leave these parameters alone: no one reads a half-updated tensor)
+};
 struct Conv1ImageArgsN { Conv1ImageArgs a[CONV_BATCH_MAX]; int n; };
 
 template <int CIN, int NPCS = F16_PIECES>
@@ -62,7 +68,37 @@ __device__ __forceinline__ void conv1_image_body(const Conv1ImageArgs& a, unsign
   float* ctab = red + 8;                                                    // E[NRC][NO][4]
   unsigned short* pivot = reinterpret_cast<unsigned short*>(ctab + G::NRC * NO * 4);      // [CIN]
   constexpr int NUW = (NU + CONV_THREADS - 1) / CONV_THREADS;
-  for (int i = tid; i < G::REC_BYTES / 16; i += CONV_THREADS) reinterpret_cast<k16_u32x4*>(rec)[i] = (k16_u32x4){0u, 0u, 0u, 0u};
+#ifdef RS16_IMAGE_PROBE
+  unsigned long long sp[8]; int spn = 0;
+#define RS16_STAMP() sp[spn++] = __builtin_amdgcn_s_memrealtime()
+#else
+#define RS16_STAMP()
+#endif
+  RS16_STAMP();
+  // the layer's weights (as this launch's SGD update leaves them, if it rides there) through LDS: consecutive threads load consecutive
+  // floats -- a thread fetching its own 24 (ky, k, o) values asked for 40-byte strides, 2.6 us of this workgroup (6.5 with the gradients)
+  float* wst = reinterpret_cast<float*>(lds_raw);              // [KS * KROW * nout] -- in the record's place, which is written later
+  const int nwts = KS * G::KROW * nout;
+  {
+    constexpr int NWT = (KS * G::KROW * NO + CONV_THREADS - 1) / CONV_THREADS;      // (every load in flight before the first use)
+    float wr[NWT], gr[NWT];
+#pragma unroll
+    for (int n = 0; n < NWT; ++n) { const int i = tid + n * CONV_THREADS; wr[n] = a.w[i < nwts ? i : 0]; }
+    if (a.gw) {
+#pragma unroll
+      for (int n = 0; n < NWT; ++n) { const int i = tid + n * CONV_THREADS; gr[n] = a.gw[i < nwts ? i : 0]; }
+    }
+#pragma unroll
+    for (int n = 0; n < NWT; ++n) {
+      const int i = tid + n * CONV_THREADS;
+      if (i < nwts) {
+        const float w = a.gw ? sgd_update(wr[n], gr[n], a.gscale, a.lr) : wr[n];      // (opt_apply_kernel's own expression)
+        wst[i] = w;
+        if (a.gw && a.w_out) a.w_out[i] = w;
+      }
+    }
+  }
+  __syncthreads();
   float wv[NUW][8];
   float vmax = 0.f;
 #pragma unroll
@@ -73,9 +109,14 @@ __device__ __forceinline__ void conv1_image_body(const Conv1ImageArgs& a, unsign
     for (int e = 0; e < 8; ++e) {
       const int kl = 8 * g + e, k = RK * ch + kl;
       const bool real = u < NU && o < nout && kl < RK && k < G::KROW;
-      const float w = a.w[real ? (ky * G::KROW + k) * nout + o : 0];
-      wv[n][e] = real ? w : 0.f;
+      wv[n][e] = real ? wst[(ky * G::KROW + k) * nout + o] : 0.f;
     }
+  }
+  float* biasn = reinterpret_cast<float*>(pivot + ((CIN + 7) & ~7));      // [16] the layer's biases as this launch leaves them
+  if (tid < 16) {
+    float bo = (a.bias && tid < nout) ? a.bias[tid] : 0.f;
+    if (a.bias && a.gb && tid < nout) { bo = sgd_update(bo, a.gb[tid], a.gscale, a.lr); if (a.b_out) a.b_out[tid] = bo; }
+    biasn[tid] = bo;
   }
   if (tid < CIN) {
     const float s_c = a.scale[tid], t_c = a.shift[tid];
@@ -103,7 +144,10 @@ __device__ __forceinline__ void conv1_image_body(const Conv1ImageArgs& a, unsign
   for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
   if (lane == 0) red[wave] = vmax;
   __syncthreads();
+  RS16_STAMP();
   vmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  for (int i = tid; i < G::REC_BYTES / 16; i += CONV_THREADS) reinterpret_cast<k16_u32x4*>(rec)[i] = (k16_u32x4){0u, 0u, 0u, 0u};
+  __syncthreads();                                   // (every thread has its weights in registers: the record takes the staging area over)
   int S = 0;
   if (vmax > 0.f && vmax < 3.0e38f) S = 14 - ilogbf(vmax);
   S = S > 100 ? 100 : (S < -100 ? -100 : S);
@@ -150,6 +194,7 @@ __device__ __forceinline__ void conv1_image_body(const Conv1ImageArgs& a, unsign
     }
   }
   __syncthreads();
+  RS16_STAMP();
   constexpr int NJ1 = KS * NCH * NO;
   constexpr int NJW = (NJ1 + CONV_THREADS - 1) / CONV_THREADS;
   double osumv[NJW];
@@ -190,6 +235,7 @@ __device__ __forceinline__ void conv1_image_body(const Conv1ImageArgs& a, unsign
   for (int o = 32; o > 0; o >>= 1) omax = fmax(omax, __shfl_xor(omax, o));
   if (lane == 0) red[4 + wave] = (float)omax;
   __syncthreads();
+  RS16_STAMP();
   const float om = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])) * 1.0001f;
   int onesT = (om > 0.f && om < 3.0e38f) ? ilogbf(om) - 14 : 0;
   onesT = onesT < 0 ? 0 : (onesT > 15 ? 15 : onesT);
@@ -214,7 +260,7 @@ __device__ __forceinline__ void conv1_image_body(const Conv1ImageArgs& a, unsign
     const int o = job & 15, xs = (job >> 4) % 5, rc = job / 80;
     float v = 0.f;
     if (o < nout) {
-      v = (a.bias ? a.bias[o] : 0.f) * sc;
+      v = biasn[o] * sc;
       if (xs > 0) v -= ctab[(rc * NO + o) * 4 + xs - 1];
     }
     reinterpret_cast<float*>(rec + G::CT_OFF)[job] = v;
@@ -234,14 +280,19 @@ __device__ __forceinline__ void conv1_image_body(const Conv1ImageArgs& a, unsign
   }
   if (tid == 0) *reinterpret_cast<float*>(rec + G::SC_OFF) = inv;
   __syncthreads();
+  RS16_STAMP();
   for (int i = tid; i < G::REC_BYTES / 16; i += CONV_THREADS) reinterpret_cast<k16_u32x4*>(a.rec)[i] = reinterpret_cast<const k16_u32x4*>(rec)[i];
+  RS16_STAMP();
+#ifdef RS16_IMAGE_PROBE
+  if (tid == 0) printf("RS16IMG gw %d: zero+loads+vmax %llu, split %llu, sums+table %llu, slots+ct %llu, copy out %llu (10 ns ticks)\n", a.gw != nullptr, sp[1] - sp[0], sp[2] - sp[1], sp[3] - sp[2], sp[4] - sp[3], sp[5] - sp[4]);
+#endif
 }
 
 template <int CIN, int NPCS = F16_PIECES>
 struct Rs16ImageLds {
   typedef Rs16Geom<CIN, NPCS> G;
   static constexpr int NU = G::KS * G::NCH * 4 * G::NO, NB = 7 / CIN + 2;
-  static constexpr int BYTES = G::REC_BYTES + (((CIN + 1) & ~1) + NU) * 8 + (NU * NB + 2 * CIN + 8 + G::NRC * G::NO * 4) * 4 + ((CIN * 2 + 15) & ~15);
+  static constexpr int BYTES = G::REC_BYTES + (((CIN + 1) & ~1) + NU) * 8 + (NU * NB + 2 * CIN + 8 + G::NRC * G::NO * 4) * 4 + ((CIN * 2 + 15) & ~15) + 2 * CIN + 64 + 64;
 };
 
 template <int CIN, int NPCS = F16_PIECES>

@@ -5,6 +5,7 @@
 // (blockIdx.y = segment).  Reductions are two-stage and fixed-order.
 #include "common.h"
 #include "stats_body.h"
+#include "conv_rs16.h"
 
 constexpr int OPT_THREADS = 256;
 
@@ -56,9 +57,85 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_apply_kernel(const OptSegs s,
                                                                 int nparts, float* norms_out) {
   __shared__ float sh_scale, sh_lr;
   const int seg = blockIdx.y;
-  if (seg == s.nseg) {                               // the rider's grid row (uniform per workgroup)
+  if (s.img_n > 0 && seg == s.nseg + (s.st_part ? 1 : 0)) {      // conv1's operand images of the next minibatch (uniform per workgroup)
+    if ((int)blockIdx.x >= s.img_n) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char img_lds[];
+    __shared__ float wh[2 * CPP_MAX_CHANNELS];
+    const int j = blockIdx.x, ws = s.img[j].seg;
+#ifdef RS16_IMAGE_PROBE
+    const unsigned long long ip0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // the update's scale, as the workgroups of segment ws compute it below (same partials, same order)
+    if (s.img[j].gw) {
+      double tot = 0.0;
+      if (threadIdx.x < 64) {
+        if (s.sq) {
+          const int gr = s.group[ws];
+          const double* q = s.sq + s.sq_begin[gr];
+          for (int i = threadIdx.x; i < s.sq_count[gr]; i += 64) tot += q[i];
+        } else {
+          for (int k = 0; k < s.nseg; ++k)
+            if (s.group[k] == s.group[ws])
+              for (int i = threadIdx.x; i < nparts; i += 64) tot += part[k * nparts + i];
+        }
+        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+      }
+      if (threadIdx.x == 0) {
+        const float norm = (float)sqrt(tot);
+        float sc = 1.f;
+        if (clip > 0.f) sc = clip * fminf(1.f / norm, 1.f / clip);
+        sh_scale = sc * grad_scale;
+      }
+    }
+    // the whitening table of the network's state column, as the first rider's waves compute it (stats_finalize_wave: a lane's rows in
+    // increasing order, then the butterfly) -- with every load of the wave's channels in flight at once (channel after channel the
+    // five round trips were 10 us of this workgroup)
+    if (s.img[j].white) {
+      if ((int)threadIdx.x < 2 * 18) wh[threadIdx.x] = s.img[j].white[threadIdx.x];      // (finished by the dW reductions' launch)
+    } else {
+      constexpr int NW = OPT_THREADS / 64, MAXC = (18 + NW - 1) / NW, MAXR = 8;
+      const int wv = (int)(threadIdx.x >> 6), ln = (int)(threadIdx.x & 63), C = s.st_C, np_ = s.st_nparts;
+      if (np_ <= 64 * MAXR) {
+        double v[MAXC][MAXR][2];
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) {
+          const int c = wv + NW * k;
+#pragma unroll
+          for (int r = 0; r < MAXR; ++r) {
+            const int b = ln + 64 * r;
+            const bool ok = c < C && b < np_;
+            const double* q = s.st_part + ((long)s.img[j].col * np_ + (ok ? b : 0)) * 2 * C;
+            v[k][r][0] = ok ? q[c] : 0.0; v[k][r][1] = ok ? q[C + c] : 0.0;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) {
+          const int c = wv + NW * k;
+          double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+          for (int r = 0; r < MAXR; ++r) if (ln + 64 * r < np_) { a0 += v[k][r][0]; a1 += v[k][r][1]; }
+          for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); }
+          if (ln == 0 && c < C) white_from_moments(a0, a1, s.st_count, s.st_eps, &wh[c], &wh[C + c]);
+        }
+      } else {
+        for (int c = wv; c < C; c += NW)
+          stats_finalize_wave_to(s.st_part, np_, C, s.st_count, &wh[c], &wh[C + c], s.st_eps, s.img[j].col, c, ln);
+      }
+    }
+    __syncthreads();
+#ifdef RS16_IMAGE_PROBE
+    if (threadIdx.x == 0) printf("RS16RIDER job %d: norm + table %llu ticks\n", j, __builtin_amdgcn_s_memrealtime() - ip0);
+#endif
+    Conv1ImageArgs ia;
+    ia.w = s.img[j].w; ia.bias = s.img[j].bias; ia.scale = wh; ia.shift = wh + 18; ia.wscale = 0.f; ia.nout = s.img[j].nout; ia.rec = s.img[j].rec;
+    ia.gw = s.img[j].gw; ia.gb = s.img[j].gb; ia.lr = s.img[j].gw ? s.lr[ws] : 0.f; ia.gscale = s.img[j].gw ? sh_scale : 0.f;
+    ia.w_out = s.img[j].gw ? s.img[j].w : nullptr; ia.b_out = s.img[j].gw ? s.img[j].bias : nullptr;
+    conv1_image_body<18>(ia, img_lds);
+    return;
+  }
+  if (s.st_part && seg == s.nseg) {                  // the rider's grid row (uniform per workgroup)
     const int job = (int)blockIdx.x * (OPT_THREADS / 64) + (int)(threadIdx.x >> 6);
-    if (job < s.st_jobs) stats_finalize_wave(s.st_part, s.st_nparts, s.st_C, s.st_count, s.st_white, s.st_eps, job, (int)(threadIdx.x & 63));
+    if (job < s.st_jobs) stats_finalize_wave(s.st_part, s.st_nparts, s.st_C, s.st_count, s.st_white, s.st_eps, job, (int)(threadIdx.x & 63), s.st_wmax);
     return;
   }
   if (s.skip_if && *s.skip_if) return;               // (uniform)
@@ -93,9 +170,11 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_apply_kernel(const OptSegs s,
   }
   __syncthreads();
   const float sc = sh_scale, lr = sh_lr;
-  float* p = s.p[seg];
-  const float* g = s.g[seg];
-  const long n = s.n[seg];
+  // (with the image rider the segment's leading conv1 parameters are updated by its image workgroup, which needs them before and after)
+  const long skip = s.img_n > 0 ? s.img_skip[seg] : 0;
+  float* p = s.p[seg] + skip;
+  const float* g = s.g[seg] + skip;
+  const long n = s.n[seg] - skip;
   const long stride = (long)gridDim.x * OPT_THREADS;
   if (s.kind == OPT_SGD) {
     long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x;
@@ -104,10 +183,10 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_apply_kernel(const OptSegs s,
 #pragma unroll
       for (int u = 0; u < 4; ++u) { pv[u] = p[i + u * stride]; gv[u] = g[i + u * stride]; }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) p[i + u * stride] = pv[u] - lr * (gv[u] * sc);
+      for (int u = 0; u < 4; ++u) p[i + u * stride] = sgd_update(pv[u], gv[u], sc, lr);
     }
     for (; i < n; i += stride)
-      p[i] = p[i] - lr * (g[i] * sc);
+      p[i] = sgd_update(p[i], g[i], sc, lr);
   } else if (s.kind == OPT_MOMENTUM) {
     float* m = s.m[seg];
     for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += stride) {
@@ -132,7 +211,17 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_apply_kernel(const OptSegs s,
 int launch_opt_apply(cpp_ctx* ctx, const OptSegs& s, float grad_scale, float clip, const double* part,
                      int nparts, float* norms_out) {
   prof_begin(ctx);
-  hipLaunchKernelGGL(opt_apply_kernel, dim3(128, s.nseg + (s.st_part ? 1 : 0)), dim3(OPT_THREADS), 0, ctx->stream, s, grad_scale,
+  const bool img = s.img_n > 0 && (s.st_part || s.img[0].white);
+  const size_t lds = img ? (size_t)Rs16ImageLds<18>::BYTES : 0;
+  if (img) {
+    if (s.kind != OPT_SGD || (s.st_part && s.st_C != 18) || s.skip_if) { cpp_set_error("opt_apply: the conv1 image rider needs plain SGD and 18 channels"); return 1; }
+    static bool attr_done[CPP_MAX_DEVICES] = {};
+    if (!attr_done[cpp_dev_slot(ctx)]) {
+      HIP_CHECK(hipFuncSetAttribute((const void*)opt_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Rs16ImageLds<18>::BYTES));
+      attr_done[cpp_dev_slot(ctx)] = true;
+    }
+  }
+  hipLaunchKernelGGL(opt_apply_kernel, dim3(128, s.nseg + (s.st_part ? 1 : 0) + (img ? 1 : 0)), dim3(OPT_THREADS), lds, ctx->stream, s, grad_scale,
                      clip, part, nparts, norms_out);
   LAUNCH_CHECK();
   prof_end(ctx, K_CLIP_SGD);

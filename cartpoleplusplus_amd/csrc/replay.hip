@@ -93,16 +93,16 @@ int launch_gather_stats(cpp_ctx* ctx, const GatherArgs& a, int dtype) {
 
 // white[w][0][c] = rsqrt(var + 1e-6), white[w][1][c] = -mean * rsqrt(var + 1e-6)   (base_network.py:97-99)
 __global__ __launch_bounds__(64) void stats_finalize_kernel(const double* part, int nparts, int which_count,
-                                                            int C, double count, float* white, double eps, uint64_t* bump) {
+                                                            int C, double count, float* white, double eps, uint64_t* bump, unsigned* wmax) {
   if (bump && blockIdx.x == 0 && threadIdx.x == 0) *bump += 1;
-  stats_finalize_wave(part, nparts, C, count, white, eps, (int)blockIdx.x, (int)threadIdx.x);
+  stats_finalize_wave(part, nparts, C, count, white, eps, (int)blockIdx.x, (int)threadIdx.x, wmax);
 }
 
 int launch_stats_finalize(cpp_ctx* ctx, const double* part, int nparts, int which_count, int C,
-                          double count, float* white, double eps, uint64_t* bump) {
+                          double count, float* white, double eps, uint64_t* bump, unsigned* wmax) {
   prof_begin(ctx);
   hipLaunchKernelGGL(stats_finalize_kernel, dim3(which_count * C), dim3(64), 0, ctx->stream, part, nparts,
-                     which_count, C, count, white, eps, bump);
+                     which_count, C, count, white, eps, bump, wmax);
   LAUNCH_CHECK();
   prof_end(ctx, K_STATS_FINALIZE);
   return 0;

@@ -59,7 +59,7 @@ void prof_end(cpp_ctx* ctx, int kid) {
 static const char* kKernelNames[K_NUM_KERNELS] = {
     "gather_stats", "stats_finalize", "stats_generic", "conv1_fwd", "conv2_fwd", "conv3_fwd",
     "conv1_dw", "conv2_dw", "conv3_dw", "conv2_dx", "conv3_dx", "dw_reduce", "gemm", "elementwise",
-    "td", "sumsq", "clip_sgd", "soft_update", "replay_fill", "naf_head", "conv1_fwd_f16", "conv1_dw_f16", "heads", "conv3_bwd", "conv2_bwd", "reduce_gather", "conv1_dw_gather"};
+    "td", "sumsq", "clip_sgd", "soft_update", "replay_fill", "naf_head", "conv1_fwd_f16", "conv1_dw_f16", "heads", "conv3_bwd", "conv2_bwd", "reduce_gather", "conv1_dw_gather", "allreduce", "conv1_image"};
 
 // ---------------------------------------------------------------------------------------------
 // context
@@ -84,7 +84,46 @@ extern "C" int cpp_ctx_create(int device_id, void* hip_stream, cpp_ctx** out) {
   HIP_CHECK(hipMemsetAsync(c->sq_part, 0, 2 * SQ_REGION * sizeof(double), c->stream));
   c->sq_n[0] = c->sq_n[1] = -1;
   for (int& g : c->sq_conv_group) g = -1;
+  // the largest whitening scale of a step, for the next step's choice of conv1 kernels (common.h: cpp_ctx::conv1_f32)
+  HIP_CHECK(hipMalloc((void**)&c->white_max_dev, sizeof(unsigned)));
+  HIP_CHECK(hipMemsetAsync(c->white_max_dev, 0, sizeof(unsigned), c->stream));
+  HIP_CHECK(hipHostMalloc((void**)&c->white_max_host, sizeof(unsigned), hipHostMallocDefault));
+  *c->white_max_host = 0u;
+  c->route_threshold = 100.f;
   *out = c;
+  return CPP_OK;
+}
+
+// Called by every training entry point before it launches anything: the pinned word holds the largest whitening scale of a step that
+// has FINISHED (one or two calls back: nobody waits for it).  Above the threshold conv1 runs on the f32-input kernels; it comes back
+// once the scale has fallen under half of it.  A flip moves kernel_epoch, on which the trainers' captured graphs are keyed.
+void ctx_route_update(cpp_ctx* ctx) {
+  if (!ctx->white_max_host || !(ctx->route_threshold > 0.f)) return;
+  const unsigned bits = *reinterpret_cast<volatile unsigned*>(ctx->white_max_host);
+  float m; memcpy(&m, &bits, sizeof(m));
+  if (bits == 0u) return;                             // (no statistics since the last reset: keep the mode)
+  const bool want = ctx->conv1_f32 ? m > 0.5f * ctx->route_threshold : m > ctx->route_threshold;
+  if (want != ctx->conv1_f32) { ctx->conv1_f32 = want; ctx->kernel_epoch++; }
+}
+// ... and by every training step as its last stream operations (inside its captured graph): copy to the host word, reset
+int ctx_route_publish(cpp_ctx* ctx) {
+  if (!ctx->white_max_host) return CPP_OK;
+  HIP_CHECK(hipMemcpyAsync(ctx->white_max_host, ctx->white_max_dev, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipMemsetAsync(ctx->white_max_dev, 0, sizeof(unsigned), ctx->stream));
+  return CPP_OK;
+}
+
+extern "C" int cpp_ctx_set_route_threshold(cpp_ctx* c, float threshold) {
+  ARG_CHECK(c, "cpp_ctx_set_route_threshold: ctx is NULL");
+  ARG_CHECK(threshold >= 0.f, "cpp_ctx_set_route_threshold: threshold %g", threshold);
+  c->route_threshold = threshold;
+  if (threshold == 0.f && c->conv1_f32) { c->conv1_f32 = false; c->kernel_epoch++; }
+  return CPP_OK;
+}
+extern "C" int cpp_ctx_get_route(cpp_ctx* c, int* conv1_f32, float* last_max_scale) {
+  ARG_CHECK(c, "cpp_ctx_get_route: ctx is NULL");
+  if (conv1_f32) *conv1_f32 = c->conv1_f32 ? 1 : 0;
+  if (last_max_scale) { const unsigned bits = c->white_max_host ? *reinterpret_cast<volatile unsigned*>(c->white_max_host) : 0u; memcpy(last_max_scale, &bits, 4); }
   return CPP_OK;
 }
 
@@ -110,6 +149,8 @@ extern "C" int cpp_ctx_destroy(cpp_ctx* c) {
   (void)hipEventDestroy(c->t0); (void)hipEventDestroy(c->t1);
   (void)hipEventDestroy(c->pe0); (void)hipEventDestroy(c->pe1);
   if (c->sq_part) (void)hipFree(c->sq_part);
+  if (c->white_max_dev) (void)hipFree(c->white_max_dev);
+  if (c->white_max_host) (void)hipHostFree(c->white_max_host);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return CPP_OK;

@@ -18,6 +18,7 @@ struct cpp_ddpg {
   cpp_batch* step_batch;
   // graph replay of ONE minibatch on host-drawn rows, no target update (cpp_ddpg_train_rows: the reference's literal loop)
   hipGraph_t rgraph; hipGraphExec_t rgexec; bool rgraph_ok; int rg_B; uint64_t rg_replay_uid;
+  uint64_t epoch;            // cpp_ctx::kernel_epoch the cached graphs were captured under (route_check)
   hipGraph_t dgraph; hipGraphExec_t dgexec; bool dgraph_ok; int dg_B, dg_nb; uint64_t dg_seed, dg_replay_uid; uint64_t dg_comm_uid; bool dgraph_refused; char dg_reason[256];   // the data-parallel step (default mode)
   // graph replay of the data-parallel half step (sample + both gradient sets)
   // three variants: 0 samples its own minibatch; 1 / 2 find it presampled (by the previous call's rider, conv1_dw_gather.hip)
@@ -49,6 +50,7 @@ extern "C" int cpp_ddpg_create(cpp_ctx* ctx, cpp_net* actor, cpp_net* critic, cp
   d->nA = actor->nparams; d->nC = critic->nparams;
   d->graph = nullptr; d->gexec = nullptr; d->graph_ok = false; d->step_batch = nullptr; d->g_replay_uid = 0;
   d->rgraph = nullptr; d->rgexec = nullptr; d->rgraph_ok = false; d->rg_B = 0; d->rg_replay_uid = 0;
+  d->epoch = ctx->kernel_epoch;
   d->dgraph = nullptr; d->dgexec = nullptr; d->dgraph_ok = false; d->dg_B = d->dg_nb = 0; d->dg_seed = d->dg_replay_uid = 0; d->dg_comm_uid = 0; d->dgraph_refused = false; d->dg_reason[0] = 0;
   memset(d->hg, 0, sizeof(d->hg)); d->dp_local = 0; d->sq_cnt[0] = d->sq_cnt[1] = 0;
   d->h_replay_uid = 0; d->h_write_gen = 0; d->pre_variant = 0; d->h_B = 0; d->h_seed = 0;
@@ -81,6 +83,19 @@ static void drop_half_graphs(cpp_ddpg* d) {
       }
       H.ok[v] = false; H.next[v] = 0;
     }
+}
+
+// Every training entry point starts here: the context may have moved conv1 to the other kernel family since the last call (nearly
+// constant channels: common.h, cpp_ctx::conv1_f32) -- the cached graphs then hold the wrong launches and a presampled minibatch may be
+// in the wrong form (sampled slots against a gathered copy): everything is rebuilt by the calls' own "key changed" paths.
+static void route_check(cpp_ddpg* d) {
+  ctx_route_update(d->ctx);
+  if (d->epoch == d->ctx->kernel_epoch) return;
+  d->epoch = d->ctx->kernel_epoch;
+  d->graph_ok = false; d->rgraph_ok = false; d->dgraph_ok = false;
+  drop_half_graphs(d);
+  d->pre_variant = 0;
+  for (cpp_net* n : {d->actor, d->critic, d->tactor, d->tcritic}) n->wimg_key = nullptr;
 }
 
 extern "C" int cpp_ddpg_destroy(cpp_ddpg* d) {
@@ -199,13 +214,14 @@ static int critic_gradients_impl(cpp_ddpg* d, cpp_batch* b, bool critic_prefix_d
 // next: the minibatch whose sample pass has already run (its per-row statistics are in next->part): its whitening tables are
 // computed by this launch's rider instead of a stats_finalize launch behind it
 static int apply(cpp_ddpg* d, bool do_actor, bool do_critic, float grad_scale, uint64_t* bump = nullptr, bool folded = false,
-                 const cpp_batch* next = nullptr, int next_B = 0, int next_C = 0, long elems = 0) {
+                 const cpp_batch* next = nullptr, int next_B = 0, int next_C = 0, long elems = 0, bool tables_done = false) {
   OptSegs s; memset(&s, 0, sizeof(s));
   s.bump = bump;
-  if (next && next_C > 0) {
+  if (next && next_C > 0 && !tables_done) {
     s.st_part = next->part; s.st_white = next->white; s.st_nparts = next_B; s.st_jobs = 2 * next_C; s.st_C = next_C;
-    s.st_count = (double)next_B * (double)(elems / next_C); s.st_eps = 1e-6;
+    s.st_count = (double)next_B * (double)(elems / next_C); s.st_eps = 1e-6; s.st_wmax = d->ctx->white_max_dev;
   }
+  d->actor->wimg_key = nullptr; d->critic->wimg_key = nullptr;      // (the parameters change)
   s.nseg = 2; s.kind = OPT_SGD;
   s.p[0] = d->actor->params; s.g[0] = d->gradbuf; s.n[0] = do_actor ? d->nA : 0; s.lr[0] = d->hp.actor_learning_rate; s.group[0] = 0;
   s.p[1] = d->critic->params; s.g[1] = d->gradbuf + d->nA; s.n[1] = do_critic ? d->nC : 0; s.lr[1] = d->hp.critic_learning_rate; s.group[1] = 1;
@@ -214,8 +230,33 @@ static int apply(cpp_ddpg* d, bool do_actor, bool do_critic, float grad_scale, u
   } else {
     RC(launch_sumsq(d->ctx, s, grad_scale, d->norm_part, NORM_PARTS));
   }
+  // conv1's operand images of the next minibatch ride along too (conv_rs16.h; opt_apply_kernel's second rider): both updates are in
+  // this launch, the next minibatch's statistics are, conv1 of all four networks will run on that kernel
+  cpp_net* inets[4] = {d->actor, d->critic, d->tactor, d->tcritic};
+  const ConvL* L0 = d->actor->spec.pixel ? &d->actor->conv[0] : nullptr;
+  const bool img = next && next_C > 0 && do_actor && do_critic && L0 && !d->actor->spec.use_batch_norm && !d->critic->spec.use_batch_norm &&
+                   conv_rs16_ok(d->ctx, L0->Cin, L0->H, L0->W, kConvOut) && next_B >= 2;
+  if (img) {
+    s.img_n = 4;
+    for (int k = 0; k < 2; ++k) {      // conv1's weights and biases open the flat buffers (cpp_net_var_info order): [w_off, b_off + nout)
+      const ConvL& L = inets[k]->conv[0];
+      if (L.w_off != 0 || L.b_off != L.w_off + (long)L.ks * L.ks * L.Cin * kConvOut) { s.img_n = 0; break; }
+      s.img_skip[k] = L.b_off + kConvOut;
+    }
+  }
+  if (img && s.img_n) {
+    for (int j = 0; j < 4; ++j) {
+      cpp_net* n = inets[j];
+      const ConvL& L = n->conv[0];
+      s.img[j].w = n->params + L.w_off; s.img[j].bias = n->params + L.b_off;
+      s.img[j].gw = j < 2 ? s.g[j] + L.w_off : nullptr; s.img[j].gb = j < 2 ? s.g[j] + L.b_off : nullptr;
+      s.img[j].rec = reinterpret_cast<unsigned char*>(n->wimg); s.img[j].seg = j < 2 ? j : 0; s.img[j].col = j < 2 ? 0 : 1; s.img[j].nout = kConvOut;
+      s.img[j].white = tables_done ? next->white + (long)s.img[j].col * 2 * next_C : nullptr;
+    }
+  }
   // norms_out[group] is only written for lists that were applied (n > 0)
   RC(launch_opt_apply(d->ctx, s, grad_scale, d->hp.gradient_clip, d->norm_part, NORM_PARTS, d->loss_norms + 1));
+  if (img && s.img_n) for (int j = 0; j < 4; ++j) inets[j]->wimg_key = next->white + (long)(j < 2 ? 0 : 1) * 2 * next_C;
   return CPP_OK;
 }
 
@@ -527,6 +568,7 @@ extern "C" int cpp_ddpg_apply_gradients(cpp_ddpg* d, float grad_scale) {
 extern "C" int cpp_ddpg_update_targets(cpp_ddpg* d) {
   ARG_CHECK(d, "cpp_ddpg_update_targets: NULL argument");
   HIP_CHECK(hipSetDevice(d->ctx->device));
+  d->tactor->wimg_key = nullptr; d->tcritic->wimg_key = nullptr;
   return launch_soft_update(d->ctx, d->tactor->params, d->actor->params, d->nA, d->tcritic->params, d->critic->params,
                             d->nC, d->hp.target_update_rate);
 }
@@ -540,7 +582,7 @@ bool direct_replay_ok(cpp_net* a, cpp_replay* r, int B) {
   const int C = a->spec.C;
   int g = 8, c = C; while (c) { int t = g % c; g = c; c = t; }
   if (r->elems % 8 != 0 || C / g > 16 || r->elems % C != 0) return false;       // statistics come from the gather kernel
-  return conv1_f16_pipes_ok(C, a->conv[0].H, a->conv[0].W, B, a->spec.use_batch_norm != 0);
+  return conv1_f16_pipes_ok(a->ctx, C, a->conv[0].H, a->conv[0].W, B, a->spec.use_batch_norm != 0);
 }
 
 static int capture_into(cpp_ctx* ctx, hipGraph_t* g, hipGraphExec_t* e, const std::function<int()>& body);
@@ -573,18 +615,32 @@ static int step_body(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int
       if (direct) { ga.out_slot[0] = d->step_batch->slot_alt[0]; ga.out_slot[1] = d->step_batch->slot_alt[1]; }
       ctx->ride = &ga; ctx->ride_done = false; ctx->ride_dtype = r->store_dtype;
     }
+    // ... and when it leaves with conv1's dW, its statistics can be finished in the dW reductions' launch (flush_dw_reduce): the tables
+    // are in memory before the optimiser's launch, whose conv1 image rider reads them (apply)
+    static const bool no_stats_ride = cpp_switch_off("CPP_RIDE_STATS");
+    StatsRide sr;
+    if (ctx->ride && ctx->ride_at_dw && Cg > 0 && !no_stats_ride) {
+      sr.part = d->step_batch->part; sr.white = d->step_batch->white; sr.nparts = B; sr.jobs = 2 * Cg; sr.C = Cg;
+      sr.count = (double)B * (double)(r->elems / Cg); sr.eps = 1e-6; sr.wmax = ctx->white_max_dev;
+      ctx->st_ride = &sr; ctx->st_ride_done = false;
+    }
     const int rc = compute_gradients(d, d->step_batch);
     const bool rode = ctx->ride != nullptr && ctx->ride_done;
-    ctx->ride = nullptr;
+    const bool tables_done = ctx->st_ride != nullptr && ctx->st_ride_done && rode;
+    ctx->ride = nullptr; ctx->st_ride = nullptr;
     if (rode && direct) { std::swap(d->step_batch->slot[0], d->step_batch->slot_alt[0]); std::swap(d->step_batch->slot[1], d->step_batch->slot_alt[1]); }
     RC(rc);
-    // (also advances the sampler's counter and, when the next minibatch's sample pass rode along above, finishes its statistics)
-    static const bool no_stats_ride = cpp_switch_off("CPP_RIDE_STATS");
+    // (also advances the sampler's counter and, when the next minibatch's sample pass rode along above, finishes its statistics --
+    // unless the dW reductions' launch already has)
     const bool stats_ride = rode && Cg > 0 && !no_stats_ride;
-    if (dp && comm) NCCL_CHECK(ncclAllReduce(d->gradbuf, d->gradbuf, (size_t)(d->nA + d->nC), ncclFloat, ncclSum, comm->comm, ctx->stream));
+    if (dp && comm) {
+      prof_begin(ctx);
+      NCCL_CHECK(ncclAllReduce(d->gradbuf, d->gradbuf, (size_t)(d->nA + d->nC), ncclFloat, ncclSum, comm->comm, ctx->stream));
+      prof_end(ctx, K_ALLREDUCE);
+    }
     // (dp: the norm is the reduced gradient's -- the partials the gradient kernels folded in are this rank's only: sumsq runs)
     RC(apply(d, true, true, (dp && comm) ? 1.0f / (float)comm->world : 1.0f, rows_dev ? nullptr : r->counter, !dp,
-             stats_ride ? d->step_batch : nullptr, B, Cg, r->elems));
+             stats_ride ? d->step_batch : nullptr, B, Cg, r->elems, tables_done));
     if (more) {
       if (stats_ride) { d->step_batch->B = B; d->step_batch->dtype = CPP_F16; d->step_batch->stats_C = Cg; }     // (replay_sample_finish's bookkeeping)
       else if (rode) RC(replay_sample_finish(r, B, Cg, C, d->step_batch));
@@ -592,7 +648,8 @@ static int step_body(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int
                                    d->step_batch, direct));
     }
   }
-  return targets ? cpp_ddpg_update_targets(d) : CPP_OK;
+  if (targets) RC(cpp_ddpg_update_targets(d));
+  return ctx_route_publish(ctx);      // (the largest whitening scale of this step, for the next call's choice of conv1 kernels)
 }
 
 // ddpg_cartpole.py:332-334 for ONE minibatch whose rows the HOST drew (replay_memory.random_indexes: numpy's RNG, :123-129):
@@ -606,6 +663,7 @@ extern "C" int cpp_ddpg_train_rows(cpp_ddpg* d, cpp_replay* r, int B, const int3
   ARG_CHECK(B >= 1 && B <= d->maxB, "cpp_ddpg_train_rows: batch %d outside [1,%d]", B, d->maxB);
   ARG_CHECK(r->elems == d->actor->state_elems && r->A == d->actor->spec.action_dim, "cpp_ddpg_train_rows: replay shape does not match the networks");
   if (r->size <= 0) { cpp_set_error("cpp_ddpg_train_rows: replay memory is empty"); return CPP_ERR_STATE; }
+  route_check(d);
   cpp_ctx* ctx = d->ctx;
   HIP_CHECK(hipSetDevice(ctx->device));
   if (!d->step_batch) RC(cpp_batch_create(ctx, d->maxB, r->elems, r->A, &d->step_batch));
@@ -634,6 +692,7 @@ extern "C" int cpp_ddpg_train_step(cpp_ddpg* d, cpp_replay* r, int B, int n_batc
   ARG_CHECK(n_batches >= 1 && (size_t)n_batches * B <= 65536, "cpp_ddpg_train_step: n_batches %d", n_batches);
   ARG_CHECK(r->elems == d->actor->state_elems && r->A == d->actor->spec.action_dim, "cpp_ddpg_train_step: replay shape does not match the networks");
   if (r->size <= 0) { cpp_set_error("cpp_ddpg_train_step: replay memory is empty"); return CPP_ERR_STATE; }
+  route_check(d);
   cpp_ctx* ctx = d->ctx;
   HIP_CHECK(hipSetDevice(ctx->device));
   if (!d->step_batch) RC(cpp_batch_create(ctx, d->maxB, r->elems, r->A, &d->step_batch));
@@ -697,7 +756,8 @@ static int half_step_body(cpp_ddpg* d, cpp_replay* r, int B, uint64_t seed, int 
   const bool rode = ctx->ride != nullptr && ctx->ride_done;
   ctx->ride = nullptr;
   *next = rode ? (cur == 0 ? 1 : 2) : 0;
-  return rc;
+  if (rc) return rc;
+  return ctx_route_publish(ctx);
 }
 
 static int capture_into(cpp_ctx* ctx, hipGraph_t* g, hipGraphExec_t* e, const std::function<int()>& body) {
@@ -779,6 +839,7 @@ static int half_step_checks(cpp_ddpg* d, cpp_replay* r, int B, const char* who) 
 }
 
 extern "C" int cpp_ddpg_sample_and_compute(cpp_ddpg* d, cpp_replay* r, int B, uint64_t seed) {
+  if (d) route_check(d);
   RC(half_step_checks(d, r, B, "cpp_ddpg_sample_and_compute"));
   HIP_CHECK(hipSetDevice(d->ctx->device));
   return half_step(d, r, B, seed, false, nullptr);
@@ -822,6 +883,7 @@ extern "C" int cpp_ddpg_dp_train_step(cpp_ddpg* d, cpp_replay* r, cpp_comm* c, i
   RC(half_step_checks(d, r, B, "cpp_ddpg_dp_train_step"));
   ARG_CHECK(n_batches >= 1 && sync_every >= 1, "cpp_ddpg_dp_train_step: n_batches %d, sync_every %d", n_batches, sync_every);
   ARG_CHECK(!c || c->ctx == d->ctx, "cpp_ddpg_dp_train_step: communicator and networks live on different contexts");
+  route_check(d);
   cpp_ctx* ctx = d->ctx;
   HIP_CHECK(hipSetDevice(ctx->device));
   const float inv = c ? 1.0f / (float)c->world : 1.0f;

@@ -84,7 +84,9 @@ struct cpp_net {
   float* params; float* grads; float* own_grads;
   Workspace ws[2];
   bool use_b16;             // this forward: conv1 (f16 pipes) leaves bf16 planes of pool1, conv2 forward reads them
-  void* wimg;               // conv1's operand image on the f16 pipes (conv_rs16.h: rebuilt in front of every forward that uses it)
+  void* wimg;               // conv1's operand image on the f16 pipes (conv_rs16.h)
+  const float* wimg_key;    // the whitening table (scale pointer) the optimiser's launch built wimg for, with the weights it left; nullptr: stale --
+                            // the next conv1 forward builds it itself.  Cleared by everything that changes the parameters.
   const int32_t* img_slot;  // conv1 reads image b from row img_slot[b] of the state pointer (the replay store); nullptr: b
   float* white;            // [2][C] statistics for cpp_net_forward
   float* white_rows;       // [maxB][2][C]: per-image statistics for cpp_net_forward_each

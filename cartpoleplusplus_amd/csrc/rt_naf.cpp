@@ -22,6 +22,7 @@ struct cpp_naf {
   hipGraph_t dgraph; hipGraphExec_t dgexec; bool dgraph_ok; int dg_B, dg_nb; uint64_t dg_seed, dg_replay_uid; uint64_t dg_comm_uid; bool dgraph_refused; char dg_reason[256];   // the data-parallel step
   // ... and including it, the loss coming back later (cpp_naf_train_rows_async / cpp_naf_loss_wait): pinned (loss, flag) slots
   hipGraph_t agraph; hipGraphExec_t agexec; bool agraph_ok; int ag_B; uint64_t ag_replay_uid;
+  uint64_t epoch;            // cpp_ctx::kernel_epoch the cached graphs were captured under (naf_route_check)
   float* res_pin; hipEvent_t res_ev[CPP_NAF_TICKETS]; uint64_t next_ticket;
   uint64_t dp_local;       // minibatches applied locally since the last parameter averaging (periodic mode)
   cpp_batch* step_batch;
@@ -59,6 +60,7 @@ extern "C" int cpp_naf_create(cpp_ctx* ctx, cpp_net* value, cpp_net* tvalue, cpp
   f->rgraph = nullptr; f->rgexec = nullptr; f->rgraph_ok = false; f->rg_B = 0; f->rg_replay_uid = 0;
   f->dgraph = nullptr; f->dgexec = nullptr; f->dgraph_ok = false; f->dg_B = f->dg_nb = 0; f->dg_seed = f->dg_replay_uid = 0; f->dg_comm_uid = 0; f->dgraph_refused = false; f->dg_reason[0] = 0;
   f->agraph = nullptr; f->agexec = nullptr; f->agraph_ok = false; f->ag_B = 0; f->ag_replay_uid = 0;
+  f->epoch = ctx->kernel_epoch;
   f->res_pin = nullptr; f->next_ticket = 0; memset(f->res_ev, 0, sizeof(f->res_ev));
   f->hgraph = nullptr; f->hexec = nullptr; f->hgraph_ok = false; f->h_B = 0; f->h_seed = 0; f->h_replay_uid = 0; f->dp_local = 0;
   const size_t nall = (size_t)(f->nV + f->nM + f->nL);
@@ -330,7 +332,7 @@ static int naf_apply(cpp_naf* f, float grad_scale, bool unless_nonfinite = false
   s.bump = bump;
   if (next && next_C > 0) {
     s.st_part = next->part; s.st_white = next->white; s.st_nparts = next_B; s.st_jobs = 2 * next_C; s.st_C = next_C;
-    s.st_count = (double)next_B * (double)(elems / next_C); s.st_eps = 1e-6;
+    s.st_count = (double)next_B * (double)(elems / next_C); s.st_eps = 1e-6; s.st_wmax = f->ctx->white_max_dev;
   }
   s.nseg = 3; s.kind = f->hp.optimiser; s.momentum = f->hp.momentum; s.beta1 = f->hp.beta1; s.beta2 = f->hp.beta2;
   s.epsilon = f->hp.epsilon; s.step = f->opt_step;
@@ -432,6 +434,14 @@ extern "C" int cpp_naf_debug_values(cpp_naf* f, cpp_batch* b, float* l_values, f
   return CPP_OK;
 }
 
+// (as rt_ddpg.cpp's route_check: the context may have moved conv1 to the other kernel family -- every cached graph is rebuilt)
+static void naf_route_check(cpp_naf* f) {
+  ctx_route_update(f->ctx);
+  if (f->epoch == f->ctx->kernel_epoch) return;
+  f->epoch = f->ctx->kernel_epoch;
+  f->graph_ok = false; f->hgraph_ok = false; f->rgraph_ok = false; f->dgraph_ok = false; f->agraph_ok = false;
+}
+
 // The inner step naf_cartpole.py:367-373.  As in the DDPG step (rt_ddpg.cpp: step_body) the sample pass of minibatch i + 1 depends on
 // nothing minibatch i computes: it rides in the launch of i's conv1 dW (or of its dW reductions), keyed by the sampler's counter + 1
 // -- the counter itself moves in i's optimiser launch, which also finishes the whitening tables of i + 1.  CPP_RIDE_GATHER=0: in sequence.
@@ -461,7 +471,11 @@ static int naf_step_body(cpp_naf* f, cpp_replay* r, int B, int n_batches, const 
     if (rode && direct) { std::swap(f->step_batch->slot[0], f->step_batch->slot_alt[0]); std::swap(f->step_batch->slot[1], f->step_batch->slot_alt[1]); }
     RC(rc);
     const bool stats_ride = rode && Cg > 0;
-    if (dp && comm) NCCL_CHECK(ncclAllReduce(f->gradbuf, f->gradbuf, (size_t)(f->nV + f->nM + f->nL), ncclFloat, ncclSum, comm->comm, ctx->stream));
+    if (dp && comm) {
+      prof_begin(ctx);
+      NCCL_CHECK(ncclAllReduce(f->gradbuf, f->gradbuf, (size_t)(f->nV + f->nM + f->nL), ncclFloat, ncclSum, comm->comm, ctx->stream));
+      prof_end(ctx, K_ALLREDUCE);
+    }
     RC(naf_apply(f, (dp && comm) ? 1.0f / (float)comm->world : 1.0f, false, rows_dev ? nullptr : r->counter, stats_ride ? f->step_batch : nullptr, B, Cg, r->elems, !dp));
     if (more) {
       if (stats_ride) { f->step_batch->B = B; f->step_batch->dtype = CPP_F16; f->step_batch->stats_C = Cg; }     // (replay_sample_finish's bookkeeping)
@@ -470,10 +484,12 @@ static int naf_step_body(cpp_naf* f, cpp_replay* r, int B, int n_batches, const 
                                    f->step_batch, direct));
     }
   }
-  return cpp_naf_update_targets(f);
+  RC(cpp_naf_update_targets(f));
+  return ctx_route_publish(ctx);      // (the largest whitening scale of this step, for the next call's choice of conv1 kernels)
 }
 
 extern "C" int cpp_naf_train_step(cpp_naf* f, cpp_replay* r, int B, int n_batches, const int32_t* idxs, uint64_t seed) {
+  if (f) naf_route_check(f);
   ARG_CHECK(f && r, "cpp_naf_train_step: NULL argument");
   ARG_CHECK(B >= 1 && B <= f->maxB, "cpp_naf_train_step: batch %d outside [1,%d]", B, f->maxB);
   ARG_CHECK(n_batches >= 1 && (size_t)n_batches * B <= 65536, "cpp_naf_train_step: n_batches %d", n_batches);
@@ -519,9 +535,11 @@ static int naf_rows_body(cpp_naf* f, cpp_replay* r, int B, bool fold = false, bo
   const int C = f->value->spec.pixel ? f->value->spec.C : 0;
   if (!sticky) HIP_CHECK(hipMemsetAsync(f->nonfinite, 0, sizeof(int), f->ctx->stream));
   RC(replay_sample_device(r, B, r->rows_in, 0, nullptr, C, f->step_batch, direct_replay_ok(f->value, r, B)));
-  return naf_compute_gradients(f, f->step_batch, fold, !sticky);
+  RC(naf_compute_gradients(f, f->step_batch, fold, !sticky));
+  return ctx_route_publish(f->ctx);
 }
 extern "C" int cpp_naf_train_rows(cpp_naf* f, cpp_replay* r, int B, const int32_t* idxs, float* loss) {
+  if (f) naf_route_check(f);
   ARG_CHECK(f && r && idxs, "cpp_naf_train_rows: NULL argument");
   ARG_CHECK(B >= 1 && B <= f->maxB, "cpp_naf_train_rows: batch %d outside [1,%d]", B, f->maxB);
   ARG_CHECK(r->elems == f->value->state_elems && r->A == f->A, "cpp_naf_train_rows: replay shape does not match the networks");
@@ -567,6 +585,7 @@ static int naf_rows_apply_body(cpp_naf* f, cpp_replay* r, int B) {
   return naf_apply(f, 1.0f, true, nullptr, nullptr, 0, 0, 0, true);
 }
 extern "C" int cpp_naf_train_rows_async(cpp_naf* f, cpp_replay* r, int B, const int32_t* idxs, uint64_t* ticket) {
+  if (f) naf_route_check(f);
   ARG_CHECK(f && r && idxs && ticket, "cpp_naf_train_rows_async: NULL argument");
   ARG_CHECK(B >= 1 && B <= f->maxB, "cpp_naf_train_rows_async: batch %d outside [1,%d]", B, f->maxB);
   ARG_CHECK(r->elems == f->value->state_elems && r->A == f->A, "cpp_naf_train_rows_async: replay shape does not match the networks");
@@ -623,7 +642,8 @@ static int naf_half_body(cpp_naf* f, cpp_replay* r, int B, uint64_t seed) {
   bool bumped = false;       // (the statistics kernel advances the sampler's counter when there is one: replay_sample_finish)
   RC(replay_sample_device(r, B, nullptr, seed, r->counter, C, f->step_batch, direct_replay_ok(f->value, r, B), r->counter, &bumped));
   if (!bumped) RC(launch_counter_add(f->ctx, r->counter, 1));
-  return naf_compute_gradients(f, f->step_batch);
+  RC(naf_compute_gradients(f, f->step_batch));
+  return ctx_route_publish(f->ctx);
 }
 
 static int naf_half_checks(cpp_naf* f, cpp_replay* r, int B, const char* who) {
@@ -637,6 +657,7 @@ static int naf_half_checks(cpp_naf* f, cpp_replay* r, int B, const char* who) {
 // sample B rows on the device (Philox; the counter advances by one) and leave the gradients of the three networks in the flat
 // buffer [value | mu | l_values]; hipGraph-captured after the first call per (B, seed, replay)
 extern "C" int cpp_naf_sample_and_compute(cpp_naf* f, cpp_replay* r, int B, uint64_t seed) {
+  if (f) naf_route_check(f);
   RC(naf_half_checks(f, r, B, "cpp_naf_sample_and_compute"));
   cpp_ctx* ctx = f->ctx;
   HIP_CHECK(hipSetDevice(ctx->device));
@@ -696,6 +717,7 @@ extern "C" int cpp_naf_dp_status(const cpp_naf* f, int* mode, char* reason, int 
 }
 
 extern "C" int cpp_naf_dp_train_step(cpp_naf* f, cpp_replay* r, cpp_comm* c, int B, int n_batches, uint64_t seed, int sync_every) {
+  if (f) naf_route_check(f);
   RC(naf_half_checks(f, r, B, "cpp_naf_dp_train_step"));
   ARG_CHECK(n_batches >= 1 && sync_every >= 1, "cpp_naf_dp_train_step: n_batches %d, sync_every %d", n_batches, sync_every);
   ARG_CHECK(!c || c->ctx == f->ctx, "cpp_naf_dp_train_step: communicator and networks live on different contexts");

@@ -105,7 +105,7 @@ extern "C" int cpp_net_create(cpp_ctx* ctx, const cpp_net_spec* spec, int max_ba
   n->ctx = ctx; n->spec = *spec; n->maxB = max_batch; n->arena.stream = ctx->stream;
   n->grads = nullptr; n->own_grads = nullptr; n->stage_state = nullptr; n->stage_action = nullptr;
   n->stage_out = nullptr; n->dw_partial[0] = n->dw_partial[1] = n->dw_partial[2] = nullptr; n->white = nullptr; n->white_rows = nullptr; n->stats_part = nullptr;
-  n->img_slot = nullptr; n->use_b16 = false; n->wimg = nullptr;
+  n->img_slot = nullptr; n->use_b16 = false; n->wimg = nullptr; n->wimg_key = nullptr;
   n->is_training = true; n->drop_counter = nullptr; n->bn_part = nullptr; n->bn_means = nullptr; n->bn_scratch = nullptr;
   int rc = net_build(n);
   if (rc) { delete n; return rc; }
@@ -164,6 +164,7 @@ extern "C" int cpp_net_var_info(const cpp_net* n, int i, char* name, int cap, in
 extern "C" int cpp_net_set_params(cpp_net* n, const float* host, int64_t cnt) {
   ARG_CHECK(n && host, "cpp_net_set_params: NULL argument");
   ARG_CHECK(cnt == n->nparams, "cpp_net_set_params: got %ld values, network has %ld", (long)cnt, n->nparams);
+  n->wimg_key = nullptr;
   HIP_CHECK(hipMemcpyAsync(n->params, host, cnt * sizeof(float), hipMemcpyHostToDevice, n->ctx->stream));
   HIP_CHECK(hipStreamSynchronize(n->ctx->stream));
   return CPP_OK;
@@ -189,6 +190,7 @@ extern "C" int cpp_net_soft_update(cpp_net* target, const cpp_net* source, float
   ARG_CHECK(coeff >= 0.f && coeff <= 1.f, "affine_combo_coeff %g outside [0,1]", coeff);    // base_network.py:22
   ARG_CHECK(target->nparams == source->nparams, "cpp_net_soft_update: shapes differ (%ld vs %ld)",
             target->nparams, source->nparams);                                             // base_network.py:30
+  target->wimg_key = nullptr;
   return launch_soft_update(target->ctx, target->params, source->params, target->nparams, nullptr, nullptr, 0, coeff);
 }
 
@@ -208,7 +210,7 @@ ConvArgs conv_fwd_args(cpp_net* n, Workspace& w, int i, const void* state, int d
   const ConvL& L = n->conv[i];
   ConvArgs a; memset(&a, 0, sizeof(a));
   if (i == 0) { a.in = state; a.in_bstride = n->state_elems; a.scale = white; a.shift = white + n->spec.C; a.white_bstride = white_bstride;
-                a.img_slot = n->img_slot; a.wimg = n->wimg;
+                a.img_slot = n->img_slot; a.wimg = n->wimg; a.wimg_key = n->wimg_key;
                 *mode = dtype == CPP_F16 ? IN_F16_WHITEN : IN_F32_WHITEN; }
   else { a.in = w.pool[i - 1]; a.in_bstride = (long)L.H * L.W * L.Cin; *mode = IN_F32_PLAIN; }
   a.w = n->params + L.w_off; a.bias = n->params + L.b_off;
@@ -274,7 +276,7 @@ BnBatch bn_batch(cpp_net* const* nets, int nn, int i, int B) {
 // conv1 on the f16 pipes can leave bf16 planes of pool1 for a conv2 forward on the bf16 pipes (same launch sequence only)
 bool trunk_b16(const cpp_net* n, int dtype, int B, long white_bstride) {
   return n->spec.pixel && !n->spec.use_batch_norm && dtype == CPP_F16 && white_bstride == 0 &&
-         conv12_b16_ok(n->conv[0].Cin, n->conv[0].H, n->conv[0].W, B);
+         conv12_b16_ok(n->ctx, n->conv[0].Cin, n->conv[0].H, n->conv[0].W, B);
 }
 
 int net_forward_trunk(cpp_net* n, Workspace& w, const void* state, int dtype, const float* white, int B,
@@ -286,6 +288,7 @@ int net_forward_trunk(cpp_net* n, Workspace& w, const void* state, int dtype, co
   for (int i = 0; i < 3; ++i) {
     int mode;
     ConvArgs a = conv_fwd_args(n, w, i, state, dtype, white, B, &mode, white_bstride);
+    if (i == 0) n->wimg_key = nullptr;
     if (!n->spec.use_batch_norm) {
       RC(launch_conv_fwd(ctx, kFwdKid[i], n->conv[i].Cin, n->conv[i].ks, mode, EPI_RELU_POOL, a));
     } else if (!n->is_training) {
@@ -403,6 +406,7 @@ int nets_forward_trunk_fused(cpp_ctx* ctx, cpp_net* const* nets, int nn, const v
     for (int k = 0; k < nn; ++k) cl[k] = conv_fwd_args(nets[k], nets[k]->ws[0], 0, sts[k], dt, whs[k], B, &mode);
     for (int k = first_target; k < nn; ++k)
       if (nets[k]->use_b16 && cl[k].out_b16) { cl[k].out = nullptr; cl[k].out_amax = nullptr; }
+    for (int k = 0; k < nn; ++k) nets[k]->wimg_key = nullptr;      // (consumed -- or not used: either way the next forward builds its own)
     RC(launch_conv_fwd_multi(ctx, kFwdKid[0], a->conv[0].Cin, a->conv[0].ks, mode, EPI_RELU_POOL, cl, nn));
   }
   bool fuse23 = conv23_fuse_ok(a->conv[1].H, a->conv[1].W, B, kConvOut);

@@ -401,7 +401,7 @@ int replay_sample_finish(cpp_replay* r, int B, int C, int channels, cpp_batch* o
   out->B = B; out->dtype = CPP_F16; out->stats_C = 0;
   if (bumped) *bumped = false;
   if (C > 0) {
-    RC(launch_stats_finalize(r->ctx, out->part, B, 2, C, (double)B * (double)(r->elems / C), out->white, 1e-6, bump));
+    RC(launch_stats_finalize(r->ctx, out->part, B, 2, C, (double)B * (double)(r->elems / C), out->white, 1e-6, bump, r->ctx->white_max_dev));
     if (bumped && bump) *bumped = true;
     out->stats_C = C;
   } else if (channels > 0) {

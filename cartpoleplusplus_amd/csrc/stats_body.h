@@ -26,9 +26,11 @@ __device__ __forceinline__ void white_from_moments(double s, double ss, double c
   *shift = (float)(-mean * inv);
 }
 
-__device__ __forceinline__ void stats_finalize_wave(const double* part, int nparts, int C, double count, float* white, double eps,
-                                                    int job, int lane) {
-  const int w = job / C, c = job - w * C;
+// one wave: channel c of state column w, from the sampled rows' partial sums, into (*scale, *shift)
+// (wmax, optional: a device word that keeps the largest whitening scale seen -- as float bits, scales are >= 0 -- for the host's choice
+// of conv1 kernels: cpp_ctx::conv1_f32, rt_core.cpp)
+__device__ __forceinline__ void stats_finalize_wave_to(const double* part, int nparts, int C, double count, float* scale, float* shift, double eps,
+                                                       int w, int c, int lane, unsigned* wmax = nullptr) {
   double s = 0.0, ss = 0.0;
 #pragma unroll 4
   for (int b = lane; b < nparts; b += 64) {
@@ -36,5 +38,13 @@ __device__ __forceinline__ void stats_finalize_wave(const double* part, int npar
     s += p[c]; ss += p[C + c];
   }
   for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
-  if (lane == 0) white_from_moments(s, ss, count, eps, &white[(long)w * 2 * C + c], &white[(long)w * 2 * C + C + c]);
+  if (lane == 0) {
+    white_from_moments(s, ss, count, eps, scale, shift);
+    if (wmax) atomicMax(wmax, __float_as_uint(*scale));
+  }
+}
+__device__ __forceinline__ void stats_finalize_wave(const double* part, int nparts, int C, double count, float* white, double eps,
+                                                    int job, int lane, unsigned* wmax = nullptr) {
+  const int w = job / C, c = job - w * C;
+  stats_finalize_wave_to(part, nparts, C, count, &white[(long)w * 2 * C + c], &white[(long)w * 2 * C + C + c], eps, w, c, lane, wmax);
 }

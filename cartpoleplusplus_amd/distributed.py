@@ -138,6 +138,16 @@ class NativeLearner(object):
         return "dp%d: one learner per GPU behind the C ABI (cpp_%s_dp_train_step), own replay shard, %s over RCCL" % (
             self.world, "naf" if self.is_naf else "ddpg", how)
 
+    def dp_status(self):
+        """which form the default step takes on this rank: 'hipgraph' (one graph replay per outer step, the all-reduce inside),
+        'stream' (the same launches on the stream: the runtime or RCCL refused the capture -- `reason` says what it said) or
+        'none' (no default-mode step has run: --sync-every / --overlap take the half-step path)."""
+        import ctypes
+        mode, reason = ctypes.c_int(0), ctypes.create_string_buffer(256)
+        fn = self._lib.cpp_naf_dp_status if self.is_naf else self._lib.cpp_ddpg_dp_status
+        self._check(fn(self.agent.naf.handle if self.is_naf else self.agent.trainer.handle, ctypes.byref(mode), reason, 256))
+        return {"path": ("none", "hipgraph", "stream")[mode.value], "reason": reason.value.decode("utf-8", "replace")}
+
     def agreement(self):
         return LoopAgreement(self.comm)
 

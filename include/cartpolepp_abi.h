@@ -88,6 +88,15 @@ int cpp_sync(cpp_ctx* ctx);
 #define CPP_PRECISION_EXACT 1
 int cpp_ctx_set_precision(cpp_ctx* ctx, int mode);
 int cpp_ctx_get_precision(cpp_ctx* ctx, int* mode);
+/* Nearly constant channels.  The f16-pipe conv1 kernels multiply the replay store's RAW pixels by whitened weights; on a channel whose
+ * whitening scale is ~10^3 and whose values do not cancel exactly (a blind camera with a rare off-colour pixel) that sits a few times
+ * further from a float64 evaluation than whitening each element first, as base_network.py:95-99 does.  Every training step leaves the
+ * largest scale of its whitening tables in pinned host memory; the NEXT training call reads it (no wait) and, above `threshold`
+ * (default 100; 0 = never), runs conv1 forward / dW and conv2 forward on the f32-input kernels (which whiten per element) until the
+ * scale has fallen under half of it.  The first affected minibatch therefore still runs on the f16 pipes.  cpp_ctx_get_route reports
+ * the current choice and the last scale seen. */
+int cpp_ctx_set_route_threshold(cpp_ctx* ctx, float threshold);
+int cpp_ctx_get_route(cpp_ctx* ctx, int* conv1_f32, float* last_max_scale);
 
 /* HIP-event stopwatch on the ctx stream (bench.py; the reference only has util.StopWatch, util.py:22). */
 int cpp_timer_begin(cpp_ctx* ctx);

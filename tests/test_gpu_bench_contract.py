@@ -70,3 +70,10 @@ def test_bench_force_dp_compares_the_two_graphs_in_one_process():
     assert ab["blocks"] == 8 and len(ab["ratio_per_block_pair"]) == 8
     assert ab["ratio"] >= 0.98, ab
     assert d["value"] >= 0.97 * ab["dp_steps_per_sec"], (d["value"], ab)      # the timed region behind the barrier is not a slower one
+    # what a first N > 1 run must report by itself -- the step's form per rank, replica bit-identity, the exposed all-reduce
+    dp = d["config"]["data_parallel"]
+    assert dp["paths"] == ["hipgraph"] and "hipgraph" in d["config"]["parallelism"], dp
+    assert len(dp["per_rank"]) == 1 and dp["per_rank"][0]["rank"] == 0 and dp["per_rank"][0]["reason"] == "", dp
+    assert dp["replicas_bit_identical"] is True and len(dp["per_rank"][0]["params_sha256_16"]) == 16, dp
+    assert dp["exposed_allreduce_us_per_minibatch"] is not None and 0.5 < dp["exposed_allreduce_us_per_minibatch"] < 200.0, dp
+    assert dp["allreduce_bytes"] == 4 * 236163, dp          # cfg3: actor 87 282 + critic 148 881 floats (0.94 MB)

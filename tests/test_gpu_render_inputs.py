@@ -49,6 +49,17 @@ def test_reference_default_render_50x50x6_B128_on_rendered_episodes():
     print("50x50x6 B=128 on render inputs:", rep)
 
 
+def test_cfg5_geometry_B512_fused_step_on_rendered_episodes_with_a_blind_camera():
+    """BASELINE configs[4]'s geometry (128 x 128 x 30, B = 512): conv1 forward and dW run their FIVE-chunk instances there (a different
+    code path: no interior loop, 254 registers), which every earlier test fed noise only.  Rendered episodes with a camera that sees
+    one colour (three channels of zero variance: whitening table (0, 0)); every bar of the cfg3 render test."""
+    rep = fused_step_against_f64_oracle((128, 128, 3, 2, 5), 512, rows=700, graph=True, seed=15, fill="render-blind", f32_twin=True)
+    print("cfg5 geometry B=512 fused graph step on render-blind inputs vs f64 oracle:", rep)
+    assert rep["white_scale_max"] == 1000.0
+    for k in ("actions", "dq_da", "q", "td", "pool1", "pool2", "pool3"):
+        assert rep["err_" + k] <= F32_FACTOR * rep["f32_err_" + k] + 1e-6, (k, rep)
+
+
 @pytest.mark.parametrize("fill", ["render", "render-blind"])
 def test_cfg4_B256_naf_step_on_rendered_episodes(fill):
     from tests.test_gpu_naf import naf_fused_step_against_f64_oracle
