@@ -572,29 +572,28 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
   };
   auto writer_half = [&](const int half, const int pr, const bool sure = false) {
     if (PLAIN) return;
-    const bool live = sure || (pr >= 0 && pr < Hp);           // uniform
-    if (half >= NC) {                               // (one lane set per pooled row: the other row's stores are dummies)
-      if (ASYNC_A) {
-#pragma unroll
-        for (int i = 0; i < SH; ++i) __builtin_amdgcn_raw_buffer_store_b32(0u, null_rsrc, 64 * i, 0, 0);   // (distinct, non-adjacent addresses: identical or adjacent stores would be merged)
-      }
-      return;
-    }
+    // (one lane set per pooled row -- NC = 1, 16-pixel strips: the other row of the pair has nothing to write, but issues the SAME five
+    // stores, out of every descriptor's range.  Rounds 3-4 issued five stores to an empty descriptor on a path of their own; one store
+    // group on every path is what lets profiles/tools/check_async_loads.py count the hand-placed waits on the kernel's flow graph.)
+    const bool dummy = half >= NC;
+    const bool live = !dummy && (sure || (pr >= 0 && pr < Hp));           // uniform
     if (!ASYNC_A && !live) return;
     const int i = half < NC ? half : 0;
     if (ASYNC_A || cact[i]) {
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
       const int prs = live ? pr : 0;
-      const f32x4 top = wtop, bot = wbot;            // (writer_load)
       const unsigned co = live ? coe[i] : 0x3FFFFFFCu;
       const int orow = prs * Wp * nout;
-      float pv[2]; int code[2];
+      float pv[2] = {0.f, 0.f}; int code[2] = {0, 0};
+      if (live || !ASYNC_A) {
+        const f32x4 top = wtop, bot = wbot;            // (writer_load)
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const bool lower = bot[2 * e] > top[2 * e];
-        const float mx = lower ? bot[2 * e] : top[2 * e];
-        code[e] = (lower ? 2 + __float_as_int(bot[2 * e + 1]) : __float_as_int(top[2 * e + 1])) | (mx > 0.f ? POOL_ACTIVE : 0);
-        pv[e] = mx > 0.f ? mx * inv : 0.f;
+        for (int e = 0; e < 2; ++e) {
+          const bool lower = bot[2 * e] > top[2 * e];
+          const float mx = lower ? bot[2 * e] : top[2 * e];
+          code[e] = (lower ? 2 + __float_as_int(bot[2 * e + 1]) : __float_as_int(top[2 * e + 1])) | (mx > 0.f ? POOL_ACTIVE : 0);
+          pv[e] = mx > 0.f ? mx * inv : 0.f;
+        }
       }
       if (fuse3 && live) lds_store(c3adr[i], prs * (C3_PW * C3_C * 4), (f32x2){pv[0], pv[1]});      // conv3's input row, in LDS
       if (ASYNC_A || wr_f32) __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(pv[0]), __float_as_uint(pv[1])}, out_rsrc, (int)(co * 4), orow * 4, 0);

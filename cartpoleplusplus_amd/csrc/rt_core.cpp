@@ -117,6 +117,7 @@ extern "C" int cpp_ctx_set_route_threshold(cpp_ctx* c, float threshold) {
   ARG_CHECK(c, "cpp_ctx_set_route_threshold: ctx is NULL");
   ARG_CHECK(threshold >= 0.f, "cpp_ctx_set_route_threshold: threshold %g", threshold);
   c->route_threshold = threshold;
+  if (c->white_max_host) *c->white_max_host = 0u;      // (what was seen under the old threshold decides nothing any more)
   if (threshold == 0.f && c->conv1_f32) { c->conv1_f32 = false; c->kernel_epoch++; }
   return CPP_OK;
 }
