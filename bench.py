@@ -451,7 +451,9 @@ def main():
         row("conv2 forward" + ("" if "conv3_fwd" in prof else " + conv3 forward"), ["conv2_fwd"],
             [(gf(L2, nfwd), B16_PIPE if "conv1_fwd_f16" in prof else "f32")] + ([] if "conv3_fwd" in prof else [(gf(L3, nfwd), "f32")])),
         row("conv2 dW + dX", ["conv2_bwd"], [(gf(L2, nb), B16_PIPE), (gf(L2, nb), "f32")]),
-        row("conv2 dW", ["conv2_dw"], [(gf(L2, nb), "f32")]),
+        # (conv2's dW on its own launch -- cfg5's 64 x 64 conv2 has no pair instance -- runs conv_dwb16_kernel, bf16 pieces, whenever conv1 /
+        # conv2 are on the f16 / bf16 pipes; round 4's line priced it against the f32 pipe)
+        row("conv2 dW", ["conv2_dw"], [(gf(L2, nb), B16_PIPE if "conv1_fwd_f16" in prof else "f32")]),
         row("conv2 dX", ["conv2_dx"], [(gf(L2, nb), "f32")]),
         row("conv3 forward", ["conv3_fwd"], [(gf(L3, nfwd), "f32")]),
         row("conv3 dW + dX", ["conv3_bwd"], [(gf(L3, nb), "f32"), (gf(L3, nb), "f32")]),
@@ -477,7 +479,7 @@ def main():
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; they come from separate
         # rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), committed under profiles/
         traffic, traffic_src = None, None
-        for rnd in ("r04", "r03", "r02", "r01"):
+        for rnd in ("r05", "r04", "r03", "r02", "r01"):
             try:
                 with open(os.path.join(ROOT, "profiles", "%s_pmc.json" % rnd)) as f:
                     pmc = json.load(f)

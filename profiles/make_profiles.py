@@ -28,6 +28,8 @@ SHORT = [("void conv_fwd_kernel<18, 5, 4, 0, 0>", "conv1_fwd"), ("void conv_dw_k
          ("void conv_fwd_kyo_kernel<10, 5, 1, 2, 3,", "conv2_dx"), ("void conv_dw_kyo_kernel<10, 5", "conv2_dw"),
          # f16 pipes with f32-exact operands
          ("void conv_fwd_k16_kernel<18, 5", "conv1_fwd_f16"), ("void conv_dw16_kernel<18, 5", "conv1_dw_f16"),
+         # round 5: conv1 forward as a row-streaming implicit GEMM, weights in registers (conv_rs16.h); its operand images as a launch of their own
+         ("void conv_fwd_rs16_kernel<18>", "conv1_fwd_f16"), ("void conv1_image_kernel<18", "conv1_image"), ("opt_apply_kernel", "clip_sgd"), ("conv_dw_reduce_kernel", "dw_reduce"),
          # bf16 pipes (conv2), whole-image conv3 forward, the fused heads, and the launches that carry two kernels
          ("void conv_fwd_k16_kernel<10, 5", "conv2_fwd"), ("void conv_dwb16_kernel<10, 5", "conv2_dw"), ("conv3_img_kernel", "conv3_fwd"),
          ("void ddpg_heads_kernel", "heads"), ("conv3_bwd_pair_kernel", "conv3_bwd"), ("conv2_bwd_pair_kernel", "conv2_bwd"), ("void conv2_bwd_pair_kernel", "conv2_bwd"),
@@ -111,8 +113,8 @@ def main(rnd):
         f.write("Command (profiles/run_profiles.sh): `rocprofv3 --kernel-trace --stats -d gpurun_out/prof_%s -o k -- python bench.py "
                 "--quick --steps 50 --warmup 10 --profile-steps 5`\n\n" % rnd)
         f.write("70 minibatch steps in total (warm-up, hipGraph-replayed timed steps, and the eager HIP-event pass); durations in\n"
-                "microseconds, from the rocpd database's `top_kernels` view (profiles/make_profiles.py).  One `conv_fwd_k16_kernel<18,5,2,2>`\n"
-                "launch computes conv1 of all four networks of a minibatch (blockIdx.y = network); likewise conv2/conv3 forward;\n"
+                "microseconds, from the rocpd database's `top_kernels` view (profiles/make_profiles.py).  One `conv_fwd_rs16_kernel<18>` (round 5;\n"
+                "rounds 2-4: `conv_fwd_k16_kernel<18,5,2,2>`) launch computes conv1 of all four networks of a minibatch (blockIdx.y = network); likewise conv2/conv3 forward;\n"
                 "the dW / dX launches carry the actor and the critic together -- conv2's and conv3's dW and dX share one launch each\n"
                 "(`conv2_bwd_pair_kernel`, `conv3_bwd_pair_kernel`), and conv1's dW shares its launch with the next minibatch's\n"
                 "sample pass (`conv1_dw_gather_kernel`, from round 3 `conv1_dw_pair_gather_kernel`: one workgroup serves the actor AND the\n"
