@@ -105,6 +105,8 @@ struct cpp_ctx {
   // and dW) and conv2 forward on the f32-input kernels until the scale is back under half of it.  kernel_epoch: bumped by every flip --
   // the trainers' captured graphs are keyed on it.
   unsigned* white_max_dev; unsigned* white_max_host; bool conv1_f32; uint64_t kernel_epoch; float route_threshold;
+  unsigned* white_max_host_dev;   // the pinned word's device address: the step's closing soft-update kernel writes it (route_rider)
+  bool route_rider;               // set by a step body in front of its target update: that launch also publishes and resets the scale word
   int n_trainers;                 // live cpp_ddpg / cpp_naf objects: their captured graphs pin the precision mode
 };
 #define SQ_REGION 2048

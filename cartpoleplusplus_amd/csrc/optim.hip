@@ -230,7 +230,14 @@ int launch_opt_apply(cpp_ctx* ctx, const OptSegs& s, float grad_scale, float cli
 
 // target.assign_sub(coeff * (target - source)) for every variable of the namespace
 __global__ void soft_update_kernel(float* t0, const float* s0, long n0, float* t1, const float* s1,
-                                   long n1, float coeff) {
+                                   long n1, float coeff, unsigned* wmax_dev, unsigned* wmax_host) {
+  // (rider of a training step's last launch: the largest whitening scale the step saw goes to the pinned host word the next step's
+  // entry point reads, and the device word starts over -- cpp_ctx::white_max_dev, rt_core.cpp: ctx_route_update)
+  if (wmax_dev && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    const unsigned m = *wmax_dev;
+    *wmax_dev = 0u;
+    __hip_atomic_store(wmax_host, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   float* t = blockIdx.y == 0 ? t0 : t1;
   const float* s = blockIdx.y == 0 ? s0 : s1;
   const long n = blockIdx.y == 0 ? n0 : n1;
@@ -243,8 +250,10 @@ __global__ void soft_update_kernel(float* t0, const float* s0, long n0, float* t
 int launch_soft_update(cpp_ctx* ctx, float* t0, const float* s0, long n0, float* t1, const float* s1,
                        long n1, float coeff) {
   prof_begin(ctx);
+  const bool pub = ctx->route_rider && ctx->white_max_host_dev != nullptr;
+  ctx->route_rider = false;
   hipLaunchKernelGGL(soft_update_kernel, dim3(128, t1 ? 2 : 1), dim3(256), 0, ctx->stream, t0, s0, n0,
-                     t1, s1, n1, coeff);
+                     t1, s1, n1, coeff, pub ? ctx->white_max_dev : nullptr, pub ? ctx->white_max_host_dev : nullptr);
   LAUNCH_CHECK();
   prof_end(ctx, K_SOFT_UPDATE);
   return 0;

@@ -89,6 +89,7 @@ extern "C" int cpp_ctx_create(int device_id, void* hip_stream, cpp_ctx** out) {
   HIP_CHECK(hipMemsetAsync(c->white_max_dev, 0, sizeof(unsigned), c->stream));
   HIP_CHECK(hipHostMalloc((void**)&c->white_max_host, sizeof(unsigned), hipHostMallocDefault));
   *c->white_max_host = 0u;
+  HIP_CHECK(hipHostGetDevicePointer((void**)&c->white_max_host_dev, c->white_max_host, 0));
   c->route_threshold = 100.f;
   *out = c;
   return CPP_OK;

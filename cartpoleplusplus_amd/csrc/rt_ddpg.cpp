@@ -648,7 +648,7 @@ static int step_body(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int
                                    d->step_batch, direct));
     }
   }
-  if (targets) RC(cpp_ddpg_update_targets(d));
+  if (targets) { ctx->route_rider = true; return cpp_ddpg_update_targets(d); }      // (the largest whitening scale of this step rides to the host in that launch)
   return ctx_route_publish(ctx);      // (the largest whitening scale of this step, for the next call's choice of conv1 kernels)
 }
 

@@ -484,8 +484,8 @@ static int naf_step_body(cpp_naf* f, cpp_replay* r, int B, int n_batches, const 
                                    f->step_batch, direct));
     }
   }
-  RC(cpp_naf_update_targets(f));
-  return ctx_route_publish(ctx);      // (the largest whitening scale of this step, for the next call's choice of conv1 kernels)
+  ctx->route_rider = true;                          // (the largest whitening scale of this step rides to the host in that launch)
+  return cpp_naf_update_targets(f);      // (the largest whitening scale of this step, for the next call's choice of conv1 kernels)
 }
 
 extern "C" int cpp_naf_train_step(cpp_naf* f, cpp_replay* r, int B, int n_batches, const int32_t* idxs, uint64_t seed) {
