@@ -341,11 +341,14 @@ struct OptSegs {
   int img_n;
   long img_skip[OPT_MAX_SEGS];   // leading parameters of a segment (conv1's weights and biases) that its image workgroup updates itself
   struct { float* w; float* bias; const float* gw; const float* gb; unsigned char* rec; int seg, col, nout;
-           const float* white; } img[4];      // white != nullptr: the column's table is already in memory (the dW reductions' launch computed it)
+           const float* white; float* mw; float* mb; } img[4];      // mw / mb: the Momentum slots of those parameters (OPT_MOMENTUM)      // white != nullptr: the column's table is already in memory (the dW reductions' launch computed it)
 };
 // the SGD update of one parameter, p - lr * (g * scale), with its roundings pinned (one product, one fused multiply-add): opt_apply_kernel
 // writes it, the conv1 image rider of the same launch recomputes it, and both must hold the same bits whatever the compiler contracts
 __host__ __device__ inline float sgd_update(float p, float g, float scale, float lr) { return __builtin_fmaf(-lr, g * scale, p); }
+// ... and Momentum's pair (util.py:73-76: accum = momentum * accum + g; p -= lr * accum), pinned the same way
+__host__ __device__ inline float momentum_accum(float m, float g, float scale, float momentum) { return __builtin_fmaf(momentum, m, g * scale); }
+__host__ __device__ inline float momentum_step(float p, float accum, float lr) { return __builtin_fmaf(-lr, accum, p); }
 int launch_sumsq(cpp_ctx* ctx, const OptSegs& s, float grad_scale, double* part, int nparts);
 int launch_opt_apply(cpp_ctx* ctx, const OptSegs& s, float grad_scale, float clip, const double* part,
                      int nparts, float* norms_out);

@@ -28,7 +28,7 @@ int conv_fwd_rs16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool plai
   Conv1ImageArgsN ia; memset(&ia, 0, sizeof(ia)); ia.n = a.n;
   for (int i = 0; i < a.n; ++i)
     ia.a[i] = Conv1ImageArgs{a.a[i].w, a.a[i].bias, a.a[i].scale, a.a[i].shift, a.a[i].wscale, a.a[i].nout,
-                             reinterpret_cast<unsigned char*>(const_cast<void*>(a.a[i].wimg)), nullptr, nullptr, 0.f, 0.f, nullptr, nullptr};
+                             reinterpret_cast<unsigned char*>(const_cast<void*>(a.a[i].wimg)), nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, 0.f, nullptr, nullptr};
   constexpr int ilds = Rs16ImageLds<18>::BYTES;
   static bool attr_done[CPP_MAX_DEVICES] = {};
   if (!attr_done[cpp_dev_slot(ctx)]) {

@@ -45,6 +45,7 @@ struct Conv1ImageArgs {
   // optional (the builder riding in the optimiser's launch, optim.hip): the weights are the ones THIS launch's SGD update is about to
   // write, w - lr * (gw * gscale), recomputed with the update's own operations -- the builder waits for nobody
   const float* gw; const float* gb; float lr, gscale;
+  float* mw; float* mb; float momentum;      // OPT_MOMENTUM: the parameters' accumulator slots (read, advanced and written back here)
   float* w_out; float* b_out;     // ... and written by THIS workgroup (the update's own workgroups leave these parameters alone: no one reads a half-updated tensor)
 };
 struct Conv1ImageArgsN { Conv1ImageArgs a[CONV_BATCH_MAX]; int n; };
@@ -84,15 +85,25 @@ __device__ __forceinline__ void conv1_image_body(const Conv1ImageArgs& a, unsign
     float wr[NWT], gr[NWT];
 #pragma unroll
     for (int n = 0; n < NWT; ++n) { const int i = tid + n * CONV_THREADS; wr[n] = a.w[i < nwts ? i : 0]; }
+    float mr[NWT];
     if (a.gw) {
 #pragma unroll
       for (int n = 0; n < NWT; ++n) { const int i = tid + n * CONV_THREADS; gr[n] = a.gw[i < nwts ? i : 0]; }
+      if (a.mw) {
+#pragma unroll
+        for (int n = 0; n < NWT; ++n) { const int i = tid + n * CONV_THREADS; mr[n] = a.mw[i < nwts ? i : 0]; }
+      }
     }
 #pragma unroll
     for (int n = 0; n < NWT; ++n) {
       const int i = tid + n * CONV_THREADS;
       if (i < nwts) {
-        const float w = a.gw ? sgd_update(wr[n], gr[n], a.gscale, a.lr) : wr[n];      // (opt_apply_kernel's own expression)
+        float w = wr[n];
+        if (a.gw && a.mw) {                                    // (opt_apply_kernel's own expressions)
+          const float acc = momentum_accum(mr[n], gr[n], a.gscale, a.momentum);
+          a.mw[i] = acc;
+          w = momentum_step(w, acc, a.lr);
+        } else if (a.gw) w = sgd_update(w, gr[n], a.gscale, a.lr);
         wst[i] = w;
         if (a.gw && a.w_out) a.w_out[i] = w;
       }
@@ -115,7 +126,11 @@ __device__ __forceinline__ void conv1_image_body(const Conv1ImageArgs& a, unsign
   float* biasn = reinterpret_cast<float*>(pivot + ((CIN + 7) & ~7));      // [16] the layer's biases as this launch leaves them
   if (tid < 16) {
     float bo = (a.bias && tid < nout) ? a.bias[tid] : 0.f;
-    if (a.bias && a.gb && tid < nout) { bo = sgd_update(bo, a.gb[tid], a.gscale, a.lr); if (a.b_out) a.b_out[tid] = bo; }
+    if (a.bias && a.gb && tid < nout) {
+      if (a.mb) { const float acc = momentum_accum(a.mb[tid], a.gb[tid], a.gscale, a.momentum); a.mb[tid] = acc; bo = momentum_step(bo, acc, a.lr); }
+      else bo = sgd_update(bo, a.gb[tid], a.gscale, a.lr);
+      if (a.b_out) a.b_out[tid] = bo;
+    }
     biasn[tid] = bo;
   }
   if (tid < CIN) {

@@ -130,6 +130,7 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_apply_kernel(const OptSegs s,
     ia.w = s.img[j].w; ia.bias = s.img[j].bias; ia.scale = wh; ia.shift = wh + 18; ia.wscale = 0.f; ia.nout = s.img[j].nout; ia.rec = s.img[j].rec;
     ia.gw = s.img[j].gw; ia.gb = s.img[j].gb; ia.lr = s.img[j].gw ? s.lr[ws] : 0.f; ia.gscale = s.img[j].gw ? sh_scale : 0.f;
     ia.w_out = s.img[j].gw ? s.img[j].w : nullptr; ia.b_out = s.img[j].gw ? s.img[j].bias : nullptr;
+    ia.mw = (s.img[j].gw && s.kind == OPT_MOMENTUM) ? s.img[j].mw : nullptr; ia.mb = (s.img[j].gw && s.kind == OPT_MOMENTUM) ? s.img[j].mb : nullptr; ia.momentum = s.momentum;
     conv1_image_body<18>(ia, img_lds);
     return;
   }
@@ -188,15 +189,15 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_apply_kernel(const OptSegs s,
     for (; i < n; i += stride)
       p[i] = sgd_update(p[i], g[i], sc, lr);
   } else if (s.kind == OPT_MOMENTUM) {
-    float* m = s.m[seg];
+    float* m = s.m[seg] + skip;
     for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += stride) {
-      const float acc = s.momentum * m[i] + g[i] * sc;
+      const float acc = momentum_accum(m[i], g[i], sc, s.momentum);
       m[i] = acc;
-      p[i] = p[i] - lr * acc;
+      p[i] = momentum_step(p[i], acc, lr);
     }
   } else {
-    float* m = s.m[seg];
-    float* v = s.v[seg];
+    float* m = s.m[seg] + skip;
+    float* v = s.v[seg] + skip;
     const float b1 = s.beta1, b2 = s.beta2;
     for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += stride) {
       const float gi = g[i] * sc;
@@ -214,7 +215,7 @@ int launch_opt_apply(cpp_ctx* ctx, const OptSegs& s, float grad_scale, float cli
   const bool img = s.img_n > 0 && (s.st_part || s.img[0].white);
   const size_t lds = img ? (size_t)Rs16ImageLds<18>::BYTES : 0;
   if (img) {
-    if (s.kind != OPT_SGD || (s.st_part && s.st_C != 18) || s.skip_if) { cpp_set_error("opt_apply: the conv1 image rider needs plain SGD and 18 channels"); return 1; }
+    if ((s.kind != OPT_SGD && s.kind != OPT_MOMENTUM) || (s.st_part && s.st_C != 18) || s.skip_if) { cpp_set_error("opt_apply: the conv1 image rider needs SGD or Momentum and 18 channels"); return 1; }
     static bool attr_done[CPP_MAX_DEVICES] = {};
     if (!attr_done[cpp_dev_slot(ctx)]) {
       HIP_CHECK(hipFuncSetAttribute((const void*)opt_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Rs16ImageLds<18>::BYTES));

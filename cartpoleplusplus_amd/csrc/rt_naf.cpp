@@ -326,11 +326,13 @@ static int naf_compute_gradients(cpp_naf* f, cpp_batch* b, bool fold = false, bo
 // bump: the replay sampler's counter, advanced by this launch; next (+ next_B, next_C, elems): the minibatch whose sample pass has
 // already run -- its whitening tables are finished by this launch's extra grid row (as in the DDPG step, rt_ddpg.cpp: apply)
 static int naf_apply(cpp_naf* f, float grad_scale, bool unless_nonfinite = false, uint64_t* bump = nullptr,
-                     const cpp_batch* next = nullptr, int next_B = 0, int next_C = 0, long elems = 0, bool folded = false) {
+                     const cpp_batch* next = nullptr, int next_B = 0, int next_C = 0, long elems = 0, bool folded = false,
+                     bool tables_done = false) {
   OptSegs s; memset(&s, 0, sizeof(s));
   if (unless_nonfinite) s.skip_if = f->nonfinite;
   s.bump = bump;
-  if (next && next_C > 0) {
+  f->value->wimg_key = nullptr; f->mu->wimg_key = nullptr;      // (the parameters change)
+  if (next && next_C > 0 && !tables_done) {
     s.st_part = next->part; s.st_white = next->white; s.st_nparts = next_B; s.st_jobs = 2 * next_C; s.st_C = next_C;
     s.st_count = (double)next_B * (double)(elems / next_C); s.st_eps = 1e-6; s.st_wmax = f->ctx->white_max_dev;
   }
@@ -350,7 +352,29 @@ static int naf_apply(cpp_naf* f, float grad_scale, bool unless_nonfinite = false
   if (!bumped) RC(launch_counter_add(f->ctx, f->opt_step, 1, unless_nonfinite ? f->nonfinite : nullptr));
   if (folded && sq_cnt > 0 && grad_scale == 1.0f) { s.sq = f->ctx->sq_part; s.sq_begin[0] = 0; s.sq_count[0] = sq_cnt; }
   else RC(launch_sumsq(f->ctx, s, grad_scale, f->norm_part, NORM_PARTS));
-  return launch_opt_apply(f->ctx, s, grad_scale, f->hp.gradient_clip, f->norm_part, NORM_PARTS, f->stats + 1);
+  // conv1's operand images of the next minibatch ride along (as rt_ddpg.cpp's apply; shared trunk: the value network's conv1 on
+  // state_1, the target value network's on state_2; SGD or Momentum -- Adam's update is not restated in the rider)
+  cpp_net* inets[2] = {f->value, f->tvalue};
+  const ConvL* L0 = (f->share && f->value->spec.pixel) ? &f->value->conv[0] : nullptr;
+  bool img = next && next_C > 0 && L0 && !unless_nonfinite && !f->value->spec.use_batch_norm && next_B >= 2 &&
+             (s.kind == OPT_SGD || s.kind == OPT_MOMENTUM) && conv_rs16_ok(f->ctx, L0->Cin, L0->H, L0->W, kConvOut) &&
+             L0->w_off == 0 && L0->b_off == (long)L0->ks * L0->ks * L0->Cin * kConvOut;
+  if (img) {
+    s.img_n = 2;
+    s.img_skip[0] = L0->b_off + kConvOut;
+    for (int j = 0; j < 2; ++j) {
+      cpp_net* n = inets[j];
+      const ConvL& L = n->conv[0];
+      s.img[j].w = n->params + L.w_off; s.img[j].bias = n->params + L.b_off;
+      s.img[j].gw = j == 0 ? s.g[0] + L.w_off : nullptr; s.img[j].gb = j == 0 ? s.g[0] + L.b_off : nullptr;
+      s.img[j].mw = j == 0 ? s.m[0] + L.w_off : nullptr; s.img[j].mb = j == 0 ? s.m[0] + L.b_off : nullptr;
+      s.img[j].rec = reinterpret_cast<unsigned char*>(n->wimg); s.img[j].seg = 0; s.img[j].col = j; s.img[j].nout = kConvOut;
+      s.img[j].white = tables_done ? next->white + (long)j * 2 * next_C : nullptr;
+    }
+  }
+  RC(launch_opt_apply(f->ctx, s, grad_scale, f->hp.gradient_clip, f->norm_part, NORM_PARTS, f->stats + 1));
+  if (img) for (int j = 0; j < 2; ++j) inets[j]->wimg_key = next->white + (long)j * 2 * next_C;
+  return CPP_OK;
 }
 
 extern "C" int cpp_naf_action(cpp_naf* f, const void* state, int dtype, int B, float* out) {
@@ -395,6 +419,7 @@ extern "C" int cpp_naf_apply_gradients(cpp_naf* f, float grad_scale) {
 extern "C" int cpp_naf_update_targets(cpp_naf* f) {
   ARG_CHECK(f, "cpp_naf_update_targets: NULL argument");
   HIP_CHECK(hipSetDevice(f->ctx->device));
+  f->tvalue->wimg_key = nullptr;
   return launch_soft_update(f->ctx, f->tvalue->params, f->value->params, f->nV, nullptr, nullptr, 0, f->hp.target_update_rate);
 }
 
@@ -440,6 +465,7 @@ static void naf_route_check(cpp_naf* f) {
   if (f->epoch == f->ctx->kernel_epoch) return;
   f->epoch = f->ctx->kernel_epoch;
   f->graph_ok = false; f->hgraph_ok = false; f->rgraph_ok = false; f->dgraph_ok = false; f->agraph_ok = false;
+  f->value->wimg_key = nullptr; f->tvalue->wimg_key = nullptr; f->mu->wimg_key = nullptr;
 }
 
 // The inner step naf_cartpole.py:367-373.  As in the DDPG step (rt_ddpg.cpp: step_body) the sample pass of minibatch i + 1 depends on
@@ -465,9 +491,18 @@ static int naf_step_body(cpp_naf* f, cpp_replay* r, int B, int n_batches, const 
       if (direct) { ga.out_slot[0] = f->step_batch->slot_alt[0]; ga.out_slot[1] = f->step_batch->slot_alt[1]; }
       ctx->ride = &ga; ctx->ride_done = false; ctx->ride_dtype = r->store_dtype;
     }
+    // (its statistics are finished in the dW reductions' launch when it leaves with conv1's dW: rt_ddpg.cpp, step_body)
+    static const bool no_stats_ride = cpp_switch_off("CPP_RIDE_STATS");
+    StatsRide sr;
+    if (ctx->ride && ctx->ride_at_dw && Cg > 0 && !no_stats_ride) {
+      sr.part = f->step_batch->part; sr.white = f->step_batch->white; sr.nparts = B; sr.jobs = 2 * Cg; sr.C = Cg;
+      sr.count = (double)B * (double)(r->elems / Cg); sr.eps = 1e-6; sr.wmax = ctx->white_max_dev;
+      ctx->st_ride = &sr; ctx->st_ride_done = false;
+    }
     const int rc = naf_compute_gradients(f, f->step_batch, true);
     const bool rode = ctx->ride != nullptr && ctx->ride_done;
-    ctx->ride = nullptr;
+    const bool tables_done = ctx->st_ride != nullptr && ctx->st_ride_done && rode;
+    ctx->ride = nullptr; ctx->st_ride = nullptr;
     if (rode && direct) { std::swap(f->step_batch->slot[0], f->step_batch->slot_alt[0]); std::swap(f->step_batch->slot[1], f->step_batch->slot_alt[1]); }
     RC(rc);
     const bool stats_ride = rode && Cg > 0;
@@ -476,7 +511,7 @@ static int naf_step_body(cpp_naf* f, cpp_replay* r, int B, int n_batches, const 
       NCCL_CHECK(ncclAllReduce(f->gradbuf, f->gradbuf, (size_t)(f->nV + f->nM + f->nL), ncclFloat, ncclSum, comm->comm, ctx->stream));
       prof_end(ctx, K_ALLREDUCE);
     }
-    RC(naf_apply(f, (dp && comm) ? 1.0f / (float)comm->world : 1.0f, false, rows_dev ? nullptr : r->counter, stats_ride ? f->step_batch : nullptr, B, Cg, r->elems, !dp));
+    RC(naf_apply(f, (dp && comm) ? 1.0f / (float)comm->world : 1.0f, false, rows_dev ? nullptr : r->counter, stats_ride ? f->step_batch : nullptr, B, Cg, r->elems, !dp, tables_done));
     if (more) {
       if (stats_ride) { f->step_batch->B = B; f->step_batch->dtype = CPP_F16; f->step_batch->stats_C = Cg; }     // (replay_sample_finish's bookkeeping)
       else if (rode) RC(replay_sample_finish(r, B, Cg, C, f->step_batch));

@@ -69,7 +69,7 @@ int main(int argc, char** argv) {
   for (int n = 0; n < NN; ++n) rs.a[n].partial = reinterpret_cast<float*>(tl);
 #endif
   Conv1ImageArgsN ia; memset(&ia, 0, sizeof(ia)); ia.n = NN;
-  for (int n = 0; n < NN; ++n) ia.a[n] = Conv1ImageArgs{rs.a[n].w, rs.a[n].bias, rs.a[n].scale, rs.a[n].shift, 0.f, NO, recs + n * G::REC_BYTES, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr};
+  for (int n = 0; n < NN; ++n) ia.a[n] = Conv1ImageArgs{rs.a[n].w, rs.a[n].bias, rs.a[n].scale, rs.a[n].shift, 0.f, NO, recs + n * G::REC_BYTES, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, 0.f, nullptr, nullptr};
   const int ilds = Rs16ImageLds<CIN>::BYTES;
   CK(hipFuncSetAttribute((const void*)conv1_image_kernel<CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, ilds));
   auto run_ring = [&]() { if (conv_fwd_k16_launch_t<CIN, 5, 2, 2>(&ctx, ring)) exit(2); };

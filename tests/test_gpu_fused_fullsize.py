@@ -60,3 +60,50 @@ def test_every_channel_count_the_flags_can_produce(cams, reps):
     render the generic and the f16-pipe kernels both see (40 x 40, odd pooled sizes further down)."""
     rep = fused_step_against_f64_oracle((40, 40, 3, cams, reps), 6, rows=150, graph=True, seed=cams + 3 * reps)
     print("%d channels:" % (3 * cams * reps), rep)
+
+
+_RIDER_SNIPPET = r"""
+import hashlib, sys
+import numpy as np
+from tests.helpers import make_pair
+from tests.test_gpu_naf import make_naf
+shape, B = (64, 64, 3, 2, 3), 64
+agent, _ref, _ = make_pair(shape, B, True, replay_size=4 * B)
+agent.replay_memory.fill_synthetic(3 * B, seed=11)
+for _ in range(3):
+    agent.train_step(B, 3)
+agent.actor.ctx.sync()
+h = hashlib.sha256()
+for n in (agent.actor, agent.critic, agent.target_actor, agent.target_critic):
+    h.update(n.get_params().tobytes())
+print("DIGEST ddpg", h.hexdigest())
+agent.close()
+agent, _ref, _ = make_naf(shape, B, True, "Momentum", {"learning_rate": 0.01, "momentum": 0.9}, seed=4, replay_size=4 * B)
+agent.replay_memory.fill_synthetic(3 * B, seed=12)
+for _ in range(3):
+    agent.train_step(B, 3)
+h = hashlib.sha256()
+for n in (agent.value_net, agent.naf.mu_net, agent.naf.l_net, agent.target_value_net):
+    h.update(n.get_params().tobytes())
+h.update(np.asarray(agent.naf.get_optimiser_state()["m"]).tobytes())
+print("DIGEST naf", h.hexdigest())
+"""
+
+
+def test_the_conv1_image_rider_is_an_arrangement_not_arithmetic():
+    """conv1's operand images (conv_rs16.h) are built by the optimiser's launch for the NEXT minibatch -- the rider restates the SGD /
+    Momentum update of conv1's own parameters (optim.hip; rt_ddpg.cpp apply, rt_naf.cpp naf_apply) -- or by a launch of their own in
+    front of the forward kernel (CPP_RIDE_IMAGE=0, ablation build).  Nine minibatches in three calls (a target update between the calls,
+    so both the rider's and the stand-alone launch's images are consumed): every parameter, target parameter and Momentum slot is
+    bit-identical between the two arrangements, DDPG (SGD) and NAF (Momentum)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for name, extra in (("rider", {}), ("own-launch", {"CPP_RIDE_IMAGE": "0"})):
+        r = subprocess.run([sys.executable, "-c", _RIDER_SNIPPET], cwd=root, env=dict(os.environ, CARTPOLEPP_ABLATION="1", **extra),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        out = r.stdout.decode()
+        assert r.returncode == 0, out[-1500:]
+        got[name] = [l for l in out.splitlines() if l.startswith("DIGEST")]
+        assert len(got[name]) == 2, out[-1500:]
+    assert got["rider"] == got["own-launch"], got
