@@ -6,6 +6,7 @@
 #endif
 #include "conv_kyo.h"
 #include "conv_dwb16.h"
+#include "conv_dx_rs.h"
 
 template <int ORDER>
 __global__ __launch_bounds__(CONV_THREADS, 2) void conv2_bwd_pair_kernel(const ConvArgsN dx, int dx_gx, const ConvArgsN dw, int dw_gx, int upi, int band, int order) {
@@ -16,15 +17,27 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv2_bwd_pair_kernel(const C
     conv_dwb16_body<10, 5, 1, ORDER>(dw, upi, band, i % dw_gx, i / dw_gx, dw_gx);
   }
 }
+// the dX half on the bf16 pipes (conv_dx_rs.h) instead of the f32-input row kernel
+template <int ORDER>
+__global__ __launch_bounds__(CONV_THREADS, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv2_bwd_pair_rs_kernel(const ConvArgsN dx, int dx_gx, const ConvArgsN dw, int dw_gx, int upi, int band, int order) {
+  int i;
+  if (!pair_grid_place((int)blockIdx.x, dx_gx * dx.n, dw_gx * dw.n, order, &i)) {
+    conv_dx_rs_body<2, ORDER>(dx, i % dx_gx, i / dx_gx);
+  } else {
+    conv_dwb16_body<10, 5, 1, ORDER>(dw, upi, band, i % dw_gx, i / dw_gx, dw_gx);
+  }
+}
 
 int launch_conv2_bwd_pair(cpp_ctx* ctx, const ConvPairSlot& slot) {
   const int ndx = slot.have_dx ? slot.dx_gx * slot.dx.n : 0, ndw = slot.have_dw ? slot.dw_gx * slot.dw.n : 0;
   if (ndx + ndw == 0) return 0;
   const size_t lds = (slot.have_dx ? slot.dx_lds : 0) > (slot.have_dw ? slot.dw_lds : 0) ? slot.dx_lds : slot.dw_lds;
   const bool nine = b16_order(ctx) == B16_NINE;      // (cpp_ctx_set_precision: every product of the bf16 pieces)
-  auto kern = nine ? conv2_bwd_pair_kernel<B16_NINE> : conv2_bwd_pair_kernel<B16_SIX>;
-  static size_t attr_dev[CPP_MAX_DEVICES][2] = {};   // (kernel attributes are per device and per kernel)
-  size_t& attr = attr_dev[cpp_dev_slot(ctx)][nine ? 1 : 0];
+  const bool rs = slot.have_dx && slot.dx_rs;
+  auto kern = rs ? (nine ? conv2_bwd_pair_rs_kernel<B16_NINE> : conv2_bwd_pair_rs_kernel<B16_SIX>)
+                 : (nine ? conv2_bwd_pair_kernel<B16_NINE> : conv2_bwd_pair_kernel<B16_SIX>);
+  static size_t attr_dev[CPP_MAX_DEVICES][4] = {};   // (kernel attributes are per device and per kernel)
+  size_t& attr = attr_dev[cpp_dev_slot(ctx)][(nine ? 1 : 0) + (rs ? 2 : 0)];
   if (lds > attr) {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = lds;
@@ -34,7 +47,10 @@ int launch_conv2_bwd_pair(cpp_ctx* ctx, const ConvPairSlot& slot) {
   if (!slot.have_dw) { memset(&dw, 0, sizeof(dw)); dw.n = 0; }
   // the dW workgroups are few, long serial chains (a band of rows each): dispatched behind the dX grid they start when dX is nearly
   // done and the launch takes dX + dW; dispatched first they run beside it (CPP_PAIR_ORDER: 0 dX first, 1 dW first, 2 interleaved)
-  static const int order = cpp_switch_int("CPP_PAIR_ORDER", PAIR_ORDER_DEFAULT);
+  // (with the bf16 dX body the picture turns round: its 256 workgroups are the long ones -- one per CU, 24 us -- and go first; the dW
+  // workgroups fill the other slot of every CU beside them and both slots afterwards: 53 us against 58 dW-first, r05_dxrs_sweep.sh)
+  static const int order_sw = cpp_switch_int("CPP_PAIR_ORDER", -1);
+  const int order = order_sw >= 0 ? order_sw : (rs ? 0 : PAIR_ORDER_DEFAULT);
   prof_begin(ctx);
   hipLaunchKernelGGL(kern, dim3(ndx + ndw), dim3(CONV_THREADS), lds, ctx->stream, dx, slot.have_dx ? slot.dx_gx : 1,
                      dw, slot.have_dw ? slot.dw_gx : 1, slot.upi, slot.band, order);

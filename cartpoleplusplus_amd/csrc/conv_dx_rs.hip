@@ -1,0 +1,39 @@
+// conv2's dX on the bf16 pipes, row-streaming (conv_dx_rs.h): its own launch, or parked for conv2_bwd_pair.hip
+#include <cstring>
+#include "conv_dx_rs.h"
+
+template <int TPR, int ORDER>
+static int conv_dx_rs_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
+  typedef DxRsGeom<TPR> G;
+  const ConvArgs& a = batch.a[0];
+  auto kern = conv_dx_rs_kernel<TPR, ORDER>;
+  static bool attr_done[CPP_MAX_DEVICES] = {};
+  if (!attr_done[cpp_dev_slot(ctx)]) {
+    HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    attr_done[cpp_dev_slot(ctx)] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((a.B + G::IPW - 1) / G::IPW, batch.n), dim3(CONV_THREADS), G::LDS_BYTES, ctx->stream, batch);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+bool conv_dx_rs_ok(const cpp_ctx* ctx, int cin, int ks, int H, int W, int nout) {
+  static const bool off = cpp_switch_off("CPP_CONV_DXRS") || cpp_switch_off("CPP_CONV_B16");
+  (void)ctx;
+  return !off && cin == KYO_NO && nout == KYO_NO && ks == 5 && (W == 32 || W == 64) && H >= 4 && !(H & 1);
+}
+
+int conv_dx_rs_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArgsN& a, bool* handled) {
+  *handled = false;
+  const ConvArgs& a0 = a.a[0];
+  if (in_mode != IN_DY || !conv_dx_rs_ok(ctx, cin, ks, a0.H, a0.W, a0.nout)) return 0;
+  *handled = true;
+  const bool nine = b16_order(ctx) == B16_NINE;
+  if (ctx->pair && ctx->pair->layer == 1 && a0.W == 32) {     // leaves with conv2's dW (conv2_bwd_pair.hip)
+    ctx->pair->dx = a; ctx->pair->dx_gx = (a0.B + 1) / 2; ctx->pair->dx_lds = DxRsGeom<2>::LDS_BYTES; ctx->pair->have_dx = true;
+    ctx->pair->dx_rs = true;
+    return 0;
+  }
+  if (a0.W == 32) return nine ? conv_dx_rs_launch_t<2, B16_NINE>(ctx, a) : conv_dx_rs_launch_t<2, B16_SIX>(ctx, a);
+  return nine ? conv_dx_rs_launch_t<4, B16_NINE>(ctx, a) : conv_dx_rs_launch_t<4, B16_SIX>(ctx, a);
+}

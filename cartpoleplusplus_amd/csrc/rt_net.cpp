@@ -466,7 +466,7 @@ int nets_backward_conv(cpp_ctx* ctx, cpp_net* const* nets, int nn, int B, const 
     static const bool no_pair3 = cpp_switch_off("CPP_CONV3_PAIR");
     static const bool no_pair2 = cpp_switch_off("CPP_CONV2_PAIR");
     const bool no_pair = i == 2 ? no_pair3 : (i == 1 ? no_pair2 : true);
-    ConvPairSlot slot; slot.have_dw = slot.have_dx = false; slot.layer = i;
+    ConvPairSlot slot; slot.have_dw = slot.have_dx = false; slot.dx_rs = false; slot.layer = i;
     if (!no_pair) ctx->pair = &slot;
     int rc = launch_conv_dw_multi(ctx, kDwKid[i], L.Cin, L.ks, mode, dl, nn, gw, gb);
     if (!rc && i > 0) rc = launch_conv_fwd_multi(ctx, kDxKid[i], kConvOut, L.ks, IN_DY, EPI_PLAIN, xl, nn);
@@ -654,6 +654,14 @@ extern "C" int cpp_net_get_pool(cpp_net* n, int which, int B, float* out) {
     HIP_CHECK(hipMemcpyAsync(tmp.data(), n->ws[0].amax[which - 11], cnt, hipMemcpyDeviceToHost, n->ctx->stream));
     HIP_CHECK(hipStreamSynchronize(n->ctx->stream));
     for (size_t i = 0; i < cnt; ++i) out[i] = (float)(tmp[i] & 3);      // (bit 2 of the byte: "the pooled output is > 0", conv_kyo.h POOL_ACTIVE)
+    return CPP_OK;
+  }
+  if (n->spec.pixel && which >= 21 && which <= 22) {   // debug: the pooled-gradient buffers of the last backward pass (dX of conv2 / conv3)
+    const ConvL& L = n->conv[which - 21];
+    ARG_CHECK(n->ws[0].dpool[which - 21], "cpp_net_get_pool: no gradient workspace");
+    const size_t cnt = (size_t)B * L.Hp * L.Wp * kConvOut;
+    HIP_CHECK(hipMemcpyAsync(out, n->ws[0].dpool[which - 21], cnt * sizeof(float), hipMemcpyDeviceToHost, n->ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(n->ctx->stream));
     return CPP_OK;
   }
   ARG_CHECK(n->spec.pixel && which >= 1 && which <= 3, "cpp_net_get_pool: which=%d (pixel nets, 1..3)", which);
