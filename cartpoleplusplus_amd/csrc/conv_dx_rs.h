@@ -55,8 +55,16 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lj = lane >> 4;
   const int swave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int simg = swave / TPR, stile = swave % TPR;
-  const int sb = bx * G::IPW + simg;
+  // a launch that would leave CUs without a workgroup (one network at 32-wide rows: 128) walks every image in TWO bands of output rows
+  // [ylo, yhi); a band reads the P dZ rows above and below it and starts its walk at a multiple of NSET (the sets' and slots'
+  // compile-time rotation), i.e. up to NSET - 1 rows early: those rows only reach output rows in front of the band, which are not stored
+  const int nbands = a.nbands > 1 ? a.nbands : 1;
+  const int band = bx % nbands;
+  const int sb = (bx / nbands) * G::IPW + simg;
   const int H = a.H, Hp = H >> 1;
+  const int ylo = nbands > 1 ? band * a.band_rows : 0, yhi = nbands > 1 ? min(H, ylo + a.band_rows) : H;
+  const int qbeg = ((ylo > P ? ylo - P : 0) / NSET) * NSET;   // first dZ row walked
+  const int qmf = min(H, yhi + P);                            // one past the last dZ row that reaches the band
   unsigned char* wvb = dxrs_lds + G::AIMG_BYTES + swave * G::WVB;
   // ---- dZ rows: lane l < 50 owns the channel pair (2 op, 2 op + 1) of pooled cell cw of the tile's window (pooled pixels 8 stile - 1 ..
   // 8 stile + 8: the tile and one cell of halo on each side); cells outside the image read zeros through the descriptors' range check
@@ -85,8 +93,8 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
     rawc[buf] = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(am_rsrc, (int)(in ? coff + (unsigned)(py * (Wp * CH)) : BIG), 0, 0);
   };
   // (the first two pooled rows are on their way while the workgroup builds the operands)
-  load_pooled(0, 0);
-  load_pooled(1, 1);
+  load_pooled(0, qbeg >> 1);
+  load_pooled(1, (qbeg >> 1) + 1);
   unsigned char* aimg = dxrs_lds;                             // the A operands: [ky'][chunk][piece][lane][8 halves]
   // ---- the A operands W'[ky'][k = (kx', o)][c], three bf16 pieces each: built ONCE per workgroup (its waves serve one network), element
   // by element from coalesced loads -- a wave building its own 30 operands spent ~1800 instructions (3.7 us) on index arithmetic and splits
@@ -191,7 +199,7 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
     };
     auto epi_store = [&]() __attribute__((always_inline)) {
       const f32x4 v = lds_load<f32x4>(trd, 0);
-      const bool live = !GEN || (yd >= 0 && yd < H);
+      const bool live = !GEN || (yd >= ylo && yd < yhi);
       __builtin_amdgcn_raw_buffer_store_b128((k16_u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
                                              out_rsrc, (int)(live ? eL : BIG), (live ? yd : 0) * (W * CH * 4), 0);
     };
@@ -214,7 +222,7 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
         }
     };
     constexpr int J = SQ / 2;                                // pooled row q / 2 mod 3
-    if (!GEN || q < H) {
+    if (!GEN || q < qmf) {
       // One wave per SIMD (1024 tiles at cfg3): nobody else issues while this wave prepares the next row, so the preparation is dealt
       // out BETWEEN the MFMAs -- the matrix pipe takes a 16x16x32 every 16 cycles, the wave can issue two or three other instructions in
       // the shadow of each (as phases of their own the ~50 VALU + 17 LDS instructions of a row left the pipe idle for a third of the step).
@@ -256,17 +264,17 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
   };
   auto block = [&](auto gentag, const int q0) __attribute__((always_inline)) {
     constexpr bool GEN = decltype(gentag)::value;
-    if (GEN && q0 + 0 >= H + 3) return; step(std::integral_constant<int, 0>{}, gentag, q0 + 0);
-    if (GEN && q0 + 1 >= H + 3) return; step(std::integral_constant<int, 1>{}, gentag, q0 + 1);
-    if (GEN && q0 + 2 >= H + 3) return; step(std::integral_constant<int, 2>{}, gentag, q0 + 2);
-    if (GEN && q0 + 3 >= H + 3) return; step(std::integral_constant<int, 3>{}, gentag, q0 + 3);
-    if (GEN && q0 + 4 >= H + 3) return; step(std::integral_constant<int, 4>{}, gentag, q0 + 4);
-    if (GEN && q0 + 5 >= H + 3) return; step(std::integral_constant<int, 5>{}, gentag, q0 + 5);
+    if (GEN && q0 + 0 >= yhi + 3) return; step(std::integral_constant<int, 0>{}, gentag, q0 + 0);
+    if (GEN && q0 + 1 >= yhi + 3) return; step(std::integral_constant<int, 1>{}, gentag, q0 + 1);
+    if (GEN && q0 + 2 >= yhi + 3) return; step(std::integral_constant<int, 2>{}, gentag, q0 + 2);
+    if (GEN && q0 + 3 >= yhi + 3) return; step(std::integral_constant<int, 3>{}, gentag, q0 + 3);
+    if (GEN && q0 + 4 >= yhi + 3) return; step(std::integral_constant<int, 4>{}, gentag, q0 + 4);
+    if (GEN && q0 + 5 >= yhi + 3) return; step(std::integral_constant<int, 5>{}, gentag, q0 + 5);
   };
-  int q0 = 0;
+  int q0 = qbeg;
   block(std::true_type{}, q0); q0 += NSET;
-  for (; q0 + NSET <= H - 4; q0 += NSET) block(std::false_type{}, q0);
-  for (; q0 < H + 3; q0 += NSET) block(std::true_type{}, q0);
+  for (; q0 >= ylo + 3 && q0 + NSET <= qmf; q0 += NSET) block(std::false_type{}, q0);      // (every step multiplies and stores a row of the band)
+  for (; q0 < yhi + 3; q0 += NSET) block(std::true_type{}, q0);
 #ifdef DXRS_CLOCK_PROBE
   if (lane == 0 && swave == 0) {
     const unsigned long long pc1 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();

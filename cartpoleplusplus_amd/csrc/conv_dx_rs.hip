@@ -12,7 +12,8 @@ static int conv_dx_rs_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     attr_done[cpp_dev_slot(ctx)] = true;
   }
-  hipLaunchKernelGGL(kern, dim3((a.B + G::IPW - 1) / G::IPW, batch.n), dim3(CONV_THREADS), G::LDS_BYTES, ctx->stream, batch);
+  const int nb = a.nbands > 1 ? a.nbands : 1;
+  hipLaunchKernelGGL(kern, dim3(((a.B + G::IPW - 1) / G::IPW) * nb, batch.n), dim3(CONV_THREADS), G::LDS_BYTES, ctx->stream, batch);
   LAUNCH_CHECK();
   return 0;
 }
@@ -23,14 +24,25 @@ bool conv_dx_rs_ok(const cpp_ctx* ctx, int cin, int ks, int H, int W, int nout) 
   return !off && cin == KYO_NO && nout == KYO_NO && ks == 5 && (W == 32 || W == 64) && H >= 4 && !(H & 1);
 }
 
-int conv_dx_rs_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArgsN& a, bool* handled) {
+int conv_dx_rs_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArgsN& a_in, bool* handled) {
   *handled = false;
-  const ConvArgs& a0 = a.a[0];
+  const ConvArgs& a0 = a_in.a[0];
   if (in_mode != IN_DY || !conv_dx_rs_ok(ctx, cin, ks, a0.H, a0.W, a0.nout)) return 0;
   *handled = true;
   const bool nine = b16_order(ctx) == B16_NINE;
+  ConvArgsN a = a_in;
+  {  // fewer workgroups than CUs: two bands of rows per image (CPP_DXRS_BANDS=0: whole images)
+    static const int bands_sw = cpp_switch_int("CPP_DXRS_BANDS", 1);      // (ablation build: 0 never, 2 always)
+    const int ipw = a0.W == 32 ? 2 : 1;
+    const int wgs = a.n * ((a0.B + ipw - 1) / ipw);
+    // (not beside conv2's dW: there the launch is bound by the two bodies' total work, and a second band walks up to NSET - 1 + 2 P rows
+    // more per image -- cfg4 33.5 -> 35.5 us, cfg3 52.8 -> 57 us with bands, profiles/experiments/r05_dxrs_bands.sh)
+    const bool paired = ctx->pair && ctx->pair->layer == 1 && a0.W == 32;
+    const bool two = bands_sw != 0 && ((wgs < ctx->num_cus && !paired) || bands_sw == 2) && a0.H >= 16 && (a0.H % 4) == 0;
+    for (int i = 0; i < a.n; ++i) { a.a[i].nbands = two ? 2 : 1; a.a[i].band_rows = two ? a0.H / 2 : a0.H; }
+  }
   if (ctx->pair && ctx->pair->layer == 1 && a0.W == 32) {     // leaves with conv2's dW (conv2_bwd_pair.hip)
-    ctx->pair->dx = a; ctx->pair->dx_gx = (a0.B + 1) / 2; ctx->pair->dx_lds = DxRsGeom<2>::LDS_BYTES; ctx->pair->have_dx = true;
+    ctx->pair->dx = a; ctx->pair->dx_gx = ((a0.B + 1) / 2) * a.a[0].nbands; ctx->pair->dx_lds = DxRsGeom<2>::LDS_BYTES; ctx->pair->have_dx = true;
     ctx->pair->dx_rs = true;
     return 0;
   }
