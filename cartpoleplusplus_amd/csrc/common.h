@@ -171,7 +171,7 @@ int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, i
 // conv3 forward of 16x16 inputs with the whole image in LDS (conv3_img.hip)
 // conv3's dW and dX are independent, latency-bound launches of ~12 us each: parked by their launchers and sent as ONE grid
 struct ConvPairSlot { int layer; bool have_dw, have_dx; ConvArgsN dw, dx; int dw_gx, dx_gx; size_t dw_lds, dx_lds; int upi, band;
-                      bool dx_rs; };      // dx_rs: the dX half is conv_dx_rs.h's body (bf16 pipes), not conv_kyo.h's
+                      bool dx_rs, dw_rs; };      // dx_rs: the dX half is conv_dx_rs.h's body (bf16 pipes), not conv_kyo.h's; dw_rs: the dW half conv_dw_rs.h's
 int launch_conv3_bwd_pair(cpp_ctx* ctx, const ConvPairSlot& slot);
 int launch_conv2_bwd_pair(cpp_ctx* ctx, const ConvPairSlot& slot);
 bool conv3_img_ok(int cin, int ks, int H, int W, int nout);
@@ -185,6 +185,7 @@ int launch_conv_dw(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, ConvArgs
 size_t conv_dw_partial_floats(cpp_ctx* ctx, int cin, int ks, int nout);
 // conv2's dX on the bf16 pipes (conv_dx_rs.h)
 int conv_dx_rs_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArgsN& a, bool* handled);
+int conv_dw_rs_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArgsN& a, int* grid, bool* handled);
 size_t conv_rs16_image_bytes();     // a network's conv1 operand image (conv_rs16.h)
 bool conv_rs16_ok(cpp_ctx* ctx, int cin, int H, int W, int nout);
 int flush_dw_reduce(cpp_ctx* ctx);     // one launch for every dW reduction queued by launch_conv_dw

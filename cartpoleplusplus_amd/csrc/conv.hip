@@ -238,6 +238,8 @@ int launch_conv_dw_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, co
   // conv2 (f32 activations in): bf16 pipes, three exact pieces per operand (conv_dwb16.h); CPP_CONV_B16=0 keeps the f32 MFMA kernel
   static const bool no_b16 = cpp_switch_off("CPP_CONV_B16");
   static const bool no_dwb16 = cpp_switch_off("CPP_CONV2_DW_B16");      // conv2's dW alone back on the f32 MFMA kernel (A/B)
+  if (!handled && !no_kyo && !no_b16 && !no_dwb16 && !dense && in_mode == IN_F32_PLAIN)      // 32-wide inputs: one wave per unit (conv_dw_rs.h)
+    rc = conv_dw_rs_dispatch(ctx, cin, ks, in_mode, batch, &grid, &handled);
   if (!handled && !no_kyo && !no_b16 && !no_dwb16 && !dense && in_mode == IN_F32_PLAIN)
     rc = conv_dwb16_dispatch(ctx, cin, ks, in_mode, batch, &grid, &handled);
   if (!handled)

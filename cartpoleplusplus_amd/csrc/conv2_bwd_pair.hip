@@ -7,6 +7,7 @@
 #include "conv_kyo.h"
 #include "conv_dwb16.h"
 #include "conv_dx_rs.h"
+#include "conv_dw_rs.h"
 
 template <int ORDER>
 __global__ __launch_bounds__(CONV_THREADS, 2) void conv2_bwd_pair_kernel(const ConvArgsN dx, int dx_gx, const ConvArgsN dw, int dw_gx, int upi, int band, int order) {
@@ -17,14 +18,15 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv2_bwd_pair_kernel(const C
     conv_dwb16_body<10, 5, 1, ORDER>(dw, upi, band, i % dw_gx, i / dw_gx, dw_gx);
   }
 }
-// the dX half on the bf16 pipes (conv_dx_rs.h) instead of the f32-input row kernel
-template <int ORDER>
+// the dX half on the bf16 pipes (conv_dx_rs.h) instead of the f32-input row kernel; DWRS: the dW half one wave per unit (conv_dw_rs.h)
+template <int ORDER, bool DWRS>
 __global__ __launch_bounds__(CONV_THREADS, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv2_bwd_pair_rs_kernel(const ConvArgsN dx, int dx_gx, const ConvArgsN dw, int dw_gx, int upi, int band, int order) {
   int i;
   if (!pair_grid_place((int)blockIdx.x, dx_gx * dx.n, dw_gx * dw.n, order, &i)) {
     conv_dx_rs_body<2, ORDER>(dx, i % dx_gx, i / dx_gx);
   } else {
-    conv_dwb16_body<10, 5, 1, ORDER>(dw, upi, band, i % dw_gx, i / dw_gx, dw_gx);
+    if (DWRS) conv_dw_rs_body<ORDER>(dw, upi, band, i % dw_gx, i / dw_gx);
+    else conv_dwb16_body<10, 5, 1, ORDER>(dw, upi, band, i % dw_gx, i / dw_gx, dw_gx);
   }
 }
 
@@ -34,10 +36,13 @@ int launch_conv2_bwd_pair(cpp_ctx* ctx, const ConvPairSlot& slot) {
   const size_t lds = (slot.have_dx ? slot.dx_lds : 0) > (slot.have_dw ? slot.dw_lds : 0) ? slot.dx_lds : slot.dw_lds;
   const bool nine = b16_order(ctx) == B16_NINE;      // (cpp_ctx_set_precision: every product of the bf16 pieces)
   const bool rs = slot.have_dx && slot.dx_rs;
-  auto kern = rs ? (nine ? conv2_bwd_pair_rs_kernel<B16_NINE> : conv2_bwd_pair_rs_kernel<B16_SIX>)
+  const bool wrs = slot.have_dw && slot.dw_rs;        // (conv_dw_rs.h only parks beside conv_dx_rs.h's dX: both dispatch on the same geometry)
+  if (wrs && !rs) { cpp_set_error("conv2 backward pair: conv_dw_rs.h's dW without conv_dx_rs.h's dX"); return 1; }
+  auto kern = rs ? (wrs ? (nine ? conv2_bwd_pair_rs_kernel<B16_NINE, true> : conv2_bwd_pair_rs_kernel<B16_SIX, true>)
+                        : (nine ? conv2_bwd_pair_rs_kernel<B16_NINE, false> : conv2_bwd_pair_rs_kernel<B16_SIX, false>))
                  : (nine ? conv2_bwd_pair_kernel<B16_NINE> : conv2_bwd_pair_kernel<B16_SIX>);
-  static size_t attr_dev[CPP_MAX_DEVICES][4] = {};   // (kernel attributes are per device and per kernel)
-  size_t& attr = attr_dev[cpp_dev_slot(ctx)][(nine ? 1 : 0) + (rs ? 2 : 0)];
+  static size_t attr_dev[CPP_MAX_DEVICES][6] = {};   // (kernel attributes are per device and per kernel)
+  size_t& attr = attr_dev[cpp_dev_slot(ctx)][(nine ? 1 : 0) + (rs ? 2 : 0) + (wrs ? 2 : 0)];
   if (lds > attr) {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = lds;

@@ -1,0 +1,285 @@
+// conv2's weight / bias gradient on the bf16 matrix pipes, ONE WAVE PER UNIT ("dwrs"): v_mfma_f32_16x16x32_bf16.
+//
+//   dW[ky][kx][c][o] = sum_{b,q,x} in[b, q, x + kx - P, c] * dZ[b, q - ky + P, x, o]          (base_network.py:111-115's conv, backward)
+//
+// conv_dwb16.h's arithmetic (both f32 operands as three bf16 pieces, the six -- CPP_PRECISION_EXACT: nine -- largest piece products,
+// f32 accumulation) and its operand layouts (the input row at a pixel pitch of CP halves, read through ds_read_b64_tr_b16; dZ rows as
+// [piece][o][lane group][8 halves] in the same pixel order), in a different division of labour.  There the four waves of a workgroup
+// share one (image, band) unit, each owning one 16-column tile of (ky, o): 24 MFMAs per wave and input row between two workgroup
+// barriers, every A fragment read by all four waves, the staging of the next rows in front of the MFMAs.  Here
+//
+//   * a WAVE owns a unit and all 4 x 4 accumulator tiles of D[m = (kx, c)][n = (ky, o)] (64 VGPRs): 96 MFMAs per input row, every
+//     A fragment read once, no barrier in the row loop -- the rows of a unit are staged in the wave's own LDS slots;
+//   * the staging work (pooled gradient + arg-max code -> dZ row -> three bf16 planes; f32 activations -> three planes) is dealt out
+//     between the MFMAs (one wave per SIMD beside conv_dx_rs.h's: nobody else would issue in its place);
+//   * the bias gradient is row (kx = P, c = CIN) x column (ky = P, o) of the same product: a "ones" channel in the input row's first plane;
+//   * the four waves of a workgroup add their accumulators through LDS in a fixed order: one partial per workgroup (a quarter of
+//     conv_dwb16.h's partials for conv_dw_reduce_kernel).
+// 32-wide inputs (one 32-pixel chunk per row), 10 -> 10 channels, 5x5.
+#pragma once
+#include <type_traits>
+#include "conv_dwb16.h"
+
+struct DwRsGeom {
+  static constexpr int KS = 5, P = 2, CIN = KYO_NO, NO = KYO_NO, W = 32, Wp = 16;
+  static constexpr int CP = 12;                               // channel pitch of a pixel in LDS (halves): 10 channels, the ones channel, one spare
+  static constexpr int MT = 4, NT = 4;                        // 16-row tiles of m = CP kx + c (60 -> 64), 16-column tiles of n = NO ky + o (50 -> 64)
+  static constexpr int ROWB = 880;                            // a plane of a staged input row: (W + 2 P) pixels x CP halves + the m over-read, bytes
+  static constexpr int XSLOT = 3 * ROWB;
+  static constexpr int NXS = 2;                               // input rows in LDS: the one being multiplied, the one being written
+  static constexpr int DOST = 80, DPC = NO * DOST, DSLOT = 3 * DPC;   // dZ row: [piece][o][4 lane groups x 16 bytes + skew]
+  static constexpr int NDS = 6;                               // dZ rows in LDS: 2 P + 1 in use, one being written
+  static constexpr int WVB = NXS * XSLOT + NDS * DSLOT;       // per wave
+  static constexpr int LDS_BYTES = 4 * WVB;
+  static constexpr int NW = KS * KS * CIN * NO;
+  static_assert(WVB % 16 == 0 && WVB >= MT * NT * 4 * 64 * 4, "the wave's slots also hold its accumulators for the final sum");
+};
+
+// units = (image, band of `band` input rows); unit u of the launch's network `by` is wave (u % 4) of workgroup u / 4.
+template <int ORDER>
+__device__ __forceinline__ void conv_dw_rs_body(const ConvArgsN& batch, const int units_per_img, const int band, const int bx, const int by) {
+  typedef DwRsGeom G;
+  constexpr int KS = G::KS, P = G::P, CIN = G::CIN, NO = G::NO, W = G::W, Wp = G::Wp, CP = G::CP, MT = G::MT, NT = G::NT;
+  constexpr int ROWB = G::ROWB, XSLOT = G::XSLOT, DOST = G::DOST, DPC = G::DPC, DSLOT = G::DSLOT, NDS = G::NDS;
+  constexpr unsigned BIG = 0x08000000u;
+  const ConvArgs& a = batch.a[by];
+  extern __shared__ __attribute__((aligned(16))) unsigned char dwrs_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lj = lane >> 4;
+  const int swave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char* wvb = dwrs_lds + swave * G::WVB;
+  unsigned char* xring = wvb;                                 // [NXS][3 planes][ROWB]
+  unsigned char* dzring = wvb + G::NXS * XSLOT;               // [NDS][3 pieces][NO][DOST]
+  const int H = a.H, Hp = H >> 1;
+  const int units = a.B * units_per_img;
+  const int unit = bx * 4 + swave;
+  const bool work = unit < units;
+  const int ub = work ? unit / units_per_img : 0;
+  const int q_lo = work ? (unit - ub * units_per_img) * band : 0;
+  const int rows = work ? min(band, H - q_lo) : 0;            // (band and q_lo are even)
+  const int y0 = q_lo - P;                                    // dZ row of ring position 0
+
+  // ---- the wave's slots: zero; the ones channel (first plane, channel CIN = bf16 1.0) of the in-image pixels of both input slots
+  for (int i = lane; i < G::WVB / 16; i += 64) reinterpret_cast<k16_u32x4*>(wvb)[i] = (k16_u32x4){0u, 0u, 0u, 0u};
+  for (int i = lane; i < G::NXS * W; i += 64) {
+    const int s = i / W, x = i - s * W;
+    *reinterpret_cast<unsigned short*>(xring + s * XSLOT + 2 * (CP * (x + P) + CIN)) = (unsigned short)0x3F80u;
+  }
+
+  // ---- input rows: lane owns channel pairs (x, 2 cp) of the row, idx = lane + 64 i = 5 x + cp: 8 contiguous bytes each
+  constexpr int NXV = 3;
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>((const float*)a.in + (long)ub * a.in_bstride), 0, work ? H * W * CIN * 4 : 0, 0x00020000);
+  unsigned xvo[NXV]; uint32_t xdst[NXV];
+#pragma unroll
+  for (int i = 0; i < NXV; ++i) {
+    const int idx = lane + 64 * i, x = idx / 5, cp = idx - 5 * x;
+    const bool on = idx < W * 5;
+    xvo[i] = on ? (unsigned)(8 * idx) : BIG;
+    xdst[i] = keep_in_vgpr(lds_addr(xring + (on ? 2 * (CP * (x + P) + 2 * cp) : ROWB - 8)));      // (idle lanes: zeros into the plane's tail)
+  }
+  f32x2 xraw[2][NXV];                                         // two rows in flight
+  auto x_load = [&](const int buf, const int q) __attribute__((always_inline)) {      // (the row offset in the VGPR: the range check does not see soffset)
+    const bool in = q < H;
+#pragma unroll
+    for (int i = 0; i < NXV; ++i) {
+      const dw16_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, (int)(in ? xvo[i] + (unsigned)(q * (W * CIN * 4)) : BIG), 0, 0);
+      xraw[buf][i] = (f32x2){__uint_as_float(v.x), __uint_as_float(v.y)};
+    }
+  };
+  auto x_store = [&](const int buf, const int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NXV; ++i) {
+      unsigned short h0, m0, l0, h1, m1, l1;
+      dwb_split3(xraw[buf][i][0], h0, m0, l0); dwb_split3(xraw[buf][i][1], h1, m1, l1);
+      lds_store(xdst[i], slot * XSLOT, (unsigned)h0 | ((unsigned)h1 << 16));
+      lds_store(xdst[i], slot * XSLOT + ROWB, (unsigned)m0 | ((unsigned)m1 << 16));
+      lds_store(xdst[i], slot * XSLOT + 2 * ROWB, (unsigned)l0 | ((unsigned)l1 << 16));
+    }
+  };
+
+  // ---- dZ rows: lane l < 40 owns channel o = l % 10 of lane group g = l / 10: the 16 bytes one lane of the B operand reads -- pixels
+  // 16 (g & 1) + 2 (g >> 1) + 4 j + r, i.e. both pixels of the pooled cells px_j = 8 (g & 1) + (g >> 1) + 2 j, j = 0 .. 3
+  const int zg = lane / NO, zo = lane - zg * NO;
+  const bool zon = lane < 4 * NO;
+  const __amdgpu_buffer_rsrc_t dp_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy.dpool + (long)ub * a.dy.dpool_bstride), 0,
+                                                                           work ? Hp * Wp * NO * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t am_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.dy.amax + (long)ub * Hp * Wp * NO), 0,
+                                                                           work ? Hp * Wp * NO : 0, 0x00020000);
+  const unsigned zoff = zon ? (unsigned)((8 * (zg & 1) + (zg >> 1)) * NO + zo) : BIG;      // element offset of cell j = 0 in a pooled row; cell j: + 2 j NO
+  const uint32_t zdst = keep_in_vgpr(lds_addr(dzring + (zon ? zo * DOST + zg * 16 : DOST - 16)));      // (idle lanes: zeros into the skew)
+  float zrg[3][4]; unsigned zrc[3][4];                        // three pooled rows in flight (conv_dx_rs.h)
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { zrg[b][j] = 0.f; zrc[b][j] = 0u; }
+  unsigned zp01[3] = {0u, 0u, 0u}, zp23[3] = {0u, 0u, 0u};    // the pieces of cells (0, 1) and (2, 3), packed
+  unsigned zm01[4] = {0u, 0u, 0u, 0u}, zm23[4] = {0u, 0u, 0u, 0u};      // per window position 2 ry + rx: which halves belong to that pixel
+  auto z_load = [&](const int buf, const int py) __attribute__((always_inline)) {
+    const bool in = py >= 0 && py < Hp;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned e = in ? zoff + (unsigned)(py * (Wp * NO) + 2 * j * NO) : BIG;
+      zrg[buf][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dp_rsrc, (int)(in ? e * 4u : BIG), 0, 0));
+      zrc[buf][j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(am_rsrc, (int)e, 0, 0);
+    }
+  };
+  auto z_convert = [&](const int buf) __attribute__((always_inline)) {
+    unsigned short pc[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g = (zrc[buf][j] & POOL_ACTIVE) ? zrg[buf][j] : 0.f;
+      dwb_split3(g, pc[j][0], pc[j][1], pc[j][2]);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      zp01[p] = (unsigned)pc[0][p] | ((unsigned)pc[1][p] << 16);
+      zp23[p] = (unsigned)pc[2][p] | ((unsigned)pc[3][p] << 16);
+    }
+#pragma unroll
+    for (int pos = 0; pos < 4; ++pos) {
+      zm01[pos] = ((zrc[buf][0] & 3u) == (unsigned)pos ? 0xFFFFu : 0u) | ((zrc[buf][1] & 3u) == (unsigned)pos ? 0xFFFF0000u : 0u);
+      zm23[pos] = ((zrc[buf][2] & 3u) == (unsigned)pos ? 0xFFFFu : 0u) | ((zrc[buf][3] & 3u) == (unsigned)pos ? 0xFFFF0000u : 0u);
+    }
+  };
+  auto z_store = [&](const int slot, const int ry) __attribute__((always_inline)) {      // dZ row 2 py + ry of the converted pooled row
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      lds_store(zdst, slot * DSLOT + p * DPC, (k16_u32x4){zp01[p] & zm01[2 * ry], zp23[p] & zm23[2 * ry], zp01[p] & zm01[2 * ry + 1], zp23[p] & zm23[2 * ry + 1]});
+  };
+
+  // ---- MFMA operands (pixel dealing and transpose reads as conv_dw16.h / conv_dwb16.h)
+  const int tj = (lane >> 2) & 3, tq = lane & 3;
+  const uint32_t aadr = keep_in_vgpr(lds_addr(xring + 2 * (CP * (16 * (lj & 1) + 4 * tj + 2 * (lj >> 1)) + 4 * tq)));
+  // column n = 16 nt + li = NO ky + o reads dZ ring position t - ky + 2 P at input row t of the band: slot (sq - ky + 2 P) mod NDS
+  uint32_t bbase[NT]; int bky[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = 16 * nt + li;
+    const bool nvalid = n < KS * NO;
+    bky[nt] = nvalid ? n / NO : 0;
+    bbase[nt] = lds_addr(dzring + (nvalid ? n % NO : 0) * DOST + lj * 16);
+  }
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (work) {
+    // ---- prologue: dZ ring positions 0 .. 2 P (rows y0 .. y0 + 4: pooled rows y0 / 2 .. y0 / 2 + 2), input row q_lo; two more of each in flight
+    const int py0 = y0 >> 1;                                  // (y0 is even; -1 for the first band: zeros)
+    z_load(0, py0); z_load(1, py0 + 1); z_load(2, py0 + 2);
+    x_load(0, q_lo); x_load(1, q_lo + 1);
+    z_convert(0); z_store(0, 0); z_store(1, 1);
+    z_convert(1); z_store(2, 0); z_store(3, 1);
+    z_convert(2); z_store(4, 0);                              // (position 5, the same pooled row, is stored by the first step)
+    z_load(0, py0 + 3); z_load(1, py0 + 4);
+    x_store(0, 0);
+    x_load(0, q_lo + 2);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // Step t (sq = t mod 6, compile time): multiply input row q_lo + t (slot t & 1) with dZ positions t .. t + 2 P; meanwhile dZ position
+    // t + 2 P + 1 (row y0 + t + 5: pooled row py0 + (t + 5) / 2, buffer ((t + 5) / 2) mod 3) and input row q_lo + t + 1 go to LDS, and
+    // the loads of pooled row py0 + (t + 5) / 2 + 2 (every second step) and of input row q_lo + t + 3 leave.
+    auto step = [&](auto sqtag, const int t) __attribute__((always_inline)) {
+      constexpr int SQ = decltype(sqtag)::value;
+      constexpr int XS = SQ & 1;
+      constexpr int ZPOS = SQ + 2 * P + 1;                    // ring position (mod 6 rows per pooled-row triple) being written
+      constexpr bool ZODD = (ZPOS & 1) != 0;                  // its image-row parity ry (y0 is even)
+      constexpr int ZBUF = (ZPOS / 2) % 3;
+      // B operands of the row: 4 column tiles x 3 pieces
+      k16_u32x4 bq[NT][3];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        // slot of this lane's column: (SQ - ky + 2 P) mod NDS -- ky differs per lane
+        int sl = SQ + 2 * P - bky[nt]; sl = sl >= NDS ? sl - NDS : sl;
+        const uint32_t ad = bbase[nt] + (uint32_t)(sl * DSLOT);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bq[nt][p] = lds_load<k16_u32x4>(ad, p * DPC);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        k16_u32x4 av[3];
+#pragma unroll
+        for (int pa = 0; pa < 3; ++pa) {
+          const int off = XS * XSLOT + pa * ROWB + mt * 32;
+          const dw16_v4s r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              reinterpret_cast<__attribute__((address_space(3))) dw16_v4s*>((uintptr_t)(aadr + (uint32_t)off)));
+          const dw16_v4s r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              reinterpret_cast<__attribute__((address_space(3))) dw16_v4s*>((uintptr_t)(aadr + (uint32_t)(off + 2 * CP))));
+          const dw16_u32x2 u0 = __builtin_bit_cast(dw16_u32x2, r0), u1 = __builtin_bit_cast(dw16_u32x2, r1);
+          av[pa] = (k16_u32x4){u0.x, u0.y, u1.x, u1.y};
+        }
+#pragma unroll
+        for (int sum = ORDER; sum >= 0; --sum)                // small products first
+#pragma unroll
+          for (int pa = 2; pa >= 0; --pa) {
+            const int pb = sum - pa;
+            if (pb >= 0 && pb <= 2) {
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dwb_bf16x8, av[pa]), __builtin_bit_cast(dwb_bf16x8, bq[nt][pb]),
+                                                                      acc[mt][nt], 0, 0, 0);
+            }
+          }
+        // the next rows' staging, a quarter behind each row tile's MFMAs
+        if (mt == 0) { if (!ZODD) z_convert(ZBUF); }
+        else if (mt == 1) { z_store(ZPOS % NDS, ZODD ? 1 : 0); if (ZODD) z_load(ZBUF, py0 + (t + 2 * P + 1) / 2 + 3); }
+        else if (mt == 2) x_store((SQ + 1) & 1, XS ^ 1);
+        else x_load((SQ + 1) & 1, q_lo + t + 3);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int t0 = 0; t0 < rows; t0 += 6) {
+      if (t0 + 0 < rows) step(std::integral_constant<int, 0>{}, t0 + 0);
+      if (t0 + 1 < rows) step(std::integral_constant<int, 1>{}, t0 + 1);
+      if (t0 + 2 < rows) step(std::integral_constant<int, 2>{}, t0 + 2);
+      if (t0 + 3 < rows) step(std::integral_constant<int, 3>{}, t0 + 3);
+      if (t0 + 4 < rows) step(std::integral_constant<int, 4>{}, t0 + 4);
+      if (t0 + 5 < rows) step(std::integral_constant<int, 5>{}, t0 + 5);
+    }
+  }
+
+  // ---- one partial per workgroup: the four waves' accumulators through their own LDS slots, added in wave order
+  float* mine = reinterpret_cast<float*>(wvb);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      *reinterpret_cast<f32x4*>(mine + ((mt * NT + nt) * 64 + lane) * 4) = acc[mt][nt];
+  __syncthreads();
+  float* part = a.partial + (long)bx * a.pstride;
+  {
+    const int nt = swave;                                     // wave w writes column tile w
+    const int n = 16 * nt + li;
+    const bool nvalid = n < KS * NO;
+    const int nky = nvalid ? n / NO : 0, no = nvalid ? n % NO : 0;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      f32x4 s = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(dwrs_lds) + ((mt * NT + nt) * 64 + lane) * 4);
+#pragma unroll
+      for (int v = 1; v < 4; ++v) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(dwrs_lds + v * G::WVB) + ((mt * NT + nt) * 64 + lane) * 4);
+        s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
+      }
+      if (nvalid && no < a.nout) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 16 * mt + 4 * lj + r;
+          const int kx = m / CP, c = m - kx * CP;
+          if (kx < KS && c < CIN) part[(nky * (KS * CIN) + kx * CIN + c) * a.nout + no] = s[r];
+          else if (kx == P && c == CIN && nky == P) part[G::NW / NO * a.nout + no] = s[r];      // the ones channel x the centre tap: sum of dZ = db
+        }
+      }
+    }
+  }
+}
+
+template <int ORDER>
+__global__ __launch_bounds__(CONV_THREADS, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_dw_rs_kernel(const ConvArgsN batch, int units_per_img, int band) {
+  conv_dw_rs_body<ORDER>(batch, units_per_img, band, blockIdx.x, blockIdx.y);
+}
+
+// conv2's dW at 32-wide inputs, 10 -> 10 channels, 5x5, pooled dZ (no batch norm)
+int conv_dw_rs_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArgsN& a, int* grid, bool* handled);

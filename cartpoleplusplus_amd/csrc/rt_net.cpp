@@ -466,7 +466,7 @@ int nets_backward_conv(cpp_ctx* ctx, cpp_net* const* nets, int nn, int B, const 
     static const bool no_pair3 = cpp_switch_off("CPP_CONV3_PAIR");
     static const bool no_pair2 = cpp_switch_off("CPP_CONV2_PAIR");
     const bool no_pair = i == 2 ? no_pair3 : (i == 1 ? no_pair2 : true);
-    ConvPairSlot slot; slot.have_dw = slot.have_dx = false; slot.dx_rs = false; slot.layer = i;
+    ConvPairSlot slot; slot.have_dw = slot.have_dx = false; slot.dx_rs = slot.dw_rs = false; slot.layer = i;
     if (!no_pair) ctx->pair = &slot;
     int rc = launch_conv_dw_multi(ctx, kDwKid[i], L.Cin, L.ks, mode, dl, nn, gw, gb);
     if (!rc && i > 0) rc = launch_conv_fwd_multi(ctx, kDxKid[i], kConvOut, L.ks, IN_DY, EPI_PLAIN, xl, nn);
