@@ -19,6 +19,9 @@
 #pragma once
 #include <type_traits>
 #include "conv_dwb16.h"
+#ifndef DWRS_INTERLEAVE
+#define DWRS_INTERLEAVE 1
+#endif
 
 struct DwRsGeom {
   static constexpr int KS = 5, P = 2, CIN = KYO_NO, NO = KYO_NO, W = 32, Wp = 16;
@@ -79,16 +82,15 @@ __device__ __forceinline__ void conv_dw_rs_body(const ConvArgsN& batch, const in
   }
   f32x2 xraw[2][NXV];                                         // two rows in flight
   auto x_load = [&](const int buf, const int q) __attribute__((always_inline)) {      // (the row offset in the VGPR: the range check does not see soffset)
-    const bool in = q < H;
+    const unsigned ro = q < H ? (unsigned)(q * (W * CIN * 4)) : BIG;      // (a scalar select: behind the image every lane is out of range)
 #pragma unroll
     for (int i = 0; i < NXV; ++i) {
-      const dw16_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, (int)(in ? xvo[i] + (unsigned)(q * (W * CIN * 4)) : BIG), 0, 0);
+      const dw16_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, (int)(xvo[i] + ro), 0, 0);
       xraw[buf][i] = (f32x2){__uint_as_float(v.x), __uint_as_float(v.y)};
     }
   };
-  auto x_store = [&](const int buf, const int slot) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < NXV; ++i) {
+  auto x_store1 = [&](const int buf, const int slot, const int i) __attribute__((always_inline)) {
+    {
       unsigned short h0, m0, l0, h1, m1, l1;
       dwb_split3(xraw[buf][i][0], h0, m0, l0); dwb_split3(xraw[buf][i][1], h1, m1, l1);
       lds_store(xdst[i], slot * XSLOT, (unsigned)h0 | ((unsigned)h1 << 16));
@@ -96,6 +98,7 @@ __device__ __forceinline__ void conv_dw_rs_body(const ConvArgsN& batch, const in
       lds_store(xdst[i], slot * XSLOT + 2 * ROWB, (unsigned)l0 | ((unsigned)l1 << 16));
     }
   };
+  auto x_store = [&](const int buf, const int slot) __attribute__((always_inline)) { x_store1(buf, slot, 0); x_store1(buf, slot, 1); x_store1(buf, slot, 2); };
 
   // ---- dZ rows: lane l < 40 owns channel o = l % 10 of lane group g = l / 10: the 16 bytes one lane of the B operand reads -- pixels
   // 16 (g & 1) + 2 (g >> 1) + 4 j + r, i.e. both pixels of the pooled cells px_j = 8 (g & 1) + (g >> 1) + 2 j, j = 0 .. 3
@@ -115,32 +118,33 @@ __device__ __forceinline__ void conv_dw_rs_body(const ConvArgsN& batch, const in
   unsigned zp01[3] = {0u, 0u, 0u}, zp23[3] = {0u, 0u, 0u};    // the pieces of cells (0, 1) and (2, 3), packed
   unsigned zm01[4] = {0u, 0u, 0u, 0u}, zm23[4] = {0u, 0u, 0u, 0u};      // per window position 2 ry + rx: which halves belong to that pixel
   auto z_load = [&](const int buf, const int py) __attribute__((always_inline)) {
-    const bool in = py >= 0 && py < Hp;
+    const unsigned ro = (py >= 0 && py < Hp) ? (unsigned)(py * (Wp * NO)) : BIG;      // (a scalar select, no branch around the loads)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const unsigned e = in ? zoff + (unsigned)(py * (Wp * NO) + 2 * j * NO) : BIG;
-      zrg[buf][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dp_rsrc, (int)(in ? e * 4u : BIG), 0, 0));
+      const unsigned e = zoff + ro + (unsigned)(2 * j * NO);
+      zrg[buf][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dp_rsrc, (int)(e * 4u), 0, 0));
       zrc[buf][j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(am_rsrc, (int)e, 0, 0);
     }
   };
-  auto z_convert = [&](const int buf) __attribute__((always_inline)) {
-    unsigned short pc[4][3];
+  auto z_convert_half = [&](const int buf, const int hf) __attribute__((always_inline)) {      // cells (0, 1) or (2, 3) of the lane's four
+    unsigned short pc[2][3];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float g = (zrc[buf][j] & POOL_ACTIVE) ? zrg[buf][j] : 0.f;
+    for (int j = 0; j < 2; ++j) {
+      const float g = (zrc[buf][2 * hf + j] & POOL_ACTIVE) ? zrg[buf][2 * hf + j] : 0.f;
       dwb_split3(g, pc[j][0], pc[j][1], pc[j][2]);
     }
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-      zp01[p] = (unsigned)pc[0][p] | ((unsigned)pc[1][p] << 16);
-      zp23[p] = (unsigned)pc[2][p] | ((unsigned)pc[3][p] << 16);
+      const unsigned v = (unsigned)pc[0][p] | ((unsigned)pc[1][p] << 16);
+      if (hf == 0) zp01[p] = v; else zp23[p] = v;
     }
 #pragma unroll
     for (int pos = 0; pos < 4; ++pos) {
-      zm01[pos] = ((zrc[buf][0] & 3u) == (unsigned)pos ? 0xFFFFu : 0u) | ((zrc[buf][1] & 3u) == (unsigned)pos ? 0xFFFF0000u : 0u);
-      zm23[pos] = ((zrc[buf][2] & 3u) == (unsigned)pos ? 0xFFFFu : 0u) | ((zrc[buf][3] & 3u) == (unsigned)pos ? 0xFFFF0000u : 0u);
+      const unsigned v = ((zrc[buf][2 * hf] & 3u) == (unsigned)pos ? 0xFFFFu : 0u) | ((zrc[buf][2 * hf + 1] & 3u) == (unsigned)pos ? 0xFFFF0000u : 0u);
+      if (hf == 0) zm01[pos] = v; else zm23[pos] = v;
     }
   };
+  auto z_convert = [&](const int buf) __attribute__((always_inline)) { z_convert_half(buf, 0); z_convert_half(buf, 1); };
   auto z_store = [&](const int slot, const int ry) __attribute__((always_inline)) {      // dZ row 2 py + ry of the converted pooled row
 #pragma unroll
     for (int p = 0; p < 3; ++p)
@@ -180,37 +184,47 @@ __device__ __forceinline__ void conv_dw_rs_body(const ConvArgsN& batch, const in
 
     // Step t (sq = t mod 6, compile time): multiply input row q_lo + t (slot t & 1) with dZ positions t .. t + 2 P; meanwhile dZ position
     // t + 2 P + 1 (row y0 + t + 5: pooled row py0 + (t + 5) / 2, buffer ((t + 5) / 2) mod 3) and input row q_lo + t + 1 go to LDS, and
-    // the loads of pooled row py0 + (t + 5) / 2 + 2 (every second step) and of input row q_lo + t + 3 leave.
+    // the loads of pooled row py0 + (t + 5) / 2 + 3 (every second step) and of input row q_lo + t + 3 leave.
+    // The row's 96 MFMAs run as 8 BLOCKS of 12: column tiles (0, 1), then (2, 3), each against the four row tiles.  Every operand is
+    // requested a block (A: 6 transpose reads) or half a row (B: the other half's 6 reads, into the registers that half has just
+    // released) before its use, and the staging work is dealt out over the blocks, between their MFMAs -- this wave is alone on its
+    // SIMD slot: what it does not issue in an MFMA's shadow leaves the matrix pipe idle.
+    k16_u32x4 bq[NT][3];
+    k16_u32x4 av[3];
+    auto b_load = [&](const int sq, const int nt) __attribute__((always_inline)) {      // column tile nt's operands for the step with t mod 6 = sq
+      int sl = sq + 2 * P - bky[nt]; sl = sl >= NDS ? sl - NDS : sl;                     // slot of this lane's column: ky differs per lane
+      const uint32_t ad = bbase[nt] + (uint32_t)(sl * DSLOT);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bq[nt][p] = lds_load<k16_u32x4>(ad, p * DPC);
+    };
+    auto a_load = [&](k16_u32x4 (&dst)[3], const int xs, const int mt) __attribute__((always_inline)) {
+#pragma unroll
+      for (int pa = 0; pa < 3; ++pa) {
+        const int off = xs * XSLOT + pa * ROWB + mt * 32;
+        const dw16_v4s r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            reinterpret_cast<__attribute__((address_space(3))) dw16_v4s*>((uintptr_t)(aadr + (uint32_t)off)));
+        const dw16_v4s r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            reinterpret_cast<__attribute__((address_space(3))) dw16_v4s*>((uintptr_t)(aadr + (uint32_t)(off + 2 * CP))));
+        const dw16_u32x2 u0 = __builtin_bit_cast(dw16_u32x2, r0), u1 = __builtin_bit_cast(dw16_u32x2, r1);
+        dst[pa] = (k16_u32x4){u0.x, u0.y, u1.x, u1.y};
+      }
+    };
+    b_load(0, 0); b_load(0, 1);
+    a_load(av, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
     auto step = [&](auto sqtag, const int t) __attribute__((always_inline)) {
       constexpr int SQ = decltype(sqtag)::value;
       constexpr int XS = SQ & 1;
-      constexpr int ZPOS = SQ + 2 * P + 1;                    // ring position (mod 6 rows per pooled-row triple) being written
+      constexpr int ZPOS = SQ + 2 * P + 1;                    // ring position being written (mod: 6 rows = three pooled rows)
       constexpr bool ZODD = (ZPOS & 1) != 0;                  // its image-row parity ry (y0 is even)
       constexpr int ZBUF = (ZPOS / 2) % 3;
-      // B operands of the row: 4 column tiles x 3 pieces
-      k16_u32x4 bq[NT][3];
+      constexpr int NPROD = ORDER == B16_NINE ? 9 : 6;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        // slot of this lane's column: (SQ - ky + 2 P) mod NDS -- ky differs per lane
-        int sl = SQ + 2 * P - bky[nt]; sl = sl >= NDS ? sl - NDS : sl;
-        const uint32_t ad = bbase[nt] + (uint32_t)(sl * DSLOT);
-#pragma unroll
-        for (int p = 0; p < 3; ++p) bq[nt][p] = lds_load<k16_u32x4>(ad, p * DPC);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        k16_u32x4 av[3];
-#pragma unroll
-        for (int pa = 0; pa < 3; ++pa) {
-          const int off = XS * XSLOT + pa * ROWB + mt * 32;
-          const dw16_v4s r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              reinterpret_cast<__attribute__((address_space(3))) dw16_v4s*>((uintptr_t)(aadr + (uint32_t)off)));
-          const dw16_v4s r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              reinterpret_cast<__attribute__((address_space(3))) dw16_v4s*>((uintptr_t)(aadr + (uint32_t)(off + 2 * CP))));
-          const dw16_u32x2 u0 = __builtin_bit_cast(dw16_u32x2, r0), u1 = __builtin_bit_cast(dw16_u32x2, r1);
-          av[pa] = (k16_u32x4){u0.x, u0.y, u1.x, u1.y};
-        }
+      for (int blk = 0; blk < 8; ++blk) {
+        const int hs = blk >> 2, mt = blk & 3;
+        // the next block's row tile (the next row's first one behind the last block: its slot was written in block 4 .. 6)
+        k16_u32x4 an[3];
+        if (blk < 7) a_load(an, XS, (blk + 1) & 3); else a_load(an, XS ^ 1, 0);
 #pragma unroll
         for (int sum = ORDER; sum >= 0; --sum)                // small products first
 #pragma unroll
@@ -218,18 +232,36 @@ __device__ __forceinline__ void conv_dw_rs_body(const ConvArgsN& batch, const in
             const int pb = sum - pa;
             if (pb >= 0 && pb <= 2) {
 #pragma unroll
-              for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dwb_bf16x8, av[pa]), __builtin_bit_cast(dwb_bf16x8, bq[nt][pb]),
-                                                                      acc[mt][nt], 0, 0, 0);
+              for (int n2 = 0; n2 < 2; ++n2)
+                acc[mt][2 * hs + n2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dwb_bf16x8, av[pa]), __builtin_bit_cast(dwb_bf16x8, bq[2 * hs + n2][pb]),
+                                                                               acc[mt][2 * hs + n2], 0, 0, 0);
             }
           }
-        // the next rows' staging, a quarter behind each row tile's MFMAs
-        if (mt == 0) { if (!ZODD) z_convert(ZBUF); }
-        else if (mt == 1) { z_store(ZPOS % NDS, ZODD ? 1 : 0); if (ZODD) z_load(ZBUF, py0 + (t + 2 * P + 1) / 2 + 3); }
-        else if (mt == 2) x_store((SQ + 1) & 1, XS ^ 1);
-        else x_load((SQ + 1) & 1, q_lo + t + 3);
+        // this block's share of the staging and of the operand requests
+        if (blk == 0) { b_load(SQ, 2); if (!ZODD) z_convert_half(ZBUF, 0); }
+        else if (blk == 1) { b_load(SQ, 3); if (!ZODD) z_convert_half(ZBUF, 1); }
+        else if (blk == 2) z_store(ZPOS % NDS, ZODD ? 1 : 0);
+        else if (blk == 3) { if (ZODD) z_load(ZBUF, py0 + (t + 2 * P + 1) / 2 + 3); x_store1((SQ + 1) & 1, XS ^ 1, 0); }
+        else if (blk == 4) x_store1((SQ + 1) & 1, XS ^ 1, 1);
+        else if (blk == 5) x_store1((SQ + 1) & 1, XS ^ 1, 2);
+        else if (blk == 6) { x_load((SQ + 1) & 1, q_lo + t + 3); b_load((SQ + 1) % 6, 0); }
+        else b_load((SQ + 1) % 6, 1);
+#if DWRS_INTERLEAVE
+#pragma unroll
+        for (int i = 0; i < 2 * NPROD; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // one MFMA
+          if (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);               // the next block's 6 transpose reads
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                          // VALU
+          if (i >= 6 && i < 9) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // a column tile's 3 reads
+          if (i >= 8) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);              // LDS writes
+          if (i == 1) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);              // loads
+          if (i == 2) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pa = 0; pa < 3; ++pa) av[pa] = an[pa];
       }
-      __builtin_amdgcn_sched_barrier(0);
     };
     for (int t0 = 0; t0 < rows; t0 += 6) {
       if (t0 + 0 < rows) step(std::integral_constant<int, 0>{}, t0 + 0);
