@@ -15,7 +15,7 @@
 //   * the bias gradient is row (kx = P, c = CIN) x column (ky = P, o) of the same product: a "ones" channel in the input row's first plane;
 //   * the four waves of a workgroup add their accumulators through LDS in a fixed order: one partial per workgroup (a quarter of
 //     conv_dwb16.h's partials for conv_dw_reduce_kernel).
-// 32-wide inputs (one 32-pixel chunk per row), 10 -> 10 channels, 5x5.
+// Rows of 32 or 64 pixels (a unit = a 32-pixel column of a band: the contraction's one chunk per row), 10 -> 10 channels, 5x5.
 #pragma once
 #include <type_traits>
 #include "conv_dwb16.h"
@@ -24,7 +24,7 @@
 #endif
 
 struct DwRsGeom {
-  static constexpr int KS = 5, P = 2, CIN = KYO_NO, NO = KYO_NO, W = 32, Wp = 16;
+  static constexpr int KS = 5, P = 2, CIN = KYO_NO, NO = KYO_NO, WC = 32;      // a unit's column of an image: 32 pixels
   static constexpr int CP = 12;                               // channel pitch of a pixel in LDS (halves): 10 channels, the ones channel, one spare
   static constexpr int MT = 4, NT = 4;                        // 16-row tiles of m = CP kx + c (60 -> 64), 16-column tiles of n = NO ky + o (50 -> 64)
   static constexpr int ROWB = 880;                            // a plane of a staged input row: (W + 2 P) pixels x CP halves + the m over-read, bytes
@@ -38,11 +38,12 @@ struct DwRsGeom {
   static_assert(WVB % 16 == 0 && WVB >= MT * NT * 4 * 64 * 4, "the wave's slots also hold its accumulators for the final sum");
 };
 
-// units = (image, band of `band` input rows); unit u of the launch's network `by` is wave (u % 4) of workgroup u / 4.
+// units = (image, band of `band` input rows, 32-pixel column); unit u of the launch's network `by` is wave (u % 4) of workgroup u / 4;
+// units_per_img = bands x columns, column fastest.
 template <int ORDER>
 __device__ __forceinline__ void conv_dw_rs_body(const ConvArgsN& batch, const int units_per_img, const int band, const int bx, const int by) {
   typedef DwRsGeom G;
-  constexpr int KS = G::KS, P = G::P, CIN = G::CIN, NO = G::NO, W = G::W, Wp = G::Wp, CP = G::CP, MT = G::MT, NT = G::NT;
+  constexpr int KS = G::KS, P = G::P, CIN = G::CIN, NO = G::NO, WC = G::WC, CP = G::CP, MT = G::MT, NT = G::NT;
   constexpr int ROWB = G::ROWB, XSLOT = G::XSLOT, DOST = G::DOST, DPC = G::DPC, DSLOT = G::DSLOT, NDS = G::NDS;
   constexpr unsigned BIG = 0x08000000u;
   const ConvArgs& a = batch.a[by];
@@ -52,33 +53,37 @@ __device__ __forceinline__ void conv_dw_rs_body(const ConvArgsN& batch, const in
   unsigned char* wvb = dwrs_lds + swave * G::WVB;
   unsigned char* xring = wvb;                                 // [NXS][3 planes][ROWB]
   unsigned char* dzring = wvb + G::NXS * XSLOT;               // [NDS][3 pieces][NO][DOST]
-  const int H = a.H, Hp = H >> 1;
+  const int H = a.H, Hp = H >> 1, W = a.W, Wp = W >> 1, ncol = W / WC;
   const int units = a.B * units_per_img;
   const int unit = bx * 4 + swave;
   const bool work = unit < units;
   const int ub = work ? unit / units_per_img : 0;
-  const int q_lo = work ? (unit - ub * units_per_img) * band : 0;
+  const int uin = unit - ub * units_per_img;
+  const int x0 = work ? (uin % ncol) * WC : 0;               // the unit's pixels: x0 .. x0 + 31
+  const int q_lo = work ? (uin / ncol) * band : 0;
   const int rows = work ? min(band, H - q_lo) : 0;            // (band and q_lo are even)
   const int y0 = q_lo - P;                                    // dZ row of ring position 0
 
   // ---- the wave's slots: zero; the ones channel (first plane, channel CIN = bf16 1.0) of the in-image pixels of both input slots
   for (int i = lane; i < G::WVB / 16; i += 64) reinterpret_cast<k16_u32x4*>(wvb)[i] = (k16_u32x4){0u, 0u, 0u, 0u};
-  for (int i = lane; i < G::NXS * W; i += 64) {
-    const int s = i / W, x = i - s * W;
+  for (int i = lane; i < G::NXS * WC; i += 64) {
+    const int s = i / WC, x = i - s * WC;
     *reinterpret_cast<unsigned short*>(xring + s * XSLOT + 2 * (CP * (x + P) + CIN)) = (unsigned short)0x3F80u;
   }
 
-  // ---- input rows: lane owns channel pairs (x, 2 cp) of the row, idx = lane + 64 i = 5 x + cp: 8 contiguous bytes each
+  // ---- input rows: the unit's pixels and P more on each side (the neighbouring column's, or the SAME padding's zeros -- out of the
+  // descriptor's range); lane owns channel pairs (wx, 2 cp) of that window, idx = lane + 64 i = 5 wx + cp: 8 contiguous bytes each
   constexpr int NXV = 3;
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>((const float*)a.in + (long)ub * a.in_bstride), 0, work ? H * W * CIN * 4 : 0, 0x00020000);
   unsigned xvo[NXV]; uint32_t xdst[NXV];
 #pragma unroll
   for (int i = 0; i < NXV; ++i) {
-    const int idx = lane + 64 * i, x = idx / 5, cp = idx - 5 * x;
-    const bool on = idx < W * 5;
-    xvo[i] = on ? (unsigned)(8 * idx) : BIG;
-    xdst[i] = keep_in_vgpr(lds_addr(xring + (on ? 2 * (CP * (x + P) + 2 * cp) : ROWB - 8)));      // (idle lanes: zeros into the plane's tail)
+    const int idx = lane + 64 * i, wx = idx / 5, cp = idx - 5 * wx;
+    const int x = x0 - P + wx;
+    const bool on = idx < (WC + 2 * P) * 5;
+    xvo[i] = (on && x >= 0 && x < W) ? (unsigned)(8 * (5 * x + cp)) : BIG;
+    xdst[i] = keep_in_vgpr(lds_addr(xring + (on ? 2 * (CP * wx + 2 * cp) : ROWB - 8)));      // (idle lanes: zeros into the plane's tail)
   }
   f32x2 xraw[2][NXV];                                         // two rows in flight
   auto x_load = [&](const int buf, const int q) __attribute__((always_inline)) {      // (the row offset in the VGPR: the range check does not see soffset)
@@ -108,7 +113,7 @@ __device__ __forceinline__ void conv_dw_rs_body(const ConvArgsN& batch, const in
                                                                            work ? Hp * Wp * NO * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t am_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.dy.amax + (long)ub * Hp * Wp * NO), 0,
                                                                            work ? Hp * Wp * NO : 0, 0x00020000);
-  const unsigned zoff = zon ? (unsigned)((8 * (zg & 1) + (zg >> 1)) * NO + zo) : BIG;      // element offset of cell j = 0 in a pooled row; cell j: + 2 j NO
+  const unsigned zoff = zon ? (unsigned)((x0 / 2 + 8 * (zg & 1) + (zg >> 1)) * NO + zo) : BIG;      // element offset of cell j = 0 in a pooled row; cell j: + 2 j NO
   const uint32_t zdst = keep_in_vgpr(lds_addr(dzring + (zon ? zo * DOST + zg * 16 : DOST - 16)));      // (idle lanes: zeros into the skew)
   float zrg[3][4]; unsigned zrc[3][4];                        // three pooled rows in flight (conv_dx_rs.h)
 #pragma unroll

@@ -6,20 +6,20 @@ int conv_dw_rs_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvAr
   *handled = false;
   static const bool off = cpp_switch_off("CPP_CONV_DWRS") || cpp_switch_off("CPP_CONV_B16");
   const ConvArgs& a = batch.a[0];
-  if (off || ks != 5 || cin != KYO_NO || in_mode != IN_F32_PLAIN || a.W != 32 || (a.H & 1) || a.H < 8 || a.nout != KYO_NO) return 0;
+  if (off || ks != 5 || cin != KYO_NO || in_mode != IN_F32_PLAIN || (a.W != 32 && a.W != 64) || (a.H & 1) || a.H < 8 || a.nout != KYO_NO) return 0;
   for (int i = 0; i < batch.n; ++i)
     if (batch.a[i].dy_dense != nullptr || ((uintptr_t)batch.a[i].in & 7) || (batch.a[i].in_bstride & 1)) return 0;
   *handled = true;
   // units = (image, band of rows), one per WAVE: bands as short as filling every SIMD's slot once allows (a band reads 2 P more dZ
   // rows than it has input rows; it multiplies no row twice)
-  const int capacity = ctx->num_cus * 4 / batch.n;
+  const int capacity = ctx->num_cus * 4 / batch.n, ncol = a.W / 32;
   int band = (a.H + 1) & ~1;
-  while (band > 8 && (band / 2) % 2 == 0 && a.B * ((a.H + band / 2 - 1) / (band / 2)) <= capacity) band /= 2;
-  const int upi = (a.H + band - 1) / band;
+  while (band > 8 && (band / 2) % 2 == 0 && a.B * ncol * ((a.H + band / 2 - 1) / (band / 2)) <= capacity) band /= 2;
+  const int upi = ((a.H + band - 1) / band) * ncol;           // (band, 32-pixel column) units of an image, column fastest
   const int grid = (a.B * upi + 3) / 4;
   *grid_out = grid;
   const bool nine = b16_order(ctx) == B16_NINE;
-  if (ctx->pair && ctx->pair->layer == 1) {                   // leaves with conv2's dX (conv2_bwd_pair.hip)
+  if (ctx->pair && ctx->pair->layer == 1 && a.W == 32) {      // leaves with conv2's dX (conv2_bwd_pair.hip)
     ctx->pair->dw = batch; ctx->pair->dw_gx = grid; ctx->pair->dw_lds = DwRsGeom::LDS_BYTES; ctx->pair->have_dw = true;
     ctx->pair->upi = upi; ctx->pair->band = band; ctx->pair->dw_rs = true;
     return 0;
