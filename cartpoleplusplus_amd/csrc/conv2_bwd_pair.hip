@@ -25,7 +25,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) __attribute__((amdgpu_waves_per_eu
   if (!pair_grid_place((int)blockIdx.x, dx_gx * dx.n, dw_gx * dw.n, order, &i)) {
     conv_dx_rs_body<2, ORDER>(dx, i % dx_gx, i / dx_gx);
   } else {
-    if (DWRS) conv_dw_rs_body<ORDER>(dw, upi, band, i % dw_gx, i / dw_gx);
+    if (DWRS) conv_dw_rs_body<5, ORDER>(dw, upi, band, i % dw_gx, i / dw_gx);
     else conv_dwb16_body<10, 5, 1, ORDER>(dw, upi, band, i % dw_gx, i / dw_gx, dw_gx);
   }
 }

@@ -23,27 +23,30 @@
 #define DWRS_INTERLEAVE 1
 #endif
 
+template <int KS_>
 struct DwRsGeom {
-  static constexpr int KS = 5, P = 2, CIN = KYO_NO, NO = KYO_NO, WC = 32;      // a unit's column of an image: 32 pixels
+  static constexpr int KS = KS_, P = KS / 2, PB = 2, CIN = KYO_NO, NO = KYO_NO, WC = 32;      // WC: a unit's column of an image, 32 pixels; PB: P rounded up to even
   static constexpr int CP = 12;                               // channel pitch of a pixel in LDS (halves): 10 channels, the ones channel, one spare
-  static constexpr int MT = 4, NT = 4;                        // 16-row tiles of m = CP kx + c (60 -> 64), 16-column tiles of n = NO ky + o (50 -> 64)
-  static constexpr int ROWB = 880;                            // a plane of a staged input row: (W + 2 P) pixels x CP halves + the m over-read, bytes
+  static constexpr int MT = (KS * CP + 15) / 16, NT = (KS * NO + 15) / 16;      // 16-row tiles of m = CP kx + c, 16-column tiles of n = NO ky + o (5x5: 4 x 4; 3x3: 3 x 2)
+  static constexpr int ROWB = 2 * (((CP * (WC + KS - 1) + 16 * MT - KS * CP) + 7) & ~7);      // a plane of a staged input row: (WC + 2 P) pixels x CP halves + the m over-read, bytes
   static constexpr int XSLOT = 3 * ROWB;
   static constexpr int NXS = 2;                               // input rows in LDS: the one being multiplied, the one being written
   static constexpr int DOST = 80, DPC = NO * DOST, DSLOT = 3 * DPC;   // dZ row: [piece][o][4 lane groups x 16 bytes + skew]
-  static constexpr int NDS = 6;                               // dZ rows in LDS: 2 P + 1 in use, one being written
+  static constexpr int NDS = KS + 1;                          // dZ rows in LDS: 2 P + 1 in use, one being written
   static constexpr int WVB = NXS * XSLOT + NDS * DSLOT;       // per wave
   static constexpr int LDS_BYTES = 4 * WVB;
   static constexpr int NW = KS * KS * CIN * NO;
-  static_assert(WVB % 16 == 0 && WVB >= MT * NT * 4 * 64 * 4, "the wave's slots also hold its accumulators for the final sum");
+  static constexpr int UNR = KS == 5 ? 6 : 12;                // steps per unrolled block: a multiple of NDS (slots), 2 (input slots) and 6 (three pooled rows in flight)
+  static_assert(KS == 5 || KS == 3, "5x5 (conv2) or 3x3 (conv3)");
+  static_assert(ROWB % 16 == 0 && WVB % 16 == 0 && WVB >= MT * NT * 4 * 64 * 4, "the wave's slots also hold its accumulators for the final sum");
 };
 
 // units = (image, band of `band` input rows, 32-pixel column); unit u of the launch's network `by` is wave (u % 4) of workgroup u / 4;
 // units_per_img = bands x columns, column fastest.
-template <int ORDER>
+template <int KSZ, int ORDER>
 __device__ __forceinline__ void conv_dw_rs_body(const ConvArgsN& batch, const int units_per_img, const int band, const int bx, const int by) {
-  typedef DwRsGeom G;
-  constexpr int KS = G::KS, P = G::P, CIN = G::CIN, NO = G::NO, WC = G::WC, CP = G::CP, MT = G::MT, NT = G::NT;
+  typedef DwRsGeom<KSZ> G;
+  constexpr int KS = G::KS, P = G::P, PB = G::PB, CIN = G::CIN, NO = G::NO, WC = G::WC, CP = G::CP, MT = G::MT, NT = G::NT;
   constexpr int ROWB = G::ROWB, XSLOT = G::XSLOT, DOST = G::DOST, DPC = G::DPC, DSLOT = G::DSLOT, NDS = G::NDS;
   constexpr unsigned BIG = 0x08000000u;
   const ConvArgs& a = batch.a[by];
@@ -53,7 +56,7 @@ __device__ __forceinline__ void conv_dw_rs_body(const ConvArgsN& batch, const in
   unsigned char* wvb = dwrs_lds + swave * G::WVB;
   unsigned char* xring = wvb;                                 // [NXS][3 planes][ROWB]
   unsigned char* dzring = wvb + G::NXS * XSLOT;               // [NDS][3 pieces][NO][DOST]
-  const int H = a.H, Hp = H >> 1, W = a.W, Wp = W >> 1, ncol = W / WC;
+  const int H = a.H, Hp = H >> 1, W = a.W, Wp = W >> 1, ncol = (W + WC - 1) / WC;
   const int units = a.B * units_per_img;
   const int unit = bx * 4 + swave;
   const bool work = unit < units;
@@ -62,7 +65,7 @@ __device__ __forceinline__ void conv_dw_rs_body(const ConvArgsN& batch, const in
   const int x0 = work ? (uin % ncol) * WC : 0;               // the unit's pixels: x0 .. x0 + 31
   const int q_lo = work ? (uin / ncol) * band : 0;
   const int rows = work ? min(band, H - q_lo) : 0;            // (band and q_lo are even)
-  const int y0 = q_lo - P;                                    // dZ row of ring position 0
+  const int y0 = q_lo - PB;                                   // dZ row of ring position 0 (even: a pooled row's first)
 
   // ---- the wave's slots: zero; the ones channel (first plane, channel CIN = bf16 1.0) of the in-image pixels of both input slots
   for (int i = lane; i < G::WVB / 16; i += 64) reinterpret_cast<k16_u32x4*>(wvb)[i] = (k16_u32x4){0u, 0u, 0u, 0u};
@@ -108,7 +111,7 @@ __device__ __forceinline__ void conv_dw_rs_body(const ConvArgsN& batch, const in
   // ---- dZ rows: lane l < 40 owns channel o = l % 10 of lane group g = l / 10: the 16 bytes one lane of the B operand reads -- pixels
   // 16 (g & 1) + 2 (g >> 1) + 4 j + r, i.e. both pixels of the pooled cells px_j = 8 (g & 1) + (g >> 1) + 2 j, j = 0 .. 3
   const int zg = lane / NO, zo = lane - zg * NO;
-  const bool zon = lane < 4 * NO;
+  const bool zon = lane < 4 * NO && x0 / 2 + 8 * (zg & 1) + (zg >> 1) + 6 < Wp;      // (16-wide rows: the second half of the chunk is padding)
   const __amdgpu_buffer_rsrc_t dp_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy.dpool + (long)ub * a.dy.dpool_bstride), 0,
                                                                            work ? Hp * Wp * NO * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t am_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.dy.amax + (long)ub * Hp * Wp * NO), 0,
@@ -159,7 +162,7 @@ __device__ __forceinline__ void conv_dw_rs_body(const ConvArgsN& batch, const in
   // ---- MFMA operands (pixel dealing and transpose reads as conv_dw16.h / conv_dwb16.h)
   const int tj = (lane >> 2) & 3, tq = lane & 3;
   const uint32_t aadr = keep_in_vgpr(lds_addr(xring + 2 * (CP * (16 * (lj & 1) + 4 * tj + 2 * (lj >> 1)) + 4 * tq)));
-  // column n = 16 nt + li = NO ky + o reads dZ ring position t - ky + 2 P at input row t of the band: slot (sq - ky + 2 P) mod NDS
+  // column n = 16 nt + li = NO ky + o reads dZ ring position t - ky + P + PB at input row t of the band: slot (sq - ky + P + PB) mod NDS
   uint32_t bbase[NT]; int bky[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -175,13 +178,15 @@ __device__ __forceinline__ void conv_dw_rs_body(const ConvArgsN& batch, const in
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   if (work) {
-    // ---- prologue: dZ ring positions 0 .. 2 P (rows y0 .. y0 + 4: pooled rows y0 / 2 .. y0 / 2 + 2), input row q_lo; two more of each in flight
+    // ---- prologue: dZ ring positions 0 .. PB + P (rows y0 ..: pooled rows y0 / 2 ..), input row q_lo; two more of each in flight
     const int py0 = y0 >> 1;                                  // (y0 is even; -1 for the first band: zeros)
     z_load(0, py0); z_load(1, py0 + 1); z_load(2, py0 + 2);
     x_load(0, q_lo); x_load(1, q_lo + 1);
-    z_convert(0); z_store(0, 0); z_store(1, 1);
-    z_convert(1); z_store(2, 0); z_store(3, 1);
-    z_convert(2); z_store(4, 0);                              // (position 5, the same pooled row, is stored by the first step)
+#pragma unroll
+    for (int d = 0; d <= PB + P; ++d) {                       // (the position behind the last one is stored by the first step)
+      if ((d & 1) == 0) z_convert((d / 2) % 3);
+      z_store(d % NDS, d & 1);
+    }
     z_load(0, py0 + 3); z_load(1, py0 + 4);
     x_store(0, 0);
     x_load(0, q_lo + 2);
@@ -197,7 +202,7 @@ __device__ __forceinline__ void conv_dw_rs_body(const ConvArgsN& batch, const in
     k16_u32x4 bq[NT][3];
     k16_u32x4 av[3];
     auto b_load = [&](const int sq, const int nt) __attribute__((always_inline)) {      // column tile nt's operands for the step with t mod 6 = sq
-      int sl = sq + 2 * P - bky[nt]; sl = sl >= NDS ? sl - NDS : sl;                     // slot of this lane's column: ky differs per lane
+      int sl = (sq + PB + P) % NDS - bky[nt]; sl = sl < 0 ? sl + NDS : sl;               // slot of this lane's column: ky differs per lane
       const uint32_t ad = bbase[nt] + (uint32_t)(sl * DSLOT);
 #pragma unroll
       for (int p = 0; p < 3; ++p) bq[nt][p] = lds_load<k16_u32x4>(ad, p * DPC);
@@ -214,16 +219,41 @@ __device__ __forceinline__ void conv_dw_rs_body(const ConvArgsN& batch, const in
         dst[pa] = (k16_u32x4){u0.x, u0.y, u1.x, u1.y};
       }
     };
-    b_load(0, 0); b_load(0, 1);
-    a_load(av, 0, 0);
+    if constexpr (KS == 5) { b_load(0, 0); b_load(0, 1); a_load(av, 0, 0); }
     __builtin_amdgcn_sched_barrier(0);
     auto step = [&](auto sqtag, const int t) __attribute__((always_inline)) {
       constexpr int SQ = decltype(sqtag)::value;
       constexpr int XS = SQ & 1;
-      constexpr int ZPOS = SQ + 2 * P + 1;                    // ring position being written (mod: 6 rows = three pooled rows)
+      constexpr int ZPOS = SQ + PB + P + 1;                   // ring position being written (mod: 6 rows = three pooled rows)
       constexpr bool ZODD = (ZPOS & 1) != 0;                  // its image-row parity ry (y0 is even)
       constexpr int ZBUF = (ZPOS / 2) % 3;
       constexpr int NPROD = ORDER == B16_NINE ? 9 : 6;
+      if constexpr (KS == 3) {
+        // 3x3 (conv3): 36 MFMAs a row against the same staging work -- the row is bound by that work whatever the order; plain sequence
+        // (bq / av requested at the top: the previous step left nothing in flight)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b_load(SQ, nt);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          a_load(av, XS, mt);
+#pragma unroll
+          for (int sum = ORDER; sum >= 0; --sum)
+#pragma unroll
+            for (int pa = 2; pa >= 0; --pa) {
+              const int pb = sum - pa;
+              if (pb >= 0 && pb <= 2) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dwb_bf16x8, av[pa]), __builtin_bit_cast(dwb_bf16x8, bq[nt][pb]),
+                                                                        acc[mt][nt], 0, 0, 0);
+              }
+            }
+          if (mt == 0) { if (!ZODD) z_convert(ZBUF); }
+          else if (mt == 1) { z_store(ZPOS % NDS, ZODD ? 1 : 0); if (ZODD) z_load(ZBUF, py0 + (t + PB + P + 1) / 2 + 3); }
+          else { x_store((SQ + 1) & 1, XS ^ 1); x_load((SQ + 1) & 1, q_lo + t + 3); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
 #pragma unroll
       for (int blk = 0; blk < 8; ++blk) {
         const int hs = blk >> 2, mt = blk & 3;
@@ -246,11 +276,11 @@ __device__ __forceinline__ void conv_dw_rs_body(const ConvArgsN& batch, const in
         if (blk == 0) { b_load(SQ, 2); if (!ZODD) z_convert_half(ZBUF, 0); }
         else if (blk == 1) { b_load(SQ, 3); if (!ZODD) z_convert_half(ZBUF, 1); }
         else if (blk == 2) z_store(ZPOS % NDS, ZODD ? 1 : 0);
-        else if (blk == 3) { if (ZODD) z_load(ZBUF, py0 + (t + 2 * P + 1) / 2 + 3); x_store1((SQ + 1) & 1, XS ^ 1, 0); }
+        else if (blk == 3) { if (ZODD) z_load(ZBUF, py0 + (t + PB + P + 1) / 2 + 3); x_store1((SQ + 1) & 1, XS ^ 1, 0); }
         else if (blk == 4) x_store1((SQ + 1) & 1, XS ^ 1, 1);
         else if (blk == 5) x_store1((SQ + 1) & 1, XS ^ 1, 2);
-        else if (blk == 6) { x_load((SQ + 1) & 1, q_lo + t + 3); b_load((SQ + 1) % 6, 0); }
-        else b_load((SQ + 1) % 6, 1);
+        else if (blk == 6) { x_load((SQ + 1) & 1, q_lo + t + 3); b_load((SQ + 1) % G::UNR, 0); }
+        else b_load((SQ + 1) % G::UNR, 1);
 #if DWRS_INTERLEAVE
 #pragma unroll
         for (int i = 0; i < 2 * NPROD; ++i) {
@@ -267,14 +297,23 @@ __device__ __forceinline__ void conv_dw_rs_body(const ConvArgsN& batch, const in
 #pragma unroll
         for (int pa = 0; pa < 3; ++pa) av[pa] = an[pa];
       }
+      }
     };
-    for (int t0 = 0; t0 < rows; t0 += 6) {
+    for (int t0 = 0; t0 < rows; t0 += G::UNR) {
       if (t0 + 0 < rows) step(std::integral_constant<int, 0>{}, t0 + 0);
       if (t0 + 1 < rows) step(std::integral_constant<int, 1>{}, t0 + 1);
       if (t0 + 2 < rows) step(std::integral_constant<int, 2>{}, t0 + 2);
       if (t0 + 3 < rows) step(std::integral_constant<int, 3>{}, t0 + 3);
       if (t0 + 4 < rows) step(std::integral_constant<int, 4>{}, t0 + 4);
       if (t0 + 5 < rows) step(std::integral_constant<int, 5>{}, t0 + 5);
+      if constexpr (G::UNR == 12) {
+        if (t0 + 6 < rows) step(std::integral_constant<int, 6>{}, t0 + 6);
+        if (t0 + 7 < rows) step(std::integral_constant<int, 7>{}, t0 + 7);
+        if (t0 + 8 < rows) step(std::integral_constant<int, 8>{}, t0 + 8);
+        if (t0 + 9 < rows) step(std::integral_constant<int, 9>{}, t0 + 9);
+        if (t0 + 10 < rows) step(std::integral_constant<int, 10>{}, t0 + 10);
+        if (t0 + 11 < rows) step(std::integral_constant<int, 11>{}, t0 + 11);
+      }
     }
   }
 
@@ -287,36 +326,35 @@ __device__ __forceinline__ void conv_dw_rs_body(const ConvArgsN& batch, const in
       *reinterpret_cast<f32x4*>(mine + ((mt * NT + nt) * 64 + lane) * 4) = acc[mt][nt];
   __syncthreads();
   float* part = a.partial + (long)bx * a.pstride;
-  {
-    const int nt = swave;                                     // wave w writes column tile w
+#pragma unroll
+  for (int tile = 0; tile < MT * NT; ++tile) {
+    if ((tile & 3) != swave) continue;                        // (wave-uniform: tile i is wave i mod 4's)
+    const int mt = tile / NT, nt = tile - mt * NT;
     const int n = 16 * nt + li;
     const bool nvalid = n < KS * NO;
     const int nky = nvalid ? n / NO : 0, no = nvalid ? n % NO : 0;
+    f32x4 s = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(dwrs_lds) + (tile * 64 + lane) * 4);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      f32x4 s = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(dwrs_lds) + ((mt * NT + nt) * 64 + lane) * 4);
+    for (int v = 1; v < 4; ++v) {
+      const f32x4 o = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(dwrs_lds + v * G::WVB) + (tile * 64 + lane) * 4);
+      s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
+    }
+    if (nvalid && no < a.nout) {
 #pragma unroll
-      for (int v = 1; v < 4; ++v) {
-        const f32x4 o = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(dwrs_lds + v * G::WVB) + ((mt * NT + nt) * 64 + lane) * 4);
-        s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
-      }
-      if (nvalid && no < a.nout) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = 16 * mt + 4 * lj + r;
-          const int kx = m / CP, c = m - kx * CP;
-          if (kx < KS && c < CIN) part[(nky * (KS * CIN) + kx * CIN + c) * a.nout + no] = s[r];
-          else if (kx == P && c == CIN && nky == P) part[G::NW / NO * a.nout + no] = s[r];      // the ones channel x the centre tap: sum of dZ = db
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int m = 16 * mt + 4 * lj + r;
+        const int kx = m / CP, c = m - kx * CP;
+        if (kx < KS && c < CIN) part[(nky * (KS * CIN) + kx * CIN + c) * a.nout + no] = s[r];
+        else if (kx == P && c == CIN && nky == P) part[G::NW / NO * a.nout + no] = s[r];      // the ones channel x the centre tap: sum of dZ = db
       }
     }
   }
 }
 
-template <int ORDER>
+template <int KSZ, int ORDER>
 __global__ __launch_bounds__(CONV_THREADS, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_dw_rs_kernel(const ConvArgsN batch, int units_per_img, int band) {
-  conv_dw_rs_body<ORDER>(batch, units_per_img, band, blockIdx.x, blockIdx.y);
+  conv_dw_rs_body<KSZ, ORDER>(batch, units_per_img, band, blockIdx.x, blockIdx.y);
 }
 
-// conv2's dW at 32-wide inputs, 10 -> 10 channels, 5x5, pooled dZ (no batch norm)
+// conv2's (5x5, rows of 32 / 64 pixels) and conv3's (3x3, rows of 16 / 32 / 64) dW, 10 -> 10 channels, pooled dZ (no batch norm)
 int conv_dw_rs_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArgsN& a, int* grid, bool* handled);
