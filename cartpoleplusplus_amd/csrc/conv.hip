@@ -136,7 +136,7 @@ int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, i
     rc = conv_fwd_kb16_dispatch(ctx, cin, ks, in_mode, batch, &handled);
     if (handled) { prof_end(ctx, kid); return rc; }
   }
-  if (!no_kyo && in_mode == IN_DY && ks == 5) {      // conv2's dX on the bf16 pipes, row-streaming (conv_dx_rs.h)
+  if (!no_kyo && in_mode == IN_DY) {      // conv2's / conv3's dX on the bf16 pipes, row-streaming (conv_dx_rs.h)
     bool handled = false;
     rc = conv_dx_rs_dispatch(ctx, cin, ks, in_mode, batch, &handled);
     if (handled) { prof_end(ctx, kid); return rc; }

@@ -23,7 +23,7 @@ template <int ORDER, bool DWRS>
 __global__ __launch_bounds__(CONV_THREADS, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv2_bwd_pair_rs_kernel(const ConvArgsN dx, int dx_gx, const ConvArgsN dw, int dw_gx, int upi, int band, int order) {
   int i;
   if (!pair_grid_place((int)blockIdx.x, dx_gx * dx.n, dw_gx * dw.n, order, &i)) {
-    conv_dx_rs_body<2, ORDER>(dx, i % dx_gx, i / dx_gx);
+    conv_dx_rs_body<5, 2, ORDER>(dx, i % dx_gx, i / dx_gx);
   } else {
     if (DWRS) conv_dw_rs_body<5, ORDER>(dw, upi, band, i % dw_gx, i / dw_gx);
     else conv_dwb16_body<10, 5, 1, ORDER>(dw, upi, band, i % dw_gx, i / dw_gx, dw_gx);

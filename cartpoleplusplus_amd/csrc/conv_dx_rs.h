@@ -27,25 +27,28 @@ typedef unsigned dxrs_u32x2 __attribute__((ext_vector_type(2)));
 #define DXRS_INTERLEAVE 1
 #endif
 
-template <int TPR>                                           // tiles per row: W = 16 TPR
+template <int KS_, int TPR>                                  // kernel size (5: conv2, 3: conv3); tiles per row: W = 16 TPR
 struct DxRsGeom {
-  static constexpr int KS = 5, P = 2, CH = KYO_NO, NCH = 2, NSET = KS + 1;
+  static constexpr int KS = KS_, P = KS / 2, CH = KYO_NO, NCH = (KS * CH + 31) / 32, NSET = KS + 1;
+  static constexpr int UNR = KS == 5 ? 6 : 12;                // steps per unrolled block: a multiple of NSET (sets), 2 (slots) and 6 (three pooled rows in flight)
   static constexpr int W = 16 * TPR, IPW = 4 / TPR;           // images per workgroup
   static constexpr int NW = KS * KS * CH * CH;                // the layer's weights
   static constexpr int AIMG_BYTES = KS * NCH * 3 * 1024;      // the A operands: one KB (64 lanes x 16 bytes) per (ky', chunk, piece)
-  static constexpr int PLB = 448;                             // a staged plane: 20 pixels x 10 channels bf16 = 400 bytes + the over-read of chunk 1 (to 428)
+  static constexpr int WPX = 16 + 2 * P;                      // pixels of a staged row: the tile and P on each side
+  // a staged plane: WPX pixels x 10 channels bf16 + the over-read of the last chunk's windows (5x5: 400 -> 428 bytes; 3x3: 360 -> 364)
+  static constexpr int PLB = ((2 * CH * 15 + 64 * (NCH - 1) + 64 + 15) & ~15) + 16;
   static constexpr int SLOTB = 3 * PLB;
   static constexpr int TRB = 640 + 16;                        // an output row of the tile on its way out (16 px x 10 ch f32) + a dump slot
   static constexpr int WVB = 2 * SLOTB + TRB;                 // per wave: two staged rows + the output row
   static constexpr int LDS_BYTES = AIMG_BYTES + 4 * WVB;
-  static_assert(4 % TPR == 0 && WVB % 16 == 0, "geometry");
+  static_assert((KS == 5 || KS == 3) && 4 % TPR == 0 && WVB % 16 == 0 && PLB >= 2 * CH * WPX + 8, "geometry");
 };
 
 // ORDER: B16_SIX / B16_NINE (the largest i + j of the piece products A_i B_j still issued: conv_k16.h)
-template <int TPR, int ORDER>
+template <int KSZ, int TPR, int ORDER>
 __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const int bx, const int by) {
-  typedef DxRsGeom<TPR> G;
-  constexpr int KS = G::KS, P = G::P, CH = G::CH, NCH = G::NCH, NSET = G::NSET, W = G::W, Wp = W / 2;
+  typedef DxRsGeom<KSZ, TPR> G;
+  constexpr int KS = G::KS, P = G::P, CH = G::CH, NCH = G::NCH, NSET = G::NSET, UNR = G::UNR, W = G::W, Wp = W / 2;
   constexpr int PLB = G::PLB, SLOTB = G::SLOTB;
   const ConvArgs& a = batch.a[by];
 #ifdef DXRS_CLOCK_PROBE
@@ -63,7 +66,7 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
   const int sb = (bx / nbands) * G::IPW + simg;
   const int H = a.H, Hp = H >> 1;
   const int ylo = nbands > 1 ? band * a.band_rows : 0, yhi = nbands > 1 ? min(H, ylo + a.band_rows) : H;
-  const int qbeg = ((ylo > P ? ylo - P : 0) / NSET) * NSET;   // first dZ row walked
+  const int qbeg = ((ylo > P ? ylo - P : 0) / UNR) * UNR;     // first dZ row walked
   const int qmf = min(H, yhi + P);                            // one past the last dZ row that reaches the band
   unsigned char* wvb = dxrs_lds + G::AIMG_BYTES + swave * G::WVB;
   // ---- dZ rows: lane l < 50 owns the channel pair (2 op, 2 op + 1) of pooled cell cw of the tile's window (pooled pixels 8 stile - 1 ..
@@ -78,8 +81,12 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
                                                                            Hp * Wp * CH, 0x00020000);
   const unsigned goff = cell ? (unsigned)((ppx * CH + 2 * op) * 4) : BIG;
   const unsigned coff = cell ? (unsigned)(ppx * CH + 2 * op) : BIG;
-  // (lanes without a cell hold zeros and write them into the first plane's tail)
-  const uint32_t sadr = keep_in_vgpr(lds_addr(wvb + (lane < 50 ? 4 * CH * cw + 4 * op : 424)));
+  // the cell's two pixels in the staged row (which starts at pixel 16 stile - P): 2 cw - 2 + P and the next one; 3x3: the first cell's even
+  // and the last cell's odd pixel lie outside it.  (Those, and the lanes without a cell -- which hold zeros --, write into the first plane's tail.)
+  constexpr int DUMP = PLB - 8;
+  const int pe = 2 * cw - 2 + P, po = pe + 1;
+  const uint32_t sadr_e = keep_in_vgpr(lds_addr(wvb + ((lane < 50 && pe >= 0 && pe < G::WPX) ? 2 * CH * pe + 4 * op : DUMP)));
+  const uint32_t sadr_o = keep_in_vgpr(lds_addr(wvb + ((lane < 50 && po >= 0 && po < G::WPX) ? 2 * CH * po + 4 * op : DUMP)));
   // three pooled rows in flight (a block of NSET = 6 steps walks three of them: buffer = pooled row mod 3, a compile-time number): a
   // row is requested two steps before its conversion -- requested one step ahead, every second step opened with a wait for the round trip
   f32x2 rawg[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
@@ -147,13 +154,13 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
   auto stage_row = [&](const int slot, const int ry) __attribute__((always_inline)) {      // dZ row 2 py + ry of the pooled row in pk / mk
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-      lds_store(sadr, slot * SLOTB + p * PLB, pk[p] & mk[ry][0]);
-      lds_store(sadr, slot * SLOTB + p * PLB + 2 * CH, pk[p] & mk[ry][1]);
+      lds_store(sadr_e, slot * SLOTB + p * PLB, pk[p] & mk[ry][0]);
+      lds_store(sadr_o, slot * SLOTB + p * PLB, pk[p] & mk[ry][1]);
     }
   };
   // operand windows: pixel li of the tile, taps kx' = 0 .. 4 -> staged pixels li .. li + 4; 8 consecutive k = 16 bytes at 20 li + 64 ch + 16 lj
   const uint32_t xrd = keep_in_vgpr(lds_addr(wvb + 2 * CH * li + 16 * lj));
-  k16_u32x4 xb[2][3];
+  k16_u32x4 xb[NCH][3];
   auto read_x = [&](const int ch, const int slot) __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
@@ -183,16 +190,16 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
   convert(0);
   stage_row(0, 0);
   read_x(0, 0);
-  read_x(1, 0);
+  if (NCH > 1) read_x(NCH - 1, 0);
   __builtin_amdgcn_sched_barrier(0);
 
   auto step = [&](auto sqtag, auto gentag, const int q) __attribute__((always_inline)) {
     constexpr int SQ = decltype(sqtag)::value;
     constexpr bool GEN = decltype(gentag)::value;
-    constexpr int SD = (SQ + 3) % NSET;                      // the set of output row q - 3: complete since the last step
+    constexpr int SD = (SQ + 2 * NSET - P - 1) % NSET;       // the set of output row q - P - 1: complete since the last step
     constexpr int SLOT = SQ & 1;                             // the LDS slot of dZ row q (q0 is a multiple of NSET = 6)
     constexpr bool EVEN = (SQ & 1) == 0;
-    const int yd = q - 3;
+    const int yd = q - P - 1;
     auto epi_write = [&]() __attribute__((always_inline)) {
       lds_store(twA, 0, (f32x2){acc[SD][0], acc[SD][1]});
       lds_store(twB, 0, (f32x2){acc[SD][2], acc[SD][3]});
@@ -213,7 +220,7 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
           if (pb >= 0 && pb <= 2) {
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky) {
-              const int s = (SQ + 2 - ky + NSET) % NSET;     // output row q + 2 - ky
+              const int s = (SQ + P - ky + NSET) % NSET;     // output row q + P - ky
               const bool restart = ch == 0 && sum == ORDER && pa == 2 && ky == 0;      // (the set output row q + 2 starts in)
               acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(k16_bf16x8, wv[ky][ch][pa]), __builtin_bit_cast(k16_bf16x8, xb[ch][pb]),
                                                                restart ? zero4 : acc[s], 0, 0, 0);
@@ -221,7 +228,7 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
           }
         }
     };
-    constexpr int J = SQ / 2;                                // pooled row q / 2 mod 3
+    constexpr int J = (SQ / 2) % 3;                          // pooled row q / 2 mod 3
     if (!GEN || q < qmf) {
       // One wave per SIMD (1024 tiles at cfg3): nobody else issues while this wave prepares the next row, so the preparation is dealt
       // out BETWEEN the MFMAs -- the matrix pipe takes a 16x16x32 every 16 cycles, the wave can issue two or three other instructions in
@@ -229,6 +236,17 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
       // Chunk 0's MFMAs carry dZ row q + 1 into LDS, the finished output row into its LDS slot and row q + 1's first operand windows out;
       // chunk 1's carry the conversion of the next pooled row (even steps), the output row's store and the second windows.
       constexpr int NMF = (ORDER == B16_NINE ? 9 : 6) * KS;  // MFMAs of a chunk
+      if constexpr (NCH == 1) {
+        // 3x3 (conv3): one chunk, 18 MFMAs a row -- the row is the staging work (the same as 5x5's) with the MFMAs in its shadow
+        mfmas(std::integral_constant<int, 0>{});
+        stage_row(SLOT ^ 1, EVEN ? 1 : 0);
+        if (EVEN) load_pooled((J + 2) % 3, (q >> 1) + 2);
+        epi_write();
+        read_x(0, SLOT ^ 1);
+        epi_store();
+        if (EVEN) convert((J + 1) % 3);
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
       mfmas(std::integral_constant<int, 0>{});
       stage_row(SLOT ^ 1, EVEN ? 1 : 0);                     // dZ row q + 1 (pooled row (q + 1) / 2: converted under the last even step)
       if (EVEN) load_pooled((J + 2) % 3, (q >> 1) + 2);      // (behind the last row: beyond the descriptors' range, zeros)
@@ -260,21 +278,31 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);
+      }
     } else { epi_write(); epi_store(); }                     // (steps behind the image: the last output rows)
   };
   auto block = [&](auto gentag, const int q0) __attribute__((always_inline)) {
     constexpr bool GEN = decltype(gentag)::value;
-    if (GEN && q0 + 0 >= yhi + 3) return; step(std::integral_constant<int, 0>{}, gentag, q0 + 0);
-    if (GEN && q0 + 1 >= yhi + 3) return; step(std::integral_constant<int, 1>{}, gentag, q0 + 1);
-    if (GEN && q0 + 2 >= yhi + 3) return; step(std::integral_constant<int, 2>{}, gentag, q0 + 2);
-    if (GEN && q0 + 3 >= yhi + 3) return; step(std::integral_constant<int, 3>{}, gentag, q0 + 3);
-    if (GEN && q0 + 4 >= yhi + 3) return; step(std::integral_constant<int, 4>{}, gentag, q0 + 4);
-    if (GEN && q0 + 5 >= yhi + 3) return; step(std::integral_constant<int, 5>{}, gentag, q0 + 5);
+    const int qe = yhi + P + 1;                              // one past the last step: output row yhi - 1 leaves at step yhi + P
+    if (GEN && q0 + 0 >= qe) return; step(std::integral_constant<int, 0>{}, gentag, q0 + 0);
+    if (GEN && q0 + 1 >= qe) return; step(std::integral_constant<int, 1>{}, gentag, q0 + 1);
+    if (GEN && q0 + 2 >= qe) return; step(std::integral_constant<int, 2>{}, gentag, q0 + 2);
+    if (GEN && q0 + 3 >= qe) return; step(std::integral_constant<int, 3>{}, gentag, q0 + 3);
+    if (GEN && q0 + 4 >= qe) return; step(std::integral_constant<int, 4>{}, gentag, q0 + 4);
+    if (GEN && q0 + 5 >= qe) return; step(std::integral_constant<int, 5>{}, gentag, q0 + 5);
+    if constexpr (UNR == 12) {
+      if (GEN && q0 + 6 >= qe) return; step(std::integral_constant<int, 6>{}, gentag, q0 + 6);
+      if (GEN && q0 + 7 >= qe) return; step(std::integral_constant<int, 7>{}, gentag, q0 + 7);
+      if (GEN && q0 + 8 >= qe) return; step(std::integral_constant<int, 8>{}, gentag, q0 + 8);
+      if (GEN && q0 + 9 >= qe) return; step(std::integral_constant<int, 9>{}, gentag, q0 + 9);
+      if (GEN && q0 + 10 >= qe) return; step(std::integral_constant<int, 10>{}, gentag, q0 + 10);
+      if (GEN && q0 + 11 >= qe) return; step(std::integral_constant<int, 11>{}, gentag, q0 + 11);
+    }
   };
   int q0 = qbeg;
-  block(std::true_type{}, q0); q0 += NSET;
-  for (; q0 >= ylo + 3 && q0 + NSET <= qmf; q0 += NSET) block(std::false_type{}, q0);      // (every step multiplies and stores a row of the band)
-  for (; q0 < yhi + 3; q0 += NSET) block(std::true_type{}, q0);
+  block(std::true_type{}, q0); q0 += UNR;
+  for (; q0 >= ylo + P + 1 && q0 + UNR <= qmf; q0 += UNR) block(std::false_type{}, q0);      // (every step multiplies and stores a row of the band)
+  for (; q0 < yhi + P + 1; q0 += UNR) block(std::true_type{}, q0);
 #ifdef DXRS_CLOCK_PROBE
   if (lane == 0 && swave == 0) {
     const unsigned long long pc1 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
@@ -286,11 +314,11 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
 #endif
 }
 
-template <int TPR, int ORDER>
+template <int KSZ, int TPR, int ORDER>
 __global__ __launch_bounds__(CONV_THREADS, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_dx_rs_kernel(const ConvArgsN batch) {
-  conv_dx_rs_body<TPR, ORDER>(batch, blockIdx.x, blockIdx.y);
+  conv_dx_rs_body<KSZ, TPR, ORDER>(batch, blockIdx.x, blockIdx.y);
 }
 
-// conv2's dX (IN_DY: pooled gradient + codes in, plain rows out) at 32- and 64-wide inputs, 10 -> 10 channels, 5x5
+// conv2's (5x5; 32- and 64-wide rows) and conv3's (3x3; 16-, 32- and 64-wide) dX: IN_DY (pooled gradient + codes in, plain rows out), 10 -> 10 channels
 int conv_dx_rs_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArgsN& a, bool* handled);
 bool conv_dx_rs_ok(const cpp_ctx* ctx, int cin, int ks, int H, int W, int nout);

@@ -2,11 +2,11 @@
 #include <cstring>
 #include "conv_dx_rs.h"
 
-template <int TPR, int ORDER>
+template <int KS, int TPR, int ORDER>
 static int conv_dx_rs_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
-  typedef DxRsGeom<TPR> G;
+  typedef DxRsGeom<KS, TPR> G;
   const ConvArgs& a = batch.a[0];
-  auto kern = conv_dx_rs_kernel<TPR, ORDER>;
+  auto kern = conv_dx_rs_kernel<KS, TPR, ORDER>;
   static bool attr_done[CPP_MAX_DEVICES] = {};
   if (!attr_done[cpp_dev_slot(ctx)]) {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
@@ -21,7 +21,11 @@ static int conv_dx_rs_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
 bool conv_dx_rs_ok(const cpp_ctx* ctx, int cin, int ks, int H, int W, int nout) {
   static const bool off = cpp_switch_off("CPP_CONV_DXRS") || cpp_switch_off("CPP_CONV_B16");
   (void)ctx;
-  return !off && cin == KYO_NO && nout == KYO_NO && ks == 5 && (W == 32 || W == 64) && H >= 4 && !(H & 1);
+  static const bool off3 = cpp_switch_off("CPP_CONV3_DXRS");
+  // (16-wide rows -- conv3 at 64x64 images -- would leave conv3_bwd_pair.hip's launch for one of their own: CPP_CONV3_DXRS_W16=1, ablation build)
+  static const bool w16 = cpp_switch_int("CPP_CONV3_DXRS_W16", 0) != 0;
+  const bool geo = (ks == 5 && (W == 32 || W == 64)) || (ks == 3 && !off3 && ((W == 16 && w16) || W == 32 || W == 64));
+  return !off && cin == KYO_NO && nout == KYO_NO && geo && H >= 4 && !(H & 1);
 }
 
 int conv_dx_rs_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArgsN& a_in, bool* handled) {
@@ -33,7 +37,7 @@ int conv_dx_rs_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvAr
   ConvArgsN a = a_in;
   {  // fewer workgroups than CUs: two bands of rows per image (CPP_DXRS_BANDS=0: whole images)
     static const int bands_sw = cpp_switch_int("CPP_DXRS_BANDS", 1);      // (ablation build: 0 never, 2 always)
-    const int ipw = a0.W == 32 ? 2 : 1;
+    const int ipw = a0.W == 16 ? 4 : (a0.W == 32 ? 2 : 1);
     const int wgs = a.n * ((a0.B + ipw - 1) / ipw);
     // (not beside conv2's dW: there the launch is bound by the two bodies' total work, and a second band walks up to NSET - 1 + 2 P rows
     // more per image -- cfg4 33.5 -> 35.5 us, cfg3 52.8 -> 57 us with bands, profiles/experiments/r05_dxrs_bands.sh)
@@ -41,11 +45,16 @@ int conv_dx_rs_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvAr
     const bool two = bands_sw != 0 && ((wgs < ctx->num_cus && !paired) || bands_sw == 2) && a0.H >= 16 && (a0.H % 4) == 0;
     for (int i = 0; i < a.n; ++i) { a.a[i].nbands = two ? 2 : 1; a.a[i].band_rows = two ? a0.H / 2 : a0.H; }
   }
-  if (ctx->pair && ctx->pair->layer == 1 && a0.W == 32) {     // leaves with conv2's dW (conv2_bwd_pair.hip)
-    ctx->pair->dx = a; ctx->pair->dx_gx = ((a0.B + 1) / 2) * a.a[0].nbands; ctx->pair->dx_lds = DxRsGeom<2>::LDS_BYTES; ctx->pair->have_dx = true;
+  if (ctx->pair && ctx->pair->layer == 1 && ks == 5 && a0.W == 32) {     // leaves with conv2's dW (conv2_bwd_pair.hip)
+    ctx->pair->dx = a; ctx->pair->dx_gx = ((a0.B + 1) / 2) * a.a[0].nbands; ctx->pair->dx_lds = DxRsGeom<5, 2>::LDS_BYTES; ctx->pair->have_dx = true;
     ctx->pair->dx_rs = true;
     return 0;
   }
-  if (a0.W == 32) return nine ? conv_dx_rs_launch_t<2, B16_NINE>(ctx, a) : conv_dx_rs_launch_t<2, B16_SIX>(ctx, a);
-  return nine ? conv_dx_rs_launch_t<4, B16_NINE>(ctx, a) : conv_dx_rs_launch_t<4, B16_SIX>(ctx, a);
+  if (ks == 3) {
+    if (a0.W == 16) return nine ? conv_dx_rs_launch_t<3, 1, B16_NINE>(ctx, a) : conv_dx_rs_launch_t<3, 1, B16_SIX>(ctx, a);
+    if (a0.W == 32) return nine ? conv_dx_rs_launch_t<3, 2, B16_NINE>(ctx, a) : conv_dx_rs_launch_t<3, 2, B16_SIX>(ctx, a);
+    return nine ? conv_dx_rs_launch_t<3, 4, B16_NINE>(ctx, a) : conv_dx_rs_launch_t<3, 4, B16_SIX>(ctx, a);
+  }
+  if (a0.W == 32) return nine ? conv_dx_rs_launch_t<5, 2, B16_NINE>(ctx, a) : conv_dx_rs_launch_t<5, 2, B16_SIX>(ctx, a);
+  return nine ? conv_dx_rs_launch_t<5, 4, B16_NINE>(ctx, a) : conv_dx_rs_launch_t<5, 4, B16_SIX>(ctx, a);
 }
