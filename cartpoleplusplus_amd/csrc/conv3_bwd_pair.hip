@@ -8,6 +8,8 @@
 #endif
 #include "conv_impl.h"
 #include "conv_kyo.h"
+#include "conv_dx_rs.h"
+#include "conv_dw_rs.h"
 
 __global__ __launch_bounds__(CONV_THREADS, 2) void conv3_bwd_pair_kernel(const ConvArgsN dx, int dx_gx, const ConvArgsN dw, int dw_gx, int order) {
   int i;
@@ -18,7 +20,36 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3_bwd_pair_kernel(const C
   }
 }
 
+// both halves on the bf16 pipes' row-streaming bodies (conv_dx_rs.h, conv_dw_rs.h; 16-wide rows)
+template <int ORDER>
+__global__ __launch_bounds__(CONV_THREADS, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3_bwd_pair_rs_kernel(const ConvArgsN dx, int dx_gx, const ConvArgsN dw, int dw_gx, int upi, int band, int order) {
+  int i;
+  if (!pair_grid_place((int)blockIdx.x, dx_gx * dx.n, dw_gx * dw.n, order, &i)) {
+    conv_dx_rs_body<3, 1, ORDER>(dx, i % dx_gx, i / dx_gx);
+  } else {
+    conv_dw_rs_body<3, ORDER>(dw, upi, band, i % dw_gx, i / dw_gx);
+  }
+}
+
 int launch_conv3_bwd_pair(cpp_ctx* ctx, const ConvPairSlot& slot) {
+  if ((slot.have_dx && slot.dx_rs) || (slot.have_dw && slot.dw_rs)) {
+    if (!(slot.have_dx && slot.dx_rs && slot.have_dw && slot.dw_rs)) { cpp_set_error("conv3 backward pair: only one half on the row-streaming bodies"); return 1; }
+    const bool nine = b16_order(ctx) == B16_NINE;
+    auto kern = nine ? conv3_bwd_pair_rs_kernel<B16_NINE> : conv3_bwd_pair_rs_kernel<B16_SIX>;
+    const size_t lds = slot.dx_lds > slot.dw_lds ? slot.dx_lds : slot.dw_lds;
+    static bool attr_done[CPP_MAX_DEVICES][2] = {};
+    if (!attr_done[cpp_dev_slot(ctx)][nine ? 1 : 0]) {
+      HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_done[cpp_dev_slot(ctx)][nine ? 1 : 0] = true;
+    }
+    static const int order = cpp_switch_int("CPP_PAIR3_ORDER", 1);
+    prof_begin(ctx);
+    hipLaunchKernelGGL(kern, dim3(slot.dx_gx * slot.dx.n + slot.dw_gx * slot.dw.n), dim3(CONV_THREADS), lds, ctx->stream, slot.dx, slot.dx_gx, slot.dw, slot.dw_gx,
+                       slot.upi, slot.band, order);
+    LAUNCH_CHECK();
+    prof_end(ctx, K_CONV3_BWD);
+    return 0;
+  }
   const int ndx = slot.have_dx ? slot.dx_gx * slot.dx.n : 0, ndw = slot.have_dw ? slot.dw_gx * slot.dw.n : 0;
   if (ndx + ndw == 0) return 0;
   const size_t lds = (slot.have_dx ? slot.dx_lds : 0) > (slot.have_dw ? slot.dw_lds : 0) ? slot.dx_lds : slot.dw_lds;

@@ -9,7 +9,7 @@ int conv_dw_rs_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvAr
   static const bool off3 = cpp_switch_off("CPP_CONV3_DWRS");
   // (16-wide rows -- conv3 at 64x64 images -- fill half of the 32-pixel chunk and would leave conv3_bwd_pair.hip's launch for one of their own)
   static const bool w16 = cpp_switch_int("CPP_CONV3_DWRS_W16", 0) != 0;
-  const bool geo5 = ks == 5 && (a.W == 32 || a.W == 64), geo3 = ks == 3 && !off3 && ((a.W == 16 && w16) || a.W == 32 || a.W == 64);
+  const bool geo5 = ks == 5 && (a.W == 32 || a.W == 64), geo3 = ks == 3 && !off3 && ((a.W == 16 && (w16 || conv3_pair_rs_ok(ctx, a.H, a.W))) || a.W == 32 || a.W == 64);
   if (off || !(geo5 || geo3) || cin != KYO_NO || in_mode != IN_F32_PLAIN || (a.H & 1) || a.H < 8 || a.nout != KYO_NO) return 0;
   for (int i = 0; i < batch.n; ++i)
     if (batch.a[i].dy_dense != nullptr || ((uintptr_t)batch.a[i].in & 7) || (batch.a[i].in_bstride & 1)) return 0;
@@ -25,6 +25,11 @@ int conv_dw_rs_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvAr
   const bool nine = b16_order(ctx) == B16_NINE;
   if (ctx->pair && ctx->pair->layer == 1 && ks == 5 && a.W == 32) {      // leaves with conv2's dX (conv2_bwd_pair.hip)
     ctx->pair->dw = batch; ctx->pair->dw_gx = grid; ctx->pair->dw_lds = DwRsGeom<5>::LDS_BYTES; ctx->pair->have_dw = true;
+    ctx->pair->upi = upi; ctx->pair->band = band; ctx->pair->dw_rs = true;
+    return 0;
+  }
+  if (ks == 3 && conv3_pair_rs_ok(ctx, a.H, a.W)) {             // leaves with conv3's dX (conv3_bwd_pair.hip)
+    ctx->pair->dw = batch; ctx->pair->dw_gx = grid; ctx->pair->dw_lds = DwRsGeom<3>::LDS_BYTES; ctx->pair->have_dw = true;
     ctx->pair->upi = upi; ctx->pair->band = band; ctx->pair->dw_rs = true;
     return 0;
   }

@@ -18,13 +18,19 @@ static int conv_dx_rs_launch_t(cpp_ctx* ctx, const ConvArgsN& batch) {
   return 0;
 }
 
+bool conv3_pair_rs_ok(const cpp_ctx* ctx, int H, int W) {
+  static const bool off = cpp_switch_off("CPP_CONV3_PAIR_RS") || cpp_switch_off("CPP_CONV_DXRS") || cpp_switch_off("CPP_CONV_DWRS") ||
+                          cpp_switch_off("CPP_CONV3_DXRS") || cpp_switch_off("CPP_CONV3_DWRS") || cpp_switch_off("CPP_CONV_B16") || cpp_switch_off("CPP_CONV3_PAIR");
+  return !off && ctx && ctx->pair && ctx->pair->layer == 2 && W == 16 && H >= 8 && !(H & 1);
+}
+
 bool conv_dx_rs_ok(const cpp_ctx* ctx, int cin, int ks, int H, int W, int nout) {
   static const bool off = cpp_switch_off("CPP_CONV_DXRS") || cpp_switch_off("CPP_CONV_B16");
   (void)ctx;
   static const bool off3 = cpp_switch_off("CPP_CONV3_DXRS");
   // (16-wide rows -- conv3 at 64x64 images -- would leave conv3_bwd_pair.hip's launch for one of their own: CPP_CONV3_DXRS_W16=1, ablation build)
   static const bool w16 = cpp_switch_int("CPP_CONV3_DXRS_W16", 0) != 0;
-  const bool geo = (ks == 5 && (W == 32 || W == 64)) || (ks == 3 && !off3 && ((W == 16 && w16) || W == 32 || W == 64));
+  const bool geo = (ks == 5 && (W == 32 || W == 64)) || (ks == 3 && !off3 && ((W == 16 && (w16 || conv3_pair_rs_ok(ctx, H, W))) || W == 32 || W == 64));
   return !off && cin == KYO_NO && nout == KYO_NO && geo && H >= 4 && !(H & 1);
 }
 
@@ -41,12 +47,17 @@ int conv_dx_rs_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvAr
     const int wgs = a.n * ((a0.B + ipw - 1) / ipw);
     // (not beside conv2's dW: there the launch is bound by the two bodies' total work, and a second band walks up to NSET - 1 + 2 P rows
     // more per image -- cfg4 33.5 -> 35.5 us, cfg3 52.8 -> 57 us with bands, profiles/experiments/r05_dxrs_bands.sh)
-    const bool paired = ctx->pair && ctx->pair->layer == 1 && a0.W == 32;
+    const bool paired = (ctx->pair && ctx->pair->layer == 1 && a0.W == 32) || (ks == 3 && conv3_pair_rs_ok(ctx, a0.H, a0.W));
     const bool two = bands_sw != 0 && ((wgs < ctx->num_cus && !paired) || bands_sw == 2) && a0.H >= 16 && (a0.H % 4) == 0;
     for (int i = 0; i < a.n; ++i) { a.a[i].nbands = two ? 2 : 1; a.a[i].band_rows = two ? a0.H / 2 : a0.H; }
   }
   if (ctx->pair && ctx->pair->layer == 1 && ks == 5 && a0.W == 32) {     // leaves with conv2's dW (conv2_bwd_pair.hip)
     ctx->pair->dx = a; ctx->pair->dx_gx = ((a0.B + 1) / 2) * a.a[0].nbands; ctx->pair->dx_lds = DxRsGeom<5, 2>::LDS_BYTES; ctx->pair->have_dx = true;
+    ctx->pair->dx_rs = true;
+    return 0;
+  }
+  if (ks == 3 && conv3_pair_rs_ok(ctx, a0.H, a0.W) && a0.nout == KYO_NO) {      // leaves with conv3's dW (conv3_bwd_pair.hip)
+    ctx->pair->dx = a; ctx->pair->dx_gx = ((a0.B + 3) / 4) * a.a[0].nbands; ctx->pair->dx_lds = DxRsGeom<3, 1>::LDS_BYTES; ctx->pair->have_dx = true;
     ctx->pair->dx_rs = true;
     return 0;
   }
