@@ -442,6 +442,10 @@ def main():
                 "bound_us": round(bound_us, 2), "frac": round(bound_us / avg_us, 4)}
     L1, L2, L3 = per_layer
     nb = nbwd
+    fast = "conv1_fwd_f16" in prof and not os.environ.get("CPP_CONV_DXRS") and not os.environ.get("CPP_CONV_DWRS")      # (the f16 / bf16 pipes are on)
+    bn = bool(getattr(args, "use_batch_norm", False))
+    rs2 = fast and not bn and shape[1] // 2 in (32, 64) and shape[0] % 4 == 0
+    rs3 = fast and not bn and shape[1] // 4 in (16, 32, 64) and shape[0] % 8 == 0 and shape[0] // 4 >= 8
     rows = [r for r in (
         row("conv1 forward", ["conv1_fwd_f16"], [(gf(L1, nfwd), F16_PIPE)]),
         row("conv1 forward (f32 MFMA)", ["conv1_fwd"], [(gf(L1, nfwd), "f32")]),
@@ -450,15 +454,17 @@ def main():
         # (when conv3 + pool3 ride as the tail of conv2's workgroups there is no conv3_fwd launch: its FLOPs belong to this row)
         row("conv2 forward" + ("" if "conv3_fwd" in prof else " + conv3 forward"), ["conv2_fwd"],
             [(gf(L2, nfwd), B16_PIPE if "conv1_fwd_f16" in prof else "f32")] + ([] if "conv3_fwd" in prof else [(gf(L3, nfwd), "f32")])),
-        row("conv2 dW + dX", ["conv2_bwd"], [(gf(L2, nb), B16_PIPE), (gf(L2, nb), "f32")]),
+        # (round 5: conv2's dX -- and conv3's dW / dX -- run on the bf16 pipes' row-streaming bodies, conv_dx_rs.h / conv_dw_rs.h, where
+        # the rows are 32 or 64 pixels wide (conv3's pair launch: 16 too); other widths keep the f32-input kernels)
+        row("conv2 dW + dX", ["conv2_bwd"], [(gf(L2, nb), B16_PIPE), (gf(L2, nb), B16_PIPE if rs2 else "f32")]),
         # (conv2's dW on its own launch -- cfg5's 64 x 64 conv2 has no pair instance -- runs conv_dwb16_kernel, bf16 pieces, whenever conv1 /
         # conv2 are on the f16 / bf16 pipes; round 4's line priced it against the f32 pipe)
         row("conv2 dW", ["conv2_dw"], [(gf(L2, nb), B16_PIPE if "conv1_fwd_f16" in prof else "f32")]),
-        row("conv2 dX", ["conv2_dx"], [(gf(L2, nb), "f32")]),
+        row("conv2 dX", ["conv2_dx"], [(gf(L2, nb), B16_PIPE if rs2 else "f32")]),
         row("conv3 forward", ["conv3_fwd"], [(gf(L3, nfwd), "f32")]),
-        row("conv3 dW + dX", ["conv3_bwd"], [(gf(L3, nb), "f32"), (gf(L3, nb), "f32")]),
-        row("conv3 dW", ["conv3_dw"], [(gf(L3, nb), "f32")]),
-        row("conv3 dX", ["conv3_dx"], [(gf(L3, nb), "f32")])) if r]
+        row("conv3 dW + dX", ["conv3_bwd"], [(gf(L3, nb), B16_PIPE if rs3 else "f32"), (gf(L3, nb), B16_PIPE if rs3 else "f32")]),
+        row("conv3 dW", ["conv3_dw"], [(gf(L3, nb), B16_PIPE if rs3 and shape[1] // 4 >= 32 else "f32")]),
+        row("conv3 dX", ["conv3_dx"], [(gf(L3, nb), B16_PIPE if rs3 and shape[1] // 4 >= 32 else "f32")])) if r]
     for r in rows:
         assert r["frac"] <= 1.0, "roofline accounting error: %r" % (r,)
     mapped = {k for r in rows for k in r["kernels"]}
@@ -525,10 +531,10 @@ def main():
         "vs_baseline": None, "dtype": "f32-acc/f16x3,bf16x9" if EXACT_PRODUCTS else "f32-acc/f16x2,bf16x6", "data": "synthetic",
         "timed_region_ms": round(1e3 * elapsed, 2), "warmup_steps_run": warmup_steps_run,
         "dtype_note": ("f32 accumulation everywhere; conv1 multiplies exact f16 operands (the replay store's pixels x three-piece f16 splits "
-                       "of the f32 weights / gradients), conv2 forward / dW three-piece bf16 splits of both f32 operands with all nine "
+                       "of the f32 weights / gradients), conv2 forward / dW / dX (round 5; and conv3's dW / dX at rows of 16+ pixels) three-piece bf16 splits of both f32 operands with all nine "
                        "products: every product exact (--precision exact)" if EXACT_PRODUCTS else
                        "f32 accumulation everywhere; conv1 multiplies the replay store's f16 pixels (exact) by a two-piece f16 split of the "
-                       "f32 weight / gradient (within one f32 ulp of it), conv2 forward / dW three-piece bf16 splits of both f32 operands with "
+                       "f32 weight / gradient (within one f32 ulp of it), conv2 forward / dW / dX (round 5; and conv3's dW / dX at rows of 16+ pixels) three-piece bf16 splits of both f32 operands with "
                        "the six largest piece products (the dropped three are at most half an f32 ulp of the product): measured as close to "
                        "the float64 oracle as the exact-product build (`control_exact_products`) and closer than the f32-input MFMA kernels "
                        "(`control`); DESIGN.md 4, 6"),

@@ -1,5 +1,6 @@
 // conv1 dW / db on the f16 matrix pipes with f32-exact operands (conv_dw16.h): instantiations + geometry selection.
 #include "conv_dw16.h"
+#include "conv_dw16_rs.h"
 
 // (cpp_ctx_set_precision: three f16 pieces of dY instead of two)
 #define DW16_CASE(CIN_, NCHK_)                                                                               \
@@ -25,6 +26,10 @@ int conv_dw16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool dense, c
   // workgroups on every CU (cfg3: 79 vs 83 us; the 50x50 render has 256 whole-image units: 82 vs 62 us; 9 channels: 57 vs 49 us --
   // profiles/experiments/r03_pairs.txt)
   static const bool no_pair = cpp_switch_off("CPP_DW16_PAIR");
+  {  // 64-wide rows of 18 channels, actor + critic: one wave per (network, 32-pixel column) unit (conv_dw16_rs.h)
+    const int rc = conv_dw16_rs_dispatch(ctx, cin, ks, in_mode, dense, a, grid, handled);
+    if (*handled) return rc;
+  }
   if (!no_pair && !dense && ctx && cin == 18 && nchk == 2 && conv_dw16_pairable(a)) {
     // (the pair kernel runs two workgroups per CU; its bands are chosen by the same one-round rule in conv_dw16_launch_t)
     const int capacity = ctx->num_cus * 2 / (a.n / 2);
