@@ -24,7 +24,10 @@ struct Dw16RsGeom {
   static constexpr int WPX = WC + 2 * P;                      // pixels of a staged row
   static constexpr int ROWB = 2 * (((CP * WPX + 16 * MT - KS * CP) + 7) & ~7);      // + the m over-read, bytes
   static constexpr int NXS = 2;
-  static constexpr int DOST = 80, DPC = NO * DOST, DSLOT = NPC * DPC;      // dY row: [piece][o][4 lane groups x 16 bytes + skew]
+  static constexpr int DOST = 80, DPC = NO * DOST;             // dY row: [piece][o][4 lane groups x 16 bytes + skew]
+  // (slots padded to 224 mod 256 bytes, which spreads a B read's 16 columns -- two or three ky, i.e. ring slots -- over 16 different bank
+  // groups: no change, 3159 / 3160 / 3178 vs 3159 / 3165 / 3150 steps/s alternating on one box; the flat layout stays)
+  static constexpr int DSLOT = NPC * DPC;
   static constexpr int NDS = KS + 1;
   static constexpr int WVB = NXS * ROWB + NDS * DSLOT;        // per wave
   static constexpr int SUMB = MT * NT * 64 * 16;              // a network's accumulators on their way to the partial: 28 tiles x 64 lanes x 16 bytes

@@ -31,7 +31,10 @@ struct DwRsGeom {
   static constexpr int ROWB = 2 * (((CP * (WC + KS - 1) + 16 * MT - KS * CP) + 7) & ~7);      // a plane of a staged input row: (WC + 2 P) pixels x CP halves + the m over-read, bytes
   static constexpr int XSLOT = 3 * ROWB;
   static constexpr int NXS = 2;                               // input rows in LDS: the one being multiplied, the one being written
-  static constexpr int DOST = 80, DPC = NO * DOST, DSLOT = 3 * DPC;   // dZ row: [piece][o][4 lane groups x 16 bytes + skew]
+  static constexpr int DOST = 80, DPC = NO * DOST;             // dZ row: [piece][o][4 lane groups x 16 bytes + skew]
+  // (slots padded to 224 mod 256 bytes, which spreads a B read's 16 columns -- two or three ky, i.e. ring slots -- over 16 different bank
+  // groups: no change, 3159 / 3160 / 3178 vs 3159 / 3165 / 3150 steps/s alternating on one box; the flat layout stays)
+  static constexpr int DSLOT = 3 * DPC;
   static constexpr int NDS = KS + 1;                          // dZ rows in LDS: 2 P + 1 in use, one being written
   static constexpr int WVB = NXS * XSLOT + NDS * DSLOT;       // per wave
   static constexpr int LDS_BYTES = 4 * WVB;

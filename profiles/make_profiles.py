@@ -35,7 +35,10 @@ SHORT = [("void conv_fwd_kernel<18, 5, 4, 0, 0>", "conv1_fwd"), ("void conv_dw_k
          ("void ddpg_heads_kernel", "heads"), ("conv3_bwd_pair_kernel", "conv3_bwd"), ("conv2_bwd_pair_kernel", "conv2_bwd"), ("void conv2_bwd_pair_kernel", "conv2_bwd"),
          ("void reduce_gather_kernel<__half>", "reduce_gather"), ("conv1_dw_gather_kernel", "conv1_dw_gather"),
          # round 3: two networks per conv1-dW workgroup (conv_dw16.h NNET = 2)
-         ("conv1_dw_pair_gather_kernel", "conv1_dw_gather"), ("void conv_dw16_pair_kernel<18, 5", "conv1_dw_f16")]
+         ("conv1_dw_pair_gather_kernel", "conv1_dw_gather"), ("void conv_dw16_pair_kernel<18, 5", "conv1_dw_f16"),
+         # round 5: the wave-per-unit / row-streaming bodies
+         ("conv_dw16_rs_kernel", "conv1_dw_f16"), ("void conv2_bwd_pair_rs_kernel", "conv2_bwd"), ("void conv3_bwd_pair_rs_kernel", "conv3_bwd"),
+         ("void conv_dx_rs_kernel<5", "conv2_dx"), ("void conv_dx_rs_kernel<3", "conv3_dx"), ("void conv_dw_rs_kernel<5", "conv2_dw"), ("void conv_dw_rs_kernel<3", "conv3_dw")]
 
 
 def short(name):
@@ -116,7 +119,8 @@ def main(rnd):
                 "microseconds, from the rocpd database's `top_kernels` view (profiles/make_profiles.py).  One `conv_fwd_rs16_kernel<18>` (round 5;\n"
                 "rounds 2-4: `conv_fwd_k16_kernel<18,5,2,2>`) launch computes conv1 of all four networks of a minibatch (blockIdx.y = network); likewise conv2/conv3 forward;\n"
                 "the dW / dX launches carry the actor and the critic together -- conv2's and conv3's dW and dX share one launch each\n"
-                "(`conv2_bwd_pair_kernel`, `conv3_bwd_pair_kernel`), and conv1's dW shares its launch with the next minibatch's\n"
+                "(`conv2_bwd_pair_kernel`, `conv3_bwd_pair_kernel`; round 5: `..._rs_kernel`, both halves on the bf16 pipes' row-streaming bodies), and conv1's dW\n"
+                "(round 5: `conv_dw16_rs_kernel`, one wave per (network, 32-pixel column) unit) shares its launch with the next minibatch's\n"
                 "sample pass (`conv1_dw_gather_kernel`, from round 3 `conv1_dw_pair_gather_kernel`: one workgroup serves the actor AND the\n"
                 "critic, and the sample pass copies the store's per-state sums instead of reading pixels; `conv_dw16_kernel` /\n"
                 "`conv_dw16_pair_kernel` alone closes each 5-minibatch graph).\n\n")
