@@ -1,6 +1,6 @@
-// conv2's weight / bias gradient on the bf16 matrix pipes, ONE WAVE PER UNIT ("dwrs"): v_mfma_f32_16x16x32_bf16.
+// conv2's and conv3's weight / bias gradient on the bf16 matrix pipes, ONE WAVE PER UNIT ("dwrs"): v_mfma_f32_16x16x32_bf16.
 //
-//   dW[ky][kx][c][o] = sum_{b,q,x} in[b, q, x + kx - P, c] * dZ[b, q - ky + P, x, o]          (base_network.py:111-115's conv, backward)
+//   dW[ky][kx][c][o] = sum_{b,q,x} in[b, q, x + kx - P, c] * dZ[b, q - ky + P, x, o]          (base_network.py:111-123's convs, backward)
 //
 // conv_dwb16.h's arithmetic (both f32 operands as three bf16 pieces, the six -- CPP_PRECISION_EXACT: nine -- largest piece products,
 // f32 accumulation) and its operand layouts (the input row at a pixel pitch of CP halves, read through ds_read_b64_tr_b16; dZ rows as
@@ -8,14 +8,15 @@
 // share one (image, band) unit, each owning one 16-column tile of (ky, o): 24 MFMAs per wave and input row between two workgroup
 // barriers, every A fragment read by all four waves, the staging of the next rows in front of the MFMAs.  Here
 //
-//   * a WAVE owns a unit and all 4 x 4 accumulator tiles of D[m = (kx, c)][n = (ky, o)] (64 VGPRs): 96 MFMAs per input row, every
+//   * a WAVE owns a unit and all 4 x 4 (3x3: 3 x 2) accumulator tiles of D[m = (kx, c)][n = (ky, o)] (64 VGPRs): 96 (36) MFMAs per input row, every
 //     A fragment read once, no barrier in the row loop -- the rows of a unit are staged in the wave's own LDS slots;
 //   * the staging work (pooled gradient + arg-max code -> dZ row -> three bf16 planes; f32 activations -> three planes) is dealt out
 //     between the MFMAs (one wave per SIMD beside conv_dx_rs.h's: nobody else would issue in its place);
 //   * the bias gradient is row (kx = P, c = CIN) x column (ky = P, o) of the same product: a "ones" channel in the input row's first plane;
 //   * the four waves of a workgroup add their accumulators through LDS in a fixed order: one partial per workgroup (a quarter of
 //     conv_dwb16.h's partials for conv_dw_reduce_kernel).
-// Rows of 32 or 64 pixels (a unit = a 32-pixel column of a band: the contraction's one chunk per row), 10 -> 10 channels, 5x5.
+// Rows of 32 or 64 pixels (a unit = a 32-pixel column of a band: the contraction's one chunk per row; 3x3 also 16-wide rows, half a chunk),
+// 10 -> 10 channels.
 #pragma once
 #include <type_traits>
 #include "conv_dwb16.h"

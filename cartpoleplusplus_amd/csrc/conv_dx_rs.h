@@ -1,6 +1,6 @@
-// conv2's dX on the bf16 matrix pipes, ROW-STREAMING with the weights resident in registers ("dxrs"): v_mfma_f32_16x16x32_bf16.
+// conv2's and conv3's dX on the bf16 matrix pipes, ROW-STREAMING with the weights resident in registers ("dxrs"): v_mfma_f32_16x16x32_bf16.
 //
-//   dX[b, y, x, c] = sum_{ky, kx, o} dZ[b, y - ky + P, x - kx + P, o] W[ky][kx][c][o]          (the gradient of base_network.py:111-115's conv)
+//   dX[b, y, x, c] = sum_{ky, kx, o} dZ[b, y - ky + P, x - kx + P, o] W[ky][kx][c][o]          (the gradient of base_network.py:111-123's convs)
 //                  = sum_{ky', kx', o} dZ[b, y + ky' - P, x + kx' - P, o] W'[ky'][kx'][o][c],   W'[ky'][kx'][o][c] = W[KS-1-ky'][KS-1-kx'][c][o]
 //
 // i.e. a forward convolution of the unpooled gradient dZ with the flipped, transposed weights -- what conv_fwd_kyo_body<.., IN_DY> computes
@@ -9,15 +9,16 @@
 // products are issued: conv2 forward's arithmetic contract, in conv_rs16.h's formulation:
 //
 //   * the MFMA's 16 ROWS are the 10 input channels c of the layer (A operand = W', lane (li, lj) holds row li's 8 consecutive
-//     k = (kx', o) of lane group lj); KS x 2 chunks x 3 pieces = 30 A operands = 120 VGPRs, built ONCE per wave and resident;
-//   * its 16 COLUMNS are pixels: a wave owns one 16-pixel tile of an image for all rows (32-wide rows: two waves per image, a
-//     workgroup = two images; 64-wide: four waves, one image);
+//     k = (kx', o) of lane group lj); 5x5: KS x 2 chunks x 3 pieces = 30 A operands = 120 VGPRs (3x3: one chunk, 9 operands), built ONCE
+//     per workgroup through LDS and resident;
+//   * its 16 COLUMNS are pixels: a wave owns one 16-pixel tile of an image for all rows (16-wide rows: a workgroup = four images;
+//     32-wide: two waves per image, two images; 64-wide: four waves, one image);
 //   * dZ rows are REBUILT from the pooled gradient and the arg-max codes (as IN_DY does), split, and staged in the wave's own LDS slots
 //     as three bf16 planes of 20 pixels (the tile + the SAME padding / the neighbours' two pixels) -- no barrier in the row loop; the
 //     operand windows are 4-byte aligned LDS reads at per-lane addresses (20 bytes per pixel);
 //   * the KS output rows a dZ row contributes to are KS accumulator sets (+ the one being written out), restarted through the C operand.
-// 60 MFMAs (90: nine products) per dZ row and wave; beside them ~40 VALU, 18 LDS accesses, one global load pair every second row and
-// one 16-byte store per lane and row.
+// 5x5: 60 MFMAs (90: nine products) per dZ row and wave; beside them ~40 VALU, 18 LDS accesses, one global load pair every second row and
+// one 16-byte store per lane and row -- dealt out BETWEEN the MFMAs (the step below).  3x3: 18 MFMAs against the same staging work.
 #pragma once
 #include <type_traits>
 #include "conv_k16.h"
