@@ -186,6 +186,8 @@ size_t conv_dw_partial_floats(cpp_ctx* ctx, int cin, int ks, int nout);
 // conv2's dX on the bf16 pipes (conv_dx_rs.h)
 int conv_dx_rs_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArgsN& a, bool* handled);
 int conv_dw_rs_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArgsN& a, int* grid, bool* handled);
+// conv2 / conv3 forward on the bf16 pipes, row-streaming (conv_fw_rs.h)
+int conv_fw_rs_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, int epi, const ConvArgsN& a, bool* handled);
 // conv3's backward at 16-wide rows (64x64 images): both halves on the row-streaming bodies, in conv3_bwd_pair.hip's one launch
 bool conv3_pair_rs_ok(const cpp_ctx* ctx, int H, int W);
 size_t conv_rs16_image_bytes();     // a network's conv1 operand image (conv_rs16.h)

@@ -131,6 +131,11 @@ int launch_conv_fwd_multi(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, i
     prof_end(ctx, kid);
     return rc;
   }
+  if (!no_kyo && in_mode == IN_F32_PLAIN && !dx_mode && !plain_fwd && epi == EPI_RELU_POOL && a.wscale == 0.f) {      // conv3 at rows of 32 / 64 pixels: row-streaming on the bf16 pipes (conv_fw_rs.h)
+    bool handled = false;
+    rc = conv_fw_rs_dispatch(ctx, cin, ks, in_mode, epi, batch, &handled);
+    if (handled) { prof_end(ctx, kid); return rc; }
+  }
   if (!no_kyo && in_mode == IN_F32_PLAIN && !dx_mode && !plain_fwd && a.in_b16 != nullptr) {      // conv2 from conv1's bf16 planes
     bool handled = false;
     rc = conv_fwd_kb16_dispatch(ctx, cin, ks, in_mode, batch, &handled);
