@@ -461,7 +461,7 @@ def main():
         # conv2 are on the f16 / bf16 pipes; round 4's line priced it against the f32 pipe)
         row("conv2 dW", ["conv2_dw"], [(gf(L2, nb), B16_PIPE if "conv1_fwd_f16" in prof else "f32")]),
         row("conv2 dX", ["conv2_dx"], [(gf(L2, nb), B16_PIPE if rs2 else "f32")]),
-        row("conv3 forward", ["conv3_fwd"], [(gf(L3, nfwd), "f32")]),
+        row("conv3 forward", ["conv3_fwd"], [(gf(L3, nfwd), B16_PIPE if rs3 and shape[1] // 4 >= 32 else "f32")]),      # (conv_fw_rs.h at rows of 32 / 64 pixels)
         row("conv3 dW + dX", ["conv3_bwd"], [(gf(L3, nb), B16_PIPE if rs3 else "f32"), (gf(L3, nb), B16_PIPE if rs3 else "f32")]),
         row("conv3 dW", ["conv3_dw"], [(gf(L3, nb), B16_PIPE if rs3 and shape[1] // 4 >= 32 else "f32")]),
         row("conv3 dX", ["conv3_dx"], [(gf(L3, nb), B16_PIPE if rs3 and shape[1] // 4 >= 32 else "f32")])) if r]

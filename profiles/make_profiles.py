@@ -38,7 +38,7 @@ SHORT = [("void conv_fwd_kernel<18, 5, 4, 0, 0>", "conv1_fwd"), ("void conv_dw_k
          ("conv1_dw_pair_gather_kernel", "conv1_dw_gather"), ("void conv_dw16_pair_kernel<18, 5", "conv1_dw_f16"),
          # round 5: the wave-per-unit / row-streaming bodies
          ("conv_dw16_rs_kernel", "conv1_dw_f16"), ("void conv2_bwd_pair_rs_kernel", "conv2_bwd"), ("void conv3_bwd_pair_rs_kernel", "conv3_bwd"),
-         ("void conv_dx_rs_kernel<5", "conv2_dx"), ("void conv_dx_rs_kernel<3", "conv3_dx"), ("void conv_dw_rs_kernel<5", "conv2_dw"), ("void conv_dw_rs_kernel<3", "conv3_dw")]
+         ("void conv_dx_rs_kernel<5", "conv2_dx"), ("void conv_dx_rs_kernel<3", "conv3_dx"), ("void conv_dw_rs_kernel<5", "conv2_dw"), ("void conv_dw_rs_kernel<3", "conv3_dw"), ("void conv_fw_rs_kernel<3", "conv3_fwd")]
 
 
 def short(name):
