@@ -1,5 +1,5 @@
 """Round 5's backward kernels (csrc/conv_dx_rs.h, conv_dw_rs.h, conv_dw16_rs.h: one wave per unit, bf16 / f16 pieces on the matrix
-pipes) against the kernels they replaced (conv_kyo.h's f32-input dX, conv_dwb16.h, conv_dw16.h's pair kernel; still in the library for
+pipes; and conv3's forward on conv_fw_rs.h where its rows are 32+ pixels wide) against the kernels they replaced (conv_kyo.h's f32-input dX, conv_dwb16.h, conv_dw16.h's pair kernel; still in the library for
 other geometries and selectable in the ablation build): the same minibatch through both, every gradient compared per variable.
 The new bodies differ from the old in summation order, in the dX products (three bf16 pieces per operand, six products, instead of
 f32 x f32) and in conv1 dW's scale (one 2^S per wave instead of per workgroup): agreement to a few f32 ulps of the gradient's size,
@@ -31,7 +31,8 @@ np.save(sys.argv[4], np.concatenate([agent.actor.get_grads(), agent.critic.get_g
 agent.close()
 """
 
-OLD = {"CPP_CONV_DXRS": "0", "CPP_CONV_DWRS": "0", "CPP_CONV1_DWRS": "0"}
+# (CPP_CONV_FWRS: conv3's forward at rows of 32+ pixels -- the cfg5-geometry case -- back on the f32-input kernel as well)
+OLD = {"CPP_CONV_DXRS": "0", "CPP_CONV_DWRS": "0", "CPP_CONV1_DWRS": "0", "CPP_CONV_FWRS": "0"}
 
 
 def _grads(tmp_path, name, shape, B, mode, extra):
