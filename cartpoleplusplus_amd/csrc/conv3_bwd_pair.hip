@@ -31,9 +31,38 @@ __global__ __launch_bounds__(CONV_THREADS, 2) __attribute__((amdgpu_waves_per_eu
   }
 }
 
+// one half on a row-streaming body, the other on the kernel it replaced (the two dispatchers decide separately: an ablation switch,
+// an unaligned buffer or a dW grid beyond the partial buffers' capacity takes one half off its body and leaves the other)
+template <int ORDER, bool DXRS>
+__global__ __launch_bounds__(CONV_THREADS, 2) void conv3_bwd_pair_mixed_kernel(const ConvArgsN dx, int dx_gx, const ConvArgsN dw, int dw_gx, int upi, int band, int order) {
+  int i;
+  if (!pair_grid_place((int)blockIdx.x, dx_gx * dx.n, dw_gx * dw.n, order, &i)) {
+    if (DXRS) conv_dx_rs_body<3, 1, ORDER>(dx, i % dx_gx, i / dx_gx);
+    else conv_fwd_kyo_body<10, 3, 1, 4, IN_DY, 16, false>(dx, i % dx_gx, i / dx_gx);
+  } else {
+    if (DXRS) conv_dw_body<10, 3, 1, IN_F32_PLAIN>(dw, i % dw_gx, i / dw_gx, dw_gx);
+    else conv_dw_rs_body<3, ORDER>(dw, upi, band, i % dw_gx, i / dw_gx);
+  }
+}
+
 int launch_conv3_bwd_pair(cpp_ctx* ctx, const ConvPairSlot& slot) {
-  if ((slot.have_dx && slot.dx_rs) || (slot.have_dw && slot.dw_rs)) {
-    if (!(slot.have_dx && slot.dx_rs && slot.have_dw && slot.dw_rs)) { cpp_set_error("conv3 backward pair: only one half on the row-streaming bodies"); return 1; }
+  const bool dx_rs = slot.have_dx && slot.dx_rs, dw_rs = slot.have_dw && slot.dw_rs;
+  if (slot.have_dx && slot.have_dw && dx_rs != dw_rs) {
+    const bool nine = b16_order(ctx) == B16_NINE;
+    auto kern = dx_rs ? (nine ? conv3_bwd_pair_mixed_kernel<B16_NINE, true> : conv3_bwd_pair_mixed_kernel<B16_SIX, true>)
+                      : (nine ? conv3_bwd_pair_mixed_kernel<B16_NINE, false> : conv3_bwd_pair_mixed_kernel<B16_SIX, false>);
+    const size_t lds = slot.dx_lds > slot.dw_lds ? slot.dx_lds : slot.dw_lds;
+    HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static const int order = cpp_switch_int("CPP_PAIR3_ORDER", 1);
+    prof_begin(ctx);
+    hipLaunchKernelGGL(kern, dim3(slot.dx_gx * slot.dx.n + slot.dw_gx * slot.dw.n), dim3(CONV_THREADS), lds, ctx->stream, slot.dx, slot.dx_gx, slot.dw, slot.dw_gx,
+                       slot.upi, slot.band, order);
+    LAUNCH_CHECK();
+    prof_end(ctx, K_CONV3_BWD);
+    return 0;
+  }
+  if (dx_rs || dw_rs) {
+    if (!(dx_rs && dw_rs)) { cpp_set_error("conv3 backward pair: one half is missing beside a row-streaming body"); return 1; }
     const bool nine = b16_order(ctx) == B16_NINE;
     auto kern = nine ? conv3_bwd_pair_rs_kernel<B16_NINE> : conv3_bwd_pair_rs_kernel<B16_SIX>;
     const size_t lds = slot.dx_lds > slot.dw_lds ? slot.dx_lds : slot.dw_lds;

@@ -21,6 +21,9 @@ int conv_dw_rs_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvAr
   while (band > 8 && (band / 2) % 2 == 0 && a.B * ncol * ((a.H + band / 2 - 1) / (band / 2)) <= capacity) band /= 2;
   const int upi = ((a.H + band - 1) / band) * ncol;           // (band, 32-pixel column) units of an image, column fastest
   const int grid = (a.B * upi + 3) / 4;
+  // one partial per workgroup: the partial buffers hold num_cus * 4 of them per network (conv_dw_partial_floats); a launch that needs
+  // more (B > 16 num_cus / ncol whole-image units: large batches, CPX partitions) is left to the kernels that clamp their grids
+  if ((size_t)grid > (size_t)ctx->num_cus * 4) { *handled = false; return 0; }
   *grid_out = grid;
   const bool nine = b16_order(ctx) == B16_NINE;
   if (ctx->pair && ctx->pair->layer == 1 && ks == 5 && a.W == 32) {      // leaves with conv2's dX (conv2_bwd_pair.hip)

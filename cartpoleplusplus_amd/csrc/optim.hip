@@ -8,6 +8,7 @@
 #include "conv_rs16.h"
 
 constexpr int OPT_THREADS = 256;
+static_assert(OPT_THREADS == CONV_THREADS, "conv1_image_body (the rider in opt_apply_kernel) strides its loops by CONV_THREADS and assumes four waves");
 
 // part[seg][blk] = sum over the block's slice of (grad_scale * g)^2, in f64
 __global__ __launch_bounds__(OPT_THREADS) void sumsq_kernel(const OptSegs s, float grad_scale,
