@@ -192,6 +192,7 @@ int conv_fw_rs_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, int epi, con
 bool conv3_pair_rs_ok(const cpp_ctx* ctx, int H, int W);
 size_t conv_rs16_image_bytes();     // a network's conv1 operand image (conv_rs16.h)
 bool conv_rs16_ok(cpp_ctx* ctx, int cin, int H, int W, int nout);
+inline bool conv_rs16_channels_ok(int cin) { return cin == 3 || cin == 6 || cin == 9 || cin == 12 || cin == 18; }      // conv_fwd_rs16.hip's instances (15: two copies of three-chunk rows spill)
 int flush_dw_reduce(cpp_ctx* ctx);     // one launch for every dW reduction queued by launch_conv_dw
 // A backward pass that fails half way (a geometry without a kernel, a launch error) must not leave its queued reductions behind:
 // they point into that network's buffers, which may be gone by the time the next pass flushes the queue.
@@ -346,7 +347,7 @@ struct OptSegs {
   // second optional rider (img_n > 0; needs the first one's inputs or finished tables): conv1's operand images for the NEXT minibatch's forward (conv_rs16.h) -- one
   // workgroup per network recomputes its conv1 weights as this launch updates them (gw == nullptr: a target network, untouched), its
   // state column's whitening table as the first rider computes it, and builds the image: conv1_image_kernel's launch disappears
-  int img_n;
+  int img_n; int img_cin;        // img_cin: conv1's input channels (the image body's instance)
   long img_skip[OPT_MAX_SEGS];   // leading parameters of a segment (conv1's weights and biases) that its image workgroup updates itself
   struct { float* w; float* bias; const float* gw; const float* gb; unsigned char* rec; int seg, col, nout;
            const float* white; float* mw; float* mb; } img[4];      // mw / mb: the Momentum slots of those parameters (OPT_MOMENTUM)      // white != nullptr: the column's table is already in memory (the dW reductions' launch computed it)

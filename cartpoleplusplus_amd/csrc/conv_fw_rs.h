@@ -188,8 +188,8 @@ __device__ __forceinline__ void conv_fw_rs_body(const ConvArgsN& batch, const in
       if (YODD) {
         lds_store(twA, 0, (f32x2){pv[0], pv[1]});
         lds_store(twB, 0, (f32x2){pv[2], pv[3]});
-        lds_store(tcA, 0, (unsigned short)(code[0] | (code[1] << 8)));
-        lds_store(tcB, 0, (unsigned short)(code[2] | (code[3] << 8)));
+        lds_store_u16(tcA, 0, (unsigned)(code[0] | (code[1] << 8)));
+        lds_store_u16(tcB, 0, (unsigned)(code[2] | (code[3] << 8)));
       }
     };
     auto stores = [&]() __attribute__((always_inline)) {

@@ -38,6 +38,13 @@ template <typename T>
 __device__ __forceinline__ void lds_store(uint32_t addr, int byte_off, const T& v) {
   *reinterpret_cast<__attribute__((address_space(3))) T*>((uintptr_t)(addr + (uint32_t)byte_off)) = v;
 }
+// a 16-bit store into bytes that are READ BACK AS DWORDS: `unsigned short` and `unsigned` are different types to the compiler's type-based
+// alias analysis, which lets the scheduler move the dword read above the halfword write (round 6: conv_rs16.h's pivots of an odd channel
+// count were read before they were written, on the first rows only); a may_alias halfword aliases everything
+typedef unsigned short __attribute__((may_alias)) lds_u16_alias;
+__device__ __forceinline__ void lds_store_u16(uint32_t addr, int byte_off, unsigned v) {
+  *reinterpret_cast<__attribute__((address_space(3))) lds_u16_alias*>((uintptr_t)(addr + (uint32_t)byte_off)) = (unsigned short)v;
+}
 
 // Arg-max code byte of a pooled cell: bits 0-1 = the window position dy * 2 + dx of the first maximum, bit 2 (POOL_ACTIVE) = the pooled
 // output is > 0, i.e. the ReLU lets the cell's gradient through -- the backward kernels rebuild dY from (pooled gradient, code) and never

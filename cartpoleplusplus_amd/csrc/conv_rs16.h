@@ -6,19 +6,27 @@
 // wave 100-150 VALU, 31 LDS reads of rotating weights, 26 waits, a pool transpose through LDS, against 48 MFMAs):
 //
 //   * The MFMA's 16 ROWS are the 10 filters (A operand = weights, lane (li, lj) holds filter li's 8 consecutive k of lane group lj),
-//     its 16 COLUMNS are pixels (B operand = the raw image row, as conv_k16.h loads it).  The weights of all KS x NCH chunks x 2 pieces
-//     (30 A operands = 120 VGPRs at 18 channels) are loaded ONCE per wave from a prebuilt image and stay in registers: the row loop
-//     reads no LDS at all.
+//     its 16 COLUMNS are pixels (B operand = the raw image row).  The weights of all KS x NCH chunks x 2 pieces (30 A operands = 120
+//     VGPRs at 13 .. 18 channels, 20 at 7 .. 12, 10 at 3 / 6) are loaded ONCE per wave from a prebuilt image and stay in registers: the
+//     row loop reads no weights.
 //   * The KS output rows an input row contributes to are KS ACCUMULATOR SETS (+ one that is being written out): a set restarts
 //     through the C operand of its first MFMA (bias and border constant), nothing rotates, nothing is reset.
+//   * The image rows go through LDS, coalesced: every lane loads 16 contiguous bytes of the strip's row segment two rows ahead of its
+//     use, the segment sits in the wave's own LDS slot one row ahead, the two pixels of SAME padding are overwritten THERE with the
+//     pivots, and the operand windows are 4-byte aligned dword reads at per-lane addresses (a misaligned ds_read_b128 is served at a
+//     fraction of the rate).  An ODD channel count (9, 15: a pixel is an odd number of halves) keeps TWO copies of the segment, the second
+//     displaced by one half (loaded from the image 2 bytes earlier): the even pixels' windows are aligned in the first, the odd
+//     pixels' in the second.
 //   * The two column tiles of a wave hold the EVEN and the ODD pixels of its 32-pixel strip: the x half of the 2x2 pool is an
-//     element-wise max of the two tiles' accumulators, the y half is the previous output row's registers (same lanes): no LDS
-//     transpose, no writer passes.  A lane ends up with 4 consecutive filters of one pooled pixel: 8-byte stores.
-//   * 60 MFMAs per input row and wave instead of 48 (10 of 16 rows are filters, against 50 of 64 columns), but ~60 VALU, no LDS and
-//     3 waits beside them instead of ~300 other instructions.
+//     element-wise max of the two tiles' accumulators, the y half is the previous output row's registers (same lanes).  The pooled
+//     row crosses the wave's LDS slot once into row layout and leaves as five contiguous stores (16 / 8 / 8 / 8 / 4 bytes per lane:
+//     f32, three bf16 planes, codes).
+//   * 20 NCH MFMAs per input row and wave (10 of 16 rows are filters, against conv_k16.h's 50 of 64 columns), ~50 VALU, ~20 LDS
+//     accesses, 2 .. 4 loads and the compiler's own waits beside them.  No hand-counted wait: every load is a builtin.
 //
 // The per-network operand image (pieces of W s 2^S, the chunks' ones weights, the border constants, the pivots) is built by
-// conv1_image_kernel below -- conv_k16.h's per-workgroup setup, run ONCE per network and minibatch instead of in all 512 workgroups.
+// conv1_image_kernel below -- conv_k16.h's per-workgroup setup, run ONCE per network and minibatch instead of in all 512 workgroups
+// (in the fused steps: by a rider of the optimiser's launch, optim.hip).
 #pragma once
 #include "conv_k16.h"
 
@@ -69,13 +77,6 @@ __device__ __forceinline__ void conv1_image_body(const Conv1ImageArgs& a, unsign
   float* ctab = red + 8;                                                    // E[NRC][NO][4]
   unsigned short* pivot = reinterpret_cast<unsigned short*>(ctab + G::NRC * NO * 4);      // [CIN]
   constexpr int NUW = (NU + CONV_THREADS - 1) / CONV_THREADS;
-#ifdef RS16_IMAGE_PROBE
-  unsigned long long sp[8]; int spn = 0;
-#define RS16_STAMP() sp[spn++] = __builtin_amdgcn_s_memrealtime()
-#else
-#define RS16_STAMP()
-#endif
-  RS16_STAMP();
   // the layer's weights (as this launch's SGD update leaves them, if it rides there) through LDS: consecutive threads load consecutive
   // floats -- a thread fetching its own 24 (ky, k, o) values asked for 40-byte strides, 2.6 us of this workgroup (6.5 with the gradients)
   float* wst = reinterpret_cast<float*>(lds_raw);              // [KS * KROW * nout] -- in the record's place, which is written later
@@ -159,7 +160,6 @@ __device__ __forceinline__ void conv1_image_body(const Conv1ImageArgs& a, unsign
   for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
   if (lane == 0) red[wave] = vmax;
   __syncthreads();
-  RS16_STAMP();
   vmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   for (int i = tid; i < G::REC_BYTES / 16; i += CONV_THREADS) reinterpret_cast<k16_u32x4*>(rec)[i] = (k16_u32x4){0u, 0u, 0u, 0u};
   __syncthreads();                                   // (every thread has its weights in registers: the record takes the staging area over)
@@ -209,7 +209,6 @@ __device__ __forceinline__ void conv1_image_body(const Conv1ImageArgs& a, unsign
     }
   }
   __syncthreads();
-  RS16_STAMP();
   constexpr int NJ1 = KS * NCH * NO;
   constexpr int NJW = (NJ1 + CONV_THREADS - 1) / CONV_THREADS;
   double osumv[NJW];
@@ -250,7 +249,6 @@ __device__ __forceinline__ void conv1_image_body(const Conv1ImageArgs& a, unsign
   for (int o = 32; o > 0; o >>= 1) omax = fmax(omax, __shfl_xor(omax, o));
   if (lane == 0) red[4 + wave] = (float)omax;
   __syncthreads();
-  RS16_STAMP();
   const float om = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])) * 1.0001f;
   int onesT = (om > 0.f && om < 3.0e38f) ? ilogbf(om) - 14 : 0;
   onesT = onesT < 0 ? 0 : (onesT > 15 ? 15 : onesT);
@@ -295,12 +293,7 @@ __device__ __forceinline__ void conv1_image_body(const Conv1ImageArgs& a, unsign
   }
   if (tid == 0) *reinterpret_cast<float*>(rec + G::SC_OFF) = inv;
   __syncthreads();
-  RS16_STAMP();
   for (int i = tid; i < G::REC_BYTES / 16; i += CONV_THREADS) reinterpret_cast<k16_u32x4*>(a.rec)[i] = reinterpret_cast<const k16_u32x4*>(rec)[i];
-  RS16_STAMP();
-#ifdef RS16_IMAGE_PROBE
-  if (tid == 0) printf("RS16IMG gw %d: zero+loads+vmax %llu, split %llu, sums+table %llu, slots+ct %llu, copy out %llu (10 ns ticks)\n", a.gw != nullptr, sp[1] - sp[0], sp[2] - sp[1], sp[3] - sp[2], sp[4] - sp[3], sp[5] - sp[4]);
-#endif
 }
 
 template <int CIN, int NPCS = F16_PIECES>
@@ -317,30 +310,39 @@ __global__ __launch_bounds__(CONV_THREADS) void conv1_image_kernel(const Conv1Im
 }
 
 // ---- the forward kernel
-#ifndef RS16_WAVES
-#define RS16_WAVES 2
-#endif
-#ifndef RS16_ROTATE_PRIO
-#define RS16_ROTATE_PRIO 1
-#endif
 typedef unsigned rs16_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned rs16_u32x2 __attribute__((ext_vector_type(2)));
 
+// the staged row segment of a wave's 32-pixel strip: pixels x0 - 2 .. x0 + 33 as they lie in the image
 template <int CIN>
-__global__ __launch_bounds__(CONV_THREADS, RS16_WAVES) __attribute__((amdgpu_waves_per_eu(RS16_WAVES, RS16_WAVES))) void conv_fwd_rs16_kernel(const ConvArgsN batch) {
+struct Rs16Seg {
   typedef Rs16Geom<CIN> G;
+  static constexpr int P = G::P, RK = G::RK, NCH = G::NCH;
+  static constexpr bool ODD = (CIN & 1) != 0;
+  static constexpr int NCOPY = ODD ? 2 : 1;                                 // (odd channel counts: a second copy displaced by one half)
+  static constexpr int PIX_BYTES = (32 + 2 * P) * CIN * 2;                  // the 36 pixels
+  static constexpr int NREAL = (PIX_BYTES + 4 + (ODD ? 2 : 0) + 15) / 16;   // 16-byte pieces loaded from the image (18 channels: the + 4 are the last window's ones slots)
+  static constexpr int WIN_BYTES = (31 * CIN + RK * (NCH - 1) + 32 + (ODD ? 1 : 0)) * 2;      // what the last pixel's last operand window reaches
+  static constexpr int NPIECE = (WIN_BYTES + 15) / 16 > NREAL ? (WIN_BYTES + 15) / 16 : NREAL; // (pieces behind the loaded ones are zeros: slots whose weights are zero)
+  static constexpr int CPYB = NPIECE * 16;
+  static constexpr int SEGB = NCOPY * CPYB + 16;                            // (+ a dump slot for the lanes a store does not concern)
+  static constexpr int NLOAD = (NPIECE + 63) / 64;                          // loads per copy, row and lane
+};
+
+template <int CIN>
+__global__ __launch_bounds__(CONV_THREADS, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_fwd_rs16_kernel(const ConvArgsN batch) {
+  typedef Rs16Geom<CIN> G;
+  typedef Rs16Seg<CIN> SG;
   constexpr int KS = G::KS, P = G::P, NCH = G::NCH, NPC = G::NPC, RK = G::RK, NSET = G::NSET;
-  static_assert((CIN & 1) == 0, "4-byte aligned operand windows");
-  static_assert(NCH == 3, "three chunks per row (the operand buffers alternate with 3 q + chunk)");
+  constexpr bool ODDC = SG::ODD;
+  constexpr int NCOPY = SG::NCOPY, NLOAD = SG::NLOAD, CPYB = SG::CPYB, SEGB = SG::SEGB;
+  static_assert(NCH >= 1 && NCH <= 3, "at most three chunks per row: 30 A operands = 120 registers");
+  static_assert((NCH * NSET) % 2 == 0, "the two operand buffers alternate with the chunk count: a block of NSET rows must hold an even number");
   constexpr int W = 64, Wp = 32;
-#ifdef RS16_TIMELINE
-  const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();
-#endif
   const ConvArgs& a = batch.a[blockIdx.y];
   // LDS: the restart values; per wave the pooled row on its way to the stores (160 f32 + 160 code bytes + a dump slot) and two staged
-  // input rows of its strip: pixels x0 - 2 .. x0 + 33 as they lie in the image, 36 CIN halves = 1296 bytes (+ 16 of over-read)
+  // input rows of its strip
   constexpr int TRB = 640 + 160 + 16;
-  constexpr int SEGB = (((32 + 2 * P) * CIN * 2 + 4 + 15) & ~15) + 16;      // (+ a dump slot for the lanes a store does not concern)
   constexpr int WVB = TRB + 2 * SEGB;
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[G::CT_BYTES + 4 * WVB];
   float* ct_lds = reinterpret_cast<float*>(lds_raw);
@@ -368,43 +370,79 @@ __global__ __launch_bounds__(CONV_THREADS, RS16_WAVES) __attribute__((amdgpu_wav
   const float inv = *reinterpret_cast<const float*>(rec + G::SC_OFF);
   const unsigned* pwt = reinterpret_cast<const unsigned*>(rec + G::PW_OFF);
   const unsigned ones = pwt[15];                              // (chunk 0, lane group 3, dword 3: both ones slots)
-  const int pt = lane % ((CIN / 2) > 0 ? (CIN / 2) : 1);      // dword t of two pivot pixels: channels 2 (t % (CIN / 2)), + 1
-  const unsigned pivw = pwt[((2 * pt) >> 3) * 4 + (((2 * pt) & 7) >> 1)];
+  // the pivot of channel c sits where k = c does: pw[chunk 0][c >> 3][(c & 7) >> 1], half c & 1
+  const auto pivot_word = [&](int c) __attribute__((always_inline)) { return pwt[(c >> 3) * 4 + ((c & 7) >> 1)]; };
 
   // ---- the image rows.  The strip's segment of a row is loaded as it lies in memory (16 contiguous bytes per lane: coalesced -- a lane
   // loading its own operand windows, as conv_k16.h does, asks the vector cache for 6 KB per row of which 1.3 KB are distinct, and that
-  // cache was the bound), goes through two registers into LDS two rows ahead of its use, the two pixels outside the image (SAME
-  // padding) are overwritten with the pivots there, and the operand windows are LDS reads at per-lane addresses.
+  // cache was the bound), goes through registers into LDS two rows ahead of its use, the two pixels outside the image (SAME padding)
+  // are overwritten with the pivots there, and the operand windows are LDS reads at per-lane addresses.
   const int rowbytes = W * CIN * 2;
   void* const in_base = (void*)((const char*)a.in + ((long)(a.img_slot ? a.img_slot[sb] : sb) * a.in_bstride) * 2 - 128);
   const int in_records = H * rowbytes + 128 + 256;
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(in_base, 0, in_records, 0x00020000);
-  constexpr int SEGL = ((32 + 2 * P) * CIN * 2 + 4 + 15) / 16;      // 16-byte pieces of a segment
-  const int gvA = 128 + (sstrip * 32 - P) * CIN * 2 + 16 * lane;
-  const int gvB = (64 + lane < SEGL) ? gvA + 1024 : 0x7FFFFFF0;      // (beyond the descriptor's range: zeros)
   unsigned char* xring = lds_raw + G::CT_BYTES + 4 * TRB + swave * 2 * SEGB;
-  const uint32_t xwA = keep_in_vgpr(lds_addr(xring + 16 * lane));
-  const uint32_t xwB = keep_in_vgpr(lds_addr(xring + ((64 + lane < SEGL) ? 1024 + 16 * lane : SEGB - 16)));
-  const uint32_t xpw = keep_in_vgpr(lds_addr(xring + (lane < CIN ? (sstrip == 0 ? 0 : (32 + P) * CIN * 2) + 4 * lane : SEGB - 16)));
+  int gv[NCOPY][NLOAD];
+  uint32_t xw[NCOPY][NLOAD];
+#pragma unroll
+  for (int cp = 0; cp < NCOPY; ++cp)
+#pragma unroll
+    for (int j = 0; j < NLOAD; ++j) {
+      const int piece = 64 * j + lane;
+      // (pieces behind the loaded ones: an offset beyond the descriptor's range reads zeros; lanes without a piece store to the dump slot)
+      gv[cp][j] = piece < SG::NREAL ? 128 + (sstrip * 32 - P) * CIN * 2 + 16 * piece - 2 * cp : 0x7FFFFFF0;
+      xw[cp][j] = keep_in_vgpr(lds_addr(xring + (piece < SG::NPIECE ? cp * CPYB + 16 * piece : SEGB - 16)));
+    }
+  // the border pixels' pivots: an even channel count writes dword t of the two pixels (channels 2 t mod CIN, + 1); an odd one the
+  // 2 CIN halves one by one, into both copies, and zeros over the halves between the 36th pixel and the end of the piece that holds it
+  // (image bytes that zero weights multiply: they must be finite, and behind the last slot of a store lies a guard band nobody wrote)
+  const int bhalf = sstrip == 0 ? 0 : (32 + P) * CIN;       // first half of the strip's two border pixels within the segment
+  uint32_t xpw[NCOPY];
+  unsigned pivw;
+  if (!ODDC) {
+    const int pt = lane % ((CIN / 2) > 0 ? (CIN / 2) : 1);
+    pivw = pivot_word(2 * pt);
+    xpw[0] = keep_in_vgpr(lds_addr(xring + (lane < CIN ? bhalf * 2 + 4 * lane : SEGB - 16)));
+  } else {
+    const int c = lane % CIN;
+    pivw = lane < 2 * CIN ? (pivot_word(c) >> (16 * (c & 1))) & 0xFFFFu : 0u;
+#pragma unroll
+    for (int cp = 0; cp < NCOPY; ++cp) {
+      const int nz = cp == 0 ? 4 : 3;                        // halves between the pixels' end and the piece's
+      const int h = lane < 2 * CIN ? bhalf + lane : (32 + 2 * P) * CIN + (lane - 2 * CIN);
+      xpw[cp] = keep_in_vgpr(lds_addr(xring + (lane < 2 * CIN + nz ? cp * CPYB + (h + cp) * 2 : SEGB - 16)));
+    }
+  }
+  // operand windows: pixel 2 li + m of the strip, chunk ch, lane group lj: halves (2 li + m) CIN + RK ch + 8 lj .. + 7 of the segment
   const uint32_t xrd = keep_in_vgpr(lds_addr(xring + (2 * li * CIN + 8 * lj) * 2));
   const uint32_t xrd1 = keep_in_vgpr(lds_addr(xring + SEGB + (2 * li * CIN + 8 * lj) * 2));
-  rs16_u32x4 stage[2];
+  rs16_u32x4 stage[NCOPY][NLOAD];
   auto load_row = [&](int q) __attribute__((always_inline)) {
-    stage[0] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, gvA, q * rowbytes, 0);
-    stage[1] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, gvB, q * rowbytes, 0);
+#pragma unroll
+    for (int cp = 0; cp < NCOPY; ++cp)
+#pragma unroll
+      for (int j = 0; j < NLOAD; ++j) stage[cp][j] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, gv[cp][j], q * rowbytes, 0);
   };
   auto stage_row = [&](int slot) __attribute__((always_inline)) {
-    lds_store(xwA, slot * SEGB, stage[0]);
-    lds_store(xwB, slot * SEGB, stage[1]);
-    lds_store(xpw, slot * SEGB, pivw);
+#pragma unroll
+    for (int cp = 0; cp < NCOPY; ++cp)
+#pragma unroll
+      for (int j = 0; j < NLOAD; ++j) lds_store(xw[cp][j], slot * SEGB, stage[cp][j]);
+    if (!ODDC) lds_store(xpw[0], slot * SEGB, pivw);
+    else {
+#pragma unroll
+      for (int cp = 0; cp < NCOPY; ++cp) lds_store_u16(xpw[cp], slot * SEGB, pivw);
+    }
   };
   k16_u32x4 xb[2][2];
   auto read_x = [&](int buf, int ch, int slot) __attribute__((always_inline)) {
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      unsigned t[4];                                           // (a 4-byte aligned ds_read_b128 is served at a fraction of the rate: dword reads, which the compiler pairs into ds_read2_b32)
+      // (the odd pixels of an odd channel count: the displaced copy, where they start on a dword)
+      const int off = (ODDC && m == 1) ? CPYB + (CIN + 1 + RK * ch) * 2 : (m * CIN + RK * ch) * 2;
+      unsigned t[4];                                           // (dword reads, which the compiler pairs into ds_read2_b32)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) t[i] = lds_load<unsigned>(slot ? xrd1 : xrd, (m * CIN + RK * ch) * 2 + 4 * i);
+      for (int i = 0; i < 4; ++i) t[i] = lds_load<unsigned>(slot ? xrd1 : xrd, off + 4 * i);
       xb[buf][m] = (k16_u32x4){t[0], t[1], t[2], lj == 3 ? ones : t[3]};
     }
   };
@@ -451,9 +489,6 @@ __global__ __launch_bounds__(CONV_THREADS, RS16_WAVES) __attribute__((amdgpu_wav
   }
   float tv[4] = {0.f, 0.f, 0.f, 0.f};
   bool xgt[4] = {false, false, false, false};
-#if defined(RS16_CLOCK_PROBE) || defined(RS16_TIMELINE)
-  const unsigned long long pc0 = __builtin_readcyclecounter(), pr0 = __builtin_amdgcn_s_memrealtime();
-#endif
   load_row(0);
   stage_row(0);
   load_row(1);
@@ -490,10 +525,10 @@ __global__ __launch_bounds__(CONV_THREADS, RS16_WAVES) __attribute__((amdgpu_wav
         }
         if (r0 == 0) {
           lds_store(twA, 0, (f32x2){pv[0], pv[1]});
-          lds_store(tcA, 0, (unsigned short)(code[0] | (code[1] << 8)));
+          lds_store_u16(tcA, 0, (unsigned)(code[0] | (code[1] << 8)));
         } else {
           lds_store(twB, 0, (f32x2){pv[2], pv[3]});
-          lds_store(tcB, 0, (unsigned short)(code[2] | (code[3] << 8)));
+          lds_store_u16(tcB, 0, (unsigned)(code[2] | (code[3] << 8)));
         }
       } else {
 #pragma unroll
@@ -528,7 +563,7 @@ __global__ __launch_bounds__(CONV_THREADS, RS16_WAVES) __attribute__((amdgpu_wav
     };
     auto mfmas = [&](auto chtag) __attribute__((always_inline)) {
       constexpr int ch = decltype(chtag)::value;
-      constexpr int BUF = (3 * SQ + ch) & 1;
+      constexpr int BUF = (NCH * SQ + ch) & 1;
 #pragma unroll
       for (int pc = NPC - 1; pc >= 0; --pc)
 #pragma unroll
@@ -539,35 +574,36 @@ __global__ __launch_bounds__(CONV_THREADS, RS16_WAVES) __attribute__((amdgpu_wav
           acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ky][ch][pc], __builtin_bit_cast(f16x8, xb[BUF][1]), first ? cg[1] : acc[s][1], 0, 0, 0);
         }
     };
+    // chunk ch of row q: the NEXT chunk's operands are requested (the next row's first chunk behind the last one), then this chunk's
+    // MFMAs, then a share of row yd's epilogue
+    auto chunk = [&](auto chtag) __attribute__((always_inline)) {
+      constexpr int ch = decltype(chtag)::value;
+      constexpr int NB = (NCH * SQ + ch + 1) & 1;
+      if (ch + 1 < NCH) read_x(NB, ch + 1, SLOT); else read_x(NB, 0, SLOT ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(chtag);
+      if (ch == 0) pool(0, 2);
+      if (ch == (NCH > 1 ? 1 : 0)) pool(2, 4);
+      if (ch == NCH - 1 && ODD) stores();
+    };
     if (!GEN || q < H) {
       // row q + 1 (in the staging registers since the last step) -> LDS; row q + 2 -> staging registers
       stage_row(SLOT ^ 1);
       load_row(q + 2);                                       // (behind the last row: beyond the descriptor's range, zeros nobody uses)
-      read_x((3 * SQ + 1) & 1, 1, SLOT);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(std::integral_constant<int, 0>{});
-      pool(0, 2);
-      read_x((3 * SQ + 2) & 1, 2, SLOT);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(std::integral_constant<int, 1>{});
-      pool(2, 4);
-      read_x((3 * SQ + 3) & 1, 0, SLOT ^ 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(std::integral_constant<int, 2>{});
-      if (ODD) stores();
+      chunk(std::integral_constant<int, 0>{});
+      if (NCH > 1) chunk(std::integral_constant<int, (NCH > 1 ? 1 : 0)>{});
+      if (NCH > 2) chunk(std::integral_constant<int, (NCH > 2 ? 2 : 0)>{});
       __builtin_amdgcn_sched_barrier(0);
     } else { pool(0, 2); pool(2, 4); if (ODD) stores(); }    // (steps behind the image: the last pooled rows)
   };
   auto block = [&](auto gentag, const int q0) __attribute__((always_inline)) {
     constexpr bool GEN = decltype(gentag)::value;
-#if RS16_ROTATE_PRIO
     {  // issue arbitration is by priority, then age: the older of a SIMD's two waves ran ahead (64 vs 88 us of a 91 us launch) and the
        // younger one finished alone at half the pipe's rate; the priorities rotate every NSET rows (as conv_k16.h's do)
       const int pr = ((int)blockIdx.y + q0 / NSET) & 3;
       if (pr == 0) __builtin_amdgcn_s_setprio(0); else if (pr == 1) __builtin_amdgcn_s_setprio(1);
       else if (pr == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
     }
-#endif
     if (GEN && q0 + 0 >= H + 3) return; step(std::integral_constant<int, 0>{}, gentag, q0 + 0);
     if (GEN && q0 + 1 >= H + 3) return; step(std::integral_constant<int, 1>{}, gentag, q0 + 1);
     if (GEN && q0 + 2 >= H + 3) return; step(std::integral_constant<int, 2>{}, gentag, q0 + 2);
@@ -579,17 +615,4 @@ __global__ __launch_bounds__(CONV_THREADS, RS16_WAVES) __attribute__((amdgpu_wav
   block(std::true_type{}, q0); q0 += NSET;
   for (; q0 + NSET <= H - 4; q0 += NSET) block(std::false_type{}, q0);
   for (; q0 < H + 3; q0 += NSET) block(std::true_type{}, q0);
-#ifdef RS16_TIMELINE
-  if (lane == 0) {
-    unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    unsigned long long* tl = reinterpret_cast<unsigned long long*>(a.partial) + 4 * ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + swave);
-    tl[0] = tl0; tl[1] = pr0; tl[2] = __builtin_amdgcn_s_memrealtime(); tl[3] = hwid;
-  }
-#endif
-#ifdef RS16_CLOCK_PROBE
-  if (lane == 0 && (blockIdx.x % 61) == 5 && blockIdx.y == 1 && swave == 0) {
-    const unsigned long long pc1 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
-    printf("RS16CLK block %d: %llu core cycles, %llu ref ticks (100 MHz) in the row loop -> %.3f GHz, %.1f cycles per row\n", (int)blockIdx.x, pc1 - pc0, pr1 - pr0, (double)(pc1 - pc0) / (10.0 * (double)(pr1 - pr0)), (double)(pc1 - pc0) / 64.0);
-  }
-#endif
 }

@@ -63,9 +63,6 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_apply_kernel(const OptSegs s,
     extern __shared__ __attribute__((aligned(16))) unsigned char img_lds[];
     __shared__ float wh[2 * CPP_MAX_CHANNELS];
     const int j = blockIdx.x, ws = s.img[j].seg;
-#ifdef RS16_IMAGE_PROBE
-    const unsigned long long ip0 = __builtin_amdgcn_s_memrealtime();
-#endif
     // the update's scale, as the workgroups of segment ws compute it below (same partials, same order)
     if (s.img[j].gw) {
       double tot = 0.0;
@@ -92,7 +89,7 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_apply_kernel(const OptSegs s,
     // increasing order, then the butterfly) -- with every load of the wave's channels in flight at once (channel after channel the
     // five round trips were 10 us of this workgroup)
     if (s.img[j].white) {
-      if ((int)threadIdx.x < 2 * 18) wh[threadIdx.x] = s.img[j].white[threadIdx.x];      // (finished by the dW reductions' launch)
+      if ((int)threadIdx.x < 2 * s.img_cin) wh[threadIdx.x] = s.img[j].white[threadIdx.x];      // (finished by the dW reductions' launch)
     } else {
       constexpr int NW = OPT_THREADS / 64, MAXC = (18 + NW - 1) / NW, MAXR = 8;
       const int wv = (int)(threadIdx.x >> 6), ln = (int)(threadIdx.x & 63), C = s.st_C, np_ = s.st_nparts;
@@ -124,15 +121,18 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_apply_kernel(const OptSegs s,
       }
     }
     __syncthreads();
-#ifdef RS16_IMAGE_PROBE
-    if (threadIdx.x == 0) printf("RS16RIDER job %d: norm + table %llu ticks\n", j, __builtin_amdgcn_s_memrealtime() - ip0);
-#endif
     Conv1ImageArgs ia;
-    ia.w = s.img[j].w; ia.bias = s.img[j].bias; ia.scale = wh; ia.shift = wh + 18; ia.wscale = 0.f; ia.nout = s.img[j].nout; ia.rec = s.img[j].rec;
+    ia.w = s.img[j].w; ia.bias = s.img[j].bias; ia.scale = wh; ia.shift = wh + s.img_cin; ia.wscale = 0.f; ia.nout = s.img[j].nout; ia.rec = s.img[j].rec;
     ia.gw = s.img[j].gw; ia.gb = s.img[j].gb; ia.lr = s.img[j].gw ? s.lr[ws] : 0.f; ia.gscale = s.img[j].gw ? sh_scale : 0.f;
     ia.w_out = s.img[j].gw ? s.img[j].w : nullptr; ia.b_out = s.img[j].gw ? s.img[j].bias : nullptr;
     ia.mw = (s.img[j].gw && s.kind == OPT_MOMENTUM) ? s.img[j].mw : nullptr; ia.mb = (s.img[j].gw && s.kind == OPT_MOMENTUM) ? s.img[j].mb : nullptr; ia.momentum = s.momentum;
-    conv1_image_body<18>(ia, img_lds);
+    switch (s.img_cin) {                                // (uniform: one of conv_fwd_rs16.hip's instances)
+      case 3: conv1_image_body<3>(ia, img_lds); break;
+      case 6: conv1_image_body<6>(ia, img_lds); break;
+      case 9: conv1_image_body<9>(ia, img_lds); break;
+      case 12: conv1_image_body<12>(ia, img_lds); break;
+      default: conv1_image_body<18>(ia, img_lds); break;
+    }
     return;
   }
   if (s.st_part && seg == s.nseg) {                  // the rider's grid row (uniform per workgroup)
@@ -210,13 +210,17 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_apply_kernel(const OptSegs s,
   }
 }
 
+static_assert(Rs16ImageLds<18>::BYTES >= Rs16ImageLds<12>::BYTES && Rs16ImageLds<18>::BYTES >= Rs16ImageLds<9>::BYTES &&
+              Rs16ImageLds<18>::BYTES >= Rs16ImageLds<6>::BYTES && Rs16ImageLds<18>::BYTES >= Rs16ImageLds<3>::BYTES, "the rider's LDS is sized for the largest instance");
 int launch_opt_apply(cpp_ctx* ctx, const OptSegs& s, float grad_scale, float clip, const double* part,
                      int nparts, float* norms_out) {
   prof_begin(ctx);
   const bool img = s.img_n > 0 && (s.st_part || s.img[0].white);
   const size_t lds = img ? (size_t)Rs16ImageLds<18>::BYTES : 0;
   if (img) {
-    if ((s.kind != OPT_SGD && s.kind != OPT_MOMENTUM) || (s.st_part && s.st_C != 18) || s.skip_if) { cpp_set_error("opt_apply: the conv1 image rider needs SGD or Momentum and 18 channels"); return 1; }
+    if ((s.kind != OPT_SGD && s.kind != OPT_MOMENTUM) || (s.st_part && s.st_C != s.img_cin) || !conv_rs16_channels_ok(s.img_cin) || s.skip_if) {
+      cpp_set_error("opt_apply: the conv1 image rider needs SGD or Momentum and a channel count conv_rs16.h is instantiated for (%d)", s.img_cin); return 1;
+    }
     static bool attr_done[CPP_MAX_DEVICES] = {};
     if (!attr_done[cpp_dev_slot(ctx)]) {
       HIP_CHECK(hipFuncSetAttribute((const void*)opt_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Rs16ImageLds<18>::BYTES));

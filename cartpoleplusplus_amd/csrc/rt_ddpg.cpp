@@ -237,7 +237,7 @@ static int apply(cpp_ddpg* d, bool do_actor, bool do_critic, float grad_scale, u
   const bool img = next && next_C > 0 && do_actor && do_critic && L0 && !d->actor->spec.use_batch_norm && !d->critic->spec.use_batch_norm &&
                    conv_rs16_ok(d->ctx, L0->Cin, L0->H, L0->W, kConvOut) && next_B >= 2;
   if (img) {
-    s.img_n = 4;
+    s.img_n = 4; s.img_cin = L0->Cin;
     for (int k = 0; k < 2; ++k) {      // conv1's weights and biases open the flat buffers (cpp_net_var_info order): [w_off, b_off + nout)
       const ConvL& L = inets[k]->conv[0];
       if (L.w_off != 0 || L.b_off != L.w_off + (long)L.ks * L.ks * L.Cin * kConvOut) { s.img_n = 0; break; }

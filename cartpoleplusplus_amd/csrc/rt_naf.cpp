@@ -360,7 +360,7 @@ static int naf_apply(cpp_naf* f, float grad_scale, bool unless_nonfinite = false
              (s.kind == OPT_SGD || s.kind == OPT_MOMENTUM) && conv_rs16_ok(f->ctx, L0->Cin, L0->H, L0->W, kConvOut) &&
              L0->w_off == 0 && L0->b_off == (long)L0->ks * L0->ks * L0->Cin * kConvOut;
   if (img) {
-    s.img_n = 2;
+    s.img_n = 2; s.img_cin = L0->Cin;
     s.img_skip[0] = L0->b_off + kConvOut;
     for (int j = 0; j < 2; ++j) {
       cpp_net* n = inets[j];

@@ -1,0 +1,75 @@
+"""Round 6: conv1 forward's row-streaming kernel (csrc/conv_rs16.h) at every channel count it is instantiated for -- 3, 6, 9 (cfg2),
+12 and 18 (cfg3) channels, 64 pixels wide -- against the (ky, o)-ring kernel it replaces there (csrc/conv_k16.h, still in the library for the
+other geometries; `CPP_CONV_RS16_CH=0` in the ablation build puts every count but 18 back on it).
+
+Both kernels issue the same products (raw f16 pixel x two f16 pieces of W s 2^S, the chunks' ones slots) and add them in the same order
+(chunk by chunk, ky inside a piece, f32 accumulators), so every pooled output whose 5x5 windows do not touch the image's left or right
+border must hold the SAME BITS; at the border columns the data-independent pivot remainder enters the accumulator at its restart instead
+of its end: a few f32 ulps of the pre-activation.  An odd channel count (9) reads its odd pixels from a second, displaced
+copy of the staged row -- an arrangement, not arithmetic.  (Parity with the float64 oracle on these kernels: test_gpu_fused_fullsize.py,
+test_gpu_render_inputs.py, test_gpu_fuzz.py run on them by default.)"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+_SNIPPET = r"""
+import sys
+import numpy as np
+from tests.helpers import make_pair, device_pool_codes
+shape, B = eval(sys.argv[1]), int(sys.argv[2])
+agent, _ref, _ = make_pair(shape, B, True, replay_size=4 * B)
+agent.replay_memory.fill_synthetic(3 * B, seed=33)
+idxs = np.arange(B, dtype=np.int32)
+agent.train_step(B, 1, idxs=idxs)
+out = {}
+for name, net in (("actor", agent.actor), ("critic", agent.critic), ("tactor", agent.target_actor), ("tcritic", agent.target_critic)):
+    if name in ("actor", "critic"):                      # (the target networks' f32 pool1 and codes are never written)
+        out[name + "_pool1"] = net.pool1.eval(B)
+        out[name + "_code1"] = device_pool_codes(net, B)["conv1"]
+    out[name + "_pool3"] = net.pool3.eval(B)
+out["grads"] = np.concatenate([agent.actor.get_grads(), agent.critic.get_grads()])
+np.savez(sys.argv[3], **out)
+agent.close()
+"""
+
+
+def _run(tmp_path, name, shape, B, extra):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / (name + ".npz"))
+    r = subprocess.run([sys.executable, "-c", _SNIPPET, repr(shape), str(B), out], cwd=root,
+                       env=dict(os.environ, CARTPOLEPP_ABLATION="1", **extra), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()[-1500:]
+    return dict(np.load(out))
+
+
+@pytest.mark.parametrize("shape,B", [
+    ((64, 64, 3, 1, 3), 256),        # cfg2: 9 channels, two chunks, the displaced copy
+    ((64, 64, 3, 1, 3), 5),          # odd batch: a workgroup with one image
+    ((64, 64, 3, 1, 1), 6),          # 3 channels: one chunk (15 of its 30 k), odd
+    ((64, 64, 3, 1, 2), 6),          # 6 channels: one full chunk
+    ((64, 64, 3, 2, 2), 6),          # 12 channels: two full chunks
+    ((32, 64, 3, 1, 3), 4),          # a shorter image (H = 32): the general blocks at both ends meet
+], ids=["cfg2-B256", "9ch-B5", "3ch", "6ch", "12ch", "9ch-32x64"])
+def test_row_streaming_conv1_at_other_channel_counts_equals_the_ring_kernel_away_from_the_borders(tmp_path, shape, B):
+    new = _run(tmp_path, "new", shape, B, {})
+    old = _run(tmp_path, "old", shape, B, {"CPP_CONV_RS16_CH": "0"})
+    for net in ("actor", "critic"):
+        pn, po = new[net + "_pool1"], old[net + "_pool1"]
+        assert np.isfinite(pn).all() and np.abs(pn).max() > 0
+        inner = (slice(None), slice(None), slice(1, -1))
+        assert np.array_equal(pn[inner], po[inner]), (net, np.abs(pn[inner] - po[inner]).max())
+        assert np.array_equal(new[net + "_code1"][inner], old[net + "_code1"][inner]), net
+        # border columns: the pivot remainder (<= 2^-12 of a term) enters at the restart: a few ulps of pre-activations of size ~10
+        d = np.abs(pn - po).max()
+        assert d <= 2e-5 * max(1.0, np.abs(po).max()), (net, d, np.abs(po).max())
+    # the target networks read conv1 through the bf16 planes only: compare what conv3 made of them
+    for net in ("actor", "critic", "tactor", "tcritic"):
+        d = np.abs(new[net + "_pool3"] - old[net + "_pool3"]).max()
+        assert d <= 2e-5 * max(1.0, np.abs(old[net + "_pool3"]).max()), (net, d)
+    g, go = new["grads"].astype(np.float64), old["grads"].astype(np.float64)
+    assert np.linalg.norm(g - go) <= 2e-5 * np.linalg.norm(go)
