@@ -5,22 +5,28 @@
 // through ds_read_b64_tr_b16, dY pieces as [piece][o][lane group][8 halves]), in conv_dw_rs.h's division of labour:
 //
 //   * a workgroup = one (image, band of rows); its four WAVES = {actor, critic} x {left, right 32-pixel column}.  A wave owns its
-//     unit's 7 x 4 accumulator tiles of D[m = (kx, c')][n = (ky, o)] (112 VGPRs): 56 MFMAs per input row, every A fragment read once
+//     unit's MT x 4 accumulator tiles of D[m = (kx, c')][n = (ky, o)] (18 channels: 7 x 4 = 112 VGPRs, 56 MFMAs per input row), every A fragment read once
 //     per row (conv_dw16.h: once per wave, four times per row and workgroup), NO barrier in the row loop -- the wave stages its own
 //     window of the row (its 32 pixels and P on each side, real pixels of the other column where there are any) and its own dY rows;
 //   * 2^S is the wave's own (the largest |pooled gradient| of its rows and columns); the column pair of a network is added through
 //     LDS after scaling back, left first, then whitened (T through a wave-private table) and written: one partial per workgroup
 //     and network, as conv_dw16.h's pair kernel leaves;
 //   * the bias gradient is row (kx = P, c' = CIN: the ones channel) x column (ky = P, o).
-// 64-wide rows of 18 channels, two f16 pieces (CPP_PRECISION_FAST), networks in pairs that read the same images (actor, critic).
+// 64-wide rows, two f16 pieces (CPP_PRECISION_FAST), networks in pairs that read the same images (actor, critic).  Instances: 18 channels
+// (7 x 4 tiles); 9 (4 x 4 tiles = 32 MFMAs per row: measured no faster than conv_dw16.h there, an opt-in of the ablation build).
 #pragma once
 #include <type_traits>
 #include "conv_dw16.h"
 
+template <int CIN_>
 struct Dw16RsGeom {
-  static constexpr int KS = 5, P = 2, PB = 2, CIN = 18, NO = KYO_NO, WC = 32, NPC = 2;
-  static constexpr int CP = 20;                               // channel pitch of a pixel in LDS (halves): 18 channels, the ones channel, one spare
-  static constexpr int MT = (KS * CP + 15) / 16, NT = (KS * NO + 15) / 16;      // 7 x 4 tiles
+  static constexpr int KS = 5, P = 2, PB = 2, CIN = CIN_, NO = KYO_NO, WC = 32, NPC = 2;
+  // channel pitch of a pixel in LDS (halves), as conv_dw16.h's: the channels, the ones channel, rounded to 8 bytes (18 channels: 20,
+  // one spare; 9: 12; 6: 8; 3: 4; 12: 16 + 4 -- a pitch of 0 (mod 8) dwords puts the 8 pixel quads of a transpose read on the same banks)
+  static constexpr int CP0 = (CIN + 1 + 3) & ~3;
+  static constexpr int CP = ((CP0 / 2) % 8 == 0) ? CP0 + 4 : CP0;
+  static constexpr bool ODD = (CIN & 1) != 0;                 // pixels are only 2-byte aligned in memory: a raw dword is stored half by half
+  static constexpr int MT = (KS * CP + 15) / 16, NT = (KS * NO + 15) / 16;      // 7 x 4 tiles at 18 channels, 4 x 4 at 9
   static constexpr int WPX = WC + 2 * P;                      // pixels of a staged row
   static constexpr int ROWB = 2 * (((CP * WPX + 16 * MT - KS * CP) + 7) & ~7);      // + the m over-read, bytes
   static constexpr int NXS = 2;
@@ -30,16 +36,19 @@ struct Dw16RsGeom {
   static constexpr int DSLOT = NPC * DPC;
   static constexpr int NDS = KS + 1;
   static constexpr int WVB = NXS * ROWB + NDS * DSLOT;        // per wave
-  static constexpr int SUMB = MT * NT * 64 * 16;              // a network's accumulators on their way to the partial: 28 tiles x 64 lanes x 16 bytes
+  static constexpr int SUMB = MT * NT * 64 * 16;              // a network's accumulators on their way to the partial: MT x NT tiles x 64 lanes x 16 bytes
+  static constexpr int BASEB = 4 * WVB > 2 * SUMB ? 4 * WVB : 2 * SUMB;      // the rings and the epilogue's sums share the front of the allocation
   static constexpr int TXB = NT * KS * 16 * 4;                // a wave's T table
-  static constexpr int LDS_BYTES = (2 * SUMB + 4 * TXB + 2 * CIN * 4 + 15) & ~15;
+  static constexpr int LDS_BYTES = (BASEB + 4 * TXB + 2 * CIN * 4 + 15) & ~15;
   static constexpr int NW = KS * KS * CIN * NO;
-  static_assert(ROWB % 16 == 0 && WVB % 16 == 0 && 4 * WVB <= 2 * SUMB, "the rings lie inside the epilogue's buffers");
+  static_assert(ROWB % 16 == 0 && WVB % 16 == 0 && BASEB % 16 == 0, "16-byte aligned slots");
+  static_assert(MT * NT * 4 <= 112, "the accumulators of a unit: at most 112 registers (18 channels); 30 channels would need 160");
 };
 
 // bx = image * nbands + band; by = the pair's first network (networks by and by + 1 read the same images with the same whitening)
+template <int CIN_>
 __device__ __forceinline__ void conv_dw16_rs_body(const ConvArgsN& batch, const int nbands, const int band, const int bx, const int by) {
-  typedef Dw16RsGeom G;
+  typedef Dw16RsGeom<CIN_> G;
   constexpr int KS = G::KS, P = G::P, PB = G::PB, CIN = G::CIN, NO = G::NO, WC = G::WC, CP = G::CP, MT = G::MT, NT = G::NT, NPC = G::NPC;
   constexpr int ROWB = G::ROWB, DOST = G::DOST, DPC = G::DPC, DSLOT = G::DSLOT, NDS = G::NDS;
   constexpr unsigned BIG = 0x08000000u;
@@ -51,7 +60,7 @@ __device__ __forceinline__ void conv_dw16_rs_body(const ConvArgsN& batch, const 
   unsigned char* wvb = dw16rs_lds + swave * G::WVB;
   unsigned char* xring = wvb;                                 // [NXS][ROWB]
   unsigned char* dzring = wvb + G::NXS * ROWB;                // [NDS][2 pieces][NO][DOST]
-  float* wsc = reinterpret_cast<float*>(dw16rs_lds + 2 * G::SUMB + 4 * G::TXB);      // [CIN] scale, [CIN] shift
+  float* wsc = reinterpret_cast<float*>(dw16rs_lds + G::BASEB + 4 * G::TXB);      // [CIN] scale, [CIN] shift
   const int H = a.H, Hp = H >> 1, W = a.W, Wp = W >> 1, nout = a.nout;
   const int ub = bx / nbands, bd = bx - ub * nbands;
   const int x0 = col * WC;
@@ -67,18 +76,33 @@ __device__ __forceinline__ void conv_dw16_rs_body(const ConvArgsN& batch, const 
     if (x >= 0 && x < W) *reinterpret_cast<unsigned short*>(xring + s * ROWB + 2 * (CP * wx + CIN)) = (unsigned short)0x3C00u;
   }
 
-  // ---- input rows: the raw dwords (two channels) of the window's pixels, idx = lane + 64 i = 9 wx + cp
-  constexpr int NXV = (G::WPX * (CIN / 2) + 63) / 64;
+  // ---- input rows: the raw dwords of the window's pixels.  Even channel count: idx = lane + 64 i = (CIN / 2) wx + cp, a dword = two
+  // channels of pixel wx.  Odd: the window's WPX CIN halves are contiguous in the image row and start on a dword (two padding pixels
+  // are an even number of halves): dword idx holds halves 2 idx, 2 idx + 1 -- of one pixel or of two neighbours -- and each goes to its
+  // own place in the pitched row (a dword is either wholly inside the image or wholly outside: the padding is 2 pixels = 2 CIN halves)
+  constexpr bool ODDC = G::ODD;
+  constexpr int NXV = ODDC ? (G::WPX * CIN / 2 + 63) / 64 : (G::WPX * (CIN / 2) + 63) / 64;
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<__half*>((const __half*)a.in + (long)(a.img_slot ? a.img_slot[ub] : ub) * a.in_bstride), 0, H * W * CIN * 2, 0x00020000);
-  unsigned xvo[NXV]; uint32_t xdst[NXV];
+  unsigned xvo[NXV]; uint32_t xdst[NXV]; uint32_t xdst_hi[ODDC ? NXV : 1];
 #pragma unroll
   for (int i = 0; i < NXV; ++i) {
-    const int idx = lane + 64 * i, wx = idx / (CIN / 2), cp = idx - (CIN / 2) * wx;
-    const int x = x0 - P + wx;
-    const bool on = idx < G::WPX * (CIN / 2);
-    xvo[i] = (on && x >= 0 && x < W) ? (unsigned)((x * CIN + 2 * cp) * 2) : BIG;
-    xdst[i] = keep_in_vgpr(lds_addr(xring + (on ? 2 * (CP * wx + 2 * cp) : ROWB - 8)));      // (idle lanes: zeros into the row's tail)
+    const int idx = lane + 64 * i;
+    if (!ODDC) {
+      const int wx = idx / (CIN / 2), cp = idx - (CIN / 2) * wx;
+      const int x = x0 - P + wx;
+      const bool on = idx < G::WPX * (CIN / 2);
+      xvo[i] = (on && x >= 0 && x < W) ? (unsigned)((x * CIN + 2 * cp) * 2) : BIG;
+      xdst[i] = keep_in_vgpr(lds_addr(xring + (on ? 2 * (CP * wx + 2 * cp) : ROWB - 8)));      // (idle lanes: zeros into the row's tail)
+    } else {
+      const int h0 = 2 * idx, h1 = 2 * idx + 1;
+      const int wx0 = h0 / CIN, wx1 = h1 / CIN;
+      const int x = x0 - P + wx0;                                // (both halves' pixels are inside the image or both outside)
+      const bool on = idx < G::WPX * CIN / 2;
+      xvo[i] = (on && x >= 0 && x < W) ? (unsigned)(((x0 - P) * CIN + h0) * 2) : BIG;
+      xdst[i] = keep_in_vgpr(lds_addr(xring + (on ? 2 * (CP * wx0 + (h0 - CIN * wx0)) : ROWB - 8)));
+      xdst_hi[i] = keep_in_vgpr(lds_addr(xring + (on ? 2 * (CP * wx1 + (h1 - CIN * wx1)) : ROWB - 6)));
+    }
   }
   unsigned xraw[2][NXV];                                      // two rows in flight
   auto x_load = [&](const int buf, const int q) __attribute__((always_inline)) {      // (the row offset in the VGPR: the range check does not see soffset)
@@ -88,7 +112,10 @@ __device__ __forceinline__ void conv_dw16_rs_body(const ConvArgsN& batch, const 
   };
   auto x_store = [&](const int buf, const int slot) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < NXV; ++i) lds_store(xdst[i], slot * ROWB, xraw[buf][i]);
+    for (int i = 0; i < NXV; ++i) {
+      if (!ODDC) lds_store(xdst[i], slot * ROWB, xraw[buf][i]);
+      else { lds_store_u16(xdst[i], slot * ROWB, xraw[buf][i] & 0xFFFFu); lds_store_u16(xdst_hi[i], slot * ROWB, xraw[buf][i] >> 16); }
+    }
   };
 
   // ---- dY rows: lane l < 40 owns channel o = l % 10 of lane group g = l / 10: the 16 bytes one lane of the B operand reads -- pixels
@@ -239,12 +266,14 @@ __device__ __forceinline__ void conv_dw16_rs_body(const ConvArgsN& batch, const 
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bq[nt][pc]), acc[mt][nt], 0, 0, 0);
-        if (mt == 0) { if (!ZODD) z_convert_half(ZBUF, 0); }
-        else if (mt == 1) { if (!ZODD) z_convert_half(ZBUF, 1); }
-        else if (mt == 2) z_store(ZPOS % NDS, ZODD ? 1 : 0);
-        else if (mt == 3) { if (ZODD) z_load(ZBUF, py0 + (t + PB + P + 1) / 2 + 2); }
-        else if (mt == 4) x_store((SQ + 1) & 1, XS ^ 1);
-        else if (mt == 5) x_load((SQ + 1) & 1, q_lo + t + 3);
+        // (the six staging tasks of a step, one behind each of the first row tiles' MFMAs; fewer than six row tiles: the rest behind the last)
+        constexpr int TL = MT - 1;
+        if (mt == (0 < TL ? 0 : TL)) { if (!ZODD) z_convert_half(ZBUF, 0); }
+        if (mt == (1 < TL ? 1 : TL)) { if (!ZODD) z_convert_half(ZBUF, 1); }
+        if (mt == (2 < TL ? 2 : TL)) z_store(ZPOS % NDS, ZODD ? 1 : 0);
+        if (mt == (3 < TL ? 3 : TL)) { if (ZODD) z_load(ZBUF, py0 + (t + PB + P + 1) / 2 + 2); }
+        if (mt == (4 < TL ? 4 : TL)) x_store((SQ + 1) & 1, XS ^ 1);
+        if (mt == (5 < TL ? 5 : TL)) x_load((SQ + 1) & 1, q_lo + t + 3);
         av = an;
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -287,7 +316,7 @@ __device__ __forceinline__ void conv_dw16_rs_body(const ConvArgsN& batch, const 
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[mt][nt][r] = o[r] + acc[mt][nt][r] * inv;
     }
-  float* tx = reinterpret_cast<float*>(dw16rs_lds + 2 * G::SUMB + swave * G::TXB);      // [NT][KS][16]
+  float* tx = reinterpret_cast<float*>(dw16rs_lds + G::BASEB + swave * G::TXB);      // [NT][KS][16]
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll

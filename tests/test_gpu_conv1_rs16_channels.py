@@ -73,3 +73,21 @@ def test_row_streaming_conv1_at_other_channel_counts_equals_the_ring_kernel_away
         assert d <= 2e-5 * max(1.0, np.abs(old[net + "_pool3"]).max()), (net, d)
     g, go = new["grads"].astype(np.float64), old["grads"].astype(np.float64)
     assert np.linalg.norm(g - go) <= 2e-5 * np.linalg.norm(go)
+
+
+@pytest.mark.parametrize("B", [256, 5])
+def test_wave_per_unit_conv1_dw_at_9_channels_agrees_with_the_kernel_it_does_not_replace(tmp_path, B):
+    """conv_dw16_rs.h (one wave per (network, 32-pixel column) unit) is templated on the channel count; its 9-channel instance (4 x 4
+    accumulator tiles per wave, raw dwords stored half by half at a 12-half pixel pitch) measured 43.0 us against conv_dw16.h's 40.4 at
+    cfg2 and stays an opt-in of the ablation build (`CPP_CONV1_DWRS_CH=1`).  Same forward pass, same products (raw pixel x two f16
+    pieces of dY 2^S), a different summation order and one 2^S per wave instead of per workgroup: a few f32 ulps of the gradient's
+    size, as for 18 channels (tests/test_gpu_backward_rs.py)."""
+    shape = (64, 64, 3, 1, 3)
+    new = _run(tmp_path, "new", shape, B, {"CPP_CONV1_DWRS_CH": "1"})["grads"].astype(np.float64)
+    old = _run(tmp_path, "old", shape, B, {})["grads"].astype(np.float64)
+    assert np.isfinite(new).all() and np.abs(new).max() > 0 and not np.array_equal(new, old)
+    h = len(new) // 2
+    for lo, hi, what in ((0, h, "actor"), (h, len(new), "critic")):
+        d = np.abs(new[lo:hi] - old[lo:hi]).max()
+        assert d <= 3e-6 * np.abs(old[lo:hi]).max(), (what, d, np.abs(old[lo:hi]).max())
+    assert np.linalg.norm(new - old) <= 2e-6 * np.linalg.norm(old)
