@@ -100,12 +100,19 @@ struct cpp_ctx {
   // Nearly constant channels (a blind camera with a rare off-colour pixel: whitening scale ~ 10^3 on values that do not cancel exactly):
   // the f16-pipe conv1 kernels multiply RAW pixels and cancel inside the MFMA, which on such a table sits ~4 x further from float64 than
   // whitening each element first, as the f32-input kernels (and the reference's TF graph, base_network.py:95-99) do.  The statistics
-  // kernels keep the largest scale of the step in white_max_dev; every training step ends with its copy to pinned host memory and a
-  // reset; the NEXT step's entry point reads the host word without waiting for anything and, above route_threshold, runs conv1 (forward
-  // and dW) and conv2 forward on the f32-input kernels until the scale is back under half of it.  kernel_epoch: bumped by every flip --
-  // the trainers' captured graphs are keyed on it.
-  unsigned* white_max_dev; unsigned* white_max_host; bool conv1_f32; uint64_t kernel_epoch; float route_threshold;
-  unsigned* white_max_host_dev;   // the pinned word's device address: the step's closing soft-update kernel writes it (route_rider)
+  // kernels keep the largest scale of a training call in white_max_dev; the call's last launch publishes it -- tagged with the call's
+  // number -- to pinned host memory and resets it; above route_threshold conv1 (forward and dW) and conv2 forward run on the f32-input
+  // kernels until the scale is back under half of it.  kernel_epoch: bumped by every flip -- the trainers' captured graphs are keyed on it.
+  // WHICH call's scale decides is a function of the program's order alone, never of host / GPU timing (round 6; rt_core.cpp:
+  // ctx_route_update): call k reads the scale of call k - 2 -- behind an event that guarantees it has landed -- or of call k - 1 if the
+  // caller has synchronised the stream since.  Two runs of the same program take the same routes at the same steps.
+  unsigned* white_max_dev; bool conv1_f32; uint64_t kernel_epoch; float route_threshold;
+  unsigned long long* route_pin;       // pinned: slot t & 1 = (tag t << 32 | float bits of the largest scale of call t)
+  unsigned long long* route_pin_dev;   // ... its device address: the call's closing soft-update kernel (route_rider) or route_publish_kernel writes it
+  unsigned* route_tag_dev;             // the number of the call that is running (written in stream order at every training entry point)
+  hipEvent_t route_ev[2];              // recorded at the entry of call k (slot k & 1): everything before call k has finished when it fires
+  uint64_t route_calls, route_done, route_min_tag;      // calls entered; calls known complete (a stream synchronisation since); tags below are ignored (threshold changed)
+  float route_last_max;                // the last scale a decision or cpp_ctx_get_route read
   bool route_rider;               // set by a step body in front of its target update: that launch also publishes and resets the scale word
   int n_trainers;                 // live cpp_ddpg / cpp_naf objects: their captured graphs pin the precision mode
 };
@@ -315,6 +322,19 @@ int launch_bn_backward(cpp_ctx* ctx, const BnBatch& bb);
 // (the next step's choice of conv1 kernels: reads the pinned word, flips cpp_ctx::conv1_f32; and the step's closing copy + reset)
 void ctx_route_update(cpp_ctx* ctx);
 int ctx_route_publish(cpp_ctx* ctx);
+// every stream synchronisation of the library goes through here: the calls entered so far are complete, which the route decision may use
+inline hipError_t ctx_sync_stream(cpp_ctx* ctx) {
+  const hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) ctx->route_done = ctx->route_calls;
+  return e;
+}
+// the publisher (device side): the scale word of the call that is running goes to its pinned slot, tagged; the word starts over
+__device__ __forceinline__ void route_publish_device(unsigned* wmax_dev, const unsigned* tag_dev, unsigned long long* pin) {
+  const unsigned m = *wmax_dev;
+  *wmax_dev = 0u;
+  const unsigned t = __hip_atomic_load(tag_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(pin + (t & 1u), ((unsigned long long)t << 32) | (unsigned long long)m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 int launch_stats_finalize(cpp_ctx* ctx, const double* part, int nparts, int which_count, int C,
                           double count, float* white, double eps = 1e-6, uint64_t* bump = nullptr, unsigned* wmax = nullptr);
 int launch_stats_generic(cpp_ctx* ctx, const void* x, int dtype, long npix, int C, float* white, double eps = 1e-6);

@@ -236,14 +236,10 @@ int launch_opt_apply(cpp_ctx* ctx, const OptSegs& s, float grad_scale, float cli
 
 // target.assign_sub(coeff * (target - source)) for every variable of the namespace
 __global__ void soft_update_kernel(float* t0, const float* s0, long n0, float* t1, const float* s1,
-                                   long n1, float coeff, unsigned* wmax_dev, unsigned* wmax_host) {
-  // (rider of a training step's last launch: the largest whitening scale the step saw goes to the pinned host word the next step's
-  // entry point reads, and the device word starts over -- cpp_ctx::white_max_dev, rt_core.cpp: ctx_route_update)
-  if (wmax_dev && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-    const unsigned m = *wmax_dev;
-    *wmax_dev = 0u;
-    __hip_atomic_store(wmax_host, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+                                   long n1, float coeff, unsigned* wmax_dev, const unsigned* tag_dev, unsigned long long* pin) {
+  // (rider of a training call's last launch: the largest whitening scale the call saw goes to its pinned slot, tagged with the call's
+  // number, and the device word starts over -- common.h: route_publish_device; rt_core.cpp: ctx_route_update)
+  if (wmax_dev && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) route_publish_device(wmax_dev, tag_dev, pin);
   float* t = blockIdx.y == 0 ? t0 : t1;
   const float* s = blockIdx.y == 0 ? s0 : s1;
   const long n = blockIdx.y == 0 ? n0 : n1;
@@ -256,10 +252,10 @@ __global__ void soft_update_kernel(float* t0, const float* s0, long n0, float* t
 int launch_soft_update(cpp_ctx* ctx, float* t0, const float* s0, long n0, float* t1, const float* s1,
                        long n1, float coeff) {
   prof_begin(ctx);
-  const bool pub = ctx->route_rider && ctx->white_max_host_dev != nullptr;
+  const bool pub = ctx->route_rider && ctx->route_pin_dev != nullptr;
   ctx->route_rider = false;
   hipLaunchKernelGGL(soft_update_kernel, dim3(128, t1 ? 2 : 1), dim3(256), 0, ctx->stream, t0, s0, n0,
-                     t1, s1, n1, coeff, pub ? ctx->white_max_dev : nullptr, pub ? ctx->white_max_host_dev : nullptr);
+                     t1, s1, n1, coeff, pub ? ctx->white_max_dev : nullptr, ctx->route_tag_dev, ctx->route_pin_dev);
   LAUNCH_CHECK();
   prof_end(ctx, K_SOFT_UPDATE);
   return 0;

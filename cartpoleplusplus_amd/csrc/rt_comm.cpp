@@ -35,7 +35,7 @@ extern "C" int cpp_comm_create(cpp_ctx* ctx, const void* unique_id, int rank, in
 extern "C" int cpp_comm_destroy(cpp_comm* c) {
   if (!c) return CPP_OK;
   (void)hipSetDevice(c->ctx->device);
-  (void)hipStreamSynchronize(c->ctx->stream);
+  (void)ctx_sync_stream(c->ctx);
   (void)hipStreamSynchronize(c->side);
   (void)ncclCommDestroy(c->comm);
   if (c->scratch) (void)hipFree(c->scratch);

@@ -84,33 +84,59 @@ extern "C" int cpp_ctx_create(int device_id, void* hip_stream, cpp_ctx** out) {
   HIP_CHECK(hipMemsetAsync(c->sq_part, 0, 2 * SQ_REGION * sizeof(double), c->stream));
   c->sq_n[0] = c->sq_n[1] = -1;
   for (int& g : c->sq_conv_group) g = -1;
-  // the largest whitening scale of a step, for the next step's choice of conv1 kernels (common.h: cpp_ctx::conv1_f32)
+  // the largest whitening scale of a training call, for a later call's choice of conv1 kernels (common.h: cpp_ctx::conv1_f32)
   HIP_CHECK(hipMalloc((void**)&c->white_max_dev, sizeof(unsigned)));
   HIP_CHECK(hipMemsetAsync(c->white_max_dev, 0, sizeof(unsigned), c->stream));
-  HIP_CHECK(hipHostMalloc((void**)&c->white_max_host, sizeof(unsigned), hipHostMallocDefault));
-  *c->white_max_host = 0u;
-  HIP_CHECK(hipHostGetDevicePointer((void**)&c->white_max_host_dev, c->white_max_host, 0));
+  HIP_CHECK(hipMalloc((void**)&c->route_tag_dev, sizeof(unsigned)));
+  HIP_CHECK(hipMemsetAsync(c->route_tag_dev, 0xFF, sizeof(unsigned), c->stream));      // (no call is running)
+  HIP_CHECK(hipHostMalloc((void**)&c->route_pin, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+  c->route_pin[0] = c->route_pin[1] = ~0ull;
+  HIP_CHECK(hipHostGetDevicePointer((void**)&c->route_pin_dev, c->route_pin, 0));
+  for (hipEvent_t& e : c->route_ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  c->route_calls = c->route_done = c->route_min_tag = 0; c->route_last_max = 0.f;
   c->route_threshold = 100.f;
   *out = c;
   return CPP_OK;
 }
 
-// Called by every training entry point before it launches anything: the pinned word holds the largest whitening scale of a step that
-// has FINISHED (one or two calls back: nobody waits for it).  Above the threshold conv1 runs on the f32-input kernels; it comes back
+// the largest scale of call t, if its publish has landed under tag t (0: nothing published -- no statistics in that call, or it failed)
+static bool route_read(cpp_ctx* ctx, uint64_t t, float* m) {
+  const unsigned long long w = *reinterpret_cast<volatile unsigned long long*>(ctx->route_pin + (t & 1));
+  const unsigned bits = (unsigned)w;
+  if ((unsigned)(w >> 32) != (unsigned)t || bits == 0u) return false;
+  memcpy(m, &bits, sizeof(*m));
+  return true;
+}
+// Called by every training entry point before it launches anything.  Call k decides from the scale call T published, T = k - 2 -- or
+// k - 1 if the stream has been synchronised since call k - 1 was entered (ctx_sync_stream: eager passes in front of a graph capture,
+// cpp_sync, parameter reads): T depends on the ORDER of the caller's calls only.  The event recorded at the entry of call k - 1 fires
+// when everything before it -- call k - 2 and its publish -- has finished; in a loop that runs ahead of the GPU by one call it has
+// fired long ago.  (Round 5 read the pinned word "without waiting for anything": which later step first saw a glint depended on when
+// the closing kernel of an earlier graph happened to land.)  Above the threshold conv1 runs on the f32-input kernels; it comes back
 // once the scale has fallen under half of it.  A flip moves kernel_epoch, on which the trainers' captured graphs are keyed.
 void ctx_route_update(cpp_ctx* ctx) {
-  if (!ctx->white_max_host || !(ctx->route_threshold > 0.f)) return;
-  const unsigned bits = *reinterpret_cast<volatile unsigned*>(ctx->white_max_host);
-  float m; memcpy(&m, &bits, sizeof(m));
-  if (bits == 0u) return;                             // (no statistics since the last reset: keep the mode)
-  const bool want = ctx->conv1_f32 ? m > 0.5f * ctx->route_threshold : m > ctx->route_threshold;
-  if (want != ctx->conv1_f32) { ctx->conv1_f32 = want; ctx->kernel_epoch++; }
+  if (!ctx->route_pin) return;
+  const uint64_t k = ctx->route_calls;
+  long long T = (long long)k - 2;
+  if ((long long)ctx->route_done - 1 > T) T = (long long)ctx->route_done - 1;
+  else if (k >= 2) (void)hipEventSynchronize(ctx->route_ev[(k - 1) & 1]);
+  float m = 0.f;
+  if (ctx->route_threshold > 0.f && T >= (long long)ctx->route_min_tag && route_read(ctx, (uint64_t)T, &m)) {
+    ctx->route_last_max = m;
+    const bool want = ctx->conv1_f32 ? m > 0.5f * ctx->route_threshold : m > ctx->route_threshold;
+    if (want != ctx->conv1_f32) { ctx->conv1_f32 = want; ctx->kernel_epoch++; }
+  }
+  // this call: its entry event, and its number for the publishers among its launches (stream order: behind call k - 1's last launch)
+  (void)hipEventRecord(ctx->route_ev[k & 1], ctx->stream);
+  (void)hipMemsetD32Async((hipDeviceptr_t)ctx->route_tag_dev, (int)(unsigned)k, 1, ctx->stream);
+  ctx->route_calls = k + 1;
 }
-// ... and by every training step as its last stream operations (inside its captured graph): copy to the host word, reset
+// ... and by every training step whose last launch is not a target update (which carries the publish as a rider: optim.hip), inside its captured graph
+__global__ void route_publish_kernel(unsigned* wmax_dev, const unsigned* tag_dev, unsigned long long* pin) { route_publish_device(wmax_dev, tag_dev, pin); }
 int ctx_route_publish(cpp_ctx* ctx) {
-  if (!ctx->white_max_host) return CPP_OK;
-  HIP_CHECK(hipMemcpyAsync(ctx->white_max_host, ctx->white_max_dev, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_CHECK(hipMemsetAsync(ctx->white_max_dev, 0, sizeof(unsigned), ctx->stream));
+  if (!ctx->route_pin) return CPP_OK;
+  hipLaunchKernelGGL(route_publish_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->white_max_dev, ctx->route_tag_dev, ctx->route_pin_dev);
+  LAUNCH_CHECK();
   return CPP_OK;
 }
 
@@ -118,17 +144,21 @@ extern "C" int cpp_ctx_set_route_threshold(cpp_ctx* c, float threshold) {
   ARG_CHECK(c, "cpp_ctx_set_route_threshold: ctx is NULL");
   ARG_CHECK(threshold >= 0.f, "cpp_ctx_set_route_threshold: threshold %g", threshold);
   c->route_threshold = threshold;
-  if (c->white_max_host) *c->white_max_host = 0u;      // (what was seen under the old threshold decides nothing any more)
+  c->route_min_tag = c->route_calls;                   // (what the calls so far saw under the old threshold decides nothing any more)
   if (threshold == 0.f && c->conv1_f32) { c->conv1_f32 = false; c->kernel_epoch++; }
   return CPP_OK;
 }
+// last_max_scale: the largest whitening scale of the newest call known to have finished (after cpp_sync: the last one entered)
 extern "C" int cpp_ctx_get_route(cpp_ctx* c, int* conv1_f32, float* last_max_scale) {
   ARG_CHECK(c, "cpp_ctx_get_route: ctx is NULL");
   if (conv1_f32) *conv1_f32 = c->conv1_f32 ? 1 : 0;
-  if (last_max_scale) { const unsigned bits = c->white_max_host ? *reinterpret_cast<volatile unsigned*>(c->white_max_host) : 0u; memcpy(last_max_scale, &bits, 4); }
+  if (last_max_scale) {
+    float m = c->route_last_max;
+    if (c->route_pin && c->route_done >= 1) (void)route_read(c, c->route_done - 1, &m);
+    *last_max_scale = m;
+  }
   return CPP_OK;
 }
-
 extern "C" int cpp_ctx_set_precision(cpp_ctx* c, int mode) {
   ARG_CHECK(c, "cpp_ctx_set_precision: ctx is NULL");
   ARG_CHECK(mode == CPP_PRECISION_FAST || mode == CPP_PRECISION_EXACT, "cpp_ctx_set_precision: mode %d is neither CPP_PRECISION_FAST nor CPP_PRECISION_EXACT", mode);
@@ -152,7 +182,8 @@ extern "C" int cpp_ctx_destroy(cpp_ctx* c) {
   (void)hipEventDestroy(c->pe0); (void)hipEventDestroy(c->pe1);
   if (c->sq_part) (void)hipFree(c->sq_part);
   if (c->white_max_dev) (void)hipFree(c->white_max_dev);
-  if (c->white_max_host) (void)hipHostFree(c->white_max_host);
+  if (c->route_tag_dev) (void)hipFree(c->route_tag_dev);
+  if (c->route_pin) { (void)hipHostFree(c->route_pin); for (hipEvent_t e : c->route_ev) (void)hipEventDestroy(e); }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return CPP_OK;
@@ -160,7 +191,7 @@ extern "C" int cpp_ctx_destroy(cpp_ctx* c) {
 
 extern "C" int cpp_sync(cpp_ctx* c) {
   ARG_CHECK(c, "cpp_sync: ctx is NULL");
-  HIP_CHECK(hipStreamSynchronize(c->stream));
+  HIP_CHECK(ctx_sync_stream(c));
   return CPP_OK;
 }
 

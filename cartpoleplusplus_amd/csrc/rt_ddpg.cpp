@@ -68,7 +68,7 @@ extern "C" int cpp_ddpg_create(cpp_ctx* ctx, cpp_net* actor, cpp_net* critic, cp
   if (!rc) rc = launch_fill(ctx, d->ones, 1, 0, 1, d->maxB, 1.0f);
   if (rc) { d->arena.release(); delete d; return rc; }
   actor->grads = d->gradbuf; critic->grads = d->gradbuf + d->nA;
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  HIP_CHECK(ctx_sync_stream(ctx));
   ctx->n_trainers += 1;
   *out = d;
   return CPP_OK;
@@ -101,7 +101,7 @@ static void route_check(cpp_ddpg* d) {
 extern "C" int cpp_ddpg_destroy(cpp_ddpg* d) {
   if (!d) return CPP_OK;
   (void)hipSetDevice(d->ctx->device);
-  (void)hipStreamSynchronize(d->ctx->stream);
+  (void)ctx_sync_stream(d->ctx);
   if (d->gexec) (void)hipGraphExecDestroy(d->gexec);
   if (d->graph) (void)hipGraphDestroy(d->graph);
   if (d->dgexec) (void)hipGraphExecDestroy(d->dgexec);
@@ -675,7 +675,7 @@ extern "C" int cpp_ddpg_train_rows(cpp_ddpg* d, cpp_replay* r, int B, const int3
     if (d->rgraph) { (void)hipGraphDestroy(d->rgraph); d->rgraph = nullptr; }
     d->rgraph_ok = false;
     RC(step_body(d, r, B, 1, r->rows_in, 0, false));          // eager pass: kernel attributes; it is also this call's minibatch
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK(ctx_sync_stream(ctx));
     RC(capture_into(ctx, &d->rgraph, &d->rgexec, [&] { return step_body(d, r, B, 1, r->rows_in, 0, false); }));
     d->rgraph_ok = true; d->rg_B = B; d->rg_replay_uid = r->uid;
     return CPP_OK;
@@ -710,7 +710,7 @@ extern "C" int cpp_ddpg_train_step(cpp_ddpg* d, cpp_replay* r, int B, int n_batc
     d->graph_ok = false;
     // one eager pass first: it sets every kernel's LDS attribute (not allowed during capture)
     RC(step_body(d, r, B, n_batches, nullptr, seed));
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK(ctx_sync_stream(ctx));
     HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     int rc = step_body(d, r, B, n_batches, nullptr, seed);
     hipError_t e = hipStreamEndCapture(ctx->stream, &d->graph);
@@ -810,13 +810,13 @@ static int half_step(cpp_ddpg* d, cpp_replay* r, int B, uint64_t seed, bool spli
     int nx = 0;
     if (v == 0) {
       RC(eager(0, &next));
-      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      HIP_CHECK(ctx_sync_stream(ctx));
       RC(capture(0, &nx));
       H.ok[0] = true; H.next[0] = nx;
       d->pre_variant = next;
       return CPP_OK;
     }
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK(ctx_sync_stream(ctx));
     RC(capture(v, &nx));
     H.ok[v] = true; H.next[v] = nx;
   }
@@ -903,7 +903,7 @@ extern "C" int cpp_ddpg_dp_train_step(cpp_ddpg* d, cpp_replay* r, cpp_comm* c, i
       if (d->dgraph) { (void)hipGraphDestroy(d->dgraph); d->dgraph = nullptr; }
       d->dgraph_ok = false;
       RC(step_body(d, r, B, n_batches, nullptr, seed, true, true, c));      // eager pass: kernel attributes; it is also this call's step
-      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      HIP_CHECK(ctx_sync_stream(ctx));
       if (d->dgraph_refused) return CPP_OK;           // (capture failed once on this trainer: every step takes the eager sequence above)
       // No N > 1 box has run this yet: if the runtime or RCCL refuses to capture / instantiate the step with the collective inside,
       // the trainer keeps the SAME sequence as plain stream launches (identical arithmetic on every rank, no graph) instead of failing.
@@ -976,7 +976,7 @@ extern "C" int cpp_ddpg_last_stats(cpp_ddpg* d, float out[3]) {
   double parts[DDPG_HEADS_MAX_WGS];
   if (d->loss_parts > 0)
     HIP_CHECK(hipMemcpyAsync(parts, d->heads_part, (size_t)d->loss_parts * sizeof(double), hipMemcpyDeviceToHost, d->ctx->stream));
-  HIP_CHECK(hipStreamSynchronize(d->ctx->stream));
+  HIP_CHECK(ctx_sync_stream(d->ctx));
   if (d->loss_parts > 0) {                          // fused heads kernel: mean(td^2) from its per-workgroup partials, fixed order
     double s = 0.0;
     for (int i = 0; i < d->loss_parts; ++i) s += parts[i];

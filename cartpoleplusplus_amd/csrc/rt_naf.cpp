@@ -82,7 +82,7 @@ extern "C" int cpp_naf_create(cpp_ctx* ctx, cpp_net* value, cpp_net* tvalue, cpp
     mu->ws[0].fcin[0] = value->ws[0].fcin.back();
     lv->ws[0].fcin[0] = value->ws[0].fcin.back();
   }
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  HIP_CHECK(ctx_sync_stream(ctx));
   ctx->n_trainers += 1;
   *out = f;
   return CPP_OK;
@@ -91,7 +91,7 @@ extern "C" int cpp_naf_create(cpp_ctx* ctx, cpp_net* value, cpp_net* tvalue, cpp
 extern "C" int cpp_naf_destroy(cpp_naf* f) {
   if (!f) return CPP_OK;
   (void)hipSetDevice(f->ctx->device);
-  (void)hipStreamSynchronize(f->ctx->stream);
+  (void)ctx_sync_stream(f->ctx);
   if (f->hexec) (void)hipGraphExecDestroy(f->hexec);
   if (f->hgraph) (void)hipGraphDestroy(f->hgraph);
   if (f->dgexec) (void)hipGraphExecDestroy(f->dgexec);
@@ -397,7 +397,7 @@ extern "C" int cpp_naf_action(cpp_naf* f, const void* state, int dtype, int B, f
   n->is_training = true; f->mu->is_training = true;
   if (frc) return frc;
   HIP_CHECK(hipMemcpyAsync(out, f->mu->ws[0].out, (size_t)B * f->A * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  HIP_CHECK(ctx_sync_stream(ctx));
   return CPP_OK;
 }
 
@@ -432,7 +432,7 @@ extern "C" int cpp_naf_train(cpp_naf* f, cpp_batch* b, float* loss) {
   int bad = 0; float l = 0.f;
   HIP_CHECK(hipMemcpyAsync(&bad, f->nonfinite, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIP_CHECK(hipMemcpyAsync(&l, f->stats, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  HIP_CHECK(ctx_sync_stream(ctx));
   if (loss) *loss = l;
   if (bad) { cpp_set_error("check_numerics: l_values / L / loss is not finite (naf_cartpole.py:242-245)"); return CPP_ERR_NUMERIC; }
   return naf_apply(f, 1.0f);
@@ -545,7 +545,7 @@ extern "C" int cpp_naf_train_step(cpp_naf* f, cpp_replay* r, int B, int n_batche
     if (f->graph) { (void)hipGraphDestroy(f->graph); f->graph = nullptr; }
     f->graph_ok = false;
     RC(naf_step_body(f, r, B, n_batches, nullptr, seed));
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK(ctx_sync_stream(ctx));
     HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     int rc = naf_step_body(f, r, B, n_batches, nullptr, seed);
     hipError_t e = hipStreamEndCapture(ctx->stream, &f->graph);
@@ -590,7 +590,7 @@ extern "C" int cpp_naf_train_rows(cpp_naf* f, cpp_replay* r, int B, const int32_
     if (f->rgraph) { (void)hipGraphDestroy(f->rgraph); f->rgraph = nullptr; }
     f->rgraph_ok = false;
     RC(naf_rows_body(f, r, B));                      // eager pass: sets kernel attributes, is this call's work
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK(ctx_sync_stream(ctx));
     HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     const int rc = naf_rows_body(f, r, B);
     const hipError_t e = hipStreamEndCapture(ctx->stream, &f->rgraph);
@@ -604,7 +604,7 @@ extern "C" int cpp_naf_train_rows(cpp_naf* f, cpp_replay* r, int B, const int32_
   int bad = 0; float l = 0.f;
   HIP_CHECK(hipMemcpyAsync(&bad, f->nonfinite, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIP_CHECK(hipMemcpyAsync(&l, f->stats, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  HIP_CHECK(ctx_sync_stream(ctx));
   if (loss) *loss = l;
   if (bad) { cpp_set_error("check_numerics: l_values / L / loss is not finite (naf_cartpole.py:242-245)"); return CPP_ERR_NUMERIC; }
   return naf_apply(f, 1.0f);
@@ -640,7 +640,7 @@ extern "C" int cpp_naf_train_rows_async(cpp_naf* f, cpp_replay* r, int B, const 
     if (f->agraph) { (void)hipGraphDestroy(f->agraph); f->agraph = nullptr; }
     f->agraph_ok = false;
     RC(naf_rows_apply_body(f, r, B));                // eager pass: sets kernel attributes, is this call's work
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK(ctx_sync_stream(ctx));
     HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     const int rc = naf_rows_apply_body(f, r, B);
     const hipError_t e = hipStreamEndCapture(ctx->stream, &f->agraph);
@@ -703,7 +703,7 @@ extern "C" int cpp_naf_sample_and_compute(cpp_naf* f, cpp_replay* r, int B, uint
     if (f->hgraph) { (void)hipGraphDestroy(f->hgraph); f->hgraph = nullptr; }
     f->hgraph_ok = false;
     RC(naf_half_body(f, r, B, seed));                // eager pass: sets kernel attributes, is this call's work
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK(ctx_sync_stream(ctx));
     HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     const int rc = naf_half_body(f, r, B, seed);
     const hipError_t e = hipStreamEndCapture(ctx->stream, &f->hgraph);
@@ -769,7 +769,7 @@ extern "C" int cpp_naf_dp_train_step(cpp_naf* f, cpp_replay* r, cpp_comm* c, int
       if (f->dgraph) { (void)hipGraphDestroy(f->dgraph); f->dgraph = nullptr; }
       f->dgraph_ok = false;
       RC(naf_step_body(f, r, B, n_batches, nullptr, seed, true, c));
-      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      HIP_CHECK(ctx_sync_stream(ctx));
       if (f->dgraph_refused) return CPP_OK;
       // (as cpp_ddpg_dp_train_step: a runtime / RCCL that refuses the capture leaves the same sequence as plain stream launches)
       HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
@@ -810,7 +810,7 @@ extern "C" int cpp_naf_last_stats(cpp_naf* f, float out[3]) {
   int bad = 0;
   HIP_CHECK(hipMemcpyAsync(out, f->stats, 2 * sizeof(float), hipMemcpyDeviceToHost, f->ctx->stream));
   HIP_CHECK(hipMemcpyAsync(&bad, f->nonfinite, sizeof(int), hipMemcpyDeviceToHost, f->ctx->stream));
-  HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
+  HIP_CHECK(ctx_sync_stream(f->ctx));
   out[2] = (float)bad;
   return CPP_OK;
 }

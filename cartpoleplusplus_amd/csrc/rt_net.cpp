@@ -135,7 +135,7 @@ extern "C" int cpp_net_create(cpp_ctx* ctx, const cpp_net_spec* spec, int max_ba
       if ((rc = dalloc(n->arena, &n->bn_scratch, (size_t)kConvOut))) return fail(rc);
     }
   }
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  HIP_CHECK(ctx_sync_stream(ctx));
   *out = n;
   return CPP_OK;
 }
@@ -143,7 +143,7 @@ extern "C" int cpp_net_create(cpp_ctx* ctx, const cpp_net_spec* spec, int max_ba
 extern "C" int cpp_net_destroy(cpp_net* n) {
   if (!n) return CPP_OK;
   (void)hipSetDevice(n->ctx->device);
-  (void)hipStreamSynchronize(n->ctx->stream);
+  (void)ctx_sync_stream(n->ctx);
   n->arena.release();
   delete n;
   return CPP_OK;
@@ -166,14 +166,14 @@ extern "C" int cpp_net_set_params(cpp_net* n, const float* host, int64_t cnt) {
   ARG_CHECK(cnt == n->nparams, "cpp_net_set_params: got %ld values, network has %ld", (long)cnt, n->nparams);
   n->wimg_key = nullptr;
   HIP_CHECK(hipMemcpyAsync(n->params, host, cnt * sizeof(float), hipMemcpyHostToDevice, n->ctx->stream));
-  HIP_CHECK(hipStreamSynchronize(n->ctx->stream));
+  HIP_CHECK(ctx_sync_stream(n->ctx));
   return CPP_OK;
 }
 extern "C" int cpp_net_get_params(cpp_net* n, float* host, int64_t cnt) {
   ARG_CHECK(n && host, "cpp_net_get_params: NULL argument");
   ARG_CHECK(cnt == n->nparams, "cpp_net_get_params: asked %ld values, network has %ld", (long)cnt, n->nparams);
   HIP_CHECK(hipMemcpyAsync(host, n->params, cnt * sizeof(float), hipMemcpyDeviceToHost, n->ctx->stream));
-  HIP_CHECK(hipStreamSynchronize(n->ctx->stream));
+  HIP_CHECK(ctx_sync_stream(n->ctx));
   return CPP_OK;
 }
 extern "C" int cpp_net_get_grads(cpp_net* n, float* host, int64_t cnt) {
@@ -181,7 +181,7 @@ extern "C" int cpp_net_get_grads(cpp_net* n, float* host, int64_t cnt) {
   ARG_CHECK(cnt == n->nparams, "cpp_net_get_grads: asked %ld values, network has %ld", (long)cnt, n->nparams);
   if (!n->grads) { cpp_set_error("cpp_net_get_grads: network has no train op (init_ops_for_training not called)"); return CPP_ERR_STATE; }
   HIP_CHECK(hipMemcpyAsync(host, n->grads, cnt * sizeof(float), hipMemcpyDeviceToHost, n->ctx->stream));
-  HIP_CHECK(hipStreamSynchronize(n->ctx->stream));
+  HIP_CHECK(ctx_sync_stream(n->ctx));
   return CPP_OK;
 }
 
@@ -596,7 +596,7 @@ extern "C" int cpp_net_forward(cpp_net* n, const void* state, int state_dtype, i
   n->is_training = true;
   if (frc) return frc;
   HIP_CHECK(hipMemcpyAsync(out, n->ws[0].out, (size_t)B * no * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  HIP_CHECK(ctx_sync_stream(ctx));
   return CPP_OK;
 }
 
@@ -640,7 +640,7 @@ extern "C" int cpp_net_forward_each(cpp_net* n, const void* state, int state_dty
   n->is_training = true;
   if (frc) return frc;
   HIP_CHECK(hipMemcpyAsync(out, n->ws[0].out, (size_t)B * no * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  HIP_CHECK(ctx_sync_stream(ctx));
   return CPP_OK;
 }
 
@@ -652,7 +652,7 @@ extern "C" int cpp_net_get_pool(cpp_net* n, int which, int B, float* out) {
     const size_t cnt = (size_t)B * L.Hp * L.Wp * kConvOut;
     std::vector<uint8_t> tmp(cnt);
     HIP_CHECK(hipMemcpyAsync(tmp.data(), n->ws[0].amax[which - 11], cnt, hipMemcpyDeviceToHost, n->ctx->stream));
-    HIP_CHECK(hipStreamSynchronize(n->ctx->stream));
+    HIP_CHECK(ctx_sync_stream(n->ctx));
     for (size_t i = 0; i < cnt; ++i) out[i] = (float)(tmp[i] & 3);      // (bit 2 of the byte: "the pooled output is > 0", conv_kyo.h POOL_ACTIVE)
     return CPP_OK;
   }
@@ -661,7 +661,7 @@ extern "C" int cpp_net_get_pool(cpp_net* n, int which, int B, float* out) {
     ARG_CHECK(n->ws[0].dpool[which - 21], "cpp_net_get_pool: no gradient workspace");
     const size_t cnt = (size_t)B * L.Hp * L.Wp * kConvOut;
     HIP_CHECK(hipMemcpyAsync(out, n->ws[0].dpool[which - 21], cnt * sizeof(float), hipMemcpyDeviceToHost, n->ctx->stream));
-    HIP_CHECK(hipStreamSynchronize(n->ctx->stream));
+    HIP_CHECK(ctx_sync_stream(n->ctx));
     return CPP_OK;
   }
   ARG_CHECK(n->spec.pixel && which >= 1 && which <= 3, "cpp_net_get_pool: which=%d (pixel nets, 1..3)", which);
@@ -669,7 +669,7 @@ extern "C" int cpp_net_get_pool(cpp_net* n, int which, int B, float* out) {
   const size_t row = (size_t)L.Hp * L.Wp * kConvOut * sizeof(float);
   const size_t spitch = (which == 3) ? ((size_t)n->flat + 1) * sizeof(float) : row;
   HIP_CHECK(hipMemcpy2DAsync(out, row, n->ws[0].pool[which - 1], spitch, row, B, hipMemcpyDeviceToHost, n->ctx->stream));
-  HIP_CHECK(hipStreamSynchronize(n->ctx->stream));
+  HIP_CHECK(ctx_sync_stream(n->ctx));
   return CPP_OK;
 }
 

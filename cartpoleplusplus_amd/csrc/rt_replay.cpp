@@ -138,7 +138,7 @@ static int replay_create(cpp_ctx* ctx, int buffer_size, int state_slots, int64_t
 static int replay_set_size(cpp_replay* r, int size) {
   r->size = size;
   HIP_CHECK(hipMemcpyAsync(r->size_dev, &r->size, sizeof(int32_t), hipMemcpyHostToDevice, r->ctx->stream));
-  HIP_CHECK(hipStreamSynchronize(r->ctx->stream));
+  HIP_CHECK(ctx_sync_stream(r->ctx));
   return CPP_OK;
 }
 extern "C" int cpp_replay_create(cpp_ctx* ctx, int buffer_size, int state_slots, int64_t state_elems,
@@ -152,7 +152,7 @@ extern "C" int cpp_replay_create_ex(cpp_ctx* ctx, int buffer_size, int state_slo
 extern "C" int cpp_replay_destroy(cpp_replay* r) {
   if (!r) return CPP_OK;
   (void)hipSetDevice(r->ctx->device);
-  (void)hipStreamSynchronize(r->ctx->stream);
+  (void)ctx_sync_stream(r->ctx);
   if (r->stage) (void)hipFree(r->stage);
   if (r->slot_list) (void)hipFree(r->slot_list);
   if (r->pinned) (void)hipHostFree(r->pinned);
@@ -186,13 +186,13 @@ extern "C" int cpp_replay_set_stats_channels(cpp_replay* r, int channels) {
   ++r->write_gen;              // (a minibatch presampled under the old setting is stale)
   if (C == 0) { r->stats_C = 0; return CPP_OK; }          // (the buffer, if any, stays allocated and unused)
   if (!r->slot_stats || r->stats_cap < C) {          // (switching off and on again reuses the buffer)
-    HIP_CHECK(hipStreamSynchronize(r->ctx->stream));
+    HIP_CHECK(ctx_sync_stream(r->ctx));
     RC(dalloc(r->arena, &r->slot_stats, (size_t)r->slots * 2 * C));
     r->stats_cap = C;
   }
   r->stats_C = C;
   RC(launch_slot_stats(r->ctx, r->store, r->store_dtype, r->elems, C, r->slot_stats, nullptr, 0, r->slots, r->lut));
-  HIP_CHECK(hipStreamSynchronize(r->ctx->stream));
+  HIP_CHECK(ctx_sync_stream(r->ctx));
   return CPP_OK;
 }
 
@@ -443,7 +443,7 @@ extern "C" int cpp_replay_sample(cpp_replay* r, int B, const int32_t* idxs, uint
 extern "C" int cpp_replay_last_indexes(cpp_replay* r, int B, int32_t* out) {
   ARG_CHECK(r && out && B >= 1 && B <= 65536, "cpp_replay_last_indexes: bad argument");
   HIP_CHECK(hipMemcpyAsync(out, r->rows_out, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, r->ctx->stream));
-  HIP_CHECK(hipStreamSynchronize(r->ctx->stream));
+  HIP_CHECK(ctx_sync_stream(r->ctx));
   return CPP_OK;
 }
 
@@ -456,7 +456,7 @@ extern "C" int cpp_replay_fill_synthetic(cpp_replay* r, int n_rows, uint64_t see
                         r->action, r->reward, r->mask, n_rows, r->A, seed));
   if (r->store_dtype == CPP_U8) RC(launch_replay_fill_u8(r->ctx, (uint8_t*)r->store, r->elems * (long)r->slots, seed));
   if (r->slot_stats && r->stats_C > 0) RC(launch_slot_stats(r->ctx, r->store, r->store_dtype, r->elems, r->stats_C, r->slot_stats, nullptr, 0, r->slots, r->lut));
-  HIP_CHECK(hipStreamSynchronize(r->ctx->stream));
+  HIP_CHECK(ctx_sync_stream(r->ctx));
   return replay_set_size(r, n_rows);
 }
 

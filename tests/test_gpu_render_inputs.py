@@ -75,8 +75,9 @@ def test_nearly_constant_channels_run_on_the_f32_input_kernels_and_meet_the_floa
     from float64 here, so the bars are relative to it.  The f16-pipe conv1 kernels multiply the RAW pixel and cancel inside the
     MFMA: 2.6e-4 from float64 on conv1 outputs where float32 numpy is 1.3e-4 and the f32-input kernel, which whitens each element
     first as base_network.py:95-99 does, 0.7e-4 (rounds 1-4 shipped that, behind a factor-3 bar and without looking at a gradient).
-    Round 5: the step publishes the largest whitening scale it saw and the NEXT step runs conv1 (forward and dW) on the f32-input
-    kernels (cpp_ctx_set_route_threshold, default 100) -- here the captured first step sees 990, the measured second one is routed.
+    Round 5: the step publishes the largest whitening scale it saw and a LATER step runs conv1 (forward and dW) on the f32-input
+    kernels (cpp_ctx_set_route_threshold, default 100; round 6: the next one if the stream was synchronised in between, the one after it
+    otherwise -- never a matter of timing) -- here the captured first step sees 990 (and synchronises), the measured second one is routed.
     Every bar of the ordinary render test then holds at the ordinary factor, gradients included."""
     from cartpoleplusplus_amd import _lib
     # (atol: the helper's absolute bars are north_star's 1e-5, which float32 numpy itself misses here by 2.4x on actions and 12x on TD; the
@@ -135,6 +136,37 @@ def test_the_route_follows_the_whitening_scale_and_can_be_switched_off():
         assert not ctx.route()[0] and ctx.route()[1] < 4.0
     finally:
         agent.close()
+
+
+def test_the_route_is_a_function_of_the_calls_not_of_host_timing():
+    """Round 5 read the published scale "without waiting for anything": which later step first ran on the f32-input kernels depended on
+    when an earlier graph's closing kernel happened to land, so two runs of one seed could differ.  Round 6: call k decides from call
+    k - 2's scale (k - 1's if the stream was synchronised in between), behind an event -- a function of the program's order alone.  The
+    same glint episodes trained twice, once with the host racing ahead of the GPU and once with the host asleep between the calls (every
+    step long finished before the next is entered): identical parameters, bit for bit, and both runs routed."""
+    import time
+    from cartpoleplusplus_amd import _lib
+    ctx = _lib.default_context()
+
+    def run(pause):
+        ctx.sync(); ctx.set_route_threshold(0.0); ctx.set_route_threshold(100.0)
+        agent, _ref, _ = make_pair(CFG3, 64, True, seed=3, replay_size=700)
+        try:
+            fill_with_rendered_episodes(agent, CFG3, 300, seed=4, blind_camera=True, glint=0.02)
+            for _ in range(8):
+                agent.train_step(64, 2)
+                if pause:
+                    time.sleep(pause)
+            ctx.sync()
+            return (np.concatenate([agent.actor.get_params(), agent.critic.get_params(), agent.target_actor.get_params()]), ctx.route())
+        finally:
+            agent.close()
+
+    p_fast, r_fast = run(0.0)
+    p_slow, r_slow = run(0.02)
+    assert r_fast[0] and r_slow[0] and r_fast[1] > 300.0, (r_fast, r_slow)
+    assert np.isfinite(p_fast).all()
+    assert np.array_equal(p_fast, p_slow), np.abs(p_fast - p_slow).max()
 
 
 def _flat_images(B, shape, rng):
