@@ -679,6 +679,15 @@ __device__ __forceinline__ void conv_dw_reduce_body(const DwReduceBatch& rb, con
     float s = 0.f;
     if (e < n) {
       int b = b0;
+      // (32 partials in flight, then 8, then one by one -- added in list order whatever the batch: the same bits; a slice of 32 partials
+      // -- conv1's 512 workgroups over 16 slices -- is one round trip instead of four)
+      for (; b + 32 <= b1; b += 32) {
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = d.partial[(long)(b + u) * d.pstride + e];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) s += v[u];
+      }
       for (; b + 8 <= b1; b += 8) {
         float v[8];
 #pragma unroll

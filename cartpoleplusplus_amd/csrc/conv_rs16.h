@@ -58,8 +58,11 @@ struct Conv1ImageArgs {
 };
 struct Conv1ImageArgsN { Conv1ImageArgs a[CONV_BATCH_MAX]; int n; };
 
-template <int CIN, int NPCS = F16_PIECES>
-__device__ __forceinline__ void conv1_image_body(const Conv1ImageArgs& a, unsigned char* lds_raw) {
+// pre(): called once the loads of the weights (gradients, accumulators) are in flight, returns the gradient scale of the update that
+// rides here -- optim.hip's rider adds up the clipping norm and fetches the whitening table in there, under the loads' latency
+struct Conv1ImageNoPre { __device__ __forceinline__ float operator()(float gscale) const { return gscale; } };
+template <int CIN, int NPCS = F16_PIECES, typename Pre = Conv1ImageNoPre>
+__device__ __forceinline__ void conv1_image_body(const Conv1ImageArgs& a, unsigned char* lds_raw, Pre pre = Pre()) {
   typedef Rs16Geom<CIN, NPCS> G;
   constexpr int KS = G::KS, P = G::P, NO = G::NO, NCH = G::NCH, NPC = G::NPC, RK = G::RK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -81,6 +84,7 @@ __device__ __forceinline__ void conv1_image_body(const Conv1ImageArgs& a, unsign
   // floats -- a thread fetching its own 24 (ky, k, o) values asked for 40-byte strides, 2.6 us of this workgroup (6.5 with the gradients)
   float* wst = reinterpret_cast<float*>(lds_raw);              // [KS * KROW * nout] -- in the record's place, which is written later
   const int nwts = KS * G::KROW * nout;
+  float gscale_b = a.gscale;
   {
     constexpr int NWT = (KS * G::KROW * NO + CONV_THREADS - 1) / CONV_THREADS;      // (every load in flight before the first use)
     float wr[NWT], gr[NWT];
@@ -95,16 +99,18 @@ __device__ __forceinline__ void conv1_image_body(const Conv1ImageArgs& a, unsign
         for (int n = 0; n < NWT; ++n) { const int i = tid + n * CONV_THREADS; mr[n] = a.mw[i < nwts ? i : 0]; }
       }
     }
+    const float gscale = pre(a.gscale);
+    gscale_b = gscale;
 #pragma unroll
     for (int n = 0; n < NWT; ++n) {
       const int i = tid + n * CONV_THREADS;
       if (i < nwts) {
         float w = wr[n];
         if (a.gw && a.mw) {                                    // (opt_apply_kernel's own expressions)
-          const float acc = momentum_accum(mr[n], gr[n], a.gscale, a.momentum);
+          const float acc = momentum_accum(mr[n], gr[n], gscale, a.momentum);
           a.mw[i] = acc;
           w = momentum_step(w, acc, a.lr);
-        } else if (a.gw) w = sgd_update(w, gr[n], a.gscale, a.lr);
+        } else if (a.gw) w = sgd_update(w, gr[n], gscale, a.lr);
         wst[i] = w;
         if (a.gw && a.w_out) a.w_out[i] = w;
       }
@@ -128,8 +134,8 @@ __device__ __forceinline__ void conv1_image_body(const Conv1ImageArgs& a, unsign
   if (tid < 16) {
     float bo = (a.bias && tid < nout) ? a.bias[tid] : 0.f;
     if (a.bias && a.gb && tid < nout) {
-      if (a.mb) { const float acc = momentum_accum(a.mb[tid], a.gb[tid], a.gscale, a.momentum); a.mb[tid] = acc; bo = momentum_step(bo, acc, a.lr); }
-      else bo = sgd_update(bo, a.gb[tid], a.gscale, a.lr);
+      if (a.mb) { const float acc = momentum_accum(a.mb[tid], a.gb[tid], gscale_b, a.momentum); a.mb[tid] = acc; bo = momentum_step(bo, acc, a.lr); }
+      else bo = sgd_update(bo, a.gb[tid], gscale_b, a.lr);
       if (a.b_out) a.b_out[tid] = bo;
     }
     biasn[tid] = bo;

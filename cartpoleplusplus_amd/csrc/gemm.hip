@@ -73,6 +73,21 @@ __device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (
 #pragma unroll
   for (int i = 0; i < S; ++i) { abase[i] = (int)((long)mrow[i] * g.sAm * 4); bbase[i] = (int)((long)ncol[i] * g.sBn * 4); }
   const int ask = (int)(g.sAk * 4), bsk = (int)(g.sBk * 4);
+  // the epilogue's own operands (the forward activation of a ReLU / tanh gradient, the running C of an accumulating GEMM) are requested
+  // HERE, by the wave that will use them: behind the reduction they were one more round trip to the memory side per level
+  float ypre[S][S][4], cpre[S][S][4];
+  const bool want_y = g.Y != nullptr && (g.epi == GE_MUL_RELU_GRAD || g.epi == GE_MUL_RELU_GRAD_X2 || g.epi == GE_MUL_TANH_GRAD || g.epi == GE_ACTOR_HEAD);
+#pragma unroll
+  for (int ti = 0; ti < S; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < S; ++tj)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (tm * S + ti) * 16 + 4 * lj + i, n = ncol[tj];
+        const bool on = wave == 0 && nv[tj] && row < g.M;
+        ypre[ti][tj][i] = (on && want_y) ? g.Y[(long)row * g.ldy + n] : 0.f;
+        cpre[ti][tj][i] = (on && g.accumulate) ? g.C[(long)row * g.ldc + n] : 0.f;
+      }
   // A wave's rounds are independent until the MFMAs: ALL operand loads of up to GEMM_R rounds are issued before the first
   // one is used.  Same k order, same summation order as a plain loop.
   constexpr int R = GEMM_R;
@@ -147,11 +162,11 @@ __device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (
     if (nv[tj] && row < g.M) {
       const int ri = (ti * S + tj) * 256 + lane * 4 + i;
       float v = ((acc[ti][tj][i] + red[0][ri]) + red[1][ri]) + red[2][ri];
-      if (g.accumulate) v += g.C[(long)row * g.ldc + n];
+      if (g.accumulate) v += cpre[ti][tj][i];
       if (g.epi == GE_RELU) v = fmaxf(v, 0.f);
       else if (g.epi == GE_TANH) v = tanhf(v);
-      else if (g.epi == GE_MUL_RELU_GRAD) v = g.Y[(long)row * g.ldy + n] > 0.f ? v : 0.f;
-      else if (g.epi == GE_MUL_RELU_GRAD_X2) v = g.Y[(long)row * g.ldy + n] > 0.f ? 2.f * v : 0.f;
+      else if (g.epi == GE_MUL_RELU_GRAD) v = ypre[ti][tj][i] > 0.f ? v : 0.f;
+      else if (g.epi == GE_MUL_RELU_GRAD_X2) v = ypre[ti][tj][i] > 0.f ? 2.f * v : 0.f;
       else if (g.epi == GE_RELU_DROPOUT) {
         v = fmaxf(v, 0.f);
         if (g.drop_counter) {
@@ -160,10 +175,10 @@ __device__ __forceinline__ void gemm_tile_t(const GemmArgs& g, int tile, float (
           v = (philox4x32_10(c, g.drop_seed, 0u).x & 1u) ? 2.f * v : 0.f;
         }
       }
-      else if (g.epi == GE_MUL_TANH_GRAD) { const float y = g.Y[(long)row * g.ldy + n]; v = v * (1.f - y * y); }
+      else if (g.epi == GE_MUL_TANH_GRAD) { const float y = ypre[ti][tj][i]; v = v * (1.f - y * y); }
       g.C[(long)row * g.ldc + n] = v;
       sq += (double)v * (double)v;
-      if (g.epi == GE_ACTOR_HEAD) { const float y = g.Y[(long)row * g.ldy + n]; g.C2[(long)row * g.ldc2 + n] = -v * (1.f - y * y); }
+      if (g.epi == GE_ACTOR_HEAD) { const float y = ypre[ti][tj][i]; g.C2[(long)row * g.ldc2 + n] = -v * (1.f - y * y); }
       else if (g.C2) g.C2[(long)row * g.ldc2 + n] = v;
     }
   }

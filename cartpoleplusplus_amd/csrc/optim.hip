@@ -49,6 +49,19 @@ int launch_sumsq(cpp_ctx* ctx, const OptSegs& s, float grad_scale, double* part,
   return 0;
 }
 
+// a lane's share of a list of f64 partials, added in list order -- eight loads in flight at a time (a `tot += q[i]` loop over ~500
+// partials was eight dependent round trips in front of every update: the launch's longest chain)
+__device__ __forceinline__ double lane_sum_f64(const double* q, const int count, const int lane, double tot = 0.0) {
+  for (int i = lane; i < count; i += 8 * 64) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int j = i + 64 * u; v[u] = q[j < count ? j : i]; }      // (no branch around a load)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) tot += (i + 64 * u < count) ? v[u] : 0.0;      // (x + 0.0 is x: squares are never -0.0)
+  }
+  return tot;
+}
+
 // g <- g * clip * min(1/norm, 1/clip) with norm over the segment's group (clip <= 0: no clipping), then
 //   SGD      : p -= lr * g
 //   Momentum : m = momentum * m + g;  p -= lr * m
@@ -63,75 +76,79 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_apply_kernel(const OptSegs s,
     extern __shared__ __attribute__((aligned(16))) unsigned char img_lds[];
     __shared__ float wh[2 * CPP_MAX_CHANNELS];
     const int j = blockIdx.x, ws = s.img[j].seg;
+    // (run by conv1_image_body once its weight / gradient loads are in flight)
+    auto pre = [&](float) __attribute__((always_inline)) -> float {
     // the update's scale, as the workgroups of segment ws compute it below (same partials, same order)
-    if (s.img[j].gw) {
-      double tot = 0.0;
-      if (threadIdx.x < 64) {
-        if (s.sq) {
-          const int gr = s.group[ws];
-          const double* q = s.sq + s.sq_begin[gr];
-          for (int i = threadIdx.x; i < s.sq_count[gr]; i += 64) tot += q[i];
-        } else {
-          for (int k = 0; k < s.nseg; ++k)
-            if (s.group[k] == s.group[ws])
-              for (int i = threadIdx.x; i < nparts; i += 64) tot += part[k * nparts + i];
-        }
-        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
-      }
-      if (threadIdx.x == 0) {
-        const float norm = (float)sqrt(tot);
-        float sc = 1.f;
-        if (clip > 0.f) sc = clip * fminf(1.f / norm, 1.f / clip);
-        sh_scale = sc * grad_scale;
-      }
-    }
-    // the whitening table of the network's state column, as the first rider's waves compute it (stats_finalize_wave: a lane's rows in
-    // increasing order, then the butterfly) -- with every load of the wave's channels in flight at once (channel after channel the
-    // five round trips were 10 us of this workgroup)
-    if (s.img[j].white) {
-      if ((int)threadIdx.x < 2 * s.img_cin) wh[threadIdx.x] = s.img[j].white[threadIdx.x];      // (finished by the dW reductions' launch)
-    } else {
-      constexpr int NW = OPT_THREADS / 64, MAXC = (18 + NW - 1) / NW, MAXR = 8;
-      const int wv = (int)(threadIdx.x >> 6), ln = (int)(threadIdx.x & 63), C = s.st_C, np_ = s.st_nparts;
-      if (np_ <= 64 * MAXR) {
-        double v[MAXC][MAXR][2];
-#pragma unroll
-        for (int k = 0; k < MAXC; ++k) {
-          const int c = wv + NW * k;
-#pragma unroll
-          for (int r = 0; r < MAXR; ++r) {
-            const int b = ln + 64 * r;
-            const bool ok = c < C && b < np_;
-            const double* q = s.st_part + ((long)s.img[j].col * np_ + (ok ? b : 0)) * 2 * C;
-            v[k][r][0] = ok ? q[c] : 0.0; v[k][r][1] = ok ? q[C + c] : 0.0;
+      if (s.img[j].gw) {
+        double tot = 0.0;
+        if (threadIdx.x < 64) {
+          if (s.sq) {
+            const int gr = s.group[ws];
+            const double* q = s.sq + s.sq_begin[gr];
+            tot = lane_sum_f64(q, s.sq_count[gr], (int)threadIdx.x);
+          } else {
+            for (int k = 0; k < s.nseg; ++k)
+              if (s.group[k] == s.group[ws])
+                tot = lane_sum_f64(part + k * nparts, nparts, (int)threadIdx.x, tot);
           }
+          for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
         }
-#pragma unroll
-        for (int k = 0; k < MAXC; ++k) {
-          const int c = wv + NW * k;
-          double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-          for (int r = 0; r < MAXR; ++r) if (ln + 64 * r < np_) { a0 += v[k][r][0]; a1 += v[k][r][1]; }
-          for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); }
-          if (ln == 0 && c < C) white_from_moments(a0, a1, s.st_count, s.st_eps, &wh[c], &wh[C + c]);
+        if (threadIdx.x == 0) {
+          const float norm = (float)sqrt(tot);
+          float sc = 1.f;
+          if (clip > 0.f) sc = clip * fminf(1.f / norm, 1.f / clip);
+          sh_scale = sc * grad_scale;
         }
-      } else {
-        for (int c = wv; c < C; c += NW)
-          stats_finalize_wave_to(s.st_part, np_, C, s.st_count, &wh[c], &wh[C + c], s.st_eps, s.img[j].col, c, ln);
       }
-    }
-    __syncthreads();
+      // the whitening table of the network's state column, as the first rider's waves compute it (stats_finalize_wave: a lane's rows in
+      // increasing order, then the butterfly) -- with every load of the wave's channels in flight at once (channel after channel the
+      // five round trips were 10 us of this workgroup)
+      if (s.img[j].white) {
+        if ((int)threadIdx.x < 2 * s.img_cin) wh[threadIdx.x] = s.img[j].white[threadIdx.x];      // (finished by the dW reductions' launch)
+      } else {
+        constexpr int NW = OPT_THREADS / 64, MAXC = (18 + NW - 1) / NW, MAXR = 8;
+        const int wv = (int)(threadIdx.x >> 6), ln = (int)(threadIdx.x & 63), C = s.st_C, np_ = s.st_nparts;
+        if (np_ <= 64 * MAXR) {
+          double v[MAXC][MAXR][2];
+#pragma unroll
+          for (int k = 0; k < MAXC; ++k) {
+            const int c = wv + NW * k;
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r) {
+              const int b = ln + 64 * r;
+              const bool ok = c < C && b < np_;
+              const double* q = s.st_part + ((long)s.img[j].col * np_ + (ok ? b : 0)) * 2 * C;
+              v[k][r][0] = ok ? q[c] : 0.0; v[k][r][1] = ok ? q[C + c] : 0.0;
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < MAXC; ++k) {
+            const int c = wv + NW * k;
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r) if (ln + 64 * r < np_) { a0 += v[k][r][0]; a1 += v[k][r][1]; }
+            for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); }
+            if (ln == 0 && c < C) white_from_moments(a0, a1, s.st_count, s.st_eps, &wh[c], &wh[C + c]);
+          }
+        } else {
+          for (int c = wv; c < C; c += NW)
+            stats_finalize_wave_to(s.st_part, np_, C, s.st_count, &wh[c], &wh[C + c], s.st_eps, s.img[j].col, c, ln);
+        }
+      }
+      __syncthreads();
+      return s.img[j].gw ? sh_scale : 0.f;
+    };
     Conv1ImageArgs ia;
     ia.w = s.img[j].w; ia.bias = s.img[j].bias; ia.scale = wh; ia.shift = wh + s.img_cin; ia.wscale = 0.f; ia.nout = s.img[j].nout; ia.rec = s.img[j].rec;
-    ia.gw = s.img[j].gw; ia.gb = s.img[j].gb; ia.lr = s.img[j].gw ? s.lr[ws] : 0.f; ia.gscale = s.img[j].gw ? sh_scale : 0.f;
+    ia.gw = s.img[j].gw; ia.gb = s.img[j].gb; ia.lr = s.img[j].gw ? s.lr[ws] : 0.f; ia.gscale = 0.f;      // (the scale: pre's return value)
     ia.w_out = s.img[j].gw ? s.img[j].w : nullptr; ia.b_out = s.img[j].gw ? s.img[j].bias : nullptr;
     ia.mw = (s.img[j].gw && s.kind == OPT_MOMENTUM) ? s.img[j].mw : nullptr; ia.mb = (s.img[j].gw && s.kind == OPT_MOMENTUM) ? s.img[j].mb : nullptr; ia.momentum = s.momentum;
     switch (s.img_cin) {                                // (uniform: one of conv_fwd_rs16.hip's instances)
-      case 3: conv1_image_body<3>(ia, img_lds); break;
-      case 6: conv1_image_body<6>(ia, img_lds); break;
-      case 9: conv1_image_body<9>(ia, img_lds); break;
-      case 12: conv1_image_body<12>(ia, img_lds); break;
-      default: conv1_image_body<18>(ia, img_lds); break;
+      case 3: conv1_image_body<3, F16_PIECES>(ia, img_lds, pre); break;
+      case 6: conv1_image_body<6, F16_PIECES>(ia, img_lds, pre); break;
+      case 9: conv1_image_body<9, F16_PIECES>(ia, img_lds, pre); break;
+      case 12: conv1_image_body<12, F16_PIECES>(ia, img_lds, pre); break;
+      default: conv1_image_body<18, F16_PIECES>(ia, img_lds, pre); break;
     }
     return;
   }
@@ -148,11 +165,11 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_apply_kernel(const OptSegs s,
     if (s.sq) {          // partials left by the kernels that wrote the gradients (cpp_ctx::sq_part), slot order
       const int gr = s.group[seg];
       const double* q = s.sq + s.sq_begin[gr];
-      for (int i = threadIdx.x; i < s.sq_count[gr]; i += 64) tot += q[i];
+      tot = lane_sum_f64(q, s.sq_count[gr], (int)threadIdx.x);
     } else {
       for (int k = 0; k < s.nseg; ++k)
         if (s.group[k] == s.group[seg])
-          for (int i = threadIdx.x; i < nparts; i += 64) tot += part[k * nparts + i];
+          tot = lane_sum_f64(part + k * nparts, nparts, (int)threadIdx.x, tot);
     }
     for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
   }
