@@ -20,9 +20,6 @@
 #pragma once
 #include <type_traits>
 #include "conv_dwb16.h"
-#ifndef DWRS_INTERLEAVE
-#define DWRS_INTERLEAVE 1
-#endif
 
 template <int KS_>
 struct DwRsGeom {
@@ -285,7 +282,6 @@ __device__ __forceinline__ void conv_dw_rs_body(const ConvArgsN& batch, const in
         else if (blk == 5) x_store1((SQ + 1) & 1, XS ^ 1, 2);
         else if (blk == 6) { x_load((SQ + 1) & 1, q_lo + t + 3); b_load((SQ + 1) % G::UNR, 0); }
         else b_load((SQ + 1) % G::UNR, 1);
-#if DWRS_INTERLEAVE
 #pragma unroll
         for (int i = 0; i < 2 * NPROD; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // one MFMA
@@ -296,7 +292,6 @@ __device__ __forceinline__ void conv_dw_rs_body(const ConvArgsN& batch, const in
           if (i == 1) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);              // loads
           if (i == 2) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
         }
-#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int pa = 0; pa < 3; ++pa) av[pa] = an[pa];

@@ -24,9 +24,6 @@
 #include "conv_k16.h"
 
 typedef unsigned dxrs_u32x2 __attribute__((ext_vector_type(2)));
-#ifndef DXRS_INTERLEAVE
-#define DXRS_INTERLEAVE 1
-#endif
 
 template <int KS_, int TPR>                                  // kernel size (5: conv2, 3: conv3); tiles per row: W = 16 TPR
 struct DxRsGeom {
@@ -52,9 +49,6 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
   constexpr int KS = G::KS, P = G::P, CH = G::CH, NCH = G::NCH, NSET = G::NSET, UNR = G::UNR, W = G::W, Wp = W / 2;
   constexpr int PLB = G::PLB, SLOTB = G::SLOTB;
   const ConvArgs& a = batch.a[by];
-#ifdef DXRS_CLOCK_PROBE
-  const unsigned long long pe0 = __builtin_amdgcn_s_memrealtime();
-#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char dxrs_lds[];
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lj = lane >> 4;
   const int swave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -185,9 +179,6 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
   for (int s = 0; s < NSET; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-#ifdef DXRS_CLOCK_PROBE
-  const unsigned long long pc0 = __builtin_readcyclecounter(), pr0 = __builtin_amdgcn_s_memrealtime();
-#endif
   convert(0);
   stage_row(0, 0);
   read_x(0, 0);
@@ -253,7 +244,6 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
       if (EVEN) load_pooled((J + 2) % 3, (q >> 1) + 2);      // (behind the last row: beyond the descriptors' range, zeros)
       epi_write();
       read_x(0, SLOT ^ 1);
-#if DXRS_INTERLEAVE
 #pragma unroll
       for (int i = 0; i < NMF; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // one MFMA
@@ -262,13 +252,11 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
         else if (i < 15) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         // 6 ds_read2: the next operand windows
         if (EVEN && i == 4) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // the pooled row's two loads
       }
-#endif
       __builtin_amdgcn_sched_barrier(0);
       mfmas(std::integral_constant<int, 1>{});
       epi_store();
       if (EVEN) convert((J + 1) % 3);                        // pooled row q / 2 + 1, requested two steps ago
       read_x(1, SLOT ^ 1);
-#if DXRS_INTERLEAVE
 #pragma unroll
       for (int i = 0; i < NMF; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -277,7 +265,6 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
         else if (EVEN && i < NMF - 3) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
         else if (i >= NMF - 3) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 6 ds_read2
       }
-#endif
       __builtin_amdgcn_sched_barrier(0);
       }
     } else { epi_write(); epi_store(); }                     // (steps behind the image: the last output rows)
@@ -304,15 +291,6 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
   block(std::true_type{}, q0); q0 += UNR;
   for (; q0 >= ylo + P + 1 && q0 + UNR <= qmf; q0 += UNR) block(std::false_type{}, q0);      // (every step multiplies and stores a row of the band)
   for (; q0 < yhi + P + 1; q0 += UNR) block(std::true_type{}, q0);
-#ifdef DXRS_CLOCK_PROBE
-  if (lane == 0 && swave == 0) {
-    const unsigned long long pc1 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
-    unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    printf("DXRSALL %d %d %u %llu %llu %llu\n", bx, by, hwid, pe0, pr0, pr1);      // (every workgroup's timeline: profiles/diag/dxrs_timeline.py)
-    if ((bx % 61) == 5 && by == 1) printf("DXRSCLK wg %d: setup %llu ticks (10 ns); row loop %llu core cycles, %llu ticks -> %.3f GHz, %.1f cycles per row\n", bx, pr0 - pe0, pc1 - pc0, pr1 - pr0,
-           (double)(pc1 - pc0) / (10.0 * (double)(pr1 - pr0)), (double)(pc1 - pc0) / (double)H);
-  }
-#endif
 }
 
 template <int KSZ, int TPR, int ORDER>

@@ -524,11 +524,22 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 #else
   constexpr bool ASYNC_A = !PLAIN;                    // (the plain-output epilogue stores a data-dependent number of rows)
 #endif
+  // Round 6: up to three chunks per row the loads are builtins the compiler counts itself (as conv_rs16.h's; every vector-memory
+  // instruction of the row loop is unconditional, so its own s_waitcnt placement is exact) and nothing below is hand-counted -- conv2
+  // forward (B16 mode: 55.7 -> 54.7 us at cfg3, 302 -> 290 at cfg5) and conv1 forward of the geometries conv_rs16.h does not take
+  // (50 x 50 renders, EXACT mode).  Five chunks (30 channels, cfg5's conv1) keep the inline-asm loads and the vmcnt(N) below: there
+  // the compiler's waits come out as vmcnt(0 .. 3) where 13 loads and stores may stay in flight, and 6 registers spill
+  // (1190 -> 1342 us; profiles/experiments/r06_k16_counted_ab.sh).  `make check-waits` still analyses the whole listing.
+#ifdef K16_ASM_LOADS
+  constexpr bool COUNTED_A = false;
+#else
+  constexpr bool COUNTED_A = NCH <= 3;
+#endif
   constexpr int LPC = XT * NPA + (ODD ? XT : 0);      // vector-memory loads per chunk and row
   auto load_a = [&](int ch, int y) {
 #pragma unroll
     for (int m = 0; m < XT; ++m) {
-      if (ASYNC_A) {
+      if (ASYNC_A && !COUNTED_A) {
 #pragma unroll
         for (int pa = 0; pa < NPA; ++pa)
           k16_issue_b128(av[pa][ch][m], in_desc, avoff, pa * plane_bytes + y * rowbytes + (m * 16 * CIN + G::RK * ch) * 2);
@@ -574,7 +585,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
     if (PLAIN) return;
     // (one lane set per pooled row -- NC = 1, 16-pixel strips: the other row of the pair has nothing to write, but issues the SAME five
     // stores, out of every descriptor's range.  Rounds 3-4 issued five stores to an empty descriptor on a path of their own; one store
-    // group on every path is what lets profiles/tools/check_async_loads.py count the hand-placed waits on the kernel's flow graph.)
+    // group on every path is what lets cartpoleplusplus_amd/csrc/tools/check_async_loads.py count the hand-placed waits on the kernel's flow graph.)
     const bool dummy = half >= NC;
     const bool live = !dummy && (sure || (pr >= 0 && pr < Hp));           // uniform
     if (!ASYNC_A && !live) return;
@@ -671,7 +682,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
       if (IN || q < H) {
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
-          if (ASYNC_A) {
+          if (ASYNC_A && !COUNTED_A) {
             // this chunk's operands were requested one row ago; issued since: the other chunks' loads and -- between chunk 0's
             // MFMAs and its loads -- the SH stores of the writer half every row carries (real or dropped: ONE wait count per chunk)
             if (ch == 0) k16_wait_vm<(NCH - 1) * LPC>(av[0][ch][0]);
@@ -725,7 +736,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
           if (ASYNC_A || q + 1 < H) load_a(ch, q + 1);   // this chunk's operands of the next row, a whole row period ahead (ASYNC_A:
                                                          // also behind the last row -- masked by the descriptor, never used -- so
                                                          // that the hand-counted waits see the same sequence in every row)
-          if (!ASYNC_A) __builtin_amdgcn_sched_barrier(0);      // (compiler-counted loads stay where they are issued: left alone, the scheduler sinks them to their first use)
+          if (!ASYNC_A || COUNTED_A) __builtin_amdgcn_sched_barrier(0);      // (compiler-counted loads stay where they are issued: left alone, the scheduler sinks them to their first use)
         }
       }
       const int y = (IN || q - P >= ymin) ? q - P : -1;      // (rows in front of the band: partial sums, dropped like the rows above the image)
@@ -793,7 +804,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
       if (ASYNC_A || prl >= 0) { writer_load(wy & 1, prl); writer_half(wy & 1, prl); }
     }
   }
-  if (ASYNC_A) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the look-ahead loads behind the last row)
+  if (ASYNC_A && !COUNTED_A) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the look-ahead loads behind the last row)
   if (fuse3) {      // conv3 + pool3 of the workgroup's two images (all four waves are here: the launcher required B % IPW == 0)
     Conv3Ops ops;
     conv3_load_ops(ops, a.n3_w, a.n3_bias, nout, li, lj);      // (requested here: carried through the row loop they would cost 24 VGPRs)

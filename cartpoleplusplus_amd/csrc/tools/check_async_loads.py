@@ -19,7 +19,7 @@ that was moved, an extra or a missing vector-memory instruction between a load a
 all end here.  Compiler-counted loads are checked the same way (they pass by construction).
 
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -o /tmp/k16.s cartpoleplusplus_amd/csrc/conv_fwd_k16.hip
-  python profiles/tools/check_async_loads.py /tmp/k16.s            # exit status 1 on a violation
+  python cartpoleplusplus_amd/csrc/tools/check_async_loads.py /tmp/k16.s            # exit status 1 on a violation
 
 csrc/Makefile runs it on conv_fwd_k16.hip's listing as part of `all` (target check-waits); tests/test_wait_checker.py feeds it doctored
 listings.

@@ -1,4 +1,4 @@
-"""profiles/tools/check_async_loads.py -- the build's check of conv_k16.h's hand-counted `s_waitcnt vmcnt(N)` (csrc/Makefile, target
+"""cartpoleplusplus_amd/csrc/tools/check_async_loads.py -- the build's check of conv_k16.h's hand-counted `s_waitcnt vmcnt(N)` (csrc/Makefile, target
 check-waits) -- on doctored listings: it must accept a correct loop (loads a whole iteration ahead, two alternative store groups of the
 same length on a branch) and reject, deterministically, each way the contract can break: a wait count that is too large, a store that
 went missing on one path, a compiler copy of a register whose load is still in flight, a wait that was moved behind its first use."""
@@ -6,7 +6,7 @@ import importlib.util
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-spec = importlib.util.spec_from_file_location("check_async_loads", os.path.join(ROOT, "profiles", "tools", "check_async_loads.py"))
+spec = importlib.util.spec_from_file_location("check_async_loads", os.path.join(ROOT, "cartpoleplusplus_amd", "csrc", "tools", "check_async_loads.py"))
 chk = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(chk)
 GOOD = open(os.path.join(ROOT, "tests", "golden", "wait_checker_listing.s")).read()
