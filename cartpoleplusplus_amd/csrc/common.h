@@ -110,6 +110,7 @@ struct cpp_ctx {
   unsigned long long* route_pin;       // pinned: slot t & 1 = (tag t << 32 | float bits of the largest scale of call t)
   unsigned long long* route_pin_dev;   // ... its device address: the call's closing soft-update kernel (route_rider) or route_publish_kernel writes it
   unsigned* route_tag_dev;             // the number of the call that is running (written in stream order at every training entry point)
+  bool route_tag_signal;               // ... by hipStreamWriteValue32 (signal memory) instead of a one-dword fill kernel
   hipEvent_t route_ev[2];              // recorded at the entry of call k (slot k & 1): everything before call k has finished when it fires
   uint64_t route_calls, route_done, route_min_tag;      // calls entered; calls known complete (a stream synchronisation since); tags below are ignored (threshold changed)
   float route_last_max;                // the last scale a decision or cpp_ctx_get_route read
@@ -359,6 +360,9 @@ struct OptSegs {
   const double* sq; int sq_begin[2], sq_count[2];   // sq != nullptr: group g's squared norm = sum of sq[sq_begin[g] .. + sq_count[g]) instead of `part`
   const uint64_t* step;        // Adam: number of applies so far INCLUDING this one (device counter)
   uint64_t* bump;              // optional: device counter incremented once by this launch (the replay sampler's Philox counter)
+  // optional (pub_wmax != nullptr): this launch closes a training call that has no target update -- its first thread publishes the call's
+  // largest whitening scale (common.h: route_publish_device) instead of a launch of its own; never together with the statistics rider
+  unsigned* pub_wmax; const unsigned* pub_tag; unsigned long long* pub_pin;
   const int* skip_if;          // optional: device flag; non-zero = leave the parameters alone (NAF's check_numerics flag: tf.check_numerics
                                // raises before the train op runs, naf_cartpole.py:242-245 -- decided on the device when nobody waits for the loss)
   // optional rider (st_part != nullptr): the whitening tables of the NEXT minibatch, whose sample pass has already run beside this

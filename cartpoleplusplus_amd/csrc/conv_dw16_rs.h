@@ -134,16 +134,19 @@ __device__ __forceinline__ void conv_dw16_rs_body(const ConvArgsN& batch, const 
   {
     const int pylo = max(0, (q_lo - P) >> 1), pyhi = min(Hp - 1, (q_lo + rows - 1 + P) >> 1);
     float vmax = 0.f;
-    for (int py = pylo; py <= pyhi; py += 4) {                // 16 loads in flight per trip (rows behind pyhi: out of range, zeros)
-      float t[4][4];
+    // (nine pooled rows = 36 loads in flight per trip: a 32-row band's 18 pooled rows are two round trips -- four rows per trip were five,
+    // in front of everything else the wave does; rows behind pyhi: out of range, zeros)
+    constexpr int PSR = 9;
+    for (int py = pylo; py <= pyhi; py += PSR) {
+      float t[PSR][4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < PSR; ++u) {
         const unsigned ro = py + u <= pyhi ? (unsigned)((py + u) * (Wp * NO)) : BIG;
 #pragma unroll
         for (int j = 0; j < 4; ++j) t[u][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dp_rsrc, (int)((zoff + ro + (unsigned)(2 * j * NO)) * 4u), 0, 0));
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < PSR; ++u)
 #pragma unroll
         for (int j = 0; j < 4; ++j) vmax = fmaxf(vmax, fabsf(t[u][j]));
     }

@@ -186,6 +186,7 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_apply_kernel(const OptSegs s,
     sh_lr = lr;
     if (blockIdx.x == 0 && norms_out && s.n[seg] > 0) norms_out[s.group[seg]] = norm;
     if (blockIdx.x == 0 && seg == 0 && s.bump) *s.bump += 1;
+    if (blockIdx.x == 0 && seg == 0 && s.pub_wmax) route_publish_device(s.pub_wmax, s.pub_tag, s.pub_pin);
   }
   __syncthreads();
   const float sc = sh_scale, lr = sh_lr;

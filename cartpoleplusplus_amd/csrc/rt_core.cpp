@@ -87,7 +87,10 @@ extern "C" int cpp_ctx_create(int device_id, void* hip_stream, cpp_ctx** out) {
   // the largest whitening scale of a training call, for a later call's choice of conv1 kernels (common.h: cpp_ctx::conv1_f32)
   HIP_CHECK(hipMalloc((void**)&c->white_max_dev, sizeof(unsigned)));
   HIP_CHECK(hipMemsetAsync(c->white_max_dev, 0, sizeof(unsigned), c->stream));
-  HIP_CHECK(hipMalloc((void**)&c->route_tag_dev, sizeof(unsigned)));
+  // (signal memory: hipStreamWriteValue32 -- a command-processor packet, no kernel -- writes the call's number into it; where the
+  // runtime offers neither, an ordinary word and a one-dword fill per call)
+  c->route_tag_signal = hipExtMallocWithFlags((void**)&c->route_tag_dev, 8, hipMallocSignalMemory) == hipSuccess && c->route_tag_dev != nullptr;
+  if (!c->route_tag_signal) { (void)hipGetLastError(); HIP_CHECK(hipMalloc((void**)&c->route_tag_dev, 8)); }
   HIP_CHECK(hipMemsetAsync(c->route_tag_dev, 0xFF, sizeof(unsigned), c->stream));      // (no call is running)
   HIP_CHECK(hipHostMalloc((void**)&c->route_pin, 2 * sizeof(unsigned long long), hipHostMallocDefault));
   c->route_pin[0] = c->route_pin[1] = ~0ull;
@@ -128,7 +131,11 @@ void ctx_route_update(cpp_ctx* ctx) {
   }
   // this call: its entry event, and its number for the publishers among its launches (stream order: behind call k - 1's last launch)
   (void)hipEventRecord(ctx->route_ev[k & 1], ctx->stream);
-  (void)hipMemsetD32Async((hipDeviceptr_t)ctx->route_tag_dev, (int)(unsigned)k, 1, ctx->stream);
+  if (ctx->route_tag_signal && hipStreamWriteValue32(ctx->stream, ctx->route_tag_dev, (uint32_t)k, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->route_tag_signal = false;                     // (not on this runtime: the fill from here on)
+  }
+  if (!ctx->route_tag_signal) (void)hipMemsetD32Async((hipDeviceptr_t)ctx->route_tag_dev, (int)(unsigned)k, 1, ctx->stream);
   ctx->route_calls = k + 1;
 }
 // ... and by every training step whose last launch is not a target update (which carries the publish as a rider: optim.hip), inside its captured graph

@@ -19,6 +19,7 @@ struct cpp_ddpg {
   // graph replay of ONE minibatch on host-drawn rows, no target update (cpp_ddpg_train_rows: the reference's literal loop)
   hipGraph_t rgraph; hipGraphExec_t rgexec; bool rgraph_ok; int rg_B; uint64_t rg_replay_uid;
   uint64_t epoch;            // cpp_ctx::kernel_epoch the cached graphs were captured under (route_check)
+  bool publish_in_apply;     // the next apply() closes a training call: its launch publishes the call's whitening scale
   hipGraph_t dgraph; hipGraphExec_t dgexec; bool dgraph_ok; int dg_B, dg_nb; uint64_t dg_seed, dg_replay_uid; uint64_t dg_comm_uid; bool dgraph_refused; char dg_reason[256];   // the data-parallel step (default mode)
   // graph replay of the data-parallel half step (sample + both gradient sets)
   // three variants: 0 samples its own minibatch; 1 / 2 find it presampled (by the previous call's rider, conv1_dw_gather.hip)
@@ -217,6 +218,10 @@ static int apply(cpp_ddpg* d, bool do_actor, bool do_critic, float grad_scale, u
                  const cpp_batch* next = nullptr, int next_B = 0, int next_C = 0, long elems = 0, bool tables_done = false) {
   OptSegs s; memset(&s, 0, sizeof(s));
   s.bump = bump;
+  if (d->publish_in_apply && !next && d->ctx->route_pin_dev) {      // (the call's last launch: step_body)
+    s.pub_wmax = d->ctx->white_max_dev; s.pub_tag = d->ctx->route_tag_dev; s.pub_pin = d->ctx->route_pin_dev;
+  }
+  d->publish_in_apply = false;
   if (next && next_C > 0 && !tables_done) {
     s.st_part = next->part; s.st_white = next->white; s.st_nparts = next_B; s.st_jobs = 2 * next_C; s.st_C = next_C;
     s.st_count = (double)next_B * (double)(elems / next_C); s.st_eps = 1e-6; s.st_wmax = d->ctx->white_max_dev;
@@ -639,6 +644,7 @@ static int step_body(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int
       prof_end(ctx, K_ALLREDUCE);
     }
     // (dp: the norm is the reduced gradient's -- the partials the gradient kernels folded in are this rank's only: sumsq runs)
+    d->publish_in_apply = !more && !targets;           // (no target update behind it: the optimiser's launch closes the call)
     RC(apply(d, true, true, (dp && comm) ? 1.0f / (float)comm->world : 1.0f, rows_dev ? nullptr : r->counter, !dp,
              stats_ride ? d->step_batch : nullptr, B, Cg, r->elems, tables_done));
     if (more) {
@@ -649,7 +655,7 @@ static int step_body(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int
     }
   }
   if (targets) { ctx->route_rider = true; return cpp_ddpg_update_targets(d); }      // (the largest whitening scale of this step rides to the host in that launch)
-  return ctx_route_publish(ctx);      // (the largest whitening scale of this step, for the next call's choice of conv1 kernels)
+  return CPP_OK;      // (... or has left with the last minibatch's optimiser launch)
 }
 
 // ddpg_cartpole.py:332-334 for ONE minibatch whose rows the HOST drew (replay_memory.random_indexes: numpy's RNG, :123-129):

@@ -5,7 +5,7 @@
 # other BASELINE configs (cfg2, cfg4 = NAF, cfg5 with 6000 rows and with one GPU's 125 000-row u8 shard, r50, batch norm).
 # Outputs under gpurun_out/; profiles/make_profiles.py turns them into the committed summaries.
 set -u
-R=${1:-r05}
+R=${1:-r06}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 REPO=$PWD
