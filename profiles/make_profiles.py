@@ -29,7 +29,7 @@ SHORT = [("void conv_fwd_kernel<18, 5, 4, 0, 0>", "conv1_fwd"), ("void conv_dw_k
          # f16 pipes with f32-exact operands
          ("void conv_fwd_k16_kernel<18, 5", "conv1_fwd_f16"), ("void conv_dw16_kernel<18, 5", "conv1_dw_f16"),
          # round 5: conv1 forward as a row-streaming implicit GEMM, weights in registers (conv_rs16.h); its operand images as a launch of their own
-         ("void conv_fwd_rs16_kernel<18>", "conv1_fwd_f16"), ("void conv1_image_kernel<18", "conv1_image"), ("opt_apply_kernel", "clip_sgd"), ("conv_dw_reduce_kernel", "dw_reduce"),
+         ("void conv_fwd_rs16_kernel<", "conv1_fwd_f16"), ("void conv1_image_kernel<", "conv1_image"), ("opt_apply_kernel", "clip_sgd"), ("conv_dw_reduce_kernel", "dw_reduce"),
          # bf16 pipes (conv2), whole-image conv3 forward, the fused heads, and the launches that carry two kernels
          ("void conv_fwd_k16_kernel<10, 5", "conv2_fwd"), ("void conv_dwb16_kernel<10, 5", "conv2_dw"), ("conv3_img_kernel", "conv3_fwd"),
          ("void ddpg_heads_kernel", "heads"), ("conv3_bwd_pair_kernel", "conv3_bwd"), ("conv2_bwd_pair_kernel", "conv2_bwd"), ("void conv2_bwd_pair_kernel", "conv2_bwd"),
@@ -37,7 +37,7 @@ SHORT = [("void conv_fwd_kernel<18, 5, 4, 0, 0>", "conv1_fwd"), ("void conv_dw_k
          # round 3: two networks per conv1-dW workgroup (conv_dw16.h NNET = 2)
          ("conv1_dw_pair_gather_kernel", "conv1_dw_gather"), ("void conv_dw16_pair_kernel<18, 5", "conv1_dw_f16"),
          # round 5: the wave-per-unit / row-streaming bodies
-         ("conv_dw16_rs_kernel", "conv1_dw_f16"), ("void conv2_bwd_pair_rs_kernel", "conv2_bwd"), ("void conv3_bwd_pair_rs_kernel", "conv3_bwd"),
+         ("conv_dw16_rs_kernel", "conv1_dw_f16"), ("void conv_dw16_rs_kernel<", "conv1_dw_f16"), ("void conv2_bwd_pair_rs_kernel", "conv2_bwd"), ("void conv3_bwd_pair_rs_kernel", "conv3_bwd"),
          ("void conv_dx_rs_kernel<5", "conv2_dx"), ("void conv_dx_rs_kernel<3", "conv3_dx"), ("void conv_dw_rs_kernel<5", "conv2_dw"), ("void conv_dw_rs_kernel<3", "conv3_dw"), ("void conv_fw_rs_kernel<3", "conv3_fwd")]
 
 
@@ -120,7 +120,7 @@ def main(rnd):
                 "rounds 2-4: `conv_fwd_k16_kernel<18,5,2,2>`) launch computes conv1 of all four networks of a minibatch (blockIdx.y = network); likewise conv2/conv3 forward;\n"
                 "the dW / dX launches carry the actor and the critic together -- conv2's and conv3's dW and dX share one launch each\n"
                 "(`conv2_bwd_pair_kernel`, `conv3_bwd_pair_kernel`; round 5: `..._rs_kernel`, both halves on the bf16 pipes' row-streaming bodies), and conv1's dW\n"
-                "(round 5: `conv_dw16_rs_kernel`, one wave per (network, 32-pixel column) unit) shares its launch with the next minibatch's\n"
+                "(round 5: `conv_dw16_rs_kernel`, one wave per (network, 32-pixel column) unit; a template on the channel count from round 6) shares its launch with the next minibatch's\n"
                 "sample pass (`conv1_dw_gather_kernel`, from round 3 `conv1_dw_pair_gather_kernel`: one workgroup serves the actor AND the\n"
                 "critic, and the sample pass copies the store's per-state sums instead of reading pixels; `conv_dw16_kernel` /\n"
                 "`conv_dw16_pair_kernel` alone closes each 5-minibatch graph).\n\n")
