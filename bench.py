@@ -485,7 +485,7 @@ def main():
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; they come from separate
         # rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), committed under profiles/
         traffic, traffic_src = None, None
-        for rnd in ("r05", "r04", "r03", "r02", "r01"):
+        for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
             try:
                 with open(os.path.join(ROOT, "profiles", "%s_pmc.json" % rnd)) as f:
                     pmc = json.load(f)
@@ -531,10 +531,12 @@ def main():
         "vs_baseline": None, "dtype": "f32-acc/f16x3,bf16x9" if EXACT_PRODUCTS else "f32-acc/f16x2,bf16x6", "data": "synthetic",
         "timed_region_ms": round(1e3 * elapsed, 2), "warmup_steps_run": warmup_steps_run,
         "dtype_note": ("f32 accumulation everywhere; conv1 multiplies exact f16 operands (the replay store's pixels x three-piece f16 splits "
-                       "of the f32 weights / gradients), conv2 forward / dW / dX (round 5; and conv3's dW / dX at rows of 16+ pixels) three-piece bf16 splits of both f32 operands with all nine "
+                       "of the f32 weights / gradients), conv2 forward / dW / dX (round 5; and conv3's dW / dX at rows of 16+ pixels) "
+                       "three-piece bf16 splits of both f32 operands with all nine "
                        "products: every product exact (--precision exact)" if EXACT_PRODUCTS else
                        "f32 accumulation everywhere; conv1 multiplies the replay store's f16 pixels (exact) by a two-piece f16 split of the "
-                       "f32 weight / gradient (within one f32 ulp of it), conv2 forward / dW / dX (round 5; and conv3's dW / dX at rows of 16+ pixels) three-piece bf16 splits of both f32 operands with "
+                       "f32 weight / gradient (within one f32 ulp of it), conv2 forward / dW / dX (round 5; and conv3's dW / dX at rows of "
+                       "16+ pixels) three-piece bf16 splits of both f32 operands with "
                        "the six largest piece products (the dropped three are at most half an f32 ulp of the product): measured as close to "
                        "the float64 oracle as the exact-product build (`control_exact_products`) and closer than the f32-input MFMA kernels "
                        "(`control`); DESIGN.md 4, 6"),
