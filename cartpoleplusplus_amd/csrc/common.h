@@ -360,6 +360,9 @@ struct OptSegs {
   const double* sq; int sq_begin[2], sq_count[2];   // sq != nullptr: group g's squared norm = sum of sq[sq_begin[g] .. + sq_count[g]) instead of `part`
   const uint64_t* step;        // Adam: number of applies so far INCLUDING this one (device counter)
   uint64_t* bump;              // optional: device counter incremented once by this launch (the replay sampler's Philox counter)
+  // optional (tgt[seg] != nullptr; SGD only): this launch closes an OUTER step -- a segment's target network takes its soft update from
+  // the parameter values this launch writes (ddpg_cartpole.py:336-337 behind the last minibatch: soft_update_kernel's launch disappears)
+  float* tgt[OPT_MAX_SEGS]; float tgt_coeff;
   // optional (pub_wmax != nullptr): this launch closes a training call that has no target update -- its first thread publishes the call's
   // largest whitening scale (common.h: route_publish_device) instead of a launch of its own; never together with the statistics rider
   unsigned* pub_wmax; const unsigned* pub_tag; unsigned long long* pub_pin;
@@ -382,6 +385,9 @@ __host__ __device__ inline float sgd_update(float p, float g, float scale, float
 // ... and Momentum's pair (util.py:73-76: accum = momentum * accum + g; p -= lr * accum), pinned the same way
 __host__ __device__ inline float momentum_accum(float m, float g, float scale, float momentum) { return __builtin_fmaf(momentum, m, g * scale); }
 __host__ __device__ inline float momentum_step(float p, float accum, float lr) { return __builtin_fmaf(-lr, accum, p); }
+// ... and the target networks' update, target - coeff * (target - source) (base_network.py:31), pinned the same way: soft_update_kernel
+// writes it, and so does the optimiser's launch when it closes an outer step (OptSegs::tgt)
+__host__ __device__ inline float soft_update_value(float t, float s, float coeff) { return __builtin_fmaf(-coeff, t - s, t); }
 int launch_sumsq(cpp_ctx* ctx, const OptSegs& s, float grad_scale, double* part, int nparts);
 int launch_opt_apply(cpp_ctx* ctx, const OptSegs& s, float grad_scale, float clip, const double* part,
                      int nparts, float* norms_out);

@@ -197,16 +197,25 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_apply_kernel(const OptSegs s,
   const long n = s.n[seg] - skip;
   const long stride = (long)gridDim.x * OPT_THREADS;
   if (s.kind == OPT_SGD) {
+    float* tp = s.tgt[seg] ? s.tgt[seg] + skip : nullptr;      // (uniform) the segment's target network: updated from the new values
+    const float tc = s.tgt_coeff;
     long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x;
     for (; i + 3 * stride < n; i += 4 * stride) {
-      float pv[4], gv[4];
+      float pv[4], gv[4], tv[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { pv[u] = p[i + u * stride]; gv[u] = g[i + u * stride]; }
+      for (int u = 0; u < 4; ++u) { pv[u] = p[i + u * stride]; gv[u] = g[i + u * stride]; if (tp) tv[u] = tp[i + u * stride]; }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) p[i + u * stride] = sgd_update(pv[u], gv[u], sc, lr);
+      for (int u = 0; u < 4; ++u) {
+        const float pn = sgd_update(pv[u], gv[u], sc, lr);
+        p[i + u * stride] = pn;
+        if (tp) tp[i + u * stride] = soft_update_value(tv[u], pn, tc);
+      }
     }
-    for (; i < n; i += stride)
-      p[i] = sgd_update(p[i], g[i], sc, lr);
+    for (; i < n; i += stride) {
+      const float pn = sgd_update(p[i], g[i], sc, lr);
+      p[i] = pn;
+      if (tp) tp[i] = soft_update_value(tp[i], pn, tc);
+    }
   } else if (s.kind == OPT_MOMENTUM) {
     float* m = s.m[seg] + skip;
     for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += stride) {
@@ -261,10 +270,7 @@ __global__ void soft_update_kernel(float* t0, const float* s0, long n0, float* t
   float* t = blockIdx.y == 0 ? t0 : t1;
   const float* s = blockIdx.y == 0 ? s0 : s1;
   const long n = blockIdx.y == 0 ? n0 : n1;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const float tv = t[i];
-    t[i] = tv - coeff * (tv - s[i]);
-  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) t[i] = soft_update_value(t[i], s[i], coeff);
 }
 
 int launch_soft_update(cpp_ctx* ctx, float* t0, const float* s0, long n0, float* t1, const float* s1,

@@ -20,6 +20,7 @@ struct cpp_ddpg {
   hipGraph_t rgraph; hipGraphExec_t rgexec; bool rgraph_ok; int rg_B; uint64_t rg_replay_uid;
   uint64_t epoch;            // cpp_ctx::kernel_epoch the cached graphs were captured under (route_check)
   bool publish_in_apply;     // the next apply() closes a training call: its launch publishes the call's whitening scale
+  bool targets_in_apply, targets_applied;      // ... and an outer step: its launch carries both target updates (step_body)
   hipGraph_t dgraph; hipGraphExec_t dgexec; bool dgraph_ok; int dg_B, dg_nb; uint64_t dg_seed, dg_replay_uid; uint64_t dg_comm_uid; bool dgraph_refused; char dg_reason[256];   // the data-parallel step (default mode)
   // graph replay of the data-parallel half step (sample + both gradient sets)
   // three variants: 0 samples its own minibatch; 1 / 2 find it presampled (by the previous call's rider, conv1_dw_gather.hip)
@@ -218,6 +219,12 @@ static int apply(cpp_ddpg* d, bool do_actor, bool do_critic, float grad_scale, u
                  const cpp_batch* next = nullptr, int next_B = 0, int next_C = 0, long elems = 0, bool tables_done = false) {
   OptSegs s; memset(&s, 0, sizeof(s));
   s.bump = bump;
+  if (d->targets_in_apply && !next && do_actor && do_critic) {      // (the outer step's last launch: both target updates leave with it)
+    s.tgt[0] = d->tactor->params; s.tgt[1] = d->tcritic->params; s.tgt_coeff = d->hp.target_update_rate;
+    d->tactor->wimg_key = nullptr; d->tcritic->wimg_key = nullptr;
+    d->targets_applied = true;
+  }
+  d->targets_in_apply = false;
   if (d->publish_in_apply && !next && d->ctx->route_pin_dev) {      // (the call's last launch: step_body)
     s.pub_wmax = d->ctx->white_max_dev; s.pub_tag = d->ctx->route_tag_dev; s.pub_pin = d->ctx->route_pin_dev;
   }
@@ -644,7 +651,10 @@ static int step_body(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int
       prof_end(ctx, K_ALLREDUCE);
     }
     // (dp: the norm is the reduced gradient's -- the partials the gradient kernels folded in are this rank's only: sumsq runs)
-    d->publish_in_apply = !more && !targets;           // (no target update behind it: the optimiser's launch closes the call)
+    static const bool no_tgt_ride = cpp_switch_off("CPP_RIDE_TARGETS");
+    d->targets_applied = false;
+    d->targets_in_apply = !more && targets && !dp && !no_tgt_ride;      // (the last minibatch of an outer step: the target updates ride in its optimiser launch)
+    d->publish_in_apply = !more && (!targets || d->targets_in_apply);   // (... which then closes the call)
     RC(apply(d, true, true, (dp && comm) ? 1.0f / (float)comm->world : 1.0f, rows_dev ? nullptr : r->counter, !dp,
              stats_ride ? d->step_batch : nullptr, B, Cg, r->elems, tables_done));
     if (more) {
@@ -654,6 +664,7 @@ static int step_body(cpp_ddpg* d, cpp_replay* r, int B, int n_batches, const int
                                    d->step_batch, direct));
     }
   }
+  if (targets && d->targets_applied) { d->targets_applied = false; return CPP_OK; }      // (both target updates and the route's publish left with the optimiser's launch)
   if (targets) { ctx->route_rider = true; return cpp_ddpg_update_targets(d); }      // (the largest whitening scale of this step rides to the host in that launch)
   return CPP_OK;      // (... or has left with the last minibatch's optimiser launch)
 }
