@@ -360,7 +360,7 @@ struct OptSegs {
   const double* sq; int sq_begin[2], sq_count[2];   // sq != nullptr: group g's squared norm = sum of sq[sq_begin[g] .. + sq_count[g]) instead of `part`
   const uint64_t* step;        // Adam: number of applies so far INCLUDING this one (device counter)
   uint64_t* bump;              // optional: device counter incremented once by this launch (the replay sampler's Philox counter)
-  // optional (tgt[seg] != nullptr; SGD only): this launch closes an OUTER step -- a segment's target network takes its soft update from
+  // optional (tgt[seg] != nullptr): this launch closes an OUTER step -- a segment's target network takes its soft update from
   // the parameter values this launch writes (ddpg_cartpole.py:336-337 behind the last minibatch: soft_update_kernel's launch disappears)
   float* tgt[OPT_MAX_SEGS]; float tgt_coeff;
   // optional (pub_wmax != nullptr): this launch closes a training call that has no target update -- its first thread publishes the call's

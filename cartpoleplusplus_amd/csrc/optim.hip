@@ -196,9 +196,9 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_apply_kernel(const OptSegs s,
   const float* g = s.g[seg] + skip;
   const long n = s.n[seg] - skip;
   const long stride = (long)gridDim.x * OPT_THREADS;
+  float* tp = s.tgt[seg] ? s.tgt[seg] + skip : nullptr;      // (uniform) the segment's target network: updated from the new values
+  const float tc = s.tgt_coeff;
   if (s.kind == OPT_SGD) {
-    float* tp = s.tgt[seg] ? s.tgt[seg] + skip : nullptr;      // (uniform) the segment's target network: updated from the new values
-    const float tc = s.tgt_coeff;
     long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x;
     for (; i + 3 * stride < n; i += 4 * stride) {
       float pv[4], gv[4], tv[4];
@@ -221,7 +221,9 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_apply_kernel(const OptSegs s,
     for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += stride) {
       const float acc = momentum_accum(m[i], g[i], sc, s.momentum);
       m[i] = acc;
-      p[i] = momentum_step(p[i], acc, lr);
+      const float pn = momentum_step(p[i], acc, lr);
+      p[i] = pn;
+      if (tp) tp[i] = soft_update_value(tp[i], pn, tc);
     }
   } else {
     float* m = s.m[seg] + skip;
@@ -232,7 +234,9 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_apply_kernel(const OptSegs s,
       const float mi = b1 * m[i] + (1.f - b1) * gi;
       const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
       m[i] = mi; v[i] = vi;
-      p[i] = p[i] - lr * mi / (sqrtf(vi) + s.epsilon);
+      const float pn = p[i] - lr * mi / (sqrtf(vi) + s.epsilon);
+      p[i] = pn;
+      if (tp) tp[i] = soft_update_value(tp[i], pn, tc);
     }
   }
 }

@@ -23,6 +23,7 @@ struct cpp_naf {
   // ... and including it, the loss coming back later (cpp_naf_train_rows_async / cpp_naf_loss_wait): pinned (loss, flag) slots
   hipGraph_t agraph; hipGraphExec_t agexec; bool agraph_ok; int ag_B; uint64_t ag_replay_uid;
   uint64_t epoch;            // cpp_ctx::kernel_epoch the cached graphs were captured under (naf_route_check)
+  bool targets_in_apply, targets_applied;      // the next naf_apply closes an outer step: its launch carries the target update (rt_ddpg.cpp's twin)
   float* res_pin; hipEvent_t res_ev[CPP_NAF_TICKETS]; uint64_t next_ticket;
   uint64_t dp_local;       // minibatches applied locally since the last parameter averaging (periodic mode)
   cpp_batch* step_batch;
@@ -332,6 +333,8 @@ static int naf_apply(cpp_naf* f, float grad_scale, bool unless_nonfinite = false
   if (unless_nonfinite) s.skip_if = f->nonfinite;
   s.bump = bump;
   f->value->wimg_key = nullptr; f->mu->wimg_key = nullptr;      // (the parameters change)
+  const bool with_targets = f->targets_in_apply && !next && !unless_nonfinite;      // (the outer step's last launch: naf_step_body)
+  f->targets_in_apply = false;
   if (next && next_C > 0 && !tables_done) {
     s.st_part = next->part; s.st_white = next->white; s.st_nparts = next_B; s.st_jobs = 2 * next_C; s.st_C = next_C;
     s.st_count = (double)next_B * (double)(elems / next_C); s.st_eps = 1e-6; s.st_wmax = f->ctx->white_max_dev;
@@ -344,6 +347,12 @@ static int naf_apply(cpp_naf* f, float grad_scale, bool unless_nonfinite = false
     s.p[k] = nets[k]->params; s.g[k] = f->gradbuf + off; s.m[k] = f->m + off; s.v[k] = f->v + off;
     s.n[k] = nets[k]->nparams; s.lr[k] = f->hp.learning_rate; s.group[k] = 0;      // ONE list, one global norm
     off += nets[k]->nparams;
+  }
+  if (with_targets) {      // the target value network's soft update (naf_cartpole.py:373) and the route's publish leave with this launch
+    s.tgt[0] = f->tvalue->params; s.tgt_coeff = f->hp.target_update_rate;
+    f->tvalue->wimg_key = nullptr;
+    if (f->ctx->route_pin_dev) { s.pub_wmax = f->ctx->white_max_dev; s.pub_tag = f->ctx->route_tag_dev; s.pub_pin = f->ctx->route_pin_dev; }
+    f->targets_applied = true;
   }
   const bool bumped = f->step_bumped; const int sq_cnt = f->sq_cnt;
   f->step_bumped = false; f->sq_cnt = 0;
@@ -511,6 +520,9 @@ static int naf_step_body(cpp_naf* f, cpp_replay* r, int B, int n_batches, const 
       NCCL_CHECK(ncclAllReduce(f->gradbuf, f->gradbuf, (size_t)(f->nV + f->nM + f->nL), ncclFloat, ncclSum, comm->comm, ctx->stream));
       prof_end(ctx, K_ALLREDUCE);
     }
+    static const bool no_tgt_ride = cpp_switch_off("CPP_RIDE_TARGETS");
+    f->targets_applied = false;
+    f->targets_in_apply = !more && !dp && !no_tgt_ride;      // (the last minibatch of an outer step: the target update rides in its optimiser launch)
     RC(naf_apply(f, (dp && comm) ? 1.0f / (float)comm->world : 1.0f, false, rows_dev ? nullptr : r->counter, stats_ride ? f->step_batch : nullptr, B, Cg, r->elems, !dp, tables_done));
     if (more) {
       if (stats_ride) { f->step_batch->B = B; f->step_batch->dtype = CPP_F16; f->step_batch->stats_C = Cg; }     // (replay_sample_finish's bookkeeping)
@@ -519,6 +531,7 @@ static int naf_step_body(cpp_naf* f, cpp_replay* r, int B, int n_batches, const 
                                    f->step_batch, direct));
     }
   }
+  if (f->targets_applied) { f->targets_applied = false; return CPP_OK; }      // (the target update and the route's publish left with the optimiser's launch)
   ctx->route_rider = true;                          // (the largest whitening scale of this step rides to the host in that launch)
   return cpp_naf_update_targets(f);      // (the largest whitening scale of this step, for the next call's choice of conv1 kernels)
 }
