@@ -80,6 +80,11 @@ extern "C" int cpp_ctx_create(int device_id, void* hip_stream, cpp_ctx** out) {
   HIP_CHECK(hipEventCreate(&c->pe0));
   HIP_CHECK(hipEventCreate(&c->pe1));
   HIP_CHECK(hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, device_id));
+  {  // (ablation build: plan grids, bands and partial buffers as for a smaller device -- a 32-CU CPX partition -- on the whole chip:
+     // tests/test_gpu_small_partition.py; the release build's cpp_switch_int is a constant)
+    const int pretend = cpp_switch_int("CPP_NUM_CUS", 0);
+    if (pretend > 0 && pretend < c->num_cus) c->num_cus = pretend;
+  }
   HIP_CHECK(hipMalloc((void**)&c->sq_part, 2 * SQ_REGION * sizeof(double)));
   HIP_CHECK(hipMemsetAsync(c->sq_part, 0, 2 * SQ_REGION * sizeof(double), c->stream));
   c->sq_n[0] = c->sq_n[1] = -1;
