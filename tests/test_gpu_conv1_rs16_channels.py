@@ -91,3 +91,18 @@ def test_wave_per_unit_conv1_dw_at_9_channels_agrees_with_the_kernel_it_does_not
         d = np.abs(new[lo:hi] - old[lo:hi]).max()
         assert d <= 3e-6 * np.abs(old[lo:hi]).max(), (what, d, np.abs(old[lo:hi]).max())
     assert np.linalg.norm(new - old) <= 2e-6 * np.linalg.norm(old)
+
+
+@pytest.mark.parametrize("H,cams,reps,B,graph,fill", [
+    (18, 1, 3, 10, True, "noise"),        # the shortest images: the row walk's first and last general blocks overlap
+    (34, 1, 1, 2, False, "render"),       # 3 channels on rendered frames
+    (50, 2, 2, 7, True, "noise"),         # 12 channels, a height that is no multiple of the block
+    (66, 1, 3, 5, True, "render"),        # 9 channels, taller than wide
+    (96, 1, 2, 3, False, "noise"),        # 6 channels
+], ids=["18x64x9", "34x64x3-render", "50x64x12", "66x64x9-render", "96x64x6"])
+def test_channel_instances_at_other_heights_against_the_f64_oracle(H, cams, reps, B, graph, fill):
+    """the row-streaming conv1 kernel's channel instances on 64-wide images of other heights, through the whole fused step against
+    oracle.DDPG(float64) at the suite's ordinary bars (a slice of `profiles/diag/rs16_geometry_parity.py`, which ran 150 such draws)."""
+    from tests.helpers import fused_step_against_f64_oracle
+    rep = fused_step_against_f64_oracle((H, 64, 3, cams, reps), B, rows=60, graph=graph, seed=17, fill=fill)
+    assert rep["err_q"] <= 1e-5, rep
