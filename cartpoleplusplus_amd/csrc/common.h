@@ -131,6 +131,8 @@ constexpr int POOL_ACTIVE = 4;
 // gradient: dY[b,y,x,o] = dpool[b,y/2,x/2,o] if amax == (POOL_ACTIVE | (y&1)*2+(x&1)) else 0  (`pool` is no longer read by any backward kernel).
 struct DyDesc {
   const float* dpool; const float* pool; const uint8_t* amax;
+  const float* imax;         // optional: per image four floats whose maximum bounds |dpool| of that image (left by the kernel that wrote dpool:
+                             // conv_dx_rs.h, ConvArgs::dx_imax) -- conv_dw16_rs.h then takes its 2^S from them instead of scanning the rows
   long dpool_bstride, pool_bstride;       // elements between images
   int Hp, Wp;
 };
@@ -161,6 +163,7 @@ struct ConvArgs {
   // conv2 forward on the bf16 pipes only (n3_w != nullptr): the workgroup also runs conv3 + pool3 of its two images from the
   // pooled rows it has just produced (kept in LDS as zero-haloed 16x16 images: conv3_img.h) -- conv3's launch disappears
   const float* n3_w; const float* n3_bias; float* n3_out; long n3_out_bstride; uint8_t* n3_amax;
+  float* dx_imax;            // dX launches (conv_dx_rs.h): per image [tile][band] slots for the largest |value| the wave stored (nullptr: not wanted)
   const void* wimg;          // conv1 on the f16 pipes: the network's operand image buffer (conv_rs16.h: conv1_image_kernel), or nullptr
   const float* wimg_key;     // == scale: the image in wimg was built by the optimiser's launch for this very table and these weights
 };
@@ -193,6 +196,7 @@ int launch_conv_dw(cpp_ctx* ctx, int kid, int cin, int ks, int in_mode, ConvArgs
 size_t conv_dw_partial_floats(cpp_ctx* ctx, int cin, int ks, int nout);
 // conv2's dX on the bf16 pipes (conv_dx_rs.h)
 int conv_dx_rs_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArgsN& a, bool* handled);
+bool conv_dx_rs_ok(const cpp_ctx* ctx, int cin, int ks, int H, int W, int nout);      // would a layer's dX run on conv_dx_rs.h?
 int conv_dw_rs_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, const ConvArgsN& a, int* grid, bool* handled);
 // conv2 / conv3 forward on the bf16 pipes, row-streaming (conv_fw_rs.h)
 int conv_fw_rs_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, int epi, const ConvArgsN& a, bool* handled);

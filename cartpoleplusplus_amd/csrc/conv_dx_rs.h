@@ -178,6 +178,7 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
 #pragma unroll
   for (int s = 0; s < NSET; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  float vmx = 0.f;                                             // the largest |value| this lane stores (a.dx_imax)
 
   convert(0);
   stage_row(0, 0);
@@ -201,6 +202,10 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
       const bool live = !GEN || (yd >= ylo && yd < yhi);
       __builtin_amdgcn_raw_buffer_store_b128((k16_u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
                                              out_rsrc, (int)(live ? eL : BIG), (live ? yd : 0) * (W * CH * 4), 0);
+      if (KS == 5) {                                          // (conv2: conv1's dW scales its f16 pieces by this bound instead of scanning the rows)
+        const float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        vmx = fmaxf(vmx, live ? m : 0.f);
+      }
     };
     auto mfmas = [&](auto chtag) __attribute__((always_inline)) {
       constexpr int ch = decltype(chtag)::value;
@@ -291,6 +296,14 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
   block(std::true_type{}, q0); q0 += UNR;
   for (; q0 >= ylo + P + 1 && q0 + UNR <= qmf; q0 += UNR) block(std::false_type{}, q0);      // (every step multiplies and stores a row of the band)
   for (; q0 < yhi + P + 1; q0 += UNR) block(std::true_type{}, q0);
+  if (KS == 5 && a.dx_imax) {                                 // slot [tile][band] of the image (a single band fills both of its tile's)
+    for (int o = 32; o > 0; o >>= 1) vmx = fmaxf(vmx, __shfl_xor(vmx, o));
+    if (lane == 0 && sb < a.B && TPR <= 2) {
+      float* im = a.dx_imax + (long)sb * 4 + stile * 2;
+      if (nbands > 1) im[band] = vmx; else { im[0] = vmx; im[1] = vmx; }
+      if (TPR == 1) { im[2] = vmx; im[3] = vmx; }
+    }
+  }
 }
 
 template <int KSZ, int TPR, int ORDER>

@@ -79,6 +79,7 @@ static int ws_alloc(cpp_net* n, Workspace& w, int from_layer, bool trunk) {
       if (i == 0 && !n->spec.use_batch_norm) RC(dalloc(n->arena, &w.pool_b16, 3 * pe));
       RC(dalloc(n->arena, &w.amax[i], pe));
       RC(dalloc(n->arena, &w.dpool[i], pe));
+      if (i == 0) RC(dalloc(n->arena, &w.dpool_imax, (size_t)mb * 4));
       if (n->spec.use_batch_norm) {
         RC(dalloc(n->arena, &w.z[i], (size_t)mb * L.H * L.W * kConvOut));
         RC(dalloc(n->arena, &w.bn_stat[i], (size_t)2 * kConvOut));
@@ -117,7 +118,7 @@ extern "C" int cpp_net_create(cpp_ctx* ctx, const cpp_net_spec* spec, int max_ba
     n->ws[1] = n->ws[0];
     if ((rc = ws_alloc(n, n->ws[1], n->cat_layer, false))) return fail(rc);
     for (int l = 0; l < n->cat_layer; ++l) { n->ws[1].fcin[l] = n->ws[0].fcin[l]; n->ws[1].dz[l] = n->ws[0].dz[l]; }
-    for (int i = 0; i < 3; ++i) { n->ws[1].pool[i] = n->ws[0].pool[i]; n->ws[1].amax[i] = n->ws[0].amax[i]; n->ws[1].dpool[i] = n->ws[0].dpool[i];
+    for (int i = 0; i < 3; ++i) { n->ws[1].pool[i] = n->ws[0].pool[i]; n->ws[1].amax[i] = n->ws[0].amax[i]; n->ws[1].dpool[i] = n->ws[0].dpool[i]; n->ws[1].dpool_imax = n->ws[0].dpool_imax;
                                   n->ws[1].z[i] = n->ws[0].z[i]; n->ws[1].bn_stat[i] = n->ws[0].bn_stat[i]; }
   }
   if (spec->pixel) {
@@ -240,6 +241,9 @@ ConvArgs conv_dw_args(cpp_net* n, Workspace& w, int i, const void* state, int dt
                 *mode = dtype == CPP_F16 ? IN_F16_WHITEN : IN_F32_WHITEN; }
   else { d.in = w.pool[i - 1]; d.in_bstride = (long)L.H * L.W * L.Cin; *mode = IN_F32_PLAIN; }
   d.nout = kConvOut; d.partial = n->dw_partial[i];
+  // conv1's dW: the bound of |dpool[0]| per image that conv2's dX left (the same predicate as that launcher's: conv_dx_rs_dispatch)
+  if (i == 0 && !n->spec.use_batch_norm && w.dpool_imax && n->conv[1].W == 32 &&
+      conv_dx_rs_ok(n->ctx, kConvOut, n->conv[1].ks, n->conv[1].H, n->conv[1].W, kConvOut)) d.dy.imax = w.dpool_imax;
   return d;
 }
 ConvArgs conv_dx_args(cpp_net* n, Workspace& w, int i, int B) {
@@ -248,6 +252,7 @@ ConvArgs conv_dx_args(cpp_net* n, Workspace& w, int i, int B) {
   conv_dy_desc(n, w, i, x, B);
   x.w = n->params + L.w_off; x.nout = L.Cin;
   x.out = w.dpool[i - 1]; x.out_bstride = (long)L.H * L.W * L.Cin;
+  if (i == 1 && !n->spec.use_batch_norm) x.dx_imax = w.dpool_imax;      // (conv2's dX on conv_dx_rs.h leaves the bound conv1's dW scales by)
   return x;
 }
 
