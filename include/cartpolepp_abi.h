@@ -90,11 +90,14 @@ int cpp_ctx_set_precision(cpp_ctx* ctx, int mode);
 int cpp_ctx_get_precision(cpp_ctx* ctx, int* mode);
 /* Nearly constant channels.  The f16-pipe conv1 kernels multiply the replay store's RAW pixels by whitened weights; on a channel whose
  * whitening scale is ~10^3 and whose values do not cancel exactly (a blind camera with a rare off-colour pixel) that sits a few times
- * further from a float64 evaluation than whitening each element first, as base_network.py:95-99 does.  Every training step leaves the
- * largest scale of its whitening tables in pinned host memory; the NEXT training call reads it (no wait) and, above `threshold`
- * (default 100; 0 = never), runs conv1 forward / dW and conv2 forward on the f32-input kernels (which whiten per element) until the
- * scale has fallen under half of it.  The first affected minibatch therefore still runs on the f16 pipes.  cpp_ctx_get_route reports
- * the current choice and the last scale seen. */
+ * further from a float64 evaluation than whitening each element first, as base_network.py:95-99 does.  Every training call leaves the
+ * largest scale of its whitening tables in pinned host memory, tagged with the call's number; above `threshold` (default 100; 0 =
+ * never) later calls run conv1 forward / dW and conv2 forward on the f32-input kernels (which whiten per element) until the scale has
+ * fallen under half of it.  WHICH call's scale a call decides from depends on the order of the caller's calls only, never on host /
+ * GPU timing: call k reads call k - 2's (behind an event that guarantees it has landed; no wait in a loop that runs ahead of the
+ * GPU), or call k - 1's if the stream has been synchronised since (cpp_sync, a parameter read, the eager pass in front of a graph
+ * capture).  The first one or two affected calls therefore still run on the f16 pipes -- the same ones in every run.
+ * cpp_ctx_get_route reports the current choice and the scale of the newest call known to have finished. */
 int cpp_ctx_set_route_threshold(cpp_ctx* ctx, float threshold);
 int cpp_ctx_get_route(cpp_ctx* ctx, int* conv1_f32, float* last_max_scale);
 
