@@ -608,7 +608,8 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
       }
       if (fuse3 && live) lds_store(c3adr[i], prs * (C3_PW * C3_C * 4), (f32x2){pv[0], pv[1]});      // conv3's input row, in LDS
       if (ASYNC_A || wr_f32) __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(pv[0]), __float_as_uint(pv[1])}, out_rsrc, (int)(co * 4), orow * 4, 0);
-      if (ASYNC_A || a.out_b16) {              // the next layer's A operand: three bf16 planes of the same tensor
+      if (!B16 && (ASYNC_A || a.out_b16)) {    // the next layer's A operand: three bf16 planes of the same tensor (conv1's output only: B16 mode is
+                                               // conv2's forward, whose output feeds conv3 as f32 -- round 6: its rows no longer split and store three dropped planes)
         // truncating split (cheaper than round-to-nearest in this MFMA-issue-bound loop, equally exact: the pieces are
         // the value's three consecutive byte-groups of significand, x = h + m + l)
         unsigned hb[2], mb[2], lb[2];
