@@ -25,7 +25,9 @@ bool conv3_pair_rs_ok(const cpp_ctx* ctx, int H, int W) {
 }
 
 bool conv_dx_rs_ok(const cpp_ctx* ctx, int cin, int ks, int H, int W, int nout) {
-  static const bool off = cpp_switch_off("CPP_CONV_DXRS") || cpp_switch_off("CPP_CONV_B16");
+  // (every switch that keeps a dX launch off this file's kernels belongs HERE: conv1's dW takes its 2^S from the bounds these kernels leave
+  // -- rt_net.cpp asks this predicate --, and a dX that ran elsewhere would leave stale ones)
+  static const bool off = cpp_switch_off("CPP_CONV_DXRS") || cpp_switch_off("CPP_CONV_B16") || cpp_switch_off("CPP_CONV_KYO");
   (void)ctx;
   static const bool off3 = cpp_switch_off("CPP_CONV3_DXRS");
   // (16-wide rows -- conv3 at 64x64 images -- would leave conv3_bwd_pair.hip's launch for one of their own: CPP_CONV3_DXRS_W16=1, ablation build)

@@ -563,7 +563,7 @@ __global__ __launch_bounds__(CONV_THREADS, K16_WGS) void conv_fwd_k16_kernel(con
 
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) load_a(ch, qbeg);
-  const __amdgpu_buffer_rsrc_t null_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0, 0x00020000);      // empty range: stores are dropped
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t null_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0, 0x00020000);      // empty range: stores are dropped
   const bool wr_f32 = PLAIN || a.out != nullptr, wr_code = a.out_amax != nullptr;     // target networks of the fused step: bf16 planes only
   // ---- the pooled-row writer, one HALF per row (round 4).  Pair r of output rows is complete at the end of step 2 r + 1; its pooled
   // row is written under the MFMAs of the next two rows: lane set i = 0 (64 of the 8 XT NO / 2 channel pairs) right behind chunk 0's

@@ -181,7 +181,7 @@ __device__ __forceinline__ void conv_fwd_kyo_body(const ConvArgsN& batch, const 
   bool qact[NCELL]; uint32_t qdst[NCELL]; int qvo[NCELL], qvd[NCELL], qco[NCELL];
   float qg[NCELL], qdv[NCELL]; int qcode[NCELL], qrc[NCELL];
   const int dyWp = W >> 1, dyHp = H >> 1;
-  const __amdgpu_buffer_rsrc_t rs_pool = __builtin_amdgcn_make_buffer_rsrc(
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_pool = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.dy.pool + (DX ? (long)b0 * a.dy.pool_bstride : 0)), 0, DX ? (int)(nimg * a.dy.pool_bstride * 4) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_dpool = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.dy.dpool + (DX ? (long)b0 * a.dy.dpool_bstride : 0)), 0, DX ? (int)(nimg * a.dy.dpool_bstride * 4) : 0, 0x00020000);
