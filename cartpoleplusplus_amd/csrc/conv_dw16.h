@@ -10,7 +10,7 @@
 //   MFMAs per 32 pixels instead of eight 32-cycle ones.
 //
 // Formulation as conv_dw_kyo.h: per input row q,  D[m = (kx,c'), n = (ky,o)] += A[m, pixel] * B[pixel, n]; wave w owns column
-// tile w of (ky,o) and all MT row tiles; units = (image, band of rows); one partial per workgroup (whitening applied to it:
+// tile w of (ky,o) and all MT row tiles (30 channels: half the row tiles of two column tiles, Dw16Geom::SPLIT); units = (image, band of rows); one partial per workgroup (whitening applied to it:
 // s_c G + t_c T) for conv_dw_reduce_kernel.
 //
 // The contraction runs over PIXELS, but an image row is channel-contiguous.  The row is copied raw into LDS with a pixel
@@ -34,6 +34,12 @@ struct Dw16Geom {
   static constexpr int CP0 = (CIN + 1 + 3) & ~3;
   static constexpr int CP = ((CP0 / 2) % 8 == 0) ? CP0 + 4 : CP0;
   static constexpr int MROWS = KS * CP, MT = (MROWS + 15) / 16;
+  // How a workgroup's four waves divide the MT x 4 accumulator tiles: MT x 1 each (wave w owns column tile w), or -- SPLIT, 30 channels:
+  // 12 row tiles -- (MT / 2) x 2 each (waves 0, 1: column tiles 0, 1; waves 2, 3: 2, 3; even waves the lower half of the row tiles).  Per
+  // 32-pixel chunk a wave then reads 6 A tiles + 2 x NPC B tiles from LDS instead of 12 + NPC: 10 KB instead of 14 KB for the same 24
+  // MFMAs, and at two workgroups per CU the LDS reads of that instance take as long as its MFMAs (probe: profiles/experiments/r06_dw16_split_probe.*)
+  static constexpr bool SPLIT = MT >= 10 && MT % 2 == 0;
+  static constexpr int NCT = SPLIT ? 2 : 1, MTW = SPLIT ? MT / 2 : MT;
   static constexpr int KROW = KS * CIN;
   static constexpr int WPAD = 32 * NCHK;
   static constexpr int ROWH = ((CP * (WPAD + KS - 1) + 16 * MT - MROWS) + 7) & ~7;     // halves per staged input row (+ m over-read)
@@ -69,7 +75,7 @@ struct Dw16Geom {
 template <int CIN, int KS, int NCHK, bool DENSE = false, int NNET = 1, int NPCS = F16_PIECES>
 __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units_per_img, int band, const int bx, const int by, const int gx) {
   typedef Dw16Geom<CIN, KS, NCHK, NPCS> G;
-  constexpr int P = G::P, NO = G::NO, MT = G::MT, CP = G::CP, NPC = G::NPC, ROWB = G::ROWB, DSLOT = G::DSLOT;
+  constexpr int P = G::P, NO = G::NO, CP = G::CP, NPC = G::NPC, ROWB = G::ROWB, DSLOT = G::DSLOT;
   static_assert((KS * NO + 15) / 16 == 4, "one column tile per wave");
   static_assert(NNET == 1 || NNET == 2, "one or two networks per workgroup");
   static_assert(NNET == 1 || !DENSE, "the two-network workgroup rebuilds dY from the pooled gradient");
@@ -263,21 +269,29 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
 
   // ---- MFMA operands
   const int tj = (lane >> 2) & 3, tq = lane & 3;
-  const uint32_t aadr = keep_in_vgpr(lds_addr(inring + 2 * (CP * (16 * (lj & 1) + 4 * tj + 2 * (lj >> 1)) + 4 * tq)));
-  const int n = 16 * wave + li;
-  const bool nvalid = n < KS * NO;
-  const int nky = nvalid ? n / NO : 0, no = nvalid ? n % NO : 0;
-  uint32_t badr[G::UNROLL];
+  constexpr int NCT = G::NCT, MTW = G::MTW;          // column tiles / row tiles per wave (Dw16Geom::SPLIT)
+  const int wcol = G::SPLIT ? (wave >> 1) : wave, mt0 = G::SPLIT ? (wave & 1) * MTW : 0;      // first column tile = NCT wcol; first row tile
+  const uint32_t aadr = keep_in_vgpr(lds_addr(inring + 2 * (CP * (16 * (lj & 1) + 4 * tj + 2 * (lj >> 1)) + 4 * tq) + mt0 * 32));
+  bool nvalid[NCT]; int nky[NCT], no[NCT];
+  uint32_t badr[NCT][G::UNROLL];
 #pragma unroll
-  for (int sq = 0; sq < G::UNROLL; ++sq) {
-    const int slot = (sq - nky + P + G::RING_DY) % G::RING_DY;            // ring slot of dY position t - ky + P, t = sq (mod 6)
-    badr[sq] = keep_in_vgpr(lds_addr(dyring + slot * DSLOT + no * G::DOST + lj * 16));
+  for (int j = 0; j < NCT; ++j) {
+    const int n = 16 * (NCT * wcol + j) + li;
+    nvalid[j] = n < KS * NO;
+    nky[j] = nvalid[j] ? n / NO : 0; no[j] = nvalid[j] ? n % NO : 0;
+#pragma unroll
+    for (int sq = 0; sq < G::UNROLL; ++sq) {
+      const int slot = (sq - nky[j] + P + G::RING_DY) % G::RING_DY;       // ring slot of dY position t - ky + P, t = sq (mod 6)
+      badr[j][sq] = keep_in_vgpr(lds_addr(dyring + slot * DSLOT + no[j] * G::DOST + lj * 16));
+    }
   }
-  f32x4 acc[NNET][MT];
+  f32x4 acc[NNET][NCT][MTW];
 #pragma unroll
   for (int k = 0; k < NNET; ++k)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[k][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NCT; ++j)
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) acc[k][j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // ---- per-unit state and the requests a unit opens with
   int ub = 0, q_lo = 0, rows = 0, y0 = 0;
@@ -438,16 +452,18 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
         const int islot = sq % G::RING_IN;
 #pragma unroll
         for (int ch = 0; ch < NCHK; ++ch) {
-          f16x8 bq[NNET][NPC];
+          f16x8 bq[NNET][NCT][NPC];
 #pragma unroll
           for (int k = 0; k < NNET; ++k)
 #pragma unroll
-            for (int pc = 0; pc < NPC; ++pc) {
-              bq[k][pc] = lds_load<f16x8>(badr[sq], k * DYB + pc * G::DPC + ch * 64);
-            }
-          k16_u32x4 av[MT];
+            for (int j = 0; j < NCT; ++j)
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
+              for (int pc = 0; pc < NPC; ++pc) {
+                bq[k][j][pc] = lds_load<f16x8>(badr[j][sq], k * DYB + pc * G::DPC + ch * 64);
+              }
+          k16_u32x4 av[MTW];
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) {
             const int off = islot * ROWB + ch * (2 * CP * 32) + mt * 32;
             const dw16_v4s r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                 reinterpret_cast<__attribute__((address_space(3))) dw16_v4s*>((uintptr_t)(aadr + (uint32_t)off)));
@@ -461,8 +477,10 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
 #pragma unroll
             for (int pc = NPC - 1; pc >= 0; --pc)
 #pragma unroll
-              for (int mt = 0; mt < MT; ++mt)
-                acc[k][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mt]), bq[k][pc], acc[k][mt], 0, 0, 0);
+              for (int j = 0; j < NCT; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+                  acc[k][j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mt]), bq[k][j][pc], acc[k][j][mt], 0, 0, 0);
         }
         __syncthreads();
       }
@@ -484,32 +502,43 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
 #ifdef DW16_CLOCK
   const unsigned long long cq1 = __builtin_amdgcn_s_memrealtime();
 #endif
+  // (the table has one [KS][16] block per COLUMN TILE: a wave's own without SPLIT; with it the T row of a kx sits in the row tiles of ONE
+  // of the two waves that share the column tiles, and both read it behind a workgroup barrier)
 #pragma unroll
   for (int k = 0; k < NNET; ++k) {
-    float* tx = reinterpret_cast<float*>(dyring + k * DYB) + wave * (KS * 16);
 #pragma unroll
-    for (int kx = 0; kx < KS; ++kx) {
-      const int m = CP * kx + CIN;                      // compile-time
-      if (lj == ((m & 15) >> 2)) tx[kx * 16 + li] = acc[k][m >> 4][m & 3];
+    for (int j = 0; j < NCT; ++j) {
+      float* tx = reinterpret_cast<float*>(dyring + k * DYB) + (NCT * wcol + j) * (KS * 16);
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        const int m = CP * kx + CIN;                    // compile-time
+        if (mt0 == ((m >> 4) / MTW) * MTW && lj == ((m & 15) >> 2)) tx[kx * 16 + li] = acc[k][j][(m >> 4) % MTW][m & 3];
+      }
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (G::SPLIT) __syncthreads();
+  else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
 #pragma unroll
   for (int k = 0; k < NNET; ++k) {
     float* part = batch.a[by + k].partial + (long)bx * batch.a[by + k].pstride;
-    const float* tx = reinterpret_cast<const float*>(dyring + k * DYB) + wave * (KS * 16);
-    if (nvalid && no < nout) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
+    for (int j = 0; j < NCT; ++j) {
+      const float* tx = reinterpret_cast<const float*>(dyring + k * DYB) + (NCT * wcol + j) * (KS * 16);
+      if (nvalid[j] && no[j] < nout) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = 16 * mt + 4 * lj + r;
-          const int kx = m / CP, c = m - kx * CP;
-          if (kx < KS && c < CIN) {
-            const float t = tx[kx * 16 + li];
-            part[(nky * G::KROW + kx * CIN + c) * nout + no] = inv[k] * (wsc[c] * acc[k][mt][r] + wsc[CIN + c] * t);
+        for (int mt = 0; mt < MTW; ++mt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = 16 * (mt0 + mt) + 4 * lj + r;
+            const int kx = m / CP, c = m - kx * CP;
+            if (kx < KS && c < CIN) {
+              const float t = tx[kx * 16 + li];
+              part[(nky[j] * G::KROW + kx * CIN + c) * nout + no[j]] = inv[k] * (wsc[c] * acc[k][j][mt][r] + wsc[CIN + c] * t);
+            }
           }
         }
       }
