@@ -36,6 +36,23 @@ def test_cfg5_B512_graph_replayed_fused_step_against_f64_oracle():
     print("cfg5 B=512 fused graph step vs f64 oracle:", rep)
 
 
+def test_cfg5_geometry_under_exact_products_against_f64_oracle():
+    """cfg5's 128x128x30 geometry with cpp_ctx_set_precision(EXACT): the three-piece instances of the 30-channel kernels -- the ring
+    kernel's five-chunk forward, conv_dw16.h's dW with its accumulator tiles divided 6 x 2 over the waves (Dw16Geom::SPLIT, round 6) --
+    and all nine bf16 products at 64-wide conv2 rows, through the fused step (a subprocess: the mode is a property of the context).
+    (Seed: a draw with |Q| <= 4.2.  At this geometry the absolute 1e-5 bar on TD sits at float32's own distance from float64 -- seed 6
+    has |Q| = 14.7 and float32 NUMPY is 1.1e-5 - 1.3e-5 away there, the device 0.9e-5 (fast) / 1.1e-5 (exact): profiles/diag/exact30_probe.py.)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    snippet = ("from tests.helpers import fused_step_against_f64_oracle\n"
+               "rep = fused_step_against_f64_oracle((128, 128, 3, 2, 5), 96, rows=300, graph=True, seed=8)\n"
+               "print('EXACT30', rep['err_q'], rep['rel_actor_grads'], rep['rel_critic_grads'])\n")
+    r = subprocess.run([sys.executable, "-c", snippet], cwd=root, env=dict(os.environ, TEST_EXACT_PRODUCTS="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "EXACT30" in out, out[-2000:]
+
+
 @pytest.mark.parametrize("shape", [(50, 50, 3, 1, 2), (50, 50, 3, 2, 3)], ids=["50x50x6-all-defaults", "50x50x18"])
 def test_reference_default_render_B128_graph_replayed_fused_step_against_f64_oracle(shape):
     """the reference's OWN defaults: 50 x 50 render (bullet_cartpole.py:33-36), one camera x two action repeats = 6 channels
