@@ -1,4 +1,5 @@
 // conv1 forward, row-streaming with the weights in registers (conv_rs16.h): instantiations + geometry selection.
+#include <cstdlib>
 #include <cstring>
 #include "conv_rs16.h"
 
@@ -16,7 +17,7 @@ static int conv_fwd_rs16_launch(cpp_ctx* ctx, const ConvArgsN& a, const Conv1Ima
     prof_end(ctx, K_CONV1_IMAGE);      // (the caller's bracket: the image launch is timed on its own, the forward kernel after it)
     prof_begin(ctx);
   }
-  hipLaunchKernelGGL(conv_fwd_rs16_kernel<CIN>, dim3((a.a[0].B + 1) / 2, a.n), dim3(CONV_THREADS), 0, ctx->stream, a);
+  hipLaunchKernelGGL(conv_fwd_rs16_kernel<CIN>, dim3(((a.a[0].B + 1) / 2) * (a.a[0].nbands > 1 ? 2 : 1), a.n), dim3(CONV_THREADS), 0, ctx->stream, a);
   LAUNCH_CHECK();
   return 0;
 }
@@ -50,12 +51,24 @@ int conv_fwd_rs16_dispatch(cpp_ctx* ctx, int cin, int ks, int in_mode, bool plai
                                reinterpret_cast<unsigned char*>(const_cast<void*>(a.a[i].wimg)), nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, 0.f, nullptr, nullptr};
   }
   const Conv1ImageArgsN* iap = build ? &ia : nullptr;
+  // Two bands of output rows per image when whole images put at most ONE workgroup on a CU (the kernel is built for two waves per SIMD:
+  // NAF's two trunks at B = 256 are 256 workgroups): the first band's height r0 is even with r0 - 2 a multiple of the row loop's period
+  // (6), as close to H / 2 as that allows (conv_rs16.h; CPP_CONV_BANDS=0 in the ablation build: whole images)
+  ConvArgsN ab = a;
+  {
+    static const bool no_bands = cpp_switch_off("CPP_CONV_BANDS");
+    int r0 = 0;
+    for (int r = 8; r + 8 <= a0.H; r += 6) if (r0 == 0 || abs(2 * r - a0.H) < abs(2 * r0 - a0.H)) r0 = r;      // r = 8, 14, 20, ...: r - 2 = 6 k
+    const int wgs = a.n * ((a0.B + 1) / 2);
+    const bool two = !no_bands && r0 != 0 && a0.H >= 32 && wgs <= ctx->num_cus;
+    for (int i = 0; i < ab.n; ++i) { ab.a[i].nbands = two ? 2 : 0; ab.a[i].band_rows = two ? r0 : 0; }
+  }
   switch (cin) {
-    case 3: return conv_fwd_rs16_launch<3>(ctx, a, iap);
-    case 6: return conv_fwd_rs16_launch<6>(ctx, a, iap);
-    case 9: return conv_fwd_rs16_launch<9>(ctx, a, iap);
-    case 12: return conv_fwd_rs16_launch<12>(ctx, a, iap);
-    default: return conv_fwd_rs16_launch<18>(ctx, a, iap);
+    case 3: return conv_fwd_rs16_launch<3>(ctx, ab, iap);
+    case 6: return conv_fwd_rs16_launch<6>(ctx, ab, iap);
+    case 9: return conv_fwd_rs16_launch<9>(ctx, ab, iap);
+    case 12: return conv_fwd_rs16_launch<12>(ctx, ab, iap);
+    default: return conv_fwd_rs16_launch<18>(ctx, ab, iap);
   }
 }
 static_assert(Rs16Geom<18>::REC_BYTES >= Rs16Geom<12>::REC_BYTES && Rs16Geom<18>::REC_BYTES >= Rs16Geom<3>::REC_BYTES, "the largest record");

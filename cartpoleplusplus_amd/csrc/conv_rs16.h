@@ -360,9 +360,17 @@ __global__ __launch_bounds__(CONV_THREADS, 2) __attribute__((amdgpu_waves_per_eu
   const int li = lane & 15, lj = lane >> 4;
   const int swave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int sstrip = swave & 1, simg = swave >> 1;
-  const int sb = (int)blockIdx.x * 2 + simg;
+  // Two bands of output rows per image (a.nbands == 2: the launcher's answer to a grid that would leave every SIMD with ONE wave -- NAF's two
+  // trunks, a single network's forward): band 0 computes output rows [0, band_rows), band 1 the rest; a band's walk starts two input rows
+  // above its first output row, on the unrolled loop's period (band_rows - 2 is a multiple of NSET), and the output rows its first steps
+  // complete with sums that miss the rows above are never stored.  Every stored output adds the same products in the same order as without bands.
+  const int nbands = a.nbands > 1 ? 2 : 1;
+  const int band = nbands > 1 ? ((int)blockIdx.x & 1) : 0;
+  const int sb = ((int)blockIdx.x / nbands) * 2 + simg;
   if (sb >= a.B) return;
   const int H = a.H, Hp = H >> 1, nout = a.nout;
+  const int y_lo = band ? a.band_rows : 0, y_hi = (nbands > 1 && band == 0) ? a.band_rows : H;     // the band's output rows
+  const int q_b = band ? y_lo - P : 0;                         // first input row of its walk
 
   // ---- weights: KS x NCH x NPC A operands, resident
   f16x8 wv[KS][NCH][NPC];
@@ -495,9 +503,9 @@ __global__ __launch_bounds__(CONV_THREADS, 2) __attribute__((amdgpu_waves_per_eu
   }
   float tv[4] = {0.f, 0.f, 0.f, 0.f};
   bool xgt[4] = {false, false, false, false};
-  load_row(0);
+  load_row(q_b);
   stage_row(0);
-  load_row(1);
+  load_row(q_b + 1);
   read_x(0, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
 
@@ -548,7 +556,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) __attribute__((amdgpu_waves_per_eu
     auto stores = [&]() __attribute__((always_inline)) {
       const f32x4 pr = lds_load<f32x4>(trd, 0);
       const unsigned cd = lds_load<unsigned>(trc, 0);
-      const bool live = !GEN || (yd >= 0 && yd < H);
+      const bool live = !GEN || (yd >= y_lo && yd < y_hi);
       const unsigned eo = live ? eL : BIG;
       const int orow = (yd >> 1) * Wp * nout;
       unsigned hb[4], mb[4], lb[4];
@@ -610,15 +618,18 @@ __global__ __launch_bounds__(CONV_THREADS, 2) __attribute__((amdgpu_waves_per_eu
       if (pr == 0) __builtin_amdgcn_s_setprio(0); else if (pr == 1) __builtin_amdgcn_s_setprio(1);
       else if (pr == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
     }
-    if (GEN && q0 + 0 >= H + 3) return; step(std::integral_constant<int, 0>{}, gentag, q0 + 0);
-    if (GEN && q0 + 1 >= H + 3) return; step(std::integral_constant<int, 1>{}, gentag, q0 + 1);
-    if (GEN && q0 + 2 >= H + 3) return; step(std::integral_constant<int, 2>{}, gentag, q0 + 2);
-    if (GEN && q0 + 3 >= H + 3) return; step(std::integral_constant<int, 3>{}, gentag, q0 + 3);
-    if (GEN && q0 + 4 >= H + 3) return; step(std::integral_constant<int, 4>{}, gentag, q0 + 4);
-    if (GEN && q0 + 5 >= H + 3) return; step(std::integral_constant<int, 5>{}, gentag, q0 + 5);
+    if (GEN && q0 + 0 >= y_hi + 3) return; step(std::integral_constant<int, 0>{}, gentag, q0 + 0);
+    if (GEN && q0 + 1 >= y_hi + 3) return; step(std::integral_constant<int, 1>{}, gentag, q0 + 1);
+    if (GEN && q0 + 2 >= y_hi + 3) return; step(std::integral_constant<int, 2>{}, gentag, q0 + 2);
+    if (GEN && q0 + 3 >= y_hi + 3) return; step(std::integral_constant<int, 3>{}, gentag, q0 + 3);
+    if (GEN && q0 + 4 >= y_hi + 3) return; step(std::integral_constant<int, 4>{}, gentag, q0 + 4);
+    if (GEN && q0 + 5 >= y_hi + 3) return; step(std::integral_constant<int, 5>{}, gentag, q0 + 5);
   };
-  int q0 = 0;
+  // the first block is a general one (the image's top rows / a band's unstored first rows: q_b + NSET - 1 - 3 = y_lo + 1, so every later
+  // step stores a row of the band); interior blocks while every step's output row is stored and every input row it asks for is interior
+  int q0 = q_b;
   block(std::true_type{}, q0); q0 += NSET;
-  for (; q0 + NSET <= H - 4; q0 += NSET) block(std::false_type{}, q0);
-  for (; q0 < H + 3; q0 += NSET) block(std::true_type{}, q0);
+  const int q_int = min(H - 4, y_hi + 3);
+  for (; q0 + NSET <= q_int; q0 += NSET) block(std::false_type{}, q0);
+  for (; q0 < y_hi + 3; q0 += NSET) block(std::true_type{}, q0);
 }

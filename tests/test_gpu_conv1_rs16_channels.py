@@ -106,3 +106,18 @@ def test_channel_instances_at_other_heights_against_the_f64_oracle(H, cams, reps
     from tests.helpers import fused_step_against_f64_oracle
     rep = fused_step_against_f64_oracle((H, 64, 3, cams, reps), B, rows=60, graph=graph, seed=17, fill=fill)
     assert rep["err_q"] <= 1e-5, rep
+
+
+@pytest.mark.parametrize("shape,B", [((64, 64, 3, 2, 3), 96), ((64, 64, 3, 1, 3), 31), ((50, 64, 3, 2, 2), 64), ((36, 64, 3, 1, 1), 40)],
+                         ids=["18ch-B96", "9ch-B31", "50x64x12-B64", "36x64x3-B40"])
+def test_two_bands_of_rows_per_image_are_an_arrangement_not_arithmetic(tmp_path, shape, B):
+    """A launch of conv_fwd_rs16_kernel that would put at most one workgroup on a CU (NAF's two trunks at B = 256; here four networks at
+    small batches) walks every image as TWO bands of output rows (round 6; `CPP_CONV_BANDS=0` in the ablation build: whole images).  A
+    band's walk starts two input rows above its first output row and its unstored first steps are the only difference: every pooled
+    value, code and bf16 plane -- and with them conv3's output and both gradient lists -- must hold the SAME BITS."""
+    new = _run(tmp_path, "bands", shape, B, {})
+    old = _run(tmp_path, "whole", shape, B, {"CPP_CONV_BANDS": "0"})
+    assert sorted(new) == sorted(old)
+    for k in new:
+        assert np.isfinite(new[k]).all() and np.array_equal(new[k], old[k]), (k, np.abs(new[k].astype(np.float64) - old[k]).max())
+    assert np.abs(new["actor_pool1"]).max() > 0 and np.abs(new["grads"]).max() > 0
