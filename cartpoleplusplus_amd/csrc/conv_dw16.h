@@ -354,6 +354,14 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
           for (int u = 0; u < 8; ++u) vmax[0] = fmaxf(vmax[0], fabsf(t[u]));
         }
         for (; e < e1; e += CONV_THREADS) vmax[0] = fmaxf(vmax[0], fabsf(dp[e]));
+      } else if (a.dy.imax) {
+        // the image's bound, left by the kernel that wrote the gradient (conv2's dX on conv_dx_rs.h; round 6): four floats instead of a
+        // scan of the unit's pooled rows in front of everything else the workgroup does
+#pragma unroll
+        for (int k = 0; k < NNET; ++k) {
+          const f32x4 im = *reinterpret_cast<const f32x4*>(batch.a[by + k].dy.imax + (long)b * 4);
+          vmax[k] = fmaxf(vmax[k], fmaxf(fmaxf(im[0], im[1]), fmaxf(im[2], im[3])));
+        }
       } else {
         const int py0 = max(0, (q_lo - P) >> 1), py1 = min(Hp - 1, (q_lo + rows - 1 + P) >> 1);
         const int e1 = (py1 + 1) * Wp * nout;
