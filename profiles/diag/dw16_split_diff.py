@@ -5,9 +5,10 @@ import os, subprocess, sys
 import numpy as np
 if len(sys.argv) > 1:
     from tests.helpers import make_pair
-    agent, _ref, _ = make_pair((128, 128, 3, 2, 5), 64, True, replay_size=256)
-    agent.replay_memory.fill_synthetic(192, seed=33)
-    agent.train_step(64, 1, idxs=np.arange(64, dtype=np.int32))
+    B = int(os.environ.get("DIFF_B", "64"))
+    agent, _ref, _ = make_pair((128, 128, 3, 2, 5), B, True, replay_size=B + 192)
+    agent.replay_memory.fill_synthetic(B + 128, seed=33)
+    agent.train_step(B, 1, idxs=np.arange(B, dtype=np.int32))
     np.savez(sys.argv[1], actor=agent.actor.get_grads(), critic=agent.critic.get_grads())
     agent.close()
     sys.exit(0)
@@ -27,3 +28,6 @@ for net in ("actor", "critic"):
     if nz.size:
         rel = d[nz] / np.maximum(np.abs(b[nz]), 1e-30)
         print("   relative differences: max", rel.max(), "median", np.median(rel))
+    if net == "actor":
+        print("   conv1 biases new :", a[7500:7510])
+        print("   conv1 biases prev:", b[7500:7510])
