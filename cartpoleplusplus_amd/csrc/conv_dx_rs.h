@@ -200,12 +200,12 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
     auto epi_store = [&]() __attribute__((always_inline)) {
       const f32x4 v = lds_load<f32x4>(trd, 0);
       const bool live = !GEN || (yd >= ylo && yd < yhi);
-      __builtin_amdgcn_raw_buffer_store_b128((k16_u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
-                                             out_rsrc, (int)(live ? eL : BIG), (live ? yd : 0) * (W * CH * 4), 0);
       if (KS == 5) {                                          // (conv2: conv1's dW scales its f16 pieces by this bound instead of scanning the rows)
         const float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
         vmx = fmaxf(vmx, live ? m : 0.f);
       }
+      buffer_store_b128_held((k16_u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
+                             out_rsrc, (int)(live ? eL : BIG), (live ? yd : 0) * (W * CH * 4));
     };
     auto mfmas = [&](auto chtag) __attribute__((always_inline)) {
       constexpr int ch = decltype(chtag)::value;

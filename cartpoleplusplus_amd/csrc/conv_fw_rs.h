@@ -198,8 +198,7 @@ __device__ __forceinline__ void conv_fw_rs_body(const ConvArgsN& batch, const in
       const bool live = !GEN || (yd >= 0 && yd < H);
       const unsigned eo = live ? eL : BIG;
       const int orow = (live ? (yd >> 1) : 0) * (Wp * CH);
-      __builtin_amdgcn_raw_buffer_store_b128((k16_u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
-                                             out_rsrc, (int)eo, orow * 4, 0);
+      buffer_store_b128_held((k16_u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, out_rsrc, (int)eo, orow * 4);
       __builtin_amdgcn_raw_buffer_store_b32(cd, amax_rsrc, (int)(live ? (eL >> 2) : BIG), orow, 0);
     };
     auto mfmas = [&](auto chtag) __attribute__((always_inline)) {

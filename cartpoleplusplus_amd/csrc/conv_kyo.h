@@ -38,6 +38,18 @@ template <typename T>
 __device__ __forceinline__ void lds_store(uint32_t addr, int byte_off, const T& v) {
   *reinterpret_cast<__attribute__((address_space(3))) T*>((uintptr_t)(addr + (uint32_t)byte_off)) = v;
 }
+// A buffer store of MORE THAN 64 BITS reads its data registers some cycles after it issues.  LLVM keeps VALU writes of those registers
+// two wait states away only when the store's soffset is NOT a register ("this hazard only exists if the instruction is not using a
+// register in the soffset field", GCNHazardRecognizer) -- every row store of the row-streaming kernels has an SGPR soffset, and on gfx950
+// a `v_max_f32 v202, |v202|, |v202|` one instruction behind `buffer_store_dwordx4 v[200:203], v174, s[0:3], s4 offen` changed what was
+// stored, differently from run to run (round 6: conv_dx_rs.h at 64-wide rows with its row maximum live; profiles/NOTEBOOK_r06.md 10).  This
+// store keeps its data registers alive and untouched for four more wait states; tools/check_store_data.py checks every listing for a
+// wide store without that distance (`make check-stores`).
+template <typename V4>
+__device__ __forceinline__ void buffer_store_b128_held(const V4& d, __amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
+  __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, voffset, soffset, 0);
+  asm volatile("s_nop 3" :: "v"(d) : "memory");
+}
 // a 16-bit store into bytes that are READ BACK AS DWORDS: `unsigned short` and `unsigned` are different types to the compiler's type-based
 // alias analysis, which lets the scheduler move the dword read above the halfword write (round 6: conv_rs16.h's pivots of an odd channel
 // count were read before they were written, on the first rows only); a may_alias halfword aliases everything

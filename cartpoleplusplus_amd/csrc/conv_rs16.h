@@ -567,8 +567,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) __attribute__((amdgpu_waves_per_eu
         mb[r] = __float_as_uint(r1) & 0xFFFF0000u;
         lb[r] = __float_as_uint(r1 - __uint_as_float(mb[r]));
       }
-      __builtin_amdgcn_raw_buffer_store_b128((rs16_u32x4){__float_as_uint(pr[0]), __float_as_uint(pr[1]), __float_as_uint(pr[2]), __float_as_uint(pr[3])},
-                                             out_rsrc, (int)(eo * 4), orow * 4, 0);
+      buffer_store_b128_held((rs16_u32x4){__float_as_uint(pr[0]), __float_as_uint(pr[1]), __float_as_uint(pr[2]), __float_as_uint(pr[3])}, out_rsrc, (int)(eo * 4), orow * 4);
       __builtin_amdgcn_raw_buffer_store_b64((rs16_u32x2){(hb[0] >> 16) | hb[1], (hb[2] >> 16) | hb[3]}, b16_rsrc, (int)(eo * 2), orow * 2, 0);
       __builtin_amdgcn_raw_buffer_store_b64((rs16_u32x2){(mb[0] >> 16) | mb[1], (mb[2] >> 16) | mb[3]}, b16_rsrc, (int)(eo * 2), plane_bytes + orow * 2, 0);
       __builtin_amdgcn_raw_buffer_store_b64((rs16_u32x2){(lb[0] >> 16) | (lb[1] & 0xFFFF0000u), (lb[2] >> 16) | (lb[3] & 0xFFFF0000u)}, b16_rsrc, (int)(eo * 2),
