@@ -127,11 +127,13 @@ enum ConvEpi { EPI_RELU_POOL = 0, EPI_PLAIN = 1 };
 
 // (the arg-max code byte of a pooled cell: bits 0-1 = window position dy * 2 + dx of the first maximum, bit 2 = the pooled output is > 0)
 constexpr int POOL_ACTIVE = 4;
+// floats per image of the bounds a dX launch leaves for the next layer's dW (conv_dx_rs.h: [4 tiles of a row][2 bands of rows])
+#define DX_IMAX_SLOTS 8
 // How to rebuild the gradient w.r.t. a conv's pre-activation output from the pooled-resolution
 // gradient: dY[b,y,x,o] = dpool[b,y/2,x/2,o] if amax == (POOL_ACTIVE | (y&1)*2+(x&1)) else 0  (`pool` is no longer read by any backward kernel).
 struct DyDesc {
   const float* dpool; const float* pool; const uint8_t* amax;
-  const float* imax;         // optional: per image four floats whose maximum bounds |dpool| of that image (left by the kernel that wrote dpool:
+  const float* imax;         // optional: per image DX_IMAX_SLOTS floats whose maximum bounds |dpool| of that image (left by the kernel that wrote dpool:
                              // conv_dx_rs.h, ConvArgs::dx_imax) -- conv_dw16_rs.h then takes its 2^S from them instead of scanning the rows
   long dpool_bstride, pool_bstride;       // elements between images
   int Hp, Wp;

@@ -359,8 +359,9 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
         // scan of the unit's pooled rows in front of everything else the workgroup does
 #pragma unroll
         for (int k = 0; k < NNET; ++k) {
-          const f32x4 im = *reinterpret_cast<const f32x4*>(batch.a[by + k].dy.imax + (long)b * 4);
-          vmax[k] = fmaxf(vmax[k], fmaxf(fmaxf(im[0], im[1]), fmaxf(im[2], im[3])));
+          const float* ip = batch.a[by + k].dy.imax + (long)b * DX_IMAX_SLOTS;
+          const f32x4 im = *reinterpret_cast<const f32x4*>(ip), im2 = *reinterpret_cast<const f32x4*>(ip + 4);
+          vmax[k] = fmaxf(vmax[k], fmaxf(fmaxf(fmaxf(im[0], im[1]), fmaxf(im[2], im[3])), fmaxf(fmaxf(im2[0], im2[1]), fmaxf(im2[2], im2[3]))));
         }
       } else {
         const int py0 = max(0, (q_lo - P) >> 1), py1 = min(Hp - 1, (q_lo + rows - 1 + P) >> 1);

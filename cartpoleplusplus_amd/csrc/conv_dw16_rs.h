@@ -135,8 +135,8 @@ __device__ __forceinline__ void conv_dw16_rs_body(const ConvArgsN& batch, const 
     const int pylo = max(0, (q_lo - P) >> 1), pyhi = min(Hp - 1, (q_lo + rows - 1 + P) >> 1);
     float vmax = 0.f;
     if (a.dy.imax) {                                          // the image's bound, left by the kernel that wrote the gradient (round 6: the scan below was 3.3 us of the launch)
-      const f32x4 im = *reinterpret_cast<const f32x4*>(a.dy.imax + (long)ub * 4);
-      vmax = fmaxf(fmaxf(im[0], im[1]), fmaxf(im[2], im[3]));
+      const f32x4 im = *reinterpret_cast<const f32x4*>(a.dy.imax + (long)ub * DX_IMAX_SLOTS), im2 = *reinterpret_cast<const f32x4*>(a.dy.imax + (long)ub * DX_IMAX_SLOTS + 4);
+      vmax = fmaxf(fmaxf(fmaxf(im[0], im[1]), fmaxf(im[2], im[3])), fmaxf(fmaxf(im2[0], im2[1]), fmaxf(im2[2], im2[3])));
     }
     // (nine pooled rows = 36 loads in flight per trip: a 32-row band's 18 pooled rows are two round trips -- four rows per trip were five,
     // in front of everything else the wave does; rows behind pyhi: out of range, zeros)

@@ -296,12 +296,13 @@ __device__ __forceinline__ void conv_dx_rs_body(const ConvArgsN& batch, const in
   block(std::true_type{}, q0); q0 += UNR;
   for (; q0 >= ylo + P + 1 && q0 + UNR <= qmf; q0 += UNR) block(std::false_type{}, q0);      // (every step multiplies and stores a row of the band)
   for (; q0 < yhi + P + 1; q0 += UNR) block(std::true_type{}, q0);
-  if (KS == 5 && a.dx_imax) {                                 // slot [tile][band] of the image (a single band fills both of its tile's)
+  if (KS == 5 && a.dx_imax) {                                 // the image's slots [4 tiles][2 bands]: a wave also fills those of the tiles and bands nobody owns
     for (int o = 32; o > 0; o >>= 1) vmx = fmaxf(vmx, __shfl_xor(vmx, o));
-    if (lane == 0 && sb < a.B && TPR <= 2) {
-      float* im = a.dx_imax + (long)sb * 4 + stile * 2;
-      if (nbands > 1) im[band] = vmx; else { im[0] = vmx; im[1] = vmx; }
-      if (TPR == 1) { im[2] = vmx; im[3] = vmx; }
+    if (lane == 0 && sb < a.B) {
+      float* im = a.dx_imax + (long)sb * DX_IMAX_SLOTS;
+      for (int t = stile; t < 4; t += TPR) {
+        if (nbands > 1) im[2 * t + band] = vmx; else { im[2 * t] = vmx; im[2 * t + 1] = vmx; }
+      }
     }
   }
 }

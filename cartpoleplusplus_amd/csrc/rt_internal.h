@@ -70,7 +70,7 @@ struct Workspace {
   unsigned short* pool_b16 = nullptr;      // pool[0] once more as three bf16 planes (conv2 forward on the bf16 pipes)
   uint8_t* amax[3] = {nullptr, nullptr, nullptr};
   float* dpool[3] = {nullptr, nullptr, nullptr};
-  float* dpool_imax = nullptr;             // [maxB][4]: bounds of |dpool[0]| per image, left by conv2's dX (conv_dx_rs.h) for conv1's dW
+  float* dpool_imax = nullptr;             // [maxB][DX_IMAX_SLOTS]: bounds of |dpool[0]| per image, left by conv2's dX (conv_dx_rs.h) for conv1's dW
   // batch norm (training mode): plain conv output (overwritten by its gradient in the backward pass), (inv, -mean*inv)
   float* z[3] = {nullptr, nullptr, nullptr};
   float* bn_stat[3] = {nullptr, nullptr, nullptr};

@@ -79,7 +79,7 @@ static int ws_alloc(cpp_net* n, Workspace& w, int from_layer, bool trunk) {
       if (i == 0 && !n->spec.use_batch_norm) RC(dalloc(n->arena, &w.pool_b16, 3 * pe));
       RC(dalloc(n->arena, &w.amax[i], pe));
       RC(dalloc(n->arena, &w.dpool[i], pe));
-      if (i == 0) RC(dalloc(n->arena, &w.dpool_imax, (size_t)mb * 4));
+      if (i == 0) RC(dalloc(n->arena, &w.dpool_imax, (size_t)mb * DX_IMAX_SLOTS));
       if (n->spec.use_batch_norm) {
         RC(dalloc(n->arena, &w.z[i], (size_t)mb * L.H * L.W * kConvOut));
         RC(dalloc(n->arena, &w.bn_stat[i], (size_t)2 * kConvOut));
@@ -242,7 +242,7 @@ ConvArgs conv_dw_args(cpp_net* n, Workspace& w, int i, const void* state, int dt
   else { d.in = w.pool[i - 1]; d.in_bstride = (long)L.H * L.W * L.Cin; *mode = IN_F32_PLAIN; }
   d.nout = kConvOut; d.partial = n->dw_partial[i];
   // conv1's dW: the bound of |dpool[0]| per image that conv2's dX left (the same predicate as that launcher's: conv_dx_rs_dispatch)
-  if (i == 0 && !n->spec.use_batch_norm && w.dpool_imax && n->conv[1].W == 32 &&
+  if (i == 0 && !n->spec.use_batch_norm && w.dpool_imax && (n->conv[1].W == 32 || n->conv[1].W == 64) &&
       conv_dx_rs_ok(n->ctx, kConvOut, n->conv[1].ks, n->conv[1].H, n->conv[1].W, kConvOut)) d.dy.imax = w.dpool_imax;
   return d;
 }
