@@ -348,3 +348,25 @@ def test_the_other_naf_head_paths_stay_parity_green_when_selected(switch):
                        stderr=subprocess.STDOUT, timeout=900)
     tail = r.stdout.decode()[-1500:]
     assert r.returncode == 0 and " passed" in tail, tail
+
+
+@pytest.mark.parametrize("shape,B,share,opt,oargs", [((64, 64, 3, 2, 3), 256, True, "Momentum", {"learning_rate": 0.01, "momentum": 0.9}),
+                                                     ((64, 64, 3, 1, 3), 96, False, "Adam", {"learning_rate": 0.001})],
+                         ids=["cfg4", "9ch-B96-own-trunks-adam"])
+def test_the_fused_naf_step_is_bit_reproducible_from_run_to_run(shape, B, share, opt, oargs):
+    """tests/test_gpu_distributed.py's three-run bit comparison for NAF (cfg4: the shared trunk at B = 256 -- conv1 forward walked as two
+    bands of rows per image since round 6 -- under Momentum; three networks on trunks of their own under Adam): no kernel of the step may
+    depend on timing.  (Round 6 met a store hazard of gfx950 that made a build differ from run to run: DESIGN 4.)"""
+    runs = []
+    for _ in range(3):
+        agent, _ref, _ = make_naf(shape, B, share, opt, oargs, seed=9, replay_size=2 * B + 64)
+        try:
+            agent.replay_memory.fill_synthetic(2 * B, seed=12)
+            for _ in range(6):
+                agent.train_step(B, 3)
+            agent.value_net.ctx.sync()
+            runs.append(np.concatenate([params_of(agent), agent.target_value_net.get_params()]))
+        finally:
+            agent.close()
+    for other in runs[1:]:
+        assert np.array_equal(runs[0], other), float(np.abs(runs[0] - other).max())
