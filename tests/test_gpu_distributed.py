@@ -192,16 +192,19 @@ def test_the_fused_cfg3_step_is_bit_reproducible_from_run_to_run():
             assert np.array_equal(x, y), float(np.abs(x - y).max())
 
 
-@pytest.mark.parametrize("shape,B", [((64, 64, 3, 1, 3), 256), ((128, 128, 3, 2, 5), 512), ((64, 64, 3, 2, 3), 64)],
-                         ids=["cfg2", "cfg5", "cfg3-B64-banded"])
-def test_the_other_configurations_steps_are_bit_reproducible_too(shape, B):
+@pytest.mark.parametrize("shape,B,kw", [((64, 64, 3, 1, 3), 256, {}), ((128, 128, 3, 2, 5), 512, {}), ((64, 64, 3, 2, 3), 64, {}),
+                                        ((64, 64, 3, 2, 3), 128, {"use_batch_norm": True}), ((64, 64, 3, 2, 3), 128, {"replay_store": "u8"}),
+                                        ((50, 50, 3, 2, 3), 128, {})],
+                         ids=["cfg2", "cfg5", "cfg3-B64-banded", "batch-norm", "u8-store", "50x50x18"])
+def test_the_other_configurations_steps_are_bit_reproducible_too(shape, B, kw):
     """the same property at cfg2 (the 9-channel instances), cfg5 (the 30-channel ring forward, conv_dw16.h's re-divided dW, the 64-wide
     row-streaming conv2 backward: round 6 met a build of that dX instance -- its per-row bound made live -- whose output differed from run
     to run in the odd channels by 1e-3 of conv1's gradient, which only the f64-oracle test at B = 512 noticed; profiles/NOTEBOOK_r06.md 10)
-    and a small batch (conv1 forward walked as two bands of rows per image)."""
+    and a small batch (conv1 forward walked as two bands of rows per image); the batch-norm networks (bn.hip, the f32-input kernels), the
+    8-bit replay store and the reference's default 50 x 50 render (the ring kernel, conv_dw16.h at 25-pixel conv2 rows) as well."""
     runs = []
     for _ in range(3):
-        agent, _ref, _ = make_pair(shape, B, True, replay_size=2 * B + 64)
+        agent, _ref, _ = make_pair(shape, B, True, replay_size=2 * B + 64, **kw)
         try:
             agent.replay_memory.fill_synthetic(2 * B, seed=11)
             for _ in range(6):
