@@ -328,10 +328,14 @@ def fused_step_against_f64_oracle(shape, B, rows, replay_store="f16", replay_siz
         cg_dev = ref.critic_gradients(t, td_override=td)
         assert_flat_close(cspec, g_c, cg_dev["grads"], rel=grad_rel, what="critic pre-clip grads vs f64 oracle's backward pass of the device's TD")
         report["critic_grads_checked_at_device_td"] = True
+        nc_dev = float(np.linalg.norm(cg_dev["grads"]))
     report["rel_actor_grads"] = max(r_[2] for r_ in per_var_report(aspec, g_a, ag["grads"]))
     report["rel_critic_grads"] = max(r_[2] for r_ in per_var_report(cspec, g_c, cg["grads"]))
     na, nc = float(np.linalg.norm(ag["grads"])), float(np.linalg.norm(cg["grads"]))
-    assert abs(stats[1] - na) < 1e-4 * max(1.0, na) and abs(stats[2] - nc) < 1e-4 * max(1.0, nc), (stats, na, nc)
+    # (the reported critic norm is the norm of the gradient checked above: where that check needed the device's TD values -- B = 1 with a
+    # TD of 1e-2: the admitted 1e-5 on TD is 1e-3 of the gradient -- the norm is held to the same gradient; rs16_geometry_parity.py 601, draw 1)
+    nc_ref = nc_dev if report.get("critic_grads_checked_at_device_td") else nc
+    assert abs(stats[1] - na) < 1e-4 * max(1.0, na) and abs(stats[2] - nc_ref) < 1e-4 * max(1.0, nc_ref), (stats, na, nc, nc_ref)
     # clip + SGD (util.py:47-50, ddpg_cartpole.py:118-119,218) and the target updates (:336-337) on top of them
     hp = O.DEFAULT_HYPER
     ca, _ = O.clip_by_global_norm(ag["grads"], hp.gradient_clip, np.float64)
