@@ -8,6 +8,9 @@ ONE instruction behind `buffer_store_dwordx4 v[200:203], v174, s[0:3], s4 offen`
 (conv_dx_rs.h with its row maximum live at 64-wide rows: conv1's gradient off by 1e-3 in all odd channels; with the data registers
 kept untouched for four cycles the same build is bit-reproducible and parity-green).
 
+Measured in isolation (profiles/diag/store_hazard_probe.hip, 4e8 stored words per case): dwordx3 / dwordx4 with an SGPR soffset are poisoned
+by a write 0 wait states behind them and clean from 1; with an immediate soffset at 0 and 1, clean from 2 (LLVM's rule); dwordx2 never.
+
 This script walks the listing of a translation unit (`hipcc -S --cuda-device-only`) and reports every multi-dword buffer / global store whose
 data registers are overwritten by a VALU instruction fewer than MIN_WAIT wait states later (MIN_WAIT_KNOWN where LLVM applies its own
 rule: immediate soffset, global stores) in straight-line code (an `s_nop n` counts
