@@ -46,6 +46,11 @@ __global__ __launch_bounds__(512) void probe(float* out, unsigned long long* cyc
         typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
         acc4[(2 * s) % NACC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b[s & 3]), acc4[(2 * s) % NACC], 0, 0, 0);
         acc4[(2 * s + 1) % NACC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b[s & 3]), acc4[(2 * s + 1) % NACC], 0, 0, 0);
+      } else if (MODE == 4) {      // the K = 16 instruction gfx950 carries forward (round 6: would a half-empty k chunk cost half?): two per slot as MODE 0
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        const f16x4 a4 = {a[0], a[1], a[2], a[3]}, b4 = {b[s & 3][0], b[s & 3][1], b[s & 3][2], b[s & 3][3]};
+        acc4[(2 * s) % NACC] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, acc4[(2 * s) % NACC], 0, 0, 0);
+        acc4[(2 * s + 1) % NACC] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, acc4[(2 * s + 1) % NACC], 0, 0, 0);
       } else {
         const float fa = __builtin_bit_cast(float, (unsigned)(__builtin_bit_cast(u32x4, a)[s & 3] & 0xBFFFFFFFu));      // (finite: exponent MSB cleared)
         const float fb = __builtin_bit_cast(float, (unsigned)(__builtin_bit_cast(u32x4, b[s & 3])[s & 3] & 0xBFFFFFFFu));
@@ -97,7 +102,16 @@ void run(const char* name, int waves_per_simd) {
   hipFree(out); hipFree(cyc);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1) {      // `mfma_rate_probe k16`: only the K = 16 question ("TFLOP/s" is printed as if a slot held 32768 flop: halve it)
+    for (int w = 1; w <= 2; ++w) {
+      run<0, 8, 0>("16x16x32 f16, 8 acc", w);
+      run<4, 8, 0>("16x16x16 f16 (legacy K = 16), 8 acc", w);
+      run<0, 8, 0, 1>("16x16x32 f16, 8 acc, RANDOM operands", w);
+      run<4, 8, 0, 1>("16x16x16 f16 (legacy K = 16), 8 acc, RANDOM", w);
+    }
+    return 0;
+  }
   for (int w = 1; w <= 2; ++w) {
     run<0, 8, 0>("16x16x32 f16, 8 acc", w);
     run<0, 4, 0>("16x16x32 f16, 4 acc", w);
