@@ -355,7 +355,7 @@ __device__ __forceinline__ void conv_dw16_body(const ConvArgsN& batch, int units
         }
         for (; e < e1; e += CONV_THREADS) vmax[0] = fmaxf(vmax[0], fabsf(dp[e]));
       } else if (a.dy.imax) {
-        // the image's bound, left by the kernel that wrote the gradient (conv2's dX on conv_dx_rs.h; round 6): four floats instead of a
+        // the image's bound, left by the kernel that wrote the gradient (conv2's dX on conv_dx_rs.h; round 6): eight floats instead of a
         // scan of the unit's pooled rows in front of everything else the workgroup does
 #pragma unroll
         for (int k = 0; k < NNET; ++k) {
